@@ -1,0 +1,872 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see pdlp_oracle.h.  Plain C11 restatement of cuOpt 25.08's PDLP
+ * (`LP/` below = /root/reference/cpp/src/linear_programming/).  Unfused on purpose: one loop per
+ * reference kernel, so each piece can be compared with one HIP kernel.
+ *
+ * Rounding contract (so that SpMV parity with the HIP kernels can be bit-exact): compiled with
+ * -ffp-contract=off; every row sum is accumulated left-to-right in CSR order starting from 0.0;
+ * long reductions (dot products, norms) use fixed 1024-element blocks summed in index order
+ * (deterministic for any thread count).
+ */
+#include "pdlp_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_INF (1.0 / 0.0)
+
+static double now_seconds(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static double* dalloc(size_t n)
+{
+  double* p = (double*)calloc(n ? n : 1, sizeof(double));
+  return p;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* presets: LP/solve.cu:64-199 ; defaults LP/pdlp_hyper_params.cu:22-80                       */
+/* ------------------------------------------------------------------------------------------ */
+void orc_hyper_preset(int mode, double* h)
+{
+  /* Stable2 (default) -- LP/solve.cu:99-130 */
+  h[ORC_H_INITIAL_STEP_SIZE_SCALING]                  = 1.0;
+  h[ORC_H_RUIZ_ITERATIONS]                            = 10;
+  h[ORC_H_DO_POCK_CHAMBOLLE]                          = 1;
+  h[ORC_H_DO_RUIZ]                                    = 1;
+  h[ORC_H_ALPHA_POCK_CHAMBOLLE]                       = 1.0;
+  h[ORC_H_ARTIFICIAL_RESTART_THRESHOLD]               = 0.36;
+  h[ORC_H_STEP_SIZE_BEFORE_SCALING]                   = 0;
+  h[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING]               = 0;
+  h[ORC_H_PRIMAL_WEIGHT_C_SCALING]                    = 1.0;
+  h[ORC_H_PRIMAL_WEIGHT_B_SCALING]                    = 1.0;
+  h[ORC_H_MAJOR_ITERATION]                            = 40;
+  h[ORC_H_MIN_ITERATION_RESTART]                      = 10;
+  h[ORC_H_RESTART_STRATEGY]                           = 1;
+  h[ORC_H_NEVER_RESTART_TO_AVERAGE]                   = 0;
+  h[ORC_H_REDUCTION_EXPONENT]                         = 0.3;
+  h[ORC_H_GROWTH_EXPONENT]                            = 0.6;
+  h[ORC_H_PRIMAL_WEIGHT_UPDATE_SMOOTHING]             = 0.5;
+  h[ORC_H_SUFFICIENT_REDUCTION]                       = 0.2;
+  h[ORC_H_NECESSARY_REDUCTION]                        = 0.8;
+  h[ORC_H_PRIMAL_IMPORTANCE]                          = 1.0;
+  h[ORC_H_PRIMAL_DISTANCE_SMOOTHING]                  = 0.5;
+  h[ORC_H_DUAL_DISTANCE_SMOOTHING]                    = 0.5;
+  h[ORC_H_LAST_RESTART_BEFORE_NEW_PRIMAL_WEIGHT]      = 1;
+  h[ORC_H_ARTIFICIAL_RESTART_IN_MAIN_LOOP]            = 0;
+  h[ORC_H_RESCALE_FOR_RESTART]                        = 1;
+  h[ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION]   = 0;
+  h[ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION]       = 0;
+  h[ORC_H_GRADIENTS_ON_FINITE_BOUNDS_AS_RESIDUALS]    = 0;
+  h[ORC_H_PROJECT_INITIAL_PRIMAL]                     = 1;
+  if (mode == 0) { /* Stable1 -- LP/solve.cu:66-96 */
+    h[ORC_H_INITIAL_STEP_SIZE_SCALING]               = 1.6;
+    h[ORC_H_RUIZ_ITERATIONS]                         = 1;
+    h[ORC_H_ALPHA_POCK_CHAMBOLLE]                    = 1.3;
+    h[ORC_H_ARTIFICIAL_RESTART_THRESHOLD]            = 0.5;
+    h[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING]            = 1;
+    h[ORC_H_PRIMAL_WEIGHT_C_SCALING]                 = 2.2;
+    h[ORC_H_PRIMAL_WEIGHT_B_SCALING]                 = 4.6;
+    h[ORC_H_MAJOR_ITERATION]                         = 52;
+    h[ORC_H_MIN_ITERATION_RESTART]                   = 0;
+    h[ORC_H_REDUCTION_EXPONENT]                      = 0.5;
+    h[ORC_H_GROWTH_EXPONENT]                         = 0.9;
+    h[ORC_H_PRIMAL_WEIGHT_UPDATE_SMOOTHING]          = 0.3;
+    h[ORC_H_NECESSARY_REDUCTION]                     = 0.5;
+    h[ORC_H_PRIMAL_IMPORTANCE]                       = 1.8;
+    h[ORC_H_PRIMAL_DISTANCE_SMOOTHING]               = 0.6;
+    h[ORC_H_DUAL_DISTANCE_SMOOTHING]                 = 0.2;
+    h[ORC_H_LAST_RESTART_BEFORE_NEW_PRIMAL_WEIGHT]   = 0;
+    h[ORC_H_RESCALE_FOR_RESTART]                     = 0;
+    h[ORC_H_GRADIENTS_ON_FINITE_BOUNDS_AS_RESIDUALS] = 1;
+    h[ORC_H_PROJECT_INITIAL_PRIMAL]                  = 0;
+  } else if (mode == 2) { /* Methodical1 -- LP/solve.cu:133-163 */
+    h[ORC_H_RUIZ_ITERATIONS]                         = 5;
+    h[ORC_H_ARTIFICIAL_RESTART_THRESHOLD]            = 0.5;
+    h[ORC_H_MAJOR_ITERATION]                         = 64;
+    h[ORC_H_MIN_ITERATION_RESTART]                   = 0;
+    h[ORC_H_RESTART_STRATEGY]                        = 2;
+    h[ORC_H_SUFFICIENT_REDUCTION]                    = 0.1;
+    h[ORC_H_NECESSARY_REDUCTION]                     = 0.9;
+    h[ORC_H_RESCALE_FOR_RESTART]                     = 0;
+    h[ORC_H_GRADIENTS_ON_FINITE_BOUNDS_AS_RESIDUALS] = 1;
+    h[ORC_H_PROJECT_INITIAL_PRIMAL]                  = 0;
+  } else if (mode == 3) { /* Fast1 -- LP/solve.cu:167-197 */
+    h[ORC_H_INITIAL_STEP_SIZE_SCALING]               = 0.8;
+    h[ORC_H_RUIZ_ITERATIONS]                         = 6;
+    h[ORC_H_DO_RUIZ]                                 = 0;
+    h[ORC_H_ALPHA_POCK_CHAMBOLLE]                    = 2.0;
+    h[ORC_H_ARTIFICIAL_RESTART_THRESHOLD]            = 0.3;
+    h[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING]            = 1;
+    h[ORC_H_PRIMAL_WEIGHT_C_SCALING]                 = 1.2;
+    h[ORC_H_PRIMAL_WEIGHT_B_SCALING]                 = 1.2;
+    h[ORC_H_MAJOR_ITERATION]                         = 76;
+    h[ORC_H_MIN_ITERATION_RESTART]                   = 6;
+    h[ORC_H_NEVER_RESTART_TO_AVERAGE]                = 1;
+    h[ORC_H_REDUCTION_EXPONENT]                      = 0.4;
+    h[ORC_H_SUFFICIENT_REDUCTION]                    = 0.3;
+    h[ORC_H_NECESSARY_REDUCTION]                     = 0.9;
+    h[ORC_H_PRIMAL_IMPORTANCE]                       = 0.8;
+    h[ORC_H_PRIMAL_DISTANCE_SMOOTHING]               = 0.8;
+    h[ORC_H_DUAL_DISTANCE_SMOOTHING]                 = 0.3;
+    h[ORC_H_ARTIFICIAL_RESTART_IN_MAIN_LOOP]         = 1;
+    h[ORC_H_GRADIENTS_ON_FINITE_BOUNDS_AS_RESIDUALS] = 1;
+    h[ORC_H_PROJECT_INITIAL_PRIMAL]                  = 0;
+  }
+}
+
+/* tolerances_t defaults: pdlp/solver_settings.hpp:179-188 */
+void orc_default_settings(double* s)
+{
+  for (int i = 0; i < 6; ++i) s[i] = 1e-4;
+  s[ORC_S_ITERATION_LIMIT]         = -1;
+  s[ORC_S_TIME_LIMIT]              = 0;
+  s[ORC_S_PER_CONSTRAINT_RESIDUAL] = 0;
+  s[ORC_S_FIRST_PRIMAL_FEASIBLE]   = 0;
+  s[ORC_S_NUM_THREADS]             = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* reductions with a fixed summation tree                                                     */
+/* ------------------------------------------------------------------------------------------ */
+#define RB 1024
+static double blocked_sum2(int n, const double* a, const double* b) /* sum a_i*b_i */
+{
+  int nb = (n + RB - 1) / RB;
+  if (nb <= 0) return 0.0;
+  double* part = (double*)malloc(sizeof(double) * (size_t)nb);
+#pragma omp parallel for schedule(static)
+  for (int blk = 0; blk < nb; ++blk) {
+    int s = blk * RB, e = s + RB < n ? s + RB : n;
+    double acc = 0.0;
+    for (int i = s; i < e; ++i) {
+      double p = a[i] * b[i];
+      acc      = acc + p;
+    }
+    part[blk] = acc;
+  }
+  double tot = 0.0;
+  for (int blk = 0; blk < nb; ++blk) tot = tot + part[blk];
+  free(part);
+  return tot;
+}
+static double blocked_sum(int n, const double* a)
+{
+  int nb = (n + RB - 1) / RB;
+  if (nb <= 0) return 0.0;
+  double* part = (double*)malloc(sizeof(double) * (size_t)nb);
+#pragma omp parallel for schedule(static)
+  for (int blk = 0; blk < nb; ++blk) {
+    int s = blk * RB, e = s + RB < n ? s + RB : n;
+    double acc = 0.0;
+    for (int i = s; i < e; ++i) acc = acc + a[i];
+    part[blk] = acc;
+  }
+  double tot = 0.0;
+  for (int blk = 0; blk < nb; ++blk) tot = tot + part[blk];
+  free(part);
+  return tot;
+}
+static double l2norm(int n, const double* a) { return sqrt(blocked_sum2(n, a, a)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* SpMV: stands in for cusparseSpMV(CSR, ALG2) at LP/pdhg.cu:87,124,                          */
+/* adaptive_step_size_strategy.cu:278, convergence_information.cu:228,301 (cuSPARSE closed)   */
+/* ------------------------------------------------------------------------------------------ */
+void orc_spmv(int rows, const int* offsets, const int* indices, const double* values,
+              const double* x, double* y)
+{
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < rows; ++i) {
+    double acc = 0.0;
+    for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
+      double p = values[k] * x[indices[k]];
+      acc      = acc + p;
+    }
+    y[i] = acc;
+  }
+}
+
+/* explicit transpose kept as its own CSR: cpp/src/mip/problem/problem.cu:277-309
+ * (raft csr_transpose -> cusparseCsr2cscEx2: stable, rows ascending inside each column) */
+void orc_csr_transpose(int m, int n, const int* offsets, const int* indices, const double* values,
+                       int* t_offsets, int* t_indices, double* t_values)
+{
+  for (int j = 0; j <= n; ++j) t_offsets[j] = 0;
+  int nnz = offsets[m];
+  for (int k = 0; k < nnz; ++k) t_offsets[indices[k] + 1]++;
+  for (int j = 0; j < n; ++j) t_offsets[j + 1] += t_offsets[j];
+  int* cur = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int j = 0; j < n; ++j) cur[j] = t_offsets[j];
+  for (int i = 0; i < m; ++i)
+    for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
+      int p        = cur[indices[k]]++;
+      t_indices[p] = i;
+      t_values[p]  = values[k];
+    }
+  free(cur);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* initial scaling vectors: LP/initial_scaling_strategy/initial_scaling.cu:36-92 (ctor),      */
+/* :94-163 Ruiz, :176-307 Pock-Chambolle ; division rule LP/utils.cuh:122-129                  */
+/* ------------------------------------------------------------------------------------------ */
+void orc_compute_scaling(int m, int n, const int* offsets, const int* indices,
+                         const double* values, const int* t_offsets, const int* t_indices,
+                         const double* t_values, const double* hyper, double* d_row,
+                         double* d_col)
+{
+  for (int i = 0; i < m; ++i) d_row[i] = 1.0;
+  for (int j = 0; j < n; ++j) d_col[j] = 1.0;
+  double* it_row = dalloc((size_t)m);
+  double* it_col = dalloc((size_t)n);
+  if (hyper[ORC_H_DO_RUIZ] != 0.0) {
+    int iters = (int)hyper[ORC_H_RUIZ_ITERATIONS];
+    for (int it = 0; it < iters; ++it) {
+      /* inf_norm_row_and_col_kernel :94-122 -- both norms from the same snapshot */
+      for (int i = 0; i < m; ++i) it_row[i] = 0.0;
+      for (int j = 0; j < n; ++j) it_col[j] = 0.0;
+      for (int i = 0; i < m; ++i)
+        for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
+          int j    = indices[k];
+          double v = fabs((values[k] * d_row[i]) * d_col[j]);
+          if (v > it_row[i]) it_row[i] = v;
+          if (v > it_col[j]) it_col[j] = v;
+        }
+      /* a_divides_sqrt_b_bounded, utils.cuh:122-129 */
+      for (int i = 0; i < m; ++i)
+        if (it_row[i] > 0.0) d_row[i] = d_row[i] / sqrt(it_row[i]);
+      for (int j = 0; j < n; ++j)
+        if (it_col[j] > 0.0) d_col[j] = d_col[j] / sqrt(it_col[j]);
+    }
+  }
+  if (hyper[ORC_H_DO_POCK_CHAMBOLLE] != 0.0) {
+    double alpha = hyper[ORC_H_ALPHA_POCK_CHAMBOLLE];
+    /* rows from A (:176-212), columns from A^T (:215-252): separate kernels in the reference */
+    for (int i = 0; i < m; ++i) {
+      double acc = 0.0;
+      for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
+        double v = fabs((values[k] * d_row[i]) * d_col[indices[k]]);
+        acc      = acc + pow(v, alpha);
+      }
+      it_row[i] = acc;
+    }
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int k = t_offsets[j]; k < t_offsets[j + 1]; ++k) {
+        double v = fabs((t_values[k] * d_row[t_indices[k]]) * d_col[j]);
+        acc      = acc + pow(v, 2.0 - alpha);
+      }
+      it_col[j] = acc;
+    }
+    for (int i = 0; i < m; ++i)
+      if (it_row[i] > 0.0) d_row[i] = d_row[i] / sqrt(it_row[i]);
+    for (int j = 0; j < n; ++j)
+      if (it_col[j] > 0.0) d_col[j] = d_col[j] / sqrt(it_col[j]);
+  }
+  free(it_row);
+  free(it_col);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* element-wise rules: LP/utils.cuh                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static inline double dmin(double a, double b) { return a < b ? a : b; } /* raft::min */
+static inline double dmax(double a, double b) { return a > b ? a : b; } /* raft::max */
+
+/* combine_finite_abs_bounds, utils.cuh:139-148 */
+static inline double combine_bounds(double lower, double upper)
+{
+  double val = 0.0;
+  if (isfinite(upper)) val = dmax(val, fabs(upper));
+  if (isfinite(lower)) val = dmax(val, fabs(lower));
+  return val;
+}
+/* violation, utils.cuh:165-178 */
+static inline double violation(double value, double lower, double upper)
+{
+  if (value < lower) return lower - value;
+  if (value > upper) return value - upper;
+  return 0.0;
+}
+/* bound_value_gradient, utils.cuh:195-202 (first branch is dead code; value==0 -> upper) */
+static inline double bound_value_gradient(double value, double lower, double upper)
+{
+  return value > 0.0 ? lower : upper;
+}
+/* bound_value_reduced_cost_product, utils.cuh:204-219 */
+static inline double bound_value_rc_product(double value, double lower, double upper)
+{
+  double bound_value = 0.0;
+  if (value > 0.0)
+    bound_value = lower;
+  else if (value < 0.0)
+    bound_value = upper;
+  return isfinite(bound_value) ? value * bound_value : 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* convergence information on the UNSCALED problem:                                            */
+/* LP/termination_strategy/convergence_information.cu:149-219 and parts :221-422               */
+/* ------------------------------------------------------------------------------------------ */
+void orc_eval(int m, int n, const int* offsets, const int* indices, const double* values,
+              const int* t_offsets, const int* t_indices, const double* t_values, const double* c,
+              const double* lo, const double* hi, const double* lb, const double* ub,
+              double obj_scale, double obj_offset, int finite_bounds_rule, double rel_primal_tol,
+              double rel_dual_tol, const double* x, const double* y, double* rc, double* out)
+{
+  double* ax   = dalloc((size_t)m);
+  double* pres = dalloc((size_t)m);
+  double* grad = dalloc((size_t)n);
+  double* dres = dalloc((size_t)n);
+  double* bv   = dalloc((size_t)(m > n ? m : n));
+  /* compute_primal_residual :221-248 */
+  orc_spmv(m, offsets, indices, values, x, ax);
+  for (int i = 0; i < m; ++i) pres[i] = violation(ax[i], lo[i], hi[i]);
+  /* compute_primal_objective :261-284 */
+  double pobj = blocked_sum2(n, x, c);
+  if (obj_scale != 1.0 || obj_offset != 0.0) pobj = obj_scale * pobj + obj_offset;
+  double l2_pres = l2norm(m, pres);
+  double linf_p  = 0.0;
+  for (int i = 0; i < m; ++i) { /* relative_residual_t, utils.cuh:385-409 ; bcomb = utils.cuh:150 */
+    double v = pres[i] - rel_primal_tol * combine_bounds(lo[i], hi[i]);
+    if (v > linf_p) linf_p = v;
+  }
+  double l2_x = l2norm(n, x);
+  /* compute_dual_residual :287-320 : grad = c - A^T y (SpMV alpha=-1, beta=1 on a copy of c) */
+  orc_spmv(n, t_offsets, t_indices, t_values, y, grad);
+  for (int j = 0; j < n; ++j) grad[j] = c[j] + (-1.0) * grad[j];
+  /* compute_reduced_cost_from_primal_gradient :369-398 */
+  for (int j = 0; j < n; ++j) {
+    double b = bound_value_gradient(grad[j], lb[j], ub[j]);
+    double r;
+    if (!finite_bounds_rule) { /* copy_gradient_if_should_be_reduced_cost, utils.cuh:221-229 */
+      if (grad[j] == 0.0)
+        r = grad[j];
+      else if (fabs(x[j] - b) <= fabs(x[j]))
+        r = grad[j];
+      else
+        r = 0.0;
+    } else { /* copy_gradient_if_finite_bounds, utils.cuh:231-239 (Stable2) */
+      if (grad[j] == 0.0)
+        r = grad[j];
+      else if (isfinite(b))
+        r = grad[j];
+      else
+        r = 0.0;
+    }
+    rc[j]   = r;
+    dres[j] = grad[j] - r;
+  }
+  /* compute_dual_objective :323-366, :401-422 */
+  for (int i = 0; i < m; ++i) bv[i] = bound_value_rc_product(y[i], lo[i], hi[i]);
+  double dobj = blocked_sum(m, bv);
+  for (int j = 0; j < n; ++j) bv[j] = bound_value_rc_product(rc[j], lb[j], ub[j]);
+  dobj = dobj + blocked_sum(n, bv);
+  if (obj_scale != 1.0 || obj_offset != 0.0) dobj = obj_scale * dobj + obj_offset;
+  double l2_dres = l2norm(n, dres);
+  double linf_d  = 0.0;
+  for (int j = 0; j < n; ++j) { /* rhs for the dual side is c_j itself (signed), :204-208 */
+    double v = dres[j] - rel_dual_tol * c[j];
+    if (v > linf_d) linf_d = v;
+  }
+  double l2_y = l2norm(m, y);
+  /* compute_remaining_stats_kernel :137-147 */
+  out[0] = pobj;
+  out[1] = dobj;
+  out[2] = fabs(pobj - dobj);
+  out[3] = fabs(pobj) + fabs(dobj);
+  out[4] = l2_pres;
+  out[5] = l2_dres;
+  out[6] = l2_x;
+  out[7] = l2_y;
+  out[8] = linf_p;
+  out[9] = linf_d;
+  free(ax);
+  free(pres);
+  free(grad);
+  free(dres);
+  free(bv);
+}
+
+/* check_termination_criteria_kernel, LP/termination_strategy/termination_strategy.cu:116-250.
+ * Returns Optimal(1) / PrimalFeasible(7) / "no termination" encoded as NumericalError(6). */
+static int termination_verdict(const double* ev, const double* s, double norm_b, double norm_c)
+{
+  int optimal_gap = ev[2] <= s[ORC_S_ABS_GAP_TOL] + s[ORC_S_REL_GAP_TOL] * ev[3];
+  if (s[ORC_S_PER_CONSTRAINT_RESIDUAL] != 0.0) {
+    int pfeas = ev[8] <= s[ORC_S_ABS_PRIMAL_TOL];
+    if (ev[9] <= s[ORC_S_ABS_DUAL_TOL] && pfeas && optimal_gap) return 1;
+    if (pfeas) return 7;
+  } else {
+    int pfeas = ev[4] <= s[ORC_S_ABS_PRIMAL_TOL] + s[ORC_S_REL_PRIMAL_TOL] * norm_b;
+    if (ev[5] <= s[ORC_S_ABS_DUAL_TOL] + s[ORC_S_REL_DUAL_TOL] * norm_c && pfeas && optimal_gap)
+      return 1;
+    if (pfeas) return 7;
+  }
+  return 6;
+}
+
+/* kernel_compute_kkt_score, LP/restart_strategy/pdlp_restart_strategy.cu:366-390 */
+static double kkt_score(const double* ev, double w)
+{
+  double w2 = w * w;
+  return sqrt(w2 * ev[4] * ev[4] + ev[5] * ev[5] / w2 + ev[2] * ev[2]);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the solver                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int m, n;
+  const int *offsets, *indices, *t_offsets, *t_indices;
+  double *A, *At;          /* scaled values      */
+  const double *Au, *Atu;  /* unscaled values    */
+  double *c, *lo, *hi, *lb, *ub;             /* scaled   */
+  const double *cu, *lou, *hiu, *lbu, *ubu;  /* unscaled (internal min-form c) */
+} prob_t;
+
+static void fill_stats(double* stats, const double* ev, int status, int steps, int attempts,
+                       double norm_b, double norm_c)
+{
+  stats[ORC_O_STATUS]                 = status;
+  stats[ORC_O_STEPS_TAKEN]            = steps;
+  stats[ORC_O_ATTEMPTED_STEPS]        = attempts;
+  stats[ORC_O_PRIMAL_OBJECTIVE]       = ev[0];
+  stats[ORC_O_DUAL_OBJECTIVE]         = ev[1];
+  stats[ORC_O_GAP]                    = ev[2];
+  stats[ORC_O_RELATIVE_GAP]           = ev[2] / (1.0 + ev[3]); /* convergence_information.cu:474 */
+  stats[ORC_O_L2_PRIMAL_RESIDUAL]     = ev[4];
+  stats[ORC_O_L2_DUAL_RESIDUAL]       = ev[5];
+  stats[ORC_O_L2_REL_PRIMAL_RESIDUAL] = ev[4] / (1.0 + norm_b);
+  stats[ORC_O_L2_REL_DUAL_RESIDUAL]   = ev[5] / (1.0 + norm_c);
+}
+
+int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const double* values,
+                   const double* c_user, const double* lo, const double* hi, const double* lb,
+                   const double* ub, int maximize, double obj_offset, const double* H,
+                   const double* S, const double* init_x, const double* init_y, double* x_out,
+                   double* y_out, double* rc_out, double* stats)
+{
+  double t_start = now_seconds();
+#ifdef _OPENMP
+  if (S[ORC_S_NUM_THREADS] > 0) omp_set_num_threads((int)S[ORC_S_NUM_THREADS]);
+#endif
+  for (int i = 0; i < ORC_O_COUNT; ++i) stats[i] = 0.0;
+  const int nnz = offsets[m];
+  /* run_pdlp_solver: n_constraints == 0 -> NumericalError, LP/solve.cu:355-359 */
+  if (m == 0) {
+    stats[ORC_O_STATUS] = 6;
+    return 0;
+  }
+  /* --- detail::problem_t, cpp/src/mip/problem/problem.cu:53-93 --- */
+  double obj_scale = 1.0;
+  double* cu       = dalloc((size_t)n);
+  for (int j = 0; j < n; ++j) cu[j] = c_user[j];
+  if (maximize) { /* problem_helpers.cuh:126-141 */
+    for (int j = 0; j < n; ++j) cu[j] = -cu[j];
+    obj_scale = -obj_scale;
+  }
+  int* t_offsets = (int*)calloc((size_t)n + 1, sizeof(int));
+  int* t_indices = (int*)calloc((size_t)(nnz ? nnz : 1), sizeof(int));
+  double* Atu    = dalloc((size_t)nnz);
+  orc_csr_transpose(m, n, offsets, indices, values, t_offsets, t_indices, Atu);
+  double* bcomb_u = dalloc((size_t)m); /* combined_bounds, utils.cuh:150-163 */
+  for (int i = 0; i < m; ++i) bcomb_u[i] = combine_bounds(lo[i], hi[i]);
+  /* convergence_information_t ctor :76-84 : constants of the termination test */
+  const double norm_c = l2norm(n, cu);
+  const double norm_b = l2norm(m, bcomb_u);
+
+  /* --- scaled copy (op_problem_scaled_, pdlp.cu:60-61) and scaling vectors (ctor) --- */
+  prob_t P;
+  P.m = m, P.n = n, P.offsets = offsets, P.indices = indices, P.t_offsets = t_offsets,
+  P.t_indices = t_indices;
+  P.Au = values, P.Atu = Atu, P.cu = cu, P.lou = lo, P.hiu = hi, P.lbu = lb, P.ubu = ub;
+  P.A  = dalloc((size_t)nnz);
+  P.At = dalloc((size_t)nnz);
+  P.c = dalloc((size_t)n), P.lb = dalloc((size_t)n), P.ub = dalloc((size_t)n);
+  P.lo = dalloc((size_t)m), P.hi = dalloc((size_t)m);
+  memcpy(P.A, values, sizeof(double) * (size_t)nnz);
+  memcpy(P.At, Atu, sizeof(double) * (size_t)nnz);
+  memcpy(P.c, cu, sizeof(double) * (size_t)n);
+  memcpy(P.lb, lb, sizeof(double) * (size_t)n);
+  memcpy(P.ub, ub, sizeof(double) * (size_t)n);
+  memcpy(P.lo, lo, sizeof(double) * (size_t)m);
+  memcpy(P.hi, hi, sizeof(double) * (size_t)m);
+  double* Dr = dalloc((size_t)m);
+  double* Dc = dalloc((size_t)n);
+  orc_compute_scaling(m, n, offsets, indices, values, t_offsets, t_indices, Atu, H, Dr, Dc);
+
+  /* --- state: saddle_point_state_t (saddle_point.cu:26-64) zero-initialised --- */
+  double *x = dalloc((size_t)n), *xn = dalloc((size_t)n), *dx = dalloc((size_t)n),
+         *xbar = dalloc((size_t)n), *aty = dalloc((size_t)n), *atyn = dalloc((size_t)n),
+         *tmpn = dalloc((size_t)n);
+  double *y = dalloc((size_t)m), *yn = dalloc((size_t)m), *dy = dalloc((size_t)m),
+         *ax = dalloc((size_t)m);
+  double *sumx = dalloc((size_t)n), *sumy = dalloc((size_t)m);
+  double sumw  = 0.0;
+  double *avgx = dalloc((size_t)n), *avgy = dalloc((size_t)m);
+  double *lrx = dalloc((size_t)n), *lry = dalloc((size_t)m); /* last_restart_duality_gap_ */
+  double *rc_cur = dalloc((size_t)n), *rc_avg = dalloc((size_t)n);
+  double *bcomb = dalloc((size_t)m);
+  double ev_cur[10], ev_avg[10];
+  double step_size = H[ORC_H_INITIAL_STEP_SIZE_SCALING], w = 0.0, tau = 0.0, sigma = 0.0;
+  int k_dev = 0, total_pdhg = 0; /* d_total_pdhg_iterations_ / total_pdhg_iterations_ */
+  int total_pdlp = 0, internal_it = 0, its_since_restart = 0, last_restart_was_average = 0;
+  double last_candidate_kkt = 0.0, last_restart_kkt = 0.0;
+  int valid_step_size = 0, num_restarts = 0, rc = 0;
+  const int major     = (int)H[ORC_H_MAJOR_ITERATION];
+  const int min_it    = (int)H[ORC_H_MIN_ITERATION_RESTART];
+  const int rule_fin  = H[ORC_H_GRADIENTS_ON_FINITE_BOUNDS_AS_RESIDUALS] == 0.0;
+  const double itlim  = S[ORC_S_ITERATION_LIMIT];
+  const double tlim   = S[ORC_S_TIME_LIMIT];
+
+  /* compute_initial_step_size, pdlp.cu:1224-1258 (eltwiseDivideCheckZero: /0 -> 0) */
+#define INIT_STEP_SIZE()                                   \
+  do {                                                     \
+    double mx = 0.0;                                       \
+    for (int k = 0; k < nnz; ++k)                          \
+      if (fabs(P.A[k]) > mx) mx = fabs(P.A[k]);            \
+    step_size = mx == 0.0 ? 0.0 : step_size / mx;          \
+  } while (0)
+  /* compute_initial_primal_weight, pdlp.cu:1260-1309 ; weighted norm utils.cuh:365-383 */
+#define INIT_PRIMAL_WEIGHT()                                                      \
+  do {                                                                            \
+    for (int i = 0; i < m; ++i) bcomb[i] = combine_bounds(P.lo[i], P.hi[i]);      \
+    double bn = sqrt(H[ORC_H_PRIMAL_WEIGHT_B_SCALING] * blocked_sum2(m, bcomb, bcomb)); \
+    double cn = sqrt(H[ORC_H_PRIMAL_WEIGHT_C_SCALING] * blocked_sum2(n, P.c, P.c));     \
+    if (bn > 0.0 && cn > 0.0)                                                     \
+      w = H[ORC_H_PRIMAL_IMPORTANCE] * (cn / bn);                                 \
+    else                                                                          \
+      w = H[ORC_H_PRIMAL_IMPORTANCE];                                             \
+  } while (0)
+
+  /* ---------------- run_solver, pdlp.cu:984-1075 ---------------- */
+  if (H[ORC_H_STEP_SIZE_BEFORE_SCALING] != 0.0) INIT_STEP_SIZE();
+  if (H[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING] != 0.0) INIT_PRIMAL_WEIGHT();
+  /* scale_problem, initial_scaling.cu:347-408 (A and A^T scaled by separate kernels :310-345) */
+  for (int i = 0; i < m; ++i)
+    for (int k = offsets[i]; k < offsets[i + 1]; ++k) P.A[k] = P.A[k] * Dr[i] * Dc[indices[k]];
+  for (int j = 0; j < n; ++j)
+    for (int k = t_offsets[j]; k < t_offsets[j + 1]; ++k)
+      P.At[k] = P.At[k] * Dc[j] * Dr[t_indices[k]];
+  for (int j = 0; j < n; ++j) {
+    P.c[j]  = P.c[j] * Dc[j];
+    P.lb[j] = P.lb[j] / Dc[j];
+    P.ub[j] = P.ub[j] / Dc[j];
+  }
+  for (int i = 0; i < m; ++i) {
+    P.lo[i] = P.lo[i] * Dr[i];
+    P.hi[i] = P.hi[i] * Dr[i];
+  }
+  /* (x, y are zero here; scale_solutions of zeros is a no-op) */
+  if (H[ORC_H_STEP_SIZE_BEFORE_SCALING] == 0.0) INIT_STEP_SIZE();
+  if (H[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING] == 0.0) INIT_PRIMAL_WEIGHT();
+  stats[ORC_O_INITIAL_STEP_SIZE]     = step_size;
+  stats[ORC_O_INITIAL_PRIMAL_WEIGHT] = w;
+  /* get_primal_and_dual_stepsizes, adaptive_step_size_strategy.cu:347-368 */
+  tau   = step_size / w;
+  sigma = step_size * w;
+  /* update_primal_dual_solutions, pdlp.cu:857-981 (the two update_* presets are off everywhere) */
+  if (init_x || init_y) {
+    if (H[ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION] != 0.0 ||
+        H[ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION] != 0.0) {
+      rc = -2;
+      goto done;
+    }
+    if (init_x)
+      for (int j = 0; j < n; ++j) x[j] = init_x[j];
+    if (init_y)
+      for (int i = 0; i < m; ++i) y[i] = init_y[i];
+    for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j]; /* scale_solutions :410-427 */
+    for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+  }
+  if (H[ORC_H_PROJECT_INITIAL_PRIMAL] != 0.0) { /* pdlp.cu:1041-1056, clamp utils.cuh:131-137 */
+    for (int j = 0; j < n; ++j) x[j] = dmin(dmax(x[j], P.lb[j]), P.ub[j]);
+    for (int j = 0; j < n; ++j) avgx[j] = dmin(dmax(avgx[j], P.lb[j]), P.ub[j]);
+  }
+
+  double t_loop = now_seconds();
+  int final_status = 6, returned_average = 0;
+  /* ---------------- main loop, pdlp.cu:1081-1185 ---------------- */
+  for (;;) {
+    int is_major = ((total_pdlp % major == 0) && total_pdlp > 0) || (total_pdlp <= min_it);
+    int error_occured = (valid_step_size == -1);
+    int artificial    = 0;
+    if (H[ORC_H_ARTIFICIAL_RESTART_IN_MAIN_LOOP] != 0.0)
+      artificial = its_since_restart >= H[ORC_H_ARTIFICIAL_RESTART_THRESHOLD] * total_pdlp;
+    if (is_major || artificial || error_occured) {
+      /* averages: pdlp.cu:1103-1123 ; weighted_average_solution.cu:114-142 */
+      if (internal_it <= 1) {
+        memcpy(avgx, x, sizeof(double) * (size_t)n);
+        memcpy(avgy, y, sizeof(double) * (size_t)m);
+      } else if (its_since_restart == 0) {
+        memset(avgx, 0, sizeof(double) * (size_t)n);
+        memset(avgy, 0, sizeof(double) * (size_t)m);
+      } else {
+        for (int j = 0; j < n; ++j) avgx[j] = sumx[j] / sumw;
+        for (int i = 0; i < m; ++i) avgy[i] = sumy[i] / sumw;
+      }
+      /* unscale_solutions, initial_scaling.cu:460-484 : in place, as the reference does */
+      for (int j = 0; j < n; ++j) avgx[j] = avgx[j] * Dc[j];
+      for (int i = 0; i < m; ++i) avgy[i] = avgy[i] * Dr[i];
+      for (int j = 0; j < n; ++j) x[j] = x[j] * Dc[j];
+      for (int i = 0; i < m; ++i) y[i] = y[i] * Dr[i];
+
+      /* ---- check_termination, pdlp.cu:537-802 ---- */
+      orc_eval(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi, lb, ub,
+               obj_scale, obj_offset, rule_fin, S[ORC_S_REL_PRIMAL_TOL], S[ORC_S_REL_DUAL_TOL], x,
+               y, rc_cur, ev_cur);
+      orc_eval(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi, lb, ub,
+               obj_scale, obj_offset, rule_fin, S[ORC_S_REL_PRIMAL_TOL], S[ORC_S_REL_DUAL_TOL],
+               avgx, avgy, rc_avg, ev_avg);
+      int t_cur = termination_verdict(ev_cur, S, norm_b, norm_c);
+      int t_avg = termination_verdict(ev_avg, S, norm_b, norm_c);
+      int done = 0, use_avg = 0, status = 6;
+      if (total_pdlp > 1) { /* :580-583 : only limits while it <= 1 */
+        if (S[ORC_S_FIRST_PRIMAL_FEASIBLE] != 0.0) { /* :587-633 */
+          if (t_avg == 7 && t_cur == 7) {
+            done = 1, status = 7, use_avg = !(ev_cur[4] < ev_avg[4]);
+          } else if (t_cur == 7) {
+            done = 1, status = 7, use_avg = 0;
+          } else if (t_avg == 7) {
+            done = 1, status = 7, use_avg = 1;
+          }
+        }
+        if (!done && t_avg == 1 && t_cur == 1) { /* :636-682 ties go to the average */
+          done = 1, status = 1, use_avg = !(kkt_score(ev_cur, w) < kkt_score(ev_avg, w));
+        }
+        if (!done && t_avg == 1) done = 1, status = 1, use_avg = 1; /* :685-700 */
+        if (!done && t_cur == 1) done = 1, status = 1, use_avg = 0; /* :701-716 */
+        /* infeasibility detection (:723-776) is not restated: default off */
+        if (!done && valid_step_size == -1) { /* :780-789 : empty solution object */
+          stats[ORC_O_STATUS] = 6;
+          final_status        = 6;
+          stats[ORC_O_STEPS_TAKEN]     = internal_it;
+          stats[ORC_O_ATTEMPTED_STEPS] = total_pdhg;
+          goto finish_noiterate;
+        }
+      }
+      /* check_limits, pdlp.cu:264-331 */
+      if (!done) {
+        if (tlim > 0.0 && isfinite(tlim) && (now_seconds() - t_start) >= tlim)
+          done = 1, status = 5, use_avg = 0;
+        else if (itlim >= 0.0 && (double)internal_it >= itlim)
+          done = 1, status = 4, use_avg = 0;
+      }
+      if (done) { /* fill_return_problem_solution, termination_strategy.cu:268-357 */
+        const double* ev = use_avg ? ev_avg : ev_cur;
+        memcpy(x_out, use_avg ? avgx : x, sizeof(double) * (size_t)n);
+        memcpy(y_out, use_avg ? avgy : y, sizeof(double) * (size_t)m);
+        memcpy(rc_out, use_avg ? rc_avg : rc_cur, sizeof(double) * (size_t)n);
+        fill_stats(stats, ev, status, internal_it, total_pdhg, norm_b, norm_c);
+        final_status     = status;
+        returned_average = use_avg;
+        goto finish;
+      }
+      /* rescale (pdlp.cu:1144-1149) or only current (:1168-1175) */
+      if (H[ORC_H_RESCALE_FOR_RESTART] != 0.0) {
+        for (int j = 0; j < n; ++j) avgx[j] = avgx[j] / Dc[j];
+        for (int i = 0; i < m; ++i) avgy[i] = avgy[i] / Dr[i];
+        for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j];
+        for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+      }
+      /* ---- compute_restart -> run_kkt_restart, pdlp_restart_strategy.cu:467-641 ---- */
+      if ((int)H[ORC_H_RESTART_STRATEGY] == 2) {
+        rc = -1; /* trust-region restart (Methodical1): not restated */
+        goto done;
+      }
+      if ((int)H[ORC_H_RESTART_STRATEGY] == 1) {
+        double cur_score = kkt_score(ev_cur, w);
+        if (its_since_restart == 0) { /* :507-514 */
+          last_candidate_kkt = cur_score;
+          last_restart_kkt   = cur_score;
+        } else {
+          double avg_score = kkt_score(ev_avg, w);
+          double cand;
+          int to_avg;
+          if (cur_score < avg_score)
+            to_avg = 0, cand = cur_score;
+          else
+            to_avg = 1, cand = avg_score;
+          /* kkt_restart_conditions :431-437 = artificial (:939-961) || kkt_decay (:407-429) */
+          int do_restart = (its_since_restart >= H[ORC_H_ARTIFICIAL_RESTART_THRESHOLD] * total_pdlp);
+          if (!do_restart) {
+            if (cand < H[ORC_H_SUFFICIENT_REDUCTION] * last_restart_kkt)
+              do_restart = 1;
+            else if (cand < H[ORC_H_NECESSARY_REDUCTION] * last_restart_kkt &&
+                     cand > last_candidate_kkt)
+              do_restart = 1;
+          }
+          if (do_restart) {
+            ++num_restarts;
+            int really_avg    = to_avg && H[ORC_H_NEVER_RESTART_TO_AVERAGE] == 0.0;
+            const double* zcx = really_avg ? avgx : x;
+            const double* zcy = really_avg ? avgy : y;
+            /* compute_distance_traveled_from_last_restart :1680-1714, :752-801 */
+            for (int j = 0; j < n; ++j) tmpn[j] = lrx[j] - 1.0 * zcx[j];
+            double pd2 = blocked_sum2(n, tmpn, tmpn);
+            for (int i = 0; i < m; ++i) ax[i] = lry[i] - 1.0 * zcy[i];
+            double dd2 = blocked_sum2(m, ax, ax);
+            if (really_avg) { /* :593-605 */
+              memcpy(x, avgx, sizeof(double) * (size_t)n);
+              memcpy(y, avgy, sizeof(double) * (size_t)m);
+              last_restart_was_average = 1;
+            } else
+              last_restart_was_average = 0;
+            /* update_last_restart_information :819-839 (only the anchors matter for KKT) and
+             * compute_new_primal_weight :684-750 ; their order does not change the result */
+            memcpy(lrx, zcx, sizeof(double) * (size_t)n);
+            memcpy(lry, zcy, sizeof(double) * (size_t)m);
+            {
+              double pdist = sqrt(pd2), ddist = sqrt(dd2);
+              const double g = 1.0e-10; /* pdlp_constants.hpp:34-35 */
+              if (!(pdist < 0.0 + g || pdist >= 1.0 / g || ddist < 0.0 + g || ddist >= 1.0 / g)) {
+                double est = ddist / pdist;
+                double th  = H[ORC_H_PRIMAL_WEIGHT_UPDATE_SMOOTHING];
+                double lw  = th * log(est) + (1.0 - th) * log(w);
+                w          = exp(lw);
+                tau        = step_size / w;
+                sigma      = step_size * w;
+              }
+            }
+            /* reset_weighted_average_solution, weighted_average_solution.cu:51-60 */
+            memset(sumx, 0, sizeof(double) * (size_t)n);
+            memset(sumy, 0, sizeof(double) * (size_t)m);
+            sumw              = 0.0;
+            its_since_restart = 0;
+            last_restart_kkt  = cand;
+          }
+          last_candidate_kkt = cand;
+        }
+      }
+      if (H[ORC_H_RESCALE_FOR_RESTART] == 0.0) {
+        for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j];
+        for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+      }
+    }
+
+    /* ---------------- take_step, pdlp.cu:1187-1222 ---------------- */
+    valid_step_size = 0;
+    while (valid_step_size == 0) {
+      /* compute_next_primal_dual_solution, pdhg.cu:160-235 */
+      if (total_pdhg == 0 || (its_since_restart == 0 && last_restart_was_average))
+        orc_spmv(n, t_offsets, t_indices, P.At, y, aty); /* compute_At_y :119-134 */
+      for (int j = 0; j < n; ++j) { /* primal_projection, utils.cuh:80-95 */
+        double gradient = P.c[j] - aty[j];
+        double next     = x[j] - (tau * gradient);
+        next            = dmax(dmin(next, P.ub[j]), P.lb[j]);
+        xn[j]           = next;
+        dx[j]           = next - x[j];
+        xbar[j]         = next - x[j] + next;
+      }
+      orc_spmv(m, offsets, indices, P.A, xbar, ax); /* pdhg.cu:87-97 */
+      for (int i = 0; i < m; ++i) {                 /* dual_projection, utils.cuh:97-112 */
+        double next = y[i] - (sigma * ax[i]);
+        double low  = next + sigma * P.lo[i];
+        double up   = next + sigma * P.hi[i];
+        next        = dmax(low, dmin(up, 0.0));
+        yn[i]       = next;
+        dy[i]       = next - y[i];
+      }
+      total_pdhg += 1;
+      /* compute_step_sizes, adaptive_step_size_strategy.cu:231-345 then kernel :91-188 */
+      orc_spmv(n, t_offsets, t_indices, P.At, yn, atyn);
+      for (int j = 0; j < n; ++j) tmpn[j] = atyn[j] - aty[j];
+      double interaction = blocked_sum2(n, tmpn, dx);
+      double ndx2        = blocked_sum2(n, dx, dx);
+      double ndy2        = blocked_sum2(m, dy, dy);
+      double movement    = H[ORC_H_PRIMAL_DISTANCE_SMOOTHING] * w * ndx2 +
+                        (H[ORC_H_DUAL_DISTANCE_SMOOTHING] / w) * ndy2;
+      if (movement <= 0.0 || movement >= 1.0e100) { /* pdlp_constants.hpp:39-47 */
+        valid_step_size = -1;
+      } else {
+        double inter = fabs(interaction);
+        k_dev += 1;
+        double kc    = (double)k_dev;
+        double limit = inter > 0.0 ? movement / inter : ORC_INF;
+        if (step_size <= limit) valid_step_size = 1;
+        double s1 = (1.0 - pow(kc + 1.0, -H[ORC_H_REDUCTION_EXPONENT])) * limit;
+        double s2 = (1.0 + pow(kc + 1.0, -H[ORC_H_GROWTH_EXPONENT])) * step_size;
+        step_size = dmin(s1, s2);
+        tau       = step_size / w;
+        sigma     = step_size * w;
+      }
+    }
+    /* add_current_solution_to_weighted_average_solution, weighted_average_solution.cu:73-108 :
+     * the weight is the step size AFTER the update above (pdlp.cu:1216-1220) */
+    for (int j = 0; j < n; ++j) sumx[j] = sumx[j] + step_size * xn[j];
+    for (int i = 0; i < m; ++i) sumy[i] = sumy[i] + step_size * yn[i];
+    sumw += step_size;
+    its_since_restart += 1;
+    /* update_solution, pdhg.cu:237-250 : pointer swaps */
+    {
+      double* t;
+      t = x, x = xn, xn = t;
+      t = y, y = yn, yn = t;
+      t = aty, aty = atyn, atyn = t;
+    }
+    ++total_pdlp;
+    ++internal_it;
+  }
+
+finish:
+finish_noiterate:
+  stats[ORC_O_FINAL_STEP_SIZE]     = step_size;
+  stats[ORC_O_FINAL_PRIMAL_WEIGHT] = w;
+  stats[ORC_O_NUM_RESTARTS]        = num_restarts;
+  stats[ORC_O_RETURNED_AVERAGE]    = returned_average;
+  stats[ORC_O_LOOP_SECONDS]        = now_seconds() - t_loop;
+  (void)final_status;
+done:
+  stats[ORC_O_SOLVE_SECONDS] = now_seconds() - t_start;
+  free(cu), free(t_offsets), free(t_indices), free(Atu), free(bcomb_u);
+  free(P.A), free(P.At), free(P.c), free(P.lb), free(P.ub), free(P.lo), free(P.hi);
+  free(Dr), free(Dc);
+  free(x), free(xn), free(dx), free(xbar), free(aty), free(atyn), free(tmpn);
+  free(y), free(yn), free(dy), free(ax), free(sumx), free(sumy), free(avgx), free(avgy);
+  free(lrx), free(lry), free(rc_cur), free(rc_avg), free(bcomb);
+  return rc;
+}
+
+/* innermost PDHG loop with a fixed step: pdhg.cu:72-158 + the A^T y' product the step-size
+ * strategy always computes (adaptive_step_size_strategy.cu:278) -- 2 SpMV per iteration */
+void orc_pdhg_fixed_steps(int m, int n, const int* offsets, const int* indices,
+                          const double* values, const int* t_offsets, const int* t_indices,
+                          const double* t_values, const double* c, const double* lo,
+                          const double* hi, const double* lb, const double* ub, double tau,
+                          double sigma, int iters, double* x, double* y)
+{
+  double *xbar = dalloc((size_t)n), *aty = dalloc((size_t)n), *ax = dalloc((size_t)m);
+  orc_spmv(n, t_offsets, t_indices, t_values, y, aty);
+  for (int it = 0; it < iters; ++it) {
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n; ++j) {
+      double gradient = c[j] - aty[j];
+      double next     = x[j] - (tau * gradient);
+      next            = dmax(dmin(next, ub[j]), lb[j]);
+      xbar[j]         = next - x[j] + next;
+      x[j]            = next;
+    }
+    orc_spmv(m, offsets, indices, values, xbar, ax);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) {
+      double next = y[i] - (sigma * ax[i]);
+      double low  = next + sigma * lo[i];
+      double up   = next + sigma * hi[i];
+      y[i]        = dmax(low, dmin(up, 0.0));
+    }
+    orc_spmv(n, t_offsets, t_indices, t_values, y, aty);
+  }
+  free(xbar), free(aty), free(ax);
+}
