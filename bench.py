@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""PDLP iterations/sec on the BASELINE.json workloads, MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|tiny|hard]
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is ONE PDLP iteration (one accepted PDHG step), including its amortised share of
+the major-iteration work (averages, 2 convergence evaluations, restart logic every 40 steps): the
+timed region is `cuoptamd_solver_advance(K)` on a solver whose problem is already resident in HBM, with
+all six tolerances at 0 so that no early exit can shorten the run (the reference's own device:
+cpp/tests/linear_programming/pdlp_test.cu:145-148).  N > 1 shards the SAME LP by row blocks (strong
+scaling) with one RCCL all-reduce of the A^T y partial products per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused CSR SpMV + dual
+projection), timed with HIP events on the solver's stream by pdlpdev_time_kernel; `cpu_baseline` is the
+C oracle's PDLP loop (oracle/pdlp_oracle.c, kind "port") on the same LP with a bounded iteration budget.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence-run", action="store_true")
+    ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1 or args.force_comm:
+        # torch first (its bundled HIP/RCCL libraries get the sonames), then our library
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from cuopt_amd import capi, synthetic
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    comm_id = None
+    if dist is not None:
+        import torch
+        buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        comm_id = bytes(buf.cpu().numpy().tobytes())
+
+    if args.workload == "hard":
+        cfg = dict(synthetic.CONFIGS["c3"], hard=True)
+    else:
+        cfg = dict(synthetic.CONFIGS[args.workload])
+    t_gen = time.time()
+    p = synthetic.generate(**cfg)
+    t_gen = time.time() - t_gen
+    m, n, nnz = p["m"], p["n"], int(len(p["values"]))
+
+    # ---- fixed-budget run: iterations / second ------------------------------------------------------
+    solver = capi.Solver(p, mode=1, tol=0.0, device=local_rank, rank=rank, world=world, comm_id=comm_id)
+    setup_s = solver.advance(0)["setup_seconds"]
+    solver.advance(args.warmup)
+    dev = solver.device
+    dev.call("synchronize")
+    barrier()
+    t0 = time.perf_counter()
+    r = solver.advance(args.steps)
+    dev.call("synchronize")
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    steps_done = r["steps_taken"] - args.warmup
+    assert r["status"] == 0 and steps_done == args.steps, (r["status_name"], steps_done)
+    its_per_s = args.steps / elapsed
+    attempts = r["attempted_steps"]
+
+    # ---- per-kernel timing with HIP events on the solver stream (dominant kernel -> roofline) --------
+    r0, r1 = solver.row_range()
+    ml = r1 - r0
+    nnz_l = int(p["offsets"][r1] - p["offsets"][r0])
+    kernels = {}
+    reps = 50 if nnz >= 5_000_000 else 200
+    names = ["PRIMAL", "SPMV_A_DUAL", "SPMV_AT_STEP", "STEP_DECISION", "SPMV_A_PLAIN", "SPMV_AT_PLAIN"]
+    for k in names:
+        kernels[k] = dev.time_kernel(k, reps)
+    bytes_alg = {
+        # 12 B per nonzero + row offsets + every gathered vector entry once + the fused epilogue streams
+        "SPMV_A_DUAL": 12 * nnz_l + 4 * (ml + 1) + 8 * n + 8 * (4 * ml + 2 * ml),   # y,lo,hi,sum_y r ; y',sum_y w
+        "SPMV_AT_STEP": 12 * nnz_l + 4 * (n + 1) + 8 * ml + 8 * (3 * n + n),        # x,x',AtY r ; AtY' w
+        "PRIMAL": 8 * (6 * n + 3 * n),                                            # x,c,AtY,lb,ub,sum_x r ; x',xbar,sum_x w
+        "SPMV_A_PLAIN": synthetic.spmv_bytes(ml, n, nnz_l),
+        "SPMV_AT_PLAIN": synthetic.spmv_bytes(n, ml, nnz_l),
+    }
+    dom = "SPMV_A_DUAL" if kernels["SPMV_A_DUAL"] >= kernels["SPMV_AT_STEP"] else "SPMV_AT_STEP"
+    achieved = bytes_alg[dom] / (kernels[dom] * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="k_spmv_a_dual" if dom == "SPMV_A_DUAL" else "k_spmv_at_step",
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=bytes_alg[dom], avg_launch_ms=round(kernels[dom], 5),
+                    per_kernel_ms={k: round(v, 5) for k, v in kernels.items()},
+                    per_kernel_gbs={k: round(bytes_alg[k] / (kernels[k] * 1e-3) / 1e9, 1) for k in bytes_alg},
+                    iteration_fused_floor_bytes=synthetic.iteration_bytes_min(m, n, nnz),
+                    iteration_frac_of_peak=round(synthetic.iteration_bytes_min(m, n, nnz) * its_per_s / 1e9
+                                                 / HBM_PEAK_GBS / max(world, 1), 4))
+    solver.close()
+
+    # ---- run to the default 1e-4 termination: wall clock incl. setup -----------------------------------
+    conv = None
+    if not args.no_convergence_run:
+        barrier()
+        t0 = time.perf_counter()
+        s2 = capi.Solver(p, mode=1, device=local_rank, rank=rank, world=world, comm_id=comm_id)
+        rr = s2.advance()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        conv = dict(status=rr["status_name"], iterations=rr["steps_taken"], wall_s=round(wall, 4),
+                    setup_s=round(rr["setup_seconds"], 4), loop_s=round(rr["loop_seconds"], 4),
+                    objective=rr["primal_objective"], objective_known=p["objective_star"],
+                    relative_gap=rr["relative_gap"], rel_primal_residual=rr["l2_relative_primal_residual"],
+                    rel_dual_residual=rr["l2_relative_dual_residual"], restarts=rr["num_restarts"])
+        s2.close()
+
+    # ---- CPU baseline: the C oracle's PDLP loop on the same LP, bounded iteration budget -----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import orcbind
+        if orcbind.available():
+            cores = os.cpu_count() or 1
+            budget = {"c3": 40, "hard": 40, "c2": 400, "tiny": 4000}[args.workload]
+            o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
+            cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
+                       kind="port", sample="oracle/pdlp_oracle.c PDLP loop (OpenMP), %d iterations of the same LP, "
+                       "loop %.2fs + setup %.2fs" % (o["steps_taken"], o["loop_seconds"],
+                                                    o["solve_seconds"] - o["loop_seconds"]))
+
+    if rank == 0:
+        info = capi.device_info(local_rank)
+        out = {
+            "metric": "pdlp_iterations_per_sec", "value": round(its_per_s, 2), "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, CSR fp64/int32, "
+                                   "Stable2 preset, tolerances 0 (fixed iteration budget)"
+                                   % (args.workload, m, n, cfg["k"], cfg["seed"], ",hard" if cfg.get("hard") else "", nnz),
+                       "rows": m, "cols": n, "nnz": nnz,
+                       "parallelism": "row-block x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
+            "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
+            "device": info["name"], "compute_units": info["compute_units"],
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

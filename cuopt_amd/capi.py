@@ -1,0 +1,619 @@
+"""ctypes binding of cuopt_amd/lib/libcuopt.so.
+
+Three layers are exposed, each a thin mirror of a C header under include/:
+  * the libcuopt C API (cuopt/linear_programming/cuopt_c.h)       -> `Problem`, `Settings`, `solve`
+  * the host driver (cuopt_amd/pdlp_solver.h)                     -> `Solver`
+  * the HIP device layer (cuopt_amd/pdlp_device.h)                -> `Device`
+There is NO CPU fallback: if the shared library is missing the import fails, and if no gfx950
+device is visible the solver calls fail with the library's error message."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcuopt.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cuopt_amd: %s is missing -- build it with `make -C cuopt_amd/csrc` (or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+# ---- constants (constants.h) ---------------------------------------------------------------------
+CUOPT_SUCCESS, CUOPT_INVALID_ARGUMENT, CUOPT_MPS_FILE_ERROR, CUOPT_MPS_PARSE_ERROR = 0, 1, 2, 3
+CUOPT_VALIDATION_ERROR, CUOPT_OUT_OF_MEMORY, CUOPT_RUNTIME_ERROR = 4, 5, 6
+CUOPT_MINIMIZE, CUOPT_MAXIMIZE = 1, -1
+STATUS = {0: "NoTermination", 1: "Optimal", 2: "PrimalInfeasible", 3: "DualInfeasible",
+          4: "IterationLimit", 5: "TimeLimit", 6: "NumericalError", 7: "PrimalFeasible",
+          8: "FeasibleFound", 9: "ConcurrentLimit"}
+
+c_int, c_double, c_void_p, c_char_p = C.c_int32, C.c_double, C.c_void_p, C.c_char_p
+P = C.POINTER
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+# ---- structs (pdlp_device.h / pdlp_solver.h) -----------------------------------------------------
+class Ctl(C.Structure):
+    _fields_ = [("step_size", c_double), ("primal_weight", c_double), ("tau", c_double),
+                ("sigma", c_double), ("sum_weights", c_double), ("last_interaction", c_double),
+                ("last_movement", c_double), ("last_dx2", c_double), ("last_dy2", c_double),
+                ("k", c_int), ("cur", c_int), ("pending_avg", c_int), ("steps_taken", c_int),
+                ("attempts", c_int), ("target_steps", c_int), ("error", c_int),
+                ("its_since_restart", c_int)]
+
+
+class StepParams(C.Structure):
+    _fields_ = [("reduction_exponent", c_double), ("growth_exponent", c_double),
+                ("primal_distance_smoothing", c_double), ("dual_distance_smoothing", c_double)]
+
+
+class LP(C.Structure):
+    _fields_ = [("m", c_int), ("n", c_int), ("offsets", c_void_p), ("indices", c_void_p),
+                ("values", c_void_p), ("c", c_void_p), ("lo", c_void_p), ("hi", c_void_p),
+                ("lb", c_void_p), ("ub", c_void_p), ("maximize", c_int),
+                ("objective_offset", c_double)]
+
+
+class Hyper(C.Structure):
+    _fields_ = [("initial_step_size_scaling", c_double), ("ruiz_iterations", c_int),
+                ("do_pock_chambolle", c_int), ("do_ruiz", c_int), ("alpha_pock_chambolle", c_double),
+                ("artificial_restart_threshold", c_double),
+                ("compute_initial_step_size_before_scaling", c_int),
+                ("compute_initial_primal_weight_before_scaling", c_int),
+                ("initial_primal_weight_c_scaling", c_double),
+                ("initial_primal_weight_b_scaling", c_double), ("major_iteration", c_int),
+                ("min_iteration_restart", c_int), ("restart_strategy", c_int),
+                ("never_restart_to_average", c_int), ("reduction_exponent", c_double),
+                ("growth_exponent", c_double), ("primal_weight_update_smoothing", c_double),
+                ("sufficient_reduction_for_restart", c_double),
+                ("necessary_reduction_for_restart", c_double), ("primal_importance", c_double),
+                ("primal_distance_smoothing", c_double), ("dual_distance_smoothing", c_double),
+                ("compute_last_restart_before_new_primal_weight", c_int),
+                ("artificial_restart_in_main_loop", c_int), ("rescale_for_restart", c_int),
+                ("update_primal_weight_on_initial_solution", c_int),
+                ("update_step_size_on_initial_solution", c_int),
+                ("handle_some_primal_gradients_on_finite_bounds_as_residuals", c_int),
+                ("project_initial_primal", c_int)]
+
+
+class SolverSettings(C.Structure):
+    _fields_ = [("absolute_gap_tolerance", c_double), ("relative_gap_tolerance", c_double),
+                ("absolute_primal_tolerance", c_double), ("relative_primal_tolerance", c_double),
+                ("absolute_dual_tolerance", c_double), ("relative_dual_tolerance", c_double),
+                ("iteration_limit", c_int), ("time_limit", c_double),
+                ("per_constraint_residual", c_int), ("first_primal_feasible", c_int),
+                ("initial_step_size", c_double), ("initial_primal_weight", c_double),
+                ("initial_k", c_int), ("use_graph", c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", c_int), ("steps_taken", c_int), ("attempted_steps", c_int),
+                ("returned_average", c_int), ("num_restarts", c_int), ("num_major_iterations", c_int),
+                ("primal_objective", c_double), ("dual_objective", c_double), ("gap", c_double),
+                ("relative_gap", c_double), ("l2_primal_residual", c_double),
+                ("l2_dual_residual", c_double), ("l2_relative_primal_residual", c_double),
+                ("l2_relative_dual_residual", c_double), ("max_primal_ray_infeasibility", c_double),
+                ("max_dual_ray_infeasibility", c_double), ("initial_step_size", c_double),
+                ("initial_primal_weight", c_double), ("step_size", c_double),
+                ("primal_weight", c_double), ("norm_b", c_double), ("norm_c", c_double),
+                ("setup_seconds", c_double), ("loop_seconds", c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["status_name"] = STATUS.get(self.status, str(self.status))
+        return d
+
+
+def _struct_dict(s):
+    return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+# ---- prototypes ----------------------------------------------------------------------------------
+def _proto(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype, f.argtypes = restype, list(argtypes)
+    return f
+
+
+_proto("cuOptGetFloatSize", C.c_int8)
+_proto("cuOptGetIntSize", C.c_int8)
+_proto("cuOptReadProblem", c_int, c_char_p, P(c_void_p))
+_proto("cuOptCreateProblem", c_int, c_int, c_int, c_int, c_double, *([c_void_p] * 4), c_char_p,
+       *([c_void_p] * 3), c_char_p, P(c_void_p))
+_proto("cuOptCreateRangedProblem", c_int, c_int, c_int, c_int, c_double, *([c_void_p] * 8), c_char_p,
+       P(c_void_p))
+_proto("cuOptDestroyProblem", None, P(c_void_p))
+for _n in ("cuOptGetNumConstraints", "cuOptGetNumVariables", "cuOptGetObjectiveSense",
+           "cuOptGetNumNonZeros", "cuOptIsMIP"):
+    _proto(_n, c_int, c_void_p, P(c_int))
+_proto("cuOptGetObjectiveOffset", c_int, c_void_p, P(c_double))
+for _n in ("cuOptGetObjectiveCoefficients", "cuOptGetConstraintSense", "cuOptGetConstraintRightHandSide",
+           "cuOptGetConstraintLowerBounds", "cuOptGetConstraintUpperBounds",
+           "cuOptGetVariableLowerBounds", "cuOptGetVariableUpperBounds", "cuOptGetVariableTypes"):
+    _proto(_n, c_int, c_void_p, c_void_p)
+_proto("cuOptGetConstraintMatrix", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuOptCreateSolverSettings", c_int, P(c_void_p))
+_proto("cuOptDestroySolverSettings", None, P(c_void_p))
+_proto("cuOptSetParameter", c_int, c_void_p, c_char_p, c_char_p)
+_proto("cuOptGetParameter", c_int, c_void_p, c_char_p, c_int, c_char_p)
+_proto("cuOptSetIntegerParameter", c_int, c_void_p, c_char_p, c_int)
+_proto("cuOptGetIntegerParameter", c_int, c_void_p, c_char_p, P(c_int))
+_proto("cuOptSetFloatParameter", c_int, c_void_p, c_char_p, c_double)
+_proto("cuOptGetFloatParameter", c_int, c_void_p, c_char_p, P(c_double))
+_proto("cuOptSolve", c_int, c_void_p, c_void_p, P(c_void_p))
+_proto("cuOptDestroySolution", None, P(c_void_p))
+_proto("cuOptGetTerminationStatus", c_int, c_void_p, P(c_int))
+_proto("cuOptGetErrorStatus", c_int, c_void_p, P(c_int))
+_proto("cuOptGetErrorString", c_int, c_void_p, c_char_p, c_int)
+for _n in ("cuOptGetPrimalSolution", "cuOptGetDualSolution", "cuOptGetReducedCosts"):
+    _proto(_n, c_int, c_void_p, c_void_p)
+for _n in ("cuOptGetObjectiveValue", "cuOptGetSolveTime", "cuOptGetMIPGap", "cuOptGetSolutionBound"):
+    _proto(_n, c_int, c_void_p, P(c_double))
+_proto("cuOptAmdGetPdlpStats", c_int, c_void_p, P(Result))
+
+_proto("cuoptamd_last_error", c_char_p)
+_proto("cuoptamd_hyper_preset", None, c_int, P(Hyper))
+_proto("cuoptamd_default_settings", None, P(SolverSettings))
+_proto("cuoptamd_solver_create", c_int, P(c_void_p), P(LP), P(Hyper), P(SolverSettings), c_void_p,
+       c_void_p, c_int, c_int, c_int, c_void_p)
+_proto("cuoptamd_solver_destroy", None, c_void_p)
+_proto("cuoptamd_solver_advance", c_int, c_void_p, c_int, P(Result))
+_proto("cuoptamd_solver_get_solution", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuoptamd_solver_device", c_void_p, c_void_p)
+_proto("cuoptamd_solver_row_range", c_int, c_void_p, P(c_int), P(c_int))
+_proto("cuoptamd_partition_rows", None, c_int, c_void_p, c_int, c_void_p)
+_proto("cuoptamd_csr_transpose", None, c_int, c_int, *([c_void_p] * 6))
+
+_proto("pdlpdev_last_error", c_char_p)
+_proto("pdlpdev_device_count", c_int)
+_proto("pdlpdev_device_info", c_int, c_int, c_char_p, c_int, P(c_int), P(C.c_int64))
+_proto("pdlpdev_create", c_int, P(c_void_p), c_int, c_int, c_int, *([c_void_p] * 11))
+_proto("pdlpdev_destroy", None, c_void_p)
+_proto("pdlpdev_comm_unique_id", c_int, c_void_p)
+_proto("pdlpdev_comm_init", c_int, c_void_p, c_int, c_int, c_void_p)
+_proto("pdlpdev_scaling_compute", c_int, c_void_p, c_int, c_int, c_int, c_double)
+_proto("pdlpdev_scale_problem", c_int, c_void_p)
+_proto("pdlpdev_init_norms", c_int, c_void_p, c_void_p)
+_proto("pdlpdev_problem_norms", c_int, c_void_p, P(c_double), P(c_double))
+_proto("pdlpdev_set_step_params", c_int, c_void_p, P(StepParams))
+_proto("pdlpdev_set_step", c_int, c_void_p, c_double, c_double)
+_proto("pdlpdev_set_k", c_int, c_void_p, c_int)
+_proto("pdlpdev_set_initial", c_int, c_void_p, c_void_p, c_void_p)
+_proto("pdlpdev_project_primal", c_int, c_void_p)
+_proto("pdlpdev_compute_aty", c_int, c_void_p)
+_proto("pdlpdev_run", c_int, c_void_p, c_int, P(Ctl))
+_proto("pdlpdev_get_ctl", c_int, c_void_p, P(Ctl))
+_proto("pdlpdev_clear_error", c_int, c_void_p)
+_proto("pdlpdev_set_graph_mode", c_int, c_void_p, c_int)
+_proto("pdlpdev_flush_average", c_int, c_void_p)
+_proto("pdlpdev_make_average", c_int, c_void_p, c_int)
+_proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)
+_proto("pdlpdev_restart", c_int, c_void_p, c_int, c_void_p)
+_proto("pdlpdev_get_solution", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
+_proto("pdlpdev_download", C.c_int64, c_void_p, c_int, c_void_p, C.c_int64)
+_proto("pdlpdev_spmv", c_int, c_void_p, c_int, c_void_p, c_void_p)
+_proto("pdlpdev_time_kernel", c_int, c_void_p, c_int, c_int, P(c_double))
+_proto("pdlpdev_synchronize", c_int, c_void_p)
+_proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
+
+# ids of pdlp_device.h
+BUF = {n: i for i, n in enumerate(
+    ["X", "Y", "X_OTHER", "Y_OTHER", "ATY", "ATY_OTHER", "XBAR", "SUM_X", "SUM_Y", "AVG_X", "AVG_Y",
+     "DROW", "DCOL", "A_VALUES", "AT_VALUES", "C", "LB", "UB", "LO", "HI", "RC_CURRENT", "RC_AVERAGE",
+     "LAST_RESTART_X", "LAST_RESTART_Y"])}
+KERNEL = {n: i for i, n in enumerate(
+    ["PRIMAL", "SPMV_A_DUAL", "SPMV_AT_STEP", "STEP_DECISION", "SPMV_A_PLAIN", "SPMV_AT_PLAIN"])}
+EV = {n: i for i, n in enumerate(
+    ["CX", "DUAL_SUM", "PRES2", "DRES2", "X2", "Y2", "LINF_PRES_REL", "LINF_DRES_REL"])}
+CURRENT, AVERAGE = 0, 1
+
+
+class CuOptError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("cuopt error %d %s" % (code, msg))
+        self.code = code
+
+
+def device_count():
+    return int(lib.pdlpdev_device_count())
+
+
+def device_info(dev=0):
+    name = C.create_string_buffer(256)
+    cus, mem = c_int(), C.c_int64()
+    rc = lib.pdlpdev_device_info(dev, name, 256, C.byref(cus), C.byref(mem))
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=mem.value)
+
+
+# ---- libcuopt C API --------------------------------------------------------------------------------
+class Problem:
+    """cuOptOptimizationProblem handle."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @classmethod
+    def read(cls, path):
+        h = c_void_p()
+        rc = lib.cuOptReadProblem(os.fsencode(path), C.byref(h))
+        if rc != CUOPT_SUCCESS:
+            raise CuOptError(rc, "cuOptReadProblem(%s)" % path)
+        return cls(h)
+
+    @classmethod
+    def from_dict(cls, p, ranged=True):
+        """p: dict with m, n, offsets, indices, values, c, lb, ub and (lo, hi) [ranged] or
+        (row_types, rhs); optional maximize, objective_offset, var_types."""
+        m, n = int(p["m"]), int(p["n"])
+        keep = [_i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"]), _f64(p["c"]),
+                _f64(p["lb"]), _f64(p["ub"])]
+        vt = p.get("var_types")
+        vt = (b"C" * n) if vt is None else bytes(bytearray(np.asarray(vt, dtype=np.uint8)))
+        h = c_void_p()
+        sense = CUOPT_MAXIMIZE if p.get("maximize", False) else CUOPT_MINIMIZE
+        off = float(p.get("objective_offset", 0.0))
+        if ranged:
+            lo, hi = _f64(p["lo"]), _f64(p["hi"])
+            rc = lib.cuOptCreateRangedProblem(m, n, sense, off, _ptr(keep[3]), _ptr(keep[0]),
+                                              _ptr(keep[1]), _ptr(keep[2]), _ptr(lo), _ptr(hi),
+                                              _ptr(keep[4]), _ptr(keep[5]), vt, C.byref(h))
+        else:
+            rt = bytes(bytearray(np.asarray(p["row_types"], dtype=np.uint8)))
+            rhs = _f64(p["rhs"])
+            rc = lib.cuOptCreateProblem(m, n, sense, off, _ptr(keep[3]), _ptr(keep[0]), _ptr(keep[1]),
+                                        _ptr(keep[2]), rt, _ptr(rhs), _ptr(keep[4]), _ptr(keep[5]), vt,
+                                        C.byref(h))
+        if rc != CUOPT_SUCCESS:
+            raise CuOptError(rc, "cuOptCreate*Problem")
+        return cls(h)
+
+    def _int(self, fn):
+        v = c_int()
+        rc = fn(self.handle, C.byref(v))
+        if rc != 0:
+            raise CuOptError(rc)
+        return v.value
+
+    @property
+    def m(self):
+        return self._int(lib.cuOptGetNumConstraints)
+
+    @property
+    def n(self):
+        return self._int(lib.cuOptGetNumVariables)
+
+    @property
+    def nnz(self):
+        return self._int(lib.cuOptGetNumNonZeros)
+
+    @property
+    def is_mip(self):
+        return bool(self._int(lib.cuOptIsMIP))
+
+    def to_dict(self):
+        m, n, nnz = self.m, self.n, self.nnz
+        d = dict(m=m, n=n, offsets=np.zeros(m + 1, np.int32), indices=np.zeros(nnz, np.int32),
+                 values=np.zeros(nnz), c=np.zeros(n), lo=np.zeros(m), hi=np.zeros(m), lb=np.zeros(n),
+                 ub=np.zeros(n), var_types=np.zeros(n, np.uint8))
+        lib.cuOptGetConstraintMatrix(self.handle, _ptr(d["offsets"]), _ptr(d["indices"]), _ptr(d["values"]))
+        lib.cuOptGetObjectiveCoefficients(self.handle, _ptr(d["c"]))
+        lib.cuOptGetConstraintLowerBounds(self.handle, _ptr(d["lo"]))
+        lib.cuOptGetConstraintUpperBounds(self.handle, _ptr(d["hi"]))
+        lib.cuOptGetVariableLowerBounds(self.handle, _ptr(d["lb"]))
+        lib.cuOptGetVariableUpperBounds(self.handle, _ptr(d["ub"]))
+        lib.cuOptGetVariableTypes(self.handle, _ptr(d["var_types"]))
+        d["maximize"] = self._int(lib.cuOptGetObjectiveSense) == CUOPT_MAXIMIZE
+        off = c_double()
+        lib.cuOptGetObjectiveOffset(self.handle, C.byref(off))
+        d["objective_offset"] = off.value
+        return d
+
+    def close(self):
+        if self.handle:
+            lib.cuOptDestroyProblem(C.byref(self.handle))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Settings:
+    """cuOptSolverSettings handle; parameters by their CUOPT_* string names."""
+
+    def __init__(self, **params):
+        self.handle = c_void_p()
+        rc = lib.cuOptCreateSolverSettings(C.byref(self.handle))
+        if rc != 0:
+            raise CuOptError(rc)
+        params.setdefault("log_to_console", False)
+        for k, v in params.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        nm = name.encode()
+        if isinstance(value, bool):
+            rc = lib.cuOptSetIntegerParameter(self.handle, nm, int(value))
+        elif isinstance(value, (int, np.integer)):
+            rc = lib.cuOptSetIntegerParameter(self.handle, nm, int(value))
+        elif isinstance(value, (float, np.floating)):
+            rc = lib.cuOptSetFloatParameter(self.handle, nm, float(value))
+        else:
+            rc = lib.cuOptSetParameter(self.handle, nm, str(value).encode())
+        if rc != 0:
+            raise CuOptError(rc, "set %s=%r" % (name, value))
+
+    def set_optimality_tolerance(self, eps):
+        for k in ("absolute_dual_tolerance", "relative_dual_tolerance", "absolute_primal_tolerance",
+                  "relative_primal_tolerance", "absolute_gap_tolerance", "relative_gap_tolerance"):
+            self.set(k, float(eps))
+
+    def get(self, name):
+        buf = C.create_string_buffer(256)
+        rc = lib.cuOptGetParameter(self.handle, name.encode(), 256, buf)
+        if rc != 0:
+            raise CuOptError(rc, "get %s" % name)
+        return buf.value.decode()
+
+    def close(self):
+        if self.handle:
+            lib.cuOptDestroySolverSettings(C.byref(self.handle))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve(problem, settings=None, **params):
+    """cuOptSolve + all solution getters -> dict.  `problem` is a Problem or a problem dict."""
+    own_problem = not isinstance(problem, Problem)
+    prob = Problem.from_dict(problem) if own_problem else problem
+    own_settings = settings is None
+    tol = params.pop("tol", None)
+    st = Settings(**params) if own_settings else settings
+    if tol is not None:
+        st.set_optimality_tolerance(tol)
+    sol = c_void_p()
+    rc = lib.cuOptSolve(prob.handle, st.handle, C.byref(sol))
+    out = dict(return_code=rc)
+    try:
+        if not sol:
+            raise CuOptError(rc, "cuOptSolve returned no solution handle")
+        v = c_int()
+        lib.cuOptGetTerminationStatus(sol, C.byref(v))
+        out["status_code"], out["status"] = v.value, STATUS.get(v.value, str(v.value))
+        lib.cuOptGetErrorStatus(sol, C.byref(v))
+        out["error_status"] = v.value
+        buf = C.create_string_buffer(4096)
+        lib.cuOptGetErrorString(sol, buf, 4096)
+        out["error_string"] = buf.value.decode()
+        if rc == CUOPT_SUCCESS:
+            n, m = prob.n, prob.m
+            x, y, z = np.zeros(n), np.zeros(m), np.zeros(n)
+            lib.cuOptGetPrimalSolution(sol, _ptr(x))
+            lib.cuOptGetDualSolution(sol, _ptr(y))
+            lib.cuOptGetReducedCosts(sol, _ptr(z))
+            d = c_double()
+            lib.cuOptGetObjectiveValue(sol, C.byref(d))
+            out["objective"] = d.value
+            lib.cuOptGetSolveTime(sol, C.byref(d))
+            out["solve_time"] = d.value
+            res = Result()
+            lib.cuOptAmdGetPdlpStats(sol, C.byref(res))
+            out.update(res.as_dict())
+            out.update(x=x, y=y, reduced_cost=z)
+    finally:
+        if sol:
+            lib.cuOptDestroySolution(C.byref(sol))
+        if own_settings:
+            st.close()
+        if own_problem:
+            prob.close()
+    return out
+
+
+# ---- host driver -----------------------------------------------------------------------------------
+def hyper_preset(mode=1):
+    h = Hyper()
+    lib.cuoptamd_hyper_preset(int(mode), C.byref(h))
+    return h
+
+
+def default_settings(**over):
+    s = SolverSettings()
+    lib.cuoptamd_default_settings(C.byref(s))
+    tol = over.pop("tol", None)
+    if tol is not None:
+        for k in ("absolute_gap_tolerance", "relative_gap_tolerance", "absolute_primal_tolerance",
+                  "relative_primal_tolerance", "absolute_dual_tolerance", "relative_dual_tolerance"):
+            setattr(s, k, float(tol))
+    for k, v in over.items():
+        setattr(s, k, v)
+    return s
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * 128)()
+    rc = lib.pdlpdev_comm_unique_id(buf)
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return bytes(buf)
+
+
+class Solver:
+    """cuoptamd_solver: step-wise control of the PDLP loop (bench, warm-started re-solves, tests)."""
+
+    def __init__(self, p, mode=1, hyper=None, settings=None, init_x=None, init_y=None, device=0,
+                 rank=0, world=1, comm_id=None, **setting_overrides):
+        self._keep = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]),
+                          c=_f64(p["c"]), lo=_f64(p["lo"]), hi=_f64(p["hi"]), lb=_f64(p["lb"]),
+                          ub=_f64(p["ub"]))
+        k = self._keep
+        self.m, self.n = int(p["m"]), int(p["n"])
+        lp = LP(self.m, self.n, _ptr(k["offsets"]), _ptr(k["indices"]), _ptr(k["values"]), _ptr(k["c"]),
+                _ptr(k["lo"]), _ptr(k["hi"]), _ptr(k["lb"]), _ptr(k["ub"]),
+                int(bool(p.get("maximize", False))), float(p.get("objective_offset", 0.0)))
+        self.hyper = hyper_preset(mode) if hyper is None else hyper
+        self.settings = default_settings(**setting_overrides) if settings is None else settings
+        ix = None if init_x is None else _f64(init_x)
+        iy = None if init_y is None else _f64(init_y)
+        cid = None
+        if comm_id is not None:
+            cid = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        self.handle = c_void_p()
+        rc = lib.cuoptamd_solver_create(C.byref(self.handle), C.byref(lp), C.byref(self.hyper),
+                                        C.byref(self.settings), _ptr(ix), _ptr(iy), device, rank, world,
+                                        cid)
+        if rc != 0:
+            msg = lib.cuoptamd_last_error().decode()
+            h, self.handle = self.handle, None
+            if h:
+                lib.cuoptamd_solver_destroy(h)
+            raise CuOptError(rc, msg)
+        self.result = Result()
+
+    def advance(self, iterations=2 ** 31 - 1):
+        rc = lib.cuoptamd_solver_advance(self.handle, int(iterations), C.byref(self.result))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        return self.result.as_dict()
+
+    def solution(self):
+        x, y, z = np.zeros(self.n), np.zeros(self.m), np.zeros(self.n)
+        rc = lib.cuoptamd_solver_get_solution(self.handle, _ptr(x), _ptr(y), _ptr(z))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        return x, y, z
+
+    @property
+    def device(self):
+        return Device(handle=c_void_p(lib.cuoptamd_solver_device(self.handle)), owner=False)
+
+    def row_range(self):
+        a, b = c_int(), c_int()
+        lib.cuoptamd_solver_row_range(self.handle, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.handle:
+            lib.cuoptamd_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def csr_transpose(m, n, offsets, indices, values):
+    offsets, indices, values = _i32(offsets), _i32(indices), _f64(values)
+    to, ti, tv = np.zeros(n + 1, np.int32), np.zeros(len(indices), np.int32), np.zeros(len(values))
+    lib.cuoptamd_csr_transpose(m, n, _ptr(offsets), _ptr(indices), _ptr(values), _ptr(to), _ptr(ti), _ptr(tv))
+    return to, ti, tv
+
+
+def partition_rows(m, offsets, world):
+    offsets = _i32(offsets)
+    b = np.zeros(world + 1, np.int32)
+    lib.cuoptamd_partition_rows(m, _ptr(offsets), world, _ptr(b))
+    return b
+
+
+# ---- device layer ------------------------------------------------------------------------------------
+class Device:
+    """pdlpdev_ctx: direct access to the HIP kernels (kernel-level parity tests, timing)."""
+
+    def __init__(self, p=None, handle=None, owner=True, device=0):
+        self.owner = owner
+        if handle is not None:
+            self.handle = handle
+            return
+        m, n = int(p["m"]), int(p["n"])
+        off, idx, val = _i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"])
+        to, ti, tv = csr_transpose(m, n, off, idx, val)
+        c, lo, hi, lb, ub = (_f64(p[k]) for k in ("c", "lo", "hi", "lb", "ub"))
+        self.handle = c_void_p()
+        rc = lib.pdlpdev_create(C.byref(self.handle), device, m, n, _ptr(off), _ptr(idx), _ptr(val),
+                                _ptr(to), _ptr(ti), _ptr(tv), _ptr(c), _ptr(lo), _ptr(hi), _ptr(lb), _ptr(ub))
+        if rc != 0:
+            msg = lib.pdlpdev_last_error().decode()
+            if self.handle:
+                lib.pdlpdev_destroy(self.handle)
+            self.handle = None
+            raise CuOptError(rc, msg)
+        self.m, self.n, self.nnz = m, n, len(val)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+
+    def call(self, name, *args):
+        self._ck(getattr(lib, "pdlpdev_" + name)(self.handle, *args))
+
+    def ctl(self):
+        c = Ctl()
+        self._ck(lib.pdlpdev_get_ctl(self.handle, C.byref(c)))
+        return c
+
+    def run(self, target_steps):
+        c = Ctl()
+        self._ck(lib.pdlpdev_run(self.handle, int(target_steps), C.byref(c)))
+        return c
+
+    def download(self, name, count):
+        out = np.zeros(int(count))
+        got = lib.pdlpdev_download(self.handle, BUF[name], _ptr(out), int(count))
+        if got < 0:
+            raise CuOptError(int(got), lib.pdlpdev_last_error().decode())
+        return out[:got]
+
+    def spmv(self, x, transpose=False, rows=None):
+        x = _f64(x)
+        y = np.zeros(int(rows))
+        self._ck(lib.pdlpdev_spmv(self.handle, int(transpose), _ptr(x), _ptr(y)))
+        return y
+
+    def eval(self, which, rule_finite=True, eps_p=1e-4, eps_d=1e-4):
+        out = np.zeros(len(EV))
+        self._ck(lib.pdlpdev_eval(self.handle, which, int(rule_finite), eps_p, eps_d, _ptr(out)))
+        return {k: out[i] for k, i in EV.items()}
+
+    def init_norms(self):
+        out = np.zeros(3)
+        self._ck(lib.pdlpdev_init_norms(self.handle, _ptr(out)))
+        return out
+
+    def time_kernel(self, kernel, reps=20):
+        ms = c_double()
+        self._ck(lib.pdlpdev_time_kernel(self.handle, KERNEL[kernel], int(reps), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.owner and self.handle:
+            lib.pdlpdev_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

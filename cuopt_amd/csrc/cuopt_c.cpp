@@ -1,0 +1,712 @@
+// libcuopt C API (include/cuopt/linear_programming/cuopt_c.h) on top of the MI355X-native PDLP
+// host driver.  Behaviour mirrors cuOpt 25.08 cpp/src/linear_programming/cuopt_c.cpp (handles,
+// null checks, return codes) and cpp/src/math_optimization/solver_settings.cu:66-330 (parameter
+// registry: names, types, ranges, defaults, string conversions).  No HIP header is included here.
+#include <cuopt/linear_programming/cuopt_c.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cuopt_amd/pdlp_solver.h"
+#include "mps_reader.hpp"
+
+namespace {
+
+constexpr double kInf = std::numeric_limits<double>::infinity();
+
+// ---- problem ------------------------------------------------------------------------------------
+// optimization_problem_t (host-resident here; the reference keeps device copies and synchronises
+// in every getter, cuopt_c.cpp:208-438 -- the getters below have the same observable behaviour)
+struct Problem {
+  int32_t m = 0, n = 0;
+  bool maximize = false;
+  double objective_offset = 0.0;
+  std::vector<int32_t> offsets, indices;
+  std::vector<double> values, c, lb, ub;
+  std::vector<char> row_types;   // empty when built from ranged bounds
+  std::vector<double> rhs;       // idem
+  std::vector<double> lo, hi;    // always materialised (problem_helpers.cuh:33-58)
+  std::vector<char> var_types;
+  bool has_integers() const
+  {
+    for (char t : var_types)
+      if (t == CUOPT_INTEGER) return true;
+    return false;
+  }
+};
+
+// ---- settings -----------------------------------------------------------------------------------
+struct Settings {
+  // pdlp_solver_settings_t
+  double tol[6] = {1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4};  // abs/rel dual, abs/rel primal, abs/rel gap
+  double primal_infeasible_tolerance = 1e-8, dual_infeasible_tolerance = 1e-8;
+  double time_limit = kInf;
+  int32_t iteration_limit = INT_MAX, pdlp_solver_mode = CUOPT_PDLP_SOLVER_MODE_STABLE2,
+          method = CUOPT_METHOD_CONCURRENT, num_cpu_threads = -1;
+  bool infeasibility_detection = false, strict_infeasibility = false, per_constraint_residual = false,
+       save_best_primal_so_far = false, first_primal_feasible = false, log_to_console = true,
+       crossover = false, mip_scaling = true, mip_heuristics_only = false;
+  // MIP tolerances are registered so that clients that set them keep working
+  double mip_abs_tol = 1e-4, mip_rel_tol = 1e-4, mip_int_tol = 1e-5, mip_abs_gap = 1e-10, mip_rel_gap = 1e-4;
+  std::string log_file, solution_file, user_problem_file;
+
+  struct FloatParam { const char* name; double* value; double lo, hi; };
+  struct IntParam { const char* name; int32_t* value; int32_t lo, hi; };
+  struct BoolParam { const char* name; bool* value; };
+  struct StringParam { const char* name; std::string* value; };
+  std::vector<FloatParam> floats;
+  std::vector<IntParam> ints;
+  std::vector<BoolParam> bools;
+  std::vector<StringParam> strings;
+
+  Settings()
+  {
+    floats = {{CUOPT_TIME_LIMIT, &time_limit, 0.0, kInf},
+              {CUOPT_ABSOLUTE_DUAL_TOLERANCE, &tol[0], 0.0, 1e-1},
+              {CUOPT_RELATIVE_DUAL_TOLERANCE, &tol[1], 0.0, 1e-1},
+              {CUOPT_ABSOLUTE_PRIMAL_TOLERANCE, &tol[2], 0.0, 1e-1},
+              {CUOPT_RELATIVE_PRIMAL_TOLERANCE, &tol[3], 0.0, 1e-1},
+              {CUOPT_ABSOLUTE_GAP_TOLERANCE, &tol[4], 0.0, 1e-1},
+              {CUOPT_RELATIVE_GAP_TOLERANCE, &tol[5], 0.0, 1e-1},
+              {CUOPT_MIP_ABSOLUTE_TOLERANCE, &mip_abs_tol, 0.0, 1e-1},
+              {CUOPT_MIP_RELATIVE_TOLERANCE, &mip_rel_tol, 0.0, 1e-1},
+              {CUOPT_MIP_INTEGRALITY_TOLERANCE, &mip_int_tol, 0.0, 1e-1},
+              {CUOPT_MIP_ABSOLUTE_GAP, &mip_abs_gap, 0.0, 1e-1},
+              {CUOPT_MIP_RELATIVE_GAP, &mip_rel_gap, 0.0, 1e-1},
+              {CUOPT_PRIMAL_INFEASIBLE_TOLERANCE, &primal_infeasible_tolerance, 0.0, 1e-1},
+              {CUOPT_DUAL_INFEASIBLE_TOLERANCE, &dual_infeasible_tolerance, 0.0, 1e-1}};
+    ints = {{CUOPT_ITERATION_LIMIT, &iteration_limit, 0, INT_MAX},
+            {CUOPT_PDLP_SOLVER_MODE, &pdlp_solver_mode, CUOPT_PDLP_SOLVER_MODE_STABLE1, CUOPT_PDLP_SOLVER_MODE_FAST1},
+            {CUOPT_METHOD, &method, CUOPT_METHOD_CONCURRENT, CUOPT_METHOD_DUAL_SIMPLEX},
+            {CUOPT_NUM_CPU_THREADS, &num_cpu_threads, -1, INT_MAX}};
+    bools = {{CUOPT_INFEASIBILITY_DETECTION, &infeasibility_detection},
+             {CUOPT_STRICT_INFEASIBILITY, &strict_infeasibility},
+             {CUOPT_PER_CONSTRAINT_RESIDUAL, &per_constraint_residual},
+             {CUOPT_SAVE_BEST_PRIMAL_SO_FAR, &save_best_primal_so_far},
+             {CUOPT_FIRST_PRIMAL_FEASIBLE, &first_primal_feasible},
+             {CUOPT_MIP_SCALING, &mip_scaling},
+             {CUOPT_MIP_HEURISTICS_ONLY, &mip_heuristics_only},
+             {CUOPT_LOG_TO_CONSOLE, &log_to_console},
+             {CUOPT_CROSSOVER, &crossover}};
+    strings = {{CUOPT_LOG_FILE, &log_file}, {CUOPT_SOLUTION_FILE, &solution_file},
+               {CUOPT_USER_PROBLEM_FILE, &user_problem_file}};
+  }
+  Settings(const Settings&)            = delete;
+  Settings& operator=(const Settings&) = delete;
+
+  // each setter returns false for "no such parameter of this type"; throws on a bad value
+  bool set_int(const std::string& name, int32_t v)
+  {
+    for (auto& p : ints)
+      if (name == p.name) {
+        if (v < p.lo || v > p.hi) throw std::out_of_range(name);
+        *p.value = v;
+        return true;
+      }
+    return false;
+  }
+  bool set_float(const std::string& name, double v)
+  {
+    for (auto& p : floats)
+      if (name == p.name) {
+        if (!(v >= p.lo && v <= p.hi)) throw std::out_of_range(name);
+        *p.value = v;
+        return true;
+      }
+    return false;
+  }
+  bool set_bool(const std::string& name, bool v)
+  {
+    for (auto& p : bools)
+      if (name == p.name) {
+        *p.value = v;
+        return true;
+      }
+    return false;
+  }
+  bool set_string(const std::string& name, const std::string& v)
+  {
+    for (auto& p : strings)
+      if (name == p.name) {
+        *p.value = v;
+        return true;
+      }
+    return false;
+  }
+  // set_parameter_from_string, solver_settings.cu:121-189
+  void set_from_string(const std::string& name, const std::string& value)
+  {
+    bool found = false;
+    for (auto& p : ints)
+      if (name == p.name) {
+        size_t used = 0;
+        long long v = std::stoll(value, &used);  // throws invalid_argument like the reference
+        if (v < p.lo || v > p.hi) throw std::out_of_range(name);
+        *p.value = (int32_t)v;
+        found    = true;
+      }
+    for (auto& p : floats)
+      if (name == p.name) {
+        double v = std::stod(value);
+        if (!(v >= p.lo && v <= p.hi)) throw std::out_of_range(name);
+        *p.value = v;
+        found    = true;
+      }
+    for (auto& p : bools)
+      if (name == p.name) {
+        // string_to_bool, solver_settings.cu:47-60
+        if (value == "true" || value == "True" || value == "TRUE" || value == "1" || value == "t" || value == "T")
+          *p.value = true;
+        else if (value == "false" || value == "False" || value == "FALSE" || value == "0" || value == "f" || value == "F")
+          *p.value = false;
+        else
+          throw std::invalid_argument(name);
+        found = true;
+      }
+    for (auto& p : strings)
+      if (name == p.name) {
+        *p.value = value;
+        found    = true;
+      }
+    if (!found) throw std::invalid_argument("Parameter " + name + " not found");
+  }
+  // get_parameter_as_string, solver_settings.cu:276-292 (std::to_string formats)
+  std::string get_as_string(const std::string& name) const
+  {
+    for (auto& p : ints)
+      if (name == p.name) return std::to_string(*p.value);
+    for (auto& p : floats)
+      if (name == p.name) return std::to_string(*p.value);
+    for (auto& p : bools)
+      if (name == p.name) return *p.value ? "true" : "false";
+    for (auto& p : strings)
+      if (name == p.name) return *p.value;
+    throw std::invalid_argument("Parameter " + name + " not found");
+  }
+};
+
+// ---- solution -----------------------------------------------------------------------------------
+struct Solution {
+  bool is_mip = false;
+  int32_t termination_status = CUOPT_TERIMINATION_STATUS_NO_TERMINATION;
+  int32_t error_status       = CUOPT_SUCCESS;
+  std::string error_message;
+  std::vector<double> x, y, rc;
+  double objective = 0.0, solve_time = 0.0;
+  cuoptamd_result stats{};
+};
+
+// cuopt::logic_error message format, cpp/include/cuopt/error.hpp:110-125
+std::string error_json(const char* type, const std::string& msg)
+{
+  return std::string("{\"CUOPT_ERROR_TYPE\": \"") + type + "\", \"msg\": \"" + msg + "\"}";
+}
+
+// problem_checking_t::check_problem_representation (LP/utilities/problem_checking.cu:100-250)
+std::string validate(const Problem& p)
+{
+  if (p.offsets.empty()) return "A_offsets must be set before calling the solver.";
+  if (p.offsets[0] != 0) return "A_offsets first value should be 0.";
+  for (size_t i = 1; i < p.offsets.size(); ++i)
+    if (p.offsets[i] < p.offsets[i - 1]) return "A_offsets values must in an increasing order.";
+  if (p.indices.size() != p.values.size()) return "A_index and A_values must have same sizes.";
+  for (int32_t j : p.indices)
+    if (j < 0 || j >= p.n) return "A_indices values must positive lower than the number of variables (c size).";
+  for (char t : p.row_types)
+    if (t != 'E' && t != 'G' && t != 'L') return "row_types values must equal to 'E', 'G' or 'L'.";
+  for (int32_t j = 0; j < p.n; ++j)
+    if (std::isnan(p.lb[j]) || std::isnan(p.ub[j])) return "Variable bounds must not be NaN.";
+  return "";
+}
+
+int create_common(Problem* p, cuopt_int_t m, cuopt_int_t n, cuopt_int_t sense, double offset,
+                  const double* c, const cuopt_int_t* off, const cuopt_int_t* idx, const double* val,
+                  const double* lb, const double* ub, const char* types)
+{
+  if (m < 0 || n < 0) return CUOPT_INVALID_ARGUMENT;
+  p->m = m, p->n = n;
+  p->maximize         = sense == CUOPT_MAXIMIZE;
+  p->objective_offset = offset;
+  p->c.assign(c, c + n);
+  p->offsets.assign(off, off + m + 1);
+  const int64_t nnz = off[m];
+  if (nnz < 0) return CUOPT_INVALID_ARGUMENT;
+  p->indices.assign(idx, idx + nnz);
+  p->values.assign(val, val + nnz);
+  p->lb.assign(lb, lb + n);
+  p->ub.assign(ub, ub + n);
+  p->var_types.resize(n);
+  for (int32_t j = 0; j < n; ++j) p->var_types[j] = types[j] == CUOPT_CONTINUOUS ? CUOPT_CONTINUOUS : CUOPT_INTEGER;
+  return CUOPT_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int8_t cuOptGetFloatSize() { return (int8_t)sizeof(cuopt_float_t); }
+int8_t cuOptGetIntSize() { return (int8_t)sizeof(cuopt_int_t); }
+
+cuopt_int_t cuOptReadProblem(const char* filename, cuOptOptimizationProblem* problem_ptr)
+{
+  if (filename == nullptr || problem_ptr == nullptr) return CUOPT_INVALID_ARGUMENT;
+  *problem_ptr = nullptr;
+  try {
+    cuopt_amd::MpsModel mdl = cuopt_amd::read_mps_file(filename);
+    auto p                  = std::make_unique<Problem>();
+    p->m = (int32_t)mdl.row_names.size(), p->n = (int32_t)mdl.var_names.size();
+    p->maximize         = mdl.maximize;
+    p->objective_offset = mdl.objective_offset;
+    p->offsets.assign(mdl.offsets.begin(), mdl.offsets.end());
+    p->indices.assign(mdl.indices.begin(), mdl.indices.end());
+    p->values = std::move(mdl.values), p->c = std::move(mdl.c);
+    p->lb = std::move(mdl.lb), p->ub = std::move(mdl.ub);
+    p->row_types = std::move(mdl.row_types), p->rhs = std::move(mdl.rhs);
+    p->lo = std::move(mdl.lo), p->hi = std::move(mdl.hi);
+    p->var_types = std::move(mdl.var_types);
+    for (char& t : p->var_types) t = t == 'I' ? CUOPT_INTEGER : CUOPT_CONTINUOUS;
+    *problem_ptr = p.release();
+  } catch (const cuopt_amd::MpsError& e) {
+    return e.cannot_open ? CUOPT_MPS_FILE_ERROR : CUOPT_MPS_PARSE_ERROR;  // cuopt_c.cpp:71-79
+  } catch (const std::exception&) {
+    return CUOPT_MPS_PARSE_ERROR;
+  }
+  return CUOPT_SUCCESS;
+}
+
+cuopt_int_t cuOptCreateProblem(cuopt_int_t num_constraints, cuopt_int_t num_variables,
+                               cuopt_int_t objective_sense, cuopt_float_t objective_offset,
+                               const cuopt_float_t* objective_coefficients,
+                               const cuopt_int_t* constraint_matrix_row_offsets,
+                               const cuopt_int_t* constraint_matrix_column_indices,
+                               const cuopt_float_t* constraint_matrix_coefficent_values,
+                               const char* constraint_sense, const cuopt_float_t* rhs,
+                               const cuopt_float_t* lower_bounds, const cuopt_float_t* upper_bounds,
+                               const char* variable_types, cuOptOptimizationProblem* problem_ptr)
+{
+  if (problem_ptr == nullptr || objective_coefficients == nullptr ||
+      constraint_matrix_row_offsets == nullptr || constraint_matrix_column_indices == nullptr ||
+      constraint_matrix_coefficent_values == nullptr || constraint_sense == nullptr || rhs == nullptr ||
+      lower_bounds == nullptr || upper_bounds == nullptr || variable_types == nullptr)
+    return CUOPT_INVALID_ARGUMENT;
+  try {
+    auto p = std::make_unique<Problem>();
+    int rc = create_common(p.get(), num_constraints, num_variables, objective_sense, objective_offset,
+                           objective_coefficients, constraint_matrix_row_offsets,
+                           constraint_matrix_column_indices, constraint_matrix_coefficent_values,
+                           lower_bounds, upper_bounds, variable_types);
+    if (rc != CUOPT_SUCCESS) return rc;
+    p->row_types.assign(constraint_sense, constraint_sense + num_constraints);
+    p->rhs.assign(rhs, rhs + num_constraints);
+    p->lo.resize(num_constraints), p->hi.resize(num_constraints);
+    for (int32_t i = 0; i < num_constraints; ++i) {  // set_constraint_bounds_if_not_set, problem_helpers.cuh:33-58
+      const char t = constraint_sense[i];
+      p->lo[i]     = (t == 'E' || t == 'G') ? rhs[i] : -kInf;
+      p->hi[i]     = (t == 'E' || t == 'L') ? rhs[i] : kInf;
+    }
+    *problem_ptr = p.release();
+  } catch (const std::exception&) {
+    return CUOPT_INVALID_ARGUMENT;
+  }
+  return CUOPT_SUCCESS;
+}
+
+cuopt_int_t cuOptCreateRangedProblem(cuopt_int_t num_constraints, cuopt_int_t num_variables,
+                                     cuopt_int_t objective_sense, cuopt_float_t objective_offset,
+                                     const cuopt_float_t* objective_coefficients,
+                                     const cuopt_int_t* constraint_matrix_row_offsets,
+                                     const cuopt_int_t* constraint_matrix_column_indices,
+                                     const cuopt_float_t* constraint_matrix_coefficients,
+                                     const cuopt_float_t* constraint_lower_bounds,
+                                     const cuopt_float_t* constraint_upper_bounds,
+                                     const cuopt_float_t* variable_lower_bounds,
+                                     const cuopt_float_t* variable_upper_bounds,
+                                     const char* variable_types, cuOptOptimizationProblem* problem_ptr)
+{
+  if (problem_ptr == nullptr || objective_coefficients == nullptr ||
+      constraint_matrix_row_offsets == nullptr || constraint_matrix_column_indices == nullptr ||
+      constraint_matrix_coefficients == nullptr || constraint_lower_bounds == nullptr ||
+      constraint_upper_bounds == nullptr || variable_lower_bounds == nullptr ||
+      variable_upper_bounds == nullptr || variable_types == nullptr)
+    return CUOPT_INVALID_ARGUMENT;
+  try {
+    auto p = std::make_unique<Problem>();
+    int rc = create_common(p.get(), num_constraints, num_variables, objective_sense, objective_offset,
+                           objective_coefficients, constraint_matrix_row_offsets,
+                           constraint_matrix_column_indices, constraint_matrix_coefficients,
+                           variable_lower_bounds, variable_upper_bounds, variable_types);
+    if (rc != CUOPT_SUCCESS) return rc;
+    p->lo.assign(constraint_lower_bounds, constraint_lower_bounds + num_constraints);
+    p->hi.assign(constraint_upper_bounds, constraint_upper_bounds + num_constraints);
+    *problem_ptr = p.release();
+  } catch (const std::exception&) {
+    return CUOPT_INVALID_ARGUMENT;
+  }
+  return CUOPT_SUCCESS;
+}
+
+void cuOptDestroyProblem(cuOptOptimizationProblem* problem_ptr)
+{
+  if (problem_ptr == nullptr || *problem_ptr == nullptr) return;
+  delete static_cast<Problem*>(*problem_ptr);
+  *problem_ptr = nullptr;
+}
+
+#define PROBLEM_GETTER_PROLOGUE(out)                                         \
+  if (problem == nullptr || (out) == nullptr) return CUOPT_INVALID_ARGUMENT; \
+  const Problem* p = static_cast<const Problem*>(problem)
+
+cuopt_int_t cuOptGetNumConstraints(cuOptOptimizationProblem problem, cuopt_int_t* num_constraints_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(num_constraints_ptr);
+  *num_constraints_ptr = p->m;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetNumVariables(cuOptOptimizationProblem problem, cuopt_int_t* num_variables_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(num_variables_ptr);
+  *num_variables_ptr = p->n;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetObjectiveSense(cuOptOptimizationProblem problem, cuopt_int_t* objective_sense_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(objective_sense_ptr);
+  *objective_sense_ptr = p->maximize ? CUOPT_MAXIMIZE : CUOPT_MINIMIZE;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetObjectiveOffset(cuOptOptimizationProblem problem, cuopt_float_t* objective_offset_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(objective_offset_ptr);
+  *objective_offset_ptr = p->objective_offset;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetObjectiveCoefficients(cuOptOptimizationProblem problem, cuopt_float_t* objective_coefficients_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(objective_coefficients_ptr);
+  std::copy(p->c.begin(), p->c.end(), objective_coefficients_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetNumNonZeros(cuOptOptimizationProblem problem, cuopt_int_t* num_non_zeros_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(num_non_zeros_ptr);
+  *num_non_zeros_ptr = (cuopt_int_t)p->values.size();
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetConstraintMatrix(cuOptOptimizationProblem problem,
+                                     cuopt_int_t* constraint_matrix_row_offsets_ptr,
+                                     cuopt_int_t* constraint_matrix_column_indices_ptr,
+                                     cuopt_float_t* constraint_matrix_coefficients_ptr)
+{
+  if (problem == nullptr || constraint_matrix_row_offsets_ptr == nullptr ||
+      constraint_matrix_column_indices_ptr == nullptr || constraint_matrix_coefficients_ptr == nullptr)
+    return CUOPT_INVALID_ARGUMENT;
+  const Problem* p = static_cast<const Problem*>(problem);
+  std::copy(p->offsets.begin(), p->offsets.end(), constraint_matrix_row_offsets_ptr);
+  std::copy(p->indices.begin(), p->indices.end(), constraint_matrix_column_indices_ptr);
+  std::copy(p->values.begin(), p->values.end(), constraint_matrix_coefficients_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetConstraintSense(cuOptOptimizationProblem problem, char* constraint_sense_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(constraint_sense_ptr);
+  std::copy(p->row_types.begin(), p->row_types.end(), constraint_sense_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetConstraintRightHandSide(cuOptOptimizationProblem problem, cuopt_float_t* rhs_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(rhs_ptr);
+  std::copy(p->rhs.begin(), p->rhs.end(), rhs_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetConstraintLowerBounds(cuOptOptimizationProblem problem, cuopt_float_t* lower_bounds_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(lower_bounds_ptr);
+  std::copy(p->lo.begin(), p->lo.end(), lower_bounds_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetConstraintUpperBounds(cuOptOptimizationProblem problem, cuopt_float_t* upper_bounds_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(upper_bounds_ptr);
+  std::copy(p->hi.begin(), p->hi.end(), upper_bounds_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetVariableLowerBounds(cuOptOptimizationProblem problem, cuopt_float_t* lower_bounds_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(lower_bounds_ptr);
+  std::copy(p->lb.begin(), p->lb.end(), lower_bounds_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetVariableUpperBounds(cuOptOptimizationProblem problem, cuopt_float_t* upper_bounds_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(upper_bounds_ptr);
+  std::copy(p->ub.begin(), p->ub.end(), upper_bounds_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetVariableTypes(cuOptOptimizationProblem problem, char* variable_types_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(variable_types_ptr);
+  std::copy(p->var_types.begin(), p->var_types.end(), variable_types_ptr);
+  return CUOPT_SUCCESS;
+}
+
+// ---- settings -------------------------------------------------------------------------------------
+cuopt_int_t cuOptCreateSolverSettings(cuOptSolverSettings* settings_ptr)
+{
+  if (settings_ptr == nullptr) return CUOPT_INVALID_ARGUMENT;
+  *settings_ptr = new (std::nothrow) Settings();
+  return *settings_ptr ? CUOPT_SUCCESS : CUOPT_OUT_OF_MEMORY;
+}
+void cuOptDestroySolverSettings(cuOptSolverSettings* settings_ptr)
+{
+  if (settings_ptr == nullptr) return;
+  delete static_cast<Settings*>(*settings_ptr);
+  *settings_ptr = nullptr;
+}
+cuopt_int_t cuOptSetParameter(cuOptSolverSettings settings, const char* parameter_name, const char* parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr || parameter_value == nullptr) return CUOPT_INVALID_ARGUMENT;
+  try {
+    static_cast<Settings*>(settings)->set_from_string(parameter_name, parameter_value);
+  } catch (const std::exception&) {
+    return CUOPT_INVALID_ARGUMENT;
+  }
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetParameter(cuOptSolverSettings settings, const char* parameter_name,
+                              cuopt_int_t parameter_value_size, char* parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr || parameter_value == nullptr || parameter_value_size <= 0)
+    return CUOPT_INVALID_ARGUMENT;
+  try {
+    std::string v = static_cast<Settings*>(settings)->get_as_string(parameter_name);
+    std::snprintf(parameter_value, (size_t)parameter_value_size, "%s", v.c_str());
+  } catch (const std::exception&) {
+    return CUOPT_INVALID_ARGUMENT;
+  }
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptSetIntegerParameter(cuOptSolverSettings settings, const char* parameter_name, cuopt_int_t parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr) return CUOPT_INVALID_ARGUMENT;
+  Settings* s = static_cast<Settings*>(settings);
+  try {
+    if (s->set_int(parameter_name, parameter_value)) return CUOPT_SUCCESS;
+    // maybe a boolean parameter (cuopt_c.cpp:493-505)
+    if (s->set_bool(parameter_name, parameter_value != 0)) return CUOPT_SUCCESS;
+  } catch (const std::exception&) {
+  }
+  return CUOPT_INVALID_ARGUMENT;
+}
+cuopt_int_t cuOptGetIntegerParameter(cuOptSolverSettings settings, const char* parameter_name, cuopt_int_t* parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr || parameter_value == nullptr) return CUOPT_INVALID_ARGUMENT;
+  const Settings* s = static_cast<const Settings*>(settings);
+  for (auto& p : s->ints)
+    if (std::strcmp(p.name, parameter_name) == 0) {
+      *parameter_value = *p.value;
+      return CUOPT_SUCCESS;
+    }
+  for (auto& p : s->bools)
+    if (std::strcmp(p.name, parameter_name) == 0) {
+      *parameter_value = *p.value ? 1 : 0;
+      return CUOPT_SUCCESS;
+    }
+  return CUOPT_INVALID_ARGUMENT;
+}
+cuopt_int_t cuOptSetFloatParameter(cuOptSolverSettings settings, const char* parameter_name, cuopt_float_t parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr) return CUOPT_INVALID_ARGUMENT;
+  try {
+    if (static_cast<Settings*>(settings)->set_float(parameter_name, parameter_value)) return CUOPT_SUCCESS;
+  } catch (const std::exception&) {
+  }
+  return CUOPT_INVALID_ARGUMENT;
+}
+cuopt_int_t cuOptGetFloatParameter(cuOptSolverSettings settings, const char* parameter_name, cuopt_float_t* parameter_value)
+{
+  if (settings == nullptr || parameter_name == nullptr || parameter_value == nullptr) return CUOPT_INVALID_ARGUMENT;
+  const Settings* s = static_cast<const Settings*>(settings);
+  for (auto& p : s->floats)
+    if (std::strcmp(p.name, parameter_name) == 0) {
+      *parameter_value = *p.value;
+      return CUOPT_SUCCESS;
+    }
+  return CUOPT_INVALID_ARGUMENT;
+}
+
+// ---- solve ----------------------------------------------------------------------------------------
+cuopt_int_t cuOptIsMIP(cuOptOptimizationProblem problem, cuopt_int_t* is_mip_ptr)
+{
+  PROBLEM_GETTER_PROLOGUE(is_mip_ptr);
+  *is_mip_ptr = p->has_integers() ? 1 : 0;
+  return CUOPT_SUCCESS;
+}
+
+cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings settings, cuOptSolution* solution_ptr)
+{
+  if (problem == nullptr || settings == nullptr || solution_ptr == nullptr) return CUOPT_INVALID_ARGUMENT;
+  const Problem* p  = static_cast<const Problem*>(problem);
+  const Settings* s = static_cast<const Settings*>(settings);
+  Solution* sol     = new (std::nothrow) Solution();
+  if (!sol) return CUOPT_OUT_OF_MEMORY;
+  *solution_ptr = sol;
+  auto error    = [&](int code, const char* type, const std::string& msg) {
+    sol->error_status  = code;
+    sol->error_message = error_json(type, msg);
+    return (cuopt_int_t)code;
+  };
+  try {
+    if (p->has_integers()) {
+      sol->is_mip = true;
+      return error(CUOPT_VALIDATION_ERROR, "ValidationError",
+                   "MILP is outside the scope of the MI355X-native PDLP library: only continuous LPs can be solved");
+    }
+    std::string bad = validate(*p);
+    if (!bad.empty()) return error(CUOPT_VALIDATION_ERROR, "ValidationError", bad);
+
+    cuoptamd_hyper hyper;
+    cuoptamd_hyper_preset(s->pdlp_solver_mode, &hyper);
+    cuoptamd_settings st;
+    cuoptamd_default_settings(&st);
+    st.absolute_dual_tolerance = s->tol[0], st.relative_dual_tolerance = s->tol[1];
+    st.absolute_primal_tolerance = s->tol[2], st.relative_primal_tolerance = s->tol[3];
+    st.absolute_gap_tolerance = s->tol[4], st.relative_gap_tolerance = s->tol[5];
+    st.iteration_limit         = s->iteration_limit;
+    st.time_limit              = s->time_limit;
+    st.per_constraint_residual = s->per_constraint_residual;
+    st.first_primal_feasible   = s->first_primal_feasible;
+    cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
+                   p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
+                   p->objective_offset};
+    // CUOPT_METHOD: this library has one engine.  Concurrent (default) and DualSimplex requests are
+    // served by PDLP as well (documented in INTEGRATION.md); the termination semantics are PDLP's.
+    cuoptamd_solver* solver = nullptr;
+    int rc = cuoptamd_solver_create(&solver, &lp, &hyper, &st, nullptr, nullptr, 0, 0, 1, nullptr);
+    if (rc != 0) {
+      std::string msg = cuoptamd_last_error();
+      cuoptamd_solver_destroy(solver);
+      if (rc == -7) return error(CUOPT_VALIDATION_ERROR, "ValidationError", msg);
+      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+    }
+    cuoptamd_result res{};
+    rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+    if (rc != 0) {
+      std::string msg = cuoptamd_last_error();
+      cuoptamd_solver_destroy(solver);
+      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+    }
+    sol->stats              = res;
+    sol->termination_status = res.status;
+    sol->objective          = res.primal_objective;  // solver_solution.cu:307-310
+    sol->solve_time         = res.setup_seconds + res.loop_seconds;
+    sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
+    rc = cuoptamd_solver_get_solution(solver, sol->x.data(), sol->y.data(), sol->rc.data());
+    cuoptamd_solver_destroy(solver);
+    if (rc != 0) return error(CUOPT_RUNTIME_ERROR, "RuntimeError", cuoptamd_last_error());
+    if (s->log_to_console) {
+      std::printf("PDLP status %d  iterations %d  primal obj %.10e  dual obj %.10e  gap %.3e  time %.3fs\n",
+                  res.status, res.steps_taken, res.primal_objective, res.dual_objective, res.gap, sol->solve_time);
+    }
+  } catch (const std::bad_alloc&) {
+    return error(CUOPT_OUT_OF_MEMORY, "OutOfMemoryError", "out of host memory");
+  } catch (const std::exception& e) {
+    return error(CUOPT_RUNTIME_ERROR, "RuntimeError", e.what());
+  }
+  return CUOPT_SUCCESS;
+}
+
+void cuOptDestroySolution(cuOptSolution* solution_ptr)
+{
+  if (solution_ptr == nullptr || *solution_ptr == nullptr) return;
+  delete static_cast<Solution*>(*solution_ptr);
+  *solution_ptr = nullptr;
+}
+
+#define SOLUTION_GETTER_PROLOGUE(out)                                         \
+  if (solution == nullptr || (out) == nullptr) return CUOPT_INVALID_ARGUMENT; \
+  const Solution* sol = static_cast<const Solution*>(solution)
+
+cuopt_int_t cuOptGetTerminationStatus(cuOptSolution solution, cuopt_int_t* termination_status_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(termination_status_ptr);
+  *termination_status_ptr = sol->termination_status;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetErrorStatus(cuOptSolution solution, cuopt_int_t* error_status_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(error_status_ptr);
+  *error_status_ptr = sol->error_status;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetErrorString(cuOptSolution solution, char* error_string_ptr, cuopt_int_t error_string_size)
+{
+  SOLUTION_GETTER_PROLOGUE(error_string_ptr);
+  if (error_string_size <= 0) return CUOPT_INVALID_ARGUMENT;
+  std::snprintf(error_string_ptr, (size_t)error_string_size, "%s", sol->error_message.c_str());
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetPrimalSolution(cuOptSolution solution, cuopt_float_t* solution_values)
+{
+  SOLUTION_GETTER_PROLOGUE(solution_values);
+  std::copy(sol->x.begin(), sol->x.end(), solution_values);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetObjectiveValue(cuOptSolution solution, cuopt_float_t* objective_value_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(objective_value_ptr);
+  *objective_value_ptr = sol->objective;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetSolveTime(cuOptSolution solution, cuopt_float_t* solve_time_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(solve_time_ptr);
+  *solve_time_ptr = sol->solve_time;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetMIPGap(cuOptSolution solution, cuopt_float_t* mip_gap_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(mip_gap_ptr);
+  if (!sol->is_mip) return CUOPT_INVALID_ARGUMENT;
+  *mip_gap_ptr = kInf;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetSolutionBound(cuOptSolution solution, cuopt_float_t* solution_bound_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(solution_bound_ptr);
+  if (!sol->is_mip) return CUOPT_INVALID_ARGUMENT;
+  *solution_bound_ptr = -kInf;
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetDualSolution(cuOptSolution solution, cuopt_float_t* dual_solution_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(dual_solution_ptr);
+  if (sol->is_mip) return CUOPT_INVALID_ARGUMENT;
+  std::copy(sol->y.begin(), sol->y.end(), dual_solution_ptr);
+  return CUOPT_SUCCESS;
+}
+cuopt_int_t cuOptGetReducedCosts(cuOptSolution solution, cuopt_float_t* reduced_cost_ptr)
+{
+  SOLUTION_GETTER_PROLOGUE(reduced_cost_ptr);
+  if (sol->is_mip) return CUOPT_INVALID_ARGUMENT;
+  std::copy(sol->rc.begin(), sol->rc.end(), reduced_cost_ptr);
+  return CUOPT_SUCCESS;
+}
+
+// Not part of the reference ABI: full PDLP statistics of a solution (additional_termination_information_t
+// is only reachable through the C++/Python API in the reference).  Used by tests and benches.
+cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats)
+{
+  SOLUTION_GETTER_PROLOGUE(stats);
+  *stats = sol->stats;
+  return CUOPT_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// gfx950 device code of the PDLP hot path: wave64 reductions, the LDS-staged CSR "stream" SpMV
+// skeleton and its fused epilogues.  Included only by pdlp_device.hip.
+//
+// Rounding contract (shared with oracle/pdlp_oracle.c so that element-wise results and short-row
+// SpMV sums are bit-identical): compiled with -ffp-contract=off (no FMA contraction); a row sum is
+// accumulated left-to-right in CSR order starting from 0.0 whenever the row has at most
+// LONG_ROW nonzeros; longer rows and all dot-product style reductions use a fixed (launch-geometry
+// determined, run-to-run reproducible) tree and are compared with a tolerance.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cuopt_amd/pdlp_device.h"
+
+namespace pdlp {
+
+constexpr int kBlock    = 256;   // threads per workgroup = 4 wave64
+constexpr int kNnzBlock = 2048;  // nonzeros staged in LDS per workgroup (16 KiB of products)
+constexpr int kLongRow  = 128;   // rows above this are reduced cooperatively, not by one lane
+constexpr int kMaxRowsPerBlock = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// wave64 / workgroup reductions.  Intra-32 butterflies use ds_swizzle (bit-mask mode: no LDS
+// memory traffic, no address VGPR); the 32<->32 exchange is one ds_bpermute.
+// ------------------------------------------------------------------------------------------------
+template <int XOR_MASK>
+__device__ __forceinline__ double swizzle_xor(double v)
+{
+  static_assert(XOR_MASK >= 1 && XOR_MASK <= 16, "ds_swizzle works inside 32 lanes");
+  constexpr int pattern = (XOR_MASK << 10) | 0x1F;  // and=0x1f, or=0, xor=XOR_MASK
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, pattern);
+  hi = __builtin_amdgcn_ds_swizzle(hi, pattern);
+  return __hiloint2double(hi, lo);
+}
+
+struct SumOp {
+  static __device__ __forceinline__ double identity() { return 0.0; }
+  static __device__ __forceinline__ double apply(double a, double b) { return a + b; }
+};
+struct MaxOp {
+  static __device__ __forceinline__ double identity() { return 0.0; }  // all our maxima are >= 0
+  static __device__ __forceinline__ double apply(double a, double b) { return a > b ? a : b; }
+};
+
+// every lane ends with the reduction over the 64 lanes; the combination tree is fixed
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v)
+{
+  v = Op::apply(v, swizzle_xor<1>(v));
+  v = Op::apply(v, swizzle_xor<2>(v));
+  v = Op::apply(v, swizzle_xor<4>(v));
+  v = Op::apply(v, swizzle_xor<8>(v));
+  v = Op::apply(v, swizzle_xor<16>(v));
+  v = Op::apply(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// result valid in thread 0 (and broadcast through `scratch[0..NQ)` after the trailing barrier)
+template <class Op, int NQ>
+__device__ __forceinline__ void block_reduce(double (&v)[NQ], double* scratch /* >= 4*NQ */)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v[q] = wave_reduce<Op>(v[q]);
+    if (lane == 0) scratch[wave * NQ + q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double acc = scratch[q];
+      for (int w = 1; w < kBlock / 64; ++w) acc = Op::apply(acc, scratch[w * NQ + q]);
+      v[q] = acc;
+    }
+  }
+}
+
+__device__ __forceinline__ bool loop_active(const pdlpdev_ctl* ctl)
+{
+  return ctl->error == 0 && ctl->steps_taken < ctl->target_steps;
+}
+
+// block b executes on XCD (b % 8) (observed dispatch order, speed only): give each XCD one
+// contiguous range of row blocks so that neighbouring rows -- which in real LPs touch neighbouring
+// columns -- share that XCD's private 4 MiB L2 for the gathered vector.
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+  const int per = (nb + 7) >> 3;
+  const int v   = (b & 7) * per + (b >> 3);
+  return v;  // may be >= nb for the ragged tail: caller skips
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR "stream" SpMV skeleton.  One workgroup owns the contiguous row range
+// [row_blocks[b], row_blocks[b+1]) whose nonzeros (<= kNnzBlock unless it is a single long row)
+// are loaded fully coalesced (lane i <-> nonzero k0+i), multiplied by the gathered vector entry
+// and parked in LDS; then lane r adds up row r's products in CSR order and hands (row, sum) to the
+// epilogue.  Epilogue concept:
+//   struct E { static constexpr int NQ; using Op; __device__ void row(int r, double sum, double (&acc)[NQ]); }
+// After the rows, acc[] is reduced over the workgroup and written to partials[q * nb + b].
+// ------------------------------------------------------------------------------------------------
+template <class Epi>
+__device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restrict__ row_blocks,
+                                                 const int32_t* __restrict__ offsets,
+                                                 const int32_t* __restrict__ indices,
+                                                 const double* __restrict__ values,
+                                                 const double* __restrict__ vec, Epi& epi,
+                                                 double* __restrict__ partials)
+{
+  __shared__ double prod[kNnzBlock];
+  __shared__ double red[4 * (Epi::NQ > 0 ? Epi::NQ : 1) + 4];
+  const int b = xcd_remap(blockIdx.x, nb);
+  if (b >= nb) return;
+  const int r0 = row_blocks[b], r1 = row_blocks[b + 1];
+  const int k0 = offsets[r0], k1 = offsets[r1];
+  const int cnt = k1 - k0;
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+
+  if (cnt <= kNnzBlock) {
+    for (int k = threadIdx.x; k < cnt; k += kBlock) {
+      const double a = __builtin_nontemporal_load(values + k0 + k);
+      const int j    = __builtin_nontemporal_load(indices + k0 + k);
+      prod[k]        = a * vec[j];
+    }
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += kBlock) {
+      const int s = offsets[r] - k0, e = offsets[r + 1] - k0;
+      double sum = 0.0;
+      if (e - s <= kLongRow) {
+        for (int k = s; k < e; ++k) sum = sum + prod[k];
+      } else {  // 4 interleaved chains: a medium-long row must not serialise the workgroup
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = s;
+        for (; k + 3 < e; k += 4) {
+          s0 += prod[k], s1 += prod[k + 1], s2 += prod[k + 2], s3 += prod[k + 3];
+        }
+        for (; k < e; ++k) s0 += prod[k];
+        sum = (s0 + s1) + (s2 + s3);
+      }
+      epi.row(r, sum, acc);
+    }
+  } else {
+    // a single row longer than the LDS tile: strided partial sums + workgroup tree
+    double part[1] = {0.0};
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+      const double a = __builtin_nontemporal_load(values + k);
+      const int j    = __builtin_nontemporal_load(indices + k);
+      part[0] += a * vec[j];
+    }
+    block_reduce<SumOp, 1>(part, red);
+    if (threadIdx.x == 0) epi.row(r0, part[0], acc);
+    __syncthreads();
+  }
+  if constexpr (Epi::NQ > 0) {
+    block_reduce<typename Epi::Op, Epi::NQ>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * nb + b] = acc[q];
+    }
+  }
+}
+
+// ---- element-wise rules of the reference (LP/utils.cuh) -----------------------------------------
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ bool dfinite(double v) { return fabs(v) <= 1.7976931348623157e308; }
+// combine_finite_abs_bounds, utils.cuh:139-148
+__device__ __forceinline__ double combine_bounds(double lower, double upper)
+{
+  double val = 0.0;
+  if (dfinite(upper)) val = dmax(val, fabs(upper));
+  if (dfinite(lower)) val = dmax(val, fabs(lower));
+  return val;
+}
+// violation, utils.cuh:165-178
+__device__ __forceinline__ double violation(double value, double lower, double upper)
+{
+  if (value < lower) return lower - value;
+  if (value > upper) return value - upper;
+  return 0.0;
+}
+// bound_value_reduced_cost_product, utils.cuh:204-219
+__device__ __forceinline__ double bound_value_product(double value, double lower, double upper)
+{
+  double bound = 0.0;
+  if (value > 0.0)
+    bound = lower;
+  else if (value < 0.0)
+    bound = upper;
+  return dfinite(bound) ? value * bound : 0.0;
+}
+
+}  // namespace pdlp

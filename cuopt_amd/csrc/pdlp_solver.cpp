@@ -1,0 +1,615 @@
+// C++ host driver of the MI355X-native PDLP solver.  No HIP header is included here: the GPU is
+// reached only through the thin C-ABI of include/cuopt_amd/pdlp_device.h.
+//
+// What lives here is the part of cuOpt's PDLP that is inherently scalar/host logic
+// (reference: cuOpt 25.08, LP/ = cpp/src/linear_programming/):
+//   - problem conversion (maximise -> minimise, explicit transpose)      mip/problem/problem.cu:53-93
+//   - the outer loop and its major-iteration schedule                     LP/pdlp.cu:1081-1185
+//   - termination verdicts and limits                                     LP/pdlp.cu:537-802,
+//                                                                         LP/termination_strategy/termination_strategy.cu:116-250
+//   - KKT restart decision + primal weight update                         LP/restart_strategy/pdlp_restart_strategy.cu:366-641,684-750
+// The reference keeps these in 1x1 device kernels + blocking D2H reads; here they are plain C++
+// working on the handful of scalars the fused device passes return, and -- unlike the reference --
+// the PDHG step loop between two major iterations runs without any host round trip.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "cuopt_amd/pdlp_solver.h"
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+#define DEV(expr)                                                          \
+  do {                                                                     \
+    int rc_ = (expr);                                                      \
+    if (rc_ != 0) return fail(rc_, "%s: %s", #expr, pdlpdev_last_error()); \
+  } while (0)
+
+using clock_type = std::chrono::steady_clock;
+double seconds_since(clock_type::time_point t0)
+{
+  return std::chrono::duration<double>(clock_type::now() - t0).count();
+}
+
+// status codes == CUOPT_TERIMINATION_STATUS_* (constants.h:65-74)
+enum : int {
+  kNoTermination  = 0,
+  kOptimal        = 1,
+  kIterationLimit = 4,
+  kTimeLimit      = 5,
+  kNumericalError = 6,
+  kPrimalFeasible = 7,
+};
+
+// convergence information of one iterate (convergence_information_t)
+struct Convergence {
+  double primal_objective = 0, dual_objective = 0, gap = 0, abs_objective = 0;
+  double l2_primal_residual = 0, l2_dual_residual = 0, l2_x = 0, l2_y = 0;
+  double linf_rel_primal_residual = 0, linf_rel_dual_residual = 0;
+};
+
+}  // namespace
+
+struct cuoptamd_solver {
+  pdlpdev_ctx* dev = nullptr;
+  cuoptamd_hyper H{};
+  cuoptamd_settings S{};
+  int32_t m_global = 0, n = 0, row_begin = 0, row_end = 0;
+  int rank = 0, world = 1;
+  bool empty_problem = false;  // n_constraints == 0 -> NumericalError (LP/solve.cu:355-359)
+  double objective_scale = 1.0, objective_offset = 0.0;
+  double norm_b = 0.0, norm_c = 0.0;
+  // loop state
+  int32_t total_iterations = 0;  // total_pdlp_iterations_ == internal_solver_iterations_ here
+  int32_t major_done_at    = -1;
+  bool step_error = false, need_aty = true, last_restart_was_average = false;
+  double last_candidate_kkt = 0.0, last_restart_kkt = 0.0;
+  pdlpdev_ctl ctl{};
+  Convergence conv_current, conv_average;
+  int returned_which = PDLPDEV_CURRENT;
+  bool finished = false;
+  cuoptamd_result result{};
+  clock_type::time_point solve_start;
+  bool started = false;
+};
+
+namespace {
+
+// ---- presets: LP/solve.cu:64-199 (defaults = Stable2, LP/pdlp_hyper_params.cu:22-80) ----------
+void preset_stable2(cuoptamd_hyper& h)
+{
+  h.initial_step_size_scaling                                  = 1.0;
+  h.ruiz_iterations                                            = 10;
+  h.do_pock_chambolle                                          = 1;
+  h.do_ruiz                                                    = 1;
+  h.alpha_pock_chambolle                                       = 1.0;
+  h.artificial_restart_threshold                               = 0.36;
+  h.compute_initial_step_size_before_scaling                   = 0;
+  h.compute_initial_primal_weight_before_scaling               = 0;
+  h.initial_primal_weight_c_scaling                            = 1.0;
+  h.initial_primal_weight_b_scaling                            = 1.0;
+  h.major_iteration                                            = 40;
+  h.min_iteration_restart                                      = 10;
+  h.restart_strategy                                           = 1;
+  h.never_restart_to_average                                   = 0;
+  h.reduction_exponent                                         = 0.3;
+  h.growth_exponent                                            = 0.6;
+  h.primal_weight_update_smoothing                             = 0.5;
+  h.sufficient_reduction_for_restart                           = 0.2;
+  h.necessary_reduction_for_restart                            = 0.8;
+  h.primal_importance                                          = 1.0;
+  h.primal_distance_smoothing                                  = 0.5;
+  h.dual_distance_smoothing                                    = 0.5;
+  h.compute_last_restart_before_new_primal_weight              = 1;
+  h.artificial_restart_in_main_loop                            = 0;
+  h.rescale_for_restart                                        = 1;
+  h.update_primal_weight_on_initial_solution                   = 0;
+  h.update_step_size_on_initial_solution                       = 0;
+  h.handle_some_primal_gradients_on_finite_bounds_as_residuals = 0;
+  h.project_initial_primal                                     = 1;
+}
+
+Convergence to_convergence(const cuoptamd_solver* s, const double* ev)
+{
+  Convergence c;
+  double pobj = ev[PDLPDEV_EV_CX], dobj = ev[PDLPDEV_EV_DUAL_SUM];
+  // compute_primal_objective / compute_dual_objective: scale and offset applied only when they are
+  // not the identity (convergence_information.cu:261-284, 401-422)
+  if (s->objective_scale != 1.0 || s->objective_offset != 0.0) {
+    pobj = s->objective_scale * pobj + s->objective_offset;
+    dobj = s->objective_scale * dobj + s->objective_offset;
+  }
+  c.primal_objective         = pobj;
+  c.dual_objective           = dobj;
+  c.gap                      = std::fabs(pobj - dobj);
+  c.abs_objective            = std::fabs(pobj) + std::fabs(dobj);
+  c.l2_primal_residual       = std::sqrt(ev[PDLPDEV_EV_PRES2]);
+  c.l2_dual_residual         = std::sqrt(ev[PDLPDEV_EV_DRES2]);
+  c.l2_x                     = std::sqrt(ev[PDLPDEV_EV_X2]);
+  c.l2_y                     = std::sqrt(ev[PDLPDEV_EV_Y2]);
+  c.linf_rel_primal_residual = ev[PDLPDEV_EV_LINF_PRES_REL];
+  c.linf_rel_dual_residual   = ev[PDLPDEV_EV_LINF_DRES_REL];
+  return c;
+}
+
+// check_termination_criteria_kernel (termination_strategy.cu:116-250): Optimal, PrimalFeasible, or
+// "keep going" (which the reference encodes as NumericalError)
+int verdict(const cuoptamd_solver* s, const Convergence& c)
+{
+  const cuoptamd_settings& t = s->S;
+  const bool gap_ok = c.gap <= t.absolute_gap_tolerance + t.relative_gap_tolerance * c.abs_objective;
+  bool primal_ok, dual_ok;
+  if (t.per_constraint_residual) {
+    primal_ok = c.linf_rel_primal_residual <= t.absolute_primal_tolerance;
+    dual_ok   = c.linf_rel_dual_residual <= t.absolute_dual_tolerance;
+  } else {
+    primal_ok = c.l2_primal_residual <= t.absolute_primal_tolerance + t.relative_primal_tolerance * s->norm_b;
+    dual_ok   = c.l2_dual_residual <= t.absolute_dual_tolerance + t.relative_dual_tolerance * s->norm_c;
+  }
+  if (dual_ok && primal_ok && gap_ok) return kOptimal;
+  if (primal_ok) return kPrimalFeasible;
+  return kNumericalError;
+}
+
+// kernel_compute_kkt_score (pdlp_restart_strategy.cu:366-390)
+double kkt_score(const Convergence& c, double w)
+{
+  const double w2 = w * w;
+  return std::sqrt(w2 * c.l2_primal_residual * c.l2_primal_residual +
+                   c.l2_dual_residual * c.l2_dual_residual / w2 + c.gap * c.gap);
+}
+
+void fill_result(cuoptamd_solver* s, int status, int which)
+{
+  const Convergence& c     = which == PDLPDEV_AVERAGE ? s->conv_average : s->conv_current;
+  cuoptamd_result& r       = s->result;
+  r.status                 = status;
+  r.returned_average       = which == PDLPDEV_AVERAGE;
+  r.steps_taken            = s->ctl.steps_taken;
+  r.attempted_steps        = s->ctl.attempts;
+  r.primal_objective       = c.primal_objective;
+  r.dual_objective         = c.dual_objective;
+  r.gap                    = c.gap;
+  r.relative_gap           = c.gap / (1.0 + c.abs_objective);  // convergence_information.cu:474-492
+  r.l2_primal_residual     = c.l2_primal_residual;
+  r.l2_dual_residual       = c.l2_dual_residual;
+  r.l2_relative_primal_residual = c.l2_primal_residual / (1.0 + s->norm_b);
+  r.l2_relative_dual_residual   = c.l2_dual_residual / (1.0 + s->norm_c);
+  r.step_size              = s->ctl.step_size;
+  r.primal_weight          = s->ctl.primal_weight;
+  s->returned_which        = which;
+}
+
+// One major iteration: averages, the two convergence evaluations, termination, limits, restart.
+// Sets *terminated when a solution must be returned.
+int major_iteration(cuoptamd_solver* s, bool* terminated)
+{
+  const cuoptamd_hyper& H = s->H;
+  pdlpdev_ctx* dev        = s->dev;
+  *terminated             = false;
+  s->result.num_major_iterations += 1;
+  DEV(pdlpdev_flush_average(dev));
+  // pdlp.cu:1110-1122: with 0 or 1 steps the average IS the iterate (avoids a*x/x != x);
+  // right after a restart the sums are empty and the reference yields zeros.
+  int mode = 2;
+  if (s->total_iterations <= 1)
+    mode = 0;
+  else if (s->ctl.its_since_restart == 0)
+    mode = 1;
+  DEV(pdlpdev_make_average(dev, mode));
+  const int rule_finite = H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
+  double ev[PDLPDEV_EV_COUNT];
+  DEV(pdlpdev_eval(dev, PDLPDEV_CURRENT, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
+  s->conv_current = to_convergence(s, ev);
+  DEV(pdlpdev_eval(dev, PDLPDEV_AVERAGE, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
+  s->conv_average = to_convergence(s, ev);
+  const int t_cur = verdict(s, s->conv_current), t_avg = verdict(s, s->conv_average);
+  const double w  = s->ctl.primal_weight;
+
+  // ---- check_termination (pdlp.cu:537-802) ----
+  bool done = false;
+  int status = kNumericalError, which = PDLPDEV_CURRENT;
+  if (s->total_iterations > 1) {  // :580-583: only limits during the first two iterations
+    if (s->S.first_primal_feasible) {  // :587-633
+      if (t_avg == kPrimalFeasible && t_cur == kPrimalFeasible) {
+        done = true, status = kPrimalFeasible;
+        which = s->conv_current.l2_primal_residual < s->conv_average.l2_primal_residual ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE;
+      } else if (t_cur == kPrimalFeasible) {
+        done = true, status = kPrimalFeasible, which = PDLPDEV_CURRENT;
+      } else if (t_avg == kPrimalFeasible) {
+        done = true, status = kPrimalFeasible, which = PDLPDEV_AVERAGE;
+      }
+    }
+    if (!done && t_avg == kOptimal && t_cur == kOptimal) {  // :636-682, ties -> average
+      done = true, status = kOptimal;
+      which = kkt_score(s->conv_current, w) < kkt_score(s->conv_average, w) ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE;
+    }
+    if (!done && t_avg == kOptimal) done = true, status = kOptimal, which = PDLPDEV_AVERAGE;   // :685-700
+    if (!done && t_cur == kOptimal) done = true, status = kOptimal, which = PDLPDEV_CURRENT;   // :701-716
+    if (!done && s->step_error) {  // :780-789: numerical error, empty solution
+      fill_result(s, kNumericalError, PDLPDEV_CURRENT);
+      *terminated = true;
+      return 0;
+    }
+  }
+  if (!done) {  // check_limits, pdlp.cu:264-331 (time first, then iterations)
+    const double tl = s->S.time_limit;
+    if (std::isfinite(tl) && seconds_since(s->solve_start) * 1000.0 >= tl * 1000.0)
+      done = true, status = kTimeLimit, which = PDLPDEV_CURRENT;
+    else if (s->total_iterations >= s->S.iteration_limit)
+      done = true, status = kIterationLimit, which = PDLPDEV_CURRENT;
+  }
+  if (done) {
+    fill_result(s, status, which);
+    *terminated = true;
+    return 0;
+  }
+
+  // ---- run_kkt_restart (pdlp_restart_strategy.cu:467-641) ----
+  if (H.restart_strategy == 1) {
+    const double cur_score = kkt_score(s->conv_current, w);
+    if (s->ctl.its_since_restart == 0) {  // :507-514
+      s->last_candidate_kkt = cur_score;
+      s->last_restart_kkt   = cur_score;
+    } else {
+      const double avg_score = kkt_score(s->conv_average, w);
+      const bool to_average  = !(cur_score < avg_score);  // ties go to the average, :524-530
+      const double candidate = to_average ? avg_score : cur_score;
+      // kkt_restart_conditions :431-437 = artificial (:939-961) || kkt_decay (:407-429)
+      bool restart = s->ctl.its_since_restart >= H.artificial_restart_threshold * s->total_iterations;
+      if (!restart) {
+        if (candidate < H.sufficient_reduction_for_restart * s->last_restart_kkt)
+          restart = true;
+        else if (candidate < H.necessary_reduction_for_restart * s->last_restart_kkt && candidate > s->last_candidate_kkt)
+          restart = true;
+      }
+      if (restart) {
+        s->result.num_restarts += 1;
+        const bool really_average = to_average && !H.never_restart_to_average;
+        double dist2[2];
+        DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, dist2));
+        s->last_restart_was_average = really_average;
+        if (really_average) s->need_aty = true;  // pdhg.cu:183-184
+        s->ctl.its_since_restart = 0;
+        s->ctl.sum_weights       = 0.0;
+        // compute_new_primal_weight (:684-750), safe guard pdlp_constants.hpp:34-35
+        const double pd = std::sqrt(dist2[0]), dd = std::sqrt(dist2[1]);
+        const double guard = 1.0e-10;
+        if (!(pd < guard || pd >= 1.0 / guard || dd < guard || dd >= 1.0 / guard)) {
+          const double theta = H.primal_weight_update_smoothing;
+          const double nw    = std::exp(theta * std::log(dd / pd) + (1.0 - theta) * std::log(w));
+          DEV(pdlpdev_set_step(dev, -1.0, nw));
+          s->ctl.primal_weight = nw;
+        }
+        s->last_restart_kkt = candidate;
+      }
+      s->last_candidate_kkt = candidate;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cuoptamd_last_error(void) { return g_error.c_str(); }
+
+void cuoptamd_hyper_preset(int mode, cuoptamd_hyper* h)
+{
+  preset_stable2(*h);
+  if (mode == 0) {  // Stable1, LP/solve.cu:66-96
+    h->initial_step_size_scaling                                  = 1.6;
+    h->ruiz_iterations                                            = 1;
+    h->alpha_pock_chambolle                                       = 1.3;
+    h->artificial_restart_threshold                               = 0.5;
+    h->compute_initial_primal_weight_before_scaling               = 1;
+    h->initial_primal_weight_c_scaling                            = 2.2;
+    h->initial_primal_weight_b_scaling                            = 4.6;
+    h->major_iteration                                            = 52;
+    h->min_iteration_restart                                      = 0;
+    h->reduction_exponent                                         = 0.5;
+    h->growth_exponent                                            = 0.9;
+    h->primal_weight_update_smoothing                             = 0.3;
+    h->necessary_reduction_for_restart                            = 0.5;
+    h->primal_importance                                          = 1.8;
+    h->primal_distance_smoothing                                  = 0.6;
+    h->dual_distance_smoothing                                    = 0.2;
+    h->compute_last_restart_before_new_primal_weight              = 0;
+    h->rescale_for_restart                                        = 0;
+    h->handle_some_primal_gradients_on_finite_bounds_as_residuals = 1;
+    h->project_initial_primal                                     = 0;
+  } else if (mode == 2) {  // Methodical1, LP/solve.cu:133-163
+    h->ruiz_iterations                                            = 5;
+    h->artificial_restart_threshold                               = 0.5;
+    h->major_iteration                                            = 64;
+    h->min_iteration_restart                                      = 0;
+    h->restart_strategy                                           = 2;
+    h->sufficient_reduction_for_restart                           = 0.1;
+    h->necessary_reduction_for_restart                            = 0.9;
+    h->rescale_for_restart                                        = 0;
+    h->handle_some_primal_gradients_on_finite_bounds_as_residuals = 1;
+    h->project_initial_primal                                     = 0;
+  } else if (mode == 3) {  // Fast1, LP/solve.cu:167-197
+    h->initial_step_size_scaling                                  = 0.8;
+    h->ruiz_iterations                                            = 6;
+    h->do_ruiz                                                    = 0;
+    h->alpha_pock_chambolle                                       = 2.0;
+    h->artificial_restart_threshold                               = 0.3;
+    h->compute_initial_primal_weight_before_scaling               = 1;
+    h->initial_primal_weight_c_scaling                            = 1.2;
+    h->initial_primal_weight_b_scaling                            = 1.2;
+    h->major_iteration                                            = 76;
+    h->min_iteration_restart                                      = 6;
+    h->never_restart_to_average                                   = 1;
+    h->reduction_exponent                                         = 0.4;
+    h->sufficient_reduction_for_restart                           = 0.3;
+    h->necessary_reduction_for_restart                            = 0.9;
+    h->primal_importance                                          = 0.8;
+    h->primal_distance_smoothing                                  = 0.8;
+    h->dual_distance_smoothing                                    = 0.3;
+    h->artificial_restart_in_main_loop                            = 1;
+    h->handle_some_primal_gradients_on_finite_bounds_as_residuals = 1;
+    h->project_initial_primal                                     = 0;
+  }
+}
+
+void cuoptamd_default_settings(cuoptamd_settings* s)
+{
+  // tolerances_t, pdlp/solver_settings.hpp:179-188
+  s->absolute_gap_tolerance = s->relative_gap_tolerance = 1e-4;
+  s->absolute_primal_tolerance = s->relative_primal_tolerance = 1e-4;
+  s->absolute_dual_tolerance = s->relative_dual_tolerance = 1e-4;
+  s->iteration_limit         = std::numeric_limits<int32_t>::max();
+  s->time_limit              = std::numeric_limits<double>::infinity();
+  s->per_constraint_residual = 0;
+  s->first_primal_feasible   = 0;
+  s->initial_step_size       = -1.0;
+  s->initial_primal_weight   = -1.0;
+  s->initial_k               = -1;
+  s->use_graph               = 1;
+}
+
+void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
+                            const double* values, int32_t* t_offsets, int32_t* t_indices,
+                            double* t_values)
+{
+  // counting sort by column; scanning rows in order keeps the row indices ascending inside every
+  // column, which is what cusparseCsr2cscEx2 produces for the reference (problem.cu:277-309)
+  std::fill(t_offsets, t_offsets + n + 1, 0);
+  const int64_t nnz = offsets[m];
+  for (int64_t k = 0; k < nnz; ++k) t_offsets[indices[k] + 1] += 1;
+  for (int32_t j = 0; j < n; ++j) t_offsets[j + 1] += t_offsets[j];
+  std::vector<int32_t> cursor(t_offsets, t_offsets + n);
+  for (int32_t i = 0; i < m; ++i)
+    for (int32_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+      const int32_t p = cursor[indices[k]]++;
+      t_indices[p]    = i;
+      t_values[p]     = values[k];
+    }
+}
+
+void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32_t* bounds)
+{
+  // contiguous blocks, boundary g at the first row whose prefix nnz reaches g/world of the total
+  const int64_t nnz = offsets[m];
+  bounds[0] = 0;
+  for (int g = 1; g < world; ++g) {
+    const int64_t want = (nnz * g) / world;
+    const int32_t* it  = std::lower_bound(offsets, offsets + m + 1, (int32_t)want);
+    int32_t row        = (int32_t)(it - offsets);
+    row                = std::max(row, bounds[g - 1]);
+    bounds[g]          = std::min(row, m);
+  }
+  bounds[world] = m;
+}
+
+int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const cuoptamd_hyper* hyper,
+                           const cuoptamd_settings* settings, const double* init_x,
+                           const double* init_y, int device, int rank, int world,
+                           const uint8_t* comm_id)
+{
+  if (!out || !lp || !hyper || !settings) return fail(-1, "cuoptamd_solver_create: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(-1, "cuoptamd_solver_create: bad rank/world");
+  if (hyper->restart_strategy == 2)
+    return fail(-7, "trust-region restart (pdlp_solver_mode Methodical1) is not implemented");
+  const auto t0 = clock_type::now();
+  cuoptamd_solver* s = new cuoptamd_solver();
+  *out               = s;
+  s->H = *hyper, s->S = *settings;
+  s->m_global = lp->m, s->n = lp->n, s->rank = rank, s->world = world;
+  s->objective_offset = lp->objective_offset;
+  const int32_t m = lp->m, n = lp->n;
+  if (m == 0) {  // run_pdlp_solver: no constraints -> NumericalError (LP/solve.cu:355-359)
+    s->empty_problem = true;
+    return 0;
+  }
+  // maximise -> minimise (problem_helpers.cuh:126-141)
+  std::vector<double> c(lp->c, lp->c + n);
+  if (lp->maximize) {
+    for (double& v : c) v = -v;
+    s->objective_scale = -1.0;
+  }
+  // this rank's row block
+  std::vector<int32_t> bounds(world + 1);
+  cuoptamd_partition_rows(m, lp->offsets, world, bounds.data());
+  s->row_begin = bounds[rank], s->row_end = bounds[rank + 1];
+  const int32_t ml = s->row_end - s->row_begin;
+  const int32_t k0 = lp->offsets[s->row_begin];
+  std::vector<int32_t> off(ml + 1);
+  for (int32_t i = 0; i <= ml; ++i) off[i] = lp->offsets[s->row_begin + i] - k0;
+  const int64_t nnz_l = off[ml];
+  const int32_t* idx  = lp->indices + k0;
+  const double* val   = lp->values + k0;
+  std::vector<int32_t> t_off(n + 1), t_idx(std::max<int64_t>(nnz_l, 1));
+  std::vector<double> t_val(std::max<int64_t>(nnz_l, 1));
+  cuoptamd_csr_transpose(ml, n, off.data(), idx, val, t_off.data(), t_idx.data(), t_val.data());
+  DEV(pdlpdev_create(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.data(),
+                     t_val.data(), c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin, lp->lb, lp->ub));
+  if (comm_id) DEV(pdlpdev_comm_init(s->dev, rank, world, comm_id));
+  else if (world > 1) return fail(-1, "cuoptamd_solver_create: world > 1 needs a communicator id");
+  DEV(pdlpdev_set_graph_mode(s->dev, settings->use_graph));
+  DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
+  pdlpdev_step_params sp{hyper->reduction_exponent, hyper->growth_exponent,
+                         hyper->primal_distance_smoothing, hyper->dual_distance_smoothing};
+  DEV(pdlpdev_set_step_params(s->dev, &sp));
+
+  // ---- [init] block of run_solver (pdlp.cu:984-1075) ----
+  double step = hyper->initial_step_size_scaling, weight = hyper->primal_importance;
+  auto initial_step_size = [&]() -> int {  // pdlp.cu:1224-1258 (x / 0 -> 0)
+    double nr[3];
+    DEV(pdlpdev_init_norms(s->dev, nr));
+    step = nr[0] == 0.0 ? 0.0 : hyper->initial_step_size_scaling / nr[0];
+    return 0;
+  };
+  auto initial_primal_weight = [&]() -> int {  // pdlp.cu:1260-1309, weighted norms utils.cuh:365-383
+    double nr[3];
+    DEV(pdlpdev_init_norms(s->dev, nr));
+    const double cn = std::sqrt(hyper->initial_primal_weight_c_scaling * nr[1]);
+    const double bn = std::sqrt(hyper->initial_primal_weight_b_scaling * nr[2]);
+    weight = (bn > 0.0 && cn > 0.0) ? hyper->primal_importance * (cn / bn) : hyper->primal_importance;
+    return 0;
+  };
+  if (hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
+  if (hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
+  DEV(pdlpdev_scaling_compute(s->dev, hyper->do_ruiz, hyper->ruiz_iterations, hyper->do_pock_chambolle, hyper->alpha_pock_chambolle));
+  DEV(pdlpdev_scale_problem(s->dev));
+  if (!hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
+  if (!hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
+  if (settings->initial_step_size >= 0.0) step = settings->initial_step_size;  // pdlp.cu:1014-1021
+  if (settings->initial_primal_weight >= 0.0) weight = settings->initial_primal_weight;
+  s->result.initial_step_size     = step;
+  s->result.initial_primal_weight = weight;
+  DEV(pdlpdev_set_step(s->dev, step, weight));
+  if (settings->initial_k >= 0) DEV(pdlpdev_set_k(s->dev, settings->initial_k));
+  if (init_x || init_y) {
+    if (hyper->update_primal_weight_on_initial_solution || hyper->update_step_size_on_initial_solution)
+      return fail(-7, "update_*_on_initial_solution hyper-parameters are not implemented");
+    DEV(pdlpdev_set_initial(s->dev, init_x, init_y ? init_y + s->row_begin : nullptr));
+  }
+  if (hyper->project_initial_primal) DEV(pdlpdev_project_primal(s->dev));  // pdlp.cu:1041-1056
+  DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
+  s->result.norm_b = s->norm_b, s->result.norm_c = s->norm_c;
+  s->result.step_size = step, s->result.primal_weight = weight;
+  s->result.setup_seconds = seconds_since(t0);
+  return 0;
+}
+
+void cuoptamd_solver_destroy(cuoptamd_solver* s)
+{
+  if (!s) return;
+  if (s->dev) pdlpdev_destroy(s->dev);
+  delete s;
+}
+
+int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result)
+{
+  if (!s) return fail(-1, "cuoptamd_solver_advance: null solver");
+  const auto t0 = clock_type::now();
+  if (!s->started) {
+    s->started     = true;
+    s->solve_start = t0;
+  }
+  auto leave = [&](int rc) {
+    s->result.loop_seconds += seconds_since(t0);
+    if (result) *result = s->result;
+    return rc;
+  };
+  if (s->empty_problem) {
+    s->result.status = kNumericalError;
+    s->finished      = true;
+    return leave(0);
+  }
+  if (s->finished) return leave(0);
+  const cuoptamd_hyper& H = s->H;
+  const int64_t budget_end64 = (int64_t)s->total_iterations + std::max<int64_t>(max_new_iterations, 0);
+  const int32_t budget_end   = (int32_t)std::min<int64_t>(budget_end64, std::numeric_limits<int32_t>::max());
+  for (;;) {
+    const int32_t it = s->total_iterations;
+    const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
+    // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
+    const bool artificial = H.artificial_restart_in_main_loop &&
+                            s->ctl.its_since_restart >= H.artificial_restart_threshold * it;
+    if ((major || artificial || s->step_error) && s->major_done_at != it) {
+      bool terminated = false;
+      int rc          = major_iteration(s, &terminated);
+      if (rc != 0) return leave(rc);
+      s->major_done_at = it;
+      if (terminated) {
+        s->finished = true;
+        return leave(0);
+      }
+    }
+    if (it >= budget_end) {
+      s->result.status          = kNoTermination;
+      s->result.steps_taken     = s->ctl.steps_taken;
+      s->result.attempted_steps = s->ctl.attempts;
+      s->result.step_size       = s->ctl.step_size;
+      s->result.primal_weight   = s->ctl.primal_weight;
+      return leave(0);
+    }
+    // ---- take_step(s) up to the next major iteration (pdlp.cu:1187-1222), no host round trips ----
+    int32_t next_major;
+    if (it + 1 <= H.min_iteration_restart || H.artificial_restart_in_main_loop)
+      next_major = it + 1;
+    else
+      next_major = (it / H.major_iteration + 1) * H.major_iteration;
+    const int32_t target = std::min(next_major, budget_end);
+    if (s->step_error) {  // take_step re-arms valid_step_size = 0 (pdlp.cu:1190)
+      s->step_error = false;
+      int rc = pdlpdev_clear_error(s->dev);
+      if (rc != 0) return leave(fail(rc, "pdlpdev_clear_error: %s", pdlpdev_last_error()));
+    }
+    if (s->need_aty) {
+      int rc = pdlpdev_compute_aty(s->dev);
+      if (rc != 0) return leave(fail(rc, "pdlpdev_compute_aty: %s", pdlpdev_last_error()));
+      s->need_aty = false;
+    }
+    int rc = pdlpdev_run(s->dev, target, &s->ctl);
+    if (rc != 0) return leave(fail(rc, "pdlpdev_run: %s", pdlpdev_last_error()));
+    s->total_iterations = s->ctl.steps_taken;
+    if (s->ctl.error) s->step_error = true;
+  }
+}
+
+int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, double* rc)
+{
+  if (!s) return fail(-1, "null solver");
+  if (s->empty_problem || !s->dev) {
+    if (x) std::fill(x, x + s->n, 0.0);
+    if (rc) std::fill(rc, rc + s->n, 0.0);
+    return 0;
+  }
+  if (y && s->world > 1) std::fill(y, y + s->m_global, 0.0);  // other ranks' rows stay 0
+  DEV(pdlpdev_get_solution(s->dev, s->returned_which, x, y ? y + s->row_begin : nullptr, rc));
+  return 0;
+}
+
+pdlpdev_ctx* cuoptamd_solver_device(cuoptamd_solver* s) { return s ? s->dev : nullptr; }
+
+int cuoptamd_solver_row_range(cuoptamd_solver* s, int32_t* row_begin, int32_t* row_end)
+{
+  if (!s) return fail(-1, "null solver");
+  if (row_begin) *row_begin = s->row_begin;
+  if (row_end) *row_end = s->row_end;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Synthetic random sparse LPs with a KNOWN primal-dual optimal pair (SURVEY.md 8(d) family S(m,n,k,seed)).
+
+    min c.x   s.t.  lo <= A x <= hi,  x >= 0
+    A: m x n CSR, k nonzeros per row (distinct sorted columns, values ~ N(0,1)), every column used
+    rows [0, m/2): equalities lo = hi = A x*;  rows [m/2, m): lo = A x* - s, hi = +inf
+    x*: 50 % zeros, else U(0,1];  y*: N(0,1) on equalities, |N(0,1)| with 30 % zeros on '>=' rows
+    s_i = 0 where y*_i > 0 else U(0,1);  z*_j = 0 where x*_j > 0 else U(0,1);  c = A^T y* + z*
+so (x*, y*) satisfies the KKT conditions and obj* = c.x* = lo.y* is the known answer.
+`hard=True` rescales rows by 10^U(-1,1) and columns by 10^U(-2,2) first, which makes PDLP need
+thousands of iterations and several restarts."""
+import numpy as np
+
+
+def _columns(rng, m, n, k):
+    if n > m * k:
+        raise ValueError("need n <= m*k so that every column can get an entry")
+    cols = rng.integers(0, n, size=(m, k), dtype=np.int64)
+    j = np.arange(n, dtype=np.int64)
+    forced_rows, forced_slots = j % m, j // m
+    cols[forced_rows, forced_slots] = j
+    nforced = np.zeros(m, dtype=np.int64)
+    np.add.at(nforced, forced_rows, 1)
+    for _ in range(100):
+        srt = np.sort(cols, axis=1)
+        bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+        if bad.size == 0:
+            return srt
+        for i in bad:  # redraw only the free slots of the offending rows
+            f = nforced[i]
+            cols[i, f:] = rng.integers(0, n, size=k - f)
+    raise RuntimeError("could not draw distinct columns")
+
+
+def generate(m, n, k=10, seed=1, hard=False):
+    rng = np.random.default_rng(seed)
+    cols = _columns(rng, m, n, k)
+    vals = rng.standard_normal((m, k))
+    if hard:
+        rs = 10.0 ** rng.uniform(-1.0, 1.0, size=m)
+        cs = 10.0 ** rng.uniform(-2.0, 2.0, size=n)
+        vals = vals * rs[:, None] * cs[cols]
+    offsets = (np.arange(m + 1, dtype=np.int64) * k).astype(np.int32)
+    indices = cols.reshape(-1).astype(np.int32)
+    values = np.ascontiguousarray(vals.reshape(-1))
+    xs = np.where(rng.random(n) < 0.5, 0.0, 1.0 - rng.random(n))  # U(0,1]
+    half = m // 2
+    ys = rng.standard_normal(m)
+    ys[half:] = np.abs(ys[half:]) * (rng.random(m - half) >= 0.3)
+    ax = (vals * xs[cols]).sum(axis=1)
+    lo, hi = ax.copy(), ax.copy()
+    slack = np.where(ys[half:] > 0.0, 0.0, rng.random(m - half))
+    lo[half:] = ax[half:] - slack
+    hi[half:] = np.inf
+    zs = np.where(xs > 0.0, 0.0, rng.random(n))
+    aty = np.zeros(n)
+    np.add.at(aty, cols.reshape(-1), (vals * ys[:, None]).reshape(-1))
+    c = aty + zs
+    return dict(m=m, n=n, offsets=offsets, indices=indices, values=values, c=c, lo=lo, hi=hi,
+                lb=np.zeros(n), ub=np.full(n, np.inf), maximize=False, objective_offset=0.0,
+                x_star=xs, y_star=ys, objective_star=float(c @ xs), seed=seed, k=k, hard=hard)
+
+
+# the configurations BASELINE.json names
+CONFIGS = {
+    "tiny": dict(m=2000, n=2000, k=10, seed=3),
+    "c2": dict(m=100_000, n=100_000, k=10, seed=1),        # 1e5 x 1e5, 1e6 nnz
+    "c3": dict(m=1_000_000, n=1_000_000, k=10, seed=2),    # 1e6 x 1e6, 1e7 nnz
+}
+
+
+def spmv_bytes(rows, cols, nnz):
+    """algorithmic bytes of one CSR SpMV (fp64 values, int32 indices): SURVEY.md 8(d)"""
+    return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
+
+
+def iteration_bytes_min(m, n, nnz):
+    """fused floor of one accepted PDHG iteration: 24 nnz + 4(m+n+2) + 8(14 n + 7 m)"""
+    return 24 * nnz + 4 * (m + n + 2) + 8 * (14 * n + 7 * m)

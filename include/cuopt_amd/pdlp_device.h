@@ -1,0 +1,221 @@
+/*
+ * Thin C-ABI over the HIP/gfx950 device layer of the PDLP solver.
+ *
+ * The C++ host driver (cuopt_amd/csrc/pdlp_solver.cpp) never includes a HIP header: everything the
+ * GPU does for the PDHG hot path is reached through the `pdlpdev_*` functions below (plain
+ * pointers and sizes, no HIP/torch types).  All pointer arguments are HOST pointers unless the
+ * name says `dev`.  Every function returns 0 on success and a negative code on failure;
+ * pdlpdev_last_error() returns the message (thread-local).
+ *
+ * What each group replaces in the reference (cuOpt 25.08, LP/ = cpp/src/linear_programming/):
+ *   create/destroy ........ detail::problem_t device storage + saddle_point_state_t
+ *                           (cpp/src/mip/problem/problem.cu:96-136, LP/saddle_point.cu:26-64),
+ *                           cusparse_view_t (LP/cusparse_view.cu:127-277)
+ *   scaling_* ............. pdlp_initial_scaling_strategy_t (LP/initial_scaling_strategy/
+ *                           initial_scaling.cu:36-163,176-307,310-484)
+ *   init_norms ............ compute_initial_step_size / compute_initial_primal_weight
+ *                           (LP/pdlp.cu:1224-1309)
+ *   run ................... pdlp_solver_t::take_step = pdhg_solver_t::take_step +
+ *                           adaptive_step_size_strategy_t::compute_step_sizes +
+ *                           weighted_average_solution_t::add_current_solution_to_weighted_average +
+ *                           pdhg_solver_t::update_solution (LP/pdlp.cu:1187-1222, LP/pdhg.cu:72-281,
+ *                           LP/step_size_strategy/adaptive_step_size_strategy.cu:91-345,
+ *                           LP/restart_strategy/weighted_average_solution.cu:73-108)
+ *   make_average .......... weighted_average_solution_t::compute_averages (…:114-142)
+ *   eval .................. convergence_information_t::compute_convergence_information
+ *                           (LP/termination_strategy/convergence_information.cu:149-422)
+ *   restart_* ............. run_kkt_restart device parts (LP/restart_strategy/
+ *                           pdlp_restart_strategy.cu:593-623,752-839,1680-1714)
+ */
+#ifndef CUOPT_AMD_PDLP_DEVICE_H
+#define CUOPT_AMD_PDLP_DEVICE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pdlpdev_ctx pdlpdev_ctx; /* opaque */
+
+/* Device-resident control block of the step loop, mirrored to the host on request.
+ * (reference: device scalars step_size_, primal_weight_, primal/dual_step_size_,
+ *  d_total_pdhg_iterations_ + pinned valid_step_size_, adaptive_step_size_strategy.hpp) */
+typedef struct pdlpdev_ctl {
+  double step_size;     /* eta                                              */
+  double primal_weight; /* w                                                */
+  double tau;           /* eta / w                                          */
+  double sigma;         /* eta * w                                          */
+  double sum_weights;   /* weighted-average denominator (sum of step sizes) */
+  double last_interaction, last_movement, last_dx2, last_dy2; /* diagnostics of the last attempt */
+  int32_t k;            /* number of step-size updates (d_total_pdhg_iterations_) */
+  int32_t cur;          /* which of the two ping-pong buffers holds the iterate   */
+  int32_t pending_avg;  /* 1: iterate `cur` has not been added to the sums yet    */
+  int32_t steps_taken;  /* accepted PDHG steps since create                       */
+  int32_t attempts;     /* attempted PDHG steps since create                      */
+  int32_t target_steps; /* kernels are no-ops once steps_taken >= target_steps    */
+  int32_t error;        /* 1: movement <= 0 or >= 1e100 (valid_step_size = -1)    */
+  int32_t its_since_restart;
+} pdlpdev_ctl;
+
+/* hyper-parameters the device kernels need (subset of pdlp_hyper_params.cuh:20-58) */
+typedef struct pdlpdev_step_params {
+  double reduction_exponent;        /* default_reduction_exponent   */
+  double growth_exponent;           /* default_growth_exponent      */
+  double primal_distance_smoothing; /* default 0.5 (Stable2)        */
+  double dual_distance_smoothing;
+} pdlpdev_step_params;
+
+/* indices into the `out` array of pdlpdev_eval (unscaled problem, min-form objective) */
+enum {
+  PDLPDEV_EV_CX = 0,        /* c.x                                                     */
+  PDLPDEV_EV_DUAL_SUM,      /* sum_i B(y_i,lo_i,hi_i) + sum_j B(rc_j,lb_j,ub_j)        */
+  PDLPDEV_EV_PRES2,         /* ||primal residual||_2^2                                 */
+  PDLPDEV_EV_DRES2,         /* ||dual residual||_2^2                                   */
+  PDLPDEV_EV_X2,            /* ||x||_2^2                                               */
+  PDLPDEV_EV_Y2,            /* ||y||_2^2                                               */
+  PDLPDEV_EV_LINF_PRES_REL, /* max_i (r_p,i - eps_rel_primal * bcomb_i), clipped at 0  */
+  PDLPDEV_EV_LINF_DRES_REL, /* max_j (r_d,j - eps_rel_dual * c_j), clipped at 0        */
+  PDLPDEV_EV_COUNT
+};
+
+/* which iterate */
+enum { PDLPDEV_CURRENT = 0, PDLPDEV_AVERAGE = 1 };
+
+/* ids for pdlpdev_download (debug / parity tests) */
+enum {
+  PDLPDEV_BUF_X = 0,      /* current primal iterate (scaled)            n */
+  PDLPDEV_BUF_Y,          /* current dual iterate (scaled)              m */
+  PDLPDEV_BUF_X_OTHER,    /* the other ping-pong primal buffer          n */
+  PDLPDEV_BUF_Y_OTHER,    /*                                            m */
+  PDLPDEV_BUF_ATY,        /* A^T y of the current iterate               n */
+  PDLPDEV_BUF_ATY_OTHER,  /*                                            n */
+  PDLPDEV_BUF_XBAR,       /* extrapolated primal 2x'-x                  n */
+  PDLPDEV_BUF_SUM_X,      /* weighted sum of primal iterates            n */
+  PDLPDEV_BUF_SUM_Y,      /*                                            m */
+  PDLPDEV_BUF_AVG_X,      /* average iterate (scaled)                   n */
+  PDLPDEV_BUF_AVG_Y,      /*                                            m */
+  PDLPDEV_BUF_DROW,       /* cumulative row scaling D_r                 m */
+  PDLPDEV_BUF_DCOL,       /* cumulative column scaling D_c              n */
+  PDLPDEV_BUF_A_VALUES,   /* values of A (scaled after scale_problem)   nnz */
+  PDLPDEV_BUF_AT_VALUES,  /* values of A^T                              nnz */
+  PDLPDEV_BUF_C,          /* scaled objective                           n */
+  PDLPDEV_BUF_LB, PDLPDEV_BUF_UB, /* scaled variable bounds             n */
+  PDLPDEV_BUF_LO, PDLPDEV_BUF_HI, /* scaled constraint bounds           m */
+  PDLPDEV_BUF_RC_CURRENT, /* reduced costs from the last eval(CURRENT)  n */
+  PDLPDEV_BUF_RC_AVERAGE, /*                                            n */
+  PDLPDEV_BUF_LAST_RESTART_X, PDLPDEV_BUF_LAST_RESTART_Y,
+  PDLPDEV_BUF_COUNT
+};
+
+/* kernels that pdlpdev_time_kernel can bracket with HIP events */
+enum {
+  PDLPDEV_K_PRIMAL = 0, /* primal projection + extrapolation + averaging          */
+  PDLPDEV_K_SPMV_A_DUAL, /* y' = proj(y - sigma*A*xbar): CSR SpMV fused with dual projection */
+  PDLPDEV_K_SPMV_AT_STEP, /* A^T y' fused with interaction / movement partials   */
+  PDLPDEV_K_STEP_DECISION, /* 1-block scalar kernel                               */
+  PDLPDEV_K_SPMV_A_PLAIN, /* y = A x (unfused CSR SpMV)                          */
+  PDLPDEV_K_SPMV_AT_PLAIN,
+  PDLPDEV_K_ITERATION,    /* the whole 4-kernel attempt                          */
+  PDLPDEV_K_COUNT
+};
+
+/* ---- environment ---------------------------------------------------------------------------- */
+const char* pdlpdev_last_error(void);
+int pdlpdev_device_count(void);
+/* name (<= len bytes), CU count, HBM bytes of device `dev` */
+int pdlpdev_device_info(int dev, char* name, int len, int* compute_units, int64_t* hbm_bytes);
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* Uploads one ROW BLOCK of the LP: `m` = rows held by this context (all rows when single-GPU),
+ * `n` = global number of variables.  A is CSR (m x n), At is the explicit CSR of its transpose
+ * (n x m) exactly like the reference keeps it (problem.cu:277-309).  c/lb/ub have n entries
+ * (min-form objective), lo/hi have m entries.  Everything is copied. */
+int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
+                   const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
+                   const int32_t* at_indices, const double* at_values, const double* c,
+                   const double* lo, const double* hi, const double* lb, const double* ub);
+void pdlpdev_destroy(pdlpdev_ctx* ctx);
+
+/* ---- multi-GPU (row-block sharding, one context per rank) ----------------------------------- */
+/* 128-byte RCCL unique id, generated on rank 0 and handed to every rank by the launcher. */
+int pdlpdev_comm_unique_id(uint8_t id[128]);
+/* Joins the communicator; afterwards every dual-side reduction and the A^T y partial product are
+ * all-reduced over xGMI inside the calls below.  world == 1 is allowed (exercise the path). */
+int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128]);
+
+/* ---- setup ----------------------------------------------------------------------------------- */
+/* D_r, D_c <- Ruiz (inf-norm, `ruiz_iterations` rounds, both sides from the same snapshot) then
+ * Pock-Chambolle(alpha).  initial_scaling.cu:36-92. */
+int pdlpdev_scaling_compute(pdlpdev_ctx* ctx, int do_ruiz, int ruiz_iterations,
+                            int do_pock_chambolle, double alpha);
+/* A <- D_r A D_c (and A^T), c <- c o D_c, lb,ub <- ./D_c, lo,hi <- o D_r.  initial_scaling.cu:347-408 */
+int pdlpdev_scale_problem(pdlpdev_ctx* ctx);
+/* out[0] = max |A_ij| ; out[1] = sum c_j^2 ; out[2] = sum bcomb_i^2 of the problem AS IT IS NOW
+ * (scaled or not), bcomb = combine_finite_abs_bounds(lo, hi) (utils.cuh:139-163). */
+int pdlpdev_init_norms(pdlpdev_ctx* ctx, double out[3]);
+/* l2 norms of the UNSCALED c and bcomb (termination constants, convergence_information.cu:76-84) */
+int pdlpdev_problem_norms(pdlpdev_ctx* ctx, double* norm_c, double* norm_b);
+int pdlpdev_set_step_params(pdlpdev_ctx* ctx, const pdlpdev_step_params* p);
+/* eta, w -> ctl (tau = eta/w, sigma = eta*w).  Pass eta < 0 to keep the current step size. */
+int pdlpdev_set_step(pdlpdev_ctx* ctx, double step_size, double primal_weight);
+/* k (d_total_pdhg_iterations_) override for warm starts (pdlp.cu:1019-1021) */
+int pdlpdev_set_k(pdlpdev_ctx* ctx, int32_t k);
+/* Initial iterate given in UNSCALED space (NULL = keep zeros): copied, divided by D_c / D_r
+ * (scale_solutions, initial_scaling.cu:410-427).  Call after pdlpdev_scaling_compute. */
+int pdlpdev_set_initial(pdlpdev_ctx* ctx, const double* x, const double* y);
+/* x <- clamp(x, lb, ub) on the scaled problem (pdlp.cu:1041-1056) */
+int pdlpdev_project_primal(pdlpdev_ctx* ctx);
+
+/* ---- the hot loop ---------------------------------------------------------------------------- */
+/* AtY <- A^T y for the current iterate (pdhg.cu:119-134); needed before the first step and after
+ * a restart to the average. */
+int pdlpdev_compute_aty(pdlpdev_ctx* ctx);
+/* Attempts PDHG steps until `target_steps` accepted steps exist in total (or the step-size error
+ * flag is raised).  No host round-trip per attempt: acceptance, step-size update, buffer flip and
+ * averaging all happen on the device; the host only reads the control block when the batch is
+ * done.  Returns the control block in *ctl. */
+int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl);
+int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
+/* re-arm the loop after the step-size error flag was raised (take_step resets valid_step_size_,
+ * pdlp.cu:1190) */
+int pdlpdev_clear_error(pdlpdev_ctx* ctx);
+/* 0: plain launches, 1: replay the attempt through a captured hipGraph (default 1) */
+int pdlpdev_set_graph_mode(pdlpdev_ctx* ctx, int use_graph);
+
+/* ---- major iteration -------------------------------------------------------------------------- */
+/* adds a still-pending accepted iterate to the running sums */
+int pdlpdev_flush_average(pdlpdev_ctx* ctx);
+/* mode 0: avg <- current ; 1: avg <- 0 ; 2: avg <- sum / sum_weights   (pdlp.cu:1110-1122) */
+int pdlpdev_make_average(pdlpdev_ctx* ctx, int mode);
+/* Convergence information of one iterate on the UNSCALED problem; the iterates stay scaled on the
+ * device, D_r/D_c are folded into the two fused SpMV passes.  `rc_rule_finite_bounds` selects
+ * copy_gradient_if_finite_bounds (Stable2) vs copy_gradient_if_should_be_reduced_cost. */
+int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
+                 double eps_rel_dual, double out[PDLPDEV_EV_COUNT]);
+/* Restart to `which` (CURRENT or AVERAGE): dist2[0] = ||x_c - x_last_restart||^2, dist2[1] same for
+ * y (scaled space); copies the candidate into the iterate when it is the average; anchors <-
+ * candidate; sums <- 0; its_since_restart <- 0. */
+int pdlpdev_restart(pdlpdev_ctx* ctx, int which, double dist2[2]);
+
+/* ---- results ---------------------------------------------------------------------------------- */
+/* UNSCALED x (n), y (m), reduced costs (n, from the last eval of that iterate); any may be NULL */
+int pdlpdev_get_solution(pdlpdev_ctx* ctx, int which, double* x, double* y, double* rc);
+/* raw buffer download; returns the number of elements copied (or < 0) */
+int64_t pdlpdev_download(pdlpdev_ctx* ctx, int buffer_id, void* host, int64_t max_elements);
+
+/* ---- measurement / parity hooks ---------------------------------------------------------------- */
+/* y = A x (transpose = 0, x has n entries, y has m) or y = A^T x through the plain CSR kernel */
+int pdlpdev_spmv(pdlpdev_ctx* ctx, int transpose, const double* x, double* y);
+/* `reps` back-to-back launches of one kernel bracketed by HIP events on the solver stream;
+ * *avg_ms = average duration of one launch.  State is not advanced (target_steps trick). */
+int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_ms);
+/* device-side generation of the iterate is not needed; but benches need a sync point */
+int pdlpdev_synchronize(pdlpdev_ctx* ctx);
+/* bytes of device memory held by the context */
+int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,153 @@
+/*
+ * C-ABI of the C++ host driver of the MI355X-native PDLP solver (cuopt_amd/csrc/pdlp_solver.cpp).
+ *
+ * This is the layer the libcuopt C API (cuopt_c.h -> cuOptSolve) sits on; it is exported so that
+ * benches, the MIP-style warm-started re-solve loop and the parity tests can drive the solver
+ * step by step.  It replaces, in the reference (cuOpt 25.08, LP/ = cpp/src/linear_programming/):
+ *   cuoptamd_solver_create .... detail::problem_t ctor (cpp/src/mip/problem/problem.cu:53-136),
+ *                               pdlp_solver_t ctor + the [init] block of run_solver
+ *                               (LP/pdlp.cu:55-188, 984-1075)
+ *   cuoptamd_solver_advance ... the while(true) loop of pdlp_solver_t::run_solver
+ *                               (LP/pdlp.cu:1081-1185) incl. check_termination (:537-802) and
+ *                               run_kkt_restart (LP/restart_strategy/pdlp_restart_strategy.cu:467-641)
+ *   cuoptamd_hyper_preset ..... set_pdlp_solver_mode (LP/solve.cu:64-212)
+ * All pointers are host pointers.  Functions return 0 or a negative code;
+ * cuoptamd_last_error() holds the message.
+ */
+#ifndef CUOPT_AMD_PDLP_SOLVER_H
+#define CUOPT_AMD_PDLP_SOLVER_H
+
+#include <stdint.h>
+
+#include "cuopt_amd/pdlp_device.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cuoptamd_solver cuoptamd_solver; /* opaque */
+
+/* LP in the user's form: objective_sense * (c.x) + offset, lo <= A x <= hi, lb <= x <= ub */
+typedef struct cuoptamd_lp {
+  int32_t m, n;
+  const int32_t* offsets; /* m+1 */
+  const int32_t* indices; /* nnz */
+  const double* values;   /* nnz */
+  const double* c;        /* n */
+  const double* lo;       /* m (may be -inf) */
+  const double* hi;       /* m (may be +inf) */
+  const double* lb;       /* n */
+  const double* ub;       /* n */
+  int32_t maximize;
+  double objective_offset;
+} cuoptamd_lp;
+
+/* pdlp_hyper_params (cpp/include/cuopt/linear_programming/pdlp/pdlp_hyper_params.cuh:20-58) */
+typedef struct cuoptamd_hyper {
+  double initial_step_size_scaling;
+  int32_t ruiz_iterations;
+  int32_t do_pock_chambolle;
+  int32_t do_ruiz;
+  double alpha_pock_chambolle;
+  double artificial_restart_threshold;
+  int32_t compute_initial_step_size_before_scaling;
+  int32_t compute_initial_primal_weight_before_scaling;
+  double initial_primal_weight_c_scaling;
+  double initial_primal_weight_b_scaling;
+  int32_t major_iteration;
+  int32_t min_iteration_restart;
+  int32_t restart_strategy; /* 0 none, 1 KKT, 2 trust region (not implemented: create fails) */
+  int32_t never_restart_to_average;
+  double reduction_exponent;
+  double growth_exponent;
+  double primal_weight_update_smoothing;
+  double sufficient_reduction_for_restart;
+  double necessary_reduction_for_restart;
+  double primal_importance;
+  double primal_distance_smoothing;
+  double dual_distance_smoothing;
+  int32_t compute_last_restart_before_new_primal_weight;
+  int32_t artificial_restart_in_main_loop;
+  int32_t rescale_for_restart;
+  int32_t update_primal_weight_on_initial_solution;
+  int32_t update_step_size_on_initial_solution;
+  int32_t handle_some_primal_gradients_on_finite_bounds_as_residuals;
+  int32_t project_initial_primal;
+} cuoptamd_hyper;
+
+/* pdlp_solver_settings_t subset (pdlp/solver_settings.hpp:70-224) */
+typedef struct cuoptamd_settings {
+  double absolute_gap_tolerance, relative_gap_tolerance;
+  double absolute_primal_tolerance, relative_primal_tolerance;
+  double absolute_dual_tolerance, relative_dual_tolerance;
+  int32_t iteration_limit; /* INT32_MAX: none */
+  double time_limit;       /* seconds; +inf: none */
+  int32_t per_constraint_residual;
+  int32_t first_primal_feasible;
+  /* warm start overrides (pdlp.cu:1014-1021); negative = not set */
+  double initial_step_size;
+  double initial_primal_weight;
+  int32_t initial_k;
+  int32_t use_graph; /* replay the PDHG attempt through hipGraphs (default 1) */
+} cuoptamd_settings;
+
+/* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */
+typedef struct cuoptamd_result {
+  int32_t status; /* pdlp_termination_status_t == CUOPT_TERIMINATION_STATUS_* ; 0 = still running */
+  int32_t steps_taken;
+  int32_t attempted_steps;
+  int32_t returned_average;
+  int32_t num_restarts;
+  int32_t num_major_iterations;
+  double primal_objective, dual_objective, gap, relative_gap;
+  double l2_primal_residual, l2_dual_residual;
+  double l2_relative_primal_residual, l2_relative_dual_residual;
+  double max_primal_ray_infeasibility, max_dual_ray_infeasibility; /* unused: 0 */
+  double initial_step_size, initial_primal_weight;
+  double step_size, primal_weight;
+  double norm_b, norm_c;
+  double setup_seconds; /* transpose + upload + scaling + initial step/weight */
+  double loop_seconds;  /* accumulated time inside cuoptamd_solver_advance */
+} cuoptamd_result;
+
+const char* cuoptamd_last_error(void);
+
+/* presets, mode numbering as CUOPT_PDLP_SOLVER_MODE_* (0 Stable1, 1 Stable2, 2 Methodical1, 3 Fast1) */
+void cuoptamd_hyper_preset(int mode, cuoptamd_hyper* h);
+void cuoptamd_default_settings(cuoptamd_settings* s);
+
+/* Builds A^T, slices this rank's row block (rank/world; world = 1: everything), uploads, scales,
+ * computes the initial step size and primal weight.  `comm_id`: 128-byte RCCL id when world > 1
+ * (or world == 1 and non-NULL to exercise the collective path), else NULL.
+ * init_x / init_y: optional initial primal / dual solution in the user's (unscaled) space. */
+int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const cuoptamd_hyper* hyper,
+                           const cuoptamd_settings* settings, const double* init_x,
+                           const double* init_y, int device, int rank, int world,
+                           const uint8_t* comm_id);
+void cuoptamd_solver_destroy(cuoptamd_solver* s);
+
+/* Runs the PDLP loop until a termination criterion fires or `max_new_iterations` further PDLP
+ * iterations (accepted steps) have been taken, whichever is first.  result->status == 0 means
+ * "budget exhausted, not terminated"; calling again continues exactly where it stopped. */
+int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result);
+
+/* x (n), y (m_global), reduced cost (n) of the returned iterate, unscaled, in the internal min-form
+ * sign convention of the reference (any pointer may be NULL). Valid after a terminating advance. */
+int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, double* rc);
+
+/* the device context (for kernel timing and buffer downloads in benches/tests) */
+pdlpdev_ctx* cuoptamd_solver_device(cuoptamd_solver* s);
+/* rows [row_begin, row_end) of A held by this rank */
+int cuoptamd_solver_row_range(cuoptamd_solver* s, int32_t* row_begin, int32_t* row_end);
+
+/* contiguous row-block partition balanced by nonzeros: fills bounds[0..world] */
+void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32_t* bounds);
+/* CSR transpose (stable: rows ascending inside each column), host, O(nnz) */
+void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
+                            const double* values, int32_t* t_offsets, int32_t* t_indices,
+                            double* t_values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""CPU: the C-ABI library loads, exports every symbol the headers declare, and the host-only part
+of the libcuopt C API (problem builder, getters, parameter registry, MPS reader) behaves like the
+reference (cpp/src/linear_programming/cuopt_c.cpp, cpp/tests/linear_programming/c_api_tests)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, decode_problem, write_mps
+from cuopt_amd import capi
+
+INF = np.inf
+
+
+def _declared_functions(header):
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    return set(re.findall(r"\b((?:cuOpt|cuoptamd_|pdlpdev_)\w+)\s*\(", txt))
+
+
+def test_every_declared_symbol_is_exported():
+    headers = glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True)
+    assert len(headers) >= 4
+    names = set()
+    for h in headers:
+        names |= _declared_functions(h)
+    assert len([n for n in names if n.startswith("cuOpt")]) == 41  # cuopt_c.h:89-668
+    missing = [n for n in sorted(names) if not hasattr(capi.lib, n)]
+    assert not missing, missing
+
+
+def test_scalar_sizes():  # c_api_tests.cpp:27-29
+    assert capi.lib.cuOptGetFloatSize() == 8 and capi.lib.cuOptGetIntSize() == 4
+
+
+def test_problem_round_trip_and_null_checks(golden_problems):
+    p = golden_problems["afiro"]["problem"]
+    prob = capi.Problem.from_dict(p)
+    assert (prob.m, prob.n, prob.nnz, prob.is_mip) == (27, 32, 83, False)
+    d = prob.to_dict()
+    for k in ("offsets", "indices", "values", "c", "lo", "hi", "lb", "ub"):
+        np.testing.assert_array_equal(d[k], p[k])
+    v = C.c_int32()
+    assert capi.lib.cuOptGetNumConstraints(None, C.byref(v)) == capi.CUOPT_INVALID_ARGUMENT
+    assert capi.lib.cuOptGetNumConstraints(prob.handle, None) == capi.CUOPT_INVALID_ARGUMENT
+    h = C.c_void_p()
+    assert capi.lib.cuOptCreateProblem(1, 1, 1, 0.0, None, None, None, None, None, None, None, None, None,
+                                       C.byref(h)) == capi.CUOPT_INVALID_ARGUMENT
+    prob.close()
+    assert not prob.handle  # Destroy NULLs the handle (cuopt_c.cpp:200-206)
+    capi.lib.cuOptDestroyProblem(None)  # tolerated
+    capi.lib.cuOptDestroyProblem(C.byref(C.c_void_p()))
+
+
+def test_sense_rhs_builder_materialises_bounds():
+    p = dict(m=3, n=2, offsets=[0, 2, 4, 6], indices=[0, 1, 0, 1, 0, 1], values=[1.0] * 6, c=[1.0, 1.0],
+             lb=[0.0, 0.0], ub=[INF, INF], row_types=np.frombuffer(b"LGE", np.uint8), rhs=[1.0, 2.0, 3.0])
+    prob = capi.Problem.from_dict(p, ranged=False)
+    d = prob.to_dict()
+    np.testing.assert_array_equal(d["lo"], [-INF, 2.0, 3.0])
+    np.testing.assert_array_equal(d["hi"], [1.0, INF, 3.0])
+    sense = np.zeros(3, np.uint8)
+    capi.lib.cuOptGetConstraintSense(prob.handle, sense.ctypes.data_as(C.c_void_p))
+    assert bytes(sense) == b"LGE"
+
+
+def test_integer_variables_are_reported():
+    p = dict(m=1, n=2, offsets=[0, 2], indices=[0, 1], values=[1.0, 1.0], c=[1.0, 1.0], lo=[0.0], hi=[1.0],
+             lb=[0.0, 0.0], ub=[1.0, 1.0], var_types=np.frombuffer(b"CI", np.uint8))
+    assert capi.Problem.from_dict(p).is_mip
+
+
+def test_parameter_registry():
+    """names/ranges/defaults: cpp/src/math_optimization/solver_settings.cu:66-118"""
+    s = capi.Settings()
+    for k in ("absolute_dual_tolerance", "relative_dual_tolerance", "absolute_primal_tolerance",
+              "relative_primal_tolerance", "absolute_gap_tolerance", "relative_gap_tolerance"):
+        assert float(s.get(k)) == pytest.approx(1e-4)
+    assert int(s.get("iteration_limit")) == 2 ** 31 - 1
+    assert int(s.get("pdlp_solver_mode")) == 1 and int(s.get("method")) == 0
+    assert s.get("time_limit") == "inf" and s.get("crossover") == "false"
+    s.set("time_limit", 2.5)
+    assert float(s.get("time_limit")) == 2.5
+    s.set("per_constraint_residual", "T")
+    assert s.get("per_constraint_residual") == "true"
+    v = C.c_int32()
+    # integer setter falls back to a boolean parameter (cuopt_c.cpp:493-505)
+    assert capi.lib.cuOptSetIntegerParameter(s.handle, b"crossover", 1) == 0
+    assert capi.lib.cuOptGetIntegerParameter(s.handle, b"crossover", C.byref(v)) == 0 and v.value == 1
+    # c_api_tests.cpp:82: bad parameter name
+    assert capi.lib.cuOptSetParameter(s.handle, b"bad_parameter_name", b"1") == capi.CUOPT_INVALID_ARGUMENT
+    assert capi.lib.cuOptSetFloatParameter(s.handle, b"absolute_gap_tolerance", 0.5) == capi.CUOPT_INVALID_ARGUMENT
+    assert capi.lib.cuOptSetIntegerParameter(s.handle, b"pdlp_solver_mode", 7) == capi.CUOPT_INVALID_ARGUMENT
+    assert capi.lib.cuOptSetParameter(s.handle, b"iteration_limit", b"abc") == capi.CUOPT_INVALID_ARGUMENT
+    assert capi.lib.cuOptSetParameter(s.handle, None, b"1") == capi.CUOPT_INVALID_ARGUMENT
+
+
+def test_read_problem_error_codes(tmp_path):
+    h = C.c_void_p()
+    # c_api_tests.cpp:86: missing file -> CUOPT_MPS_FILE_ERROR
+    assert capi.lib.cuOptReadProblem(b"/nonexistent/file.mps", C.byref(h)) == capi.CUOPT_MPS_FILE_ERROR
+    assert not h
+    bad = tmp_path / "bad.mps"
+    bad.write_text("NAME x\nROWS\n N obj\n L r1\nCOLUMNS\n    x nosuchrow 1.0\nRHS\nENDATA\n")
+    assert capi.lib.cuOptReadProblem(os.fsencode(str(bad)), C.byref(h)) == capi.CUOPT_MPS_PARSE_ERROR
+
+
+def test_mps_round_trip_through_own_writer(golden_problems, tmp_path):
+    for name, g in golden_problems.items():
+        path = str(tmp_path / (name + ".mps"))
+        write_mps(path, g["problem"])
+        d = capi.Problem.read(path).to_dict()
+        p = g["problem"]
+        assert (d["m"], d["n"], d["maximize"]) == (p["m"], p["n"], p["maximize"])
+        assert d["objective_offset"] == pytest.approx(p["objective_offset"])
+        for k in ("offsets", "indices", "values", "c", "lo", "hi", "lb", "ub"):
+            np.testing.assert_allclose(d[k], p[k], rtol=0, atol=0, err_msg="%s:%s" % (name, k))
+
+
+REF_DIR = "/root/reference/datasets/linear_programming"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DIR), reason="reference datasets only exist in the build container")
+def test_mps_reader_matches_reference_parser_on_all_fixtures(golden_parser):
+    """every datasets/linear_programming/*.mps: same accept/reject decision as the reference's parser
+    in free-format mode, and identical CSR / bounds / objective when accepted."""
+    checked = 0
+    for name, ref in sorted(golden_parser.items()):
+        h = C.c_void_p()
+        rc = capi.lib.cuOptReadProblem(os.fsencode(os.path.join(REF_DIR, name)), C.byref(h))
+        if not ref["ok"]:
+            assert rc == capi.CUOPT_MPS_PARSE_ERROR, name
+            continue
+        assert rc == 0, name
+        d = capi.Problem(h).to_dict()
+        r = decode_problem(ref)
+        assert (d["m"], d["n"], d["maximize"]) == (r["m"], r["n"], r["maximize"]), name
+        assert d["objective_offset"] == r["objective_offset"], name
+        for k in ("offsets", "indices", "values", "c", "lo", "hi", "lb", "ub"):
+            np.testing.assert_array_equal(d[k], r[k], err_msg="%s:%s" % (name, k))
+        ref_types = bytes(bytearray(ref["var_types"])).replace(b"\x00", b"C")
+        assert bytes(bytearray(d["var_types"])) == ref_types, name
+        checked += 1
+    assert checked >= 20
+
+
+def test_no_gpu_means_loud_failure_not_fallback(golden_problems):
+    """the product has no CPU path: without a HIP device cuOptSolve must report an error"""
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = capi.solve(golden_problems["afiro"]["problem"])
+    assert r["return_code"] == capi.CUOPT_RUNTIME_ERROR
+    assert "no HIP device" in r["error_string"]
+
+
+def test_partition_rows_balances_nonzeros():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 50, size=1000)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for world in (1, 2, 4, 8):
+        b = capi.partition_rows(1000, off, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0)
+        per = np.diff(off[b])
+        assert per.max() - per.min() <= 2 * 50
+
+
+def test_csr_transpose_matches_scipy():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1)
+    a = sp.random(40, 30, density=0.2, random_state=rng, format="csr")
+    to, ti, tv = capi.csr_transpose(40, 30, a.indptr, a.indices, a.data)
+    t = sp.csr_matrix((tv, ti, to), shape=(30, 40))
+    assert abs(t - a.T).max() == 0
+    assert np.all(np.diff(to) >= 0) and all(np.all(np.diff(ti[to[j]:to[j + 1]]) > 0) for j in range(30))

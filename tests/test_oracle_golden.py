@@ -1,0 +1,110 @@
+"""CPU: pins the C oracle (oracle/pdlp_oracle.c) on every known answer the reference's own tests
+hold for the PDLP path, and on the objectives of the reference's CPU dual simplex (recorded in
+tests/golden/problems.json by scripts/make_golden.py; re-checked live when oracle/_ref exists)."""
+import numpy as np
+import pytest
+
+from oracle import orcbind, refbind
+
+pytestmark = pytest.mark.skipif(not orcbind.available(), reason="oracle/liboracle_pdlp.so not built")
+
+INF = np.inf
+
+
+def test_afiro_objective_matches_reference_tests(golden_problems):
+    g = golden_problems["afiro"]
+    p = g["problem"]
+    assert (p["m"], p["n"], len(p["values"])) == (27, 32, 83)
+    # pdlp_test.cu:58-84 : within 1 % of -464 at default tolerance
+    s = orcbind.solve(p)
+    assert s["status"] == "Optimal"
+    assert abs(s["primal_objective"] - (-464.0)) <= 0.01 * 464.0
+    # test_lp_solver.py:101-121 : -464.7531 (rel 1e-6) at 1e-12 tolerances; oracle run at 1e-10
+    s = orcbind.solve(p, tol=1e-10)
+    assert s["status"] == "Optimal"
+    assert s["primal_objective"] == pytest.approx(-464.7531, rel=1e-6)
+    assert s["primal_objective"] == pytest.approx(g["meta"]["reference_dual_simplex"]["objective"], rel=1e-7)
+
+
+def test_afiro_initial_step_size_and_primal_weight(golden_problems):
+    """pdlp_test.cu:237-239,276-283: Methodical1 (Ruiz x5 + Pock-Chambolle 1.0), 0 iterations."""
+    p = golden_problems["afiro"]["problem"]
+    h = orcbind.hyper_preset(2)
+    h[orcbind.H["ORC_H_RESTART_STRATEGY"]] = 1  # the restart flavour is irrelevant at iteration 0
+    s = orcbind.solve(p, hyper=h, iteration_limit=0)
+    assert s["initial_step_size"] == pytest.approx(1.4893, abs=1e-4)
+    assert s["initial_primal_weight"] == pytest.approx(0.0141652, abs=1e-4)
+
+
+def test_iteration_limit_status(golden_problems):
+    p = golden_problems["afiro"]["problem"]
+    s = orcbind.solve(p, tol=0.0, iteration_limit=10)  # pdlp_test.cu:134-157
+    assert s["status"] == "IterationLimit" and np.abs(s["x"]).sum() > 0
+    s = orcbind.solve(p, iteration_limit=1)  # c_api_tests.cpp:73-80
+    assert s["status"] == "IterationLimit"
+
+
+@pytest.mark.parametrize("name", ["good-max", "max_offset", "mip-sample-relaxation",
+                                  "mip-bb_optimality-relaxation", "good-mps-1", "lp_model_with_var_bounds"])
+def test_small_lps_match_reference_dual_simplex(golden_problems, name):
+    g = golden_problems[name]
+    s = orcbind.solve(g["problem"])
+    assert s["status"] == "Optimal"
+    ref = g["meta"]["reference_dual_simplex"]["objective"]
+    assert s["primal_objective"] == pytest.approx(ref, abs=2e-3 * (1 + abs(ref)))
+    if "pinned_objective" in g["meta"]:  # pdlp_test.cu:909-943: +-1e-4 ... at default tolerance
+        assert s["primal_objective"] == pytest.approx(g["meta"]["pinned_objective"], abs=1e-3)
+
+
+def test_ranged_lp_from_c_api_test():
+    """c_api_test.c:761-873: max 5x+8y, 2x+3y<=12, 3x+y<=6, 2<=x+2y<=8, 0<=x,y<=10 -> 32 +-1e-3"""
+    p = dict(m=3, n=2, offsets=[0, 2, 4, 6], indices=[0, 1, 0, 1, 0, 1], values=[2.0, 3.0, 3.0, 1.0, 1.0, 2.0],
+             c=[5.0, 8.0], lo=[-INF, -INF, 2.0], hi=[12.0, 6.0, 8.0], lb=[0.0, 0.0], ub=[10.0, 10.0],
+             maximize=True, objective_offset=0.0)
+    s = orcbind.solve(p)
+    assert s["status"] == "Optimal"
+    assert s["primal_objective"] == pytest.approx(32.0, abs=1e-3 * 33)
+
+
+def test_per_constraint_residual_identity_lp():
+    """pdlp_test.cu:633-715: 3x3 identity, x fixed by bounds at (0.02, 0.03, 0.1), rhs 0:
+    the L2 test at tol 0.1 passes only per-constraint when the max residual is 0.1."""
+    p = dict(m=3, n=3, offsets=[0, 1, 2, 3], indices=[0, 1, 2], values=[1.0, 1.0, 1.0], c=[0.0, 0.0, 0.0],
+             lo=[0.0, 0.0, 0.0], hi=[0.0, 0.0, 0.0], lb=[0.02, 0.03, 0.1], ub=[0.02, 0.03, 0.1])
+    ev = orcbind.evaluate(p, np.array([0.02, 0.03, 0.1]), np.zeros(3), rel_primal_tol=0.0)
+    assert ev["linf_rel_primal_residual"] == pytest.approx(0.1, abs=1e-15)
+    assert ev["l2_primal_residual"] == pytest.approx(np.sqrt(0.02 ** 2 + 0.03 ** 2 + 0.1 ** 2))
+
+
+def test_trivially_optimal_lp_returns_at_iteration_two():
+    """test_lp_solver.py:56-87: 2x1 toy LP with optimum x=0: all stats 0, Optimal."""
+    p = dict(m=2, n=1, offsets=[0, 1, 2], indices=[0, 0], values=[1.0, 1.0], c=[0.0], lo=[-INF, -INF],
+             hi=[1.0, 1.0], lb=[0.0], ub=[INF])
+    s = orcbind.solve(p)
+    assert s["status"] == "Optimal" and s["steps_taken"] == 2
+    assert s["primal_objective"] == 0.0 and np.all(s["x"] == 0.0)
+
+
+def test_empty_constraint_matrix_is_numerical_error():
+    """pdlp_test.cu:875-889 / LP/solve.cu:355-359"""
+    p = dict(m=0, n=2, offsets=[0], indices=[], values=[], c=[1.0, 1.0], lo=[], hi=[], lb=[0.0, 0.0], ub=[1.0, 1.0])
+    assert orcbind.solve(p)["status"] == "NumericalError"
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_reference_dual_simplex_live(golden_problems):
+    for name, g in golden_problems.items():
+        live = refbind.dual_simplex(g["problem"])
+        assert live["status"] == "OPTIMAL"
+        assert live["objective"] == pytest.approx(g["meta"]["reference_dual_simplex"]["objective"], abs=1e-9)
+
+
+def test_synthetic_family_known_optimum():
+    from cuopt_amd import synthetic
+    p = synthetic.generate(2000, 2000, 10, seed=3)
+    # strong duality of the construction
+    dual = float(np.where(np.isfinite(p["lo"]), p["lo"], 0.0) @ p["y_star"])
+    assert dual == pytest.approx(p["objective_star"], rel=1e-10, abs=1e-10)
+    s = orcbind.solve(p)
+    assert s["status"] == "Optimal"
+    assert s["primal_objective"] == pytest.approx(p["objective_star"], abs=1e-3 * (1 + abs(p["objective_star"])) * 10)
