@@ -158,13 +158,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orcbind
         if orcbind.available():
-            cores = os.cpu_count() or 1
-            budget = {"c3": 40, "hard": 40, "c2": 400, "tiny": 4000}[args.workload]
+            cores = orcbind.default_threads(16)
+            # calibrate on 4 iterations, then size the sample to ~15 s of loop time (bounded)
+            o = orcbind.solve(p, tol=0.0, iteration_limit=4, num_threads=cores)
+            per_it = max(o["loop_seconds"] / max(o["steps_taken"], 1.0), 1e-6)
+            budget = int(min(max(15.0 / per_it, 8), 4000))
             o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
             cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
-                       kind="port", sample="oracle/pdlp_oracle.c PDLP loop (OpenMP), %d iterations of the same LP, "
-                       "loop %.2fs + setup %.2fs" % (o["steps_taken"], o["loop_seconds"],
-                                                    o["solve_seconds"] - o["loop_seconds"]))
+                       kind="port", sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d threads), %d iterations of the same "
+                       "LP: loop %.2fs + setup %.2fs" % (cores, o["steps_taken"], o["loop_seconds"],
+                                                       o["solve_seconds"] - o["loop_seconds"]))
 
     if rank == 0:
         info = capi.device_info(local_rank)

@@ -418,7 +418,7 @@ def solve(problem, settings=None, **params):
             out["solve_time"] = d.value
             res = Result()
             lib.cuOptAmdGetPdlpStats(sol, C.byref(res))
-            out.update(res.as_dict())
+            out.update({k: v for k, v in res.as_dict().items() if k != "status"})
             out.update(x=x, y=y, reduced_cost=z)
     finally:
         if sol:

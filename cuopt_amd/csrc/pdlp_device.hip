@@ -425,21 +425,25 @@ k_step_stats(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, const double* 
 //     compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188),
 //     the accept/flip of update_solution (pdhg.cu:237-250) and add_weight_sums
 //     (weighted_average_solution.cu:63-71).
-__global__ void __launch_bounds__(kBlock)
+constexpr int kDecisionThreads = 1024;  // one wide workgroup: every partial is one independent load
+__global__ void __launch_bounds__(kDecisionThreads)
 k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
                 const double* __restrict__ part_t, int nb_t, const double* __restrict__ dy2_reduced,
                 pdlpdev_step_params sp)
 {
-  __shared__ double red[16];
+  __shared__ double red[3 * kDecisionThreads / 64];
   if (!loop_active(ctl)) return;
   double acc[3] = {0.0, 0.0, 0.0};
-  if (dy2_reduced == nullptr)
-    for (int i = threadIdx.x; i < nb_dy; i += kBlock) acc[0] += part_dy[i];
-  for (int i = threadIdx.x; i < nb_t; i += kBlock) {
+  if (dy2_reduced == nullptr) {
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
+  }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < nb_t; i += kDecisionThreads) {
     acc[1] += part_t[i];
     acc[2] += part_t[nb_t + i];
   }
-  block_reduce<SumOp, 3>(acc, red);
+  block_reduce<SumOp, 3, kDecisionThreads / 64>(acc, red);
   if (threadIdx.x != 0) return;
   const double dy2         = dy2_reduced ? dy2_reduced[0] : acc[0];
   const double interaction = acc[1];
@@ -1085,7 +1089,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   k_spmv_a_dual<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
   if (!ctx->comm) {
     k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
-    k_step_decision<<<1, kBlock, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
+    k_step_decision<<<1, kDecisionThreads, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
   } else {
     // partial A^T y' of this row block -> ar_buf[0..n), ||dy||^2 partial -> ar_buf[n]; ONE all-reduce
     k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], ctx->ar_buf, 1);
@@ -1094,7 +1098,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)n + 1, rccl::kSum));
     const int g = std::min(grid_for(n), kGenericBlocks);
     k_step_stats<<<g, kBlock, 0, s>>>(n, g, ctx->ctl, ctx->ar_buf, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_g);
-    k_step_decision<<<1, kBlock, 0, s>>>(ctx->ctl, nullptr, 0, ctx->part_g, g, ctx->ar_buf + n, ctx->sp);
+    k_step_decision<<<1, kDecisionThreads, 0, s>>>(ctx->ctl, nullptr, 0, ctx->part_g, g, ctx->ar_buf + n, ctx->sp);
   }
   LAUNCH_CHECK();
   return 0;
@@ -1372,7 +1376,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
         k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
         break;
       case PDLPDEV_K_STEP_DECISION:
-        k_step_decision<<<1, kBlock, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
+        k_step_decision<<<1, kDecisionThreads, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
         HIP_TRY(hipMemcpyAsync(ctx->ctl, &forced, sizeof(forced), hipMemcpyHostToDevice, s));
         break;
       case PDLPDEV_K_SPMV_A_PLAIN:

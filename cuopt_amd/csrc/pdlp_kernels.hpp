@@ -57,8 +57,8 @@ __device__ __forceinline__ double wave_reduce(double v)
 }
 
 // result valid in thread 0 (and broadcast through `scratch[0..NQ)` after the trailing barrier)
-template <class Op, int NQ>
-__device__ __forceinline__ void block_reduce(double (&v)[NQ], double* scratch /* >= 4*NQ */)
+template <class Op, int NQ, int WAVES = kBlock / 64>
+__device__ __forceinline__ void block_reduce(double (&v)[NQ], double* scratch /* >= WAVES*NQ */)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -71,7 +71,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[NQ], double* scratch /*
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       double acc = scratch[q];
-      for (int w = 1; w < kBlock / 64; ++w) acc = Op::apply(acc, scratch[w * NQ + q]);
+      for (int w = 1; w < WAVES; ++w) acc = Op::apply(acc, scratch[w * NQ + q]);
       v[q] = acc;
     }
   }

@@ -62,6 +62,14 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def default_threads(cap=8):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(cap, avail))
+
+
 def hyper_preset(mode=1):
     h = np.zeros(H["ORC_H_COUNT"])
     lib().orc_hyper_preset(int(mode), _p(h))
@@ -132,6 +140,9 @@ def solve(p, mode=1, hyper=None, init_x=None, init_y=None, **settings):
     m, n = int(p["m"]), int(p["n"])
     h = hyper_preset(mode) if hyper is None else _f64(hyper)
     s = default_settings()
+    # never let OpenMP spawn one thread per *visible* CPU: on cgroup-limited hosts that is a
+    # pathological oversubscription.  Default: at most 8 threads (override with num_threads=...).
+    settings.setdefault("num_threads", default_threads())
     if "tol" in settings:
         s[:6] = settings.pop("tol")
     for k, v in settings.items():
