@@ -1,0 +1,92 @@
+"""CPU, 2 processes over gloo: the row-block sharding math of the multi-GPU path.
+
+The product's collectives run on RCCL inside libcuopt.so and need GPUs; what can be pinned on CPU is
+the decomposition itself, with the C oracle standing in for the per-rank kernels:
+  * cuoptamd_partition_rows + per-rank CSR slice + per-rank explicit transpose (product host code),
+  * A x is rank-local given a replicated x; A^T y = sum over ranks of (A_block)^T y_block  -> ONE sum
+    all-reduce of n doubles; column inf-norms (Ruiz) -> max all-reduce; dual-side dot products -> sum,
+  * the all-reduced quantities equal the unsharded ones (exactly for max, to rounding for sums)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuopt_amd import capi, synthetic
+    from oracle import orcbind
+    p = synthetic.generate(3001, 2500, 7, seed=21)
+    m, n = p["m"], p["n"]
+    bounds = capi.partition_rows(m, p["offsets"], world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    k0, k1 = int(p["offsets"][r0]), int(p["offsets"][r1])
+    off = (p["offsets"][r0:r1 + 1] - k0).astype(np.int32)
+    idx, val = p["indices"][k0:k1], p["values"][k0:k1]
+    to, ti, tv = capi.csr_transpose(r1 - r0, n, off, idx, val)
+    rng = np.random.default_rng(5)  # same on every rank: replicated primal side
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    # local A x (no communication)
+    ax_local = orcbind.spmv(off, idx, val, x)
+    # partial A^T y + all-reduce
+    aty = torch.from_numpy(orcbind.spmv(to, ti, tv, y[r0:r1]))
+    dist.all_reduce(aty, op=dist.ReduceOp.SUM)
+    # Ruiz column inf-norm: local max over the row block + max all-reduce
+    colmax = np.zeros(n)
+    np.maximum.at(colmax, idx, np.abs(val))
+    colmax = torch.from_numpy(colmax)
+    dist.all_reduce(colmax, op=dist.ReduceOp.MAX)
+    # a dual-side dot product
+    dy2 = torch.tensor([float(y[r0:r1] @ y[r0:r1])], dtype=torch.float64)
+    dist.all_reduce(dy2, op=dist.ReduceOp.SUM)
+    # gather A x pieces for the check
+    pieces = [None] * world
+    dist.all_gather_object(pieces, (r0, r1, ax_local))
+    if rank == 0:
+        tof, tif, tvf = orcbind.transpose(m, n, p["offsets"], p["indices"], p["values"])
+        ax = np.concatenate([q[2] for q in sorted(pieces, key=lambda q: q[0])])
+        cm = np.zeros(n)
+        np.maximum.at(cm, p["indices"], np.abs(p["values"]))
+        out.put(dict(bounds=bounds.tolist(),
+                     ax_equal=bool(np.array_equal(ax, orcbind.spmv(p["offsets"], p["indices"], p["values"], x))),
+                     aty_err=float(np.max(np.abs(aty.numpy() - orcbind.spmv(tof, tif, tvf, y)))),
+                     colmax_equal=bool(np.array_equal(colmax.numpy(), cm)),
+                     dy2_err=float(abs(dy2.item() - y @ y)), nnz=[int(p["offsets"][b]) for b in bounds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_row_block_sharding_reproduces_unsharded_products(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for q in procs:
+        q.start()
+    res = out.get(timeout=120)
+    for q in procs:
+        q.join(timeout=60)
+        assert q.exitcode == 0
+    assert res["bounds"][0] == 0 and res["bounds"][-1] == 3001
+    per = np.diff(res["nnz"])
+    assert per.max() - per.min() <= 7  # balanced by nonzeros to within one row
+    assert res["ax_equal"] and res["colmax_equal"]
+    assert res["aty_err"] < 1e-12 and res["dy2_err"] < 1e-9
