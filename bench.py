@@ -38,8 +38,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
+    ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel"], help="CUOPT_AMD_SPMV_LAYOUT")
     args = ap.parse_args()
 
+    if args.spmv_layout:
+        os.environ["CUOPT_AMD_SPMV_LAYOUT"] = args.spmv_layout
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +99,7 @@ def main():
     setup_s = solver.advance(0)["setup_seconds"]
     solver.advance(args.warmup)
     dev = solver.device
+    layout = dev.layout()
     dev.call("synchronize")
     barrier()
     t0 = time.perf_counter()
@@ -182,7 +186,7 @@ def main():
                        "rows": m, "cols": n, "nnz": nnz,
                        "parallelism": "row-block x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
-            "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
+            "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"],
         }
         print(json.dumps(out), flush=True)

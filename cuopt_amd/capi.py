@@ -208,6 +208,7 @@ _proto("pdlpdev_spmv", c_int, c_void_p, c_int, c_void_p, c_void_p)
 _proto("pdlpdev_time_kernel", c_int, c_void_p, c_int, c_int, P(c_double))
 _proto("pdlpdev_synchronize", c_int, c_void_p)
 _proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
+_proto("pdlpdev_layout_info", c_int, c_void_p, c_void_p)
 
 # ids of pdlp_device.h
 BUF = {n: i for i, n in enumerate(
@@ -601,6 +602,12 @@ class Device:
         out = np.zeros(3)
         self._ck(lib.pdlpdev_init_norms(self.handle, _ptr(out)))
         return out
+
+    def layout(self):
+        out = np.zeros(6, np.int32)
+        self._ck(lib.pdlpdev_layout_info(self.handle, _ptr(out)))
+        return dict(A=dict(panels=bool(out[0]), workgroups=int(out[1]), slabs=int(out[2])),
+                    At=dict(panels=bool(out[3]), workgroups=int(out[4]), slabs=int(out[5])))
 
     def time_kernel(self, kernel, reps=20):
         ms = c_double()

@@ -94,6 +94,13 @@ struct pdlpdev_ctx {
   double *a_val = nullptr, *at_val = nullptr;
   int32_t *a_rb = nullptr, *at_rb = nullptr;  // row-block boundaries of the stream kernels
   int a_nb = 0, at_nb = 0;
+  // slab-major row panels (optional second layout of the same nonzeros, see pdlp_kernels.hpp)
+  struct Panels {
+    bool on = false;
+    PanelView v{};
+    int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
+    double* val   = nullptr;
+  } pa, pat;
   // problem vectors: scaled working copies and the unscaled originals
   double *c = nullptr, *lb = nullptr, *ub = nullptr, *lo = nullptr, *hi = nullptr;
   double *c_u = nullptr, *lb_u = nullptr, *ub_u = nullptr, *lo_u = nullptr, *hi_u = nullptr;
@@ -487,6 +494,36 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   }
 }
 
+// panel-layout twins of (2) and (3): same epilogues, slab-major gather (pdlp_kernels.hpp)
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
+               double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
+               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part)
+{
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
+                 ctl->pending_avg != 0};
+  panel_spmv_block(P, xbar, e, part);
+}
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
+                const double* __restrict__ y1, const double* __restrict__ x0,
+                const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
+                double* __restrict__ part)
+{
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
+  panel_spmv_block(P, cur ? y0 : y1 /* y' */, e, part);
+}
+__global__ void __launch_bounds__(kBlock)
+k_permute(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
+{
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    dst[i] = src[perm[i]];
+}
+
 // deferred averaging made explicit (called before a major iteration consumes the sums)
 __global__ void __launch_bounds__(kBlock)
 k_flush_average(int n, int m, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0,
@@ -783,6 +820,84 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
   return rb;
 }
 
+
+// ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
+struct PanelHost {
+  bool ok = false;
+  int W = 0, S = 0;
+  std::vector<int32_t> row0, tile_ptr, perm, col;
+  std::vector<uint16_t> rowptr;
+  std::vector<int64_t> rp_base;
+};
+static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
+                              int64_t slab_bytes, bool force)
+{
+  PanelHost P;
+  const int64_t nnz = off[rows];
+  if (rows <= 0 || cols <= 0 || nnz <= 0) return P;
+  // worth it only when the gathered vector overflows an XCD's L2 (4 MiB, shared with the matrix stream)
+  if (!force && (int64_t)cols * 8 <= 2 * (int64_t)1048576) return P;
+  int S = (int)(((int64_t)cols * 8 + slab_bytes - 1) / slab_bytes);
+  S     = std::max(1, std::min(S, 16));
+  const int32_t slab_w = (cols + S - 1) / S;
+  // panels: ~20K nonzeros each (two 512-thread workgroups per CU, 512 panels fill the chip at 1e7 nnz),
+  // at most kPanelMaxRows rows
+  const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(20000, (nnz + 511) / 512));
+  P.row0.push_back(0);
+  int32_t start = 0;
+  while (start < rows) {
+    int32_t end = start;
+    int64_t cnt = 0;
+    while (end < rows && end - start < kPanelMaxRows && cnt < target) {
+      cnt += off[end + 1] - off[end];
+      ++end;
+    }
+    P.row0.push_back(end);
+    start = end;
+  }
+  const int W = (int)P.row0.size() - 1;
+  P.W = W, P.S = S;
+  // pass 1: nonzeros per (panel, slab)
+  std::vector<int64_t> count((size_t)W * S + 1, 0);
+  for (int w = 0; w < W; ++w)
+    for (int64_t t = off[P.row0[w]]; t < off[P.row0[w + 1]]; ++t) count[(size_t)w * S + idx[t] / slab_w] += 1;
+  P.tile_ptr.resize((size_t)W * S + 1);
+  int64_t pos = 0;
+  for (size_t i = 0; i < (size_t)W * S; ++i) {
+    if (count[i] >= 65536) return P;  // 16-bit row pointers would overflow: keep the CSR stream layout
+    P.tile_ptr[i] = (int32_t)pos;
+    pos += count[i];
+  }
+  P.tile_ptr[(size_t)W * S] = (int32_t)pos;
+  // pass 2: placement + per-tile row pointers
+  P.perm.resize(nnz), P.col.resize(nnz);
+  P.rp_base.resize((size_t)W * S);
+  P.rowptr.resize((size_t)S * ((size_t)rows + W));
+  std::vector<int32_t> cursor(S);
+  int64_t rp = 0;
+  for (int w = 0; w < W; ++w) {
+    const int32_t a = P.row0[w], b = P.row0[w + 1], nr = b - a;
+    for (int s2 = 0; s2 < S; ++s2) {
+      cursor[s2]                    = P.tile_ptr[(size_t)w * S + s2];
+      P.rp_base[(size_t)w * S + s2] = rp + (int64_t)s2 * (nr + 1);
+    }
+    for (int32_t i = a; i < b; ++i) {
+      for (int s2 = 0; s2 < S; ++s2)
+        P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + (i - a))] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
+      for (int32_t t = off[i]; t < off[i + 1]; ++t) {
+        const int s2 = idx[t] / slab_w;
+        const int32_t q = cursor[s2]++;
+        P.perm[q] = t, P.col[q] = idx[t];
+      }
+    }
+    for (int s2 = 0; s2 < S; ++s2)
+      P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + nr)] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
+    rp += (int64_t)S * (nr + 1);
+  }
+  P.ok = true;
+  return P;
+}
+
 static int upload_i32(pdlpdev_ctx* c, int32_t** dst, const int32_t* src, size_t count)
 {
   TRY(dev_alloc(c, dst, count));
@@ -794,6 +909,36 @@ static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t co
   TRY(dev_alloc(c, dst, count));
   if (count && src)
     HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+
+static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h)
+{
+  if (!h.ok) return 0;
+  int32_t *row0 = nullptr, *tile_ptr = nullptr, *col = nullptr;
+  uint16_t* rowptr = nullptr;
+  int64_t* rp_base = nullptr;
+  TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
+  TRY(upload_i32(c, &tile_ptr, h.tile_ptr.data(), h.tile_ptr.size()));
+  TRY(upload_i32(c, &col, h.col.data(), h.col.size()));
+  TRY(upload_i32(c, &dst->perm, h.perm.data(), h.perm.size()));
+  TRY(dev_alloc(c, &rowptr, h.rowptr.size()));
+  HIP_TRY(hipMemcpyAsync(rowptr, h.rowptr.data(), h.rowptr.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &rp_base, h.rp_base.size()));
+  HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &dst->val, h.perm.size()));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
+  dst->v  = PanelView{h.W, h.S, row0, tile_ptr, rowptr, rp_base, col, dst->val};
+  dst->on = true;
+  return 0;
+}
+// panel values <- current CSR values (after upload and again after scale_problem)
+static int sync_panel_values(pdlpdev_ctx* c)
+{
+  if (c->pa.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pa.perm, c->a_val, c->pa.val);
+  if (c->pat.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pat.perm, c->at_val, c->pat.val);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -858,8 +1003,22 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(dev_alloc(ctx, &ctx->avgx, n)); TRY(dev_alloc(ctx, &ctx->avgy, m));
   TRY(dev_alloc(ctx, &ctx->lrx, n)); TRY(dev_alloc(ctx, &ctx->lry, m));
   TRY(dev_alloc(ctx, &ctx->tmp_n, n)); TRY(dev_alloc(ctx, &ctx->tmp_m, m));
-  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max(ctx->a_nb, 1)));
-  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max(ctx->at_nb, 1)));
+  {
+    // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel ; CUOPT_AMD_SLAB_BYTES (default 1 MiB)
+    const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
+    const std::string mode = mode_env ? mode_env : "auto";
+    const char* slab_env   = getenv("CUOPT_AMD_SLAB_BYTES");
+    const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1048576;
+    if (mode != "stream") {
+      const bool force = mode == "panel";
+      PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force);
+      TRY(upload_panels(ctx, &ctx->pa, ha));
+      PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force);
+      TRY(upload_panels(ctx, &ctx->pat, hat));
+    }
+  }
+  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max(std::max(ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0), 1)));
+  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max(std::max(ctx->at_nb, ctx->pat.on ? ctx->pat.v.W : 0), 1)));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
@@ -869,6 +1028,7 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
   HIP_TRY(hipGetLastError());
+  TRY(sync_panel_values(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -970,6 +1130,7 @@ int pdlpdev_scale_problem(pdlpdev_ctx* ctx)
   k_scale_vectors<<<grid_for(std::max(ctx->m, ctx->n)), kBlock, 0, s>>>(ctx->n, ctx->m, ctx->c, ctx->lb, ctx->ub, ctx->dc, ctx->lo, ctx->hi, ctx->dr);
   LAUNCH_CHECK();
   ctx->scaled = true;
+  TRY(sync_panel_values(ctx));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
@@ -1080,20 +1241,45 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
   return 0;
 }
 
+
+// launch helpers: pick the layout (slab-major panels when built, CSR stream otherwise)
+static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
+static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
+static void launch_a_dual(pdlpdev_ctx* ctx)
+{
+  hipStream_t s = ctx->stream;
+  if (ctx->pa.on)
+    k_panel_a_dual<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+  else
+    k_spmv_a_dual<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+}
+static void launch_at_step(pdlpdev_ctx* ctx)
+{
+  hipStream_t s = ctx->stream;
+  if (ctx->pat.on)
+    k_panel_at_step<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+  else
+    k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+}
+static void launch_decision(pdlpdev_ctx* ctx)
+{
+  k_step_decision<<<1, kDecisionThreads, 0, ctx->stream>>>(ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at, step_partials(ctx), nullptr, ctx->sp);
+}
+
 // one PDHG attempt = 4 launches (single GPU) on ctx->stream
 static int enqueue_attempt(pdlpdev_ctx* ctx)
 {
   hipStream_t s = ctx->stream;
   const int n = ctx->n;
   k_primal<<<grid_for(n), kBlock, 0, s>>>(n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
-  k_spmv_a_dual<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+  launch_a_dual(ctx);
   if (!ctx->comm) {
-    k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
-    k_step_decision<<<1, kDecisionThreads, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
+    launch_at_step(ctx);
+    launch_decision(ctx);
   } else {
     // partial A^T y' of this row block -> ar_buf[0..n), ||dy||^2 partial -> ar_buf[n]; ONE all-reduce
     k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], ctx->ar_buf, 1);
-    k_sum_partials_to<<<1, kBlock, 0, s>>>(ctx->part_a, ctx->a_nb, ctx->ar_buf + n);
+    k_sum_partials_to<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), ctx->ar_buf + n);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)n + 1, rccl::kSum));
     const int g = std::min(grid_for(n), kGenericBlocks);
@@ -1369,14 +1555,10 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
       case PDLPDEV_K_PRIMAL:
         k_primal<<<grid_for(ctx->n), kBlock, 0, s>>>(ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
         break;
-      case PDLPDEV_K_SPMV_A_DUAL:
-        k_spmv_a_dual<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
-        break;
-      case PDLPDEV_K_SPMV_AT_STEP:
-        k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
-        break;
+      case PDLPDEV_K_SPMV_A_DUAL: launch_a_dual(ctx); break;
+      case PDLPDEV_K_SPMV_AT_STEP: launch_at_step(ctx); break;
       case PDLPDEV_K_STEP_DECISION:
-        k_step_decision<<<1, kDecisionThreads, 0, s>>>(ctx->ctl, ctx->part_a, ctx->a_nb, ctx->part_at, ctx->at_nb, nullptr, ctx->sp);
+        launch_decision(ctx);
         HIP_TRY(hipMemcpyAsync(ctx->ctl, &forced, sizeof(forced), hipMemcpyHostToDevice, s));
         break;
       case PDLPDEV_K_SPMV_A_PLAIN:
@@ -1414,5 +1596,11 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
   return 0;
 }
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
+int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
+{
+  out[0] = ctx->pa.on ? 1 : 0, out[1] = ctx->pa.on ? ctx->pa.v.W : ctx->a_nb, out[2] = ctx->pa.on ? ctx->pa.v.S : 1;
+  out[3] = ctx->pat.on ? 1 : 0, out[4] = ctx->pat.on ? ctx->pat.v.W : ctx->at_nb, out[5] = ctx->pat.on ? ctx->pat.v.S : 1;
+  return 0;
+}
 
 }  // extern "C"

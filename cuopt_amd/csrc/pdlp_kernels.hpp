@@ -164,6 +164,87 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Slab-major row panels: the SpMV used when the gathered vector does not fit an XCD's 4 MiB L2.
+// Measured on the 1e6 x 1e6 random LP (profiles/r01_spmv_tuning_table.txt): the CSR stream kernel is
+// bound by the gather (48 % L2 hit rate, ~4.3x the algorithmic bytes fetched from the fabric); walking
+// the columns in L2-sized slabs takes the SpMV from 105 us to ~75 us.
+//   * workgroup w owns the contiguous row panel [row0[w], row0[w+1]) (balanced by nonzeros,
+//     <= kPanelMaxRows rows so that one partial sum per row lives in LDS);
+//   * the panel's nonzeros are stored slab by slab (slab = column range of ~1 MiB of the gathered
+//     vector), rows ascending inside a slab, CSR order inside a (row, slab) cell -> with sorted CSR
+//     columns every row is still summed strictly left to right (bit-identical to the oracle);
+//   * every workgroup walks the slabs in the same order at the same pace (equal work per panel), so at
+//     any moment an XCD's gathers fall into one slab that its L2 holds; no synchronisation is needed
+//     for correctness;
+//   * rowptr is 16-bit, relative to the tile start (tiles hold < 65536 nonzeros by construction).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPanelThreads = 512;
+constexpr int kPanelChunk   = 4096;   // nonzeros staged per pass (32 KiB of products)
+constexpr int kPanelMaxRows = 3584;   // 28 KiB of per-row partial sums
+constexpr int kPanelWaves   = kPanelThreads / 64;
+
+struct PanelView {
+  int W, S;
+  const int32_t* __restrict__ row0;      // W+1
+  const int32_t* __restrict__ tile_ptr;  // W*S+1, positions in the permuted nonzero arrays
+  const uint16_t* __restrict__ rowptr;   // per tile: (rows_w + 1) offsets relative to the tile start
+  const int64_t* __restrict__ rp_base;   // W*S: where each tile's rowptr starts
+  const int32_t* __restrict__ col;       // permuted column indices
+  const double* __restrict__ val;        // permuted values
+};
+
+template <class Epi>
+__device__ __forceinline__ void panel_spmv_block(const PanelView& P, const double* __restrict__ vec,
+                                                 Epi& epi, double* __restrict__ partials)
+{
+  __shared__ double prod[kPanelChunk];
+  __shared__ double psum[kPanelMaxRows];
+  __shared__ double red[kPanelWaves * (Epi::NQ > 0 ? Epi::NQ : 1)];
+  const int w  = blockIdx.x;
+  const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
+  for (int s = 0; s < P.S; ++s) {
+    const int t0 = P.tile_ptr[w * P.S + s], t1 = P.tile_ptr[w * P.S + s + 1];
+    const uint16_t* __restrict__ rp = P.rowptr + P.rp_base[w * P.S + s];
+    for (int c0 = t0; c0 < t1; c0 += kPanelChunk) {
+      const int c1 = c0 + kPanelChunk < t1 ? c0 + kPanelChunk : t1;
+      __syncthreads();
+#pragma unroll 4
+      for (int k = c0 + threadIdx.x; k < c1; k += kPanelThreads) {
+        const double a = __builtin_nontemporal_load(P.val + k);
+        const int j    = __builtin_nontemporal_load(P.col + k);
+        prod[k - c0]   = a * vec[j];
+      }
+      __syncthreads();
+      const int lo = c0 - t0, hi = c1 - t0;
+      for (int r = threadIdx.x; r < nr; r += kPanelThreads) {
+        int a = rp[r], b = rp[r + 1];
+        a = a > lo ? a : lo;
+        b = b < hi ? b : hi;
+        if (a < b) {
+          double sum = psum[r];
+          for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+          psum[r] = sum;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads) epi.row(r0 + r, psum[r], acc);
+  if constexpr (Epi::NQ > 0) {
+    block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
+    }
+  }
+}
+
 // ---- element-wise rules of the reference (LP/utils.cuh) -----------------------------------------
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }

@@ -214,6 +214,10 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
 int pdlpdev_synchronize(pdlpdev_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
+/* SpMV layout actually in use: out = {A: panels?(0/1), workgroups, slabs, A^T: panels?, workgroups, slabs}.
+ * Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default: slab-major row panels when the
+ * gathered vector exceeds 2 MiB, CSR stream otherwise) | stream | panel ; CUOPT_AMD_SLAB_BYTES (1 MiB). */
+int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6]);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,51 @@ __global__ void __launch_bounds__(256) k_sub(int rows, const int* __restrict__ o
   if (lane == 0) y[gid] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// slab-major row panels: workgroup w owns a contiguous row panel; its nonzeros are stored slab by slab
+// (column ranges of the gathered vector sized for the 4 MiB per-XCD L2); all workgroups walk the slabs
+// in the same order at the same pace, so at any time the gathers of an XCD fall into one slab.
+template <int T, int CH>
+__global__ void __launch_bounds__(T) k_slab(int S, const int* __restrict__ panel_row0, const int* __restrict__ tile_ptr,
+                                            const int* __restrict__ rowptr, const long* __restrict__ rp_base,
+                                            const int* __restrict__ col, const double* __restrict__ val,
+                                            const double* __restrict__ x, double* __restrict__ y)
+{
+  extern __shared__ double lds[];
+  double* prod = lds;
+  double* psum = lds + CH;
+  const int w = blockIdx.x, r0 = panel_row0[w], nr = panel_row0[w + 1] - r0;
+  for (int r = threadIdx.x; r < nr; r += T) psum[r] = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const int t0 = tile_ptr[w * S + s], t1 = tile_ptr[w * S + s + 1];
+    const int* __restrict__ rp = rowptr + rp_base[w * S + s];
+    for (int c0 = t0; c0 < t1; c0 += CH) {
+      const int c1 = c0 + CH < t1 ? c0 + CH : t1;
+      __syncthreads();
+#pragma unroll 4
+      for (int k = c0 + threadIdx.x; k < c1; k += T) {
+        const double a = __builtin_nontemporal_load(val + k);
+        const int j    = __builtin_nontemporal_load(col + k);
+        prod[k - c0]   = a * x[j];
+      }
+      __syncthreads();
+      for (int r = threadIdx.x; r < nr; r += T) {
+        int a = rp[r], b = rp[r + 1];
+        a = a > c0 ? a : c0;
+        b = b < c1 ? b : c1;
+        if (a < b) {
+          double sum = psum[r];
+          for (int k = a; k < b; ++k) sum = sum + prod[k - c0];
+          psum[r] = sum;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < nr; r += T) y[r0 + r] = psum[r];
+}
+
 // ---------------------------------------------------------------------------------------------------
 static std::vector<int> row_blocks(int rows, const std::vector<int>& off, int nnzb, int max_rows)
 {
@@ -229,6 +274,7 @@ int main(int argc, char** argv)
   CK(hipMemcpy(d_x, x.data(), cols * 8, hipMemcpyHostToDevice));
   const double bytes = 12.0 * nnz + 4.0 * (rows + 1) + 8.0 * cols + 8.0 * rows;
   Timer T;
+  Timer& T_ = T;
   std::vector<double> y(rows);
   auto report = [&](const char* name, double us, bool check) {
     long bad = 0;
@@ -309,6 +355,66 @@ int main(int argc, char** argv)
     snprintf(nm, sizeof nm, "column slabs x%d (rows<=1024/blk)", S);
     report(nm, us, true);
     for (int s2 = 0; s2 < S; ++s2) { CK(hipFree(doff[s2])); CK(hipFree(didx[s2])); CK(hipFree(dval[s2])); CK(hipFree(drb[s2])); }
+  }
+
+  // ---- slab-major row panels -----------------------------------------------------------------------------
+  for (int S : {1, 2, 4, 8}) for (int W : {256, 512, 1024}) {
+    const int SW = (cols + S - 1) / S;
+    std::vector<int> prow0(W + 1);
+    for (int w = 0; w <= W; ++w) {
+      long want = nnz * w / W;
+      prow0[w] = (int)(std::lower_bound(off.begin(), off.end(), (int)want) - off.begin());
+    }
+    prow0[W] = rows;
+    std::vector<int> tile_ptr((size_t)W * S + 1), pcol(nnz + 8, 0);
+    std::vector<double> pval(nnz + 8, 0.0);
+    std::vector<long> rp_base((size_t)W * S);
+    std::vector<int> rowptr;
+    rowptr.reserve((size_t)S * (rows + W));
+    long pos = 0;
+    int max_rows = 0;
+    for (int w = 0; w < W; ++w) {
+      const int a = prow0[w], b = prow0[w + 1];
+      max_rows = std::max(max_rows, b - a);
+      for (int s2 = 0; s2 < S; ++s2) {
+        tile_ptr[(size_t)w * S + s2] = (int)pos;
+        rp_base[(size_t)w * S + s2]  = (long)rowptr.size();
+        for (int i = a; i < b; ++i) {
+          rowptr.push_back((int)pos);
+          for (int t = off[i]; t < off[i + 1]; ++t)
+            if (idx[t] / SW == s2) pcol[pos] = idx[t], pval[pos] = val[t], ++pos;
+        }
+        rowptr.push_back((int)pos);
+      }
+    }
+    tile_ptr[(size_t)W * S] = (int)pos;
+    int *d_p0, *d_tp, *d_rp, *d_pc; long* d_rb; double* d_pv;
+    CK(hipMalloc(&d_p0, prow0.size() * 4)); CK(hipMalloc(&d_tp, tile_ptr.size() * 4)); CK(hipMalloc(&d_rp, rowptr.size() * 4));
+    CK(hipMalloc(&d_pc, pcol.size() * 4)); CK(hipMalloc(&d_rb, rp_base.size() * 8)); CK(hipMalloc(&d_pv, pval.size() * 8));
+    CK(hipMemcpy(d_p0, prow0.data(), prow0.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tp, tile_ptr.data(), tile_ptr.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_rp, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pc, pcol.data(), pcol.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_rb, rp_base.data(), rp_base.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pv, pval.data(), pval.size() * 8, hipMemcpyHostToDevice));
+    for (int T : {512, 1024}) {
+      constexpr int CH = 4096;
+      const size_t lds = (size_t)(CH + max_rows) * 8;
+      if (lds > 160 * 1024) continue;
+      CK(hipMemset(d_y, 0, rows * 8));
+      double us;
+      if (T == 512) {
+        CK(hipFuncSetAttribute((const void*)k_slab<512, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        us = T_.run([&] { k_slab<512, CH><<<W, 512, lds>>>(S, d_p0, d_tp, d_rp, d_rb, d_pc, d_pv, d_x, d_y); }, reps);
+      } else {
+        CK(hipFuncSetAttribute((const void*)k_slab<1024, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        us = T_.run([&] { k_slab<1024, CH><<<W, 1024, lds>>>(S, d_p0, d_tp, d_rp, d_rb, d_pc, d_pv, d_x, d_y); }, reps);
+      }
+      char nm[96];
+      snprintf(nm, sizeof nm, "slab-major S=%d W=%d T=%d lds=%zuK", S, W, T, lds / 1024);
+      report(nm, us, true);
+    }
+    CK(hipFree(d_p0)); CK(hipFree(d_tp)); CK(hipFree(d_rp)); CK(hipFree(d_pc)); CK(hipFree(d_rb)); CK(hipFree(d_pv));
   }
   {
     CK(hipMemset(d_y, 0, rows * 8));
