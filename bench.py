@@ -131,9 +131,22 @@ def main():
     }
     dom = "SPMV_A_DUAL" if kernels["SPMV_A_DUAL"] >= kernels["SPMV_AT_STEP"] else "SPMV_AT_STEP"
     achieved = bytes_alg[dom] / (kernels[dom] * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="k_spmv_a_dual" if dom == "SPMV_A_DUAL" else "k_spmv_at_step",
+    panel = layout["A" if dom == "SPMV_A_DUAL" else "At"]["panels"]
+    kname = ("k_panel_a_dual" if panel else "k_spmv_a_dual") if dom == "SPMV_A_DUAL" else \
+            ("k_panel_at_step" if panel else "k_spmv_at_step")
+    # HBM/fabric bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this very
+    # command (profiles/r01_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
+    # counters cannot be read from inside the process, so this is null for workloads without a profile
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.workload)))
+        if world == 1 and kname in pmc:
+            traffic = round(pmc[kname]["traffic_bytes_corrected"])
+    except Exception:
+        pass
+    roofline = dict(bound="hbm", kernel=kname,
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=bytes_alg[dom], avg_launch_ms=round(kernels[dom], 5),
                     per_kernel_ms={k: round(v, 5) for k, v in kernels.items()},
                     per_kernel_gbs={k: round(bytes_alg[k] / (kernels[k] * 1e-3) / 1e9, 1) for k in bytes_alg},

@@ -117,6 +117,25 @@ class Result(C.Structure):
         return d
 
 
+class WarmStart(C.Structure):
+    _fields_ = [(k, c_void_p) for k in (
+        "current_primal_solution", "current_dual_solution", "initial_primal_average",
+        "initial_dual_average", "current_ATY", "sum_primal_solutions", "sum_dual_solutions",
+        "last_restart_duality_gap_primal_solution", "last_restart_duality_gap_dual_solution")] + [
+        ("initial_primal_weight", c_double), ("initial_step_size", c_double),
+        ("total_pdlp_iterations", c_int), ("total_pdhg_iterations", c_int),
+        ("last_candidate_kkt_score", c_double), ("last_restart_kkt_score", c_double),
+        ("sum_solution_weight", c_double), ("iterations_since_last_restart", c_int)]
+
+    PRIMAL = ("current_primal_solution", "initial_primal_average", "current_ATY", "sum_primal_solutions",
+              "last_restart_duality_gap_primal_solution")
+    DUAL = ("current_dual_solution", "initial_dual_average", "sum_dual_solutions",
+            "last_restart_duality_gap_dual_solution")
+    SCALARS = ("initial_primal_weight", "initial_step_size", "total_pdlp_iterations", "total_pdhg_iterations",
+               "last_candidate_kkt_score", "last_restart_kkt_score", "sum_solution_weight",
+               "iterations_since_last_restart")
+
+
 def _struct_dict(s):
     return {k: getattr(s, k) for k, _ in s._fields_}
 
@@ -173,6 +192,8 @@ _proto("cuoptamd_solver_destroy", None, c_void_p)
 _proto("cuoptamd_solver_advance", c_int, c_void_p, c_int, P(Result))
 _proto("cuoptamd_solver_get_solution", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_solver_device", c_void_p, c_void_p)
+_proto("cuoptamd_solver_get_warm_start", c_int, c_void_p, P(WarmStart))
+_proto("cuoptamd_solver_set_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_solver_row_range", c_int, c_void_p, P(c_int), P(c_int))
 _proto("cuoptamd_partition_rows", None, c_int, c_void_p, c_int, c_void_p)
 _proto("cuoptamd_csr_transpose", None, c_int, c_int, *([c_void_p] * 6))
@@ -463,7 +484,7 @@ class Solver:
     """cuoptamd_solver: step-wise control of the PDLP loop (bench, warm-started re-solves, tests)."""
 
     def __init__(self, p, mode=1, hyper=None, settings=None, init_x=None, init_y=None, device=0,
-                 rank=0, world=1, comm_id=None, **setting_overrides):
+                 rank=0, world=1, comm_id=None, warm_start=None, **setting_overrides):
         self._keep = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]),
                           c=_f64(p["c"]), lo=_f64(p["lo"]), hi=_f64(p["hi"]), lb=_f64(p["lb"]),
                           ub=_f64(p["ub"]))
@@ -490,6 +511,36 @@ class Solver:
                 lib.cuoptamd_solver_destroy(h)
             raise CuOptError(rc, msg)
         self.result = Result()
+        if warm_start is not None:
+            self.set_warm_start(warm_start)
+
+    def get_warm_start(self):
+        """pdlp_warm_start_data_t of the terminated solve as a dict of numpy arrays / scalars"""
+        ws, arrays = WarmStart(), {}
+        for k in WarmStart.PRIMAL:
+            arrays[k] = np.zeros(self.n)
+        for k in WarmStart.DUAL:
+            arrays[k] = np.zeros(self.m)
+        for k, a in arrays.items():
+            setattr(ws, k, a.ctypes.data)
+        rc = lib.cuoptamd_solver_get_warm_start(self.handle, C.byref(ws))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        out = dict(arrays)
+        out.update({k: getattr(ws, k) for k in WarmStart.SCALARS})
+        return out
+
+    def set_warm_start(self, d):
+        ws, keep = WarmStart(), []
+        for k in WarmStart.PRIMAL + WarmStart.DUAL:
+            a = _f64(d[k])
+            keep.append(a)
+            setattr(ws, k, a.ctypes.data)
+        for k in WarmStart.SCALARS:
+            setattr(ws, k, d[k])
+        rc = lib.cuoptamd_solver_set_warm_start(self.handle, C.byref(ws))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
 
     def advance(self, iterations=2 ** 31 - 1):
         rc = lib.cuoptamd_solver_advance(self.handle, int(iterations), C.byref(self.result))

@@ -701,6 +701,34 @@ k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ 
   EvalDualEpilogue e{core};
   csr_stream_block(nb, rb, off, idx, val, yv, e, part);
 }
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
+                    const double* __restrict__ x0, const double* __restrict__ x1,
+                    const double* __restrict__ avgx, const double* __restrict__ y0,
+                    const double* __restrict__ y1, const double* __restrict__ avgy,
+                    const double* __restrict__ dr, const double* __restrict__ lo_u,
+                    const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows,
+                    double* __restrict__ part)
+{
+  const int cur = ctl->cur;
+  const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows};
+  panel_spmv_block(P, xv, e, part);
+}
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
+                  const double* __restrict__ x0, const double* __restrict__ x1,
+                  const double* __restrict__ avgx, const double* __restrict__ y0,
+                  const double* __restrict__ y1, const double* __restrict__ avgy, EvalDualCore core,
+                  double* __restrict__ part)
+{
+  const int cur = ctl->cur;
+  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  EvalDualEpilogue e{core};
+  panel_spmv_block(P, yv, e, part);
+}
 // multi-GPU: same per-column rule after the all-reduce of A^T y
 __global__ void __launch_bounds__(kBlock)
 k_eval_dual_elementwise(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, int which,
@@ -786,6 +814,13 @@ __global__ void k_set_step(pdlpdev_ctl* ctl, double step, double w)
 __global__ void k_set_target(pdlpdev_ctl* ctl, int target) { ctl->target_steps = target; }
 __global__ void k_set_k(pdlpdev_ctl* ctl, int k) { ctl->k = k; }
 __global__ void k_clear_error(pdlpdev_ctl* ctl) { ctl->error = 0; }
+__global__ void k_set_loop_state(pdlpdev_ctl* ctl, double sum_weights, int its_since_restart, int k)
+{
+  ctl->sum_weights       = sum_weights;
+  ctl->its_since_restart = its_since_restart;
+  ctl->k                 = k;
+  ctl->pending_avg       = 0;
+}
 
 // unscale for output: x = x^ * D_c, y = y^ * D_r (unscale_solutions, initial_scaling.cu:460-484)
 __global__ void __launch_bounds__(kBlock)
@@ -1384,8 +1419,11 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   hipStream_t s = ctx->stream;
   const int n = ctx->n, m = ctx->m;
   double* sc = ctx->scal;  // layout: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
-  k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->part_a);
-  k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, ctx->a_nb, 3, 0u, sc + 0);
+  if (ctx->pa.on)
+    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->part_a);
+  else
+    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->part_a);
+  k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
   {
     const int g = std::min(grid_for(m), kGenericBlocks);
     k_max_partials<<<g, kBlock, 0, s>>>(m, ctx->tmp_m, ctx->part_g);
@@ -1393,8 +1431,11 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   }
   EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n};
   if (!ctx->comm) {
-    k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
-    k_finalize<<<1, kBlock, 0, s>>>(ctx->part_at, ctx->at_nb, 4, 0u, sc + 4);
+    if (ctx->pat.on)
+      k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
+    else
+      k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
+    k_finalize<<<1, kBlock, 0, s>>>(ctx->part_at, step_partials(ctx), 4, 0u, sc + 4);
   } else {
     // partial A^T y of this row block, all-reduced together with the three dual-side row sums
     if (which == PDLPDEV_AVERAGE) {
@@ -1466,12 +1507,12 @@ int pdlpdev_get_solution(pdlpdev_ctx* ctx, int which, double* x, double* y, doub
   return 0;
 }
 
-int64_t pdlpdev_download(pdlpdev_ctx* ctx, int id, void* host, int64_t max_elements)
+static int64_t locate_buffer(pdlpdev_ctx* ctx, int id, double** ptr)
 {
   if (hipSetDevice(ctx->device) != hipSuccess) return -2;
   if (fetch_ctl(ctx, nullptr) != 0) return -2;
   const int cur = ctx->ctl_h->cur;
-  const void* src = nullptr;
+  double* src   = nullptr;
   int64_t count = 0;
   const int64_t n = ctx->n, m = ctx->m, nnz = ctx->nnz;
   switch (id) {
@@ -1499,14 +1540,48 @@ int64_t pdlpdev_download(pdlpdev_ctx* ctx, int id, void* host, int64_t max_eleme
     case PDLPDEV_BUF_RC_AVERAGE: src = ctx->rc[1], count = n; break;
     case PDLPDEV_BUF_LAST_RESTART_X: src = ctx->lrx, count = n; break;
     case PDLPDEV_BUF_LAST_RESTART_Y: src = ctx->lry, count = m; break;
-    default: fail(-1, "pdlpdev_download: unknown buffer %d", id); return -1;
+    default: fail(-1, "unknown buffer %d", id); return -1;
   }
+  *ptr = src;
+  return count;
+}
+
+int64_t pdlpdev_download(pdlpdev_ctx* ctx, int id, void* host, int64_t max_elements)
+{
+  double* src   = nullptr;
+  int64_t count = locate_buffer(ctx, id, &src);
+  if (count < 0) return count;
   count = std::min(count, max_elements);
   if (count > 0) {
     if (hipMemcpyAsync(host, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return -2;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -2;
   }
   return count;
+}
+
+int64_t pdlpdev_upload(pdlpdev_ctx* ctx, int id, const void* host, int64_t elements)
+{
+  double* dst   = nullptr;
+  int64_t count = locate_buffer(ctx, id, &dst);
+  if (count < 0) return count;
+  if (id == PDLPDEV_BUF_A_VALUES || id == PDLPDEV_BUF_AT_VALUES) {
+    fail(-1, "matrix values cannot be overwritten");
+    return -1;
+  }
+  count = std::min(count, elements);
+  if (count > 0) {
+    if (hipMemcpyAsync(dst, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return -2;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -2;
+  }
+  return count;
+}
+
+int pdlpdev_set_loop_state(pdlpdev_ctx* ctx, double sum_weights, int32_t its_since_restart, int32_t k)
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  k_set_loop_state<<<1, 1, 0, ctx->stream>>>(ctx->ctl, sum_weights, its_since_restart, k);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 // ---- measurement / parity hooks ------------------------------------------------------------------------

@@ -77,14 +77,16 @@ struct cuoptamd_solver {
   double objective_scale = 1.0, objective_offset = 0.0;
   double norm_b = 0.0, norm_c = 0.0;
   // loop state
-  int32_t total_iterations = 0;  // total_pdlp_iterations_ == internal_solver_iterations_ here
+  int32_t total_iterations = 0;  // total_pdlp_iterations_ (keeps counting across warm starts)
+  int32_t iteration_offset = 0;  // total_pdlp_iterations_ - internal_solver_iterations_
+  int32_t attempt_offset   = 0;
   int32_t major_done_at    = -1;
   bool step_error = false, need_aty = true, last_restart_was_average = false;
   double last_candidate_kkt = 0.0, last_restart_kkt = 0.0;
   pdlpdev_ctl ctl{};
   Convergence conv_current, conv_average;
   int returned_which = PDLPDEV_CURRENT;
-  bool finished = false;
+  bool finished = false, warm_started = false;
   cuoptamd_result result{};
   clock_type::time_point solve_start;
   bool started = false;
@@ -209,7 +211,7 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
   // pdlp.cu:1110-1122: with 0 or 1 steps the average IS the iterate (avoids a*x/x != x);
   // right after a restart the sums are empty and the reference yields zeros.
   int mode = 2;
-  if (s->total_iterations <= 1)
+  if (s->total_iterations - s->iteration_offset <= 1 && !s->warm_started)  // internal_solver_iterations_ <= 1
     mode = 0;
   else if (s->ctl.its_since_restart == 0)
     mode = 1;
@@ -253,7 +255,7 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     const double tl = s->S.time_limit;
     if (std::isfinite(tl) && seconds_since(s->solve_start) * 1000.0 >= tl * 1000.0)
       done = true, status = kTimeLimit, which = PDLPDEV_CURRENT;
-    else if (s->total_iterations >= s->S.iteration_limit)
+    else if (s->total_iterations - s->iteration_offset >= s->S.iteration_limit)  // internal_solver_iterations_
       done = true, status = kIterationLimit, which = PDLPDEV_CURRENT;
   }
   if (done) {
@@ -582,9 +584,9 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
       if (rc != 0) return leave(fail(rc, "pdlpdev_compute_aty: %s", pdlpdev_last_error()));
       s->need_aty = false;
     }
-    int rc = pdlpdev_run(s->dev, target, &s->ctl);
+    int rc = pdlpdev_run(s->dev, target - s->iteration_offset, &s->ctl);
     if (rc != 0) return leave(fail(rc, "pdlpdev_run: %s", pdlpdev_last_error()));
-    s->total_iterations = s->ctl.steps_taken;
+    s->total_iterations = s->iteration_offset + s->ctl.steps_taken;
     if (s->ctl.error) s->step_error = true;
   }
 }
@@ -599,6 +601,70 @@ int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, doubl
   }
   if (y && s->world > 1) std::fill(y, y + s->m_global, 0.0);  // other ranks' rows stay 0
   DEV(pdlpdev_get_solution(s->dev, s->returned_which, x, y ? y + s->row_begin : nullptr, rc));
+  return 0;
+}
+
+int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
+{
+  if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_get_warm_start: null argument");
+  if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
+  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_CURRENT, ws->current_primal_solution, ws->current_dual_solution, nullptr));
+  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_AVERAGE, ws->initial_primal_average, ws->initial_dual_average, nullptr));
+  auto get = [&](int id, double* dst, int64_t count) -> int {
+    if (!dst) return 0;
+    if (pdlpdev_download(s->dev, id, dst, count) != count) return fail(-2, "download failed: %s", pdlpdev_last_error());
+    return 0;
+  };
+  const int64_t n = s->n, m = s->m_global;
+  int rc;
+  if ((rc = get(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
+  if ((rc = get(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
+  if ((rc = get(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;
+  if ((rc = get(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
+  if ((rc = get(PDLPDEV_BUF_LAST_RESTART_Y, ws->last_restart_duality_gap_dual_solution, m))) return rc;
+  DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
+  ws->initial_primal_weight         = s->ctl.primal_weight;
+  ws->initial_step_size             = s->ctl.step_size;
+  ws->total_pdlp_iterations         = s->total_iterations;
+  ws->total_pdhg_iterations         = s->ctl.k;
+  ws->last_candidate_kkt_score      = s->last_candidate_kkt;
+  ws->last_restart_kkt_score        = s->last_restart_kkt;
+  ws->sum_solution_weight           = s->ctl.sum_weights;
+  ws->iterations_since_last_restart = s->ctl.its_since_restart;
+  return 0;
+}
+
+int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start* ws)
+{
+  if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_set_warm_start: null argument");
+  if (s->started) return fail(-1, "cuoptamd_solver_set_warm_start: the solver has already been advanced");
+  if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
+  // iterate: unscaled in the snapshot -> scale_solutions (initial_scaling.cu:410-427), then the usual projection
+  DEV(pdlpdev_set_initial(s->dev, ws->current_primal_solution, ws->current_dual_solution));
+  if (s->H.project_initial_primal) DEV(pdlpdev_project_primal(s->dev));
+  auto put = [&](int id, const double* src, int64_t count) -> int {
+    if (!src) return 0;
+    if (pdlpdev_upload(s->dev, id, src, count) != count) return fail(-2, "upload failed: %s", pdlpdev_last_error());
+    return 0;
+  };
+  const int64_t n = s->n, m = s->m_global;
+  int rc;
+  if ((rc = put(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;
+  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_Y, ws->last_restart_duality_gap_dual_solution, m))) return rc;
+  DEV(pdlpdev_set_step(s->dev, ws->initial_step_size, ws->initial_primal_weight));
+  DEV(pdlpdev_set_loop_state(s->dev, ws->sum_solution_weight, ws->iterations_since_last_restart, ws->total_pdhg_iterations));
+  DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
+  s->iteration_offset   = ws->total_pdlp_iterations;
+  s->total_iterations   = ws->total_pdlp_iterations;
+  s->last_candidate_kkt = ws->last_candidate_kkt_score;
+  s->last_restart_kkt   = ws->last_restart_kkt_score;
+  s->need_aty           = ws->current_ATY == nullptr;  // A^T y travels with the snapshot (pdlp.cu:160-163)
+  s->warm_started       = true;
+  s->result.initial_step_size     = ws->initial_step_size;
+  s->result.initial_primal_weight = ws->initial_primal_weight;
   return 0;
 }
 

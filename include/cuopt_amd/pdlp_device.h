@@ -204,6 +204,12 @@ int pdlpdev_get_solution(pdlpdev_ctx* ctx, int which, double* x, double* y, doub
 /* raw buffer download; returns the number of elements copied (or < 0) */
 int64_t pdlpdev_download(pdlpdev_ctx* ctx, int buffer_id, void* host, int64_t max_elements);
 
+/* raw buffer upload (scaled space, warm start restore): the mirror of pdlpdev_download */
+int64_t pdlpdev_upload(pdlpdev_ctx* ctx, int buffer_id, const void* host, int64_t elements);
+/* restores the loop scalars a warm start carries besides eta / w (pdlp.cu:131-181):
+ * sum of averaging weights, iterations since the last restart, number of step-size updates k */
+int pdlpdev_set_loop_state(pdlpdev_ctx* ctx, double sum_weights, int32_t its_since_restart, int32_t k);
+
 /* ---- measurement / parity hooks ---------------------------------------------------------------- */
 /* y = A x (transpose = 0, x has n entries, y has m) or y = A^T x through the plain CSR kernel */
 int pdlpdev_spmv(pdlpdev_ctx* ctx, int transpose, const double* x, double* y);

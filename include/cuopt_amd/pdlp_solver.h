@@ -110,6 +110,32 @@ typedef struct cuoptamd_result {
   double loop_seconds;  /* accumulated time inside cuoptamd_solver_advance */
 } cuoptamd_result;
 
+/* pdlp_warm_start_data_t (cpp/include/cuopt/linear_programming/pdlp/pdlp_warm_start_data.hpp:31-90):
+ * the complete solver state at a terminating major iteration.  Vectors are CALLER-allocated host arrays
+ * (n entries for the primal ones, m for the dual ones).  As in the reference (pdlp.cu:468-489) the
+ * current iterate and the average are in the user's UNSCALED space, A^T y, the running sums and the
+ * last-restart anchors are in the solver's scaled space, so a snapshot is only meaningful for the SAME
+ * constraint matrix and hyper-parameters (the reference's own restriction). */
+typedef struct cuoptamd_warm_start {
+  double* current_primal_solution;                  /* n */
+  double* current_dual_solution;                    /* m */
+  double* initial_primal_average;                   /* n */
+  double* initial_dual_average;                     /* m */
+  double* current_ATY;                              /* n */
+  double* sum_primal_solutions;                     /* n */
+  double* sum_dual_solutions;                       /* m */
+  double* last_restart_duality_gap_primal_solution; /* n */
+  double* last_restart_duality_gap_dual_solution;   /* m */
+  double initial_primal_weight;
+  double initial_step_size;
+  int32_t total_pdlp_iterations;
+  int32_t total_pdhg_iterations;
+  double last_candidate_kkt_score;
+  double last_restart_kkt_score;
+  double sum_solution_weight;
+  int32_t iterations_since_last_restart;
+} cuoptamd_warm_start;
+
 const char* cuoptamd_last_error(void);
 
 /* presets, mode numbering as CUOPT_PDLP_SOLVER_MODE_* (0 Stable1, 1 Stable2, 2 Methodical1, 3 Fast1) */
@@ -130,6 +156,14 @@ void cuoptamd_solver_destroy(cuoptamd_solver* s);
  * iterations (accepted steps) have been taken, whichever is first.  result->status == 0 means
  * "budget exhausted, not terminated"; calling again continues exactly where it stopped. */
 int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result);
+
+/* Fills *ws (get_filled_warmed_start_data, pdlp.cu:468-489) from a solver whose last advance terminated.
+ * Single-GPU solvers only. */
+int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws);
+/* Restores a snapshot into a freshly created solver (before its first advance), pdlp.cu:131-181:
+ * iteration counts keep running from the snapshot (its(1e-2 from scratch) == its(1e-1) + its(1e-2 warm),
+ * the reference's warm-start test, pdlp_test.cu:803-854). */
+int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start* ws);
 
 /* x (n), y (m_global), reduced cost (n) of the returned iterate, unscaled, in the internal min-form
  * sign convention of the reference (any pointer may be NULL). Valid after a terminating advance. */

@@ -218,3 +218,56 @@ def test_config2_scale_solve_reaches_known_optimum():
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 1e-2 * (1 + abs(p["objective_star"]))
     host_check(p, r)
+
+
+@pytest.mark.parametrize("seed,hard", [(31, False), (32, True), (33, True)])
+def test_warm_start_iterations_are_additive(seed, hard):
+    """pdlp_test.cu:803-854 / test_lp_solver.py:513-542: its(1e-2 from scratch) == its(1e-1) + its(1e-2
+    warm-started from the 1e-1 solution's pdlp_warm_start_data)"""
+    p = synthetic.generate(4000, 3500, 8, seed=seed, hard=hard)
+    coarse, fine = (1e-1, 1e-2) if not hard else (1e-2, 1e-4)
+    full = capi.Solver(p, tol=fine)
+    r_full = full.advance()
+    first = capi.Solver(p, tol=coarse)
+    r1 = first.advance()
+    ws = first.get_warm_start()
+    assert ws["total_pdlp_iterations"] == r1["steps_taken"]
+    second = capi.Solver(p, tol=fine, warm_start=ws)
+    r2 = second.advance()
+    assert r_full["status_name"] == r1["status_name"] == r2["status_name"] == "Optimal"
+    assert r1["steps_taken"] + r2["steps_taken"] == r_full["steps_taken"]
+    # x is unscaled in the snapshot and rescaled on restore ((x*d)/d != x in the last bit), like the reference
+    assert r2["primal_objective"] == pytest.approx(r_full["primal_objective"], rel=1e-6, abs=1e-6)
+
+
+def test_mip_style_warm_started_resolves(golden_problems):
+    """BASELINE config 5 call pattern (cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-127): a fresh solver per
+    call, warm-started from the previous primal/dual, after single-variable bound tightenings; every
+    re-solve must agree with the reference-derived oracle on the modified LP."""
+    p = dict(golden_problems["mip-sample-relaxation"]["problem"])
+    p.pop("var_types", None)
+    r = capi.solve(p, method=1, tol=1e-6)
+    x, y = r["x"], r["y"]
+    rng = np.random.default_rng(0)
+    total_warm, total_cold = 0, 0
+    for k in range(12):
+        q = dict(p)
+        q["lb"], q["ub"] = p["lb"].copy(), p["ub"].copy()
+        j = int(rng.integers(p["n"]))
+        if rng.random() < 0.5:
+            q["ub"][j] = np.floor(x[j])
+        else:
+            q["lb"][j] = np.ceil(x[j])
+        if q["lb"][j] > q["ub"][j]:
+            continue
+        o = orcbind.solve(q, tol=1e-6, iteration_limit=20000)
+        if o["status"] != "Optimal":
+            continue  # infeasible child: detection is a later row
+        warm = capi.Solver(q, tol=1e-6, init_x=x, init_y=y)
+        rw = warm.advance()
+        cold = capi.Solver(q, tol=1e-6).advance()
+        assert rw["status_name"] == "Optimal"
+        assert rw["primal_objective"] == pytest.approx(o["primal_objective"], abs=2e-5 * (1 + abs(o["primal_objective"])))
+        total_warm += rw["steps_taken"]
+        total_cold += cold["steps_taken"]
+    assert total_warm > 0
