@@ -96,7 +96,9 @@ class SolverSettings(C.Structure):
                 ("iteration_limit", c_int), ("time_limit", c_double),
                 ("per_constraint_residual", c_int), ("first_primal_feasible", c_int),
                 ("initial_step_size", c_double), ("initial_primal_weight", c_double),
-                ("initial_k", c_int), ("use_graph", c_int)]
+                ("initial_k", c_int), ("use_graph", c_int), ("detect_infeasibility", c_int),
+                ("strict_infeasibility", c_int), ("primal_infeasible_tolerance", c_double),
+                ("dual_infeasible_tolerance", c_double)]
 
 
 class Result(C.Structure):
@@ -106,7 +108,8 @@ class Result(C.Structure):
                 ("relative_gap", c_double), ("l2_primal_residual", c_double),
                 ("l2_dual_residual", c_double), ("l2_relative_primal_residual", c_double),
                 ("l2_relative_dual_residual", c_double), ("max_primal_ray_infeasibility", c_double),
-                ("max_dual_ray_infeasibility", c_double), ("initial_step_size", c_double),
+                ("max_dual_ray_infeasibility", c_double), ("primal_ray_linear_objective", c_double),
+                ("dual_ray_linear_objective", c_double), ("initial_step_size", c_double),
                 ("initial_primal_weight", c_double), ("step_size", c_double),
                 ("primal_weight", c_double), ("norm_b", c_double), ("norm_c", c_double),
                 ("setup_seconds", c_double), ("loop_seconds", c_double)]
@@ -223,6 +226,7 @@ _proto("pdlpdev_flush_average", c_int, c_void_p)
 _proto("pdlpdev_make_average", c_int, c_void_p, c_int)
 _proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)
 _proto("pdlpdev_restart", c_int, c_void_p, c_int, c_void_p)
+_proto("pdlpdev_eval_infeasibility", c_int, c_void_p, c_int, c_int, c_void_p)
 _proto("pdlpdev_get_solution", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_download", C.c_int64, c_void_p, c_int, c_void_p, C.c_int64)
 _proto("pdlpdev_spmv", c_int, c_void_p, c_int, c_void_p, c_void_p)
@@ -648,6 +652,12 @@ class Device:
         out = np.zeros(len(EV))
         self._ck(lib.pdlpdev_eval(self.handle, which, int(rule_finite), eps_p, eps_d, _ptr(out)))
         return {k: out[i] for k, i in EV.items()}
+
+    def eval_infeasibility(self, which, rule_finite=True):
+        out = np.zeros(4)
+        self._ck(lib.pdlpdev_eval_infeasibility(self.handle, which, int(rule_finite), _ptr(out)))
+        return dict(zip(["max_primal_ray_infeasibility", "primal_ray_linear_objective",
+                         "max_dual_ray_infeasibility", "dual_ray_linear_objective"], out.tolist()))
 
     def init_norms(self):
         out = np.zeros(3)

@@ -583,6 +583,10 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
     st.first_primal_feasible   = s->first_primal_feasible;
+    st.detect_infeasibility        = s->infeasibility_detection;
+    st.strict_infeasibility        = s->strict_infeasibility;
+    st.primal_infeasible_tolerance = s->primal_infeasible_tolerance;
+    st.dual_infeasible_tolerance   = s->dual_infeasible_tolerance;
     cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
                    p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
                    p->objective_offset};

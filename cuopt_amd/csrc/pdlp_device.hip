@@ -111,6 +111,7 @@ struct pdlpdev_ctx {
   double *xbar = nullptr, *sumx = nullptr, *sumy = nullptr, *avgx = nullptr, *avgy = nullptr;
   double *lrx = nullptr, *lry = nullptr, *rc[2] = {nullptr, nullptr};
   double *tmp_n = nullptr, *tmp_m = nullptr;
+  double *ax_u = nullptr, *aty_u = nullptr;  // unscaled A x / A^T y of the last pdlpdev_eval
   // reductions
   double *part_a = nullptr, *part_at = nullptr;  // per-row-block partials (8 quantities each)
   double *part_g = nullptr;                      // generic grid-stride partials
@@ -614,10 +615,12 @@ struct EvalPrimalEpilogue {
   const double* __restrict__ hi_u;
   double eps_rel;
   double* __restrict__ linf_rows;  // per-row r_p,i - eps*bcomb_i (max-reduced by a second pass)
+  double* __restrict__ ax_out;     // (A x)_i of the unscaled problem, kept for the infeasibility pass
   __device__ __forceinline__ void row(int i, double v, double (&acc)[3])
   {
     const double d  = dr[i];
     const double ax = v / d;
+    ax_out[i]       = ax;
     const double yi = yhat[i] * d;
     const double lo = lo_u[i], hi = hi_u[i];
     const double rp = violation(ax, lo, hi);
@@ -635,12 +638,12 @@ k_eval_primal(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const double* __restrict__ y0, const double* __restrict__ y1,
               const double* __restrict__ avgy, const double* __restrict__ dr,
               const double* __restrict__ lo_u, const double* __restrict__ hi_u, double eps_rel,
-              double* __restrict__ linf_rows, double* __restrict__ part)
+              double* __restrict__ linf_rows, double* __restrict__ ax_out, double* __restrict__ part)
 {
   const int cur = ctl->cur;
   const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows};
+  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
   csr_stream_block(nb, rb, off, idx, val, xv, e, part);
 }
 
@@ -655,11 +658,13 @@ struct EvalDualCore {
   int rule_finite;
   double* __restrict__ rc_out;
   double* __restrict__ linf_rows;
+  double* __restrict__ aty_out;  // (A^T y)_j of the unscaled problem, kept for the infeasibility pass
   // acc: 0 ||r_d||^2, 1 sum B(rc,lb,ub), 2 c.x, 3 ||x||^2
   __device__ __forceinline__ void col(int j, double aty_scaled, double (&acc)[4])
   {
     const double d    = dc[j];
     const double aty  = aty_scaled / d;
+    aty_out[j]        = aty;
     const double cj   = c_u[j];
     const double g    = cj - aty;
     const double xj   = xhat[j] * d;
@@ -708,12 +713,12 @@ k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
                     const double* __restrict__ y1, const double* __restrict__ avgy,
                     const double* __restrict__ dr, const double* __restrict__ lo_u,
                     const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows,
-                    double* __restrict__ part)
+                    double* __restrict__ ax_out, double* __restrict__ part)
 {
   const int cur = ctl->cur;
   const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows};
+  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
   panel_spmv_block(P, xv, e, part);
 }
 __global__ void __launch_bounds__(kPanelThreads)
@@ -757,6 +762,82 @@ k_max_partials(int n, const double* __restrict__ v, double* __restrict__ part)
     acc[0] = v[i] > acc[0] ? v[i] : acc[0];
   block_reduce<MaxOp, 1>(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+
+// ---- infeasibility information (infeasibility_information.cu:176-223): the iterate is the ray estimate.
+// rows: max_i violation((A x)_i, homogenous bounds), max |y_i|, sum_i B(y_i, lo_i, hi_i)
+__global__ void __launch_bounds__(kBlock)
+k_infeas_rows(int m, int nbg, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ ax,
+              const double* __restrict__ y0, const double* __restrict__ y1, const double* __restrict__ avgy,
+              const double* __restrict__ dr, const double* __restrict__ lo_u, const double* __restrict__ hi_u,
+              double* __restrict__ part)
+{
+  __shared__ double red[12];
+  const int cur = ctl->cur;
+  const double* __restrict__ yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  double mx[2] = {0.0, 0.0}, sm[1] = {0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+    const double lo = lo_u[i], hi = hi_u[i];
+    const double hl = dfinite(lo) ? 0.0 : lo, hu = dfinite(hi) ? 0.0 : hi;  // zero_if_is_finite, :86-98
+    const double r  = fabs(violation(ax[i], hl, hu));
+    const double yi = yv[i] * dr[i];
+    mx[0] = r > mx[0] ? r : mx[0];
+    mx[1] = fabs(yi) > mx[1] ? fabs(yi) : mx[1];
+    sm[0] += bound_value_product(yi, lo, hi);
+  }
+  block_reduce<MaxOp, 2>(mx, red);
+  __syncthreads();
+  block_reduce<SumOp, 1>(sm, red + 8);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x]           = mx[0];
+    part[nbg + blockIdx.x]     = mx[1];
+    part[2 * nbg + blockIdx.x] = sm[0];
+  }
+}
+// columns: g = -A^T y ; rc by the preset's rule ; max |g - rc|, max |rc|, max |x|, max bound violation of x,
+//          sum_j B(rc_j, lb_j, ub_j), c.x
+__global__ void __launch_bounds__(kBlock)
+k_infeas_cols(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ aty,
+              const double* __restrict__ x0, const double* __restrict__ x1, const double* __restrict__ avgx,
+              const double* __restrict__ dc, const double* __restrict__ c_u, const double* __restrict__ lb_u,
+              const double* __restrict__ ub_u, int rule_finite, double* __restrict__ part)
+{
+  __shared__ double red[28];
+  const int cur = ctl->cur;
+  const double* __restrict__ xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  double mx[4] = {0.0, 0.0, 0.0, 0.0}, sm[2] = {0.0, 0.0};
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    const double g  = -1.0 * aty[j];
+    const double xj = xv[j] * dc[j];
+    const double lb = lb_u[j], ub = ub_u[j];
+    const double bv = g > 0.0 ? lb : ub;
+    double rc;
+    if (g == 0.0)
+      rc = g;
+    else if (rule_finite)
+      rc = dfinite(bv) ? g : 0.0;
+    else
+      rc = fabs(xj - bv) <= fabs(xj) ? g : 0.0;
+    const double rd = fabs(g - rc);
+    double viol     = 0.0;  // max_violation, utils.cuh:181-193
+    if (dfinite(lb)) viol = dmax(viol, -xj);
+    if (dfinite(ub)) viol = dmax(viol, xj);
+    mx[0] = rd > mx[0] ? rd : mx[0];
+    mx[1] = fabs(rc) > mx[1] ? fabs(rc) : mx[1];
+    mx[2] = fabs(xj) > mx[2] ? fabs(xj) : mx[2];
+    mx[3] = viol > mx[3] ? viol : mx[3];
+    sm[0] += bound_value_product(rc, lb, ub);
+    sm[1] += c_u[j] * xj;
+  }
+  block_reduce<MaxOp, 4>(mx, red);
+  __syncthreads();
+  block_reduce<SumOp, 2>(sm, red + 16);
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) part[(size_t)q * nbg + blockIdx.x] = mx[q];
+    part[(size_t)4 * nbg + blockIdx.x] = sm[0];
+    part[(size_t)5 * nbg + blockIdx.x] = sm[1];
+  }
 }
 
 // restart: squared distances to the last-restart anchors, candidate -> iterate/anchors, sums <- 0
@@ -1038,6 +1119,7 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(dev_alloc(ctx, &ctx->avgx, n)); TRY(dev_alloc(ctx, &ctx->avgy, m));
   TRY(dev_alloc(ctx, &ctx->lrx, n)); TRY(dev_alloc(ctx, &ctx->lry, m));
   TRY(dev_alloc(ctx, &ctx->tmp_n, n)); TRY(dev_alloc(ctx, &ctx->tmp_m, m));
+  TRY(dev_alloc(ctx, &ctx->ax_u, m)); TRY(dev_alloc(ctx, &ctx->aty_u, n));
   {
     // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel ; CUOPT_AMD_SLAB_BYTES (default 1 MiB)
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
@@ -1420,16 +1502,16 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   const int n = ctx->n, m = ctx->m;
   double* sc = ctx->scal;  // layout: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
   if (ctx->pa.on)
-    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->part_a);
+    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u, ctx->part_a);
   else
-    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->part_a);
+    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u, ctx->part_a);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
   {
     const int g = std::min(grid_for(m), kGenericBlocks);
     k_max_partials<<<g, kBlock, 0, s>>>(m, ctx->tmp_m, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 1u, sc + 3);
   }
-  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n};
+  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n, ctx->aty_u};
   if (!ctx->comm) {
     if (ctx->pat.on)
       k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
@@ -1467,6 +1549,43 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   out[PDLPDEV_EV_CX]            = h[6];
   out[PDLPDEV_EV_X2]            = h[7];
   out[PDLPDEV_EV_LINF_DRES_REL] = h[8];
+  return 0;
+}
+
+int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double out[4])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->comm) return fail(-7, "infeasibility detection is not available on the row-block sharded path yet");
+  hipStream_t s = ctx->stream;
+  const int n = ctx->n, m = ctx->m;
+  const int gr = std::min(grid_for(m), kGenericBlocks), gc = std::min(grid_for(n), kGenericBlocks);
+  double* part_rows = ctx->part_g;             // 3 * gr
+  double* part_cols = ctx->part_g + 3 * 2048;  // 6 * gc  (part_g holds 8 * 2048)
+  k_infeas_rows<<<gr, kBlock, 0, s>>>(m, gr, ctx->ctl, which, ctx->ax_u, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, part_rows);
+  k_finalize<<<1, kBlock, 0, s>>>(part_rows, gr, 3, 0x3u, ctx->scal + 16);
+  k_infeas_cols<<<gc, kBlock, 0, s>>>(n, gc, ctx->ctl, which, ctx->aty_u, ctx->x[0], ctx->x[1], ctx->avgx, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, rc_rule_finite_bounds, part_cols);
+  k_finalize<<<1, kBlock, 0, s>>>(part_cols, gc, 6, 0xFu, ctx->scal + 24);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->scal_h + 16, ctx->scal + 16, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const double* r = ctx->scal_h + 16;  // max hom. primal residual, ||y||_inf, sum B(y)
+  const double* c = ctx->scal_h + 24;  // max hom. dual residual, ||rc||_inf, ||x||_inf, max violation, sum B(rc), c.x
+  // compute_remaining_stats_kernel, infeasibility_information.cu:115-172
+  double max_primal = r[0], primal_obj = c[2] == 0.0 ? 0.0 : c[5] * (1.0 / c[2]);
+  double max_dual = c[0], dual_obj = r[2] + c[4];
+  const double scaling = std::max(r[1], c[1]);
+  if (scaling != 0.0) {
+    max_dual /= scaling;
+    dual_obj /= scaling;
+  } else {
+    max_dual = 0.0, dual_obj = 0.0;
+  }
+  if (c[2] > 0.0) {
+    max_primal = std::max(max_primal, c[3]) / c[2];
+  } else {
+    max_primal = 0.0, primal_obj = 0.0;
+  }
+  out[0] = max_primal, out[1] = primal_obj, out[2] = max_dual, out[3] = dual_obj;
   return 0;
 }
 

@@ -52,6 +52,8 @@ double seconds_since(clock_type::time_point t0)
 enum : int {
   kNoTermination  = 0,
   kOptimal        = 1,
+  kPrimalInfeasible = 2,
+  kDualInfeasible   = 3,
   kIterationLimit = 4,
   kTimeLimit      = 5,
   kNumericalError = 6,
@@ -63,6 +65,7 @@ struct Convergence {
   double primal_objective = 0, dual_objective = 0, gap = 0, abs_objective = 0;
   double l2_primal_residual = 0, l2_dual_residual = 0, l2_x = 0, l2_y = 0;
   double linf_rel_primal_residual = 0, linf_rel_dual_residual = 0;
+  double infeasibility[4] = {0, 0, 0, 0};  // max primal ray infeas., primal ray objective, max dual ray infeas., dual ray objective
 };
 
 }  // namespace
@@ -167,6 +170,11 @@ int verdict(const cuoptamd_solver* s, const Convergence& c)
   }
   if (dual_ok && primal_ok && gap_ok) return kOptimal;
   if (primal_ok) return kPrimalFeasible;
+  if (t.detect_infeasibility) {  // termination_strategy.cu:228-249
+    const double* f = c.infeasibility;
+    if (f[3] > 0.0 && f[2] / f[3] <= t.primal_infeasible_tolerance) return kPrimalInfeasible;
+    if (f[1] < 0.0 && f[0] / -f[1] <= t.dual_infeasible_tolerance) return kDualInfeasible;
+  }
   return kNumericalError;
 }
 
@@ -196,6 +204,10 @@ void fill_result(cuoptamd_solver* s, int status, int which)
   r.l2_relative_dual_residual   = c.l2_dual_residual / (1.0 + s->norm_c);
   r.step_size              = s->ctl.step_size;
   r.primal_weight          = s->ctl.primal_weight;
+  r.max_primal_ray_infeasibility = c.infeasibility[0];
+  r.primal_ray_linear_objective  = c.infeasibility[1];
+  r.max_dual_ray_infeasibility   = c.infeasibility[2];
+  r.dual_ray_linear_objective    = c.infeasibility[3];
   s->returned_which        = which;
 }
 
@@ -220,8 +232,10 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
   double ev[PDLPDEV_EV_COUNT];
   DEV(pdlpdev_eval(dev, PDLPDEV_CURRENT, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
   s->conv_current = to_convergence(s, ev);
+  if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_CURRENT, rule_finite, s->conv_current.infeasibility));
   DEV(pdlpdev_eval(dev, PDLPDEV_AVERAGE, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
   s->conv_average = to_convergence(s, ev);
+  if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_AVERAGE, rule_finite, s->conv_average.infeasibility));
   const int t_cur = verdict(s, s->conv_current), t_avg = verdict(s, s->conv_average);
   const double w  = s->ctl.primal_weight;
 
@@ -245,6 +259,18 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     }
     if (!done && t_avg == kOptimal) done = true, status = kOptimal, which = PDLPDEV_AVERAGE;   // :685-700
     if (!done && t_cur == kOptimal) done = true, status = kOptimal, which = PDLPDEV_CURRENT;   // :701-716
+    if (!done && s->S.detect_infeasibility) {  // :718-776: strict -> one iterate suffices, else both must agree
+      const bool cur_inf = t_cur == kPrimalInfeasible || t_cur == kDualInfeasible;
+      const bool avg_inf = t_avg == kPrimalInfeasible || t_avg == kDualInfeasible;
+      if (s->S.strict_infeasibility) {
+        if (cur_inf)
+          done = true, status = t_cur, which = PDLPDEV_CURRENT;
+        else if (avg_inf)
+          done = true, status = t_avg, which = PDLPDEV_AVERAGE;
+      } else if (cur_inf && t_cur == t_avg) {
+        done = true, status = t_cur, which = PDLPDEV_CURRENT;
+      }
+    }
     if (!done && s->step_error) {  // :780-789: numerical error, empty solution
       fill_result(s, kNumericalError, PDLPDEV_CURRENT);
       *terminated = true;
@@ -387,6 +413,10 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->initial_primal_weight   = -1.0;
   s->initial_k               = -1;
   s->use_graph               = 1;
+  s->detect_infeasibility    = 0;
+  s->strict_infeasibility    = 0;
+  s->primal_infeasible_tolerance = 1e-8;
+  s->dual_infeasible_tolerance   = 1e-8;
 }
 
 void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,

@@ -193,6 +193,11 @@ int pdlpdev_make_average(pdlpdev_ctx* ctx, int mode);
  * copy_gradient_if_finite_bounds (Stable2) vs copy_gradient_if_should_be_reduced_cost. */
 int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
                  double eps_rel_dual, double out[PDLPDEV_EV_COUNT]);
+/* Infeasibility information of the iterate evaluated by the LAST pdlpdev_eval(which) call (its A x and
+ * A^T y are reused; the iterate itself is the ray estimate, infeasibility_information.cu:176-223):
+ * out = {max_primal_ray_infeasibility, primal_ray_linear_objective, max_dual_ray_infeasibility,
+ *        dual_ray_linear_objective} after compute_remaining_stats (:115-172). */
+int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double out[4]);
 /* Restart to `which` (CURRENT or AVERAGE): dist2[0] = ||x_c - x_last_restart||^2, dist2[1] same for
  * y (scaled space); copies the candidate into the iterate when it is the average; anchors <-
  * candidate; sums <- 0; its_since_restart <- 0. */

@@ -89,6 +89,12 @@ typedef struct cuoptamd_settings {
   double initial_primal_weight;
   int32_t initial_k;
   int32_t use_graph; /* replay the PDHG attempt through hipGraphs (default 1) */
+  /* infeasibility detection (pdlp/solver_settings.hpp: detect_infeasibility, strict_infeasibility;
+   * tolerances default 1e-8, solver_settings.cu:83-84) */
+  int32_t detect_infeasibility;
+  int32_t strict_infeasibility;
+  double primal_infeasible_tolerance;
+  double dual_infeasible_tolerance;
 } cuoptamd_settings;
 
 /* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */
@@ -102,7 +108,8 @@ typedef struct cuoptamd_result {
   double primal_objective, dual_objective, gap, relative_gap;
   double l2_primal_residual, l2_dual_residual;
   double l2_relative_primal_residual, l2_relative_dual_residual;
-  double max_primal_ray_infeasibility, max_dual_ray_infeasibility; /* unused: 0 */
+  double max_primal_ray_infeasibility, max_dual_ray_infeasibility; /* filled when detect_infeasibility */
+  double primal_ray_linear_objective, dual_ray_linear_objective;
   double initial_step_size, initial_primal_weight;
   double step_size, primal_weight;
   double norm_b, norm_c;

@@ -44,6 +44,7 @@ def lib():
         _lib.orc_csr_transpose.argtypes = [ci, ci] + [vp] * 6
         _lib.orc_compute_scaling.argtypes = [ci, ci] + [vp] * 9
         _lib.orc_eval.argtypes = [ci, ci] + [vp] * 11 + [cd, cd, ci, cd, cd] + [vp] * 4
+        _lib.orc_eval_infeasibility.argtypes = [ci, ci] + [vp] * 11 + [ci] + [vp] * 3
         _lib.orc_pdlp_solve.argtypes = [ci, ci] + [vp] * 8 + [ci, cd] + [vp] * 8
         _lib.orc_pdlp_solve.restype = ci
         _lib.orc_pdhg_fixed_steps.argtypes = [ci, ci] + [vp] * 11 + [cd, cd, ci, vp, vp]
@@ -125,6 +126,22 @@ def evaluate(p, x, y, finite_bounds_rule=True, rel_primal_tol=1e-4, rel_dual_tol
     r = dict(zip(keys, out.tolist()))
     r["reduced_cost"] = rc
     return r
+
+
+def evaluate_infeasibility(p, x, y, finite_bounds_rule=True):
+    m, n = int(p["m"]), int(p["n"])
+    offsets, indices, values = _i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"])
+    to, ti, tv = transpose(m, n, offsets, indices, values)
+    c = _f64(p["c"]).copy()
+    if p.get("maximize", False):
+        c = -c
+    lo, hi, lb, ub = (_f64(p[k]) for k in ("lo", "hi", "lb", "ub"))
+    out = np.zeros(4)
+    x, y = _f64(x), _f64(y)
+    lib().orc_eval_infeasibility(m, n, _p(offsets), _p(indices), _p(values), _p(to), _p(ti), _p(tv), _p(c),
+                                 _p(lo), _p(hi), _p(lb), _p(ub), int(finite_bounds_rule), _p(x), _p(y), _p(out))
+    return dict(zip(["max_primal_ray_infeasibility", "primal_ray_linear_objective",
+                     "max_dual_ray_infeasibility", "dual_ray_linear_objective"], out.tolist()))
 
 
 STATUS = {0: "NoTermination", 1: "Optimal", 2: "PrimalInfeasible", 3: "DualInfeasible",

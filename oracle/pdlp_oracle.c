@@ -134,6 +134,10 @@ void orc_default_settings(double* s)
   s[ORC_S_PER_CONSTRAINT_RESIDUAL] = 0;
   s[ORC_S_FIRST_PRIMAL_FEASIBLE]   = 0;
   s[ORC_S_NUM_THREADS]             = 0;
+  s[ORC_S_INFEASIBILITY_DETECTION] = 0;
+  s[ORC_S_STRICT_INFEASIBILITY]    = 0;
+  s[ORC_S_PRIMAL_INFEASIBLE_TOL]   = 1e-8; /* solver_settings.cu:83-84 */
+  s[ORC_S_DUAL_INFEASIBLE_TOL]     = 1e-8;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -399,6 +403,108 @@ void orc_eval(int m, int n, const int* offsets, const int* indices, const double
   free(bv);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* infeasibility information: LP/termination_strategy/infeasibility_information.cu            */
+/* ------------------------------------------------------------------------------------------ */
+static double inf_norm(int n, const double* v) /* my_inf_norm */
+{
+  double mx = 0.0;
+  for (int i = 0; i < n; ++i)
+    if (fabs(v[i]) > mx) mx = fabs(v[i]);
+  return mx;
+}
+void orc_eval_infeasibility(int m, int n, const int* offsets, const int* indices, const double* values,
+                            const int* t_offsets, const int* t_indices, const double* t_values,
+                            const double* c, const double* lo, const double* hi, const double* lb,
+                            const double* ub, int finite_bounds_rule, const double* x, const double* y,
+                            double* out)
+{
+  double* ax   = dalloc((size_t)m);
+  double* grad = dalloc((size_t)n);
+  double* rc   = dalloc((size_t)n);
+  double* res  = dalloc((size_t)(m > n ? m : n));
+  /* :184-198 primal ray = the primal iterate */
+  const double primal_ray_inf_norm = inf_norm(n, x);
+  const double inv = primal_ray_inf_norm == 0.0 ? 0.0 : 1.0 / primal_ray_inf_norm; /* DivideCheckZero */
+  /* compute_homogenous_primal_residual :225-248 ; homogenous bounds :86-98 (zero_if_is_finite) */
+  orc_spmv(m, offsets, indices, values, x, ax);
+  for (int i = 0; i < m; ++i) {
+    double hl = isfinite(lo[i]) ? 0.0 : lo[i], hu = isfinite(hi[i]) ? 0.0 : hi[i];
+    res[i]    = violation(ax[i], hl, hu);
+  }
+  double max_primal_ray_infeasibility = inf_norm(m, res);
+  /* compute_max_violation :250-270 ; max_violation functor utils.cuh:181-193 */
+  double primal_ray_max_violation = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double lm = 0.0;
+    if (isfinite(lb[j])) lm = dmax(lm, -x[j]);
+    if (isfinite(ub[j])) lm = dmax(lm, x[j]);
+    if (lm > primal_ray_max_violation) primal_ray_max_violation = lm;
+  }
+  /* compute_homogenous_primal_objective :272-292 */
+  double primal_ray_linear_objective = blocked_sum2(n, x, c) * inv;
+  /* compute_homogenous_dual_residual :294-325 : gradient = -A^T y (c = 0 in the homogenous problem) */
+  orc_spmv(n, t_offsets, t_indices, t_values, y, grad);
+  for (int j = 0; j < n; ++j) grad[j] = -1.0 * grad[j];
+  for (int j = 0; j < n; ++j) { /* compute_reduced_cost_from_primal_gradient :368-394 */
+    double b = bound_value_gradient(grad[j], lb[j], ub[j]);
+    double r;
+    if (!finite_bounds_rule) {
+      if (grad[j] == 0.0)
+        r = grad[j];
+      else if (fabs(x[j] - b) <= fabs(x[j]))
+        r = grad[j];
+      else
+        r = 0.0;
+    } else {
+      if (grad[j] == 0.0)
+        r = grad[j];
+      else if (isfinite(b))
+        r = grad[j];
+      else
+        r = 0.0;
+    }
+    rc[j]  = r;
+    res[j] = grad[j] - r;
+  }
+  double max_dual_ray_infeasibility = inf_norm(n, res);
+  /* compute_homogenous_dual_objective :327-366 + reduced cost contribution :396-417 */
+  for (int i = 0; i < m; ++i) res[i] = bound_value_rc_product(y[i], lo[i], hi[i]);
+  double dual_ray_linear_objective = blocked_sum(m, res);
+  for (int j = 0; j < n; ++j) res[j] = bound_value_rc_product(rc[j], lb[j], ub[j]);
+  dual_ray_linear_objective = dual_ray_linear_objective + blocked_sum(n, res);
+  const double dual_ray_inf_norm = inf_norm(m, y), rc_inf_norm = inf_norm(n, rc);
+  /* compute_remaining_stats_kernel :115-172 */
+  double scaling = dmax(dual_ray_inf_norm, rc_inf_norm);
+  if (scaling < 0.0 || scaling > 0.0) {
+    max_dual_ray_infeasibility = max_dual_ray_infeasibility / scaling;
+    dual_ray_linear_objective  = dual_ray_linear_objective / scaling;
+  } else {
+    max_dual_ray_infeasibility = 0.0;
+    dual_ray_linear_objective  = 0.0;
+  }
+  if (primal_ray_inf_norm > 0.0) {
+    max_primal_ray_infeasibility =
+      dmax(max_primal_ray_infeasibility, primal_ray_max_violation) / primal_ray_inf_norm;
+  } else {
+    max_primal_ray_infeasibility = 0.0;
+    primal_ray_linear_objective  = 0.0;
+  }
+  out[0] = max_primal_ray_infeasibility;
+  out[1] = primal_ray_linear_objective;
+  out[2] = max_dual_ray_infeasibility;
+  out[3] = dual_ray_linear_objective;
+  free(ax), free(grad), free(rc), free(res);
+}
+/* infeasibility part of check_termination_criteria_kernel, termination_strategy.cu:228-249 */
+static int infeasibility_verdict(const double* inf, const double* s)
+{
+  if (inf[3] > 0.0 && inf[2] / inf[3] <= s[ORC_S_PRIMAL_INFEASIBLE_TOL]) return 2; /* PrimalInfeasible */
+  if (inf[1] < 0.0 && inf[0] / -inf[1] <= s[ORC_S_DUAL_INFEASIBLE_TOL]) return 3;  /* DualInfeasible */
+  return 6;
+}
+
 /* check_termination_criteria_kernel, LP/termination_strategy/termination_strategy.cu:116-250.
  * Returns Optimal(1) / PrimalFeasible(7) / "no termination" encoded as NumericalError(6). */
 static int termination_verdict(const double* ev, const double* s, double norm_b, double norm_c)
@@ -632,6 +738,15 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
                avgx, avgy, rc_avg, ev_avg);
       int t_cur = termination_verdict(ev_cur, S, norm_b, norm_c);
       int t_avg = termination_verdict(ev_avg, S, norm_b, norm_c);
+      if (S[ORC_S_INFEASIBILITY_DETECTION] != 0.0) { /* termination_strategy.cu:80-107,228-249 */
+        double inf_cur[4], inf_avg[4];
+        orc_eval_infeasibility(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi, lb,
+                               ub, rule_fin, x, y, inf_cur);
+        orc_eval_infeasibility(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi, lb,
+                               ub, rule_fin, avgx, avgy, inf_avg);
+        if (t_cur == 6) t_cur = infeasibility_verdict(inf_cur, S);
+        if (t_avg == 6) t_avg = infeasibility_verdict(inf_avg, S);
+      }
       int done = 0, use_avg = 0, status = 6;
       if (total_pdlp > 1) { /* :580-583 : only limits while it <= 1 */
         if (S[ORC_S_FIRST_PRIMAL_FEASIBLE] != 0.0) { /* :587-633 */
@@ -648,7 +763,17 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
         }
         if (!done && t_avg == 1) done = 1, status = 1, use_avg = 1; /* :685-700 */
         if (!done && t_cur == 1) done = 1, status = 1, use_avg = 0; /* :701-716 */
-        /* infeasibility detection (:723-776) is not restated: default off */
+        /* infeasibility (:718-776): strict -> either iterate alone, else both must agree */
+        if (!done && S[ORC_S_INFEASIBILITY_DETECTION] != 0.0) {
+          if (S[ORC_S_STRICT_INFEASIBILITY] != 0.0) {
+            if (t_cur == 2 || t_cur == 3)
+              done = 1, status = t_cur, use_avg = 0;
+            else if (t_avg == 2 || t_avg == 3)
+              done = 1, status = t_avg, use_avg = 1;
+          } else if ((t_cur == 2 && t_avg == 2) || (t_cur == 3 && t_avg == 3)) {
+            done = 1, status = t_cur, use_avg = 0;
+          }
+        }
         if (!done && valid_step_size == -1) { /* :780-789 : empty solution object */
           stats[ORC_O_STATUS] = 6;
           final_status        = 6;

@@ -72,6 +72,10 @@ enum {
   ORC_S_PER_CONSTRAINT_RESIDUAL,
   ORC_S_FIRST_PRIMAL_FEASIBLE,
   ORC_S_NUM_THREADS, /* 0 = leave OpenMP default */
+  ORC_S_INFEASIBILITY_DETECTION,
+  ORC_S_STRICT_INFEASIBILITY,
+  ORC_S_PRIMAL_INFEASIBLE_TOL,
+  ORC_S_DUAL_INFEASIBLE_TOL,
   ORC_S_COUNT
 };
 
@@ -123,6 +127,16 @@ void orc_eval(int m, int n, const int* offsets, const int* indices, const double
               const double* lo, const double* hi, const double* lb, const double* ub,
               double obj_scale, double obj_offset, int finite_bounds_rule, double rel_primal_tol,
               double rel_dual_tol, const double* x, const double* y, double* rc, double* out);
+
+/* infeasibility_information_t::compute_infeasibility_information (the iterate itself is the ray
+ * estimate), LP/termination_strategy/infeasibility_information.cu:176-223 and :115-172.
+ * out[0..3] = max_primal_ray_infeasibility, primal_ray_linear_objective,
+ *             max_dual_ray_infeasibility, dual_ray_linear_objective   (after compute_remaining_stats) */
+void orc_eval_infeasibility(int m, int n, const int* offsets, const int* indices, const double* values,
+                            const int* t_offsets, const int* t_indices, const double* t_values,
+                            const double* c, const double* lo, const double* hi, const double* lb,
+                            const double* ub, int finite_bounds_rule, const double* x, const double* y,
+                            double* out);
 
 /* Full PDLP solve.  c/lo/hi/lb/ub are the USER's problem (maximize handled inside like
  * problem_helpers.cuh:126-141).  init_x/init_y may be NULL.  x_out (n), y_out (m), rc_out (n).

@@ -271,3 +271,48 @@ def test_mip_style_warm_started_resolves(golden_problems):
         total_warm += rw["steps_taken"]
         total_cold += cold["steps_taken"]
     assert total_warm > 0
+
+
+def infeasible_lp_of_the_c_api_test():
+    """cpp/tests/linear_programming/c_api_tests/c_api_test.c:625-757 (9 constraints, 4 variables)"""
+    rhs = np.array([0.5, 3.0, 6.0, 2.0, 2.0, 5.0, 10.0, 14.0, 1.0])
+    sense = "GGLLLGLLG"
+    return dict(m=9, n=4, offsets=[0, 2, 4, 6, 7, 9, 10, 12, 15, 17],
+                indices=[0, 1, 0, 1, 0, 1, 3, 2, 3, 2, 0, 3, 0, 1, 2, 1, 2],
+                values=[-0.5, 1.0, 2.0, -1.0, 3.0, 1.0, 1.0, 3.0, -1.0, 1.0, 1.0, 1.0, 1.0, 2.0, 1.0, 1.0, 1.0],
+                c=[0.0] * 4, lb=[0.0] * 4, ub=[INF] * 4,
+                lo=np.array([rhs[i] if s in "GE" else -INF for i, s in enumerate(sense)]),
+                hi=np.array([rhs[i] if s in "LE" else INF for i, s in enumerate(sense)]))
+
+
+def test_infeasibility_information_matches_oracle():
+    """infeasibility_information.cu:176-223 on arbitrary iterates (both reduced-cost rules)"""
+    for p in (synthetic.generate(3000, 2500, 8, seed=41), infeasible_lp_of_the_c_api_test()):
+        rng = np.random.default_rng(7)
+        x = np.abs(rng.standard_normal(p["n"])) * (rng.random(p["n"]) < 0.8)
+        y = rng.standard_normal(p["m"])
+        for rule in (True, False):
+            dev = capi.Device(p)
+            dev.call("scaling_compute", 1, 10, 1, 1.0)
+            dev.call("scale_problem")
+            dev.call("set_initial", capi._ptr(x), capi._ptr(y))
+            dev.eval(capi.CURRENT, rule_finite=rule)
+            got = dev.eval_infeasibility(capi.CURRENT, rule_finite=rule)
+            ref = orcbind.evaluate_infeasibility(p, x, y, finite_bounds_rule=rule)
+            for k in ref:
+                assert got[k] == pytest.approx(ref[k], rel=1e-10, abs=1e-12), k
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_primal_infeasible_lp_is_detected(strict):
+    """the reference's own infeasible LP (solved there by dual simplex -> INFEASIBLE); PDLP with
+    infeasibility_detection must report PrimalInfeasible (status 2) like the oracle does"""
+    p = infeasible_lp_of_the_c_api_test()
+    o = orcbind.solve(p, infeasibility_detection=1, strict_infeasibility=int(strict), iteration_limit=20000)
+    r = capi.solve(p, method=1, infeasibility_detection=True, strict_infeasibility=strict, iteration_limit=20000)
+    assert o["status"] == "PrimalInfeasible"
+    assert r["status"] == "PrimalInfeasible" and r["status_code"] == 2
+    assert r["steps_taken"] == int(o["steps_taken"])
+    assert r["dual_ray_linear_objective"] > 0.0
+    # without detection the same LP just runs into the limit (reference default: detection off)
+    assert capi.solve(p, method=1, iteration_limit=400)["status"] == "IterationLimit"
