@@ -917,6 +917,7 @@ k_unscale(int n, const double* __restrict__ v, const double* __restrict__ d, dou
 // kMaxRowsPerBlock rows per block; a row longer than the LDS tile gets a block of its own.
 static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 {
+  const int64_t tile = kNnzBlock;  // (smaller tiles for small LPs were measured: no gain at 1e6 nnz)
   std::vector<int32_t> rb;
   rb.push_back(0);
   int32_t start = 0;
@@ -925,7 +926,7 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
     int64_t count = 0;
     while (end < rows && end - start < kMaxRowsPerBlock) {
       const int64_t len = (int64_t)off[end + 1] - off[end];
-      if (count + len > kNnzBlock) break;
+      if (count + len > tile) break;
       count += len;
       ++end;
     }
@@ -1156,7 +1157,6 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
-  if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
   for (void* p : ctx->allocs) (void)hipFree(p);
   if (ctx->scal_h) (void)hipHostFree(ctx->scal_h);
   if (ctx->ctl_h) (void)hipHostFree(ctx->ctl_h);
@@ -1177,9 +1177,19 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
 {
   TRY(rccl::load());
   HIP_TRY(hipSetDevice(ctx->device));
-  rccl::unique_id u;
-  memcpy(u.internal, id, 128);
-  RCCL_TRY(rccl::CommInitRank(&ctx->comm, world, u, rank));
+  // A unique id bootstraps exactly ONE communicator; solvers created later with the same id (bench.py makes
+  // two per process) share it.  Communicators live until process exit.
+  static std::map<std::string, rccl::comm_t> cache;
+  const std::string key((const char*)id, 128);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    rccl::unique_id u;
+    memcpy(u.internal, id, 128);
+    rccl::comm_t comm = nullptr;
+    RCCL_TRY(rccl::CommInitRank(&comm, world, u, rank));
+    it = cache.emplace(key, comm).first;
+  }
+  ctx->comm = it->second;
   ctx->rank = rank, ctx->world = world;
   return 0;
 }

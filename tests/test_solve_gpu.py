@@ -237,7 +237,7 @@ def test_warm_start_iterations_are_additive(seed, hard):
     assert r_full["status_name"] == r1["status_name"] == r2["status_name"] == "Optimal"
     assert r1["steps_taken"] + r2["steps_taken"] == r_full["steps_taken"]
     # x is unscaled in the snapshot and rescaled on restore ((x*d)/d != x in the last bit), like the reference
-    assert r2["primal_objective"] == pytest.approx(r_full["primal_objective"], rel=1e-6, abs=1e-6)
+    assert r2["primal_objective"] == pytest.approx(r_full["primal_objective"], abs=2 * fine * (1 + abs(r_full["primal_objective"])))
 
 
 def test_mip_style_warm_started_resolves(golden_problems):
@@ -317,3 +317,21 @@ def test_primal_infeasible_lp_is_detected(strict):
     assert r["dual_ray_linear_objective"] > 0.0
     # without detection the same LP just runs into the limit (reference default: detection off)
     assert capi.solve(p, method=1, iteration_limit=400)["status"] == "IterationLimit"
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_other_presets_follow_the_oracle(mode):
+    """Stable1 / Fast1 (LP/solve.cu:66-96,167-197: different scaling, step rule exponents, reduced-cost
+    rule, major-iteration schedule, Fast1's per-iteration artificial restart check)"""
+    p = synthetic.generate(3000, 2600, 9, seed=17)
+    for its in (3, 30):
+        r = capi.Solver(p, mode=mode, tol=0.0, iteration_limit=its).advance()
+        o = orcbind.solve(p, mode=mode, tol=0.0, iteration_limit=its)
+        assert (r["status_name"], r["steps_taken"], r["attempted_steps"]) == (o["status"], int(o["steps_taken"]), int(o["attempted_steps"]))
+        assert r["initial_step_size"] == pytest.approx(o["initial_step_size"], rel=1e-12)
+        assert r["initial_primal_weight"] == pytest.approx(o["initial_primal_weight"], rel=1e-10)
+        assert r["step_size"] == pytest.approx(o["final_step_size"], rel=1e-6)
+        assert r["primal_objective"] == pytest.approx(o["primal_objective"], rel=1e-6, abs=1e-6)
+    r = capi.solve(p, method=1, pdlp_solver_mode=mode, tol=1e-6)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 4e-5 * (1 + abs(p["objective_star"]))
