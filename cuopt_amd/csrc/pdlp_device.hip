@@ -571,6 +571,16 @@ k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
   StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
   csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr);
 }
+// panel twin of k_spmv_at_cur (A^T y of the iterate / of the trial iterate, optionally into `out_override`)
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_at_cur(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
+               const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
+               double* __restrict__ out_override, int use_next)
+{
+  const int cur = ctl->cur ^ (use_next ? 1 : 0);
+  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
+  panel_spmv_block(P, cur ? y1 : y0, e, nullptr);
+}
 __global__ void __launch_bounds__(kBlock)
 k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ out)
 {
@@ -1351,15 +1361,18 @@ int pdlpdev_project_primal(pdlpdev_ctx* ctx)
 }
 
 // ---- hot loop -------------------------------------------------------------------------------------
+}  // extern "C"
+static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next);
+extern "C" {
 int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 {
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   if (!ctx->comm) {
-    k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], nullptr, 0);
+    launch_at_cur(ctx, nullptr, 0);
     LAUNCH_CHECK();
   } else {
-    k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], ctx->ar_buf, 0);
+    launch_at_cur(ctx, ctx->ar_buf, 0);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)ctx->n, rccl::kSum));
     TRY(fetch_ctl(ctx, nullptr));
@@ -1388,6 +1401,14 @@ static void launch_at_step(pdlpdev_ctx* ctx)
   else
     k_spmv_at_step<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
 }
+static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
+{
+  hipStream_t s = ctx->stream;
+  if (ctx->pat.on)
+    k_panel_at_cur<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
+  else
+    k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
+}
 static void launch_decision(pdlpdev_ctx* ctx)
 {
   k_step_decision<<<1, kDecisionThreads, 0, ctx->stream>>>(ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at, step_partials(ctx), nullptr, ctx->sp);
@@ -1405,7 +1426,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     launch_decision(ctx);
   } else {
     // partial A^T y' of this row block -> ar_buf[0..n), ||dy||^2 partial -> ar_buf[n]; ONE all-reduce
-    k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], ctx->ar_buf, 1);
+    launch_at_cur(ctx, ctx->ar_buf, 1);
     k_sum_partials_to<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), ctx->ar_buf + n);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)n + 1, rccl::kSum));
@@ -1533,7 +1554,7 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
     if (which == PDLPDEV_AVERAGE) {
       k_spmv_plain<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->avgy, ctx->ar_buf);
     } else {
-      k_spmv_at_cur<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], ctx->ar_buf, 0);
+      launch_at_cur(ctx, ctx->ar_buf, 0);
     }
     HIP_TRY(hipMemcpyAsync(ctx->ar_buf + n, sc, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)n + 3, rccl::kSum));
