@@ -225,7 +225,8 @@ _proto("pdlpdev_set_graph_mode", c_int, c_void_p, c_int)
 _proto("pdlpdev_flush_average", c_int, c_void_p)
 _proto("pdlpdev_make_average", c_int, c_void_p, c_int)
 _proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)
-_proto("pdlpdev_restart", c_int, c_void_p, c_int, c_void_p)
+_proto("pdlpdev_restart", c_int, c_void_p, c_int, c_int, c_void_p)
+_proto("pdlpdev_trust_region_bounds", c_int, c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_void_p)
 _proto("pdlpdev_eval_infeasibility", c_int, c_void_p, c_int, c_int, c_void_p)
 _proto("pdlpdev_get_solution", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_download", C.c_int64, c_void_p, c_int, c_void_p, C.c_int64)
@@ -658,6 +659,12 @@ class Device:
         self._ck(lib.pdlpdev_eval_infeasibility(self.handle, which, int(rule_finite), _ptr(out)))
         return dict(zip(["max_primal_ray_infeasibility", "primal_ray_linear_objective",
                          "max_dual_ray_infeasibility", "dual_ray_linear_objective"], out.tolist()))
+
+    def trust_region_bounds(self, which, wp, wd, pds=0.5, dds=0.5, primal_weight=1.0, radius=-1.0):
+        out = np.zeros(6)
+        self._ck(lib.pdlpdev_trust_region_bounds(self.handle, which, wp, wd, pds, dds, primal_weight, radius, _ptr(out)))
+        return dict(zip(["primal_distance2", "dual_distance2", "distance", "lagrangian", "lower_bound",
+                         "upper_bound"], out.tolist()))
 
     def init_norms(self):
         out = np.zeros(3)

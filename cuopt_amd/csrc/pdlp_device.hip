@@ -111,7 +111,8 @@ struct pdlpdev_ctx {
   double *xbar = nullptr, *sumx = nullptr, *sumy = nullptr, *avgx = nullptr, *avgy = nullptr;
   double *lrx = nullptr, *lry = nullptr, *rc[2] = {nullptr, nullptr};
   double *tmp_n = nullptr, *tmp_m = nullptr;
-  double *ax_u = nullptr, *aty_u = nullptr;  // unscaled A x / A^T y of the last pdlpdev_eval
+  double *ax_u[3] = {nullptr, nullptr, nullptr}, *aty_u[3] = {nullptr, nullptr, nullptr};  // unscaled A x / A^T y of pdlpdev_eval(which)
+  double* rc_scratch = nullptr;  // reduced costs of eval(LAST_RESTART): never returned
   // reductions
   double *part_a = nullptr, *part_at = nullptr;  // per-row-block partials (8 quantities each)
   double *part_g = nullptr;                      // generic grid-stride partials
@@ -850,10 +851,160 @@ k_infeas_cols(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, int which, co
   }
 }
 
+
+// ---- trust-region restart support (Methodical1) -------------------------------------------------------
+// Virtual element k of the joint vector z = (x, y) of the UNSCALED problem at point `which`:
+//   k <  n : center x_k, objective g_k = c_k - (A^T y)_k, bounds [lb, ub], weight wp
+//   k >= n : center y_i, objective -(subgradient_i - (A x)_i), transformed bounds, weight wd
+// (solve_bound_constrained_trust_region :1400-1465; compute_subgradient_kernel :1739-1780;
+//  compute_direction_and_threshold utils.cuh:291-322; transformed bounds utils.cuh:242-255)
+struct TrPoint {
+  const double* __restrict__ xhat;
+  const double* __restrict__ yhat;
+  const double* __restrict__ lrx;
+  const double* __restrict__ lry;
+  const double* __restrict__ dc;
+  const double* __restrict__ dr;
+  const double* __restrict__ aty;
+  const double* __restrict__ ax;
+  const double* __restrict__ c_u;
+  const double* __restrict__ lb_u;
+  const double* __restrict__ ub_u;
+  const double* __restrict__ lo_u;
+  const double* __restrict__ hi_u;
+  int n, m;
+  double wp, wd;
+};
+struct TrElem {
+  double center, obj, lb, ub, w, dir, thr, grad, sub;  // grad: primal / dual gradient; sub: dual subgradient
+};
+__device__ __forceinline__ TrElem tr_element(const TrPoint& P, int k)
+{
+  TrElem e;
+  if (k < P.n) {
+    e.center = P.xhat[k] * P.dc[k];
+    e.grad   = P.c_u[k] - P.aty[k];
+    e.obj    = e.grad;
+    e.sub    = 0.0;
+    e.lb = P.lb_u[k], e.ub = P.ub_u[k], e.w = P.wp;
+  } else {
+    const int i      = k - P.n;
+    const double yi  = P.yhat[i] * P.dr[i];
+    const double lo = P.lo_u[i], hi = P.hi_u[i], pp = P.ax[i];
+    double sub;
+    if (yi < 0.0)
+      sub = hi;
+    else if (yi > 0.0)
+      sub = lo;
+    else if (!dfinite(hi) && !dfinite(lo))
+      sub = 0.0;
+    else if (!dfinite(hi) && dfinite(lo))
+      sub = lo;
+    else if (dfinite(hi) && !dfinite(lo))
+      sub = hi;
+    else
+      sub = pp < lo ? lo : (pp > hi ? hi : pp);
+    e.center = yi;
+    e.sub    = sub;
+    e.grad   = sub - pp;
+    e.obj    = -e.grad;
+    e.lb     = dfinite(hi) ? -__builtin_huge_val() : 0.0;
+    e.ub     = dfinite(lo) ? __builtin_huge_val() : 0.0;
+    e.w      = P.wd;
+  }
+  e.dir = 0.0, e.thr = 0.0;
+  if (e.center >= e.ub && e.obj <= 0.0) return e;
+  if (e.center <= e.lb && e.obj >= 0.0) return e;
+  if (e.obj == 0.0) {
+    e.thr = __builtin_huge_val();
+    return e;
+  }
+  e.dir = -e.obj / e.w;
+  if (e.dir > 0.0)
+    e.thr = (e.ub - e.center) / e.dir;
+  else if (e.dir < 0.0)
+    e.thr = (e.lb - e.center) / e.dir;
+  return e;
+}
+// pass 0: distances to the last-restart anchors, the three Lagrangian dot products, ||objective||^2,
+//         sum w dir^2 over everything, largest finite threshold
+__global__ void __launch_bounds__(kBlock) k_tr_stats(TrPoint P, int nbg, double* __restrict__ part)
+{
+  __shared__ double red[40];
+  double sm[7] = {0, 0, 0, 0, 0, 0, 0}, mx[1] = {0.0};
+  const int N = P.n + P.m;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+    const TrElem e = tr_element(P, k);
+    if (k < P.n) {
+      const double d = (P.lrx[k] - P.xhat[k]) * P.dc[k];
+      sm[0] += d * d;
+      sm[2] += P.c_u[k] * e.center;
+      sm[3] += e.center * P.aty[k];
+    } else {
+      const int i    = k - P.n;
+      const double d = (P.lry[i] - P.yhat[i]) * P.dr[i];
+      sm[1] += d * d;
+      sm[4] += e.center * e.sub;  // y . subgradient
+    }
+    sm[5] += e.obj * e.obj;
+    sm[6] += e.w * e.dir * e.dir;
+    if (dfinite(e.thr) && e.thr > mx[0]) mx[0] = e.thr;
+  }
+  block_reduce<SumOp, 7>(sm, red);
+  __syncthreads();
+  block_reduce<MaxOp, 1>(mx, red + 32);
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 7; ++q) part[(size_t)q * nbg + blockIdx.x] = sm[q];
+    part[(size_t)7 * nbg + blockIdx.x] = mx[0];
+  }
+}
+// pass(t): low(t) = sum_{thr <= t} w (clamp(center + t dir) - center)^2 ; high(t) = sum_{thr > t} w dir^2
+__global__ void __launch_bounds__(kBlock) k_tr_pass(TrPoint P, double t, int nbg, double* __restrict__ part)
+{
+  __shared__ double red[12];
+  double sm[2] = {0.0, 0.0};
+  const int N = P.n + P.m;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+    const TrElem e = tr_element(P, k);
+    if (e.dir == 0.0) continue;
+    if (e.thr <= t) {
+      const double tp = dmin(dmax(e.center + t * e.dir, e.lb), e.ub);
+      const double d  = tp - e.center;
+      sm[0] += (d * d) * e.w;
+    } else {
+      sm[1] += (e.dir * e.dir) * e.w;
+    }
+  }
+  block_reduce<SumOp, 2>(sm, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x]       = sm[0];
+    part[nbg + blockIdx.x] = sm[1];
+  }
+}
+// final: sum g_x (x_tr - x), sum g_y (y_tr - y) with z_tr = clamp(center + t dir)  (compute_bound :1052-1076)
+__global__ void __launch_bounds__(kBlock) k_tr_final(TrPoint P, double t, int nbg, double* __restrict__ part)
+{
+  __shared__ double red[12];
+  double sm[2] = {0.0, 0.0};
+  const int N = P.n + P.m;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+    const TrElem e = tr_element(P, k);
+    double tr      = e.center;
+    if (e.dir != 0.0) tr = dmin(dmax(e.center + t * e.dir, e.lb), e.ub);
+    sm[k < P.n ? 0 : 1] += (tr - e.center) * e.grad;
+  }
+  block_reduce<SumOp, 2>(sm, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x]       = sm[0];
+    part[nbg + blockIdx.x] = sm[1];
+  }
+}
+
 // restart: squared distances to the last-restart anchors, candidate -> iterate/anchors, sums <- 0
 // (pdlp_restart_strategy.cu:593-623,752-839)
 __global__ void __launch_bounds__(kBlock)
-k_restart(int n, int m, int which, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0,
+k_restart(int n, int m, int which, int unscaled, const double* __restrict__ dc, const double* __restrict__ dr,
+          const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0,
           double* __restrict__ x1, double* __restrict__ y0, double* __restrict__ y1,
           const double* __restrict__ avgx, const double* __restrict__ avgy, double* __restrict__ lrx,
           double* __restrict__ lry, double* __restrict__ sumx, double* __restrict__ sumy,
@@ -868,7 +1019,8 @@ k_restart(int n, int m, int which, const pdlpdev_ctl* __restrict__ ctl, double* 
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < tot; i += gridDim.x * kBlock) {
     if (i < n) {
       const double cand = which == PDLPDEV_AVERAGE ? avgx[i] : x[i];
-      const double d    = lrx[i] - 1.0 * cand;
+      double d          = lrx[i] - 1.0 * cand;
+      if (unscaled) d *= dc[i];
       acc[0] += d * d;
       if (which == PDLPDEV_AVERAGE) x[i] = cand;
       lrx[i]  = cand;
@@ -876,7 +1028,8 @@ k_restart(int n, int m, int which, const pdlpdev_ctl* __restrict__ ctl, double* 
     }
     if (i < m) {
       const double cand = which == PDLPDEV_AVERAGE ? avgy[i] : y[i];
-      const double d    = lry[i] - 1.0 * cand;
+      double d          = lry[i] - 1.0 * cand;
+      if (unscaled) d *= dr[i];
       acc[1] += d * d;
       if (which == PDLPDEV_AVERAGE) y[i] = cand;
       lry[i]  = cand;
@@ -1130,7 +1283,11 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(dev_alloc(ctx, &ctx->avgx, n)); TRY(dev_alloc(ctx, &ctx->avgy, m));
   TRY(dev_alloc(ctx, &ctx->lrx, n)); TRY(dev_alloc(ctx, &ctx->lry, m));
   TRY(dev_alloc(ctx, &ctx->tmp_n, n)); TRY(dev_alloc(ctx, &ctx->tmp_m, m));
-  TRY(dev_alloc(ctx, &ctx->ax_u, m)); TRY(dev_alloc(ctx, &ctx->aty_u, n));
+  for (int i = 0; i < 3; ++i) {
+    TRY(dev_alloc(ctx, &ctx->ax_u[i], m));
+    TRY(dev_alloc(ctx, &ctx->aty_u[i], n));
+  }
+  TRY(dev_alloc(ctx, &ctx->rc_scratch, n));
   {
     // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel ; CUOPT_AMD_SLAB_BYTES (default 1 MiB)
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
@@ -1531,28 +1688,32 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int n = ctx->n, m = ctx->m;
+  // LAST_RESTART is evaluated like the average, with the anchors in the "alternative iterate" slots
+  const double* altx = which == PDLPDEV_LAST_RESTART ? ctx->lrx : ctx->avgx;
+  const double* alty = which == PDLPDEV_LAST_RESTART ? ctx->lry : ctx->avgy;
+  const int kw       = which == PDLPDEV_CURRENT ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE;
   double* sc = ctx->scal;  // layout: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
   if (ctx->pa.on)
-    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u, ctx->part_a);
+    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u[which], ctx->part_a);
   else
-    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u, ctx->part_a);
+    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u[which], ctx->part_a);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
   {
     const int g = std::min(grid_for(m), kGenericBlocks);
     k_max_partials<<<g, kBlock, 0, s>>>(m, ctx->tmp_m, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 1u, sc + 3);
   }
-  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n, ctx->aty_u};
+  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n, ctx->aty_u[which]};
   if (!ctx->comm) {
     if (ctx->pat.on)
-      k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
+      k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else
-      k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->y[0], ctx->y[1], ctx->avgy, core, ctx->part_at);
+      k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_at, step_partials(ctx), 4, 0u, sc + 4);
   } else {
     // partial A^T y of this row block, all-reduced together with the three dual-side row sums
-    if (which == PDLPDEV_AVERAGE) {
-      k_spmv_plain<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->avgy, ctx->ar_buf);
+    if (kw == PDLPDEV_AVERAGE) {
+      k_spmv_plain<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, alty, ctx->ar_buf);
     } else {
       launch_at_cur(ctx, ctx->ar_buf, 0);
     }
@@ -1561,7 +1722,7 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
     HIP_TRY(hipMemcpyAsync(sc, ctx->ar_buf + n, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     TRY(allreduce(ctx, sc + 3, 1, rccl::kMax));
     const int g = std::min(grid_for(n), kGenericBlocks);
-    k_eval_dual_elementwise<<<g, kBlock, 0, s>>>(n, g, ctx->ctl, which, ctx->x[0], ctx->x[1], ctx->avgx, ctx->ar_buf, core, ctx->part_g);
+    k_eval_dual_elementwise<<<g, kBlock, 0, s>>>(n, g, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->ar_buf, core, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 4, 0u, sc + 4);
   }
   {
@@ -1592,9 +1753,9 @@ int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_b
   const int gr = std::min(grid_for(m), kGenericBlocks), gc = std::min(grid_for(n), kGenericBlocks);
   double* part_rows = ctx->part_g;             // 3 * gr
   double* part_cols = ctx->part_g + 3 * 2048;  // 6 * gc  (part_g holds 8 * 2048)
-  k_infeas_rows<<<gr, kBlock, 0, s>>>(m, gr, ctx->ctl, which, ctx->ax_u, ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, part_rows);
+  k_infeas_rows<<<gr, kBlock, 0, s>>>(m, gr, ctx->ctl, which, ctx->ax_u[which], ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, part_rows);
   k_finalize<<<1, kBlock, 0, s>>>(part_rows, gr, 3, 0x3u, ctx->scal + 16);
-  k_infeas_cols<<<gc, kBlock, 0, s>>>(n, gc, ctx->ctl, which, ctx->aty_u, ctx->x[0], ctx->x[1], ctx->avgx, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, rc_rule_finite_bounds, part_cols);
+  k_infeas_cols<<<gc, kBlock, 0, s>>>(n, gc, ctx->ctl, which, ctx->aty_u[which], ctx->x[0], ctx->x[1], ctx->avgx, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, rc_rule_finite_bounds, part_cols);
   k_finalize<<<1, kBlock, 0, s>>>(part_cols, gc, 6, 0xFu, ctx->scal + 24);
   LAUNCH_CHECK();
   HIP_TRY(hipMemcpyAsync(ctx->scal_h + 16, ctx->scal + 16, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1620,12 +1781,70 @@ int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_b
   return 0;
 }
 
-int pdlpdev_restart(pdlpdev_ctx* ctx, int which, double dist2[2])
+int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double wp, double wd, double pds, double dds,
+                                double primal_weight, double radius, double out[6])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->comm) return fail(-7, "trust-region restart is not available on the row-block sharded path yet");
+  TRY(fetch_ctl(ctx, nullptr));
+  const int cur = ctx->ctl_h->cur;
+  hipStream_t s = ctx->stream;
+  TrPoint P{which == PDLPDEV_CURRENT ? ctx->x[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgx : ctx->lrx),
+            which == PDLPDEV_CURRENT ? ctx->y[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgy : ctx->lry),
+            ctx->lrx, ctx->lry, ctx->dc, ctx->dr, ctx->aty_u[which], ctx->ax_u[which], ctx->c_u, ctx->lb_u,
+            ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->n, ctx->m, wp, wd};
+  const int g = std::min(grid_for((int64_t)ctx->n + ctx->m), kGenericBlocks);
+  k_tr_stats<<<g, kBlock, 0, s>>>(P, g, ctx->part_g);
+  k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 8, 0x80u, ctx->scal + 32);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->scal_h + 32, ctx->scal + 32, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const double* st = ctx->scal_h + 32;
+  const double pd2 = st[0], dd2 = st[1];
+  // compute_distance_traveled_last_restart_kernel :803-817
+  const double own = sqrt(pd2 * pds * primal_weight + dd2 * (dds / primal_weight));
+  const double T   = radius >= 0.0 ? radius : own;
+  const double lagrangian = (st[2] - st[3]) + st[4];  // compute_lagrangian_value :1817-1900
+  double t = 0.0;
+  if (!(T == 0.0 || sqrt(st[5]) == 0.0)) {
+    // Monotone fixed point on the breakpoint structure: with the partition of coordinates frozen at t the
+    // radius is low(t) + s^2 high(t); its root s = F(t) satisfies t < F(t) <= t* for t < t*, and F(t*) = t*.
+    // Start from the unconstrained root; stop when the partition (hence t) no longer changes.
+    t = st[6] > 0.0 ? T / sqrt(st[6]) : 0.0;
+    for (int it = 0; it < 200; ++it) {
+      k_tr_pass<<<g, kBlock, 0, s>>>(P, t, g, ctx->part_g);
+      k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 2, 0u, ctx->scal + 40);
+      LAUNCH_CHECK();
+      HIP_TRY(hipMemcpyAsync(ctx->scal_h + 40, ctx->scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      const double low = ctx->scal_h[40], high = ctx->scal_h[41];
+      if (high <= 0.0) {  // everything that moves is at its bound (target_threshold_determination_kernel)
+        t = st[7];
+        break;
+      }
+      const double rem = T * T - low;
+      const double tn  = rem > 0.0 ? sqrt(rem / high) : t;
+      if (!(tn > t)) break;
+      t = tn;
+    }
+  }
+  k_tr_final<<<g, kBlock, 0, s>>>(P, t, g, ctx->part_g);
+  k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 2, 0u, ctx->scal + 40);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->scal_h + 40, ctx->scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  out[0] = pd2, out[1] = dd2, out[2] = own, out[3] = lagrangian;
+  out[4] = lagrangian + ctx->scal_h[40];
+  out[5] = lagrangian + ctx->scal_h[41];
+  return 0;
+}
+
+int pdlpdev_restart(pdlpdev_ctx* ctx, int which, int unscaled_distances, double dist2[2])
 {
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int g = std::min(grid_for(std::max(ctx->n, ctx->m)), kGenericBlocks);
-  k_restart<<<g, kBlock, 0, s>>>(ctx->n, ctx->m, which, ctx->ctl, ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->avgx, ctx->avgy, ctx->lrx, ctx->lry, ctx->sumx, ctx->sumy, ctx->part_g);
+  k_restart<<<g, kBlock, 0, s>>>(ctx->n, ctx->m, which, unscaled_distances, ctx->dc, ctx->dr, ctx->ctl, ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->avgx, ctx->avgy, ctx->lrx, ctx->lry, ctx->sumx, ctx->sumy, ctx->part_g);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 2, 0u, ctx->scal);
   k_restart_ctl<<<1, 1, 0, s>>>(ctx->ctl);
   LAUNCH_CHECK();

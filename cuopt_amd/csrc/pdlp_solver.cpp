@@ -86,6 +86,9 @@ struct cuoptamd_solver {
   int32_t major_done_at    = -1;
   bool step_error = false, need_aty = true, last_restart_was_average = false;
   double last_candidate_kkt = 0.0, last_restart_kkt = 0.0;
+  // the reference leaves gap_reduction_ratio_last_trial_ uninitialised (pdlp_restart_strategy.cu:160);
+  // 1.0 is the published algorithm's start value (same choice as the oracle)
+  double gap_reduction_ratio_last_trial = 1.0;
   pdlpdev_ctl ctl{};
   Convergence conv_current, conv_average;
   int returned_which = PDLPDEV_CURRENT;
@@ -312,7 +315,7 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
         s->result.num_restarts += 1;
         const bool really_average = to_average && !H.never_restart_to_average;
         double dist2[2];
-        DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, dist2));
+        DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, !H.rescale_for_restart, dist2));
         s->last_restart_was_average = really_average;
         if (really_average) s->need_aty = true;  // pdhg.cu:183-184
         s->ctl.its_since_restart = 0;
@@ -329,6 +332,52 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
         s->last_restart_kkt = candidate;
       }
       s->last_candidate_kkt = candidate;
+    }
+  }
+  // ---- run_trust_region_restart (pdlp_restart_strategy.cu:277-364), Methodical1 ----
+  if (H.restart_strategy == 2 && s->ctl.its_since_restart != 0) {
+    const double tau = s->ctl.tau, sigma = s->ctl.sigma;
+    const double wp = tau == 0.0 ? 0.0 : 1.0 / tau, wd = sigma == 0.0 ? 0.0 : 1.0 / sigma;  // norm weights :301-310
+    const double pds = H.primal_distance_smoothing, dds = H.dual_distance_smoothing;
+    bool restart = s->ctl.its_since_restart >= H.artificial_restart_threshold * s->total_iterations;
+    // compute_localized_duality_gaps :982-1030 (A x / A^T y of both iterates are those of the evaluations above)
+    double avg[6], cur[6];
+    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_AVERAGE, wp, wd, pds, dds, w, -1.0, avg));
+    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_CURRENT, wp, wd, pds, dds, w, -1.0, cur));
+    const double ng_avg = (avg[5] - avg[4]) / avg[2], ng_cur = (cur[5] - cur[4]) / cur[2];
+    const bool to_average = ng_cur / cur[2] >= ng_avg / avg[2];  // pick_restart_candidate_kernel :841-856
+    const double* cand    = to_average ? avg : cur;
+    const double ng_cand  = to_average ? ng_avg : ng_cur;
+    if (!restart) {  // should_do_adaptive_restart_normalized_duality_gap :905-937
+      double ev_lr[PDLPDEV_EV_COUNT], lr[6];
+      DEV(pdlpdev_eval(dev, PDLPDEV_LAST_RESTART, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev_lr));
+      DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_LAST_RESTART, wp, wd, pds, dds, w, cand[2], lr));
+      const double ng_lr = (lr[5] - lr[4]) / cand[2];
+      const double ratio = ng_cand / ng_lr;  // adaptive_restart_triggered :876-903
+      if (ratio < H.necessary_reduction_for_restart &&
+          (ratio < H.sufficient_reduction_for_restart || ratio > s->gap_reduction_ratio_last_trial))
+        restart = true;
+      s->gap_reduction_ratio_last_trial = ratio;
+    }
+    if (restart) {
+      s->result.num_restarts += 1;
+      const bool really_average = to_average && !H.never_restart_to_average;
+      double dist2[2];
+      DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, 1, dist2));
+      // the reference measures the distances of the PICKED candidate even when never_restart_to_average
+      // redirects the copy; only Fast1 sets that flag and it uses the KKT restart
+      s->last_restart_was_average = really_average;
+      if (really_average) s->need_aty = true;
+      s->ctl.its_since_restart = 0;
+      s->ctl.sum_weights       = 0.0;
+      const double pd = std::sqrt(cand[0]), dd = std::sqrt(cand[1]);
+      const double guard = 1.0e-10;
+      if (!(pd < guard || pd >= 1.0 / guard || dd < guard || dd >= 1.0 / guard)) {
+        const double theta = H.primal_weight_update_smoothing;
+        const double nw    = std::exp(theta * std::log(dd / pd) + (1.0 - theta) * std::log(w));
+        DEV(pdlpdev_set_step(dev, -1.0, nw));
+        s->ctl.primal_weight = nw;
+      }
     }
   }
   return 0;
@@ -460,8 +509,10 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
 {
   if (!out || !lp || !hyper || !settings) return fail(-1, "cuoptamd_solver_create: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(-1, "cuoptamd_solver_create: bad rank/world");
-  if (hyper->restart_strategy == 2)
-    return fail(-7, "trust-region restart (pdlp_solver_mode Methodical1) is not implemented");
+  if (hyper->restart_strategy == 2 && hyper->rescale_for_restart)
+    return fail(-7, "trust-region restart is implemented for rescale_for_restart = false only (every preset that uses it)");
+  if (hyper->restart_strategy == 2 && world > 1)
+    return fail(-7, "trust-region restart (Methodical1) is single-GPU only");
   const auto t0 = clock_type::now();
   cuoptamd_solver* s = new cuoptamd_solver();
   *out               = s;

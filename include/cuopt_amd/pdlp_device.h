@@ -80,7 +80,7 @@ enum {
 };
 
 /* which iterate */
-enum { PDLPDEV_CURRENT = 0, PDLPDEV_AVERAGE = 1 };
+enum { PDLPDEV_CURRENT = 0, PDLPDEV_AVERAGE = 1, PDLPDEV_LAST_RESTART = 2 /* eval / trust region only */ };
 
 /* ids for pdlpdev_download (debug / parity tests) */
 enum {
@@ -200,8 +200,22 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
 int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double out[4]);
 /* Restart to `which` (CURRENT or AVERAGE): dist2[0] = ||x_c - x_last_restart||^2, dist2[1] same for
  * y (scaled space); copies the candidate into the iterate when it is the average; anchors <-
- * candidate; sums <- 0; its_since_restart <- 0. */
-int pdlpdev_restart(pdlpdev_ctx* ctx, int which, double dist2[2]);
+ * candidate; sums <- 0; its_since_restart <- 0.  unscaled_distances != 0: the distances are those of the
+ * UNSCALED iterates (presets with rescale_for_restart = false run the restart on unscaled iterates,
+ * pdlp.cu:1144-1175); the anchors themselves always stay in the solver's scaled space. */
+int pdlpdev_restart(pdlpdev_ctx* ctx, int which, int unscaled_distances, double dist2[2]);
+/* Trust-region restart support (Methodical1; bound_optimal_objective + solve_bound_constrained_trust_region,
+ * pdlp_restart_strategy.cu:1032-1050,1391-1678) for the point `which` whose pdlpdev_eval(which) ran last
+ * (its A x / A^T y are reused), on the UNSCALED problem:
+ *   in : primal/dual norm weights (1/tau, 1/sigma), distance smoothing constants, primal weight,
+ *        radius (< 0: use the point's own distance_traveled)
+ *   out: {primal_distance^2, dual_distance^2, distance_traveled, lagrangian, lower_bound, upper_bound}
+ * The breakpoint search of the reference (sort + median bisection in a cooperative kernel) is replaced by a
+ * monotone fixed-point iteration t <- sqrt((r^2 - low(t)) / high(t)) of streaming passes: same threshold. */
+int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double primal_norm_weight,
+                                double dual_norm_weight, double primal_distance_smoothing,
+                                double dual_distance_smoothing, double primal_weight, double radius,
+                                double out[6]);
 
 /* ---- results ---------------------------------------------------------------------------------- */
 /* UNSCALED x (n), y (m), reduced costs (n, from the last eval of that iterate); any may be NULL */

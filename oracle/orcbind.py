@@ -44,6 +44,7 @@ def lib():
         _lib.orc_csr_transpose.argtypes = [ci, ci] + [vp] * 6
         _lib.orc_compute_scaling.argtypes = [ci, ci] + [vp] * 9
         _lib.orc_eval.argtypes = [ci, ci] + [vp] * 11 + [cd, cd, ci, cd, cd] + [vp] * 4
+        _lib.orc_trust_region_bounds.argtypes = [ci, ci] + [vp] * 11 + [cd, cd, cd] + [vp] * 3
         _lib.orc_eval_infeasibility.argtypes = [ci, ci] + [vp] * 11 + [ci] + [vp] * 3
         _lib.orc_pdlp_solve.argtypes = [ci, ci] + [vp] * 8 + [ci, cd] + [vp] * 8
         _lib.orc_pdlp_solve.restype = ci
@@ -126,6 +127,22 @@ def evaluate(p, x, y, finite_bounds_rule=True, rel_primal_tol=1e-4, rel_dual_tol
     r = dict(zip(keys, out.tolist()))
     r["reduced_cost"] = rc
     return r
+
+
+def trust_region_bounds(p, x, y, wp, wd, radius):
+    m, n = int(p["m"]), int(p["n"])
+    offsets, indices, values = _i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"])
+    to, ti, tv = transpose(m, n, offsets, indices, values)
+    c = _f64(p["c"]).copy()
+    if p.get("maximize", False):
+        c = -c
+    lo, hi, lb, ub = (_f64(p[k]) for k in ("lo", "hi", "lb", "ub"))
+    out = np.zeros(3)
+    x, y = _f64(x), _f64(y)
+    lib().orc_trust_region_bounds(m, n, _p(offsets), _p(indices), _p(values), _p(to), _p(ti), _p(tv), _p(c),
+                                  _p(lo), _p(hi), _p(lb), _p(ub), float(wp), float(wd), float(radius), _p(x),
+                                  _p(y), _p(out))
+    return dict(lagrangian=out[0], lower_bound=out[1], upper_bound=out[2])
 
 
 def evaluate_infeasibility(p, x, y, finite_bounds_rule=True):

@@ -530,6 +530,191 @@ static double kkt_score(const double* ev, double w)
   return sqrt(w2 * ev[4] * ev[4] + ev[5] * ev[5] / w2 + ev[2] * ev[2]);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* trust-region restart (Methodical1): LP/restart_strategy/pdlp_restart_strategy.cu            */
+/*   run_trust_region_restart :277-364, compute_localized_duality_gaps :982-1030,              */
+/*   bound_optimal_objective :1032-1050, solve_bound_constrained_trust_region :1290-1678,      */
+/*   gradients / lagrangian :1716-1900.  The restart strategy object is built on the UNSCALED  */
+/*   problem (pdlp.cu:99-103) and, with rescale_for_restart = false, sees unscaled iterates.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const double *x, *y;      /* the point (unscaled) */
+  double pd2, dd2;          /* squared distances to the last restart point */
+  double distance;          /* distance_traveled (weighted) */
+  double lagrangian, lower, upper, normalized_gap;
+} gap_t;
+
+typedef struct {
+  double thr, dir, lb, ub, center, w;
+} tr_item;
+static int tr_cmp(const void* a, const void* b)
+{
+  double x = ((const tr_item*)a)->thr, y = ((const tr_item*)b)->thr;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* bound_optimal_objective on the unscaled problem; radius = g->distance; wp/wd = norm weights */
+static void bound_optimal_objective(int m, int n, const int* off, const int* idx, const double* val,
+                                    const int* toff, const int* tidx, const double* tval,
+                                    const double* c, const double* lo, const double* hi,
+                                    const double* lb, const double* ub, double wp, double wd, gap_t* g)
+{
+  const int N = n + m;
+  double* gx  = dalloc((size_t)n); /* primal gradient c - A^T y          :1716-1737 */
+  double* gy  = dalloc((size_t)m); /* dual gradient  subgradient - A x   :1782-1815 */
+  double* aty = dalloc((size_t)n);
+  double* sub = dalloc((size_t)m);
+  orc_spmv(n, toff, tidx, tval, g->y, aty);
+  for (int j = 0; j < n; ++j) gx[j] = c[j] + (-1.0) * aty[j];
+  orc_spmv(m, off, idx, val, g->x, gy);
+  for (int i = 0; i < m; ++i) { /* compute_subgradient_kernel :1739-1780 */
+    double lower = lo[i], upper = hi[i], pp = gy[i], yi = g->y[i], sc;
+    if (yi < 0.0)
+      sc = upper;
+    else if (yi > 0.0)
+      sc = lower;
+    else if (!isfinite(upper) && !isfinite(lower))
+      sc = 0.0;
+    else if (!isfinite(upper) && isfinite(lower))
+      sc = lower;
+    else if (isfinite(upper) && !isfinite(lower))
+      sc = upper;
+    else
+      sc = pp < lower ? lower : (pp > upper ? upper : pp);
+    sub[i] = sc;
+    gy[i]  = sc - gy[i];
+  }
+  /* compute_lagrangian_value :1817-1900 : c.x - x.(A^T y) + y.subgradient */
+  g->lagrangian = (blocked_sum2(n, g->x, c) - blocked_sum2(n, g->x, aty)) + blocked_sum2(m, g->y, sub);
+
+  /* solve_bound_constrained_trust_region :1391-1678 */
+  double* xtr = dalloc((size_t)n);
+  double* ytr = dalloc((size_t)m);
+  double obj2 = 0.0;
+  for (int j = 0; j < n; ++j) obj2 += gx[j] * gx[j];
+  for (int i = 0; i < m; ++i) obj2 += gy[i] * gy[i];
+  if (g->distance == 0.0 || sqrt(obj2) == 0.0) {
+    memcpy(xtr, g->x, sizeof(double) * (size_t)n);
+    memcpy(ytr, g->y, sizeof(double) * (size_t)m);
+  } else {
+    tr_item* it   = (tr_item*)calloc((size_t)N, sizeof(tr_item));
+    double* udir  = dalloc((size_t)N); /* unsorted_direction_full_ */
+    for (int k = 0; k < N; ++k) {
+      double center, obj, lower, upper, wt;
+      if (k < n) {
+        center = g->x[k], obj = gx[k], lower = lb[k], upper = ub[k], wt = wp;
+      } else {
+        int i  = k - n; /* objective = -dual gradient ; transformed bounds utils.cuh:242-255 */
+        center = g->y[i], obj = -gy[i], wt = wd;
+        lower  = isfinite(hi[i]) ? -ORC_INF : 0.0;
+        upper  = isfinite(lo[i]) ? ORC_INF : 0.0;
+      }
+      it[k].center = center, it[k].lb = lower, it[k].ub = upper, it[k].w = wt;
+      it[k].dir = 0.0, it[k].thr = 0.0;
+      /* compute_direction_and_threshold, utils.cuh:291-322 */
+      if (center >= upper && obj <= 0.0) continue;
+      if (center <= lower && obj >= 0.0) continue;
+      if (obj == 0.0) {
+        it[k].thr = ORC_INF;
+        continue;
+      }
+      it[k].dir = -obj / wt;
+      if (it[k].dir > 0.0)
+        it[k].thr = (upper - center) / it[k].dir;
+      else if (it[k].dir < 0.0)
+        it[k].thr = (lower - center) / it[k].dir;
+    }
+    double high_r2 = 0.0, low_r2 = 0.0; /* weighted_l2_if_infinite, utils.cuh:325-341 */
+    for (int k = 0; k < N; ++k) {
+      udir[k] = it[k].dir;
+      if (isinf(it[k].thr)) high_r2 += it[k].dir * it[k].dir * it[k].w;
+    }
+    qsort(it, (size_t)N, sizeof(tr_item), tr_cmp);
+    int lowi = 0, highi = N;
+    for (int k = N - 1; k >= 0; --k)
+      if (it[k].thr == -ORC_INF) {
+        lowi = k + 1;
+        break;
+      }
+    for (int k = 0; k < N; ++k)
+      if (it[k].thr == ORC_INF) {
+        highi = k;
+        break;
+      }
+    const double target = g->distance;
+    while (lowi != highi) { /* solve_bound_constrained_trust_region_kernel :1290-1356 */
+      int size    = highi - lowi;
+      double test = (size & 1) == 0 ? 0.5 * (it[lowi + size / 2 - 1].thr + it[lowi + size / 2].thr)
+                                    : it[lowi + size / 2].thr;
+      double test_r2 = 0.0;
+      for (int k = lowi; k < highi; ++k) {
+        double tp = dmin(dmax(it[k].center + test * it[k].dir, it[k].lb), it[k].ub);
+        double d  = tp - it[k].center;
+        test_r2 += (d * d) * it[k].w;
+      }
+      int too_high = low_r2 + test_r2 + (test * test) * high_r2 >= target * target;
+      if (too_high) {
+        int nh = highi;
+        for (int k = lowi; k < highi; ++k)
+          if (it[k].thr >= test) {
+            nh = k;
+            break;
+          }
+        for (int k = nh; k < highi; ++k) high_r2 += (it[k].dir * it[k].dir) * it[k].w;
+        highi = nh;
+      } else {
+        int nl = lowi;
+        for (int k = highi - 1; k >= lowi; --k)
+          if (it[k].thr <= test) {
+            nl = k + 1;
+            break;
+          }
+        for (int k = lowi; k < nl; ++k) {
+          double tp = dmin(dmax(it[k].center + test * it[k].dir, it[k].lb), it[k].ub);
+          double d  = tp - it[k].center;
+          low_r2 += (d * d) * it[k].w;
+        }
+        lowi = nl;
+      }
+    }
+    double tthr; /* target_threshold_determination_kernel :1109-1128 */
+    if (high_r2 <= 0.0) {
+      tthr = it[0].thr;
+      for (int k = 1; k < N; ++k)
+        if (it[k].thr > tthr) tthr = it[k].thr;
+    } else {
+      tthr = sqrt(((target * target) - low_r2) / high_r2);
+    }
+    for (int j = 0; j < n; ++j) xtr[j] = dmin(dmax(g->x[j] + tthr * udir[j], lb[j]), ub[j]);
+    for (int i = 0; i < m; ++i) {
+      double lower = isfinite(hi[i]) ? -ORC_INF : 0.0, upper = isfinite(lo[i]) ? ORC_INF : 0.0;
+      ytr[i]       = dmin(dmax(g->y[i] + tthr * udir[n + i], lower), upper);
+    }
+    free(it), free(udir);
+  }
+  /* compute_bound :1052-1076 */
+  double lsum = 0.0, usum = 0.0;
+  for (int j = 0; j < n; ++j) lsum += (xtr[j] - g->x[j]) * gx[j];
+  for (int i = 0; i < m; ++i) usum += (ytr[i] - g->y[i]) * gy[i];
+  g->lower = lsum + g->lagrangian;
+  g->upper = usum + g->lagrangian;
+  free(gx), free(gy), free(aty), free(sub), free(xtr), free(ytr);
+}
+
+void orc_trust_region_bounds(int m, int n, const int* offsets, const int* indices, const double* values,
+                             const int* t_offsets, const int* t_indices, const double* t_values,
+                             const double* c, const double* lo, const double* hi, const double* lb,
+                             const double* ub, double wp, double wd, double radius, const double* x,
+                             const double* y, double* out)
+{
+  gap_t g;
+  g.x = x, g.y = y, g.pd2 = g.dd2 = 0.0, g.distance = radius;
+  bound_optimal_objective(m, n, offsets, indices, values, t_offsets, t_indices, t_values, c, lo, hi, lb, ub, wp,
+                          wd, &g);
+  out[0] = g.lagrangian, out[1] = g.lower, out[2] = g.upper;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* the solver                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -630,6 +815,9 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
   int k_dev = 0, total_pdhg = 0; /* d_total_pdhg_iterations_ / total_pdhg_iterations_ */
   int total_pdlp = 0, internal_it = 0, its_since_restart = 0, last_restart_was_average = 0;
   double last_candidate_kkt = 0.0, last_restart_kkt = 0.0;
+  /* gap_reduction_ratio_last_trial_ is an UNINITIALISED device scalar in the reference
+   * (pdlp_restart_strategy.cu:160); the published algorithm (PDLP, FirstOrderLp.jl) starts it at 1 */
+  double gap_ratio_last_trial = 1.0;
   int valid_step_size = 0, num_restarts = 0, rc = 0;
   const int major     = (int)H[ORC_H_MAJOR_ITERATION];
   const int min_it    = (int)H[ORC_H_MIN_ITERATION_RESTART];
@@ -807,9 +995,70 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
         for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
       }
       /* ---- compute_restart -> run_kkt_restart, pdlp_restart_strategy.cu:467-641 ---- */
-      if ((int)H[ORC_H_RESTART_STRATEGY] == 2) {
-        rc = -1; /* trust-region restart (Methodical1): not restated */
-        goto done;
+      if ((int)H[ORC_H_RESTART_STRATEGY] == 2) { /* run_trust_region_restart :277-364 */
+        if (H[ORC_H_RESCALE_FOR_RESTART] != 0.0) {
+          rc = -1; /* only the preset combination (unscaled iterates + unscaled problem) is restated */
+          goto done;
+        }
+        if (its_since_restart != 0) {
+          const double wp = tau == 0.0 ? 0.0 : 1.0 / tau, wd = sigma == 0.0 ? 0.0 : 1.0 / sigma;
+          const double pds = H[ORC_H_PRIMAL_DISTANCE_SMOOTHING], dds = H[ORC_H_DUAL_DISTANCE_SMOOTHING];
+          int do_restart = (its_since_restart >= H[ORC_H_ARTIFICIAL_RESTART_THRESHOLD] * total_pdlp);
+          gap_t G[2]; /* 0 = average, 1 = current  (compute_localized_duality_gaps :982-1030) */
+          G[0].x = avgx, G[0].y = avgy, G[1].x = x, G[1].y = y;
+          for (int q = 0; q < 2; ++q) {
+            for (int j = 0; j < n; ++j) tmpn[j] = lrx[j] - 1.0 * G[q].x[j];
+            G[q].pd2 = blocked_sum2(n, tmpn, tmpn);
+            for (int i = 0; i < m; ++i) ax[i] = lry[i] - 1.0 * G[q].y[i];
+            G[q].dd2      = blocked_sum2(m, ax, ax);
+            G[q].distance = sqrt(G[q].pd2 * pds * w + G[q].dd2 * (dds / w)); /* :803-817 */
+            bound_optimal_objective(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi,
+                                    lb, ub, wp, wd, &G[q]);
+            G[q].normalized_gap = (G[q].upper - G[q].lower) / G[q].distance;
+          }
+          /* pick_restart_candidate_kernel :841-856 */
+          int to_avg = (G[1].normalized_gap / G[1].distance >= G[0].normalized_gap / G[0].distance);
+          gap_t* cand = to_avg ? &G[0] : &G[1];
+          if (!do_restart) { /* should_do_adaptive_restart_normalized_duality_gap :905-937 */
+            gap_t L;
+            L.x = lrx, L.y = lry;
+            L.distance = sqrt(cand->pd2 * pds * w + cand->dd2 * (dds / w));
+            bound_optimal_objective(m, n, offsets, indices, P.Au, t_offsets, t_indices, P.Atu, cu, lo, hi,
+                                    lb, ub, wp, wd, &L);
+            L.normalized_gap = (L.upper - L.lower) / L.distance;
+            double ratio     = cand->normalized_gap / L.normalized_gap; /* adaptive_restart_triggered :876-903 */
+            if (ratio < H[ORC_H_NECESSARY_REDUCTION] &&
+                (ratio < H[ORC_H_SUFFICIENT_REDUCTION] || ratio > gap_ratio_last_trial))
+              do_restart = 1;
+            gap_ratio_last_trial = ratio;
+          }
+          if (do_restart) {
+            ++num_restarts;
+            int really_avg = to_avg && H[ORC_H_NEVER_RESTART_TO_AVERAGE] == 0.0;
+            if (really_avg) {
+              memcpy(x, avgx, sizeof(double) * (size_t)n);
+              memcpy(y, avgy, sizeof(double) * (size_t)m);
+              last_restart_was_average = 1;
+            } else
+              last_restart_was_average = 0;
+            memcpy(lrx, cand->x, sizeof(double) * (size_t)n); /* update_last_restart_information */
+            memcpy(lry, cand->y, sizeof(double) * (size_t)m);
+            {
+              double pdist = sqrt(cand->pd2), ddist = sqrt(cand->dd2); /* compute_new_primal_weight */
+              const double g = 1.0e-10;
+              if (!(pdist < 0.0 + g || pdist >= 1.0 / g || ddist < 0.0 + g || ddist >= 1.0 / g)) {
+                double th = H[ORC_H_PRIMAL_WEIGHT_UPDATE_SMOOTHING];
+                w         = exp(th * log(ddist / pdist) + (1.0 - th) * log(w));
+                tau       = step_size / w;
+                sigma     = step_size * w;
+              }
+            }
+            memset(sumx, 0, sizeof(double) * (size_t)n);
+            memset(sumy, 0, sizeof(double) * (size_t)m);
+            sumw              = 0.0;
+            its_since_restart = 0;
+          }
+        }
       }
       if ((int)H[ORC_H_RESTART_STRATEGY] == 1) {
         double cur_score = kkt_score(ev_cur, w);

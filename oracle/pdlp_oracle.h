@@ -138,6 +138,14 @@ void orc_eval_infeasibility(int m, int n, const int* offsets, const int* indices
                             const double* ub, int finite_bounds_rule, const double* x, const double* y,
                             double* out);
 
+/* bound_optimal_objective (pdlp_restart_strategy.cu:1032-1050) of the point (x, y) on the unscaled problem
+ * with norm weights wp / wd and trust-region radius `radius`:  out = {lagrangian, lower_bound, upper_bound} */
+void orc_trust_region_bounds(int m, int n, const int* offsets, const int* indices, const double* values,
+                             const int* t_offsets, const int* t_indices, const double* t_values,
+                             const double* c, const double* lo, const double* hi, const double* lb,
+                             const double* ub, double wp, double wd, double radius, const double* x,
+                             const double* y, double* out);
+
 /* Full PDLP solve.  c/lo/hi/lb/ub are the USER's problem (maximize handled inside like
  * problem_helpers.cuh:126-141).  init_x/init_y may be NULL.  x_out (n), y_out (m), rc_out (n).
  * Returns 0, or a negative value for an unsupported configuration (e.g. trust-region restart). */

@@ -36,6 +36,14 @@ def test_afiro_initial_step_size_and_primal_weight(golden_problems):
     assert s["initial_primal_weight"] == pytest.approx(0.0141652, abs=1e-4)
 
 
+def test_afiro_methodical1_trust_region_restart(golden_problems):
+    """test_lp_solver.py:101-121: afiro, pdlp_solver_mode Methodical1 (trust-region restart), all
+    tolerances 1e-12 -> -464.7531 (pytest.approx default rel 1e-6)"""
+    s = orcbind.solve(golden_problems["afiro"]["problem"], mode=2, tol=1e-12)
+    assert s["status"] == "Optimal"
+    assert s["primal_objective"] == pytest.approx(-464.7531)
+
+
 def test_iteration_limit_status(golden_problems):
     p = golden_problems["afiro"]["problem"]
     s = orcbind.solve(p, tol=0.0, iteration_limit=10)  # pdlp_test.cu:134-157

@@ -76,8 +76,6 @@ def test_initial_step_and_weight_goldens(golden_problems):
     r = capi.Solver(p, hyper=h, iteration_limit=0).advance()
     assert r["initial_step_size"] == pytest.approx(1.4893, abs=1e-4)
     assert r["initial_primal_weight"] == pytest.approx(0.0141652, abs=1e-4)
-    with pytest.raises(capi.CuOptError):
-        capi.Solver(p, mode=2)
 
 
 def test_iteration_and_time_limits(golden_problems):
@@ -335,3 +333,53 @@ def test_other_presets_follow_the_oracle(mode):
     r = capi.solve(p, method=1, pdlp_solver_mode=mode, tol=1e-6)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 4e-5 * (1 + abs(p["objective_star"]))
+
+
+def test_trust_region_bounds_match_oracle(golden_problems):
+    """bound_optimal_objective / solve_bound_constrained_trust_region (pdlp_restart_strategy.cu:1032-1050,
+    1391-1678): Lagrangian value and the two objective bounds at a point, several radii (inside the first
+    breakpoint, across many breakpoints, beyond all of them)"""
+    for p in (synthetic.generate(2500, 2000, 8, seed=51), golden_problems["afiro"]["problem"]):
+        rng = np.random.default_rng(9)
+        x = np.abs(rng.standard_normal(p["n"])) * (rng.random(p["n"]) < 0.7)
+        y = rng.standard_normal(p["m"])
+        y = np.where(np.isinf(p["lo"]), -np.abs(y), y) * (rng.random(p["m"]) < 0.8)
+        dev = capi.Device(p)
+        dev.call("scaling_compute", 1, 5, 1, 1.0)
+        dev.call("scale_problem")
+        dev.call("set_initial", capi._ptr(x), capi._ptr(y))
+        dev.eval(capi.CURRENT)
+        for wp, wd, radius in ((2.0, 0.7, 1e-3), (2.0, 0.7, 0.5), (0.3, 5.0, 10.0), (1.0, 1.0, 1e4)):
+            got = dev.trust_region_bounds(capi.CURRENT, wp, wd, radius=radius)
+            ref = orcbind.trust_region_bounds(p, x, y, wp, wd, radius)
+            scale = 1.0 + abs(ref["lagrangian"])
+            assert got["lagrangian"] == pytest.approx(ref["lagrangian"], rel=1e-10, abs=1e-10 * scale)
+            assert got["lower_bound"] == pytest.approx(ref["lower_bound"], rel=1e-9, abs=1e-9 * scale), (wp, wd, radius)
+            assert got["upper_bound"] == pytest.approx(ref["upper_bound"], rel=1e-9, abs=1e-9 * scale), (wp, wd, radius)
+        # anchors are zero right after create: the distances are the weighted norms of the point itself
+        got = dev.trust_region_bounds(capi.CURRENT, 1.0, 1.0, pds=0.5, dds=0.5, primal_weight=2.0)
+        assert got["primal_distance2"] == pytest.approx(float(x @ x), rel=1e-12)
+        assert got["dual_distance2"] == pytest.approx(float(y @ y), rel=1e-12)
+        assert got["distance"] == pytest.approx(np.sqrt(x @ x * 0.5 * 2.0 + y @ y * 0.5 / 2.0), rel=1e-12)
+
+
+def test_methodical1_trust_region_restart(golden_problems):
+    """pdlp_solver_mode = Methodical1: test_lp_solver.py:101-121 pins afiro at -464.7531 (rel 1e-6) with
+    this preset at 1e-12 tolerances (here 1e-9); and the solve follows the oracle's restatement"""
+    p = golden_problems["afiro"]["problem"]
+    r = capi.solve(p, method=1, pdlp_solver_mode=2, tol=1e-9)
+    assert r["status"] == "Optimal"
+    assert r["objective"] == pytest.approx(-464.7531, rel=1e-6)
+    o = orcbind.solve(p, mode=2, tol=1e-9)
+    assert o["status"] == "Optimal" and o["primal_objective"] == pytest.approx(-464.7531, rel=1e-6)
+    q = synthetic.generate(3000, 2600, 9, seed=17)
+    for its in (64, 128):  # majors at 0, 64, 128 (min_iteration_restart = 0)
+        rr = capi.Solver(q, mode=2, tol=0.0, iteration_limit=its).advance()
+        oo = orcbind.solve(q, mode=2, tol=0.0, iteration_limit=its)
+        assert (rr["steps_taken"], rr["attempted_steps"]) == (int(oo["steps_taken"]), int(oo["attempted_steps"]))
+        assert rr["primal_weight"] == pytest.approx(oo["final_primal_weight"], rel=1e-6)
+    rr = capi.solve(q, method=1, pdlp_solver_mode=2, tol=1e-6)
+    oo = orcbind.solve(q, mode=2, tol=1e-6)
+    assert rr["status"] == oo["status"] == "Optimal"
+    assert abs(rr["objective"] - q["objective_star"]) <= 4e-5 * (1 + abs(q["objective_star"]))
+    assert 0.5 * oo["steps_taken"] - 128 <= rr["steps_taken"] <= 2.0 * oo["steps_taken"] + 128
