@@ -343,7 +343,8 @@ def test_trust_region_bounds_match_oracle(golden_problems):
         rng = np.random.default_rng(9)
         x = np.abs(rng.standard_normal(p["n"])) * (rng.random(p["n"]) < 0.7)
         y = rng.standard_normal(p["m"])
-        y = np.where(np.isinf(p["lo"]), -np.abs(y), y) * (rng.random(p["m"]) < 0.8)
+        y = np.where(np.isinf(p["lo"]), -np.abs(y), y)  # dual feasible signs: no infinite subgradients
+        y = np.where(np.isinf(p["hi"]), np.abs(y), y) * (rng.random(p["m"]) < 0.8)
         dev = capi.Device(p)
         dev.call("scaling_compute", 1, 5, 1, 1.0)
         dev.call("scale_problem")
