@@ -176,10 +176,11 @@ def main():
         from oracle import orcbind
         if orcbind.available():
             cores = orcbind.default_threads(16)
-            # calibrate on 4 iterations, then size the sample to ~15 s of loop time (bounded)
-            o = orcbind.solve(p, tol=0.0, iteration_limit=4, num_threads=cores)
+            # calibrate on 12 iterations (all of them major iterations: an over-estimate), then size the sample to
+            # <= ~25 s of loop time
+            o = orcbind.solve(p, tol=0.0, iteration_limit=12, num_threads=cores)
             per_it = max(o["loop_seconds"] / max(o["steps_taken"], 1.0), 1e-6)
-            budget = int(min(max(15.0 / per_it, 8), 4000))
+            budget = int(min(max(25.0 / per_it, 40), 4000))
             o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
             cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
                        kind="port", sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d threads), %d iterations of the same "

@@ -79,6 +79,9 @@ def main():
         "lp_model_with_var_bounds": problem_entry(os.path.join(lp, "lp_model_with_var_bounds.mps")),
         "mip-sample-relaxation": problem_entry(os.path.join(mip, "sample.mps")),
         "mip-bb_optimality-relaxation": problem_entry(os.path.join(mip, "bb_optimality.mps")),
+        # BASELINE config 5 inputs (LP relaxations of datasets/mip; integrality dropped by the tests)
+        "mip-50v-10-free-bound-relaxation": problem_entry(os.path.join(mip, "50v-10-free-bound.mps")),
+        "mip-neos5-free-bound-relaxation": problem_entry(os.path.join(mip, "neos5-free-bound.mps")),
     }
     # goldens of the reference's initial-solution test (afiro, Methodical1): step size / primal weight
     afiro = refbind.parse_mps(os.path.join(lp, "afiro_original.mps"))

@@ -384,3 +384,64 @@ def test_methodical1_trust_region_restart(golden_problems):
     assert rr["status"] == oo["status"] == "Optimal"
     assert abs(rr["objective"] - q["objective_star"]) <= 4e-5 * (1 + abs(q["objective_star"]))
     assert 0.5 * oo["steps_taken"] - 128 <= rr["steps_taken"] <= 2.0 * oo["steps_taken"] + 128
+
+
+@pytest.mark.parametrize("name", ["mip-50v-10-free-bound-relaxation", "mip-neos5-free-bound-relaxation"])
+def test_structured_lp_relaxations_match_reference_dual_simplex(golden_problems, name):
+    """BASELINE config 5 inputs: LP relaxations of datasets/mip instances (233 x 2013 and 63 x 63), objective
+    pinned by the reference's own CPU dual simplex compiled in place"""
+    g = golden_problems[name]
+    p = dict(g["problem"])
+    p.pop("var_types", None)
+    ref = g["meta"]["reference_dual_simplex"]["objective"]
+    for eps in (1e-4, 1e-8):
+        r = capi.solve(p, method=1, tol=eps)
+        o = g["meta"]["oracle"]["%g" % eps]
+        assert r["status"] == o["status"] == "Optimal"
+        assert abs(r["objective"] - ref) <= 4 * eps * (1 + abs(ref))
+        assert abs(r["objective"] - o["primal_objective"]) <= 4 * eps * (1 + abs(ref))
+        host_check(p, r, eps=eps)
+        assert 0.5 * o["steps_taken"] - 80 <= r["steps_taken"] <= 2.0 * o["steps_taken"] + 80
+
+
+def test_repeated_warm_started_resolves_on_a_structured_relaxation(golden_problems):
+    """config 5 call pattern on the 50v-10 relaxation: 20 re-solves after random single-variable bound
+    tightenings, each warm-started from the previous primal/dual like relaxed_lp.cu:74-108; every result is
+    checked against scipy/HiGHS on the modified LP, and warm starts must not cost more iterations overall"""
+    from scipy.optimize import linprog
+    p = dict(golden_problems["mip-50v-10-free-bound-relaxation"]["problem"])
+    p.pop("var_types", None)
+    A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+    r = capi.solve(p, method=1, tol=1e-6)
+    x, y = r["x"], r["y"]
+    rng = np.random.default_rng(3)
+    lb, ub = p["lb"].copy(), p["ub"].copy()
+    warm_total = cold_total = solved = 0
+    for k in range(20):
+        frac = np.nonzero((np.abs(x - np.round(x)) > 1e-3) & np.isfinite(ub))[0]
+        if frac.size == 0:
+            break
+        j = int(rng.choice(frac))
+        nlb, nub = lb.copy(), ub.copy()
+        if rng.random() < 0.5:
+            nub[j] = np.floor(x[j])
+        else:
+            nlb[j] = np.ceil(x[j])
+        q = dict(p, lb=nlb, ub=nub)
+        A_ub = sp.vstack([A[np.isfinite(p["hi"])], -A[np.isfinite(p["lo"])]])
+        b_ub = np.concatenate([p["hi"][np.isfinite(p["hi"])], -p["lo"][np.isfinite(p["lo"])]])
+        ref = linprog(p["c"], A_ub=A_ub, b_ub=b_ub, bounds=list(zip(nlb, nub)), method="highs")
+        if ref.status != 0:
+            continue  # infeasible child
+        warm = capi.Solver(q, tol=1e-6, init_x=x, init_y=y)
+        rw = warm.advance()
+        rc = capi.Solver(q, tol=1e-6).advance()
+        assert rw["status_name"] == "Optimal"
+        assert rw["primal_objective"] == pytest.approx(ref.fun, abs=2e-5 * (1 + abs(ref.fun)))
+        x, y, _ = warm.solution()
+        lb, ub = nlb, nub
+        warm_total += rw["steps_taken"]
+        cold_total += rc["steps_taken"]
+        solved += 1
+    assert solved >= 5
+    assert warm_total <= cold_total
