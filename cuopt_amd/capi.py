@@ -98,7 +98,8 @@ class SolverSettings(C.Structure):
                 ("initial_step_size", c_double), ("initial_primal_weight", c_double),
                 ("initial_k", c_int), ("use_graph", c_int), ("detect_infeasibility", c_int),
                 ("strict_infeasibility", c_int), ("primal_infeasible_tolerance", c_double),
-                ("dual_infeasible_tolerance", c_double)]
+                ("dual_infeasible_tolerance", c_double), ("save_best_primal_so_far", c_int),
+                ("log_to_console", c_int), ("log_file", c_char_p)]
 
 
 class Result(C.Structure):
@@ -226,6 +227,7 @@ _proto("pdlpdev_flush_average", c_int, c_void_p)
 _proto("pdlpdev_make_average", c_int, c_void_p, c_int)
 _proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)
 _proto("pdlpdev_restart", c_int, c_void_p, c_int, c_int, c_void_p)
+_proto("pdlpdev_save_best", c_int, c_void_p, c_int)
 _proto("pdlpdev_trust_region_bounds", c_int, c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_void_p)
 _proto("pdlpdev_eval_infeasibility", c_int, c_void_p, c_int, c_int, c_void_p)
 _proto("pdlpdev_get_solution", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)

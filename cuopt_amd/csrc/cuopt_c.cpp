@@ -35,6 +35,7 @@ struct Problem {
   std::vector<double> rhs;       // idem
   std::vector<double> lo, hi;    // always materialised (problem_helpers.cuh:33-58)
   std::vector<char> var_types;
+  std::vector<std::string> var_names;  // from the MPS file (empty for array-built problems)
   bool has_integers() const
   {
     for (char t : var_types)
@@ -272,6 +273,7 @@ cuopt_int_t cuOptReadProblem(const char* filename, cuOptOptimizationProblem* pro
     p->row_types = std::move(mdl.row_types), p->rhs = std::move(mdl.rhs);
     p->lo = std::move(mdl.lo), p->hi = std::move(mdl.hi);
     p->var_types = std::move(mdl.var_types);
+    p->var_names = std::move(mdl.var_names);
     for (char& t : p->var_types) t = t == 'I' ? CUOPT_INTEGER : CUOPT_CONTINUOUS;
     *problem_ptr = p.release();
   } catch (const cuopt_amd::MpsError& e) {
@@ -587,6 +589,9 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.strict_infeasibility        = s->strict_infeasibility;
     st.primal_infeasible_tolerance = s->primal_infeasible_tolerance;
     st.dual_infeasible_tolerance   = s->dual_infeasible_tolerance;
+    st.save_best_primal_so_far     = s->save_best_primal_so_far;
+    st.log_to_console              = s->log_to_console;
+    st.log_file                    = s->log_file.empty() ? nullptr : s->log_file.c_str();
     cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
                    p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
                    p->objective_offset};
@@ -615,9 +620,18 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     rc = cuoptamd_solver_get_solution(solver, sol->x.data(), sol->y.data(), sol->rc.data());
     cuoptamd_solver_destroy(solver);
     if (rc != 0) return error(CUOPT_RUNTIME_ERROR, "RuntimeError", cuoptamd_last_error());
-    if (s->log_to_console) {
-      std::printf("PDLP status %d  iterations %d  primal obj %.10e  dual obj %.10e  gap %.3e  time %.3fs\n",
-                  res.status, res.steps_taken, res.primal_objective, res.dual_objective, res.gap, sol->solve_time);
+    if (!s->solution_file.empty()) {
+      // write_to_sol_file (solver_solution.cu:370-387, math_optimization/solution_writer.cu)
+      if (FILE* f = std::fopen(s->solution_file.c_str(), "w")) {
+        const bool ok = res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL || res.status == CUOPT_TERIMINATION_STATUS_PRIMAL_FEASIBLE;
+        std::fprintf(f, "# Status: %s\n", !ok ? "Infeasible" : (res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL ? "Optimal" : "PrimalFeasible"));
+        if (ok) {
+          std::fprintf(f, "# Objective value: %.18g\n", sol->objective);
+          for (size_t j = 0; j < p->var_names.size() && j < sol->x.size(); ++j)
+            std::fprintf(f, "%s %.18g\n", p->var_names[j].c_str(), sol->x[j]);
+        }
+        std::fclose(f);
+      }
     }
   } catch (const std::bad_alloc&) {
     return error(CUOPT_OUT_OF_MEMORY, "OutOfMemoryError", "out of host memory");

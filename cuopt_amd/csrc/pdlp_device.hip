@@ -113,6 +113,7 @@ struct pdlpdev_ctx {
   double *tmp_n = nullptr, *tmp_m = nullptr;
   double *ax_u[3] = {nullptr, nullptr, nullptr}, *aty_u[3] = {nullptr, nullptr, nullptr};  // unscaled A x / A^T y of pdlpdev_eval(which)
   double* rc_scratch = nullptr;  // reduced costs of eval(LAST_RESTART): never returned
+  double *bestx = nullptr, *besty = nullptr, *bestrc = nullptr;  // save_best_primal_so_far snapshot (scaled x, y)
   // reductions
   double *part_a = nullptr, *part_at = nullptr;  // per-row-block partials (8 quantities each)
   double *part_g = nullptr;                      // generic grid-stride partials
@@ -1854,6 +1855,24 @@ int pdlpdev_restart(pdlpdev_ctx* ctx, int which, int unscaled_distances, double 
   return 0;
 }
 
+int pdlpdev_save_best(pdlpdev_ctx* ctx, int which)
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->bestx) {
+    TRY(dev_alloc(ctx, &ctx->bestx, ctx->n));
+    TRY(dev_alloc(ctx, &ctx->besty, ctx->m));
+    TRY(dev_alloc(ctx, &ctx->bestrc, ctx->n));
+  }
+  TRY(fetch_ctl(ctx, nullptr));
+  const int cur = ctx->ctl_h->cur;
+  hipStream_t s = ctx->stream;
+  const bool avg = which == PDLPDEV_AVERAGE;
+  HIP_TRY(hipMemcpyAsync(ctx->bestx, avg ? ctx->avgx : ctx->x[cur], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->besty, avg ? ctx->avgy : ctx->y[cur], (size_t)ctx->m * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->bestrc, ctx->rc[avg ? 1 : 0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
 // ---- results ----------------------------------------------------------------------------------------
 int pdlpdev_get_solution(pdlpdev_ctx* ctx, int which, double* x, double* y, double* rc)
 {
@@ -1861,6 +1880,21 @@ int pdlpdev_get_solution(pdlpdev_ctx* ctx, int which, double* x, double* y, doub
   TRY(fetch_ctl(ctx, nullptr));
   const int cur = ctx->ctl_h->cur;
   hipStream_t s = ctx->stream;
+  if (which == PDLPDEV_BEST) {
+    if (!ctx->bestx) return fail(-1, "pdlpdev_get_solution(BEST): nothing was saved");
+    if (x) {
+      k_unscale<<<grid_for(ctx->n), kBlock, 0, s>>>(ctx->n, ctx->bestx, ctx->dc, ctx->tmp_n);
+      HIP_TRY(hipMemcpyAsync(x, ctx->tmp_n, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (y) {
+      k_unscale<<<grid_for(ctx->m), kBlock, 0, s>>>(ctx->m, ctx->besty, ctx->dr, ctx->tmp_m);
+      HIP_TRY(hipMemcpyAsync(y, ctx->tmp_m, (size_t)ctx->m * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (rc) HIP_TRY(hipMemcpyAsync(rc, ctx->bestrc, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, s));
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+  }
   if (x) {
     k_unscale<<<grid_for(ctx->n), kBlock, 0, s>>>(ctx->n, which == PDLPDEV_AVERAGE ? ctx->avgx : ctx->x[cur], ctx->dc, ctx->tmp_n);
     HIP_TRY(hipMemcpyAsync(x, ctx->tmp_n, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, s));

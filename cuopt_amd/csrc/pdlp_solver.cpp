@@ -89,6 +89,16 @@ struct cuoptamd_solver {
   // the reference leaves gap_reduction_ratio_last_trial_ uninitialised (pdlp_restart_strategy.cu:160);
   // 1.0 is the published algorithm's start value (same choice as the oracle)
   double gap_reduction_ratio_last_trial = 1.0;
+  // save_best_primal_so_far: primal_quality_adapter_t of the stored point (convergence_information.hpp:110-124)
+  struct Quality {
+    bool feasible = false;
+    double residual = std::numeric_limits<double>::infinity();
+    double objective = 0.0;
+    bool operator==(const Quality& o) const { return feasible == o.feasible && residual == o.residual && objective == o.objective; }
+  } best_quality;
+  bool have_best = false, maximize = false;
+  cuoptamd_result best_result{};
+  std::string log_path;
   pdlpdev_ctl ctl{};
   Convergence conv_current, conv_average;
   int returned_which = PDLPDEV_CURRENT;
@@ -214,6 +224,46 @@ void fill_result(cuoptamd_solver* s, int status, int which)
   s->returned_which        = which;
 }
 
+
+void log_line(const cuoptamd_solver* s, const char* fmt, ...)
+{
+  if (!s->S.log_to_console && s->log_path.empty()) return;
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (s->S.log_to_console) {
+    std::fputs(buf, stdout);
+    std::fflush(stdout);
+  }
+  if (!s->log_path.empty()) {
+    if (FILE* f = std::fopen(s->log_path.c_str(), "a")) {
+      std::fputs(buf, f);
+      std::fclose(f);
+    }
+  }
+}
+// one row of the iteration table (print_termination_criteria, termination_strategy.cu:380-390)
+void log_iteration(const cuoptamd_solver* s, const Convergence& c)
+{
+  log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->total_iterations, c.primal_objective,
+           c.dual_objective, c.gap, c.l2_primal_residual, c.l2_dual_residual, seconds_since(s->solve_start));
+}
+
+// get_best_quality (pdlp.cu:344-378): feasibility first, then objective (sense aware), else least residual
+const cuoptamd_solver::Quality& best_of(const cuoptamd_solver* s, const cuoptamd_solver::Quality& a,
+                                        const cuoptamd_solver::Quality& b)
+{
+  if (a.feasible && !b.feasible) return a;
+  if (!a.feasible && b.feasible) return b;
+  if (a.feasible && b.feasible) {
+    const bool a_lower = a.objective < b.objective;
+    return ((!s->maximize && a_lower) || (s->maximize && !a_lower)) ? a : b;
+  }
+  return a.residual < b.residual ? a : b;
+}
+
 // One major iteration: averages, the two convergence evaluations, termination, limits, restart.
 // Sets *terminated when a solution must be returned.
 int major_iteration(cuoptamd_solver* s, bool* terminated)
@@ -280,6 +330,21 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
       return 0;
     }
   }
+  if (!done && s->S.save_best_primal_so_far) {  // record_best_primal_so_far, pdlp.cu:390-466
+    const cuoptamd_solver::Quality qc{t_cur == kPrimalFeasible, s->conv_current.l2_primal_residual, s->conv_current.primal_objective};
+    const cuoptamd_solver::Quality qa{t_avg == kPrimalFeasible, s->conv_average.l2_primal_residual, s->conv_average.primal_objective};
+    const cuoptamd_solver::Quality& cand = best_of(s, qc, qa);
+    const cuoptamd_solver::Quality& over = best_of(s, cand, s->best_quality);
+    if (!(over == s->best_quality) || !s->have_best) {
+      const int bw = (&cand == &qc) ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE;
+      s->best_quality = over;
+      DEV(pdlpdev_save_best(dev, bw));
+      fill_result(s, kTimeLimit, bw);
+      s->best_result = s->result;
+      s->have_best   = true;
+    }
+  }
+  if (s->total_iterations % 1000 == 0) log_iteration(s, s->conv_current);  // pdlp.cu:798
   if (!done) {  // check_limits, pdlp.cu:264-331 (time first, then iterations)
     const double tl = s->S.time_limit;
     if (std::isfinite(tl) && seconds_since(s->solve_start) * 1000.0 >= tl * 1000.0)
@@ -288,7 +353,16 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
       done = true, status = kIterationLimit, which = PDLPDEV_CURRENT;
   }
   if (done) {
-    fill_result(s, status, which);
+    if ((status == kTimeLimit || status == kIterationLimit) && s->S.save_best_primal_so_far && s->have_best) {
+      const int nr = s->result.num_restarts, nm = s->result.num_major_iterations;
+      s->result                      = s->best_result;  // the stored point and its statistics
+      s->result.status               = status;
+      s->result.num_restarts         = nr;
+      s->result.num_major_iterations = nm;
+      s->returned_which              = PDLPDEV_BEST;
+    } else {
+      fill_result(s, status, which);
+    }
     *terminated = true;
     return 0;
   }
@@ -466,6 +540,9 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->strict_infeasibility    = 0;
   s->primal_infeasible_tolerance = 1e-8;
   s->dual_infeasible_tolerance   = 1e-8;
+  s->save_best_primal_so_far     = 0;
+  s->log_to_console              = 0;
+  s->log_file                    = nullptr;
 }
 
 void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
@@ -517,6 +594,8 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   cuoptamd_solver* s = new cuoptamd_solver();
   *out               = s;
   s->H = *hyper, s->S = *settings;
+  if (settings->log_file && settings->log_file[0]) s->log_path = settings->log_file;
+  s->S.log_file = nullptr;  // the caller's string is not kept
   s->m_global = lp->m, s->n = lp->n, s->rank = rank, s->world = world;
   s->objective_offset = lp->objective_offset;
   const int32_t m = lp->m, n = lp->n;
@@ -530,6 +609,8 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     for (double& v : c) v = -v;
     s->objective_scale = -1.0;
   }
+  s->maximize               = lp->maximize != 0;
+  s->best_quality.objective = s->maximize ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();  // pdlp.cu:183-185
   // this rank's row block
   std::vector<int32_t> bounds(world + 1);
   cuoptamd_partition_rows(m, lp->offsets, world, bounds.data());
@@ -609,6 +690,8 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
   if (!s->started) {
     s->started     = true;
     s->solve_start = t0;
+    log_line(s, "PDLP on gfx950: %d constraints, %d variables\n", s->m_global, s->n);
+    log_line(s, "   Iter    Primal Obj.      Dual Obj.    Gap        Primal Res.  Dual Res.   Time\n");  // pdlp.cu:1077-1080
   }
   auto leave = [&](int rc) {
     s->result.loop_seconds += seconds_since(t0);
@@ -637,6 +720,11 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
       s->major_done_at = it;
       if (terminated) {
         s->finished = true;
+        log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->result.steps_taken, s->result.primal_objective,
+                 s->result.dual_objective, s->result.gap, s->result.l2_primal_residual, s->result.l2_dual_residual,
+                 seconds_since(s->solve_start));
+        log_line(s, "PDLP finished: status %d, %d iterations, %d restarts\n", s->result.status, s->result.steps_taken,
+                 s->result.num_restarts);
         return leave(0);
       }
     }

@@ -80,7 +80,12 @@ enum {
 };
 
 /* which iterate */
-enum { PDLPDEV_CURRENT = 0, PDLPDEV_AVERAGE = 1, PDLPDEV_LAST_RESTART = 2 /* eval / trust region only */ };
+enum {
+  PDLPDEV_CURRENT = 0,
+  PDLPDEV_AVERAGE = 1,
+  PDLPDEV_LAST_RESTART = 2, /* eval / trust region only */
+  PDLPDEV_BEST = 3          /* get_solution only: the snapshot taken by pdlpdev_save_best */
+};
 
 /* ids for pdlpdev_download (debug / parity tests) */
 enum {
@@ -216,6 +221,10 @@ int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double primal_norm_
                                 double dual_norm_weight, double primal_distance_smoothing,
                                 double dual_distance_smoothing, double primal_weight, double radius,
                                 double out[6]);
+
+/* save_best_primal_so_far (pdlp.cu:390-466): keeps a copy of iterate `which` (CURRENT or AVERAGE) and of its
+ * reduced costs; retrieved with pdlpdev_get_solution(PDLPDEV_BEST) */
+int pdlpdev_save_best(pdlpdev_ctx* ctx, int which);
 
 /* ---- results ---------------------------------------------------------------------------------- */
 /* UNSCALED x (n), y (m), reduced costs (n, from the last eval of that iterate); any may be NULL */

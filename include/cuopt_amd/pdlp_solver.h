@@ -95,6 +95,13 @@ typedef struct cuoptamd_settings {
   int32_t strict_infeasibility;
   double primal_infeasible_tolerance;
   double dual_infeasible_tolerance;
+  /* on a time / iteration limit return the best primal point seen at a major iteration instead of the last
+   * iterate (pdlp.cu:264-331,390-466) */
+  int32_t save_best_primal_so_far;
+  /* iteration log (header + one line every 1000 iterations + summary, pdlp.cu:508-535,1077-1080): to stdout
+   * and/or appended to log_file (NULL or "" = none) */
+  int32_t log_to_console;
+  const char* log_file;
 } cuoptamd_settings;
 
 /* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */

@@ -445,3 +445,40 @@ def test_repeated_warm_started_resolves_on_a_structured_relaxation(golden_proble
         solved += 1
     assert solved >= 5
     assert warm_total <= cold_total
+
+
+def test_save_best_primal_so_far():
+    """pdlp_test.cu:717-772: with an iteration limit, save_best_primal_so_far returns the best primal point
+    seen at a major iteration (feasible > infeasible, then objective, else least residual): its primal
+    residual can only be lower or equal to that of the last iterate"""
+    p = synthetic.generate(4000, 3500, 8, seed=32, hard=True)
+    for limit in (120, 400):
+        a = capi.solve(p, method=1, tol=0.0, iteration_limit=limit)
+        b = capi.solve(p, method=1, tol=0.0, iteration_limit=limit, save_best_primal_so_far=True)
+        assert a["status"] == b["status"] == "IterationLimit"
+        assert b["l2_primal_residual"] <= a["l2_primal_residual"] * (1 + 1e-12)
+        # the reported statistics belong to the returned point
+        A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+        ax = A @ b["x"]
+        viol = np.maximum(np.maximum(p["lo"] - ax, ax - p["hi"]), 0.0)
+        assert np.linalg.norm(viol) == pytest.approx(b["l2_primal_residual"], rel=1e-6, abs=1e-9)
+        assert float(p["c"] @ b["x"]) == pytest.approx(b["primal_objective"], rel=1e-6, abs=1e-6)
+
+
+def test_log_file_and_solution_file(golden_problems, tmp_path):
+    g = golden_problems["afiro"]
+    mps, log, sol = str(tmp_path / "afiro.mps"), str(tmp_path / "pdlp.log"), str(tmp_path / "afiro.sol")
+    write_mps(mps, g["problem"], name="AFIRO")
+    prob = capi.Problem.read(mps)
+    r = capi.solve(prob, method=1, log_file=log, solution_file=sol)
+    assert r["status"] == "Optimal"
+    text = open(log).read()
+    assert "Primal Obj." in text and "PDLP finished: status 1" in text
+    lines = open(sol).read().splitlines()  # math_optimization/solution_writer.cu format
+    assert lines[0] == "# Status: Optimal" and lines[1].startswith("# Objective value: ")
+    assert float(lines[1].split(":")[1]) == pytest.approx(r["objective"], rel=1e-15)
+    names = g["problem"]["var_names"]
+    assert len(lines) == 2 + len(names)
+    for j, ln in enumerate(lines[2:]):
+        nm, val = ln.split()
+        assert nm == names[j] and float(val) == r["x"][j]
