@@ -585,7 +585,9 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
     st.first_primal_feasible   = s->first_primal_feasible;
-    st.detect_infeasibility        = s->infeasibility_detection;
+    // CUOPT_METHOD other than PDLP (Concurrent = default, DualSimplex) is served by PDLP as well; a simplex
+    // would prove infeasibility/unboundedness, so those requests run PDLP WITH its infeasibility detection
+    st.detect_infeasibility        = s->infeasibility_detection || s->method != CUOPT_METHOD_PDLP;
     st.strict_infeasibility        = s->strict_infeasibility;
     st.primal_infeasible_tolerance = s->primal_infeasible_tolerance;
     st.dual_infeasible_tolerance   = s->dual_infeasible_tolerance;

@@ -482,3 +482,24 @@ def test_log_file_and_solution_file(golden_problems, tmp_path):
     for j, ln in enumerate(lines[2:]):
         nm, val = ln.split()
         assert nm == names[j] and float(val) == r["x"][j]
+
+
+def test_reference_c_api_test_translation_unit_runs_against_our_library(golden_problems, tmp_path):
+    """The reference's own pure-C test code (cpp/tests/linear_programming/c_api_tests/c_api_test.c), compiled
+    in place and unmodified against OUR cuopt_c.h and linked to OUR libcuopt.so (oracle/Makefile ->
+    oracle/_ref/ref_capi_runner), driven like c_api_tests.cpp:27-97 drives it."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_capi_runner")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_capi_runner not built (needs /root/reference at build time)")
+    mps = str(tmp_path / "afiro.mps")
+    write_mps(mps, golden_problems["afiro"]["problem"], name="AFIRO")
+    out = subprocess.run([exe, mps], capture_output=True, text=True, timeout=300)
+    report = {ln.split()[0]: ln for ln in out.stdout.splitlines() if " expected " in ln}
+    for name in ("int_size", "float_size", "afiro_rc", "afiro_status", "afiro_pdlp_status", "iteration_limit_status",
+                 "bad_parameter_name", "missing_file", "infeasible_problem", "ranged_rc", "ranged_status",
+                 "ranged_objective_32"):
+        assert name in report and report[name].rstrip().endswith("OK"), out.stdout + out.stderr
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "DIFFERS(out of scope)" in report["burglar_mip"]  # MILP is rejected, documented in INTEGRATION.md
