@@ -4,6 +4,7 @@
 // registry: names, types, ranges, defaults, string conversions).  No HIP header is included here.
 #include <cuopt/linear_programming/cuopt_c.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -581,6 +582,15 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.absolute_dual_tolerance = s->tol[0], st.relative_dual_tolerance = s->tol[1];
     st.absolute_primal_tolerance = s->tol[2], st.relative_primal_tolerance = s->tol[3];
     st.absolute_gap_tolerance = s->tol[4], st.relative_gap_tolerance = s->tol[5];
+    if (s->method != CUOPT_METHOD_PDLP && p->values.size() <= 100000) {
+      // The reference's Concurrent (default) / DualSimplex methods return the simplex VERTEX on small LPs (the CPU
+      // simplex wins the race there: c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings).  This library
+      // has one engine, so such requests run PDLP to simplex-grade tolerances (<= 1e-8) when the LP is small
+      // (<= 1e5 nonzeros, microseconds per iteration); large LPs keep the user's tolerances (PDLP wins the race).
+      double* tols[6] = {&st.absolute_dual_tolerance,   &st.relative_dual_tolerance, &st.absolute_primal_tolerance,
+                         &st.relative_primal_tolerance, &st.absolute_gap_tolerance,  &st.relative_gap_tolerance};
+      for (double* t : tols) *t = std::min(*t, 1e-8);
+    }
     st.iteration_limit         = s->iteration_limit;
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
