@@ -11,10 +11,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include "host_parallel.hpp"
 #include "pdlp_kernels.hpp"
 
 using namespace pdlp;
@@ -1106,9 +1109,12 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 struct PanelHost {
   bool ok = false;
   int W = 0, S = 0;
-  std::vector<int32_t> row0, tile_ptr, perm, col;
-  std::vector<uint16_t> rowptr;
+  std::vector<int32_t> row0, tile_ptr;
   std::vector<int64_t> rp_base;
+  // the three big arrays are deliberately NOT zero-filled (every entry is written by pass 2)
+  std::unique_ptr<int32_t[]> perm, col;
+  std::unique_ptr<uint16_t[]> rowptr;
+  size_t nnz = 0, rowptr_size = 0;
 };
 static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
                               int64_t slab_bytes, bool force)
@@ -1138,10 +1144,12 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S;
-  // pass 1: nonzeros per (panel, slab)
+  // pass 1: nonzeros per (panel, slab) -- panels are independent, so both passes run over host threads
   std::vector<int64_t> count((size_t)W * S + 1, 0);
-  for (int w = 0; w < W; ++w)
-    for (int64_t t = off[P.row0[w]]; t < off[P.row0[w + 1]]; ++t) count[(size_t)w * S + idx[t] / slab_w] += 1;
+  cuopt_amd::parallel_tasks(W, [&](int w) {
+    int64_t* cw = &count[(size_t)w * S];
+    for (int64_t t = off[P.row0[w]]; t < off[P.row0[w + 1]]; ++t) cw[idx[t] / slab_w] += 1;
+  }, nnz);
   P.tile_ptr.resize((size_t)W * S + 1);
   int64_t pos = 0;
   for (size_t i = 0; i < (size_t)W * S; ++i) {
@@ -1151,13 +1159,14 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   P.tile_ptr[(size_t)W * S] = (int32_t)pos;
   // pass 2: placement + per-tile row pointers
-  P.perm.resize(nnz), P.col.resize(nnz);
+  P.nnz = (size_t)nnz, P.rowptr_size = (size_t)S * ((size_t)rows + W);
+  P.perm.reset(new int32_t[P.nnz]), P.col.reset(new int32_t[P.nnz]);
+  P.rowptr.reset(new uint16_t[P.rowptr_size]);
   P.rp_base.resize((size_t)W * S);
-  P.rowptr.resize((size_t)S * ((size_t)rows + W));
-  std::vector<int32_t> cursor(S);
-  int64_t rp = 0;
-  for (int w = 0; w < W; ++w) {
+  cuopt_amd::parallel_tasks(W, [&](int w) {
     const int32_t a = P.row0[w], b = P.row0[w + 1], nr = b - a;
+    const int64_t rp = (int64_t)S * ((int64_t)a + w);  // rowptr entries of all earlier panels
+    std::vector<int32_t> cursor(S);
     for (int s2 = 0; s2 < S; ++s2) {
       cursor[s2]                    = P.tile_ptr[(size_t)w * S + s2];
       P.rp_base[(size_t)w * S + s2] = rp + (int64_t)s2 * (nr + 1);
@@ -1173,8 +1182,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
     }
     for (int s2 = 0; s2 < S; ++s2)
       P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + nr)] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
-    rp += (int64_t)S * (nr + 1);
-  }
+  }, nnz);
   P.ok = true;
   return P;
 }
@@ -1202,13 +1210,13 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
   int64_t* rp_base = nullptr;
   TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
   TRY(upload_i32(c, &tile_ptr, h.tile_ptr.data(), h.tile_ptr.size()));
-  TRY(upload_i32(c, &col, h.col.data(), h.col.size()));
-  TRY(upload_i32(c, &dst->perm, h.perm.data(), h.perm.size()));
-  TRY(dev_alloc(c, &rowptr, h.rowptr.size()));
-  HIP_TRY(hipMemcpyAsync(rowptr, h.rowptr.data(), h.rowptr.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(upload_i32(c, &col, h.col.get(), h.nnz));
+  TRY(upload_i32(c, &dst->perm, h.perm.get(), h.nnz));
+  TRY(dev_alloc(c, &rowptr, h.rowptr_size));
+  HIP_TRY(hipMemcpyAsync(rowptr, h.rowptr.get(), h.rowptr_size * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &rp_base, h.rp_base.size()));
   HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &dst->val, h.perm.size()));
+  TRY(dev_alloc(c, &dst->val, h.nnz));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
   dst->v  = PanelView{h.W, h.S, row0, tile_ptr, rowptr, rp_base, col, dst->val};
   dst->on = true;
@@ -1253,6 +1261,15 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   if (pdlpdev_device_count() <= device)
     return fail(-5, "pdlpdev_create: no HIP device %d visible (this solver has no CPU fallback)", device);
   HIP_TRY(hipSetDevice(device));
+  const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto tlast = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cuopt_amd setup]   dev: %-22s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - tlast).count());
+    tlast = now;
+  };
   pdlpdev_ctx* ctx = new pdlpdev_ctx();
   ctx->device      = device;
   ctx->m = m, ctx->n = n, ctx->nnz = a_offsets[m];
@@ -1266,6 +1283,7 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
   TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz));
   TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz));
+  lap("alloc + upload CSR x2");
   std::vector<int32_t> rba = build_row_blocks(m, a_offsets), rbt = build_row_blocks(n, at_offsets);
   ctx->a_nb = (int)rba.size() - 1, ctx->at_nb = (int)rbt.size() - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
@@ -1297,10 +1315,15 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1048576;
     if (mode != "stream") {
       const bool force = mode == "panel";
+      lap("row blocks + vectors");
       PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force);
+      lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha));
+      lap("upload panels A");
       PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force);
+      lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
+      lap("upload panels At");
     }
   }
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max(std::max(ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0), 1)));

@@ -16,12 +16,15 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
+#include "host_parallel.hpp"
 
 namespace {
 
@@ -549,19 +552,57 @@ void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const 
                             const double* values, int32_t* t_offsets, int32_t* t_indices,
                             double* t_values)
 {
-  // counting sort by column; scanning rows in order keeps the row indices ascending inside every
-  // column, which is what cusparseCsr2cscEx2 produces for the reference (problem.cu:277-309)
-  std::fill(t_offsets, t_offsets + n + 1, 0);
+  // Parallel counting sort by column.  Thread t owns a contiguous chunk of rows; because the chunks are
+  // ordered and every thread scans its rows in order, the row indices come out ascending inside every
+  // column -- what cusparseCsr2cscEx2 produces for the reference (problem.cu:277-309) -- for any thread count.
   const int64_t nnz = offsets[m];
-  for (int64_t k = 0; k < nnz; ++k) t_offsets[indices[k] + 1] += 1;
-  for (int32_t j = 0; j < n; ++j) t_offsets[j + 1] += t_offsets[j];
-  std::vector<int32_t> cursor(t_offsets, t_offsets + n);
-  for (int32_t i = 0; i < m; ++i)
-    for (int32_t k = offsets[i]; k < offsets[i + 1]; ++k) {
-      const int32_t p = cursor[indices[k]]++;
-      t_indices[p]    = i;
-      t_values[p]     = values[k];
+  const int T       = nnz < (1 << 18) ? 1 : cuopt_amd::host_threads();
+  std::vector<int32_t> row_cut(T + 1);
+  for (int t = 0; t <= T; ++t) {  // chunks balanced by nonzeros
+    const int64_t want = nnz * t / T;
+    row_cut[t]         = (int32_t)(std::lower_bound(offsets, offsets + m + 1, (int32_t)want) - offsets);
+  }
+  row_cut[0] = 0, row_cut[T] = m;
+  // hist[t][j] = entries of column j inside chunk t, later turned into chunk t's write cursor for column j
+  std::vector<std::vector<int32_t>> hist(T);
+  cuopt_amd::parallel_tasks(T, [&](int t) {
+    hist[t].assign((size_t)n, 0);
+    int32_t* h = hist[t].data();
+    for (int64_t k = offsets[row_cut[t]]; k < offsets[row_cut[t + 1]]; ++k) h[indices[k]] += 1;
+  });
+  // column totals -> offsets; per (column, chunk) start positions
+  const int CT = T;  // columns are split over the same number of workers for the prefix pass
+  std::vector<int64_t> col_block_sum(CT + 1, 0);
+  std::vector<int32_t> col_cut(CT + 1);
+  for (int t = 0; t <= CT; ++t) col_cut[t] = (int32_t)((int64_t)n * t / CT);
+  cuopt_amd::parallel_tasks(CT, [&](int b) {
+    int64_t s = 0;
+    for (int32_t j = col_cut[b]; j < col_cut[b + 1]; ++j)
+      for (int t = 0; t < T; ++t) s += hist[t][j];
+    col_block_sum[b + 1] = s;
+  });
+  for (int b = 0; b < CT; ++b) col_block_sum[b + 1] += col_block_sum[b];
+  cuopt_amd::parallel_tasks(CT, [&](int b) {
+    int64_t pos = col_block_sum[b];
+    for (int32_t j = col_cut[b]; j < col_cut[b + 1]; ++j) {
+      t_offsets[j] = (int32_t)pos;
+      for (int t = 0; t < T; ++t) {
+        const int32_t c = hist[t][j];
+        hist[t][j]      = (int32_t)pos;
+        pos += c;
+      }
     }
+  });
+  t_offsets[n] = (int32_t)nnz;
+  cuopt_amd::parallel_tasks(T, [&](int t) {
+    int32_t* cursor = hist[t].data();
+    for (int32_t i = row_cut[t]; i < row_cut[t + 1]; ++i)
+      for (int32_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+        const int32_t q = cursor[indices[k]]++;
+        t_indices[q]    = i;
+        t_values[q]     = values[k];
+      }
+  });
 }
 
 void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32_t* bounds)
@@ -591,6 +632,13 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   if (hyper->restart_strategy == 2 && world > 1)
     return fail(-7, "trust-region restart (Methodical1) is single-GPU only");
   const auto t0 = clock_type::now();
+  const bool timing = std::getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto lap = [&, last = t0](const char* what) mutable {
+    if (!timing) return;
+    const auto now = clock_type::now();
+    std::fprintf(stderr, "[cuopt_amd setup] %-28s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - last).count());
+    last = now;
+  };
   cuoptamd_solver* s = new cuoptamd_solver();
   *out               = s;
   s->H = *hyper, s->S = *settings;
@@ -622,11 +670,15 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   const int64_t nnz_l = off[ml];
   const int32_t* idx  = lp->indices + k0;
   const double* val   = lp->values + k0;
-  std::vector<int32_t> t_off(n + 1), t_idx(std::max<int64_t>(nnz_l, 1));
-  std::vector<double> t_val(std::max<int64_t>(nnz_l, 1));
-  cuoptamd_csr_transpose(ml, n, off.data(), idx, val, t_off.data(), t_idx.data(), t_val.data());
-  DEV(pdlpdev_create(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.data(),
-                     t_val.data(), c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin, lp->lb, lp->ub));
+  std::vector<int32_t> t_off(n + 1);
+  std::unique_ptr<int32_t[]> t_idx(new int32_t[std::max<int64_t>(nnz_l, 1)]);  // no zero fill of 120 MB
+  std::unique_ptr<double[]> t_val(new double[std::max<int64_t>(nnz_l, 1)]);
+  lap("partition + slice");
+  cuoptamd_csr_transpose(ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get());
+  lap("host transpose");
+  DEV(pdlpdev_create(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(),
+                     t_val.get(), c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin, lp->lb, lp->ub));
+  lap("pdlpdev_create (upload+panels)");
   if (comm_id) DEV(pdlpdev_comm_init(s->dev, rank, world, comm_id));
   else if (world > 1) return fail(-1, "cuoptamd_solver_create: world > 1 needs a communicator id");
   DEV(pdlpdev_set_graph_mode(s->dev, settings->use_graph));
@@ -653,8 +705,11 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   };
   if (hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
   if (hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
+  lap("norms + params");
   DEV(pdlpdev_scaling_compute(s->dev, hyper->do_ruiz, hyper->ruiz_iterations, hyper->do_pock_chambolle, hyper->alpha_pock_chambolle));
+  lap("scaling_compute");
   DEV(pdlpdev_scale_problem(s->dev));
+  lap("scale_problem");
   if (!hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
   if (!hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
   if (settings->initial_step_size >= 0.0) step = settings->initial_step_size;  // pdlp.cu:1014-1021
@@ -672,6 +727,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
   s->result.norm_b = s->norm_b, s->result.norm_c = s->norm_c;
   s->result.step_size = step, s->result.primal_weight = weight;
+  lap("initial step/weight/iterate");
   s->result.setup_seconds = seconds_since(t0);
   return 0;
 }
