@@ -209,6 +209,7 @@ _proto("pdlpdev_create", c_int, P(c_void_p), c_int, c_int, c_int, *([c_void_p] *
 _proto("pdlpdev_destroy", None, c_void_p)
 _proto("pdlpdev_comm_unique_id", c_int, c_void_p)
 _proto("pdlpdev_comm_init", c_int, c_void_p, c_int, c_int, c_void_p)
+_proto("pdlpdev_softcomm_create", c_int, c_int, c_void_p)
 _proto("pdlpdev_scaling_compute", c_int, c_void_p, c_int, c_int, c_int, c_double)
 _proto("pdlpdev_scale_problem", c_int, c_void_p)
 _proto("pdlpdev_init_norms", c_int, c_void_p, c_void_p)
@@ -482,6 +483,15 @@ def default_settings(**over):
 def comm_unique_id():
     buf = (C.c_uint8 * 128)()
     rc = lib.pdlpdev_comm_unique_id(buf)
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return bytes(buf)
+
+
+def softcomm_id(world):
+    """token of an in-process communicator for `world` solver threads (verification only)"""
+    buf = (C.c_uint8 * 128)()
+    rc = lib.pdlpdev_softcomm_create(int(world), buf)
     if rc != 0:
         raise CuOptError(rc, lib.pdlpdev_last_error().decode())
     return bytes(buf)

@@ -84,6 +84,51 @@ static int load()
                   rccl::GetErrorString ? rccl::GetErrorString(r_) : "rccl error");         \
   } while (0)
 
+
+// ================================================================================================
+// in-process "soft" communicator (verification of the sharded path at world > 1 on one GPU)
+// ================================================================================================
+#include <condition_variable>
+#include <mutex>
+namespace softcomm {
+constexpr char kMagic[8] = {'C', 'U', 'O', 'P', 'T', 'S', 'F', 'T'};
+struct Comm {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  std::vector<double*> bufs;     // this round's buffer of every rank
+  std::vector<double*> scratch;  // per-rank result staging
+  std::vector<size_t> scratch_size;
+  void barrier()
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    const int gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != generation; });
+    }
+  }
+};
+struct Peers {
+  const double* p[16];
+};
+__global__ void __launch_bounds__(256) k_combine(Peers peers, int world, size_t count, int op, double* __restrict__ out)
+{
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    double acc = peers.p[0][i];
+    for (int r = 1; r < world; ++r) {  // fixed rank order -> every rank computes the same bits
+      const double v = peers.p[r][i];
+      acc            = op == 0 ? acc + v : (v > acc ? v : acc);
+    }
+    out[i] = acc;
+  }
+}
+}  // namespace softcomm
+
 // ================================================================================================
 // context
 // ================================================================================================
@@ -125,7 +170,8 @@ struct pdlpdev_ctx {
   pdlpdev_ctl *ctl = nullptr, *ctl_h = nullptr;  // device control block + pinned mirror
   pdlpdev_step_params sp = {0.3, 0.6, 0.5, 0.5};
   // multi-GPU
-  rccl::comm_t comm = nullptr;
+  rccl::comm_t comm = nullptr;  // non-null also marks "sharded mode" when the soft communicator is used
+  softcomm::Comm* soft = nullptr;
   int rank = 0, world = 1;
   double* ar_buf = nullptr;  // n + 8 doubles: A^T y partial + packed scalars
   // graphs
@@ -1364,8 +1410,28 @@ int pdlpdev_comm_unique_id(uint8_t id[128])
   memcpy(id, u.internal, 128);
   return 0;
 }
+int pdlpdev_softcomm_create(int world, uint8_t id[128])
+{
+  if (world < 1 || world > 16) return fail(-1, "pdlpdev_softcomm_create: world must be in 1..16");
+  softcomm::Comm* c = new softcomm::Comm();
+  c->world = world;
+  c->bufs.assign(world, nullptr), c->scratch.assign(world, nullptr), c->scratch_size.assign(world, 0);
+  memset(id, 0, 128);
+  memcpy(id, softcomm::kMagic, 8);
+  memcpy(id + 8, &c, sizeof(c));
+  return 0;
+}
 int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128])
 {
+  if (memcmp(id, softcomm::kMagic, 8) == 0) {
+    softcomm::Comm* c = nullptr;
+    memcpy(&c, id + 8, sizeof(c));
+    if (!c || c->world != world) return fail(-1, "soft communicator: world mismatch");
+    ctx->soft = c;
+    ctx->comm = reinterpret_cast<rccl::comm_t>(c);  // marks sharded mode; never passed to RCCL
+    ctx->rank = rank, ctx->world = world;
+    return 0;
+  }
   TRY(rccl::load());
   HIP_TRY(hipSetDevice(ctx->device));
   // A unique id bootstraps exactly ONE communicator; solvers created later with the same id (bench.py makes
@@ -1387,6 +1453,27 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
 static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
 {
   if (!ctx->comm) return 0;
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    if (c->scratch_size[r] < count) {
+      if (c->scratch[r]) (void)hipFree(c->scratch[r]);
+      HIP_TRY(hipMalloc((void**)&c->scratch[r], count * sizeof(double)));
+      c->scratch_size[r] = count;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
+    c->bufs[r] = buf;
+    c->barrier();                                // everybody's contribution is complete and published
+    softcomm::Peers peers;
+    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q];
+    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
+    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, op == rccl::kSum ? 0 : 1, c->scratch[r]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    c->barrier();                                // nobody still reads the inputs
+    HIP_TRY(hipMemcpyAsync(buf, c->scratch[r], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
   RCCL_TRY(rccl::AllReduce(buf, buf, count, rccl::kFloat64, op, ctx->comm, ctx->stream));
   return 0;
 }

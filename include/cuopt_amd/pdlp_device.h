@@ -149,6 +149,14 @@ int pdlpdev_comm_unique_id(uint8_t id[128]);
  * all-reduced over xGMI inside the calls below.  world == 1 is allowed (exercise the path). */
 int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128]);
 
+/* In-process communicator for `world` contexts driven by `world` host threads of ONE process (any devices,
+ * typically all on the same GPU): the collectives are executed by a kernel that reads the peers' buffers
+ * directly, with host-thread barriers around it.  It exists so that the row-block sharded algorithm can be
+ * verified end to end at world > 1 on a single-GPU machine (tests/test_sharded_gpu.py); production multi-GPU
+ * runs use RCCL.  Fills `id` with a token that pdlpdev_comm_init / cuoptamd_solver_create accept in place of
+ * an RCCL unique id.  The communicator lives until process exit. */
+int pdlpdev_softcomm_create(int world, uint8_t id[128]);
+
 /* ---- setup ----------------------------------------------------------------------------------- */
 /* D_r, D_c <- Ruiz (inf-norm, `ruiz_iterations` rounds, both sides from the same snapshot) then
  * Pock-Chambolle(alpha).  initial_scaling.cu:36-92. */
