@@ -196,6 +196,7 @@ _proto("cuoptamd_solver_destroy", None, c_void_p)
 _proto("cuoptamd_solver_advance", c_int, c_void_p, c_int, P(Result))
 _proto("cuoptamd_solver_get_solution", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_solver_device", c_void_p, c_void_p)
+_proto("cuoptamd_batch_solve", c_int, c_int, c_void_p, P(Hyper), P(SolverSettings), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_solver_get_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_solver_set_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_solver_row_range", c_int, c_void_p, P(c_int), P(c_int))
@@ -591,6 +592,35 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+def batch_solve(problems, mode=1, max_threads=0, device=0, **setting_overrides):
+    """cuoptamd_batch_solve: independent LPs solved concurrently on one GPU -> list of result dicts"""
+    k = len(problems)
+    lps, keep = (LP * k)(), []
+    for i, p in enumerate(problems):
+        a = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]), c=_f64(p["c"]),
+                 lo=_f64(p["lo"]), hi=_f64(p["hi"]), lb=_f64(p["lb"]), ub=_f64(p["ub"]))
+        keep.append(a)
+        lps[i] = LP(int(p["m"]), int(p["n"]), _ptr(a["offsets"]), _ptr(a["indices"]), _ptr(a["values"]), _ptr(a["c"]),
+                    _ptr(a["lo"]), _ptr(a["hi"]), _ptr(a["lb"]), _ptr(a["ub"]), int(bool(p.get("maximize", False))),
+                    float(p.get("objective_offset", 0.0)))
+    hyper, settings = hyper_preset(mode), default_settings(**setting_overrides)
+    results = (Result * k)()
+    xs = [np.zeros(int(p["n"])) for p in problems]
+    ys = [np.zeros(int(p["m"])) for p in problems]
+    zs = [np.zeros(int(p["n"])) for p in problems]
+    arr = lambda vs: (c_void_p * k)(*[v.ctypes.data for v in vs])
+    ax, ay, az = arr(xs), arr(ys), arr(zs)
+    rc = lib.cuoptamd_batch_solve(k, lps, C.byref(hyper), C.byref(settings), device, int(max_threads), results, ax, ay, az)
+    if rc != 0:
+        raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+    out = []
+    for i in range(k):
+        d = results[i].as_dict()
+        d.update(x=xs[i], y=ys[i], reduced_cost=zs[i])
+        out.append(d)
+    return out
 
 
 def csr_transpose(m, n, offsets, indices, values):

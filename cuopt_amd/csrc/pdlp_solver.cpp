@@ -21,6 +21,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
@@ -890,6 +891,34 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   s->warm_started       = true;
   s->result.initial_step_size     = ws->initial_step_size;
   s->result.initial_primal_weight = ws->initial_primal_weight;
+  return 0;
+}
+
+int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper,
+                         const cuoptamd_settings* settings, int device, int max_threads,
+                         cuoptamd_result* results, double** x, double** y, double** rc)
+{
+  if (count < 0 || (count > 0 && (!lps || !hyper || !settings || !results)))
+    return fail(-1, "cuoptamd_batch_solve: null argument");
+  const int nt = std::max(1, std::min<int>(count, max_threads > 0 ? max_threads : cuopt_amd::host_threads()));
+  std::vector<int> codes(count, 0);
+  std::vector<std::string> messages(count);
+  std::vector<std::thread> pool;
+  for (int w = 0; w < nt; ++w)
+    pool.emplace_back([&, w] {
+      for (int i = w; i < count; i += nt) {
+        cuoptamd_solver* s = nullptr;
+        int rc_ = cuoptamd_solver_create(&s, &lps[i], hyper, settings, nullptr, nullptr, device, 0, 1, nullptr);
+        if (rc_ == 0) rc_ = cuoptamd_solver_advance(s, std::numeric_limits<int32_t>::max(), &results[i]);
+        if (rc_ == 0) rc_ = cuoptamd_solver_get_solution(s, x ? x[i] : nullptr, y ? y[i] : nullptr, rc ? rc[i] : nullptr);
+        if (rc_ != 0) messages[i] = cuoptamd_last_error();  // thread-local message of this worker
+        codes[i] = rc_;
+        cuoptamd_solver_destroy(s);
+      }
+    });
+  for (auto& t : pool) t.join();
+  for (int i = 0; i < count; ++i)
+    if (codes[i] != 0) return fail(codes[i], "LP %d of the batch: %s", i, messages[i].c_str());
   return 0;
 }
 

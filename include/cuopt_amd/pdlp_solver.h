@@ -183,6 +183,14 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
  * sign convention of the reference (any pointer may be NULL). Valid after a terminating advance. */
 int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, double* rc);
 
+/* Batch solve (call_batch_solve, LP/utilities/cython_solve.cu:264-296: independent LPs solved concurrently on
+ * one GPU, one host thread + one stream each, at most `max_threads` at a time; <= 0: one per available core,
+ * capped at 16).  results[i] is filled for every LP; x[i] / y[i] / rc[i] (each may be NULL, as may the arrays)
+ * receive the solutions.  Returns 0 if every solve ran (look at results[i].status), else the first error. */
+int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper,
+                         const cuoptamd_settings* settings, int device, int max_threads,
+                         cuoptamd_result* results, double** x, double** y, double** rc);
+
 /* the device context (for kernel timing and buffer downloads in benches/tests) */
 pdlpdev_ctx* cuoptamd_solver_device(cuoptamd_solver* s);
 /* rows [row_begin, row_end) of A held by this rank */

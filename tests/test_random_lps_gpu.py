@@ -100,3 +100,14 @@ def test_concurrent_solves_with_different_presets_are_independent():
         assert b is not None and a["status"] == b["status"] == "Optimal"
         assert (a["steps_taken"], a["objective"]) == (b["steps_taken"], b["objective"])
         np.testing.assert_array_equal(a["x"], b["x"])
+
+
+def test_batch_solve_equals_individual_solves():
+    """call_batch_solve (LP/utilities/cython_solve.cu:264-296): a batch of independent LPs on one GPU"""
+    ps = [random_lp(200 + i, m=60 + 5 * i, n=80 + 3 * i)[0] for i in range(9)]
+    solo = [capi.Solver(p, tol=1e-6).advance() for p in ps]
+    batch = capi.batch_solve(ps, tol=1e-6, max_threads=4)
+    for a, b, p in zip(solo, batch, ps):
+        assert a["status_name"] == b["status_name"] == "Optimal"
+        assert (a["steps_taken"], a["primal_objective"]) == (b["steps_taken"], b["primal_objective"])
+        assert len(b["x"]) == p["n"] and np.all(b["x"] >= p["lb"] - 1e-6)

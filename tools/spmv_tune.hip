@@ -358,7 +358,7 @@ int main(int argc, char** argv)
   }
 
   // ---- slab-major row panels -----------------------------------------------------------------------------
-  for (int S : {1, 2, 4, 8}) for (int W : {256, 512, 1024}) {
+  for (int S : {4, 8, 12, 16, 24, 32}) for (int W : {512, 1024, 2048}) {
     const int SW = (cols + S - 1) / S;
     std::vector<int> prow0(W + 1);
     for (int w = 0; w <= W; ++w) {
@@ -397,7 +397,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_pc, pcol.data(), pcol.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_rb, rp_base.data(), rp_base.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_pv, pval.data(), pval.size() * 8, hipMemcpyHostToDevice));
-    for (int T : {512, 1024}) {
+    for (int T : {256, 512}) {
       constexpr int CH = 4096;
       const size_t lds = (size_t)(CH + max_rows) * 8;
       if (lds > 160 * 1024) continue;
@@ -407,8 +407,8 @@ int main(int argc, char** argv)
         CK(hipFuncSetAttribute((const void*)k_slab<512, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         us = T_.run([&] { k_slab<512, CH><<<W, 512, lds>>>(S, d_p0, d_tp, d_rp, d_rb, d_pc, d_pv, d_x, d_y); }, reps);
       } else {
-        CK(hipFuncSetAttribute((const void*)k_slab<1024, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        us = T_.run([&] { k_slab<1024, CH><<<W, 1024, lds>>>(S, d_p0, d_tp, d_rp, d_rb, d_pc, d_pv, d_x, d_y); }, reps);
+        CK(hipFuncSetAttribute((const void*)k_slab<256, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        us = T_.run([&] { k_slab<256, CH><<<W, 256, lds>>>(S, d_p0, d_tp, d_rp, d_rb, d_pc, d_pv, d_x, d_y); }, reps);
       }
       char nm[96];
       snprintf(nm, sizeof nm, "slab-major S=%d W=%d T=%d lds=%zuK", S, W, T, lds / 1024);
