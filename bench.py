@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
@@ -196,7 +196,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, CSR fp64/int32, "
                                    "Stable2 preset, tolerances 0 (fixed iteration budget)"
-                                   % (args.workload, m, n, cfg["k"], cfg["seed"], ",hard" if cfg.get("hard") else "", nnz),
+                                   % (args.workload, m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""), nnz),
                        "rows": m, "cols": n, "nnz": nnz,
                        "parallelism": "row-block x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,

@@ -632,6 +632,12 @@ k_panel_at_cur(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* _
   StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
   panel_spmv_block(P, cur ? y1 : y0, e, nullptr);
 }
+__global__ void __launch_bounds__(kPanelThreads)
+k_panel_plain(PanelView P, const double* __restrict__ vec, double* __restrict__ out)
+{
+  StoreEpilogue e{out};
+  panel_spmv_block(P, vec, e, nullptr);
+}
 __global__ void __launch_bounds__(kBlock)
 k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ out)
 {
@@ -1233,15 +1239,15 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   return P;
 }
 
-static int upload_i32(pdlpdev_ctx* c, int32_t** dst, const int32_t* src, size_t count)
+static int upload_i32(pdlpdev_ctx* c, int32_t** dst, const int32_t* src, size_t count, size_t pad = 0)
 {
-  TRY(dev_alloc(c, dst, count));
+  TRY(dev_alloc(c, dst, count + pad));
   if (count) HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   return 0;
 }
-static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t count)
+static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t count, size_t pad = 0)
 {
-  TRY(dev_alloc(c, dst, count));
+  TRY(dev_alloc(c, dst, count + pad));
   if (count && src)
     HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   return 0;
@@ -1274,6 +1280,38 @@ static int sync_panel_values(pdlpdev_ctx* c)
   if (c->pa.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pa.perm, c->a_val, c->pa.val);
   if (c->pat.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pat.perm, c->at_val, c->pat.val);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// auto layout: both layouts of a matrix are timed on the device (plain SpMV, 1 warm-up + 3 launches each) and the
+// slower one is dropped -- a structured LP whose gathers are local runs fastest through the CSR stream kernel
+// even when the gathered vector exceeds L2; a random one through the slab-major panels.
+static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb, const int32_t* rb, const int32_t* off,
+                       const int32_t* idx, const double* val, const double* vec, double* out, const char* name)
+{
+  if (!pn->on) return 0;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float ms_stream = 0.f, ms_panel = 0.f;
+  for (int which = 0; which < 2; ++which) {
+    for (int rep = 0; rep < 4; ++rep) {
+      if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+      if (which == 0)
+        k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out);
+      else
+        k_panel_plain<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
+    }
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(which == 0 ? &ms_stream : &ms_panel, e0, e1));
+  }
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  if (getenv("CUOPT_AMD_TIMING"))
+    fprintf(stderr, "[cuopt_amd setup]   layout %-3s: stream %.1f us, panels %.1f us -> %s\n", name, ms_stream * 1e3 / 3,
+            ms_panel * 1e3 / 3, ms_stream <= ms_panel ? "stream" : "panels");
+  if (ms_stream <= ms_panel) pn->on = false;
+  (void)rows;
   return 0;
 }
 
@@ -1324,11 +1362,11 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   const size_t nnz = (size_t)ctx->nnz;
   if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
   TRY(upload_i32(ctx, &ctx->a_off, a_offsets, (size_t)m + 1));
-  TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz));
-  TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz));
+  TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz, 8));  // +8: the vector loads of the stream kernel may over-read
+  TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz, 8));
   TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
-  TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz));
-  TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz));
+  TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
+  TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
   lap("alloc + upload CSR x2");
   std::vector<int32_t> rba = build_row_blocks(m, a_offsets), rbt = build_row_blocks(n, at_offsets);
   ctx->a_nb = (int)rba.size() - 1, ctx->at_nb = (int)rbt.size() - 1;
@@ -1384,6 +1422,14 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
   HIP_TRY(hipGetLastError());
   TRY(sync_panel_values(ctx));
+  {
+    const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
+    if (!mode_env || std::string(mode_env) == "auto") {
+      TRY(pick_layout(ctx, &ctx->pa, m, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->tmp_n, ctx->tmp_m, "A"));
+      TRY(pick_layout(ctx, &ctx->pat, n, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->tmp_m, ctx->tmp_n, "A^T"));
+      lap("layout autotune");
+    }
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }

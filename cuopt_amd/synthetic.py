@@ -7,14 +7,27 @@
     s_i = 0 where y*_i > 0 else U(0,1);  z*_j = 0 where x*_j > 0 else U(0,1);  c = A^T y* + z*
 so (x*, y*) satisfies the KKT conditions and obj* = c.x* = lo.y* is the known answer.
 `hard=True` rescales rows by 10^U(-1,1) and columns by 10^U(-2,2) first, which makes PDLP need
-thousands of iterations and several restarts."""
+thousands of iterations and several restarts.  `band=B` draws the columns of row i within +-B of the
+diagonal position instead of uniformly (a STRUCTURED LP: staircase / time-expanded models look like this);
+the uniform family is the gather-adversarial worst case for SpMV."""
 import numpy as np
 
 
-def _columns(rng, m, n, k):
+def _draw(rng, m, n, k, band, rows=None):
+    """k column indices per row: uniform on [0, n), or within +-band of the row's scaled diagonal position"""
+    rows = np.arange(m, dtype=np.int64) if rows is None else rows
+    if not band:
+        return rng.integers(0, n, size=(len(rows), k), dtype=np.int64)
+    centre = (rows * n) // m
+    width = min(2 * band + 1, n)
+    lo = np.clip(centre - band, 0, n - width)  # the window slides at the edges instead of collapsing
+    return lo[:, None] + rng.integers(0, width, size=(len(rows), k), dtype=np.int64)
+
+
+def _columns(rng, m, n, k, band=0):
     if n > m * k:
         raise ValueError("need n <= m*k so that every column can get an entry")
-    cols = rng.integers(0, n, size=(m, k), dtype=np.int64)
+    cols = _draw(rng, m, n, k, band)
     j = np.arange(n, dtype=np.int64)
     forced_rows, forced_slots = j % m, j // m
     cols[forced_rows, forced_slots] = j
@@ -27,13 +40,13 @@ def _columns(rng, m, n, k):
             return srt
         for i in bad:  # redraw only the free slots of the offending rows
             f = nforced[i]
-            cols[i, f:] = rng.integers(0, n, size=k - f)
+            cols[i, f:] = _draw(rng, m, n, k, band, rows=np.array([i]))[0, : k - f]
     raise RuntimeError("could not draw distinct columns")
 
 
-def generate(m, n, k=10, seed=1, hard=False):
+def generate(m, n, k=10, seed=1, hard=False, band=0):
     rng = np.random.default_rng(seed)
-    cols = _columns(rng, m, n, k)
+    cols = _columns(rng, m, n, k, band)
     vals = rng.standard_normal((m, k))
     if hard:
         rs = 10.0 ** rng.uniform(-1.0, 1.0, size=m)
@@ -57,7 +70,7 @@ def generate(m, n, k=10, seed=1, hard=False):
     c = aty + zs
     return dict(m=m, n=n, offsets=offsets, indices=indices, values=values, c=c, lo=lo, hi=hi,
                 lb=np.zeros(n), ub=np.full(n, np.inf), maximize=False, objective_offset=0.0,
-                x_star=xs, y_star=ys, objective_star=float(c @ xs), seed=seed, k=k, hard=hard)
+                x_star=xs, y_star=ys, objective_star=float(c @ xs), seed=seed, k=k, hard=hard, band=band)
 
 
 # the configurations BASELINE.json names
@@ -65,6 +78,7 @@ CONFIGS = {
     "tiny": dict(m=2000, n=2000, k=10, seed=3),
     "c2": dict(m=100_000, n=100_000, k=10, seed=1),        # 1e5 x 1e5, 1e6 nnz
     "c3": dict(m=1_000_000, n=1_000_000, k=10, seed=2),    # 1e6 x 1e6, 1e7 nnz
+    "banded": dict(m=1_000_000, n=1_000_000, k=10, seed=2, band=2000),  # same size, structured columns
 }
 
 

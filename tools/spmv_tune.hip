@@ -246,6 +246,7 @@ int main(int argc, char** argv)
 {
   const int rows = argc > 1 ? atoi(argv[1]) : 1000000, cols = argc > 2 ? atoi(argv[2]) : 1000000;
   const int k = argc > 3 ? atoi(argv[3]) : 10, reps = argc > 4 ? atoi(argv[4]) : 30;
+  const long band = argc > 5 ? atol(argv[5]) : 0;  // > 0: columns within +-band of the (scaled) diagonal
   const long nnz = (long)rows * k;
   std::vector<int> off(rows + 1), idx(nnz + 8, 0);
   std::vector<double> val(nnz + 8, 0.0), x(cols), yref(rows);
@@ -254,7 +255,14 @@ int main(int argc, char** argv)
   for (int i = 0; i <= rows; ++i) off[i] = i * k;
   for (int i = 0; i < rows; ++i) {
     int* p = &idx[(long)i * k];
-    for (int t = 0; t < k; ++t) p[t] = (int)(rng() % (uint64_t)cols);
+    for (int t = 0; t < k; ++t) {
+      if (band > 0) {
+        long c0 = (long)((double)i * cols / rows) + (long)(rng() % (uint64_t)(2 * band + 1)) - band;
+        p[t]    = (int)std::min<long>(std::max<long>(c0, 0), cols - 1);
+      } else {
+        p[t] = (int)(rng() % (uint64_t)cols);
+      }
+    }
     std::sort(p, p + k);
     for (int t = 0; t < k; ++t) val[(long)i * k + t] = nd(rng);
   }
