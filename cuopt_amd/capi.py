@@ -125,16 +125,17 @@ class WarmStart(C.Structure):
     _fields_ = [(k, c_void_p) for k in (
         "current_primal_solution", "current_dual_solution", "initial_primal_average",
         "initial_dual_average", "current_ATY", "sum_primal_solutions", "sum_dual_solutions",
-        "last_restart_duality_gap_primal_solution", "last_restart_duality_gap_dual_solution")] + [
+        "last_restart_duality_gap_primal_solution", "last_restart_duality_gap_dual_solution",
+        "current_primal_solution_scaled", "current_dual_solution_scaled")] + [
         ("initial_primal_weight", c_double), ("initial_step_size", c_double),
         ("total_pdlp_iterations", c_int), ("total_pdhg_iterations", c_int),
         ("last_candidate_kkt_score", c_double), ("last_restart_kkt_score", c_double),
         ("sum_solution_weight", c_double), ("iterations_since_last_restart", c_int)]
 
     PRIMAL = ("current_primal_solution", "initial_primal_average", "current_ATY", "sum_primal_solutions",
-              "last_restart_duality_gap_primal_solution")
+              "last_restart_duality_gap_primal_solution", "current_primal_solution_scaled")
     DUAL = ("current_dual_solution", "initial_dual_average", "sum_dual_solutions",
-            "last_restart_duality_gap_dual_solution")
+            "last_restart_duality_gap_dual_solution", "current_dual_solution_scaled")
     SCALARS = ("initial_primal_weight", "initial_step_size", "total_pdlp_iterations", "total_pdhg_iterations",
                "last_candidate_kkt_score", "last_restart_kkt_score", "sum_solution_weight",
                "iterations_since_last_restart")
@@ -551,6 +552,8 @@ class Solver:
     def set_warm_start(self, d):
         ws, keep = WarmStart(), []
         for k in WarmStart.PRIMAL + WarmStart.DUAL:
+            if d.get(k) is None:
+                continue  # optional vectors (scaled iterate) may be absent: NULL
             a = _f64(d[k])
             keep.append(a)
             setattr(ws, k, a.ctypes.data)

@@ -843,6 +843,8 @@ int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
   };
   const int64_t n = s->n, m = s->m_global;
   int rc;
+  if ((rc = get(PDLPDEV_BUF_X, ws->current_primal_solution_scaled, n))) return rc;
+  if ((rc = get(PDLPDEV_BUF_Y, ws->current_dual_solution_scaled, m))) return rc;
   if ((rc = get(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
   if ((rc = get(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
   if ((rc = get(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;
@@ -875,6 +877,8 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   };
   const int64_t n = s->n, m = s->m_global;
   int rc;
+  if ((rc = put(PDLPDEV_BUF_X, ws->current_primal_solution_scaled, n))) return rc;  // bit-exact iterate if given
+  if ((rc = put(PDLPDEV_BUF_Y, ws->current_dual_solution_scaled, m))) return rc;
   if ((rc = put(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
   if ((rc = put(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
   if ((rc = put(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;

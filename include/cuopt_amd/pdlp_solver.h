@@ -140,6 +140,11 @@ typedef struct cuoptamd_warm_start {
   double* sum_dual_solutions;                       /* m */
   double* last_restart_duality_gap_primal_solution; /* n */
   double* last_restart_duality_gap_dual_solution;   /* m */
+  /* optional (may be NULL): the current iterate in the solver's scaled space.  (x * D) / D is not x in the last
+   * bit, so a restore from the unscaled iterate alone perturbs the trajectory; when these are present the
+   * restore is bit-exact and its(full) == its(coarse) + its(warm) holds exactly. */
+  double* current_primal_solution_scaled;           /* n */
+  double* current_dual_solution_scaled;             /* m */
   double initial_primal_weight;
   double initial_step_size;
   int32_t total_pdlp_iterations;

@@ -234,6 +234,12 @@ def test_warm_start_iterations_are_additive(seed, hard):
     r2 = second.advance()
     assert r_full["status_name"] == r1["status_name"] == r2["status_name"] == "Optimal"
     assert r1["steps_taken"] + r2["steps_taken"] == r_full["steps_taken"]
+    assert r2["primal_objective"] == r_full["primal_objective"]  # bit-exact restore (scaled iterate in the snapshot)
+    # a snapshot holding only the reference's 9 vectors (unscaled iterate) still resumes, to rounding
+    ws9 = {k: v for k, v in ws.items() if not k.endswith("_scaled")}
+    r3 = capi.Solver(p, tol=fine, warm_start=ws9).advance()
+    assert r3["status_name"] == "Optimal"
+    assert abs(r1["steps_taken"] + r3["steps_taken"] - r_full["steps_taken"]) <= 400
     # x is unscaled in the snapshot and rescaled on restore ((x*d)/d != x in the last bit), like the reference
     assert r2["primal_objective"] == pytest.approx(r_full["primal_objective"], abs=2 * fine * (1 + abs(r_full["primal_objective"])))
 
