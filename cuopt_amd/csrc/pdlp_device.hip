@@ -694,7 +694,7 @@ struct EvalPrimalEpilogue {
     acc[0] += rp * rp;
     acc[1] += bound_value_product(yi, lo, hi);
     acc[2] += yi * yi;
-    linf_rows[i] = rp - eps_rel * combine_bounds(lo, hi);  // relative_residual_t, utils.cuh:385-409
+    if (linf_rows) linf_rows[i] = rp - eps_rel * combine_bounds(lo, hi);  // relative_residual_t, utils.cuh:385-409
   }
 };
 __global__ void __launch_bounds__(kBlock)
@@ -750,7 +750,7 @@ struct EvalDualCore {
     acc[1] += bound_value_product(rc, lb, ub);
     acc[2] += cj * xj;
     acc[3] += xj * xj;
-    linf_rows[j] = rd - eps_rel * cj;  // the dual "rhs" is c_j itself (signed), :204-208
+    if (linf_rows) linf_rows[j] = rd - eps_rel * cj;  // the dual "rhs" is c_j itself (signed), :204-208
   }
 };
 struct EvalDualEpilogue {
@@ -1849,18 +1849,23 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   const double* altx = which == PDLPDEV_LAST_RESTART ? ctx->lrx : ctx->avgx;
   const double* alty = which == PDLPDEV_LAST_RESTART ? ctx->lry : ctx->avgy;
   const int kw       = which == PDLPDEV_CURRENT ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE;
+  // the per-constraint (l-infinity) residuals are only consumed when per_constraint_residual is set: the host
+  // driver passes negative eps_rel otherwise and the two extra vectors + four reduction launches are skipped
+  const bool want_linf = eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0;
+  double* linf_m = want_linf ? ctx->tmp_m : nullptr;
+  double* linf_n = want_linf ? ctx->tmp_n : nullptr;
   double* sc = ctx->scal;  // layout: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
   if (ctx->pa.on)
-    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u[which], ctx->part_a);
+    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else
-    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, ctx->tmp_m, ctx->ax_u[which], ctx->part_a);
+    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
-  {
+  if (want_linf) {
     const int g = std::min(grid_for(m), kGenericBlocks);
     k_max_partials<<<g, kBlock, 0, s>>>(m, ctx->tmp_m, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 1u, sc + 3);
   }
-  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], ctx->tmp_n, ctx->aty_u[which]};
+  EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], linf_n, ctx->aty_u[which]};
   if (!ctx->comm) {
     if (ctx->pat.on)
       k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
@@ -1877,12 +1882,12 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
     HIP_TRY(hipMemcpyAsync(ctx->ar_buf + n, sc, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     TRY(allreduce(ctx, ctx->ar_buf, (size_t)n + 3, rccl::kSum));
     HIP_TRY(hipMemcpyAsync(sc, ctx->ar_buf + n, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    TRY(allreduce(ctx, sc + 3, 1, rccl::kMax));
+    if (want_linf) TRY(allreduce(ctx, sc + 3, 1, rccl::kMax));
     const int g = std::min(grid_for(n), kGenericBlocks);
     k_eval_dual_elementwise<<<g, kBlock, 0, s>>>(n, g, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->ar_buf, core, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 4, 0u, sc + 4);
   }
-  {
+  if (want_linf) {
     const int g = std::min(grid_for(n), kGenericBlocks);
     k_max_partials<<<g, kBlock, 0, s>>>(n, ctx->tmp_n, ctx->part_g);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 1u, sc + 8);
@@ -1893,11 +1898,11 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   out[PDLPDEV_EV_PRES2]         = h[0];
   out[PDLPDEV_EV_DUAL_SUM]      = h[1] + h[5];
   out[PDLPDEV_EV_Y2]            = h[2];
-  out[PDLPDEV_EV_LINF_PRES_REL] = h[3];
+  out[PDLPDEV_EV_LINF_PRES_REL] = want_linf ? h[3] : 0.0;
   out[PDLPDEV_EV_DRES2]         = h[4];
   out[PDLPDEV_EV_CX]            = h[6];
   out[PDLPDEV_EV_X2]            = h[7];
-  out[PDLPDEV_EV_LINF_DRES_REL] = h[8];
+  out[PDLPDEV_EV_LINF_DRES_REL] = want_linf ? h[8] : 0.0;
   return 0;
 }
 

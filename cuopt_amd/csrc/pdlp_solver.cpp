@@ -286,11 +286,14 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     mode = 1;
   DEV(pdlpdev_make_average(dev, mode));
   const int rule_finite = H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
+  // the l-infinity residuals are only consumed by the per-constraint verdict (termination_strategy.cu:189-205)
+  const double eps_p = s->S.per_constraint_residual ? s->S.relative_primal_tolerance : -1.0;
+  const double eps_d = s->S.per_constraint_residual ? s->S.relative_dual_tolerance : -1.0;
   double ev[PDLPDEV_EV_COUNT];
-  DEV(pdlpdev_eval(dev, PDLPDEV_CURRENT, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
+  DEV(pdlpdev_eval(dev, PDLPDEV_CURRENT, rule_finite, eps_p, eps_d, ev));
   s->conv_current = to_convergence(s, ev);
   if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_CURRENT, rule_finite, s->conv_current.infeasibility));
-  DEV(pdlpdev_eval(dev, PDLPDEV_AVERAGE, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev));
+  DEV(pdlpdev_eval(dev, PDLPDEV_AVERAGE, rule_finite, eps_p, eps_d, ev));
   s->conv_average = to_convergence(s, ev);
   if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_AVERAGE, rule_finite, s->conv_average.infeasibility));
   const int t_cur = verdict(s, s->conv_current), t_avg = verdict(s, s->conv_average);
@@ -428,7 +431,7 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     const double ng_cand  = to_average ? ng_avg : ng_cur;
     if (!restart) {  // should_do_adaptive_restart_normalized_duality_gap :905-937
       double ev_lr[PDLPDEV_EV_COUNT], lr[6];
-      DEV(pdlpdev_eval(dev, PDLPDEV_LAST_RESTART, rule_finite, s->S.relative_primal_tolerance, s->S.relative_dual_tolerance, ev_lr));
+      DEV(pdlpdev_eval(dev, PDLPDEV_LAST_RESTART, rule_finite, -1.0, -1.0, ev_lr));
       DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_LAST_RESTART, wp, wd, pds, dds, w, cand[2], lr));
       const double ng_lr = (lr[5] - lr[4]) / cand[2];
       const double ratio = ng_cand / ng_lr;  // adaptive_restart_triggered :876-903

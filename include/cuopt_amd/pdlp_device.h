@@ -203,7 +203,9 @@ int pdlpdev_flush_average(pdlpdev_ctx* ctx);
 int pdlpdev_make_average(pdlpdev_ctx* ctx, int mode);
 /* Convergence information of one iterate on the UNSCALED problem; the iterates stay scaled on the
  * device, D_r/D_c are folded into the two fused SpMV passes.  `rc_rule_finite_bounds` selects
- * copy_gradient_if_finite_bounds (Stable2) vs copy_gradient_if_should_be_reduced_cost. */
+ * copy_gradient_if_finite_bounds (Stable2) vs copy_gradient_if_should_be_reduced_cost.
+ * Negative eps_rel_*: the two l-infinity residuals are not needed (reported as 0; saves two vectors of
+ * traffic and four launches per evaluation). */
 int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
                  double eps_rel_dual, double out[PDLPDEV_EV_COUNT]);
 /* Infeasibility information of the iterate evaluated by the LAST pdlpdev_eval(which) call (its A x and
