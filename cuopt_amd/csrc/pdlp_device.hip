@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <mutex>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -57,8 +58,10 @@ static int (*CommInitRank)(comm_t*, int, unique_id, int);
 static int (*CommDestroy)(comm_t);
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
 static const char* (*GetErrorString)(int);
+static std::mutex load_mutex;
 static int load()
 {
+  std::lock_guard<std::mutex> guard(load_mutex);
   if (lib) return 0;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* nm : names) {
@@ -1293,19 +1296,25 @@ static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  float ms_stream = 0.f, ms_panel = 0.f;
-  for (int which = 0; which < 2; ++which) {
-    for (int rep = 0; rep < 4; ++rep) {
-      if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+  float ms_stream = 1e30f, ms_panel = 1e30f;
+  for (int round = 0; round < 2; ++round)  // interleaved rounds, minimum per layout: robust to one-off stalls
+    for (int which = 0; which < 2; ++which) {
+      for (int rep = 0; rep < 4; ++rep) {
+        if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+        if (which == 0)
+          k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out);
+        else
+          k_panel_plain<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
+      }
+      HIP_TRY(hipEventRecord(e1, c->stream));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
       if (which == 0)
-        k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out);
+        ms_stream = std::min(ms_stream, ms);
       else
-        k_panel_plain<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
+        ms_panel = std::min(ms_panel, ms);
     }
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    HIP_TRY(hipEventElapsedTime(which == 0 ? &ms_stream : &ms_panel, e0, e1));
-  }
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   if (getenv("CUOPT_AMD_TIMING"))
     fprintf(stderr, "[cuopt_amd setup]   layout %-3s: stream %.1f us, panels %.1f us -> %s\n", name, ms_stream * 1e3 / 3,
