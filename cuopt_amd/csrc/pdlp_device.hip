@@ -179,6 +179,10 @@ struct pdlpdev_ctx {
   double* ar_buf = nullptr;  // n + 8 doubles: A^T y partial + packed scalars
   // graphs
   int use_graph = 1;
+  char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
+  char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
+  size_t arena_used = 0;
+  bool small_resident = false;  // whole attempt batches inside one workgroup (k_pdhg_small)
   std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
   std::vector<void*> allocs;
   int64_t bytes = 0;
@@ -187,14 +191,59 @@ struct pdlpdev_ctx {
 constexpr int kGenericBlocks = 1024;
 constexpr int kScalars       = 64;
 
+// Streams (an HSA queue each: ~2 ms to create), the pinned read-back block and the first arena chunk are handed from
+// a destroyed context to the next one created on the same device: back-to-back small solves (cuOptSolve in a loop,
+// MIP-style re-solves) otherwise spend more time in these three calls than in PDHG.  Never freed (a few per device).
+struct Recycled {
+  int device;
+  hipStream_t stream;
+  double* pinned;
+  char* chunk;
+};
+static std::mutex g_recycle_mutex;
+static std::vector<Recycled> g_recycled;
+static bool take_recycled(int device, Recycled* out)
+{
+  std::lock_guard<std::mutex> lock(g_recycle_mutex);
+  for (size_t i = 0; i < g_recycled.size(); ++i)
+    if (g_recycled[i].device == device) {
+      *out = g_recycled[i];
+      g_recycled.erase(g_recycled.begin() + i);
+      return true;
+    }
+  return false;
+}
+static bool give_recycled(const Recycled& r)
+{
+  std::lock_guard<std::mutex> lock(g_recycle_mutex);
+  if (g_recycled.size() >= 16) return false;
+  g_recycled.push_back(r);
+  return true;
+}
+
+// Zero-filled device memory.  Buffers under 256 KiB are carved out of 1 MiB chunks: a small LP (the MIP-style
+// re-solve case) needs ~60 buffers, and 60 hipMalloc + hipFree calls cost more than its whole solve.
+constexpr size_t kArenaChunk = (size_t)1 << 20, kArenaMaxItem = (size_t)256 << 10;
 template <class T>
 static int dev_alloc(pdlpdev_ctx* c, T** p, size_t count)
 {
   size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  c->bytes += (int64_t)bytes;
+  if (bytes <= kArenaMaxItem) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (c->arena == nullptr || c->arena_used + need > kArenaChunk) {
+      HIP_TRY(hipMalloc((void**)&c->arena, kArenaChunk));
+      HIP_TRY(hipMemsetAsync(c->arena, 0, kArenaChunk, c->stream));
+      c->allocs.push_back(c->arena);
+      c->arena_used = 0;
+    }
+    *p = (T*)(c->arena + c->arena_used);
+    c->arena_used += need;
+    return 0;
+  }
   HIP_TRY(hipMalloc((void**)p, bytes));
   HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
   c->allocs.push_back(*p);
-  c->bytes += (int64_t)bytes;
   return 0;
 }
 #define TRY(expr)          \
@@ -487,6 +536,52 @@ k_step_stats(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, const double* 
 //     compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188),
 //     the accept/flip of update_solution (pdhg.cu:237-250) and add_weight_sums
 //     (weighted_average_solution.cu:63-71).
+// The scalar rule of compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188) +
+// the accept/flip of update_solution (pdhg.cu:237-250) + add_weight_sums (weighted_average_solution.cu:63-71).
+// One thread.
+// `pw` (optional): pow(k + 2, -reduction_exponent), pow(k + 2, -growth_exponent) for the k the attempt
+// started with, computed off the critical path by the caller.
+__device__ __forceinline__ void apply_step_decision(pdlpdev_ctl* ctl, double dy2, double interaction, double dx2,
+                                                    const pdlpdev_step_params& sp, const double* pw = nullptr)
+{
+  const double w = ctl->primal_weight;
+  double step    = ctl->step_size;
+  const double movement = sp.primal_distance_smoothing * w * dx2 + (sp.dual_distance_smoothing / w) * dy2;
+  ctl->last_interaction = interaction;
+  ctl->last_movement    = movement;
+  ctl->last_dx2         = dx2;
+  ctl->last_dy2         = dy2;
+  ctl->attempts += 1;
+  bool accepted;
+  if (movement <= 0.0 || movement >= 1.0e100) {  // pdlp_constants.hpp:39-47
+    // reference: flag -1, k and eta untouched; take_step still averages and swaps
+    // (pdlp.cu:1193-1221) and the next loop trip is forced to be a major iteration.
+    ctl->error = 1;
+    accepted   = true;
+  } else {
+    const double inter = fabs(interaction);
+    ctl->k += 1;
+    const double kc    = (double)ctl->k;
+    const double limit = inter > 0.0 ? movement / inter : __builtin_huge_val();
+    accepted           = step <= limit;
+    const double s1    = (1.0 - (pw ? pw[0] : pow(kc + 1.0, -sp.reduction_exponent))) * limit;
+    const double s2    = (1.0 + (pw ? pw[1] : pow(kc + 1.0, -sp.growth_exponent))) * step;
+    step               = dmin(s1, s2);
+    ctl->step_size     = step;
+    ctl->tau           = step / w;
+    ctl->sigma         = step * w;
+  }
+  if (accepted) {
+    ctl->cur ^= 1;
+    ctl->pending_avg = 1;
+    ctl->sum_weights += step;  // the ALREADY UPDATED step size (pdlp.cu:1216-1220)
+    ctl->steps_taken += 1;
+    ctl->its_since_restart += 1;
+  } else {
+    ctl->pending_avg = 0;
+  }
+}
+
 constexpr int kDecisionThreads = 1024;  // one wide workgroup: every partial is one independent load
 __global__ void __launch_bounds__(kDecisionThreads)
 k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
@@ -507,46 +602,188 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   }
   block_reduce<SumOp, 3, kDecisionThreads / 64>(acc, red);
   if (threadIdx.x != 0) return;
-  const double dy2         = dy2_reduced ? dy2_reduced[0] : acc[0];
-  const double interaction = acc[1];
-  const double dx2         = acc[2];
-  const double w           = ctl->primal_weight;
-  double step              = ctl->step_size;
-  const double movement =
-    sp.primal_distance_smoothing * w * dx2 + (sp.dual_distance_smoothing / w) * dy2;
-  ctl->last_interaction = interaction;
-  ctl->last_movement    = movement;
-  ctl->last_dx2         = dx2;
-  ctl->last_dy2         = dy2;
-  ctl->attempts += 1;
-  bool accepted;
-  if (movement <= 0.0 || movement >= 1.0e100) {  // pdlp_constants.hpp:39-47
-    // reference: flag -1, k and eta untouched; take_step still averages and swaps
-    // (pdlp.cu:1193-1221) and the next loop trip is forced to be a major iteration.
-    ctl->error = 1;
-    accepted   = true;
-  } else {
-    const double inter = fabs(interaction);
-    ctl->k += 1;
-    const double kc    = (double)ctl->k;
-    const double limit = inter > 0.0 ? movement / inter : __builtin_huge_val();
-    accepted           = step <= limit;
-    const double s1    = (1.0 - pow(kc + 1.0, -sp.reduction_exponent)) * limit;
-    const double s2    = (1.0 + pow(kc + 1.0, -sp.growth_exponent)) * step;
-    step               = dmin(s1, s2);
-    ctl->step_size     = step;
-    ctl->tau           = step / w;
-    ctl->sigma         = step * w;
+  apply_step_decision(ctl, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small LPs (MIP-style repeated re-solves, BASELINE config 5): the whole batch of PDHG attempts between two
+// major iterations runs inside ONE workgroup, with the LP on chip.  At this size a 4-launch attempt is pure
+// launch latency (~15 us) and even L2 round trips (3-4 dependent ones per phase) cost more than the arithmetic,
+// so nothing is re-read from memory inside the loop:
+//   * lane t keeps nonzeros t, t+T, ... of A and of A^T (value + column) in registers;
+//   * lane t owns rows / columns t, t+T, ...: their CSR extents and every per-element vector
+//     (x, A^T y, c, bounds, running sums ...) live in its registers;
+//   * the two gathered vectors (xbar, y'), the nonzero products and the constant vectors (c, bounds) sit in LDS.
+// Products are val * vec[col] and every row is added up by its owner in CSR order, so x', y', A^T y' are
+// bit-identical to the multi-launch kernels (and the oracle); the three step-size sums use a different,
+// fixed reduction tree.  T lanes, Q elements and U nonzeros per lane: m, n <= Q*T, nnz <= U*T.
+// ------------------------------------------------------------------------------------------------
+struct SmallView {
+  int m, n, nnz;
+  const int32_t *a_off, *a_idx, *at_off, *at_idx;
+  const double *a_val, *at_val, *c, *lb, *ub, *lo, *hi;
+  double *x0, *x1, *y0, *y1, *aty0, *aty1, *sumx, *sumy;
+};
+template <int T, int Q, int U>
+__global__ void __launch_bounds__(T)
+k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params sp, int max_attempts)
+{
+  extern __shared__ double lds[];
+  double* xbar_s = lds;               // Q*T
+  double* yn_s   = xbar_s + Q * T;    // Q*T
+  double* c_s    = yn_s + Q * T;      // constants, read with stride 1 by their owners
+  double* lb_s   = c_s + Q * T;
+  double* ub_s   = lb_s + Q * T;
+  double* lo_s   = ub_s + Q * T;
+  double* hi_s   = lo_s + Q * T;
+  double* prod   = hi_s + Q * T;      // U*T
+  __shared__ double red[3 * (T / 64)];
+  __shared__ pdlpdev_ctl lc;  // workgroup copy of the control block: read by everyone, written by thread 0
+  __shared__ double pw[2];    // the two powers of the step-size rule, computed by the last wave while rows are summed
+  const int t = threadIdx.x;
+  if (t == 0) lc = *ctl;
+  double a_val[U], at_val[U];
+  int a_col[U], at_col[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k  = t + u * T;
+    const bool in = k < V.nnz;
+    a_val[u]  = in ? V.a_val[k] : 0.0;
+    a_col[u]  = in ? V.a_idx[k] : 0;
+    at_val[u] = in ? V.at_val[k] : 0.0;
+    at_col[u] = in ? V.at_idx[k] : 0;
   }
-  if (accepted) {
-    ctl->cur ^= 1;
-    ctl->pending_avg = 1;
-    ctl->sum_weights += step;  // the ALREADY UPDATED step size (pdlp.cu:1216-1220)
-    ctl->steps_taken += 1;
-    ctl->its_since_restart += 1;
-  } else {
-    ctl->pending_avg = 0;
+  __syncthreads();
+  const int cur0 = lc.cur;
+  int r0[Q], r1[Q], c0[Q], c1[Q];  // CSR extents of the owned rows of A and of A^T (empty when out of range)
+  double x[Q], xn[Q], aty[Q], atyn[Q], sumx[Q], y[Q], yn[Q], sumy[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = t + q * T;
+    const bool row = e < V.m, col = e < V.n;
+    r0[q] = row ? V.a_off[e] : 0, r1[q] = row ? V.a_off[e + 1] : 0;
+    c0[q] = col ? V.at_off[e] : 0, c1[q] = col ? V.at_off[e + 1] : 0;
+    c_s[e] = col ? V.c[e] : 0.0, lb_s[e] = col ? V.lb[e] : 0.0, ub_s[e] = col ? V.ub[e] : 0.0;
+    x[q]    = col ? (cur0 ? V.x1 : V.x0)[e] : 0.0;
+    aty[q]  = col ? (cur0 ? V.aty1 : V.aty0)[e] : 0.0;
+    sumx[q] = col ? V.sumx[e] : 0.0;
+    lo_s[e] = row ? V.lo[e] : 0.0, hi_s[e] = row ? V.hi[e] : 0.0;
+    y[q]    = row ? (cur0 ? V.y1 : V.y0)[e] : 0.0;
+    sumy[q] = row ? V.sumy[e] : 0.0;
+    xn[q] = x[q], atyn[q] = aty[q], yn[q] = y[q];
   }
+  for (int attempt = 0; attempt < max_attempts; ++attempt) {
+    if (lc.error != 0 || lc.steps_taken >= lc.target_steps) break;  // uniform: lc is shared
+    const int cur       = lc.cur;
+    const double tau = lc.tau, sigma = lc.sigma, weight = lc.step_size;
+    const bool pend     = lc.pending_avg != 0;
+    const double knext  = (double)(lc.k + 1) + 1.0;
+    // primal projection (utils.cuh:80-95) + deferred averaging
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = t + q * T;
+      if (j < V.n) {
+        const double gradient = c_s[j] - aty[q];
+        double next           = x[q] - (tau * gradient);
+        next                  = dmax(dmin(next, ub_s[j]), lb_s[j]);
+        xn[q]                 = next;
+        xbar_s[j]             = next - x[q] + next;
+        if (pend) sumx[q] = sumx[q] + weight * x[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) prod[t + u * T] = a_val[u] * xbar_s[a_col[u]];
+    __syncthreads();
+    // y' = proj(y - sigma A xbar) (utils.cuh:97-112), ||dy||^2
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = t + q * T;
+      if (i < V.m) {
+        double ax = 0.0;
+        for (int k = r0[q]; k < r1[q]; ++k) ax = ax + prod[k];
+        double next      = y[q] - (sigma * ax);
+        const double low = next + sigma * lo_s[i];
+        const double up  = next + sigma * hi_s[i];
+        next             = dmax(low, dmin(up, 0.0));
+        yn[q]            = next;
+        yn_s[i]          = next;
+        const double dy  = next - y[q];
+        acc[0] += dy * dy;
+        if (pend) sumy[q] = sumy[q] + weight * y[q];
+      }
+    }
+    if (t >= T - 2) pw[t - (T - 2)] = pow(knext, t == T - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) prod[t + u * T] = at_val[u] * yn_s[at_col[u]];
+    __syncthreads();
+    // A^T y' + interaction / ||dx||^2 (adaptive_step_size_strategy.cu:278-340)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = t + q * T;
+      if (j < V.n) {
+        double v = 0.0;
+        for (int k = c0[q]; k < c1[q]; ++k) v = v + prod[k];
+        atyn[q]          = v;
+        const double dx  = xn[q] - x[q];
+        const double dty = v - aty[q];
+        acc[1] += dty * dx;
+        acc[2] += dx * dx;
+      }
+    }
+    block_reduce<SumOp, 3, T / 64>(acc, red);
+    if (t == 0) apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
+    __syncthreads();
+    if (lc.cur != cur) {  // accepted: the candidate becomes the iterate
+#pragma unroll
+      for (int q = 0; q < Q; ++q) x[q] = xn[q], aty[q] = atyn[q], y[q] = yn[q];
+    }
+  }
+  {
+    const int cur = lc.cur;
+    double* xo    = cur ? V.x1 : V.x0;
+    double* yo    = cur ? V.y1 : V.y0;
+    double* atyo  = cur ? V.aty1 : V.aty0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int e = t + q * T;
+      if (e < V.n) xo[e] = x[q], atyo[e] = aty[q], V.sumx[e] = sumx[q];
+      if (e < V.m) yo[e] = y[q], V.sumy[e] = sumy[q];
+    }
+  }
+  __syncthreads();
+  if (t == 0) *ctl = lc;
+}
+// the three instantiations, smallest first: (lanes, elements per lane, nonzeros per lane)
+struct ResidentTier { int T, Q, U; };
+constexpr ResidentTier kResidentTiers[3] = {{256, 2, 8}, {1024, 1, 8}, {1024, 2, 4}};
+static int resident_tier(int m, int n, int64_t nnz)
+{
+  for (int i = 0; i < 3; ++i) {
+    const ResidentTier& r = kResidentTiers[i];
+    if (m <= r.Q * r.T && n <= r.Q * r.T && nnz <= (int64_t)r.U * r.T) return i;
+  }
+  return -1;
+}
+static size_t resident_lds_bytes(int tier)
+{
+  const ResidentTier& r = kResidentTiers[tier];
+  return sizeof(double) * (size_t)r.T * (7 * r.Q + r.U);
+}
+template <int T, int Q, int U>
+static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_ctl* ctl, const pdlpdev_step_params& sp)
+{
+  static bool configured = false;  // per instantiation; LDS beyond 64 KiB has to be requested once
+  if (!configured) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_pdhg_resident<T, Q, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)resident_lds_bytes(tier)));
+    configured = true;
+  }
+  k_pdhg_resident<T, Q, U><<<1, T, resident_lds_bytes(tier), s>>>(V, ctl, sp, 1 << 14);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // panel-layout twins of (2) and (3): same epilogues, slab-major gather (pdlp_kernels.hpp)
@@ -1367,7 +1604,20 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   ctx->device      = device;
   ctx->m = m, ctx->n = n, ctx->nnz = a_offsets[m];
   *out = ctx;
-  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  {
+    Recycled r;
+    if (take_recycled(device, &r)) {
+      ctx->stream = r.stream, ctx->scal_h = r.pinned, ctx->arena = r.chunk, ctx->first_chunk = r.chunk;
+      HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      HIP_TRY(hipHostMalloc((void**)&ctx->scal_h, kScalars * sizeof(double) + sizeof(pdlpdev_ctl)));  // one pinned block
+      HIP_TRY(hipMalloc((void**)&ctx->arena, kArenaChunk));
+      HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
+      ctx->first_chunk = ctx->arena;
+    }
+    ctx->ctl_h = (pdlpdev_ctl*)(ctx->scal_h + kScalars);
+  }
   const size_t nnz = (size_t)ctx->nnz;
   if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
   TRY(upload_i32(ctx, &ctx->a_off, a_offsets, (size_t)m + 1));
@@ -1419,14 +1669,20 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
       lap("upload panels At");
     }
   }
+  {
+    // small LPs: a whole batch of attempts inside one workgroup (CUOPT_AMD_SMALL=0 switches it off)
+    const char* small_env = getenv("CUOPT_AMD_SMALL");
+    const int tier        = resident_tier(m, n, ctx->nnz);
+    ctx->small_resident   = tier >= 0 && !(small_env && atoi(small_env) == 0);
+    if (small_env && atoi(small_env) != 0 && tier < 0)
+      return fail(-1, "CUOPT_AMD_SMALL=1: the LP does not fit the resident kernel (m, n <= 2048, nnz <= 4096 ...)");
+  }
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max(std::max(ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0), 1)));
   TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max(std::max(ctx->at_nb, ctx->pat.on ? ctx->pat.v.W : 0), 1)));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
   TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + 8));
-  HIP_TRY(hipHostMalloc((void**)&ctx->scal_h, kScalars * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&ctx->ctl_h, sizeof(pdlpdev_ctl)));
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
   HIP_TRY(hipGetLastError());
@@ -1450,9 +1706,12 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   for (void* p : ctx->allocs) (void)hipFree(p);
-  if (ctx->scal_h) (void)hipHostFree(ctx->scal_h);
-  if (ctx->ctl_h) (void)hipHostFree(ctx->ctl_h);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk;
+  if (!(whole && give_recycled(Recycled{ctx->device, ctx->stream, ctx->scal_h, ctx->first_chunk}))) {
+    if (ctx->first_chunk) (void)hipFree(ctx->first_chunk);
+    if (ctx->scal_h) (void)hipHostFree(ctx->scal_h);  // ctl_h lives in the same block
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  }
   delete ctx;
 }
 
@@ -1686,6 +1945,89 @@ int pdlpdev_project_primal(pdlpdev_ctx* ctx)
 // ---- hot loop -------------------------------------------------------------------------------------
 }  // extern "C"
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next);
+// single-workgroup head of a major iteration (pdlpdev_major_eval) for LPs on the resident path
+struct MajorSmallArgs {
+  int m, n, mode, rule_finite, want_linf;
+  double eps_p, eps_d;
+  const int32_t *a_off, *a_idx, *at_off, *at_idx;
+  const double *a_val, *at_val;
+  pdlpdev_ctl* ctl;
+  double *x0, *x1, *y0, *y1, *sumx, *sumy, *avgx, *avgy;
+  const double *dr, *dc, *c_u, *lb_u, *ub_u, *lo_u, *hi_u;
+  double *linf_m, *linf_n, *ax_cur, *ax_avg, *aty_cur, *aty_avg, *rc_cur, *rc_avg;
+  double* sc;  // current at sc[0..9), average at sc[32..41)
+};
+constexpr int kMajorThreads = 1024;
+// rows r = t, t+T, ... of M vec, each added up left to right by one lane (same order as every other SpMV here)
+template <class Epi, int NQ>
+__device__ __forceinline__ void small_rows(int rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                           const double* __restrict__ val, const double* vec, Epi& e, double (&acc)[NQ])
+{
+  for (int r = threadIdx.x; r < rows; r += kMajorThreads) {
+    double v = 0.0;
+    for (int k = off[r]; k < off[r + 1]; ++k) v = v + val[k] * vec[idx[k]];
+    e.row(r, v, acc);
+  }
+}
+__global__ void __launch_bounds__(kMajorThreads) k_major_small(MajorSmallArgs A)
+{
+  __shared__ double red[4 * kMajorThreads / 64];
+  const int t = threadIdx.x;
+  const int cur = A.ctl->cur;
+  double* x = cur ? A.x1 : A.x0;
+  double* y = cur ? A.y1 : A.y0;
+  const bool pend = A.ctl->pending_avg != 0;
+  const double w = A.ctl->step_size, sw = A.ctl->sum_weights;
+  for (int j = t; j < A.n; j += kMajorThreads) {
+    double sx = A.sumx[j];
+    if (pend) A.sumx[j] = sx = sx + w * x[j];
+    A.avgx[j] = A.mode == 0 ? x[j] : (A.mode == 1 ? 0.0 : sx / sw);
+  }
+  for (int i = t; i < A.m; i += kMajorThreads) {
+    double sy = A.sumy[i];
+    if (pend) A.sumy[i] = sy = sy + w * y[i];
+    A.avgy[i] = A.mode == 0 ? y[i] : (A.mode == 1 ? 0.0 : sy / sw);
+  }
+  __syncthreads();  // also orders the global writes above against the reads below (one workgroup)
+  if (t == 0) A.ctl->pending_avg = 0;
+  for (int which = 0; which < 2; ++which) {
+    const double* xv = which ? A.avgx : x;
+    const double* yv = which ? A.avgy : y;
+    double* sc       = A.sc + 32 * which;
+    {
+      EvalPrimalEpilogue e{yv, A.dr, A.lo_u, A.hi_u, A.eps_p, A.want_linf ? A.linf_m : nullptr, which ? A.ax_avg : A.ax_cur};
+      double acc[3] = {0.0, 0.0, 0.0};
+      small_rows(A.m, A.a_off, A.a_idx, A.a_val, xv, e, acc);
+      block_reduce<SumOp, 3, kMajorThreads / 64>(acc, red);
+      if (t == 0) sc[0] = acc[0], sc[1] = acc[1], sc[2] = acc[2];
+      __syncthreads();
+      if (A.want_linf) {
+        double mx[1] = {0.0};
+        for (int i = t; i < A.m; i += kMajorThreads) mx[0] = dmax(mx[0], A.linf_m[i]);  // own writes
+        block_reduce<MaxOp, 1, kMajorThreads / 64>(mx, red);
+        if (t == 0) sc[3] = mx[0];
+        __syncthreads();
+      }
+    }
+    {
+      EvalDualEpilogue e{EvalDualCore{xv, A.dc, A.c_u, A.lb_u, A.ub_u, A.eps_d, A.rule_finite, which ? A.rc_avg : A.rc_cur,
+                                      A.want_linf ? A.linf_n : nullptr, which ? A.aty_avg : A.aty_cur}};
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      small_rows(A.n, A.at_off, A.at_idx, A.at_val, yv, e, acc);
+      block_reduce<SumOp, 4, kMajorThreads / 64>(acc, red);
+      if (t == 0) sc[4] = acc[0], sc[5] = acc[1], sc[6] = acc[2], sc[7] = acc[3];
+      __syncthreads();
+      if (A.want_linf) {
+        double mx[1] = {0.0};
+        for (int j = t; j < A.n; j += kMajorThreads) mx[0] = dmax(mx[0], A.linf_n[j]);
+        block_reduce<MaxOp, 1, kMajorThreads / 64>(mx, red);
+        if (t == 0) sc[8] = mx[0];
+        __syncthreads();
+      }
+    }
+  }
+}
+
 extern "C" {
 int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 {
@@ -1788,6 +2130,23 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   HIP_TRY(hipSetDevice(ctx->device));
   k_set_target<<<1, 1, 0, ctx->stream>>>(ctx->ctl, target_steps);
   LAUNCH_CHECK();
+  if (ctx->small_resident && !ctx->comm) {
+    // one launch runs attempts until the target is reached (rejected attempts included); the cap only bounds
+    // a pathological rejection streak, in which case the loop below relaunches
+    SmallView V{ctx->m, ctx->n, (int)ctx->nnz, ctx->a_off, ctx->a_idx, ctx->at_off, ctx->at_idx, ctx->a_val, ctx->at_val,
+                ctx->c, ctx->lb, ctx->ub, ctx->lo, ctx->hi, ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->aty[0],
+                ctx->aty[1], ctx->sumx, ctx->sumy};
+    const int tier = resident_tier(ctx->m, ctx->n, ctx->nnz);
+    for (int guard = 0; guard < 1000; ++guard) {
+      if (tier == 0) TRY((launch_resident<256, 2, 8>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
+      if (tier == 1) TRY((launch_resident<1024, 1, 8>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
+      if (tier == 2) TRY((launch_resident<1024, 2, 4>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
+      TRY(fetch_ctl(ctx, nullptr));
+      if (ctx->ctl_h->error != 0 || ctx->ctl_h->steps_taken >= target_steps) break;
+    }
+    if (ctl) *ctl = *ctx->ctl_h;
+    return 0;
+  }
   TRY(fetch_ctl(ctx, nullptr));
   // Each attempt accepts at most one step, so `remaining` attempts can never overshoot; rejected
   // attempts are made up for in the next round (one control-block read per round, not per step).
@@ -1848,10 +2207,10 @@ int pdlpdev_make_average(pdlpdev_ctx* ctx, int mode)
   return 0;
 }
 
-int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
-                 double eps_rel_dual, double out[PDLPDEV_EV_COUNT])
+// the launches of one convergence evaluation; results land in sc[0..9) (layout below), nothing is read back
+static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
+                        double eps_rel_dual, double* sc)
 {
-  HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int n = ctx->n, m = ctx->m;
   // LAST_RESTART is evaluated like the average, with the anchors in the "alternative iterate" slots
@@ -1863,7 +2222,7 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   const bool want_linf = eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0;
   double* linf_m = want_linf ? ctx->tmp_m : nullptr;
   double* linf_n = want_linf ? ctx->tmp_n : nullptr;
-  double* sc = ctx->scal;  // layout: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
+  // layout of sc: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
   if (ctx->pa.on)
     k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else
@@ -1902,8 +2261,10 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 1u, sc + 8);
   }
   LAUNCH_CHECK();
-  TRY(fetch_scalars(ctx, 9));
-  const double* h = ctx->scal_h;
+  return 0;
+}
+static void read_eval(const double* h, bool want_linf, double out[PDLPDEV_EV_COUNT])
+{
   out[PDLPDEV_EV_PRES2]         = h[0];
   out[PDLPDEV_EV_DUAL_SUM]      = h[1] + h[5];
   out[PDLPDEV_EV_Y2]            = h[2];
@@ -1912,6 +2273,43 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
   out[PDLPDEV_EV_CX]            = h[6];
   out[PDLPDEV_EV_X2]            = h[7];
   out[PDLPDEV_EV_LINF_DRES_REL] = want_linf ? h[8] : 0.0;
+}
+int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
+                 double eps_rel_dual, double out[PDLPDEV_EV_COUNT])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(enqueue_eval(ctx, which, rc_rule_finite_bounds, eps_rel_primal, eps_rel_dual, ctx->scal));
+  TRY(fetch_scalars(ctx, 9));
+  read_eval(ctx->scal_h, eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0, out);
+  return 0;
+}
+
+// ---- the head of a major iteration in one go ------------------------------------------------------
+// flush the deferred average, form the average iterate, evaluate the current and the average iterate
+// (pdlp.cu:1102-1160): one read-back instead of two; for LPs on the resident path one launch instead of ~12.
+int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bounds, double eps_rel_primal,
+                       double eps_rel_dual, double out_current[PDLPDEV_EV_COUNT], double out_average[PDLPDEV_EV_COUNT])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  const bool want_linf = eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0;
+  if (ctx->small_resident && !ctx->comm) {
+    MajorSmallArgs A{ctx->m, ctx->n, average_mode, rc_rule_finite_bounds, want_linf ? 1 : 0, eps_rel_primal, eps_rel_dual,
+                     ctx->a_off, ctx->a_idx, ctx->at_off, ctx->at_idx, ctx->a_val, ctx->at_val, ctx->ctl,
+                     ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->sumx, ctx->sumy, ctx->avgx, ctx->avgy,
+                     ctx->dr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->tmp_m, ctx->tmp_n,
+                     ctx->ax_u[PDLPDEV_CURRENT], ctx->ax_u[PDLPDEV_AVERAGE], ctx->aty_u[PDLPDEV_CURRENT],
+                     ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal};
+    k_major_small<<<1, kMajorThreads, 0, ctx->stream>>>(A);
+    LAUNCH_CHECK();
+  } else {
+    TRY(pdlpdev_flush_average(ctx));
+    TRY(pdlpdev_make_average(ctx, average_mode));
+    TRY(enqueue_eval(ctx, PDLPDEV_CURRENT, rc_rule_finite_bounds, eps_rel_primal, eps_rel_dual, ctx->scal));
+    TRY(enqueue_eval(ctx, PDLPDEV_AVERAGE, rc_rule_finite_bounds, eps_rel_primal, eps_rel_dual, ctx->scal + 32));
+  }
+  TRY(fetch_scalars(ctx, 41));
+  read_eval(ctx->scal_h, want_linf, out_current);
+  read_eval(ctx->scal_h + 32, want_linf, out_average);
   return 0;
 }
 
@@ -2248,6 +2646,7 @@ int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   out[0] = ctx->pa.on ? 1 : 0, out[1] = ctx->pa.on ? ctx->pa.v.W : ctx->a_nb, out[2] = ctx->pa.on ? ctx->pa.v.S : 1;
   out[3] = ctx->pat.on ? 1 : 0, out[4] = ctx->pat.on ? ctx->pat.v.W : ctx->at_nb, out[5] = ctx->pat.on ? ctx->pat.v.S : 1;
+  if (ctx->small_resident) out[0] = out[3] = 2;  // 2 = resident single-workgroup loop
   return 0;
 }
 

@@ -276,7 +276,6 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
   pdlpdev_ctx* dev        = s->dev;
   *terminated             = false;
   s->result.num_major_iterations += 1;
-  DEV(pdlpdev_flush_average(dev));
   // pdlp.cu:1110-1122: with 0 or 1 steps the average IS the iterate (avoids a*x/x != x);
   // right after a restart the sums are empty and the reference yields zeros.
   int mode = 2;
@@ -284,18 +283,19 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     mode = 0;
   else if (s->ctl.its_since_restart == 0)
     mode = 1;
-  DEV(pdlpdev_make_average(dev, mode));
   const int rule_finite = H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
   // the l-infinity residuals are only consumed by the per-constraint verdict (termination_strategy.cu:189-205)
   const double eps_p = s->S.per_constraint_residual ? s->S.relative_primal_tolerance : -1.0;
   const double eps_d = s->S.per_constraint_residual ? s->S.relative_dual_tolerance : -1.0;
-  double ev[PDLPDEV_EV_COUNT];
-  DEV(pdlpdev_eval(dev, PDLPDEV_CURRENT, rule_finite, eps_p, eps_d, ev));
+  double ev[PDLPDEV_EV_COUNT], ev_avg[PDLPDEV_EV_COUNT];
+  // pending average + average iterate + both convergence evaluations, one read-back
+  DEV(pdlpdev_major_eval(dev, mode, rule_finite, eps_p, eps_d, ev, ev_avg));
   s->conv_current = to_convergence(s, ev);
-  if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_CURRENT, rule_finite, s->conv_current.infeasibility));
-  DEV(pdlpdev_eval(dev, PDLPDEV_AVERAGE, rule_finite, eps_p, eps_d, ev));
-  s->conv_average = to_convergence(s, ev);
-  if (s->S.detect_infeasibility) DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_AVERAGE, rule_finite, s->conv_average.infeasibility));
+  s->conv_average = to_convergence(s, ev_avg);
+  if (s->S.detect_infeasibility) {
+    DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_CURRENT, rule_finite, s->conv_current.infeasibility));
+    DEV(pdlpdev_eval_infeasibility(dev, PDLPDEV_AVERAGE, rule_finite, s->conv_average.infeasibility));
+  }
   const int t_cur = verdict(s, s->conv_current), t_avg = verdict(s, s->conv_average);
   const double w  = s->ctl.primal_weight;
 

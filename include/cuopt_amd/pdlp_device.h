@@ -208,6 +208,10 @@ int pdlpdev_make_average(pdlpdev_ctx* ctx, int mode);
  * traffic and four launches per evaluation). */
 int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
                  double eps_rel_dual, double out[PDLPDEV_EV_COUNT]);
+/* The head of a major iteration in one call: flush_average + make_average(average_mode) + eval(CURRENT) +
+ * eval(AVERAGE), with a single read-back (one launch in total for LPs on the resident small-LP path). */
+int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bounds, double eps_rel_primal,
+                       double eps_rel_dual, double out_current[PDLPDEV_EV_COUNT], double out_average[PDLPDEV_EV_COUNT]);
 /* Infeasibility information of the iterate evaluated by the LAST pdlpdev_eval(which) call (its A x and
  * A^T y are reused; the iterate itself is the ray estimate, infeasibility_information.cu:176-223):
  * out = {max_primal_ray_infeasibility, primal_ray_linear_objective, max_dual_ray_infeasibility,
@@ -260,7 +264,9 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx);
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
 /* SpMV layout actually in use: out = {A: panels?(0/1), workgroups, slabs, A^T: panels?, workgroups, slabs}.
  * Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default: slab-major row panels when the
- * gathered vector exceeds 2 MiB, CSR stream otherwise) | stream | panel ; CUOPT_AMD_SLAB_BYTES (1 MiB). */
+ * gathered vector exceeds 2 MiB and measure faster at setup, CSR stream otherwise) | stream | panel ;
+ * CUOPT_AMD_SLAB_BYTES (1 MiB).  out[0] = out[3] = 2: small LP (m + n <= 16384, nnz <= 65536; CUOPT_AMD_SMALL=0/1
+ * overrides) whose attempt batches run inside ONE resident workgroup instead of 4 launches per attempt. */
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6]);
 
 #ifdef __cplusplus

@@ -16,6 +16,7 @@ def layout(request, monkeypatch):
     mode, slab = request.param
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
     monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(slab))
+    monkeypatch.setenv("CUOPT_AMD_SMALL", "0")  # these LPs are small: keep them on the multi-launch kernels under test
     return mode
 
 
