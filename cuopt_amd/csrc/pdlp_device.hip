@@ -624,9 +624,23 @@ struct SmallView {
   const double *a_val, *at_val, *c, *lb, *ub, *lo, *hi;
   double *x0, *x1, *y0, *y1, *aty0, *aty1, *sumx, *sumy;
 };
+// prod[a..b) added up strictly left to right; eight LDS reads are in flight before the first add
+__device__ __forceinline__ double lds_row_sum(const double* prod, int a, int b)
+{
+  double acc = 0.0;
+  for (int k = a; k < b; k += 8) {
+    double p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = prod[k + i < b ? k + i : a];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = k + i < b ? acc + p[i] : acc;
+  }
+  return acc;
+}
 template <int T, int Q, int U>
 __global__ void __launch_bounds__(T)
-k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params sp, int max_attempts)
+k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_ctl* __restrict__ ctl_host, pdlpdev_step_params sp,
+                int target_steps, int max_attempts)
 {
   extern __shared__ double lds[];
   double* xbar_s = lds;               // Q*T
@@ -637,11 +651,15 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
   double* lo_s   = ub_s + Q * T;
   double* hi_s   = lo_s + Q * T;
   double* prod   = hi_s + Q * T;      // U*T
-  __shared__ double red[3 * (T / 64)];
-  __shared__ pdlpdev_ctl lc;  // workgroup copy of the control block: read by everyone, written by thread 0
-  __shared__ double pw[2];    // the two powers of the step-size rule, computed by the last wave while rows are summed
+  // two sets (attempt parity) of cross-wave partials: a wave may start the next attempt's reduction while a slower
+  // one still reads this attempt's table -- the barriers in between only order the *other* buffers
+  __shared__ double red[2][3 * 16];
+  __shared__ double pw[2][2];  // the two powers of the step-size rule, computed by the last wave while rows are summed
   const int t = threadIdx.x;
-  if (t == 0) lc = *ctl;
+  // Every lane keeps its own copy of the control block and repeats the (uniform) step decision: no broadcast
+  // through LDS and no barrier between the reduction and the next primal step.
+  pdlpdev_ctl lc = *ctl;
+  lc.target_steps = target_steps;
   double a_val[U], at_val[U];
   int a_col[U], at_col[U];
 #pragma unroll
@@ -653,7 +671,6 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
     at_val[u] = in ? V.at_val[k] : 0.0;
     at_col[u] = in ? V.at_idx[k] : 0;
   }
-  __syncthreads();
   const int cur0 = lc.cur;
   int r0[Q], r1[Q], c0[Q], c1[Q];  // CSR extents of the owned rows of A and of A^T (empty when out of range)
   double x[Q], xn[Q], aty[Q], atyn[Q], sumx[Q], y[Q], yn[Q], sumy[Q];
@@ -672,12 +689,14 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
     sumy[q] = row ? V.sumy[e] : 0.0;
     xn[q] = x[q], atyn[q] = aty[q], yn[q] = y[q];
   }
+  const int used = (V.nnz + T - 1) / T;  // nonzero slots in use (uniform): tiny LPs skip the empty ones
   for (int attempt = 0; attempt < max_attempts; ++attempt) {
-    if (lc.error != 0 || lc.steps_taken >= lc.target_steps) break;  // uniform: lc is shared
+    if (lc.error != 0 || lc.steps_taken >= lc.target_steps) break;  // uniform: every lane holds the same lc
     const int cur       = lc.cur;
     const double tau = lc.tau, sigma = lc.sigma, weight = lc.step_size;
     const bool pend     = lc.pending_avg != 0;
     const double knext  = (double)(lc.k + 1) + 1.0;
+    const int par       = attempt & 1;
     // primal projection (utils.cuh:80-95) + deferred averaging
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -693,7 +712,8 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < U; ++u) prod[t + u * T] = a_val[u] * xbar_s[a_col[u]];
+    for (int u = 0; u < U; ++u)
+      if (u < used) prod[t + u * T] = a_val[u] * xbar_s[a_col[u]];
     __syncthreads();
     // y' = proj(y - sigma A xbar) (utils.cuh:97-112), ||dy||^2
     double acc[3] = {0.0, 0.0, 0.0};
@@ -701,8 +721,7 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
     for (int q = 0; q < Q; ++q) {
       const int i = t + q * T;
       if (i < V.m) {
-        double ax = 0.0;
-        for (int k = r0[q]; k < r1[q]; ++k) ax = ax + prod[k];
+        const double ax = lds_row_sum(prod, r0[q], r1[q]);
         double next      = y[q] - (sigma * ax);
         const double low = next + sigma * lo_s[i];
         const double up  = next + sigma * hi_s[i];
@@ -714,18 +733,18 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
         if (pend) sumy[q] = sumy[q] + weight * y[q];
       }
     }
-    if (t >= T - 2) pw[t - (T - 2)] = pow(knext, t == T - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
+    if (t >= T - 2) pw[par][t - (T - 2)] = pow(knext, t == T - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < U; ++u) prod[t + u * T] = at_val[u] * yn_s[at_col[u]];
+    for (int u = 0; u < U; ++u)
+      if (u < used) prod[t + u * T] = at_val[u] * yn_s[at_col[u]];
     __syncthreads();
     // A^T y' + interaction / ||dx||^2 (adaptive_step_size_strategy.cu:278-340)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int j = t + q * T;
       if (j < V.n) {
-        double v = 0.0;
-        for (int k = c0[q]; k < c1[q]; ++k) v = v + prod[k];
+        const double v = lds_row_sum(prod, c0[q], c1[q]);
         atyn[q]          = v;
         const double dx  = xn[q] - x[q];
         const double dty = v - aty[q];
@@ -733,9 +752,8 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
         acc[2] += dx * dx;
       }
     }
-    block_reduce<SumOp, 3, T / 64>(acc, red);
-    if (t == 0) apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
-    __syncthreads();
+    block_sum_fast<3, T / 64>(acc, red[par]);
+    apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw[par]);
     if (lc.cur != cur) {  // accepted: the candidate becomes the iterate
 #pragma unroll
       for (int q = 0; q < Q; ++q) x[q] = xn[q], aty[q] = atyn[q], y[q] = yn[q];
@@ -753,12 +771,11 @@ k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_step_params 
       if (e < V.m) yo[e] = y[q], V.sumy[e] = sumy[q];
     }
   }
-  __syncthreads();
-  if (t == 0) *ctl = lc;
+  if (t == 0) *ctl = lc, *ctl_host = lc;  // the pinned mirror saves the read-back copy
 }
 // the three instantiations, smallest first: (lanes, elements per lane, nonzeros per lane)
 struct ResidentTier { int T, Q, U; };
-constexpr ResidentTier kResidentTiers[3] = {{256, 2, 8}, {1024, 1, 8}, {1024, 2, 4}};
+constexpr ResidentTier kResidentTiers[3] = {{256, 2, 8}, {512, 2, 16}, {512, 4, 8}};
 static int resident_tier(int m, int n, int64_t nnz)
 {
   for (int i = 0; i < 3; ++i) {
@@ -773,7 +790,8 @@ static size_t resident_lds_bytes(int tier)
   return sizeof(double) * (size_t)r.T * (7 * r.Q + r.U);
 }
 template <int T, int Q, int U>
-static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_ctl* ctl, const pdlpdev_step_params& sp)
+static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_ctl* ctl, pdlpdev_ctl* ctl_host,
+                           const pdlpdev_step_params& sp, int target_steps)
 {
   static bool configured = false;  // per instantiation; LDS beyond 64 KiB has to be requested once
   if (!configured) {
@@ -781,7 +799,7 @@ static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_
                                 (int)resident_lds_bytes(tier)));
     configured = true;
   }
-  k_pdhg_resident<T, Q, U><<<1, T, resident_lds_bytes(tier), s>>>(V, ctl, sp, 1 << 14);
+  k_pdhg_resident<T, Q, U><<<1, T, resident_lds_bytes(tier), s>>>(V, ctl, ctl_host, sp, target_steps, 1 << 14);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1955,7 +1973,7 @@ struct MajorSmallArgs {
   double *x0, *x1, *y0, *y1, *sumx, *sumy, *avgx, *avgy;
   const double *dr, *dc, *c_u, *lb_u, *ub_u, *lo_u, *hi_u;
   double *linf_m, *linf_n, *ax_cur, *ax_avg, *aty_cur, *aty_avg, *rc_cur, *rc_avg;
-  double* sc;  // current at sc[0..9), average at sc[32..41)
+  double* sc;  // current at sc[0..9), average at sc[32..41)  (pinned host memory: no read-back copy)
 };
 constexpr int kMajorThreads = 1024;
 // rows r = t, t+T, ... of M vec, each added up left to right by one lane (same order as every other SpMV here)
@@ -2128,25 +2146,26 @@ static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
 int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
 {
   HIP_TRY(hipSetDevice(ctx->device));
-  k_set_target<<<1, 1, 0, ctx->stream>>>(ctx->ctl, target_steps);
-  LAUNCH_CHECK();
   if (ctx->small_resident && !ctx->comm) {
     // one launch runs attempts until the target is reached (rejected attempts included); the cap only bounds
-    // a pathological rejection streak, in which case the loop below relaunches
+    // a pathological rejection streak, in which case the loop below relaunches.  The kernel takes the target as
+    // an argument and leaves the control block in pinned host memory: one launch + one synchronize per call.
     SmallView V{ctx->m, ctx->n, (int)ctx->nnz, ctx->a_off, ctx->a_idx, ctx->at_off, ctx->at_idx, ctx->a_val, ctx->at_val,
                 ctx->c, ctx->lb, ctx->ub, ctx->lo, ctx->hi, ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->aty[0],
                 ctx->aty[1], ctx->sumx, ctx->sumy};
     const int tier = resident_tier(ctx->m, ctx->n, ctx->nnz);
     for (int guard = 0; guard < 1000; ++guard) {
-      if (tier == 0) TRY((launch_resident<256, 2, 8>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
-      if (tier == 1) TRY((launch_resident<1024, 1, 8>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
-      if (tier == 2) TRY((launch_resident<1024, 2, 4>(ctx->stream, tier, V, ctx->ctl, ctx->sp)));
-      TRY(fetch_ctl(ctx, nullptr));
+      if (tier == 0) TRY((launch_resident<256, 2, 8>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
+      if (tier == 1) TRY((launch_resident<512, 2, 16>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
+      if (tier == 2) TRY((launch_resident<512, 4, 8>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->ctl_h->error != 0 || ctx->ctl_h->steps_taken >= target_steps) break;
     }
     if (ctl) *ctl = *ctx->ctl_h;
     return 0;
   }
+  k_set_target<<<1, 1, 0, ctx->stream>>>(ctx->ctl, target_steps);
+  LAUNCH_CHECK();
   TRY(fetch_ctl(ctx, nullptr));
   // Each attempt accepts at most one step, so `remaining` attempts can never overshoot; rejected
   // attempts are made up for in the next round (one control-block read per round, not per step).
@@ -2298,16 +2317,17 @@ int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bo
                      ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->sumx, ctx->sumy, ctx->avgx, ctx->avgy,
                      ctx->dr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->tmp_m, ctx->tmp_n,
                      ctx->ax_u[PDLPDEV_CURRENT], ctx->ax_u[PDLPDEV_AVERAGE], ctx->aty_u[PDLPDEV_CURRENT],
-                     ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal};
+                     ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal_h};
     k_major_small<<<1, kMajorThreads, 0, ctx->stream>>>(A);
     LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   } else {
     TRY(pdlpdev_flush_average(ctx));
     TRY(pdlpdev_make_average(ctx, average_mode));
     TRY(enqueue_eval(ctx, PDLPDEV_CURRENT, rc_rule_finite_bounds, eps_rel_primal, eps_rel_dual, ctx->scal));
     TRY(enqueue_eval(ctx, PDLPDEV_AVERAGE, rc_rule_finite_bounds, eps_rel_primal, eps_rel_dual, ctx->scal + 32));
+    TRY(fetch_scalars(ctx, 41));
   }
-  TRY(fetch_scalars(ctx, 41));
   read_eval(ctx->scal_h, want_linf, out_current);
   read_eval(ctx->scal_h + 32, want_linf, out_average);
   return 0;

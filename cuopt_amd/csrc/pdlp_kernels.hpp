@@ -81,6 +81,57 @@ __device__ __forceinline__ void block_reduce(double (&v)[NQ], double* scratch /*
   }
 }
 
+// ---- latency-optimised sum for single-workgroup loops (resident small-LP path) ---------------------
+// DPP lane permutes run at VALU latency (a few cycles) where ds_swizzle / ds_bpermute pay an LDS round trip.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// every lane ends with the sum over its 16-lane DPP row; fixed tree: xor 1, xor 2, half mirror, mirror
+__device__ __forceinline__ double row16_sum(double v)
+{
+  v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = v + dpp_move<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v = v + dpp_move<0x140>(v);  // row_mirror: the other 8 of the 16
+  return v;
+}
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v)  // wave-uniform result
+{
+  v = row16_sum(v);
+  return ((read_lane(v, 0) + read_lane(v, 16)) + read_lane(v, 32)) + read_lane(v, 48);
+}
+// Sum of NQ (<= 4) quantities over WAVES (<= 16) waves; EVERY lane of every wave ends with the totals (each wave
+// repeats the cheap cross-wave step), so a uniform decision can follow without a second barrier.
+// One barrier; the cross-wave step is one 16-lane row reduction per quantity instead of a serial loop.
+template <int NQ, int WAVES>
+__device__ __forceinline__ void block_sum_fast(double (&v)[NQ], double* scratch /* >= 16*NQ */)
+{
+  static_assert(NQ <= 4 && WAVES <= 16, "one DPP row per quantity");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double w = wave_sum_dpp(v[q]);
+    if (lane == 0) scratch[q * 16 + wave] = w;
+  }
+  __syncthreads();
+  const int q = lane >> 4, i = lane & 15;
+  double part = (q < NQ && i < WAVES) ? scratch[q * 16 + i] : 0.0;
+  part        = row16_sum(part);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) v[k] = read_lane(part, 16 * k);
+}
+
 __device__ __forceinline__ bool loop_active(const pdlpdev_ctl* ctl)
 {
   return ctl->error == 0 && ctl->steps_taken < ctl->target_steps;

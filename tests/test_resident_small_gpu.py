@@ -19,8 +19,8 @@ def solver(p, small, monkeypatch, **kw):
 
 def test_auto_selection(monkeypatch):
     monkeypatch.delenv("CUOPT_AMD_SMALL", raising=False)
-    assert capi.Device(synthetic.generate(2000, 2000, 2, seed=3)).layout()["resident"]  # 1024 lanes x 2 elements
-    assert capi.Device(synthetic.generate(1000, 1000, 8, seed=3)).layout()["resident"]  # 1024 lanes x 8 nonzeros
+    assert capi.Device(synthetic.generate(2000, 2000, 2, seed=3)).layout()["resident"]  # 512 lanes x 4 elements
+    assert capi.Device(synthetic.generate(1000, 1000, 8, seed=3)).layout()["resident"]  # 512 lanes x 16 nonzeros
     assert capi.Device(synthetic.generate(300, 500, 4, seed=3)).layout()["resident"]  # 256 lanes
     assert not capi.Device(synthetic.generate(2000, 2000, 10, seed=3)).layout()["resident"]  # too many nonzeros
     assert not capi.Device(synthetic.generate(3000, 1000, 2, seed=3)).layout()["resident"]  # m > 2048
