@@ -194,6 +194,8 @@ _proto("cuoptamd_default_settings", None, P(SolverSettings))
 _proto("cuoptamd_solver_create", c_int, P(c_void_p), P(LP), P(Hyper), P(SolverSettings), c_void_p,
        c_void_p, c_int, c_int, c_int, c_void_p)
 _proto("cuoptamd_solver_destroy", None, c_void_p)
+_proto("cuoptamd_solver_reset", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(SolverSettings), c_void_p,
+       c_void_p)
 _proto("cuoptamd_solver_advance", c_int, c_void_p, c_int, P(Result))
 _proto("cuoptamd_solver_get_solution", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_solver_device", c_void_p, c_void_p)
@@ -562,6 +564,20 @@ class Solver:
         rc = lib.cuoptamd_solver_set_warm_start(self.handle, C.byref(ws))
         if rc != 0:
             raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+
+    def reset(self, lb=None, ub=None, lo=None, hi=None, init_x=None, init_y=None, **setting_overrides):
+        """cuoptamd_solver_reset: new bounds (None = unchanged) on the same A, c; afterwards the solver is
+        indistinguishable from one freshly created on the modified LP (MIP-style re-solve without set-up)."""
+        arrays = [None if a is None else _f64(a) for a in (lb, ub, lo, hi, init_x, init_y)]
+        st = None
+        if setting_overrides:
+            self.settings = default_settings(**setting_overrides)
+            st = C.byref(self.settings)
+        rc = lib.cuoptamd_solver_reset(self.handle, _ptr(arrays[0]), _ptr(arrays[1]), _ptr(arrays[2]), _ptr(arrays[3]),
+                                       st, _ptr(arrays[4]), _ptr(arrays[5]))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        self.result = Result()
 
     def advance(self, iterations=2 ** 31 - 1):
         rc = lib.cuoptamd_solver_advance(self.handle, int(iterations), C.byref(self.result))

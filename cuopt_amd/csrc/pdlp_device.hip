@@ -339,6 +339,24 @@ __global__ void __launch_bounds__(kBlock) k_scale_vectors(int n, int m, double* 
     }
   }
 }
+// the bound part of k_scale_vectors alone (pdlpdev_reset): same expressions, so a re-solve with new bounds is
+// bit-identical to a fresh solver; NULL = that vector is unchanged
+__global__ void __launch_bounds__(kBlock) k_scale_bounds(int n, int m, double* lb, double* ub,
+                                                         const double* __restrict__ dc, double* lo, double* hi,
+                                                         const double* __restrict__ dr)
+{
+  const int tot = n > m ? n : m;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < tot; i += gridDim.x * kBlock) {
+    if (i < n) {
+      if (lb) lb[i] = lb[i] / dc[i];
+      if (ub) ub[i] = ub[i] / dc[i];
+    }
+    if (i < m) {
+      if (lo) lo[i] = lo[i] * dr[i];
+      if (hi) hi[i] = hi[i] * dr[i];
+    }
+  }
+}
 __global__ void __launch_bounds__(kBlock) k_div_inplace(int n, double* __restrict__ v,
                                                         const double* __restrict__ d)
 {
@@ -1898,6 +1916,53 @@ int pdlpdev_init_norms(pdlpdev_ctx* ctx, double out[3])
   out[0] = ctx->scal_h[0], out[1] = ctx->scal_h[1], out[2] = ctx->scal_h[2];
   return 0;
 }
+
+// New bounds for the SAME matrix and objective, iterate and all loop state back to their values right after
+// pdlpdev_scale_problem: what a MIP heuristic needs between two relaxations (relaxed_lp.cu:53-127 builds a whole
+// new pdlp_solver_t instead).  D_r, D_c depend on A only (initial_scaling.cu:125-307), so nothing is rescaled.
+int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const double* lo, const double* hi)
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->scaled) return fail(-1, "pdlpdev_reset: the problem has not been scaled yet");
+  hipStream_t s = ctx->stream;
+  const size_t nb = (size_t)ctx->n * sizeof(double), mb = (size_t)ctx->m * sizeof(double);
+  auto put = [&](const double* src, double* unscaled, double* scaled, size_t bytes) -> int {
+    if (!src || bytes == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(unscaled, src, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(scaled, unscaled, bytes, hipMemcpyDeviceToDevice, s));
+    return 0;
+  };
+  TRY(put(lb, ctx->lb_u, ctx->lb, nb));
+  TRY(put(ub, ctx->ub_u, ctx->ub, nb));
+  TRY(put(lo, ctx->lo_u, ctx->lo, mb));
+  TRY(put(hi, ctx->hi_u, ctx->hi, mb));
+  if (lb || ub || lo || hi)
+    k_scale_bounds<<<grid_for(std::max(ctx->m, ctx->n)), kBlock, 0, s>>>(ctx->n, ctx->m, lb ? ctx->lb : nullptr, ub ? ctx->ub : nullptr,
+                                                                      ctx->dc, lo ? ctx->lo : nullptr, hi ? ctx->hi : nullptr, ctx->dr);
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipMemsetAsync(ctx->x[i], 0, nb, s));
+    HIP_TRY(hipMemsetAsync(ctx->aty[i], 0, nb, s));
+    HIP_TRY(hipMemsetAsync(ctx->rc[i], 0, nb, s));
+    HIP_TRY(hipMemsetAsync(ctx->y[i], 0, mb, s));
+  }
+  for (double* v : {ctx->xbar, ctx->sumx, ctx->avgx, ctx->lrx}) HIP_TRY(hipMemsetAsync(v, 0, nb, s));
+  for (double* v : {ctx->sumy, ctx->avgy, ctx->lry}) HIP_TRY(hipMemsetAsync(v, 0, mb, s));
+  HIP_TRY(hipMemsetAsync(ctx->ctl, 0, sizeof(pdlpdev_ctl), s));
+  LAUNCH_CHECK();
+  return 0;
+}
+// out[0] = sum c_j^2, out[1] = sum bcomb_i^2 of the scaled (unscaled != 0: the user's) problem
+int pdlpdev_weight_norms(pdlpdev_ctx* ctx, int unscaled, double out[2])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(reduce_vec(ctx, 1, ctx->n, unscaled ? ctx->c_u : ctx->c, nullptr, 1));
+  TRY(reduce_vec(ctx, 2, ctx->m, unscaled ? ctx->lo_u : ctx->lo, unscaled ? ctx->hi_u : ctx->hi, 2));
+  TRY(allreduce(ctx, ctx->scal + 2, 1, rccl::kSum));
+  TRY(fetch_scalars(ctx, 3));
+  out[0] = ctx->scal_h[1], out[1] = ctx->scal_h[2];
+  return 0;
+}
+
 
 int pdlpdev_problem_norms(pdlpdev_ctx* ctx, double* norm_c, double* norm_b)
 {

@@ -83,6 +83,7 @@ struct cuoptamd_solver {
   bool empty_problem = false;  // n_constraints == 0 -> NumericalError (LP/solve.cu:355-359)
   double objective_scale = 1.0, objective_offset = 0.0;
   double norm_b = 0.0, norm_c = 0.0;
+  double computed_step = 0.0, computed_weight = 0.0;  // compute_initial_step_size / _primal_weight, before overrides
   // loop state
   int32_t total_iterations = 0;  // total_pdlp_iterations_ (keeps counting across warm starts)
   int32_t iteration_offset = 0;  // total_pdlp_iterations_ - internal_solver_iterations_
@@ -624,6 +625,31 @@ void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32
   bounds[world] = m;
 }
 
+// tail of the [init] block of run_solver (pdlp.cu:1014-1056): overrides, step/weight/k on the device, optional
+// initial iterate, projection.  Shared by cuoptamd_solver_create and cuoptamd_solver_reset.
+static int start_run(cuoptamd_solver* s, const double* init_x, const double* init_y)
+{
+  const cuoptamd_hyper* hyper = &s->H;
+  const cuoptamd_settings* settings = &s->S;
+  double step = s->computed_step, weight = s->computed_weight;
+  if (settings->initial_step_size >= 0.0) step = settings->initial_step_size;  // pdlp.cu:1014-1021
+  if (settings->initial_primal_weight >= 0.0) weight = settings->initial_primal_weight;
+  s->result.initial_step_size     = step;
+  s->result.initial_primal_weight = weight;
+  DEV(pdlpdev_set_step(s->dev, step, weight));
+  if (settings->initial_k >= 0) DEV(pdlpdev_set_k(s->dev, settings->initial_k));
+  if (init_x || init_y) {
+    if (hyper->update_primal_weight_on_initial_solution || hyper->update_step_size_on_initial_solution)
+      return fail(-7, "update_*_on_initial_solution hyper-parameters are not implemented");
+    DEV(pdlpdev_set_initial(s->dev, init_x, init_y ? init_y + s->row_begin : nullptr));
+  }
+  if (hyper->project_initial_primal) DEV(pdlpdev_project_primal(s->dev));  // pdlp.cu:1041-1056
+  DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
+  s->result.norm_b = s->norm_b, s->result.norm_c = s->norm_c;
+  s->result.step_size = step, s->result.primal_weight = weight;
+  return 0;
+}
+
 int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const cuoptamd_hyper* hyper,
                            const cuoptamd_settings* settings, const double* init_x,
                            const double* init_y, int device, int rank, int world,
@@ -716,21 +742,8 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   lap("scale_problem");
   if (!hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
   if (!hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
-  if (settings->initial_step_size >= 0.0) step = settings->initial_step_size;  // pdlp.cu:1014-1021
-  if (settings->initial_primal_weight >= 0.0) weight = settings->initial_primal_weight;
-  s->result.initial_step_size     = step;
-  s->result.initial_primal_weight = weight;
-  DEV(pdlpdev_set_step(s->dev, step, weight));
-  if (settings->initial_k >= 0) DEV(pdlpdev_set_k(s->dev, settings->initial_k));
-  if (init_x || init_y) {
-    if (hyper->update_primal_weight_on_initial_solution || hyper->update_step_size_on_initial_solution)
-      return fail(-7, "update_*_on_initial_solution hyper-parameters are not implemented");
-    DEV(pdlpdev_set_initial(s->dev, init_x, init_y ? init_y + s->row_begin : nullptr));
-  }
-  if (hyper->project_initial_primal) DEV(pdlpdev_project_primal(s->dev));  // pdlp.cu:1041-1056
-  DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
-  s->result.norm_b = s->norm_b, s->result.norm_c = s->norm_c;
-  s->result.step_size = step, s->result.primal_weight = weight;
+  s->computed_step = step, s->computed_weight = weight;
+  { int rc = start_run(s, init_x, init_y); if (rc) return rc; }
   lap("initial step/weight/iterate");
   s->result.setup_seconds = seconds_since(t0);
   return 0;
@@ -741,6 +754,44 @@ void cuoptamd_solver_destroy(cuoptamd_solver* s)
   if (!s) return;
   if (s->dev) pdlpdev_destroy(s->dev);
   delete s;
+}
+
+int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub, const double* lo, const double* hi,
+                          const cuoptamd_settings* settings, const double* init_x, const double* init_y)
+{
+  if (!s) return fail(-1, "cuoptamd_solver_reset: null solver");
+  const auto t0 = clock_type::now();
+  if (settings) {
+    s->S = *settings;
+    if (settings->log_file && settings->log_file[0]) s->log_path = settings->log_file;
+    s->S.log_file = nullptr;
+  }
+  // loop state as freshly constructed
+  const cuoptamd_result blank{};
+  s->total_iterations = 0, s->iteration_offset = 0, s->attempt_offset = 0, s->major_done_at = -1;
+  s->step_error = false, s->need_aty = true, s->last_restart_was_average = false;
+  s->last_candidate_kkt = 0.0, s->last_restart_kkt = 0.0, s->gap_reduction_ratio_last_trial = 1.0;
+  s->best_quality = cuoptamd_solver::Quality{};
+  s->best_quality.objective = s->maximize ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+  s->have_best = false, s->best_result = blank;
+  s->conv_current = Convergence{}, s->conv_average = Convergence{};
+  s->returned_which = PDLPDEV_CURRENT, s->finished = false, s->warm_started = false, s->started = false;
+  s->result = blank;
+  if (s->empty_problem) return 0;
+  DEV(pdlpdev_reset(s->dev, lb, ub, lo ? lo + s->row_begin : nullptr, hi ? hi + s->row_begin : nullptr));
+  if (lo || hi) {
+    // ||b|| of the termination rule and the initial primal weight depend on the row bounds (pdlp.cu:1260-1309)
+    DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
+    double nr[2];
+    DEV(pdlpdev_weight_norms(s->dev, s->H.compute_initial_primal_weight_before_scaling, nr));
+    const double cn = std::sqrt(s->H.initial_primal_weight_c_scaling * nr[0]);
+    const double bn = std::sqrt(s->H.initial_primal_weight_b_scaling * nr[1]);
+    s->computed_weight = (bn > 0.0 && cn > 0.0) ? s->H.primal_importance * (cn / bn) : s->H.primal_importance;
+  }
+  DEV(pdlpdev_set_graph_mode(s->dev, s->S.use_graph));
+  { int rc = start_run(s, init_x, init_y); if (rc) return rc; }
+  s->result.setup_seconds = seconds_since(t0);
+  return 0;
 }
 
 int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result)

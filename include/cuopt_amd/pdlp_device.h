@@ -167,6 +167,13 @@ int pdlpdev_scale_problem(pdlpdev_ctx* ctx);
 /* out[0] = max |A_ij| ; out[1] = sum c_j^2 ; out[2] = sum bcomb_i^2 of the problem AS IT IS NOW
  * (scaled or not), bcomb = combine_finite_abs_bounds(lo, hi) (utils.cuh:139-163). */
 int pdlpdev_init_norms(pdlpdev_ctx* ctx, double out[3]);
+/* out[0] = sum c_j^2, out[1] = sum bcomb_i^2 of the scaled problem (unscaled != 0: of the user's problem) */
+int pdlpdev_weight_norms(pdlpdev_ctx* ctx, int unscaled, double out[2]);
+/* Re-solve support (the MIP heuristics' call pattern, relaxed_lp.cu:53-175): replaces the variable / constraint bounds
+ * (host arrays in the user's space; NULL = unchanged) of an already scaled problem and puts iterate, sums, restart
+ * anchors and the control block back to their state right after pdlpdev_scale_problem.  Matrix, objective, D_r, D_c,
+ * layouts and graphs are kept; continue with set_step / set_k / set_initial / project_primal as after create. */
+int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const double* lo, const double* hi);
 /* l2 norms of the UNSCALED c and bcomb (termination constants, convergence_information.cu:76-84) */
 int pdlpdev_problem_norms(pdlpdev_ctx* ctx, double* norm_c, double* norm_b);
 int pdlpdev_set_step_params(pdlpdev_ctx* ctx, const pdlpdev_step_params* p);

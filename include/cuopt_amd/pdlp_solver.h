@@ -171,6 +171,16 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
                            const uint8_t* comm_id);
 void cuoptamd_solver_destroy(cuoptamd_solver* s);
 
+/* Persistent re-solve, the MIP heuristics' call pattern (get_relaxed_lp_solution / run_lp_with_vars_fixed,
+ * cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-175: same A and c, tightened or fixed bounds, previous primal/dual as the
+ * initial point).  The reference constructs a new pdlp_solver_t per call (transpose, scaling, cuSPARSE set-up again);
+ * here the solver keeps A, A^T, D_r, D_c and its kernels' layouts and only takes the new bounds.
+ * lb / ub (n) and lo / hi (m_global): user-space host arrays, NULL = unchanged.  settings: NULL = unchanged.
+ * init_x / init_y as in cuoptamd_solver_create.  Afterwards the solver behaves exactly (bit for bit) like a solver
+ * freshly created on the modified LP: call cuoptamd_solver_advance. */
+int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub, const double* lo, const double* hi,
+                          const cuoptamd_settings* settings, const double* init_x, const double* init_y);
+
 /* Runs the PDLP loop until a termination criterion fires or `max_new_iterations` further PDLP
  * iterations (accepted steps) have been taken, whichever is first.  result->status == 0 means
  * "budget exhausted, not terminated"; calling again continues exactly where it stopped. */
