@@ -735,8 +735,8 @@ class Device:
     def layout(self):
         out = np.zeros(6, np.int32)
         self._ck(lib.pdlpdev_layout_info(self.handle, _ptr(out)))
-        return dict(A=dict(panels=out[0] == 1, workgroups=int(out[1]), slabs=int(out[2])),
-                    At=dict(panels=out[3] == 1, workgroups=int(out[4]), slabs=int(out[5])),
+        return dict(A=dict(panels=bool(out[0] == 1), workgroups=int(out[1]), slabs=int(out[2])),
+                    At=dict(panels=bool(out[3] == 1), workgroups=int(out[4]), slabs=int(out[5])),
                     resident=bool(out[0] == 2))
 
     def time_kernel(self, kernel, reps=20):

@@ -601,26 +601,37 @@ __device__ __forceinline__ void apply_step_decision(pdlpdev_ctl* ctl, double dy2
 }
 
 constexpr int kDecisionThreads = 1024;  // one wide workgroup: every partial is one independent load
+// Latency is all that matters here (one workgroup on the critical path of every attempt): the control block is
+// read once into registers (uniform -> scalar loads) and written back once, the two pow() of the step-size rule
+// are evaluated by the last wave while the others fetch partials, the sums use DPP lane permutes.
 __global__ void __launch_bounds__(kDecisionThreads)
 k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
                 const double* __restrict__ part_t, int nb_t, const double* __restrict__ dy2_reduced,
                 pdlpdev_step_params sp)
 {
-  __shared__ double red[3 * kDecisionThreads / 64];
-  if (!loop_active(ctl)) return;
+  __shared__ double red[3 * 16];
+  __shared__ double pw[2];
+  pdlpdev_ctl lc = *ctl;
+  if (!(lc.error == 0 && lc.steps_taken < lc.target_steps)) return;
+  const int t = threadIdx.x;
+  if (t >= kDecisionThreads - 2) {
+    const double knext = (double)(lc.k + 1) + 1.0;
+    pw[t - (kDecisionThreads - 2)] = pow(knext, t == kDecisionThreads - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
+  }
   double acc[3] = {0.0, 0.0, 0.0};
   if (dy2_reduced == nullptr) {
 #pragma unroll 4
-    for (int i = threadIdx.x; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
+    for (int i = t; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
   }
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nb_t; i += kDecisionThreads) {
+  for (int i = t; i < nb_t; i += kDecisionThreads) {
     acc[1] += part_t[i];
     acc[2] += part_t[nb_t + i];
   }
-  block_reduce<SumOp, 3, kDecisionThreads / 64>(acc, red);
-  if (threadIdx.x != 0) return;
-  apply_step_decision(ctl, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp);
+  block_sum_fast<3, kDecisionThreads / 64>(acc, red);
+  if (t != 0) return;
+  apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
+  *ctl = lc;
 }
 
 // ------------------------------------------------------------------------------------------------
