@@ -2052,19 +2052,21 @@ struct MajorSmallArgs {
   double* sc;  // current at sc[0..9), average at sc[32..41)  (pinned host memory: no read-back copy)
 };
 constexpr int kMajorThreads = 1024;
-// rows r = t, t+T, ... of M vec, each added up left to right by one lane (same order as every other SpMV here)
+// M vec for a matrix of <= 8192 nonzeros: all products in parallel into LDS, then every row is added up left to
+// right by one lane (same order as every other SpMV here)
 template <class Epi, int NQ>
 __device__ __forceinline__ void small_rows(int rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                                           const double* __restrict__ val, const double* vec, Epi& e, double (&acc)[NQ])
+                                           const double* __restrict__ val, const double* vec, double* prod, Epi& e,
+                                           double (&acc)[NQ])
 {
-  for (int r = threadIdx.x; r < rows; r += kMajorThreads) {
-    double v = 0.0;
-    for (int k = off[r]; k < off[r + 1]; ++k) v = v + val[k] * vec[idx[k]];
-    e.row(r, v, acc);
-  }
+  const int nnz = off[rows];
+  for (int k = threadIdx.x; k < nnz; k += kMajorThreads) prod[k] = val[k] * vec[idx[k]];
+  __syncthreads();
+  for (int r = threadIdx.x; r < rows; r += kMajorThreads) e.row(r, lds_row_sum(prod, off[r], off[r + 1]), acc);
 }
 __global__ void __launch_bounds__(kMajorThreads) k_major_small(MajorSmallArgs A)
 {
+  extern __shared__ double prod[];  // nnz doubles
   __shared__ double red[4 * kMajorThreads / 64];
   const int t = threadIdx.x;
   const int cur = A.ctl->cur;
@@ -2091,8 +2093,8 @@ __global__ void __launch_bounds__(kMajorThreads) k_major_small(MajorSmallArgs A)
     {
       EvalPrimalEpilogue e{yv, A.dr, A.lo_u, A.hi_u, A.eps_p, A.want_linf ? A.linf_m : nullptr, which ? A.ax_avg : A.ax_cur};
       double acc[3] = {0.0, 0.0, 0.0};
-      small_rows(A.m, A.a_off, A.a_idx, A.a_val, xv, e, acc);
-      block_reduce<SumOp, 3, kMajorThreads / 64>(acc, red);
+      small_rows(A.m, A.a_off, A.a_idx, A.a_val, xv, prod, e, acc);
+      block_sum_fast<3, kMajorThreads / 64>(acc, red);
       if (t == 0) sc[0] = acc[0], sc[1] = acc[1], sc[2] = acc[2];
       __syncthreads();
       if (A.want_linf) {
@@ -2107,8 +2109,8 @@ __global__ void __launch_bounds__(kMajorThreads) k_major_small(MajorSmallArgs A)
       EvalDualEpilogue e{EvalDualCore{xv, A.dc, A.c_u, A.lb_u, A.ub_u, A.eps_d, A.rule_finite, which ? A.rc_avg : A.rc_cur,
                                       A.want_linf ? A.linf_n : nullptr, which ? A.aty_avg : A.aty_cur}};
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      small_rows(A.n, A.at_off, A.at_idx, A.at_val, yv, e, acc);
-      block_reduce<SumOp, 4, kMajorThreads / 64>(acc, red);
+      small_rows(A.n, A.at_off, A.at_idx, A.at_val, yv, prod, e, acc);
+      block_sum_fast<4, kMajorThreads / 64>(acc, red);
       if (t == 0) sc[4] = acc[0], sc[5] = acc[1], sc[6] = acc[2], sc[7] = acc[3];
       __syncthreads();
       if (A.want_linf) {
@@ -2394,7 +2396,13 @@ int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bo
                      ctx->dr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->tmp_m, ctx->tmp_n,
                      ctx->ax_u[PDLPDEV_CURRENT], ctx->ax_u[PDLPDEV_AVERAGE], ctx->aty_u[PDLPDEV_CURRENT],
                      ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal_h};
-    k_major_small<<<1, kMajorThreads, 0, ctx->stream>>>(A);
+    const size_t lds = sizeof(double) * (size_t)std::max<int64_t>(ctx->nnz, 1);
+    static bool configured = false;  // LDS beyond 64 KiB has to be requested once
+    if (!configured) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_major_small, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+      configured = true;
+    }
+    k_major_small<<<1, kMajorThreads, lds, ctx->stream>>>(A);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   } else {
