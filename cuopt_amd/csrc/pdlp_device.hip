@@ -818,16 +818,34 @@ static size_t resident_lds_bytes(int tier)
   const ResidentTier& r = kResidentTiers[tier];
   return sizeof(double) * (size_t)r.T * (7 * r.Q + r.U);
 }
+// hipFuncSetAttribute is per device and must happen before the first launch that asks for > 64 KiB of LDS:
+// one flag per (kernel instantiation, device), taken under a lock (batch solves create contexts from many threads)
+struct PerDeviceOnce {
+  std::mutex m;
+  bool done[64] = {};
+  template <class F>
+  int run(int device, F&& f)
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (device < 0 || device >= 64) return f();
+    if (done[device]) return 0;
+    const int rc = f();
+    if (rc == 0) done[device] = true;
+    return rc;
+  }
+};
 template <int T, int Q, int U>
 static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_ctl* ctl, pdlpdev_ctl* ctl_host,
                            const pdlpdev_step_params& sp, int target_steps)
 {
-  static bool configured = false;  // per instantiation; LDS beyond 64 KiB has to be requested once
-  if (!configured) {
+  static PerDeviceOnce once;  // per instantiation
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  TRY(once.run(device, [&]() -> int {
     HIP_TRY(hipFuncSetAttribute((const void*)k_pdhg_resident<T, Q, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)resident_lds_bytes(tier)));
-    configured = true;
-  }
+    return 0;
+  }));
   k_pdhg_resident<T, Q, U><<<1, T, resident_lds_bytes(tier), s>>>(V, ctl, ctl_host, sp, target_steps, 1 << 14);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -2397,11 +2415,11 @@ int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bo
                      ctx->ax_u[PDLPDEV_CURRENT], ctx->ax_u[PDLPDEV_AVERAGE], ctx->aty_u[PDLPDEV_CURRENT],
                      ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal_h};
     const size_t lds = sizeof(double) * (size_t)std::max<int64_t>(ctx->nnz, 1);
-    static bool configured = false;  // LDS beyond 64 KiB has to be requested once
-    if (!configured) {
+    static PerDeviceOnce once;
+    TRY(once.run(ctx->device, [&]() -> int {
       HIP_TRY(hipFuncSetAttribute((const void*)k_major_small, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-      configured = true;
-    }
+      return 0;
+    }));
     k_major_small<<<1, kMajorThreads, lds, ctx->stream>>>(A);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(ctx->stream));

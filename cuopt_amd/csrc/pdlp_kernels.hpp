@@ -182,6 +182,17 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
   const int base = k0 & ~3;
   if (cnt <= kNnzBlock) {
     constexpr int kPasses = kNnzTile / (4 * kBlock);
+    // extents of the lane's first rows, requested together with the matrix stream: their latency would otherwise sit
+    // between the barrier and the row sums (every workgroup of a mid-size LP is one dependent chain of round trips)
+    constexpr int kPre = 4;
+    int ext0[kPre], ext1[kPre];
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+      int r   = r0 + threadIdx.x + q * kBlock;
+      r       = r < r1 ? r : r1 - 1;
+      ext0[q] = offsets[r];
+      ext1[q] = offsets[r + 1];
+    }
     vec4d a[kPasses];
     vec4i j[kPasses];
 #pragma unroll
@@ -201,8 +212,17 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
       *reinterpret_cast<vec4d*>(&prod[4 * (p * kBlock + threadIdx.x)]) = a[p] * g;
     }
     __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r1; r += kBlock) {
-      const int s = offsets[r] - base, e = offsets[r + 1] - base;
+    int q = 0;
+    for (int r = r0 + threadIdx.x; r < r1; r += kBlock, ++q) {
+      int s, e;
+      switch (q) {  // register arrays want static indices
+        case 0: s = ext0[0], e = ext1[0]; break;
+        case 1: s = ext0[1], e = ext1[1]; break;
+        case 2: s = ext0[2], e = ext1[2]; break;
+        case 3: s = ext0[3], e = ext1[3]; break;
+        default: s = offsets[r], e = offsets[r + 1]; break;
+      }
+      s -= base, e -= base;
       double sum = 0.0;
       if (e - s <= kLongRow) {
         for (int k = s; k < e; ++k) sum = sum + prod[k];
@@ -269,6 +289,33 @@ struct PanelView {
   const double* __restrict__ val;        // permuted values
 };
 
+// products of one chunk [c0, c1) into LDS: N rounds in which every lane owns a nonzero, then the ragged tail
+template <int N>
+__device__ __forceinline__ void panel_products(const PanelView& P, const double* __restrict__ vec, double* prod,
+                                               int c0, int c1)
+{
+  if constexpr (N > 0) {
+    double a[N], x[N];
+    int j[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const int k = c0 + threadIdx.x + u * kPanelThreads;
+      a[u]        = __builtin_nontemporal_load(P.val + k);
+      j[u]        = __builtin_nontemporal_load(P.col + k);
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) x[u] = vec[j[u]];
+#pragma unroll
+    for (int u = 0; u < N; ++u) prod[threadIdx.x + u * kPanelThreads] = a[u] * x[u];
+  }
+  const int k = c0 + threadIdx.x + N * kPanelThreads;
+  if (k < c1) {
+    const double a = __builtin_nontemporal_load(P.val + k);
+    const int j    = __builtin_nontemporal_load(P.col + k);
+    prod[k - c0]   = a * vec[j];
+  }
+}
+
 template <class Epi>
 __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const double* __restrict__ vec,
                                                  Epi& epi, double* __restrict__ partials)
@@ -278,29 +325,55 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
   __shared__ double red[kPanelWaves * (Epi::NQ > 0 ? Epi::NQ : 1)];
   const int w  = blockIdx.x;
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
+  // this panel's tile boundaries and row-pointer bases (S <= 16), fetched once: a scalar load per slab would sit on
+  // the critical path of every tile
+  __shared__ int tile_s[17];
+  __shared__ long long base_s[16];
+  if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
+  if (threadIdx.x < P.S) base_s[threadIdx.x] = P.rp_base[w * P.S + threadIdx.x];
   for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
+  __syncthreads();
+  constexpr int kRowsPer = (kPanelMaxRows + kPanelThreads - 1) / kPanelThreads;
   for (int s = 0; s < P.S; ++s) {
-    const int t0 = P.tile_ptr[w * P.S + s], t1 = P.tile_ptr[w * P.S + s + 1];
-    const uint16_t* __restrict__ rp = P.rowptr + P.rp_base[w * P.S + s];
+    const int t0 = tile_s[s], t1 = tile_s[s + 1];
+    const uint16_t* __restrict__ rp = P.rowptr + base_s[s];
+    // the lane's row extents in this tile, requested before the products so that their latency hides behind them
+    unsigned ext[kRowsPer];
+#pragma unroll
+    for (int q = 0; q < kRowsPer; ++q) {
+      int r  = threadIdx.x + q * kPanelThreads;
+      r      = r < nr ? r : 0;
+      ext[q] = (unsigned)rp[r] | ((unsigned)rp[r + 1] << 16);
+    }
     for (int c0 = t0; c0 < t1; c0 += kPanelChunk) {
       const int c1 = c0 + kPanelChunk < t1 ? c0 + kPanelChunk : t1;
       __syncthreads();
-#pragma unroll 4
-      for (int k = c0 + threadIdx.x; k < c1; k += kPanelThreads) {
-        const double a = __builtin_nontemporal_load(P.val + k);
-        const int j    = __builtin_nontemporal_load(P.col + k);
-        prod[k - c0]   = a * vec[j];
+      // N full rounds (every lane has a nonzero: straight-line code, all loads then all gathers in flight) + a tail
+      switch ((c1 - c0) / kPanelThreads) {
+        case 0: panel_products<0>(P, vec, prod, c0, c1); break;
+        case 1: panel_products<1>(P, vec, prod, c0, c1); break;
+        case 2: panel_products<2>(P, vec, prod, c0, c1); break;
+        case 3: panel_products<3>(P, vec, prod, c0, c1); break;
+        case 4: panel_products<4>(P, vec, prod, c0, c1); break;
+        case 5: panel_products<5>(P, vec, prod, c0, c1); break;
+        case 6: panel_products<6>(P, vec, prod, c0, c1); break;
+        case 7: panel_products<7>(P, vec, prod, c0, c1); break;
+        default: panel_products<8>(P, vec, prod, c0, c1); break;
       }
       __syncthreads();
       const int lo = c0 - t0, hi = c1 - t0;
-      for (int r = threadIdx.x; r < nr; r += kPanelThreads) {
-        int a = rp[r], b = rp[r + 1];
-        a = a > lo ? a : lo;
-        b = b < hi ? b : hi;
-        if (a < b) {
-          double sum = psum[r];
-          for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
-          psum[r] = sum;
+#pragma unroll
+      for (int q = 0; q < kRowsPer; ++q) {
+        const int r = threadIdx.x + q * kPanelThreads;
+        if (r < nr) {
+          int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+          a = a > lo ? a : lo;
+          b = b < hi ? b : hi;
+          if (a < b) {
+            double sum = psum[r];
+            for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+            psum[r] = sum;
+          }
         }
       }
     }

@@ -62,8 +62,10 @@ def highs(p, A):
     return sgn * res.fun + p["objective_offset"]
 
 
+@pytest.mark.parametrize("resident", [True, False], ids=["resident-loop", "multi-launch"])
 @pytest.mark.parametrize("seed", range(12))
-def test_random_lp_against_highs_and_oracle(seed):
+def test_random_lp_against_highs_and_oracle(seed, resident, monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SMALL", "1" if resident else "0")  # both loops see every bound flavour
     p, A = random_lp(seed)
     ref = highs(p, A)
     r = capi.solve(p, method=1, tol=1e-8, iteration_limit=200000)
