@@ -289,95 +289,136 @@ struct PanelView {
   const double* __restrict__ val;        // permuted values
 };
 
-// products of one chunk [c0, c1) into LDS: N rounds in which every lane owns a nonzero, then the ragged tail
-template <int N>
-__device__ __forceinline__ void panel_products(const PanelView& P, const double* __restrict__ vec, double* prod,
-                                               int c0, int c1)
+// ---- the chunks of a panel, one stage ahead ------------------------------------------------------------------------
+// A chunk is <= kPanelChunk consecutive nonzeros of one tile, handled in R = ceil(len / 512) rounds (lane <-> nonzero;
+// only the last round has idle lanes: they re-read the chunk's last nonzero and never store).  The value / column
+// loads and the packed 16-bit row extents of chunk i+1 are requested before the row sums of chunk i, so one of the two
+// dependent memory round trips of a chunk (matrix stream -> gather) always overlaps LDS work of the same workgroup.
+// Stages are straight-line code selected by a switch on R (exact load accounting, no wasted gathers).
+constexpr int kPanelPer     = kPanelChunk / kPanelThreads;                          // rounds per full chunk
+constexpr int kPanelRowsPer = (kPanelMaxRows + kPanelThreads - 1) / kPanelThreads;  // rows per lane
+struct PanelChunk {
+  int s, c0, c1, t0;  // tile (slab) index, nonzero range of the chunk, start of its tile
+  bool valid;
+};
+template <int R>
+__device__ __forceinline__ void panel_load(const PanelView& P, double (&va)[kPanelPer], int (&ja)[kPanelPer], int c0, int c1)
 {
-  if constexpr (N > 0) {
-    double a[N], x[N];
-    int j[N];
 #pragma unroll
-    for (int u = 0; u < N; ++u) {
-      const int k = c0 + threadIdx.x + u * kPanelThreads;
-      a[u]        = __builtin_nontemporal_load(P.val + k);
-      j[u]        = __builtin_nontemporal_load(P.col + k);
-    }
-#pragma unroll
-    for (int u = 0; u < N; ++u) x[u] = vec[j[u]];
-#pragma unroll
-    for (int u = 0; u < N; ++u) prod[threadIdx.x + u * kPanelThreads] = a[u] * x[u];
-  }
-  const int k = c0 + threadIdx.x + N * kPanelThreads;
-  if (k < c1) {
-    const double a = __builtin_nontemporal_load(P.val + k);
-    const int j    = __builtin_nontemporal_load(P.col + k);
-    prod[k - c0]   = a * vec[j];
+  for (int u = 0; u < R; ++u) {
+    int k = c0 + threadIdx.x + u * kPanelThreads;
+    if (u == R - 1) k = k < c1 ? k : c1 - 1;
+    va[u] = __builtin_nontemporal_load(P.val + k);
+    ja[u] = __builtin_nontemporal_load(P.col + k);
   }
 }
+template <int R>
+__device__ __forceinline__ void panel_products(const double* __restrict__ vec, double* prod, const double (&va)[kPanelPer],
+                                               const int (&ja)[kPanelPer], int len)
+{
+  double x[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) x[u] = vec[ja[u]];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int i = threadIdx.x + u * kPanelThreads;
+    if (u < R - 1 || i < len) prod[i] = va[u] * x[u];
+  }
+}
+#define PANEL_DISPATCH(rounds, CALL) \
+  switch (rounds) {                   \
+    case 1: CALL(1); break;           \
+    case 2: CALL(2); break;           \
+    case 3: CALL(3); break;           \
+    case 4: CALL(4); break;           \
+    case 5: CALL(5); break;           \
+    case 6: CALL(6); break;           \
+    case 7: CALL(7); break;           \
+    default: CALL(8); break;          \
+  }
 
 template <class Epi>
 __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const double* __restrict__ vec,
                                                  Epi& epi, double* __restrict__ partials)
 {
+  static_assert(kPanelPer == 8, "PANEL_DISPATCH enumerates 1..8 rounds");
   __shared__ double prod[kPanelChunk];
   __shared__ double psum[kPanelMaxRows];
   __shared__ double red[kPanelWaves * (Epi::NQ > 0 ? Epi::NQ : 1)];
+  __shared__ int tile_s[17];        // this panel's tile boundaries (S <= 16) and row-pointer bases, fetched once
+  __shared__ long long base_s[16];
   const int w  = blockIdx.x;
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
-  // this panel's tile boundaries and row-pointer bases (S <= 16), fetched once: a scalar load per slab would sit on
-  // the critical path of every tile
-  __shared__ int tile_s[17];
-  __shared__ long long base_s[16];
   if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
   if (threadIdx.x < P.S) base_s[threadIdx.x] = P.rp_base[w * P.S + threadIdx.x];
   for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
   __syncthreads();
-  constexpr int kRowsPer = (kPanelMaxRows + kPanelThreads - 1) / kPanelThreads;
-  for (int s = 0; s < P.S; ++s) {
-    const int t0 = tile_s[s], t1 = tile_s[s + 1];
-    const uint16_t* __restrict__ rp = P.rowptr + base_s[s];
-    // the lane's row extents in this tile, requested before the products so that their latency hides behind them
-    unsigned ext[kRowsPer];
-#pragma unroll
-    for (int q = 0; q < kRowsPer; ++q) {
-      int r  = threadIdx.x + q * kPanelThreads;
-      r      = r < nr ? r : 0;
-      ext[q] = (unsigned)rp[r] | ((unsigned)rp[r + 1] << 16);
+  auto advance = [&](PanelChunk c) -> PanelChunk {
+    if (c.valid && c.c1 < tile_s[c.s + 1]) {  // next chunk of the same tile
+      c.c0 = c.c1;
+      c.c1 = c.c0 + kPanelChunk < tile_s[c.s + 1] ? c.c0 + kPanelChunk : tile_s[c.s + 1];
+      return c;
     }
-    for (int c0 = t0; c0 < t1; c0 += kPanelChunk) {
-      const int c1 = c0 + kPanelChunk < t1 ? c0 + kPanelChunk : t1;
-      __syncthreads();
-      // N full rounds (every lane has a nonzero: straight-line code, all loads then all gathers in flight) + a tail
-      switch ((c1 - c0) / kPanelThreads) {
-        case 0: panel_products<0>(P, vec, prod, c0, c1); break;
-        case 1: panel_products<1>(P, vec, prod, c0, c1); break;
-        case 2: panel_products<2>(P, vec, prod, c0, c1); break;
-        case 3: panel_products<3>(P, vec, prod, c0, c1); break;
-        case 4: panel_products<4>(P, vec, prod, c0, c1); break;
-        case 5: panel_products<5>(P, vec, prod, c0, c1); break;
-        case 6: panel_products<6>(P, vec, prod, c0, c1); break;
-        case 7: panel_products<7>(P, vec, prod, c0, c1); break;
-        default: panel_products<8>(P, vec, prod, c0, c1); break;
-      }
-      __syncthreads();
-      const int lo = c0 - t0, hi = c1 - t0;
+    int s = c.s + 1;
+    while (s < P.S && tile_s[s + 1] == tile_s[s]) ++s;  // empty tiles contribute nothing
+    c.valid = s < P.S;
+    c.s     = s;
+    if (c.valid) {
+      c.t0 = c.c0 = tile_s[s];
+      c.c1 = c.c0 + kPanelChunk < tile_s[s + 1] ? c.c0 + kPanelChunk : tile_s[s + 1];
+    }
+    return c;
+  };
+  double va[kPanelPer];
+  int ja[kPanelPer];
+  unsigned ext_next[kPanelRowsPer], ext[kPanelRowsPer];  // (begin | end << 16) of the lane's rows in the chunk's tile
+  // (macros, not lambdas: the register arrays must stay visible to scalar replacement)
+#define PANEL_ROUNDS(c) (((c).c1 - (c).c0 + kPanelThreads - 1) / kPanelThreads)
+#define PANEL_CALL_LOAD(R) panel_load<R>(P, va, ja, nxt.c0, nxt.c1)
+#define PANEL_CALL_PRODUCTS(R) panel_products<R>(vec, prod, va, ja, cur.c1 - cur.c0)
+#define PANEL_REQUEST(c)                                                         \
+  if ((c).valid) {                                                               \
+    PANEL_DISPATCH(PANEL_ROUNDS(c), PANEL_CALL_LOAD)                             \
+    const uint16_t* __restrict__ rp_ = P.rowptr + base_s[(c).s];                 \
+    _Pragma("unroll") for (int q = 0; q < kPanelRowsPer; ++q) {                  \
+      int r_      = threadIdx.x + q * kPanelThreads;                             \
+      r_          = r_ < nr ? r_ : 0;                                            \
+      ext_next[q] = (unsigned)rp_[r_] | ((unsigned)rp_[r_ + 1] << 16);           \
+    }                                                                            \
+  }
+  PanelChunk none{-1, 0, 0, 0, false};
+  PanelChunk nxt = advance(none);
+  PANEL_REQUEST(nxt)
+  PanelChunk cur = nxt;
+  while (cur.valid) {
+    __syncthreads();  // the previous chunk's row sums are done with prod
+    PANEL_DISPATCH(PANEL_ROUNDS(cur), PANEL_CALL_PRODUCTS)
 #pragma unroll
-      for (int q = 0; q < kRowsPer; ++q) {
-        const int r = threadIdx.x + q * kPanelThreads;
-        if (r < nr) {
-          int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
-          a = a > lo ? a : lo;
-          b = b < hi ? b : hi;
-          if (a < b) {
-            double sum = psum[r];
-            for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
-            psum[r] = sum;
-          }
+    for (int q = 0; q < kPanelRowsPer; ++q) ext[q] = ext_next[q];
+    const int lo = cur.c0 - cur.t0, hi = cur.c1 - cur.t0;
+    nxt = advance(cur);
+    PANEL_REQUEST(nxt)  // in flight during the row sums below
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPanelRowsPer; ++q) {
+      const int r = threadIdx.x + q * kPanelThreads;
+      if (r < nr) {
+        int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+        a = a > lo ? a : lo;
+        b = b < hi ? b : hi;
+        if (a < b) {
+          double sum = psum[r];
+          for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+          psum[r] = sum;
         }
       }
     }
+    cur = nxt;
   }
+#undef PANEL_REQUEST
+#undef PANEL_CALL_PRODUCTS
+#undef PANEL_CALL_LOAD
+#undef PANEL_ROUNDS
   __syncthreads();
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
@@ -391,6 +432,7 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
     }
   }
 }
+#undef PANEL_DISPATCH
 
 // ---- element-wise rules of the reference (LP/utils.cuh) -----------------------------------------
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
