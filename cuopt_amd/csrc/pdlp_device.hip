@@ -241,8 +241,13 @@ static int dev_alloc(pdlpdev_ctx* c, T** p, size_t count)
     c->arena_used += need;
     return 0;
   }
+  static const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipMalloc((void**)p, bytes));
+  const auto t1 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
+  if (timing && std::chrono::duration<double>(t1 - t0).count() > 1e-3)  // only the surprising ones
+    fprintf(stderr, "[cuopt_amd setup]     hipMalloc %10zu B: %.2f ms\n", bytes, 1e3 * std::chrono::duration<double>(t1 - t0).count());
   c->allocs.push_back(*p);
   return 0;
 }
@@ -1469,8 +1474,8 @@ struct PanelHost {
   std::vector<int32_t> row0, tile_ptr;
   std::vector<int64_t> rp_base;
   // the three big arrays are deliberately NOT zero-filled (every entry is written by pass 2)
-  std::unique_ptr<int32_t[]> perm, col;
-  std::unique_ptr<uint16_t[]> rowptr;
+  cuopt_amd::PoolArray<int32_t> perm, col;
+  cuopt_amd::PoolArray<uint16_t> rowptr;
   size_t nnz = 0, rowptr_size = 0;
 };
 static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
@@ -1519,8 +1524,8 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   P.tile_ptr[(size_t)W * S] = (int32_t)pos;
   // pass 2: placement + per-tile row pointers
   P.nnz = (size_t)nnz, P.rowptr_size = (size_t)S * ((size_t)rows + W);
-  P.perm.reset(new int32_t[P.nnz]), P.col.reset(new int32_t[P.nnz]);
-  P.rowptr.reset(new uint16_t[P.rowptr_size]);
+  P.perm.reset(P.nnz), P.col.reset(P.nnz);
+  P.rowptr.reset(P.rowptr_size);
   P.rp_base.resize((size_t)W * S);
   cuopt_amd::parallel_tasks(W, [&](int w) {
     const int32_t a = P.row0[w], b = P.row0[w + 1], nr = b - a;
@@ -1736,6 +1741,7 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
       lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
       lap("upload panels At");
+      HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
     }
   }
   {
@@ -1752,14 +1758,18 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
   TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + 8));
+  lap("partial buffers");
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
   HIP_TRY(hipGetLastError());
+  lap("fill D");
   TRY(sync_panel_values(ctx));
+  lap("panel values (permute)");
   {
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
     if (!mode_env || std::string(mode_env) == "auto") {
       TRY(pick_layout(ctx, &ctx->pa, m, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->tmp_n, ctx->tmp_m, "A"));
+      lap("layout autotune A");
       TRY(pick_layout(ctx, &ctx->pat, n, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->tmp_m, ctx->tmp_n, "A^T"));
       lap("layout autotune");
     }

@@ -701,8 +701,8 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   const int32_t* idx  = lp->indices + k0;
   const double* val   = lp->values + k0;
   std::vector<int32_t> t_off(n + 1);
-  std::unique_ptr<int32_t[]> t_idx(new int32_t[std::max<int64_t>(nnz_l, 1)]);  // no zero fill of 120 MB
-  std::unique_ptr<double[]> t_val(new double[std::max<int64_t>(nnz_l, 1)]);
+  cuopt_amd::PoolArray<int32_t> t_idx((size_t)std::max<int64_t>(nnz_l, 1));  // no zero fill of 120 MB, pooled
+  cuopt_amd::PoolArray<double> t_val((size_t)std::max<int64_t>(nnz_l, 1));
   lap("partition + slice");
   cuoptamd_csr_transpose(ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get());
   lap("host transpose");
