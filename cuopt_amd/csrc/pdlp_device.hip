@@ -1463,6 +1463,11 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
     rb.push_back(end);
     start = end;
   }
+  // second half: the nonzero position where each block starts (off[rb[b]]), so that a workgroup learns its row range
+  // AND its nonzero range in one round trip instead of two dependent ones
+  const size_t nb1 = rb.size();
+  rb.resize(2 * nb1);
+  for (size_t b = 0; b < nb1; ++b) rb[nb1 + b] = off[rb[b]];
   return rb;
 }
 
@@ -1700,7 +1705,7 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
   TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
   lap("alloc + upload CSR x2");
   std::vector<int32_t> rba = build_row_blocks(m, a_offsets), rbt = build_row_blocks(n, at_offsets);
-  ctx->a_nb = (int)rba.size() - 1, ctx->at_nb = (int)rbt.size() - 1;
+  ctx->a_nb = (int)rba.size() / 2 - 1, ctx->at_nb = (int)rbt.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
   TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
   TRY(upload_f64(ctx, &ctx->c, c, n)); TRY(upload_f64(ctx, &ctx->c_u, c, n));

@@ -169,7 +169,7 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
   const int b = xcd_remap(blockIdx.x, nb);
   if (b >= nb) return;
   const int r0 = row_blocks[b], r1 = row_blocks[b + 1];
-  const int k0 = offsets[r0], k1 = offsets[r1];
+  const int k0 = row_blocks[nb + 1 + b], k1 = row_blocks[nb + 2 + b];  // = offsets[r0], offsets[r1] (build_row_blocks)
   const int cnt = k1 - k0;
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
