@@ -1664,6 +1664,16 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
                    const int32_t* at_indices, const double* at_values, const double* c,
                    const double* lo, const double* hi, const double* lb, const double* ub)
 {
+  return pdlpdev_create_overlapped(out, device, m, n, a_offsets, a_indices, a_values, at_offsets, at_indices, at_values,
+                                   nullptr, nullptr, c, lo, hi, lb, ub);
+}
+
+int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
+                              const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
+                              const int32_t* at_indices, const double* at_values,
+                              void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
+                              const double* hi, const double* lb, const double* ub)
+{
   if (!out || m < 0 || n < 0 || !a_offsets || !at_offsets) return fail(-1, "pdlpdev_create: bad argument");
   if (pdlpdev_device_count() <= device)
     return fail(-5, "pdlpdev_create: no HIP device %d visible (this solver has no CPU fallback)", device);
@@ -1696,18 +1706,15 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
     ctx->ctl_h = (pdlpdev_ctl*)(ctx->scal_h + kScalars);
   }
   const size_t nnz = (size_t)ctx->nnz;
-  if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
+  // Everything that needs A only comes first; the caller may still be transposing on other threads (A^T is not
+  // touched before transpose_ready returns).
   TRY(upload_i32(ctx, &ctx->a_off, a_offsets, (size_t)m + 1));
   TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz, 8));  // +8: the vector loads of the stream kernel may over-read
   TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz, 8));
-  TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
-  TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
-  TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
-  lap("alloc + upload CSR x2");
-  std::vector<int32_t> rba = build_row_blocks(m, a_offsets), rbt = build_row_blocks(n, at_offsets);
-  ctx->a_nb = (int)rba.size() / 2 - 1, ctx->at_nb = (int)rbt.size() / 2 - 1;
+  lap("alloc + upload A");
+  std::vector<int32_t> rba = build_row_blocks(m, a_offsets);
+  ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
-  TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
   TRY(upload_f64(ctx, &ctx->c, c, n)); TRY(upload_f64(ctx, &ctx->c_u, c, n));
   TRY(upload_f64(ctx, &ctx->lb, lb, n)); TRY(upload_f64(ctx, &ctx->lb_u, lb, n));
   TRY(upload_f64(ctx, &ctx->ub, ub, n)); TRY(upload_f64(ctx, &ctx->ub_u, ub, n));
@@ -1735,18 +1742,31 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
     // 1.33 MiB of the gathered vector per slab: measured optimum on the 1e6 x 1e6 random LP (6 slabs: 71 us per
     // SpMV; 8 slabs of 1 MiB: 74 us; 4 slabs of 2 MiB: 75 us) -- fewer tiles per panel against L2 capacity
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
+    const bool force = mode == "panel";
+    lap("row blocks + vectors");
     if (mode != "stream") {
-      const bool force = mode == "panel";
-      lap("row blocks + vectors");
       PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force);
       lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha));
       lap("upload panels A");
+      HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
+    }
+    if (transpose_ready) transpose_ready(user);
+    lap("wait for the transpose");
+    if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
+    TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
+    TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
+    TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
+    std::vector<int32_t> rbt = build_row_blocks(n, at_offsets);
+    ctx->at_nb = (int)rbt.size() / 2 - 1;
+    TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
+    lap("upload A^T");
+    if (mode != "stream") {
       PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force);
       lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
       lap("upload panels At");
-      HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
   }
   {

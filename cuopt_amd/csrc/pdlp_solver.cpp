@@ -704,10 +704,25 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   cuopt_amd::PoolArray<int32_t> t_idx((size_t)std::max<int64_t>(nnz_l, 1));  // no zero fill of 120 MB, pooled
   cuopt_amd::PoolArray<double> t_val((size_t)std::max<int64_t>(nnz_l, 1));
   lap("partition + slice");
-  cuoptamd_csr_transpose(ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get());
-  lap("host transpose");
-  DEV(pdlpdev_create(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(),
-                     t_val.get(), c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin, lp->lb, lp->ub));
+  // The transpose (host threads) runs while the device layer uploads A and builds A's panels; it is joined by the
+  // callback right before A^T is needed, and by the guard on every other path.
+  struct TransposeJob {
+    std::thread worker;
+    static void wait(void* self) { static_cast<TransposeJob*>(self)->join(); }
+    void join() { if (worker.joinable()) worker.join(); }
+    ~TransposeJob() { join(); }
+  } job;
+  {
+    const int32_t* off_p = off.data();
+    int32_t* t_off_p     = t_off.data();
+    int32_t* t_idx_p     = t_idx.get();
+    double* t_val_p      = t_val.get();
+    job.worker = std::thread([=] { cuoptamd_csr_transpose(ml, n, off_p, idx, val, t_off_p, t_idx_p, t_val_p); });
+  }
+  DEV(pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
+                                &TransposeJob::wait, &job, c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin,
+                                lp->lb, lp->ub));
+  job.join();
   lap("pdlpdev_create (upload+panels)");
   if (comm_id) DEV(pdlpdev_comm_init(s->dev, rank, world, comm_id));
   else if (world > 1) return fail(-1, "cuoptamd_solver_create: world > 1 needs a communicator id");

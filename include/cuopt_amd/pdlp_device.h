@@ -140,6 +140,15 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
                    const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
                    const int32_t* at_indices, const double* at_values, const double* c,
                    const double* lo, const double* hi, const double* lb, const double* ub);
+/* Same, for a caller that is still building A^T on other threads: the three at_* arrays must have their final
+ * addresses, but their CONTENTS are read only after transpose_ready(user) has returned (NULL: they are ready now).
+ * Everything that needs A alone (upload, row blocks, panels of A, all vectors) happens before that call; the callback
+ * is invoked exactly once unless the function fails earlier, so a caller that started a thread joins it on every path. */
+int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
+                              const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
+                              const int32_t* at_indices, const double* at_values,
+                              void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
+                              const double* hi, const double* lb, const double* ub);
 void pdlpdev_destroy(pdlpdev_ctx* ctx);
 
 /* ---- multi-GPU (row-block sharding, one context per rank) ----------------------------------- */
