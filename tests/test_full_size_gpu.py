@@ -1,0 +1,73 @@
+"""GPU: BASELINE config 3 at full size (1e6 x 1e6, 1e7 nonzeros) through size-independent properties:
+ * the SpMV of BOTH layouts against the C oracle's CSR SpMV on the same vectors, bit for bit, for A and A^T (rows
+   of A hold 10 nonzeros, rows of A^T a few dozen at most: one left-to-right sum each, no contraction on either side);
+ * <A x, y> == <x, A^T y> (the explicit transpose is consistent with A);
+ * a full cuOptSolve to the default 1e-4: status, objective against the optimum known by construction
+   (c.x* = b.y*), and the returned x, y re-verified ON THE HOST against the reference's termination
+   inequalities (termination_strategy.cu:116-250) with scipy;
+ * the same iteration count from both SpMV layouts over a fixed budget (same decisions)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cuopt_amd import capi, synthetic
+from oracle import orcbind
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    return synthetic.generate(**synthetic.CONFIGS["c3"])
+
+
+def test_spmv_of_both_layouts_is_bit_exact_at_full_size(c3, monkeypatch):
+    p = c3
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = capi.csr_transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    ref_ax = orcbind.spmv(p["offsets"], p["indices"], p["values"], x)
+    ref_aty = orcbind.spmv(to, ti, tv, y)
+    assert abs(ref_ax @ y - x @ ref_aty) <= 1e-9 * (np.linalg.norm(ref_ax) * np.linalg.norm(y))
+    for layout in ("stream", "panel"):
+        monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
+        dev = capi.Device(p)
+        assert dev.layout()["A"]["panels"] == (layout == "panel")
+        np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), ref_ax)
+        np.testing.assert_array_equal(dev.spmv(y, True, p["n"]), ref_aty)
+        dev.close()
+
+
+def test_solve_to_default_tolerance_and_host_verification(c3):
+    p = c3
+    r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
+    assert r["status"] == "Optimal"
+    known = p["objective_star"]
+    assert abs(r["objective"] - known) <= 2e-4 * (1.0 + abs(known))
+    A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+    x, y = r["x"], r["y"]
+    assert float(p["c"] @ x) == pytest.approx(r["primal_objective"], rel=1e-9)
+    ax = A @ x
+    viol = np.maximum(np.maximum(p["lo"] - ax, ax - p["hi"]), 0.0)
+    bcomb = np.maximum(np.where(np.isfinite(p["lo"]), np.abs(p["lo"]), 0), np.where(np.isfinite(p["hi"]), np.abs(p["hi"]), 0))
+    assert np.linalg.norm(viol) == pytest.approx(r["l2_primal_residual"], rel=1e-6, abs=1e-9)
+    assert np.linalg.norm(viol) <= 1e-4 + 1e-4 * np.linalg.norm(bcomb)
+    assert np.all(x >= p["lb"]) and np.all(x <= p["ub"])
+    g = p["c"] - A.T @ y
+    bv = np.where(g > 0, p["lb"], p["ub"])
+    rc = np.where((g == 0) | np.isfinite(bv), g, 0.0)
+    assert np.linalg.norm(g - rc) <= 1e-4 + 1e-4 * np.linalg.norm(p["c"])
+    assert r["gap"] <= 1e-4 + 1e-4 * (abs(r["primal_objective"]) + abs(r["dual_objective"]))
+
+
+def test_both_layouts_take_the_same_decisions(c3, monkeypatch):
+    got = {}
+    for layout in ("stream", "panel"):
+        monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
+        s = capi.Solver(c3, tol=0.0, iteration_limit=120)
+        r = s.advance()
+        got[layout] = (r["steps_taken"], r["attempted_steps"], r["num_restarts"], r["primal_objective"], r["step_size"])
+        s.close()
+    assert got["stream"][:3] == got["panel"][:3]
+    assert got["stream"][3] == pytest.approx(got["panel"][3], rel=1e-9)
+    assert got["stream"][4] == pytest.approx(got["panel"][4], rel=1e-9)
