@@ -1972,6 +1972,20 @@ static int reduce_vec(pdlpdev_ctx* ctx, int mode, int64_t n, const double* a, co
   return 0;
 }
 
+// max over the ranks of one host scalar (identity without a communicator): lets every rank of a sharded solve
+// take the same wall-clock decision (time limit), which they must -- the collectives have to match up
+int pdlpdev_agree_max(pdlpdev_ctx* ctx, double* value)
+{
+  if (!ctx->comm) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(ctx->scal + 60, value, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TRY(allreduce(ctx, ctx->scal + 60, 1, rccl::kMax));
+  HIP_TRY(hipMemcpyAsync(ctx->scal_h + 60, ctx->scal + 60, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *value = ctx->scal_h[60];
+  return 0;
+}
+
 int pdlpdev_init_norms(pdlpdev_ctx* ctx, double out[3])
 {
   HIP_TRY(hipSetDevice(ctx->device));

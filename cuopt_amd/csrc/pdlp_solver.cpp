@@ -355,7 +355,9 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
   if (s->total_iterations % 1000 == 0) log_iteration(s, s->conv_current);  // pdlp.cu:798
   if (!done) {  // check_limits, pdlp.cu:264-331 (time first, then iterations)
     const double tl = s->S.time_limit;
-    if (std::isfinite(tl) && seconds_since(s->solve_start) * 1000.0 >= tl * 1000.0)
+    double elapsed  = std::isfinite(tl) ? seconds_since(s->solve_start) : 0.0;
+    if (std::isfinite(tl) && s->world > 1) DEV(pdlpdev_agree_max(dev, &elapsed));  // every rank must stop together
+    if (std::isfinite(tl) && elapsed * 1000.0 >= tl * 1000.0)
       done = true, status = kTimeLimit, which = PDLPDEV_CURRENT;
     else if (s->total_iterations - s->iteration_offset >= s->S.iteration_limit)  // internal_solver_iterations_
       done = true, status = kIterationLimit, which = PDLPDEV_CURRENT;

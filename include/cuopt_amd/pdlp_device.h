@@ -176,6 +176,8 @@ int pdlpdev_scale_problem(pdlpdev_ctx* ctx);
 /* out[0] = max |A_ij| ; out[1] = sum c_j^2 ; out[2] = sum bcomb_i^2 of the problem AS IT IS NOW
  * (scaled or not), bcomb = combine_finite_abs_bounds(lo, hi) (utils.cuh:139-163). */
 int pdlpdev_init_norms(pdlpdev_ctx* ctx, double out[3]);
+/* *value <- max over the ranks of *value (no-op on an unsharded solver): wall-clock decisions of a sharded solve */
+int pdlpdev_agree_max(pdlpdev_ctx* ctx, double* value);
 /* out[0] = sum c_j^2, out[1] = sum bcomb_i^2 of the scaled problem (unscaled != 0: of the user's problem) */
 int pdlpdev_weight_norms(pdlpdev_ctx* ctx, int unscaled, double out[2]);
 /* Re-solve support (the MIP heuristics' call pattern, relaxed_lp.cu:53-175): replaces the variable / constraint bounds

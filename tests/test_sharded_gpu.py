@@ -91,3 +91,16 @@ def test_sharded_unbalanced_rows():
     b = run_sharded(p, 3, tol=1e-6)[0][0]
     assert a["status_name"] == b["status_name"]
     assert b["primal_objective"] == pytest.approx(a["primal_objective"], abs=2e-5 * (1 + abs(a["primal_objective"])))
+
+
+def test_sharded_ranks_stop_together_on_a_time_limit():
+    """wall-clock decisions are agreed across ranks (max of the elapsed times), otherwise one rank would leave while
+    the others wait in the next all-reduce"""
+    p = synthetic.generate(6000, 5000, 8, seed=63)
+    out = run_sharded(p, 4, tol=0.0, time_limit=0.05, iteration_limit=10 ** 8)
+    first = out[0][0]
+    assert first["status_name"] == "TimeLimit" and first["steps_taken"] > 0
+    for r, x, _, _ in out:
+        assert (r["status_name"], r["steps_taken"], r["attempted_steps"]) == (first["status_name"], first["steps_taken"],
+                                                                              first["attempted_steps"])
+        np.testing.assert_array_equal(x, out[0][1])
