@@ -152,7 +152,11 @@ def main():
                     per_kernel_gbs={k: round(bytes_alg[k] / (kernels[k] * 1e-3) / 1e9, 1) for k in bytes_alg},
                     iteration_fused_floor_bytes=synthetic.iteration_bytes_min(m, n, nnz),
                     iteration_frac_of_peak=round(synthetic.iteration_bytes_min(m, n, nnz) * its_per_s / 1e9
-                                                 / HBM_PEAK_GBS / max(world, 1), 4))
+                                                 / HBM_PEAK_GBS / max(world, 1), 4),
+                    traffic_source=None if traffic is None else
+                    "profiles/r01_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this command (2*FETCH+WRITE, "
+                    "KiB->B), taken with 1 MiB slabs; the final 1.33 MiB-slab kernel has the same byte streams "
+                    "(L2 counters: profiles/r01_pmc_c3_l2_final.txt)" % args.workload)
     solver.close()
 
     # ---- run to the default 1e-4 termination: wall clock incl. setup -----------------------------------
