@@ -582,15 +582,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.absolute_dual_tolerance = s->tol[0], st.relative_dual_tolerance = s->tol[1];
     st.absolute_primal_tolerance = s->tol[2], st.relative_primal_tolerance = s->tol[3];
     st.absolute_gap_tolerance = s->tol[4], st.relative_gap_tolerance = s->tol[5];
-    if (s->method != CUOPT_METHOD_PDLP && p->values.size() <= 100000) {
-      // The reference's Concurrent (default) / DualSimplex methods return the simplex VERTEX on small LPs (the CPU
-      // simplex wins the race there: c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings).  This library
-      // has one engine, so such requests run PDLP to simplex-grade tolerances (<= 1e-8) when the LP is small
-      // (<= 1e5 nonzeros, microseconds per iteration); large LPs keep the user's tolerances (PDLP wins the race).
-      double* tols[6] = {&st.absolute_dual_tolerance,   &st.relative_dual_tolerance, &st.absolute_primal_tolerance,
-                         &st.relative_primal_tolerance, &st.absolute_gap_tolerance,  &st.relative_gap_tolerance};
-      for (double* t : tols) *t = std::min(*t, 1e-8);
-    }
+    const bool simplex_grade = s->method != CUOPT_METHOD_PDLP && p->values.size() <= 100000;
     st.iteration_limit         = s->iteration_limit;
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
@@ -609,6 +601,24 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
                    p->objective_offset};
     // CUOPT_METHOD: this library has one engine.  Concurrent (default) and DualSimplex requests are
     // served by PDLP as well (documented in INTEGRATION.md); the termination semantics are PDLP's.
+    // The reference's Concurrent (default) / DualSimplex methods return the simplex VERTEX on small LPs (the CPU
+    // simplex wins the race there: c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings).  This library has
+    // one engine, so such requests first run PDLP to simplex-grade tolerances (<= 1e-8) when the LP is small
+    // (<= 1e5 nonzeros, microseconds per iteration), under a bounded budget: PDLP can stall at 1e-8 on small degenerate
+    // LPs (the primal weight of pdlp_restart_strategy.cu:684-750 collapses, e.g. datasets/mip/minrep_inf.mps), and
+    // with the default iteration limit (INT_MAX) that would never return.  If the budget runs out, the same solver
+    // object is reset (cuoptamd_solver_reset: scaling and matrices are kept) and the LP is solved at the tolerances
+    // and limits the user asked for.  Large LPs keep the user's tolerances from the start (PDLP wins the race).
+    const cuoptamd_settings st_user = st;
+    constexpr int32_t kSimplexGradeBudget = 50000;
+    bool budgeted = false;
+    if (simplex_grade) {
+      double* tols[6] = {&st.absolute_dual_tolerance,   &st.relative_dual_tolerance, &st.absolute_primal_tolerance,
+                         &st.relative_primal_tolerance, &st.absolute_gap_tolerance,  &st.relative_gap_tolerance};
+      bool tighter = false;
+      for (double* t : tols) tighter = tighter || *t > 1e-8, *t = std::min(*t, 1e-8);
+      if (tighter && st.iteration_limit > kSimplexGradeBudget) st.iteration_limit = kSimplexGradeBudget, budgeted = true;
+    }
     cuoptamd_solver* solver = nullptr;
     int rc = cuoptamd_solver_create(&solver, &lp, &hyper, &st, nullptr, nullptr, 0, 0, 1, nullptr);
     if (rc != 0) {
@@ -619,11 +629,18 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     }
     cuoptamd_result res{};
     rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+    double first_attempt_seconds = 0.0;
+    if (rc == 0 && budgeted && res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT) {
+      first_attempt_seconds = res.setup_seconds + res.loop_seconds;
+      rc = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_user, nullptr, nullptr);
+      if (rc == 0) rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+    }
     if (rc != 0) {
       std::string msg = cuoptamd_last_error();
       cuoptamd_solver_destroy(solver);
       return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
     }
+    res.setup_seconds += first_attempt_seconds;
     sol->stats              = res;
     sol->termination_status = res.status;
     sol->objective          = res.primal_objective;  // solver_solution.cu:307-310

@@ -53,7 +53,9 @@ def problem_entry(path, relax=True, pinned=None, source=None):
         d["pinned_source"] = source
     orc = {}
     for tol in (1e-4, 1e-8):
-        s = orcbind.solve(p, tol=tol, num_threads=1)
+        # bounded: PDLP (reference rule, pdlp_restart_strategy.cu:684-750) can stall at 1e-8 on tiny degenerate LPs
+        # (minrep_inf: the primal weight collapses); the recorded status says so
+        s = orcbind.solve(p, tol=tol, num_threads=1, iteration_limit=200000)
         orc["%g" % tol] = {k: s[k] for k in ("status", "steps_taken", "attempted_steps",
                                              "primal_objective", "dual_objective", "gap",
                                              "l2_primal_residual", "l2_dual_residual",
@@ -65,24 +67,43 @@ def problem_entry(path, relax=True, pinned=None, source=None):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only_names = set(filter(None, os.environ.get("GOLDEN_ONLY", "").split(",")))
     lp = os.path.join(REF, "linear_programming")
     mip = os.path.join(REF, "mip")
-    problems = {
-        "afiro": problem_entry(os.path.join(lp, "afiro_original.mps"), pinned=-464.7531,
-                               source="python/cuopt/cuopt/tests/linear_programming/test_lp_solver.py:119; "
-                                      "cpp/tests/linear_programming/pdlp_test.cu:58-84"),
-        "good-max": problem_entry(os.path.join(lp, "good-max.mps"), pinned=17.0,
-                                  source="cpp/tests/linear_programming/pdlp_test.cu:909-925"),
-        "max_offset": problem_entry(os.path.join(lp, "max_offset.mps"), pinned=0.0,
-                                    source="cpp/tests/linear_programming/pdlp_test.cu:927-943"),
-        "good-mps-1": problem_entry(os.path.join(lp, "good-mps-1.mps")),
-        "lp_model_with_var_bounds": problem_entry(os.path.join(lp, "lp_model_with_var_bounds.mps")),
-        "mip-sample-relaxation": problem_entry(os.path.join(mip, "sample.mps")),
-        "mip-bb_optimality-relaxation": problem_entry(os.path.join(mip, "bb_optimality.mps")),
+    specs = [
+        ("afiro", os.path.join(lp, "afiro_original.mps"),
+         dict(pinned=-464.7531, source="python/cuopt/cuopt/tests/linear_programming/test_lp_solver.py:119; "
+                                       "cpp/tests/linear_programming/pdlp_test.cu:58-84")),
+        ("good-max", os.path.join(lp, "good-max.mps"),
+         dict(pinned=17.0, source="cpp/tests/linear_programming/pdlp_test.cu:909-925")),
+        ("max_offset", os.path.join(lp, "max_offset.mps"),
+         dict(pinned=0.0, source="cpp/tests/linear_programming/pdlp_test.cu:927-943")),
+        ("good-mps-1", os.path.join(lp, "good-mps-1.mps"), {}),
+        ("lp_model_with_var_bounds", os.path.join(lp, "lp_model_with_var_bounds.mps"), {}),
+        ("mip-sample-relaxation", os.path.join(mip, "sample.mps"), {}),
+        ("mip-bb_optimality-relaxation", os.path.join(mip, "bb_optimality.mps"), {}),
         # BASELINE config 5 inputs (LP relaxations of datasets/mip; integrality dropped by the tests)
-        "mip-50v-10-free-bound-relaxation": problem_entry(os.path.join(mip, "50v-10-free-bound.mps")),
-        "mip-neos5-free-bound-relaxation": problem_entry(os.path.join(mip, "neos5-free-bound.mps")),
-    }
+        ("mip-50v-10-free-bound-relaxation", os.path.join(mip, "50v-10-free-bound.mps"), {}),
+        ("mip-neos5-free-bound-relaxation", os.path.join(mip, "neos5-free-bound.mps"), {}),
+        ("mip-sudoku-relaxation", os.path.join(mip, "sudoku.mps"), {}),
+        # the reference's dual simplex needs ~5 minutes on this degenerate relaxation (6347 pivots)
+        ("mip-cod105_max-relaxation", os.path.join(mip, "cod105_max.mps"), {}),
+        # small LP-shaped fixtures of the MIP tests (cpp/tests/mip/empty_fixed_problems_test.cu:65,
+        # termination_test.cu:68, feasibility_jump_tests.cu:273): fixed variables, a trivial row, a tiny relaxation
+        ("mip-fixed-problem-relaxation", os.path.join(mip, "fixed-problem.mps"), {}),
+        ("mip-trivial-presolve-optimality-relaxation", os.path.join(mip, "trivial-presolve-optimality.mps"), {}),
+        ("mip-minrep_inf-relaxation", os.path.join(mip, "minrep_inf.mps"), {}),
+    ]
+    # GOLDEN_ONLY=name1,name2: regenerate these entries only and keep the rest of problems.json as it is
+    problems = json.load(open(os.path.join(OUT, "problems.json"))) if only_names else {}
+    for name, path, kw in specs:
+        if only_names and name not in only_names:
+            continue
+        problems[name] = problem_entry(path, **kw)
+        print("  ", name, problems[name]["reference_dual_simplex"], flush=True)
+    if only_names:
+        json.dump(problems, open(os.path.join(OUT, "problems.json"), "w"), indent=0)
+        return
     # goldens of the reference's initial-solution test (afiro, Methodical1): step size / primal weight
     afiro = refbind.parse_mps(os.path.join(lp, "afiro_original.mps"))
     s = orcbind.solve(afiro, mode=1, iteration_limit=0)

@@ -92,7 +92,8 @@ def test_iteration_and_time_limits(golden_problems):
 
 
 @pytest.mark.parametrize("name", ["good-max", "max_offset", "good-mps-1", "lp_model_with_var_bounds",
-                                  "mip-sample-relaxation", "mip-bb_optimality-relaxation"])
+                                  "mip-sample-relaxation", "mip-bb_optimality-relaxation",
+                                  "mip-fixed-problem-relaxation", "mip-trivial-presolve-optimality-relaxation"])
 def test_small_lps(golden_problems, name):
     g = golden_problems[name]
     p = dict(g["problem"])
@@ -392,10 +393,11 @@ def test_methodical1_trust_region_restart(golden_problems):
     assert 0.5 * oo["steps_taken"] - 128 <= rr["steps_taken"] <= 2.0 * oo["steps_taken"] + 128
 
 
-@pytest.mark.parametrize("name", ["mip-50v-10-free-bound-relaxation", "mip-neos5-free-bound-relaxation"])
+@pytest.mark.parametrize("name", ["mip-50v-10-free-bound-relaxation", "mip-neos5-free-bound-relaxation",
+                                  "mip-sudoku-relaxation", "mip-cod105_max-relaxation"])
 def test_structured_lp_relaxations_match_reference_dual_simplex(golden_problems, name):
-    """BASELINE config 5 inputs: LP relaxations of datasets/mip instances (233 x 2013 and 63 x 63), objective
-    pinned by the reference's own CPU dual simplex compiled in place"""
+    """BASELINE config 5 inputs: LP relaxations of datasets/mip instances (233 x 2013, 63 x 63, 353 x 730,
+    1024 x 1024 with 57 344 nonzeros), objective pinned by the reference's own CPU dual simplex compiled in place"""
     g = golden_problems[name]
     p = dict(g["problem"])
     p.pop("var_types", None)
@@ -404,7 +406,8 @@ def test_structured_lp_relaxations_match_reference_dual_simplex(golden_problems,
         r = capi.solve(p, method=1, tol=eps)
         o = g["meta"]["oracle"]["%g" % eps]
         assert r["status"] == o["status"] == "Optimal"
-        assert abs(r["objective"] - ref) <= 4 * eps * (1 + abs(ref))
+        # (cod105: the reference simplex itself stops 3.2e-6 short of the optimum 128/7 that PDLP reaches at 1e-8)
+        assert abs(r["objective"] - ref) <= max(4 * eps * (1 + abs(ref)), 5e-6 if "cod105" in name else 0.0)
         assert abs(r["objective"] - o["primal_objective"]) <= 4 * eps * (1 + abs(ref))
         host_check(p, r, eps=eps)
         assert 0.5 * o["steps_taken"] - 80 <= r["steps_taken"] <= 2.0 * o["steps_taken"] + 80
@@ -509,3 +512,23 @@ def test_reference_c_api_test_translation_unit_runs_against_our_library(golden_p
         assert name in report and report[name].rstrip().endswith("OK"), out.stdout + out.stderr
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIFFERS(out of scope)" in report["burglar_mip"]  # MILP is rejected, documented in INTEGRATION.md
+
+
+def test_default_method_does_not_hang_where_pdlp_stalls_at_simplex_grade(golden_problems):
+    """datasets/mip/minrep_inf.mps: PDLP (the reference's rule, restated in the oracle) never reaches 1e-8 on this
+    6 x 4 LP.  A Concurrent / DualSimplex request first tries simplex-grade tolerances under a bounded budget and
+    then answers at the user's own tolerances from the same solver object -- with the default iteration limit
+    (INT_MAX) an unbudgeted attempt would never return."""
+    g = golden_problems["mip-minrep_inf-relaxation"]
+    p = dict(g["problem"])
+    p.pop("var_types", None)
+    ref = g["meta"]["reference_dual_simplex"]["objective"]
+    t0 = time.perf_counter()
+    r = capi.solve(p)  # method 0 (Concurrent), default tolerances and limits
+    assert time.perf_counter() - t0 < 5.0
+    assert r["status"] == "Optimal" and abs(r["objective"] - ref) <= 2e-3 * (1 + abs(ref))
+    stalled = capi.solve(p, method=1, tol=1e-8, iteration_limit=20000)
+    o = g["meta"]["oracle"]["1e-08"]
+    assert stalled["status"] == o["status"] == "IterationLimit"
+    ok = capi.solve(p, method=1, tol=1e-4)
+    assert ok["status"] == "Optimal" and ok["steps_taken"] == g["meta"]["oracle"]["0.0001"]["steps_taken"]
