@@ -99,7 +99,7 @@ class SolverSettings(C.Structure):
                 ("initial_k", c_int), ("use_graph", c_int), ("detect_infeasibility", c_int),
                 ("strict_infeasibility", c_int), ("primal_infeasible_tolerance", c_double),
                 ("dual_infeasible_tolerance", c_double), ("save_best_primal_so_far", c_int),
-                ("log_to_console", c_int), ("log_file", c_char_p)]
+                ("log_to_console", c_int), ("log_file", c_char_p), ("unbounded_from_feasible_iterates", c_int)]
 
 
 class Result(C.Structure):

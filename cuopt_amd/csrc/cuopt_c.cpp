@@ -591,6 +591,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     // would prove infeasibility/unboundedness, so those requests run PDLP WITH its infeasibility detection
     st.detect_infeasibility        = s->infeasibility_detection || s->method != CUOPT_METHOD_PDLP;
     st.strict_infeasibility        = s->strict_infeasibility;
+    st.unbounded_from_feasible_iterates = s->method != CUOPT_METHOD_PDLP;  // a simplex would say UNBOUNDED
     st.primal_infeasible_tolerance = s->primal_infeasible_tolerance;
     st.dual_infeasible_tolerance   = s->dual_infeasible_tolerance;
     st.save_best_primal_so_far     = s->save_best_primal_so_far;

@@ -187,7 +187,14 @@ int verdict(const cuoptamd_solver* s, const Convergence& c)
     dual_ok   = c.l2_dual_residual <= t.absolute_dual_tolerance + t.relative_dual_tolerance * s->norm_c;
   }
   if (dual_ok && primal_ok && gap_ok) return kOptimal;
-  if (primal_ok) return kPrimalFeasible;
+  if (primal_ok) {
+    // (see cuoptamd_settings::unbounded_from_feasible_iterates: not the reference's PDLP, which stops looking here)
+    if (t.detect_infeasibility && t.unbounded_from_feasible_iterates && !t.first_primal_feasible) {
+      const double* f = c.infeasibility;
+      if (f[1] < 0.0 && f[0] / -f[1] <= t.dual_infeasible_tolerance) return kDualInfeasible;
+    }
+    return kPrimalFeasible;
+  }
   if (t.detect_infeasibility) {  // termination_strategy.cu:228-249
     const double* f = c.infeasibility;
     if (f[3] > 0.0 && f[2] / f[3] <= t.primal_infeasible_tolerance) return kPrimalInfeasible;
@@ -553,6 +560,7 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->save_best_primal_so_far     = 0;
   s->log_to_console              = 0;
   s->log_file                    = nullptr;
+  s->unbounded_from_feasible_iterates = 0;
 }
 
 void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,

@@ -102,6 +102,13 @@ typedef struct cuoptamd_settings {
    * and/or appended to log_file (NULL or "" = none) */
   int32_t log_to_console;
   const char* log_file;
+  /* The reference's verdict kernel returns PrimalFeasible BEFORE it looks at the rays (termination_strategy.cu:190-226
+   * vs :228-249), so its PDLP never reports an unbounded LP whose iterates are primal feasible: it runs until the
+   * step-size arithmetic overflows (NumericalError).  Non-zero: a primal-feasible iterate whose normalised ray meets
+   * the dual-infeasibility test is reported as DualInfeasible (needs detect_infeasibility; both iterates must agree
+   * unless strict).  Default 0 = the reference's PDLP; cuOptSolve sets it for Concurrent / DualSimplex requests, where
+   * the reference's simplex would return UNBOUNDED. */
+  int32_t unbounded_from_feasible_iterates;
 } cuoptamd_settings;
 
 /* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */

@@ -65,9 +65,36 @@ def problem_entry(path, relax=True, pinned=None, source=None):
     return d
 
 
+def parser_goldens(lp):
+    parsed = {}
+    for path in sorted(glob.glob(os.path.join(lp, "*.mps"))):
+        name = os.path.basename(path)
+        try:
+            p = refbind.parse_mps(path, fixed_format=False)
+            parsed[name] = dict(ok=True, m=p["m"], n=p["n"], nnz=p["nnz"], maximize=p["maximize"],
+                                objective_offset=p["objective_offset"], offsets=enc(p["offsets"]),
+                                indices=enc(p["indices"]), values=enc(p["values"]), c=enc(p["c"]),
+                                lo=enc(p["lo"]), hi=enc(p["hi"]), lb=enc(p["lb"]), ub=enc(p["ub"]),
+                                var_types=enc(p["var_types"]), row_names=p["row_names"],
+                                var_names=p["var_names"])
+            if p["m"] > 0:  # what the reference's own CPU dual simplex says about the LP in the file
+                ds = refbind.dual_simplex(p)
+                obj = ds["objective"]
+                parsed[name]["reference_dual_simplex"] = dict(
+                    status=ds["status"], iterations=ds["iterations"],
+                    objective=obj if np.isfinite(obj) else None)
+        except refbind.RefMpsError as e:
+            parsed[name] = dict(ok=False, error=str(e)[:200])
+    json.dump(parsed, open(os.path.join(OUT, "mps_parser.json"), "w"), indent=0)
+    return parsed
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only_names = set(filter(None, os.environ.get("GOLDEN_ONLY", "").split(",")))
+    if os.environ.get("GOLDEN_PARSER_ONLY"):  # mps_parser.json alone
+        parser_goldens(os.path.join(REF, "linear_programming"))
+        return
     lp = os.path.join(REF, "linear_programming")
     mip = os.path.join(REF, "mip")
     specs = [
@@ -118,20 +145,7 @@ def main():
                                                oracle_methodical1_primal_weight=s2["initial_primal_weight"])
     json.dump(problems, open(os.path.join(OUT, "problems.json"), "w"), indent=0)
 
-    parsed = {}
-    for path in sorted(glob.glob(os.path.join(lp, "*.mps"))):
-        name = os.path.basename(path)
-        try:
-            p = refbind.parse_mps(path, fixed_format=False)
-            parsed[name] = dict(ok=True, m=p["m"], n=p["n"], nnz=p["nnz"], maximize=p["maximize"],
-                                objective_offset=p["objective_offset"], offsets=enc(p["offsets"]),
-                                indices=enc(p["indices"]), values=enc(p["values"]), c=enc(p["c"]),
-                                lo=enc(p["lo"]), hi=enc(p["hi"]), lb=enc(p["lb"]), ub=enc(p["ub"]),
-                                var_types=enc(p["var_types"]), row_names=p["row_names"],
-                                var_names=p["var_names"])
-        except refbind.RefMpsError as e:
-            parsed[name] = dict(ok=False, error=str(e)[:200])
-    json.dump(parsed, open(os.path.join(OUT, "mps_parser.json"), "w"), indent=0)
+    parsed = parser_goldens(lp)
     print("problems:", {k: (v["m"], v["n"], v["nnz"], v["reference_dual_simplex"]["objective"]) for k, v in problems.items()})
     print("parser fixtures:", sum(v["ok"] for v in parsed.values()), "ok /", len(parsed))
 

@@ -532,3 +532,31 @@ def test_default_method_does_not_hang_where_pdlp_stalls_at_simplex_grade(golden_
     assert stalled["status"] == o["status"] == "IterationLimit"
     ok = capi.solve(p, method=1, tol=1e-4)
     assert ok["status"] == "Optimal" and ok["steps_taken"] == g["meta"]["oracle"]["0.0001"]["steps_taken"]
+
+
+def test_every_lp_fixture_of_the_reference_through_the_c_api(golden_parser):
+    """all 21 non-empty files of datasets/linear_programming the reference parser accepts, solved with DEFAULT
+    settings (method Concurrent) against the verdict of the reference's own dual simplex: same objective, status
+    Infeasible (2) for the three infeasible files and Unbounded (3) for the two unbounded ones; with
+    CUOPT_METHOD_PDLP + infeasibility detection the unbounded ones end like the reference's PDLP (NumericalError:
+    its verdict kernel returns PrimalFeasible before it looks at the rays)"""
+    from conftest import decode_problem
+    count = 0
+    for name, e in golden_parser.items():
+        ds = e.get("reference_dual_simplex") if e["ok"] else None
+        if not ds:
+            continue
+        p = decode_problem(e)
+        p.pop("var_types", None)
+        r = capi.solve(p, iteration_limit=400000)
+        count += 1
+        if ds["status"] == "OPTIMAL":
+            assert r["status"] == "Optimal", name
+            assert abs(r["objective"] - ds["objective"]) <= 2e-6 * (1 + abs(ds["objective"])), name
+        elif ds["status"] == "INFEASIBLE":
+            assert r["status_code"] == 2, (name, r["status"])
+        else:
+            assert r["status_code"] == 3, (name, r["status"])
+            like_ref = capi.solve(p, method=1, infeasibility_detection=True, iteration_limit=400000)
+            assert like_ref["status"] == "NumericalError", name
+    assert count == 21
