@@ -37,6 +37,8 @@ struct Problem {
   std::vector<double> lo, hi;    // always materialised (problem_helpers.cuh:33-58)
   std::vector<char> var_types;
   std::vector<std::string> var_names;  // from the MPS file (empty for array-built problems)
+  std::vector<std::string> row_names;  // idem
+  std::string problem_name, objective_name;
   bool has_integers() const
   {
     for (char t : var_types)
@@ -213,6 +215,91 @@ std::string error_json(const char* type, const std::string& msg)
 }
 
 // problem_checking_t::check_problem_representation (LP/utilities/problem_checking.cu:100-250)
+// CUOPT_USER_PROBLEM_FILE (solve.cu:586-589 -> problem_t::write_as_mps, mip/problem/write_mps.cu): the problem as the
+// solver sees it, free-format MPS, values with 17 significant digits.  Own writer; two deliberate differences from
+// the reference's: a two-sided row is written as a 'G' row with RHS = lower bound and RANGES = upper - lower (the
+// reference writes such rows as 'L' with the lower bound as RHS, which MPS readers -- its own included -- read back as
+// [lower - range, lower]), and the objective offset is kept (negated RHS entry of the objective row).
+bool write_problem_as_mps(const Problem& p, const std::string& path)
+{
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) return false;
+  auto row = [&](int32_t i) { return (size_t)i < p.row_names.size() ? p.row_names[i] : "R" + std::to_string(i); };
+  auto col = [&](int32_t j) { return (size_t)j < p.var_names.size() ? p.var_names[j] : "C" + std::to_string(j); };
+  const std::string obj = p.objective_name.empty() ? "OBJ" : p.objective_name;
+  std::fprintf(f, "NAME          %s\n", p.problem_name.c_str());
+  if (p.maximize) std::fprintf(f, "OBJSENSE\n    MAX\n");
+  std::fprintf(f, "ROWS\n N  %s\n", obj.c_str());
+  // a two-sided row is a 'G' row [rhs, rhs + range] or an 'L' row [rhs - range, rhs]: whichever reproduces the other
+  // bound exactly in floating point (lo + (hi - lo) may be one ulp off hi)
+  auto ranged_as_L = [&](int32_t i) {
+    const double lo = p.lo[i], hi = p.hi[i], r = hi - lo;
+    return std::isfinite(lo) && std::isfinite(hi) && lo != hi && lo + r != hi && hi - r == lo;
+  };
+  for (int32_t i = 0; i < p.m; ++i) {
+    const double lo = p.lo[i], hi = p.hi[i];
+    char type = lo == hi ? 'E' : (std::isinf(lo) && lo < 0 ? (std::isinf(hi) ? 'N' : 'L') : 'G');
+    if (ranged_as_L(i)) type = 'L';
+    std::fprintf(f, " %c  %s\n", type, row(i).c_str());
+  }
+  // COLUMNS wants the matrix by column: counting sort of the CSR entries
+  std::vector<int64_t> start((size_t)p.n + 1, 0);
+  for (int32_t j : p.indices) start[(size_t)j + 1] += 1;
+  for (int32_t j = 0; j < p.n; ++j) start[(size_t)j + 1] += start[j];
+  std::vector<int32_t> rows_of(p.indices.size());
+  std::vector<double> vals_of(p.indices.size());
+  {
+    std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+    for (int32_t i = 0; i < p.m; ++i)
+      for (int32_t k = p.offsets[i]; k < p.offsets[i + 1]; ++k) {
+        const int64_t q = cursor[p.indices[k]]++;
+        rows_of[q] = i, vals_of[q] = p.values[k];
+      }
+  }
+  std::fprintf(f, "COLUMNS\n");
+  bool in_int = false;
+  for (int32_t j = 0; j < p.n; ++j) {
+    const bool integer = p.var_types[j] == CUOPT_INTEGER;
+    if (integer && !in_int) std::fprintf(f, "    MARK0001  'MARKER'                 'INTORG'\n"), in_int = true;
+    if (!integer && in_int) std::fprintf(f, "    MARK0001  'MARKER'                 'INTEND'\n"), in_int = false;
+    bool any = false;
+    if (p.c[j] != 0.0) std::fprintf(f, "    %s %s %.17g\n", col(j).c_str(), obj.c_str(), p.c[j]), any = true;
+    for (int64_t q = start[j]; q < start[(size_t)j + 1]; ++q)
+      std::fprintf(f, "    %s %s %.17g\n", col(j).c_str(), row(rows_of[q]).c_str(), vals_of[q]), any = true;
+    if (!any) std::fprintf(f, "    %s %s 0\n", col(j).c_str(), obj.c_str());  // a column must appear to exist
+  }
+  if (in_int) std::fprintf(f, "    MARK0001  'MARKER'                 'INTEND'\n");
+  std::fprintf(f, "RHS\n");
+  if (p.objective_offset != 0.0) std::fprintf(f, "    RHS1      %s %.17g\n", obj.c_str(), -p.objective_offset);
+  for (int32_t i = 0; i < p.m; ++i) {
+    const double rhs = (std::isinf(p.lo[i]) || ranged_as_L(i)) ? p.hi[i] : p.lo[i];
+    if (std::isfinite(rhs) && rhs != 0.0) std::fprintf(f, "    RHS1      %s %.17g\n", row(i).c_str(), rhs);
+  }
+  bool ranges = false;
+  for (int32_t i = 0; i < p.m; ++i)
+    if (std::isfinite(p.lo[i]) && std::isfinite(p.hi[i]) && p.lo[i] != p.hi[i]) {
+      if (!ranges) std::fprintf(f, "RANGES\n"), ranges = true;
+      std::fprintf(f, "    RNG1      %s %.17g\n", row(i).c_str(), p.hi[i] - p.lo[i]);
+    }
+  std::fprintf(f, "BOUNDS\n");
+  for (int32_t j = 0; j < p.n; ++j) {
+    const double lb = p.lb[j], ub = p.ub[j];
+    const std::string name = col(j);
+    if (std::isinf(lb) && lb < 0 && std::isinf(ub) && ub > 0) {
+      std::fprintf(f, " FR BOUND1    %s\n", name.c_str());
+    } else if (lb == ub) {
+      std::fprintf(f, " FX BOUND1    %s %.17g\n", name.c_str(), lb);
+    } else {
+      if (std::isinf(lb) && lb < 0) std::fprintf(f, " MI BOUND1    %s\n", name.c_str());
+      else if (lb != 0.0) std::fprintf(f, " LO BOUND1    %s %.17g\n", name.c_str(), lb);
+      if (std::isfinite(ub)) std::fprintf(f, " UP BOUND1    %s %.17g\n", name.c_str(), ub);
+      else if (p.var_types[j] == CUOPT_INTEGER && lb == 0.0) std::fprintf(f, " PL BOUND1    %s\n", name.c_str());
+    }
+  }
+  std::fprintf(f, "ENDATA\n");
+  return std::fclose(f) == 0;
+}
+
 std::string validate(const Problem& p)
 {
   if (p.offsets.empty()) return "A_offsets must be set before calling the solver.";
@@ -275,6 +362,8 @@ cuopt_int_t cuOptReadProblem(const char* filename, cuOptOptimizationProblem* pro
     p->lo = std::move(mdl.lo), p->hi = std::move(mdl.hi);
     p->var_types = std::move(mdl.var_types);
     p->var_names = std::move(mdl.var_names);
+    p->row_names = std::move(mdl.row_names);
+    p->problem_name = mdl.problem_name, p->objective_name = mdl.objective_name;
     for (char& t : p->var_types) t = t == 'I' ? CUOPT_INTEGER : CUOPT_CONTINUOUS;
     *problem_ptr = p.release();
   } catch (const cuopt_amd::MpsError& e) {
@@ -567,6 +656,8 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     return (cuopt_int_t)code;
   };
   try {
+    if (!s->user_problem_file.empty() && !write_problem_as_mps(*p, s->user_problem_file))
+      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", "could not write the user problem file " + s->user_problem_file);
     if (p->has_integers()) {
       sol->is_mip = true;
       return error(CUOPT_VALIDATION_ERROR, "ValidationError",

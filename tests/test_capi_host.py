@@ -8,6 +8,7 @@ import re
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from conftest import ROOT, decode_problem, write_mps
 from cuopt_amd import capi
@@ -176,3 +177,35 @@ def test_csr_transpose_matches_scipy():
     t = sp.csr_matrix((tv, ti, to), shape=(30, 40))
     assert abs(t - a.T).max() == 0
     assert np.all(np.diff(to) >= 0) and all(np.all(np.diff(ti[to[j]:to[j + 1]]) > 0) for j in range(30))
+
+
+def test_user_problem_file_round_trip(tmp_path):
+    """CUOPT_USER_PROBLEM_FILE (solve.cu:586-589, test_lp_solver.py:675-700): cuOptSolve writes the problem as MPS before
+    anything else happens (so this runs without a GPU: the solve itself then fails loudly); reading the file back
+    gives the same LP -- every bound flavour, ranged rows, both senses, objective offset, 17 significant digits.
+    Free rows have no MPS row type of their own: they are written as additional N rows, which MPS readers skip."""
+    from test_random_lps_gpu import random_lp
+    for seed in range(6):
+        p, _ = random_lp(seed)
+        if seed == 3:
+            p["lb"][0] = p["ub"][0] = 1.5  # FX
+        path = str(tmp_path / ("user_%d.mps" % seed))
+        prob = capi.Problem.from_dict(p)
+        st = capi.Settings(user_problem_file=path, iteration_limit=1)
+        sol = C.c_void_p()
+        capi.lib.cuOptSolve(prob.handle, st.handle, C.byref(sol))
+        capi.lib.cuOptDestroySolution(C.byref(sol))
+        back = capi.Problem.read(path).to_dict()
+        keep = np.isfinite(p["lo"]) | np.isfinite(p["hi"])
+        A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))[keep]
+        A.sort_indices()
+        assert back["m"] == int(keep.sum()) and back["n"] == p["n"]
+        np.testing.assert_array_equal(back["offsets"], A.indptr)
+        np.testing.assert_array_equal(back["indices"], A.indices)
+        np.testing.assert_array_equal(back["values"], A.data)
+        for k in ("c", "lb", "ub"):
+            np.testing.assert_array_equal(back[k], p[k])
+        # (a two-sided row travels as bound + range: exact whenever one of the two encodings is, else within an ulp)
+        np.testing.assert_allclose(back["lo"], p["lo"][keep], rtol=3e-16, atol=0)
+        np.testing.assert_allclose(back["hi"], p["hi"][keep], rtol=3e-16, atol=0)
+        assert back["maximize"] == p["maximize"] and back["objective_offset"] == p["objective_offset"]

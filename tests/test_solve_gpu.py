@@ -560,3 +560,46 @@ def test_every_lp_fixture_of_the_reference_through_the_c_api(golden_parser):
             like_ref = capi.solve(p, method=1, infeasibility_detection=True, iteration_limit=400000)
             assert like_ref["status"] == "NumericalError", name
     assert count == 21
+
+
+def test_write_files_like_the_python_test_of_the_reference(golden_problems, tmp_path):
+    """test_lp_solver.py:675-700: solve afiro with CUOPT_USER_PROBLEM_FILE set (method DualSimplex), parse the written
+    MPS, solve THAT with CUOPT_SOLUTION_FILE set: Optimal, -464.7531, and both files exist"""
+    p = dict(golden_problems["afiro"]["problem"])
+    out_mps, out_sol = str(tmp_path / "afiro_out.mps"), str(tmp_path / "afiro.sol")
+    r = capi.solve(p, method=2, user_problem_file=out_mps)
+    assert r["status"] == "Optimal" and os.path.isfile(out_mps)
+    again = capi.Problem.read(out_mps)
+    r2 = capi.solve(again, method=2, solution_file=out_sol)
+    assert r2["status"] == "Optimal"
+    assert r2["objective"] == pytest.approx(-464.7531, rel=1e-6)
+    text = open(out_sol).read().splitlines()
+    assert text[0] == "# Status: Optimal" and len(text) == 2 + p["n"]
+
+
+def test_very_low_accuracy_and_initial_solution_like_pdlp_test(golden_problems):
+    """pdlp_test.cu:86-110 (absolute tolerances at the minimal 1e-12, relative 0, PDLP method: Optimal, objective within
+    1 % of -464.7531) and :112-132 (initial primal = all ones: Optimal, same objective)"""
+    p = golden_problems["afiro"]["problem"]
+    tiny = dict(absolute_dual_tolerance=1e-12, relative_dual_tolerance=0.0, absolute_primal_tolerance=1e-12,
+                relative_primal_tolerance=0.0, absolute_gap_tolerance=1e-12, relative_gap_tolerance=0.0)
+    s = capi.Solver(p, iteration_limit=2000000, **tiny)
+    r = s.advance()
+    assert r["status_name"] == "Optimal" and abs(r["primal_objective"] + 464.7531) <= 0.01 * 464.7531
+    o = orcbind.solve(p, iteration_limit=2000000, abs_dual_tol=1e-12, rel_dual_tol=0.0, abs_primal_tol=1e-12,
+                      rel_primal_tol=0.0, abs_gap_tol=1e-12, rel_gap_tol=0.0)
+    assert o["status"] == "Optimal" and 0.5 * o["steps_taken"] - 200 <= r["steps_taken"] <= 2 * o["steps_taken"] + 200
+    s2 = capi.Solver(p, tol=1e-4, init_x=np.ones(p["n"]))
+    r2 = s2.advance()
+    assert r2["status_name"] == "Optimal" and abs(r2["primal_objective"] + 464.7531) <= 0.01 * 464.7531
+    o2 = orcbind.solve(p, tol=1e-4, init_x=np.ones(p["n"]))
+    assert r2["steps_taken"] == int(o2["steps_taken"])
+
+
+def test_initial_step_size_and_primal_weight_are_taken_verbatim(golden_problems):
+    """pdlp_test.cu:525-554: with iteration_limit 0 in Methodical1, set_initial_step_size(1.0) /
+    set_initial_primal_weight(2.0) are what the solver reports afterwards"""
+    p = golden_problems["afiro"]["problem"]
+    s = capi.Solver(p, mode=2, iteration_limit=0, initial_step_size=1.0, initial_primal_weight=2.0)
+    r = s.advance()
+    assert r["status_name"] == "IterationLimit" and r["step_size"] == 1.0 and r["primal_weight"] == 2.0
