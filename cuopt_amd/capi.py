@@ -130,7 +130,8 @@ class WarmStart(C.Structure):
         ("initial_primal_weight", c_double), ("initial_step_size", c_double),
         ("total_pdlp_iterations", c_int), ("total_pdhg_iterations", c_int),
         ("last_candidate_kkt_score", c_double), ("last_restart_kkt_score", c_double),
-        ("sum_solution_weight", c_double), ("iterations_since_last_restart", c_int)]
+        ("sum_solution_weight", c_double), ("iterations_since_last_restart", c_int),
+        ("n_variables", c_int), ("n_constraints", c_int)]
 
     PRIMAL = ("current_primal_solution", "initial_primal_average", "current_ATY", "sum_primal_solutions",
               "last_restart_duality_gap_primal_solution", "current_primal_solution_scaled")
@@ -138,7 +139,7 @@ class WarmStart(C.Structure):
             "last_restart_duality_gap_dual_solution", "current_dual_solution_scaled")
     SCALARS = ("initial_primal_weight", "initial_step_size", "total_pdlp_iterations", "total_pdhg_iterations",
                "last_candidate_kkt_score", "last_restart_kkt_score", "sum_solution_weight",
-               "iterations_since_last_restart")
+               "iterations_since_last_restart", "n_variables", "n_constraints")
 
 
 def _struct_dict(s):

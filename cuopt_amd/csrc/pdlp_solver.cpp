@@ -913,6 +913,7 @@ int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
 {
   if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_get_warm_start: null argument");
   if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
+  ws->n_variables = s->n, ws->n_constraints = s->m_global;
   DEV(pdlpdev_get_solution(s->dev, PDLPDEV_CURRENT, ws->current_primal_solution, ws->current_dual_solution, nullptr));
   DEV(pdlpdev_get_solution(s->dev, PDLPDEV_AVERAGE, ws->initial_primal_average, ws->initial_dual_average, nullptr));
   auto get = [&](int id, double* dst, int64_t count) -> int {
@@ -946,6 +947,9 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_set_warm_start: null argument");
   if (s->started) return fail(-1, "cuoptamd_solver_set_warm_start: the solver has already been advanced");
   if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
+  if ((ws->n_variables != 0 && ws->n_variables != s->n) || (ws->n_constraints != 0 && ws->n_constraints != s->m_global))
+    return fail(-1, "cuoptamd_solver_set_warm_start: the snapshot belongs to a %d x %d problem, this one is %d x %d",
+                ws->n_constraints, ws->n_variables, s->m_global, s->n);
   // iterate: unscaled in the snapshot -> scale_solutions (initial_scaling.cu:410-427), then the usual projection
   DEV(pdlpdev_set_initial(s->dev, ws->current_primal_solution, ws->current_dual_solution));
   if (s->H.project_initial_primal) DEV(pdlpdev_project_primal(s->dev));

@@ -160,6 +160,9 @@ typedef struct cuoptamd_warm_start {
   double last_restart_kkt_score;
   double sum_solution_weight;
   int32_t iterations_since_last_restart;
+  /* sizes of the problem the snapshot was taken from (filled by get_warm_start; 0 = unknown): a snapshot of another
+   * problem is refused by set_warm_start, like the reference (test_lp_solver.py:545-565) */
+  int32_t n_variables, n_constraints;
 } cuoptamd_warm_start;
 
 const char* cuoptamd_last_error(void);

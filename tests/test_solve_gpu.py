@@ -603,3 +603,17 @@ def test_initial_step_size_and_primal_weight_are_taken_verbatim(golden_problems)
     s = capi.Solver(p, mode=2, iteration_limit=0, initial_step_size=1.0, initial_primal_weight=2.0)
     r = s.advance()
     assert r["status_name"] == "IterationLimit" and r["step_size"] == 1.0 and r["primal_weight"] == 2.0
+
+
+def test_warm_start_of_another_problem_is_refused(golden_problems):
+    """test_lp_solver.py:545-565: the warm-start data of one problem handed to the solve of another one must raise"""
+    a = synthetic.generate(900, 700, 6, seed=8)
+    s = capi.Solver(a, tol=1e-1, iteration_limit=5000)
+    s.advance()
+    ws = s.get_warm_start()
+    assert (ws["n_variables"], ws["n_constraints"]) == (700, 900)
+    with pytest.raises(capi.CuOptError):
+        capi.Solver(golden_problems["afiro"]["problem"], tol=1e-4, warm_start=ws)
+    # the same problem takes it
+    r = capi.Solver(a, tol=1e-4, warm_start=ws, iteration_limit=20000).advance()
+    assert r["status_name"] == "Optimal"
