@@ -724,7 +724,9 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     double first_attempt_seconds = 0.0;
     if (rc == 0 && budgeted && res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT) {
       first_attempt_seconds = res.setup_seconds + res.loop_seconds;
-      rc = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_user, nullptr, nullptr);
+      cuoptamd_settings st_rest = st_user;  // the caller's time limit covers both attempts
+      if (std::isfinite(st_rest.time_limit)) st_rest.time_limit = std::max(0.0, st_rest.time_limit - first_attempt_seconds);
+      rc = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_rest, nullptr, nullptr);
       if (rc == 0) rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
     }
     if (rc != 0) {
