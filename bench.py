@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
-    ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel"], help="CUOPT_AMD_SPMV_LAYOUT")
+    ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel", "jag", "timed"], help="CUOPT_AMD_SPMV_LAYOUT")
     args = ap.parse_args()
 
     if args.spmv_layout:
@@ -131,9 +131,9 @@ def main():
     }
     dom = "SPMV_A_DUAL" if kernels["SPMV_A_DUAL"] >= kernels["SPMV_AT_STEP"] else "SPMV_AT_STEP"
     achieved = bytes_alg[dom] / (kernels[dom] * 1e-3) / 1e9
-    panel = layout["A" if dom == "SPMV_A_DUAL" else "At"]["panels"]
-    kname = ("k_panel_a_dual" if panel else "k_spmv_a_dual") if dom == "SPMV_A_DUAL" else \
-            ("k_panel_at_step" if panel else "k_spmv_at_step")
+    lname = layout["A" if dom == "SPMV_A_DUAL" else "At"]["layout"]
+    prefix = {"panel": "k_panel_", "jag": "k_jag_", "stream": "k_spmv_", "resident": "k_spmv_"}[lname]
+    kname = prefix + ("a_dual" if dom == "SPMV_A_DUAL" else "at_step")
     # HBM/fabric bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this very
     # command (profiles/r01_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile

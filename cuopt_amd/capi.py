@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcuopt.so")
+LIB_PATH = os.environ.get("CUOPT_AMD_LIB") or os.path.join(_HERE, "lib", "libcuopt.so")  # override: A/B builds while tuning
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -736,9 +736,16 @@ class Device:
     def layout(self):
         out = np.zeros(6, np.int32)
         self._ck(lib.pdlpdev_layout_info(self.handle, _ptr(out)))
-        return dict(A=dict(panels=bool(out[0] == 1), workgroups=int(out[1]), slabs=int(out[2])),
-                    At=dict(panels=bool(out[3] == 1), workgroups=int(out[4]), slabs=int(out[5])),
-                    resident=bool(out[0] == 2))
+        names = {0: "stream", 1: "panel", 2: "resident", 3: "jag"}
+
+        def side(k):
+            d = dict(layout=names[int(out[k])], panels=bool(out[k] == 1), workgroups=int(out[k + 1]))
+            if out[k] == 3:
+                d["lds_window_coverage_pct"] = int(out[k + 2])
+            else:
+                d["slabs"] = int(out[k + 2])
+            return d
+        return dict(A=side(0), At=side(3), resident=bool(out[0] == 2))
 
     def time_kernel(self, kernel, reps=20):
         ms = c_double()

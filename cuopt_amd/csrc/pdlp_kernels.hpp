@@ -434,6 +434,156 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 }
 #undef PANEL_DISPATCH
 
+// ------------------------------------------------------------------------------------------------
+// Sorted jagged rows ("jag"): the SpMV for STRUCTURED matrices, whose rows touch a narrow column range.
+// Measured (tools/spmv_tune2.hip, profiles/r02_spmv_tune2.txt): an 8-byte gather through the vector
+// memory path costs ~1.85 clocks of the CU's texture-address unit per lane even when it hits L1
+// (1e7 gathers never finish under 30 us), and every L1 miss occupies one of a CU's limited miss slots
+// for an L2 round trip.  A workgroup of this layout therefore copies the column window its rows use
+// into LDS once (coalesced) and gathers from LDS; entries outside the window fall back to a global
+// load, per lane.
+//   * rows are cut into groups of G (<= kJagMaxGroup) consecutive rows, one wave64 per group, kJagWaves
+//     groups per workgroup; inside a group the rows with 1..kLongRow nonzeros are sorted by length
+//     (descending, stable) and stored as jagged diagonals per pass of 64 rows: entry k of every row
+//     of the pass that has one, contiguous -- lane <-> row, coalesced, no padding, no LDS staging of
+//     products and no barrier in the loop;
+//   * a lane adds up ITS row left to right in a register -> bit-identical to a sequential CSR sum;
+//   * rows longer than kLongRow are summed by their wave cooperatively from the CSR arrays (64
+//     strided chains + the fixed butterfly), like every long row of the other layouts;
+//   * the row sums go through the wave's LDS strip so that the fused epilogue runs in natural row
+//     order (coalesced streams whatever the sort did to the rows).
+// ------------------------------------------------------------------------------------------------
+constexpr int kJagWaves    = 8;
+constexpr int kJagThreads  = kJagWaves * 64;
+constexpr int kJagWindow   = 8192;  // entries of the gathered vector staged per workgroup (64 KiB)
+constexpr int kJagMaxGroup = 256;   // rows per wave (2 KiB of row sums)
+constexpr int kJagU        = 8;     // jagged diagonals requested per round
+constexpr size_t kJagLdsBytes = sizeof(double) * (size_t)(kJagWindow + kJagWaves * kJagMaxGroup);  // 80 KiB: two workgroups per CU
+
+struct JagView {
+  int rows, G, ngroups, nblk;
+  const int32_t* __restrict__ tile_e;   // ngroups + 1: first entry of each group
+  const int32_t* __restrict__ tile_sr;  // ngroups + 1: first row descriptor of each group
+  const uint16_t* __restrict__ sr;      // (length - 1) << 9 | row within the group, sorted by length
+  const int32_t* __restrict__ col;      // jagged-diagonal order
+  const double* __restrict__ val;
+  const int32_t* __restrict__ win;      // 2 * nblk: first column and length of the LDS window
+  const int32_t* __restrict__ lr_ptr;   // ngroups + 1: the group's rows longer than kLongRow ...
+  const int32_t* __restrict__ lr_row;   // ... as global row numbers, read from the CSR arrays below
+  const int32_t* __restrict__ off;
+  const int32_t* __restrict__ idx;
+  const double* __restrict__ csr_val;
+};
+
+template <class Epi>
+__device__ __forceinline__ void jag_block(const JagView& J, const double* __restrict__ vec, Epi& epi,
+                                          double* __restrict__ partials)
+{
+  extern __shared__ __attribute__((aligned(16))) double jag_lds[];
+  double* xwin   = jag_lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int blk  = xcd_remap(blockIdx.x, J.nblk);
+  if (blk >= J.nblk) return;
+  double* psum        = jag_lds + kJagWindow + wave * kJagMaxGroup;
+  const int g         = blk * kJagWaves + wave;
+  const int wbase     = J.win[2 * blk];
+  const unsigned wlen = (unsigned)J.win[2 * blk + 1];
+  for (unsigned i = threadIdx.x; i < wlen; i += kJagThreads) xwin[i] = vec[wbase + i];
+  __syncthreads();
+  auto gather = [&](int j) -> double {
+    const unsigned rel = (unsigned)(j - wbase);
+    return rel < wlen ? xwin[rel] : vec[j];
+  };
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+  if (g < J.ngroups) {
+    const int G   = J.G;
+    int e         = __builtin_amdgcn_readfirstlane(J.tile_e[g]);
+    const int sr0 = __builtin_amdgcn_readfirstlane(J.tile_sr[g]);
+    const int ns  = __builtin_amdgcn_readfirstlane(J.tile_sr[g + 1]) - sr0;
+    for (int i = lane; i < G; i += 64) psum[i] = 0.0;  // rows without nonzeros
+    for (int p0 = 0; p0 < ns; p0 += 64) {
+      const int i      = p0 + lane;
+      const bool have  = i < ns;
+      const unsigned d = have ? (unsigned)J.sr[sr0 + i] : 0u;
+      const int cnt    = have ? (int)(d >> 9) + 1 : 0;
+      const int lrow   = (int)(d & 511u);
+      double sum       = 0.0;
+      const int kmax   = __builtin_amdgcn_readfirstlane(cnt);  // sorted: lane 0 holds the longest row of the pass
+      for (int k0 = 0; k0 < kmax; k0 += kJagU) {
+        int at[kJagU];
+#pragma unroll
+        for (int u = 0; u < kJagU; ++u) {  // diagonal k holds one entry per row longer than k: a prefix of the lanes
+          at[u] = e;
+          e += __builtin_popcountll(__ballot(cnt > k0 + u));
+        }
+        double a[kJagU];
+        int j[kJagU];
+#pragma unroll
+        for (int u = 0; u < kJagU; ++u) {
+          a[u] = 0.0, j[u] = wbase;
+          if (cnt > k0 + u) {
+            a[u] = __builtin_nontemporal_load(J.val + at[u] + lane);
+            j[u] = __builtin_nontemporal_load(J.col + at[u] + lane);
+          }
+        }
+        double xv[kJagU];
+#pragma unroll
+        for (int u = 0; u < kJagU; ++u) {
+          xv[u] = 0.0;
+          if (cnt > k0 + u) xv[u] = gather(j[u]);
+        }
+        // lanes past their row's end add +0.0 * 0.0: a sum that started at +0.0 is never -0.0, so this changes no bit
+#pragma unroll
+        for (int u = 0; u < kJagU; ++u) sum = sum + a[u] * xv[u];
+      }
+      if (have) psum[lrow] = sum;
+    }
+    // rows longer than kLongRow: 64 strided chains and the fixed wave tree (compared with a tolerance, like every
+    // long row of the other layouts)
+    const int q1 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g + 1]);
+    for (int q = __builtin_amdgcn_readfirstlane(J.lr_ptr[g]); q < q1; ++q) {
+      const int r  = __builtin_amdgcn_readfirstlane(J.lr_row[q]);
+      const int k0 = __builtin_amdgcn_readfirstlane(J.off[r]), k1 = __builtin_amdgcn_readfirstlane(J.off[r + 1]);
+      double part = 0.0;
+      for (int k = k0 + lane; k < k1; k += 256) {
+        double a[4];
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = 0.0, j[u] = wbase;
+          if (k + 64 * u < k1) {
+            a[u] = __builtin_nontemporal_load(J.csr_val + k + 64 * u);
+            j[u] = __builtin_nontemporal_load(J.idx + k + 64 * u);
+          }
+        }
+        double xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = k + 64 * u < k1 ? gather(j[u]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part = part + a[u] * xv[u];
+      }
+      part = wave_reduce<SumOp>(part);
+      if (lane == 0) psum[r - g * G] = part;
+    }
+    __builtin_amdgcn_wave_barrier();  // the strip is private to the wave: LDS operations of a wave complete in order
+    for (int i = lane; i < G; i += 64) {
+      const int row = g * G + i;
+      if (row < J.rows) epi.row(row, psum[i], acc);
+    }
+  }
+  if constexpr (Epi::NQ > 0) {
+    __syncthreads();  // every wave is done with the window: its first bytes become the reduction scratch
+    block_reduce<typename Epi::Op, Epi::NQ, kJagWaves>(acc, xwin);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * J.nblk + blk] = acc[q];
+    }
+  }
+}
+
 // ---- element-wise rules of the reference (LP/utils.cuh) -----------------------------------------
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }

@@ -1,6 +1,6 @@
-"""GPU: the slab-major row-panel SpMV layout (used when the gathered vector overflows an XCD's L2) must
-give the same numbers as the CSR stream layout: bit-exact rows (CSR columns are sorted, so every row is
-still summed left to right), same PDLP decisions."""
+"""GPU: the slab-major row-panel SpMV layout (used when the gathered vector overflows an XCD's L2) and the
+sorted jagged-row layout with LDS column windows (used for structured matrices) must give the same numbers
+as the CSR stream layout: bit-exact rows (every row is still summed left to right), same PDLP decisions."""
 import numpy as np
 import pytest
 
@@ -11,7 +11,8 @@ from test_kernels_gpu import ragged_problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20)], ids=["panel-4KiB-slabs", "panel-1slab", "stream"])
+@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20), ("jag", 1 << 20)],
+                ids=["panel-4KiB-slabs", "panel-1slab", "stream", "jag"])
 def layout(request, monkeypatch):
     mode, slab = request.param
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
@@ -42,6 +43,7 @@ def test_layout_is_what_was_asked(layout):
     p = synthetic.generate(3000, 2600, 9, seed=12)
     lay = capi.Device(p).layout()
     assert lay["A"]["panels"] == lay["At"]["panels"] == (layout == "panel")
+    assert lay["A"]["layout"] == lay["At"]["layout"] == layout
     if layout == "panel":
         assert lay["A"]["slabs"] >= 1 and lay["A"]["workgroups"] >= 1
 
@@ -96,3 +98,52 @@ def test_solve_to_tolerance(layout):
     r = capi.solve(p, method=1, tol=1e-6)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+
+
+def test_structured_matrix_gets_the_jagged_layout_by_itself(monkeypatch):
+    """auto: a banded LP (every gather inside the workgroup's LDS window) takes the jagged layout, a random one does not;
+    the solve through it reaches the optimum known by construction"""
+    monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
+    p = synthetic.generate(70000, 70000, 8, seed=5, band=600)
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "jag"
+    assert lay["A"]["lds_window_coverage_pct"] == 100
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
+    np.testing.assert_array_equal(dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y))
+    q = synthetic.generate(70000, 70000, 8, seed=5)
+    assert capi.Device(q).layout()["A"]["layout"] != "jag"
+    r = capi.solve(p, method=1, tol=1e-6)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+
+
+def test_jagged_layout_partial_windows(monkeypatch):
+    """columns half inside, half far outside the LDS window: the per-lane fallback to a global gather"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
+    monkeypatch.setenv("CUOPT_AMD_SMALL", "0")
+    rng = np.random.default_rng(3)
+    m, n, k = 20000, 200000, 12
+    cols = np.empty((m, k), np.int64)
+    centre = (np.arange(m) * n) // m
+    cols[:, : k // 2] = np.clip(centre[:, None] + rng.integers(-300, 300, size=(m, k // 2)), 0, n - 1)
+    cols[:, k // 2:] = rng.integers(0, n, size=(m, k - k // 2))
+    cols.sort(axis=1)
+    keep = np.ones((m, k), bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    lens = keep.sum(axis=1)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = cols[keep].astype(np.int32)
+    values = rng.standard_normal(len(indices))
+    p = dict(m=m, n=n, offsets=offsets, indices=indices, values=values, c=rng.standard_normal(n), lo=-np.ones(m), hi=np.ones(m),
+             lb=np.zeros(n), ub=np.ones(n), maximize=False, objective_offset=0.0)
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == "jag" and 30 <= lay["A"]["lds_window_coverage_pct"] <= 70
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    to, ti, tv = orcbind.transpose(m, n, offsets, indices, values)
+    np.testing.assert_array_equal(dev.spmv(x, False, m), orcbind.spmv(offsets, indices, values, x))
+    np.testing.assert_array_equal(dev.spmv(y, True, n), orcbind.spmv(to, ti, tv, y))
