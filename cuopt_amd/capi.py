@@ -229,6 +229,7 @@ _proto("pdlpdev_run", c_int, c_void_p, c_int, P(Ctl))
 _proto("pdlpdev_get_ctl", c_int, c_void_p, P(Ctl))
 _proto("pdlpdev_clear_error", c_int, c_void_p)
 _proto("pdlpdev_set_graph_mode", c_int, c_void_p, c_int)
+_proto("pdlpdev_prepare_graphs", c_int, c_void_p)
 _proto("pdlpdev_flush_average", c_int, c_void_p)
 _proto("pdlpdev_make_average", c_int, c_void_p, c_int)
 _proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)

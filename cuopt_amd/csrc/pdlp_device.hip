@@ -2652,6 +2652,17 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   return 0;
 }
 
+int pdlpdev_prepare_graphs(pdlpdev_ctx* ctx)
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->use_graph || ctx->comm || ctx->small_resident) return 0;
+  for (int chunk = 1; chunk <= 64; chunk *= 2) {
+    hipGraphExec_t g;
+    TRY(get_graph(ctx, chunk, &g));
+  }
+  return 0;
+}
+
 int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl)
 {
   HIP_TRY(hipSetDevice(ctx->device));

@@ -213,6 +213,9 @@ int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
 int pdlpdev_clear_error(pdlpdev_ctx* ctx);
 /* 0: plain launches, 1: replay the attempt through a captured hipGraph (default 1) */
 int pdlpdev_set_graph_mode(pdlpdev_ctx* ctx, int use_graph);
+/* instantiate every replay size (1, 2, ... 64 attempts) now instead of at first use (measurement: keeps graph
+ * instantiation out of a timed region; a solve does not need it) */
+int pdlpdev_prepare_graphs(pdlpdev_ctx* ctx);
 
 /* ---- major iteration -------------------------------------------------------------------------- */
 /* adds a still-pending accepted iterate to the running sums */
