@@ -99,7 +99,8 @@ class SolverSettings(C.Structure):
                 ("initial_k", c_int), ("use_graph", c_int), ("detect_infeasibility", c_int),
                 ("strict_infeasibility", c_int), ("primal_infeasible_tolerance", c_double),
                 ("dual_infeasible_tolerance", c_double), ("save_best_primal_so_far", c_int),
-                ("log_to_console", c_int), ("log_file", c_char_p), ("unbounded_from_feasible_iterates", c_int)]
+                ("log_to_console", c_int), ("log_file", c_char_p), ("unbounded_from_feasible_iterates", c_int),
+                ("accept_enabled", c_int), ("accept_tolerance", c_double * 6)]
 
 
 class Result(C.Structure):
@@ -113,7 +114,8 @@ class Result(C.Structure):
                 ("dual_ray_linear_objective", c_double), ("initial_step_size", c_double),
                 ("initial_primal_weight", c_double), ("step_size", c_double),
                 ("primal_weight", c_double), ("norm_b", c_double), ("norm_c", c_double),
-                ("setup_seconds", c_double), ("loop_seconds", c_double)]
+                ("setup_seconds", c_double), ("loop_seconds", c_double),
+                ("accepted_at_looser_tolerances", c_int), ("gpus", c_int)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -188,6 +190,7 @@ for _n in ("cuOptGetPrimalSolution", "cuOptGetDualSolution", "cuOptGetReducedCos
 for _n in ("cuOptGetObjectiveValue", "cuOptGetSolveTime", "cuOptGetMIPGap", "cuOptGetSolutionBound"):
     _proto(_n, c_int, c_void_p, P(c_double))
 _proto("cuOptAmdGetPdlpStats", c_int, c_void_p, P(Result))
+_proto("cuOptAmdGetSolveInfo", c_int, c_void_p, c_char_p, c_int)
 
 _proto("cuoptamd_last_error", c_char_p)
 _proto("cuoptamd_hyper_preset", None, c_int, P(Hyper))
@@ -456,6 +459,13 @@ def solve(problem, settings=None, **params):
             lib.cuOptAmdGetPdlpStats(sol, C.byref(res))
             out.update({k: v for k, v in res.as_dict().items() if k != "status"})
             out.update(x=x, y=y, reduced_cost=z)
+            info = C.create_string_buffer(1024)
+            lib.cuOptAmdGetSolveInfo(sol, info, 1024)
+            try:
+                import json as _json
+                out["solve_info"] = _json.loads(info.value.decode())
+            except ValueError:
+                out["solve_info"] = info.value.decode()
     finally:
         if sol:
             lib.cuOptDestroySolution(C.byref(sol))

@@ -55,6 +55,10 @@ struct Settings {
   double time_limit = kInf;
   int32_t iteration_limit = INT_MAX, pdlp_solver_mode = CUOPT_PDLP_SOLVER_MODE_STABLE2,
           method = CUOPT_METHOD_CONCURRENT, num_cpu_threads = -1;
+  // extensions of this library (not in the reference's registry): row blocks / GPUs of one solve (0 = the
+  // CUOPT_AMD_NUM_GPUS environment variable, default 1) and the simplex-grade emulation switch (-1 = the
+  // CUOPT_AMD_SIMPLEX_GRADE environment variable, default on)
+  int32_t num_gpus = 0, simplex_grade = -1;
   bool infeasibility_detection = false, strict_infeasibility = false, per_constraint_residual = false,
        save_best_primal_so_far = false, first_primal_feasible = false, log_to_console = true,
        crossover = false, mip_scaling = true, mip_heuristics_only = false;
@@ -90,7 +94,9 @@ struct Settings {
     ints = {{CUOPT_ITERATION_LIMIT, &iteration_limit, 0, INT_MAX},
             {CUOPT_PDLP_SOLVER_MODE, &pdlp_solver_mode, CUOPT_PDLP_SOLVER_MODE_STABLE1, CUOPT_PDLP_SOLVER_MODE_FAST1},
             {CUOPT_METHOD, &method, CUOPT_METHOD_CONCURRENT, CUOPT_METHOD_DUAL_SIMPLEX},
-            {CUOPT_NUM_CPU_THREADS, &num_cpu_threads, -1, INT_MAX}};
+            {CUOPT_NUM_CPU_THREADS, &num_cpu_threads, -1, INT_MAX},
+            {"amd_num_gpus", &num_gpus, 0, 16},
+            {"amd_simplex_grade", &simplex_grade, -1, 1}};
     bools = {{CUOPT_INFEASIBILITY_DETECTION, &infeasibility_detection},
              {CUOPT_STRICT_INFEASIBILITY, &strict_infeasibility},
              {CUOPT_PER_CONSTRAINT_RESIDUAL, &per_constraint_residual},
@@ -206,6 +212,7 @@ struct Solution {
   std::vector<double> x, y, rc;
   double objective = 0.0, solve_time = 0.0;
   cuoptamd_result stats{};
+  std::string solve_info;  // cuOptAmdGetSolveInfo: which engine / attempt answered
 };
 
 // cuopt::logic_error message format, cpp/include/cuopt/error.hpp:110-125
@@ -656,15 +663,15 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     return (cuopt_int_t)code;
   };
   try {
-    if (!s->user_problem_file.empty() && !write_problem_as_mps(*p, s->user_problem_file))
-      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", "could not write the user problem file " + s->user_problem_file);
     if (p->has_integers()) {
       sol->is_mip = true;
       return error(CUOPT_VALIDATION_ERROR, "ValidationError",
                    "MILP is outside the scope of the MI355X-native PDLP library: only continuous LPs can be solved");
     }
-    std::string bad = validate(*p);
+    std::string bad = validate(*p);  // before anything walks the arrays (the MPS writer below trusts the indices)
     if (!bad.empty()) return error(CUOPT_VALIDATION_ERROR, "ValidationError", bad);
+    if (!s->user_problem_file.empty() && !write_problem_as_mps(*p, s->user_problem_file))
+      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", "could not write the user problem file " + s->user_problem_file);
 
     cuoptamd_hyper hyper;
     cuoptamd_hyper_preset(s->pdlp_solver_mode, &hyper);
@@ -673,16 +680,32 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.absolute_dual_tolerance = s->tol[0], st.relative_dual_tolerance = s->tol[1];
     st.absolute_primal_tolerance = s->tol[2], st.relative_primal_tolerance = s->tol[3];
     st.absolute_gap_tolerance = s->tol[4], st.relative_gap_tolerance = s->tol[5];
-    const bool simplex_grade = s->method != CUOPT_METHOD_PDLP && p->values.size() <= 100000;
+    auto env_int = [](const char* name, int fallback) {
+      const char* v = std::getenv(name);
+      return v && *v ? std::atoi(v) : fallback;
+    };
+    const int gpus = std::max(1, s->num_gpus > 0 ? s->num_gpus : env_int("CUOPT_AMD_NUM_GPUS", 1));
+    // CUOPT_METHOD: this library has ONE engine, PDLP.  Concurrent (the default) and DualSimplex requests, and
+    // crossover = true, are served by PDLP and say so in the log and in cuOptAmdGetSolveInfo.  The reference's
+    // Concurrent / DualSimplex return the simplex VERTEX on small LPs (the CPU simplex wins the race there:
+    // c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings), so for such requests on small LPs (<= 1e5
+    // nonzeros, microseconds per iteration) PDLP aims at simplex-grade tolerances (1e-8) -- the "simplex-grade
+    // emulation", switched off by CUOPT_AMD_SIMPLEX_GRADE=0 or the integer parameter "amd_simplex_grade" = 0.
+    // The caller's own tolerances stay in force as the ACCEPTANCE set (cuoptamd_settings::accept_tolerance): the
+    // first iterate that meets them is kept and returned as Optimal if the tight solve runs out of the caller's
+    // iteration / time limit or of the emulation's budget, so limits behave as in the reference's Concurrent mode.
+    const bool other_method  = s->method != CUOPT_METHOD_PDLP;
+    const bool grade_on      = (s->simplex_grade >= 0 ? s->simplex_grade : env_int("CUOPT_AMD_SIMPLEX_GRADE", 1)) != 0;
+    const bool simplex_grade = other_method && grade_on && gpus == 1 && p->values.size() <= 100000;
     st.iteration_limit         = s->iteration_limit;
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
     st.first_primal_feasible   = s->first_primal_feasible;
-    // CUOPT_METHOD other than PDLP (Concurrent = default, DualSimplex) is served by PDLP as well; a simplex
-    // would prove infeasibility/unboundedness, so those requests run PDLP WITH its infeasibility detection
-    st.detect_infeasibility        = s->infeasibility_detection || s->method != CUOPT_METHOD_PDLP;
+    // a simplex would prove infeasibility / unboundedness: the emulation runs PDLP WITH its infeasibility detection
+    // (small LPs only -- large ones keep the reference PDLP's default, detection off unless asked for)
+    st.detect_infeasibility        = s->infeasibility_detection || simplex_grade;
     st.strict_infeasibility        = s->strict_infeasibility;
-    st.unbounded_from_feasible_iterates = s->method != CUOPT_METHOD_PDLP;  // a simplex would say UNBOUNDED
+    st.unbounded_from_feasible_iterates = simplex_grade;  // a simplex would say UNBOUNDED
     st.primal_infeasible_tolerance = s->primal_infeasible_tolerance;
     st.dual_infeasible_tolerance   = s->dual_infeasible_tolerance;
     st.save_best_primal_so_far     = s->save_best_primal_so_far;
@@ -691,58 +714,93 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
                    p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
                    p->objective_offset};
-    // CUOPT_METHOD: this library has one engine.  Concurrent (default) and DualSimplex requests are
-    // served by PDLP as well (documented in INTEGRATION.md); the termination semantics are PDLP's.
-    // The reference's Concurrent (default) / DualSimplex methods return the simplex VERTEX on small LPs (the CPU
-    // simplex wins the race there: c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings).  This library has
-    // one engine, so such requests first run PDLP to simplex-grade tolerances (<= 1e-8) when the LP is small
-    // (<= 1e5 nonzeros, microseconds per iteration), under a bounded budget: PDLP can stall at 1e-8 on small degenerate
-    // LPs (the primal weight of pdlp_restart_strategy.cu:684-750 collapses, e.g. datasets/mip/minrep_inf.mps), and
-    // with the default iteration limit (INT_MAX) that would never return.  If the budget runs out, the same solver
-    // object is reset (cuoptamd_solver_reset: scaling and matrices are kept) and the LP is solved at the tolerances
-    // and limits the user asked for.  Large LPs keep the user's tolerances from the start (PDLP wins the race).
+    auto say = [&](const std::string& line) {
+      if (s->log_to_console) std::fputs(line.c_str(), stdout), std::fflush(stdout);
+      if (!s->log_file.empty())
+        if (FILE* f = std::fopen(s->log_file.c_str(), "a")) std::fputs(line.c_str(), f), std::fclose(f);
+    };
+    const char* method_name = s->method == CUOPT_METHOD_CONCURRENT ? "Concurrent" : s->method == CUOPT_METHOD_DUAL_SIMPLEX ? "DualSimplex" : "PDLP";
+    if (other_method || s->crossover)
+      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover" : "") +
+          " requested: served by PDLP (the only engine of this library)" +
+          (simplex_grade ? ", simplex-grade tolerances 1e-8 with the requested ones as acceptance set\n" : "\n"));
     const cuoptamd_settings st_user = st;
     constexpr int32_t kSimplexGradeBudget = 50000;
-    bool budgeted = false;
+    bool tightened = false;
     if (simplex_grade) {
-      double* tols[6] = {&st.absolute_dual_tolerance,   &st.relative_dual_tolerance, &st.absolute_primal_tolerance,
-                         &st.relative_primal_tolerance, &st.absolute_gap_tolerance,  &st.relative_gap_tolerance};
-      bool tighter = false;
-      for (double* t : tols) tighter = tighter || *t > 1e-8, *t = std::min(*t, 1e-8);
-      if (tighter && st.iteration_limit > kSimplexGradeBudget) st.iteration_limit = kSimplexGradeBudget, budgeted = true;
-    }
-    cuoptamd_solver* solver = nullptr;
-    int rc = cuoptamd_solver_create(&solver, &lp, &hyper, &st, nullptr, nullptr, 0, 0, 1, nullptr);
-    if (rc != 0) {
-      std::string msg = cuoptamd_last_error();
-      cuoptamd_solver_destroy(solver);
-      if (rc == -7) return error(CUOPT_VALIDATION_ERROR, "ValidationError", msg);
-      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+      double* tols[6]   = {&st.absolute_gap_tolerance,    &st.relative_gap_tolerance,  &st.absolute_primal_tolerance,
+                           &st.relative_primal_tolerance, &st.absolute_dual_tolerance, &st.relative_dual_tolerance};
+      for (int i = 0; i < 6; ++i) {
+        st.accept_tolerance[i] = *tols[i];
+        tightened              = tightened || *tols[i] > 1e-8;
+        *tols[i]               = std::min(*tols[i], 1e-8);
+      }
+      if (tightened) {
+        st.accept_enabled  = 1;
+        st.iteration_limit = std::min(st.iteration_limit, kSimplexGradeBudget);
+      }
     }
     cuoptamd_result res{};
-    rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
     double first_attempt_seconds = 0.0;
-    if (rc == 0 && budgeted && res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT) {
-      first_attempt_seconds = res.setup_seconds + res.loop_seconds;
-      cuoptamd_settings st_rest = st_user;  // the caller's time limit covers both attempts
-      if (std::isfinite(st_rest.time_limit)) st_rest.time_limit = std::max(0.0, st_rest.time_limit - first_attempt_seconds);
-      rc = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_rest, nullptr, nullptr);
-      if (rc == 0) rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
-    }
-    if (rc != 0) {
-      std::string msg = cuoptamd_last_error();
+    std::string answered = simplex_grade && tightened ? "simplex_grade_1e-8" : "requested_tolerances";
+    sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
+    if (gpus > 1) {
+      const int soft = env_int("CUOPT_AMD_SOFT_COMMUNICATOR", 0);
+      const int rc   = cuoptamd_solve_sharded(&lp, &hyper, &st, gpus, soft, &res, sol->x.data(), sol->y.data(), sol->rc.data());
+      if (rc != 0) {
+        const std::string msg = cuoptamd_last_error();
+        if (rc == -7) return error(CUOPT_VALIDATION_ERROR, "ValidationError", msg);
+        return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+      }
+    } else {
+      cuoptamd_solver* solver = nullptr;
+      int rc = cuoptamd_solver_create(&solver, &lp, &hyper, &st, nullptr, nullptr, 0, 0, 1, nullptr);
+      if (rc != 0) {
+        std::string msg = cuoptamd_last_error();
+        cuoptamd_solver_destroy(solver);
+        if (rc == -7) return error(CUOPT_VALIDATION_ERROR, "ValidationError", msg);
+        return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+      }
+      rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+      const bool on_limit = res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT || res.status == CUOPT_TERIMINATION_STATUS_TIME_LIMIT;
+      if (rc == 0 && res.accepted_at_looser_tolerances) answered = "requested_tolerances_kept_during_simplex_grade_attempt";
+      if (rc == 0 && tightened && on_limit && !res.accepted_at_looser_tolerances) {
+        // the tight attempt ended on a limit and no iterate met even the requested tolerances: whatever is left of the
+        // caller's limits goes to a plain solve at the requested tolerances (same solver object: matrices and scaling kept)
+        first_attempt_seconds = res.setup_seconds + res.loop_seconds;
+        cuoptamd_settings st_rest = st_user;
+        if (st_user.iteration_limit != INT_MAX) st_rest.iteration_limit = std::max(0, st_user.iteration_limit - res.steps_taken);
+        if (std::isfinite(st_rest.time_limit)) st_rest.time_limit = std::max(0.0, st_rest.time_limit - first_attempt_seconds);
+        if (st_rest.iteration_limit > 0 && st_rest.time_limit > 0.0) {
+          answered = "requested_tolerances_after_simplex_grade_budget";
+          rc = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_rest, nullptr, nullptr);
+          if (rc == 0) rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+        } else {
+          answered = "limit_reached_during_simplex_grade_attempt";
+        }
+      }
+      if (rc == 0) rc = cuoptamd_solver_get_solution(solver, sol->x.data(), sol->y.data(), sol->rc.data());
+      if (rc != 0) {
+        std::string msg = cuoptamd_last_error();
+        cuoptamd_solver_destroy(solver);
+        return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+      }
       cuoptamd_solver_destroy(solver);
-      return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
+    }
+    {
+      char info[512];
+      std::snprintf(info, sizeof info,
+                    "{\"engine\": \"pdlp\", \"requested_method\": \"%s\", \"crossover_requested\": %s, \"simplex_grade_emulation\": %s, "
+                    "\"answered_by\": \"%s\", \"gpus\": %d, \"iterations\": %d}",
+                    method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false", answered.c_str(), gpus, res.steps_taken);
+      sol->solve_info = info;
+      if (other_method || s->crossover) say("cuopt_amd: " + sol->solve_info + "\n");
     }
     res.setup_seconds += first_attempt_seconds;
     sol->stats              = res;
     sol->termination_status = res.status;
     sol->objective          = res.primal_objective;  // solver_solution.cu:307-310
     sol->solve_time         = res.setup_seconds + res.loop_seconds;
-    sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
-    rc = cuoptamd_solver_get_solution(solver, sol->x.data(), sol->y.data(), sol->rc.data());
-    cuoptamd_solver_destroy(solver);
-    if (rc != 0) return error(CUOPT_RUNTIME_ERROR, "RuntimeError", cuoptamd_last_error());
     if (!s->solution_file.empty()) {
       // write_to_sol_file (solver_solution.cu:370-387, math_optimization/solution_writer.cu)
       if (FILE* f = std::fopen(s->solution_file.c_str(), "w")) {
@@ -761,6 +819,16 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
   } catch (const std::exception& e) {
     return error(CUOPT_RUNTIME_ERROR, "RuntimeError", e.what());
   }
+  return CUOPT_SUCCESS;
+}
+
+// Extension (not part of the reference's 41 functions): a JSON line saying which engine answered the request --
+// {"engine", "requested_method", "crossover_requested", "simplex_grade_emulation", "answered_by", "gpus", "iterations"}.
+cuopt_int_t cuOptAmdGetSolveInfo(cuOptSolution solution, char* buffer, cuopt_int_t buffer_size)
+{
+  if (solution == nullptr || buffer == nullptr || buffer_size <= 0) return CUOPT_INVALID_ARGUMENT;
+  const Solution* sol = static_cast<const Solution*>(solution);
+  std::snprintf(buffer, (size_t)buffer_size, "%s", sol->solve_info.c_str());
   return CUOPT_SUCCESS;
 }
 

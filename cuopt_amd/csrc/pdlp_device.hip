@@ -2138,19 +2138,28 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
   }
   TRY(rccl::load());
   HIP_TRY(hipSetDevice(ctx->device));
-  // A unique id bootstraps exactly ONE communicator; solvers created later with the same id (bench.py makes
-  // two per process) share it.  Communicators live until process exit.
+  // A unique id bootstraps exactly ONE communicator per rank; solvers created later with the same (id, rank) -- bench.py
+  // makes two per process -- share it.  The ranks of a single-process sharded solve (cuoptamd_solve_sharded: one host
+  // thread per device) each get their own; ncclCommInitRank blocks until every rank has joined, so it runs outside the
+  // lock.  Communicators live until process exit.
+  static std::mutex cache_mutex;
   static std::map<std::string, rccl::comm_t> cache;
-  const std::string key((const char*)id, 128);
-  auto it = cache.find(key);
-  if (it == cache.end()) {
+  std::string key((const char*)id, 128);
+  key.append((const char*)&rank, sizeof(rank));
+  rccl::comm_t comm = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    auto it = cache.find(key);
+    if (it != cache.end()) comm = it->second;
+  }
+  if (!comm) {
     rccl::unique_id u;
     memcpy(u.internal, id, 128);
-    rccl::comm_t comm = nullptr;
     RCCL_TRY(rccl::CommInitRank(&comm, world, u, rank));
-    it = cache.emplace(key, comm).first;
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    cache.emplace(key, comm);
   }
-  ctx->comm = it->second;
+  ctx->comm = comm;
   ctx->rank = rank, ctx->world = world;
   return 0;
 }

@@ -103,6 +103,8 @@ struct cuoptamd_solver {
   } best_quality;
   bool have_best = false, maximize = false;
   cuoptamd_result best_result{};
+  bool have_accepted = false;  // settings.accept_tolerance: first iterate that met the looser set (snapshot = best buffers)
+  cuoptamd_result accepted_result{};
   std::string log_path;
   pdlpdev_ctl ctl{};
   Convergence conv_current, conv_average;
@@ -174,6 +176,22 @@ Convergence to_convergence(const cuoptamd_solver* s, const double* ev)
 
 // check_termination_criteria_kernel (termination_strategy.cu:116-250): Optimal, PrimalFeasible, or
 // "keep going" (which the reference encodes as NumericalError)
+// Optimal by the looser acceptance tolerances (cuoptamd_settings::accept_tolerance)?  Same three inequalities.
+bool accepted_by_looser(const cuoptamd_solver* s, const Convergence& c)
+{
+  const double* a = s->S.accept_tolerance;
+  const bool gap_ok = c.gap <= a[0] + a[1] * c.abs_objective;
+  bool primal_ok, dual_ok;
+  if (s->S.per_constraint_residual) {
+    primal_ok = c.linf_rel_primal_residual <= a[2];
+    dual_ok   = c.linf_rel_dual_residual <= a[4];
+  } else {
+    primal_ok = c.l2_primal_residual <= a[2] + a[3] * s->norm_b;
+    dual_ok   = c.l2_dual_residual <= a[4] + a[5] * s->norm_c;
+  }
+  return gap_ok && primal_ok && dual_ok;
+}
+
 int verdict(const cuoptamd_solver* s, const Convergence& c)
 {
   const cuoptamd_settings& t = s->S;
@@ -359,6 +377,17 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
       s->have_best   = true;
     }
   }
+  if (!done && s->S.accept_enabled && !s->S.save_best_primal_so_far && !s->have_accepted && s->total_iterations > 1) {
+    const bool ac = accepted_by_looser(s, s->conv_current), aa = accepted_by_looser(s, s->conv_average);
+    if (ac || aa) {
+      const int aw = (ac && aa) ? (kkt_score(s->conv_current, w) < kkt_score(s->conv_average, w) ? PDLPDEV_CURRENT : PDLPDEV_AVERAGE)
+                                : (aa ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT);
+      DEV(pdlpdev_save_best(dev, aw));
+      fill_result(s, kOptimal, aw);
+      s->accepted_result = s->result;
+      s->have_accepted   = true;
+    }
+  }
   if (s->total_iterations % 1000 == 0) log_iteration(s, s->conv_current);  // pdlp.cu:798
   if (!done) {  // check_limits, pdlp.cu:264-331 (time first, then iterations)
     const double tl = s->S.time_limit;
@@ -376,6 +405,16 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
       s->result.status               = status;
       s->result.num_restarts         = nr;
       s->result.num_major_iterations = nm;
+      s->returned_which              = PDLPDEV_BEST;
+    } else if ((status == kTimeLimit || status == kIterationLimit) && s->have_accepted) {
+      const int nr = s->result.num_restarts, nm = s->result.num_major_iterations;
+      const int steps = s->ctl.steps_taken, attempts = s->ctl.attempts;
+      s->result                      = s->accepted_result;  // Optimal at the tolerances the caller asked for
+      s->result.num_restarts         = nr;
+      s->result.num_major_iterations = nm;
+      s->result.steps_taken          = steps;  // the work that was done, not the moment of acceptance
+      s->result.attempted_steps      = attempts;
+      s->result.accepted_at_looser_tolerances = 1;
       s->returned_which              = PDLPDEV_BEST;
     } else {
       fill_result(s, status, which);
@@ -561,6 +600,8 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->log_to_console              = 0;
   s->log_file                    = nullptr;
   s->unbounded_from_feasible_iterates = 0;
+  s->accept_enabled                   = 0;
+  for (double& t : s->accept_tolerance) t = 1e-4;
 }
 
 void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
@@ -799,6 +840,7 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
   s->best_quality = cuoptamd_solver::Quality{};
   s->best_quality.objective = s->maximize ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
   s->have_best = false, s->best_result = blank;
+  s->have_accepted = false, s->accepted_result = blank;
   s->conv_current = Convergence{}, s->conv_average = Convergence{};
   s->returned_which = PDLPDEV_CURRENT, s->finished = false, s->warm_started = false, s->started = false;
   s->result = blank;
@@ -830,6 +872,7 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
     log_line(s, "   Iter    Primal Obj.      Dual Obj.    Gap        Primal Res.  Dual Res.   Time\n");  // pdlp.cu:1077-1080
   }
   auto leave = [&](int rc) {
+    s->result.gpus = s->world;
     s->result.loop_seconds += seconds_since(t0);
     if (result) *result = s->result;
     return rc;
@@ -906,6 +949,57 @@ int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, doubl
   }
   if (y && s->world > 1) std::fill(y, y + s->m_global, 0.0);  // other ranks' rows stay 0
   DEV(pdlpdev_get_solution(s->dev, s->returned_which, x, y ? y + s->row_begin : nullptr, rc));
+  return 0;
+}
+
+int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, const cuoptamd_settings* settings,
+                           int gpus, int soft_communicator, cuoptamd_result* result, double* x, double* y, double* rc)
+{
+  if (!lp || !hyper || !settings || !result) return fail(-1, "cuoptamd_solve_sharded: null argument");
+  if (gpus < 1 || gpus > 16) return fail(-1, "cuoptamd_solve_sharded: 1..16 row blocks");
+  if (!soft_communicator && pdlpdev_device_count() < gpus)
+    return fail(-5, "cuoptamd_solve_sharded: %d GPUs requested, %d visible (there is no CPU fallback)", gpus,
+                pdlpdev_device_count());
+  uint8_t id[128];
+  if (soft_communicator) {
+    if (pdlpdev_softcomm_create(gpus, id) != 0) return fail(-6, "%s", pdlpdev_last_error());
+  } else {
+    if (pdlpdev_comm_unique_id(id) != 0) return fail(-6, "%s", pdlpdev_last_error());
+  }
+  struct Rank {
+    int rc = 0;
+    std::string error;
+    cuoptamd_result res{};
+  };
+  std::vector<Rank> ranks(gpus);
+  if (y) std::fill(y, y + lp->m, 0.0);
+  std::vector<std::thread> pool;
+  for (int g = 0; g < gpus; ++g)
+    pool.emplace_back([&, g] {
+      Rank& me = ranks[g];
+      cuoptamd_settings st = *settings;
+      if (g != 0) st.log_to_console = 0, st.log_file = nullptr;  // one voice
+      cuoptamd_solver* solver = nullptr;
+      me.rc = cuoptamd_solver_create(&solver, lp, hyper, &st, nullptr, nullptr, soft_communicator ? 0 : g, g, gpus, id);
+      if (me.rc == 0) me.rc = cuoptamd_solver_advance(solver, std::numeric_limits<int32_t>::max(), &me.res);
+      if (me.rc == 0) {
+        // every rank holds the same x and reduced costs (replicated primal side) and ITS rows of y
+        std::vector<double> yl(y ? (size_t)lp->m : 0);
+        me.rc = cuoptamd_solver_get_solution(solver, g == 0 ? x : nullptr, y ? yl.data() : nullptr, g == 0 ? rc : nullptr);
+        if (me.rc == 0 && y) {
+          int32_t r0 = 0, r1 = 0;
+          cuoptamd_solver_row_range(solver, &r0, &r1);
+          std::copy(yl.begin() + r0, yl.begin() + r1, y + r0);
+        }
+      }
+      if (me.rc != 0) me.error = cuoptamd_last_error();  // thread-local message: carry it to the caller's thread
+      cuoptamd_solver_destroy(solver);
+    });
+  for (auto& t : pool) t.join();
+  for (int g = 0; g < gpus; ++g)
+    if (ranks[g].rc != 0) return fail(ranks[g].rc, "rank %d of %d: %s", g, gpus, ranks[g].error.c_str());
+  *result      = ranks[0].res;
+  result->gpus = gpus;
   return 0;
 }
 

@@ -1,0 +1,39 @@
+/* Extensions of this library to the libcuopt C API (include/cuopt/linear_programming/cuopt_c.h mirrors the reference's
+ * 41 functions unchanged; nothing here exists in NVIDIA/cuopt).
+ *
+ * Extra parameters accepted by cuOptSetIntegerParameter / cuOptGetIntegerParameter:
+ *   CUOPT_AMD_NUM_GPUS       row blocks of one solve, one GPU each, inside the calling process (RCCL over xGMI).
+ *                            0 (default) = the CUOPT_AMD_NUM_GPUS environment variable, else 1.
+ *   CUOPT_AMD_SIMPLEX_GRADE  1 / 0: serve Concurrent / DualSimplex requests on small LPs (<= 1e5 nonzeros) at
+ *                            simplex-grade tolerances (1e-8) with the requested tolerances as acceptance set
+ *                            (cuoptamd_settings::accept_tolerance).  -1 (default) = the CUOPT_AMD_SIMPLEX_GRADE
+ *                            environment variable, else on.
+ */
+#ifndef CUOPT_AMD_CUOPT_C_EXT_H
+#define CUOPT_AMD_CUOPT_C_EXT_H
+
+#include "cuopt/linear_programming/cuopt_c.h"
+#include "cuopt_amd/pdlp_solver.h"
+
+#define CUOPT_AMD_NUM_GPUS "amd_num_gpus"
+#define CUOPT_AMD_SIMPLEX_GRADE "amd_simplex_grade"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* full PDLP statistics of an LP solution (the reference exposes additional_termination_information_t through its
+ * C++ / Python API only: cpp/include/cuopt/linear_programming/pdlp/solver_solution.hpp:63-103) */
+cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats);
+
+/* which engine / attempt answered the request, as one JSON object:
+ * {"engine": "pdlp", "requested_method": "Concurrent|DualSimplex|PDLP", "crossover_requested": bool,
+ *  "simplex_grade_emulation": bool, "answered_by": "...", "gpus": N, "iterations": K}
+ * (the reference runs dual simplex / crossover for such requests, LP/solve.cu:383-443,467-547; this library has one
+ * engine and says so instead of pretending) */
+cuopt_int_t cuOptAmdGetSolveInfo(cuOptSolution solution, char* buffer, cuopt_int_t buffer_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -109,6 +109,15 @@ typedef struct cuoptamd_settings {
    * unless strict).  Default 0 = the reference's PDLP; cuOptSolve sets it for Concurrent / DualSimplex requests, where
    * the reference's simplex would return UNBOUNDED. */
   int32_t unbounded_from_feasible_iterates;
+  /* A second, looser tolerance set (abs gap, rel gap, abs primal, rel primal, abs dual, rel dual).  When enabled, the
+   * first iterate seen at a major iteration that is Optimal by THESE tolerances is kept; if the run then ends on an
+   * iteration or time limit before the main tolerances are met, the kept iterate is returned with status Optimal
+   * (cuoptamd_result::accepted_at_looser_tolerances = 1).  cuOptSolve uses it for Concurrent / DualSimplex requests
+   * on small LPs: the main tolerances are simplex-grade (1e-8), the looser set is what the caller asked for, so the
+   * caller's limits are honoured exactly as the reference's Concurrent mode would.  Ignored when
+   * save_best_primal_so_far is set (same snapshot buffers). */
+  int32_t accept_enabled;
+  double accept_tolerance[6];
 } cuoptamd_settings;
 
 /* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */
@@ -129,7 +138,17 @@ typedef struct cuoptamd_result {
   double norm_b, norm_c;
   double setup_seconds; /* transpose + upload + scaling + initial step/weight */
   double loop_seconds;  /* accumulated time inside cuoptamd_solver_advance */
+  int32_t accepted_at_looser_tolerances; /* 1: the returned point is the one kept under settings.accept_tolerance */
+  int32_t gpus;                          /* row blocks the LP was sharded into (1 = single GPU) */
 } cuoptamd_result;
+
+/* Row-block sharded solve inside ONE process: `gpus` host threads, one solver per visible device
+ * (device g for rank g), row blocks balanced by nonzeros, RCCL all-reduce over xGMI (ncclCommInitRank from every thread
+ * with one unique id).  Returns rank 0's statistics, the replicated primal solution / reduced costs and the GATHERED
+ * dual solution (y has lp->m entries).  `soft_communicator` != 0 runs all ranks on device 0 through the in-process
+ * communicator instead of RCCL (verification on a single-GPU box; not a production mode). */
+int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, const cuoptamd_settings* settings,
+                           int gpus, int soft_communicator, cuoptamd_result* result, double* x, double* y, double* rc);
 
 /* pdlp_warm_start_data_t (cpp/include/cuopt/linear_programming/pdlp/pdlp_warm_start_data.hpp:31-90):
  * the complete solver state at a terminating major iteration.  Vectors are CALLER-allocated host arrays

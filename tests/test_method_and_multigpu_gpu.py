@@ -1,0 +1,126 @@
+"""GPU: how cuOptSolve serves requests the reference would hand to its dual simplex (Concurrent = default, DualSimplex,
+crossover: LP/solve.cu:383-443,467-547) and the single-process multi-GPU path (SURVEY 8(e)) behind the same call.
+
+This library has one engine (PDLP).  Non-PDLP methods on small LPs run at simplex-grade tolerances with the caller's own
+tolerances as the acceptance set, so the caller's iteration / time limits behave as in the reference's Concurrent mode;
+CUOPT_AMD_SIMPLEX_GRADE=0 / "amd_simplex_grade" = 0 switches the emulation off; cuOptAmdGetSolveInfo says what happened."""
+import numpy as np
+import pytest
+
+from cuopt_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+INF = float("inf")
+
+
+def ranged_lp():  # c_api_test.c:761-873, optimum 32
+    return dict(m=3, n=2, offsets=[0, 2, 4, 6], indices=[0, 1, 0, 1, 0, 1], values=[2.0, 3.0, 3.0, 1.0, 1.0, 2.0],
+                c=[5.0, 8.0], lo=[-INF, -INF, 2.0], hi=[12.0, 6.0, 8.0], lb=[0.0, 0.0], ub=[10.0, 10.0], maximize=True)
+
+
+def test_solve_info_names_the_engine_and_the_attempt():
+    r = capi.solve(ranged_lp(), method=2, crossover=True)  # DualSimplex + crossover requested
+    info = r["solve_info"]
+    assert info["engine"] == "pdlp" and info["requested_method"] == "DualSimplex" and info["crossover_requested"] is True
+    assert info["simplex_grade_emulation"] is True and info["answered_by"] == "simplex_grade_1e-8" and info["gpus"] == 1
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(32.0, abs=1e-5)
+    r = capi.solve(ranged_lp(), method=1)
+    assert r["solve_info"]["simplex_grade_emulation"] is False and r["solve_info"]["answered_by"] == "requested_tolerances"
+
+
+def test_simplex_grade_opt_out(monkeypatch):
+    on = capi.solve(ranged_lp())
+    monkeypatch.setenv("CUOPT_AMD_SIMPLEX_GRADE", "0")
+    off = capi.solve(ranged_lp())
+    assert on["solve_info"]["simplex_grade_emulation"] is True and off["solve_info"]["simplex_grade_emulation"] is False
+    assert off["status"] == on["status"] == "Optimal"
+    assert off["steps_taken"] <= on["steps_taken"]
+    assert off["steps_taken"] == capi.solve(ranged_lp(), method=1)["steps_taken"]  # exactly a PDLP request
+    monkeypatch.delenv("CUOPT_AMD_SIMPLEX_GRADE")
+    again = capi.solve(ranged_lp(), amd_simplex_grade=0)  # the parameter beats the environment default
+    assert again["solve_info"]["simplex_grade_emulation"] is False
+
+
+def test_default_method_honours_the_callers_iteration_limit():
+    """ADVICE r1: with iteration_limit <= the emulation's budget the tight attempt used to eat the whole limit and return
+    IterationLimit although the requested 1e-4 had been met long before.  The acceptance set keeps that iterate."""
+    p = synthetic.generate(400, 300, 6, seed=9, hard=True)
+    plain = capi.solve(p, method=1)  # what PDLP needs at 1e-4
+    assert plain["status"] == "Optimal"
+    limit = plain["steps_taken"] + 200  # enough for 1e-4, far too little for 1e-8 on this badly scaled LP
+    tight = capi.solve(p, method=1, tol=1e-8, iteration_limit=limit)
+    assert tight["status"] == "IterationLimit"
+    r = capi.solve(p, iteration_limit=limit)  # default method (Concurrent)
+    assert r["status"] == "Optimal" and r["accepted_at_looser_tolerances"] == 1
+    assert r["solve_info"]["answered_by"] == "requested_tolerances_kept_during_simplex_grade_attempt"
+    assert r["steps_taken"] <= limit
+    scale = 1 + abs(p["objective_star"])
+    assert abs(r["objective"] - p["objective_star"]) <= 5e-4 * scale
+    # the kept point is one that met the requested tolerances
+    assert r["relative_gap"] <= 1e-4 + 1e-12 and r["l2_relative_primal_residual"] <= 1e-4 + 1e-12
+
+
+def test_default_method_time_limit_falls_back_too():
+    p = synthetic.generate(400, 300, 6, seed=9, hard=True)
+    r = capi.solve(p, time_limit=0.0)
+    assert r["status"] == "TimeLimit"  # nothing was accepted yet: the limit status is reported as is
+    assert r["solve_info"]["answered_by"] in ("limit_reached_during_simplex_grade_attempt", "simplex_grade_1e-8")
+
+
+def test_large_default_request_keeps_the_reference_pdlp_defaults():
+    """> 1e5 nonzeros: no tightening, no forced infeasibility detection (ADVICE r1)"""
+    p = synthetic.generate(30000, 30000, 5, seed=3)
+    a = capi.solve(p)
+    b = capi.solve(p, method=1)
+    assert a["solve_info"]["simplex_grade_emulation"] is False
+    assert (a["status"], a["steps_taken"], a["objective"]) == (b["status"], b["steps_taken"], b["objective"])
+
+
+def _check_gathered_dual(p, r):
+    """where a reduced cost is reported it IS the dual residual c - A^T y of the unscaled problem (elsewhere the residual
+    is dual infeasibility and small): a gathered y with a block of zeros would satisfy neither"""
+    from oracle import orcbind
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    g = p["c"] - orcbind.spmv(to, ti, tv, r["y"])
+    z = r["reduced_cost"]
+    tol = 1e-9 * (1 + np.abs(p["c"]).max())
+    np.testing.assert_allclose(g[z != 0.0], z[z != 0.0], rtol=0, atol=tol)
+    assert np.abs(g[z == 0.0]).max() <= 1e-3 * (1 + np.abs(p["c"]).max())
+    bounds = np.linspace(0, p["m"], 9).astype(int)
+    assert all(np.any(r["y"][a:b] != 0.0) for a, b in zip(bounds[:-1], bounds[1:]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cuoptsolve_shards_over_gpus_through_the_in_process_communicator(world, monkeypatch):
+    """CUOPT_AMD_NUM_GPUS behind cuOptSolve; the in-process communicator stands in for RCCL on this one-GPU box"""
+    p = synthetic.generate(6000, 5000, 8, seed=61)
+    single = capi.solve(p, method=1, tol=1e-6)
+    monkeypatch.setenv("CUOPT_AMD_SOFT_COMMUNICATOR", "1")
+    r = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=world)
+    assert r["status"] == "Optimal" and r["gpus"] == world and r["solve_info"]["gpus"] == world
+    scale = 1 + abs(p["objective_star"])
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * scale
+    assert abs(r["objective"] - single["objective"]) <= 2e-5 * scale
+    _check_gathered_dual(p, r)
+    monkeypatch.setenv("CUOPT_AMD_NUM_GPUS", str(world))  # the environment spelling
+    e = capi.solve(p, method=1, tol=1e-6)
+    assert (e["gpus"], e["steps_taken"], e["objective"]) == (world, r["steps_taken"], r["objective"])
+
+
+def test_more_gpus_than_visible_is_a_loud_error(monkeypatch):
+    monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)
+    n = capi.device_count()
+    r = capi.solve(ranged_lp(), method=1, amd_num_gpus=min(n + 1, 16)) if n < 16 else None
+    if r is not None:
+        assert r["return_code"] == capi.CUOPT_RUNTIME_ERROR and "visible" in r["error_string"]
+
+
+@pytest.mark.skipif(capi.device_count() < 2, reason="needs two GPUs: RCCL with two ranks in one process")
+def test_rccl_two_ranks_in_one_process(monkeypatch):
+    monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)
+    p = synthetic.generate(6000, 5000, 8, seed=61)
+    single = capi.solve(p, method=1, tol=1e-6)
+    r = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=2)
+    assert r["status"] == "Optimal" and r["gpus"] == 2
+    assert abs(r["objective"] - single["objective"]) <= 2e-5 * (1 + abs(single["objective"]))
+    _check_gathered_dual(p, r)
