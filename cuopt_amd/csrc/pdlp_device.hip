@@ -1334,6 +1334,7 @@ struct TrPoint {
   const double* __restrict__ hi_u;
   int n, m;
   double wp, wd;
+  int first;  // 0, or n on the ranks of a sharded solve that leave the (replicated) primal part to rank 0
 };
 struct TrElem {
   double center, obj, lb, ub, w, dir, thr, grad, sub;  // grad: primal / dual gradient; sub: dual subgradient
@@ -1393,7 +1394,7 @@ __global__ void __launch_bounds__(kBlock) k_tr_stats(TrPoint P, int nbg, double*
   __shared__ double red[40];
   double sm[7] = {0, 0, 0, 0, 0, 0, 0}, mx[1] = {0.0};
   const int N = P.n + P.m;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+  for (int k = P.first + blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
     const TrElem e = tr_element(P, k);
     if (k < P.n) {
       const double d = (P.lrx[k] - P.xhat[k]) * P.dc[k];
@@ -1424,7 +1425,7 @@ __global__ void __launch_bounds__(kBlock) k_tr_pass(TrPoint P, double t, int nbg
   __shared__ double red[12];
   double sm[2] = {0.0, 0.0};
   const int N = P.n + P.m;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+  for (int k = P.first + blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
     const TrElem e = tr_element(P, k);
     if (e.dir == 0.0) continue;
     if (e.thr <= t) {
@@ -1447,7 +1448,7 @@ __global__ void __launch_bounds__(kBlock) k_tr_final(TrPoint P, double t, int nb
   __shared__ double red[12];
   double sm[2] = {0.0, 0.0};
   const int N = P.n + P.m;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+  for (int k = P.first + blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
     const TrElem e = tr_element(P, k);
     double tr      = e.center;
     if (e.dir != 0.0) tr = dmin(dmax(e.center + t * e.dir, e.lb), e.ub);
@@ -2827,7 +2828,6 @@ int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bo
 int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double out[4])
 {
   HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->comm) return fail(-7, "infeasibility detection is not available on the row-block sharded path yet");
   hipStream_t s = ctx->stream;
   const int n = ctx->n, m = ctx->m;
   const int gr = std::min(grid_for(m), kGenericBlocks), gc = std::min(grid_for(n), kGenericBlocks);
@@ -2835,6 +2835,11 @@ int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_b
   double* part_cols = ctx->part_g + 3 * 2048;  // 6 * gc  (part_g holds 8 * 2048)
   k_infeas_rows<<<gr, kBlock, 0, s>>>(m, gr, ctx->ctl, which, ctx->ax_u[which], ctx->y[0], ctx->y[1], ctx->avgy, ctx->dr, ctx->lo_u, ctx->hi_u, part_rows);
   k_finalize<<<1, kBlock, 0, s>>>(part_rows, gr, 3, 0x3u, ctx->scal + 16);
+  if (ctx->comm) {  // the rows are sharded: two maxima and one sum over the row blocks (infeasibility_information.cu:175-223);
+    LAUNCH_CHECK();  // the column side below works on replicated vectors (A^T y was all-reduced by the evaluation)
+    TRY(allreduce(ctx, ctx->scal + 16, 2, rccl::kMax));
+    TRY(allreduce(ctx, ctx->scal + 18, 1, rccl::kSum));
+  }
   k_infeas_cols<<<gc, kBlock, 0, s>>>(n, gc, ctx->ctl, which, ctx->aty_u[which], ctx->x[0], ctx->x[1], ctx->avgx, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, rc_rule_finite_bounds, part_cols);
   k_finalize<<<1, kBlock, 0, s>>>(part_cols, gc, 6, 0xFu, ctx->scal + 24);
   LAUNCH_CHECK();
@@ -2865,18 +2870,23 @@ int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double wp, double w
                                 double primal_weight, double radius, double out[6])
 {
   HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->comm) return fail(-7, "trust-region restart is not available on the row-block sharded path yet");
   TRY(fetch_ctl(ctx, nullptr));
   const int cur = ctx->ctl_h->cur;
   hipStream_t s = ctx->stream;
   TrPoint P{which == PDLPDEV_CURRENT ? ctx->x[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgx : ctx->lrx),
             which == PDLPDEV_CURRENT ? ctx->y[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgy : ctx->lry),
             ctx->lrx, ctx->lry, ctx->dc, ctx->dr, ctx->aty_u[which], ctx->ax_u[which], ctx->c_u, ctx->lb_u,
-            ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->n, ctx->m, wp, wd};
+            ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->n, ctx->m, wp, wd, (ctx->comm && ctx->rank != 0) ? ctx->n : 0};
+  // sharded: the dual coordinates are this rank's rows, the primal ones are replicated and counted by rank 0 only;
+  // every pass ends in a sum (and one max) over the ranks (pdlp_restart_strategy.cu:277-364 works on whole vectors)
   const int g = std::min(grid_for((int64_t)ctx->n + ctx->m), kGenericBlocks);
   k_tr_stats<<<g, kBlock, 0, s>>>(P, g, ctx->part_g);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 8, 0x80u, ctx->scal + 32);
   LAUNCH_CHECK();
+  if (ctx->comm) {
+    TRY(allreduce(ctx, ctx->scal + 32, 7, rccl::kSum));
+    TRY(allreduce(ctx, ctx->scal + 39, 1, rccl::kMax));
+  }
   HIP_TRY(hipMemcpyAsync(ctx->scal_h + 32, ctx->scal + 32, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   const double* st = ctx->scal_h + 32;
@@ -2895,6 +2905,7 @@ int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double wp, double w
       k_tr_pass<<<g, kBlock, 0, s>>>(P, t, g, ctx->part_g);
       k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 2, 0u, ctx->scal + 40);
       LAUNCH_CHECK();
+      if (ctx->comm) TRY(allreduce(ctx, ctx->scal + 40, 2, rccl::kSum));
       HIP_TRY(hipMemcpyAsync(ctx->scal_h + 40, ctx->scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       const double low = ctx->scal_h[40], high = ctx->scal_h[41];
@@ -2911,6 +2922,7 @@ int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double wp, double w
   k_tr_final<<<g, kBlock, 0, s>>>(P, t, g, ctx->part_g);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 2, 0u, ctx->scal + 40);
   LAUNCH_CHECK();
+  if (ctx->comm) TRY(allreduce(ctx, ctx->scal + 40, 2, rccl::kSum));
   HIP_TRY(hipMemcpyAsync(ctx->scal_h + 40, ctx->scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   out[0] = pd2, out[1] = dd2, out[2] = own, out[3] = lagrangian;

@@ -710,8 +710,6 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   if (world < 1 || rank < 0 || rank >= world) return fail(-1, "cuoptamd_solver_create: bad rank/world");
   if (hyper->restart_strategy == 2 && hyper->rescale_for_restart)
     return fail(-7, "trust-region restart is implemented for rescale_for_restart = false only (every preset that uses it)");
-  if (hyper->restart_strategy == 2 && world > 1)
-    return fail(-7, "trust-region restart (Methodical1) is single-GPU only");
   const auto t0 = clock_type::now();
   const bool timing = std::getenv("CUOPT_AMD_TIMING") != nullptr;
   auto lap = [&, last = t0](const char* what) mutable {
@@ -1006,24 +1004,31 @@ int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, c
 int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
 {
   if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_get_warm_start: null argument");
-  if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
+  // Sharded solver: the primal-side vectors are replicated, of the dual-side (m-sized) vectors this rank owns rows
+  // [row_begin, row_end): they land at their global positions, the other rows are zeroed -- the snapshots of all ranks
+  // add up to the full one (pdlp.cu:468-489 copies whole vectors).
   ws->n_variables = s->n, ws->n_constraints = s->m_global;
-  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_CURRENT, ws->current_primal_solution, ws->current_dual_solution, nullptr));
-  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_AVERAGE, ws->initial_primal_average, ws->initial_dual_average, nullptr));
+  const int64_t n = s->n, ml = s->row_end - s->row_begin;
+  auto own_rows = [&](double* v) -> double* {
+    if (!v) return nullptr;
+    if (s->world > 1) std::fill(v, v + s->m_global, 0.0);
+    return v + s->row_begin;
+  };
+  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_CURRENT, ws->current_primal_solution, own_rows(ws->current_dual_solution), nullptr));
+  DEV(pdlpdev_get_solution(s->dev, PDLPDEV_AVERAGE, ws->initial_primal_average, own_rows(ws->initial_dual_average), nullptr));
   auto get = [&](int id, double* dst, int64_t count) -> int {
     if (!dst) return 0;
     if (pdlpdev_download(s->dev, id, dst, count) != count) return fail(-2, "download failed: %s", pdlpdev_last_error());
     return 0;
   };
-  const int64_t n = s->n, m = s->m_global;
   int rc;
   if ((rc = get(PDLPDEV_BUF_X, ws->current_primal_solution_scaled, n))) return rc;
-  if ((rc = get(PDLPDEV_BUF_Y, ws->current_dual_solution_scaled, m))) return rc;
+  if ((rc = get(PDLPDEV_BUF_Y, own_rows(ws->current_dual_solution_scaled), ml))) return rc;
   if ((rc = get(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
   if ((rc = get(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
-  if ((rc = get(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;
+  if ((rc = get(PDLPDEV_BUF_SUM_Y, own_rows(ws->sum_dual_solutions), ml))) return rc;
   if ((rc = get(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
-  if ((rc = get(PDLPDEV_BUF_LAST_RESTART_Y, ws->last_restart_duality_gap_dual_solution, m))) return rc;
+  if ((rc = get(PDLPDEV_BUF_LAST_RESTART_Y, own_rows(ws->last_restart_duality_gap_dual_solution), ml))) return rc;
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
   ws->initial_primal_weight         = s->ctl.primal_weight;
   ws->initial_step_size             = s->ctl.step_size;
@@ -1040,27 +1045,28 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
 {
   if (!s || !ws || !s->dev) return fail(-1, "cuoptamd_solver_set_warm_start: null argument");
   if (s->started) return fail(-1, "cuoptamd_solver_set_warm_start: the solver has already been advanced");
-  if (s->world > 1) return fail(-7, "warm start snapshots are single-GPU only");
   if ((ws->n_variables != 0 && ws->n_variables != s->n) || (ws->n_constraints != 0 && ws->n_constraints != s->m_global))
     return fail(-1, "cuoptamd_solver_set_warm_start: the snapshot belongs to a %d x %d problem, this one is %d x %d",
                 ws->n_constraints, ws->n_variables, s->m_global, s->n);
   // iterate: unscaled in the snapshot -> scale_solutions (initial_scaling.cu:410-427), then the usual projection
-  DEV(pdlpdev_set_initial(s->dev, ws->current_primal_solution, ws->current_dual_solution));
+  // (a sharded solver takes the FULL snapshot and keeps its own rows of the m-sized vectors)
+  auto own_rows = [&](const double* v) -> const double* { return v ? v + s->row_begin : nullptr; };
+  DEV(pdlpdev_set_initial(s->dev, ws->current_primal_solution, own_rows(ws->current_dual_solution)));
   if (s->H.project_initial_primal) DEV(pdlpdev_project_primal(s->dev));
   auto put = [&](int id, const double* src, int64_t count) -> int {
     if (!src) return 0;
     if (pdlpdev_upload(s->dev, id, src, count) != count) return fail(-2, "upload failed: %s", pdlpdev_last_error());
     return 0;
   };
-  const int64_t n = s->n, m = s->m_global;
+  const int64_t n = s->n, ml = s->row_end - s->row_begin;
   int rc;
   if ((rc = put(PDLPDEV_BUF_X, ws->current_primal_solution_scaled, n))) return rc;  // bit-exact iterate if given
-  if ((rc = put(PDLPDEV_BUF_Y, ws->current_dual_solution_scaled, m))) return rc;
+  if ((rc = put(PDLPDEV_BUF_Y, own_rows(ws->current_dual_solution_scaled), ml))) return rc;
   if ((rc = put(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
   if ((rc = put(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
-  if ((rc = put(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions, m))) return rc;
+  if ((rc = put(PDLPDEV_BUF_SUM_Y, own_rows(ws->sum_dual_solutions), ml))) return rc;
   if ((rc = put(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
-  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_Y, ws->last_restart_duality_gap_dual_solution, m))) return rc;
+  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_Y, own_rows(ws->last_restart_duality_gap_dual_solution), ml))) return rc;
   DEV(pdlpdev_set_step(s->dev, ws->initial_step_size, ws->initial_primal_weight));
   DEV(pdlpdev_set_loop_state(s->dev, ws->sum_solution_weight, ws->iterations_since_last_restart, ws->total_pdhg_iterations));
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));

@@ -104,3 +104,78 @@ def test_sharded_ranks_stop_together_on_a_time_limit():
         assert (r["status_name"], r["steps_taken"], r["attempted_steps"]) == (first["status_name"], first["steps_taken"],
                                                                               first["attempted_steps"])
         np.testing.assert_array_equal(x, out[0][1])
+
+
+# ---- the parts of the path that were single-GPU only in round 1, now under sharding (world 4, in-process communicator) ------
+def test_sharded_infeasibility_detection_matches_single_rank():
+    """infeasibility_information.cu:175-223 on row blocks: two maxima and one sum over the ranks"""
+    from test_solve_gpu import infeasible_lp_of_the_c_api_test
+    p = infeasible_lp_of_the_c_api_test()
+    kw = dict(detect_infeasibility=1, tol=1e-6, iteration_limit=20000)
+    single = capi.Solver(p, **kw).advance()
+    assert single["status_name"] == "PrimalInfeasible"
+    out = run_sharded(p, 3, **kw)
+    for r, _, _, _ in out:
+        assert (r["status_name"], r["steps_taken"]) == (out[0][0]["status_name"], out[0][0]["steps_taken"])
+    assert out[0][0]["status_name"] == "PrimalInfeasible"
+    # (the single-rank solve of this 9 x 4 LP runs in the resident kernel, the sharded one through the launches: the
+    # iteration at which the certificate passes may differ, its value only in the low digits)
+    for k in ("max_dual_ray_infeasibility", "dual_ray_linear_objective"):
+        assert out[0][0][k] == pytest.approx(single[k], rel=1e-3, abs=1e-9)
+    # and a feasible LP is not flagged
+    q = synthetic.generate(3000, 2600, 9, seed=17)
+    ok = run_sharded(q, 4, detect_infeasibility=1, tol=1e-5)[0][0]
+    assert ok["status_name"] == "Optimal"
+
+
+def test_sharded_trust_region_restart_matches_single_rank():
+    """Methodical1 (pdlp_restart_strategy.cu:277-364) with the dual coordinates sharded: same decisions over the first
+    major iterations, same optimum"""
+    q = synthetic.generate(3000, 2600, 9, seed=17)
+    for its in (64, 128):
+        a = capi.Solver(q, mode=2, tol=0.0, iteration_limit=its).advance()
+        b = run_sharded(q, 4, mode=2, tol=0.0, iteration_limit=its)[0][0]
+        assert (a["steps_taken"], a["attempted_steps"], a["num_restarts"]) == (b["steps_taken"], b["attempted_steps"], b["num_restarts"])
+        assert b["primal_weight"] == pytest.approx(a["primal_weight"], rel=1e-8)
+    a = capi.Solver(q, mode=2, tol=1e-6).advance()
+    b = run_sharded(q, 4, mode=2, tol=1e-6)[0][0]
+    assert a["status_name"] == b["status_name"] == "Optimal"
+    assert abs(b["primal_objective"] - q["objective_star"]) <= 4e-5 * (1 + abs(q["objective_star"]))
+    assert 0.5 * a["steps_taken"] - 128 <= b["steps_taken"] <= 2.0 * a["steps_taken"] + 128
+
+
+def test_sharded_warm_start_snapshots_add_up_and_resume():
+    """pdlp.cu:468-489 / 131-181 under sharding: every rank's snapshot carries its rows of the dual-side vectors, the
+    snapshots add up to the full one, and a sharded solve resumed from the sum needs exactly the remaining iterations"""
+    p = synthetic.generate(4000, 3500, 8, seed=31)
+    world, coarse, fine = 4, 1e-1, 1e-2
+    full = run_sharded(p, world, tol=fine)[0][0]
+    cid = capi.softcomm_id(world)
+    snaps, res, err = [None] * world, [None] * world, []
+
+    def first(rank):
+        try:
+            s = capi.Solver(p, rank=rank, world=world, comm_id=cid, tol=coarse)
+            res[rank] = s.advance()
+            snaps[rank] = (s.get_warm_start(), s.row_range())
+            s.close()
+        except Exception as e:
+            err.append(e)
+    ts = [threading.Thread(target=first, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    assert not err, err
+    merged = dict(snaps[0][0])
+    for k in capi.WarmStart.DUAL:
+        total = np.zeros(p["m"])
+        for ws, (r0, r1) in snaps:
+            assert not np.any(ws[k][:r0]) and not np.any(ws[k][r1:])  # only its own rows
+            total += ws[k]
+        merged[k] = total
+    for k in capi.WarmStart.PRIMAL:
+        for ws, _ in snaps:
+            np.testing.assert_array_equal(ws[k], snaps[0][0][k])  # replicated
+    second = run_sharded(p, world, tol=fine, warm_start=merged)[0][0]
+    assert full["status_name"] == res[0]["status_name"] == second["status_name"] == "Optimal"
+    assert res[0]["steps_taken"] + second["steps_taken"] == full["steps_taken"]
+    assert second["primal_objective"] == full["primal_objective"]
