@@ -2643,7 +2643,12 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   int guard = 0;
   while (ctx->ctl_h->error == 0 && ctx->ctl_h->steps_taken < target_steps) {
     int remaining = target_steps - ctx->ctl_h->steps_taken;
-    if (ctx->use_graph && !ctx->comm) {
+    // Sharded solves enqueue plain launches: capturing the RCCL all-reduce into the attempt graph was tried
+    // (CUOPT_AMD_GRAPH_COMM=1 enables it) and the process died inside the capture with the RCCL 2.26 that PyTorch
+    // bundles (one rank, ROCm 7.2) -- left off until it can be exercised on a multi-GPU node.  The in-process
+    // communicator synchronises on the host and can never be captured.
+    static const bool graph_comm = getenv("CUOPT_AMD_GRAPH_COMM") && atoi(getenv("CUOPT_AMD_GRAPH_COMM")) == 1;
+    if (ctx->use_graph && (!ctx->comm || (graph_comm && !ctx->soft))) {
       while (remaining > 0) {
         int chunk = 1;
         while (chunk * 2 <= remaining && chunk < 64) chunk *= 2;
