@@ -323,6 +323,15 @@ std::string validate(const Problem& p)
   return "";
 }
 
+// Inputs may be host or device arrays (reference: cuopt_c.cpp:119, raft::copy at :261-403); the problem object is
+// host-resident here, so device arrays are copied down once (pdlpdev_copy_in asks the HIP runtime what the pointer is).
+template <class T>
+void fetch(std::vector<T>& dst, const T* src, size_t count)
+{
+  dst.resize(count);
+  if (count && pdlpdev_copy_in(dst.data(), src, count * sizeof(T)) != 0) throw std::runtime_error(pdlpdev_last_error());
+}
+
 int create_common(Problem* p, cuopt_int_t m, cuopt_int_t n, cuopt_int_t sense, double offset,
                   const double* c, const cuopt_int_t* off, const cuopt_int_t* idx, const double* val,
                   const double* lb, const double* ub, const char* types)
@@ -331,16 +340,18 @@ int create_common(Problem* p, cuopt_int_t m, cuopt_int_t n, cuopt_int_t sense, d
   p->m = m, p->n = n;
   p->maximize         = sense == CUOPT_MAXIMIZE;
   p->objective_offset = offset;
-  p->c.assign(c, c + n);
-  p->offsets.assign(off, off + m + 1);
-  const int64_t nnz = off[m];
+  fetch(p->c, c, (size_t)n);
+  fetch(p->offsets, off, (size_t)m + 1);
+  const int64_t nnz = p->offsets[m];
   if (nnz < 0) return CUOPT_INVALID_ARGUMENT;
-  p->indices.assign(idx, idx + nnz);
-  p->values.assign(val, val + nnz);
-  p->lb.assign(lb, lb + n);
-  p->ub.assign(ub, ub + n);
+  fetch(p->indices, idx, (size_t)nnz);
+  fetch(p->values, val, (size_t)nnz);
+  fetch(p->lb, lb, (size_t)n);
+  fetch(p->ub, ub, (size_t)n);
+  std::vector<char> t;
+  fetch(t, types, (size_t)n);
   p->var_types.resize(n);
-  for (int32_t j = 0; j < n; ++j) p->var_types[j] = types[j] == CUOPT_CONTINUOUS ? CUOPT_CONTINUOUS : CUOPT_INTEGER;
+  for (int32_t j = 0; j < n; ++j) p->var_types[j] = t[j] == CUOPT_CONTINUOUS ? CUOPT_CONTINUOUS : CUOPT_INTEGER;
   return CUOPT_SUCCESS;
 }
 
@@ -403,13 +414,13 @@ cuopt_int_t cuOptCreateProblem(cuopt_int_t num_constraints, cuopt_int_t num_vari
                            constraint_matrix_column_indices, constraint_matrix_coefficent_values,
                            lower_bounds, upper_bounds, variable_types);
     if (rc != CUOPT_SUCCESS) return rc;
-    p->row_types.assign(constraint_sense, constraint_sense + num_constraints);
-    p->rhs.assign(rhs, rhs + num_constraints);
+    fetch(p->row_types, constraint_sense, (size_t)num_constraints);
+    fetch(p->rhs, rhs, (size_t)num_constraints);
     p->lo.resize(num_constraints), p->hi.resize(num_constraints);
     for (int32_t i = 0; i < num_constraints; ++i) {  // set_constraint_bounds_if_not_set, problem_helpers.cuh:33-58
-      const char t = constraint_sense[i];
-      p->lo[i]     = (t == 'E' || t == 'G') ? rhs[i] : -kInf;
-      p->hi[i]     = (t == 'E' || t == 'L') ? rhs[i] : kInf;
+      const char t = p->row_types[i];
+      p->lo[i]     = (t == 'E' || t == 'G') ? p->rhs[i] : -kInf;
+      p->hi[i]     = (t == 'E' || t == 'L') ? p->rhs[i] : kInf;
     }
     *problem_ptr = p.release();
   } catch (const std::exception&) {
@@ -443,8 +454,8 @@ cuopt_int_t cuOptCreateRangedProblem(cuopt_int_t num_constraints, cuopt_int_t nu
                            constraint_matrix_column_indices, constraint_matrix_coefficients,
                            variable_lower_bounds, variable_upper_bounds, variable_types);
     if (rc != CUOPT_SUCCESS) return rc;
-    p->lo.assign(constraint_lower_bounds, constraint_lower_bounds + num_constraints);
-    p->hi.assign(constraint_upper_bounds, constraint_upper_bounds + num_constraints);
+    fetch(p->lo, constraint_lower_bounds, (size_t)num_constraints);
+    fetch(p->hi, constraint_upper_bounds, (size_t)num_constraints);
     *problem_ptr = p.release();
   } catch (const std::exception&) {
     return CUOPT_INVALID_ARGUMENT;

@@ -136,6 +136,40 @@ __global__ void __launch_bounds__(256) k_combine(Peers peers, int world, size_t 
 }
 }  // namespace softcomm
 
+// ---- roctx ranges (the reference marks every phase with NVTX: LP/pdhg.cu:75,168,241, LP/pdlp.cu:541,1227) --------------
+// bound lazily like RCCL: without the library (or with CUOPT_AMD_ROCTX=0) the calls are no-ops
+namespace roctx {
+static int (*Push)(const char*) = nullptr;
+static int (*Pop)()             = nullptr;
+static std::once_flag once;
+static void load()
+{
+  std::call_once(once, [] {
+    const char* env = getenv("CUOPT_AMD_ROCTX");
+    if (env && atoi(env) == 0) return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        Push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        Pop  = (int (*)())dlsym(h, "roctxRangePop");
+        if (Push && Pop) return;
+        Push = nullptr, Pop = nullptr;
+      }
+    }
+  });
+}
+struct Range {
+  explicit Range(const char* name)
+  {
+    load();
+    if (Push) Push(name);
+  }
+  ~Range()
+  {
+    if (Pop) Pop();
+  }
+};
+}  // namespace roctx
+
 // ================================================================================================
 // context
 // ================================================================================================
@@ -1946,6 +1980,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
                               void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
                               const double* hi, const double* lb, const double* ub)
 {
+  roctx::Range range("pdlp: device set-up (upload, layouts)");
   if (!out || m < 0 || n < 0 || !a_offsets || !at_offsets) return fail(-1, "pdlpdev_create: bad argument");
   if (pdlpdev_device_count() <= device)
     return fail(-5, "pdlpdev_create: no HIP device %d visible (this solver has no CPU fallback)", device);
@@ -2211,6 +2246,7 @@ static int fetch_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* out)
 // ---- setup ----------------------------------------------------------------------------------------
 int pdlpdev_scaling_compute(pdlpdev_ctx* ctx, int do_ruiz, int ruiz_iterations, int do_pc, double alpha)
 {
+  roctx::Range range("pdlp: Ruiz + Pock-Chambolle scaling");
   HIP_TRY(hipSetDevice(ctx->device));
   const int m = ctx->m, n = ctx->n;
   hipStream_t s = ctx->stream;
@@ -2616,6 +2652,7 @@ static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
 
 int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
 {
+  roctx::Range range("pdlp: PDHG attempts");
   HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->small_resident && !ctx->comm) {
     // one launch runs attempts until the target is reached (rejected attempts included); the cap only bounds
@@ -2665,6 +2702,35 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   }
   if (ctl) *ctl = *ctx->ctl_h;
   return 0;
+}
+
+// The reference accepts host OR device arrays at the C API (cuopt_c.cpp:119,261-403 copy with raft::copy).  The
+// front end (plain C++, no HIP header) asks here: device / managed memory is copied down, anything else -- also when no
+// HIP device or runtime is usable -- is an ordinary host pointer.
+int pdlpdev_copy_in(void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0) return 0;
+  if (!dst || !src) return fail(-1, "pdlpdev_copy_in: null pointer");
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  const hipError_t e = hipPointerGetAttributes(&attr, src);
+  if (e == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  (void)hipGetLastError();  // "invalid value" for plain host memory is the normal case
+  memcpy(dst, src, bytes);
+  return 0;
+}
+
+void pdlpdev_range_push(const char* name)
+{
+  roctx::load();
+  if (roctx::Push) roctx::Push(name);
+}
+void pdlpdev_range_pop(void)
+{
+  if (roctx::Pop) roctx::Pop();
 }
 
 int pdlpdev_prepare_graphs(pdlpdev_ctx* ctx)
@@ -2800,6 +2866,7 @@ int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double 
 int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bounds, double eps_rel_primal,
                        double eps_rel_dual, double out_current[PDLPDEV_EV_COUNT], double out_average[PDLPDEV_EV_COUNT])
 {
+  roctx::Range range("pdlp: major iteration evaluation (averages + convergence information)");
   HIP_TRY(hipSetDevice(ctx->device));
   const bool want_linf = eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0;
   if (ctx->small_resident && !ctx->comm) {

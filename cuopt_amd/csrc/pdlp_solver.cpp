@@ -296,8 +296,14 @@ const cuoptamd_solver::Quality& best_of(const cuoptamd_solver* s, const cuoptamd
 
 // One major iteration: averages, the two convergence evaluations, termination, limits, restart.
 // Sets *terminated when a solution must be returned.
+struct HostRange {  // roctx range of a host-side phase (LP/pdlp.cu:541,1227 are NVTX ranges in the reference)
+  explicit HostRange(const char* name) { pdlpdev_range_push(name); }
+  ~HostRange() { pdlpdev_range_pop(); }
+};
+
 int major_iteration(cuoptamd_solver* s, bool* terminated)
 {
+  HostRange range("pdlp: major iteration (termination + restart logic)");
   const cuoptamd_hyper& H = s->H;
   pdlpdev_ctx* dev        = s->dev;
   *terminated             = false;
@@ -706,6 +712,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
                            const double* init_y, int device, int rank, int world,
                            const uint8_t* comm_id)
 {
+  HostRange range("pdlp: solver set-up (partition, transpose, scaling, initial step)");
   if (!out || !lp || !hyper || !settings) return fail(-1, "cuoptamd_solver_create: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(-1, "cuoptamd_solver_create: bad rank/world");
   if (hyper->restart_strategy == 2 && hyper->rescale_for_restart)

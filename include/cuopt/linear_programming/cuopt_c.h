@@ -10,7 +10,8 @@
  * Scope of this implementation: continuous LPs are solved by the HIP PDLP solver
  * on gfx950.  Problems with integer variables are accepted by the builder and every getter, but
  * cuOptSolve reports CUOPT_VALIDATION_ERROR for them (MILP heuristics are out of scope).
- * All array arguments are HOST pointers; the library copies them at create time
+ * Array arguments of the create functions may be HOST or DEVICE (hipMalloc / managed) pointers, as in the reference
+ * (cuopt_c.cpp:119,261-403); the library copies them at create time
  * (reference: cuopt_c.cpp:103-140 copies with raft::copy, caller may free immediately).
  */
 #ifndef CUOPT_C_API_H

@@ -216,6 +216,12 @@ int pdlpdev_set_graph_mode(pdlpdev_ctx* ctx, int use_graph);
 /* instantiate every replay size (1, 2, ... 64 attempts) now instead of at first use (measurement: keeps graph
  * instantiation out of a timed region; a solve does not need it) */
 int pdlpdev_prepare_graphs(pdlpdev_ctx* ctx);
+/* roctx ranges for rocprofv3 --marker-trace (no-ops when the roctx library is absent or CUOPT_AMD_ROCTX=0); the device
+ * layer marks set-up, scaling, attempt batches and major-iteration evaluations itself, the host driver its phases */
+/* copy `bytes` from a caller pointer that may live in host OR device / managed memory into host memory */
+int pdlpdev_copy_in(void* dst, const void* src, size_t bytes);
+void pdlpdev_range_push(const char* name);
+void pdlpdev_range_pop(void);
 
 /* ---- major iteration -------------------------------------------------------------------------- */
 /* adds a still-pending accepted iterate to the running sums */

@@ -103,26 +103,30 @@ def test_one_pdhg_attempt_bit_exact(tiny):
     rng = np.random.default_rng(2)
     x0 = np.abs(rng.standard_normal(p["n"]))
     y0 = rng.standard_normal(p["m"])
-    step, w = 0.05, 1.3
-    dev = capi.Device(p)
-    dev.call("set_initial", capi._ptr(x0), capi._ptr(y0))
-    dev.call("set_step", step, w)
-    dev.call("compute_aty")
-    ctl = dev.run(1)
-    assert ctl.attempts >= 1
     to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
-    x, y = x0.copy(), y0.copy()
     L = orcbind.lib()
     P = orcbind._p
     offs, idx, val = (np.ascontiguousarray(p[k]) for k in ("offsets", "indices", "values"))
-    L.orc_pdhg_fixed_steps(p["m"], p["n"], P(offs), P(idx), P(val), P(to), P(ti), P(tv), P(p["c"]), P(p["lo"]),
-                           P(p["hi"]), P(p["lb"]), P(p["ub"]), step / w, step * w, 1, P(x), P(y))
-    if ctl.attempts == 1 and ctl.steps_taken == 1:  # accepted at once: the new iterate is `current`
-        np.testing.assert_array_equal(dev.download("X", p["n"]), x)
-        np.testing.assert_array_equal(dev.download("Y", p["m"]), y)
-        np.testing.assert_array_equal(dev.download("ATY", p["n"]), orcbind.spmv(to, ti, tv, y))
-    else:
-        pytest.skip("first trial step rejected for this seed; covered by the full-solve parity tests")
+    w = 1.3
+    for step in (0.05, 0.01, 0.002):
+        dev = capi.Device(p)
+        dev.call("set_initial", capi._ptr(x0), capi._ptr(y0))
+        dev.call("set_step", step, w)
+        dev.call("compute_aty")
+        ctl = dev.run(1)
+        assert ctl.attempts >= 1
+        if ctl.attempts != 1:
+            continue  # rejected and retried with a smaller step of the device's own choosing: try the next fixed step
+        x, y = x0.copy(), y0.copy()
+        L.orc_pdhg_fixed_steps(p["m"], p["n"], P(offs), P(idx), P(val), P(to), P(ti), P(tv), P(p["c"]), P(p["lo"]),
+                               P(p["hi"]), P(p["lb"]), P(p["ub"]), step / w, step * w, 1, P(x), P(y))
+        # accepted: the new iterate is `current`; rejected: the trial iterate sits in the other buffers
+        names = ("X", "Y", "ATY") if ctl.steps_taken == 1 else ("X_OTHER", "Y_OTHER", "ATY_OTHER")
+        np.testing.assert_array_equal(dev.download(names[0], p["n"]), x)
+        np.testing.assert_array_equal(dev.download(names[1], p["m"]), y)
+        np.testing.assert_array_equal(dev.download(names[2], p["n"]), orcbind.spmv(to, ti, tv, y))
+        return
+    pytest.fail("no single-attempt run to compare")
 
 
 def test_convergence_information_matches_oracle(tiny, golden_problems):

@@ -124,3 +124,55 @@ def test_rccl_two_ranks_in_one_process(monkeypatch):
     assert r["status"] == "Optimal" and r["gpus"] == 2
     assert abs(r["objective"] - single["objective"]) <= 2e-5 * (1 + abs(single["objective"]))
     _check_gathered_dual(p, r)
+
+
+def test_create_problem_from_device_arrays():
+    """the reference's C API accepts host or device arrays (cuopt_c.cpp:119, raft::copy at :261-403): a client that builds
+    its CSR in HIP memory hands the device pointers to cuOptCreateRangedProblem / cuOptCreateProblem"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    held = []
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), max(a.nbytes, 8)) == 0
+        assert hip.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        held.append(d)
+        return d
+
+    p = synthetic.generate(3000, 2600, 9, seed=12)
+    L = capi.lib
+    m, n = p["m"], p["n"]
+    dv = {k: to_device(np.asarray(p[k], dtype=(np.int32 if k in ("offsets", "indices") else np.float64)))
+          for k in ("c", "offsets", "indices", "values", "lo", "hi", "lb", "ub")}
+    types = to_device(np.frombuffer(b"C" * n, dtype=np.uint8))
+    prob = C.c_void_p()
+    fn = L.cuOptCreateRangedProblem
+    saved = fn.argtypes
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double] + [C.c_void_p] * 9 + [C.POINTER(C.c_void_p)]
+    try:
+        rc = fn(m, n, capi.CUOPT_MINIMIZE, 0.0, dv["c"], dv["offsets"], dv["indices"], dv["values"], dv["lo"], dv["hi"],
+                dv["lb"], dv["ub"], types, C.byref(prob))
+    finally:
+        fn.argtypes = saved
+    assert rc == capi.CUOPT_SUCCESS
+    # what the library holds equals the host originals ...
+    got = np.zeros(len(p["values"]))
+    off, idx = np.zeros(m + 1, np.int32), np.zeros(len(p["indices"]), np.int32)
+    assert L.cuOptGetConstraintMatrix(prob, capi._ptr(off), capi._ptr(idx), capi._ptr(got)) == 0
+    np.testing.assert_array_equal(got, p["values"])
+    np.testing.assert_array_equal(off, p["offsets"])
+    np.testing.assert_array_equal(idx, p["indices"])
+    # ... and solves to the same result as the host-built problem
+    wrapped = capi.Problem(prob)
+    r_dev = capi.solve(wrapped, method=1, tol=1e-6)
+    r_host = capi.solve(p, method=1, tol=1e-6)
+    assert r_dev["status"] == "Optimal"
+    assert (r_dev["steps_taken"], r_dev["objective"]) == (r_host["steps_taken"], r_host["objective"])
+    L.cuOptDestroyProblem(C.byref(prob))
+    for d in held:
+        hip.hipFree(d)
