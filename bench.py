@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
@@ -111,12 +111,15 @@ def main():
         dist.broadcast(buf, 0)
         comm_id = bytes(buf.cpu().numpy().tobytes())
 
+    structured = args.workload in ("staircase", "block_angular", "powerlaw")
     if args.workload == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)
+    elif structured:
+        cfg = dict(kind=args.workload, m=1_000_000, n=1_000_000, k=10, seed=7)
     else:
         cfg = dict(synthetic.CONFIGS[args.workload])
     t_gen = time.time()
-    p = synthetic.generate(**cfg)
+    p = synthetic.generate_structured(**cfg) if structured else synthetic.generate(**cfg)
     t_gen = time.time() - t_gen
     m, n, nnz = p["m"], p["n"], int(len(p["values"]))
 
@@ -245,9 +248,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
             "ms_per_step": round(1e3 * elapsed / timed_steps, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, CSR fp64/int32, "
+            "config": {"workload": "%s: synthetic %s sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, longest row %d, CSR fp64/int32, "
                                    "Stable2 preset, tolerances 0 (fixed iteration budget)"
-                                   % (args.workload, m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""), nnz),
+                                   % (args.workload, "structured (cuopt_amd/synthetic.py generate_structured)" if structured else "random",
+                                      m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""),
+                                      nnz, int(np.diff(p["offsets"]).max())),
                        "rows": m, "cols": n, "nnz": nnz,
                        "parallelism": "row-block x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,

@@ -1831,7 +1831,7 @@ static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, c
   HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &dst->val, h.nent + 8));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's JagHost
-  dst->v    = JagView{h.rows, h.G, h.ngroups, h.nblk, tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};
+  dst->v    = JagView{h.rows, h.G, h.ngroups, h.nblk, (int)h.lr_row.size(), tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};
   dst->nent = (int64_t)h.nent;
   dst->on   = true;
   return 0;
@@ -1871,7 +1871,7 @@ static int jag_launch(pdlpdev_ctx* c, void (*kernel)(JagView, KArgs...), const J
       done.push_back(key);
     }
   }
-  launch_k(c, kernel, stream_grid(v.nblk), kJagThreads, kJagLdsBytes, v, args...);
+  launch_k(c, kernel, stream_grid(v.nblk + v.nlong), kJagThreads, kJagLdsBytes, v, args...);
   return 0;
 }
 
@@ -2099,8 +2099,8 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     if (small_env && atoi(small_env) != 0 && tier < 0)
       return fail(-1, "CUOPT_AMD_SMALL=1: the LP does not fit the resident kernel (m, n <= 2048, nnz <= 4096 ...)");
   }
-  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk : 0, 1})));
-  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk : 0, 1})));
+  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
+  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
@@ -2547,8 +2547,8 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 
 
 // launch helpers: pick the layout (jagged rows with LDS windows, slab-major panels, CSR stream)
-static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
-static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
+static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
+static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
 static void launch_a_dual(pdlpdev_ctx* ctx)
 {
   hipStream_t s = ctx->stream;

@@ -402,15 +402,29 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 #pragma unroll
     for (int q = 0; q < kPanelRowsPer; ++q) {
       const int r = threadIdx.x + q * kPanelThreads;
+      int a = 0, b = 0;
       if (r < nr) {
-        int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+        a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
         a = a > lo ? a : lo;
         b = b < hi ? b : hi;
-        if (a < b) {
-          double sum = psum[r];
-          for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
-          psum[r] = sum;
-        }
+      }
+      const bool is_long = b - a > kLongRow;
+      if (a < b && !is_long) {  // left to right by the row's lane: bit-identical to a sequential CSR sum
+        double sum = psum[r];
+        for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+        psum[r] = sum;
+      }
+      // a segment longer than kLongRow would keep ONE lane busy for thousands of dependent LDS reads: its wave sums it
+      // together instead (64 strided chains + the fixed butterfly; compared with a tolerance like every long row)
+      unsigned long long todo = __ballot(is_long);
+      while (todo) {
+        const int l  = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int la = __builtin_amdgcn_readlane(a, l), lb = __builtin_amdgcn_readlane(b, l);
+        double part  = 0.0;
+        for (int k = la + (int)(threadIdx.x & 63); k < lb; k += 64) part = part + prod[k - lo];
+        part = wave_reduce<SumOp>(part);
+        if ((int)(threadIdx.x & 63) == l) psum[r] = psum[r] + part;
       }
     }
     cur = nxt;
@@ -448,8 +462,8 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 //     of the pass that has one, contiguous -- lane <-> row, coalesced, no padding, no LDS staging of
 //     products and no barrier in the loop;
 //   * a lane adds up ITS row left to right in a register -> bit-identical to a sequential CSR sum;
-//   * rows longer than kLongRow are summed by their wave cooperatively from the CSR arrays (64
-//     strided chains + the fixed butterfly), like every long row of the other layouts;
+//   * rows longer than kLongRow get a workgroup each (appended to the grid): 512 strided chains + the
+//     fixed tree, read from the CSR arrays, like every long row of the other layouts;
 //   * the row sums go through the wave's LDS strip so that the fused epilogue runs in natural row
 //     order (coalesced streams whatever the sort did to the rows).
 // ------------------------------------------------------------------------------------------------
@@ -458,10 +472,11 @@ constexpr int kJagThreads  = kJagWaves * 64;
 constexpr int kJagWindow   = 8192;  // entries of the gathered vector staged per workgroup (64 KiB)
 constexpr int kJagMaxGroup = 256;   // rows per wave (2 KiB of row sums)
 constexpr int kJagU        = 8;     // jagged diagonals requested per round
+constexpr long long kJagNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
 constexpr size_t kJagLdsBytes = sizeof(double) * (size_t)(kJagWindow + kJagWaves * kJagMaxGroup);  // 80 KiB: two workgroups per CU
 
 struct JagView {
-  int rows, G, ngroups, nblk;
+  int rows, G, ngroups, nblk, nlong;  // workgroups: nblk of kJagWaves groups, then one per long row
   const int32_t* __restrict__ tile_e;   // ngroups + 1: first entry of each group
   const int32_t* __restrict__ tile_sr;  // ngroups + 1: first row descriptor of each group
   const uint16_t* __restrict__ sr;      // (length - 1) << 9 | row within the group, sorted by length
@@ -483,21 +498,51 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
   double* xwin   = jag_lds;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int blk  = xcd_remap(blockIdx.x, J.nblk);
-  if (blk >= J.nblk) return;
+  const int nparts = J.nblk + J.nlong;
+  const int blk    = xcd_remap(blockIdx.x, nparts);
+  if (blk >= nparts) return;
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+  if (blk >= J.nblk) {
+    // ---- a row longer than kLongRow: the whole workgroup strides over it (fixed tree, compared with a tolerance like
+    // every long row of the other layouts); such rows are spread over the grid instead of queueing up in one wave ----
+    const int r  = J.lr_row[blk - J.nblk];
+    const int k0 = J.off[r], k1 = J.off[r + 1];
+    double part[1] = {0.0};
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += 4 * kJagThreads) {
+      double a[4];
+      int j[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = 0.0, j[u] = 0;
+        if (k + u * kJagThreads < k1) {
+          a[u] = __builtin_nontemporal_load(J.csr_val + k + u * kJagThreads);
+          j[u] = __builtin_nontemporal_load(J.idx + k + u * kJagThreads);
+        }
+      }
+      double xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = k + u * kJagThreads < k1 ? vec[j[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) part[0] = part[0] + a[u] * xv[u];
+    }
+    block_reduce<SumOp, 1, kJagWaves>(part, xwin);
+    if (threadIdx.x == 0) epi.row(r, part[0], acc);
+    if constexpr (Epi::NQ > 0) {
+      if (threadIdx.x == 0) {  // one row: thread 0's accumulators are the workgroup's
+#pragma unroll
+        for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * nparts + blk] = acc[q];
+      }
+    }
+    return;
+  }
   double* psum        = jag_lds + kJagWindow + wave * kJagMaxGroup;
   const int g         = blk * kJagWaves + wave;
   const int wbase     = J.win[2 * blk];
   const unsigned wlen = (unsigned)J.win[2 * blk + 1];
   for (unsigned i = threadIdx.x; i < wlen; i += kJagThreads) xwin[i] = vec[wbase + i];
   __syncthreads();
-  auto gather = [&](int j) -> double {
-    const unsigned rel = (unsigned)(j - wbase);
-    return rel < wlen ? xwin[rel] : vec[j];
-  };
-  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
-#pragma unroll
-  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
   if (g < J.ngroups) {
     const int G   = J.G;
     int e         = __builtin_amdgcn_readfirstlane(J.tile_e[g]);
@@ -529,49 +574,34 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
             j[u] = __builtin_nontemporal_load(J.col + at[u] + lane);
           }
         }
+        // gathers: LDS window first choice; the entries outside it are requested from global memory back to back (all
+        // of a round's loads in flight together) before the LDS reads
         double xv[kJagU];
+        bool outside[kJagU];
 #pragma unroll
         for (int u = 0; u < kJagU; ++u) {
-          xv[u] = 0.0;
-          if (cnt > k0 + u) xv[u] = gather(j[u]);
+          outside[u] = cnt > k0 + u && (unsigned)(j[u] - wbase) >= wlen;
+          xv[u]      = 0.0;
+          if (outside[u]) xv[u] = vec[j[u]];
         }
+#pragma unroll
+        for (int u = 0; u < kJagU; ++u)
+          if (cnt > k0 + u && !outside[u]) xv[u] = xwin[(unsigned)(j[u] - wbase)];
         // lanes past their row's end add +0.0 * 0.0: a sum that started at +0.0 is never -0.0, so this changes no bit
 #pragma unroll
         for (int u = 0; u < kJagU; ++u) sum = sum + a[u] * xv[u];
       }
       if (have) psum[lrow] = sum;
     }
-    // rows longer than kLongRow: 64 strided chains and the fixed wave tree (compared with a tolerance, like every
-    // long row of the other layouts)
-    const int q1 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g + 1]);
-    for (int q = __builtin_amdgcn_readfirstlane(J.lr_ptr[g]); q < q1; ++q) {
-      const int r  = __builtin_amdgcn_readfirstlane(J.lr_row[q]);
-      const int k0 = __builtin_amdgcn_readfirstlane(J.off[r]), k1 = __builtin_amdgcn_readfirstlane(J.off[r + 1]);
-      double part = 0.0;
-      for (int k = k0 + lane; k < k1; k += 256) {
-        double a[4];
-        int j[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a[u] = 0.0, j[u] = wbase;
-          if (k + 64 * u < k1) {
-            a[u] = __builtin_nontemporal_load(J.csr_val + k + 64 * u);
-            j[u] = __builtin_nontemporal_load(J.idx + k + 64 * u);
-          }
-        }
-        double xv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = k + 64 * u < k1 ? gather(j[u]) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) part = part + a[u] * xv[u];
-      }
-      part = wave_reduce<SumOp>(part);
-      if (lane == 0) psum[r - g * G] = part;
+    // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue below skips them
+    {
+      const int q0 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g]), q1 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g + 1]);
+      for (int q = q0 + lane; q < q1; q += 64) psum[J.lr_row[q] - g * G] = __longlong_as_double(kJagNotMine);
     }
     __builtin_amdgcn_wave_barrier();  // the strip is private to the wave: LDS operations of a wave complete in order
     for (int i = lane; i < G; i += 64) {
       const int row = g * G + i;
-      if (row < J.rows) epi.row(row, psum[i], acc);
+      if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, psum[i], acc);
     }
   }
   if constexpr (Epi::NQ > 0) {
@@ -579,7 +609,7 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     block_reduce<typename Epi::Op, Epi::NQ, kJagWaves>(acc, xwin);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * J.nblk + blk] = acc[q];
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * nparts + blk] = acc[q];
     }
   }
 }

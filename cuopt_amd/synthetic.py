@@ -90,3 +90,72 @@ def spmv_bytes(rows, cols, nnz):
 def iteration_bytes_min(m, n, nnz):
     """fused floor of one accepted PDHG iteration: 24 nnz + 4(m+n+2) + 8(14 n + 7 m)"""
     return 24 * nnz + 4 * (m + n + 2) + 8 * (14 * n + 7 * m)
+
+
+# ---- structured families (stand-ins for the Mittelmann LPs of pdlp_test.cu:189-235, which cannot be fetched) ----------------
+def _finish(m, n, rows, cols, vals, rng, meta):
+    """CSR + a primal-dual optimal pair by construction (same recipe as generate()) from a ragged pattern"""
+    import scipy.sparse as sp
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    xs = np.where(rng.random(n) < 0.5, 0.0, 1.0 - rng.random(n))
+    half = m // 2
+    ys = rng.standard_normal(m)
+    ys[half:] = np.abs(ys[half:]) * (rng.random(m - half) >= 0.3)
+    ax = a @ xs
+    lo, hi = ax.copy(), ax.copy()
+    slack = np.where(ys[half:] > 0.0, 0.0, rng.random(m - half))
+    lo[half:] = ax[half:] - slack
+    hi[half:] = np.inf
+    zs = np.where(xs > 0.0, 0.0, rng.random(n))
+    c = a.T @ ys + zs
+    out = dict(m=m, n=n, offsets=a.indptr.astype(np.int32), indices=a.indices.astype(np.int32),
+               values=np.ascontiguousarray(a.data, dtype=np.float64), c=c, lo=lo, hi=hi, lb=np.zeros(n),
+               ub=np.full(n, np.inf), maximize=False, objective_offset=0.0, x_star=xs, y_star=ys,
+               objective_star=float(c @ xs))
+    out.update(meta)
+    return out
+
+
+def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
+    """kind = 'staircase'     time-expanded model: stages of 1000 rows x 1000 columns, a row couples its own stage (60 %)
+                              with the next one (40 %)
+              'block_angular' 100 independent diagonal blocks + 0.02 % linking rows that run through EVERY block
+                              (thousands of nonzeros each: the long-row path) + 1 % linking columns
+              'powerlaw'      row lengths ~ Pareto(1.5) with mean ~k, capped at 20000, uniform columns (hub constraints)
+    every column gets at least one entry; (x*, y*) is optimal by construction, objective_star is the known answer."""
+    rng = np.random.default_rng(seed)
+    r_forced = np.arange(n, dtype=np.int64) % m
+    c_forced = np.arange(n, dtype=np.int64)
+    if kind == "staircase":
+        stage = 1000
+        rows = np.repeat(np.arange(m, dtype=np.int64), k)
+        st = (rows * n // m) // stage
+        nxt = rng.random(len(rows)) < 0.4
+        base = (st + nxt) * stage
+        cols = np.minimum(base + rng.integers(0, stage, size=len(rows)), n - 1)
+    elif kind == "block_angular":
+        blocks = 100
+        bw_r, bw_c = m // blocks, n // blocks
+        nlink_rows = max(m // 5000, 1)
+        rows = np.repeat(np.arange(m - nlink_rows, dtype=np.int64), k - 1)
+        blk = rows // bw_r
+        link_col = rng.random(len(rows)) < 0.01  # linking columns: the last 1 % of the columns
+        cols = np.where(link_col, n - 1 - rng.integers(0, max(n // 100, 1), size=len(rows)),
+                        np.minimum(blk, blocks - 1) * bw_c + rng.integers(0, bw_c, size=len(rows)))
+        per_link = (m * k - len(rows)) // nlink_rows  # the remaining nonzeros go to the linking rows
+        lr = np.repeat(np.arange(m - nlink_rows, m, dtype=np.int64), per_link)
+        lc = rng.integers(0, n, size=len(lr))
+        rows, cols = np.concatenate([rows, lr]), np.concatenate([cols, lc])
+    elif kind == "powerlaw":
+        xm = k / 3.0
+        lens = np.minimum((xm * (1.0 - rng.random(m)) ** (-1.0 / 1.5)).astype(np.int64) + 1, 20000)
+        rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+        cols = rng.integers(0, n, size=len(rows))
+    else:
+        raise ValueError(kind)
+    rows = np.concatenate([rows, r_forced])
+    cols = np.concatenate([cols, c_forced])
+    vals = rng.standard_normal(len(rows))
+    return _finish(m, n, rows, cols, vals, rng, dict(seed=seed, k=k, kind=kind, hard=False, band=0))
