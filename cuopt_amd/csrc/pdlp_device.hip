@@ -1603,7 +1603,7 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 
 // ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
 struct PanelHost {
-  bool ok = false;
+  bool ok = false, any_long = false;
   int W = 0, S = 0;
   std::vector<int32_t> row0, tile_ptr;
   std::vector<int64_t> rp_base;
@@ -1642,6 +1642,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S;
+  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = off[i + 1] - off[i] > kLongRow;
   // pass 1: nonzeros per (panel, slab) -- panels are independent, so both passes run over host threads
   std::vector<int64_t> count((size_t)W * S + 1, 0);
   cuopt_amd::parallel_tasks(W, [&](int w) {
@@ -1891,7 +1892,7 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
   HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &dst->val, h.nnz));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
-  dst->v  = PanelView{h.W, h.S, row0, tile_ptr, rowptr, rp_base, col, dst->val};
+  dst->v  = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
   dst->on = true;
   return 0;
 }

@@ -281,6 +281,7 @@ constexpr int kPanelWaves   = kPanelThreads / 64;
 
 struct PanelView {
   int W, S;
+  int any_long;  // some row has more than kLongRow nonzeros: the row-sum phase takes the variant that shares such rows
   const int32_t* __restrict__ row0;      // W+1
   const int32_t* __restrict__ tile_ptr;  // W*S+1, positions in the permuted nonzero arrays
   const uint16_t* __restrict__ rowptr;   // per tile: (rows_w + 1) offsets relative to the tile start
@@ -399,32 +400,64 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
     nxt = advance(cur);
     PANEL_REQUEST(nxt)  // in flight during the row sums below
     __syncthreads();
+    if (!P.any_long) {  // (uniform) the common case: no extra instruction in the loop
+#pragma unroll
+      for (int q = 0; q < kPanelRowsPer; ++q) {
+        const int r = threadIdx.x + q * kPanelThreads;
+        if (r < nr) {
+          int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+          a = a > lo ? a : lo;
+          b = b < hi ? b : hi;
+          if (a < b) {
+            double sum = psum[r];
+            for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+            psum[r] = sum;
+          }
+        }
+      }
+      cur = nxt;
+      continue;
+    }
+    bool any_long = false;
 #pragma unroll
     for (int q = 0; q < kPanelRowsPer; ++q) {
       const int r = threadIdx.x + q * kPanelThreads;
-      int a = 0, b = 0;
       if (r < nr) {
-        a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+        int a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
         a = a > lo ? a : lo;
         b = b < hi ? b : hi;
+        if (b - a > kLongRow) {
+          any_long = true;  // handled below, by the whole wave
+        } else if (a < b) {  // left to right by the row's lane: bit-identical to a sequential CSR sum
+          double sum = psum[r];
+          for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
+          psum[r] = sum;
+        }
       }
-      const bool is_long = b - a > kLongRow;
-      if (a < b && !is_long) {  // left to right by the row's lane: bit-identical to a sequential CSR sum
-        double sum = psum[r];
-        for (int k = a; k < b; ++k) sum = sum + prod[k - lo];
-        psum[r] = sum;
-      }
-      // a segment longer than kLongRow would keep ONE lane busy for thousands of dependent LDS reads: its wave sums it
-      // together instead (64 strided chains + the fixed butterfly; compared with a tolerance like every long row)
-      unsigned long long todo = __ballot(is_long);
-      while (todo) {
-        const int l  = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int la = __builtin_amdgcn_readlane(a, l), lb = __builtin_amdgcn_readlane(b, l);
-        double part  = 0.0;
-        for (int k = la + (int)(threadIdx.x & 63); k < lb; k += 64) part = part + prod[k - lo];
-        part = wave_reduce<SumOp>(part);
-        if ((int)(threadIdx.x & 63) == l) psum[r] = psum[r] + part;
+    }
+    // A segment longer than kLongRow would keep ONE lane busy for thousands of dependent LDS reads: its wave sums it
+    // together instead (64 strided chains + the fixed butterfly; compared with a tolerance like every long row).
+    // One ballot per chunk on the common path.
+    if (__ballot(any_long)) {
+#pragma unroll
+      for (int q = 0; q < kPanelRowsPer; ++q) {
+        const int r = threadIdx.x + q * kPanelThreads;
+        int a = 0, b = 0;
+        if (r < nr) {
+          a = (int)(ext[q] & 0xFFFFu), b = (int)(ext[q] >> 16);
+          a = a > lo ? a : lo;
+          b = b < hi ? b : hi;
+        }
+        unsigned long long todo = __ballot(b - a > kLongRow);
+        while (todo) {
+          const int l  = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int la = __builtin_amdgcn_readlane(a, l), lb = __builtin_amdgcn_readlane(b, l);
+          double part  = 0.0;
+          for (int k = la + (int)(threadIdx.x & 63); k < lb; k += 64) part = part + prod[k - lo];
+          part = wave_reduce<SumOp>(part);
+          if ((int)(threadIdx.x & 63) == l) psum[r] = psum[r] + part;
+        }
       }
     }
     cur = nxt;
