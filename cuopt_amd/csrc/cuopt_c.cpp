@@ -5,6 +5,7 @@
 #include <cuopt/linear_programming/cuopt_c.h>
 
 #include <algorithm>
+#include <cctype>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -917,6 +918,66 @@ cuopt_int_t cuOptGetReducedCosts(cuOptSolution solution, cuopt_float_t* reduced_
   SOLUTION_GETTER_PROLOGUE(reduced_cost_ptr);
   if (sol->is_mip) return CUOPT_INVALID_ARGUMENT;
   std::copy(sol->rc.begin(), sol->rc.end(), reduced_cost_ptr);
+  return CUOPT_SUCCESS;
+}
+
+// Extension: the counterpart of CUOPT_SOLUTION_FILE -- reads a .sol file (what write_to_sol_file produces, or the MIPLIB
+// flavour) back into the variable order of `problem`.  Behaviour of the reference's reader
+// (cpp/src/math_optimization/solution_reader.cu:57-145): '#' / '=' lines may carry "objective value" / "obj" and "status:",
+// every other non-empty line is "name value"; a variable of the problem that the file does not mention is an error.
+cuopt_int_t cuOptAmdReadSolutionFile(cuOptOptimizationProblem problem, const char* filename, cuopt_float_t* values,
+                                     cuopt_float_t* objective_value, char* status, cuopt_int_t status_size)
+{
+  if (problem == nullptr || filename == nullptr || values == nullptr) return CUOPT_INVALID_ARGUMENT;
+  const Problem* p = static_cast<const Problem*>(problem);
+  if (p->var_names.size() != (size_t)p->n) return CUOPT_VALIDATION_ERROR;  // names come from an MPS file
+  FILE* f = std::fopen(filename, "r");
+  if (!f) return CUOPT_MPS_FILE_ERROR;
+  std::vector<std::pair<std::string, double>> found;
+  double obj = std::numeric_limits<double>::quiet_NaN();
+  std::string stat;
+  char line[4096];
+  auto lower = [](std::string t) {
+    for (char& c : t) c = (char)std::tolower((unsigned char)c);
+    return t;
+  };
+  while (std::fgets(line, sizeof line, f)) {
+    std::string t(line);
+    while (!t.empty() && (t.back() == '\n' || t.back() == '\r')) t.pop_back();
+    if (t.empty()) continue;
+    if (t[0] == '#' || t[0] == '=') {
+      const std::string lo = lower(t);
+      size_t pos = lo.find("objective value");
+      if (pos == std::string::npos) pos = lo.find("obj");
+      if (pos != std::string::npos) {
+        const size_t at = t.find_first_of("-+.0123456789", pos);
+        if (at != std::string::npos) obj = std::strtod(t.c_str() + at, nullptr);
+        continue;
+      }
+      pos = lo.find("status:");
+      if (pos != std::string::npos) {
+        const size_t a = t.find_first_not_of(" \t:", pos + 7);
+        if (a != std::string::npos) stat = t.substr(a, t.find_first_of(" \t", a) - a);
+      }
+      continue;
+    }
+    char name[2048];
+    double v;
+    if (std::sscanf(t.c_str(), "%2047s %lf", name, &v) == 2) found.emplace_back(name, v);
+  }
+  std::fclose(f);
+  std::sort(found.begin(), found.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (int32_t j = 0; j < p->n; ++j) {
+    auto it = std::lower_bound(found.begin(), found.end(), p->var_names[j],
+                               [](const auto& a, const std::string& key) { return a.first < key; });
+    if (it == found.end() || it->first != p->var_names[j]) return CUOPT_VALIDATION_ERROR;  // "Variable not found in solution"
+    // (a name listed twice: the last occurrence wins, like the reference's map assignment)
+    auto last = it;
+    while (last + 1 != found.end() && (last + 1)->first == it->first) ++last;
+    values[j] = last->second;
+  }
+  if (objective_value) *objective_value = obj;
+  if (status && status_size > 0) std::snprintf(status, (size_t)status_size, "%s", stat.c_str());
   return CUOPT_SUCCESS;
 }
 

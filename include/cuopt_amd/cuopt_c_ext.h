@@ -33,6 +33,13 @@ cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats)
  * engine and says so instead of pretending) */
 cuopt_int_t cuOptAmdGetSolveInfo(cuOptSolution solution, char* buffer, cuopt_int_t buffer_size);
 
+/* reads a .sol file (CUOPT_SOLUTION_FILE output, or MIPLIB style) into the variable order of `problem` (which must carry
+ * variable names, i.e. come from cuOptReadProblem); objective_value / status may be NULL.  Mirrors
+ * cpp/src/math_optimization/solution_reader.cu:57-145.  CUOPT_MPS_FILE_ERROR: cannot open; CUOPT_VALIDATION_ERROR: a
+ * variable of the problem is not in the file. */
+cuopt_int_t cuOptAmdReadSolutionFile(cuOptOptimizationProblem problem, const char* filename, cuopt_float_t* values,
+                                     cuopt_float_t* objective_value, char* status, cuopt_int_t status_size);
+
 #ifdef __cplusplus
 }
 #endif

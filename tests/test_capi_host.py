@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
     for h in headers:
         names |= _declared_functions(h)
     assert len([n for n in names if n.startswith("cuOpt") and not n.startswith("cuOptAmd")]) == 41  # cuopt_c.h:89-668
-    assert {n for n in names if n.startswith("cuOptAmd")} == {"cuOptAmdGetPdlpStats", "cuOptAmdGetSolveInfo"}  # cuopt_c_ext.h
+    assert {n for n in names if n.startswith("cuOptAmd")} == {"cuOptAmdGetPdlpStats", "cuOptAmdGetSolveInfo", "cuOptAmdReadSolutionFile"}  # cuopt_c_ext.h
     missing = [n for n in sorted(names) if not hasattr(capi.lib, n)]
     assert not missing, missing
 
@@ -210,3 +210,31 @@ def test_user_problem_file_round_trip(tmp_path):
         np.testing.assert_allclose(back["lo"], p["lo"][keep], rtol=3e-16, atol=0)
         np.testing.assert_allclose(back["hi"], p["hi"][keep], rtol=3e-16, atol=0)
         assert back["maximize"] == p["maximize"] and back["objective_offset"] == p["objective_offset"]
+
+
+def test_solution_file_reader(tmp_path):
+    """cuOptAmdReadSolutionFile vs the behaviour of solution_reader.cu:57-145 (own writer format and MIPLIB flavour)"""
+    mps = tmp_path / "p.mps"
+    mps.write_text("NAME T\nROWS\n N COST\n L R1\nCOLUMNS\n X1 COST 1 R1 1\n YY COST 2 R1 1\n Z COST 3 R1 1\nRHS\n RHS R1 4\nENDATA\n")
+    prob = capi.Problem.read(str(mps))
+    sol = tmp_path / "a.sol"
+    sol.write_text("# Status: Optimal\n# Objective value: -12.5\nZ 3.25\nX1 1e-3\n\nYY -7\n# trailing comment\n")
+    vals = np.zeros(3)
+    obj = C.c_double()
+    status = C.create_string_buffer(64)
+    fn = capi.lib.cuOptAmdReadSolutionFile
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_double), C.c_char_p, C.c_int32]
+    assert fn(prob.handle, str(sol).encode(), capi._ptr(vals), C.byref(obj), status, 64) == capi.CUOPT_SUCCESS
+    np.testing.assert_array_equal(vals, [1e-3, -7.0, 3.25])
+    assert obj.value == -12.5 and status.value == b"Optimal"
+    mip = tmp_path / "b.sol"
+    mip.write_text("=obj= 42\nX1 1\nYY 2\nZ 3\nZ 4\n")  # MIPLIB flavour; a repeated name: last one wins
+    assert fn(prob.handle, str(mip).encode(), capi._ptr(vals), C.byref(obj), None, 0) == capi.CUOPT_SUCCESS
+    np.testing.assert_array_equal(vals, [1.0, 2.0, 4.0])
+    assert obj.value == 42.0
+    short = tmp_path / "c.sol"
+    short.write_text("X1 1\nZ 3\n")
+    assert fn(prob.handle, str(short).encode(), capi._ptr(vals), None, None, 0) == capi.CUOPT_VALIDATION_ERROR
+    assert fn(prob.handle, str(tmp_path / "none.sol").encode(), capi._ptr(vals), None, None, 0) == capi.CUOPT_MPS_FILE_ERROR
+    prob.close()
