@@ -175,11 +175,11 @@ def main():
     prefix = {"panel": "k_panel_", "jag": "k_jag_", "stream": "k_spmv_", "resident": "k_spmv_"}[lname]
     kname = prefix + ("a_dual" if dom == "SPMV_A_DUAL" else "at_step")
     # HBM/fabric bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this very
-    # command (profiles/r01_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
+    # command (profiles/r02_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.workload)))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.workload)))
         if world == 1 and kname in pmc:
             traffic = round(pmc[kname]["traffic_bytes_corrected"])
     except Exception:
@@ -194,9 +194,8 @@ def main():
                     iteration_frac_of_peak=round(synthetic.iteration_bytes_min(m, n, nnz) * its_per_s / 1e9
                                                  / HBM_PEAK_GBS / max(world, 1), 4),
                     traffic_source=None if traffic is None else
-                    "profiles/r01_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this command (2*FETCH+WRITE, "
-                    "KiB->B), taken with 1 MiB slabs; the final 1.33 MiB-slab kernel has the same byte streams "
-                    "(L2 counters: profiles/r01_pmc_c3_l2_final.txt)" % args.workload)
+                    "profiles/r02_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                    "(scripts/r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % args.workload)
     solver.close()
 
     # ---- run to the default 1e-4 termination: wall clock incl. setup -----------------------------------
