@@ -1706,7 +1706,7 @@ struct JagHost {
   bool ok = false;
   int rows = 0, G = 0, ngroups = 0, nblk = 0;
   std::vector<int32_t> tile_e, tile_sr, win, lr_ptr, lr_row;
-  cuopt_amd::PoolArray<uint16_t> sr;
+  cuopt_amd::PoolArray<uint32_t> sr;
   cuopt_amd::PoolArray<int32_t> col, perm;
   size_t nsr = 0, nent = 0;
   double coverage = 0.0;
@@ -1721,7 +1721,8 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 65536 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
-  const int ngroups = (rows + G - 1) / G, nblk = (ngroups + kJagWaves - 1) / kJagWaves;
+  const int nblk = (int)(((int64_t)rows + (int64_t)kJagWaves * G - 1) / ((int64_t)kJagWaves * G));
+  const int ngroups = nblk * kJagWaves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
   H.rows = rows, H.G = G, H.ngroups = ngroups, H.nblk = nblk;
   // LDS window of every workgroup: the whole column span of its rows when that fits, else the kJagWindow-wide range
   // holding the most nonzeros
@@ -1754,28 +1755,15 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   for (int b = 0; b < nblk; ++b) cov += covered[b];
   H.coverage = (double)cov / (double)nnz;
   if (mode == 0 && H.coverage < 0.5) return H;
-  // pass 1: rows (1..kLongRow nonzeros), entries and long rows of every group
-  H.tile_e.assign((size_t)ngroups + 1, 0), H.tile_sr.assign((size_t)ngroups + 1, 0), H.lr_ptr.assign((size_t)ngroups + 1, 0);
-  for (int g = 0; g < ngroups; ++g) {
-    const int32_t r0 = g * G, r1 = std::min(rows, r0 + G);
-    int32_t ns = 0, nl = 0;
-    int64_t ne = 0;
-    for (int32_t r = r0; r < r1; ++r) {
-      const int32_t len = off[r + 1] - off[r];
-      if (len > kLongRow)
-        ++nl;
-      else if (len > 0)
-        ++ns, ne += len;
-    }
-    H.tile_sr[g + 1] = H.tile_sr[g] + ns, H.lr_ptr[g + 1] = H.lr_ptr[g] + nl;
-    H.tile_e[g + 1] = (int32_t)(H.tile_e[g] + ne);
-  }
-  H.nsr = (size_t)H.tile_sr[ngroups], H.nent = (size_t)H.tile_e[ngroups];
-  H.sr.reset(H.nsr + 1), H.col.reset(H.nent + 1), H.perm.reset(H.nent + 1);
-  H.lr_row.assign((size_t)H.lr_ptr[ngroups], 0);
-  // pass 2: stable counting sort by length (descending), then the jagged diagonals of every pass of 64 rows
-  cuopt_amd::parallel_tasks(ngroups, [&](int g) {
-    const int32_t r0 = g * G, r1 = std::min(rows, r0 + G);
+  // Per workgroup: rows with 1..kLongRow nonzeros sorted by length (descending, stable), cut into passes of 64, the
+  // passes dealt to the waves in snake order (0..7, 7..0, ...): every wave gets the same share of long and short
+  // passes, and a pass holds rows of nearly equal length.  pass 1 sizes everything, pass 2 fills.
+  const int brows = kJagWaves * G;
+  H.tile_e.assign((size_t)ngroups + 1, 0), H.tile_sr.assign((size_t)ngroups + 1, 0), H.lr_ptr.assign((size_t)nblk + 1, 0);
+  auto wave_of_pass = [](int p) { return ((p / kJagWaves) & 1) ? kJagWaves - 1 - (p % kJagWaves) : p % kJagWaves; };
+  // sorted order of a workgroup's short rows (local row numbers), number of them returned
+  auto sort_block = [&](int b, std::vector<int32_t>& order) -> int32_t {
+    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
     int32_t bucket[kLongRow + 2] = {0};
     for (int32_t r = r0; r < r1; ++r) {
       const int32_t len = off[r + 1] - off[r];
@@ -1784,31 +1772,66 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     int32_t start[kLongRow + 2];
     int32_t run = 0;
     for (int i = 0; i <= kLongRow; ++i) start[i] = run, run += bucket[i];
-    int32_t order[512];
-    int32_t nl = H.lr_ptr[g];
+    order.resize((size_t)run);
     for (int32_t r = r0; r < r1; ++r) {
       const int32_t len = off[r + 1] - off[r];
-      if (len > kLongRow)
-        H.lr_row[nl++] = r;
-      else if (len >= 1)
-        order[start[kLongRow - len]++] = r - r0;
+      if (len >= 1 && len <= kLongRow) order[start[kLongRow - len]++] = r - r0;
     }
-    const int32_t ns = H.tile_sr[g + 1] - H.tile_sr[g];
-    uint16_t* sr = H.sr.get() + H.tile_sr[g];
-    for (int32_t i = 0; i < ns; ++i) {
-      const int32_t len = off[r0 + order[i] + 1] - off[r0 + order[i]];
-      sr[i] = (uint16_t)(((len - 1) << 9) | order[i]);
+    return run;
+  };
+  std::vector<int32_t> gsr((size_t)nblk * kJagWaves, 0);
+  std::vector<int64_t> gent((size_t)nblk * kJagWaves, 0);
+  std::vector<int32_t> nlong(nblk, 0);
+  cuopt_amd::parallel_tasks(nblk, [&](int b) {
+    std::vector<int32_t> order;
+    const int32_t ns = sort_block(b, order);
+    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
+    for (int32_t r = r0; r < r1; ++r) nlong[b] += off[r + 1] - off[r] > kLongRow;
+    for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
+      const int w = wave_of_pass(p);
+      for (int32_t i = i0; i < std::min(ns, i0 + 64); ++i) {
+        gsr[(size_t)b * kJagWaves + w] += 1;
+        gent[(size_t)b * kJagWaves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
+      }
     }
-    int64_t e = H.tile_e[g];
-    for (int32_t i0 = 0; i0 < ns; i0 += 64) {
-      const int32_t i1   = std::min(ns, i0 + 64);
+  }, nnz);
+  for (int g = 0; g < ngroups; ++g) {
+    H.tile_sr[g + 1] = H.tile_sr[g] + gsr[g];
+    H.tile_e[g + 1]  = (int32_t)(H.tile_e[g] + gent[g]);
+  }
+  for (int b = 0; b < nblk; ++b) H.lr_ptr[b + 1] = H.lr_ptr[b] + nlong[b];
+  H.nsr = (size_t)H.tile_sr[ngroups], H.nent = (size_t)H.tile_e[ngroups];
+  H.sr.reset(H.nsr + 1), H.col.reset(H.nent + 1), H.perm.reset(H.nent + 1);
+  H.lr_row.assign((size_t)H.lr_ptr[nblk], 0);
+  cuopt_amd::parallel_tasks(nblk, [&](int b) {
+    std::vector<int32_t> order;
+    const int32_t ns = sort_block(b, order);
+    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
+    int32_t nl = H.lr_ptr[b];
+    for (int32_t r = r0; r < r1; ++r)
+      if (off[r + 1] - off[r] > kLongRow) H.lr_row[nl++] = r;
+    int32_t srpos[kJagWaves];
+    int64_t epos[kJagWaves];
+    for (int w = 0; w < kJagWaves; ++w) {
+      const int g = b * kJagWaves + w;
+      srpos[w] = g < ngroups ? H.tile_sr[g] : 0, epos[w] = g < ngroups ? H.tile_e[g] : 0;
+    }
+    for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
+      const int w = wave_of_pass(p);
+      const int32_t i1 = std::min(ns, i0 + 64);
+      for (int32_t i = i0; i < i1; ++i) {
+        const int32_t len = off[r0 + order[i] + 1] - off[r0 + order[i]];
+        H.sr[srpos[w]++] = ((uint32_t)(len - 1) << 16) | (uint32_t)order[i];
+      }
       const int32_t kmax = off[r0 + order[i0] + 1] - off[r0 + order[i0]];
+      int64_t e = epos[w];
       for (int32_t k = 0; k < kmax; ++k)
         for (int32_t i = i0; i < i1; ++i) {
           const int32_t r = r0 + order[i];
           if (off[r + 1] - off[r] <= k) break;  // sorted: the rest of the pass is shorter still
           H.col[e] = idx[off[r] + k], H.perm[e] = off[r] + k, ++e;
         }
+      epos[w] = e;
     }
   }, nnz);
   H.ok = true;
@@ -1820,7 +1843,7 @@ static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, c
   dst->coverage = h.coverage;
   if (!h.ok) return 0;
   int32_t *tile_e = nullptr, *tile_sr = nullptr, *win = nullptr, *lr_ptr = nullptr, *lr_row = nullptr, *col = nullptr;
-  uint16_t* sr = nullptr;
+  uint32_t* sr = nullptr;
   TRY(upload_i32(c, &tile_e, h.tile_e.data(), h.tile_e.size()));
   TRY(upload_i32(c, &tile_sr, h.tile_sr.data(), h.tile_sr.size()));
   TRY(upload_i32(c, &win, h.win.data(), h.win.size()));
@@ -1829,7 +1852,7 @@ static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, c
   TRY(upload_i32(c, &col, h.col.get(), h.nent, 8));
   TRY(upload_i32(c, &dst->perm, h.perm.get(), h.nent, 8));
   TRY(dev_alloc(c, &sr, h.nsr + 8));
-  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &dst->val, h.nent + 8));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's JagHost
   dst->v    = JagView{h.rows, h.G, h.ngroups, h.nblk, (int)h.lr_row.size(), tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};

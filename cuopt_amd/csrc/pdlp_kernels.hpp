@@ -489,16 +489,18 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 // for an L2 round trip.  A workgroup of this layout therefore copies the column window its rows use
 // into LDS once (coalesced) and gathers from LDS; entries outside the window fall back to a global
 // load, per lane.
-//   * rows are cut into groups of G (<= kJagMaxGroup) consecutive rows, one wave64 per group, kJagWaves
-//     groups per workgroup; inside a group the rows with 1..kLongRow nonzeros are sorted by length
-//     (descending, stable) and stored as jagged diagonals per pass of 64 rows: entry k of every row
-//     of the pass that has one, contiguous -- lane <-> row, coalesced, no padding, no LDS staging of
-//     products and no barrier in the loop;
+//   * a workgroup owns kJagWaves * G (G <= kJagMaxGroup) consecutive rows; its rows with 1..kLongRow
+//     nonzeros are sorted by length (descending, stable), cut into passes of 64 and dealt to the 8
+//     waves in snake order (equal work, and every pass holds rows of nearly equal length: 97 % of the
+//     lanes of a jagged diagonal are live on Poisson row lengths, 80 % when each wave sorted only its own
+//     256 rows).  A pass is stored as jagged diagonals: entry k of every row of the pass that has one,
+//     contiguous -- lane <-> row, coalesced, no padding, no LDS staging of products and no barrier in
+//     the loop;
 //   * a lane adds up ITS row left to right in a register -> bit-identical to a sequential CSR sum;
 //   * rows longer than kLongRow get a workgroup each (appended to the grid): 512 strided chains + the
 //     fixed tree, read from the CSR arrays, like every long row of the other layouts;
-//   * the row sums go through the wave's LDS strip so that the fused epilogue runs in natural row
-//     order (coalesced streams whatever the sort did to the rows).
+//   * the row sums go through a 16 KiB LDS strip of the workgroup so that the fused epilogue runs in
+//     natural row order (coalesced streams whatever the sort did to the rows).
 // ------------------------------------------------------------------------------------------------
 constexpr int kJagWaves    = 8;
 constexpr int kJagThreads  = kJagWaves * 64;
@@ -512,11 +514,11 @@ struct JagView {
   int rows, G, ngroups, nblk, nlong;  // workgroups: nblk of kJagWaves groups, then one per long row
   const int32_t* __restrict__ tile_e;   // ngroups + 1: first entry of each group
   const int32_t* __restrict__ tile_sr;  // ngroups + 1: first row descriptor of each group
-  const uint16_t* __restrict__ sr;      // (length - 1) << 9 | row within the group, sorted by length
+  const uint32_t* __restrict__ sr;      // (length - 1) << 16 | row within the WORKGROUP's rows, sorted by length
   const int32_t* __restrict__ col;      // jagged-diagonal order
   const double* __restrict__ val;
   const int32_t* __restrict__ win;      // 2 * nblk: first column and length of the LDS window
-  const int32_t* __restrict__ lr_ptr;   // ngroups + 1: the group's rows longer than kLongRow ...
+  const int32_t* __restrict__ lr_ptr;   // nblk + 1: the workgroup's rows longer than kLongRow ...
   const int32_t* __restrict__ lr_row;   // ... as global row numbers, read from the CSR arrays below
   const int32_t* __restrict__ off;
   const int32_t* __restrict__ idx;
@@ -570,24 +572,28 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     }
     return;
   }
-  double* psum        = jag_lds + kJagWindow + wave * kJagMaxGroup;
+  double* psum        = jag_lds + kJagWindow;  // row sums of the workgroup's rows, natural order
   const int g         = blk * kJagWaves + wave;
+  const int brows     = kJagWaves * J.G;
+  const int row0      = blk * brows;
   const int wbase     = J.win[2 * blk];
   const unsigned wlen = (unsigned)J.win[2 * blk + 1];
   for (unsigned i = threadIdx.x; i < wlen; i += kJagThreads) xwin[i] = vec[wbase + i];
+  for (int i = threadIdx.x; i < brows; i += kJagThreads) psum[i] = 0.0;  // rows without nonzeros
+  // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue skips them
+  for (int q = J.lr_ptr[blk] + (int)threadIdx.x; q < J.lr_ptr[blk + 1]; q += kJagThreads)
+    psum[J.lr_row[q] - row0] = __longlong_as_double(kJagNotMine);
   __syncthreads();
   if (g < J.ngroups) {
-    const int G   = J.G;
     int e         = __builtin_amdgcn_readfirstlane(J.tile_e[g]);
     const int sr0 = __builtin_amdgcn_readfirstlane(J.tile_sr[g]);
     const int ns  = __builtin_amdgcn_readfirstlane(J.tile_sr[g + 1]) - sr0;
-    for (int i = lane; i < G; i += 64) psum[i] = 0.0;  // rows without nonzeros
     for (int p0 = 0; p0 < ns; p0 += 64) {
       const int i      = p0 + lane;
       const bool have  = i < ns;
-      const unsigned d = have ? (unsigned)J.sr[sr0 + i] : 0u;
-      const int cnt    = have ? (int)(d >> 9) + 1 : 0;
-      const int lrow   = (int)(d & 511u);
+      const unsigned d = have ? J.sr[sr0 + i] : 0u;
+      const int cnt    = have ? (int)(d >> 16) + 1 : 0;
+      const int lrow   = (int)(d & 0xFFFFu);
       double sum       = 0.0;
       const int kmax   = __builtin_amdgcn_readfirstlane(cnt);  // sorted: lane 0 holds the longest row of the pass
       for (int k0 = 0; k0 < kmax; k0 += kJagU) {
@@ -626,16 +632,11 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
       }
       if (have) psum[lrow] = sum;
     }
-    // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue below skips them
-    {
-      const int q0 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g]), q1 = __builtin_amdgcn_readfirstlane(J.lr_ptr[g + 1]);
-      for (int q = q0 + lane; q < q1; q += 64) psum[J.lr_row[q] - g * G] = __longlong_as_double(kJagNotMine);
-    }
-    __builtin_amdgcn_wave_barrier();  // the strip is private to the wave: LDS operations of a wave complete in order
-    for (int i = lane; i < G; i += 64) {
-      const int row = g * G + i;
-      if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, psum[i], acc);
-    }
+  }
+  __syncthreads();  // the strip is complete: the fused epilogue streams the workgroup's rows in natural order
+  for (int i = threadIdx.x; i < brows; i += kJagThreads) {
+    const int row = row0 + i;
+    if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, psum[i], acc);
   }
   if constexpr (Epi::NQ > 0) {
     __syncthreads();  // every wave is done with the window: its first bytes become the reduction scratch
