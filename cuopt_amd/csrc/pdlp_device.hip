@@ -942,7 +942,8 @@ k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* 
   panel_spmv_block(P, cur ? y0 : y1 /* y' */, e, part);
 }
 // jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column window
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
              double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part)
@@ -951,9 +952,10 @@ k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __res
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0};
-  jag_block(J, xbar, e, part);
+  jag_block<decltype(e), WAVES>(J, xbar, e, part);
 }
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_at_step(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
               const double* __restrict__ y1, const double* __restrict__ x0,
               const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
@@ -962,7 +964,7 @@ k_jag_at_step(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __re
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  jag_block(J, cur ? y0 : y1 /* y' */, e, part);
+  jag_block<decltype(e), WAVES>(J, cur ? y0 : y1 /* y' */, e, part);
 }
 __global__ void __launch_bounds__(kBlock)
 k_permute(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
@@ -1033,20 +1035,22 @@ k_panel_plain(PanelView P, const double* __restrict__ vec, double* __restrict__ 
   StoreEpilogue e{out};
   panel_spmv_block(P, vec, e, nullptr);
 }
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_at_cur(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
              const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
              double* __restrict__ out_override, int use_next)
 {
   const int cur = ctl->cur ^ (use_next ? 1 : 0);
   StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  jag_block(J, cur ? y1 : y0, e, nullptr);
+  jag_block<decltype(e), WAVES>(J, cur ? y1 : y0, e, nullptr);
 }
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_plain(JagView J, const double* __restrict__ vec, double* __restrict__ out)
 {
   StoreEpilogue e{out};
-  jag_block(J, vec, e, nullptr);
+  jag_block<decltype(e), WAVES>(J, vec, e, nullptr);
 }
 __global__ void __launch_bounds__(kBlock)
 k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ out)
@@ -1211,7 +1215,8 @@ k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
   EvalDualEpilogue e{core};
   panel_spmv_block(P, yv, e, part);
 }
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_eval_primal(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
                   const double* __restrict__ x0, const double* __restrict__ x1,
                   const double* __restrict__ avgx, const double* __restrict__ y0,
@@ -1224,9 +1229,10 @@ k_jag_eval_primal(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
   const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  jag_block(J, xv, e, part);
+  jag_block<decltype(e), WAVES>(J, xv, e, part);
 }
-__global__ void __launch_bounds__(kJagThreads)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 k_jag_eval_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
                 const double* __restrict__ x0, const double* __restrict__ x1,
                 const double* __restrict__ avgx, const double* __restrict__ y0,
@@ -1237,7 +1243,7 @@ k_jag_eval_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
   core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalDualEpilogue e{core};
-  jag_block(J, yv, e, part);
+  jag_block<decltype(e), WAVES>(J, yv, e, part);
 }
 // multi-GPU: same per-column rule after the all-reduce of A^T y
 __global__ void __launch_bounds__(kBlock)
@@ -1704,7 +1710,7 @@ static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t co
 // ---- sorted jagged rows: host-side construction (structure only; values are permuted on the device) -------------
 struct JagHost {
   bool ok = false;
-  int rows = 0, G = 0, ngroups = 0, nblk = 0;
+  int rows = 0, G = 0, waves = 8, ngroups = 0, nblk = 0;
   std::vector<int32_t> tile_e, tile_sr, win, lr_ptr, lr_row;
   cuopt_amd::PoolArray<uint32_t> sr;
   cuopt_amd::PoolArray<int32_t> col, perm;
@@ -1717,50 +1723,62 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   JagHost H;
   const int64_t nnz = rows > 0 ? off[rows] : 0;
   if (rows <= 0 || cols <= 0 || nnz <= 0) return H;
-  // one wave per group, kJagWaves groups per workgroup: keep a few hundred workgroups on the chip
+  // one wave per group of G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
   int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 65536 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
-  const int nblk = (int)(((int64_t)rows + (int64_t)kJagWaves * G - 1) / ((int64_t)kJagWaves * G));
-  const int ngroups = nblk * kJagWaves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
-  H.rows = rows, H.G = G, H.ngroups = ngroups, H.nblk = nblk;
-  // LDS window of every workgroup: the whole column span of its rows when that fits, else the kJagWindow-wide range
-  // holding the most nonzeros
-  H.win.assign((size_t)2 * nblk, 0);
-  std::vector<int64_t> covered(nblk, 0);
-  cuopt_amd::parallel_tasks(nblk, [&](int b) {
-    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * kJagWaves * G, rows);
-    const int32_t r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * kJagWaves * G, rows);
-    const int64_t k0 = off[r0], k1 = off[r1];
-    if (k1 <= k0) return;
-    int32_t lo = idx[k0], hi = idx[k0];
-    for (int64_t k = k0; k < k1; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
-    if ((int64_t)hi - lo + 1 <= kJagWindow) {
-      H.win[2 * b] = lo, H.win[2 * b + 1] = hi - lo + 1;
-      covered[b]   = k1 - k0;
-      return;
-    }
-    std::vector<int32_t> cs(idx + k0, idx + k1);
-    std::sort(cs.begin(), cs.end());
-    size_t best_i = 0, best = 0, j = 0;
-    for (size_t i = 0; i < cs.size(); ++i) {
-      while (j < cs.size() && (int64_t)cs[j] - cs[i] < kJagWindow) ++j;
-      if (j - i > best) best = j - i, best_i = i;
-    }
-    const int32_t base = cs[best_i];
-    H.win[2 * b] = base, H.win[2 * b + 1] = (int32_t)std::min<int64_t>(kJagWindow, (int64_t)cols - base);
-    covered[b]   = (int64_t)best;
-  }, nnz);
-  int64_t cov = 0;
-  for (int b = 0; b < nblk; ++b) cov += covered[b];
-  H.coverage = (double)cov / (double)nnz;
+  // LDS window of every workgroup: the whole column span of its rows when that fits, else the range of `wcap` columns
+  // holding the most nonzeros.  Evaluated for both geometries (8 waves / 8192 columns, 16 waves / 16384 columns).
+  auto windows = [&](int waves, std::vector<int32_t>& win) -> double {
+    const int wcap = jag_window(waves);
+    const int nb   = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
+    win.assign((size_t)2 * nb, 0);
+    std::vector<int64_t> covered(nb, 0);
+    cuopt_amd::parallel_tasks(nb, [&](int b) {
+      const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * waves * G, rows);
+      const int32_t r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * waves * G, rows);
+      const int64_t k0 = off[r0], k1 = off[r1];
+      if (k1 <= k0) return;
+      int32_t lo = idx[k0], hi = idx[k0];
+      for (int64_t k = k0; k < k1; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
+      if ((int64_t)hi - lo + 1 <= wcap) {
+        win[2 * b] = lo, win[2 * b + 1] = hi - lo + 1;
+        covered[b] = k1 - k0;
+        return;
+      }
+      std::vector<int32_t> cs(idx + k0, idx + k1);
+      std::sort(cs.begin(), cs.end());
+      size_t best_i = 0, best = 0, j = 0;
+      for (size_t i = 0; i < cs.size(); ++i) {
+        while (j < cs.size() && (int64_t)cs[j] - cs[i] < wcap) ++j;
+        if (j - i > best) best = j - i, best_i = i;
+      }
+      const int32_t base = cs[best_i];
+      win[2 * b] = base, win[2 * b + 1] = (int32_t)std::min<int64_t>(wcap, (int64_t)cols - base);
+      covered[b] = (int64_t)best;
+    }, nnz);
+    int64_t cov = 0;
+    for (int b = 0; b < nb; ++b) cov += covered[b];
+    return (double)cov / (double)nnz;
+  };
+  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) serves more gathers from LDS on block
+  // structure wider than 8192 columns (block-angular workload: 72 % -> 87 %) and is 1-4 % faster on banded matrices, but
+  // it LOST on the block-angular A^T (78 -> 102 us) for a reason the counters did not show, so it is not chosen
+  // automatically.
+  int waves = 8;
+  if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
+    if (atoi(env) == 16) waves = 16;
+  H.coverage = windows(waves, H.win);
   if (mode == 0 && H.coverage < 0.5) return H;
+  const int nblk    = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
+  const int ngroups = nblk * waves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
+  H.rows = rows, H.G = G, H.waves = waves, H.ngroups = ngroups, H.nblk = nblk;
   // Per workgroup: rows with 1..kLongRow nonzeros sorted by length (descending, stable), cut into passes of 64, the
   // passes dealt to the waves in snake order (0..7, 7..0, ...): every wave gets the same share of long and short
   // passes, and a pass holds rows of nearly equal length.  pass 1 sizes everything, pass 2 fills.
-  const int brows = kJagWaves * G;
+  const int brows = waves * G;
   H.tile_e.assign((size_t)ngroups + 1, 0), H.tile_sr.assign((size_t)ngroups + 1, 0), H.lr_ptr.assign((size_t)nblk + 1, 0);
-  auto wave_of_pass = [](int p) { return ((p / kJagWaves) & 1) ? kJagWaves - 1 - (p % kJagWaves) : p % kJagWaves; };
+  auto wave_of_pass = [waves](int p) { return ((p / waves) & 1) ? waves - 1 - (p % waves) : p % waves; };
   // sorted order of a workgroup's short rows (local row numbers), number of them returned
   auto sort_block = [&](int b, std::vector<int32_t>& order) -> int32_t {
     const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
@@ -1779,8 +1797,8 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     }
     return run;
   };
-  std::vector<int32_t> gsr((size_t)nblk * kJagWaves, 0);
-  std::vector<int64_t> gent((size_t)nblk * kJagWaves, 0);
+  std::vector<int32_t> gsr((size_t)nblk * waves, 0);
+  std::vector<int64_t> gent((size_t)nblk * waves, 0);
   std::vector<int32_t> nlong(nblk, 0);
   cuopt_amd::parallel_tasks(nblk, [&](int b) {
     std::vector<int32_t> order;
@@ -1790,8 +1808,8 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
       const int w = wave_of_pass(p);
       for (int32_t i = i0; i < std::min(ns, i0 + 64); ++i) {
-        gsr[(size_t)b * kJagWaves + w] += 1;
-        gent[(size_t)b * kJagWaves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
+        gsr[(size_t)b * waves + w] += 1;
+        gent[(size_t)b * waves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
       }
     }
   }, nnz);
@@ -1810,10 +1828,10 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     int32_t nl = H.lr_ptr[b];
     for (int32_t r = r0; r < r1; ++r)
       if (off[r + 1] - off[r] > kLongRow) H.lr_row[nl++] = r;
-    int32_t srpos[kJagWaves];
-    int64_t epos[kJagWaves];
-    for (int w = 0; w < kJagWaves; ++w) {
-      const int g = b * kJagWaves + w;
+    int32_t srpos[16];
+    int64_t epos[16];
+    for (int w = 0; w < waves; ++w) {
+      const int g = b * waves + w;
       srpos[w] = g < ngroups ? H.tile_sr[g] : 0, epos[w] = g < ngroups ? H.tile_e[g] : 0;
     }
     for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
@@ -1855,7 +1873,7 @@ static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, c
   HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &dst->val, h.nent + 8));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's JagHost
-  dst->v    = JagView{h.rows, h.G, h.ngroups, h.nblk, (int)h.lr_row.size(), tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};
+  dst->v    = JagView{h.rows, h.G, h.waves, h.ngroups, h.nblk, (int)h.lr_row.size(), tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};
   dst->nent = (int64_t)h.nent;
   dst->on   = true;
   return 0;
@@ -1881,23 +1899,27 @@ static void launch_k(pdlpdev_ctx* c, void (*kernel)(KArgs...), dim3 grid, dim3 b
   }
   kernel<<<grid, block, lds, c->stream>>>(static_cast<KArgs>(args)...);
 }
-// Launch of a jagged-layout kernel: 80 KiB of dynamic LDS (the attribute is per kernel and device, set once)
+// Launch of a jagged-layout kernel: 80 or 160 KiB of dynamic LDS (the attribute is per kernel and device, set once)
 template <typename... KArgs, typename... Args>
 static int jag_launch(pdlpdev_ctx* c, void (*kernel)(JagView, KArgs...), const JagView& v, Args... args)
 {
   static std::mutex mu;
   static std::vector<std::pair<const void*, int>> done;
+  const size_t lds = jag_lds_bytes(v.waves);
   {
     std::lock_guard<std::mutex> lock(mu);
     const std::pair<const void*, int> key((const void*)kernel, c->device);
     if (std::find(done.begin(), done.end(), key) == done.end()) {
-      HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJagLdsBytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       done.push_back(key);
     }
   }
-  launch_k(c, kernel, stream_grid(v.nblk + v.nlong), kJagThreads, kJagLdsBytes, v, args...);
+  launch_k(c, kernel, stream_grid(v.nblk + v.nlong), v.waves * 64, lds, v, args...);
   return 0;
 }
+// the two geometries are two instantiations of every jagged kernel
+#define JAG_LAUNCH(ctx, KERNEL, VIEW, ...) \
+  ((VIEW).waves == 16 ? jag_launch(ctx, KERNEL<16>, VIEW, __VA_ARGS__) : jag_launch(ctx, KERNEL<8>, VIEW, __VA_ARGS__))
 
 static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h)
 {
@@ -2577,7 +2599,7 @@ static void launch_a_dual(pdlpdev_ctx* ctx)
 {
   hipStream_t s = ctx->stream;
   if (ctx->ja.on)
-    (void)jag_launch(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
   else if (ctx->pa.on)
     launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
   else
@@ -2587,7 +2609,7 @@ static void launch_at_step(pdlpdev_ctx* ctx)
 {
   hipStream_t s = ctx->stream;
   if (ctx->jat.on)
-    (void)jag_launch(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else
@@ -2597,7 +2619,7 @@ static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
   hipStream_t s = ctx->stream;
   if (ctx->jat.on)
-    (void)jag_launch(ctx, k_jag_at_cur, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
+    (void)JAG_LAUNCH(ctx, k_jag_at_cur, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_cur, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else
@@ -2609,14 +2631,14 @@ static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, dou
   hipStream_t s = ctx->stream;
   if (transpose) {
     if (ctx->jat.on)
-      (void)jag_launch(ctx, k_jag_plain, ctx->jat.v, vec, out);
+      (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->jat.v, vec, out);
     else if (ctx->pat.on)
       launch_k(ctx, k_panel_plain, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, vec, out);
     else
       launch_k(ctx, k_spmv_plain, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, vec, out);
   } else {
     if (ctx->ja.on)
-      (void)jag_launch(ctx, k_jag_plain, ctx->ja.v, vec, out);
+      (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->ja.v, vec, out);
     else if (ctx->pa.on)
       launch_k(ctx, k_panel_plain, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, vec, out);
     else
@@ -2820,7 +2842,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   double* linf_n = want_linf ? ctx->tmp_n : nullptr;
   // layout of sc: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
   if (ctx->ja.on)
-    (void)jag_launch(ctx, k_jag_eval_primal, ctx->ja.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
+    (void)JAG_LAUNCH(ctx, k_jag_eval_primal, ctx->ja.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else if (ctx->pa.on)
     k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else
@@ -2834,7 +2856,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], linf_n, ctx->aty_u[which]};
   if (!ctx->comm) {
     if (ctx->jat.on)
-      (void)jag_launch(ctx, k_jag_eval_dual, ctx->jat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
+      (void)JAG_LAUNCH(ctx, k_jag_eval_dual, ctx->jat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else if (ctx->pat.on)
       k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else

@@ -489,7 +489,7 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 // for an L2 round trip.  A workgroup of this layout therefore copies the column window its rows use
 // into LDS once (coalesced) and gathers from LDS; entries outside the window fall back to a global
 // load, per lane.
-//   * a workgroup owns kJagWaves * G (G <= kJagMaxGroup) consecutive rows; its rows with 1..kLongRow
+//   * a workgroup owns waves * G (G <= kJagMaxGroup) consecutive rows; its rows with 1..kLongRow
 //     nonzeros are sorted by length (descending, stable), cut into passes of 64 and dealt to the 8
 //     waves in snake order (equal work, and every pass holds rows of nearly equal length: 97 % of the
 //     lanes of a jagged diagonal are live on Poisson row lengths, 80 % when each wave sorted only its own
@@ -502,16 +502,17 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 //   * the row sums go through a 16 KiB LDS strip of the workgroup so that the fused epilogue runs in
 //     natural row order (coalesced streams whatever the sort did to the rows).
 // ------------------------------------------------------------------------------------------------
-constexpr int kJagWaves    = 8;
-constexpr int kJagThreads  = kJagWaves * 64;
-constexpr int kJagWindow   = 8192;  // entries of the gathered vector staged per workgroup (64 KiB)
+// Two geometries: 8 waves + a window of 8192 entries (80 KiB of LDS, two workgroups per CU), or 16 waves + 16384 entries
+// (160 KiB, one workgroup per CU: the same 16 waves per CU, twice the rows sharing a window twice as wide) -- chosen per
+// matrix at set-up (8 waves unless CUOPT_AMD_JAG_WAVES=16: see build_jag).
 constexpr int kJagMaxGroup = 256;   // rows per wave (2 KiB of row sums)
 constexpr int kJagU        = 8;     // jagged diagonals requested per round
+constexpr int jag_window(int waves) { return waves == 16 ? 16384 : 8192; }  // entries of the gathered vector per workgroup
+constexpr size_t jag_lds_bytes(int waves) { return sizeof(double) * (size_t)(jag_window(waves) + waves * kJagMaxGroup); }
 constexpr long long kJagNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
-constexpr size_t kJagLdsBytes = sizeof(double) * (size_t)(kJagWindow + kJagWaves * kJagMaxGroup);  // 80 KiB: two workgroups per CU
 
 struct JagView {
-  int rows, G, ngroups, nblk, nlong;  // workgroups: nblk of kJagWaves groups, then one per long row
+  int rows, G, waves, ngroups, nblk, nlong;  // workgroups: nblk of `waves` groups, then one per long row
   const int32_t* __restrict__ tile_e;   // ngroups + 1: first entry of each group
   const int32_t* __restrict__ tile_sr;  // ngroups + 1: first row descriptor of each group
   const uint32_t* __restrict__ sr;      // (length - 1) << 16 | row within the WORKGROUP's rows, sorted by length
@@ -525,7 +526,7 @@ struct JagView {
   const double* __restrict__ csr_val;
 };
 
-template <class Epi>
+template <class Epi, int WAVES>
 __device__ __forceinline__ void jag_block(const JagView& J, const double* __restrict__ vec, Epi& epi,
                                           double* __restrict__ partials)
 {
@@ -545,24 +546,24 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     const int r  = J.lr_row[blk - J.nblk];
     const int k0 = J.off[r], k1 = J.off[r + 1];
     double part[1] = {0.0};
-    for (int k = k0 + (int)threadIdx.x; k < k1; k += 4 * kJagThreads) {
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += 4 * (WAVES * 64)) {
       double a[4];
       int j[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         a[u] = 0.0, j[u] = 0;
-        if (k + u * kJagThreads < k1) {
-          a[u] = __builtin_nontemporal_load(J.csr_val + k + u * kJagThreads);
-          j[u] = __builtin_nontemporal_load(J.idx + k + u * kJagThreads);
+        if (k + u * (WAVES * 64) < k1) {
+          a[u] = __builtin_nontemporal_load(J.csr_val + k + u * (WAVES * 64));
+          j[u] = __builtin_nontemporal_load(J.idx + k + u * (WAVES * 64));
         }
       }
       double xv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = k + u * kJagThreads < k1 ? vec[j[u]] : 0.0;
+      for (int u = 0; u < 4; ++u) xv[u] = k + u * (WAVES * 64) < k1 ? vec[j[u]] : 0.0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) part[0] = part[0] + a[u] * xv[u];
     }
-    block_reduce<SumOp, 1, kJagWaves>(part, xwin);
+    block_reduce<SumOp, 1, WAVES>(part, xwin);
     if (threadIdx.x == 0) epi.row(r, part[0], acc);
     if constexpr (Epi::NQ > 0) {
       if (threadIdx.x == 0) {  // one row: thread 0's accumulators are the workgroup's
@@ -572,16 +573,16 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     }
     return;
   }
-  double* psum        = jag_lds + kJagWindow;  // row sums of the workgroup's rows, natural order
-  const int g         = blk * kJagWaves + wave;
-  const int brows     = kJagWaves * J.G;
+  double* psum        = jag_lds + jag_window(WAVES);  // row sums of the workgroup's rows, natural order
+  const int g         = blk * WAVES + wave;
+  const int brows     = WAVES * J.G;
   const int row0      = blk * brows;
   const int wbase     = J.win[2 * blk];
   const unsigned wlen = (unsigned)J.win[2 * blk + 1];
-  for (unsigned i = threadIdx.x; i < wlen; i += kJagThreads) xwin[i] = vec[wbase + i];
-  for (int i = threadIdx.x; i < brows; i += kJagThreads) psum[i] = 0.0;  // rows without nonzeros
+  for (unsigned i = threadIdx.x; i < wlen; i += (WAVES * 64)) xwin[i] = vec[wbase + i];
+  for (int i = threadIdx.x; i < brows; i += (WAVES * 64)) psum[i] = 0.0;  // rows without nonzeros
   // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue skips them
-  for (int q = J.lr_ptr[blk] + (int)threadIdx.x; q < J.lr_ptr[blk + 1]; q += kJagThreads)
+  for (int q = J.lr_ptr[blk] + (int)threadIdx.x; q < J.lr_ptr[blk + 1]; q += (WAVES * 64))
     psum[J.lr_row[q] - row0] = __longlong_as_double(kJagNotMine);
   __syncthreads();
   if (g < J.ngroups) {
@@ -634,13 +635,13 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     }
   }
   __syncthreads();  // the strip is complete: the fused epilogue streams the workgroup's rows in natural order
-  for (int i = threadIdx.x; i < brows; i += kJagThreads) {
+  for (int i = threadIdx.x; i < brows; i += (WAVES * 64)) {
     const int row = row0 + i;
     if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, psum[i], acc);
   }
   if constexpr (Epi::NQ > 0) {
     __syncthreads();  // every wave is done with the window: its first bytes become the reduction scratch
-    block_reduce<typename Epi::Op, Epi::NQ, kJagWaves>(acc, xwin);
+    block_reduce<typename Epi::Op, Epi::NQ, WAVES>(acc, xwin);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * nparts + blk] = acc[q];

@@ -11,10 +11,13 @@ from test_kernels_gpu import ragged_problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20), ("jag", 1 << 20)],
-                ids=["panel-4KiB-slabs", "panel-1slab", "stream", "jag"])
+@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20), ("jag", 8), ("jag", 16)],
+                ids=["panel-4KiB-slabs", "panel-1slab", "stream", "jag-8-waves", "jag-16-waves"])
 def layout(request, monkeypatch):
     mode, slab = request.param
+    if mode == "jag":  # both geometries of the jagged layout (8 waves / 8192-column window, 16 waves / 16384)
+        monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(slab))
+        slab = 1 << 20
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
     monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(slab))
     monkeypatch.setenv("CUOPT_AMD_SMALL", "0")  # these LPs are small: keep them on the multi-launch kernels under test
