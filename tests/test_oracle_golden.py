@@ -162,3 +162,67 @@ def test_every_lp_fixture_against_the_reference_simplex_verdict(golden_parser):
         else:
             assert s["status"] == "NumericalError", name
     assert seen == {"OPTIMAL": 16, "INFEASIBLE": 3, "UNBOUNDED": 2}
+
+
+def test_trust_region_bounds_against_an_independent_solution():
+    """Second pin of the oracle's literal restatement of solve_bound_constrained_trust_region
+    (pdlp_restart_strategy.cu:1290-1356, 1391-1678; until now pinned only through afiro's -464.7531 under Methodical1):
+    the same bound-constrained trust-region problem solved WITHOUT the sort / median bisection on breakpoints -- a
+    plain numpy bisection on the step length t of z(t) = clamp(center + t * direction) until the weighted radius is met --
+    must give the same Lagrangian value and the same two objective bounds, on random points, weights and radii
+    (inside the first breakpoint, across many, beyond all of them)."""
+    import scipy.sparse as sp
+    from cuopt_amd import synthetic
+    rng = np.random.default_rng(5)
+    for seed in (1, 2, 3):
+        p = synthetic.generate(400, 300, 6, seed=seed)
+        p["ub"] = np.where(rng.random(p["n"]) < 0.5, 1.5, np.inf)  # some finite upper bounds too
+        A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+        x = np.clip(np.abs(rng.standard_normal(p["n"])) * (rng.random(p["n"]) < 0.7), p["lb"], p["ub"])
+        y = rng.standard_normal(p["m"])
+        y = np.where(np.isinf(p["lo"]), -np.abs(y), y)
+        y = np.where(np.isinf(p["hi"]), np.abs(y), y) * (rng.random(p["m"]) < 0.8)
+        lo, hi, lb, ub, c = p["lo"], p["hi"], p["lb"], p["ub"], p["c"]
+        aty, ax = A.T @ y, A @ x
+        gx = c - aty
+        clipped = np.clip(ax, lo, hi)
+        sub = np.where(y < 0, hi, np.where(y > 0, lo, np.where(np.isinf(hi) & np.isinf(lo), 0.0,
+                       np.where(np.isinf(hi), lo, np.where(np.isinf(lo), hi, clipped)))))
+        gy = sub - ax
+        lagrangian = c @ x - x @ aty + y @ sub
+        center = np.concatenate([x, y])
+        obj = np.concatenate([gx, -gy])
+        low = np.concatenate([lb, np.where(np.isfinite(hi), -np.inf, 0.0)])
+        upp = np.concatenate([ub, np.where(np.isfinite(lo), np.inf, 0.0)])
+        for wp, wd, radius in ((2.0, 0.7, 1e-3), (2.0, 0.7, 0.5), (0.3, 5.0, 10.0), (1.0, 1.0, 1e4)):
+            w = np.concatenate([np.full(p["n"], wp), np.full(p["m"], wd)])
+            blocked = ((center >= upp) & (obj <= 0)) | ((center <= low) & (obj >= 0))
+            direction = np.where(blocked, 0.0, -obj / w)
+
+            def moved(t):
+                with np.errstate(invalid="ignore"):
+                    z = np.clip(center + t * direction, low, upp)
+                return np.where(direction == 0.0, 0.0, z - center)
+
+            def radius2(t):
+                d = moved(t)
+                return float(np.sum(w * d * d))
+            t_hi = 1.0
+            while radius2(t_hi) < radius * radius and t_hi < 1e30:
+                t_hi *= 4.0  # beyond every breakpoint the radius stops growing: the loop ends by the cap
+            t_lo = 0.0
+            if radius2(t_hi) >= radius * radius:
+                for _ in range(200):
+                    mid = 0.5 * (t_lo + t_hi)
+                    if radius2(mid) >= radius * radius:
+                        t_hi = mid
+                    else:
+                        t_lo = mid
+            d = moved(t_hi)
+            lower = lagrangian + float(d[: p["n"]] @ gx)
+            upper = lagrangian + float(d[p["n"]:] @ gy)
+            ref = orcbind.trust_region_bounds(p, x, y, wp, wd, radius)
+            scale = 1.0 + abs(lagrangian)
+            assert ref["lagrangian"] == pytest.approx(lagrangian, rel=1e-12, abs=1e-12 * scale)
+            assert ref["lower_bound"] == pytest.approx(lower, rel=1e-8, abs=1e-8 * scale), (seed, wp, wd, radius)
+            assert ref["upper_bound"] == pytest.approx(upper, rel=1e-8, abs=1e-8 * scale), (seed, wp, wd, radius)
