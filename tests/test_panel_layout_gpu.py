@@ -148,3 +148,43 @@ def test_jagged_layout_partial_windows(monkeypatch):
     to, ti, tv = orcbind.transpose(m, n, offsets, indices, values)
     np.testing.assert_array_equal(dev.spmv(x, False, m), orcbind.spmv(offsets, indices, values, x))
     np.testing.assert_array_equal(dev.spmv(y, True, n), orcbind.spmv(to, ti, tv, y))
+
+
+@pytest.mark.parametrize("m,n,waves", [(66000, 1000, 8), (200000, 150000, 8), (200000, 150000, 16), (70001, 90001, 16),
+                                       (800000, 300000, 8)])
+def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch):
+    """every group size of the jagged layout (64 / 128 / 256 rows per wave: rows >= 65536 / 196608 / 786432), both
+    geometries, rectangular matrices, a ragged last workgroup, empty rows, rows of exactly 127 / 128 / 129 nonzeros (the
+    boundary between the left-to-right and the tree path) and a few rows of thousands"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
+    monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(waves))
+    rng = np.random.default_rng(m + n)
+    lens = rng.poisson(4.0, size=m).astype(np.int64)
+    lens[rng.integers(0, m, size=200)] = 0
+    for special in (127, 128, 129, 1, 2500):
+        lens[rng.integers(0, m, size=6)] = min(special, n)
+    lens[-1] = min(129, n)  # a long row in the ragged tail
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    centre = (np.arange(m) * n) // m
+    rows = np.repeat(np.arange(m), lens)
+    cols = (np.repeat(centre, lens) + rng.integers(-3000, 3000, size=offsets[-1])) % n
+    # distinct sorted columns per row
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    keep = np.ones(len(cols), bool)
+    keep[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+    rows, cols = rows[keep], cols[keep]
+    lens = np.bincount(rows, minlength=m)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    values = rng.standard_normal(len(cols))
+    p = dict(m=m, n=n, offsets=offsets, indices=cols.astype(np.int32), values=values, c=np.zeros(n), lo=-np.ones(m),
+             hi=np.ones(m), lb=np.zeros(n), ub=np.ones(n), maximize=False, objective_offset=0.0)
+    dev = capi.Device(p)
+    assert dev.layout()["A"]["layout"] == dev.layout()["At"]["layout"] == "jag"
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    to, ti, tv = orcbind.transpose(m, n, offsets, p["indices"], values)
+    for got, ref, ln in ((dev.spmv(x, False, m), orcbind.spmv(offsets, p["indices"], values, x), lens),
+                         (dev.spmv(y, True, n), orcbind.spmv(to, ti, tv, y), np.diff(to))):
+        np.testing.assert_array_equal(got[ln <= 128], ref[ln <= 128])
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
+    dev.close()
