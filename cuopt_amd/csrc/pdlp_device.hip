@@ -1729,16 +1729,20 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   if (G == 0) return H;
   // LDS window of every workgroup: the whole column span of its rows when that fits, else the range of `wcap` columns
   // holding the most nonzeros.  Evaluated for both geometries (8 waves / 8192 columns, 16 waves / 16384 columns).
-  auto windows = [&](int waves, std::vector<int32_t>& win) -> double {
+  // `stride` > 1 looks at every stride-th workgroup only (a cheap estimate: random matrices are turned away after a few
+  // milliseconds instead of sorting all their column indices)
+  auto windows = [&](int waves, std::vector<int32_t>& win, int stride) -> double {
     const int wcap = jag_window(waves);
     const int nb   = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
     win.assign((size_t)2 * nb, 0);
-    std::vector<int64_t> covered(nb, 0);
-    cuopt_amd::parallel_tasks(nb, [&](int b) {
+    std::vector<int64_t> covered(nb, 0), seen(nb, 0);
+    cuopt_amd::parallel_tasks((nb + stride - 1) / stride, [&](int task) {
+      const int b = task * stride;
       const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * waves * G, rows);
       const int32_t r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * waves * G, rows);
       const int64_t k0 = off[r0], k1 = off[r1];
       if (k1 <= k0) return;
+      seen[b] = k1 - k0;
       int32_t lo = idx[k0], hi = idx[k0];
       for (int64_t k = k0; k < k1; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
       if ((int64_t)hi - lo + 1 <= wcap) {
@@ -1756,10 +1760,10 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
       const int32_t base = cs[best_i];
       win[2 * b] = base, win[2 * b + 1] = (int32_t)std::min<int64_t>(wcap, (int64_t)cols - base);
       covered[b] = (int64_t)best;
-    }, nnz);
-    int64_t cov = 0;
-    for (int b = 0; b < nb; ++b) cov += covered[b];
-    return (double)cov / (double)nnz;
+    }, nnz / stride);
+    int64_t cov = 0, tot = 0;
+    for (int b = 0; b < nb; ++b) cov += covered[b], tot += seen[b];
+    return tot ? (double)cov / (double)tot : 0.0;
   };
   // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) serves more gathers from LDS on block
   // structure wider than 8192 columns (block-angular workload: 72 % -> 87 %) and is 1-4 % faster on banded matrices, but
@@ -1768,7 +1772,12 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   int waves = 8;
   if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
     if (atoi(env) == 16) waves = 16;
-  H.coverage = windows(waves, H.win);
+  if (mode == 0) {  // estimate first
+    const int nb = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
+    H.coverage   = windows(waves, H.win, std::max(1, nb / 48));
+    if (H.coverage < 0.35) return H;
+  }
+  H.coverage = windows(waves, H.win, 1);
   if (mode == 0 && H.coverage < 0.5) return H;
   const int nblk    = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
   const int ngroups = nblk * waves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
