@@ -1629,10 +1629,12 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   int S = (int)(((int64_t)cols * 8 + slab_bytes - 1) / slab_bytes);
   S     = std::max(1, std::min(S, 16));
   const int32_t slab_w = (cols + S - 1) / S;
-  // panels: ~20K nonzeros each (two 512-thread workgroups per CU, 512 panels fill the chip at 1e7 nnz),
-  // at most kPanelMaxRows rows
+  // panels: two 512-thread workgroups per CU = 512 resident panels, and ALL panels should be resident at once (they walk
+  // the slabs in lockstep; a 513th panel runs alone afterwards: the power-law LP with 11.4 M nonzeros took 104 us per SpMV
+  // with 570 panels of 20 K nonzeros and takes 75 with 512 of 22 K).  So the panel size follows the matrix, up to
+  // 60 K nonzeros (beyond that the row-sum strip, kPanelMaxRows, and the 16-bit tile pointers set the limits).
   const char* target_env = getenv("CUOPT_AMD_PANEL_NNZ");
-  const int64_t cap    = target_env ? std::max<int64_t>(2048, atoll(target_env)) : 20000;
+  const int64_t cap    = target_env ? std::max<int64_t>(2048, atoll(target_env)) : 60000;
   const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz + 511) / 512));
   P.row0.push_back(0);
   int32_t start = 0;
