@@ -179,3 +179,23 @@ def test_sharded_warm_start_snapshots_add_up_and_resume():
     assert full["status_name"] == res[0]["status_name"] == second["status_name"] == "Optimal"
     assert res[0]["steps_taken"] + second["steps_taken"] == full["steps_taken"]
     assert second["primal_objective"] == full["primal_objective"]
+
+
+@pytest.mark.parametrize("layout", ["jag", "panel"])
+def test_sharded_solve_through_the_other_layouts(layout, monkeypatch):
+    """row-block sharding on top of the jagged / panel layouts (every rank builds them for ITS row block and that block's
+    transpose): same decisions on all ranks, same optimum as the single-rank solve"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
+    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(32 * 1024))
+    p = synthetic.generate(30000, 26000, 8, seed=71, band=900)
+    single = capi.Solver(p, tol=1e-5).advance()
+    out = run_sharded(p, 3, tol=1e-5)
+    for r, x, _, _ in out:
+        assert (r["status_name"], r["steps_taken"], r["attempted_steps"]) == (out[0][0]["status_name"], out[0][0]["steps_taken"],
+                                                                              out[0][0]["attempted_steps"])
+        np.testing.assert_array_equal(x, out[0][1])
+    r0 = out[0][0]
+    assert r0["status_name"] == single["status_name"] == "Optimal"
+    scale = 1 + abs(p["objective_star"])
+    assert abs(r0["primal_objective"] - p["objective_star"]) <= 2e-4 * scale
+    assert abs(r0["primal_objective"] - single["primal_objective"]) <= 2e-4 * scale
