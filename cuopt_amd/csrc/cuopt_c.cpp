@@ -246,6 +246,9 @@ bool write_problem_as_mps(const Problem& p, const std::string& path)
   };
   for (int32_t i = 0; i < p.m; ++i) {
     const double lo = p.lo[i], hi = p.hi[i];
+    // (a free row, -inf..+inf, has no MPS spelling other than 'N'; every reader -- this library's and the reference's --
+    // drops N rows after the first, so such rows disappear on a round trip: the LP is unchanged, its row count is not.
+    // The reference's writer turns them into 'G' rows with right-hand side 0, which changes the LP.)
     char type = lo == hi ? 'E' : (std::isinf(lo) && lo < 0 ? (std::isinf(hi) ? 'N' : 'L') : 'G');
     if (ranged_as_L(i)) type = 'L';
     std::fprintf(f, " %c  %s\n", type, row(i).c_str());
