@@ -191,6 +191,7 @@ for _n in ("cuOptGetObjectiveValue", "cuOptGetSolveTime", "cuOptGetMIPGap", "cuO
     _proto(_n, c_int, c_void_p, P(c_double))
 _proto("cuOptAmdGetPdlpStats", c_int, c_void_p, P(Result))
 _proto("cuOptAmdGetSolveInfo", c_int, c_void_p, c_char_p, c_int)
+_proto("cuOptAmdGetName", c_int, c_void_p, c_int, c_int, c_char_p, c_int)
 
 _proto("cuoptamd_last_error", c_char_p)
 _proto("cuoptamd_hyper_preset", None, c_int, P(Hyper))
@@ -361,6 +362,15 @@ class Problem:
         lib.cuOptGetObjectiveOffset(self.handle, C.byref(off))
         d["objective_offset"] = off.value
         return d
+
+    def names(self, kind):
+        """variable (kind 0) or row (kind 1) names of a problem read from an MPS file; [] when it has none"""
+        out, buf = [], C.create_string_buffer(4096)
+        for i in range(self.n if kind == 0 else self.m):
+            if lib.cuOptAmdGetName(self.handle, kind, i, buf, 4096) != CUOPT_SUCCESS:
+                return []
+            out.append(buf.value.decode())
+        return out
 
     def close(self):
         if self.handle:

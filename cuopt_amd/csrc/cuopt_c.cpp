@@ -984,6 +984,19 @@ cuopt_int_t cuOptAmdReadSolutionFile(cuOptOptimizationProblem problem, const cha
   return CUOPT_SUCCESS;
 }
 
+// Extension: variable / row names of a problem read from an MPS file (the reference exposes them through its Python data
+// model, data_model.py:592-600; its C API has no getter).  kind 0 = variable, 1 = constraint row.
+cuopt_int_t cuOptAmdGetName(cuOptOptimizationProblem problem, cuopt_int_t kind, cuopt_int_t index, char* buffer,
+                            cuopt_int_t buffer_size)
+{
+  if (problem == nullptr || buffer == nullptr || buffer_size <= 0 || (kind != 0 && kind != 1)) return CUOPT_INVALID_ARGUMENT;
+  const Problem* p = static_cast<const Problem*>(problem);
+  const std::vector<std::string>& names = kind == 0 ? p->var_names : p->row_names;
+  if (index < 0 || (size_t)index >= names.size()) return CUOPT_INVALID_ARGUMENT;
+  std::snprintf(buffer, (size_t)buffer_size, "%s", names[(size_t)index].c_str());
+  return CUOPT_SUCCESS;
+}
+
 // Not part of the reference ABI: full PDLP statistics of a solution (additional_termination_information_t
 // is only reachable through the C++/Python API in the reference).  Used by tests and benches.
 cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats)

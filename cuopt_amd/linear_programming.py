@@ -246,6 +246,7 @@ def Read(mps_file_path, fixed_mps_format=False):
     prob = capi.Problem.read(mps_file_path)
     try:
         d = prob.to_dict()
+        var_names, row_names = prob.names(0), prob.names(1)
     finally:
         prob.close()
     dm = DataModel()
@@ -259,6 +260,8 @@ def Read(mps_file_path, fixed_mps_format=False):
     dm.set_objective_offset(d.get("objective_offset", 0.0))
     if d.get("var_types") is not None:
         dm.set_variable_types(np.array([chr(c) for c in np.asarray(d["var_types"], dtype=np.uint8)]))
+    dm.set_variable_names(var_names)
+    dm.set_row_names(row_names)
     return dm
 
 
@@ -437,7 +440,11 @@ def Solve(data_model, solver_settings=None, log_file=""):
         solver_settings.set_parameter(CUOPT_LOG_FILE, log_file)
     if _is_mip(data_model.get_variable_types()):
         raise ValueError("MILP is outside the scope of the MI355X-native PDLP library: only continuous LPs can be solved")
-    p = data_model._problem_dict()
+    try:
+        p = data_model._problem_dict()
+    except ValueError as e:  # an incomplete model is a ValidationError SOLUTION, not an exception (solver.py / test_lp_solver.py:323-383)
+        return Solution(ProblemCategory.LP, {}, 0.0, np.zeros(0), np.zeros(0), np.zeros(0), 0, ErrorStatus.ValidationError,
+                        str(e), 0.0, 0.0, 0.0, 0.0, 0.0, 0)
     st = solver_settings.toDict()
     ws = solver_settings.get_pdlp_warm_start_data()
     init_x, init_y = data_model.get_initial_primal_solution(), data_model.get_initial_dual_solution()
@@ -480,6 +487,8 @@ def BatchSolve(data_model_list, solver_settings=None, log_file=""):
     """solver.py:101-190: independent LPs solved concurrently on one GPU (cuoptamd_batch_solve) -> (solutions, seconds)"""
     if solver_settings is None:
         solver_settings = SolverSettings()
+    if solver_settings.get_pdlp_warm_start_data() is not None:
+        raise ValueError("BatchSolve: pdlp_warm_start_data cannot be used in batch mode")  # test_lp_solver.py:567-589
     st = solver_settings.toDict()
     names = {"absolute_gap_tolerance", "relative_gap_tolerance", "absolute_primal_tolerance", "relative_primal_tolerance",
              "absolute_dual_tolerance", "relative_dual_tolerance", "iteration_limit", "time_limit"}

@@ -33,6 +33,11 @@ cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats)
  * engine and says so instead of pretending) */
 cuopt_int_t cuOptAmdGetSolveInfo(cuOptSolution solution, char* buffer, cuopt_int_t buffer_size);
 
+/* name of variable (kind 0) / constraint row (kind 1) `index` of a problem that came from cuOptReadProblem
+ * (CUOPT_INVALID_ARGUMENT when the problem carries no names) */
+cuopt_int_t cuOptAmdGetName(cuOptOptimizationProblem problem, cuopt_int_t kind, cuopt_int_t index, char* buffer,
+                            cuopt_int_t buffer_size);
+
 /* reads a .sol file (CUOPT_SOLUTION_FILE output, or MIPLIB style) into the variable order of `problem` (which must carry
  * variable names, i.e. come from cuOptReadProblem); objective_value / status may be NULL.  Mirrors
  * cpp/src/math_optimization/solution_reader.cu:57-145.  CUOPT_MPS_FILE_ERROR: cannot open; CUOPT_VALIDATION_ERROR: a

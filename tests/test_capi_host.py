@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
     for h in headers:
         names |= _declared_functions(h)
     assert len([n for n in names if n.startswith("cuOpt") and not n.startswith("cuOptAmd")]) == 41  # cuopt_c.h:89-668
-    assert {n for n in names if n.startswith("cuOptAmd")} == {"cuOptAmdGetPdlpStats", "cuOptAmdGetSolveInfo", "cuOptAmdReadSolutionFile"}  # cuopt_c_ext.h
+    assert {n for n in names if n.startswith("cuOptAmd")} == {"cuOptAmdGetPdlpStats", "cuOptAmdGetSolveInfo", "cuOptAmdReadSolutionFile", "cuOptAmdGetName"}  # cuopt_c_ext.h
     missing = [n for n in sorted(names) if not hasattr(capi.lib, n)]
     assert not missing, missing
 

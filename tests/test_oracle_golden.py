@@ -1,6 +1,9 @@
 """CPU: pins the C oracle (oracle/pdlp_oracle.c) on every known answer the reference's own tests
 hold for the PDLP path, and on the objectives of the reference's CPU dual simplex (recorded in
 tests/golden/problems.json by scripts/make_golden.py; re-checked live when oracle/_ref exists)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -226,3 +229,17 @@ def test_trust_region_bounds_against_an_independent_solution():
             assert ref["lagrangian"] == pytest.approx(lagrangian, rel=1e-12, abs=1e-12 * scale)
             assert ref["lower_bound"] == pytest.approx(lower, rel=1e-8, abs=1e-8 * scale), (seed, wp, wd, radius)
             assert ref["upper_bound"] == pytest.approx(upper, rel=1e-8, abs=1e-8 * scale), (seed, wp, wd, radius)
+
+
+def test_afiro_solution_vector_of_the_reference_pdlp(golden_problems):
+    """ITERATE-LEVEL pin against cuOpt's own PDLP: test_lp_solver.py:386-475 (test_parse_var_names) holds the 32 primal
+    values cuOpt's PDLP returns on afiro at default settings (method PDLP, Stable2, 1e-4) and compares them with rel 1e-4.
+    The oracle -- scaling, initial step / weight, 160 PDHG iterations with their accept/reject decisions, the KKT
+    restarts, the averaging and the choice of the returned iterate -- reproduces that vector to ~1e-9."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "afiro_pdlp_vars.json")))
+    meta = golden_problems["afiro"]["meta"]
+    assert meta["var_names"] == g["expected_names"]
+    o = orcbind.solve(golden_problems["afiro"]["problem"])
+    assert o["status"] == "Optimal"
+    want = np.array([g["expected_values"][n] for n in meta["var_names"]])
+    np.testing.assert_allclose(o["x"], want, rtol=1e-6, atol=1e-9)  # the reference's own tolerance is rel 1e-4

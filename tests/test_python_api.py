@@ -157,3 +157,110 @@ def test_batch_solve_matches_individual_solves(golden_problems):  # test_lp_solv
         one = lp.Solve(dm, settings)
         assert b.get_termination_status() == one.get_termination_status()
         assert b.get_primal_objective() == pytest.approx(one.get_primal_objective(), rel=1e-6, abs=1e-9)
+
+
+def test_solver_settings():  # test_lp_solver.py:267-320 (no GPU involved)
+    settings = lp.SolverSettings()
+    names = (lp.CUOPT_ABSOLUTE_DUAL_TOLERANCE, lp.CUOPT_RELATIVE_DUAL_TOLERANCE, lp.CUOPT_ABSOLUTE_PRIMAL_TOLERANCE,
+             lp.CUOPT_RELATIVE_PRIMAL_TOLERANCE, lp.CUOPT_ABSOLUTE_GAP_TOLERANCE, lp.CUOPT_RELATIVE_GAP_TOLERANCE,
+             lp.CUOPT_PRIMAL_INFEASIBLE_TOLERANCE, lp.CUOPT_DUAL_INFEASIBLE_TOLERANCE)
+    for k in names:
+        settings.set_parameter(k, 1e-5)
+    for k in names:
+        assert settings.get_parameter(k) == 1e-5
+    assert settings.get_parameter(CUOPT_TIME_LIMIT) == float("inf")
+    settings.set_parameter(CUOPT_ITERATION_LIMIT, 10)
+    settings.set_parameter(CUOPT_TIME_LIMIT, 10.2)
+    assert settings.get_parameter(CUOPT_ITERATION_LIMIT) == 10 and settings.get_parameter(CUOPT_TIME_LIMIT) == 10.2
+    settings.set_parameter(CUOPT_INFEASIBILITY_DETECTION, False)
+    assert not settings.get_parameter(CUOPT_INFEASIBILITY_DETECTION)
+    assert settings.get_parameter(CUOPT_PDLP_SOLVER_MODE) == int(PDLPSolverMode.Stable2)
+    with pytest.raises(ValueError):
+        settings.set_parameter(CUOPT_PDLP_SOLVER_MODE, 10)
+    settings.set_parameter(CUOPT_PDLP_SOLVER_MODE, PDLPSolverMode.Methodical1)
+    assert settings.get_parameter(CUOPT_PDLP_SOLVER_MODE) == int(PDLPSolverMode.Methodical1)
+
+
+def test_check_data_model_validity_without_a_gpu():  # test_lp_solver.py:323-360: incomplete models -> ValidationError solutions
+    dm = lp.DataModel()
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.ValidationError
+    dm.set_csr_constraint_matrix(np.array([1.0]), np.array([0], dtype=np.int32), np.array([0, 1], dtype=np.int32))
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.ValidationError
+    dm.set_constraint_bounds(np.array([1.0]))
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.ValidationError
+    dm.set_objective_coefficients(np.array([1.0]))
+    dm.set_maximize(True)
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.ValidationError  # row types still missing
+
+
+@pytest.mark.gpu
+def test_check_data_model_validity_complete_models_solve():  # test_lp_solver.py:361-383
+    dm = lp.DataModel()
+    dm.set_csr_constraint_matrix(np.array([1.0]), np.array([0], dtype=np.int32), np.array([0, 1], dtype=np.int32))
+    dm.set_constraint_bounds(np.array([1.0]))
+    dm.set_objective_coefficients(np.array([1.0]))
+    dm.set_row_types(np.array(["E"]))
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.Success
+    dm.set_constraint_lower_bounds(np.array([1.0]))
+    dm.set_constraint_upper_bounds(np.array([1.0]))
+    assert lp.Solve(dm).get_error_status() == lp.ErrorStatus.Success
+
+
+@pytest.mark.gpu
+def test_parse_var_names_and_the_reference_pdlp_solution_vector(golden_problems, tmp_path):
+    """test_lp_solver.py:386-475: names survive the parser, and the solution of a PDLP request at default settings equals,
+    variable by variable, the vector the reference's test holds for cuOpt's PDLP (rel 1e-4 there; 1e-6 here)"""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "afiro_pdlp_vars.json")))
+    path = tmp_path / "afiro.mps"
+    p = dict(golden_problems["afiro"]["problem"])
+    p["var_names"], p["row_names"] = golden_problems["afiro"]["meta"]["var_names"], golden_problems["afiro"]["meta"]["row_names"]
+    write_mps(str(path), p, name="AFIRO")
+    dm = lp.Read(str(path))
+    assert dm.get_variable_names() == g["expected_names"]
+    settings = lp.SolverSettings()
+    settings.set_parameter(CUOPT_METHOD, SolverMethod.PDLP)
+    solution = lp.Solve(dm, settings)
+    assert solution.get_termination_reason() == "Optimal"
+    assert len(solution.get_vars()) == len(g["expected_values"])
+    for key, want in g["expected_values"].items():
+        assert solution.get_vars()[key] == pytest.approx(want, rel=1e-6, abs=1e-9)
+
+
+@pytest.mark.gpu
+def test_batch_solver_refuses_warm_start_data(golden_problems):  # test_lp_solver.py:567-589
+    dm = model_of(golden_problems["afiro"]["problem"])
+    settings = lp.SolverSettings()
+    settings.set_parameter(CUOPT_METHOD, SolverMethod.PDLP)
+    settings.set_optimality_tolerance(1e-3)
+    settings.set_pdlp_warm_start_data(lp.Solve(dm, settings).get_pdlp_warm_start_data())
+    with pytest.raises(Exception):
+        lp.BatchSolve([dm, dm], settings)
+
+
+@pytest.mark.gpu
+def test_dual_simplex_request(golden_problems):
+    """test_lp_solver.py:592-606 asks for SolverMethod.DualSimplex and gets -464.7531 from the simplex.  This library has
+    one engine: same status and objective (simplex-grade tolerances), and it SAYS it was PDLP (the one assertion of the
+    reference test that is deliberately inverted)"""
+    dm = model_of(golden_problems["afiro"]["problem"])
+    settings = lp.SolverSettings()
+    settings.set_parameter(CUOPT_METHOD, SolverMethod.DualSimplex)
+    solution = lp.Solve(dm, settings)
+    assert solution.get_termination_status() == LPTerminationStatus.Optimal
+    assert solution.get_primal_objective() == pytest.approx(-464.7531)
+    assert solution.get_solved_by_pdlp()
+
+
+@pytest.mark.gpu
+def test_milp_models_are_refused():  # test_lp_solver.py:630-672 (test_bound_in_maximization) is a MILP: out of scope
+    dm = lp.DataModel()
+    dm.set_objective_coefficients(np.array([15.0, 100.0]))
+    dm.set_maximize(True)
+    dm.set_csr_constraint_matrix(np.array([2.0, 20.0]), np.array([0, 1], dtype=np.int32), np.array([0, 2], dtype=np.int32))
+    dm.set_constraint_bounds(np.array([102.0]))
+    dm.set_row_types(np.array(["L"]))
+    dm.set_variable_types(np.array(["I", "I"]))
+    with pytest.raises(ValueError):
+        lp.Solve(dm)
