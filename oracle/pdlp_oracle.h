@@ -14,8 +14,12 @@
  *     Methodical1 initial step size 1.4893 / primal weight 0.0141652, good-max 17, max_offset 0,
  *     ranged LP 32, per-constraint residual 0.1, iteration-limit statuses, 2x1 toy LP ...),
  *   - objectives of the reference's own CPU dual simplex compiled in place (oracle/_ref).
- * Iterate-level (bit-for-bit x_k) parity with cuOpt is unpinned by any fixture (cuSPARSE's
- * reduction order is closed source) -- see DESIGN.md "parity".
+ *   - the SOLUTION VECTOR cuOpt's own PDLP returns on afiro at default settings, held by the reference's
+ *     test_lp_solver.py:386-475 (32 values, compared there with rel 1e-4): reproduced to ~1e-9, i.e. the whole
+ *     trajectory (scaling, 160 iterations of accept/reject, restarts, averaging, returned iterate) follows cuOpt's,
+ *   - an independent solution of the bound-constrained trust-region problem for the Methodical1 restart.
+ * Bit-for-bit x_k parity with cuOpt is not attainable (cuSPARSE's reduction order is closed source); parity is
+ * pinned at the level of that vector, the initial step / weight, statuses and objectives -- see DESIGN.md "parity".
  */
 #ifndef PDLP_ORACLE_H
 #define PDLP_ORACLE_H
