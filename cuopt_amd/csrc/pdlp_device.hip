@@ -455,6 +455,15 @@ __global__ void __launch_bounds__(kBlock) k_reduce(int64_t n, const double* __re
     block_reduce<SumOp, 1>(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
 }
+__global__ void __launch_bounds__(kBlock) k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                double* __restrict__ part)
+{
+  __shared__ double red[8];
+  double acc[1] = {0.0};
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc[0] += a[i] * b[i];
+  block_reduce<SumOp, 1>(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
 // out[dst + q] = reduce(part[q*nb .. q*nb+nb)) ; op_mask bit q set => max
 __global__ void __launch_bounds__(kBlock) k_finalize(const double* __restrict__ part, int nb, int nq,
                                                      unsigned op_mask, double* __restrict__ out)
@@ -2485,6 +2494,36 @@ int pdlpdev_set_initial(pdlpdev_ctx* ctx, const double* x, const double* y)
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+// update_step_size_on_initial_solution (pdlp.cu:878-948): the quantities of one compute_step_sizes call with
+// delta_primal = x0, delta_dual = y' = y0 and a zero A^T y -- on the SCALED iterate that set_initial left in the current
+// buffers.  out = {interaction x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|, max|y0|}.  Leaves A^T y0 in the current A^T y
+// buffer (which is what the loop needs next anyway).
+int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(pdlpdev_compute_aty(ctx));
+  TRY(fetch_ctl(ctx, nullptr));
+  const int cur = ctx->ctl_h->cur;
+  hipStream_t s = ctx->stream;
+  const int n = ctx->n, m = ctx->m;
+  const int g = std::min(grid_for(n), kGenericBlocks);
+  k_dot<<<g, kBlock, 0, s>>>(n, ctx->x[cur], ctx->aty[cur], ctx->part_g);
+  k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 0u, ctx->scal + 48);
+  TRY(reduce_vec(ctx, 1, n, ctx->x[cur], nullptr, 49));
+  TRY(reduce_vec(ctx, 1, m, ctx->y[cur], nullptr, 50));
+  TRY(reduce_vec(ctx, 0, n, ctx->x[cur], nullptr, 51));
+  TRY(reduce_vec(ctx, 0, m, ctx->y[cur], nullptr, 52));
+  LAUNCH_CHECK();
+  if (ctx->comm) {  // the dual side is sharded
+    TRY(allreduce(ctx, ctx->scal + 50, 1, rccl::kSum));
+    TRY(allreduce(ctx, ctx->scal + 52, 1, rccl::kMax));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->scal_h + 48, ctx->scal + 48, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < 5; ++i) out[i] = ctx->scal_h[48 + i];
+  return 0;
+}
+
 int pdlpdev_project_primal(pdlpdev_ctx* ctx)
 {
   HIP_TRY(hipSetDevice(ctx->device));

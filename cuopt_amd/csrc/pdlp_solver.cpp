@@ -696,9 +696,48 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
   DEV(pdlpdev_set_step(s->dev, step, weight));
   if (settings->initial_k >= 0) DEV(pdlpdev_set_k(s->dev, settings->initial_k));
   if (init_x || init_y) {
-    if (hyper->update_primal_weight_on_initial_solution || hyper->update_step_size_on_initial_solution)
-      return fail(-7, "update_*_on_initial_solution hyper-parameters are not implemented");
     DEV(pdlpdev_set_initial(s->dev, init_x, init_y ? init_y + s->row_begin : nullptr));
+    // update_{step_size,primal_weight}_on_initial_solution (pdlp.cu:878-979; off in every preset, toggled by the
+    // reference's initial_solution_test, pdlp_test.cu:245-523: no change without BOTH iterates or with an all-zero one)
+    if (hyper->update_step_size_on_initial_solution && init_x && init_y) {
+      if (hyper->compute_initial_step_size_before_scaling)
+        return fail(-7, "update_step_size_on_initial_solution with compute_initial_step_size_before_scaling is not implemented");
+      double st[5];
+      DEV(pdlpdev_initial_solution_stats(s->dev, st));
+      if (st[3] != 0.0 && st[4] != 0.0) {
+        // one compute_step_sizes with delta = the initial iterate and A^T y = 0 (adaptive_step_size_strategy.cu:91-188);
+        // the kernel's own increment of the device iteration counter is not undone
+        const double movement = hyper->primal_distance_smoothing * weight * st[1] + (hyper->dual_distance_smoothing / weight) * st[2];
+        if (movement > 0.0 && movement < 1.0e100) {
+          const int k_after  = (settings->initial_k >= 0 ? settings->initial_k : 0) + 1;
+          const double coef = (double)k_after, inter = std::fabs(st[0]);
+          const double limit = inter > 0.0 ? movement / inter : std::numeric_limits<double>::infinity();
+          const double s1 = (1.0 - std::pow(coef + 1.0, -hyper->reduction_exponent)) * limit;
+          const double s2 = (1.0 + std::pow(coef + 1.0, -hyper->growth_exponent)) * step;
+          step = std::min(s1, s2);
+          DEV(pdlpdev_set_step(s->dev, step, weight));
+          DEV(pdlpdev_set_k(s->dev, k_after));
+        } else {
+          s->step_error = true;  // valid_step_size = -1: the first loop trip is a major iteration that reports it
+        }
+      }
+      s->need_aty = false;  // A^T y0 was just computed
+    }
+    if (hyper->update_primal_weight_on_initial_solution) {
+      // update_distance (pdlp_restart_strategy.cu:440-465): distance to the (zero) anchors, anchors <- iterate, new weight;
+      // on the unscaled iterate when the initial weight is computed before scaling (pdlp.cu:950-979)
+      double dist2[2];
+      DEV(pdlpdev_restart(s->dev, PDLPDEV_CURRENT, hyper->compute_initial_primal_weight_before_scaling ? 1 : 0, dist2));
+      const double pd = std::sqrt(dist2[0]), dd = std::sqrt(dist2[1]);
+      const double guard = 1.0e-10;
+      if (!(pd < guard || pd >= 1.0 / guard || dd < guard || dd >= 1.0 / guard)) {
+        const double theta = hyper->primal_weight_update_smoothing;
+        weight = std::exp(theta * std::log(dd / pd) + (1.0 - theta) * std::log(weight));
+        DEV(pdlpdev_set_step(s->dev, -1.0, weight));
+      }
+    }
+    s->result.initial_step_size     = step;
+    s->result.initial_primal_weight = weight;
   }
   if (hyper->project_initial_primal) DEV(pdlpdev_project_primal(s->dev));  // pdlp.cu:1041-1056
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));

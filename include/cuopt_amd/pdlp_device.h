@@ -197,6 +197,9 @@ int pdlpdev_set_k(pdlpdev_ctx* ctx, int32_t k);
 int pdlpdev_set_initial(pdlpdev_ctx* ctx, const double* x, const double* y);
 /* x <- clamp(x, lb, ub) on the scaled problem (pdlp.cu:1041-1056) */
 int pdlpdev_project_primal(pdlpdev_ctx* ctx);
+/* {x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|, max|y0|} of the scaled initial iterate (update_step_size_on_initial_solution,
+ * pdlp.cu:878-948); leaves A^T y0 in the current A^T y buffer */
+int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5]);
 
 /* ---- the hot loop ---------------------------------------------------------------------------- */
 /* AtY <- A^T y for the current iterate (pdhg.cu:119-134); needed before the first step and after

@@ -871,19 +871,69 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
   /* get_primal_and_dual_stepsizes, adaptive_step_size_strategy.cu:347-368 */
   tau   = step_size / w;
   sigma = step_size * w;
-  /* update_primal_dual_solutions, pdlp.cu:857-981 (the two update_* presets are off everywhere) */
+  /* update_primal_dual_solutions, pdlp.cu:857-981.  The two update_* hyper-parameters are off in every preset; the
+   * reference's initial_solution_test (pdlp_test.cu:245-523) toggles them and pins the behaviour: nothing changes without
+   * BOTH iterates, or when one of them is all zero; both non-zero -> new step size / new primal weight. */
   if (init_x || init_y) {
-    if (H[ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION] != 0.0 ||
-        H[ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION] != 0.0) {
-      rc = -2;
-      goto done;
-    }
     if (init_x)
       for (int j = 0; j < n; ++j) x[j] = init_x[j];
     if (init_y)
       for (int i = 0; i < m; ++i) y[i] = init_y[i];
-    for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j]; /* scale_solutions :410-427 */
-    for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+    if (H[ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION] != 0.0) { /* pdlp.cu:878-948 */
+      int nzx = 0, nzy = 0;
+      for (int j = 0; j < n; ++j) nzx |= x[j] != 0.0;
+      for (int i = 0; i < m; ++i) nzy |= y[i] != 0.0;
+      if (init_x && init_y && nzx && nzy) {
+        if (H[ORC_H_STEP_SIZE_BEFORE_SCALING] != 0.0) { /* unscaled vectors against the scaled matrix: no preset does it */
+          rc = -2;
+          goto done;
+        }
+        /* delta_primal = x0, delta_dual = potential_next_dual = y0 (scaled, :917-926), current A^T y = 0 */
+        for (int j = 0; j < n; ++j) dx[j] = x[j] / Dc[j];
+        for (int i = 0; i < m; ++i) dy[i] = y[i] / Dr[i];
+        orc_spmv(n, t_offsets, t_indices, P.At, dy, atyn);
+        /* compute_step_sizes with the device iteration counter incremented by the kernel
+         * (adaptive_step_size_strategy.cu:91-188: *pdhg_iteration += 1 is NOT undone by the host's --) */
+        const double inter = blocked_sum2(n, dx, atyn), dx2 = blocked_sum2(n, dx, dx), dy2 = blocked_sum2(m, dy, dy);
+        const double movement = H[ORC_H_PRIMAL_DISTANCE_SMOOTHING] * w * dx2 + (H[ORC_H_DUAL_DISTANCE_SMOOTHING] / w) * dy2;
+        if (movement <= 0.0 || movement >= 1.0e100) {
+          valid_step_size = -1;
+        } else {
+          k_dev += 1;
+          const double coef  = (double)k_dev;
+          const double limit = fabs(inter) > 0.0 ? movement / fabs(inter) : ORC_INF;
+          const double s1    = (1.0 - pow(coef + 1.0, -H[ORC_H_REDUCTION_EXPONENT])) * limit;
+          const double s2    = (1.0 + pow(coef + 1.0, -H[ORC_H_GROWTH_EXPONENT])) * step_size;
+          step_size          = dmin(s1, s2);
+          tau                = step_size / w;
+          sigma              = step_size * w;
+        }
+        for (int j = 0; j < n; ++j) atyn[j] = 0.0;
+      }
+    }
+    /* the iterate is scaled before the weight update unless the weight is computed before scaling (:950-979) */
+    if (H[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING] == 0.0) {
+      for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j]; /* scale_solutions :410-427 */
+      for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+    }
+    if (H[ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION] != 0.0) { /* update_distance, pdlp_restart_strategy.cu:440-465 */
+      const double pdist = sqrt(blocked_sum2(n, x, x)), ddist = sqrt(blocked_sum2(m, y, y)); /* anchors are zero */
+      memcpy(lrx, x, sizeof(double) * (size_t)n); /* update_last_restart_information (as they are at this point) */
+      memcpy(lry, y, sizeof(double) * (size_t)m);
+      const double g = 1.0e-10; /* compute_new_primal_weight :684-750 */
+      if (!(pdist < 0.0 + g || pdist >= 1.0 / g || ddist < 0.0 + g || ddist >= 1.0 / g)) {
+        const double th = H[ORC_H_PRIMAL_WEIGHT_UPDATE_SMOOTHING];
+        w               = exp(th * log(ddist / pdist) + (1.0 - th) * log(w));
+        tau             = step_size / w;
+        sigma           = step_size * w;
+      }
+    }
+    if (H[ORC_H_PRIMAL_WEIGHT_BEFORE_SCALING] != 0.0) {
+      for (int j = 0; j < n; ++j) x[j] = x[j] / Dc[j];
+      for (int i = 0; i < m; ++i) y[i] = y[i] / Dr[i];
+    }
+    stats[ORC_O_INITIAL_STEP_SIZE]     = step_size; /* what get_step_size_h() / get_primal_weight_h() show the test */
+    stats[ORC_O_INITIAL_PRIMAL_WEIGHT] = w;
   }
   if (H[ORC_H_PROJECT_INITIAL_PRIMAL] != 0.0) { /* pdlp.cu:1041-1056, clamp utils.cuh:131-137 */
     for (int j = 0; j < n; ++j) x[j] = dmin(dmax(x[j], P.lb[j]), P.ub[j]);

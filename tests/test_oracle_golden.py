@@ -243,3 +243,34 @@ def test_afiro_solution_vector_of_the_reference_pdlp(golden_problems):
     assert o["status"] == "Optimal"
     want = np.array([g["expected_values"][n] for n in meta["var_names"]])
     np.testing.assert_allclose(o["x"], want, rtol=1e-6, atol=1e-9)  # the reference's own tolerance is rel 1e-4
+
+
+def _initial(golden_problems, upd_step, upd_weight, x0=None, y0=None):
+    p = golden_problems["afiro"]["problem"]
+    h = orcbind.hyper_preset(2)  # Methodical1, like the reference test
+    h[orcbind.H["ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION"]] = float(upd_step)
+    h[orcbind.H["ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION"]] = float(upd_weight)
+    o = orcbind.solve(p, mode=2, hyper=h, tol=0.0, iteration_limit=0,
+                      init_x=None if x0 is None else np.full(p["n"], float(x0)),
+                      init_y=None if y0 is None else np.full(p["m"], float(y0)))
+    return o["initial_step_size"], o["initial_primal_weight"]
+
+
+def test_initial_solution_test_of_the_reference(golden_problems):
+    """pdlp_test.cu:245-523 (initial_solution_test): with update_{step_size,primal_weight}_on_initial_solution toggled, the
+    pinned 1.4893 / 0.0141652 stay put unless BOTH initial iterates are given and non-zero, in which case the toggled
+    quantity (and only it) moves"""
+    step0, w0, tol = 1.4893, 0.0141652, 1e-4
+    same = lambda v, ref: abs(v - ref) <= tol
+    for us, uw in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        for x0, y0 in ((None, None), (1, None), (None, 1), (0, 0), (0, None), (None, 0)):
+            s, w = _initial(golden_problems, us, uw, x0, y0)
+            assert same(s, step0) and same(w, w0), (us, uw, x0, y0, s, w)
+    s, w = _initial(golden_problems, 0, 0, 1, 1)       # flags off: an initial solution changes nothing (:285-318)
+    assert same(s, step0) and same(w, w0)
+    s, w = _initial(golden_problems, 0, 1, 1, 1)       # :470-487
+    assert same(s, step0) and not same(w, w0)
+    s, w = _initial(golden_problems, 1, 0, 1, 1)       # :488-503
+    assert not same(s, step0) and same(w, w0)
+    s, w = _initial(golden_problems, 1, 1, 1, 1)
+    assert not same(s, step0) and not same(w, w0)

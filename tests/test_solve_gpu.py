@@ -617,3 +617,43 @@ def test_warm_start_of_another_problem_is_refused(golden_problems):
     # the same problem takes it
     r = capi.Solver(a, tol=1e-4, warm_start=ws, iteration_limit=20000).advance()
     assert r["status_name"] == "Optimal"
+
+
+def test_initial_solution_test_of_the_reference_on_the_device(golden_problems):
+    """pdlp_test.cu:245-523 with the two update_*_on_initial_solution hyper-parameters toggled: unchanged 1.4893 / 0.0141652
+    unless both initial iterates are given and non-zero; then step size / primal weight move, to the oracle's values"""
+    p = golden_problems["afiro"]["problem"]
+    step0, w0, tol = 1.4893, 0.0141652, 1e-4
+
+    def run(us, uw, x0, y0):
+        h = capi.hyper_preset(2)
+        h.update_step_size_on_initial_solution, h.update_primal_weight_on_initial_solution = us, uw
+        s = capi.Solver(p, hyper=h, tol=0.0, iteration_limit=0, init_x=None if x0 is None else np.full(p["n"], float(x0)),
+                        init_y=None if y0 is None else np.full(p["m"], float(y0)))
+        r = s.advance()
+        s.close()
+        oh = orcbind.hyper_preset(2)
+        oh[orcbind.H["ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION"]] = float(us)
+        oh[orcbind.H["ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION"]] = float(uw)
+        o = orcbind.solve(p, mode=2, hyper=oh, tol=0.0, iteration_limit=0,
+                          init_x=None if x0 is None else np.full(p["n"], float(x0)),
+                          init_y=None if y0 is None else np.full(p["m"], float(y0)))
+        assert r["initial_step_size"] == pytest.approx(o["initial_step_size"], rel=1e-9)
+        assert r["initial_primal_weight"] == pytest.approx(o["initial_primal_weight"], rel=1e-9)
+        return r["initial_step_size"], r["initial_primal_weight"]
+    same = lambda v, ref: abs(v - ref) <= tol
+    for us, uw in ((1, 0), (0, 1), (1, 1)):
+        for x0, y0 in ((None, None), (1, None), (None, 1), (0, 0)):
+            s, w = run(us, uw, x0, y0)
+            assert same(s, step0) and same(w, w0), (us, uw, x0, y0)
+    s, w = run(0, 1, 1, 1)
+    assert same(s, step0) and not same(w, w0)
+    s, w = run(1, 0, 1, 1)
+    assert not same(s, step0) and same(w, w0)
+    s, w = run(1, 1, 1, 1)
+    assert not same(s, step0) and not same(w, w0)
+    # and a solve from such a start still converges to the pinned objective
+    h = capi.hyper_preset(1)
+    h.update_step_size_on_initial_solution = h.update_primal_weight_on_initial_solution = 1
+    r = capi.Solver(p, hyper=h, tol=1e-6, init_x=np.full(p["n"], 1.0), init_y=np.full(p["m"], 1.0)).advance()
+    assert r["status_name"] == "Optimal" and r["primal_objective"] == pytest.approx(-464.7531, rel=1e-4)
