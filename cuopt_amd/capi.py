@@ -100,7 +100,8 @@ class SolverSettings(C.Structure):
                 ("strict_infeasibility", c_int), ("primal_infeasible_tolerance", c_double),
                 ("dual_infeasible_tolerance", c_double), ("save_best_primal_so_far", c_int),
                 ("log_to_console", c_int), ("log_file", c_char_p), ("unbounded_from_feasible_iterates", c_int),
-                ("accept_enabled", c_int), ("accept_tolerance", c_double * 6)]
+                ("accept_enabled", c_int), ("accept_tolerance", c_double * 6),
+                ("relative_primal_tolerance_factor", c_double), ("relative_dual_tolerance_factor", c_double)]
 
 
 class Result(C.Structure):

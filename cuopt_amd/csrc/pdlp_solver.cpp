@@ -608,6 +608,7 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->unbounded_from_feasible_iterates = 0;
   s->accept_enabled                   = 0;
   for (double& t : s->accept_tolerance) t = 1e-4;
+  s->relative_primal_tolerance_factor = s->relative_dual_tolerance_factor = -1.0;
 }
 
 void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
@@ -688,6 +689,9 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
 {
   const cuoptamd_hyper* hyper = &s->H;
   const cuoptamd_settings* settings = &s->S;
+  // set_relative_{primal,dual}_tolerance_factor (pdlp.cu:209-231): the caller's ||b|| / ||c|| for the termination rule
+  if (settings->relative_primal_tolerance_factor >= 0.0) s->norm_b = settings->relative_primal_tolerance_factor;
+  if (settings->relative_dual_tolerance_factor >= 0.0) s->norm_c = settings->relative_dual_tolerance_factor;
   double step = s->computed_step, weight = s->computed_weight;
   if (settings->initial_step_size >= 0.0) step = settings->initial_step_size;  // pdlp.cu:1014-1021
   if (settings->initial_primal_weight >= 0.0) weight = settings->initial_primal_weight;
@@ -890,9 +894,10 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
   s->result = blank;
   if (s->empty_problem) return 0;
   DEV(pdlpdev_reset(s->dev, lb, ub, lo ? lo + s->row_begin : nullptr, hi ? hi + s->row_begin : nullptr));
+  // ||b||, ||c|| of the termination rule: from the problem again (the previous settings may have overridden them)
+  DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
   if (lo || hi) {
-    // ||b|| of the termination rule and the initial primal weight depend on the row bounds (pdlp.cu:1260-1309)
-    DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
+    // the initial primal weight depends on the row bounds (pdlp.cu:1260-1309)
     double nr[2];
     DEV(pdlpdev_weight_norms(s->dev, s->H.compute_initial_primal_weight_before_scaling, nr));
     const double cn = std::sqrt(s->H.initial_primal_weight_c_scaling * nr[0]);

@@ -118,6 +118,10 @@ typedef struct cuoptamd_settings {
    * save_best_primal_so_far is set (same snapshot buffers). */
   int32_t accept_enabled;
   double accept_tolerance[6];
+  /* set_relative_{primal,dual}_tolerance_factor (pdlp.cu:209-231): the norms ||b|| / ||c|| of the termination rule
+   * (eps_abs + eps_rel * factor) replaced by the caller's values -- the MIP side keeps them fixed across re-solves.
+   * Negative (default): computed from the problem. */
+  double relative_primal_tolerance_factor, relative_dual_tolerance_factor;
 } cuoptamd_settings;
 
 /* additional_termination_information_t (pdlp/solver_solution.hpp:63-103) + run statistics */

@@ -138,6 +138,8 @@ void orc_default_settings(double* s)
   s[ORC_S_STRICT_INFEASIBILITY]    = 0;
   s[ORC_S_PRIMAL_INFEASIBLE_TOL]   = 1e-8; /* solver_settings.cu:83-84 */
   s[ORC_S_DUAL_INFEASIBLE_TOL]     = 1e-8;
+  s[ORC_S_PRIMAL_TOLERANCE_FACTOR] = -1.0;
+  s[ORC_S_DUAL_TOLERANCE_FACTOR]   = -1.0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -775,8 +777,9 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
   double* bcomb_u = dalloc((size_t)m); /* combined_bounds, utils.cuh:150-163 */
   for (int i = 0; i < m; ++i) bcomb_u[i] = combine_bounds(lo[i], hi[i]);
   /* convergence_information_t ctor :76-84 : constants of the termination test */
-  const double norm_c = l2norm(n, cu);
-  const double norm_b = l2norm(m, bcomb_u);
+  /* (overridable: set_relative_{dual,primal}_tolerance_factor, pdlp.cu:209-231 / convergence_information.cu:110-123) */
+  const double norm_c = S[ORC_S_DUAL_TOLERANCE_FACTOR] >= 0.0 ? S[ORC_S_DUAL_TOLERANCE_FACTOR] : l2norm(n, cu);
+  const double norm_b = S[ORC_S_PRIMAL_TOLERANCE_FACTOR] >= 0.0 ? S[ORC_S_PRIMAL_TOLERANCE_FACTOR] : l2norm(m, bcomb_u);
 
   /* --- scaled copy (op_problem_scaled_, pdlp.cu:60-61) and scaling vectors (ctor) --- */
   prob_t P;

@@ -80,6 +80,8 @@ enum {
   ORC_S_STRICT_INFEASIBILITY,
   ORC_S_PRIMAL_INFEASIBLE_TOL,
   ORC_S_DUAL_INFEASIBLE_TOL,
+  ORC_S_PRIMAL_TOLERANCE_FACTOR, /* < 0: ||b|| (default); else set_relative_primal_tolerance_factor, pdlp.cu:216-220 */
+  ORC_S_DUAL_TOLERANCE_FACTOR,   /* < 0: ||c|| (default); else set_relative_dual_tolerance_factor,   pdlp.cu:209-213 */
   ORC_S_COUNT
 };
 

@@ -657,3 +657,24 @@ def test_initial_solution_test_of_the_reference_on_the_device(golden_problems):
     h.update_step_size_on_initial_solution = h.update_primal_weight_on_initial_solution = 1
     r = capi.Solver(p, hyper=h, tol=1e-6, init_x=np.full(p["n"], 1.0), init_y=np.full(p["m"], 1.0)).advance()
     assert r["status_name"] == "Optimal" and r["primal_objective"] == pytest.approx(-464.7531, rel=1e-4)
+
+
+def test_relative_tolerance_factors(golden_problems):
+    """pdlp_test.cu:611-631 (initial_rhs_and_c): set_relative_{primal,dual}_tolerance_factor replace ||b|| and ||c|| in the
+    termination rule (eps_abs + eps_rel * factor); what was set is what the solver reports and uses"""
+    p = golden_problems["afiro"]["problem"]
+    base = capi.Solver(p, tol=1e-6).advance()
+    r = capi.Solver(p, tol=1e-6, relative_primal_tolerance_factor=1.0, relative_dual_tolerance_factor=2.0).advance()
+    assert (r["norm_b"], r["norm_c"]) == (1.0, 2.0) and (base["norm_b"], base["norm_c"]) != (1.0, 2.0)
+    assert r["status_name"] == "Optimal"
+    # ||b||, ||c|| of afiro are > 2: smaller factors = a tighter rule = at least as many iterations, and it is met
+    assert base["norm_b"] > 1.0 and base["norm_c"] > 2.0 and r["steps_taken"] >= base["steps_taken"]
+    assert r["l2_primal_residual"] <= 1e-6 + 1e-6 * 1.0 and r["l2_dual_residual"] <= 1e-6 + 1e-6 * 2.0
+    o = orcbind.solve(p, tol=1e-6, primal_tolerance_factor=1.0, dual_tolerance_factor=2.0)
+    assert o["status"] == "Optimal" and int(o["steps_taken"]) == r["steps_taken"]
+    # a reset without the factors goes back to the problem's own norms
+    s = capi.Solver(p, tol=1e-6, relative_primal_tolerance_factor=1.0, relative_dual_tolerance_factor=2.0)
+    s.advance()
+    s.reset(tol=1e-6)
+    again = s.advance()
+    assert (again["norm_b"], again["norm_c"], again["steps_taken"]) == (base["norm_b"], base["norm_c"], base["steps_taken"])
