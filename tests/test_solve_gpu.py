@@ -678,3 +678,23 @@ def test_relative_tolerance_factors(golden_problems):
     s.reset(tol=1e-6)
     again = s.advance()
     assert (again["norm_b"], again["norm_c"], again["steps_taken"]) == (base["norm_b"], base["norm_c"], base["steps_taken"])
+
+
+def test_first_primal_feasible_like_pdlp_test():
+    """pdlp_test.cu:774-802 (ns1687037 is not shipped: a badly scaled synthetic LP plays its part): with per-constraint
+    residuals at 1e-2 and a budget that is too small for optimality, the plain solve ends in IterationLimit while
+    first_primal_feasible = true returns PrimalFeasible -- and the returned point IS primal feasible by that rule"""
+    p = synthetic.generate(3000, 2500, 8, seed=77, hard=True)
+    kw = dict(method=1, tol=1e-2, per_constraint_residual=True)
+    feas = capi.solve(p, first_primal_feasible=True, iteration_limit=100000, **kw)
+    assert feas["status"] == "PrimalFeasible"
+    plain = capi.solve(p, iteration_limit=feas["steps_taken"], **kw)
+    assert plain["status"] == "IterationLimit"
+    o = orcbind.solve(p, tol=1e-2, per_constraint_residual=1, first_primal_feasible=1, iteration_limit=100000)
+    assert o["status"] == "PrimalFeasible" and int(o["steps_taken"]) == feas["steps_taken"]
+    import scipy.sparse as sp
+    A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+    ax = A @ feas["x"]
+    viol = np.maximum(np.maximum(p["lo"] - ax, ax - p["hi"]), 0.0)
+    bcomb = np.maximum(np.where(np.isfinite(p["lo"]), np.abs(p["lo"]), 0), np.where(np.isfinite(p["hi"]), np.abs(p["hi"]), 0))
+    assert np.all(viol <= 1e-2 + 1e-2 * bcomb + 1e-12)  # termination_strategy.cu:189-205
