@@ -1627,6 +1627,33 @@ struct PanelHost {
   cuopt_amd::PoolArray<uint16_t> rowptr;
   size_t nnz = 0, rowptr_size = 0;
 };
+// Bytes of the gathered vector that the CSR stream kernel keeps live in ONE XCD's L2: an XCD owns a contiguous range of
+// row blocks and has 32 CUs x 8 workgroups x 2048 nonzeros = 512 K nonzeros of consecutive rows in flight, so what it
+// re-reads from L2 is the set of 128-byte lines those rows touch.  Estimated on up to four evenly spaced windows of that
+// size (exact when the matrix is smaller), mean over the windows.  Structural and reproducible: this, not a timing, is
+// what 'auto' decides on.
+constexpr int64_t kPanelWorkingSetBytes = 4 * (int64_t)1048576;  // an XCD's L2; calibration: profiles/r02_layout_rule.txt
+static int64_t gather_working_set(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx)
+{
+  const int64_t nnz = off[rows], window = 512 * 1024;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) return 0;
+  const int samples = nnz <= window ? 1 : (int)std::min<int64_t>(4, (nnz + window - 1) / window);
+  std::vector<uint8_t> seen((size_t)(cols >> 4) + 1);
+  int64_t total = 0;
+  for (int s = 0; s < samples; ++s) {
+    const int64_t first = samples == 1 ? 0 : (nnz - window) * s / (samples - 1);
+    const int64_t last  = std::min(nnz, first + window);
+    std::fill(seen.begin(), seen.end(), 0);
+    int64_t lines = 0;
+    for (int64_t k = first; k < last; ++k) {
+      uint8_t& b = seen[(size_t)(idx[k] >> 4)];
+      lines += !b;
+      b = 1;
+    }
+    total += lines * 128;
+  }
+  return total / samples;
+}
 static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
                               int64_t slab_bytes, bool force)
 {
@@ -1972,9 +1999,10 @@ static int sync_panel_values(pdlpdev_ctx* c)
   return 0;
 }
 
-// auto layout: both layouts of a matrix are timed on the device (plain SpMV, 1 warm-up + 3 launches each) and the
-// slower one is dropped -- a structured LP whose gathers are local runs fastest through the CSR stream kernel
-// even when the gathered vector exceeds L2; a random one through the slab-major panels.
+// CUOPT_AMD_SPMV_LAYOUT=timed: both layouts of a matrix are timed on the device (plain SpMV, 1 warm-up + 3 launches each)
+// and the slower one is dropped.  This is how the structural rule of 'auto' (gather_working_set) was calibrated; it is
+// not the default because two close timings make the choice -- and with it the grouping of the reduction partials, the
+// step sizes and the iteration count -- differ from run to run.
 static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb, const int32_t* rb, const int32_t* off,
                        const int32_t* idx, const double* val, const double* vec, double* out, const char* name)
 {
@@ -2118,7 +2146,21 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     // SpMV; 8 slabs of 1 MiB: 74 us; 4 slabs of 2 MiB: 75 us) -- fewer tiles per panel against L2 capacity
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
     const bool force = mode == "panel";
-    const bool try_jag = mode == "auto" || mode == "jag" || mode == "timed";
+    const bool timed = mode == "timed";
+    const bool try_jag = mode == "auto" || mode == "jag" || timed;
+    // auto, not jagged: panels when the CSR stream kernel's live gather set overflows what an XCD's L2 keeps of it
+    const char* ws_env     = getenv("CUOPT_AMD_PANEL_WS_BYTES");
+    const int64_t ws_limit = ws_env ? atoll(ws_env) : kPanelWorkingSetBytes;
+    auto want_panels = [&](int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, const char* name) {
+      if (force) return true;
+      if (!timed && (mode != "auto" || (int64_t)cols * 8 <= ws_limit)) return false;
+      if (timed && !getenv("CUOPT_AMD_TIMING")) return true;
+      const int64_t ws = gather_working_set(rows, cols, off, idx);
+      if (getenv("CUOPT_AMD_TIMING"))
+        fprintf(stderr, "[cuopt_amd setup]   layout %-3s: live gather set of the stream kernel %.2f MiB (limit %.2f) -> %s\n", name,
+                ws / 1048576.0, ws_limit / 1048576.0, ws > ws_limit ? "panels" : "stream");
+      return timed || ws > ws_limit;
+    };
     lap("row blocks + vectors");
     if (try_jag) {
       JagHost ja = build_jag(m, n, a_offsets, a_indices, mode == "jag" ? 1 : 0);
@@ -2126,8 +2168,8 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       TRY(upload_jag(ctx, &ctx->ja, ja, ctx->a_off, ctx->a_idx, ctx->a_val));
       lap("upload jag A");
     }
-    if (mode != "stream" && mode != "jag" && !ctx->ja.on) {
-      PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force);
+    if (mode != "stream" && mode != "jag" && !ctx->ja.on && want_panels(m, n, a_offsets, a_indices, "A")) {
+      PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force || !timed);
       lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha));
       lap("upload panels A");
@@ -2149,8 +2191,8 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       TRY(upload_jag(ctx, &ctx->jat, jat, ctx->at_off, ctx->at_idx, ctx->at_val));
       lap("upload jag At");
     }
-    if (mode != "stream" && mode != "jag" && !ctx->jat.on) {
-      PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force);
+    if (mode != "stream" && mode != "jag" && !ctx->jat.on && want_panels(n, m, at_offsets, at_indices, "A^T")) {
+      PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force || !timed);
       lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
       lap("upload panels At");
@@ -2180,7 +2222,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   lap("panel values (permute)");
   {
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
-    if (!mode_env || std::string(mode_env) == "auto") {
+    if (mode_env && std::string(mode_env) == "timed") {
       TRY(pick_layout(ctx, &ctx->pa, m, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->tmp_n, ctx->tmp_m, "A"));
       lap("layout autotune A");
       TRY(pick_layout(ctx, &ctx->pat, n, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->tmp_m, ctx->tmp_n, "A^T"));

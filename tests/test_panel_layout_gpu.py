@@ -122,6 +122,30 @@ def test_structured_matrix_gets_the_jagged_layout_by_itself(monkeypatch):
     assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
 
 
+def test_auto_layout_is_a_structural_rule(monkeypatch):
+    """auto never times anything: jagged rows when the LDS windows hold half of the gathers, else panels iff the CSR stream
+    kernel's live gather set (128-byte lines touched by 512 K consecutive nonzeros) exceeds an XCD's L2 -- the same matrix gets
+    the same layout on every run (round-1 advisor: timed choice made iteration counts irreproducible).  The limit is lowered
+    here so that a 70000-column matrix exercises both sides of it."""
+    monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
+    rnd = synthetic.generate(70000, 70000, 8, seed=5)                 # touches every line of the 547 KiB vector
+    wide = synthetic.generate(70000, 70000, 8, seed=5, band=9000)     # 512 K nonzeros = 65536 rows: band + rows wide
+    narrow = synthetic.generate(70000, 8000, 8, seed=5)               # 62.5 KiB vector: under any limit
+    monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(256 * 1024))
+    for _ in range(3):
+        assert capi.Device(rnd).layout()["A"]["layout"] == "panel"
+        assert capi.Device(rnd).layout()["At"]["layout"] == "panel"
+    assert capi.Device(narrow).layout()["A"]["layout"] == "stream"
+    assert capi.Device(wide).layout()["A"]["layout"] in ("panel", "stream")
+    monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(1 << 30))
+    assert capi.Device(rnd).layout()["A"]["layout"] == capi.Device(rnd).layout()["At"]["layout"] == "stream"
+    monkeypatch.delenv("CUOPT_AMD_PANEL_WS_BYTES")
+    assert capi.Device(rnd).layout()["A"]["layout"] == "stream"        # default limit: 4 MiB
+    a = capi.Solver(rnd, tol=1e-6).advance()
+    b = capi.Solver(rnd, tol=1e-6).advance()
+    assert (a["steps_taken"], a["attempted_steps"], a["primal_objective"]) == (b["steps_taken"], b["attempted_steps"], b["primal_objective"])
+
+
 def test_jagged_layout_partial_windows(monkeypatch):
     """columns half inside, half far outside the LDS window: the per-lane fallback to a global gather"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
