@@ -145,6 +145,38 @@ class WarmStart(C.Structure):
                "iterations_since_last_restart", "n_variables", "n_constraints")
 
 
+def remap_warm_start(d, var_mapping=None, constraint_mapping=None):
+    """set_pdlp_warm_start_data(data, var_mapping, constraint_mapping) (LP/solver_settings.cu:92-240): the snapshot `d` (a dict
+    as Solver.get_warm_start returns it) carried over to a problem with len(var_mapping) variables / len(constraint_mapping)
+    constraints; None or empty = that side is unchanged.  Host-side, no GPU involved."""
+    vm = np.ascontiguousarray([] if var_mapping is None else var_mapping, dtype=np.int32)
+    cm = np.ascontiguousarray([] if constraint_mapping is None else constraint_mapping, dtype=np.int32)
+    n_new = len(vm) or int(d["n_variables"])
+    m_new = len(cm) or int(d["n_constraints"])
+    src, dst, keep, out = WarmStart(), WarmStart(), [], {}
+    for names, size in ((WarmStart.PRIMAL, n_new), (WarmStart.DUAL, m_new)):
+        for k in names:
+            if d.get(k) is None:
+                out[k] = None
+                continue
+            a = _f64(d[k])
+            keep.append(a)
+            setattr(src, k, a.ctypes.data)
+            out[k] = np.zeros(size)
+            setattr(dst, k, out[k].ctypes.data)
+    for k in WarmStart.SCALARS:
+        setattr(src, k, d[k])
+    rc = lib.cuoptamd_warm_start_remap(C.byref(src), vm.ctypes.data_as(P(c_int)), len(vm), cm.ctypes.data_as(P(c_int)), len(cm),
+                                       C.byref(dst))
+    if rc != 0:
+        raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+    for k in ("current_primal_solution_scaled", "current_dual_solution_scaled"):
+        if not getattr(dst, k):
+            out[k] = None
+    out.update({k: getattr(dst, k) for k in WarmStart.SCALARS})
+    return out
+
+
 def _struct_dict(s):
     return {k: getattr(s, k) for k, _ in s._fields_}
 
@@ -208,6 +240,7 @@ _proto("cuoptamd_solver_device", c_void_p, c_void_p)
 _proto("cuoptamd_batch_solve", c_int, c_int, c_void_p, P(Hyper), P(SolverSettings), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_solver_get_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_solver_set_warm_start", c_int, c_void_p, P(WarmStart))
+_proto("cuoptamd_warm_start_remap", c_int, P(WarmStart), P(c_int), c_int, P(c_int), c_int, P(WarmStart))
 _proto("cuoptamd_solver_row_range", c_int, c_void_p, P(c_int), P(c_int))
 _proto("cuoptamd_partition_rows", None, c_int, c_void_p, c_int, c_void_p)
 _proto("cuoptamd_csr_transpose", None, c_int, c_int, *([c_void_p] * 6))

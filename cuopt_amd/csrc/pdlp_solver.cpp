@@ -1132,6 +1132,81 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   return 0;
 }
 
+// pdlp_solver_settings_t::set_pdlp_warm_start_data with var_mapping / constraint_mapping (LP/solver_settings.cu:92-240),
+// as its two tests pin it (unit_tests/solver_settings_test.cu:84-181 smaller, :183-280 bigger).  The reference scatters IN
+// PLACE over the old vector's whole range with a map of the new, shorter length (it reads past the map); what the tests
+// pin -- and what is restated here, out of place -- is  new[map[i]] = old[i]  for i < new size, then truncation; a longer
+// map only says "pad with zeros"; an empty map or one of the same length leaves that side untouched.
+int cuoptamd_warm_start_remap(const cuoptamd_warm_start* in, const int32_t* var_mapping, int32_t n_mapping,
+                              const int32_t* constraint_mapping, int32_t m_mapping, cuoptamd_warm_start* out)
+{
+  if (!in || !out) return fail(-1, "cuoptamd_warm_start_remap: null argument");
+  if (n_mapping < 0 || m_mapping < 0 || (n_mapping > 0 && !var_mapping) || (m_mapping > 0 && !constraint_mapping))
+    return fail(-1, "cuoptamd_warm_start_remap: a mapping is missing");
+  const int32_t n_old = in->n_variables, m_old = in->n_constraints;
+  if (n_old <= 0 || m_old <= 0) return fail(-1, "cuoptamd_warm_start_remap: the snapshot does not carry its sizes");
+  const int32_t n_new = n_mapping ? n_mapping : n_old, m_new = m_mapping ? m_mapping : m_old;
+  auto check = [](const int32_t* map, int32_t len, int32_t old_len) {
+    if (len >= old_len) return true;
+    std::vector<char> seen((size_t)len, 0);
+    for (int32_t i = 0; i < len; ++i) {
+      if (map[i] < 0 || map[i] >= len || seen[(size_t)map[i]]) return false;
+      seen[(size_t)map[i]] = 1;
+    }
+    return true;
+  };
+  if (!check(var_mapping, n_mapping, n_old) || !check(constraint_mapping, m_mapping, m_old))
+    return fail(-1, "cuoptamd_warm_start_remap: a shrinking mapping must be a permutation of 0..new size-1");
+  auto move = [](const double* src, double* dst, const int32_t* map, int32_t len_map, int32_t len_old, int32_t len_new) -> bool {
+    if (!src) return dst == nullptr;
+    if (!dst) return false;
+    if (len_map != 0 && len_new < len_old) {
+      for (int32_t i = 0; i < len_new; ++i) dst[map[i]] = src[i];
+    } else {
+      const int32_t keep = std::min(len_old, len_new);
+      std::copy(src, src + keep, dst);
+      std::fill(dst + keep, dst + len_new, 0.0);
+    }
+    return true;
+  };
+  bool ok = true;
+  ok &= move(in->current_primal_solution, out->current_primal_solution, var_mapping, n_mapping, n_old, n_new);
+  ok &= move(in->initial_primal_average, out->initial_primal_average, var_mapping, n_mapping, n_old, n_new);
+  ok &= move(in->current_ATY, out->current_ATY, var_mapping, n_mapping, n_old, n_new);
+  ok &= move(in->sum_primal_solutions, out->sum_primal_solutions, var_mapping, n_mapping, n_old, n_new);
+  ok &= move(in->last_restart_duality_gap_primal_solution, out->last_restart_duality_gap_primal_solution, var_mapping, n_mapping, n_old, n_new);
+  ok &= move(in->current_dual_solution, out->current_dual_solution, constraint_mapping, m_mapping, m_old, m_new);
+  ok &= move(in->initial_dual_average, out->initial_dual_average, constraint_mapping, m_mapping, m_old, m_new);
+  ok &= move(in->sum_dual_solutions, out->sum_dual_solutions, constraint_mapping, m_mapping, m_old, m_new);
+  ok &= move(in->last_restart_duality_gap_dual_solution, out->last_restart_duality_gap_dual_solution, constraint_mapping, m_mapping, m_old, m_new);
+  if (!ok) return fail(-1, "cuoptamd_warm_start_remap: the output snapshot must provide every vector the input has");
+  // the scaled iterate belongs to the old problem's scaling: it does not survive a change of the problem
+  if (n_new != n_old || m_new != m_old) {
+    out->current_primal_solution_scaled = nullptr;
+    out->current_dual_solution_scaled   = nullptr;
+  } else {
+    if (in->current_primal_solution_scaled && out->current_primal_solution_scaled)
+      std::copy(in->current_primal_solution_scaled, in->current_primal_solution_scaled + n_old, out->current_primal_solution_scaled);
+    else
+      out->current_primal_solution_scaled = nullptr;
+    if (in->current_dual_solution_scaled && out->current_dual_solution_scaled)
+      std::copy(in->current_dual_solution_scaled, in->current_dual_solution_scaled + m_old, out->current_dual_solution_scaled);
+    else
+      out->current_dual_solution_scaled = nullptr;
+  }
+  out->initial_primal_weight         = in->initial_primal_weight;
+  out->initial_step_size             = in->initial_step_size;
+  out->total_pdlp_iterations         = in->total_pdlp_iterations;
+  out->total_pdhg_iterations         = in->total_pdhg_iterations;
+  out->last_candidate_kkt_score      = in->last_candidate_kkt_score;
+  out->last_restart_kkt_score        = in->last_restart_kkt_score;
+  out->sum_solution_weight           = in->sum_solution_weight;
+  out->iterations_since_last_restart = in->iterations_since_last_restart;
+  out->n_variables                   = n_new;
+  out->n_constraints                 = m_new;
+  return 0;
+}
+
 int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper,
                          const cuoptamd_settings* settings, int device, int max_threads,
                          cuoptamd_result* results, double** x, double** y, double** rc)

@@ -227,6 +227,14 @@ int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws);
  * the reference's warm-start test, pdlp_test.cu:803-854). */
 int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start* ws);
 
+/* set_pdlp_warm_start_data(data, var_mapping, constraint_mapping) of the reference (LP/solver_settings.cu:92-240): a
+ * snapshot of an n_old x m_old problem for a problem with n_mapping variables / m_mapping constraints (0 = that side is
+ * unchanged).  Shorter: new[map[i]] = old[i] for i < new size (the map must be a permutation of 0..new size-1), the
+ * rest is dropped; longer: the old entries, then zeros (the map's values are not read, as in the reference).  `out`'s
+ * vectors are caller-allocated at the new sizes; the scaled iterate is dropped when a size changes.  Host only. */
+int cuoptamd_warm_start_remap(const cuoptamd_warm_start* in, const int32_t* var_mapping, int32_t n_mapping,
+                              const int32_t* constraint_mapping, int32_t m_mapping, cuoptamd_warm_start* out);
+
 /* x (n), y (m_global), reduced cost (n) of the returned iterate, unscaled, in the internal min-form
  * sign convention of the reference (any pointer may be NULL). Valid after a terminating advance. */
 int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, double* rc);

@@ -238,3 +238,53 @@ def test_solution_file_reader(tmp_path):
     assert fn(prob.handle, str(short).encode(), capi._ptr(vals), None, None, 0) == capi.CUOPT_VALIDATION_ERROR
     assert fn(prob.handle, str(tmp_path / "none.sol").encode(), capi._ptr(vals), None, None, 0) == capi.CUOPT_MPS_FILE_ERROR
     prob.close()
+
+
+def _snapshot(primal, dual):
+    d = {k: np.array(primal, dtype=np.float64) for k in capi.WarmStart.PRIMAL}
+    d.update({k: np.array(dual, dtype=np.float64) for k in capi.WarmStart.DUAL})
+    d.update({k: -1 for k in capi.WarmStart.SCALARS})
+    d.update(n_variables=len(primal), n_constraints=len(dual))
+    return d
+
+
+PRIMAL_SIDE = [k for k in capi.WarmStart.PRIMAL if not k.endswith("_scaled")]
+DUAL_SIDE = [k for k in capi.WarmStart.DUAL if not k.endswith("_scaled")]
+
+
+def test_warm_start_smaller_vector():
+    """unit_tests/solver_settings_test.cu:84-181: two of four variables kept (0 - 1 swapped), three of four constraints
+    (1 - 2 swapped); every primal-side / dual-side vector of the snapshot follows, the scalars travel unchanged"""
+    out = capi.remap_warm_start(_snapshot([0.0, 1.0, 2.0, 3.0], [0.0, 1.0, 2.0, 3.0]), [1, 0], [0, 2, 1])
+    for k in PRIMAL_SIDE:
+        assert out[k].tolist() == [1.0, 0.0], k
+    for k in DUAL_SIDE:
+        assert out[k].tolist() == [0.0, 2.0, 1.0], k
+    assert (out["n_variables"], out["n_constraints"]) == (2, 3)
+    assert out["initial_step_size"] == -1 and out["total_pdlp_iterations"] == -1
+    assert out["current_primal_solution_scaled"] is None and out["current_dual_solution_scaled"] is None
+
+
+def test_warm_start_bigger_vector():
+    """unit_tests/solver_settings_test.cu:183-280: six variables for four, seven constraints for three -> zero padding"""
+    out = capi.remap_warm_start(_snapshot([0.0, 1.0, 2.0, 3.0], [0.0, 1.0, 2.0]), list(range(6)), list(range(7)))
+    for k in PRIMAL_SIDE:
+        assert out[k].tolist() == [0.0, 1.0, 2.0, 3.0, 0.0, 0.0], k
+    for k in DUAL_SIDE:
+        assert out[k].tolist() == [0.0, 1.0, 2.0, 0.0, 0.0, 0.0, 0.0], k
+    assert (out["n_variables"], out["n_constraints"]) == (6, 7)
+
+
+def test_warm_start_mapping_edge_cases():
+    """no mapping = untouched side (solver_settings.cu:98 `size() != 0`); where the reference would scatter out of range, an error"""
+    snap = _snapshot([0.0, 1.0, 2.0, 3.0], [5.0, 6.0, 7.0])
+    out = capi.remap_warm_start(snap, None, [1, 0])
+    assert out["current_primal_solution"].tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert out["current_primal_solution_scaled"] is None  # a size changed: the old scaling's iterate is dropped
+    assert out["current_dual_solution"].tolist() == [6.0, 5.0]
+    same = capi.remap_warm_start(snap, [3, 2, 1, 0], None)  # same length: neither branch of the reference runs
+    assert same["current_primal_solution"].tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert same["current_primal_solution_scaled"].tolist() == [0.0, 1.0, 2.0, 3.0]
+    for bad in ([0, 2], [1, 1], [-1, 0]):
+        with pytest.raises(capi.CuOptError):
+            capi.remap_warm_start(snap, bad, None)
