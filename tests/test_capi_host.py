@@ -288,3 +288,22 @@ def test_warm_start_mapping_edge_cases():
     for bad in ([0, 2], [1, 1], [-1, 0]):
         with pytest.raises(capi.CuOptError):
             capi.remap_warm_start(snap, bad, None)
+
+
+def test_problem_checking_through_the_c_api():
+    """unit_tests/optimization_problem_test.cu:341-414 (test_csr_validity cases 1-4, test_row_type_invalidity_char) through the
+    boundary: cuOptSolve answers CUOPT_VALIDATION_ERROR with the reference's message (utilities/problem_checking.cu) and still
+    hands out a solution handle holding it (cuopt_c.cpp:613-618) -- before any device is touched, so this runs without a GPU"""
+    base = dict(m=2, n=1, offsets=[0, 1, 2], indices=[0, 0], values=[1.0, 1.0], c=[1.0], lb=[0.0], ub=[np.inf],
+                row_types=np.frombuffer(b"EE", np.uint8), rhs=[1.0, 1.0])
+    cases = [(dict(offsets=[1, 1, 2]), "A_offsets first value should be 0"),
+             (dict(offsets=[0, 2, 1], indices=[0]), "increasing order"),
+             (dict(indices=[0, -1]), "A_indices"),
+             (dict(indices=[0, 1]), "A_indices"),
+             (dict(row_types=np.frombuffer(b"EN", np.uint8)), "row_types values must equal to 'E', 'G' or 'L'")]
+    for change, message in cases:
+        prob = capi.Problem.from_dict(dict(base, **change), ranged=False)
+        r = capi.solve(prob, method=1)
+        prob.close()
+        assert r["return_code"] == capi.CUOPT_VALIDATION_ERROR, change
+        assert r["error_status"] == capi.CUOPT_VALIDATION_ERROR and message in r["error_string"], r["error_string"]
