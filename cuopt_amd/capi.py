@@ -796,7 +796,7 @@ class Device:
         def side(k):
             d = dict(layout=names[int(out[k])], panels=bool(out[k] == 1), workgroups=int(out[k + 1]))
             if out[k] == 3:
-                d["lds_window_coverage_pct"] = int(out[k + 2])
+                d["lds_gather_saving_pct"] = int(out[k + 2])  # 100 * (1 - cost of filling the LDS column sets / gathers served)
             else:
                 d["slabs"] = int(out[k + 2])
             return d

@@ -197,7 +197,7 @@ struct pdlpdev_ctx {
     int32_t* perm = nullptr;  // position in CSR order of each jagged-order entry
     double* val   = nullptr;
     int64_t nent  = 0;
-    double coverage = 0.0;    // share of the nonzeros whose gather is served from the LDS window
+    double saving = 0.0;      // share of the global gathers the LDS column sets save (build_jag)
   } ja, jat;
   // problem vectors: scaled working copies and the unscaled originals
   double *c = nullptr, *lb = nullptr, *ub = nullptr, *lo = nullptr, *hi = nullptr;
@@ -1748,87 +1748,146 @@ static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t co
 // ---- sorted jagged rows: host-side construction (structure only; values are permuted on the device) -------------
 struct JagHost {
   bool ok = false;
-  int rows = 0, G = 0, waves = 8, ngroups = 0, nblk = 0;
-  std::vector<int32_t> tile_e, tile_sr, win, lr_ptr, lr_row;
+  int rows = 0, waves = 8, ngroups = 0, nblk = 0;
+  std::vector<int32_t> row0, tile_e, tile_sr, win, set_ptr, set_col, lr_ptr, lr_row;
   cuopt_amd::PoolArray<uint32_t> sr;
-  cuopt_amd::PoolArray<int32_t> col, perm;
+  cuopt_amd::PoolArray<uint16_t> slot;
+  cuopt_amd::PoolArray<int32_t> perm;
   size_t nsr = 0, nent = 0;
-  double coverage = 0.0;
+  double saving = 0.0;  // share of the global gathers the LDS column sets save: 1 - (cost of filling the sets) / nonzeros
 };
-// `mode`: 0 = use the layout when at least half of the gathers are served from the LDS windows, 1 = always build it
+// open-addressing set of column indices with O(1) clear (a stamp per slot)
+struct ColumnSet {
+  std::vector<int32_t> key;
+  std::vector<uint32_t> stamp;
+  uint32_t now = 0, mask;
+  explicit ColumnSet(int capacity_log2) : key((size_t)1 << capacity_log2), stamp((size_t)1 << capacity_log2, 0), mask((1u << capacity_log2) - 1) {}
+  void clear() { ++now; }
+  bool contains(int32_t c) const
+  {
+    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+    while (stamp[h] == now) {
+      if (key[h] == c) return true;
+      h = (h + 1) & mask;
+    }
+    return false;
+  }
+  bool insert(int32_t c)  // true when c was not there
+  {
+    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+    while (stamp[h] == now) {
+      if (key[h] == c) return false;
+      h = (h + 1) & mask;
+    }
+    stamp[h] = now, key[h] = c;
+    return true;
+  }
+};
+// `mode`: 0 = use the layout when filling the LDS column sets costs at most half of the gathers they serve, 1 = always
 static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode)
 {
   JagHost H;
   const int64_t nnz = rows > 0 ? off[rows] : 0;
   if (rows <= 0 || cols <= 0 || nnz <= 0) return H;
-  // one wave per group of G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
+  // one wave per group of up to G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
   int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 65536 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
-  // LDS window of every workgroup: the whole column span of its rows when that fits, else the range of `wcap` columns
-  // holding the most nonzeros.  Evaluated for both geometries (8 waves / 8192 columns, 16 waves / 16384 columns).
-  // `stride` > 1 looks at every stride-th workgroup only (a cheap estimate: random matrices are turned away after a few
-  // milliseconds instead of sorting all their column indices)
-  auto windows = [&](int waves, std::vector<int32_t>& win, int stride) -> double {
-    const int wcap = jag_window(waves);
-    const int nb   = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
-    win.assign((size_t)2 * nb, 0);
-    std::vector<int64_t> covered(nb, 0), seen(nb, 0);
-    cuopt_amd::parallel_tasks((nb + stride - 1) / stride, [&](int task) {
-      const int b = task * stride;
-      const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * waves * G, rows);
-      const int32_t r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * waves * G, rows);
-      const int64_t k0 = off[r0], k1 = off[r1];
-      if (k1 <= k0) return;
-      seen[b] = k1 - k0;
-      int32_t lo = idx[k0], hi = idx[k0];
-      for (int64_t k = k0; k < k1; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
-      if ((int64_t)hi - lo + 1 <= wcap) {
-        win[2 * b] = lo, win[2 * b + 1] = hi - lo + 1;
-        covered[b] = k1 - k0;
-        return;
-      }
-      std::vector<int32_t> cs(idx + k0, idx + k1);
-      std::sort(cs.begin(), cs.end());
-      size_t best_i = 0, best = 0, j = 0;
-      for (size_t i = 0; i < cs.size(); ++i) {
-        while (j < cs.size() && (int64_t)cs[j] - cs[i] < wcap) ++j;
-        if (j - i > best) best = j - i, best_i = i;
-      }
-      const int32_t base = cs[best_i];
-      win[2 * b] = base, win[2 * b + 1] = (int32_t)std::min<int64_t>(wcap, (int64_t)cols - base);
-      covered[b] = (int64_t)best;
-    }, nnz / stride);
-    int64_t cov = 0, tot = 0;
-    for (int b = 0; b < nb; ++b) cov += covered[b], tot += seen[b];
-    return tot ? (double)cov / (double)tot : 0.0;
-  };
-  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) serves more gathers from LDS on block
-  // structure wider than 8192 columns (block-angular workload: 72 % -> 87 %) and is 1-4 % faster on banded matrices, but
-  // it LOST on the block-angular A^T (78 -> 102 us) for a reason the counters did not show, so it is not chosen
-  // automatically.
+  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) is 1-4 % faster on banded matrices but
+  // LOST on the block-angular A^T (78 -> 102 us) for a reason the counters did not show, so it is not chosen automatically.
   int waves = 8;
   if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
     if (atoi(env) == 16) waves = 16;
-  if (mode == 0) {  // estimate first
-    const int nb = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
-    H.coverage   = windows(waves, H.win, std::max(1, nb / 48));
-    if (H.coverage < 0.35) return H;
+  const int wcap = jag_window(waves), brows = waves * G;
+  // A workgroup's rows: consecutive, at most `brows`, and as many as keep their DISTINCT columns within the LDS window
+  // (rows longer than kLongRow do not count: they gather from global memory in workgroups of their own).  Greedy from
+  // `first`; returns the end of the block.
+  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit) -> int32_t {
+    set.clear();
+    int32_t distinct = 0, r = first;
+    const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + brows, limit);
+    for (; r < last; ++r) {
+      const int32_t len = off[r + 1] - off[r];
+      if (len > kLongRow) continue;
+      if (distinct + len > wcap) {  // may overflow: count the new columns before inserting any
+        int32_t fresh = 0;
+        for (int32_t k = off[r]; k < off[r + 1]; ++k) fresh += !set.contains(idx[k]);
+        if (distinct + fresh > wcap) break;
+      }
+      for (int32_t k = off[r]; k < off[r + 1]; ++k) distinct += set.insert(idx[k]);
+    }
+    return std::max(r, first + 1);  // a row of <= kLongRow nonzeros always fits an empty set
+  };
+  // cost of a block in gather equivalents: what filling its LDS set costs (a contiguous range is a coalesced copy, a list
+  // costs one request per run of consecutive columns) against the gathers it serves.  Also decides range vs list.
+  struct BlockSet {
+    int32_t wbase = 0, wlen = 0;  // contiguous range, or ...
+    std::vector<int32_t> cols;    // ... sorted distinct columns
+    int64_t refs = 0, cost = 0;
+  };
+  auto block_set = [&](int32_t r0, int32_t r1, std::vector<int32_t>& scratch) -> BlockSet {
+    BlockSet B;
+    int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+    for (int32_t r = r0; r < r1; ++r) {
+      if (off[r + 1] - off[r] > kLongRow) continue;
+      for (int32_t k = off[r]; k < off[r + 1]; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
+      B.refs += off[r + 1] - off[r];
+    }
+    if (hi < 0) return B;
+    if ((int64_t)hi - lo + 1 <= wcap) {
+      B.wbase = lo, B.wlen = hi - lo + 1;
+      B.cost  = 1 + B.wlen / 16;
+      return B;
+    }
+    scratch.clear();
+    for (int32_t r = r0; r < r1; ++r)
+      if (off[r + 1] - off[r] <= kLongRow) scratch.insert(scratch.end(), idx + off[r], idx + off[r + 1]);
+    std::sort(scratch.begin(), scratch.end());
+    scratch.erase(std::unique(scratch.begin(), scratch.end()), scratch.end());
+    B.cols = scratch;
+    int64_t runs = 0;
+    for (size_t i = 0; i < B.cols.size(); ++i) runs += i == 0 || B.cols[i] != B.cols[i - 1] + 1;
+    B.cost = runs + (int64_t)B.cols.size() / 16;
+    return B;
+  };
+  if (mode == 0) {  // estimate on ~48 blocks first: a random matrix is turned away after a few milliseconds
+    const int samples = (int)std::min<int64_t>(48, std::max<int64_t>(1, rows / brows));
+    std::vector<int64_t> refs(samples, 0), cost(samples, 0);
+    cuopt_amd::parallel_tasks(samples, [&](int t) {
+      ColumnSet set(waves == 16 ? 16 : 15);
+      std::vector<int32_t> scratch;
+      const int32_t first = (int32_t)((int64_t)rows * t / samples);
+      const BlockSet B    = block_set(first, block_end(set, first, rows), scratch);
+      refs[t] = B.refs, cost[t] = B.cost;
+    }, nnz);
+    int64_t r = 0, c = 0;
+    for (int t = 0; t < samples; ++t) r += refs[t], c += cost[t];
+    H.saving = r ? 1.0 - (double)c / (double)r : 0.0;
+    if (H.saving < 0.35) return H;
   }
-  H.coverage = windows(waves, H.win, 1);
-  if (mode == 0 && H.coverage < 0.5) return H;
-  const int nblk    = (int)(((int64_t)rows + (int64_t)waves * G - 1) / ((int64_t)waves * G));
+  // the partition: chunks of rows are cut independently (a chunk boundary is a block boundary), in parallel
+  const int32_t chunk_rows = 8 * brows;
+  const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
+  std::vector<std::vector<int32_t>> cuts(nchunks);
+  cuopt_amd::parallel_tasks(nchunks, [&](int t) {
+    ColumnSet set(waves == 16 ? 16 : 15);
+    const int32_t c0 = (int32_t)((int64_t)t * chunk_rows), c1 = (int32_t)std::min<int64_t>((int64_t)c0 + chunk_rows, rows);
+    for (int32_t r = c0; r < c1;) cuts[t].push_back(r = block_end(set, r, c1));
+  }, nnz);
+  H.row0.push_back(0);
+  for (auto& v : cuts) H.row0.insert(H.row0.end(), v.begin(), v.end());
+  const int nblk    = (int)H.row0.size() - 1;
   const int ngroups = nblk * waves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
-  H.rows = rows, H.G = G, H.waves = waves, H.ngroups = ngroups, H.nblk = nblk;
+  H.rows = rows, H.waves = waves, H.ngroups = ngroups, H.nblk = nblk;
   // Per workgroup: rows with 1..kLongRow nonzeros sorted by length (descending, stable), cut into passes of 64, the
   // passes dealt to the waves in snake order (0..7, 7..0, ...): every wave gets the same share of long and short
-  // passes, and a pass holds rows of nearly equal length.  pass 1 sizes everything, pass 2 fills.
-  const int brows = waves * G;
+  // passes, and a pass holds rows of nearly equal length.  pass 1 sizes everything (and builds the column sets), pass 2 fills.
   H.tile_e.assign((size_t)ngroups + 1, 0), H.tile_sr.assign((size_t)ngroups + 1, 0), H.lr_ptr.assign((size_t)nblk + 1, 0);
+  H.set_ptr.assign((size_t)nblk + 1, 0), H.win.assign((size_t)2 * nblk, 0);
   auto wave_of_pass = [waves](int p) { return ((p / waves) & 1) ? waves - 1 - (p % waves) : p % waves; };
   // sorted order of a workgroup's short rows (local row numbers), number of them returned
   auto sort_block = [&](int b, std::vector<int32_t>& order) -> int32_t {
-    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
+    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
     int32_t bucket[kLongRow + 2] = {0};
     for (int32_t r = r0; r < r1; ++r) {
       const int32_t len = off[r + 1] - off[r];
@@ -1847,10 +1906,11 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   std::vector<int32_t> gsr((size_t)nblk * waves, 0);
   std::vector<int64_t> gent((size_t)nblk * waves, 0);
   std::vector<int32_t> nlong(nblk, 0);
+  std::vector<BlockSet> sets(nblk);
   cuopt_amd::parallel_tasks(nblk, [&](int b) {
-    std::vector<int32_t> order;
+    std::vector<int32_t> order, scratch;
     const int32_t ns = sort_block(b, order);
-    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
+    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
     for (int32_t r = r0; r < r1; ++r) nlong[b] += off[r + 1] - off[r] > kLongRow;
     for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
       const int w = wave_of_pass(p);
@@ -1859,19 +1919,35 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
         gent[(size_t)b * waves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
       }
     }
+    sets[b] = block_set(r0, r1, scratch);
   }, nnz);
+  int64_t refs = 0, cost = 0;
+  for (int b = 0; b < nblk; ++b) {
+    refs += sets[b].refs, cost += sets[b].cost;
+    H.win[2 * b] = sets[b].wbase, H.win[2 * b + 1] = sets[b].wlen;
+    H.set_ptr[b + 1] = H.set_ptr[b] + (int32_t)sets[b].cols.size();
+    H.lr_ptr[b + 1]  = H.lr_ptr[b] + nlong[b];
+  }
+  H.saving = refs ? 1.0 - (double)cost / (double)refs : 0.0;
+  if (mode == 0 && H.saving < 0.5) return H;
   for (int g = 0; g < ngroups; ++g) {
     H.tile_sr[g + 1] = H.tile_sr[g] + gsr[g];
     H.tile_e[g + 1]  = (int32_t)(H.tile_e[g] + gent[g]);
   }
-  for (int b = 0; b < nblk; ++b) H.lr_ptr[b + 1] = H.lr_ptr[b] + nlong[b];
   H.nsr = (size_t)H.tile_sr[ngroups], H.nent = (size_t)H.tile_e[ngroups];
-  H.sr.reset(H.nsr + 1), H.col.reset(H.nent + 1), H.perm.reset(H.nent + 1);
+  H.sr.reset(H.nsr + 1), H.slot.reset(H.nent + 1), H.perm.reset(H.nent + 1);
   H.lr_row.assign((size_t)H.lr_ptr[nblk], 0);
+  H.set_col.assign((size_t)H.set_ptr[nblk], 0);
   cuopt_amd::parallel_tasks(nblk, [&](int b) {
     std::vector<int32_t> order;
     const int32_t ns = sort_block(b, order);
-    const int32_t r0 = (int32_t)std::min<int64_t>((int64_t)b * brows, rows), r1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * brows, rows);
+    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
+    const BlockSet& B = sets[b];
+    std::copy(B.cols.begin(), B.cols.end(), H.set_col.begin() + H.set_ptr[b]);
+    auto slot_of = [&](int32_t c) -> uint16_t {
+      if (B.wlen) return (uint16_t)(c - B.wbase);
+      return (uint16_t)(std::lower_bound(B.cols.begin(), B.cols.end(), c) - B.cols.begin());
+    };
     int32_t nl = H.lr_ptr[b];
     for (int32_t r = r0; r < r1; ++r)
       if (off[r + 1] - off[r] > kLongRow) H.lr_row[nl++] = r;
@@ -1879,7 +1955,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     int64_t epos[16];
     for (int w = 0; w < waves; ++w) {
       const int g = b * waves + w;
-      srpos[w] = g < ngroups ? H.tile_sr[g] : 0, epos[w] = g < ngroups ? H.tile_e[g] : 0;
+      srpos[w] = H.tile_sr[g], epos[w] = H.tile_e[g];
     }
     for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
       const int w = wave_of_pass(p);
@@ -1894,7 +1970,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
         for (int32_t i = i0; i < i1; ++i) {
           const int32_t r = r0 + order[i];
           if (off[r + 1] - off[r] <= k) break;  // sorted: the rest of the pass is shorter still
-          H.col[e] = idx[off[r] + k], H.perm[e] = off[r] + k, ++e;
+          H.slot[e] = slot_of(idx[off[r] + k]), H.perm[e] = off[r] + k, ++e;
         }
       epos[w] = e;
     }
@@ -1905,22 +1981,29 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
 static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, const int32_t* d_off, const int32_t* d_idx,
                       const double* d_val)
 {
-  dst->coverage = h.coverage;
+  dst->saving = h.saving;
   if (!h.ok) return 0;
-  int32_t *tile_e = nullptr, *tile_sr = nullptr, *win = nullptr, *lr_ptr = nullptr, *lr_row = nullptr, *col = nullptr;
-  uint32_t* sr = nullptr;
+  int32_t *row0 = nullptr, *tile_e = nullptr, *tile_sr = nullptr, *win = nullptr, *set_ptr = nullptr, *set_col = nullptr,
+          *lr_ptr = nullptr, *lr_row = nullptr;
+  uint32_t* sr   = nullptr;
+  uint16_t* slot = nullptr;
+  TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
   TRY(upload_i32(c, &tile_e, h.tile_e.data(), h.tile_e.size()));
   TRY(upload_i32(c, &tile_sr, h.tile_sr.data(), h.tile_sr.size()));
   TRY(upload_i32(c, &win, h.win.data(), h.win.size()));
+  TRY(upload_i32(c, &set_ptr, h.set_ptr.data(), h.set_ptr.size()));
+  TRY(upload_i32(c, &set_col, h.set_col.data(), h.set_col.size(), 8));
   TRY(upload_i32(c, &lr_ptr, h.lr_ptr.data(), h.lr_ptr.size()));
   TRY(upload_i32(c, &lr_row, h.lr_row.data(), h.lr_row.size()));
-  TRY(upload_i32(c, &col, h.col.get(), h.nent, 8));
   TRY(upload_i32(c, &dst->perm, h.perm.get(), h.nent, 8));
   TRY(dev_alloc(c, &sr, h.nsr + 8));
   HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &slot, h.nent + 64));
+  HIP_TRY(hipMemcpyAsync(slot, h.slot.get(), h.nent * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   TRY(dev_alloc(c, &dst->val, h.nent + 8));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's JagHost
-  dst->v    = JagView{h.rows, h.G, h.waves, h.ngroups, h.nblk, (int)h.lr_row.size(), tile_e, tile_sr, sr, col, dst->val, win, lr_ptr, lr_row, d_off, d_idx, d_val};
+  dst->v    = JagView{h.rows, h.waves, h.ngroups, h.nblk, (int)h.lr_row.size(), row0, tile_e, tile_sr, sr, slot, dst->val,
+                      win, set_ptr, set_col, lr_ptr, lr_row, d_off, d_idx, d_val};
   dst->nent = (int64_t)h.nent;
   dst->on   = true;
   return 0;
@@ -3403,10 +3486,10 @@ int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
   // windows), workgroups, slabs (panels) or percent of the gathers served from LDS (jagged)
   out[0] = ctx->ja.on ? 3 : ctx->pa.on ? 1 : 0;
   out[1] = ctx->ja.on ? ctx->ja.v.nblk : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb;
-  out[2] = ctx->ja.on ? (int)(100.0 * ctx->ja.coverage + 0.5) : ctx->pa.on ? ctx->pa.v.S : 1;
+  out[2] = ctx->ja.on ? (int)(100.0 * ctx->ja.saving + 0.5) : ctx->pa.on ? ctx->pa.v.S : 1;
   out[3] = ctx->jat.on ? 3 : ctx->pat.on ? 1 : 0;
   out[4] = ctx->jat.on ? ctx->jat.v.nblk : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb;
-  out[5] = ctx->jat.on ? (int)(100.0 * ctx->jat.coverage + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
+  out[5] = ctx->jat.on ? (int)(100.0 * ctx->jat.saving + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
   if (ctx->small_resident) out[0] = out[3] = 2;
   return 0;
 }

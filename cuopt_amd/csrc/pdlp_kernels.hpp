@@ -482,17 +482,21 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 #undef PANEL_DISPATCH
 
 // ------------------------------------------------------------------------------------------------
-// Sorted jagged rows ("jag"): the SpMV for STRUCTURED matrices, whose rows touch a narrow column range.
+// Sorted jagged rows ("jag"): the SpMV for STRUCTURED matrices, whose rows re-use a limited set of columns.
 // Measured (tools/spmv_tune2.hip, profiles/r02_spmv_tune2.txt): an 8-byte gather through the vector
 // memory path costs ~1.85 clocks of the CU's texture-address unit per lane even when it hits L1
 // (1e7 gathers never finish under 30 us), and every L1 miss occupies one of a CU's limited miss slots
-// for an L2 round trip.  A workgroup of this layout therefore copies the column window its rows use
-// into LDS once (coalesced) and gathers from LDS; entries outside the window fall back to a global
-// load, per lane.
-//   * a workgroup owns waves * G (G <= kJagMaxGroup) consecutive rows; its rows with 1..kLongRow
-//     nonzeros are sorted by length (descending, stable), cut into passes of 64 and dealt to the 8
-//     waves in snake order (equal work, and every pass holds rows of nearly equal length: 97 % of the
-//     lanes of a jagged diagonal are live on Poisson row lengths, 80 % when each wave sorted only its own
+// for an L2 round trip.  A workgroup of this layout therefore copies EVERY column its rows use into LDS
+// once and gathers from LDS only:
+//   * a workgroup owns consecutive rows, at most waves * kJagMaxGroup of them and as many as keep the set of
+//     distinct columns they touch within the LDS window (jag_window entries); the set is either one contiguous
+//     column range (banded matrices: copied coalesced, no list) or a sorted list of columns (several bands,
+//     linking rows / columns, block structure: one 4-byte index per slot).  The matrix entries carry the
+//     16-bit LDS slot of their column, not the column: 10 bytes per nonzero instead of 12, and no entry ever
+//     falls back to a global gather;
+//   * its rows with 1..kLongRow nonzeros are sorted by length (descending, stable), cut into passes of 64 and
+//     dealt to the waves in snake order (equal work, and every pass holds rows of nearly equal length: 97 % of
+//     the lanes of a jagged diagonal are live on Poisson row lengths, 80 % when each wave sorted only its own
 //     256 rows).  A pass is stored as jagged diagonals: entry k of every row of the pass that has one,
 //     contiguous -- lane <-> row, coalesced, no padding, no LDS staging of products and no barrier in
 //     the loop;
@@ -512,13 +516,16 @@ constexpr size_t jag_lds_bytes(int waves) { return sizeof(double) * (size_t)(jag
 constexpr long long kJagNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
 
 struct JagView {
-  int rows, G, waves, ngroups, nblk, nlong;  // workgroups: nblk of `waves` groups, then one per long row
+  int rows, waves, ngroups, nblk, nlong;  // workgroups: nblk of `waves` groups, then one per long row
+  const int32_t* __restrict__ row0;     // nblk + 1: first row of each workgroup
   const int32_t* __restrict__ tile_e;   // ngroups + 1: first entry of each group
   const int32_t* __restrict__ tile_sr;  // ngroups + 1: first row descriptor of each group
   const uint32_t* __restrict__ sr;      // (length - 1) << 16 | row within the WORKGROUP's rows, sorted by length
-  const int32_t* __restrict__ col;      // jagged-diagonal order
+  const uint16_t* __restrict__ slot;    // jagged-diagonal order: LDS slot of the entry's column
   const double* __restrict__ val;
-  const int32_t* __restrict__ win;      // 2 * nblk: first column and length of the LDS window
+  const int32_t* __restrict__ win;      // 2 * nblk: (first column, length) of a contiguous column set; length 0: a list
+  const int32_t* __restrict__ set_ptr;  // nblk + 1: the workgroup's column list ...
+  const int32_t* __restrict__ set_col;  // ... sorted columns, slot s holds vec[set_col[set_ptr[blk] + s]]
   const int32_t* __restrict__ lr_ptr;   // nblk + 1: the workgroup's rows longer than kLongRow ...
   const int32_t* __restrict__ lr_row;   // ... as global row numbers, read from the CSR arrays below
   const int32_t* __restrict__ off;
@@ -575,17 +582,22 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
   }
   double* psum        = jag_lds + jag_window(WAVES);  // row sums of the workgroup's rows, natural order
   const int g         = blk * WAVES + wave;
-  const int brows     = WAVES * J.G;
-  const int row0      = blk * brows;
+  const int row0      = J.row0[blk];
+  const int brows     = J.row0[blk + 1] - row0;
   const int wbase     = J.win[2 * blk];
   const unsigned wlen = (unsigned)J.win[2 * blk + 1];
-  for (unsigned i = threadIdx.x; i < wlen; i += (WAVES * 64)) xwin[i] = vec[wbase + i];
+  if (wlen) {
+    for (unsigned i = threadIdx.x; i < wlen; i += (WAVES * 64)) xwin[i] = vec[wbase + i];
+  } else {
+    const int s0 = J.set_ptr[blk], ns = J.set_ptr[blk + 1] - s0;
+    for (int i = threadIdx.x; i < ns; i += (WAVES * 64)) xwin[i] = vec[__builtin_nontemporal_load(J.set_col + s0 + i)];
+  }
   for (int i = threadIdx.x; i < brows; i += (WAVES * 64)) psum[i] = 0.0;  // rows without nonzeros
   // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue skips them
   for (int q = J.lr_ptr[blk] + (int)threadIdx.x; q < J.lr_ptr[blk + 1]; q += (WAVES * 64))
     psum[J.lr_row[q] - row0] = __longlong_as_double(kJagNotMine);
   __syncthreads();
-  if (g < J.ngroups) {
+  {
     int e         = __builtin_amdgcn_readfirstlane(J.tile_e[g]);
     const int sr0 = __builtin_amdgcn_readfirstlane(J.tile_sr[g]);
     const int ns  = __builtin_amdgcn_readfirstlane(J.tile_sr[g + 1]) - sr0;
@@ -605,29 +617,20 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
           e += __builtin_popcountll(__ballot(cnt > k0 + u));
         }
         double a[kJagU];
-        int j[kJagU];
+        unsigned j[kJagU];
 #pragma unroll
         for (int u = 0; u < kJagU; ++u) {
-          a[u] = 0.0, j[u] = wbase;
+          a[u] = 0.0, j[u] = 0;
           if (cnt > k0 + u) {
             a[u] = __builtin_nontemporal_load(J.val + at[u] + lane);
-            j[u] = __builtin_nontemporal_load(J.col + at[u] + lane);
+            j[u] = __builtin_nontemporal_load(J.slot + at[u] + lane);
           }
         }
-        // gathers: LDS window first choice; the entries outside it are requested from global memory back to back (all
-        // of a round's loads in flight together) before the LDS reads
+        // every gather is an LDS read.  Lanes past their row's end add +0.0 * 0.0: a sum that started at +0.0 is never
+        // -0.0, so this changes no bit
         double xv[kJagU];
-        bool outside[kJagU];
 #pragma unroll
-        for (int u = 0; u < kJagU; ++u) {
-          outside[u] = cnt > k0 + u && (unsigned)(j[u] - wbase) >= wlen;
-          xv[u]      = 0.0;
-          if (outside[u]) xv[u] = vec[j[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < kJagU; ++u)
-          if (cnt > k0 + u && !outside[u]) xv[u] = xwin[(unsigned)(j[u] - wbase)];
-        // lanes past their row's end add +0.0 * 0.0: a sum that started at +0.0 is never -0.0, so this changes no bit
+        for (int u = 0; u < kJagU; ++u) xv[u] = cnt > k0 + u ? xwin[j[u]] : 0.0;
 #pragma unroll
         for (int u = 0; u < kJagU; ++u) sum = sum + a[u] * xv[u];
       }

@@ -123,6 +123,7 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
                               with the next one (40 %)
               'block_angular' 100 independent diagonal blocks + 0.02 % linking rows that run through EVERY block
                               (thousands of nonzeros each: the long-row path) + 1 % linking columns
+              'multiband'     three bands of +-500 columns at lags 0, +n/10 and -3n/10
               'powerlaw'      row lengths ~ Pareto(1.5) with mean ~k, capped at 20000, uniform columns (hub constraints)
     every column gets at least one entry; (x*, y*) is optimal by construction, objective_star is the known answer."""
     rng = np.random.default_rng(seed)
@@ -148,6 +149,13 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
         lr = np.repeat(np.arange(m - nlink_rows, m, dtype=np.int64), per_link)
         lc = rng.integers(0, n, size=len(lr))
         rows, cols = np.concatenate([rows, lr]), np.concatenate([cols, lc])
+    elif kind == "multiband":
+        # three far-apart bands (a time-expanded model with two lags, or a 3-D grid): no contiguous window of columns holds a row
+        # block, but every row block re-uses a small SET of columns
+        rows = np.repeat(np.arange(m, dtype=np.int64), k)
+        centre = rows * n // m
+        lag = rng.choice(np.array([0, 0, 0, 0, n // 10, n // 10, n // 10, -(3 * n) // 10, -(3 * n) // 10, -(3 * n) // 10]), size=len(rows))
+        cols = (centre + lag + rng.integers(-500, 501, size=len(rows))) % n
     elif kind == "powerlaw":
         xm = k / 3.0
         lens = np.minimum((xm * (1.0 - rng.random(m)) ** (-1.0 / 1.5)).astype(np.int64) + 1, 20000)

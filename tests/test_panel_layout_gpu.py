@@ -109,7 +109,7 @@ def test_structured_matrix_gets_the_jagged_layout_by_itself(monkeypatch):
     dev = capi.Device(p)
     lay = dev.layout()
     assert lay["A"]["layout"] == lay["At"]["layout"] == "jag"
-    assert lay["A"]["lds_window_coverage_pct"] == 100
+    assert lay["A"]["lds_gather_saving_pct"] >= 90  # contiguous column ranges: filling the LDS sets is a coalesced copy
     rng = np.random.default_rng(1)
     x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
     to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
@@ -130,12 +130,12 @@ def test_auto_layout_is_a_structural_rule(monkeypatch):
     monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
     rnd = synthetic.generate(70000, 70000, 8, seed=5)                 # touches every line of the 547 KiB vector
     wide = synthetic.generate(70000, 70000, 8, seed=5, band=9000)     # 512 K nonzeros = 65536 rows: band + rows wide
-    narrow = synthetic.generate(70000, 8000, 8, seed=5)               # 62.5 KiB vector: under any limit
+    narrow = synthetic.generate(70000, 8000, 8, seed=5)               # 62.5 KiB vector: fits one LDS window
     monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(256 * 1024))
     for _ in range(3):
         assert capi.Device(rnd).layout()["A"]["layout"] == "panel"
         assert capi.Device(rnd).layout()["At"]["layout"] == "panel"
-    assert capi.Device(narrow).layout()["A"]["layout"] == "stream"
+    assert capi.Device(narrow).layout()["A"]["layout"] == "jag"       # 8000 columns: the whole vector is one LDS window
     assert capi.Device(wide).layout()["A"]["layout"] in ("panel", "stream")
     monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(1 << 30))
     assert capi.Device(rnd).layout()["A"]["layout"] == capi.Device(rnd).layout()["At"]["layout"] == "stream"
@@ -146,8 +146,9 @@ def test_auto_layout_is_a_structural_rule(monkeypatch):
     assert (a["steps_taken"], a["attempted_steps"], a["primal_objective"]) == (b["steps_taken"], b["attempted_steps"], b["primal_objective"])
 
 
-def test_jagged_layout_partial_windows(monkeypatch):
-    """columns half inside, half far outside the LDS window: the per-lane fallback to a global gather"""
+def test_jagged_layout_column_lists(monkeypatch):
+    """half of every row's columns near the diagonal, half anywhere: the workgroups' column sets are LISTS (sorted distinct columns,
+    one LDS slot each), every gather is served from LDS, and the sums stay bit-identical to the sequential CSR sums"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
     monkeypatch.setenv("CUOPT_AMD_SMALL", "0")
     rng = np.random.default_rng(3)
@@ -167,11 +168,54 @@ def test_jagged_layout_partial_windows(monkeypatch):
              lb=np.zeros(n), ub=np.ones(n), maximize=False, objective_offset=0.0)
     dev = capi.Device(p)
     lay = dev.layout()
-    assert lay["A"]["layout"] == "jag" and 30 <= lay["A"]["lds_window_coverage_pct"] <= 70
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "jag"
+    assert lay["A"]["lds_gather_saving_pct"] <= 70   # the scattered half costs a request per slot
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     to, ti, tv = orcbind.transpose(m, n, offsets, indices, values)
     np.testing.assert_array_equal(dev.spmv(x, False, m), orcbind.spmv(offsets, indices, values, x))
     np.testing.assert_array_equal(dev.spmv(y, True, n), orcbind.spmv(to, ti, tv, y))
+    dev.close()
+    monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT")
+    assert capi.Device(p).layout()["A"]["layout"] != "jag"  # auto: filling these sets costs more than half of what they serve
+
+
+def test_jagged_layout_row_blocks_follow_the_column_sets(monkeypatch):
+    """rows of ~100 scattered nonzeros: a workgroup takes only as many rows as keep its distinct columns within the 8192-entry LDS
+    window (about 80 here instead of 512), so the grid grows; a matrix with several far-apart bands (a 3-D grid: offsets +-1, +-nx,
+    +-nx*ny) has no contiguous window but small column sets -> auto picks the jagged layout.  Bit-exact either way."""
+    monkeypatch.setenv("CUOPT_AMD_SMALL", "0")
+    rng = np.random.default_rng(9)
+    m, n = 66000, 120000
+    lens = rng.integers(90, 110, size=m)
+    rows = np.repeat(np.arange(m), lens)
+    cols = rng.integers(0, n, size=len(rows))
+    import scipy.sparse as sp
+    a = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)), shape=(m, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    nx, ny = 100, 80   # +-8000: no 8192-column window holds a row block, its ~1750 distinct columns fit easily
+    grid = sp.diags([rng.standard_normal(m - abs(o)) for o in (-nx * ny, -nx, -1, 0, 1, nx, nx * ny)], (-nx * ny, -nx, -1, 0, 1, nx, nx * ny),
+                    shape=(m, m), format="csr")
+    for mat, mode, expect_blocks in ((a, "jag", 600), (grid, None, 0)):
+        if mode:
+            monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
+        else:
+            monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
+        mm, nn = mat.shape
+        p = dict(m=mm, n=nn, offsets=mat.indptr.astype(np.int32), indices=mat.indices.astype(np.int32),
+                 values=np.ascontiguousarray(mat.data), c=np.zeros(nn), lo=-np.ones(mm), hi=np.ones(mm), lb=np.zeros(nn), ub=np.ones(nn),
+                 maximize=False, objective_offset=0.0)
+        dev = capi.Device(p)
+        lay = dev.layout()
+        assert lay["A"]["layout"] == lay["At"]["layout"] == "jag", lay
+        assert lay["A"]["workgroups"] >= expect_blocks
+        if not mode:
+            assert lay["A"]["lds_gather_saving_pct"] >= 70
+        x, y = rng.standard_normal(nn), rng.standard_normal(mm)
+        to, ti, tv = orcbind.transpose(mm, nn, p["offsets"], p["indices"], p["values"])
+        np.testing.assert_array_equal(dev.spmv(x, False, mm), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
+        np.testing.assert_array_equal(dev.spmv(y, True, nn), orcbind.spmv(to, ti, tv, y))
+        dev.close()
 
 
 @pytest.mark.parametrize("m,n,waves", [(66000, 1000, 8), (200000, 150000, 8), (200000, 150000, 16), (70001, 90001, 16),

@@ -10,7 +10,7 @@ from oracle import orcbind
 from test_solve_gpu import host_check
 
 pytestmark = pytest.mark.gpu
-KINDS = ["staircase", "block_angular", "powerlaw"]
+KINDS = ["staircase", "block_angular", "powerlaw", "multiband"]
 
 
 @pytest.fixture(scope="module", params=KINDS)
