@@ -2044,7 +2044,7 @@ static int jag_launch(pdlpdev_ctx* c, void (*kernel)(JagView, KArgs...), const J
       done.push_back(key);
     }
   }
-  launch_k(c, kernel, stream_grid(v.nblk + v.nlong), v.waves * 64, lds, v, args...);
+  launch_k(c, kernel, ((v.nblk + 7) & ~7) + v.nlong, v.waves * 64, lds, v, args...);
   return 0;
 }
 // the two geometries are two instantiations of every jagged kernel

@@ -510,7 +510,10 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 // (160 KiB, one workgroup per CU: the same 16 waves per CU, twice the rows sharing a window twice as wide) -- chosen per
 // matrix at set-up (8 waves unless CUOPT_AMD_JAG_WAVES=16: see build_jag).
 constexpr int kJagMaxGroup = 256;   // rows per wave (2 KiB of row sums)
-constexpr int kJagU        = 8;     // jagged diagonals requested per round
+#ifndef CUOPT_AMD_JAG_U
+#define CUOPT_AMD_JAG_U 8
+#endif
+constexpr int kJagU        = CUOPT_AMD_JAG_U;  // jagged diagonals requested per round (tuning builds: -DCUOPT_AMD_JAG_U=...)
 constexpr int jag_window(int waves) { return waves == 16 ? 16384 : 8192; }  // entries of the gathered vector per workgroup
 constexpr size_t jag_lds_bytes(int waves) { return sizeof(double) * (size_t)(jag_window(waves) + waves * kJagMaxGroup); }
 constexpr long long kJagNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
@@ -541,9 +544,19 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
   double* xwin   = jag_lds;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // grid: the row blocks (blockIdx & 7 = XCD -> a contiguous range of row blocks per XCD), padded to a multiple of 8, then the
+  // long rows round-robin over the XCDs (inside one xcd_remap over both, the last XCDs would get long rows only);
+  // partials keep the order [row blocks..., long rows...]
   const int nparts = J.nblk + J.nlong;
-  const int blk    = xcd_remap(blockIdx.x, nparts);
-  if (blk >= nparts) return;
+  const int nb8    = (J.nblk + 7) & ~7;
+  int blk;
+  if ((int)blockIdx.x < nb8) {
+    blk = xcd_remap((int)blockIdx.x, J.nblk);
+    if (blk >= J.nblk) return;
+  } else {
+    blk = J.nblk + ((int)blockIdx.x - nb8);
+    if (blk >= nparts) return;
+  }
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
@@ -586,17 +599,48 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
   const int brows     = J.row0[blk + 1] - row0;
   const int wbase     = J.win[2 * blk];
   const unsigned wlen = (unsigned)J.win[2 * blk + 1];
+  // fill the LDS column set, eight requests per thread in flight (a plain loop pays one round trip per element)
+  constexpr int kFill = 8, T = WAVES * 64;
   if (wlen) {
-    for (unsigned i = threadIdx.x; i < wlen; i += (WAVES * 64)) xwin[i] = vec[wbase + i];
+    for (unsigned b0 = 0; b0 < wlen; b0 += kFill * T) {
+      double v[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const unsigned i = b0 + u * T + threadIdx.x;
+        v[u] = i < wlen ? vec[wbase + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const unsigned i = b0 + u * T + threadIdx.x;
+        if (i < wlen) xwin[i] = v[u];
+      }
+    }
   } else {
     const int s0 = J.set_ptr[blk], ns = J.set_ptr[blk + 1] - s0;
-    for (int i = threadIdx.x; i < ns; i += (WAVES * 64)) xwin[i] = vec[__builtin_nontemporal_load(J.set_col + s0 + i)];
+    for (int b0 = 0; b0 < ns; b0 += kFill * T) {
+      int c[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int i = b0 + u * T + (int)threadIdx.x;
+        c[u] = i < ns ? __builtin_nontemporal_load(J.set_col + s0 + i) : -1;
+      }
+      double v[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) v[u] = c[u] >= 0 ? vec[c[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int i = b0 + u * T + (int)threadIdx.x;
+        if (i < ns) xwin[i] = v[u];
+      }
+    }
   }
   for (int i = threadIdx.x; i < brows; i += (WAVES * 64)) psum[i] = 0.0;  // rows without nonzeros
-  // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue skips them
+  __syncthreads();
+  // rows longer than kLongRow belong to their own workgroups (above): mark them so that the epilogue skips them.  AFTER the
+  // barrier: the zero fill above touches the same strip entries from other waves; the passes below never write these entries
+  // (they hold rows of <= kLongRow nonzeros only) and the barrier before the epilogue publishes the marks.
   for (int q = J.lr_ptr[blk] + (int)threadIdx.x; q < J.lr_ptr[blk + 1]; q += (WAVES * 64))
     psum[J.lr_row[q] - row0] = __longlong_as_double(kJagNotMine);
-  __syncthreads();
   {
     int e         = __builtin_amdgcn_readfirstlane(J.tile_e[g]);
     const int sr0 = __builtin_amdgcn_readfirstlane(J.tile_sr[g]);

@@ -218,6 +218,34 @@ def test_jagged_layout_row_blocks_follow_the_column_sets(monkeypatch):
         dev.close()
 
 
+@pytest.mark.parametrize("waves", [8, 16])
+def test_jagged_layout_with_hundreds_of_long_rows(waves, monkeypatch):
+    """power-law row lengths: ~600 rows longer than 128 nonzeros, each summed by a workgroup of its own that is dispatched BEFORE the
+    row blocks -- the row block that contains such a row must leave it alone (its strip entry is marked after the zero fill, behind
+    a barrier: the two used to race)"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
+    monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(waves))
+    p = synthetic.generate_structured("powerlaw", m=200000, n=200000, k=8, seed=11)
+    lens = np.diff(p["offsets"])
+    assert (lens > 128).sum() > 300
+    dev = capi.Device(p)
+    assert dev.layout()["A"]["layout"] == "jag"
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    for _ in range(3):  # a race does not lose every time
+        for got, ref, ln in ((dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x), lens),
+                             (dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y), np.diff(to))):
+            np.testing.assert_array_equal(got[ln <= 128], ref[ln <= 128])
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
+    dev.close()
+    # the fused kernels too: first iterations against the oracle's decisions (reductions over row blocks AND long rows)
+    r = capi.Solver(p, tol=0.0, iteration_limit=40).advance()
+    o = orcbind.solve(p, tol=0.0, iteration_limit=40)
+    assert (r["steps_taken"], r["attempted_steps"]) == (int(o["steps_taken"]), int(o["attempted_steps"]))
+    assert r["primal_objective"] == pytest.approx(o["primal_objective"], rel=1e-8, abs=1e-8)
+
+
 @pytest.mark.parametrize("m,n,waves", [(66000, 1000, 8), (200000, 150000, 8), (200000, 150000, 16), (70001, 90001, 16),
                                        (800000, 300000, 8)])
 def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch):
