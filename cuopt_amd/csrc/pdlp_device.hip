@@ -647,7 +647,9 @@ __device__ __forceinline__ void apply_step_decision(pdlpdev_ctl* ctl, double dy2
   ctl->last_dy2         = dy2;
   ctl->attempts += 1;
   bool accepted;
-  if (movement <= 0.0 || movement >= 1.0e100) {  // pdlp_constants.hpp:39-47
+  // pdlp_constants.hpp:39-47 (movement <= 0 or >= 1e100), written so that a NaN -- which the reference's comparisons let through
+  // into an endless series of rejected steps -- takes the same "invalid step size" exit (-> NumericalError at the next check)
+  if (!(movement > 0.0) || !(movement < 1.0e100) || interaction != interaction) {
     // reference: flag -1, k and eta untouched; take_step still averages and swaps
     // (pdlp.cu:1193-1221) and the next loop trip is forced to be a major iteration.
     ctl->error = 1;
@@ -1568,6 +1570,7 @@ __global__ void k_set_step(pdlpdev_ctl* ctl, double step, double w)
 __global__ void k_set_target(pdlpdev_ctl* ctl, int target) { ctl->target_steps = target; }
 __global__ void k_set_k(pdlpdev_ctl* ctl, int k) { ctl->k = k; }
 __global__ void k_clear_error(pdlpdev_ctl* ctl) { ctl->error = 0; }
+__global__ void k_set_error(pdlpdev_ctl* ctl) { ctl->error = 1; }
 __global__ void k_set_loop_state(pdlpdev_ctl* ctl, double sum_weights, int its_since_restart, int k)
 {
   ctl->sum_weights       = sum_weights;
@@ -2918,7 +2921,15 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
     } else {
       for (int i = 0; i < remaining; ++i) TRY(enqueue_attempt(ctx));
     }
+    const int before = ctx->ctl_h->steps_taken, asked = target_steps - before;
     TRY(fetch_ctl(ctx, nullptr));
+    // every rejection shrinks the step size; 64 in a row (a whole round without one accepted step) leave nothing of it:
+    // report it like the reference's invalid step size instead of re-enqueueing forever
+    if (ctx->ctl_h->error == 0 && ctx->ctl_h->steps_taken == before && asked >= 64) {
+      k_set_error<<<1, 1, 0, ctx->stream>>>(ctx->ctl);
+      LAUNCH_CHECK();
+      TRY(fetch_ctl(ctx, nullptr));
+    }
     if (++guard > 100000) return fail(-6, "pdlpdev_run: no progress");
   }
   if (ctl) *ctl = *ctx->ctl_h;

@@ -1125,7 +1125,12 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   s->total_iterations   = ws->total_pdlp_iterations;
   s->last_candidate_kkt = ws->last_candidate_kkt_score;
   s->last_restart_kkt   = ws->last_restart_kkt_score;
-  s->need_aty           = ws->current_ATY == nullptr;  // A^T y travels with the snapshot (pdlp.cu:160-163)
+  // A^T y travels with the snapshot (pdlp.cu:160-163) -- and is trusted when the snapshot also carries the scaled iterate it
+  // belongs to (the bit-exact resume).  A snapshot without it (the reference's nine vectors: y is re-scaled on restore; or one
+  // carried to another problem by cuoptamd_warm_start_remap, whose A^T y is zero-padded / permuted) gets A^T y recomputed from
+  // the restored y: one SpMV, and the step-size rule never sees an interaction term that does not vanish with the step
+  // (which ends in an endless series of rejected steps).
+  s->need_aty           = ws->current_ATY == nullptr || ws->current_dual_solution_scaled == nullptr;
   s->warm_started       = true;
   s->result.initial_step_size     = ws->initial_step_size;
   s->result.initial_primal_weight = ws->initial_primal_weight;

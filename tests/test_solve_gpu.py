@@ -619,6 +619,18 @@ def test_warm_start_of_another_problem_is_refused(golden_problems):
     assert r["status_name"] == "Optimal"
 
 
+@pytest.mark.timeout(120)
+def test_non_finite_data_ends_in_numerical_error_not_in_an_endless_loop():
+    """a NaN coefficient makes every step-size quantity NaN; the reference's comparisons (pdlp_constants.hpp:39-47, movement <= 0 or
+    >= 1e100) let a NaN through to a step that is rejected for ever.  Here it takes the invalid-step-size exit: NumericalError"""
+    for size in ((30, 20, 4), (4000, 3500, 8)):  # the on-chip loop and the multi-launch loop
+        p = synthetic.generate(*size, seed=4)
+        p["values"] = p["values"].copy()
+        p["values"][3] = np.nan
+        r = capi.solve(p, method=1, tol=1e-4, iteration_limit=5000)
+        assert r["return_code"] == 0 and r["status"] == "NumericalError", r["status"]
+
+
 def test_warm_start_carried_to_a_grown_and_a_shrunk_problem():
     """set_pdlp_warm_start_data with mappings (LP/solver_settings.cu:92-240) used for what it is for: the snapshot of an LP warm-starts
     (i) the same LP with extra rows and columns appended (zero padding) and (ii) the LP with its last rows dropped and two of the kept
@@ -652,11 +664,17 @@ def test_warm_start_carried_to_a_grown_and_a_shrunk_problem():
     scale = 1 + abs(o["primal_objective"])
     assert abs(warm["primal_objective"] - o["primal_objective"]) <= 2e-4 * scale
     assert warm["steps_taken"] < cold["steps_taken"]
-    # (ii) shrunk: the last 100 ('>=') rows dropped, rows 0 and 1 swapped
-    keep = np.arange(p["m"] - 100)
-    perm = keep.copy()
+    # (ii) shrunk: a base LP whose last 100 rows are inactive at the optimum (y* = 0, slack > 0); they are dropped (the optimum stays)
+    # and rows 0 and 1 of the kept ones are swapped
+    inactive = np.nonzero((p["y_star"] == 0.0) & np.isinf(p["hi"]))[0][:100]
+    order = np.concatenate([np.setdiff1d(np.arange(p["m"]), inactive), inactive])
+    base = lp_of(a[order], p["c"], p["lo"][order], p["hi"][order])
+    first = capi.Solver(base, tol=1e-3)
+    assert first.advance()["status_name"] == "Optimal"
+    ws = first.get_warm_start()
+    perm = np.arange(p["m"] - 100)
     perm[[0, 1]] = [1, 0]
-    small = lp_of(a[perm], p["c"], p["lo"][perm], p["hi"][perm])
+    small = lp_of(a[order][perm], p["c"], p["lo"][order][perm], p["hi"][order][perm])
     ws_small = capi.remap_warm_start(ws, None, perm)   # new[perm[i]] = old[i]: a swap is its own inverse
     assert ws_small["current_dual_solution"][0] == ws["current_dual_solution"][1]
     cold = capi.Solver(small, tol=1e-5).advance()
@@ -664,6 +682,7 @@ def test_warm_start_carried_to_a_grown_and_a_shrunk_problem():
     o = orcbind.solve(small, tol=1e-5)
     assert cold["status_name"] == warm["status_name"] == o["status"] == "Optimal"
     assert abs(warm["primal_objective"] - o["primal_objective"]) <= 2e-4 * (1 + abs(o["primal_objective"]))
+    assert abs(warm["primal_objective"] - p["objective_star"]) <= 2e-4 * (1 + abs(p["objective_star"]))
     assert warm["steps_taken"] < cold["steps_taken"]
 
 
