@@ -1793,7 +1793,9 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   const int64_t nnz = rows > 0 ? off[rows] : 0;
   if (rows <= 0 || cols <= 0 || nnz <= 0) return H;
   // one wave per group of up to G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
-  int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 65536 ? 64 : 0;
+  // (below ~1.3e5 rows the layout has fewer workgroups than the chip has CUs and the CSR stream kernel's many small workgroups
+  // win by 8 % on banded 7e4- and 1e5-row LPs; from 2e5 rows on the jagged layout wins: 28.9 k vs 26.9 k it/s)
+  int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
   // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) is 1-4 % faster on banded matrices but

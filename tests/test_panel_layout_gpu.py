@@ -105,7 +105,7 @@ def test_structured_matrix_gets_the_jagged_layout_by_itself(monkeypatch):
     """auto: a banded LP (every gather inside the workgroup's LDS window) takes the jagged layout, a random one does not;
     the solve through it reaches the optimum known by construction"""
     monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
-    p = synthetic.generate(70000, 70000, 8, seed=5, band=600)
+    p = synthetic.generate(140000, 140000, 8, seed=5, band=600)
     dev = capi.Device(p)
     lay = dev.layout()
     assert lay["A"]["layout"] == lay["At"]["layout"] == "jag"
@@ -115,8 +115,10 @@ def test_structured_matrix_gets_the_jagged_layout_by_itself(monkeypatch):
     to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
     np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
     np.testing.assert_array_equal(dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y))
-    q = synthetic.generate(70000, 70000, 8, seed=5)
+    q = synthetic.generate(140000, 140000, 8, seed=5)
     assert capi.Device(q).layout()["A"]["layout"] != "jag"
+    small = synthetic.generate(70000, 70000, 8, seed=5, band=600)
+    assert capi.Device(small).layout()["A"]["layout"] == "stream"  # under 131072 rows the stream kernel's small workgroups win
     r = capi.solve(p, method=1, tol=1e-6)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
@@ -130,7 +132,7 @@ def test_auto_layout_is_a_structural_rule(monkeypatch):
     monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
     rnd = synthetic.generate(70000, 70000, 8, seed=5)                 # touches every line of the 547 KiB vector
     wide = synthetic.generate(70000, 70000, 8, seed=5, band=9000)     # 512 K nonzeros = 65536 rows: band + rows wide
-    narrow = synthetic.generate(70000, 8000, 8, seed=5)               # 62.5 KiB vector: fits one LDS window
+    narrow = synthetic.generate(140000, 8000, 8, seed=5)              # 62.5 KiB vector: fits one LDS window
     monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(256 * 1024))
     for _ in range(3):
         assert capi.Device(rnd).layout()["A"]["layout"] == "panel"
@@ -180,13 +182,13 @@ def test_jagged_layout_column_lists(monkeypatch):
 
 
 def test_jagged_layout_row_blocks_follow_the_column_sets(monkeypatch):
-    """rows of ~100 scattered nonzeros: a workgroup takes only as many rows as keep its distinct columns within the 8192-entry LDS
-    window (about 80 here instead of 512), so the grid grows; a matrix with several far-apart bands (a 3-D grid: offsets +-1, +-nx,
+    """rows of ~45 scattered nonzeros: a workgroup takes only as many rows as keep its distinct columns within the 8192-entry LDS
+    window (about 180 here instead of 512), so the grid grows; a matrix with several far-apart bands (a 3-D grid: offsets +-1, +-nx,
     +-nx*ny) has no contiguous window but small column sets -> auto picks the jagged layout.  Bit-exact either way."""
     monkeypatch.setenv("CUOPT_AMD_SMALL", "0")
     rng = np.random.default_rng(9)
-    m, n = 66000, 120000
-    lens = rng.integers(90, 110, size=m)
+    m, n = 140000, 120000
+    lens = rng.integers(40, 50, size=m)
     rows = np.repeat(np.arange(m), lens)
     cols = rng.integers(0, n, size=len(rows))
     import scipy.sparse as sp
