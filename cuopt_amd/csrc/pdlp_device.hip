@@ -190,7 +190,7 @@ struct pdlpdev_ctx {
     int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
     double* val   = nullptr;
   } pa, pat;
-  // sorted jagged rows with an LDS column window (third layout, structured matrices; pdlp_kernels.hpp)
+  // sorted jagged rows with LDS column sets (third layout, structured matrices; pdlp_kernels.hpp)
   struct Jag {
     bool on = false;
     JagView v{};
@@ -952,7 +952,7 @@ k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* 
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
   panel_spmv_block(P, cur ? y0 : y1 /* y' */, e, part);
 }
-// jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column window
+// jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column sets
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
@@ -2225,8 +2225,9 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(dev_alloc(ctx, &ctx->rc_scratch, n));
   {
     // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel | jag ; CUOPT_AMD_SLAB_BYTES.
-    // auto: the jagged layout when at least half of a matrix's gathers fall into the LDS column windows (a structural
-    // test: reproducible); otherwise slab-major panels vs. the CSR stream, timed on the device (pick_layout)
+    // auto is structural (reproducible): the jagged layout when filling its LDS column sets costs at most half of the gathers
+    // they serve (build_jag), else slab-major panels iff the stream kernel's live gather set exceeds an XCD's L2
+    // (gather_working_set), else the CSR stream.  "timed" times panels against the stream on the device (pick_layout).
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
     const std::string mode = mode_env ? mode_env : "auto";
     const char* slab_env   = getenv("CUOPT_AMD_SLAB_BYTES");
@@ -2772,7 +2773,7 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 }
 
 
-// launch helpers: pick the layout (jagged rows with LDS windows, slab-major panels, CSR stream)
+// launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
 static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
 static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
 static void launch_a_dual(pdlpdev_ctx* ctx)
@@ -3495,8 +3496,8 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
-  // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS
-  // windows), workgroups, slabs (panels) or percent of the gathers served from LDS (jagged)
+  // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column
+  // sets), workgroups, slabs (panels) or percent of the global gathers the LDS sets save (jagged)
   out[0] = ctx->ja.on ? 3 : ctx->pa.on ? 1 : 0;
   out[1] = ctx->ja.on ? ctx->ja.v.nblk : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb;
   out[2] = ctx->ja.on ? (int)(100.0 * ctx->ja.saving + 0.5) : ctx->pa.on ? ctx->pa.v.S : 1;

@@ -292,11 +292,12 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
 int pdlpdev_synchronize(pdlpdev_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
-/* SpMV layout actually in use: out = {A: panels?(0/1), workgroups, slabs, A^T: panels?, workgroups, slabs}.
- * Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default: slab-major row panels when the
- * gathered vector exceeds 2 MiB and measure faster at setup, CSR stream otherwise) | stream | panel ;
- * CUOPT_AMD_SLAB_BYTES (1 MiB).  out[0] = out[3] = 2: small LP (m + n <= 16384, nnz <= 65536; CUOPT_AMD_SMALL=0/1
- * overrides) whose attempt batches run inside ONE resident workgroup instead of 4 launches per attempt. */
+/* SpMV layout actually in use: out = {A: layout, workgroups, detail, A^T: layout, workgroups, detail}; layout 0 = CSR stream,
+ * 1 = slab-major row panels (detail: slabs), 2 = small LP whose attempt batches run inside ONE resident workgroup
+ * (CUOPT_AMD_SMALL=0/1 overrides), 3 = sorted jagged rows with LDS column sets (detail: percent of the global gathers the
+ * sets save).  Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default; a structural, reproducible rule:
+ * DESIGN.md section 3) | stream | panel | jag | timed ; CUOPT_AMD_SLAB_BYTES (1.33 MiB), CUOPT_AMD_PANEL_WS_BYTES (4 MiB),
+ * CUOPT_AMD_JAG_WAVES (8 | 16). */
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6]);
 
 #ifdef __cplusplus
