@@ -1,62 +1,116 @@
-// Cost of a grid-wide barrier on MI355X (one workgroup per CU, all co-resident): is a persistent whole-chip PDHG loop for
-// mid-size LPs (1e5..1e6 nonzeros, the matrices resident in the chip's aggregate LDS) cheaper per phase than a kernel boundary
-// inside a hipGraph (~1.7 us gap + ramp)?   hipcc --offload-arch=gfx950 -O3 tools/grid_barrier.hip -o grid_barrier
+// Feasibility probe for a persistent multi-workgroup PDHG loop: cost of a grid-wide barrier on MI355X
+// (G workgroups, agent-scope atomics + fences so that data written before the barrier is visible across XCDs).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/grid_barrier tools/grid_barrier.hip && tools/bin/grid_barrier
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int MODE>  // 0: relaxed atomics only, 1: release/acquire fences at agent scope, 2: + a 64-byte payload exchanged per block
-__global__ void __launch_bounds__(256) k_barrier(unsigned* counter, double* payload, int iters, double* out)
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// sense-reversing counter barrier; returns false on timeout (someone is not resident)
+__device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned G, unsigned& epoch, int* abort_flag)
 {
-  const unsigned G = gridDim.x;
-  double acc = 0.0;
-  for (int it = 0; it < iters; ++it) {
-    if (MODE == 2 && threadIdx.x < 8) payload[(size_t)blockIdx.x * 8 + threadIdx.x] = acc + it + threadIdx.x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (MODE >= 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (unsigned)(it + 1) * G;
-      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-      if (MODE >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (MODE == 2) {  // every block reads every other block's payload (G * 64 bytes): the reduction a PDHG decision needs
-      double s = 0.0;
-      for (unsigned b = threadIdx.x; b < G * 8; b += 256) s += __builtin_nontemporal_load(payload + b);
-      acc += s;
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    epoch += 1;
+    const unsigned target = epoch * G;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    long spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1L << 24) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
     }
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+  __syncthreads();
+  return ok;
+}
+
+// two-level variant: 16 workgroups share a group counter (their arrivals proceed in parallel with the other groups'),
+// the last arriver of a group bumps the top counter that everybody polls.  counters: [0] top, [32*(1+grp)] groups
+__device__ __forceinline__ bool grid_barrier2(unsigned* counters, unsigned G, unsigned& epoch, int* abort_flag)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    epoch += 1;
+    const unsigned grp = blockIdx.x >> 4, ngroups = (G + 15) >> 4;
+    const unsigned size = grp + 1 < ngroups ? 16u : G - 16u * (ngroups - 1);
+    const unsigned prev = __hip_atomic_fetch_add(counters + 32 * (1 + grp), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1 == epoch * size) __hip_atomic_fetch_add(counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = epoch * ngroups;
+    long spins = 0;
+    while (__hip_atomic_load(counters, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1L << 24) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+// each round: every WG writes its slot, barrier, every WG sums all slots (checks cross-XCD visibility), barrier
+template <int MODE>
+__global__ void k_probe(unsigned* counter, int* abort_flag, double* slots, double* out, int rounds, int with_data)
+{
+  __shared__ double red[16];
+  const unsigned G = gridDim.x;
+  unsigned epoch = 0;
+  double check = 0.0;
+  for (int r = 0; r < rounds; ++r) {
+    if (with_data && threadIdx.x == 0) slots[blockIdx.x] = (double)(r + 1) * (blockIdx.x + 1);
+    if (!(MODE ? grid_barrier2(counter, G, epoch, abort_flag) : grid_barrier(counter, G, epoch, abort_flag))) return;
+    if (with_data) {
+      double s = 0.0;
+      for (unsigned i = threadIdx.x; i < G; i += blockDim.x) s += slots[i];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) for (unsigned w = 0; w < blockDim.x / 64; ++w) check += red[w];
+      if (!(MODE ? grid_barrier2(counter, G, epoch, abort_flag) : grid_barrier(counter, G, epoch, abort_flag))) return;
+    }
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = check;
 }
 
 int main()
 {
-  int dev = 0; CK(hipSetDevice(dev));
-  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, dev));
-  unsigned* counter; double *payload, *out;
-  CK(hipMalloc(&counter, 4)); CK(hipMalloc(&payload, 1024 * 64)); CK(hipMalloc(&out, 1024 * 8));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int iters = 2000;
-  for (int G : {64, 256, 512}) {
-    if (G > 2 * p.multiProcessorCount) continue;
-    for (int mode = 0; mode < 3; ++mode) {
-      float best = 1e30f;
-      for (int rep = 0; rep < 3; ++rep) {
-        CK(hipMemset(counter, 0, 4));
-        CK(hipEventRecord(e0, 0));
-        if (mode == 0) k_barrier<0><<<G, 256>>>(counter, payload, iters, out);
-        if (mode == 1) k_barrier<1><<<G, 256>>>(counter, payload, iters, out);
-        if (mode == 2) k_barrier<2><<<G, 256>>>(counter, payload, iters, out);
-        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        best = ms < best ? ms : best;
+  unsigned* counter; int* abort_flag; double *slots, *out;
+  CHECK(hipMalloc(&counter, 8192)); CHECK(hipMalloc(&abort_flag, 256));
+  CHECK(hipMalloc(&slots, 4096 * 8)); CHECK(hipMalloc(&out, 4096 * 8));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int mode : {0, 1})
+  for (int T : {512})
+    for (int G : {8, 32, 64, 128, 200, 256})
+      for (int with_data : {0, 1}) {
+        const int rounds = 2000;
+        CHECK(hipMemset(counter, 0, 8192)); CHECK(hipMemset(abort_flag, 0, 256));
+        if (mode) k_probe<1><<<G, T>>>(counter, abort_flag, slots, out, 10, with_data); else k_probe<0><<<G, T>>>(counter, abort_flag, slots, out, 10, with_data);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemset(counter, 0, 8192));
+        CHECK(hipEventRecord(e0));
+        if (mode) k_probe<1><<<G, T>>>(counter, abort_flag, slots, out, rounds, with_data); else k_probe<0><<<G, T>>>(counter, abort_flag, slots, out, rounds, with_data);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        int ab; CHECK(hipMemcpy(&ab, abort_flag, 4, hipMemcpyDeviceToHost));
+        std::vector<double> h(G); CHECK(hipMemcpy(h.data(), out, G * 8, hipMemcpyDeviceToHost));
+        // expected check: sum_r (r+1) * G(G+1)/2
+        const double expect = with_data ? (double)rounds * (rounds + 1) / 2 * ((double)G * (G + 1) / 2) : 0.0;
+        bool good = true;
+        for (int g = 0; g < G; ++g) good = good && h[g] == expect;
+        printf("%s T=%4d G=%3d %s: %.2f us per barrier%s%s\n", mode ? "two-level" : "flat     ", T, G, with_data ? "data+2 barriers/round" : "barrier only       ",
+               1e3 * ms / rounds / (with_data ? 2 : 1), ab ? "  ABORTED" : "", good ? "" : "  WRONG DATA");
       }
-      printf("grid %3d workgroups, mode %d (%s): %.2f us per barrier\n", G, mode,
-             mode == 0 ? "relaxed atomics" : mode == 1 ? "release/acquire fences" : "fences + all-to-all 64 B payload", best * 1e3 / iters);
-    }
-  }
-  // for comparison: an empty kernel per phase inside a hipGraph
   return 0;
 }
