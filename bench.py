@@ -56,6 +56,11 @@ def reference_dual_simplex_block(root, cutoff_s=15.0):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON record: libraries loaded below write banners to file descriptor 1 (RCCL prints its
+    # version block there when the first communicator is created), so everything else is sent to stderr
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -244,7 +249,7 @@ def main():
         info = capi.device_info(local_rank)
         out = {
             "metric": "pdlp_iterations_per_sec", "value": round(its_per_s, 2), "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
+            "n_gpus": world, "rccl_nranks": world if dist is not None else 0, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
             "ms_per_step": round(1e3 * elapsed / timed_steps, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic %s sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, longest row %d, CSR fp64/int32, "
@@ -253,12 +258,13 @@ def main():
                                       m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""),
                                       nnz, int(np.diff(p["offsets"]).max())),
                        "rows": m, "cols": n, "nnz": nnz,
-                       "parallelism": "row-block x%d + RCCL all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": ("row-block x%d + RCCL %s" % (world, "reduce-scatter / all-gather (sliced primal)" if capi.lib.pdlpdev_shard_dataflow(dev.handle) == 2 else "all-reduce")) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
             "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"],
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

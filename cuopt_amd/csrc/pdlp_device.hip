@@ -61,6 +61,8 @@ static int (*GetUniqueId)(unique_id*);
 static int (*CommInitRank)(comm_t*, int, unique_id, int);
 static int (*CommDestroy)(comm_t);
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+static int (*ReduceScatter)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+static int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
 static const char* (*GetErrorString)(int);
 static std::mutex load_mutex;
 static int load()
@@ -77,6 +79,8 @@ static int load()
   *(void**)&CommInitRank   = dlsym(lib, "ncclCommInitRank");
   *(void**)&CommDestroy    = dlsym(lib, "ncclCommDestroy");
   *(void**)&AllReduce      = dlsym(lib, "ncclAllReduce");
+  *(void**)&ReduceScatter  = dlsym(lib, "ncclReduceScatter");
+  *(void**)&AllGather      = dlsym(lib, "ncclAllGather");
   *(void**)&GetErrorString = dlsym(lib, "ncclGetErrorString");
   if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce)
     return fail(-3, "RCCL symbols missing");
@@ -173,6 +177,7 @@ struct Range {
 // ================================================================================================
 // context
 // ================================================================================================
+constexpr size_t kSlicePad = 512;  // spare entries of the vectors that are exchanged in equal slices (sliced-primal dataflow)
 struct pdlpdev_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -223,7 +228,14 @@ struct pdlpdev_ctx {
   rccl::comm_t comm = nullptr;  // non-null also marks "sharded mode" when the soft communicator is used
   softcomm::Comm* soft = nullptr;
   int rank = 0, world = 1;
-  double* ar_buf = nullptr;  // n + 8 doubles: A^T y partial + packed scalars
+  double* ar_buf = nullptr;  // n + pad doubles: A^T y partial + packed scalars
+  // "sliced primal" dataflow of a sharded solve (CUOPT_AMD_SHARD_DATAFLOW=rsag): inside the attempt loop a rank updates only
+  // its slice [rank * slice, rank * slice + slice) of the primal-side vectors; reduce-scatter(A^T y' partials) -> slice of
+  // A^T y', all-gather(xbar slices) -> the gathered vector of the next A xbar.  Outside the loop everything is replicated.
+  bool rsag = false;
+  int slice = 0;               // entries per rank, a multiple of 16; slice * world >= n
+  double* rs_buf = nullptr;    // slice + 8: this rank's part of the reduced A^T y'
+  double* rs_scal = nullptr;   // ||dy||^2, interaction, ||dx||^2 partial sums of this rank -> all-reduced
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
   bool prof_armed = false;
@@ -1071,6 +1083,21 @@ k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ 
   for (int i = threadIdx.x; i < nb; i += kBlock) acc[0] += part[i];
   block_reduce<SumOp, 1>(acc, red);
   if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// sliced-primal dataflow: this rank's three step-size partial sums, side by side, for ONE small all-reduce
+__global__ void __launch_bounds__(kBlock)
+k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t, double* __restrict__ out)
+{
+  __shared__ double red[3 * 8];
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nb_dy; i += kBlock) acc[0] += part_dy[i];
+  for (int i = threadIdx.x; i < nb_t; i += kBlock) {
+    acc[1] += part_t[i];
+    acc[2] += part_t[nb_t + i];
+  }
+  block_reduce<SumOp, 3>(acc, red);
+  if (threadIdx.x == 0) out[0] = acc[0], out[1] = acc[1], out[2] = acc[2];
 }
 
 // ================================================================================================
@@ -2210,11 +2237,13 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(upload_f64(ctx, &ctx->lo, lo, m)); TRY(upload_f64(ctx, &ctx->lo_u, lo, m));
   TRY(upload_f64(ctx, &ctx->hi, hi, m)); TRY(upload_f64(ctx, &ctx->hi_u, hi, m));
   TRY(dev_alloc(ctx, &ctx->dr, m)); TRY(dev_alloc(ctx, &ctx->dc, n));
+  // x, A^T y, xbar, sum_x carry kSlicePad spare entries: the sliced-primal dataflow of a sharded solve all-gathers them in
+  // equal slices of a multiple of 16 entries per rank (slice * world may exceed n by up to 16 * 16 - 1)
   for (int i = 0; i < 2; ++i) {
-    TRY(dev_alloc(ctx, &ctx->x[i], n)); TRY(dev_alloc(ctx, &ctx->y[i], m));
-    TRY(dev_alloc(ctx, &ctx->aty[i], n)); TRY(dev_alloc(ctx, &ctx->rc[i], n));
+    TRY(dev_alloc(ctx, &ctx->x[i], (size_t)n + kSlicePad)); TRY(dev_alloc(ctx, &ctx->y[i], m));
+    TRY(dev_alloc(ctx, &ctx->aty[i], (size_t)n + kSlicePad)); TRY(dev_alloc(ctx, &ctx->rc[i], n));
   }
-  TRY(dev_alloc(ctx, &ctx->xbar, n)); TRY(dev_alloc(ctx, &ctx->sumx, n)); TRY(dev_alloc(ctx, &ctx->sumy, m));
+  TRY(dev_alloc(ctx, &ctx->xbar, (size_t)n + kSlicePad)); TRY(dev_alloc(ctx, &ctx->sumx, (size_t)n + kSlicePad)); TRY(dev_alloc(ctx, &ctx->sumy, m));
   TRY(dev_alloc(ctx, &ctx->avgx, n)); TRY(dev_alloc(ctx, &ctx->avgy, m));
   TRY(dev_alloc(ctx, &ctx->lrx, n)); TRY(dev_alloc(ctx, &ctx->lry, m));
   TRY(dev_alloc(ctx, &ctx->tmp_n, n)); TRY(dev_alloc(ctx, &ctx->tmp_m, m));
@@ -2301,7 +2330,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
-  TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + 8));
+  TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + kSlicePad));
   lap("partial buffers");
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
@@ -2358,6 +2387,21 @@ int pdlpdev_softcomm_create(int world, uint8_t id[128])
   memcpy(id + 8, &c, sizeof(c));
   return 0;
 }
+// CUOPT_AMD_SHARD_DATAFLOW = allreduce (default) | rsag : see the `rsag` fields of the context
+static int setup_dataflow(pdlpdev_ctx* ctx)
+{
+  const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
+  if (!env || std::string(env) == "allreduce") return 0;
+  if (std::string(env) != "rsag") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce or rsag");
+  if (ctx->world > 16) return fail(-1, "the sliced-primal dataflow supports up to 16 ranks");
+  if (!ctx->soft && (!rccl::ReduceScatter || !rccl::AllGather)) return fail(-3, "RCCL: ncclReduceScatter / ncclAllGather missing");
+  const int per = (ctx->n + ctx->world - 1) / ctx->world;
+  ctx->slice    = (per + 15) & ~15;
+  ctx->rsag     = true;
+  TRY(dev_alloc(ctx, &ctx->rs_buf, (size_t)ctx->slice + 8));
+  TRY(dev_alloc(ctx, &ctx->rs_scal, 8));
+  return 0;
+}
 int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128])
 {
   if (memcmp(id, softcomm::kMagic, 8) == 0) {
@@ -2367,7 +2411,7 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
     ctx->soft = c;
     ctx->comm = reinterpret_cast<rccl::comm_t>(c);  // marks sharded mode; never passed to RCCL
     ctx->rank = rank, ctx->world = world;
-    return 0;
+    return setup_dataflow(ctx);
   }
   TRY(rccl::load());
   HIP_TRY(hipSetDevice(ctx->device));
@@ -2394,6 +2438,46 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
   }
   ctx->comm = comm;
   ctx->rank = rank, ctx->world = world;
+  return setup_dataflow(ctx);
+}
+// recv[0..count) = sum over the ranks of send[rank * count ..][0..count)   (ncclReduceScatter)
+static int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t count)
+{
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
+    c->bufs[r] = const_cast<double*>(send);
+    c->barrier();
+    softcomm::Peers peers;
+    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q] + (size_t)r * count;
+    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
+    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, 0, recv);  // recv is nobody's input
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    c->barrier();  // nobody still reads the inputs
+    return 0;
+  }
+  RCCL_TRY(rccl::ReduceScatter(send, recv, count, rccl::kFloat64, rccl::kSum, ctx->comm, ctx->stream));
+  return 0;
+}
+// buf[q * count ..][0..count) = rank q's slice, in place (ncclAllGather with sendbuff = recvbuff + rank * count)
+static int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count)
+{
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    c->bufs[r] = buf;
+    c->barrier();
+    for (int q = 0; q < c->world; ++q)
+      if (q != r)
+        HIP_TRY(hipMemcpyAsync(buf + (size_t)q * count, c->bufs[q] + (size_t)q * count, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    c->barrier();  // nobody still reads my slice
+    return 0;
+  }
+  RCCL_TRY(rccl::AllGather(buf + (size_t)ctx->rank * count, buf, count, rccl::kFloat64, ctx->comm, ctx->stream));
   return 0;
 }
 static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
@@ -2836,6 +2920,29 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
 {
   hipStream_t s = ctx->stream;
   const int n = ctx->n;
+  if (ctx->rsag) {
+    // sliced primal: primal step on this rank's columns -> all-gather(xbar) -> local rows of A -> partial A^T y' ->
+    // reduce-scatter -> this rank's columns of A^T y' and of the step-size sums -> ONE 3-scalar all-reduce -> the same
+    // decision on every rank.  Same wire bytes as the all-reduce of the replicated dataflow, 1/world of its element-wise work.
+    const size_t cs = (size_t)ctx->rank * ctx->slice;
+    const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
+    launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs);
+    LAUNCH_CHECK();
+    TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
+    launch_a_dual(ctx);
+    launch_at_cur(ctx, ctx->ar_buf, 1);
+    LAUNCH_CHECK();
+    TRY(reduce_scatter(ctx, ctx->ar_buf, ctx->rs_buf, (size_t)ctx->slice));
+    const int g = std::min(grid_for(len), kGenericBlocks);
+    launch_k(ctx, k_step_stats, g, kBlock, 0, len, g, ctx->ctl, ctx->rs_buf, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs, ctx->part_g);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_g, g, ctx->rs_scal);
+    LAUNCH_CHECK();
+    TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
+    launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
+    LAUNCH_CHECK();
+    return 0;
+  }
   launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
   launch_a_dual(ctx);
   if (!ctx->comm) {
@@ -2934,6 +3041,14 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
       TRY(fetch_ctl(ctx, nullptr));
     }
     if (++guard > 100000) return fail(-6, "pdlpdev_run: no progress");
+  }
+  if (ctx->rsag && guard > 0) {
+    // back to replicated primal vectors for everything outside the loop (major iterations, snapshots, the solution): the
+    // current x, its A^T y and the running sum are complete on their owners' slices only
+    const int cur = ctx->ctl_h->cur;
+    TRY(all_gather(ctx, ctx->x[cur], (size_t)ctx->slice));
+    TRY(all_gather(ctx, ctx->aty[cur], (size_t)ctx->slice));
+    TRY(all_gather(ctx, ctx->sumx, (size_t)ctx->slice));
   }
   if (ctl) *ctl = *ctx->ctl_h;
   return 0;
@@ -3494,6 +3609,7 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
   return 0;
 }
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
+int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->rsag ? 2 : 1; }
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column

@@ -292,6 +292,10 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
 int pdlpdev_synchronize(pdlpdev_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
+/* sharded solves: 0 = not sharded, 1 = replicated primal update behind one all-reduce(n + 1) per attempt (default),
+ * 2 = sliced primal update: reduce-scatter(A^T y' partials) + all-gather(xbar) + a 3-scalar all-reduce
+ * (CUOPT_AMD_SHARD_DATAFLOW=rsag) */
+int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx);
 /* SpMV layout actually in use: out = {A: layout, workgroups, detail, A^T: layout, workgroups, detail}; layout 0 = CSR stream,
  * 1 = slab-major row panels (detail: slabs), 2 = small LP whose attempt batches run inside ONE resident workgroup
  * (CUOPT_AMD_SMALL=0/1 overrides), 3 = sorted jagged rows with LDS column sets (detail: percent of the global gathers the
