@@ -29,7 +29,7 @@ def test_spmv_of_both_layouts_is_bit_exact_at_full_size(c3, monkeypatch):
     ref_ax = orcbind.spmv(p["offsets"], p["indices"], p["values"], x)
     ref_aty = orcbind.spmv(to, ti, tv, y)
     assert abs(ref_ax @ y - x @ ref_aty) <= 1e-9 * (np.linalg.norm(ref_ax) * np.linalg.norm(y))
-    for layout in ("stream", "panel", "jag"):  # (jag on a random matrix: almost every gather takes the global fallback)
+    for layout in ("stream", "panel", "jag"):  # (jag on a random matrix: row blocks of ~800 rows, 8192 scattered slots each)
         monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
         dev = capi.Device(p)
         assert dev.layout()["A"]["layout"] == dev.layout()["At"]["layout"] == layout
@@ -71,3 +71,21 @@ def test_both_layouts_take_the_same_decisions(c3, monkeypatch):
     assert got["stream"][:3] == got["panel"][:3]
     assert got["stream"][3] == pytest.approx(got["panel"][3], rel=1e-9)
     assert got["stream"][4] == pytest.approx(got["panel"][4], rel=1e-9)
+
+
+def test_banded_lp_at_full_size_through_the_jagged_layout():
+    """the structured 1e7-nnz LP of bench.py --workload banded: auto picks the jagged layout (contiguous column sets, 16-bit slots),
+    SpMV bit-identical to the oracle's for A and A^T, and the solve reaches the optimum known by construction"""
+    p = synthetic.generate(**synthetic.CONFIGS["banded"])
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "jag" and lay["A"]["lds_gather_saving_pct"] >= 90
+    np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
+    np.testing.assert_array_equal(dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y))
+    dev.close()
+    r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-4 * (1.0 + abs(p["objective_star"]))
