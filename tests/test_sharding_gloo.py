@@ -56,6 +56,29 @@ def _worker(rank, world, port, out):
     # a dual-side dot product
     dy2 = torch.tensor([float(y[r0:r1] @ y[r0:r1])], dtype=torch.float64)
     dist.all_reduce(dy2, op=dist.ReduceOp.SUM)
+    # the SLICED primal dataflow (CUOPT_AMD_SHARD_DATAFLOW=rsag, pdlp_device.hip enqueue_attempt): equal slices of a multiple of 16
+    # columns per rank over a padded buffer; reduce-scatter of the A^T y partials -> primal step on the slice -> all-gather
+    per = (n + world - 1) // world
+    sl = (per + 15) & ~15
+    padded = np.zeros(sl * world)
+    padded[:n] = orcbind.spmv(to, ti, tv, y[r0:r1])
+    mine = None
+    for q in range(world):  # ncclReduceScatter: chunk q is reduced onto rank q
+        chunk = torch.from_numpy(padded[q * sl:(q + 1) * sl].copy())
+        dist.reduce(chunk, dst=q, op=dist.ReduceOp.SUM)
+        if q == rank:
+            mine = chunk.numpy()
+    cs = rank * sl
+    ln = max(0, min(sl, n - cs))
+    tau = 0.37
+    x_new = np.maximum(x[cs:cs + ln] - tau * (p["c"][cs:cs + ln] - mine[:ln]), 0.0)
+    xbar_slice = np.zeros(sl)
+    xbar_slice[:ln] = 2.0 * x_new - x[cs:cs + ln]
+    gathered = [torch.zeros(sl, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(xbar_slice))  # ncclAllGather
+    xbar = np.concatenate([g.numpy() for g in gathered])[:n]
+    sums = torch.tensor([float(y[r0:r1] @ y[r0:r1]), float(x_new @ mine[:ln]), float(x_new @ x_new)], dtype=torch.float64)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)  # the 3-scalar all-reduce: identical bits on every rank
     # gather A x pieces for the check
     pieces = [None] * world
     dist.all_gather_object(pieces, (r0, r1, ax_local))
@@ -68,7 +91,10 @@ def _worker(rank, world, port, out):
                      ax_equal=bool(np.array_equal(ax, orcbind.spmv(p["offsets"], p["indices"], p["values"], x))),
                      aty_err=float(np.max(np.abs(aty.numpy() - orcbind.spmv(tof, tif, tvf, y)))),
                      colmax_equal=bool(np.array_equal(colmax.numpy(), cm)),
-                     dy2_err=float(abs(dy2.item() - y @ y)), nnz=[int(p["offsets"][b]) for b in bounds]))
+                     dy2_err=float(abs(dy2.item() - y @ y)), nnz=[int(p["offsets"][b]) for b in bounds],
+                     slice=sl, xbar_err=float(np.max(np.abs(xbar - (2.0 * np.maximum(x - tau * (p["c"] - orcbind.spmv(tof, tif, tvf, y)), 0.0) - x)))),
+                     sums_err=float(abs(sums[0].item() - y @ y)),
+                     dx2_err=float(abs(sums[2].item() - np.sum(np.maximum(x - tau * (p["c"] - orcbind.spmv(tof, tif, tvf, y)), 0.0) ** 2)))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -90,3 +116,6 @@ def test_row_block_sharding_reproduces_unsharded_products(world):
     assert per.max() - per.min() <= 7  # balanced by nonzeros to within one row
     assert res["ax_equal"] and res["colmax_equal"]
     assert res["aty_err"] < 1e-12 and res["dy2_err"] < 1e-9
+    # sliced primal dataflow: 2500 columns over 2 ranks = slices of 1264 (28 entries of padding behind the last one)
+    assert res["slice"] == 1264
+    assert res["xbar_err"] < 1e-12 and res["sums_err"] < 1e-9 and res["dx2_err"] < 1e-9
