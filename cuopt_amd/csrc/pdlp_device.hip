@@ -195,6 +195,9 @@ struct pdlpdev_ctx {
     int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
     double* val   = nullptr;
   } pa, pat;
+  // rows of A / of A^T with more than kLongRow nonzeros (set-up kernels give each a workgroup instead of a lane)
+  int32_t *a_long = nullptr, *at_long = nullptr;
+  int a_nlong = 0, at_nlong = 0;
   // sorted jagged rows with LDS column sets (third layout, structured matrices; pdlp_kernels.hpp)
   struct Jag {
     bool on = false;
@@ -345,6 +348,7 @@ __global__ void __launch_bounds__(kBlock) k_row_norm(int rows, const int32_t* __
                                                      double exponent, double* __restrict__ out)
 {
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < rows; r += gridDim.x * kBlock) {
+    if (off[r + 1] - off[r] > kLongRow) continue;  // k_row_norm_long: one lane walking thousands of nonzeros stalls its wave
     double acc = 0.0;
     for (int k = off[r]; k < off[r + 1]; ++k) {
       const int j = idx[k];
@@ -360,6 +364,42 @@ __global__ void __launch_bounds__(kBlock) k_row_norm(int rows, const int32_t* __
     }
     out[r] = acc;
   }
+}
+// rows longer than kLongRow: one workgroup per row (the block-angular LP's 200 linking rows of 5000 nonzeros cost 3.9 ms per
+// call, 42 ms of set-up, when a single lane walked each).  The maximum is order independent.  The Pock-Chambolle SUM stays
+// bit-identical to the sequential one (the scaling vectors are compared with the oracle bit for bit): the workgroup loads and
+// transforms 256 entries at a time, coalesced, into LDS, and ONE lane adds them up in order -- the adds are the only serial part.
+template <bool TRANSPOSED, bool POW>
+__global__ void __launch_bounds__(kBlock) k_row_norm_long(const int32_t* __restrict__ rows_long, const int32_t* __restrict__ off,
+                                                          const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                                          const double* __restrict__ d_row, const double* __restrict__ d_col,
+                                                          double exponent, double* __restrict__ out)
+{
+  __shared__ double buf[kBlock];
+  __shared__ double red[8];
+  const int r = rows_long[blockIdx.x], k1 = off[r + 1];
+  double acc[1] = {0.0};
+  for (int k0 = off[r]; k0 < k1; k0 += kBlock) {
+    const int k = k0 + (int)threadIdx.x;
+    double v    = 0.0;
+    if (k < k1) {
+      const int j = idx[k];
+      v           = !TRANSPOSED ? fabs((val[k] * d_row[r]) * d_col[j]) : fabs((val[k] * d_row[j]) * d_col[r]);
+    }
+    if (POW) {
+      buf[threadIdx.x] = exponent == 1.0 ? v : pow(v, exponent);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int cnt = k1 - k0 < kBlock ? k1 - k0 : kBlock;
+        for (int i = 0; i < cnt; ++i) acc[0] = acc[0] + buf[i];
+      }
+      __syncthreads();
+    } else {
+      acc[0] = v > acc[0] ? v : acc[0];
+    }
+  }
+  if (!POW) block_reduce<MaxOp, 1>(acc, red);
+  if (threadIdx.x == 0) out[r] = acc[0];
 }
 // a_divides_sqrt_b_bounded, utils.cuh:122-129
 __global__ void __launch_bounds__(kBlock) k_div_sqrt(int n, double* __restrict__ d,
@@ -382,9 +422,18 @@ __global__ void __launch_bounds__(kBlock) k_scale_matrix(int rows, const int32_t
                                                          const double* __restrict__ d_other)
 {
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < rows; r += gridDim.x * kBlock) {
+    if (off[r + 1] - off[r] > kLongRow) continue;  // k_scale_matrix_long
     const double ds = d_self[r];
     for (int k = off[r]; k < off[r + 1]; ++k) val[k] = val[k] * ds * d_other[idx[k]];
   }
+}
+__global__ void __launch_bounds__(kBlock) k_scale_matrix_long(const int32_t* __restrict__ rows_long, const int32_t* __restrict__ off,
+                                                              const int32_t* __restrict__ idx, double* __restrict__ val,
+                                                              const double* __restrict__ d_self, const double* __restrict__ d_other)
+{
+  const int r     = rows_long[blockIdx.x];
+  const double ds = d_self[r];
+  for (int k = off[r] + (int)threadIdx.x; k < off[r + 1]; k += kBlock) val[k] = val[k] * ds * d_other[idx[k]];
 }
 __global__ void __launch_bounds__(kBlock) k_scale_vectors(int n, int m, double* __restrict__ c,
                                                           double* __restrict__ lb,
@@ -2228,6 +2277,15 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz, 8));  // +8: the vector loads of the stream kernel may over-read
   TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz, 8));
   lap("alloc + upload A");
+  auto long_rows = [](int32_t rows, const int32_t* off) {
+    std::vector<int32_t> v;
+    for (int32_t r = 0; r < rows; ++r)
+      if (off[r + 1] - off[r] > kLongRow) v.push_back(r);
+    return v;
+  };
+  std::vector<int32_t> la = long_rows(m, a_offsets), lat;  // alive until the stream is synchronised at the end
+  ctx->a_nlong = (int)la.size();
+  if (ctx->a_nlong) TRY(upload_i32(ctx, &ctx->a_long, la.data(), la.size()));
   std::vector<int32_t> rba = build_row_blocks(m, a_offsets);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
@@ -2299,6 +2357,9 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
     TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
     TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
+    lat           = long_rows(n, at_offsets);
+    ctx->at_nlong = (int)lat.size();
+    if (ctx->at_nlong) TRY(upload_i32(ctx, &ctx->at_long, lat.data(), lat.size()));
     std::vector<int32_t> rbt = build_row_blocks(n, at_offsets);
     ctx->at_nb = (int)rbt.size() / 2 - 1;
     TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
@@ -2536,10 +2597,14 @@ int pdlpdev_scaling_compute(pdlpdev_ctx* ctx, int do_ruiz, int ruiz_iterations, 
   auto pass = [&](bool pow_mode, double e_row, double e_col) -> int {
     if (!pow_mode) {
       k_row_norm<false, false><<<grid_for(m), kBlock, 0, s>>>(m, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc, 1.0, ctx->tmp_m);
+      if (ctx->a_nlong) k_row_norm_long<false, false><<<ctx->a_nlong, kBlock, 0, s>>>(ctx->a_long, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc, 1.0, ctx->tmp_m);
       k_row_norm<true, false><<<grid_for(n), kBlock, 0, s>>>(n, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dr, ctx->dc, 1.0, ctx->tmp_n);
+      if (ctx->at_nlong) k_row_norm_long<true, false><<<ctx->at_nlong, kBlock, 0, s>>>(ctx->at_long, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dr, ctx->dc, 1.0, ctx->tmp_n);
     } else {
       k_row_norm<false, true><<<grid_for(m), kBlock, 0, s>>>(m, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc, e_row, ctx->tmp_m);
+      if (ctx->a_nlong) k_row_norm_long<false, true><<<ctx->a_nlong, kBlock, 0, s>>>(ctx->a_long, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc, e_row, ctx->tmp_m);
       k_row_norm<true, true><<<grid_for(n), kBlock, 0, s>>>(n, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dr, ctx->dc, e_col, ctx->tmp_n);
+      if (ctx->at_nlong) k_row_norm_long<true, true><<<ctx->at_nlong, kBlock, 0, s>>>(ctx->at_long, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dr, ctx->dc, e_col, ctx->tmp_n);
     }
     LAUNCH_CHECK();
     // row-block sharding: a column's norm is spread over the ranks
@@ -2562,7 +2627,9 @@ int pdlpdev_scale_problem(pdlpdev_ctx* ctx)
   if (ctx->scaled) return fail(-1, "problem already scaled");
   hipStream_t s = ctx->stream;
   k_scale_matrix<<<grid_for(ctx->m), kBlock, 0, s>>>(ctx->m, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc);
+  if (ctx->a_nlong) k_scale_matrix_long<<<ctx->a_nlong, kBlock, 0, s>>>(ctx->a_long, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->dr, ctx->dc);
   k_scale_matrix<<<grid_for(ctx->n), kBlock, 0, s>>>(ctx->n, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dc, ctx->dr);
+  if (ctx->at_nlong) k_scale_matrix_long<<<ctx->at_nlong, kBlock, 0, s>>>(ctx->at_long, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->dc, ctx->dr);
   k_scale_vectors<<<grid_for(std::max(ctx->m, ctx->n)), kBlock, 0, s>>>(ctx->n, ctx->m, ctx->c, ctx->lb, ctx->ub, ctx->dc, ctx->lo, ctx->hi, ctx->dr);
   LAUNCH_CHECK();
   ctx->scaled = true;
