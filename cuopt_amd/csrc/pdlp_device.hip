@@ -1837,10 +1837,17 @@ struct JagHost {
 };
 // open-addressing set of column indices with O(1) clear (a stamp per slot)
 struct ColumnSet {
-  std::vector<int32_t> key;
+  std::vector<int32_t> key, payload;
   std::vector<uint32_t> stamp;
   uint32_t now = 0, mask;
-  explicit ColumnSet(int capacity_log2) : key((size_t)1 << capacity_log2), stamp((size_t)1 << capacity_log2, 0), mask((1u << capacity_log2) - 1) {}
+  explicit ColumnSet(int capacity_log2)
+      : key((size_t)1 << capacity_log2), payload((size_t)1 << capacity_log2), stamp((size_t)1 << capacity_log2, 0), mask((1u << capacity_log2) - 1) {}
+  int32_t& at(int32_t c)  // payload of a column that is in the set
+  {
+    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+    while (key[h] != c || stamp[h] != now) h = (h + 1) & mask;
+    return payload[h];
+  }
   void clear() { ++now; }
   bool contains(int32_t c) const
   {
@@ -1862,6 +1869,14 @@ struct ColumnSet {
     return true;
   }
 };
+// one set per host thread and capacity (the tasks of a parallel_tasks call share their thread's)
+static ColumnSet& thread_column_set(int capacity_log2, int which)
+{
+  thread_local std::unique_ptr<ColumnSet> sets[2][2];
+  std::unique_ptr<ColumnSet>& p = sets[capacity_log2 == 16][which];
+  if (!p) p.reset(new ColumnSet(capacity_log2));
+  return *p;
+}
 // `mode`: 0 = use the layout when filling the LDS column sets costs at most half of the gathers they serve, 1 = always
 static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode)
 {
@@ -1906,7 +1921,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     std::vector<int32_t> cols;    // ... sorted distinct columns
     int64_t refs = 0, cost = 0;
   };
-  auto block_set = [&](int32_t r0, int32_t r1, std::vector<int32_t>& scratch) -> BlockSet {
+  auto block_set = [&](int32_t r0, int32_t r1, ColumnSet& set) -> BlockSet {
     BlockSet B;
     int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
     for (int32_t r = r0; r < r1; ++r) {
@@ -1920,12 +1935,12 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
       B.cost  = 1 + B.wlen / 16;
       return B;
     }
-    scratch.clear();
+    set.clear();
     for (int32_t r = r0; r < r1; ++r)
-      if (off[r + 1] - off[r] <= kLongRow) scratch.insert(scratch.end(), idx + off[r], idx + off[r + 1]);
-    std::sort(scratch.begin(), scratch.end());
-    scratch.erase(std::unique(scratch.begin(), scratch.end()), scratch.end());
-    B.cols = scratch;
+      if (off[r + 1] - off[r] <= kLongRow)
+        for (int32_t k = off[r]; k < off[r + 1]; ++k)
+          if (set.insert(idx[k])) B.cols.push_back(idx[k]);
+    std::sort(B.cols.begin(), B.cols.end());  // only the distinct columns (<= the LDS window) are sorted
     int64_t runs = 0;
     for (size_t i = 0; i < B.cols.size(); ++i) runs += i == 0 || B.cols[i] != B.cols[i - 1] + 1;
     B.cost = runs + (int64_t)B.cols.size() / 16;
@@ -1935,10 +1950,10 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     const int samples = (int)std::min<int64_t>(48, std::max<int64_t>(1, rows / brows));
     std::vector<int64_t> refs(samples, 0), cost(samples, 0);
     cuopt_amd::parallel_tasks(samples, [&](int t) {
-      ColumnSet set(waves == 16 ? 16 : 15);
-      std::vector<int32_t> scratch;
+      ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
       const int32_t first = (int32_t)((int64_t)rows * t / samples);
-      const BlockSet B    = block_set(first, block_end(set, first, rows), scratch);
+      const int32_t last  = block_end(set, first, rows);
+      const BlockSet B    = block_set(first, last, set);
       refs[t] = B.refs, cost[t] = B.cost;
     }, nnz);
     int64_t r = 0, c = 0;
@@ -1951,7 +1966,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
   std::vector<std::vector<int32_t>> cuts(nchunks);
   cuopt_amd::parallel_tasks(nchunks, [&](int t) {
-    ColumnSet set(waves == 16 ? 16 : 15);
+    ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
     const int32_t c0 = (int32_t)((int64_t)t * chunk_rows), c1 = (int32_t)std::min<int64_t>((int64_t)c0 + chunk_rows, rows);
     for (int32_t r = c0; r < c1;) cuts[t].push_back(r = block_end(set, r, c1));
   }, nnz);
@@ -1989,7 +2004,8 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   std::vector<int32_t> nlong(nblk, 0);
   std::vector<BlockSet> sets(nblk);
   cuopt_amd::parallel_tasks(nblk, [&](int b) {
-    std::vector<int32_t> order, scratch;
+    std::vector<int32_t> order;
+    ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
     const int32_t ns = sort_block(b, order);
     const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
     for (int32_t r = r0; r < r1; ++r) nlong[b] += off[r + 1] - off[r] > kLongRow;
@@ -2000,7 +2016,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
         gent[(size_t)b * waves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
       }
     }
-    sets[b] = block_set(r0, r1, scratch);
+    sets[b] = block_set(r0, r1, set);
   }, nnz);
   int64_t refs = 0, cost = 0;
   for (int b = 0; b < nblk; ++b) {
@@ -2025,10 +2041,15 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
     const BlockSet& B = sets[b];
     std::copy(B.cols.begin(), B.cols.end(), H.set_col.begin() + H.set_ptr[b]);
-    auto slot_of = [&](int32_t c) -> uint16_t {
-      if (B.wlen) return (uint16_t)(c - B.wbase);
-      return (uint16_t)(std::lower_bound(B.cols.begin(), B.cols.end(), c) - B.cols.begin());
-    };
+    ColumnSet& map = thread_column_set(waves == 16 ? 16 : 15, 1);  // column -> slot of a list-mode set
+    if (!B.wlen) {
+      map.clear();
+      for (size_t i = 0; i < B.cols.size(); ++i) {
+        map.insert(B.cols[i]);
+        map.at(B.cols[i]) = (int32_t)i;
+      }
+    }
+    auto slot_of = [&](int32_t c) -> uint16_t { return B.wlen ? (uint16_t)(c - B.wbase) : (uint16_t)map.at(c); };
     int32_t nl = H.lr_ptr[b];
     for (int32_t r = r0; r < r1; ++r)
       if (off[r + 1] - off[r] > kLongRow) H.lr_row[nl++] = r;
