@@ -1751,17 +1751,32 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   const char* target_env = getenv("CUOPT_AMD_PANEL_NNZ");
   const int64_t cap    = target_env ? std::max<int64_t>(2048, atoll(target_env)) : 60000;
   const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz + 511) / 512));
-  P.row0.push_back(0);
-  int32_t start = 0;
-  while (start < rows) {
-    int32_t end = start;
-    int64_t cnt = 0;
-    while (end < rows && end - start < kPanelMaxRows && cnt < target) {
-      cnt += off[end + 1] - off[end];
-      ++end;
+  // A panel takes rows while they fit under the target (a row above the target is a panel of its own): all panels run at
+  // once, so the LARGEST one sets the kernel time -- letting a panel overshoot by its last row made panels of 42 K nonzeros
+  // next to the average 22 K on the power-law LP (rows of up to 20 000 nonzeros) and cost 26 of its 117 us.  The target grows
+  // (proportionally first, then in 1 % steps) until the panels fit the 512 resident slots again.
+  auto cut = [&](int64_t tgt) {
+    P.row0.assign(1, 0);
+    int32_t start = 0;
+    while (start < rows) {
+      int32_t end = start;
+      int64_t cnt = 0;
+      while (end < rows && end - start < kPanelMaxRows) {
+        const int64_t len = off[end + 1] - off[end];
+        if (cnt > 0 && cnt + len > tgt) break;
+        cnt += len;
+        ++end;
+      }
+      P.row0.push_back(end);
+      start = end;
     }
-    P.row0.push_back(end);
-    start = end;
+  };
+  int64_t tgt = target;
+  cut(tgt);
+  for (int it = 0; it < 64 && (int)P.row0.size() - 1 > 512 && tgt < cap; ++it) {
+    const int64_t w = (int64_t)P.row0.size() - 1;
+    tgt = std::min<int64_t>(cap, it == 0 ? (int64_t)((double)tgt * (double)w / 512.0 * 1.002) + 1 : tgt + tgt / 100 + 1);
+    cut(tgt);
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S;
