@@ -195,6 +195,7 @@ struct pdlpdev_ctx {
     int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
     double* val   = nullptr;
   } pa, pat;
+  int cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   // rows of A / of A^T with more than kLongRow nonzeros (set-up kernels give each a workgroup instead of a lane)
   int32_t *a_long = nullptr, *at_long = nullptr;
   int a_nlong = 0, at_nlong = 0;
@@ -1893,7 +1894,7 @@ static ColumnSet& thread_column_set(int capacity_log2, int which)
   return *p;
 }
 // `mode`: 0 = use the layout when filling the LDS column sets costs at most half of the gathers they serve, 1 = always
-static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode)
+static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode, int cus)
 {
   JagHost H;
   const int64_t nnz = rows > 0 ? off[rows] : 0;
@@ -1910,13 +1911,14 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
     if (atoi(env) == 16) waves = 16;
   const int wcap = jag_window(waves), brows = waves * G;
+  const int slots = cus * (waves == 16 ? 1 : 2);  // workgroups resident at once: 80 KiB of LDS each (160 KiB with 16 waves)
   // A workgroup's rows: consecutive, at most `brows`, and as many as keep their DISTINCT columns within the LDS window
   // (rows longer than kLongRow do not count: they gather from global memory in workgroups of their own).  Greedy from
   // `first`; returns the end of the block.
-  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit) -> int32_t {
+  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit, int32_t row_cap) -> int32_t {
     set.clear();
     int32_t distinct = 0, r = first;
-    const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + brows, limit);
+    const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + row_cap, limit);
     for (; r < last; ++r) {
       const int32_t len = off[r + 1] - off[r];
       if (len > kLongRow) continue;
@@ -1967,7 +1969,7 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
     cuopt_amd::parallel_tasks(samples, [&](int t) {
       ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
       const int32_t first = (int32_t)((int64_t)rows * t / samples);
-      const int32_t last  = block_end(set, first, rows);
+      const int32_t last  = block_end(set, first, rows, brows);
       const BlockSet B    = block_set(first, last, set);
       refs[t] = B.refs, cost[t] = B.cost;
     }, nnz);
@@ -1979,14 +1981,32 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   // the partition: chunks of rows are cut independently (a chunk boundary is a block boundary), in parallel
   const int32_t chunk_rows = 8 * brows;
   const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
-  std::vector<std::vector<int32_t>> cuts(nchunks);
-  cuopt_amd::parallel_tasks(nchunks, [&](int t) {
-    ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
-    const int32_t c0 = (int32_t)((int64_t)t * chunk_rows), c1 = (int32_t)std::min<int64_t>((int64_t)c0 + chunk_rows, rows);
-    for (int32_t r = c0; r < c1;) cuts[t].push_back(r = block_end(set, r, c1));
-  }, nnz);
-  H.row0.push_back(0);
-  for (auto& v : cuts) H.row0.insert(H.row0.end(), v.begin(), v.end());
+  auto partition = [&](int32_t row_cap) {
+    std::vector<std::vector<int32_t>> cuts(nchunks);
+    cuopt_amd::parallel_tasks(nchunks, [&](int t) {
+      ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
+      const int32_t c0 = (int32_t)((int64_t)t * chunk_rows), c1 = (int32_t)std::min<int64_t>((int64_t)c0 + chunk_rows, rows);
+      for (int32_t r = c0; r < c1;) cuts[t].push_back(r = block_end(set, r, c1, row_cap));
+    }, nnz);
+    std::vector<int32_t> row0(1, 0);
+    for (auto& v : cuts) row0.insert(row0.end(), v.begin(), v.end());
+    return row0;
+  };
+  H.row0 = partition(brows);
+  // All workgroups of a round run at once (`slots` of them fit the chip) and the kernel lasts rounds x the largest block.  When
+  // the column sets cut the blocks short (block-angular LP: 672 blocks on 512 slots, the second round a third full), smaller
+  // blocks that fill the same number of rounds are strictly better: 2 x t(980 rows) instead of 2 x t(1490 rows).
+  if (slots > 0 && (int)H.row0.size() - 1 > slots) {
+    const int nb = (int)H.row0.size() - 1, rounds = (nb + slots - 1) / slots;
+    if ((double)nb < 0.9 * (double)rounds * (double)slots) {
+      int32_t cap = (int32_t)std::ceil((double)rows / (0.97 * (double)rounds * (double)slots));
+      cap         = std::max<int32_t>(64, (cap + 63) & ~63);  // whole passes of 64 rows
+      if (cap < brows) {
+        std::vector<int32_t> alt = partition(cap);
+        if (((int)alt.size() - 1 + slots - 1) / slots <= rounds) H.row0.swap(alt);
+      }
+    }
+  }
   const int nblk    = (int)H.row0.size() - 1;
   const int ngroups = nblk * waves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
   H.rows = rows, H.waves = waves, H.ngroups = ngroups, H.nblk = nblk;
@@ -2290,6 +2310,10 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   };
   pdlpdev_ctx* ctx = new pdlpdev_ctx();
   ctx->device      = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cus = cus;
+  }
   ctx->m = m, ctx->n = n, ctx->nnz = a_offsets[m];
   *out = ctx;
   {
@@ -2375,7 +2399,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     };
     lap("row blocks + vectors");
     if (try_jag) {
-      JagHost ja = build_jag(m, n, a_offsets, a_indices, mode == "jag" ? 1 : 0);
+      JagHost ja = build_jag(m, n, a_offsets, a_indices, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag A");
       TRY(upload_jag(ctx, &ctx->ja, ja, ctx->a_off, ctx->a_idx, ctx->a_val));
       lap("upload jag A");
@@ -2401,7 +2425,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
     lap("upload A^T");
     if (try_jag) {
-      JagHost jat = build_jag(n, m, at_offsets, at_indices, mode == "jag" ? 1 : 0);
+      JagHost jat = build_jag(n, m, at_offsets, at_indices, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag At");
       TRY(upload_jag(ctx, &ctx->jat, jat, ctx->at_off, ctx->at_idx, ctx->at_val));
       lap("upload jag At");

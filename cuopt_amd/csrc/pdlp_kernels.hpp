@@ -566,22 +566,25 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
     const int r  = J.lr_row[blk - J.nblk];
     const int k0 = J.off[r], k1 = J.off[r + 1];
     double part[1] = {0.0};
-    for (int k = k0 + (int)threadIdx.x; k < k1; k += 4 * (WAVES * 64)) {
-      double a[4];
-      int j[4];
+    // 16 entries per thread in flight: a row of up to 8192 nonzeros costs two dependent round trips (entries, then gathers),
+    // not two per 2048 -- these workgroups run behind the row blocks and their latency is the kernel's tail
+    constexpr int kLongU = 16;
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += kLongU * (WAVES * 64)) {
+      double a[kLongU];
+      int j[kLongU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kLongU; ++u) {
         a[u] = 0.0, j[u] = 0;
         if (k + u * (WAVES * 64) < k1) {
           a[u] = __builtin_nontemporal_load(J.csr_val + k + u * (WAVES * 64));
           j[u] = __builtin_nontemporal_load(J.idx + k + u * (WAVES * 64));
         }
       }
-      double xv[4];
+      double xv[kLongU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = k + u * (WAVES * 64) < k1 ? vec[j[u]] : 0.0;
+      for (int u = 0; u < kLongU; ++u) xv[u] = k + u * (WAVES * 64) < k1 ? vec[j[u]] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) part[0] = part[0] + a[u] * xv[u];
+      for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
     }
     block_reduce<SumOp, 1, WAVES>(part, xwin);
     if (threadIdx.x == 0) epi.row(r, part[0], acc);
