@@ -1905,8 +1905,9 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
-  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16) is 1-4 % faster on banded matrices but
-  // LOST on the block-angular A^T (78 -> 102 us) for a reason the counters did not show, so it is not chosen automatically.
+  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16: 16384 columns, one workgroup per CU) measured
+  // 1-3 % faster on the banded, block-angular and multi-band LPs with the column-set version of this layout -- inside the noise
+  // of two runs, so the default stays with the geometry every profile of this round was taken with.
   int waves = 8;
   if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
     if (atoi(env) == 16) waves = 16;
