@@ -2990,7 +2990,6 @@ static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ct
 static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
 static void launch_a_dual(pdlpdev_ctx* ctx)
 {
-  hipStream_t s = ctx->stream;
   if (ctx->ja.on)
     (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
   else if (ctx->pa.on)
@@ -3000,7 +2999,6 @@ static void launch_a_dual(pdlpdev_ctx* ctx)
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
-  hipStream_t s = ctx->stream;
   if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
@@ -3010,7 +3008,6 @@ static void launch_at_step(pdlpdev_ctx* ctx)
 }
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
-  hipStream_t s = ctx->stream;
   if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_cur, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else if (ctx->pat.on)
@@ -3021,7 +3018,6 @@ static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 // plain y = A x (transpose = 0) or y = A^T x through the layout the solver iterates with
 static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, double* out)
 {
-  hipStream_t s = ctx->stream;
   if (transpose) {
     if (ctx->jat.on)
       (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->jat.v, vec, out);
@@ -3046,7 +3042,6 @@ static void launch_decision(pdlpdev_ctx* ctx)
 // one PDHG attempt = 4 launches (single GPU) on ctx->stream
 static int enqueue_attempt(pdlpdev_ctx* ctx)
 {
-  hipStream_t s = ctx->stream;
   const int n = ctx->n;
   if (ctx->rsag) {
     // sliced primal: primal step on this rank's columns -> all-gather(xbar) -> local rows of A -> partial A^T y' ->
