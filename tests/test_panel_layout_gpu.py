@@ -251,7 +251,7 @@ def test_jagged_layout_with_hundreds_of_long_rows(waves, monkeypatch):
 @pytest.mark.parametrize("m,n,waves", [(66000, 1000, 8), (200000, 150000, 8), (200000, 150000, 16), (70001, 90001, 16),
                                        (800000, 300000, 8)])
 def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch):
-    """every group size of the jagged layout (64 / 128 / 256 rows per wave: rows >= 65536 / 196608 / 786432), both
+    """every group size of the jagged layout (64 / 128 / 256 rows per wave: forced below 196608 rows / rows >= 196608 / 786432), both
     geometries, rectangular matrices, a ragged last workgroup, empty rows, rows of exactly 127 / 128 / 129 nonzeros (the
     boundary between the left-to-right and the tree path) and a few rows of thousands"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
