@@ -133,7 +133,7 @@ def main():
     # additionally EVERY step is a major iteration while the step count is <= min_iteration_restart, pdlp.cu:1082-1084).
     # Whatever --steps / --warmup say, the timed region therefore (i) starts past that initial phase, on a major-
     # iteration boundary, with every hipGraph replay size instantiated, and (ii) covers a whole number of
-    # major-iteration periods: timed_steps = steps rounded up to a multiple of the period (at least five periods).  `steps` is reported as
+    # major-iteration periods: timed_steps = steps rounded up to a multiple of the period (at least five periods), (iii) below.  `steps` is reported as
     # given, `timed_steps` and `warmup_done` as run; ms_per_step = elapsed / timed_steps.
     solver = capi.Solver(p, mode=1, tol=0.0, device=local_rank, rank=rank, world=world, comm_id=comm_id)
     setup_s = solver.advance(0)["setup_seconds"]
@@ -145,6 +145,25 @@ def main():
     timed_steps = max((max(args.steps, 1) + period - 1) // period, 5) * period  # at least five periods: a stable clock
     solver.advance(pre)
     layout = dev.layout()
+    # ... and (iii) starts at the device's steady clocks: a GPU that sat idle while the LP was generated runs its first tens of
+    # milliseconds below them (measured: the same 200 timed steps gave 4.7 k it/s right after start-up and 5.7 k once warm), so
+    # untimed batches of five periods run until two consecutive batches agree within 2 % (at most 4 s).  Every rank takes the same
+    # decision: the batch times are max-reduced over the ranks first.
+    warm_rates, warm_wall = [], 0.0
+    while True:
+        dev.call("synchronize")
+        barrier()
+        tb = time.perf_counter()
+        solver.advance(5 * period)
+        dev.call("synchronize")
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - tb)
+        pre += 5 * period
+        warm_wall += dt
+        warm_rates.append(5 * period / dt)
+        steady = len(warm_rates) >= 3 and all(abs(warm_rates[-i] - warm_rates[-i - 1]) <= 0.02 * warm_rates[-i] for i in (1, 2))
+        if steady or warm_wall > 4.0 or len(warm_rates) >= 100:
+            break
     dev.call("synchronize")
     barrier()
     t0 = time.perf_counter()
@@ -249,7 +268,7 @@ def main():
         info = capi.device_info(local_rank)
         out = {
             "metric": "pdlp_iterations_per_sec", "value": round(its_per_s, 2), "unit": "iterations/s",
-            "n_gpus": world, "rccl_nranks": world if dist is not None else 0, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
+            "n_gpus": world, "rccl_nranks": world if dist is not None else 0, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre, "clock_warmup_batches": len(warm_rates),
             "ms_per_step": round(1e3 * elapsed / timed_steps, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic %s sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, longest row %d, CSR fp64/int32, "
