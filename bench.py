@@ -2,7 +2,11 @@
 """PDLP iterations/sec on the BASELINE.json workloads, MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|tiny|hard]
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1: one process per GPU over RCCL.  Either the caller launches them (`python -m torch.distributed.run --nproc-per-node N
+  ... bench.py --gpus N ...`: WORLD_SIZE / RANK / LOCAL_RANK in the environment) or plain `python bench.py --gpus N` starts
+  that launcher itself (127.0.0.1, a free port) and relays the one JSON line of rank 0; `--self-launch` forces the launcher
+  for N = 1 too (one RCCL rank: `rccl_nranks` 1).  More GPUs requested than visible: every rank stops with
+  "N GPUs requested, V visible" and the exit code is non-zero -- there is no fallback to fewer devices.
 
 A "step" is ONE PDLP iteration (one accepted PDHG step), including its amortised share of
 the major-iteration work (averages, 2 convergence evaluations, restart logic every 40 steps): the
@@ -69,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
+    ap.add_argument("--self-launch", action="store_true", help="go through the torch.distributed.run launcher also for one GPU")
     ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel", "jag", "timed"], help="CUOPT_AMD_SPMV_LAYOUT")
     args = ap.parse_args()
 
@@ -77,10 +82,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        # not under a launcher: start one process per GPU ourselves and relay rank 0's record
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        child = [a for a in sys.argv[1:] if a != "--self-launch"]
+        if args.gpus == 1 and "--force-comm" not in child:
+            child.append("--force-comm")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+        record = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if record:
+            os.write(record_fd, (record[-1] + "\n").encode())
+        sys.exit(r.returncode if r.returncode else (0 if record else 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
     dist = None
     if world > 1 or args.force_comm:
@@ -89,6 +109,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        visible = torch.cuda.device_count()
+        if visible < world:
+            # (after the launcher ran: every rank sees the same count and leaves; nobody waits in a rendezvous)
+            sys.exit("bench.py: %d GPUs requested, %d visible" % (world, visible))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from cuopt_amd import capi, synthetic
@@ -145,6 +169,7 @@ def main():
     timed_steps = max((max(args.steps, 1) + period - 1) // period, 5) * period  # at least five periods: a stable clock
     solver.advance(pre)
     layout = dev.layout()
+    dataflow = capi.lib.pdlpdev_shard_dataflow(dev.handle)  # read while the solver (and its device context) is alive
     # ... and (iii) starts at the device's steady clocks: a GPU that sat idle while the LP was generated runs its first tens of
     # milliseconds below them (measured: the same 200 timed steps gave 4.7 k it/s right after start-up and 5.7 k once warm), so
     # untimed batches of five periods run until two consecutive batches agree within 2 % (at most 4 s).  Every rank takes the same
@@ -277,7 +302,7 @@ def main():
                                       m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""),
                                       nnz, int(np.diff(p["offsets"]).max())),
                        "rows": m, "cols": n, "nnz": nnz,
-                       "parallelism": ("row-block x%d + RCCL %s" % (world, "reduce-scatter / all-gather (sliced primal)" if capi.lib.pdlpdev_shard_dataflow(dev.handle) == 2 else "all-reduce")) if world > 1 else "single GPU"},
+                       "parallelism": ("row-block x%d + RCCL %s" % (world, "reduce-scatter / all-gather (sliced primal)" if dataflow == 2 else "all-reduce")) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
             "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"],

@@ -240,6 +240,22 @@ struct pdlpdev_ctx {
   int slice = 0;               // entries per rank, a multiple of 16; slice * world >= n
   double* rs_buf = nullptr;    // slice + 8: this rank's part of the reduced A^T y'
   double* rs_scal = nullptr;   // ||dy||^2, interaction, ||dx||^2 partial sums of this rank -> all-reduced
+  // "owner computes" dataflow (CUOPT_AMD_SHARD_DATAFLOW=owner): on top of the sliced primal update a rank also holds ITS
+  // COLUMNS of A (rows [rank * slice, ...) of A^T over ALL rows of A), so that A^T y' of its slice is complete on the rank:
+  // all-gather(xbar slices) -> local rows of A -> y' -> all-gather(y' row blocks) -> local columns of A -> slice of A^T y'
+  // and of the step-size sums.  No partial products travel, nothing is reduced but three scalars, and every column is summed
+  // over all rows in row order exactly as on one GPU.
+  bool owner = false;
+  int ypad = 0;               // entries per rank in the gathered dual vector: the largest row block, a multiple of 16
+  double* ygather = nullptr;  // world * ypad: rank q's y' at [q * ypad, ...); also the gather vector of the column block
+  int32_t oc_rows = 0;        // columns of A this rank owns (= rows of the column block)
+  int64_t oc_nnz = 0;
+  int32_t *oc_off = nullptr, *oc_idx = nullptr, *oc_rb = nullptr, *oc_long = nullptr;
+  double* oc_val = nullptr;
+  int oc_nb = 0, oc_nlong = 0;
+  Panels poc;
+  Jag joc;
+  double* part_oc = nullptr;
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
   bool prof_armed = false;
@@ -589,6 +605,7 @@ struct DualEpilogue {
   double* __restrict__ sumy;
   double sigma, weight;
   bool pend;
+  double* __restrict__ copy = nullptr;  // sharded solves, owner-computes dataflow: y' also goes to this rank's slot of the gathered dual
   // the row's operands, separable from the arithmetic so that a layout can request them before its row sums are ready
   struct Ops {
     double y, lo, hi, sum;
@@ -602,6 +619,7 @@ struct DualEpilogue {
     const double up  = next + sigma * o.hi;
     next            = dmax(low, dmin(up, 0.0));
     yn[i]           = next;
+    if (copy) copy[i] = next;
     const double dy = next - yi;
     acc[0] += dy * dy;
     if (pend) sumy[i] = o.sum + weight * yi;
@@ -613,12 +631,12 @@ k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const int32_t* __restrict__ idx, const double* __restrict__ val,
               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
               double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part)
+              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0};
+                 ctl->pending_avg != 0, ycopy};
   csr_stream_block(nb, rb, off, idx, val, xbar, e, part);
 }
 
@@ -995,12 +1013,12 @@ static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
                double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part)
+               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0};
+                 ctl->pending_avg != 0, ycopy};
   panel_spmv_block(P, xbar, e, part);
 }
 __global__ void __launch_bounds__(kPanelThreads)
@@ -1019,12 +1037,12 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
              double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part)
+             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0};
+                 ctl->pending_avg != 0, ycopy};
   jag_block<decltype(e), WAVES>(J, xbar, e, part);
 }
 template <int WAVES>
@@ -2216,6 +2234,8 @@ static int sync_panel_values(pdlpdev_ctx* c)
   if (c->pat.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pat.perm, c->at_val, c->pat.val);
   if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->a_val, c->ja.val);
   if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->at_val, c->jat.val);
+  if (c->poc.on) k_permute<<<grid_for(c->oc_nnz), kBlock, 0, c->stream>>>(c->oc_nnz, c->poc.perm, c->oc_val, c->poc.val);
+  if (c->joc.on) k_permute<<<grid_for(c->joc.nent), kBlock, 0, c->stream>>>(c->joc.nent, c->joc.perm, c->oc_val, c->joc.val);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2514,12 +2534,14 @@ static int setup_dataflow(pdlpdev_ctx* ctx)
 {
   const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
   if (!env || std::string(env) == "allreduce") return 0;
-  if (std::string(env) != "rsag") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce or rsag");
-  if (ctx->world > 16) return fail(-1, "the sliced-primal dataflow supports up to 16 ranks");
+  const std::string flow = env;
+  if (flow != "rsag" && flow != "owner") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce, rsag or owner");
+  if (ctx->world > 16) return fail(-1, "the sliced-primal dataflows support up to 16 ranks");
   if (!ctx->soft && (!rccl::ReduceScatter || !rccl::AllGather)) return fail(-3, "RCCL: ncclReduceScatter / ncclAllGather missing");
   const int per = (ctx->n + ctx->world - 1) / ctx->world;
   ctx->slice    = (per + 15) & ~15;
-  ctx->rsag     = true;
+  ctx->rsag     = true;  // both keep the primal side in slices inside the attempt loop
+  ctx->owner    = flow == "owner";  // ... the column block arrives with pdlpdev_owner_setup
   TRY(dev_alloc(ctx, &ctx->rs_buf, (size_t)ctx->slice + 8));
   TRY(dev_alloc(ctx, &ctx->rs_scal, 8));
   return 0;
@@ -2627,6 +2649,93 @@ static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
     return 0;
   }
   RCCL_TRY(rccl::AllReduce(buf, buf, count, rccl::kFloat64, op, ctx->comm, ctx->stream));
+  return 0;
+}
+
+static inline int oc_partials(const pdlpdev_ctx* ctx) { return ctx->joc.on ? ctx->joc.v.nblk + ctx->joc.v.nlong : ctx->poc.on ? ctx->poc.v.W : ctx->oc_nb; }
+int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols)
+{
+  if (!ctx->owner) return fail(-1, "pdlpdev_owner_slice: the solver does not run the owner-computes dataflow");
+  const int64_t cs = (int64_t)ctx->rank * ctx->slice;
+  *col_begin       = (int32_t)std::min<int64_t>(cs, ctx->n);
+  *ncols           = (int32_t)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)ctx->n - cs));
+  return 0;
+}
+// The column block of the owner-computes dataflow: rows [col_begin, col_begin + ncols) of the GLOBAL A^T (column indices =
+// global row numbers of A, ascending: every column is then summed over the rows in the order one GPU uses), unscaled
+// values; row_bounds[world + 1] = the ranks' row blocks.  Call after pdlpdev_scale_problem: the values are scaled here with
+// this rank's D_c and the gathered D_r, by the expression the transposed copy of an unsharded solve goes through.
+int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx, const double* val, const int32_t* row_bounds)
+{
+  if (!ctx->owner) return fail(-1, "pdlpdev_owner_setup: the solver does not run the owner-computes dataflow");
+  if (!ctx->scaled) return fail(-1, "pdlpdev_owner_setup: call after pdlpdev_scale_problem");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int32_t cb = 0, nc = 0;
+  TRY(pdlpdev_owner_slice(ctx, &cb, &nc));
+  if (row_bounds[ctx->rank + 1] - row_bounds[ctx->rank] != ctx->m) return fail(-1, "pdlpdev_owner_setup: row bounds disagree with this rank's block");
+  int maxrows = 0;
+  for (int q = 0; q < ctx->world; ++q) maxrows = std::max(maxrows, row_bounds[q + 1] - row_bounds[q]);
+  ctx->ypad = (maxrows + 15) & ~15;
+  const int64_t gcols = (int64_t)ctx->world * ctx->ypad;
+  if (gcols >= ((int64_t)1 << 31)) return fail(-1, "pdlpdev_owner_setup: gathered dual too long");
+  const int64_t nnz = nc > 0 ? off[nc] : 0;
+  ctx->oc_rows = nc, ctx->oc_nnz = nnz;
+  // global row -> position in the gathered dual (rank q's rows at [q * ypad, ...))
+  std::vector<int32_t> ridx((size_t)std::max<int64_t>(nnz, 1));
+  {
+    std::vector<int32_t> shift(ctx->world);
+    for (int q = 0; q < ctx->world; ++q) shift[q] = q * ctx->ypad - row_bounds[q];
+    for (int32_t r = 0; r < nc; ++r) {
+      int q = 0;
+      for (int k = off[r]; k < off[r + 1]; ++k) {  // ascending rows: the owner only moves forward
+        while (idx[k] >= row_bounds[q + 1]) ++q;
+        ridx[k] = idx[k] + shift[q];
+      }
+    }
+  }
+  TRY(upload_i32(ctx, &ctx->oc_off, off, (size_t)nc + 1));
+  TRY(upload_i32(ctx, &ctx->oc_idx, ridx.data(), (size_t)nnz, 8));
+  TRY(upload_f64(ctx, &ctx->oc_val, val, (size_t)nnz, 8));
+  TRY(dev_alloc(ctx, &ctx->ygather, (size_t)gcols + kSlicePad));
+  std::vector<int32_t> longs;
+  for (int32_t r = 0; r < nc; ++r)
+    if (off[r + 1] - off[r] > kLongRow) longs.push_back(r);
+  ctx->oc_nlong = (int)longs.size();
+  if (ctx->oc_nlong) TRY(upload_i32(ctx, &ctx->oc_long, longs.data(), longs.size()));
+  std::vector<int32_t> rb = build_row_blocks(nc, off);
+  ctx->oc_nb = (int)rb.size() / 2 - 1;
+  TRY(upload_i32(ctx, &ctx->oc_rb, rb.data(), rb.size()));
+  // scaling: D_r of every rank's rows in the gathered layout (ygather doubles as the staging buffer), then (val * D_c[j]) * D_r[i]
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->ygather + (size_t)ctx->rank * ctx->ypad, ctx->dr, (size_t)ctx->m * sizeof(double), hipMemcpyDeviceToDevice, s));
+  TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
+  k_scale_matrix<<<grid_for(nc), kBlock, 0, s>>>(nc, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->dc + cb, ctx->ygather);
+  if (ctx->oc_nlong) k_scale_matrix_long<<<ctx->oc_nlong, kBlock, 0, s>>>(ctx->oc_long, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->dc + cb, ctx->ygather);
+  HIP_TRY(hipGetLastError());
+  // layouts, by the rules of the two other matrices (timed mode counts as auto here)
+  {
+    const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
+    std::string mode     = mode_env ? mode_env : "auto";
+    if (mode == "timed") mode = "auto";
+    const char* slab_env     = getenv("CUOPT_AMD_SLAB_BYTES");
+    const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
+    const char* ws_env       = getenv("CUOPT_AMD_PANEL_WS_BYTES");
+    const int64_t ws_limit   = ws_env ? atoll(ws_env) : kPanelWorkingSetBytes;
+    if (nc > 0 && (mode == "auto" || mode == "jag")) {
+      JagHost j = build_jag(nc, (int32_t)gcols, off, ridx.data(), mode == "jag" ? 1 : 0, ctx->cus);
+      TRY(upload_jag(ctx, &ctx->joc, j, ctx->oc_off, ctx->oc_idx, ctx->oc_val));
+    }
+    const bool panels = mode == "panel" || (mode == "auto" && gcols * 8 > ws_limit && gather_working_set(nc, (int32_t)gcols, off, ridx.data()) > ws_limit);
+    if (nc > 0 && !ctx->joc.on && panels) {
+      PanelHost h = build_panels(nc, (int32_t)gcols, off, ridx.data(), slab_bytes, true);
+      TRY(upload_panels(ctx, &ctx->poc, h));
+    }
+  }
+  TRY(dev_alloc(ctx, &ctx->part_oc, (size_t)8 * std::max(oc_partials(ctx), 1)));
+  if (ctx->poc.on) k_permute<<<grid_for(ctx->oc_nnz), kBlock, 0, s>>>(ctx->oc_nnz, ctx->poc.perm, ctx->oc_val, ctx->poc.val);
+  if (ctx->joc.on) k_permute<<<grid_for(ctx->joc.nent), kBlock, 0, s>>>(ctx->joc.nent, ctx->joc.perm, ctx->oc_val, ctx->joc.val);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));  // the host arrays are the caller's
   return 0;
 }
 
@@ -2988,14 +3097,14 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
 static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
 static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
-static void launch_a_dual(pdlpdev_ctx* ctx)
+static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr)
 {
   if (ctx->ja.on)
-    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
   else if (ctx->pa.on)
-    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
   else
-    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a);
+    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
@@ -3039,10 +3148,43 @@ static void launch_decision(pdlpdev_ctx* ctx)
   launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at, step_partials(ctx), nullptr, ctx->sp);
 }
 
+// owner-computes dataflow: A^T y' of this rank's columns from the gathered y' (complete sums) + the step statistics of the slice
+static void launch_oc_step(pdlpdev_ctx* ctx)
+{
+  const size_t cs = (size_t)ctx->rank * ctx->slice;
+  double *x0 = ctx->x[0] + cs, *x1 = ctx->x[1] + cs, *t0 = ctx->aty[0] + cs, *t1 = ctx->aty[1] + cs;
+  const double* yg = ctx->ygather;  // the trial dual of every rank, whichever ping-pong buffer it lives in
+  if (ctx->joc.on)
+    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->joc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
+  else if (ctx->poc.on)
+    launch_k(ctx, k_panel_at_step, ctx->poc.v.W, kPanelThreads, 0, ctx->poc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
+  else
+    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->oc_nb), kBlock, 0, ctx->oc_nb, ctx->oc_rb, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
+}
+
 // one PDHG attempt = 4 launches (single GPU) on ctx->stream
 static int enqueue_attempt(pdlpdev_ctx* ctx)
 {
   const int n = ctx->n;
+  if (ctx->owner) {
+    if (!ctx->oc_off) return fail(-1, "owner-computes dataflow: pdlpdev_owner_setup was not called");
+    const size_t cs = (size_t)ctx->rank * ctx->slice;
+    const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
+    launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs);
+    LAUNCH_CHECK();
+    TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
+    launch_a_dual(ctx, ctx->ygather + (size_t)ctx->rank * ctx->ypad);
+    LAUNCH_CHECK();
+    TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
+    launch_oc_step(ctx);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
+    LAUNCH_CHECK();
+    TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
+    launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
+    LAUNCH_CHECK();
+    return 0;
+  }
   if (ctx->rsag) {
     // sliced primal: primal step on this rank's columns -> all-gather(xbar) -> local rows of A -> partial A^T y' ->
     // reduce-scatter -> this rank's columns of A^T y' and of the step-size sums -> ONE 3-scalar all-reduce -> the same
@@ -3732,7 +3874,7 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
   return 0;
 }
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
-int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->rsag ? 2 : 1; }
+int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->owner ? 3 : ctx->rsag ? 2 : 1; }
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column

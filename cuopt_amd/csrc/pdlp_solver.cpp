@@ -854,6 +854,30 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   lap("scaling_compute");
   DEV(pdlpdev_scale_problem(s->dev));
   lap("scale_problem");
+  if (world > 1 && pdlpdev_shard_dataflow(s->dev) == 3) {
+    // owner-computes dataflow: this rank's columns of A over ALL rows (rows of the global A^T), cut from the caller's CSR
+    int32_t cb = 0, nc = 0;
+    DEV(pdlpdev_owner_slice(s->dev, &cb, &nc));
+    std::vector<int32_t> coff((size_t)nc + 1, 0);
+    const int64_t nnz_g = lp->offsets[m];
+    for (int64_t k = 0; k < nnz_g; ++k) {
+      const int32_t j = lp->indices[k] - cb;
+      if (j >= 0 && j < nc) ++coff[j + 1];
+    }
+    for (int32_t j = 0; j < nc; ++j) coff[j + 1] += coff[j];
+    std::vector<int32_t> cidx((size_t)std::max<int32_t>(coff[nc], 1)), cur(coff.begin(), coff.end() - 1);
+    std::vector<double> cval((size_t)std::max<int32_t>(coff[nc], 1));
+    for (int32_t i = 0; i < m; ++i)  // rows ascending: every column lists its rows in the order an unsharded solve sums them
+      for (int32_t k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k) {
+        const int32_t j = lp->indices[k] - cb;
+        if (j >= 0 && j < nc) {
+          const int32_t p = cur[j]++;
+          cidx[p] = i, cval[p] = lp->values[k];
+        }
+      }
+    DEV(pdlpdev_owner_setup(s->dev, coff.data(), cidx.data(), cval.data(), bounds.data()));
+    lap("owner-computes column block");
+  }
   if (!hyper->compute_initial_step_size_before_scaling) { int rc = initial_step_size(); if (rc) return rc; }
   if (!hyper->compute_initial_primal_weight_before_scaling) { int rc = initial_primal_weight(); if (rc) return rc; }
   s->computed_step = step, s->computed_weight = weight;

@@ -292,10 +292,18 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
 int pdlpdev_synchronize(pdlpdev_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
-/* sharded solves: 0 = not sharded, 1 = replicated primal update behind one all-reduce(n + 1) per attempt (default),
+/* sharded solves: 0 = not sharded, 1 = replicated primal update behind one all-reduce(n + 1) per attempt,
  * 2 = sliced primal update: reduce-scatter(A^T y' partials) + all-gather(xbar) + a 3-scalar all-reduce
- * (CUOPT_AMD_SHARD_DATAFLOW=rsag) */
+ * (CUOPT_AMD_SHARD_DATAFLOW=rsag), 3 = owner computes: the rank also holds its COLUMNS of A, all-gather(xbar slices) +
+ * all-gather(y' row blocks) + a 3-scalar all-reduce, no partial products on the wire (CUOPT_AMD_SHARD_DATAFLOW=owner) */
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx);
+/* owner-computes dataflow: the columns [*col_begin, *col_begin + *ncols) of A this rank owns ... */
+int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols);
+/* ... and their nonzeros over ALL rows of A: rows [col_begin, col_begin + ncols) of the global A^T as CSR (indices = global
+ * row numbers, ascending; UNSCALED values; offsets start at 0), row_bounds[world + 1] = the ranks' row blocks
+ * (cuoptamd_partition_rows).  After pdlpdev_scale_problem, before the first pdlpdev_run. */
+int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* offsets, const int32_t* indices, const double* values,
+                        const int32_t* row_bounds);
 /* SpMV layout actually in use: out = {A: layout, workgroups, detail, A^T: layout, workgroups, detail}; layout 0 = CSR stream,
  * 1 = slab-major row panels (detail: slabs), 2 = small LP whose attempt batches run inside ONE resident workgroup
  * (CUOPT_AMD_SMALL=0/1 overrides), 3 = sorted jagged rows with LDS column sets (detail: percent of the global gathers the

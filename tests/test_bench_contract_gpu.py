@@ -32,3 +32,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == d["unit"]
     assert d["value"] > cpu["value"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` needs no wrapper: it starts torch.distributed.run itself and relays rank 0's record.  With one
+    GPU the launcher path is forced by --self-launch (one RCCL rank); asking for more GPUs than the box has ends, AFTER the
+    launcher ran, in "N GPUs requested, V visible" and a non-zero exit code."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--workload", "tiny", "--steps", "20",
+                        "--warmup", "5", "--no-cpu-baseline", "--no-convergence-run"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_nranks"] == 1 and d["value"] > 0
+    from cuopt_amd import capi
+    visible = capi.device_count()
+    if visible < 16:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(visible + 1), "--workload", "tiny"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert r.returncode != 0 and not r.stdout.strip()
+        assert "%d GPUs requested, %d visible" % (visible + 1, visible) in r.stderr

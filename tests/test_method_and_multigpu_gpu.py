@@ -90,7 +90,7 @@ def _check_gathered_dual(p, r):
     assert all(np.any(r["y"][a:b] != 0.0) for a, b in zip(bounds[:-1], bounds[1:]))
 
 
-@pytest.mark.parametrize("dataflow", ["allreduce", "rsag"])
+@pytest.mark.parametrize("dataflow", ["allreduce", "rsag", "owner"])
 @pytest.mark.parametrize("world", [2, 4])
 def test_cuoptsolve_shards_over_gpus_through_the_in_process_communicator(world, dataflow, monkeypatch):
     """CUOPT_AMD_NUM_GPUS behind cuOptSolve; the in-process communicator stands in for RCCL on this one-GPU box; both sharded
@@ -118,7 +118,7 @@ def test_more_gpus_than_visible_is_a_loud_error(monkeypatch):
         assert r["return_code"] == capi.CUOPT_RUNTIME_ERROR and "visible" in r["error_string"]
 
 
-@pytest.mark.parametrize("dataflow", ["allreduce", "rsag"])
+@pytest.mark.parametrize("dataflow", ["allreduce", "rsag", "owner"])
 @pytest.mark.skipif(capi.device_count() < 2, reason="needs two GPUs: RCCL with two ranks in one process")
 def test_rccl_two_ranks_in_one_process(dataflow, monkeypatch):
     monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)

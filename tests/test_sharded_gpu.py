@@ -14,11 +14,12 @@ from cuopt_amd import capi, synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["allreduce", "rsag"])
+@pytest.fixture(autouse=True, params=["allreduce", "rsag", "owner"])
 def dataflow(request, monkeypatch):
-    """every test of this file runs through both sharded dataflows: the replicated primal update behind ONE all-reduce(n + 1) per
-    attempt, and the sliced primal update (reduce-scatter of the A^T y' partials -> this rank's columns -> all-gather of xbar,
-    plus one 3-scalar all-reduce: CUOPT_AMD_SHARD_DATAFLOW=rsag)"""
+    """every test of this file runs through the three sharded dataflows: the replicated primal update behind ONE all-reduce(n + 1)
+    per attempt, the sliced primal update (reduce-scatter of the A^T y' partials -> this rank's columns -> all-gather of xbar,
+    plus one 3-scalar all-reduce: CUOPT_AMD_SHARD_DATAFLOW=rsag), and owner-computes (the rank also holds its columns of A:
+    all-gather of xbar slices, all-gather of y' row blocks, complete column sums on the owner: CUOPT_AMD_SHARD_DATAFLOW=owner)"""
     monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", request.param)
     return request.param
 
@@ -31,7 +32,7 @@ def run_sharded(p, world, **kw):
         try:
             s = capi.Solver(p, rank=rank, world=world, comm_id=cid, **kw)
             import os
-            assert capi.lib.pdlpdev_shard_dataflow(s.device.handle) == {"allreduce": 1, "rsag": 2}[os.environ["CUOPT_AMD_SHARD_DATAFLOW"]]
+            assert capi.lib.pdlpdev_shard_dataflow(s.device.handle) == {"allreduce": 1, "rsag": 2, "owner": 3}[os.environ["CUOPT_AMD_SHARD_DATAFLOW"]]
             r = s.advance()
             x, y, rc = s.solution()
             out[rank] = (r, x, y, s.row_range())
@@ -212,18 +213,21 @@ def test_sharded_solve_through_the_other_layouts(layout, monkeypatch):
     assert abs(r0["primal_objective"] - single["primal_objective"]) <= 2e-4 * scale
 
 
-def test_both_dataflows_walk_the_same_path(monkeypatch):
-    """the two dataflows differ only in how the three step-size sums are grouped: same decisions over the first iterations, same
-    optimum; and a world whose slices do not divide n (3 ranks, n = 5003: slices of 1680, the last one short)"""
+def test_all_dataflows_walk_the_same_path(monkeypatch):
+    """the dataflows differ only in how the three step-size sums (and, for the two that reduce partial products, the column sums)
+    are grouped: same decisions over the first iterations, same optimum; and a world whose slices do not divide n (3 ranks,
+    n = 5003: slices of 1680, the last one short)"""
     p = synthetic.generate(6000, 5003, 8, seed=67)
     res = {}
-    for flow in ("allreduce", "rsag"):
+    for flow in ("allreduce", "rsag", "owner"):
         monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", flow)
         res[flow] = (run_sharded(p, 3, tol=0.0, iteration_limit=40), run_sharded(p, 3, tol=1e-6))
-    a, b = res["allreduce"], res["rsag"]
-    assert (a[0][0][0]["steps_taken"], a[0][0][0]["attempted_steps"]) == (b[0][0][0]["steps_taken"], b[0][0][0]["attempted_steps"])
-    np.testing.assert_allclose(a[0][0][1], b[0][0][1], rtol=1e-9, atol=1e-12)
-    for rank in range(3):
-        np.testing.assert_array_equal(b[0][rank][1], b[0][0][1])  # replicated again outside the loop
-    assert a[1][0][0]["status_name"] == b[1][0][0]["status_name"] == "Optimal"
-    assert abs(a[1][0][0]["primal_objective"] - b[1][0][0]["primal_objective"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+    a = res["allreduce"]
+    for flow in ("rsag", "owner"):
+        b = res[flow]
+        assert (a[0][0][0]["steps_taken"], a[0][0][0]["attempted_steps"]) == (b[0][0][0]["steps_taken"], b[0][0][0]["attempted_steps"])
+        np.testing.assert_allclose(a[0][0][1], b[0][0][1], rtol=1e-9, atol=1e-12)
+        for rank in range(3):
+            np.testing.assert_array_equal(b[0][rank][1], b[0][0][1])  # replicated again outside the loop
+        assert a[1][0][0]["status_name"] == b[1][0][0]["status_name"] == "Optimal"
+        assert abs(a[1][0][0]["primal_objective"] - b[1][0][0]["primal_objective"]) <= 2e-5 * (1 + abs(p["objective_star"]))
