@@ -131,14 +131,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    comm_id = None
-    if dist is not None:
+    def fresh_comm_id():
+        """an RCCL unique id bootstraps ONE communicator per rank, and the library destroys it with the last solver that
+        uses it: every solver of this script gets its own id (rank 0 draws, everybody receives)"""
+        if dist is None:
+            return None
         import torch
         buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(buf, 0)
-        comm_id = bytes(buf.cpu().numpy().tobytes())
+        return bytes(buf.cpu().numpy().tobytes())
+
+    comm_id = fresh_comm_id()
 
     structured = args.workload in ("staircase", "block_angular", "powerlaw", "multiband")
     if args.workload == "hard":
@@ -170,6 +175,7 @@ def main():
     solver.advance(pre)
     layout = dev.layout()
     dataflow = capi.lib.pdlpdev_shard_dataflow(dev.handle)  # read while the solver (and its device context) is alive
+    transport = ", direct peer stores" if world > 1 and capi.lib.pdlpdev_shard_transport(dev.handle) == 1 else ""
     # ... and (iii) starts at the device's steady clocks: a GPU that sat idle while the LP was generated runs its first tens of
     # milliseconds below them (measured: the same 200 timed steps gave 4.7 k it/s right after start-up and 5.7 k once warm), so
     # untimed batches of five periods run until two consecutive batches agree within 2 % (at most 4 s).  Every rank takes the same
@@ -252,7 +258,7 @@ def main():
     if not args.no_convergence_run:
         barrier()
         t0 = time.perf_counter()
-        s2 = capi.Solver(p, mode=1, device=local_rank, rank=rank, world=world, comm_id=comm_id)
+        s2 = capi.Solver(p, mode=1, device=local_rank, rank=rank, world=world, comm_id=fresh_comm_id())
         rr = s2.advance()
         wall = max_over_ranks(time.perf_counter() - t0)
         conv = dict(status=rr["status_name"], iterations=rr["steps_taken"], wall_s=round(wall, 4),
@@ -302,7 +308,8 @@ def main():
                                       m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""),
                                       nnz, int(np.diff(p["offsets"]).max())),
                        "rows": m, "cols": n, "nnz": nnz,
-                       "parallelism": ("row-block x%d + RCCL %s" % (world, "reduce-scatter / all-gather (sliced primal)" if dataflow == 2 else "all-reduce")) if world > 1 else "single GPU"},
+                       "parallelism": ("row-block x%d + RCCL %s" % (world, {1: "all-reduce (replicated primal)", 2: "reduce-scatter / all-gather (sliced primal)",
+                                                                       3: "owner computes: all-gather(xbar) + all-gather(y'), rows and columns of A per rank"}.get(dataflow, "?") + transport)) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
             "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"],

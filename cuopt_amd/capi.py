@@ -282,6 +282,7 @@ _proto("pdlpdev_time_kernel", c_int, c_void_p, c_int, c_int, P(c_double))
 _proto("pdlpdev_synchronize", c_int, c_void_p)
 _proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
 _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
+_proto("pdlpdev_shard_transport", c_int, c_void_p)
 _proto("pdlpdev_layout_info", c_int, c_void_p, c_void_p)
 
 # ids of pdlp_device.h

@@ -9,6 +9,7 @@
 #include <utility>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <mutex>
 #include <math.h>
 #include <stdarg.h>
@@ -60,6 +61,7 @@ static void* lib;
 static int (*GetUniqueId)(unique_id*);
 static int (*CommInitRank)(comm_t*, int, unique_id, int);
 static int (*CommDestroy)(comm_t);
+static int (*CommAbort)(comm_t);
 static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
 static int (*ReduceScatter)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
 static int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
@@ -78,6 +80,7 @@ static int load()
   *(void**)&GetUniqueId    = dlsym(lib, "ncclGetUniqueId");
   *(void**)&CommInitRank   = dlsym(lib, "ncclCommInitRank");
   *(void**)&CommDestroy    = dlsym(lib, "ncclCommDestroy");
+  *(void**)&CommAbort      = dlsym(lib, "ncclCommAbort");
   *(void**)&AllReduce      = dlsym(lib, "ncclAllReduce");
   *(void**)&ReduceScatter  = dlsym(lib, "ncclReduceScatter");
   *(void**)&AllGather      = dlsym(lib, "ncclAllGather");
@@ -96,6 +99,32 @@ static int load()
   } while (0)
 
 
+// RCCL communicators of this process: one per (unique id, rank), shared by the solvers created with the same pair while
+// any of them is alive (reference count); the last solver to go destroys it -- a unique id bootstraps exactly one communicator
+// per rank, so a caller that creates a second solver after the first one is gone draws a new id.
+namespace comm_cache {
+struct Entry {
+  rccl::comm_t comm;
+  int refs;
+  bool aborted = false;
+};
+static std::mutex mu;
+static std::map<std::string, Entry> map;
+static void release(const std::string& key)
+{
+  rccl::comm_t dead = nullptr;
+  bool aborted      = false;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = map.find(key);
+    if (it == map.end() || --it->second.refs > 0) return;
+    dead = it->second.comm, aborted = it->second.aborted;
+    map.erase(it);
+  }
+  if (dead && !aborted && rccl::CommDestroy) (void)rccl::CommDestroy(dead);  // (ncclCommAbort already freed an aborted one)
+}
+}  // namespace comm_cache
+
 // ================================================================================================
 // in-process "soft" communicator (verification of the sharded path at world > 1 on one GPU)
 // ================================================================================================
@@ -108,22 +137,37 @@ struct Comm {
   std::mutex mu;
   std::condition_variable cv;
   int arrived = 0, generation = 0;
+  int refs = 0;                  // solvers attached (the last one to leave frees the communicator)
+  bool aborted = false;          // a rank failed: every barrier returns false from now on, nobody waits for the missing rank
   std::vector<double*> bufs;     // this round's buffer of every rank
   std::vector<double*> scratch;  // per-rank result staging
   std::vector<size_t> scratch_size;
-  void barrier()
+  std::vector<void*> p2p_base;   // direct-peer transport: every rank's landing block (same device, same process)
+  bool barrier()
   {
     std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
     const int gen = generation;
     if (++arrived == world) {
       arrived = 0;
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return gen != generation; });
+      cv.wait(lk, [&] { return gen != generation || aborted; });
     }
+    return !aborted;
+  }
+  void abort()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
   }
 };
+#define SOFT_BARRIER(c)                                                                                   \
+  do {                                                                                                    \
+    if (!(c)->barrier()) return fail(-6, "in-process communicator: another rank failed, solve abandoned"); \
+  } while (0)
 struct Peers {
   const double* p[16];
 };
@@ -173,6 +217,86 @@ struct Range {
   }
 };
 }  // namespace roctx
+
+// ================================================================================================
+// direct peer transport (owner-computes dataflow): push / pull kernels
+// ================================================================================================
+namespace p2pdev {
+struct Peers {
+  char* base[16];
+};
+constexpr int kKinds = 3;  // exchanges per attempt: xbar slices, y' row blocks, step-size scalars
+__device__ __forceinline__ bool active(const pdlpdev_ctl* ctl) { return ctl->error == 0 && ctl->steps_taken < ctl->target_steps; }
+
+// this rank's `len` doubles -> offset `dst_off` (bytes) + slot of every rank's landing block; then, once every workgroup's
+// stores are out (system-scope fence + ticket), the last workgroup raises this rank's flag of exchange `kind` in every block.
+__global__ void __launch_bounds__(256) k_push(const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ src, int len, Peers P, int world,
+                                              int rank, size_t dst_off, size_t flag_off, int kind, unsigned long long* __restrict__ epoch,
+                                              unsigned* __restrict__ ticket)
+{
+  if (!active(ctl)) return;
+  for (int q = 0; q < world; ++q) {
+    double* __restrict__ dst = reinterpret_cast<double*>(P.base[q] + dst_off);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  __shared__ bool last;
+  if (threadIdx.x == 0) last = atomicAdd(&ticket[kind], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence_system();
+  if (threadIdx.x == 0) {
+    ticket[kind] = 0;
+    epoch[kind] += 1;
+  }
+  __syncthreads();
+  const unsigned long long e = epoch[kind];
+  if ((int)threadIdx.x < world) {
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(P.base[threadIdx.x] + flag_off) + (size_t)kind * world + rank;
+    __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles).  Every
+// workgroup polls for itself (local memory, one load per rank per poll); patience is bounded: a peer that never arrives sets
+// the step error and the fault flag instead of hanging the device.
+__global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ ctl, double* __restrict__ dst, const double* __restrict__ land, int count,
+                                              const unsigned long long* __restrict__ flags, int world, int kind,
+                                              const unsigned long long* __restrict__ epoch, int* __restrict__ fault)
+{
+  if (!active(ctl)) return;
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
+    const unsigned long long want = epoch[kind];
+    const unsigned long long* f   = flags + (size_t)kind * world + threadIdx.x;
+    const unsigned long long t0   = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 500000000ull) {  // 5 s at 100 MHz
+        ok = 0;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (!ok) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
+    return;
+  }
+  __threadfence_system();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(land + i);
+}
+// the three step-size sums of the attempt from every rank's landed scalars, added up in rank order: the same bits on every rank
+__global__ void k_sum_scalars(const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ landed, int world, double* __restrict__ out)
+{
+  if (!active(ctl) || threadIdx.x >= 3) return;
+  double acc = 0.0;
+  for (int q = 0; q < world; ++q) acc += landed[4 * q + threadIdx.x];
+  out[threadIdx.x] = acc;
+}
+}  // namespace p2pdev
 
 // ================================================================================================
 // context
@@ -231,6 +355,7 @@ struct pdlpdev_ctx {
   // multi-GPU
   rccl::comm_t comm = nullptr;  // non-null also marks "sharded mode" when the soft communicator is used
   softcomm::Comm* soft = nullptr;
+  std::string comm_key;  // RCCL: this solver's entry of the communicator cache
   int rank = 0, world = 1;
   double* ar_buf = nullptr;  // n + pad doubles: A^T y partial + packed scalars
   // "sliced primal" dataflow of a sharded solve (CUOPT_AMD_SHARD_DATAFLOW=rsag): inside the attempt loop a rank updates only
@@ -256,6 +381,23 @@ struct pdlpdev_ctx {
   Panels poc;
   Jag joc;
   double* part_oc = nullptr;
+  // direct peer transport of the owner-computes dataflow (CUOPT_AMD_SHARD_TRANSPORT=p2p): every rank owns one fine-grained
+  // LANDING block [xbar of all ranks | y' of all ranks | 4 step-size scalars per rank | 3 * world epoch flags]; a producer
+  // stores its slice into every rank's block (peer-mapped: same process -> the pointer itself after
+  // hipDeviceEnablePeerAccess, other process -> hipIpcOpenMemHandle) and then raises its flag there; a consumer waits for the
+  // world flags of the exchange, then copies the landed data into its ordinary vectors.  No collective call, no host between
+  // the kernels of an attempt -> the attempt graph replays as on one GPU.
+  struct P2P {
+    bool on = false;
+    char* base = nullptr;            // this rank's landing block
+    size_t bytes = 0;
+    size_t off_x = 0, off_y = 0, off_s = 0, off_f = 0;  // byte offsets inside every rank's block
+    p2pdev::Peers peers{};           // base of every rank's block as THIS process addresses it
+    std::vector<void*> opened;       // hipIpcOpenMemHandle mappings to close
+    unsigned long long* epoch = nullptr;  // device: epochs of the three exchanges (xbar, y', scalars) as this rank counts them
+    unsigned* ticket = nullptr;      // device: last-workgroup tickets of the push kernels
+    int* fault = nullptr;            // device: set when a wait ran out of patience (peer died)
+  } p2p;
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
   bool prof_armed = false;
@@ -2499,6 +2641,9 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);
+  if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
+  if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
   for (void* p : ctx->allocs) (void)hipFree(p);
   const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk;
   if (!(whole && give_recycled(Recycled{ctx->device, ctx->stream, ctx->scal_h, ctx->first_chunk}))) {
@@ -2529,7 +2674,7 @@ int pdlpdev_softcomm_create(int world, uint8_t id[128])
   memcpy(id + 8, &c, sizeof(c));
   return 0;
 }
-// CUOPT_AMD_SHARD_DATAFLOW = allreduce (default) | rsag : see the `rsag` fields of the context
+// CUOPT_AMD_SHARD_DATAFLOW = allreduce (default) | rsag | owner : see the `rsag` / `owner` fields of the context
 static int setup_dataflow(pdlpdev_ctx* ctx)
 {
   const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
@@ -2543,7 +2688,7 @@ static int setup_dataflow(pdlpdev_ctx* ctx)
   ctx->rsag     = true;  // both keep the primal side in slices inside the attempt loop
   ctx->owner    = flow == "owner";  // ... the column block arrives with pdlpdev_owner_setup
   TRY(dev_alloc(ctx, &ctx->rs_buf, (size_t)ctx->slice + 8));
-  TRY(dev_alloc(ctx, &ctx->rs_scal, 8));
+  TRY(dev_alloc(ctx, &ctx->rs_scal, 8 + 4 * 16));  // [0..3) this rank's sums, [4..7) the ranks' sums, [8..) landed scalars (p2p)
   return 0;
 }
 int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128])
@@ -2552,6 +2697,10 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
     softcomm::Comm* c = nullptr;
     memcpy(&c, id + 8, sizeof(c));
     if (!c || c->world != world) return fail(-1, "soft communicator: world mismatch");
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      c->refs += 1;
+    }
     ctx->soft = c;
     ctx->comm = reinterpret_cast<rccl::comm_t>(c);  // marks sharded mode; never passed to RCCL
     ctx->rank = rank, ctx->world = world;
@@ -2563,26 +2712,43 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
   // makes two per process -- share it.  The ranks of a single-process sharded solve (cuoptamd_solve_sharded: one host
   // thread per device) each get their own; ncclCommInitRank blocks until every rank has joined, so it runs outside the
   // lock.  Communicators live until process exit.
-  static std::mutex cache_mutex;
-  static std::map<std::string, rccl::comm_t> cache;
   std::string key((const char*)id, 128);
   key.append((const char*)&rank, sizeof(rank));
   rccl::comm_t comm = nullptr;
   {
-    std::lock_guard<std::mutex> lock(cache_mutex);
-    auto it = cache.find(key);
-    if (it != cache.end()) comm = it->second;
+    std::lock_guard<std::mutex> lock(comm_cache::mu);
+    auto it = comm_cache::map.find(key);
+    if (it != comm_cache::map.end()) comm = it->second.comm, it->second.refs += 1;
   }
   if (!comm) {
     rccl::unique_id u;
     memcpy(u.internal, id, 128);
     RCCL_TRY(rccl::CommInitRank(&comm, world, u, rank));
-    std::lock_guard<std::mutex> lock(cache_mutex);
-    cache.emplace(key, comm);
+    std::lock_guard<std::mutex> lock(comm_cache::mu);
+    comm_cache::map.emplace(key, comm_cache::Entry{comm, 1});
   }
-  ctx->comm = comm;
+  ctx->comm = comm, ctx->comm_key = key;
   ctx->rank = rank, ctx->world = world;
   return setup_dataflow(ctx);
+}
+// A rank of a sharded solve failed: nobody may wait for it.  Aborts every communicator this process created from `id`
+// (ncclCommAbort ends the collectives in flight; the in-process communicator wakes its barriers) -- the other ranks' next
+// collective returns an error instead of blocking.
+int pdlpdev_comm_abort(const uint8_t id[128])
+{
+  if (memcmp(id, softcomm::kMagic, 8) == 0) {
+    softcomm::Comm* c = nullptr;
+    memcpy(&c, id + 8, sizeof(c));
+    if (c) c->abort();
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(comm_cache::mu);
+  for (auto& kv : comm_cache::map)
+    if (kv.first.compare(0, 128, std::string((const char*)id, 128)) == 0 && !kv.second.aborted) {
+      kv.second.aborted = true;
+      if (rccl::CommAbort) (void)rccl::CommAbort(kv.second.comm);
+    }
+  return 0;
 }
 // recv[0..count) = sum over the ranks of send[rank * count ..][0..count)   (ncclReduceScatter)
 static int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t count)
@@ -2592,14 +2758,14 @@ static int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, si
     const int r       = ctx->rank;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
     c->bufs[r] = const_cast<double*>(send);
-    c->barrier();
+    SOFT_BARRIER(c);
     softcomm::Peers peers;
     for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q] + (size_t)r * count;
     const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
     softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, 0, recv);  // recv is nobody's input
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    c->barrier();  // nobody still reads the inputs
+    SOFT_BARRIER(c);  // nobody still reads the inputs
     return 0;
   }
   RCCL_TRY(rccl::ReduceScatter(send, recv, count, rccl::kFloat64, rccl::kSum, ctx->comm, ctx->stream));
@@ -2613,12 +2779,12 @@ static int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count)
     const int r       = ctx->rank;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     c->bufs[r] = buf;
-    c->barrier();
+    SOFT_BARRIER(c);
     for (int q = 0; q < c->world; ++q)
       if (q != r)
         HIP_TRY(hipMemcpyAsync(buf + (size_t)q * count, c->bufs[q] + (size_t)q * count, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    c->barrier();  // nobody still reads my slice
+    SOFT_BARRIER(c);  // nobody still reads my slice
     return 0;
   }
   RCCL_TRY(rccl::AllGather(buf + (size_t)ctx->rank * count, buf, count, rccl::kFloat64, ctx->comm, ctx->stream));
@@ -2637,14 +2803,14 @@ static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
     c->bufs[r] = buf;
-    c->barrier();                                // everybody's contribution is complete and published
+    SOFT_BARRIER(c);                                // everybody's contribution is complete and published
     softcomm::Peers peers;
     for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q];
     const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
     softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, op == rccl::kSum ? 0 : 1, c->scratch[r]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    c->barrier();                                // nobody still reads the inputs
+    SOFT_BARRIER(c);                                // nobody still reads the inputs
     HIP_TRY(hipMemcpyAsync(buf, c->scratch[r], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
   }
@@ -2653,6 +2819,76 @@ static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
 }
 
 static inline int oc_partials(const pdlpdev_ctx* ctx) { return ctx->joc.on ? ctx->joc.v.nblk + ctx->joc.v.nlong : ctx->poc.on ? ctx->poc.v.W : ctx->oc_nb; }
+
+// Direct peer transport: allocate this rank's landing block and learn where the other ranks' blocks are.
+//   in-process communicator: the ranks are contexts of one process (tests: on ONE device) -> a table in the communicator;
+//   RCCL: one 128-byte record per rank {IPC handle, process id, pointer, device} all-gathered through the communicator:
+//   same process -> the pointer itself (peer access enabled), another process -> hipIpcOpenMemHandle.
+static int p2p_setup(pdlpdev_ctx* ctx)
+{
+  pdlpdev_ctx::P2P& P = ctx->p2p;
+  const size_t W = (size_t)ctx->world;
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  P.off_x = 0;
+  P.off_y = align(P.off_x + W * (size_t)ctx->slice * sizeof(double));
+  P.off_s = align(P.off_y + W * (size_t)ctx->ypad * sizeof(double));
+  P.off_f = align(P.off_s + W * 4 * sizeof(double));
+  P.bytes = (P.off_f + p2pdev::kKinds * W * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+  HIP_TRY(hipExtMallocWithFlags((void**)&P.base, P.bytes, hipDeviceMallocFinegrained));
+  HIP_TRY(hipMemset(P.base, 0, P.bytes));
+  TRY(dev_alloc(ctx, &P.epoch, 4));
+  TRY(dev_alloc(ctx, &P.ticket, 4));
+  TRY(dev_alloc(ctx, &P.fault, 4));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (c->p2p_base.size() != W) c->p2p_base.assign(W, nullptr);
+      c->p2p_base[ctx->rank] = P.base;
+    }
+    SOFT_BARRIER(c);
+    for (size_t q = 0; q < W; ++q) P.peers.base[q] = (char*)c->p2p_base[q];
+    SOFT_BARRIER(c);  // everybody has read the table before anybody can overwrite it with the next solver's blocks
+  } else {
+    struct Rec {
+      hipIpcMemHandle_t handle;
+      unsigned long long pid, ptr, device;
+      char pad[128 - sizeof(hipIpcMemHandle_t) - 24];
+    };
+    static_assert(sizeof(Rec) == 128, "one record = 16 doubles on the wire");
+    std::vector<Rec> recs(W);
+    Rec mine;
+    memset(&mine, 0, sizeof(mine));
+    HIP_TRY(hipIpcGetMemHandle(&mine.handle, P.base));
+    mine.pid = (unsigned long long)getpid(), mine.ptr = (unsigned long long)(uintptr_t)P.base, mine.device = (unsigned long long)ctx->device;
+    double* wire = nullptr;
+    TRY(dev_alloc(ctx, &wire, W * 16));
+    HIP_TRY(hipMemcpyAsync(wire + (size_t)ctx->rank * 16, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    RCCL_TRY(rccl::AllGather(wire + (size_t)ctx->rank * 16, wire, 16, rccl::kFloat64, ctx->comm, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(recs.data(), wire, W * sizeof(Rec), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q < W; ++q) {
+      if ((int)q == ctx->rank) {
+        P.peers.base[q] = P.base;
+      } else if (recs[q].pid == mine.pid) {
+        if ((int)recs[q].device != ctx->device) {
+          const hipError_t e = hipDeviceEnablePeerAccess((int)recs[q].device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(-2, "hipDeviceEnablePeerAccess(%d): %s", (int)recs[q].device, hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+        P.peers.base[q] = (char*)(uintptr_t)recs[q].ptr;
+      } else {
+        void* mapped = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&mapped, recs[q].handle, hipIpcMemLazyEnablePeerAccess));
+        P.opened.push_back(mapped);
+        P.peers.base[q] = (char*)mapped;
+      }
+    }
+  }
+  P.on = true;
+  return 0;
+}
 int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols)
 {
   if (!ctx->owner) return fail(-1, "pdlpdev_owner_slice: the solver does not run the owner-computes dataflow");
@@ -2732,6 +2968,11 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx
     }
   }
   TRY(dev_alloc(ctx, &ctx->part_oc, (size_t)8 * std::max(oc_partials(ctx), 1)));
+  {
+    const char* tr = getenv("CUOPT_AMD_SHARD_TRANSPORT");
+    if (tr && std::string(tr) == "p2p") TRY(p2p_setup(ctx));
+    else if (tr && std::string(tr) != "collective") return fail(-1, "CUOPT_AMD_SHARD_TRANSPORT must be collective or p2p");
+  }
   if (ctx->poc.on) k_permute<<<grid_for(ctx->oc_nnz), kBlock, 0, s>>>(ctx->oc_nnz, ctx->poc.perm, ctx->oc_val, ctx->poc.val);
   if (ctx->joc.on) k_permute<<<grid_for(ctx->joc.nent), kBlock, 0, s>>>(ctx->joc.nent, ctx->joc.perm, ctx->oc_val, ctx->joc.val);
   HIP_TRY(hipGetLastError());
@@ -3173,6 +3414,34 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
              ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs);
     LAUNCH_CHECK();
+    if (ctx->p2p.on) {
+      // direct peer stores + epoch flags instead of collectives: kernels only, nothing between them but stream order
+      pdlpdev_ctx::P2P& P = ctx->p2p;
+      const int W = ctx->world, r = ctx->rank;
+      const unsigned long long* flags = reinterpret_cast<const unsigned long long*>(P.base + P.off_f);
+      auto push = [&](int kind, const double* src, int count, size_t dst_off) {
+        const int g = std::max(1, std::min((count + 2047) / 2048, 64));
+        launch_k(ctx, p2pdev::k_push, g, 256, 0, ctx->ctl, src, count, P.peers, W, r, dst_off, P.off_f, kind, P.epoch, P.ticket);
+      };
+      auto pull = [&](int kind, double* dst, size_t land_off, int count) {
+        const int g = std::max(1, std::min((count + 4095) / 4096, 128));
+        launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, flags, W, kind, P.epoch, P.fault);
+      };
+      push(0, ctx->xbar + cs, len, P.off_x + (size_t)r * ctx->slice * sizeof(double));
+      pull(0, ctx->xbar, P.off_x, W * ctx->slice);
+      double* mine = ctx->ygather + (size_t)r * ctx->ypad;
+      launch_a_dual(ctx, mine);
+      push(1, mine, ctx->m, P.off_y + (size_t)r * ctx->ypad * sizeof(double));
+      pull(1, ctx->ygather, P.off_y, W * ctx->ypad);
+      launch_oc_step(ctx);
+      launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
+      push(2, ctx->rs_scal, 3, P.off_s + (size_t)r * 4 * sizeof(double));
+      pull(2, ctx->rs_scal + 8, P.off_s, 4 * W);
+      launch_k(ctx, p2pdev::k_sum_scalars, 1, 64, 0, ctx->ctl, ctx->rs_scal + 8, W, ctx->rs_scal + 4);
+      launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 5, 1, ctx->rs_scal + 4, ctx->sp);
+      LAUNCH_CHECK();
+      return 0;
+    }
     TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
     launch_a_dual(ctx, ctx->ygather + (size_t)ctx->rank * ctx->ypad);
     LAUNCH_CHECK();
@@ -3284,7 +3553,7 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
     // bundles (one rank, ROCm 7.2) -- left off until it can be exercised on a multi-GPU node.  The in-process
     // communicator synchronises on the host and can never be captured.
     static const bool graph_comm = getenv("CUOPT_AMD_GRAPH_COMM") && atoi(getenv("CUOPT_AMD_GRAPH_COMM")) == 1;
-    if (ctx->use_graph && (!ctx->comm || (graph_comm && !ctx->soft))) {
+    if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || (graph_comm && !ctx->soft))) {
       while (remaining > 0) {
         int chunk = 1;
         while (chunk * 2 <= remaining && chunk < 64) chunk *= 2;
@@ -3351,7 +3620,7 @@ void pdlpdev_range_pop(void)
 int pdlpdev_prepare_graphs(pdlpdev_ctx* ctx)
 {
   HIP_TRY(hipSetDevice(ctx->device));
-  if (!ctx->use_graph || ctx->comm || ctx->small_resident) return 0;
+  if (!ctx->use_graph || (ctx->comm && !ctx->p2p.on) || ctx->small_resident) return 0;
   for (int chunk = 1; chunk <= 64; chunk *= 2) {
     hipGraphExec_t g;
     TRY(get_graph(ctx, chunk, &g));
@@ -3875,6 +4144,7 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
 }
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->owner ? 3 : ctx->rsag ? 2 : 1; }
+int pdlpdev_shard_transport(pdlpdev_ctx* ctx) { return ctx->p2p.on ? 1 : 0; }
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column

@@ -17,8 +17,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -750,6 +753,20 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
   return 0;
 }
 
+// cuoptamd_solve_sharded runs one host thread per rank.  A rank whose set-up fails before the communicator exists (out of
+// memory, a layout that cannot be built ...) would leave the others waiting in ncclCommInitRank for ever: the threads
+// therefore agree on their status right before it (this hook, set per thread; max of the ranks' error codes), and a rank
+// that fails later aborts the communicators (pdlpdev_comm_abort).
+static thread_local std::function<int(int)> t_agree_before_comm;
+// test hook: CUOPT_AMD_FAULT_INJECT="<rank>:create" | "<rank>:advance" makes that rank of a sharded solve fail there
+static bool fault_injected(int rank, int world, const char* where)
+{
+  const char* env = std::getenv("CUOPT_AMD_FAULT_INJECT");
+  if (!env || world <= 1) return false;
+  const std::string want = std::to_string(rank) + ":" + where;
+  return want == env;
+}
+
 int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const cuoptamd_hyper* hyper,
                            const cuoptamd_settings* settings, const double* init_x,
                            const double* init_y, int device, int rank, int world,
@@ -818,10 +835,19 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     double* t_val_p      = t_val.get();
     job.worker = std::thread([=] { cuoptamd_csr_transpose(ml, n, off_p, idx, val, t_off_p, t_idx_p, t_val_p); });
   }
-  DEV(pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
-                                &TransposeJob::wait, &job, c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin,
-                                lp->lb, lp->ub));
-  job.join();
+  {
+    int rc = pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
+                                       &TransposeJob::wait, &job, c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin,
+                                       lp->lb, lp->ub);
+    if (rc == 0 && fault_injected(rank, world, "create")) rc = -6;
+    job.join();
+    if (rc != 0) fail(rc, "pdlpdev_create: %s", rc == -6 ? "injected fault (CUOPT_AMD_FAULT_INJECT)" : pdlpdev_last_error());
+    if (t_agree_before_comm) {
+      const int all = t_agree_before_comm(rc);
+      if (rc == 0 && all != 0) return fail(all, "another rank of the sharded solve failed during set-up");
+    }
+    if (rc != 0) return rc;
+  }
   lap("pdlpdev_create (upload+panels)");
   if (comm_id) DEV(pdlpdev_comm_init(s->dev, rank, world, comm_id));
   else if (world > 1) return fail(-1, "cuoptamd_solver_create: world > 1 needs a communicator id");
@@ -961,6 +987,8 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
   const int32_t budget_end   = (int32_t)std::min<int64_t>(budget_end64, std::numeric_limits<int32_t>::max());
   for (;;) {
     const int32_t it = s->total_iterations;
+    if (it >= H.major_iteration && fault_injected(s->rank, s->world, "advance"))
+      return leave(fail(-6, "injected fault (CUOPT_AMD_FAULT_INJECT)"));
     const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
     // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
     const bool artificial = H.artificial_restart_in_main_loop &&
@@ -1046,6 +1074,11 @@ int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, c
   };
   std::vector<Rank> ranks(gpus);
   if (y) std::fill(y, y + lp->m, 0.0);
+  struct Agreement {  // one-shot barrier of the rank threads carrying the worst error code
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, worst = 0;
+  } agreement;
   std::vector<std::thread> pool;
   for (int g = 0; g < gpus; ++g)
     pool.emplace_back([&, g] {
@@ -1053,8 +1086,22 @@ int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, c
       cuoptamd_settings st = *settings;
       if (g != 0) st.log_to_console = 0, st.log_file = nullptr;  // one voice
       cuoptamd_solver* solver = nullptr;
+      t_agree_before_comm = [&](int rc) {
+        std::unique_lock<std::mutex> lk(agreement.mu);
+        if (rc != 0 && agreement.worst == 0) agreement.worst = rc;
+        if (++agreement.arrived == gpus) agreement.cv.notify_all();
+        else agreement.cv.wait(lk, [&] { return agreement.arrived == gpus; });
+        return agreement.worst;
+      };
       me.rc = cuoptamd_solver_create(&solver, lp, hyper, &st, nullptr, nullptr, soft_communicator ? 0 : g, g, gpus, id);
-      if (me.rc == 0) me.rc = cuoptamd_solver_advance(solver, std::numeric_limits<int32_t>::max(), &me.res);
+      t_agree_before_comm = nullptr;
+      if (me.rc == 0) {
+        me.rc = cuoptamd_solver_advance(solver, std::numeric_limits<int32_t>::max(), &me.res);
+      }
+      if (me.rc != 0) {
+        me.error = cuoptamd_last_error();  // thread-local message: carry it to the caller's thread
+        (void)pdlpdev_comm_abort(id);      // nobody waits for this rank in a collective
+      }
       if (me.rc == 0) {
         // every rank holds the same x and reduced costs (replicated primal side) and ITS rows of y
         std::vector<double> yl(y ? (size_t)lp->m : 0);
@@ -1065,12 +1112,15 @@ int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, c
           std::copy(yl.begin() + r0, yl.begin() + r1, y + r0);
         }
       }
-      if (me.rc != 0) me.error = cuoptamd_last_error();  // thread-local message: carry it to the caller's thread
+      if (me.rc != 0 && me.error.empty()) me.error = cuoptamd_last_error();
       cuoptamd_solver_destroy(solver);
     });
   for (auto& t : pool) t.join();
-  for (int g = 0; g < gpus; ++g)
-    if (ranks[g].rc != 0) return fail(ranks[g].rc, "rank %d of %d: %s", g, gpus, ranks[g].error.c_str());
+  // report the rank that failed first-hand, not one that merely noticed ("another rank failed", an aborted collective)
+  for (int pass = 0; pass < 2; ++pass)
+    for (int g = 0; g < gpus; ++g)
+      if (ranks[g].rc != 0 && (pass == 1 || (ranks[g].error.find("another rank") == std::string::npos && ranks[g].error.find("abandoned") == std::string::npos)))
+        return fail(ranks[g].rc, "rank %d of %d: %s", g, gpus, ranks[g].error.c_str());
   *result      = ranks[0].res;
   result->gpus = gpus;
   return 0;

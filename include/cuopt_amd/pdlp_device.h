@@ -165,6 +165,9 @@ int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[12
  * runs use RCCL.  Fills `id` with a token that pdlpdev_comm_init / cuoptamd_solver_create accept in place of
  * an RCCL unique id.  The communicator lives until process exit. */
 int pdlpdev_softcomm_create(int world, uint8_t id[128]);
+/* A rank of a sharded solve failed: aborts every communicator THIS process created from `id` (ncclCommAbort / the in-process
+ * communicator's barriers), so that the other ranks' collectives return an error instead of waiting for the missing rank. */
+int pdlpdev_comm_abort(const uint8_t id[128]);
 
 /* ---- setup ----------------------------------------------------------------------------------- */
 /* D_r, D_c <- Ruiz (inf-norm, `ruiz_iterations` rounds, both sides from the same snapshot) then
@@ -297,6 +300,11 @@ int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
  * (CUOPT_AMD_SHARD_DATAFLOW=rsag), 3 = owner computes: the rank also holds its COLUMNS of A, all-gather(xbar slices) +
  * all-gather(y' row blocks) + a 3-scalar all-reduce, no partial products on the wire (CUOPT_AMD_SHARD_DATAFLOW=owner) */
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx);
+/* transport of the owner-computes dataflow's exchanges: 0 = collectives (RCCL all-gather / 3-scalar all-reduce, or the in-process
+ * communicator), 1 = direct peer stores into the ranks' landing blocks + epoch flags, kernels only
+ * (CUOPT_AMD_SHARD_TRANSPORT=p2p; peers of the same process are addressed directly, other processes through HIP IPC handles
+ * exchanged over the communicator) */
+int pdlpdev_shard_transport(pdlpdev_ctx* ctx);
 /* owner-computes dataflow: the columns [*col_begin, *col_begin + *ncols) of A this rank owns ... */
 int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols);
 /* ... and their nonzeros over ALL rows of A: rows [col_begin, col_begin + ncols) of the global A^T as CSR (indices = global

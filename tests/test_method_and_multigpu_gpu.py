@@ -118,11 +118,14 @@ def test_more_gpus_than_visible_is_a_loud_error(monkeypatch):
         assert r["return_code"] == capi.CUOPT_RUNTIME_ERROR and "visible" in r["error_string"]
 
 
-@pytest.mark.parametrize("dataflow", ["allreduce", "rsag", "owner"])
+@pytest.mark.parametrize("dataflow", ["allreduce", "rsag", "owner", "owner+p2p"])
 @pytest.mark.skipif(capi.device_count() < 2, reason="needs two GPUs: RCCL with two ranks in one process")
 def test_rccl_two_ranks_in_one_process(dataflow, monkeypatch):
+    """two devices, two host threads, real RCCL; "owner+p2p": the exchanges of the owner-computes dataflow as direct stores into
+    the peer's landing block (hipDeviceEnablePeerAccess) instead of collectives"""
     monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)
-    monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", dataflow)
+    monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", dataflow.split("+")[0])
+    monkeypatch.setenv("CUOPT_AMD_SHARD_TRANSPORT", "p2p" if dataflow.endswith("p2p") else "collective")
     p = synthetic.generate(6000, 5000, 8, seed=61)
     single = capi.solve(p, method=1, tol=1e-6)
     r = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=2)
