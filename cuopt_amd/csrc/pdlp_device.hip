@@ -228,34 +228,51 @@ struct Peers {
 constexpr int kKinds = 3;  // exchanges per attempt: xbar slices, y' row blocks, step-size scalars
 __device__ __forceinline__ bool active(const pdlpdev_ctl* ctl) { return ctl->error == 0 && ctl->steps_taken < ctl->target_steps; }
 
-// this rank's `len` doubles -> offset `dst_off` (bytes) + slot of every rank's landing block; then, once every workgroup's
-// stores are out (system-scope fence + ticket), the last workgroup raises this rank's flag of exchange `kind` in every block.
-__global__ void __launch_bounds__(256) k_push(const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ src, int len, Peers P, int world,
-                                              int rank, size_t dst_off, size_t flag_off, int kind, unsigned long long* __restrict__ epoch,
-                                              unsigned* __restrict__ ticket)
+// What a PRODUCING kernel (primal step, dual step, packing of the step-size sums) needs to store its results straight into
+// every rank's landing block and to raise this rank's flag there; lives in device memory (one per exchange), kernels take a
+// pointer (null: no peer transport) and read the table with scalar loads.
+struct Push {
+  Peers P;
+  int world, rank, kind;
+  size_t dst_off, flag_off;  // bytes inside every rank's block: this rank's slot of the exchange / the flag area
+  unsigned long long* epoch;
+  unsigned* ticket;
+  __device__ __forceinline__ double* slot(int q) const { return reinterpret_cast<double*>(P.base[q] + dst_off); }
+};
+// Called by EVERY workgroup at the end of a producing kernel: once all stores of the grid are out (system-scope fence, then a
+// ticket), the last workgroup advances this rank's epoch of the exchange and raises its flag in every rank's block.
+__device__ __forceinline__ void publish(const Push* T)
 {
-  if (!active(ctl)) return;
-  for (int q = 0; q < world; ++q) {
-    double* __restrict__ dst = reinterpret_cast<double*>(P.base[q] + dst_off);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
-  }
   __threadfence_system();
   __syncthreads();
-  __shared__ bool last;
-  if (threadIdx.x == 0) last = atomicAdd(&ticket[kind], 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(&T->ticket[T->kind], 1u) != gridDim.x - 1) return;
   __threadfence_system();
-  if (threadIdx.x == 0) {
-    ticket[kind] = 0;
-    epoch[kind] += 1;
-  }
-  __syncthreads();
-  const unsigned long long e = epoch[kind];
-  if ((int)threadIdx.x < world) {
-    unsigned long long* flag = reinterpret_cast<unsigned long long*>(P.base[threadIdx.x] + flag_off) + (size_t)kind * world + rank;
+  T->ticket[T->kind]         = 0;
+  const unsigned long long e = T->epoch[T->kind] + 1;
+  T->epoch[T->kind]          = e;
+  for (int q = 0; q < T->world; ++q) {
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(T->P.base[q] + T->flag_off) + (size_t)T->kind * T->world + T->rank;
     __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+// lane q waits for rank q's flag of exchange `kind`; false when patience ran out (5 s: a peer died)
+__device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int world, int kind, const unsigned long long* epoch)
+{
+  bool ok = true;
+  if ((int)threadIdx.x < world) {
+    const unsigned long long want = epoch[kind];
+    const unsigned long long* f   = flags + (size_t)kind * world + threadIdx.x;
+    const unsigned long long t0   = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 500000000ull) {  // 100 MHz
+        ok = false;
+        break;
+      }
+    }
+  }
+  return __syncthreads_and(ok);
 }
 // wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles).  Every
 // workgroup polls for itself (local memory, one load per rank per poll); patience is bounded: a peer that never arrives sets
@@ -265,36 +282,12 @@ __global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ ctl, dou
                                               const unsigned long long* __restrict__ epoch, int* __restrict__ fault)
 {
   if (!active(ctl)) return;
-  __shared__ int ok;
-  if (threadIdx.x == 0) ok = 1;
-  __syncthreads();
-  if ((int)threadIdx.x < world) {
-    const unsigned long long want = epoch[kind];
-    const unsigned long long* f   = flags + (size_t)kind * world + threadIdx.x;
-    const unsigned long long t0   = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 500000000ull) {  // 5 s at 100 MHz
-        ok = 0;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  if (!ok) {
+  if (!wait_flags(flags, world, kind, epoch)) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
     return;
   }
   __threadfence_system();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(land + i);
-}
-// the three step-size sums of the attempt from every rank's landed scalars, added up in rank order: the same bits on every rank
-__global__ void k_sum_scalars(const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ landed, int world, double* __restrict__ out)
-{
-  if (!active(ctl) || threadIdx.x >= 3) return;
-  double acc = 0.0;
-  for (int q = 0; q < world; ++q) acc += landed[4 * q + threadIdx.x];
-  out[threadIdx.x] = acc;
 }
 }  // namespace p2pdev
 
@@ -397,6 +390,7 @@ struct pdlpdev_ctx {
     unsigned long long* epoch = nullptr;  // device: epochs of the three exchanges (xbar, y', scalars) as this rank counts them
     unsigned* ticket = nullptr;      // device: last-workgroup tickets of the push kernels
     int* fault = nullptr;            // device: set when a wait ran out of patience (peer died)
+    p2pdev::Push* push_dev = nullptr;  // device: the three exchanges' descriptors (xbar, y', scalars) for the producing kernels
   } p2p;
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
@@ -714,7 +708,7 @@ __global__ void __launch_bounds__(kBlock)
 k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, double* __restrict__ x1,
          const double* __restrict__ aty0, const double* __restrict__ aty1,
          const double* __restrict__ c, const double* __restrict__ lb, const double* __restrict__ ub,
-         double* __restrict__ xbar, double* __restrict__ sumx)
+         double* __restrict__ xbar, double* __restrict__ sumx, const p2pdev::Push* __restrict__ push)
 {
   if (!loop_active(ctl)) return;
   const int cur       = ctl->cur;
@@ -730,9 +724,13 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
     double next           = xj - (tau * gradient);
     next                  = dmax(dmin(next, ub[j]), lb[j]);
     xn[j]                 = next;
-    xbar[j]               = next - xj + next;
+    const double xb       = next - xj + next;
+    xbar[j]               = xb;
+    if (push)  // sharded solve, direct peer transport: this rank's slice of xbar lands in every rank's block
+      for (int q = 0; q < push->world; ++q) push->slot(q)[j] = xb;
     if (pend) sumx[j] = sumx[j] + weight * xj;
   }
+  if (push) p2pdev::publish(push);
 }
 
 // (2) rows of A: v = A xbar (stream SpMV) -> dual projection (utils.cuh:97-112) -> ||dy||^2 partial,
@@ -748,6 +746,7 @@ struct DualEpilogue {
   double sigma, weight;
   bool pend;
   double* __restrict__ copy = nullptr;  // sharded solves, owner-computes dataflow: y' also goes to this rank's slot of the gathered dual
+  const p2pdev::Push* __restrict__ push = nullptr;  // ... or, with the direct peer transport, into every rank's landing block
   // the row's operands, separable from the arithmetic so that a layout can request them before its row sums are ready
   struct Ops {
     double y, lo, hi, sum;
@@ -762,6 +761,8 @@ struct DualEpilogue {
     next            = dmax(low, dmin(up, 0.0));
     yn[i]           = next;
     if (copy) copy[i] = next;
+    if (push)
+      for (int q = 0; q < push->world; ++q) push->slot(q)[i] = next;
     const double dy = next - yi;
     acc[0] += dy * dy;
     if (pend) sumy[i] = o.sum + weight * yi;
@@ -773,13 +774,15 @@ k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const int32_t* __restrict__ idx, const double* __restrict__ val,
               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
               double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
+              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+              const p2pdev::Push* __restrict__ push)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy};
+                 ctl->pending_avg != 0, ycopy, push};
   csr_stream_block(nb, rb, off, idx, val, xbar, e, part);
+  if (push) p2pdev::publish(push);
 }
 
 // (3) rows of A^T: AtY' = A^T y' (stream SpMV) fused with the step-size statistics
@@ -931,6 +934,27 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   block_sum_fast<3, kDecisionThreads / 64>(acc, red);
   if (t != 0) return;
   apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
+  *ctl = lc;
+}
+
+// direct peer transport of a sharded solve: wait for every rank's three step-size sums (landed in this rank's block), add them
+// up in rank order -- the same bits on every rank -- and take the decision
+__global__ void __launch_bounds__(64)
+k_step_decision_p2p(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ landed, const unsigned long long* __restrict__ flags, int world,
+                    const unsigned long long* __restrict__ epoch, int* __restrict__ fault, pdlpdev_step_params sp)
+{
+  if (!loop_active(ctl)) return;
+  if (!p2pdev::wait_flags(flags, world, 2, epoch)) {
+    if (threadIdx.x == 0) *fault = 1, ctl->error = 1;
+    return;
+  }
+  __threadfence_system();
+  if (threadIdx.x != 0) return;
+  double sum[3] = {0.0, 0.0, 0.0};
+  for (int q = 0; q < world; ++q)
+    for (int k = 0; k < 3; ++k) sum[k] += __hip_atomic_load(landed + 4 * q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  pdlpdev_ctl lc = *ctl;
+  apply_step_decision(&lc, sum[0], sum[1], sum[2], sp);
   *ctl = lc;
 }
 
@@ -1155,13 +1179,15 @@ static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
                double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
+               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+               const p2pdev::Push* __restrict__ push)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy};
+                 ctl->pending_avg != 0, ycopy, push};
   panel_spmv_block(P, xbar, e, part);
+  if (push) p2pdev::publish(push);
 }
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
@@ -1179,13 +1205,15 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
              double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy)
+             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+             const p2pdev::Push* __restrict__ push)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy};
+                 ctl->pending_avg != 0, ycopy, push};
   jag_block<decltype(e), WAVES>(J, xbar, e, part);
+  if (push) p2pdev::publish(push);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -1297,8 +1325,10 @@ k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ 
 
 // sliced-primal dataflow: this rank's three step-size partial sums, side by side, for ONE small all-reduce
 __global__ void __launch_bounds__(kBlock)
-k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t, double* __restrict__ out)
+k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t, double* __restrict__ out,
+                 const pdlpdev_ctl* __restrict__ ctl, const p2pdev::Push* __restrict__ push)
 {
+  if (push && !loop_active(ctl)) return;
   __shared__ double red[3 * 8];
   double acc[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < nb_dy; i += kBlock) acc[0] += part_dy[i];
@@ -1307,7 +1337,15 @@ k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __
     acc[2] += part_t[nb_t + i];
   }
   block_reduce<SumOp, 3>(acc, red);
-  if (threadIdx.x == 0) out[0] = acc[0], out[1] = acc[1], out[2] = acc[2];
+  if (threadIdx.x == 0) {
+    out[0] = acc[0], out[1] = acc[1], out[2] = acc[2];
+    if (push)
+      for (int q = 0; q < push->world; ++q) {
+        double* d = push->slot(q);
+        d[0] = acc[0], d[1] = acc[1], d[2] = acc[2];
+      }
+  }
+  if (push) p2pdev::publish(push);
 }
 
 // ================================================================================================
@@ -2674,12 +2712,12 @@ int pdlpdev_softcomm_create(int world, uint8_t id[128])
   memcpy(id + 8, &c, sizeof(c));
   return 0;
 }
-// CUOPT_AMD_SHARD_DATAFLOW = allreduce (default) | rsag | owner : see the `rsag` / `owner` fields of the context
+// CUOPT_AMD_SHARD_DATAFLOW = owner (default) | allreduce | rsag : see the `rsag` / `owner` fields of the context
 static int setup_dataflow(pdlpdev_ctx* ctx)
 {
   const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
-  if (!env || std::string(env) == "allreduce") return 0;
-  const std::string flow = env;
+  const std::string flow = env ? env : "owner";  // default since round 3: nothing but the slices themselves travels
+  if (flow == "allreduce") return 0;
   if (flow != "rsag" && flow != "owner") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce, rsag or owner");
   if (ctx->world > 16) return fail(-1, "the sliced-primal dataflows support up to 16 ranks");
   if (!ctx->soft && (!rccl::ReduceScatter || !rccl::AllGather)) return fail(-3, "RCCL: ncclReduceScatter / ncclAllGather missing");
@@ -2885,6 +2923,15 @@ static int p2p_setup(pdlpdev_ctx* ctx)
         P.peers.base[q] = (char*)mapped;
       }
     }
+  }
+  {
+    p2pdev::Push h[p2pdev::kKinds];
+    const size_t slot[p2pdev::kKinds] = {P.off_x + (size_t)ctx->rank * ctx->slice * sizeof(double), P.off_y + (size_t)ctx->rank * ctx->ypad * sizeof(double),
+                                         P.off_s + (size_t)ctx->rank * 4 * sizeof(double)};
+    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch, P.ticket};
+    TRY(dev_alloc(ctx, &P.push_dev, p2pdev::kKinds));
+    HIP_TRY(hipMemcpyAsync(P.push_dev, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   P.on = true;
   return 0;
@@ -3338,14 +3385,14 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
 static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
 static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
-static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr)
+static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pdev::Push* push = nullptr)
 {
   if (ctx->ja.on)
-    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
+    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else if (ctx->pa.on)
-    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
+    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else
-    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy);
+    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
@@ -3412,33 +3459,26 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     const size_t cs = (size_t)ctx->rank * ctx->slice;
     const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
     launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
-             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs);
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, ctx->p2p.on ? ctx->p2p.push_dev : (const p2pdev::Push*)nullptr);
     LAUNCH_CHECK();
     if (ctx->p2p.on) {
-      // direct peer stores + epoch flags instead of collectives: kernels only, nothing between them but stream order
+      // direct peer stores + epoch flags instead of collectives: the producing kernels (the primal step above, the dual step,
+      // the packing of the step-size sums) store into every rank's landing block and raise this rank's flag from their last
+      // workgroup; a consumer waits for the world flags and copies the landed vector into ordinary memory.  Kernels only,
+      // nothing between them but stream order: 7 launches per attempt.
       pdlpdev_ctx::P2P& P = ctx->p2p;
-      const int W = ctx->world, r = ctx->rank;
+      const int W = ctx->world;
       const unsigned long long* flags = reinterpret_cast<const unsigned long long*>(P.base + P.off_f);
-      auto push = [&](int kind, const double* src, int count, size_t dst_off) {
-        const int g = std::max(1, std::min((count + 2047) / 2048, 64));
-        launch_k(ctx, p2pdev::k_push, g, 256, 0, ctx->ctl, src, count, P.peers, W, r, dst_off, P.off_f, kind, P.epoch, P.ticket);
-      };
       auto pull = [&](int kind, double* dst, size_t land_off, int count) {
         const int g = std::max(1, std::min((count + 4095) / 4096, 128));
         launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, flags, W, kind, P.epoch, P.fault);
       };
-      push(0, ctx->xbar + cs, len, P.off_x + (size_t)r * ctx->slice * sizeof(double));
       pull(0, ctx->xbar, P.off_x, W * ctx->slice);
-      double* mine = ctx->ygather + (size_t)r * ctx->ypad;
-      launch_a_dual(ctx, mine);
-      push(1, mine, ctx->m, P.off_y + (size_t)r * ctx->ypad * sizeof(double));
+      launch_a_dual(ctx, nullptr, P.push_dev + 1);
       pull(1, ctx->ygather, P.off_y, W * ctx->ypad);
       launch_oc_step(ctx);
-      launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
-      push(2, ctx->rs_scal, 3, P.off_s + (size_t)r * 4 * sizeof(double));
-      pull(2, ctx->rs_scal + 8, P.off_s, 4 * W);
-      launch_k(ctx, p2pdev::k_sum_scalars, 1, 64, 0, ctx->ctl, ctx->rs_scal + 8, W, ctx->rs_scal + 4);
-      launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 5, 1, ctx->rs_scal + 4, ctx->sp);
+      launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal, ctx->ctl, P.push_dev + 2);
+      launch_k(ctx, k_step_decision_p2p, 1, 64, 0, ctx->ctl, reinterpret_cast<const double*>(P.base + P.off_s), flags, W, P.epoch, P.fault, ctx->sp);
       LAUNCH_CHECK();
       return 0;
     }
@@ -3447,7 +3487,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     LAUNCH_CHECK();
     TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
     launch_oc_step(ctx);
-    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal, ctx->ctl, (const p2pdev::Push*)nullptr);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
     launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
@@ -3461,7 +3501,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     const size_t cs = (size_t)ctx->rank * ctx->slice;
     const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
     launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
-             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs);
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, (const p2pdev::Push*)nullptr);
     LAUNCH_CHECK();
     TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
     launch_a_dual(ctx);
@@ -3470,14 +3510,14 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     TRY(reduce_scatter(ctx, ctx->ar_buf, ctx->rs_buf, (size_t)ctx->slice));
     const int g = std::min(grid_for(len), kGenericBlocks);
     launch_k(ctx, k_step_stats, g, kBlock, 0, len, g, ctx->ctl, ctx->rs_buf, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs, ctx->part_g);
-    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_g, g, ctx->rs_scal);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_g, g, ctx->rs_scal, ctx->ctl, (const p2pdev::Push*)nullptr);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
     launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
     LAUNCH_CHECK();
     return 0;
   }
-  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
   launch_a_dual(ctx);
   if (!ctx->comm) {
     launch_at_step(ctx);
@@ -4076,7 +4116,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   auto one = [&]() {
     switch (kernel_id) {
       case PDLPDEV_K_PRIMAL:
-        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
         break;
       case PDLPDEV_K_SPMV_A_DUAL: launch_a_dual(ctx); break;
       case PDLPDEV_K_SPMV_AT_STEP: launch_at_step(ctx); break;

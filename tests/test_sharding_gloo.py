@@ -79,6 +79,25 @@ def _worker(rank, world, port, out):
     xbar = np.concatenate([g.numpy() for g in gathered])[:n]
     sums = torch.tensor([float(y[r0:r1] @ y[r0:r1]), float(x_new @ mine[:ln]), float(x_new @ x_new)], dtype=torch.float64)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)  # the 3-scalar all-reduce: identical bits on every rank
+    # OWNER-COMPUTES dataflow (CUOPT_AMD_SHARD_DATAFLOW=owner, pdlpdev_owner_setup): the rank also holds its slice of COLUMNS of A over
+    # all rows (rows of the global A^T, row indices remapped into the gathered dual: rank q's rows at [q * ypad, ...)); after an
+    # all-gather of the row blocks' y the column sums are complete on the owner -- and bit-identical to the unsharded A^T y,
+    # because every column adds its rows in the same (ascending) order
+    tof_g, tif_g, tvf_g = orcbind.transpose(m, n, p["offsets"], p["indices"], p["values"])
+    c0, c1 = int(tof_g[cs]) if ln else 0, int(tof_g[cs + ln]) if ln else 0
+    coff = (tof_g[cs:cs + ln + 1] - c0).astype(np.int32) if ln else np.zeros(1, np.int32)
+    cidx, cval = tif_g[c0:c1], tvf_g[c0:c1]
+    ypad = (int(np.max(np.diff(bounds))) + 15) & ~15
+    owner_of = np.searchsorted(np.asarray(bounds[1:]), cidx, side="right")
+    ridx = (cidx + owner_of * ypad - np.asarray(bounds)[owner_of]).astype(np.int32)
+    yslot = np.zeros(ypad)
+    yslot[:r1 - r0] = y[r0:r1]
+    ys = [torch.zeros(ypad, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ys, torch.from_numpy(yslot))  # ncclAllGather of the y' row blocks
+    ygather = np.concatenate([g.numpy() for g in ys])
+    aty_owner = orcbind.spmv(coff, ridx, cval, ygather) if ln else np.zeros(0)
+    owner_pieces = [None] * world
+    dist.all_gather_object(owner_pieces, (cs, aty_owner))
     # gather A x pieces for the check
     pieces = [None] * world
     dist.all_gather_object(pieces, (r0, r1, ax_local))
@@ -92,6 +111,8 @@ def _worker(rank, world, port, out):
                      aty_err=float(np.max(np.abs(aty.numpy() - orcbind.spmv(tof, tif, tvf, y)))),
                      colmax_equal=bool(np.array_equal(colmax.numpy(), cm)),
                      dy2_err=float(abs(dy2.item() - y @ y)), nnz=[int(p["offsets"][b]) for b in bounds],
+                     owner_aty_equal=bool(np.array_equal(np.concatenate([q[1] for q in sorted(owner_pieces, key=lambda q: q[0])]),
+                                                         orcbind.spmv(tof, tif, tvf, y))), ypad=ypad,
                      slice=sl, xbar_err=float(np.max(np.abs(xbar - (2.0 * np.maximum(x - tau * (p["c"] - orcbind.spmv(tof, tif, tvf, y)), 0.0) - x)))),
                      sums_err=float(abs(sums[0].item() - y @ y)),
                      dx2_err=float(abs(sums[2].item() - np.sum(np.maximum(x - tau * (p["c"] - orcbind.spmv(tof, tif, tvf, y)), 0.0) ** 2)))))
@@ -119,3 +140,5 @@ def test_row_block_sharding_reproduces_unsharded_products(world):
     # sliced primal dataflow: 2500 columns over 2 ranks = slices of 1264 (28 entries of padding behind the last one)
     assert res["slice"] == 1264
     assert res["xbar_err"] < 1e-12 and res["sums_err"] < 1e-9 and res["dx2_err"] < 1e-9
+    # owner-computes dataflow: complete column sums on the owner, BIT-identical to the unsharded A^T y
+    assert res["owner_aty_equal"] and res["ypad"] % 16 == 0
