@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
     ap.add_argument("--self-launch", action="store_true", help="go through the torch.distributed.run launcher also for one GPU")
-    ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel", "jag", "timed"], help="CUOPT_AMD_SPMV_LAYOUT")
+    ap.add_argument("--spmv-layout", default=None, choices=["auto", "stream", "panel", "jag", "pb", "timed"], help="CUOPT_AMD_SPMV_LAYOUT")
     args = ap.parse_args()
 
     if args.spmv_layout:
@@ -227,7 +227,7 @@ def main():
     dom = "SPMV_A_DUAL" if kernels["SPMV_A_DUAL"] >= kernels["SPMV_AT_STEP"] else "SPMV_AT_STEP"
     achieved = bytes_alg[dom] / (kernels[dom] * 1e-3) / 1e9
     lname = layout["A" if dom == "SPMV_A_DUAL" else "At"]["layout"]
-    prefix = {"panel": "k_panel_", "jag": "k_jag_", "stream": "k_spmv_", "resident": "k_spmv_"}[lname]
+    prefix = {"panel": "k_panel_", "jag": "k_jag_", "stream": "k_spmv_", "resident": "k_spmv_", "pb": "k_pb_"}[lname]
     kname = prefix + ("a_dual" if dom == "SPMV_A_DUAL" else "at_step")
     # HBM/fabric bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this very
     # command (profiles/r02_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the

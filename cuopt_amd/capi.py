@@ -793,12 +793,14 @@ class Device:
     def layout(self):
         out = np.zeros(6, np.int32)
         self._ck(lib.pdlpdev_layout_info(self.handle, _ptr(out)))
-        names = {0: "stream", 1: "panel", 2: "resident", 3: "jag"}
+        names = {0: "stream", 1: "panel", 2: "resident", 3: "jag", 4: "pb"}
 
         def side(k):
             d = dict(layout=names[int(out[k])], panels=bool(out[k] == 1), workgroups=int(out[k + 1]))
             if out[k] == 3:
                 d["lds_gather_saving_pct"] = int(out[k + 2])  # 100 * (1 - cost of filling the LDS column sets / gathers served)
+            elif out[k] == 4:
+                d["padding_pct"] = int(out[k + 2])  # gather-free layout: padded entries over nonzeros - 1, in percent (workgroups = bins)
             else:
                 d["slabs"] = int(out[k + 2])
             return d

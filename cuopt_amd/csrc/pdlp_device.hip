@@ -325,6 +325,16 @@ struct pdlpdev_ctx {
     int64_t nent  = 0;
     double saving = 0.0;      // share of the global gathers the LDS column sets save (build_jag)
   } ja, jat;
+  // gather-free layout (fourth layout: huge unstructured matrices; pdlp_kernels.hpp "pb")
+  struct Pb {
+    bool on = false;
+    PbView v{};
+    int32_t* perm = nullptr;  // position in CSR order of each padded P-order entry (-1: padding)
+    double* val   = nullptr;
+    int64_t np    = 0;        // padded entries
+    int p_threads = 512;      // phase P workgroup: 512 (8192-column panels) or 1024 (16384)
+    double pad    = 1.0;      // padded entries / nonzeros
+  } pba, pbat;
   // problem vectors: scaled working copies and the unscaled originals
   double *c = nullptr, *lb = nullptr, *ub = nullptr, *lo = nullptr, *hi = nullptr;
   double *c_u = nullptr, *lb_u = nullptr, *ub_u = nullptr, *lo_u = nullptr, *hi_u = nullptr;
@@ -1227,6 +1237,74 @@ k_jag_at_step(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __re
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
   jag_block<decltype(e), WAVES>(J, cur ? y0 : y1 /* y' */, e, part);
 }
+// (plain SpMV: A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
+struct StoreEpilogue {
+  static constexpr int NQ = 0;
+  using Op = SumOp;
+  double* __restrict__ out;
+  __device__ __forceinline__ void row(int r, double v, double (&)[1]) { out[r] = v; }
+};
+// gather-free twins: phase P (one kernel, the gathered vector chosen on the device like the other layouts do) and phase R with
+// the same epilogues
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+k_pb_products(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  if (in_loop && !loop_active(ctl)) return;
+  // mode 0: v0.  1: cur ? v0 : v1 (the trial iterate of a ping-pong pair).  2: cur ? v1 : v0 (the current one).
+  const double* vec = v0;
+  if (mode != 0) {
+    const bool cur = ctl->cur != 0;
+    vec            = (cur == (mode == 1)) ? v0 : v1;
+  }
+  pb_products_block<THREADS>(V, vec, pb_lds);
+}
+__global__ void __launch_bounds__(kPbThreads)
+k_pb_a_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
+            const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+            const p2pdev::Push* __restrict__ push)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size, ctl->pending_avg != 0, ycopy, push};
+  pb_rows_block(V, e, part, pb_lds);
+  if (push) p2pdev::publish(push);
+}
+__global__ void __launch_bounds__(kPbThreads)
+k_pb_at_step(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
+             double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
+  pb_rows_block(V, e, part, pb_lds);
+}
+__global__ void __launch_bounds__(kPbThreads)
+k_pb_at_cur(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ aty0, double* __restrict__ aty1,
+            double* __restrict__ out_override, int use_next)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  const int cur = ctl->cur ^ (use_next ? 1 : 0);
+  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
+  pb_rows_block(V, e, nullptr, pb_lds);
+}
+__global__ void __launch_bounds__(kPbThreads) k_pb_plain(PbView V, double* __restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  StoreEpilogue e{out};
+  pb_rows_block(V, e, nullptr, pb_lds);
+}
+__global__ void __launch_bounds__(kBlock)
+k_permute_pad(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
+{
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t k = perm[i];
+    dst[i]          = k >= 0 ? src[k] : 0.0;
+  }
+}
 __global__ void __launch_bounds__(kBlock)
 k_permute(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
 {
@@ -1254,12 +1332,6 @@ k_flush_average(int n, int m, const pdlpdev_ctl* __restrict__ ctl, const double*
 __global__ void k_clear_pending(pdlpdev_ctl* ctl) { ctl->pending_avg = 0; }
 
 // plain SpMV (A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
-struct StoreEpilogue {
-  static constexpr int NQ = 0;
-  using Op = SumOp;
-  double* __restrict__ out;
-  __device__ __forceinline__ void row(int r, double v, double (&)[1]) { out[r] = v; }
-};
 __global__ void __launch_bounds__(kBlock)
 k_spmv_plain(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
              const int32_t* __restrict__ idx, const double* __restrict__ val,
@@ -1500,6 +1572,28 @@ k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalDualEpilogue e{core};
   panel_spmv_block(P, yv, e, part);
+}
+__global__ void __launch_bounds__(kPbThreads)
+k_pb_eval_primal(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
+                 const double* __restrict__ avgy, const double* __restrict__ dr, const double* __restrict__ lo_u,
+                 const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows, double* __restrict__ ax_out,
+                 double* __restrict__ part)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  const int cur    = ctl->cur;
+  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
+  pb_rows_block(V, e, part, pb_lds);
+}
+__global__ void __launch_bounds__(kPbThreads)
+k_pb_eval_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0, const double* __restrict__ x1,
+               const double* __restrict__ avgx, EvalDualCore core, double* __restrict__ part)
+{
+  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
+  const int cur = ctl->cur;
+  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  EvalDualEpilogue e{core};
+  pb_rows_block(V, e, part, pb_lds);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -2387,6 +2481,253 @@ static int jag_launch(pdlpdev_ctx* c, void (*kernel)(JagView, KArgs...), const J
 #define JAG_LAUNCH(ctx, KERNEL, VIEW, ...) \
   ((VIEW).waves == 16 ? jag_launch(ctx, KERNEL<16>, VIEW, __VA_ARGS__) : jag_launch(ctx, KERNEL<8>, VIEW, __VA_ARGS__))
 
+
+// ---- gather-free layout: host-side construction (structure only; values are permuted on the device) -----------------
+// Parallel over bins on the host pool's threads; every pass is O(nnz).  Geometry: panels of 8192 columns (16384 when the
+// gathered vector has more than 2 M entries: fewer, longer chunks), pieces of 8 entries unless the chunks (nnz / (panels x bins))
+// are shorter than 24 entries (then 4: at 1e8 nonzeros -- chunks of 13 -- 8-entry pieces pad by 33 % and run 20 % slower), bins filled to kPbCap padded entries (found by iterating on the per-bin nonzero target:
+// the padding of a bin depends on how its entries spread over the panels).
+struct PbHost {
+  bool ok = false;
+  std::string why;
+  int rows = 0, cols = 0, S = 0, B = 0, gshift = 3, panel_shift = 13, p_threads = 512;
+  int64_t np = 0, nnz = 0;
+  std::vector<int32_t> bin_row0, bin_e0, wg_e0, wg_panel, bin_grp, grp_pos;
+  cuopt_amd::PoolArray<int32_t> perm, piece_dst;
+  cuopt_amd::PoolArray<uint16_t> lidx, pos;
+  cuopt_amd::PoolArray<uint32_t> sr;
+};
+static PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced)
+{
+  PbHost H;
+  H.rows = rows, H.cols = cols;
+  const int64_t nnz = rows > 0 ? off[rows] : 0;
+  H.nnz = nnz;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) { H.why = "empty matrix"; return H; }
+  int longest = 0;
+  for (int32_t r = 0; r < rows; ++r) longest = std::max(longest, off[r + 1] - off[r]);
+  // a row is summed by ONE lane, left to right: fine up to a few hundred entries, a serial chain beyond
+  if (longest > (forced ? kPbCap / 2 : 256)) { H.why = "a row with " + std::to_string(longest) + " nonzeros"; return H; }
+  H.panel_shift = cols > (1 << 21) ? 14 : 13;
+  H.p_threads   = H.panel_shift == 14 ? 1024 : 512;
+  const int SP  = 1 << H.panel_shift;
+  const int S   = (cols + SP - 1) >> H.panel_shift;
+  H.S           = S;
+  const int threads = cuopt_amd::host_threads();
+  // bins: consecutive rows, <= target nonzeros and <= kPbMaxRows rows; the target is lowered until every bin's padded image fits
+  double target = 0.93 * kPbCap;
+  int G = 8;
+  std::vector<int32_t> row0;
+  for (int iter = 0; iter < 24; ++iter) {
+    row0.assign(1, 0);
+    while (row0.back() < rows) {
+      const int32_t r0 = row0.back();
+      const int64_t lim = (int64_t)off[r0] + (int64_t)target;
+      int32_t r1 = (int32_t)(std::upper_bound(off + r0, off + rows + 1, (int32_t)std::min<int64_t>(lim, nnz)) - off) - 1;
+      r1 = std::min(std::max(r1, r0 + 1), std::min(rows, r0 + kPbMaxRows));
+      row0.push_back(r1);
+    }
+    const int B = (int)row0.size() - 1;
+    if (iter == 0) G = nnz / ((int64_t)S * B) >= 24 ? 8 : 4;
+    std::vector<int> worst(threads * 4, 0);
+    cuopt_amd::parallel_tasks((int)worst.size(), [&](int t) {
+      std::vector<int> cnt(S, 0);
+      std::vector<int> touched;
+      int w = 0;
+      for (int b = t; b < B; b += (int)worst.size()) {
+        touched.clear();
+        int padded = 0;
+        for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) {
+          const int s_ = idx[k] >> H.panel_shift;
+          if (cnt[s_] % G == 0) padded += G;
+          if (cnt[s_]++ == 0) touched.push_back(s_);
+        }
+        for (int s_ : touched) cnt[s_] = 0;
+        w = std::max(w, padded);
+      }
+      worst[t] = w;
+    }, nnz);
+    const int maxpad = *std::max_element(worst.begin(), worst.end());
+    if (maxpad <= kPbCap) break;
+    if (iter == 23) { H.why = "bins do not converge"; return H; }
+    target *= std::min(0.97, 0.99 * (double)kPbCap / (double)maxpad);
+  }
+  H.gshift   = G == 8 ? 3 : 2;
+  H.bin_row0 = row0;
+  const int B = (int)row0.size() - 1;
+  H.B         = B;
+  // chunk sizes (bin-major), the bins' images, P order (panel-major) starts
+  cuopt_amd::PoolArray<int32_t> cnt((size_t)B * S), lstart((size_t)B * S);
+  H.bin_e0.assign(B + 1, 0);
+  std::vector<int32_t> bin_size(B);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    for (int b = t; b < B; b += threads * 4) {
+      int32_t* c = cnt.get() + (size_t)b * S;
+      std::fill(c, c + S, 0);
+      for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) c[idx[k] >> H.panel_shift]++;
+      int32_t at = 0;
+      int32_t* l = lstart.get() + (size_t)b * S;
+      for (int s_ = 0; s_ < S; ++s_) {
+        l[s_] = at;
+        at += (c[s_] + G - 1) / G * G;
+      }
+      bin_size[b] = at;
+    }
+  }, nnz);
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    H.bin_e0[b] = (int32_t)total;
+    total += bin_size[b];
+    if (total >= ((int64_t)1 << 31) - 65536) { H.why = "more than 2^31 padded entries"; return H; }
+  }
+  H.bin_e0[B] = (int32_t)total;
+  H.np        = total;
+  cuopt_amd::PoolArray<int32_t> pstart((size_t)S * B + 1);
+  {
+    int64_t at = 0;
+    for (int s_ = 0; s_ < S; ++s_)
+      for (int b = 0; b < B; ++b) {
+        pstart[(size_t)s_ * B + b] = (int32_t)at;
+        at += (cnt[(size_t)b * S + s_] + G - 1) / G * G;
+      }
+    pstart[(size_t)S * B] = (int32_t)at;
+  }
+  H.perm.reset((size_t)total + 64), H.lidx.reset((size_t)total + 64), H.piece_dst.reset((size_t)(total >> H.gshift) + 64);
+  H.pos.reset((size_t)nnz + 128), H.sr.reset((size_t)rows + 64);
+  H.bin_grp.assign(B + 1, 0);
+  for (int b = 0; b < B; ++b) H.bin_grp[b + 1] = H.bin_grp[b] + (row0[b + 1] - row0[b] + 63) / 64;
+  H.grp_pos.assign((size_t)H.bin_grp[B] + 1, 0);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    // padding slots first (a chunk's tail), then the entries
+    for (int64_t i = (int64_t)t * total / (threads * 4), e = (int64_t)(t + 1) * total / (threads * 4); i < e; ++i) H.perm[i] = -1, H.lidx[i] = 0;
+  }, total);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    std::vector<int32_t> cur(S);
+    std::vector<uint16_t> epos;
+    std::vector<int32_t> order;
+    for (int b = t; b < B; b += threads * 4) {
+      const int32_t r0 = row0[b], nr = row0[b + 1] - r0, k0 = off[r0];
+      std::fill(cur.begin(), cur.end(), 0);
+      epos.resize((size_t)(off[r0 + nr] - k0));
+      const int32_t* l = lstart.get() + (size_t)b * S;
+      for (int32_t r = r0; r < r0 + nr; ++r)
+        for (int k = off[r]; k < off[r + 1]; ++k) {
+          const int s_     = idx[k] >> H.panel_shift;
+          const int rank   = cur[s_]++;
+          const int32_t pp = pstart[(size_t)s_ * B + b] + rank;
+          H.perm[pp]       = k;
+          H.lidx[pp]       = (uint16_t)(idx[k] & (SP - 1));
+          epos[k - k0]     = (uint16_t)(l[s_] + rank);
+        }
+      // pieces of this bin's chunks
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int np_ = (cnt[(size_t)b * S + s_] + G - 1) / G;
+        const int32_t p0 = pstart[(size_t)s_ * B + b] >> H.gshift, d0 = (H.bin_e0[b] + l[s_]) >> H.gshift;
+        for (int i = 0; i < np_; ++i) H.piece_dst[p0 + i] = d0 + i;
+      }
+      // rows sorted by length (descending, stable), groups of 64, jagged diagonals of positions
+      order.resize(nr);
+      for (int i = 0; i < nr; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return off[r0 + x + 1] - off[r0 + x] > off[r0 + y + 1] - off[r0 + y]; });
+      int32_t at = k0;  // the bin's positions start where its nonzeros start
+      for (int i = 0; i < nr; ++i) H.sr[r0 + i] = ((uint32_t)(off[r0 + order[i] + 1] - off[r0 + order[i]]) << 16) | (uint32_t)order[i];
+      for (int g0 = 0, g = 0; g0 < nr; g0 += 64, ++g) {
+        H.grp_pos[H.bin_grp[b] + g] = at;
+        const int g1   = std::min(nr, g0 + 64);
+        const int kmax = off[r0 + order[g0] + 1] - off[r0 + order[g0]];
+        for (int k = 0; k < kmax; ++k)
+          for (int i = g0; i < g1; ++i) {
+            const int32_t r = r0 + order[i];
+            if (off[r + 1] - off[r] <= k) break;
+            H.pos[at++] = epos[off[r] + k - k0];
+          }
+      }
+    }
+  }, nnz);
+  H.grp_pos[H.bin_grp[B]] = (int32_t)nnz;
+  for (int i = 0; i < 128; ++i) H.pos[(size_t)nnz + i] = 0;
+  // P workgroups: every panel's entries in Q parts (pieces are not split)
+  const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
+  for (int s_ = 0; s_ < S; ++s_) {
+    const int64_t e0 = pstart[(size_t)s_ * B], e1 = pstart[(size_t)(s_ + 1) * B];
+    const int64_t per = std::max<int64_t>(G, ((e1 - e0 + Q - 1) / Q + G - 1) / G * G);
+    for (int64_t e = e0; e < e1; e += per) {
+      H.wg_e0.push_back((int32_t)e);
+      H.wg_panel.push_back(s_);
+    }
+  }
+  H.wg_e0.push_back((int32_t)total);
+  H.ok = true;
+  return H;
+}
+static int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h)
+{
+  if (!h.ok) return 0;
+  int32_t *piece_dst = nullptr, *wg_e0 = nullptr, *wg_panel = nullptr, *bin_row0 = nullptr, *bin_e0 = nullptr, *bin_grp = nullptr, *grp_pos = nullptr;
+  uint16_t *lidx = nullptr, *pos = nullptr;
+  uint32_t* sr = nullptr;
+  double* prod = nullptr;
+  TRY(upload_i32(c, &dst->perm, h.perm.get(), (size_t)h.np, 64));
+  TRY(upload_i32(c, &piece_dst, h.piece_dst.get(), (size_t)(h.np >> h.gshift), 64));
+  TRY(upload_i32(c, &wg_e0, h.wg_e0.data(), h.wg_e0.size()));
+  TRY(upload_i32(c, &wg_panel, h.wg_panel.data(), h.wg_panel.size()));
+  TRY(upload_i32(c, &bin_row0, h.bin_row0.data(), h.bin_row0.size()));
+  TRY(upload_i32(c, &bin_e0, h.bin_e0.data(), h.bin_e0.size()));
+  TRY(upload_i32(c, &bin_grp, h.bin_grp.data(), h.bin_grp.size()));
+  TRY(upload_i32(c, &grp_pos, h.grp_pos.data(), h.grp_pos.size()));
+  TRY(dev_alloc(c, &lidx, (size_t)h.np + 64));
+  HIP_TRY(hipMemcpyAsync(lidx, h.lidx.get(), (size_t)h.np * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &pos, (size_t)h.nnz + 128));
+  HIP_TRY(hipMemcpyAsync(pos, h.pos.get(), ((size_t)h.nnz + 128) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &sr, (size_t)h.rows + 64));
+  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), (size_t)h.rows * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &dst->val, (size_t)h.np + 64));
+  TRY(dev_alloc(c, &prod, (size_t)h.np + 256));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's PbHost
+  dst->v = PbView{h.rows, h.cols, h.S, h.B, h.gshift, h.panel_shift, (int)h.wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
+                  bin_row0, bin_e0, sr, bin_grp, grp_pos, pos, prod};
+  dst->np = h.np, dst->p_threads = h.p_threads, dst->pad = (double)h.np / (double)h.nnz;
+  dst->on = true;
+  return 0;
+}
+// the two launches of a gather-free SpMV: phase P with the gathered vector picked on the device (mode: see k_pb_products), ...
+static int pb_products(pdlpdev_ctx* c, const pdlpdev_ctx::Pb& L, const double* v0, const double* v1, int mode, int in_loop)
+{
+  static std::mutex mu;
+  static std::vector<std::pair<int, int>> done;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<int, int> key(L.p_threads, c->device);
+    if (std::find(done.begin(), done.end(), key) == done.end()) {
+      if (L.p_threads == 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_pb_products<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      else HIP_TRY(hipFuncSetAttribute((const void*)k_pb_products<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done.push_back(key);
+    }
+  }
+  const int grid   = (L.v.nwg + 7) & ~7;
+  const size_t lds = sizeof(double) << L.v.panel_shift;
+  if (L.p_threads == 1024) launch_k(c, k_pb_products<1024>, grid, 1024, lds, L.v, c->ctl, v0, v1, mode, in_loop);
+  else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl, v0, v1, mode, in_loop);
+  return 0;
+}
+// ... and phase R with the epilogue of the call site
+template <typename... KArgs, typename... Args>
+static int pb_rows(pdlpdev_ctx* c, void (*kernel)(PbView, KArgs...), const pdlpdev_ctx::Pb& L, Args... args)
+{
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<const void*, int> key((const void*)kernel, c->device);
+    if (std::find(done.begin(), done.end(), key) == done.end()) {
+      HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPbLdsBytes));
+      done.push_back(key);
+    }
+  }
+  launch_k(c, kernel, (L.v.B + 7) & ~7, kPbThreads, kPbLdsBytes, L.v, args...);
+  return 0;
+}
+
 static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h)
 {
   if (!h.ok) return 0;
@@ -2414,6 +2755,8 @@ static int sync_panel_values(pdlpdev_ctx* c)
   if (c->pat.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pat.perm, c->at_val, c->pat.val);
   if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->a_val, c->ja.val);
   if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->at_val, c->jat.val);
+  if (c->pba.on) k_permute_pad<<<grid_for(c->pba.np), kBlock, 0, c->stream>>>(c->pba.np, c->pba.perm, c->a_val, c->pba.val);
+  if (c->pbat.on) k_permute_pad<<<grid_for(c->pbat.np), kBlock, 0, c->stream>>>(c->pbat.np, c->pbat.perm, c->at_val, c->pbat.val);
   if (c->poc.on) k_permute<<<grid_for(c->oc_nnz), kBlock, 0, c->stream>>>(c->oc_nnz, c->poc.perm, c->oc_val, c->poc.val);
   if (c->joc.on) k_permute<<<grid_for(c->joc.nent), kBlock, 0, c->stream>>>(c->joc.nent, c->joc.perm, c->oc_val, c->joc.val);
   HIP_TRY(hipGetLastError());
@@ -2582,8 +2925,12 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     // 1.33 MiB of the gathered vector per slab: measured optimum on the 1e6 x 1e6 random LP (6 slabs: 71 us per
     // SpMV; 8 slabs of 1 MiB: 74 us; 4 slabs of 2 MiB: 75 us) -- fewer tiles per panel against L2 capacity
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
+    if (mode != "auto" && mode != "stream" && mode != "panel" && mode != "jag" && mode != "timed" && mode != "pb")
+      return fail(-1, "CUOPT_AMD_SPMV_LAYOUT must be auto, stream, panel, jag, pb or timed");
     const bool force = mode == "panel";
     const bool timed = mode == "timed";
+    // gather-free layout: on request, or (auto) where the panels would need more than their 16 slabs to keep a slab in L2
+    auto want_pb = [&](int32_t cols) { return mode == "pb" || (mode == "auto" && (int64_t)cols * 8 > 16 * slab_bytes); };
     const bool try_jag = mode == "auto" || mode == "jag" || timed;
     // auto, not jagged: panels when the CSR stream kernel's live gather set overflows what an XCD's L2 keeps of it
     const char* ws_env     = getenv("CUOPT_AMD_PANEL_WS_BYTES");
@@ -2605,7 +2952,14 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       TRY(upload_jag(ctx, &ctx->ja, ja, ctx->a_off, ctx->a_idx, ctx->a_val));
       lap("upload jag A");
     }
-    if (mode != "stream" && mode != "jag" && !ctx->ja.on && want_panels(m, n, a_offsets, a_indices, "A")) {
+    if (!ctx->ja.on && want_pb(n) && (mode == "pb" || want_panels(m, n, a_offsets, a_indices, "A"))) {
+      PbHost hb = build_pb(m, n, a_offsets, a_indices, ctx->cus, mode == "pb");
+      lap("build_pb A");
+      if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", hb.why.c_str());
+      TRY(upload_pb(ctx, &ctx->pba, hb));
+      lap("upload pb A");
+    }
+    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, a_offsets, a_indices, "A")) {
       PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force || !timed);
       lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha));
@@ -2631,7 +2985,14 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       TRY(upload_jag(ctx, &ctx->jat, jat, ctx->at_off, ctx->at_idx, ctx->at_val));
       lap("upload jag At");
     }
-    if (mode != "stream" && mode != "jag" && !ctx->jat.on && want_panels(n, m, at_offsets, at_indices, "A^T")) {
+    if (!ctx->jat.on && want_pb(m) && (mode == "pb" || want_panels(n, m, at_offsets, at_indices, "A^T"))) {
+      PbHost hb = build_pb(n, m, at_offsets, at_indices, ctx->cus, mode == "pb");
+      lap("build_pb At");
+      if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", hb.why.c_str());
+      TRY(upload_pb(ctx, &ctx->pbat, hb));
+      lap("upload pb At");
+    }
+    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->jat.on && !ctx->pbat.on && want_panels(n, m, at_offsets, at_indices, "A^T")) {
       PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force || !timed);
       lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
@@ -2647,8 +3008,8 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     if (small_env && atoi(small_env) != 0 && tier < 0)
       return fail(-1, "CUOPT_AMD_SMALL=1: the LP does not fit the resident kernel (m, n <= 2048, nnz <= 4096 ...)");
   }
-  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
-  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
+  TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pba.on ? ctx->pba.v.B : 0, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
+  TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pbat.on ? ctx->pbat.v.B : 0, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
@@ -3383,11 +3744,14 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 
 
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
-static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
-static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
+static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->pba.on ? ctx->pba.v.B : ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
+static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->pbat.on ? ctx->pbat.v.B : ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
 static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pdev::Push* push = nullptr)
 {
-  if (ctx->ja.on)
+  if (ctx->pba.on) {
+    (void)pb_products(ctx, ctx->pba, ctx->xbar, nullptr, 0, 1);
+    (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+  } else if (ctx->ja.on)
     (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else if (ctx->pa.on)
     launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
@@ -3396,7 +3760,10 @@ static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pde
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
-  if (ctx->jat.on)
+  if (ctx->pbat.on) {
+    (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 1, 1);  // y' = the trial dual
+    (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+  } else if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
@@ -3405,7 +3772,10 @@ static void launch_at_step(pdlpdev_ctx* ctx)
 }
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
-  if (ctx->jat.on)
+  if (ctx->pbat.on) {
+    (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], use_next ? 1 : 2, 0);
+    (void)pb_rows(ctx, k_pb_at_cur, ctx->pbat, ctx->ctl, ctx->aty[0], ctx->aty[1], out_override, use_next);
+  } else if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_cur, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_cur, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
@@ -3416,14 +3786,20 @@ static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, double* out)
 {
   if (transpose) {
-    if (ctx->jat.on)
+    if (ctx->pbat.on) {
+      (void)pb_products(ctx, ctx->pbat, vec, nullptr, 0, 0);
+      (void)pb_rows(ctx, k_pb_plain, ctx->pbat, out);
+    } else if (ctx->jat.on)
       (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->jat.v, vec, out);
     else if (ctx->pat.on)
       launch_k(ctx, k_panel_plain, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, vec, out);
     else
       launch_k(ctx, k_spmv_plain, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, vec, out);
   } else {
-    if (ctx->ja.on)
+    if (ctx->pba.on) {
+      (void)pb_products(ctx, ctx->pba, vec, nullptr, 0, 0);
+      (void)pb_rows(ctx, k_pb_plain, ctx->pba, out);
+    } else if (ctx->ja.on)
       (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->ja.v, vec, out);
     else if (ctx->pa.on)
       launch_k(ctx, k_panel_plain, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, vec, out);
@@ -3719,7 +4095,11 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   double* linf_m = want_linf ? ctx->tmp_m : nullptr;
   double* linf_n = want_linf ? ctx->tmp_n : nullptr;
   // layout of sc: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
-  if (ctx->ja.on)
+  if (ctx->pba.on) {
+    if (kw == PDLPDEV_AVERAGE) TRY(pb_products(ctx, ctx->pba, altx, nullptr, 0, 0));
+    else TRY(pb_products(ctx, ctx->pba, ctx->x[0], ctx->x[1], 2, 0));
+    TRY(pb_rows(ctx, k_pb_eval_primal, ctx->pba, ctx->ctl, kw, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a));
+  } else if (ctx->ja.on)
     (void)JAG_LAUNCH(ctx, k_jag_eval_primal, ctx->ja.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else if (ctx->pa.on)
     k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
@@ -3733,7 +4113,11 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   }
   EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], linf_n, ctx->aty_u[which]};
   if (!ctx->comm) {
-    if (ctx->jat.on)
+    if (ctx->pbat.on) {
+      if (kw == PDLPDEV_AVERAGE) TRY(pb_products(ctx, ctx->pbat, alty, nullptr, 0, 0));
+      else TRY(pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 2, 0));
+      TRY(pb_rows(ctx, k_pb_eval_dual, ctx->pbat, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, core, ctx->part_at));
+    } else if (ctx->jat.on)
       (void)JAG_LAUNCH(ctx, k_jag_eval_dual, ctx->jat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else if (ctx->pat.on)
       k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
@@ -4189,12 +4573,12 @@ int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column
   // sets), workgroups, slabs (panels) or percent of the global gathers the LDS sets save (jagged)
-  out[0] = ctx->ja.on ? 3 : ctx->pa.on ? 1 : 0;
-  out[1] = ctx->ja.on ? ctx->ja.v.nblk : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb;
-  out[2] = ctx->ja.on ? (int)(100.0 * ctx->ja.saving + 0.5) : ctx->pa.on ? ctx->pa.v.S : 1;
-  out[3] = ctx->jat.on ? 3 : ctx->pat.on ? 1 : 0;
-  out[4] = ctx->jat.on ? ctx->jat.v.nblk : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb;
-  out[5] = ctx->jat.on ? (int)(100.0 * ctx->jat.saving + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
+  out[0] = ctx->pba.on ? 4 : ctx->ja.on ? 3 : ctx->pa.on ? 1 : 0;
+  out[1] = ctx->pba.on ? ctx->pba.v.B : ctx->ja.on ? ctx->ja.v.nblk : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb;
+  out[2] = ctx->pba.on ? (int)(100.0 * (ctx->pba.pad - 1.0) + 0.5) : ctx->ja.on ? (int)(100.0 * ctx->ja.saving + 0.5) : ctx->pa.on ? ctx->pa.v.S : 1;
+  out[3] = ctx->pbat.on ? 4 : ctx->jat.on ? 3 : ctx->pat.on ? 1 : 0;
+  out[4] = ctx->pbat.on ? ctx->pbat.v.B : ctx->jat.on ? ctx->jat.v.nblk : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb;
+  out[5] = ctx->pbat.on ? (int)(100.0 * (ctx->pbat.pad - 1.0) + 0.5) : ctx->jat.on ? (int)(100.0 * ctx->jat.saving + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
   if (ctx->small_resident) out[0] = out[3] = 2;
   return 0;
 }

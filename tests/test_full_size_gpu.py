@@ -89,3 +89,53 @@ def test_banded_lp_at_full_size_through_the_jagged_layout():
     r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 2e-4 * (1.0 + abs(p["objective_star"]))
+
+
+def test_gather_free_layout_at_full_size(c3, monkeypatch):
+    """the gather-free layout on C3 itself (122 panels x ~1150 bins per side): both products bit-identical to the oracle's,
+    same decisions as the panels over the first major iterations"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(c3["n"]), rng.standard_normal(c3["m"])
+    to, ti, tv = orcbind.transpose(c3["m"], c3["n"], c3["offsets"], c3["indices"], c3["values"])
+    dev = capi.Device(c3)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "pb" and lay["A"]["padding_pct"] <= 10
+    np.testing.assert_array_equal(dev.spmv(x, False, c3["m"]), orcbind.spmv(c3["offsets"], c3["indices"], c3["values"], x))
+    np.testing.assert_array_equal(dev.spmv(y, True, c3["n"]), orcbind.spmv(to, ti, tv, y))
+    dev.close()
+    got = {}
+    for layout in ("panel", "pb"):
+        monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
+        s = capi.Solver(c3, tol=0.0, iteration_limit=120)
+        r = s.advance()
+        got[layout] = (r["steps_taken"], r["attempted_steps"], r["num_restarts"], r["primal_objective"], r["step_size"])
+        s.close()
+    assert got["panel"][:3] == got["pb"][:3]
+    assert got["panel"][3] == pytest.approx(got["pb"][3], rel=1e-9) and got["panel"][4] == pytest.approx(got["pb"][4], rel=1e-9)
+
+
+def test_auto_takes_the_gather_free_layout_beyond_sixteen_slabs(monkeypatch):
+    """3e6 x 3e6, 3e7 nonzeros, uniformly random columns: the gathered vector (24 MB) is more than the panel layout's 16 slabs
+    can keep L2-resident, auto builds the gather-free layout (16384-column panels, 4-entry pieces); A x bit-identical to the
+    oracle's, the solve reaches the constructed optimum, and it takes the decisions the panels take"""
+    monkeypatch.delenv("CUOPT_AMD_SPMV_LAYOUT", raising=False)
+    p = synthetic.generate(3_000_000, 3_000_000, 10, seed=9)
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "pb"
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(p["n"])
+    np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
+    dev.close()
+    r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
+    assert r["status"] == "Optimal", (r["status"], r["steps_taken"])
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-4 * (1.0 + abs(p["objective_star"]))
+    got = {}
+    for layout in ("panel", "pb"):
+        monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
+        s = capi.Solver(p, tol=0.0, iteration_limit=120)
+        q = s.advance()
+        got[layout] = (q["steps_taken"], q["attempted_steps"], q["num_restarts"], q["primal_objective"])
+        s.close()
+    assert got["panel"][:3] == got["pb"][:3] and got["panel"][3] == pytest.approx(got["pb"][3], rel=1e-9)

@@ -1,0 +1,65 @@
+"""GPU: the gather-free SpMV layout ("pb", pdlp_kernels.hpp): several source panels and bins, both piece sizes, both panel
+widths, the automatic choice for gathered vectors beyond the panels' 16 slabs, a full solve."""
+import numpy as np
+import pytest
+
+from cuopt_amd import capi, synthetic
+from oracle import orcbind
+
+pytestmark = pytest.mark.gpu
+
+
+def _both_products_bit_exact(p, dev, seed=1):
+    rng = np.random.default_rng(seed)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    np.testing.assert_array_equal(dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x))
+    np.testing.assert_array_equal(dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y))
+
+
+@pytest.mark.parametrize("shape", [(60000, 50000, 10), (200000, 30000, 3), (30000, 200000, 16)], ids=["square", "tall", "wide"])
+def test_products_are_bit_exact_and_the_solve_reaches_the_optimum(shape, monkeypatch):
+    """several 8192-column panels and dozens of bins on both sides; chunks of a few entries (4-entry pieces) on the tall / wide
+    matrices, longer ones (8-entry pieces) on the square one"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    m, n, k = shape
+    p = synthetic.generate(m, n, k, seed=23)
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "pb" and lay["A"]["workgroups"] > 8
+    _both_products_bit_exact(p, dev)
+    r = capi.solve(p, method=1, tol=1e-6)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+    # the same decisions as the CSR stream layout over the first iterations (only the grouping of the reduction partials differs)
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "stream")
+    a = capi.Solver(p, tol=0.0, iteration_limit=40).advance()
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    b = capi.Solver(p, tol=0.0, iteration_limit=40).advance()
+    assert (a["steps_taken"], a["attempted_steps"]) == (b["steps_taken"], b["attempted_steps"])
+    assert b["step_size"] == pytest.approx(a["step_size"], rel=1e-9)
+
+
+def test_rows_of_every_length_and_empty_rows(monkeypatch):
+    """empty rows, rows of hundreds and of two thousand nonzeros: one lane adds up its row left to right, so EVERY row -- not only
+    those up to 128 nonzeros as in the other layouts -- is bit-identical to the sequential sum"""
+    from test_kernels_gpu import ragged_problem
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    p = ragged_problem(m=3000, n=2500)
+    dev = capi.Device(p)
+    assert dev.layout()["A"]["layout"] == "pb"
+    _both_products_bit_exact(p, dev)
+
+
+def test_a_matrix_the_layout_cannot_hold_is_refused_loudly(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    rng = np.random.default_rng(0)
+    m, n = 50, 9000
+    lens = np.full(m, 4)
+    lens[7] = 8000  # more than half a bin in one row
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int32)
+    p = dict(m=m, n=n, offsets=off, indices=idx, values=rng.standard_normal(off[-1]), c=np.ones(n), lo=np.full(m, -1.0), hi=np.full(m, 1.0),
+             lb=np.zeros(n), ub=np.ones(n))
+    with pytest.raises(Exception, match="gather-free"):
+        capi.Device(p)

@@ -1,6 +1,8 @@
 """GPU: the slab-major row-panel SpMV layout (used when the gathered vector overflows an XCD's L2) and the
 sorted jagged-row layout with LDS column windows (used for structured matrices) must give the same numbers
-as the CSR stream layout: bit-exact rows (every row is still summed left to right), same PDLP decisions."""
+as the CSR stream layout: bit-exact rows (every row is still summed left to right), same PDLP decisions.  So must the
+gather-free layout ("pb": products streamed through LDS-resident slices of the vector, rows summed from an LDS image of their
+products; tools/spmv_pb.hip), which sums EVERY row left to right whatever its length."""
 import numpy as np
 import pytest
 
@@ -11,8 +13,8 @@ from test_kernels_gpu import ragged_problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20), ("jag", 8), ("jag", 16)],
-                ids=["panel-4KiB-slabs", "panel-1slab", "stream", "jag-8-waves", "jag-16-waves"])
+@pytest.fixture(params=[("panel", 4096), ("panel", 1 << 20), ("stream", 1 << 20), ("jag", 8), ("jag", 16), ("pb", 1 << 20)],
+                ids=["panel-4KiB-slabs", "panel-1slab", "stream", "jag-8-waves", "jag-16-waves", "gather-free"])
 def layout(request, monkeypatch):
     mode, slab = request.param
     if mode == "jag":  # both geometries of the jagged layout (8 waves / 8192-column window, 16 waves / 16384)
