@@ -757,6 +757,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     }
     cuoptamd_result res{};
     double first_attempt_seconds = 0.0;
+    int32_t first_attempt_steps = 0, first_attempt_attempts = 0;  // work of a simplex-grade attempt that a second solve followed
     std::string answered = simplex_grade && tightened ? "simplex_grade_1e-8" : "requested_tolerances";
     sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
     if (gpus > 1) {
@@ -783,6 +784,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
         // the tight attempt ended on a limit and no iterate met even the requested tolerances: whatever is left of the
         // caller's limits goes to a plain solve at the requested tolerances (same solver object: matrices and scaling kept)
         first_attempt_seconds = res.setup_seconds + res.loop_seconds;
+        first_attempt_steps = res.steps_taken, first_attempt_attempts = res.attempted_steps;
         cuoptamd_settings st_rest = st_user;
         if (st_user.iteration_limit != INT_MAX) st_rest.iteration_limit = std::max(0, st_user.iteration_limit - res.steps_taken);
         if (std::isfinite(st_rest.time_limit)) st_rest.time_limit = std::max(0.0, st_rest.time_limit - first_attempt_seconds);
@@ -806,11 +808,17 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       char info[512];
       std::snprintf(info, sizeof info,
                     "{\"engine\": \"pdlp\", \"requested_method\": \"%s\", \"crossover_requested\": %s, \"simplex_grade_emulation\": %s, "
-                    "\"answered_by\": \"%s\", \"gpus\": %d, \"iterations\": %d}",
-                    method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false", answered.c_str(), gpus, res.steps_taken);
+                    "\"answered_by\": \"%s\", \"gpus\": %d, \"iterations\": %d, \"simplex_grade_attempt_iterations\": %d}",
+                    method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false", answered.c_str(), gpus,
+                    res.steps_taken + (answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0),
+                    answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0);
       sol->solve_info = info;
       if (other_method || s->crossover) say("cuopt_amd: " + sol->solve_info + "\n");
     }
+    // a second solve after the simplex-grade budget starts over (its trajectory at the looser tolerances is a different one):
+    // the iterations of BOTH are what the call cost, and that is what the statistics and the solve info report
+    if (answered != "requested_tolerances_after_simplex_grade_budget") first_attempt_steps = first_attempt_attempts = 0;
+    res.steps_taken += first_attempt_steps, res.attempted_steps += first_attempt_attempts;
     res.setup_seconds += first_attempt_seconds;
     sol->stats              = res;
     sol->termination_status = res.status;

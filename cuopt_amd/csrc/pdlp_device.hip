@@ -406,6 +406,9 @@ struct pdlpdev_ctx {
   // dispatch itself, what rocprofv3 --kernel-trace reports)
   bool prof_armed = false;
   hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+  unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
+  bool ticket_decision = false;
+  int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
   // graphs
   int use_graph = 1;
   char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
@@ -945,6 +948,66 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   if (t != 0) return;
   apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
   *ctl = lc;
+}
+
+// The decision in the TAIL of the A^T y' kernel (CUOPT_AMD_TICKET_DECISION=1, round-2 review item 8): every workgroup publishes
+// its partial sums (agent-scope release by the thread that wrote them) and takes a ticket; the workgroup that draws the last
+// one acquires, finishes the three sums in a fixed order and applies the rule -- no all-wait barrier, one launch less.
+struct DecisionTail {
+  unsigned* ticket;  // null: the decision stays in its own kernel
+  const double* part_dy;
+  int nb_dy;
+  pdlpdev_step_params sp;
+};
+template <int THREADS>
+__device__ __forceinline__ void decision_tail(pdlpdev_ctl* __restrict__ ctl, const DecisionTail& T, double* __restrict__ part_t, int nb_t, int my_part,
+                                              double* scratch /* >= 3 * 16 + 2 doubles of LDS, free at this point */)
+{
+  __shared__ int is_last;
+  __syncthreads();  // the workgroup's partials are written (thread 0), everybody is done with `scratch`
+  if (threadIdx.x == 0) {
+    // publish this workgroup's two partials write-through (system-scope stores: no L2 write-back of the whole XCD as an
+    // agent-scope release fence would cost -- measured: +13 us per attempt), wait for them, then take the ticket
+    if (my_part < nb_t) {
+      __hip_atomic_store(part_t + my_part, part_t[my_part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(part_t + nb_t + my_part, part_t[nb_t + my_part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(T.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x == 0) *T.ticket = 0;
+  double* pw = scratch + 3 * 16;
+  const int k = ctl->k;
+  if (threadIdx.x == THREADS - 1 || threadIdx.x == THREADS - 2) {
+    const double knext = (double)(k + 1) + 1.0;
+    pw[threadIdx.x - (THREADS - 2)] = pow(knext, threadIdx.x == THREADS - 2 ? -T.sp.reduction_exponent : -T.sp.growth_exponent);
+  }
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < T.nb_dy; i += THREADS) acc[0] += T.part_dy[i];  // the previous kernel's: ordinary loads
+  for (int i = threadIdx.x; i < nb_t; i += THREADS) {
+    acc[1] += __hip_atomic_load(part_t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    acc[2] += __hip_atomic_load(part_t + nb_t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  block_sum_fast<3, THREADS / 64>(acc, scratch);
+  if (threadIdx.x != 0) return;
+  pdlpdev_ctl lc = *ctl;
+  apply_step_decision(&lc, acc[0], acc[1], acc[2], T.sp, pw);
+  *ctl = lc;
+}
+__global__ void __launch_bounds__(kBlock)
+k_spmv_at_step_decide(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                      const double* __restrict__ val, pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
+                      const double* __restrict__ y1, const double* __restrict__ x0, const double* __restrict__ x1,
+                      double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part, DecisionTail T)
+{
+  __shared__ double tail_scratch[3 * 16 + 2];
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
+  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part);
+  decision_tail<kBlock>(ctl, T, part, nb, xcd_remap(blockIdx.x, nb), tail_scratch);
 }
 
 // direct peer transport of a sharded solve: wait for every rank's three step-size sums (landed in this rank's block), add them
@@ -3014,6 +3077,11 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
   TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + kSlicePad));
+  TRY(dev_alloc(ctx, &ctx->ticket, 4));
+  {
+    const char* tk = getenv("CUOPT_AMD_TICKET_DECISION");
+    ctx->ticket_decision = tk && atoi(tk) == 1;
+  }
   lap("partial buffers");
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
@@ -3505,6 +3573,7 @@ int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const do
 {
   HIP_TRY(hipSetDevice(ctx->device));
   if (!ctx->scaled) return fail(-1, "pdlpdev_reset: the problem has not been scaled yet");
+  ctx->rejected_in_a_row = 0;
   hipStream_t s = ctx->stream;
   const size_t nb = (size_t)ctx->n * sizeof(double), mb = (size_t)ctx->m * sizeof(double);
   auto put = [&](const double* src, double* unscaled, double* scaled, size_t bytes) -> int {
@@ -3896,8 +3965,14 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
   launch_a_dual(ctx);
   if (!ctx->comm) {
-    launch_at_step(ctx);
-    launch_decision(ctx);
+    if (ctx->ticket_decision && !ctx->pbat.on && !ctx->jat.on && !ctx->pat.on) {
+      DecisionTail T{ctx->ticket, ctx->part_a, dual_partials(ctx), ctx->sp};
+      launch_k(ctx, k_spmv_at_step_decide, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl,
+               ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, T);
+    } else {
+      launch_at_step(ctx);
+      launch_decision(ctx);
+    }
   } else {
     // partial A^T y' of this row block -> ar_buf[0..n), ||dy||^2 partial -> ar_buf[n]; ONE all-reduce
     launch_at_cur(ctx, ctx->ar_buf, 1);
@@ -3983,9 +4058,12 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
     }
     const int before = ctx->ctl_h->steps_taken, asked = target_steps - before;
     TRY(fetch_ctl(ctx, nullptr));
-    // every rejection shrinks the step size; 64 in a row (a whole round without one accepted step) leave nothing of it:
-    // report it like the reference's invalid step size instead of re-enqueueing forever
-    if (ctx->ctl_h->error == 0 && ctx->ctl_h->steps_taken == before && asked >= 64) {
+    // every rejection shrinks the step size; 64 in a row leave nothing of it: report it like the reference's invalid step
+    // size instead of re-enqueueing forever.  Counted across rounds AND calls (a call asks for at most one major-iteration
+    // period: 40 steps under Stable2, fewer than 64)
+    ctx->rejected_in_a_row = ctx->ctl_h->steps_taken == before ? ctx->rejected_in_a_row + asked : 0;
+    if (ctx->ctl_h->error == 0 && ctx->rejected_in_a_row >= 64) {
+      ctx->rejected_in_a_row = 0;
       k_set_error<<<1, 1, 0, ctx->stream>>>(ctx->ctl);
       LAUNCH_CHECK();
       TRY(fetch_ctl(ctx, nullptr));
