@@ -966,6 +966,97 @@ static void run_fused(const FusedConfig& c, const Csr& a, const Csr& at, Side& A
   for (void* p : {(void*)d_row0, (void*)d_tp, (void*)d_rp, (void*)d_rb, (void*)d_col, (void*)d_val}) CK(hipFree(p));
 }
 
+// rows [r0, r1) of a as a matrix of its own
+static Csr sub_rows(const Csr& a, int r0, int r1)
+{
+  Csr s;
+  s.rows = r1 - r0, s.cols = a.cols;
+  s.off.resize(s.rows + 1);
+  for (int i = 0; i <= s.rows; ++i) s.off[i] = a.off[r0 + i] - a.off[r0];
+  s.idx.assign(a.idx.begin() + a.off[r0], a.idx.begin() + a.off[r1]);
+  s.val.assign(a.val.begin() + a.off[r0], a.val.begin() + a.off[r1]);
+  return s;
+}
+
+// HYBRID: the two designs are bound by different resources (the gather kernel by the texture-address path and the L2 miss
+// slots, the gather-free pair by HBM bandwidth), so the first `share` of the rows goes through the gather kernel on one stream
+// while the rest goes through P + R on a second one.  Rows are independent: every row is still summed left to right.
+static void run_hybrid(double share, int W, const Csr& a, Side& A, int reps)
+{
+  const int rs = (int)((double)a.rows * share);
+  Csr top = sub_rows(a, 0, rs), bot = sub_rows(a, rs, a.rows);
+  SlabHost sh = build_slabs(top, W, 6);
+  int max_rows = 0;
+  for (int w = 0; w < sh.W; ++w) max_rows = std::max(max_rows, sh.row0[w + 1] - sh.row0[w]);
+  Config pc{8192, 4, 9088, 8, 512, 512, false, false, ""};
+  PbHost hb = build_pb(bot, uniform_panels(bot.cols, pc.SP), pc.cap, pc.G, pc.Q, max_rows_of(pc));
+  PbDev db = to_device(hb);
+  int* d_row0 = upload(sh.row0); int* d_tp = upload(sh.tile_ptr); int* d_rp = upload(sh.rowptr);
+  int64_t* d_rb = upload(sh.rp_base); int* d_col = upload(sh.col); double* d_val = upload(sh.val);
+  restore(A);
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  hipEvent_t fork, join, e0, e1;
+  CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  Streams st{A.a, A.b, A.c, A.d, A.y + rs, A.part, 0.01, 0.5};
+  constexpr int CH = 4096;
+  CK(hipFuncSetAttribute((const void*)k_slab<512, CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_pb_p<512, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_pb_r<512, 0, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  auto gather_part = [&](hipStream_t s) {
+    k_slab<512, CH, false><<<sh.W, 512, (size_t)(CH + max_rows) * 8, s>>>(sh.S, d_row0, d_tp, d_rp, d_rb, d_col, d_val, A.x, A.y, db.v, db.prod);
+  };
+  auto pb_part = [&](hipStream_t s) {
+    k_pb_p<512, 4, false><<<(db.nwg + 7) / 8 * 8, 512, (size_t)db.v.max_panel * 8, s>>>(db.v, A.x, db.prod);
+    k_pb_r<512, 0, 16, false><<<(db.v.B + 7) / 8 * 8, 512, (size_t)(db.v.cap + hb.max_bin_rows + 128) * 8, s>>>(db.v, db.prod, st);
+  };
+  auto timeit = [&](int mode) {  // 0: both parts one after the other on one stream, 1: concurrently, gather first, 2: concurrently, P first
+    for (int rep = -3; rep < reps; ++rep) {
+      if (rep == 0) CK(hipEventRecord(e0, s1));
+      k_elementwise<<<2048, 256, 0, s1>>>(a.cols, A.a, A.b, A.c, A.d, A.d, A.c, A.b);
+      if (mode == 0) {
+        gather_part(s1);
+        pb_part(s1);
+      } else {
+        CK(hipEventRecord(fork, s1));
+        CK(hipStreamWaitEvent(s2, fork, 0));
+        if (mode == 1) { gather_part(s1); pb_part(s2); }
+        else { pb_part(s2); gather_part(s1); }
+        CK(hipEventRecord(join, s2));
+        CK(hipStreamWaitEvent(s1, join, 0));
+      }
+    }
+    CK(hipEventRecord(e1, s1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / reps;
+  };
+  // correctness first (sequential mode)
+  k_elementwise<<<1, 1, 0, s1>>>(0, A.a, A.b, A.c, A.d, A.d, A.c, A.b);
+  gather_part(s1);
+  pb_part(s1);
+  CK(hipStreamSynchronize(s1));
+  const bool ok = check(A.y, A.ref, "hybrid A x");
+  const double t_seq = timeit(0), t_con = timeit(1), t_con2 = timeit(2);
+  // the element-wise kernel alone, to subtract
+  CK(hipEventRecord(e0, s1));
+  for (int rep = 0; rep < reps; ++rep) k_elementwise<<<2048, 256, 0, s1>>>(a.cols, A.a, A.b, A.c, A.d, A.d, A.c, A.b);
+  CK(hipEventRecord(e1, s1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double t_el = ms * 1e3 / reps;
+  printf("HYBRID gather share %.2f (W %4d panels) + gather-free %.2f | one after the other %6.1f us, concurrent %6.1f us (gather launched first) / %6.1f us (P first)  [element-wise kernel %.1f us subtracted] %s\n",
+         share, W, 1.0 - share, t_seq - t_el, t_con - t_el, t_con2 - t_el, t_el, ok ? "ok" : "WRONG");
+  fflush(stdout);
+  release(db);
+  for (void* q : {(void*)d_row0, (void*)d_tp, (void*)d_rp, (void*)d_rb, (void*)d_col, (void*)d_val}) CK(hipFree(q));
+  CK(hipStreamDestroy(s1)); CK(hipStreamDestroy(s2));
+}
+
 int main(int argc, char** argv)
 {
   const int m    = argc > 1 ? atoi(argv[1]) : 1000000;
@@ -1025,6 +1116,12 @@ int main(int argc, char** argv)
   Side A = make_side(a, 77), At = make_side(at, 78);
   if (mode == "prof") {
     run_config(configs[which], a, at, A, At, reps, true);
+    return 0;
+  }
+  if (mode == "hybrid") {
+    run_hybrid(1.0, 512, a, A, reps);
+    for (double share : {0.8, 0.7, 0.6, 0.5, 0.4})
+      for (int W : {512, 384, 256}) run_hybrid(share, W, a, A, reps);
     return 0;
   }
   if (mode == "proffused") {
