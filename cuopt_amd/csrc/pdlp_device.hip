@@ -239,16 +239,19 @@ struct Push {
   unsigned* ticket;
   __device__ __forceinline__ double* slot(int q) const { return reinterpret_cast<double*>(P.base[q] + dst_off); }
 };
-// Called by EVERY workgroup at the end of a producing kernel: once all stores of the grid are out (system-scope fence, then a
-// ticket), the last workgroup advances this rank's epoch of the exchange and raises its flag in every rank's block.
+// A producing kernel's store into a landing block: system scope = write-through, so that publishing needs no cache write-back
+__device__ __forceinline__ void put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Called by EVERY workgroup at the end of a producing kernel: every thread waits for its own write-through stores, the
+// workgroup takes a ticket, and the workgroup that draws the last one advances this rank's epoch of the exchange and raises
+// its flag in every rank's block.  (A system-scope fence per thread instead -- the first version -- cost 380 us per attempt at
+// C3: every fence is a write-back of the XCD's L2.)
 __device__ __forceinline__ void publish(const Push* T)
 {
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x != 0) return;
-  if (atomicAdd(&T->ticket[T->kind], 1u) != gridDim.x - 1) return;
-  __threadfence_system();
-  T->ticket[T->kind]         = 0;
+  if (__hip_atomic_fetch_add(&T->ticket[T->kind], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+  __hip_atomic_store(&T->ticket[T->kind], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long e = T->epoch[T->kind] + 1;
   T->epoch[T->kind]          = e;
   for (int q = 0; q < T->world; ++q) {
@@ -256,7 +259,8 @@ __device__ __forceinline__ void publish(const Push* T)
     __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-// lane q waits for rank q's flag of exchange `kind`; false when patience ran out (5 s: a peer died)
+// lane q waits for rank q's flag of exchange `kind` (relaxed polls), then ONE lane acquires for the workgroup; false when
+// patience ran out (5 s: a peer died)
 __device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int world, int kind, const unsigned long long* epoch)
 {
   bool ok = true;
@@ -264,7 +268,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int 
     const unsigned long long want = epoch[kind];
     const unsigned long long* f   = flags + (size_t)kind * world + threadIdx.x;
     const unsigned long long t0   = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
       __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > 500000000ull) {  // 100 MHz
         ok = false;
@@ -272,7 +276,10 @@ __device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int 
       }
     }
   }
-  return __syncthreads_and(ok);
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0) __threadfence_system();
+  __syncthreads();
+  return ok;
 }
 // wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles).  Every
 // workgroup polls for itself (local memory, one load per rank per poll); patience is bounded: a peer that never arrives sets
@@ -286,8 +293,12 @@ __global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ ctl, dou
     if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
     return;
   }
-  __threadfence_system();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(land + i);
+  // (count is a multiple of 16 entries and both buffers are 256-byte aligned: 16-byte requests)
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const v2* __restrict__ src2 = reinterpret_cast<const v2*>(land);
+  v2* __restrict__ dst2       = reinterpret_cast<v2*>(dst);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < (count >> 1); i += gridDim.x * 256) dst2[i] = __builtin_nontemporal_load(src2 + i);
+  if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[count - 1] = land[count - 1];
 }
 }  // namespace p2pdev
 
@@ -740,7 +751,7 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
     const double xb       = next - xj + next;
     xbar[j]               = xb;
     if (push)  // sharded solve, direct peer transport: this rank's slice of xbar lands in every rank's block
-      for (int q = 0; q < push->world; ++q) push->slot(q)[j] = xb;
+      for (int q = 0; q < push->world; ++q) p2pdev::put(push->slot(q) + j, xb);
     if (pend) sumx[j] = sumx[j] + weight * xj;
   }
   if (push) p2pdev::publish(push);
@@ -775,7 +786,7 @@ struct DualEpilogue {
     yn[i]           = next;
     if (copy) copy[i] = next;
     if (push)
-      for (int q = 0; q < push->world; ++q) push->slot(q)[i] = next;
+      for (int q = 0; q < push->world; ++q) p2pdev::put(push->slot(q) + i, next);
     const double dy = next - yi;
     acc[0] += dy * dy;
     if (pend) sumy[i] = o.sum + weight * yi;
@@ -1021,7 +1032,6 @@ k_step_decision_p2p(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ la
     if (threadIdx.x == 0) *fault = 1, ctl->error = 1;
     return;
   }
-  __threadfence_system();
   if (threadIdx.x != 0) return;
   double sum[3] = {0.0, 0.0, 0.0};
   for (int q = 0; q < world; ++q)
@@ -1477,7 +1487,7 @@ k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __
     if (push)
       for (int q = 0; q < push->world; ++q) {
         double* d = push->slot(q);
-        d[0] = acc[0], d[1] = acc[1], d[2] = acc[2];
+        p2pdev::put(d, acc[0]), p2pdev::put(d + 1, acc[1]), p2pdev::put(d + 2, acc[2]);
       }
   }
   if (push) p2pdev::publish(push);
@@ -3915,7 +3925,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
       const int W = ctx->world;
       const unsigned long long* flags = reinterpret_cast<const unsigned long long*>(P.base + P.off_f);
       auto pull = [&](int kind, double* dst, size_t land_off, int count) {
-        const int g = std::max(1, std::min((count + 4095) / 4096, 128));
+        const int g = std::max(1, std::min((count + 2047) / 2048, 1024));
         launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, flags, W, kind, P.epoch, P.fault);
       };
       pull(0, ctx->xbar, P.off_x, W * ctx->slice);

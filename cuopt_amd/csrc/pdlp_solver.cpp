@@ -880,7 +880,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   lap("scaling_compute");
   DEV(pdlpdev_scale_problem(s->dev));
   lap("scale_problem");
-  if (world > 1 && pdlpdev_shard_dataflow(s->dev) == 3) {
+  if (comm_id && pdlpdev_shard_dataflow(s->dev) == 3) {  // (also with ONE rank behind a communicator: bench.py --force-comm)
     // owner-computes dataflow: this rank's columns of A over ALL rows (rows of the global A^T), cut from the caller's CSR
     int32_t cb = 0, nc = 0;
     DEV(pdlpdev_owner_slice(s->dev, &cb, &nc));

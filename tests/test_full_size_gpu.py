@@ -139,3 +139,26 @@ def test_auto_takes_the_gather_free_layout_beyond_sixteen_slabs(monkeypatch):
         got[layout] = (q["steps_taken"], q["attempted_steps"], q["num_restarts"], q["primal_objective"])
         s.close()
     assert got["panel"][:3] == got["pb"][:3] and got["panel"][3] == pytest.approx(got["pb"][3], rel=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["powerlaw", "block_angular"])
+def test_long_row_families_at_full_size(kind):
+    """bench.py --workload powerlaw / block_angular (1e6 x 1e6, ~1e7 nnz; rows of up to 20 000 / 5 000 nonzeros): the layout auto
+    picks -- panels with wave-shared long rows / jagged rows with long-row workgroups -- against the oracle's CSR sums (rows of at
+    most 128 nonzeros bit-exact, longer ones to the fixed-tree tolerance), <A x, y> = <x, A^T y>, and a solve to 1e-4 against the
+    optimum known by construction"""
+    p = synthetic.generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7)
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    dev = capi.Device(p)
+    ax, aty = dev.spmv(x, False, p["m"]), dev.spmv(y, True, p["n"])
+    for got, ref, lens in ((ax, orcbind.spmv(p["offsets"], p["indices"], p["values"], x), np.diff(p["offsets"])),
+                           (aty, orcbind.spmv(to, ti, tv, y), np.diff(to))):
+        np.testing.assert_array_equal(got[lens <= 128], ref[lens <= 128])
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
+    assert float(ax @ y) == pytest.approx(float(x @ aty), rel=1e-10)
+    dev.close()
+    r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 1e-3 * (1.0 + abs(p["objective_star"]))

@@ -53,7 +53,7 @@ def run_child(world, its, tol, transport):
     return d["out"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_direct_peer_transport_walks_the_path_of_the_collectives(world):
     """same decisions, same iterates (bit for bit: both transports add the ranks' three step-size sums in rank order), at a
     fixed budget and to the optimum; slices that do not divide n"""
