@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "c3x10"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
@@ -145,7 +145,7 @@ def main():
 
     comm_id = fresh_comm_id()
 
-    structured = args.workload in ("staircase", "block_angular", "powerlaw", "multiband")
+    structured = args.workload in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
     if args.workload == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)
     elif structured:

@@ -283,6 +283,7 @@ _proto("pdlpdev_synchronize", c_int, c_void_p)
 _proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
 _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
 _proto("pdlpdev_shard_transport", c_int, c_void_p)
+_proto("pdlpdev_dense_info", c_int, c_void_p, c_void_p)
 _proto("pdlpdev_layout_info", c_int, c_void_p, c_void_p)
 
 # ids of pdlp_device.h
@@ -805,6 +806,11 @@ class Device:
                 d["slabs"] = int(out[k + 2])
             return d
         return dict(A=side(0), At=side(3), resident=bool(out[0] == 2))
+
+    def dense_info(self):
+        out = np.zeros(3, np.int64)
+        self._ck(lib.pdlpdev_dense_info(self.handle, _ptr(out)))
+        return dict(on=bool(out[0]), segments=int(out[1]), entries=int(out[2]))
 
     def time_kernel(self, kernel, reps=20):
         ms = c_double()

@@ -336,6 +336,30 @@ struct pdlpdev_ctx {
     int64_t nent  = 0;
     double saving = 0.0;      // share of the global gathers the LDS column sets save (build_jag)
   } ja, jat;
+  // Dense row segments (runs of >= kDenseMin consecutive columns inside a row: budget / convexity / linking constraints that
+  // run through a block of variables) are stored INDEX-FREE, 8 bytes per entry instead of 12, and multiplied by two streaming
+  // kernels of their own (k_dense_rows: lane <-> entry, the vector read coalesced; k_dense_cols: lane <-> column, the rows that
+  // cover it in ascending order); the four layouts then work on the sparse remainder ("hot" CSR: ha_* / hat_*, the matrices
+  // without the segments' entries) and add what the segments contribute ahead of their fused epilogues (dense_plus).  The
+  // set-up kernels (norms, scaling) keep running on the full CSR.  Rows / columns a segment touches are compared with the
+  // oracle at the long-row tolerance (their sums are split in two).
+  struct Dense {
+    bool on = false;
+    int nrows = 0, nseg = 0, ntiles = 0;
+    int64_t nent = 0;
+    int32_t *row = nullptr, *row_seg = nullptr;  // rows that own segments, their segment ranges
+    int32_t *seg_row = nullptr, *seg_c0 = nullptr, *seg_len = nullptr, *seg_ptr = nullptr;  // nseg (+1)
+    int32_t *ch_seg = nullptr, *ch_k0 = nullptr, *row_ch = nullptr;  // chunks of the segments (k_dense_rows), per owning row
+    double* ch_part = nullptr;
+    int nchunks = 0;
+    int32_t *tile_ptr = nullptr, *tile_seg = nullptr, *tile_id = nullptr;  // per 256-column tile some segment overlaps: those segments, ascending rows
+    int32_t *perm = nullptr, *s_perm_a = nullptr, *s_perm_at = nullptr;  // positions in the FULL CSR of A / A / A^T
+    double* val = nullptr;                   // nent: the segments' values, row after row
+    double *add_m = nullptr, *add_n = nullptr;  // what the segments contribute to A v (per row) / A^T v (per column)
+    int64_t hot_nnz = 0;
+  } dense;
+  int32_t *ha_off = nullptr, *ha_idx = nullptr, *hat_off = nullptr, *hat_idx = nullptr;  // the CSR the hot loop multiplies:
+  double *ha_val = nullptr, *hat_val = nullptr;                                          // a_* / at_* unless dense.on
   // gather-free layout (fourth layout: huge unstructured matrices; pdlp_kernels.hpp "pb")
   struct Pb {
     bool on = false;
@@ -415,8 +439,11 @@ struct pdlpdev_ctx {
   } p2p;
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
+  // (a call site may consist of several launches -- dense segments, phase P, phase R: each gets its own pair, the durations add up)
   bool prof_armed = false;
-  hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+  static constexpr int kProfPairs = 4;
+  hipEvent_t prof_ev[2 * kProfPairs] = {};
+  int prof_used = 0;
   unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
   bool ticket_decision = false;
   int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
@@ -799,13 +826,13 @@ k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
               double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
-              const p2pdev::Push* __restrict__ push)
+              const p2pdev::Push* __restrict__ push, const double* __restrict__ dadd)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0, ycopy, push};
-  csr_stream_block(nb, rb, off, idx, val, xbar, e, part);
+  csr_stream_block(nb, rb, off, idx, val, xbar, e, part, dadd);
   if (push) p2pdev::publish(push);
 }
 
@@ -838,12 +865,12 @@ k_spmv_at_step(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict
                const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
                const double* __restrict__ y1, const double* __restrict__ x0,
                const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
-               double* __restrict__ part)
+               double* __restrict__ part, const double* __restrict__ dadd)
 {
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part);
+  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part, dadd);
 }
 
 // multi-GPU variant of (3): after the all-reduce of the A^T y' partial products
@@ -1011,13 +1038,13 @@ __global__ void __launch_bounds__(kBlock)
 k_spmv_at_step_decide(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                       const double* __restrict__ val, pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
                       const double* __restrict__ y1, const double* __restrict__ x0, const double* __restrict__ x1,
-                      double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part, DecisionTail T)
+                      double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part, DecisionTail T, const double* __restrict__ dadd)
 {
   __shared__ double tail_scratch[3 * 16 + 2];
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part);
+  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part, dadd);
   decision_tail<kBlock>(ctl, T, part, nb, xcd_remap(blockIdx.x, nb), tail_scratch);
 }
 
@@ -1310,6 +1337,83 @@ k_jag_at_step(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __re
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
   jag_block<decltype(e), WAVES>(J, cur ? y0 : y1 /* y' */, e, part);
 }
+// ---- dense row segments: index-free storage (pdlpdev_ctx::Dense) ---------------------------------------------------------
+struct DenseView {
+  const int32_t* __restrict__ row;
+  const int32_t* __restrict__ row_seg;
+  const int32_t* __restrict__ seg_row;
+  const int32_t* __restrict__ seg_c0;
+  const int32_t* __restrict__ seg_len;
+  const int32_t* __restrict__ seg_ptr;
+  const int32_t* __restrict__ tile_ptr;
+  const int32_t* __restrict__ tile_seg;
+  const int32_t* __restrict__ tile_id;  // the 256-column tiles some segment overlaps
+  const double* __restrict__ val;
+  const int32_t* __restrict__ ch_seg;   // chunks of <= kDenseChunk entries of a segment: one workgroup each ...
+  const int32_t* __restrict__ ch_k0;
+  const int32_t* __restrict__ row_ch;   // ... and per owning row its chunk range (added up in this order)
+  double* __restrict__ ch_part;
+};
+constexpr int kDenseChunk = 4096;
+// the gathered vector of a call site, picked on the device like the layouts do (see k_pb_products)
+__device__ __forceinline__ const double* pick_vector(const pdlpdev_ctl* ctl, const double* v0, const double* v1, int mode)
+{
+  if (mode == 0) return v0;
+  const bool cur = ctl->cur != 0;
+  return (cur == (mode == 1)) ? v0 : v1;
+}
+// rows of A, stage 1: one workgroup per chunk of a segment; lane <-> entry, values and vector are coalesced streams
+__global__ void __launch_bounds__(kBlock)
+k_dense_rows(DenseView D, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
+{
+  __shared__ double red[8];
+  if (in_loop && !loop_active(ctl)) return;
+  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
+  const int sg = D.ch_seg[blockIdx.x], k0 = D.ch_k0[blockIdx.x];
+  const int len = min(kDenseChunk, D.seg_len[sg] - k0);
+  const double* __restrict__ a = D.val + D.seg_ptr[sg] + k0;
+  const double* __restrict__ x = vec + D.seg_c0[sg] + k0;
+  double c[kDenseChunk / kBlock];
+#pragma unroll
+  for (int u = 0; u < kDenseChunk / kBlock; ++u) {
+    const int k = threadIdx.x + u * kBlock;
+    c[u]        = k < len ? __builtin_nontemporal_load(a + k) * x[k] : 0.0;
+  }
+  double acc[1] = {0.0};
+#pragma unroll
+  for (int u = 0; u < kDenseChunk / kBlock; ++u) acc[0] += c[u];
+  block_reduce<SumOp, 1>(acc, red);
+  if (threadIdx.x == 0) D.ch_part[blockIdx.x] = acc[0];
+}
+// stage 2: a lane per owning row adds up its chunks in order
+__global__ void __launch_bounds__(kBlock)
+k_dense_rows_finish(DenseView D, int nrows, const pdlpdev_ctl* __restrict__ ctl, int in_loop, double* __restrict__ add)
+{
+  if (in_loop && !loop_active(ctl)) return;
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nrows) return;
+  double acc = 0.0;
+  for (int q = D.row_ch[b]; q < D.row_ch[b + 1]; ++q) acc += D.ch_part[q];
+  add[D.row[b]] = acc;
+}
+// rows of A^T (columns of A): lane <-> column of a 256-column tile; the segments that overlap the tile in ascending row order
+__global__ void __launch_bounds__(kBlock)
+k_dense_cols(DenseView D, int n, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode,
+             int in_loop, double* __restrict__ add)
+{
+  if (in_loop && !loop_active(ctl)) return;
+  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
+  const int tile = D.tile_id[blockIdx.x];
+  const int j    = tile * kBlock + (int)threadIdx.x;
+  double acc     = 0.0;
+  for (int q = D.tile_ptr[blockIdx.x]; q < D.tile_ptr[blockIdx.x + 1]; ++q) {
+    const int sg = D.tile_seg[q];
+    const int c0 = D.seg_c0[sg];
+    if (j >= c0 && j < c0 + D.seg_len[sg]) acc += __builtin_nontemporal_load(D.val + D.seg_ptr[sg] + (j - c0)) * vec[D.seg_row[sg]];
+  }
+  if (j < n) add[j] = acc;
+}
+
 // (plain SpMV: A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
 struct StoreEpilogue {
   static constexpr int NQ = 0;
@@ -1408,10 +1512,10 @@ __global__ void k_clear_pending(pdlpdev_ctl* ctl) { ctl->pending_avg = 0; }
 __global__ void __launch_bounds__(kBlock)
 k_spmv_plain(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
              const int32_t* __restrict__ idx, const double* __restrict__ val,
-             const double* __restrict__ vec, double* __restrict__ out)
+             const double* __restrict__ vec, double* __restrict__ out, const double* __restrict__ dadd)
 {
   StoreEpilogue e{out};
-  csr_stream_block(nb, rb, off, idx, val, vec, e, nullptr);
+  csr_stream_block(nb, rb, off, idx, val, vec, e, nullptr, dadd);
 }
 // variants that pick the ping-pong buffer on the device
 __global__ void __launch_bounds__(kBlock)
@@ -1419,11 +1523,11 @@ k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const int32_t* __restrict__ idx, const double* __restrict__ val,
               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
               const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
-              double* __restrict__ out_override, int use_next)
+              double* __restrict__ out_override, int use_next, const double* __restrict__ dadd)
 {
   const int cur = ctl->cur ^ (use_next ? 1 : 0);
   StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr);
+  csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr, dadd);
 }
 // panel twin of k_spmv_at_cur (A^T y of the iterate / of the trial iterate, optionally into `out_override`)
 __global__ void __launch_bounds__(kPanelThreads)
@@ -1550,13 +1654,13 @@ k_eval_primal(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
               const double* __restrict__ y0, const double* __restrict__ y1,
               const double* __restrict__ avgy, const double* __restrict__ dr,
               const double* __restrict__ lo_u, const double* __restrict__ hi_u, double eps_rel,
-              double* __restrict__ linf_rows, double* __restrict__ ax_out, double* __restrict__ part)
+              double* __restrict__ linf_rows, double* __restrict__ ax_out, double* __restrict__ part, const double* __restrict__ dadd)
 {
   const int cur = ctl->cur;
   const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  csr_stream_block(nb, rb, off, idx, val, xv, e, part);
+  csr_stream_block(nb, rb, off, idx, val, xv, e, part, dadd);
 }
 
 // dual side (convergence_information.cu:261-320,369-422): one column j per lane
@@ -1610,13 +1714,13 @@ k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ 
             const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0,
             const double* __restrict__ x1, const double* __restrict__ avgx,
             const double* __restrict__ y0, const double* __restrict__ y1,
-            const double* __restrict__ avgy, EvalDualCore core, double* __restrict__ part)
+            const double* __restrict__ avgy, EvalDualCore core, double* __restrict__ part, const double* __restrict__ dadd)
 {
   const int cur = ctl->cur;
   core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalDualEpilogue e{core};
-  csr_stream_block(nb, rb, off, idx, val, yv, e, part);
+  csr_stream_block(nb, rb, off, idx, val, yv, e, part, dadd);
 }
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
@@ -2522,12 +2626,13 @@ template <typename... KArgs, typename... Args>
 static void launch_k(pdlpdev_ctx* c, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, Args... args)
 {
   static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
-  if (c->prof_armed) {
-    c->prof_armed = false;
+  if (c->prof_armed && c->prof_used < pdlpdev_ctx::kProfPairs) {
+    hipEvent_t e0_ = c->prof_ev[2 * c->prof_used], e1_ = c->prof_ev[2 * c->prof_used + 1];
+    c->prof_used += 1;
     std::tuple<std::remove_cv_t<KArgs>...> vals{static_cast<KArgs>(args)...};
     void* ptrs[sizeof...(KArgs)];
     arg_pointers(vals, ptrs, std::index_sequence_for<KArgs...>{});
-    (void)hipExtLaunchKernel((const void*)kernel, grid, block, ptrs, lds, c->stream, c->prof_e0, c->prof_e1, 0);
+    (void)hipExtLaunchKernel((const void*)kernel, grid, block, ptrs, lds, c->stream, e0_, e1_, 0);
     return;
   }
   kernel<<<grid, block, lds, c->stream>>>(static_cast<KArgs>(args)...);
@@ -2824,12 +2929,18 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
 // panel values <- current CSR values (after upload and again after scale_problem)
 static int sync_panel_values(pdlpdev_ctx* c)
 {
-  if (c->pa.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pa.perm, c->a_val, c->pa.val);
-  if (c->pat.on) k_permute<<<grid_for(c->nnz), kBlock, 0, c->stream>>>(c->nnz, c->pat.perm, c->at_val, c->pat.val);
-  if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->a_val, c->ja.val);
-  if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->at_val, c->jat.val);
-  if (c->pba.on) k_permute_pad<<<grid_for(c->pba.np), kBlock, 0, c->stream>>>(c->pba.np, c->pba.perm, c->a_val, c->pba.val);
-  if (c->pbat.on) k_permute_pad<<<grid_for(c->pbat.np), kBlock, 0, c->stream>>>(c->pbat.np, c->pbat.perm, c->at_val, c->pbat.val);
+  const int64_t hot = c->dense.hot_nnz;
+  if (c->dense.on) {  // first the hot copies of the matrices and the segments' values, from the full (just scaled) CSR
+    k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_a, c->a_val, c->ha_val);
+    k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_at, c->at_val, c->hat_val);
+    k_permute<<<grid_for(c->dense.nent), kBlock, 0, c->stream>>>(c->dense.nent, c->dense.perm, c->a_val, c->dense.val);
+  }
+  if (c->pa.on) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->pa.perm, c->ha_val, c->pa.val);
+  if (c->pat.on) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->pat.perm, c->hat_val, c->pat.val);
+  if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->ha_val, c->ja.val);
+  if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->hat_val, c->jat.val);
+  if (c->pba.on) k_permute_pad<<<grid_for(c->pba.np), kBlock, 0, c->stream>>>(c->pba.np, c->pba.perm, c->ha_val, c->pba.val);
+  if (c->pbat.on) k_permute_pad<<<grid_for(c->pbat.np), kBlock, 0, c->stream>>>(c->pbat.np, c->pbat.perm, c->hat_val, c->pbat.val);
   if (c->poc.on) k_permute<<<grid_for(c->oc_nnz), kBlock, 0, c->stream>>>(c->oc_nnz, c->poc.perm, c->oc_val, c->poc.val);
   if (c->joc.on) k_permute<<<grid_for(c->joc.nent), kBlock, 0, c->stream>>>(c->joc.nent, c->joc.perm, c->oc_val, c->joc.val);
   HIP_TRY(hipGetLastError());
@@ -2853,7 +2964,7 @@ static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb
       for (int rep = 0; rep < 4; ++rep) {
         if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
         if (which == 0)
-          k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out);
+          k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out, (const double*)nullptr);
         else
           k_panel_plain<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
       }
@@ -2875,9 +2986,109 @@ static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb
   return 0;
 }
 
+// ---- dense row segments: detection and the sparse remainder (host) -----------------------------------------------------------
+constexpr int kDenseMin = 256;  // consecutive columns of one row from which index-free storage is used
+struct DenseHost {
+  bool on = false;
+  std::vector<int32_t> row, row_seg, seg_row, seg_c0, seg_len, seg_ptr, tile_id, tile_ptr, tile_seg, perm;
+  std::vector<int32_t> s_off, s_idx, s_perm;     // A without the segments' entries (+ where each entry sits in the full CSR)
+  std::vector<int32_t> st_off, st_idx, st_perm;  // A^T likewise
+  std::vector<int32_t> first_seg;                // per row of A: first segment (seg_row ascending), -1 none
+  std::vector<int32_t> ch_seg, ch_k0, row_ch;    // chunks of <= kDenseChunk entries, per owning row
+  int64_t nent = 0;
+};
+static void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t* idx, DenseHost* D)
+{
+  const int64_t nnz = off[m];
+  for (int32_t r = 0; r < m; ++r) {
+    bool owner = false;
+    for (int k = off[r]; k < off[r + 1];) {
+      int e = k;
+      while (e + 1 < off[r + 1] && idx[e + 1] == idx[e] + 1) ++e;
+      const int len = e - k + 1;
+      if (len >= kDenseMin) {
+        if (!owner) {
+          D->row.push_back(r);
+          D->row_seg.push_back((int32_t)D->seg_row.size());
+          owner = true;
+        }
+        D->seg_row.push_back(r), D->seg_c0.push_back(idx[k]), D->seg_len.push_back(len), D->seg_ptr.push_back((int32_t)D->nent);
+        for (int q = k; q <= e; ++q) D->perm.push_back(q);
+        D->nent += len;
+      }
+      k = e + 1;
+    }
+  }
+  D->row_seg.push_back((int32_t)D->seg_row.size());
+  D->seg_ptr.push_back((int32_t)D->nent);
+  // worth a second code path only when the segments carry a visible share of the matrix
+  const char* env = getenv("CUOPT_AMD_DENSE");
+  const int want  = env ? atoi(env) : -1;  // 0 off, 1 on whenever a segment exists, default: >= 2 % of the nonzeros
+  D->on = want != 0 && D->nent > 0 && (want == 1 || D->nent * 50 >= nnz) && D->seg_row.size() <= 65536;
+  if (!D->on) return;
+  for (size_t b = 0; b < D->row.size(); ++b) {
+    D->row_ch.push_back((int32_t)D->ch_seg.size());
+    for (int32_t q = D->row_seg[b]; q < D->row_seg[b + 1]; ++q)
+      for (int32_t k0 = 0; k0 < D->seg_len[q]; k0 += kDenseChunk) D->ch_seg.push_back(q), D->ch_k0.push_back(k0);
+  }
+  D->row_ch.push_back((int32_t)D->ch_seg.size());
+  // sparse remainder of A
+  D->first_seg.assign(m, -1);
+  for (size_t b = 0; b < D->row.size(); ++b) D->first_seg[D->row[b]] = D->row_seg[b];
+  D->s_off.assign((size_t)m + 1, 0);
+  D->s_idx.reserve((size_t)(nnz - D->nent)), D->s_perm.reserve((size_t)(nnz - D->nent));
+  auto covered = [&](int32_t r, int32_t c) {
+    const int32_t f = D->first_seg[r];
+    if (f < 0) return false;
+    for (int32_t q = f; q < (int32_t)D->seg_row.size() && D->seg_row[q] == r; ++q)
+      if (c >= D->seg_c0[q] && c < D->seg_c0[q] + D->seg_len[q]) return true;
+    return false;
+  };
+  for (int32_t r = 0; r < m; ++r) {
+    for (int k = off[r]; k < off[r + 1]; ++k)
+      if (!covered(r, idx[k])) D->s_idx.push_back(idx[k]), D->s_perm.push_back(k);
+    D->s_off[r + 1] = (int32_t)D->s_idx.size();
+  }
+  // 256-column tiles of A^T's side
+  const int ntiles_all = (n + kBlock - 1) / kBlock;
+  std::vector<int32_t> cnt(ntiles_all, 0);
+  for (size_t q = 0; q < D->seg_row.size(); ++q)
+    for (int t = D->seg_c0[q] / kBlock; t <= (D->seg_c0[q] + D->seg_len[q] - 1) / kBlock; ++t) cnt[t]++;
+  std::vector<int32_t> slot(ntiles_all, -1);
+  D->tile_ptr.push_back(0);
+  for (int t = 0; t < ntiles_all; ++t)
+    if (cnt[t]) {
+      slot[t] = (int32_t)D->tile_id.size();
+      D->tile_id.push_back(t);
+      D->tile_ptr.push_back(D->tile_ptr.back() + cnt[t]);
+    }
+  D->tile_seg.assign((size_t)D->tile_ptr.back(), 0);
+  std::vector<int32_t> cur(D->tile_ptr.begin(), D->tile_ptr.end() - 1);
+  for (size_t q = 0; q < D->seg_row.size(); ++q)  // segments in ascending row order: the order A^T's rows list them in
+    for (int t = D->seg_c0[q] / kBlock; t <= (D->seg_c0[q] + D->seg_len[q] - 1) / kBlock; ++t) D->tile_seg[cur[slot[t]]++] = (int32_t)q;
+}
+// the sparse remainder of A^T (entry (j, i) goes when row i of A holds column j in a segment)
+static void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const int32_t* t_off, const int32_t* t_idx)
+{
+  (void)Din;
+  D->st_off.assign((size_t)n + 1, 0);
+  for (int32_t j = 0; j < n; ++j) {
+    for (int k = t_off[j]; k < t_off[j + 1]; ++k) {
+      const int32_t r = t_idx[k], f = D->first_seg[r];
+      bool cov = false;
+      for (int32_t q = f; f >= 0 && q < (int32_t)D->seg_row.size() && D->seg_row[q] == r; ++q)
+        if (j >= D->seg_c0[q] && j < D->seg_c0[q] + D->seg_len[q]) { cov = true; break; }
+      if (!cov) D->st_idx.push_back(r), D->st_perm.push_back(k);
+    }
+    D->st_off[j + 1] = (int32_t)D->st_idx.size();
+  }
+}
+static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
+
 extern "C" {
 
 const char* pdlpdev_last_error(void) { return g_err.c_str(); }
+void pdlpdev_create_hint(int sharded) { g_create_sharded = sharded; }
 
 int pdlpdev_device_count(void)
 {
@@ -2963,7 +3174,43 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   std::vector<int32_t> la = long_rows(m, a_offsets), lat;  // alive until the stream is synchronised at the end
   ctx->a_nlong = (int)la.size();
   if (ctx->a_nlong) TRY(upload_i32(ctx, &ctx->a_long, la.data(), la.size()));
-  std::vector<int32_t> rba = build_row_blocks(m, a_offsets);
+  // dense row segments leave the hot loop's copy of the matrix (single-GPU solves; CUOPT_AMD_DENSE=0 switches the path off)
+  DenseHost DH;
+  if (!g_create_sharded) find_dense_segments(m, n, a_offsets, a_indices, &DH);
+  g_create_sharded       = 0;
+  const int32_t* A_off   = DH.on ? DH.s_off.data() : a_offsets;
+  const int32_t* A_idx   = DH.on ? DH.s_idx.data() : a_indices;
+  ctx->ha_off = ctx->a_off, ctx->ha_idx = ctx->a_idx, ctx->ha_val = ctx->a_val;
+  ctx->dense.hot_nnz = (int64_t)A_off[m];
+  if (DH.on) {
+    pdlpdev_ctx::Dense& D = ctx->dense;
+    D.nrows = (int)DH.row.size(), D.nseg = (int)DH.seg_row.size(), D.ntiles = (int)DH.tile_id.size(), D.nent = DH.nent;
+    TRY(upload_i32(ctx, &ctx->ha_off, A_off, (size_t)m + 1));
+    TRY(upload_i32(ctx, &ctx->ha_idx, A_idx, (size_t)D.hot_nnz, 8));
+    TRY(dev_alloc(ctx, &ctx->ha_val, (size_t)D.hot_nnz + 8));
+    TRY(upload_i32(ctx, &D.s_perm_a, DH.s_perm.data(), DH.s_perm.size()));
+    TRY(upload_i32(ctx, &D.row, DH.row.data(), DH.row.size()));
+    TRY(upload_i32(ctx, &D.row_seg, DH.row_seg.data(), DH.row_seg.size()));
+    TRY(upload_i32(ctx, &D.seg_row, DH.seg_row.data(), DH.seg_row.size()));
+    TRY(upload_i32(ctx, &D.seg_c0, DH.seg_c0.data(), DH.seg_c0.size()));
+    TRY(upload_i32(ctx, &D.seg_len, DH.seg_len.data(), DH.seg_len.size()));
+    TRY(upload_i32(ctx, &D.seg_ptr, DH.seg_ptr.data(), DH.seg_ptr.size()));
+    TRY(upload_i32(ctx, &D.tile_id, DH.tile_id.data(), DH.tile_id.size()));
+    TRY(upload_i32(ctx, &D.tile_ptr, DH.tile_ptr.data(), DH.tile_ptr.size()));
+    TRY(upload_i32(ctx, &D.tile_seg, DH.tile_seg.data(), DH.tile_seg.size()));
+    TRY(upload_i32(ctx, &D.perm, DH.perm.data(), DH.perm.size()));
+    D.nchunks = (int)DH.ch_seg.size();
+    TRY(upload_i32(ctx, &D.ch_seg, DH.ch_seg.data(), DH.ch_seg.size()));
+    TRY(upload_i32(ctx, &D.ch_k0, DH.ch_k0.data(), DH.ch_k0.size()));
+    TRY(upload_i32(ctx, &D.row_ch, DH.row_ch.data(), DH.row_ch.size()));
+    TRY(dev_alloc(ctx, &D.ch_part, (size_t)D.nchunks + 8));
+    TRY(dev_alloc(ctx, &D.val, (size_t)D.nent + 8));
+    TRY(dev_alloc(ctx, &D.add_m, (size_t)m));
+    TRY(dev_alloc(ctx, &D.add_n, (size_t)n));
+    D.on = true;
+    if (timing) fprintf(stderr, "[cuopt_amd setup]   dense: %d segments in %d rows, %lld of %lld nonzeros stored index-free\n", D.nseg, D.nrows, (long long)D.nent, (long long)ctx->nnz);
+  }
+  std::vector<int32_t> rba = build_row_blocks(m, A_off);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
   TRY(upload_f64(ctx, &ctx->c, c, n)); TRY(upload_f64(ctx, &ctx->c_u, c, n));
@@ -3020,20 +3267,20 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     };
     lap("row blocks + vectors");
     if (try_jag) {
-      JagHost ja = build_jag(m, n, a_offsets, a_indices, mode == "jag" ? 1 : 0, ctx->cus);
+      JagHost ja = build_jag(m, n, A_off, A_idx, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag A");
-      TRY(upload_jag(ctx, &ctx->ja, ja, ctx->a_off, ctx->a_idx, ctx->a_val));
+      TRY(upload_jag(ctx, &ctx->ja, ja, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
       lap("upload jag A");
     }
-    if (!ctx->ja.on && want_pb(n) && (mode == "pb" || want_panels(m, n, a_offsets, a_indices, "A"))) {
-      PbHost hb = build_pb(m, n, a_offsets, a_indices, ctx->cus, mode == "pb");
+    if (!ctx->ja.on && want_pb(n) && (mode == "pb" || want_panels(m, n, A_off, A_idx, "A"))) {
+      PbHost hb = build_pb(m, n, A_off, A_idx, ctx->cus, mode == "pb");
       lap("build_pb A");
       if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", hb.why.c_str());
       TRY(upload_pb(ctx, &ctx->pba, hb));
       lap("upload pb A");
     }
-    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, a_offsets, a_indices, "A")) {
-      PanelHost ha = build_panels(m, n, a_offsets, a_indices, slab_bytes, force || !timed);
+    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, A_off, A_idx, "A")) {
+      PanelHost ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed);
       lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha));
       lap("upload panels A");
@@ -3048,25 +3295,36 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     lat           = long_rows(n, at_offsets);
     ctx->at_nlong = (int)lat.size();
     if (ctx->at_nlong) TRY(upload_i32(ctx, &ctx->at_long, lat.data(), lat.size()));
-    std::vector<int32_t> rbt = build_row_blocks(n, at_offsets);
+    if (DH.on) strip_transpose(DH, &DH, n, at_offsets, at_indices);
+    const int32_t* T_off = DH.on ? DH.st_off.data() : at_offsets;
+    const int32_t* T_idx = DH.on ? DH.st_idx.data() : at_indices;
+    ctx->hat_off = ctx->at_off, ctx->hat_idx = ctx->at_idx, ctx->hat_val = ctx->at_val;
+    if (DH.on) {
+      if ((int64_t)T_off[n] != ctx->dense.hot_nnz) return fail(-1, "pdlpdev_create: the sparse remainders of A and A^T disagree");
+      TRY(upload_i32(ctx, &ctx->hat_off, T_off, (size_t)n + 1));
+      TRY(upload_i32(ctx, &ctx->hat_idx, T_idx, (size_t)ctx->dense.hot_nnz, 8));
+      TRY(dev_alloc(ctx, &ctx->hat_val, (size_t)ctx->dense.hot_nnz + 8));
+      TRY(upload_i32(ctx, &ctx->dense.s_perm_at, DH.st_perm.data(), DH.st_perm.size()));
+    }
+    std::vector<int32_t> rbt = build_row_blocks(n, T_off);
     ctx->at_nb = (int)rbt.size() / 2 - 1;
     TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
     lap("upload A^T");
     if (try_jag) {
-      JagHost jat = build_jag(n, m, at_offsets, at_indices, mode == "jag" ? 1 : 0, ctx->cus);
+      JagHost jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag At");
-      TRY(upload_jag(ctx, &ctx->jat, jat, ctx->at_off, ctx->at_idx, ctx->at_val));
+      TRY(upload_jag(ctx, &ctx->jat, jat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload jag At");
     }
-    if (!ctx->jat.on && want_pb(m) && (mode == "pb" || want_panels(n, m, at_offsets, at_indices, "A^T"))) {
-      PbHost hb = build_pb(n, m, at_offsets, at_indices, ctx->cus, mode == "pb");
+    if (!ctx->jat.on && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
+      PbHost hb = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
       lap("build_pb At");
       if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", hb.why.c_str());
       TRY(upload_pb(ctx, &ctx->pbat, hb));
       lap("upload pb At");
     }
-    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->jat.on && !ctx->pbat.on && want_panels(n, m, at_offsets, at_indices, "A^T")) {
-      PanelHost hat = build_panels(n, m, at_offsets, at_indices, slab_bytes, force || !timed);
+    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->jat.on && !ctx->pbat.on && want_panels(n, m, T_off, T_idx, "A^T")) {
+      PanelHost hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
       lap("build_panels At");
       TRY(upload_panels(ctx, &ctx->pat, hat));
       lap("upload panels At");
@@ -3077,9 +3335,13 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     // small LPs: a whole batch of attempts inside one workgroup (CUOPT_AMD_SMALL=0 switches it off)
     const char* small_env = getenv("CUOPT_AMD_SMALL");
     const int tier        = resident_tier(m, n, ctx->nnz);
-    ctx->small_resident   = tier >= 0 && !(small_env && atoi(small_env) == 0);
+    ctx->small_resident   = tier >= 0 && !(small_env && atoi(small_env) == 0) && !ctx->dense.on;
     if (small_env && atoi(small_env) != 0 && tier < 0)
       return fail(-1, "CUOPT_AMD_SMALL=1: the LP does not fit the resident kernel (m, n <= 2048, nnz <= 4096 ...)");
+  }
+  if (ctx->dense.on) {  // every layout adds the segments' contribution ahead of its epilogue
+    ctx->pa.v.dense_add = ctx->ja.v.dense_add = ctx->pba.v.dense_add = ctx->dense.add_m;
+    ctx->pat.v.dense_add = ctx->jat.v.dense_add = ctx->pbat.v.dense_add = ctx->dense.add_n;
   }
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pba.on ? ctx->pba.v.B : 0, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pbat.on ? ctx->pbat.v.B : 0, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
@@ -3102,9 +3364,9 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   {
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
     if (mode_env && std::string(mode_env) == "timed") {
-      TRY(pick_layout(ctx, &ctx->pa, m, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->tmp_n, ctx->tmp_m, "A"));
+      TRY(pick_layout(ctx, &ctx->pa, m, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->tmp_n, ctx->tmp_m, "A"));
       lap("layout autotune A");
-      TRY(pick_layout(ctx, &ctx->pat, n, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->tmp_m, ctx->tmp_n, "A^T"));
+      TRY(pick_layout(ctx, &ctx->pat, n, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->tmp_m, ctx->tmp_n, "A^T"));
       lap("layout autotune");
     }
   }
@@ -3822,11 +4084,25 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 }
 
 
+// dense row segments: their share of A v (transpose = 0) / A^T v lands in dense.add_m / add_n right before the layout's kernel adds it
+static void dense_part(pdlpdev_ctx* ctx, int transpose, const double* v0, const double* v1, int mode, int in_loop)
+{
+  const pdlpdev_ctx::Dense& D = ctx->dense;
+  if (!D.on) return;
+  DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
+  if (transpose) {
+    launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
+  } else {
+    launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl, v0, v1, mode, in_loop);
+    launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl, in_loop, D.add_m);
+  }
+}
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
 static inline int dual_partials(const pdlpdev_ctx* ctx) { return ctx->pba.on ? ctx->pba.v.B : ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : ctx->pa.on ? ctx->pa.v.W : ctx->a_nb; }
 static inline int step_partials(const pdlpdev_ctx* ctx) { return ctx->pbat.on ? ctx->pbat.v.B : ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb; }
 static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pdev::Push* push = nullptr)
 {
+  dense_part(ctx, 0, ctx->xbar, nullptr, 0, 1);
   if (ctx->pba.on) {
     (void)pb_products(ctx, ctx->pba, ctx->xbar, nullptr, 0, 1);
     (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
@@ -3835,10 +4111,11 @@ static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pde
   else if (ctx->pa.on)
     launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else
-    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
+  dense_part(ctx, 1, ctx->y[0], ctx->y[1], 1, 1);
   if (ctx->pbat.on) {
     (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 1, 1);  // y' = the trial dual
     (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
@@ -3847,10 +4124,11 @@ static void launch_at_step(pdlpdev_ctx* ctx)
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else
-    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
 }
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
+  dense_part(ctx, 1, ctx->y[0], ctx->y[1], use_next ? 1 : 2, 0);
   if (ctx->pbat.on) {
     (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], use_next ? 1 : 2, 0);
     (void)pb_rows(ctx, k_pb_at_cur, ctx->pbat, ctx->ctl, ctx->aty[0], ctx->aty[1], out_override, use_next);
@@ -3859,11 +4137,12 @@ static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
   else if (ctx->pat.on)
     launch_k(ctx, k_panel_at_cur, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else
-    launch_k(ctx, k_spmv_at_cur, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
+    launch_k(ctx, k_spmv_at_cur, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next, ctx->dense.add_n);
 }
 // plain y = A x (transpose = 0) or y = A^T x through the layout the solver iterates with
 static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, double* out)
 {
+  dense_part(ctx, transpose, vec, nullptr, 0, 0);
   if (transpose) {
     if (ctx->pbat.on) {
       (void)pb_products(ctx, ctx->pbat, vec, nullptr, 0, 0);
@@ -3873,7 +4152,7 @@ static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, dou
     else if (ctx->pat.on)
       launch_k(ctx, k_panel_plain, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, vec, out);
     else
-      launch_k(ctx, k_spmv_plain, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, vec, out);
+      launch_k(ctx, k_spmv_plain, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, vec, out, ctx->dense.add_n);
   } else {
     if (ctx->pba.on) {
       (void)pb_products(ctx, ctx->pba, vec, nullptr, 0, 0);
@@ -3883,7 +4162,7 @@ static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, dou
     else if (ctx->pa.on)
       launch_k(ctx, k_panel_plain, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, vec, out);
     else
-      launch_k(ctx, k_spmv_plain, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, vec, out);
+      launch_k(ctx, k_spmv_plain, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, vec, out, ctx->dense.add_m);
   }
 }
 static void launch_decision(pdlpdev_ctx* ctx)
@@ -3902,7 +4181,7 @@ static void launch_oc_step(pdlpdev_ctx* ctx)
   else if (ctx->poc.on)
     launch_k(ctx, k_panel_at_step, ctx->poc.v.W, kPanelThreads, 0, ctx->poc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
   else
-    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->oc_nb), kBlock, 0, ctx->oc_nb, ctx->oc_rb, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
+    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->oc_nb), kBlock, 0, ctx->oc_nb, ctx->oc_rb, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc, (const double*)nullptr);
 }
 
 // one PDHG attempt = 4 launches (single GPU) on ctx->stream
@@ -3977,8 +4256,9 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   if (!ctx->comm) {
     if (ctx->ticket_decision && !ctx->pbat.on && !ctx->jat.on && !ctx->pat.on) {
       DecisionTail T{ctx->ticket, ctx->part_a, dual_partials(ctx), ctx->sp};
-      launch_k(ctx, k_spmv_at_step_decide, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl,
-               ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, T);
+      dense_part(ctx, 1, ctx->y[0], ctx->y[1], 1, 1);
+      launch_k(ctx, k_spmv_at_step_decide, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl,
+               ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, T, ctx->dense.add_n);
     } else {
       launch_at_step(ctx);
       launch_decision(ctx);
@@ -4183,6 +4463,8 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   double* linf_m = want_linf ? ctx->tmp_m : nullptr;
   double* linf_n = want_linf ? ctx->tmp_n : nullptr;
   // layout of sc: [0..2] primal sums, [3] primal linf, [4..7] dual sums, [8] dual linf
+  if (kw == PDLPDEV_AVERAGE) dense_part(ctx, 0, altx, nullptr, 0, 0);
+  else dense_part(ctx, 0, ctx->x[0], ctx->x[1], 2, 0);
   if (ctx->pba.on) {
     if (kw == PDLPDEV_AVERAGE) TRY(pb_products(ctx, ctx->pba, altx, nullptr, 0, 0));
     else TRY(pb_products(ctx, ctx->pba, ctx->x[0], ctx->x[1], 2, 0));
@@ -4192,7 +4474,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   else if (ctx->pa.on)
     k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else
-    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->a_off, ctx->a_idx, ctx->a_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
+    k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a, ctx->dense.add_m);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
   if (want_linf) {
     const int g = std::min(grid_for(m), kGenericBlocks);
@@ -4201,6 +4483,8 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   }
   EvalDualCore core{nullptr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, eps_rel_dual, rc_rule_finite_bounds, which == PDLPDEV_LAST_RESTART ? ctx->rc_scratch : ctx->rc[which == PDLPDEV_AVERAGE ? 1 : 0], linf_n, ctx->aty_u[which]};
   if (!ctx->comm) {
+    if (kw == PDLPDEV_AVERAGE) dense_part(ctx, 1, alty, nullptr, 0, 0);
+    else dense_part(ctx, 1, ctx->y[0], ctx->y[1], 2, 0);
     if (ctx->pbat.on) {
       if (kw == PDLPDEV_AVERAGE) TRY(pb_products(ctx, ctx->pbat, alty, nullptr, 0, 0));
       else TRY(pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 2, 0));
@@ -4210,7 +4494,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
     else if (ctx->pat.on)
       k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else
-      k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->at_off, ctx->at_idx, ctx->at_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
+      k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at, ctx->dense.add_n);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_at, step_partials(ctx), 4, 0u, sc + 4);
   } else {
     // partial A^T y of this row block, all-reduced together with the three dual-side row sums
@@ -4581,10 +4865,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   HIP_TRY(hipMemcpyAsync(sy, ctx->sumy, (size_t)ctx->m * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->ctl, &forced, sizeof(forced), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  ctx->prof_e0 = e0, ctx->prof_e1 = e1;
+  for (hipEvent_t& e : ctx->prof_ev) HIP_TRY(hipEventCreate(&e));
   auto one = [&]() {
     switch (kernel_id) {
       case PDLPDEV_K_PRIMAL:
@@ -4618,6 +4899,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
       const bool mine = id == slot;
       kernel_id       = mine ? wanted : id;
       ctx->prof_armed = mine && timed;
+      if (ctx->prof_armed) ctx->prof_used = 0;
       rc              = one();
       ctx->prof_armed = false;
       if (rc != 0) break;
@@ -4631,10 +4913,12 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   float ms = 0.f;
   for (int i = 0; i < reps; ++i) {
     TRY(attempt(true));
-    HIP_TRY(hipEventSynchronize(e1));
-    float one_ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&one_ms, e0, e1));
-    ms += one_ms;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int q = 0; q < ctx->prof_used; ++q) {  // the launches of the call site: their own durations, added up
+      float one_ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&one_ms, ctx->prof_ev[2 * q], ctx->prof_ev[2 * q + 1]));
+      ms += one_ms;
+    }
   }
   if (avg_ms) *avg_ms = (double)ms / reps;
   // restore
@@ -4642,8 +4926,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   HIP_TRY(hipMemcpyAsync(ctx->sumy, sy, (size_t)ctx->m * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->ctl, &saved, sizeof(saved), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
-  ctx->prof_e0 = ctx->prof_e1 = nullptr;
-  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  for (hipEvent_t& e : ctx->prof_ev) (void)hipEventDestroy(e), e = nullptr;
   (void)hipFree(sx), (void)hipFree(sy);
   return 0;
 }
@@ -4657,6 +4940,11 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->owner ? 3 : ctx->rsag ? 2 : 1; }
 int pdlpdev_shard_transport(pdlpdev_ctx* ctx) { return ctx->p2p.on ? 1 : 0; }
+int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3])
+{
+  out[0] = ctx->dense.on ? 1 : 0, out[1] = ctx->dense.nseg, out[2] = ctx->dense.nent;
+  return 0;
+}
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column

@@ -132,6 +132,10 @@ __device__ __forceinline__ void block_sum_fast(double (&v)[NQ], double* scratch 
   for (int k = 0; k < NQ; ++k) v[k] = read_lane(part, 16 * k);
 }
 
+// Dense row segments (index-free storage, pdlp_device.hip "dense"): the layouts below multiply the SPARSE remainder of the matrix;
+// what the dense segments contribute to row r was computed just before and is added here, ahead of the fused epilogue.
+__device__ __forceinline__ double dense_plus(const double* __restrict__ add, int r, double v) { return add ? v + add[r] : v; }
+
 __device__ __forceinline__ bool loop_active(const pdlpdev_ctl* ctl)
 {
   return ctl->error == 0 && ctl->steps_taken < ctl->target_steps;
@@ -162,7 +166,7 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
                                                  const int32_t* __restrict__ indices,
                                                  const double* __restrict__ values,
                                                  const double* __restrict__ vec, Epi& epi,
-                                                 double* __restrict__ partials)
+                                                 double* __restrict__ partials, const double* __restrict__ dense_add = nullptr)
 {
   __shared__ __attribute__((aligned(32))) double prod[kNnzTile];
   __shared__ double red[4 * (Epi::NQ > 0 ? Epi::NQ : 1) + 4];
@@ -235,7 +239,7 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
         for (; k < e; ++k) s0 += prod[k];
         sum = (s0 + s1) + (s2 + s3);
       }
-      epi.row(r, sum, acc);
+      epi.row(r, dense_plus(dense_add, r, sum), acc);
     }
   } else {
     // a single row longer than the LDS tile: strided partial sums + workgroup tree
@@ -246,7 +250,7 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
       part[0] += a * vec[j];
     }
     block_reduce<SumOp, 1>(part, red);
-    if (threadIdx.x == 0) epi.row(r0, part[0], acc);
+    if (threadIdx.x == 0) epi.row(r0, dense_plus(dense_add, r0, part[0]), acc);
     __syncthreads();
   }
   if constexpr (Epi::NQ > 0) {
@@ -288,6 +292,7 @@ struct PanelView {
   const int64_t* __restrict__ rp_base;   // W*S: where each tile's rowptr starts
   const int32_t* __restrict__ col;       // permuted column indices
   const double* __restrict__ val;        // permuted values
+  const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
 };
 
 // ---- the chunks of a panel, one stage ahead ------------------------------------------------------------------------
@@ -470,7 +475,7 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
-  for (int r = threadIdx.x; r < nr; r += kPanelThreads) epi.row(r0 + r, psum[r], acc);
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
   if constexpr (Epi::NQ > 0) {
     block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
     if (threadIdx.x == 0) {
@@ -534,6 +539,7 @@ struct JagView {
   const int32_t* __restrict__ off;
   const int32_t* __restrict__ idx;
   const double* __restrict__ csr_val;
+  const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
 };
 
 template <class Epi, int WAVES>
@@ -587,7 +593,7 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
       for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
     }
     block_reduce<SumOp, 1, WAVES>(part, xwin);
-    if (threadIdx.x == 0) epi.row(r, part[0], acc);
+    if (threadIdx.x == 0) epi.row(r, dense_plus(J.dense_add, r, part[0]), acc);
     if constexpr (Epi::NQ > 0) {
       if (threadIdx.x == 0) {  // one row: thread 0's accumulators are the workgroup's
 #pragma unroll
@@ -687,7 +693,7 @@ __device__ __forceinline__ void jag_block(const JagView& J, const double* __rest
   __syncthreads();  // the strip is complete: the fused epilogue streams the workgroup's rows in natural order
   for (int i = threadIdx.x; i < brows; i += (WAVES * 64)) {
     const int row = row0 + i;
-    if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, psum[i], acc);
+    if (row < J.rows && __double_as_longlong(psum[i]) != kJagNotMine) epi.row(row, dense_plus(J.dense_add, row, psum[i]), acc);
   }
   if constexpr (Epi::NQ > 0) {
     __syncthreads();  // every wave is done with the window: its first bytes become the reduction scratch
@@ -735,6 +741,7 @@ struct PbView {
   const int32_t* __restrict__ grp_pos;   // first position of every 64-row group
   const uint16_t* __restrict__ pos;      // nnz (+ pad): position inside the bin's image, jagged-diagonal order
   double* __restrict__ prod;             // padded entries (+ pad)
+  const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
 };
 
 // phase P of one workgroup.  xs: LDS, 1 << panel_shift doubles.
@@ -869,7 +876,7 @@ __device__ __forceinline__ void pb_rows_block(const PbView& V, Epi& epi, double*
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
-  for (int i = threadIdx.x; i < brows; i += THREADS) epi.row(row0 + i, strip[i], acc);
+  for (int i = threadIdx.x; i < brows; i += THREADS) epi.row(row0 + i, dense_plus(V.dense_add, row0 + i, strip[i]), acc);
   if constexpr (Epi::NQ > 0) {
     __syncthreads();  // every wave is done with the image: its first bytes become the reduction scratch
     block_reduce<typename Epi::Op, Epi::NQ, WAVES>(acc, lp);

@@ -836,6 +836,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     job.worker = std::thread([=] { cuoptamd_csr_transpose(ml, n, off_p, idx, val, t_off_p, t_idx_p, t_val_p); });
   }
   {
+    pdlpdev_create_hint(world > 1 || comm_id != nullptr);
     int rc = pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
                                        &TransposeJob::wait, &job, c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin,
                                        lp->lb, lp->ub);

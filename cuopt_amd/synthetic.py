@@ -126,6 +126,9 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
                               (thousands of nonzeros each: the long-row path) + 1 % linking columns
               'multiband'     three bands of +-500 columns at lags 0, +n/10 and -3n/10
               'powerlaw'      row lengths ~ Pareto(1.5) with mean ~k, capped at 20000, uniform columns (hub constraints)
+              'dense_rows'    a random sparse LP (k - 2 nonzeros per row) + m / 25000 DENSE constraints that run through a
+                              contiguous block of n / 20 variables each (budget / convexity / linking rows): ~17 % of the
+                              nonzeros sit in dense row segments (index-free storage, pdlp_device.hip "dense")
     every column gets at least one entry; (x*, y*) is optimal by construction, objective_star is the known answer."""
     rng = np.random.default_rng(seed)
     r_forced = np.arange(n, dtype=np.int64) % m
@@ -162,6 +165,14 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
         lens = np.minimum((xm * (1.0 - rng.random(m)) ** (-1.0 / 1.5)).astype(np.int64) + 1, 20000)
         rows = np.repeat(np.arange(m, dtype=np.int64), lens)
         cols = rng.integers(0, n, size=len(rows))
+    elif kind == "dense_rows":
+        rows = np.repeat(np.arange(m, dtype=np.int64), max(k - 2, 1))
+        cols = rng.integers(0, n, size=len(rows))
+        nd, width = max(m // 25000, 2), max(n // 20, 300)
+        d_rows = np.sort(rng.choice(m, size=nd, replace=False))
+        starts = rng.integers(0, n - width, size=nd)
+        rows = np.concatenate([rows, np.repeat(d_rows, width)])
+        cols = np.concatenate([cols, (starts[:, None] + np.arange(width)[None, :]).reshape(-1)])
     else:
         raise ValueError(kind)
     rows = np.concatenate([rows, r_forced])

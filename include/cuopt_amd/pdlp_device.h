@@ -144,6 +144,9 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
  * addresses, but their CONTENTS are read only after transpose_ready(user) has returned (NULL: they are ready now).
  * Everything that needs A alone (upload, row blocks, panels of A, all vectors) happens before that call; the callback
  * is invoked exactly once unless the function fails earlier, so a caller that started a thread joins it on every path. */
+/* the NEXT context created by this thread will run behind a communicator (sharded solve): paths that exist on one GPU only --
+ * dense row segments, the resident small-LP kernel -- are not set up */
+void pdlpdev_create_hint(int sharded);
 int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
                               const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
                               const int32_t* at_indices, const double* at_values,
@@ -300,6 +303,10 @@ int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
  * (CUOPT_AMD_SHARD_DATAFLOW=rsag), 3 = owner computes: the rank also holds its COLUMNS of A, all-gather(xbar slices) +
  * all-gather(y' row blocks) + a 3-scalar all-reduce, no partial products on the wire (CUOPT_AMD_SHARD_DATAFLOW=owner) */
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx);
+/* dense row segments (runs of >= 256 consecutive columns inside a row, stored index-free and multiplied by their own streaming
+ * kernels; CUOPT_AMD_DENSE = 0 off | 1 whenever a segment exists | default: when they hold >= 2 % of the nonzeros; single-GPU
+ * solves): out = {in use, segments, entries} */
+int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3]);
 /* transport of the owner-computes dataflow's exchanges: 0 = collectives (RCCL all-gather / 3-scalar all-reduce, or the in-process
  * communicator), 1 = direct peer stores into the ranks' landing blocks + epoch flags, kernels only
  * (CUOPT_AMD_SHARD_TRANSPORT=p2p; peers of the same process are addressed directly, other processes through HIP IPC handles
