@@ -358,6 +358,17 @@ struct pdlpdev_ctx {
     double *add_m = nullptr, *add_n = nullptr;  // what the segments contribute to A v (per row) / A^T v (per column)
     int64_t hot_nnz = 0;
   } dense;
+  // Rows of more than kLongExtract nonzeros (hub constraints / hub variables) are taken out of the hot CSR of THEIR matrix (the other
+  // matrix keeps their entries: there they are one entry per row) and multiplied in chunks by k_long_rows; the layouts add the
+  // result like a dense segment's.  A panel or a row block is then never stretched by a single row.
+  struct LongRows {
+    bool on = false;
+    int nrows = 0, nchunks = 0;
+    int64_t nent = 0;
+    int32_t *row = nullptr, *row_ch = nullptr, *row_flag = nullptr, *ch_k0 = nullptr, *ch_len = nullptr, *idx = nullptr, *perm = nullptr;
+    double *val = nullptr, *part = nullptr;
+  } long_a, long_at;
+  int64_t hot_nnz_at = 0;
   int32_t *ha_off = nullptr, *ha_idx = nullptr, *hat_off = nullptr, *hat_idx = nullptr;  // the CSR the hot loop multiplies:
   double *ha_val = nullptr, *hat_val = nullptr;                                          // a_* / at_* unless dense.on
   // gather-free layout (fourth layout: huge unstructured matrices; pdlp_kernels.hpp "pb")
@@ -441,7 +452,7 @@ struct pdlpdev_ctx {
   // dispatch itself, what rocprofv3 --kernel-trace reports)
   // (a call site may consist of several launches -- dense segments, phase P, phase R: each gets its own pair, the durations add up)
   bool prof_armed = false;
-  static constexpr int kProfPairs = 4;
+  static constexpr int kProfPairs = 8;
   hipEvent_t prof_ev[2 * kProfPairs] = {};
   int prof_used = 0;
   unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
@@ -1412,6 +1423,56 @@ k_dense_cols(DenseView D, int n, const pdlpdev_ctl* __restrict__ ctl, const doub
     if (j >= c0 && j < c0 + D.seg_len[sg]) acc += __builtin_nontemporal_load(D.val + D.seg_ptr[sg] + (j - c0)) * vec[D.seg_row[sg]];
   }
   if (j < n) add[j] = acc;
+}
+
+// ---- extracted long rows (pdlpdev_ctx::LongRows): rows of more than kLongExtract nonzeros leave the layouts; chunks of <= 4096
+// entries get a workgroup each (values and columns are coalesced streams, 16 gathers per lane in flight, fixed tree), a lane per
+// row adds the chunks up in order.  No panel / row block is stretched by one row any more.
+struct LongView {
+  const int32_t* __restrict__ row;
+  const int32_t* __restrict__ row_ch;
+  const int32_t* __restrict__ row_flag;  // 1: the row also owns dense segments, whose share is already in `add`
+  const int32_t* __restrict__ ch_k0;
+  const int32_t* __restrict__ ch_len;
+  const int32_t* __restrict__ idx;
+  const double* __restrict__ val;
+  double* __restrict__ part;
+};
+__global__ void __launch_bounds__(kBlock)
+k_long_rows(LongView L, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
+{
+  __shared__ double red[8];
+  if (in_loop && !loop_active(ctl)) return;
+  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
+  const int k0 = L.ch_k0[blockIdx.x], len = L.ch_len[blockIdx.x];
+  constexpr int U = kDenseChunk / kBlock;
+  double a[U];
+  int j[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = threadIdx.x + u * kBlock;
+    a[u] = 0.0, j[u] = 0;
+    if (k < len) {
+      a[u] = __builtin_nontemporal_load(L.val + k0 + k);
+      j[u] = __builtin_nontemporal_load(L.idx + k0 + k);
+    }
+  }
+  double acc[1] = {0.0};
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[0] += a[u] * vec[j[u]];
+  block_reduce<SumOp, 1>(acc, red);
+  if (threadIdx.x == 0) L.part[blockIdx.x] = acc[0];
+}
+__global__ void __launch_bounds__(kBlock)
+k_long_rows_finish(LongView L, int nrows, const pdlpdev_ctl* __restrict__ ctl, int in_loop, double* __restrict__ add)
+{
+  if (in_loop && !loop_active(ctl)) return;
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nrows) return;
+  const int r = L.row[b];
+  double acc  = L.row_flag[b] ? add[r] : 0.0;
+  for (int q = L.row_ch[b]; q < L.row_ch[b + 1]; ++q) acc += L.part[q];
+  add[r] = acc;
 }
 
 // (plain SpMV: A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
@@ -2929,14 +2990,15 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
 // panel values <- current CSR values (after upload and again after scale_problem)
 static int sync_panel_values(pdlpdev_ctx* c)
 {
-  const int64_t hot = c->dense.hot_nnz;
-  if (c->dense.on) {  // first the hot copies of the matrices and the segments' values, from the full (just scaled) CSR
-    k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_a, c->a_val, c->ha_val);
-    k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_at, c->at_val, c->hat_val);
-    k_permute<<<grid_for(c->dense.nent), kBlock, 0, c->stream>>>(c->dense.nent, c->dense.perm, c->a_val, c->dense.val);
-  }
+  const int64_t hot = c->dense.hot_nnz, hot_t = c->hot_nnz_at;
+  // first the hot copies of the matrices, the segments' and the extracted rows' values, from the full (just scaled) CSR
+  if (c->ha_val != c->a_val) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_a, c->a_val, c->ha_val);
+  if (c->hat_val != c->at_val) k_permute<<<grid_for(hot_t), kBlock, 0, c->stream>>>(hot_t, c->dense.s_perm_at, c->at_val, c->hat_val);
+  if (c->dense.on) k_permute<<<grid_for(c->dense.nent), kBlock, 0, c->stream>>>(c->dense.nent, c->dense.perm, c->a_val, c->dense.val);
+  if (c->long_a.on) k_permute<<<grid_for(c->long_a.nent), kBlock, 0, c->stream>>>(c->long_a.nent, c->long_a.perm, c->a_val, c->long_a.val);
+  if (c->long_at.on) k_permute<<<grid_for(c->long_at.nent), kBlock, 0, c->stream>>>(c->long_at.nent, c->long_at.perm, c->at_val, c->long_at.val);
   if (c->pa.on) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->pa.perm, c->ha_val, c->pa.val);
-  if (c->pat.on) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->pat.perm, c->hat_val, c->pat.val);
+  if (c->pat.on) k_permute<<<grid_for(hot_t), kBlock, 0, c->stream>>>(hot_t, c->pat.perm, c->hat_val, c->pat.val);
   if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->ha_val, c->ja.val);
   if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->hat_val, c->jat.val);
   if (c->pba.on) k_permute_pad<<<grid_for(c->pba.np), kBlock, 0, c->stream>>>(c->pba.np, c->pba.perm, c->ha_val, c->pba.val);
@@ -3083,6 +3145,48 @@ static void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const
     D->st_off[j + 1] = (int32_t)D->st_idx.size();
   }
 }
+constexpr int kLongExtract = 2048;  // rows longer than this leave the layouts when CUOPT_AMD_LONG_ROWS=1
+struct LongHost {
+  bool on = false;
+  std::vector<int32_t> row, row_ch, row_flag, ch_k0, ch_len, idx, perm;
+};
+// (h_off, h_idx, h_perm): the hot CSR so far -- empty: the full CSR (base_off, base_idx), identity permutation; rewritten without
+// the long rows' entries when there are any
+static void extract_long_rows(int32_t rows, const int32_t* base_off, const int32_t* base_idx, std::vector<int32_t>& h_off,
+                              std::vector<int32_t>& h_idx, std::vector<int32_t>& h_perm, const std::vector<int32_t>* first_seg, LongHost* L)
+{
+  // opt-in (CUOPT_AMD_LONG_ROWS=1): measured on the power-law and block-angular workloads (profiles/r03_long_rows.txt) the two
+  // extra launches cost more than the imbalance they remove
+  const char* env = getenv("CUOPT_AMD_LONG_ROWS");
+  if (!env || atoi(env) == 0) return;
+  const bool full      = h_off.empty();
+  const int32_t* off   = full ? base_off : h_off.data();
+  const int32_t* idx   = full ? base_idx : h_idx.data();
+  bool any = false;
+  for (int32_t r = 0; r < rows && !any; ++r) any = off[r + 1] - off[r] > kLongExtract;
+  if (!any) return;
+  std::vector<int32_t> n_off((size_t)rows + 1, 0), n_idx, n_perm;
+  n_idx.reserve((size_t)off[rows]), n_perm.reserve((size_t)off[rows]);
+  for (int32_t r = 0; r < rows; ++r) {
+    const int len = off[r + 1] - off[r];
+    if (len > kLongExtract) {
+      L->row.push_back(r);
+      L->row_flag.push_back(first_seg && (*first_seg)[r] >= 0 ? 1 : 0);
+      L->row_ch.push_back((int32_t)L->ch_k0.size());
+      for (int k0 = 0; k0 < len; k0 += kDenseChunk) {
+        L->ch_k0.push_back((int32_t)L->idx.size() + k0);
+        L->ch_len.push_back(std::min(kDenseChunk, len - k0));
+      }
+      for (int k = off[r]; k < off[r + 1]; ++k) L->idx.push_back(idx[k]), L->perm.push_back(full ? k : h_perm[k]);
+    } else {
+      for (int k = off[r]; k < off[r + 1]; ++k) n_idx.push_back(idx[k]), n_perm.push_back(full ? k : h_perm[k]);
+    }
+    n_off[r + 1] = (int32_t)n_idx.size();
+  }
+  L->row_ch.push_back((int32_t)L->ch_k0.size());
+  L->on = true;
+  h_off.swap(n_off), h_idx.swap(n_idx), h_perm.swap(n_perm);
+}
 static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
 
 extern "C" {
@@ -3174,21 +3278,48 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   std::vector<int32_t> la = long_rows(m, a_offsets), lat;  // alive until the stream is synchronised at the end
   ctx->a_nlong = (int)la.size();
   if (ctx->a_nlong) TRY(upload_i32(ctx, &ctx->a_long, la.data(), la.size()));
-  // dense row segments leave the hot loop's copy of the matrix (single-GPU solves; CUOPT_AMD_DENSE=0 switches the path off)
+  // dense row segments and rows of thousands of nonzeros leave the hot loop's copy of the matrix (single-GPU solves;
+  // CUOPT_AMD_DENSE=0 / CUOPT_AMD_LONG_ROWS=0 switch the two paths off)
+  const bool one_gpu = !g_create_sharded;
+  g_create_sharded   = 0;
   DenseHost DH;
-  if (!g_create_sharded) find_dense_segments(m, n, a_offsets, a_indices, &DH);
-  g_create_sharded       = 0;
-  const int32_t* A_off   = DH.on ? DH.s_off.data() : a_offsets;
-  const int32_t* A_idx   = DH.on ? DH.s_idx.data() : a_indices;
+  LongHost LA, LAT;
+  std::vector<int32_t> hA_off, hA_idx, hA_perm, hT_off, hT_idx, hT_perm;  // the hot CSRs where they differ from the full ones
+  if (one_gpu) find_dense_segments(m, n, a_offsets, a_indices, &DH);
+  if (DH.on) hA_off.swap(DH.s_off), hA_idx.swap(DH.s_idx), hA_perm.swap(DH.s_perm);
+  if (one_gpu) extract_long_rows(m, a_offsets, a_indices, hA_off, hA_idx, hA_perm, DH.on ? &DH.first_seg : nullptr, &LA);
+  const bool hot_a     = !hA_off.empty();
+  const int32_t* A_off = hot_a ? hA_off.data() : a_offsets;
+  const int32_t* A_idx = hot_a ? hA_idx.data() : a_indices;
   ctx->ha_off = ctx->a_off, ctx->ha_idx = ctx->a_idx, ctx->ha_val = ctx->a_val;
   ctx->dense.hot_nnz = (int64_t)A_off[m];
+  auto upload_long = [&](pdlpdev_ctx::LongRows& L, const LongHost& H) -> int {
+    L.nrows = (int)H.row.size(), L.nchunks = (int)H.ch_k0.size(), L.nent = (int64_t)H.idx.size();
+    TRY(upload_i32(ctx, &L.row, H.row.data(), H.row.size()));
+    TRY(upload_i32(ctx, &L.row_ch, H.row_ch.data(), H.row_ch.size()));
+    TRY(upload_i32(ctx, &L.row_flag, H.row_flag.data(), H.row_flag.size()));
+    TRY(upload_i32(ctx, &L.ch_k0, H.ch_k0.data(), H.ch_k0.size()));
+    TRY(upload_i32(ctx, &L.ch_len, H.ch_len.data(), H.ch_len.size()));
+    TRY(upload_i32(ctx, &L.idx, H.idx.data(), H.idx.size(), 8));
+    TRY(upload_i32(ctx, &L.perm, H.perm.data(), H.perm.size()));
+    TRY(dev_alloc(ctx, &L.val, (size_t)L.nent + 8));
+    TRY(dev_alloc(ctx, &L.part, (size_t)L.nchunks + 8));
+    L.on = true;
+    return 0;
+  };
+  if (hot_a) {
+    TRY(upload_i32(ctx, &ctx->ha_off, A_off, (size_t)m + 1));
+    TRY(upload_i32(ctx, &ctx->ha_idx, A_idx, (size_t)ctx->dense.hot_nnz, 8));
+    TRY(dev_alloc(ctx, &ctx->ha_val, (size_t)ctx->dense.hot_nnz + 8));
+    TRY(upload_i32(ctx, &ctx->dense.s_perm_a, hA_perm.data(), hA_perm.size()));
+  }
+  if (LA.on) {
+    TRY(upload_long(ctx->long_a, LA));
+    if (timing) fprintf(stderr, "[cuopt_amd setup]   long rows of A: %d rows, %lld nonzeros in %d chunks\n", ctx->long_a.nrows, (long long)ctx->long_a.nent, ctx->long_a.nchunks);
+  }
   if (DH.on) {
     pdlpdev_ctx::Dense& D = ctx->dense;
     D.nrows = (int)DH.row.size(), D.nseg = (int)DH.seg_row.size(), D.ntiles = (int)DH.tile_id.size(), D.nent = DH.nent;
-    TRY(upload_i32(ctx, &ctx->ha_off, A_off, (size_t)m + 1));
-    TRY(upload_i32(ctx, &ctx->ha_idx, A_idx, (size_t)D.hot_nnz, 8));
-    TRY(dev_alloc(ctx, &ctx->ha_val, (size_t)D.hot_nnz + 8));
-    TRY(upload_i32(ctx, &D.s_perm_a, DH.s_perm.data(), DH.s_perm.size()));
     TRY(upload_i32(ctx, &D.row, DH.row.data(), DH.row.size()));
     TRY(upload_i32(ctx, &D.row_seg, DH.row_seg.data(), DH.row_seg.size()));
     TRY(upload_i32(ctx, &D.seg_row, DH.seg_row.data(), DH.seg_row.size()));
@@ -3205,11 +3336,10 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     TRY(upload_i32(ctx, &D.row_ch, DH.row_ch.data(), DH.row_ch.size()));
     TRY(dev_alloc(ctx, &D.ch_part, (size_t)D.nchunks + 8));
     TRY(dev_alloc(ctx, &D.val, (size_t)D.nent + 8));
-    TRY(dev_alloc(ctx, &D.add_m, (size_t)m));
-    TRY(dev_alloc(ctx, &D.add_n, (size_t)n));
     D.on = true;
     if (timing) fprintf(stderr, "[cuopt_amd setup]   dense: %d segments in %d rows, %lld of %lld nonzeros stored index-free\n", D.nseg, D.nrows, (long long)D.nent, (long long)ctx->nnz);
   }
+  if (DH.on || LA.on) TRY(dev_alloc(ctx, &ctx->dense.add_m, (size_t)m));
   std::vector<int32_t> rba = build_row_blocks(m, A_off);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
@@ -3295,17 +3425,30 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     lat           = long_rows(n, at_offsets);
     ctx->at_nlong = (int)lat.size();
     if (ctx->at_nlong) TRY(upload_i32(ctx, &ctx->at_long, lat.data(), lat.size()));
-    if (DH.on) strip_transpose(DH, &DH, n, at_offsets, at_indices);
-    const int32_t* T_off = DH.on ? DH.st_off.data() : at_offsets;
-    const int32_t* T_idx = DH.on ? DH.st_idx.data() : at_indices;
-    ctx->hat_off = ctx->at_off, ctx->hat_idx = ctx->at_idx, ctx->hat_val = ctx->at_val;
     if (DH.on) {
-      if ((int64_t)T_off[n] != ctx->dense.hot_nnz) return fail(-1, "pdlpdev_create: the sparse remainders of A and A^T disagree");
-      TRY(upload_i32(ctx, &ctx->hat_off, T_off, (size_t)n + 1));
-      TRY(upload_i32(ctx, &ctx->hat_idx, T_idx, (size_t)ctx->dense.hot_nnz, 8));
-      TRY(dev_alloc(ctx, &ctx->hat_val, (size_t)ctx->dense.hot_nnz + 8));
-      TRY(upload_i32(ctx, &ctx->dense.s_perm_at, DH.st_perm.data(), DH.st_perm.size()));
+      strip_transpose(DH, &DH, n, at_offsets, at_indices);
+      hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
     }
+    if (one_gpu) extract_long_rows(n, at_offsets, at_indices, hT_off, hT_idx, hT_perm, nullptr, &LAT);
+    const bool hot_t     = !hT_off.empty();
+    const int32_t* T_off = hot_t ? hT_off.data() : at_offsets;
+    const int32_t* T_idx = hot_t ? hT_idx.data() : at_indices;
+    ctx->hat_off = ctx->at_off, ctx->hat_idx = ctx->at_idx, ctx->hat_val = ctx->at_val;
+    ctx->hot_nnz_at = (int64_t)T_off[n];
+    if (hot_t) {
+      TRY(upload_i32(ctx, &ctx->hat_off, T_off, (size_t)n + 1));
+      TRY(upload_i32(ctx, &ctx->hat_idx, T_idx, (size_t)ctx->hot_nnz_at, 8));
+      TRY(dev_alloc(ctx, &ctx->hat_val, (size_t)ctx->hot_nnz_at + 8));
+      TRY(upload_i32(ctx, &ctx->dense.s_perm_at, hT_perm.data(), hT_perm.size()));
+    }
+    if (LAT.on) {
+      // a long column inside a 256-column tile the dense segments touch starts from what k_dense_cols just wrote there (possibly 0)
+      if (DH.on)
+        for (size_t b = 0; b < LAT.row.size(); ++b) LAT.row_flag[b] = std::binary_search(DH.tile_id.begin(), DH.tile_id.end(), LAT.row[b] / kBlock) ? 1 : 0;
+      TRY(upload_long(ctx->long_at, LAT));
+      if (timing) fprintf(stderr, "[cuopt_amd setup]   long rows of A^T: %d rows, %lld nonzeros in %d chunks\n", ctx->long_at.nrows, (long long)ctx->long_at.nent, ctx->long_at.nchunks);
+    }
+    if (DH.on || LAT.on) TRY(dev_alloc(ctx, &ctx->dense.add_n, (size_t)n));
     std::vector<int32_t> rbt = build_row_blocks(n, T_off);
     ctx->at_nb = (int)rbt.size() / 2 - 1;
     TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
@@ -3335,14 +3478,13 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     // small LPs: a whole batch of attempts inside one workgroup (CUOPT_AMD_SMALL=0 switches it off)
     const char* small_env = getenv("CUOPT_AMD_SMALL");
     const int tier        = resident_tier(m, n, ctx->nnz);
-    ctx->small_resident   = tier >= 0 && !(small_env && atoi(small_env) == 0) && !ctx->dense.on;
+    ctx->small_resident   = tier >= 0 && !(small_env && atoi(small_env) == 0) && !ctx->dense.add_m && !ctx->dense.add_n;
     if (small_env && atoi(small_env) != 0 && tier < 0)
       return fail(-1, "CUOPT_AMD_SMALL=1: the LP does not fit the resident kernel (m, n <= 2048, nnz <= 4096 ...)");
   }
-  if (ctx->dense.on) {  // every layout adds the segments' contribution ahead of its epilogue
-    ctx->pa.v.dense_add = ctx->ja.v.dense_add = ctx->pba.v.dense_add = ctx->dense.add_m;
-    ctx->pat.v.dense_add = ctx->jat.v.dense_add = ctx->pbat.v.dense_add = ctx->dense.add_n;
-  }
+  // every layout adds what the dense segments / the extracted long rows contribute ahead of its epilogue (null: nothing to add)
+  ctx->pa.v.dense_add = ctx->ja.v.dense_add = ctx->pba.v.dense_add = ctx->dense.add_m;
+  ctx->pat.v.dense_add = ctx->jat.v.dense_add = ctx->pbat.v.dense_add = ctx->dense.add_n;
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pba.on ? ctx->pba.v.B : 0, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pbat.on ? ctx->pbat.v.B : 0, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
@@ -4087,14 +4229,21 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 // dense row segments: their share of A v (transpose = 0) / A^T v lands in dense.add_m / add_n right before the layout's kernel adds it
 static void dense_part(pdlpdev_ctx* ctx, int transpose, const double* v0, const double* v1, int mode, int in_loop)
 {
-  const pdlpdev_ctx::Dense& D = ctx->dense;
-  if (!D.on) return;
-  DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
-  if (transpose) {
-    launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
-  } else {
-    launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl, v0, v1, mode, in_loop);
-    launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl, in_loop, D.add_m);
+  const pdlpdev_ctx::Dense& D    = ctx->dense;
+  const pdlpdev_ctx::LongRows& L = transpose ? ctx->long_at : ctx->long_a;
+  if (D.on) {
+    DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
+    if (transpose) {
+      launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
+    } else {
+      launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl, v0, v1, mode, in_loop);
+      launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl, in_loop, D.add_m);
+    }
+  }
+  if (L.on) {  // after the segments: a row that owns both starts from their share
+    LongView W{L.row, L.row_ch, L.row_flag, L.ch_k0, L.ch_len, L.idx, L.val, L.part};
+    launch_k(ctx, k_long_rows, L.nchunks, kBlock, 0, W, ctx->ctl, v0, v1, mode, in_loop);
+    launch_k(ctx, k_long_rows_finish, (L.nrows + kBlock - 1) / kBlock, kBlock, 0, W, L.nrows, ctx->ctl, in_loop, transpose ? D.add_n : D.add_m);
   }
 }
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
