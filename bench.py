@@ -230,15 +230,17 @@ def main():
     prefix = {"panel": "k_panel_", "jag": "k_jag_", "stream": "k_spmv_", "resident": "k_spmv_", "pb": "k_pb_"}[lname]
     kname = prefix + ("a_dual" if dom == "SPMV_A_DUAL" else "at_step")
     # HBM/fabric bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this very
-    # command (profiles/r02_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
+    # command (profiles/r03_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.workload)))
-        if world == 1 and kname in pmc:
-            traffic = round(pmc[kname]["traffic_bytes_corrected"])
-    except Exception:
-        pass
+    traffic, traffic_file = None, None
+    for rnd in ("r03", "r02"):  # the newest committed PMC summary of this workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, args.workload))))
+            if world == 1 and kname in pmc:
+                traffic, traffic_file = round(pmc[kname]["traffic_bytes_corrected"]), "profiles/%s_pmc_%s.json" % (rnd, args.workload)
+                break
+        except Exception:
+            pass
     roofline = dict(bound="hbm", kernel=kname,
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -249,8 +251,8 @@ def main():
                     iteration_frac_of_peak=round(synthetic.iteration_bytes_min(m, n, nnz) * its_per_s / 1e9
                                                  / HBM_PEAK_GBS / max(world, 1), 4),
                     traffic_source=None if traffic is None else
-                    "profiles/r02_pmc_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                    "(scripts/r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % args.workload)
+                    "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                    "(scripts/r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
     solver.close()
 
     # ---- run to the default 1e-4 termination: wall clock incl. setup -----------------------------------

@@ -36,21 +36,21 @@ static double* dalloc(size_t n)
   double* p = (double*)malloc((n ? n : 1) * sizeof(double));
   if (!p) return p;
   const long long cnt = (long long)(n ? n : 1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cnt > 65536)
   for (long long i = 0; i < cnt; ++i) p[i] = 0.0;
   return p;
 }
 /* parallel copy of a matrix array by ROWS: the pages of row block b are touched by the thread that multiplies row block b */
 static void copy_rows_d(int rows, const int* offsets, const double* src, double* dst)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (rows > 16384)
   for (int i = 0; i < rows; ++i)
     for (int k = offsets[i]; k < offsets[i + 1]; ++k) dst[k] = src[k];
 }
 static int* copy_rows_i(int rows, const int* offsets, const int* src)
 {
   int* dst = (int*)malloc(sizeof(int) * (size_t)(offsets[rows] > 0 ? offsets[rows] : 1));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (rows > 16384)
   for (int i = 0; i < rows; ++i)
     for (int k = offsets[i]; k < offsets[i + 1]; ++k) dst[k] = src[k];
   return dst;
@@ -1214,7 +1214,7 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
       /* compute_next_primal_dual_solution, pdhg.cu:160-235 */
       if (total_pdhg == 0 || (its_since_restart == 0 && last_restart_was_average))
         orc_spmv(n, t_offsets, t_idx_local, P.At, y, aty); /* compute_At_y :119-134 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384) /* (small LPs: a fork per loop would cost more than the loop) */
       for (int j = 0; j < n; ++j) { /* primal_projection, utils.cuh:80-95 */
         double gradient = P.c[j] - aty[j];
         double next     = x[j] - (tau * gradient);
@@ -1224,7 +1224,7 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
         xbar[j]         = next - x[j] + next;
       }
       orc_spmv(m, offsets, idx_local, P.A, xbar, ax); /* pdhg.cu:87-97 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m > 16384)
       for (int i = 0; i < m; ++i) {                 /* dual_projection, utils.cuh:97-112 */
         double next = y[i] - (sigma * ax[i]);
         double low  = next + sigma * P.lo[i];
@@ -1236,7 +1236,7 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
       total_pdhg += 1;
       /* compute_step_sizes, adaptive_step_size_strategy.cu:231-345 then kernel :91-188 */
       orc_spmv(n, t_offsets, t_idx_local, P.At, yn, atyn);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
       for (int j = 0; j < n; ++j) tmpn[j] = atyn[j] - aty[j];
       double interaction = blocked_sum2(n, tmpn, dx);
       double ndx2        = blocked_sum2(n, dx, dx);
@@ -1260,9 +1260,9 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
     }
     /* add_current_solution_to_weighted_average_solution, weighted_average_solution.cu:73-108 :
      * the weight is the step size AFTER the update above (pdlp.cu:1216-1220) */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
     for (int j = 0; j < n; ++j) sumx[j] = sumx[j] + step_size * xn[j];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m > 16384)
     for (int i = 0; i < m; ++i) sumy[i] = sumy[i] + step_size * yn[i];
     sumw += step_size;
     its_since_restart += 1;

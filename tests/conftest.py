@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the oracle's OpenMP threads sleep between its (many, short) parallel regions instead of spinning: the GPU boxes give a test run a
+# CPU quota, and spinning workers eat it while the test thread waits for the device
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
