@@ -12,8 +12,9 @@ A "step" is ONE PDLP iteration (one accepted PDHG step), includin
 the major-iteration work (averages, 2 convergence evaluations, restart logic every 40 steps): the
 timed region is `cuoptamd_solver_advance(K)` on a solver whose problem is already resident in HBM, with
 all six tolerances at 0 so that no early exit can shorten the run (the reference's own device:
-cpp/tests/linear_programming/pdlp_test.cu:145-148).  N > 1 shards the SAME LP by row blocks (strong
-scaling) with one RCCL all-reduce of the A^T y partial products per step.
+cpp/tests/linear_programming/pdlp_test.cu:145-148).  N > 1 shards the SAME LP (strong scaling): every rank holds a row block
+and a column block of A, the slices of xbar and y' are all-gathered over RCCL each step (owner-computes dataflow, the default;
+CUOPT_AMD_SHARD_DATAFLOW / CUOPT_AMD_SHARD_TRANSPORT select the others, `config.parallelism` names what ran).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused CSR SpMV + dual
 projection), timed with HIP events on the solver's stream by pdlpdev_time_kernel; `cpu_baseline` is the
