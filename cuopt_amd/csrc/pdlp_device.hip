@@ -322,6 +322,7 @@ struct pdlpdev_ctx {
     PanelView v{};
     int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
     double* val   = nullptr;
+    int64_t nent  = 0;        // nonzeros inside the panels (rows with a workgroup of their own are read from the CSR)
   } pa, pat;
   int cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   // rows of A / of A^T with more than kLongRow nonzeros (set-up kernels give each a workgroup instead of a lane)
@@ -2229,7 +2230,8 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 // ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
 struct PanelHost {
   bool ok = false, any_long = false;
-  int W = 0, S = 0;
+  int W = 0, S = 0;                        // W: panels only
+  std::vector<int32_t> own_row, own_ptr;   // rows of more than kPanelOwnRow nonzeros (a workgroup each, behind the panels); per panel
   std::vector<int32_t> row0, tile_ptr;
   std::vector<int64_t> rp_base;
   // the three big arrays are deliberately NOT zero-filled (every entry is written by pass 2)
@@ -2281,11 +2283,19 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   // 60 K nonzeros (beyond that the row-sum strip, kPanelMaxRows, and the 16-bit tile pointers set the limits).
   const char* target_env = getenv("CUOPT_AMD_PANEL_NNZ");
   const int64_t cap    = target_env ? std::max<int64_t>(2048, atoll(target_env)) : 60000;
-  const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz + 511) / 512));
+  const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz + 511) / 512));  // (own rows: recomputed below)
   // A panel takes rows while they fit under the target (a row above the target is a panel of its own): all panels run at
   // once, so the LARGEST one sets the kernel time -- letting a panel overshoot by its last row made panels of 42 K nonzeros
   // next to the average 22 K on the power-law LP (rows of up to 20 000 nonzeros) and cost 26 of its 117 us.  The target grows
   // (proportionally first, then in 1 % steps) until the panels fit the 512 resident slots again.
+  // rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels (CUOPT_AMD_PANEL_OWN_ROWS=0: they stay inside)
+  const char* own_env = getenv("CUOPT_AMD_PANEL_OWN_ROWS");
+  const bool own_on   = !(own_env && atoi(own_env) == 0);
+  std::vector<char> is_own(rows, 0);
+  int64_t own_nnz = 0;
+  if (own_on)
+    for (int32_t i = 0; i < rows; ++i)
+      if (off[i + 1] - off[i] > kPanelOwnRow) is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];
   auto cut = [&](int64_t tgt) {
     P.row0.assign(1, 0);
     int32_t start = 0;
@@ -2293,7 +2303,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
       int32_t end = start;
       int64_t cnt = 0;
       while (end < rows && end - start < kPanelMaxRows) {
-        const int64_t len = off[end + 1] - off[end];
+        const int64_t len = is_own[end] ? 0 : off[end + 1] - off[end];
         if (cnt > 0 && cnt + len > tgt) break;
         cnt += len;
         ++end;
@@ -2302,21 +2312,33 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
       start = end;
     }
   };
-  int64_t tgt = target;
+  int64_t tgt = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz - own_nnz + 511) / 512));
+  (void)target;
   cut(tgt);
-  for (int it = 0; it < 64 && (int)P.row0.size() - 1 > 512 && tgt < cap; ++it) {
+  // (the rows with a workgroup of their own share the 512 resident slots with the panels: behind a full house they would run alone)
+  const int slots = std::max(64, 512 - (int)P.own_row.size());
+  tgt             = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz - own_nnz + slots - 1) / slots));
+  cut(tgt);
+  for (int it = 0; it < 64 && (int)P.row0.size() - 1 > slots && tgt < cap; ++it) {
     const int64_t w = (int64_t)P.row0.size() - 1;
-    tgt = std::min<int64_t>(cap, it == 0 ? (int64_t)((double)tgt * (double)w / 512.0 * 1.002) + 1 : tgt + tgt / 100 + 1);
+    tgt = std::min<int64_t>(cap, it == 0 ? (int64_t)((double)tgt * (double)w / (double)slots * 1.002) + 1 : tgt + tgt / 100 + 1);
     cut(tgt);
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S;
-  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = off[i + 1] - off[i] > kLongRow;
+  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
+  P.own_ptr.assign((size_t)W + 1, 0);
+  for (int w = 0, q = 0; w < W; ++w) {
+    while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;
+    P.own_ptr[w + 1] = q;
+  }
   // pass 1: nonzeros per (panel, slab) -- panels are independent, so both passes run over host threads
   std::vector<int64_t> count((size_t)W * S + 1, 0);
   cuopt_amd::parallel_tasks(W, [&](int w) {
     int64_t* cw = &count[(size_t)w * S];
-    for (int64_t t = off[P.row0[w]]; t < off[P.row0[w + 1]]; ++t) cw[idx[t] / slab_w] += 1;
+    for (int32_t i = P.row0[w]; i < P.row0[w + 1]; ++i)
+      if (!is_own[i])
+        for (int64_t t = off[i]; t < off[i + 1]; ++t) cw[idx[t] / slab_w] += 1;
   }, nnz);
   P.tile_ptr.resize((size_t)W * S + 1);
   int64_t pos = 0;
@@ -2327,7 +2349,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   P.tile_ptr[(size_t)W * S] = (int32_t)pos;
   // pass 2: placement + per-tile row pointers
-  P.nnz = (size_t)nnz, P.rowptr_size = (size_t)S * ((size_t)rows + W);
+  P.nnz = (size_t)(nnz - own_nnz), P.rowptr_size = (size_t)S * ((size_t)rows + W);
   P.perm.reset(P.nnz), P.col.reset(P.nnz);
   P.rowptr.reset(P.rowptr_size);
   P.rp_base.resize((size_t)W * S);
@@ -2342,6 +2364,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
     for (int32_t i = a; i < b; ++i) {
       for (int s2 = 0; s2 < S; ++s2)
         P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + (i - a))] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
+      if (is_own[i]) continue;
       for (int32_t t = off[i]; t < off[i + 1]; ++t) {
         const int s2 = idx[t] / slab_w;
         const int32_t q = cursor[s2]++;
@@ -2967,7 +2990,8 @@ static int pb_rows(pdlpdev_ctx* c, void (*kernel)(PbView, KArgs...), const pdlpd
   return 0;
 }
 
-static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h)
+static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h, const int32_t* d_off, const int32_t* d_idx,
+                         const double* d_val)
 {
   if (!h.ok) return 0;
   int32_t *row0 = nullptr, *tile_ptr = nullptr, *col = nullptr;
@@ -2984,6 +3008,16 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
   TRY(dev_alloc(c, &dst->val, h.nnz));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
   dst->v  = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
+  dst->nent = (int64_t)h.nnz;
+  if (!h.own_row.empty()) {  // W becomes the number of workgroups / partials: the panels, then a workgroup per own row
+    int32_t *own_row = nullptr, *own_ptr = nullptr;
+    TRY(upload_i32(c, &own_row, h.own_row.data(), h.own_row.size()));
+    TRY(upload_i32(c, &own_ptr, h.own_ptr.data(), h.own_ptr.size()));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dst->v.NP = h.W, dst->v.W = h.W + (int)h.own_row.size();
+    dst->v.own_row = own_row, dst->v.own_ptr = own_ptr;
+    dst->v.csr_off = d_off, dst->v.csr_idx = d_idx, dst->v.csr_val = d_val;
+  }
   dst->on = true;
   return 0;
 }
@@ -2997,13 +3031,14 @@ static int sync_panel_values(pdlpdev_ctx* c)
   if (c->dense.on) k_permute<<<grid_for(c->dense.nent), kBlock, 0, c->stream>>>(c->dense.nent, c->dense.perm, c->a_val, c->dense.val);
   if (c->long_a.on) k_permute<<<grid_for(c->long_a.nent), kBlock, 0, c->stream>>>(c->long_a.nent, c->long_a.perm, c->a_val, c->long_a.val);
   if (c->long_at.on) k_permute<<<grid_for(c->long_at.nent), kBlock, 0, c->stream>>>(c->long_at.nent, c->long_at.perm, c->at_val, c->long_at.val);
-  if (c->pa.on) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->pa.perm, c->ha_val, c->pa.val);
-  if (c->pat.on) k_permute<<<grid_for(hot_t), kBlock, 0, c->stream>>>(hot_t, c->pat.perm, c->hat_val, c->pat.val);
+  (void)hot, (void)hot_t;
+  if (c->pa.on) k_permute<<<grid_for(c->pa.nent), kBlock, 0, c->stream>>>(c->pa.nent, c->pa.perm, c->ha_val, c->pa.val);
+  if (c->pat.on) k_permute<<<grid_for(c->pat.nent), kBlock, 0, c->stream>>>(c->pat.nent, c->pat.perm, c->hat_val, c->pat.val);
   if (c->ja.on) k_permute<<<grid_for(c->ja.nent), kBlock, 0, c->stream>>>(c->ja.nent, c->ja.perm, c->ha_val, c->ja.val);
   if (c->jat.on) k_permute<<<grid_for(c->jat.nent), kBlock, 0, c->stream>>>(c->jat.nent, c->jat.perm, c->hat_val, c->jat.val);
   if (c->pba.on) k_permute_pad<<<grid_for(c->pba.np), kBlock, 0, c->stream>>>(c->pba.np, c->pba.perm, c->ha_val, c->pba.val);
   if (c->pbat.on) k_permute_pad<<<grid_for(c->pbat.np), kBlock, 0, c->stream>>>(c->pbat.np, c->pbat.perm, c->hat_val, c->pbat.val);
-  if (c->poc.on) k_permute<<<grid_for(c->oc_nnz), kBlock, 0, c->stream>>>(c->oc_nnz, c->poc.perm, c->oc_val, c->poc.val);
+  if (c->poc.on) k_permute<<<grid_for(c->poc.nent), kBlock, 0, c->stream>>>(c->poc.nent, c->poc.perm, c->oc_val, c->poc.val);
   if (c->joc.on) k_permute<<<grid_for(c->joc.nent), kBlock, 0, c->stream>>>(c->joc.nent, c->joc.perm, c->oc_val, c->joc.val);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -3412,7 +3447,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, A_off, A_idx, "A")) {
       PanelHost ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed);
       lap("build_panels A");
-      TRY(upload_panels(ctx, &ctx->pa, ha));
+      TRY(upload_panels(ctx, &ctx->pa, ha, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
       lap("upload panels A");
       HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
     }
@@ -3469,7 +3504,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->jat.on && !ctx->pbat.on && want_panels(n, m, T_off, T_idx, "A^T")) {
       PanelHost hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
       lap("build_panels At");
-      TRY(upload_panels(ctx, &ctx->pat, hat));
+      TRY(upload_panels(ctx, &ctx->pat, hat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload panels At");
       HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
@@ -3854,7 +3889,7 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx
     const bool panels = mode == "panel" || (mode == "auto" && gcols * 8 > ws_limit && gather_working_set(nc, (int32_t)gcols, off, ridx.data()) > ws_limit);
     if (nc > 0 && !ctx->joc.on && panels) {
       PanelHost h = build_panels(nc, (int32_t)gcols, off, ridx.data(), slab_bytes, true);
-      TRY(upload_panels(ctx, &ctx->poc, h));
+      TRY(upload_panels(ctx, &ctx->poc, h, ctx->oc_off, ctx->oc_idx, ctx->oc_val));
     }
   }
   TRY(dev_alloc(ctx, &ctx->part_oc, (size_t)8 * std::max(oc_partials(ctx), 1)));
@@ -3863,7 +3898,7 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx
     if (tr && std::string(tr) == "p2p") TRY(p2p_setup(ctx));
     else if (tr && std::string(tr) != "collective") return fail(-1, "CUOPT_AMD_SHARD_TRANSPORT must be collective or p2p");
   }
-  if (ctx->poc.on) k_permute<<<grid_for(ctx->oc_nnz), kBlock, 0, s>>>(ctx->oc_nnz, ctx->poc.perm, ctx->oc_val, ctx->poc.val);
+  if (ctx->poc.on) k_permute<<<grid_for(ctx->poc.nent), kBlock, 0, s>>>(ctx->poc.nent, ctx->poc.perm, ctx->oc_val, ctx->poc.val);
   if (ctx->joc.on) k_permute<<<grid_for(ctx->joc.nent), kBlock, 0, s>>>(ctx->joc.nent, ctx->joc.perm, ctx->oc_val, ctx->joc.val);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // the host arrays are the caller's

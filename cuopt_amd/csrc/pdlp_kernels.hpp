@@ -293,7 +293,18 @@ struct PanelView {
   const int32_t* __restrict__ col;       // permuted column indices
   const double* __restrict__ val;        // permuted values
   const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
+  // Rows of more than kPanelOwnRow nonzeros are not in the panels: each gets a workgroup of its own BEHIND the panels in the same
+  // grid (W = NP panels + the own rows; a 20 000-entry row inside a panel is one wave adding up 3 000-entry segments while seven
+  // waves wait, and that panel sets the kernel time).  They are read from the CSR arrays the layout was built on.
+  int NP = 0;                                   // panels proper (0: same as W)
+  const int32_t* __restrict__ own_row = nullptr;   // W - NP rows
+  const int32_t* __restrict__ own_ptr = nullptr;   // NP + 1: the own rows inside each panel's row range (marked: skipped by its epilogue)
+  const int32_t* __restrict__ csr_off = nullptr;
+  const int32_t* __restrict__ csr_idx = nullptr;
+  const double* __restrict__ csr_val  = nullptr;
 };
+constexpr int kPanelOwnRow = 4096;
+constexpr long long kPanelNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
 
 // ---- the chunks of a panel, one stage ahead ------------------------------------------------------------------------
 // A chunk is <= kPanelChunk consecutive nonzeros of one tile, handled in R = ceil(len / 512) rounds (lane <-> nonzero;
@@ -354,11 +365,51 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
   __shared__ int tile_s[17];        // this panel's tile boundaries (S <= 16) and row-pointer bases, fetched once
   __shared__ long long base_s[16];
   const int w  = blockIdx.x;
+  const int NP = P.NP ? P.NP : P.W;
+  if (w >= NP) {
+    // ---- a row of its own: the whole workgroup strides over it, 16 entries per thread in flight (fixed tree, compared with a
+    // tolerance like every long row)
+    const int r  = P.own_row[w - NP];
+    const int k0 = P.csr_off[r], k1 = P.csr_off[r + 1];
+    double part[1] = {0.0};
+    constexpr int kLongU = 16;
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += kLongU * kPanelThreads) {
+      double a[kLongU];
+      int j[kLongU];
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) {
+        a[u] = 0.0, j[u] = 0;
+        if (k + u * kPanelThreads < k1) {
+          a[u] = __builtin_nontemporal_load(P.csr_val + k + u * kPanelThreads);
+          j[u] = __builtin_nontemporal_load(P.csr_idx + k + u * kPanelThreads);
+        }
+      }
+      double xv[kLongU];
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) xv[u] = k + u * kPanelThreads < k1 ? vec[j[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
+    }
+    block_reduce<SumOp, 1, kPanelWaves>(part, prod);
+    double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+    for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+    if (threadIdx.x == 0) {
+      epi.row(r, dense_plus(P.dense_add, r, part[0]), acc);
+      if constexpr (Epi::NQ > 0) {
+#pragma unroll
+        for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
+      }
+    }
+    return;
+  }
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
   if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
   if (threadIdx.x < P.S) base_s[threadIdx.x] = P.rp_base[w * P.S + threadIdx.x];
   for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
   __syncthreads();
+  if (P.own_ptr)  // rows that have a workgroup of their own: no segment of theirs is in the tiles, the epilogue below skips them
+    for (int q = P.own_ptr[w] + (int)threadIdx.x; q < P.own_ptr[w + 1]; q += kPanelThreads) psum[P.own_row[q] - r0] = __longlong_as_double(kPanelNotMine);
   auto advance = [&](PanelChunk c) -> PanelChunk {
     if (c.valid && c.c1 < tile_s[c.s + 1]) {  // next chunk of the same tile
       c.c0 = c.c1;
@@ -475,7 +526,8 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
-  for (int r = threadIdx.x; r < nr; r += kPanelThreads) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads)
+    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
   if constexpr (Epi::NQ > 0) {
     block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
     if (threadIdx.x == 0) {

@@ -288,3 +288,29 @@ def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch
         np.testing.assert_array_equal(got[ln <= 128], ref[ln <= 128])
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
     dev.close()
+
+
+@pytest.mark.parametrize("own", ["1", "0"])
+def test_panels_with_hub_rows_of_their_own(own, monkeypatch):
+    """rows of more than 4096 nonzeros get a workgroup each behind the panels (CUOPT_AMD_PANEL_OWN_ROWS=0: they stay inside the
+    panels, summed wave by wave): same numbers to the long-row tolerance, short rows bit-exact, same decisions"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(64 * 1024))
+    monkeypatch.setenv("CUOPT_AMD_PANEL_OWN_ROWS", own)
+    p = synthetic.generate_structured("powerlaw", m=200000, n=200000, k=10, seed=11)
+    lens = np.diff(p["offsets"])
+    assert (lens > 4096).sum() >= 2
+    dev = capi.Device(p)
+    assert dev.layout()["A"]["layout"] == "panel"
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
+    for got, ref, ln in ((dev.spmv(x, False, p["m"]), orcbind.spmv(p["offsets"], p["indices"], p["values"], x), lens),
+                         (dev.spmv(y, True, p["n"]), orcbind.spmv(to, ti, tv, y), np.diff(to))):
+        np.testing.assert_array_equal(got[ln <= 128], ref[ln <= 128])
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
+    dev.close()
+    r = capi.Solver(p, tol=0.0, iteration_limit=80).advance()
+    o = orcbind.solve(p, tol=0.0, iteration_limit=80)
+    assert (r["steps_taken"], r["attempted_steps"]) == (int(o["steps_taken"]), int(o["attempted_steps"]))
+    assert r["step_size"] == pytest.approx(o["final_step_size"], rel=1e-8)
