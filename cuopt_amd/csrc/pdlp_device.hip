@@ -4532,6 +4532,11 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
     }
     const int before = ctx->ctl_h->steps_taken, asked = target_steps - before;
     TRY(fetch_ctl(ctx, nullptr));
+    if (ctx->p2p.on && ctx->ctl_h->error != 0) {  // a wait of the direct peer transport ran out of patience: a peer is gone
+      int fault = 0;
+      HIP_TRY(hipMemcpy(&fault, ctx->p2p.fault, sizeof(int), hipMemcpyDeviceToHost));
+      if (fault) return fail(-6, "direct peer transport: rank %d waited 5 s for another rank's data (a peer failed or is stuck)", ctx->rank);
+    }
     // every rejection shrinks the step size; 64 in a row leave nothing of it: report it like the reference's invalid step
     // size instead of re-enqueueing forever.  Counted across rounds AND calls (a call asks for at most one major-iteration
     // period: 40 steps under Stable2, fewer than 64)

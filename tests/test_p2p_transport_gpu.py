@@ -85,3 +85,26 @@ def test_a_failing_rank_ends_the_sharded_solve_instead_of_hanging_it(where, data
     monkeypatch.delenv("CUOPT_AMD_FAULT_INJECT")
     ok = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=3)  # and the library is usable afterwards
     assert ok["status"] == "Optimal"
+
+
+FAULT_CHILD = r"""
+import json, sys
+sys.path.insert(0, %(root)r)
+from cuopt_amd import capi, synthetic
+p = synthetic.generate(3000, 2600, 8, seed=5)
+r = capi.solve(p, method=1, tol=1e-8, amd_num_gpus=3)
+print(json.dumps(dict(rc=r["return_code"], err=r.get("error_string", ""))))
+"""
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_that_dies_under_the_peer_transport_ends_the_solve(monkeypatch):
+    """with direct peer stores nobody sits in a collective: the surviving ranks' device-side waits run out of patience (5 s), the
+    solve ends in CUOPT_RUNTIME_ERROR naming the rank that failed first-hand"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", CUOPT_AMD_SHARD_DATAFLOW="owner", CUOPT_AMD_SHARD_TRANSPORT="p2p",
+               CUOPT_AMD_SOFT_COMMUNICATOR="1", CUOPT_AMD_FAULT_INJECT="1:advance")
+    r = subprocess.run([sys.executable, "-c", FAULT_CHILD % dict(root=ROOT)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    from cuopt_amd import capi
+    assert d["rc"] == capi.CUOPT_RUNTIME_ERROR and "rank 1 of 3" in d["err"] and "injected fault" in d["err"]

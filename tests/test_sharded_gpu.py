@@ -193,7 +193,7 @@ def test_sharded_warm_start_snapshots_add_up_and_resume():
     assert second["primal_objective"] == full["primal_objective"]
 
 
-@pytest.mark.parametrize("layout", ["jag", "panel"])
+@pytest.mark.parametrize("layout", ["jag", "panel", "pb"])
 def test_sharded_solve_through_the_other_layouts(layout, monkeypatch):
     """row-block sharding on top of the jagged / panel layouts (every rank builds them for ITS row block and that block's
     transpose): same decisions on all ranks, same optimum as the single-rank solve"""
