@@ -281,6 +281,7 @@ _proto("pdlpdev_spmv", c_int, c_void_p, c_int, c_void_p, c_void_p)
 _proto("pdlpdev_time_kernel", c_int, c_void_p, c_int, c_int, P(c_double))
 _proto("pdlpdev_synchronize", c_int, c_void_p)
 _proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
+_proto("cuoptamd_dual_simplex", c_int, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
 _proto("pdlpdev_shard_transport", c_int, c_void_p)
 _proto("pdlpdev_dense_info", c_int, c_void_p, c_void_p)
@@ -558,6 +559,27 @@ def softcomm_id(world):
     if rc != 0:
         raise CuOptError(rc, lib.pdlpdev_last_error().decode())
     return bytes(buf)
+
+
+SIMPLEX_STATUS = {1: "Optimal", 2: "PrimalInfeasible", 3: "Unbounded", 5: "IterationLimit", 6: "TimeLimit", 7: "NumericalError",
+                  8: "TooLarge", 9: "Cancelled"}
+
+
+def dual_simplex(p, time_limit=0.0, iteration_limit=0):
+    """cuoptamd_dual_simplex: the library's own small-LP dual simplex (host code, no GPU involved)"""
+    k = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]), c=_f64(p["c"]), lo=_f64(p["lo"]),
+             hi=_f64(p["hi"]), lb=_f64(p["lb"]), ub=_f64(p["ub"]))
+    m, n = int(p["m"]), int(p["n"])
+    lp = LP(m, n, _ptr(k["offsets"]), _ptr(k["indices"]), _ptr(k["values"]), _ptr(k["c"]), _ptr(k["lo"]), _ptr(k["hi"]), _ptr(k["lb"]),
+            _ptr(k["ub"]), int(bool(p.get("maximize", False))), float(p.get("objective_offset", 0.0)))
+    status, its, obj = c_int(0), c_int(0), c_double(0.0)
+    x, y, rc = np.zeros(n), np.zeros(m), np.zeros(n)
+    ret = lib.cuoptamd_dual_simplex(C.byref(lp), float(time_limit), int(iteration_limit), None, C.byref(status), C.byref(its),
+                                    C.byref(obj), _ptr(x), _ptr(y), _ptr(rc))
+    if ret != 0:
+        raise CuOptError(ret, "cuoptamd_dual_simplex")
+    return dict(status=SIMPLEX_STATUS.get(status.value, str(status.value)), iterations=its.value, objective=obj.value, x=x, y=y,
+                reduced_cost=rc)
 
 
 class Solver:

@@ -13,8 +13,11 @@
 #include <limits>
 #include <memory>
 #include <new>
+#include <atomic>
+#include <chrono>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
@@ -60,6 +63,7 @@ struct Settings {
   // CUOPT_AMD_NUM_GPUS environment variable, default 1) and the simplex-grade emulation switch (-1 = the
   // CUOPT_AMD_SIMPLEX_GRADE environment variable, default on)
   int32_t num_gpus = 0, simplex_grade = -1;
+  int32_t dual_simplex = -1;  // the small-LP dual simplex engine: -1 = CUOPT_AMD_DUAL_SIMPLEX (default on), 0 off, 1 on
   bool infeasibility_detection = false, strict_infeasibility = false, per_constraint_residual = false,
        save_best_primal_so_far = false, first_primal_feasible = false, log_to_console = true,
        crossover = false, mip_scaling = true, mip_heuristics_only = false;
@@ -97,7 +101,8 @@ struct Settings {
             {CUOPT_METHOD, &method, CUOPT_METHOD_CONCURRENT, CUOPT_METHOD_DUAL_SIMPLEX},
             {CUOPT_NUM_CPU_THREADS, &num_cpu_threads, -1, INT_MAX},
             {"amd_num_gpus", &num_gpus, 0, 16},
-            {"amd_simplex_grade", &simplex_grade, -1, 1}};
+            {"amd_simplex_grade", &simplex_grade, -1, 1},
+            {"amd_dual_simplex", &dual_simplex, -1, 1}};
     bools = {{CUOPT_INFEASIBILITY_DETECTION, &infeasibility_detection},
              {CUOPT_STRICT_INFEASIBILITY, &strict_infeasibility},
              {CUOPT_PER_CONSTRAINT_RESIDUAL, &per_constraint_residual},
@@ -711,7 +716,46 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     // iteration / time limit or of the emulation's budget, so limits behave as in the reference's Concurrent mode.
     const bool other_method  = s->method != CUOPT_METHOD_PDLP;
     const bool grade_on      = (s->simplex_grade >= 0 ? s->simplex_grade : env_int("CUOPT_AMD_SIMPLEX_GRADE", 1)) != 0;
-    const bool simplex_grade = other_method && grade_on && gpus == 1 && p->values.size() <= 100000;
+    cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
+                   p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
+                   p->objective_offset};
+    // Round 3: a SECOND engine for small LPs, an own bounded dual simplex (dual_simplex.cpp; the reference's second engine is its
+    // CPU dual simplex, LP/solve.cu:295-347).  CUOPT_METHOD_DUAL_SIMPLEX: it answers, if it can (<= 3000 rows; it abstains on
+    // numerical trouble) -- otherwise PDLP serves the request as before.  CUOPT_METHOD_CONCURRENT: it races PDLP (a host thread
+    // against the GPU; whoever finishes first with a verdict answers, the other one is cancelled: LP/solve.cu:383-443).
+    // CUOPT_AMD_DUAL_SIMPLEX=0 / "amd_dual_simplex" = 0 switch it off (then: the simplex-grade emulation below).  No GPU -> the
+    // engine is not consulted either: this library has no CPU-only mode.
+    const bool engine_on = other_method && gpus == 1 && pdlpdev_device_count() >= 1 &&
+                           (s->dual_simplex >= 0 ? s->dual_simplex : env_int("CUOPT_AMD_DUAL_SIMPLEX", 1)) != 0;
+    struct SimplexRun {
+      int32_t status = 8, iterations = 0;
+      double objective = 0.0, seconds = 0.0;
+      std::vector<double> x, y, rc;
+      volatile int32_t cancel = 0;
+      std::atomic<int> done{0};
+      bool conclusive() const { return status == 1 || status == 2 || status == 3; }
+    } sx;
+    auto run_simplex = [&](double tlim, int32_t itlim) {
+      const auto t0 = std::chrono::steady_clock::now();
+      sx.x.assign(p->n, 0.0), sx.y.assign(p->m, 0.0), sx.rc.assign(p->n, 0.0);
+      if (tlim <= 0.0 || itlim <= 0) {  // no budget at all: the limit is the verdict (0 means "none" to the engine's own interface)
+        sx.status = tlim <= 0.0 ? 6 : 5;
+        sx.done.store(1);
+        return;
+      }
+      (void)cuoptamd_dual_simplex(&lp, std::isfinite(tlim) ? tlim : 0.0, itlim == INT_MAX ? 0 : itlim, &sx.cancel, &sx.status, &sx.iterations,
+                                  &sx.objective, sx.x.data(), sx.y.data(), sx.rc.data());
+      sx.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      sx.done.store(1);
+    };
+    bool engine_ran = false, engine_answered = false;
+    if (engine_on && s->method == CUOPT_METHOD_DUAL_SIMPLEX) {
+      run_simplex(s->time_limit, s->iteration_limit);
+      engine_ran      = sx.status != 8;
+      engine_answered = sx.conclusive() || sx.status == 5 || sx.status == 6;  // its own limits count as its answer
+    }
+    const bool racing        = engine_on && s->method == CUOPT_METHOD_CONCURRENT;
+    const bool simplex_grade = other_method && grade_on && gpus == 1 && p->values.size() <= 100000 && !racing && !engine_answered;
     st.iteration_limit         = s->iteration_limit;
     st.time_limit              = s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
@@ -726,9 +770,6 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     st.save_best_primal_so_far     = s->save_best_primal_so_far;
     st.log_to_console              = s->log_to_console;
     st.log_file                    = s->log_file.empty() ? nullptr : s->log_file.c_str();
-    cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
-                   p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
-                   p->objective_offset};
     auto say = [&](const std::string& line) {
       if (s->log_to_console) std::fputs(line.c_str(), stdout), std::fflush(stdout);
       if (!s->log_file.empty())
@@ -736,9 +777,11 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     };
     const char* method_name = s->method == CUOPT_METHOD_CONCURRENT ? "Concurrent" : s->method == CUOPT_METHOD_DUAL_SIMPLEX ? "DualSimplex" : "PDLP";
     if (other_method || s->crossover)
-      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover" : "") +
-          " requested: served by PDLP (the only engine of this library)" +
-          (simplex_grade ? ", simplex-grade tolerances 1e-8 with the requested ones as acceptance set\n" : "\n"));
+      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (not implemented: ignored)" : "") + " requested: " +
+          (engine_answered ? "answered by the small-LP dual simplex\n"
+           : racing        ? "the small-LP dual simplex (host thread) races PDLP (GPU)\n"
+                           : std::string("served by PDLP") + (engine_ran ? " (the dual simplex abstained)" : "") +
+                                 (simplex_grade ? ", simplex-grade tolerances 1e-8 with the requested ones as acceptance set\n" : "\n")));
     const cuoptamd_settings st_user = st;
     constexpr int32_t kSimplexGradeBudget = 50000;
     bool tightened = false;
@@ -760,7 +803,22 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     int32_t first_attempt_steps = 0, first_attempt_attempts = 0;  // work of a simplex-grade attempt that a second solve followed
     std::string answered = simplex_grade && tightened ? "simplex_grade_1e-8" : "requested_tolerances";
     sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
-    if (gpus > 1) {
+    auto take_simplex = [&]() {  // the dual simplex's verdict as the solve's result
+      static const int map[10] = {0, CUOPT_TERIMINATION_STATUS_OPTIMAL, CUOPT_TERIMINATION_STATUS_INFEASIBLE, CUOPT_TERIMINATION_STATUS_UNBOUNDED, 0,
+                                  CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT, CUOPT_TERIMINATION_STATUS_TIME_LIMIT, CUOPT_TERIMINATION_STATUS_NUMERICAL_ERROR,
+                                  CUOPT_TERIMINATION_STATUS_NUMERICAL_ERROR, CUOPT_TERIMINATION_STATUS_NUMERICAL_ERROR};
+      res                  = cuoptamd_result{};
+      res.status           = map[std::max(0, std::min(9, (int)sx.status))];
+      res.steps_taken      = res.attempted_steps = sx.iterations;
+      res.primal_objective = res.dual_objective = sx.status == 1 ? sx.objective : 0.0;
+      res.loop_seconds     = sx.seconds;
+      res.gpus             = 1;
+      if (sx.status == 1) sol->x = sx.x, sol->y = sx.y, sol->rc = sx.rc;
+      answered = "dual_simplex";
+    };
+    if (engine_answered) {
+      take_simplex();
+    } else if (gpus > 1) {
       const int soft = env_int("CUOPT_AMD_SOFT_COMMUNICATOR", 0);
       const int rc   = cuoptamd_solve_sharded(&lp, &hyper, &st, gpus, soft, &res, sol->x.data(), sol->y.data(), sol->rc.data());
       if (rc != 0) {
@@ -777,7 +835,31 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
         if (rc == -7) return error(CUOPT_VALIDATION_ERROR, "ValidationError", msg);
         return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
       }
-      rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+      if (racing) {
+        // Concurrent: the simplex on a host thread, PDLP here in batches of a few major iterations; the first verdict wins
+        std::thread worker([&] { run_simplex(s->time_limit, s->iteration_limit); });
+        for (;;) {
+          if (sx.done.load() && sx.conclusive()) break;
+          rc = cuoptamd_solver_advance(solver, 400, &res);
+          if (rc != 0 || res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION) break;
+        }
+        const bool pdlp_done = rc == 0 && res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION;
+        if (pdlp_done && !(sx.done.load() && sx.conclusive())) sx.cancel = 1;
+        worker.join();
+        engine_ran = sx.status != 8;
+        // PDLP's Optimal / infeasibility verdicts stand; a limit or an error of PDLP's is overruled by a verdict of the simplex
+        const bool pdlp_verdict = pdlp_done && (res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL || res.status == CUOPT_TERIMINATION_STATUS_INFEASIBLE ||
+                                                res.status == CUOPT_TERIMINATION_STATUS_UNBOUNDED);
+        if (rc == 0 && sx.conclusive() && !(pdlp_verdict && sx.cancel)) {
+          engine_answered = true;
+          cuoptamd_solver_destroy(solver);
+          solver = nullptr;
+          take_simplex();
+        }
+      } else {
+        rc = cuoptamd_solver_advance(solver, INT_MAX, &res);
+      }
+      if (!engine_answered) {
       const bool on_limit = res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT || res.status == CUOPT_TERIMINATION_STATUS_TIME_LIMIT;
       if (rc == 0 && res.accepted_at_looser_tolerances) answered = "requested_tolerances_kept_during_simplex_grade_attempt";
       if (rc == 0 && tightened && on_limit && !res.accepted_at_looser_tolerances) {
@@ -803,13 +885,16 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
         return error(CUOPT_RUNTIME_ERROR, "RuntimeError", msg);
       }
       cuoptamd_solver_destroy(solver);
+      }
     }
     {
-      char info[512];
+      char info[768];
       std::snprintf(info, sizeof info,
-                    "{\"engine\": \"pdlp\", \"requested_method\": \"%s\", \"crossover_requested\": %s, \"simplex_grade_emulation\": %s, "
+                    "{\"engine\": \"%s\", \"requested_method\": \"%s\", \"crossover_requested\": %s, \"simplex_grade_emulation\": %s, "
+                    "\"dual_simplex_consulted\": %s, \"dual_simplex_status\": %d, "
                     "\"answered_by\": \"%s\", \"gpus\": %d, \"iterations\": %d, \"simplex_grade_attempt_iterations\": %d}",
-                    method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false", answered.c_str(), gpus,
+                    engine_answered ? "dual_simplex" : "pdlp", method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false",
+                    engine_ran ? "true" : "false", (int)sx.status, answered.c_str(), gpus,
                     res.steps_taken + (answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0),
                     answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0);
       sol->solve_info = info;

@@ -11,8 +11,8 @@ with `from cuopt_amd import linear_programming as lp`.  Where the reference goes
 module goes through ctypes (cuopt_amd/capi.py) into cuopt_amd/lib/libcuopt.so; there is no CPU fallback.
 
 PDLP requests (method = SolverMethod.PDLP) run on a `cuoptamd_solver`, which is what carries initial solutions and
-`pdlp_warm_start_data` in and out; Concurrent / DualSimplex requests go through `cuOptSolve` and are served by PDLP as
-documented in DESIGN.md section 8 (`Solution.get_solved_by_pdlp()` is always True: there is one engine)."""
+`pdlp_warm_start_data` in and out; Concurrent / DualSimplex requests go through `cuOptSolve`, where the library's small-LP dual
+simplex answers or races PDLP (`Solution.get_solved_by_pdlp()` says which engine answered)."""
 import time
 from enum import IntEnum
 
@@ -458,7 +458,8 @@ def Solve(data_model, solver_settings=None, log_file=""):
                             ErrorStatus(r["error_status"]), r["error_string"], 0.0, 0.0, 0.0, 0.0, 0.0, 0)
         return Solution(ProblemCategory.LP, _named(data_model, r["x"]), r["solve_time"], r["x"], r["y"], r["reduced_cost"],
                         r["status_code"], ErrorStatus.Success, "", r["l2_primal_residual"], r["l2_dual_residual"],
-                        r["objective"], r["dual_objective"], r["gap"], r["steps_taken"])
+                        r["objective"], r["dual_objective"], r["gap"], r["steps_taken"],
+                        solved_by_pdlp=(r.get("solve_info") or {}).get("engine", "pdlp") == "pdlp")
     # ---- PDLP proper: a cuoptamd_solver carries initial iterates and warm-start snapshots
     names = {"absolute_gap_tolerance", "relative_gap_tolerance", "absolute_primal_tolerance", "relative_primal_tolerance",
              "absolute_dual_tolerance", "relative_dual_tolerance", "iteration_limit", "time_limit", "per_constraint_residual",

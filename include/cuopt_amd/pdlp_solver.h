@@ -188,6 +188,15 @@ typedef struct cuoptamd_warm_start {
   int32_t n_variables, n_constraints;
 } cuoptamd_warm_start;
 
+/* The second engine (the reference's: cpp/src/dual_simplex, LP/solve.cu:295-347): an own bounded dual simplex with a dense
+ * basis inverse for SMALL LPs (m <= 3000, n + m <= 60000, nnz <= 400000), host code like the reference's.
+ * *status: 1 optimal (x, y, rc, objective filled; y and rc in the convention rc = c - A^T y), 2 primal infeasible,
+ * 3 unbounded, 5 iteration limit, 6 time limit, 7 numerical trouble / the engine abstains (a vertex on the box of the infinite
+ * bounds whose ray costs less than any dual tolerance), 8 too large for this engine (nothing was done), 9 cancelled
+ * (*cancel became non-zero: the other engine of a Concurrent solve finished first).  time_limit <= 0 / iteration_limit <= 0: none. */
+int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
+                          int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc);
+
 const char* cuoptamd_last_error(void);
 
 /* presets, mode numbering as CUOPT_PDLP_SOLVER_MODE_* (0 Stable1, 1 Stable2, 2 Methodical1, 3 Fast1) */

@@ -1,0 +1,109 @@
+"""CPU: the library's own small-LP dual simplex (cuopt_amd/csrc/dual_simplex.cpp, host code -- no GPU involved) against the verdicts and
+objectives of the REFERENCE's dual simplex held in the goldens (tests/golden/problems.json: the LP relaxations of datasets/mip and
+the LP fixtures; tests/golden/mps_parser.json: all 21 non-empty LP files of datasets/linear_programming)."""
+import numpy as np
+import pytest
+
+from conftest import decode_problem
+from cuopt_amd import capi
+
+STATUS = {"OPTIMAL": "Optimal", "INFEASIBLE": "PrimalInfeasible", "UNBOUNDED": "Unbounded"}
+
+
+def _check_vertex(p, r, tol=1e-7):
+    """primal feasible, reduced costs = c - A^T y, signs of the reduced costs / duals match the active bounds, strong duality"""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
+    x, y, z = r["x"], r["y"], r["reduced_cost"]
+    ax = A @ x
+    scale = 1 + max(np.abs(ax).max(initial=0), np.abs(x).max(initial=0))
+    assert np.all(ax >= p["lo"] - tol * scale) and np.all(ax <= p["hi"] + tol * scale)
+    assert np.all(x >= p["lb"] - tol * scale) and np.all(x <= p["ub"] + tol * scale)
+    sense = -1.0 if p.get("maximize") else 1.0
+    np.testing.assert_allclose(p["c"] - A.T @ y, z, atol=tol * (1 + np.abs(p["c"]).max()))
+    # minimisation form: a positive reduced cost needs x at its lower bound, a negative one at its upper bound
+    zs, ys = sense * z, sense * y
+    assert np.all((zs <= tol) | (np.abs(x - p["lb"]) <= tol * scale)) and np.all((zs >= -tol) | (np.abs(x - p["ub"]) <= tol * scale))
+    assert np.all((ys <= tol) | (np.abs(ax - p["lo"]) <= tol * scale)) and np.all((ys >= -tol) | (np.abs(ax - p["hi"]) <= tol * scale))
+
+
+def test_the_lp_relaxations_and_fixtures_of_the_goldens(golden_problems):
+    for name, g in golden_problems.items():
+        p, ref = g["problem"], g["meta"]["reference_dual_simplex"]
+        if p["m"] > 500:
+            continue  # cod105 (1024 rows, 6.6 k pivots): below
+        r = capi.dual_simplex(p)
+        if name == "mip-minrep_inf-relaxation":
+            # 0.0210643 + 0.978936 > 1: the LP has a ray whose cost is -3e-6 per unit.  The reference's simplex calls it optimal
+            # (0.21064), HiGHS unbounded; this engine abstains and PDLP answers (tests/test_solve_gpu.py)
+            assert r["status"] == "NumericalError"
+            continue
+        assert r["status"] == STATUS[ref["status"]], name
+        assert r["objective"] == pytest.approx(ref["objective"], rel=1e-9, abs=1e-9), name
+        _check_vertex(p, r)
+
+
+def test_every_lp_file_of_the_reference(golden_parser):
+    seen = 0
+    for name, v in golden_parser.items():
+        if not v.get("ok") or "reference_dual_simplex" not in v:
+            continue
+        p, ref = decode_problem(v), v["reference_dual_simplex"]
+        r = capi.dual_simplex(p)
+        assert r["status"] == STATUS[ref["status"]], name
+        if ref["status"] == "OPTIMAL":
+            assert r["objective"] == pytest.approx(ref["objective"], rel=1e-9, abs=1e-9), name
+            _check_vertex(p, r)
+        seen += 1
+    assert seen == 21
+
+
+def test_random_lps_against_highs():
+    """feasible bounded LPs with ranged rows, free / boxed / one-sided variables: same optimum as scipy's HiGHS"""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        m, n = int(rng.integers(5, 40)), int(rng.integers(5, 60))
+        A = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.4)
+        x0 = rng.standard_normal(n)
+        lb = np.where(rng.random(n) < 0.3, -np.inf, x0 - rng.random(n))
+        ub = np.where(rng.random(n) < 0.3, np.inf, x0 + rng.random(n))
+        ax = A @ x0
+        lo = np.where(rng.random(m) < 0.3, -np.inf, ax - rng.random(m))
+        hi = np.where(rng.random(m) < 0.3, np.inf, ax + rng.random(m))
+        hi = np.where(rng.random(m) < 0.2, lo, hi)  # some equalities
+        hi = np.where(np.isfinite(hi), hi, np.inf)
+        lo = np.where(np.isneginf(lo) & np.isfinite(hi) & (rng.random(m) < 0.1), hi, lo)
+        y0 = rng.standard_normal(m)
+        c = A.T @ y0 + rng.standard_normal(n) * 0.1  # keeps the LP from being unbounded in most trials
+        import scipy.sparse as sp
+        S = sp.csr_matrix(A)
+        p = dict(m=m, n=n, offsets=S.indptr.astype(np.int32), indices=S.indices.astype(np.int32), values=S.data.astype(np.float64), c=c,
+                 lo=lo, hi=hi, lb=lb, ub=ub, maximize=bool(trial % 2))
+        rows, rhs = [], []
+        for i in range(m):
+            if np.isfinite(hi[i]):
+                rows.append(A[i]), rhs.append(hi[i])
+            if np.isfinite(lo[i]):
+                rows.append(-A[i]), rhs.append(-lo[i])
+        h = linprog(-c if p["maximize"] else c, A_ub=np.array(rows) if rows else None, b_ub=np.array(rhs) if rows else None,
+                    bounds=list(zip(lb, ub)), method="highs")
+        r = capi.dual_simplex(p)
+        if h.status == 0:
+            assert r["status"] == "Optimal", trial
+            assert r["objective"] == pytest.approx(-h.fun if p["maximize"] else h.fun, rel=1e-7, abs=1e-7), trial
+            _check_vertex(p, r)
+        elif h.status == 3:
+            assert r["status"] in ("Unbounded", "NumericalError"), trial
+        elif h.status == 2:
+            assert r["status"] == "PrimalInfeasible", trial
+
+
+def test_limits_and_size_gate():
+    from cuopt_amd import synthetic
+    p = synthetic.generate(300, 260, 6, seed=4)
+    assert capi.dual_simplex(p, iteration_limit=3)["status"] == "IterationLimit"
+    big = synthetic.generate(4000, 3000, 4, seed=4)
+    assert capi.dual_simplex(big)["status"] == "TooLarge"  # > 3000 rows: this engine is for small LPs, PDLP has the rest
+    r = capi.dual_simplex(p)
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(p["objective_star"], rel=1e-8)

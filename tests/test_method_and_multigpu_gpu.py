@@ -1,9 +1,11 @@
 """GPU: how cuOptSolve serves requests the reference would hand to its dual simplex (Concurrent = default, DualSimplex,
 crossover: LP/solve.cu:383-443,467-547) and the single-process multi-GPU path behind the same call.
 
-This library has one engine (PDLP).  Non-PDLP methods on small LPs run at simplex-grade tolerances with the caller's own
-tolerances as the acceptance set, so the caller's iteration / time limits behave as in the reference's Concurrent mode;
-CUOPT_AMD_SIMPLEX_GRADE=0 / "amd_simplex_grade" = 0 switches the emulation off; cuOptAmdGetSolveInfo says what happened."""
+Round 3: small LPs have a second engine, the library's own bounded dual simplex (dual_simplex.cpp): a DualSimplex request is
+answered by it, a Concurrent request lets it race PDLP.  Where it is switched off (CUOPT_AMD_DUAL_SIMPLEX=0 / "amd_dual_simplex"
+= 0) or abstains, non-PDLP methods on small LPs run PDLP at simplex-grade tolerances with the caller's own tolerances as the
+acceptance set (the round-1/2 emulation; CUOPT_AMD_SIMPLEX_GRADE=0 / "amd_simplex_grade" = 0 switches that off too);
+cuOptAmdGetSolveInfo says what happened."""
 import numpy as np
 import pytest
 
@@ -18,7 +20,36 @@ def ranged_lp():  # c_api_test.c:761-873, optimum 32
                 c=[5.0, 8.0], lo=[-INF, -INF, 2.0], hi=[12.0, 6.0, 8.0], lb=[0.0, 0.0], ub=[10.0, 10.0], maximize=True)
 
 
-def test_solve_info_names_the_engine_and_the_attempt():
+def test_dual_simplex_requests_are_answered_by_the_dual_simplex():
+    r = capi.solve(ranged_lp(), method=2, crossover=True)  # DualSimplex + crossover requested
+    info = r["solve_info"]
+    assert info["engine"] == "dual_simplex" and info["answered_by"] == "dual_simplex" and info["dual_simplex_status"] == 1
+    assert info["requested_method"] == "DualSimplex" and info["crossover_requested"] is True and info["simplex_grade_emulation"] is False
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(32.0, abs=1e-9)  # a vertex: exact
+    # the vertex satisfies the LP exactly and carries duals in the c - A^T y convention
+    x, y, z = r["x"], r["y"], r["reduced_cost"]
+    A = np.array([[2.0, 3.0], [3.0, 1.0], [1.0, 2.0]])
+    assert np.all(A @ x <= np.array([12.0, 6.0, 8.0]) + 1e-9) and (A @ x)[2] >= 2.0 - 1e-9
+    np.testing.assert_allclose(np.array([5.0, 8.0]) - A.T @ y, z, atol=1e-9)
+    # Concurrent (the default): the simplex races PDLP and wins on an LP of this size
+    c = capi.solve(ranged_lp())
+    assert c["solve_info"]["engine"] == "dual_simplex" and c["objective"] == pytest.approx(32.0, abs=1e-9)
+    # a PDLP request never consults it
+    r = capi.solve(ranged_lp(), method=1)
+    assert r["solve_info"]["engine"] == "pdlp" and r["solve_info"]["dual_simplex_consulted"] is False
+    assert r["solve_info"]["simplex_grade_emulation"] is False and r["solve_info"]["answered_by"] == "requested_tolerances"
+
+
+def test_large_lps_are_left_to_pdlp_and_limits_are_limits():
+    p = synthetic.generate(6000, 5000, 8, seed=61)  # 6000 rows: beyond the dense basis inverse of the simplex engine
+    r = capi.solve(p, method=2)
+    assert r["status"] == "Optimal" and r["solve_info"]["engine"] == "pdlp" and r["solve_info"]["dual_simplex_status"] == 8
+    t = capi.solve(ranged_lp(), method=2, time_limit=0.0)
+    assert t["status"] == "TimeLimit"
+
+
+def test_solve_info_names_the_engine_and_the_attempt(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")  # the round-1/2 emulation: PDLP alone serves the request
     r = capi.solve(ranged_lp(), method=2, crossover=True)  # DualSimplex + crossover requested
     info = r["solve_info"]
     assert info["engine"] == "pdlp" and info["requested_method"] == "DualSimplex" and info["crossover_requested"] is True
@@ -26,9 +57,12 @@ def test_solve_info_names_the_engine_and_the_attempt():
     assert r["status"] == "Optimal" and r["objective"] == pytest.approx(32.0, abs=1e-5)
     r = capi.solve(ranged_lp(), method=1)
     assert r["solve_info"]["simplex_grade_emulation"] is False and r["solve_info"]["answered_by"] == "requested_tolerances"
+    again = capi.solve(ranged_lp(), method=2, amd_dual_simplex=1)  # the parameter beats the environment
+    assert again["solve_info"]["engine"] == "dual_simplex"
 
 
 def test_simplex_grade_opt_out(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")
     on = capi.solve(ranged_lp())
     monkeypatch.setenv("CUOPT_AMD_SIMPLEX_GRADE", "0")
     off = capi.solve(ranged_lp())
@@ -41,7 +75,8 @@ def test_simplex_grade_opt_out(monkeypatch):
     assert again["solve_info"]["simplex_grade_emulation"] is False
 
 
-def test_default_method_honours_the_callers_iteration_limit():
+def test_default_method_honours_the_callers_iteration_limit(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")
     """ADVICE r1: with iteration_limit <= the emulation's budget the tight attempt used to eat the whole limit and return
     IterationLimit although the requested 1e-4 had been met long before.  The acceptance set keeps that iterate."""
     p = synthetic.generate(400, 300, 6, seed=9, hard=True)
@@ -60,8 +95,11 @@ def test_default_method_honours_the_callers_iteration_limit():
     assert r["relative_gap"] <= 1e-4 + 1e-12 and r["l2_relative_primal_residual"] <= 1e-4 + 1e-12
 
 
-def test_default_method_time_limit_falls_back_too():
+def test_default_method_time_limit_falls_back_too(monkeypatch):
     p = synthetic.generate(400, 300, 6, seed=9, hard=True)
+    r = capi.solve(p, time_limit=0.0)  # both engines out of time before they start
+    assert r["status"] == "TimeLimit"
+    monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")
     r = capi.solve(p, time_limit=0.0)
     assert r["status"] == "TimeLimit"  # nothing was accepted yet: the limit status is reported as is
     assert r["solve_info"]["answered_by"] in ("limit_reached_during_simplex_grade_attempt", "simplex_grade_1e-8")

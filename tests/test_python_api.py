@@ -241,16 +241,15 @@ def test_batch_solver_refuses_warm_start_data(golden_problems):  # test_lp_solve
 
 @pytest.mark.gpu
 def test_dual_simplex_request(golden_problems):
-    """test_lp_solver.py:592-606 asks for SolverMethod.DualSimplex and gets -464.7531 from the simplex.  This library has
-    one engine: same status and objective (simplex-grade tolerances), and it SAYS it was PDLP (the one assertion of the
-    reference test that is deliberately inverted)"""
+    """test_lp_solver.py:592-606 asks for SolverMethod.DualSimplex and gets -464.7531 from the simplex -- as here, from the
+    library's own small-LP dual simplex (round 3; rounds 1-2 served the request with PDLP and said so)"""
     dm = model_of(golden_problems["afiro"]["problem"])
     settings = lp.SolverSettings()
     settings.set_parameter(CUOPT_METHOD, SolverMethod.DualSimplex)
     solution = lp.Solve(dm, settings)
     assert solution.get_termination_status() == LPTerminationStatus.Optimal
     assert solution.get_primal_objective() == pytest.approx(-464.7531)
-    assert solution.get_solved_by_pdlp()
+    assert not solution.get_solved_by_pdlp()
 
 
 @pytest.mark.gpu
