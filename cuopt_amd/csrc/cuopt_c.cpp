@@ -705,8 +705,9 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       return v && *v ? std::atoi(v) : fallback;
     };
     const int gpus = std::max(1, s->num_gpus > 0 ? s->num_gpus : env_int("CUOPT_AMD_NUM_GPUS", 1));
-    // CUOPT_METHOD: this library has ONE engine, PDLP.  Concurrent (the default) and DualSimplex requests, and
-    // crossover = true, are served by PDLP and say so in the log and in cuOptAmdGetSolveInfo.  The reference's
+    // CUOPT_METHOD: PDLP is this library's engine; small LPs have a second one, the dual simplex of dual_simplex.cpp (below).
+    // Where that one is off, abstains or finds the LP too large, Concurrent (the default) and DualSimplex requests are
+    // served by PDLP and say so in the log and in cuOptAmdGetSolveInfo; crossover = true is ignored (and said).  The reference's
     // Concurrent / DualSimplex return the simplex VERTEX on small LPs (the CPU simplex wins the race there:
     // c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings), so for such requests on small LPs (<= 1e5
     // nonzeros, microseconds per iteration) PDLP aims at simplex-grade tolerances (1e-8) -- the "simplex-grade

@@ -3,7 +3,7 @@
 // run_concurrent; cpp/src/dual_simplex/).  Own implementation, nothing of the reference's simplex is linked or restated:
 // the textbook bounded dual simplex (Dantzig pricing on the primal infeasibilities, Harris' two-pass dual ratio test) on
 //     min c.x   s.t.  A x - s = 0,   lb <= x <= ub,   lo <= s <= hi
-// with a DENSE explicit basis inverse (rank-one updates, refactorisation from scratch every 100 pivots), which is what
+// with a DENSE explicit basis inverse (rank-one updates, refactorisation from scratch every 400 pivots), which is what
 // an LP of a few thousand rows needs and no more.  Infinite bounds are boxed (+-BIG) so that the slack basis is dual
 // feasible from the start; a solution that leans on a box bound is solved again with a 1000 times larger box, and if
 // it still does, the LP is unbounded.  Host code: the reference's simplex is CPU code too; PDLP on the GPU stays the
@@ -219,7 +219,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       }
     }
     S.iterations += 1;
-    if (++since_refactor >= 100) {
+    if (++since_refactor >= 400) {  // (a refactorisation is O(m^3), a pivot O(m^2))
       if (!S.refactor()) return 7;
       S.recompute();
       since_refactor = 0;

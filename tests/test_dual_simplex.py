@@ -43,6 +43,16 @@ def test_the_lp_relaxations_and_fixtures_of_the_goldens(golden_problems):
         _check_vertex(p, r)
 
 
+def test_the_largest_relaxation_of_the_goldens(golden_problems):
+    """cod105_max: 1024 x 1024, 57 k nonzeros, ~6.6 k pivots (the reference's simplex: 6347 pivots, 18.28571109; the optimum is 128/7)"""
+    g = golden_problems["mip-cod105_max-relaxation"]
+    r = capi.dual_simplex(g["problem"], time_limit=240)
+    assert r["status"] == "Optimal"
+    assert r["objective"] == pytest.approx(128.0 / 7.0, rel=1e-9)
+    assert r["objective"] == pytest.approx(g["meta"]["reference_dual_simplex"]["objective"], rel=1e-6)
+    _check_vertex(g["problem"], r, tol=1e-6)
+
+
 def test_every_lp_file_of_the_reference(golden_parser):
     seen = 0
     for name, v in golden_parser.items():
