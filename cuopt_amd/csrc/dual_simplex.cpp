@@ -125,21 +125,25 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   for (int i = 0; i < m; ++i) S.Binv[(size_t)i * m + i] = -1.0;
   S.recompute();
   std::vector<double> alpha(N), w(m);
+  std::vector<int> passed(m, 0);  // iteration (+1) at which the row was passed over as "violated by rounding only"
   const double tol_d = 1e-9;
   int since_refactor = 0;
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
     if (cancel && *cancel) return 9;  // the other engine of a Concurrent solve has finished
     if ((S.iterations & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
-    // leaving row: the largest primal infeasibility
+    // leaving row: the largest primal infeasibility (primal tolerance 1e-7 relative to the bound; the reference's simplex: 1e-6
+    // absolute).  A row whose violation is within 1e-6 and that has no entering candidate is rounding, not a proof of
+    // infeasibility (the box bounds put values of 1e6 into the basis): it is passed over.
     int r = -1;
     double worst = 0.0;
     for (int i = 0; i < m; ++i) {
+      if (passed[i] == S.iterations + 1) continue;
       const int b     = S.basic[i];
       const double v  = S.z[b];
       const double lo = S.L[b] - v, up = v - S.U[b];
       const double inf = std::max(lo, up);
-      const double tol = 1e-9 * (1.0 + std::fabs(lo > up ? S.L[b] : S.U[b]));
+      const double tol = 1e-7 * (1.0 + std::fabs(lo > up ? S.L[b] : S.U[b]));
       if (inf > tol && inf > worst) worst = inf, r = i;
     }
     if (r < 0) return 1;
@@ -166,7 +170,18 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       if (!eligible) continue;
       tmax = std::min(tmax, (std::fabs(S.d[j]) + tol_d) / std::fabs(a));
     }
-    if (tmax == kInf) return 2;  // no entering variable: the row proves primal infeasibility
+    if (tmax == kInf && worst <= 1e-6 * (1.0 + std::fabs(to_low ? S.L[p] : S.U[p]))) {
+      passed[r] = S.iterations + 1;
+      continue;
+    }
+    if (tmax == kInf) {  // no entering variable: the row proves primal infeasibility
+      if (std::getenv("CUOPT_AMD_SIMPLEX_DEBUG")) {
+        std::fprintf(stderr, "[simplex] infeasible row %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g; nonbasic:\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol);
+        for (int j = 0; j < N; ++j)
+          if (S.pos[j] < 0 && alpha[j] != 0.0) std::fprintf(stderr, "   j %d alpha %.3g atU %d z %.6g [%.6g, %.6g] d %.3g\n", j, alpha[j], (int)S.atU[j], S.z[j], S.L[j], S.U[j], S.d[j]);
+      }
+      return 2;
+    }
     int q        = -1;
     double apick = 0.0;
     for (int j = 0; j < N; ++j) {

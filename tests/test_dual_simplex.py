@@ -69,24 +69,35 @@ def test_every_lp_file_of_the_reference(golden_parser):
 
 
 def test_random_lps_against_highs():
-    """feasible bounded LPs with ranged rows, free / boxed / one-sided variables: same optimum as scipy's HiGHS"""
+    """ranged / equality rows, free / boxed / one-sided variables, real and small-integer (degenerate) data, some infeasible and
+    some unbounded: same verdict and optimum as scipy's HiGHS (an "infeasible" of HiGHS is re-checked with a zero objective: its
+    presolve says that of unbounded LPs too)"""
+    import scipy.sparse as sp
     from scipy.optimize import linprog
-    rng = np.random.default_rng(7)
-    for trial in range(12):
-        m, n = int(rng.integers(5, 40)), int(rng.integers(5, 60))
-        A = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.4)
-        x0 = rng.standard_normal(n)
-        lb = np.where(rng.random(n) < 0.3, -np.inf, x0 - rng.random(n))
-        ub = np.where(rng.random(n) < 0.3, np.inf, x0 + rng.random(n))
+    rng = np.random.default_rng(11)
+    seen = {}
+    for trial in range(80):
+        m, n = int(rng.integers(2, 60)), int(rng.integers(2, 90))
+        dens = rng.choice([0.1, 0.3, 0.7])
+        integer = rng.random() < 0.5
+        draw = (lambda size: rng.integers(0, 3, size=size).astype(float)) if integer else (lambda size: rng.random(size))
+        A = (rng.integers(-3, 4, size=(m, n)).astype(float) if integer else rng.standard_normal((m, n))) * (rng.random((m, n)) < dens)
+        x0 = rng.integers(-2, 3, size=n).astype(float) if integer else rng.standard_normal(n)
+        lb = np.where(rng.random(n) < 0.3, -np.inf, x0 - draw(n))
+        ub = np.where(rng.random(n) < 0.3, np.inf, x0 + draw(n))
         ax = A @ x0
-        lo = np.where(rng.random(m) < 0.3, -np.inf, ax - rng.random(m))
-        hi = np.where(rng.random(m) < 0.3, np.inf, ax + rng.random(m))
-        hi = np.where(rng.random(m) < 0.2, lo, hi)  # some equalities
-        hi = np.where(np.isfinite(hi), hi, np.inf)
-        lo = np.where(np.isneginf(lo) & np.isfinite(hi) & (rng.random(m) < 0.1), hi, lo)
-        y0 = rng.standard_normal(m)
-        c = A.T @ y0 + rng.standard_normal(n) * 0.1  # keeps the LP from being unbounded in most trials
-        import scipy.sparse as sp
+        lo = np.where(rng.random(m) < 0.3, -np.inf, ax - draw(m))
+        hi = np.where(rng.random(m) < 0.3, np.inf, ax + draw(m))
+        eq = rng.random(m) < 0.25
+        lo, hi = np.where(eq, ax, lo), np.where(eq, ax, hi)
+        if rng.random() < 0.15:  # an empty row that cannot be satisfied
+            i = rng.integers(m)
+            lo[i] = ax[i] + 5 + abs(ax[i])
+            hi[i] = lo[i] + 1
+            A[i] = 0
+        c = rng.integers(-3, 4, size=n).astype(float) if integer else rng.standard_normal(n)
+        if rng.random() < 0.6:
+            c = A.T @ rng.standard_normal(m) + 0.1 * c
         S = sp.csr_matrix(A)
         p = dict(m=m, n=n, offsets=S.indptr.astype(np.int32), indices=S.indices.astype(np.int32), values=S.data.astype(np.float64), c=c,
                  lo=lo, hi=hi, lb=lb, ub=ub, maximize=bool(trial % 2))
@@ -96,17 +107,21 @@ def test_random_lps_against_highs():
                 rows.append(A[i]), rhs.append(hi[i])
             if np.isfinite(lo[i]):
                 rows.append(-A[i]), rhs.append(-lo[i])
-        h = linprog(-c if p["maximize"] else c, A_ub=np.array(rows) if rows else None, b_ub=np.array(rhs) if rows else None,
-                    bounds=list(zip(lb, ub)), method="highs")
-        r = capi.dual_simplex(p)
-        if h.status == 0:
-            assert r["status"] == "Optimal", trial
-            assert r["objective"] == pytest.approx(-h.fun if p["maximize"] else h.fun, rel=1e-7, abs=1e-7), trial
-            _check_vertex(p, r)
-        elif h.status == 3:
-            assert r["status"] in ("Unbounded", "NumericalError"), trial
-        elif h.status == 2:
-            assert r["status"] == "PrimalInfeasible", trial
+        kw = dict(A_ub=np.array(rows) if rows else None, b_ub=np.array(rhs) if rows else None, bounds=list(zip(lb, ub)), method="highs")
+        h = linprog(-c if p["maximize"] else c, **kw)
+        verdict = {0: "Optimal", 2: "PrimalInfeasible", 3: "Unbounded"}[h.status]
+        if verdict == "PrimalInfeasible" and linprog(0 * c, **kw).status == 0:
+            verdict = "Unbounded"
+        r = capi.dual_simplex(p, time_limit=30)
+        seen[verdict] = seen.get(verdict, 0) + 1
+        if verdict == "Unbounded":
+            assert r["status"] in ("Unbounded", "NumericalError"), trial  # (the engine may abstain on a ray that costs next to nothing)
+            continue
+        assert r["status"] == verdict, trial
+        if verdict == "Optimal":
+            assert r["objective"] == pytest.approx(-h.fun if p["maximize"] else h.fun, rel=1e-6, abs=1e-6), trial
+            _check_vertex(p, r, tol=1e-6)
+    assert seen.get("Optimal", 0) >= 20 and seen.get("PrimalInfeasible", 0) >= 5 and seen.get("Unbounded", 0) >= 5
 
 
 def test_limits_and_size_gate():
