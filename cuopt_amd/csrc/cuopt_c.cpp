@@ -778,7 +778,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     };
     const char* method_name = s->method == CUOPT_METHOD_CONCURRENT ? "Concurrent" : s->method == CUOPT_METHOD_DUAL_SIMPLEX ? "DualSimplex" : "PDLP";
     if (other_method || s->crossover)
-      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (not implemented: ignored)" : "") + " requested: " +
+      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (small LPs: a vertex through the dual simplex; otherwise not done)" : "") + " requested: " +
           (engine_answered ? "answered by the small-LP dual simplex\n"
            : racing        ? "the small-LP dual simplex (host thread) races PDLP (GPU)\n"
                            : std::string("served by PDLP") + (engine_ran ? " (the dual simplex abstained)" : "") +
@@ -888,14 +888,36 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       cuoptamd_solver_destroy(solver);
       }
     }
+    // crossover (LP/solve.cu:467-547: from PDLP's point to a basic solution): not implemented as an algorithm of its own.  On LPs
+    // the dual simplex can hold, a crossover request behind an Optimal PDLP answer is served by solving the LP with the dual
+    // simplex and returning ITS vertex when it confirms the objective -- the result crossover promises (a basic optimal
+    // solution), reached from a cold start; larger LPs keep PDLP's point, and the solve info says which it was.
+    const char* crossover_by = "none";
+    if (s->crossover && !engine_answered && gpus == 1 && res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL && pdlpdev_device_count() >= 1 &&
+        (s->dual_simplex >= 0 ? s->dual_simplex : env_int("CUOPT_AMD_DUAL_SIMPLEX", 1)) != 0) {
+      sx.cancel = 0;
+      run_simplex(std::isfinite(s->time_limit) ? std::max(1e-3, s->time_limit - (res.setup_seconds + res.loop_seconds)) : s->time_limit, INT_MAX);
+      engine_ran = engine_ran || sx.status != 8;
+      if (sx.status == 1 && std::fabs(sx.objective - res.primal_objective) <= 1e-2 * (1.0 + std::fabs(res.primal_objective))) {
+        sol->x = sx.x, sol->y = sx.y, sol->rc = sx.rc;
+        res.primal_objective = res.dual_objective = sx.objective;
+        res.gap = res.relative_gap = 0.0;
+        res.loop_seconds += sx.seconds;
+        crossover_by = "dual_simplex_cold_start";
+      } else {
+        crossover_by = sx.status == 8 ? "not_done_lp_too_large_for_the_dual_simplex" : "not_done_dual_simplex_disagreed_or_abstained";
+      }
+    } else if (s->crossover) {
+      crossover_by = engine_answered ? "not_needed_vertex_from_the_dual_simplex" : "not_done";
+    }
     {
-      char info[768];
+      char info[1024];
       std::snprintf(info, sizeof info,
                     "{\"engine\": \"%s\", \"requested_method\": \"%s\", \"crossover_requested\": %s, \"simplex_grade_emulation\": %s, "
-                    "\"dual_simplex_consulted\": %s, \"dual_simplex_status\": %d, "
+                    "\"dual_simplex_consulted\": %s, \"dual_simplex_status\": %d, \"crossover\": \"%s\", "
                     "\"answered_by\": \"%s\", \"gpus\": %d, \"iterations\": %d, \"simplex_grade_attempt_iterations\": %d}",
                     engine_answered ? "dual_simplex" : "pdlp", method_name, s->crossover ? "true" : "false", simplex_grade ? "true" : "false",
-                    engine_ran ? "true" : "false", (int)sx.status, answered.c_str(), gpus,
+                    engine_ran ? "true" : "false", (int)sx.status, crossover_by, answered.c_str(), gpus,
                     res.steps_taken + (answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0),
                     answered == "requested_tolerances_after_simplex_grade_budget" ? first_attempt_steps : 0);
       sol->solve_info = info;

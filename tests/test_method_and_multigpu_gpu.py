@@ -40,6 +40,23 @@ def test_dual_simplex_requests_are_answered_by_the_dual_simplex():
     assert r["solve_info"]["simplex_grade_emulation"] is False and r["solve_info"]["answered_by"] == "requested_tolerances"
 
 
+def test_crossover_request_behind_pdlp_returns_a_vertex_on_small_lps():
+    """CUOPT_METHOD_PDLP + crossover: PDLP's point is exchanged for the dual simplex's vertex when that confirms the objective; an
+    LP beyond the simplex engine keeps PDLP's point and says so"""
+    from cuopt_amd import synthetic
+    p = synthetic.generate(300, 260, 6, seed=4)
+    plain = capi.solve(p, method=1)
+    r = capi.solve(p, method=1, crossover=True)
+    assert r["status"] == plain["status"] == "Optimal" and r["solve_info"]["crossover"] == "dual_simplex_cold_start"
+    assert abs(r["objective"] - p["objective_star"]) <= 1e-8 * (1 + abs(p["objective_star"]))  # exact, PDLP's was 1e-4
+    assert abs(plain["objective"] - p["objective_star"]) > abs(r["objective"] - p["objective_star"])
+    x = r["x"]
+    assert np.sum((x > 1e-12)) <= p["m"]  # a basic solution: at most m variables off their bound (lb = 0, ub = inf here)
+    big = synthetic.generate(6000, 5000, 8, seed=61)
+    q = capi.solve(big, method=1, crossover=True)
+    assert q["status"] == "Optimal" and q["solve_info"]["crossover"] == "not_done_lp_too_large_for_the_dual_simplex"
+
+
 def test_large_lps_are_left_to_pdlp_and_limits_are_limits():
     p = synthetic.generate(6000, 5000, 8, seed=61)  # 6000 rows: beyond the dense basis inverse of the simplex engine
     r = capi.solve(p, method=2)
