@@ -282,6 +282,7 @@ _proto("pdlpdev_time_kernel", c_int, c_void_p, c_int, c_int, P(c_double))
 _proto("pdlpdev_synchronize", c_int, c_void_p)
 _proto("pdlpdev_device_bytes", C.c_int64, c_void_p)
 _proto("cuoptamd_dual_simplex", c_int, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuoptamd_dual_simplex_from", c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
 _proto("pdlpdev_shard_transport", c_int, c_void_p)
 _proto("pdlpdev_dense_info", c_int, c_void_p, c_void_p)
@@ -565,8 +566,9 @@ SIMPLEX_STATUS = {1: "Optimal", 2: "PrimalInfeasible", 3: "Unbounded", 5: "Itera
                   8: "TooLarge", 9: "Cancelled"}
 
 
-def dual_simplex(p, time_limit=0.0, iteration_limit=0):
-    """cuoptamd_dual_simplex: the library's own small-LP dual simplex (host code, no GPU involved)"""
+def dual_simplex(p, time_limit=0.0, iteration_limit=0, x0=None, y0=None):
+    """cuoptamd_dual_simplex: the library's own dual simplex (host code, no GPU involved); x0: start from the basis guessed from
+    that point (cuoptamd_dual_simplex_from: the crossover of a first-order solution)"""
     k = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]), c=_f64(p["c"]), lo=_f64(p["lo"]),
              hi=_f64(p["hi"]), lb=_f64(p["lb"]), ub=_f64(p["ub"]))
     m, n = int(p["m"]), int(p["n"])
@@ -574,8 +576,13 @@ def dual_simplex(p, time_limit=0.0, iteration_limit=0):
             _ptr(k["ub"]), int(bool(p.get("maximize", False))), float(p.get("objective_offset", 0.0)))
     status, its, obj = c_int(0), c_int(0), c_double(0.0)
     x, y, rc = np.zeros(n), np.zeros(m), np.zeros(n)
-    ret = lib.cuoptamd_dual_simplex(C.byref(lp), float(time_limit), int(iteration_limit), None, C.byref(status), C.byref(its),
-                                    C.byref(obj), _ptr(x), _ptr(y), _ptr(rc))
+    if x0 is not None:
+        start, duals = _f64(x0), None if y0 is None else _f64(y0)
+        ret = lib.cuoptamd_dual_simplex_from(C.byref(lp), _ptr(start), None if duals is None else _ptr(duals), float(time_limit), int(iteration_limit), None, C.byref(status),
+                                             C.byref(its), C.byref(obj), _ptr(x), _ptr(y), _ptr(rc))
+    else:
+        ret = lib.cuoptamd_dual_simplex(C.byref(lp), float(time_limit), int(iteration_limit), None, C.byref(status), C.byref(its),
+                                        C.byref(obj), _ptr(x), _ptr(y), _ptr(rc))
     if ret != 0:
         raise CuOptError(ret, "cuoptamd_dual_simplex")
     return dict(status=SIMPLEX_STATUS.get(status.value, str(status.value)), iterations=its.value, objective=obj.value, x=x, y=y,

@@ -736,7 +736,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       std::atomic<int> done{0};
       bool conclusive() const { return status == 1 || status == 2 || status == 3; }
     } sx;
-    auto run_simplex = [&](double tlim, int32_t itlim) {
+    auto run_simplex = [&](double tlim, int32_t itlim, const double* from_x = nullptr, const double* from_y = nullptr) {
       const auto t0 = std::chrono::steady_clock::now();
       sx.x.assign(p->n, 0.0), sx.y.assign(p->m, 0.0), sx.rc.assign(p->n, 0.0);
       if (tlim <= 0.0 || itlim <= 0) {  // no budget at all: the limit is the verdict (0 means "none" to the engine's own interface)
@@ -744,8 +744,12 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
         sx.done.store(1);
         return;
       }
-      (void)cuoptamd_dual_simplex(&lp, std::isfinite(tlim) ? tlim : 0.0, itlim == INT_MAX ? 0 : itlim, &sx.cancel, &sx.status, &sx.iterations,
-                                  &sx.objective, sx.x.data(), sx.y.data(), sx.rc.data());
+      if (from_x)
+        (void)cuoptamd_dual_simplex_from(&lp, from_x, from_y, std::isfinite(tlim) ? tlim : 0.0, itlim == INT_MAX ? 0 : itlim, &sx.cancel, &sx.status,
+                                         &sx.iterations, &sx.objective, sx.x.data(), sx.y.data(), sx.rc.data());
+      else
+        (void)cuoptamd_dual_simplex(&lp, std::isfinite(tlim) ? tlim : 0.0, itlim == INT_MAX ? 0 : itlim, &sx.cancel, &sx.status, &sx.iterations,
+                                    &sx.objective, sx.x.data(), sx.y.data(), sx.rc.data());
       sx.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       sx.done.store(1);
     };
@@ -778,7 +782,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     };
     const char* method_name = s->method == CUOPT_METHOD_CONCURRENT ? "Concurrent" : s->method == CUOPT_METHOD_DUAL_SIMPLEX ? "DualSimplex" : "PDLP";
     if (other_method || s->crossover)
-      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (small LPs: a vertex through the dual simplex; otherwise not done)" : "") + " requested: " +
+      say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (the dual simplex from the basis PDLP's point suggests; not done beyond its size limits)" : "") + " requested: " +
           (engine_answered ? "answered by the small-LP dual simplex\n"
            : racing        ? "the small-LP dual simplex (host thread) races PDLP (GPU)\n"
                            : std::string("served by PDLP") + (engine_ran ? " (the dual simplex abstained)" : "") +
@@ -888,22 +892,23 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       cuoptamd_solver_destroy(solver);
       }
     }
-    // crossover (LP/solve.cu:467-547: from PDLP's point to a basic solution): not implemented as an algorithm of its own.  On LPs
-    // the dual simplex can hold, a crossover request behind an Optimal PDLP answer is served by solving the LP with the dual
-    // simplex and returning ITS vertex when it confirms the objective -- the result crossover promises (a basic optimal
-    // solution), reached from a cold start; larger LPs keep PDLP's point, and the solve info says which it was.
+    // crossover (LP/solve.cu:467-547: from PDLP's point to a basic solution): the dual simplex started from the basis PDLP's point
+    // suggests (cuoptamd_dual_simplex_from: the variables and rows strictly inside their bounds, then the ones with the smallest
+    // reduced costs; repaired with slacks) -- a few pivots when the point is close to a vertex.  Its vertex replaces PDLP's point
+    // when it confirms the objective; LPs beyond the engine's size limits keep PDLP's point, and the solve info says which it was.
     const char* crossover_by = "none";
     if (s->crossover && !engine_answered && gpus == 1 && res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL && pdlpdev_device_count() >= 1 &&
         (s->dual_simplex >= 0 ? s->dual_simplex : env_int("CUOPT_AMD_DUAL_SIMPLEX", 1)) != 0) {
       sx.cancel = 0;
-      run_simplex(std::isfinite(s->time_limit) ? std::max(1e-3, s->time_limit - (res.setup_seconds + res.loop_seconds)) : s->time_limit, INT_MAX);
+      const std::vector<double> px(sol->x), py(sol->y);
+      run_simplex(std::isfinite(s->time_limit) ? std::max(1e-3, s->time_limit - (res.setup_seconds + res.loop_seconds)) : s->time_limit, INT_MAX, px.data(), py.data());
       engine_ran = engine_ran || sx.status != 8;
       if (sx.status == 1 && std::fabs(sx.objective - res.primal_objective) <= 1e-2 * (1.0 + std::fabs(res.primal_objective))) {
         sol->x = sx.x, sol->y = sx.y, sol->rc = sx.rc;
         res.primal_objective = res.dual_objective = sx.objective;
         res.gap = res.relative_gap = 0.0;
         res.loop_seconds += sx.seconds;
-        crossover_by = "dual_simplex_cold_start";
+        crossover_by = "dual_simplex_from_the_pdlp_point";
       } else {
         crossover_by = sx.status == 8 ? "not_done_lp_too_large_for_the_dual_simplex" : "not_done_dual_simplex_disagreed_or_abstained";
       }

@@ -1,13 +1,17 @@
-// A bounded dual simplex for SMALL LPs: this library's second engine behind CUOPT_METHOD_DUAL_SIMPLEX and the
-// Concurrent method (the reference runs its CPU dual simplex there: LP/solve.cu:295-347 run_dual_simplex, :383-443
+// A bounded dual simplex: this library's second engine behind CUOPT_METHOD_DUAL_SIMPLEX, the Concurrent method and
+// crossover requests (the reference runs its CPU dual simplex there: LP/solve.cu:295-347 run_dual_simplex, :383-443
 // run_concurrent; cpp/src/dual_simplex/).  Own implementation, nothing of the reference's simplex is linked or restated:
-// the textbook bounded dual simplex (Dantzig pricing on the primal infeasibilities, Harris' two-pass dual ratio test) on
+// the textbook bounded dual simplex (dual steepest-edge pricing on the primal infeasibilities, Harris' two-pass dual ratio
+// test) on
 //     min c.x   s.t.  A x - s = 0,   lb <= x <= ub,   lo <= s <= hi
-// with a DENSE explicit basis inverse (rank-one updates, refactorisation from scratch every 400 pivots), which is what
-// an LP of a few thousand rows needs and no more.  Infinite bounds are boxed (+-BIG) so that the slack basis is dual
-// feasible from the start; a solution that leans on a box bound is solved again with a 1000 times larger box, and if
-// it still does, the LP is unbounded.  Host code: the reference's simplex is CPU code too; PDLP on the GPU stays the
-// engine for everything that is not small.
+// The basis is kept as a SPARSE LU factorisation (left-looking, Gilbert-Peierls: the columns sorted by length, threshold
+// partial pivoting with the sparser row preferred; a dependent column is replaced by the slack of a row that found no
+// pivot) with product-form updates behind it, refactorised every 100 pivots.  The pivot row is formed from the ROWS of A
+// (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
+// dual feasible once every nonbasic variable sits on the bound its reduced cost points to -- which is also what lets a
+// solve start from a basis guessed from another engine's solution (cuoptamd_dual_simplex_from: the crossover of a PDLP
+// solution).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
+// the LP is unbounded.  Host code: the reference's simplex is CPU code too; PDLP on the GPU stays the engine for large LPs.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -16,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <numeric>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
@@ -23,20 +28,40 @@
 namespace {
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
+constexpr int kRefactorEvery = 100;
 
 struct Simplex {
   int m = 0, n = 0, N = 0;
+  const int32_t* rp = nullptr;  // rows of A: the caller's CSR
+  const int32_t* rj = nullptr;
+  const double* rv  = nullptr;
   // columns of A (CSC) -- column j of M = [A | -I] is A's column j for j < n, -e_(j-n) behind
   std::vector<int32_t> cp, ci;
   std::vector<double> cv;
   std::vector<double> g, L, U;      // cost, bounds of z = (x, s)
+  std::vector<double> g0;           // the true cost while cost shifts are in force (empty: none)
   std::vector<char> boxedL, boxedU; // the bound is an artificial box bound
-  std::vector<int> basic, pos;      // basic[r] = variable, pos[j] = row or -1
+  std::vector<int> basic, pos;      // basic[k] = variable of basis position k, pos[j] = position or -1
   std::vector<char> atU;            // nonbasic at its upper bound
   std::vector<double> z, d, y;      // primal values, reduced costs, duals
-  std::vector<double> Binv;         // m x m, row major
+  std::vector<double> beta;         // dual steepest-edge weights, per VARIABLE (positions move at a refactorisation)
   int iterations = 0;
+  bool steepest  = true;
 
+  // ---- the factorisation: row prow[k] is the pivot of basis position k; L unit lower (by columns, original row numbers),
+  //      U by columns (pivot numbers above the diagonal), Ud the diagonal
+  std::vector<int> Lp, Li, Up, Ui, pinv, prow;
+  std::vector<double> Lx, Ux, Ud;
+  // product-form updates: position Er[e], pivot Ew[e], the other entries of the entering column in Ep/Ei/Ex
+  std::vector<int> Ep, Ei, Er;
+  std::vector<double> Ex, Ew;
+  // work space
+  std::vector<double> wx;
+  std::vector<int> inpat, pattern, mark, topo, dstack, dptr, rowcnt;
+  int stamp = 0, nucleus = 0;
+  int64_t factor_ops = 0;  // work of the last factorisation (entries touched): what a refactorisation is weighed against
+
+  int col_count(int j) const { return j >= n ? 1 : cp[j + 1] - cp[j]; }
   double col_dot(const double* row, int j) const  // row . M_j
   {
     if (j >= n) return -row[j - n];
@@ -44,46 +69,265 @@ struct Simplex {
     for (int k = cp[j]; k < cp[j + 1]; ++k) s += row[ci[k]] * cv[k];
     return s;
   }
-  // Binv from scratch (Gauss-Jordan with partial pivoting on the basis matrix); false: singular
-  bool refactor()
+
+  // LU of the columns `cand` (variables, in priority order when there are more than fit); rewrites basic / pos.  Candidates
+  // that are linearly dependent on the ones before them (or come after m pivots were found) are returned in `rejected`;
+  // rows left without a pivot get their slack.
+  void factor(const std::vector<int>& cand, std::vector<int>* rejected, int nprio = -1)
   {
-    std::vector<double> Bm((size_t)m * m, 0.0);
-    for (int r = 0; r < m; ++r) {
-      const int j = basic[r];
-      if (j >= n) Bm[(size_t)(j - n) * m + r] = -1.0;
+    // ---- the order of the columns and, where the structure hands it out, the pivot row: bases of LPs are close to triangular.
+    //  1. column singletons of the active part (a column with ONE entry in the rows that have no pivot yet: every slack to begin
+    //     with): pivot there -- nothing below the pivot, no elimination at all;
+    //  2. row singletons (a row that ONE remaining column reaches): pivot there if the entry is not small for its column -- the
+    //     column's other entries become multipliers, but no other column has an entry in that row: no fill;
+    //  3. what is left (the nucleus) in the order of the active column lengths, threshold partial pivoting, sparser row first.
+    // (nprio >= 0: only the first nprio candidates are ordered this way; the others follow them, shortest first, so that of a
+    // dependent set it is never one of the first nprio that is turned away because of one of the others)
+    const int nc = nprio >= 0 ? std::min(nprio, (int)cand.size()) : (int)cand.size();
+    std::vector<int> rstart(m + 1, 0), ccount(nc, 0), rcount(m, 0);
+    auto each_entry = [&](int c, auto&& f) {
+      const int j = cand[c];
+      if (j >= n) f(j - n, -1.0);
       else
-        for (int k = cp[j]; k < cp[j + 1]; ++k) Bm[(size_t)ci[k] * m + r] = cv[k];
-    }
-    Binv.assign((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i) Binv[(size_t)i * m + i] = 1.0;
-    for (int c = 0; c < m; ++c) {
-      int piv = c;
-      double best = std::fabs(Bm[(size_t)c * m + c]);
-      for (int i = c + 1; i < m; ++i)
-        if (std::fabs(Bm[(size_t)i * m + c]) > best) best = std::fabs(Bm[(size_t)i * m + c]), piv = i;
-      if (best < 1e-11) return false;
-      if (piv != c) {
-        for (int k = 0; k < m; ++k) std::swap(Bm[(size_t)piv * m + k], Bm[(size_t)c * m + k]), std::swap(Binv[(size_t)piv * m + k], Binv[(size_t)c * m + k]);
-      }
-      const double inv = 1.0 / Bm[(size_t)c * m + c];
-      for (int k = 0; k < m; ++k) Bm[(size_t)c * m + k] *= inv, Binv[(size_t)c * m + k] *= inv;
-      for (int i = 0; i < m; ++i) {
-        if (i == c) continue;
-        const double f = Bm[(size_t)i * m + c];
-        if (f == 0.0) continue;
-        double* bi       = &Bm[(size_t)i * m];
-        double* vi       = &Binv[(size_t)i * m];
-        const double* bc = &Bm[(size_t)c * m];
-        const double* vc = &Binv[(size_t)c * m];
-        for (int k = 0; k < m; ++k) bi[k] -= f * bc[k], vi[k] -= f * vc[k];
+        for (int e = cp[j]; e < cp[j + 1]; ++e) f(ci[e], cv[e]);
+    };
+    for (int c = 0; c < nc; ++c) each_entry(c, [&](int i, double) { rstart[i + 1]++, ccount[c]++; });
+    for (int i = 0; i < m; ++i) rcount[i] = rstart[i + 1], rstart[i + 1] += rstart[i];
+    std::vector<int> rcols(rstart[m]), fill_at(rstart.begin(), rstart.end() - 1);
+    for (int c = 0; c < nc; ++c) each_entry(c, [&](int i, double) { rcols[fill_at[i]++] = c; });
+    std::vector<char> cdone(nc, 0), ractive(m, 1);
+    std::vector<std::pair<int, int>> order;  // (candidate, forced pivot row or -1)
+    order.reserve(cand.size());
+    std::vector<int> queue;
+    for (int c = 0; c < nc; ++c)
+      if (ccount[c] == 1) queue.push_back(c);
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const int c = queue[h];
+      if (cdone[c] || ccount[c] != 1) continue;
+      int row = -1;
+      each_entry(c, [&](int i, double) { if (ractive[i]) row = i; });
+      if (row < 0) continue;
+      order.emplace_back(c, row), cdone[c] = 1, ractive[row] = 0;
+      for (int e = rstart[row]; e < rstart[row + 1]; ++e) {
+        const int c2 = rcols[e];
+        if (!cdone[c2] && --ccount[c2] == 1) queue.push_back(c2);
       }
     }
-    return true;
+    queue.clear();
+    for (int i = 0; i < m; ++i) {
+      if (!ractive[i]) continue;
+      int live = 0;
+      for (int e = rstart[i]; e < rstart[i + 1]; ++e) live += !cdone[rcols[e]];
+      rcount[i] = live;
+      if (live == 1) queue.push_back(i);
+    }
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const int i = queue[h];
+      if (!ractive[i] || rcount[i] != 1) continue;
+      int c = -1;
+      for (int e = rstart[i]; e < rstart[i + 1]; ++e)
+        if (!cdone[rcols[e]]) c = rcols[e];
+      if (c < 0) continue;
+      double here = 0.0, colmax = 0.0;
+      each_entry(c, [&](int i2, double v) {
+        if (!ractive[i2]) return;
+        colmax = std::max(colmax, std::fabs(v));
+        if (i2 == i) here += v;
+      });
+      if (std::fabs(here) < 0.01 * colmax || here == 0.0) continue;  // too small a pivot for its column: the nucleus decides
+      order.emplace_back(c, i), cdone[c] = 1, ractive[i] = 0;
+      each_entry(c, [&](int i2, double) {
+        if (ractive[i2] && --rcount[i2] == 1) queue.push_back(i2);
+      });
+    }
+    {
+      std::vector<int> rest;
+      for (int c = 0; c < nc; ++c)
+        if (!cdone[c]) {
+          int live = 0;
+          each_entry(c, [&](int i, double) { live += ractive[i]; });
+          ccount[c] = live;
+          rest.push_back(c);
+        }
+      std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return ccount[x] < ccount[y]; });
+      for (int c : rest) order.emplace_back(c, -1);
+      nucleus = (int)rest.size();
+      rest.clear();
+      for (int c = nc; c < (int)cand.size(); ++c) rest.push_back(c);
+      std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return col_count(cand[x]) < col_count(cand[y]); });
+      for (int c : rest) order.emplace_back(c, -1);
+    }
+    rowcnt.swap(rcount);
+    factor_ops = rstart[m];
+    pinv.assign(m, -1), prow.assign(m, -1);
+    Lp.assign(1, 0), Up.assign(1, 0);
+    Li.clear(), Lx.clear(), Ui.clear(), Ux.clear(), Ud.clear();
+    Ep.assign(1, 0), Ei.clear(), Ex.clear(), Er.clear(), Ew.clear();
+    wx.assign(m, 0.0), inpat.assign(m, -1), mark.assign(m, -1);
+    std::vector<int> nb;
+    nb.reserve(m);
+    int k = 0;
+    stamp = 0;
+    for (const auto& oc : order) {
+      const int j = cand[oc.first], forced = oc.second;
+      if (k == m) {
+        if (rejected) rejected->push_back(j);
+        continue;
+      }
+      const int st = stamp++;
+      pattern.clear();
+      auto touch = [&](int i) {
+        if (inpat[i] != st) inpat[i] = st, pattern.push_back(i);
+      };
+      double colmax = 1.0;
+      if (j >= n) wx[j - n] = -1.0, touch(j - n);
+      else {
+        colmax = 0.0;
+        for (int e = cp[j]; e < cp[j + 1]; ++e) wx[ci[e]] += cv[e], touch(ci[e]), colmax = std::max(colmax, std::fabs(cv[e]));  // (+=: a file may list an entry twice)
+      }
+      // the pivots this column reaches through L, in topological order (depth-first, iterative)
+      topo.clear();
+      const size_t n0 = pattern.size();
+      for (size_t t = 0; t < n0; ++t) {
+        const int start = pinv[pattern[t]];
+        if (start < 0 || mark[start] == st) continue;
+        dstack.assign(1, start), dptr.assign(1, Lp[start]);
+        mark[start] = st;
+        while (!dstack.empty()) {
+          const int jj = dstack.back();
+          int& e       = dptr.back();
+          bool down    = false;
+          while (e < Lp[jj + 1]) {
+            const int nx = pinv[Li[e++]];
+            if (nx >= 0 && mark[nx] != st) {
+              mark[nx] = st;
+              dstack.push_back(nx), dptr.push_back(Lp[nx]);
+              down = true;
+              break;
+            }
+          }
+          if (!down) {
+            topo.push_back(jj);
+            dstack.pop_back(), dptr.pop_back();
+          }
+        }
+      }
+      for (size_t t = topo.size(); t-- > 0;) {
+        const int jj    = topo[t];
+        const double xj = wx[prow[jj]];
+        if (xj == 0.0) continue;
+        Ui.push_back(jj), Ux.push_back(xj);
+        for (int e = Lp[jj]; e < Lp[jj + 1]; ++e) touch(Li[e]), wx[Li[e]] -= Lx[e] * xj;
+        factor_ops += Lp[jj + 1] - Lp[jj] + 1;
+      }
+      factor_ops += (int64_t)pattern.size();
+      double best = 0.0;
+      for (int i : pattern)
+        if (pinv[i] < 0) best = std::max(best, std::fabs(wx[i]));
+      if (best <= std::max(1e-11, 1e-9 * colmax)) {  // dependent on the columns before it
+        Ui.resize(Up.back()), Ux.resize(Up.back());
+        for (int i : pattern) wx[i] = 0.0;
+        if (rejected) rejected->push_back(j);
+        continue;
+      }
+      int piv = forced >= 0 && pinv[forced] < 0 && std::fabs(wx[forced]) >= 0.01 * best ? forced : -1;
+      for (int i : pattern) {
+        if (piv == forced && forced >= 0) break;
+        if (pinv[i] >= 0 || std::fabs(wx[i]) < 0.1 * best) continue;
+        if (piv < 0 || rowcnt[i] < rowcnt[piv] || (rowcnt[i] == rowcnt[piv] && std::fabs(wx[i]) > std::fabs(wx[piv]))) piv = i;
+      }
+      const double pv = wx[piv];
+      Ud.push_back(pv), Up.push_back((int)Ui.size());
+      for (int i : pattern)
+        if (pinv[i] < 0 && i != piv && wx[i] != 0.0) Li.push_back(i), Lx.push_back(wx[i] / pv);
+      Lp.push_back((int)Li.size());
+      for (int i : pattern) wx[i] = 0.0;
+      pinv[piv] = k, prow[k] = piv, nb.push_back(j), ++k;
+    }
+    for (int i = 0; i < m; ++i)
+      if (pinv[i] < 0) {
+        Ud.push_back(-1.0), Up.push_back((int)Ui.size()), Lp.push_back((int)Li.size());
+        pinv[i] = k, prow[k] = i, nb.push_back(n + i), ++k;
+      }
+    basic.swap(nb);
+    std::fill(pos.begin(), pos.end(), -1);
+    for (int q = 0; q < m; ++q) pos[basic[q]] = q;
   }
-  // z_B, y, d from the nonbasic values and the current inverse
+  // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
+  void ftran(std::vector<double>& x, std::vector<double>& w) const
+  {
+    for (int k = 0; k < m; ++k) {
+      const double xj = x[prow[k]];
+      if (xj == 0.0) continue;
+      for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
+    }
+    for (int k = m - 1; k >= 0; --k) {
+      double v = x[prow[k]];
+      if (v != 0.0) {
+        v /= Ud[k];
+        for (int e = Up[k]; e < Up[k + 1]; ++e) x[prow[Ui[e]]] -= Ux[e] * v;
+      }
+      w[k] = v;
+    }
+    const int ne = (int)Er.size();
+    for (int e = 0; e < ne; ++e) {
+      const double xr = w[Er[e]];
+      if (xr == 0.0) continue;
+      const double t = xr / Ew[e];
+      for (int q = Ep[e]; q < Ep[e + 1]; ++q) w[Ei[q]] -= Ex[q] * t;
+      w[Er[e]] = t;
+    }
+  }
+  // rho = B^-T t : `t` by POSITION (destroyed), rho by ROW
+  void btran(std::vector<double>& t, std::vector<double>& rho) const
+  {
+    for (int e = (int)Er.size() - 1; e >= 0; --e) {
+      double s = t[Er[e]];
+      for (int q = Ep[e]; q < Ep[e + 1]; ++q) s -= t[Ei[q]] * Ex[q];
+      t[Er[e]] = s / Ew[e];
+    }
+    for (int k = 0; k < m; ++k) {
+      double s = t[k];
+      for (int e = Up[k]; e < Up[k + 1]; ++e) s -= Ux[e] * t[Ui[e]];
+      t[k] = s / Ud[k];
+    }
+    for (int k = m - 1; k >= 0; --k) {
+      double s = t[k];
+      for (int e = Lp[k]; e < Lp[k + 1]; ++e) s -= Lx[e] * rho[Li[e]];
+      rho[prow[k]] = s;
+    }
+  }
+  void push_eta(int r, const std::vector<double>& w)
+  {
+    for (int i = 0; i < m; ++i)
+      if (i != r && w[i] != 0.0) Ei.push_back(i), Ex.push_back(w[i]);
+    Ep.push_back((int)Ei.size()), Er.push_back(r), Ew.push_back(w[r]);
+  }
+  // debug: || B w - a || and || B^T rho - t || for one right-hand side each
+  void check_factor(const char* where)
+  {
+    std::vector<double> a(m), w(m), x(m), t(m), rho(m, 0.0);
+    for (int i = 0; i < m; ++i) a[i] = std::sin(1.0 + i), t[i] = std::cos(2.0 + i);
+    x = a;
+    ftran(x, w);
+    std::vector<double> res(a);
+    for (int k = 0; k < m; ++k) {
+      const int j = basic[k];
+      if (j >= n) res[j - n] += w[k];
+      else
+        for (int e = cp[j]; e < cp[j + 1]; ++e) res[ci[e]] -= cv[e] * w[k];
+    }
+    double e1 = 0.0, e2 = 0.0;
+    for (int i = 0; i < m; ++i) e1 = std::max(e1, std::fabs(res[i]));
+    x = t;
+    btran(x, rho);
+    for (int k = 0; k < m; ++k) e2 = std::max(e2, std::fabs(col_dot(rho.data(), basic[k]) - t[k]));
+    std::fprintf(stderr, "[simplex] %s: residual of B w = a %.3g, of B^T rho = t %.3g\n", where, e1, e2);
+  }
+  // z_B, y, d from the nonbasic values and the current factorisation
   void recompute()
   {
-    std::vector<double> rhs(m, 0.0);  // -N z_N
+    std::vector<double> rhs(m, 0.0), w(m, 0.0);  // -N z_N
     for (int j = 0; j < N; ++j) {
       if (pos[j] >= 0) continue;
       const double v = z[j];
@@ -92,51 +336,89 @@ struct Simplex {
       else
         for (int k = cp[j]; k < cp[j + 1]; ++k) rhs[ci[k]] -= cv[k] * v;
     }
-    for (int r = 0; r < m; ++r) {
-      double s         = 0.0;
-      const double* br = &Binv[(size_t)r * m];
-      for (int i = 0; i < m; ++i) s += br[i] * rhs[i];
-      z[basic[r]] = s;
-    }
-    std::fill(y.begin(), y.end(), 0.0);
-    for (int r = 0; r < m; ++r) {
-      const double gb = g[basic[r]];
-      if (gb == 0.0) continue;
-      const double* br = &Binv[(size_t)r * m];
-      for (int i = 0; i < m; ++i) y[i] += gb * br[i];
-    }
+    ftran(rhs, w);
+    for (int k = 0; k < m; ++k) z[basic[k]] = w[k];
+    for (int k = 0; k < m; ++k) w[k] = g[basic[k]];
+    btran(w, y);
     for (int j = 0; j < N; ++j) d[j] = pos[j] >= 0 ? 0.0 : g[j] - col_dot(y.data(), j);
   }
+  // every nonbasic variable onto the bound its reduced cost points to (boxed: always possible); true when something moved
+  // (shift: where the bound asked for is an artificial box bound, the COST is moved instead so that the reduced cost becomes 0
+  //  -- a start from another engine's point must not throw variables out to the box; the caller takes the shifts back later)
+  bool make_dual_feasible(double tol_d, bool shift = false)
+  {
+    bool moved = false;
+    for (int j = 0; j < N; ++j) {
+      if (pos[j] >= 0 || L[j] == U[j]) continue;
+      const bool want_upper = d[j] < -tol_d, want_lower = d[j] > tol_d;
+      if ((want_upper && !atU[j]) || (want_lower && atU[j])) {
+        if (shift && (want_upper ? boxedU[j] : boxedL[j])) {
+          if (g0.empty()) g0 = g;
+          g[j] -= d[j], d[j] = 0.0;
+          continue;
+        }
+        atU[j] = want_upper;
+        z[j]   = atU[j] ? U[j] : L[j];
+        moved  = true;
+      }
+    }
+    return moved;
+  }
+  // a fresh factorisation of the current basis (repaired where it has become singular), then everything derived from it
+  void rebuild(double tol_d)
+  {
+    const auto t_in = std::chrono::steady_clock::now();
+    std::vector<int> rejected, cand(basic);
+    const size_t eta_entries = Ei.size();
+    factor(cand, &rejected);
+    if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+    for (int j : rejected) {  // left the basis: onto the nearer bound
+      atU[j] = std::fabs(U[j] - z[j]) < std::fabs(z[j] - L[j]);
+      z[j]   = atU[j] ? U[j] : L[j];
+    }
+    for (int k = 0; k < m; ++k)
+      if (beta[basic[k]] <= 0.0) beta[basic[k]] = 1.0;
+    recompute();
+    if (make_dual_feasible(tol_d)) recompute();
+    if (debug) tsec[7] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+    if (debug && (++rebuilds % 10) == 0) {
+      int structurals = 0;
+      for (int k = 0; k < m; ++k) structurals += basic[k] < n;
+      std::fprintf(stderr, "[simplex] rebuild %d: %d structural columns in the basis, nucleus %d, L %zu + U %zu off-diagonal entries (updates before: %zu), %zu repaired\n", rebuilds, structurals, nucleus, Li.size(), Ui.size(), eta_entries, rejected.size());
+    }
+  }
+  bool debug   = false;
+  int rebuilds = 0;
+  double tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, updates, rebuild}
+};
+struct Lap {
+  double* acc;
+  std::chrono::steady_clock::time_point t0;
+  Lap(Simplex& S, int slot) : acc(S.debug ? &S.tsec[slot] : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
+  ~Lap() { if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-// status: 1 optimal, 2 primal infeasible, 5 iteration limit, 6 time limit, 7 numerical trouble
+// status: 1 optimal, 2 primal infeasible, 5 iteration limit, 6 time limit, 7 numerical trouble, 9 cancelled.  Continues from
+// the basis and the nonbasic bounds S holds (factorised, recomputed, dual feasible).
 int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
 {
   const int m = S.m, n = S.n, N = S.N;
-  // slack basis: B = -I, dual feasible by the choice of the nonbasic bounds (every bound is finite after boxing)
-  S.basic.resize(m), S.pos.assign(N, -1), S.atU.assign(N, 0);
-  for (int r = 0; r < m; ++r) S.basic[r] = n + r, S.pos[n + r] = r;
-  S.z.assign(N, 0.0), S.d.assign(N, 0.0), S.y.assign(m, 0.0);
-  for (int j = 0; j < n; ++j) {
-    S.atU[j] = S.g[j] < 0.0;
-    S.z[j]   = S.atU[j] ? S.U[j] : S.L[j];
-  }
-  S.Binv.assign((size_t)m * m, 0.0);
-  for (int i = 0; i < m; ++i) S.Binv[(size_t)i * m + i] = -1.0;
-  S.recompute();
-  std::vector<double> alpha(N), w(m);
-  std::vector<int> passed(m, 0);  // iteration (+1) at which the row was passed over as "violated by rounding only"
+  std::vector<double> alpha(N, 0.0), w(m), rho(m), tvec(m), tau(m), col(m);
+  std::vector<int> touched, astamp(N, -1);
+  std::vector<int> passed(m, 0);  // iteration (+1) at which the position was passed over as "violated by rounding only"
   const double tol_d = 1e-9;
-  int since_refactor = 0;
+  int since_refactor = 0, sweep = 0;
+  int64_t extra_ops = 0;
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
     if (cancel && *cancel) return 9;  // the other engine of a Concurrent solve has finished
-    if ((S.iterations & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
-    // leaving row: the largest primal infeasibility (primal tolerance 1e-7 relative to the bound; the reference's simplex: 1e-6
-    // absolute).  A row whose violation is within 1e-6 and that has no entering candidate is rounding, not a proof of
-    // infeasibility (the box bounds put values of 1e6 into the basis): it is passed over.
+    if ((S.iterations & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
+    // leaving position: the largest primal infeasibility, squared over its steepest-edge weight (primal tolerance 1e-7 relative
+    // to the bound; the reference's simplex: 1e-6 absolute).  A position whose violation is within 1e-6 and that has no entering
+    // candidate is rounding, not a proof of infeasibility (the box bounds put values of 1e6 into the basis): it is passed over.
     int r = -1;
-    double worst = 0.0;
+    double worst = 0.0, worst_inf = 0.0;
+    { Lap lap(S, 0);
     for (int i = 0; i < m; ++i) {
       if (passed[i] == S.iterations + 1) continue;
       const int b     = S.basic[i];
@@ -144,129 +426,243 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       const double lo = S.L[b] - v, up = v - S.U[b];
       const double inf = std::max(lo, up);
       const double tol = 1e-7 * (1.0 + std::fabs(lo > up ? S.L[b] : S.U[b]));
-      if (inf > tol && inf > worst) worst = inf, r = i;
+      if (inf <= tol) continue;
+      const double score = S.steepest ? inf * inf / S.beta[b] : inf;
+      if (score > worst) worst = score, worst_inf = inf, r = i;
+    }
     }
     if (r < 0) return 1;
     const int p        = S.basic[r];
     const bool to_low  = S.z[p] < S.L[p];
     const double delta = to_low ? S.L[p] - S.z[p] : S.U[p] - S.z[p];  // change the leaving variable needs
     const double sigma = to_low ? 1.0 : -1.0;
-    // row r of the tableau
-    const double* br = &S.Binv[(size_t)r * m];
-    double amax      = 0.0;
-    for (int j = 0; j < N; ++j) {
-      alpha[j] = 0.0;
-      if (S.pos[j] >= 0 || S.L[j] == S.U[j]) continue;
-      alpha[j] = S.col_dot(br, j);
-      amax     = std::max(amax, std::fabs(alpha[j]));
+    // row r of the inverse, then of the tableau (from the rows of A that row touches)
+    std::fill(tvec.begin(), tvec.end(), 0.0);
+    tvec[r] = 1.0;
+    { Lap lap(S, 1); S.btran(tvec, rho); }
+    ++sweep;
+    touched.clear();
+    double amax = 0.0;
+    { Lap lap(S, 2);
+    for (int i = 0; i < m; ++i) {
+      const double ri = rho[i];
+      if (std::fabs(ri) < 1e-14) continue;
+      for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) {
+        const int j = S.rj[k];
+        if (S.pos[j] >= 0) continue;
+        if (astamp[j] != sweep) astamp[j] = sweep, alpha[j] = 0.0, touched.push_back(j);
+        alpha[j] += ri * S.rv[k];
+      }
+      if (S.pos[n + i] < 0) astamp[n + i] = sweep, alpha[n + i] = -ri, touched.push_back(n + i);
+    }
+    }
+    for (int j : touched) {
+      if (S.L[j] == S.U[j]) alpha[j] = 0.0;  // a fixed variable never enters
+      amax = std::max(amax, std::fabs(alpha[j]));
     }
     const double ptol = std::max(1e-11, 1e-9 * amax);
     // Harris: pass 1 the largest step that keeps every reduced cost within tol_d of its sign, pass 2 the largest pivot under it
     double tmax = kInf;
-    for (int j = 0; j < N; ++j) {
+    for (int j : touched) {
       const double a = sigma * alpha[j];
-      if (S.pos[j] >= 0 || std::fabs(a) <= ptol) continue;
+      if (std::fabs(a) <= ptol) continue;
       const bool eligible = S.atU[j] ? a > 0.0 : a < 0.0;
       if (!eligible) continue;
       tmax = std::min(tmax, (std::fabs(S.d[j]) + tol_d) / std::fabs(a));
     }
-    if (tmax == kInf && worst <= 1e-6 * (1.0 + std::fabs(to_low ? S.L[p] : S.U[p]))) {
+    if (tmax == kInf && worst_inf <= 1e-6 * (1.0 + std::fabs(to_low ? S.L[p] : S.U[p]))) {
       passed[r] = S.iterations + 1;
       continue;
     }
     if (tmax == kInf) {  // no entering variable: the row proves primal infeasibility
-      if (std::getenv("CUOPT_AMD_SIMPLEX_DEBUG")) {
-        std::fprintf(stderr, "[simplex] infeasible row %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g; nonbasic:\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol);
-        for (int j = 0; j < N; ++j)
-          if (S.pos[j] < 0 && alpha[j] != 0.0) std::fprintf(stderr, "   j %d alpha %.3g atU %d z %.6g [%.6g, %.6g] d %.3g\n", j, alpha[j], (int)S.atU[j], S.z[j], S.L[j], S.U[j], S.d[j]);
+      if (since_refactor != 0) {  // ... if a fresh factorisation says so too
+        S.rebuild(tol_d);
+        since_refactor = 0, extra_ops = 0;
+        continue;
       }
+      if (std::getenv("CUOPT_AMD_SIMPLEX_DEBUG"))
+        std::fprintf(stderr, "[simplex] infeasible position %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol);
       return 2;
     }
     int q        = -1;
     double apick = 0.0;
-    for (int j = 0; j < N; ++j) {
+    for (int j : touched) {
       const double a = sigma * alpha[j];
-      if (S.pos[j] >= 0 || std::fabs(a) <= ptol) continue;
+      if (std::fabs(a) <= ptol) continue;
       const bool eligible = S.atU[j] ? a > 0.0 : a < 0.0;
       if (!eligible) continue;
       if (std::fabs(S.d[j]) / std::fabs(a) <= tmax && std::fabs(a) > apick) apick = std::fabs(a), q = j;
     }
     if (q < 0) return 7;
     // entering column
-    for (int i = 0; i < m; ++i) {
-      const double* bi = &S.Binv[(size_t)i * m];
-      double s         = 0.0;
-      if (q >= n) s = -bi[q - n];
-      else
-        for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) s += bi[S.ci[k]] * S.cv[k];
-      w[i] = s;
-    }
+    std::fill(col.begin(), col.end(), 0.0);
+    if (q >= n) col[q - n] = -1.0;
+    else
+      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k];
+    { Lap lap(S, 4); S.ftran(col, w); }
     if (std::fabs(w[r]) < 1e-11 || std::fabs(w[r] - alpha[q]) > 1e-6 * (1.0 + std::fabs(alpha[q]))) {
-      // the inverse has drifted: rebuild it and look again
-      if (since_refactor == 0 || !S.refactor()) return 7;
-      S.recompute();
-      since_refactor = 0;
+      // the factorisation has drifted: rebuild it and look again
+      if (since_refactor == 0) return 7;
+      S.rebuild(tol_d);
+      since_refactor = 0, extra_ops = 0;
       continue;
+    }
+    // steepest-edge weights: beta_i += kappa_i (kappa_i beta_r - 2 tau_i), kappa_i = w_i / w_r, tau = B^-1 rho
+    if (S.steepest) {
+      Lap lap(S, 5);
+      double br = 0.0;
+      for (int i = 0; i < m; ++i) br += rho[i] * rho[i];
+      S.beta[p] = br;  // exact, whatever the updates had made of it
+      col       = rho;
+      S.ftran(col, tau);
+      const double wr = w[r];
+      for (int i = 0; i < m; ++i) {
+        if (i == r || w[i] == 0.0) continue;
+        const double kap = w[i] / wr;
+        double& b        = S.beta[S.basic[i]];
+        b                = std::max(b + kap * (kap * br - 2.0 * tau[i]), 1e-4);
+      }
+      S.beta[q] = std::max(br / (wr * wr), 1e-4);
     }
     // duals: d_j -= theta alpha_rj, the entering variable's becomes 0, the leaving one's -theta
     const double theta = S.d[q] / alpha[q];
-    for (int j = 0; j < N; ++j)
-      if (S.pos[j] < 0 && alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
+    for (int j : touched)
+      if (alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
     S.d[q] = 0.0;
     S.d[p] = -theta;
-    // primal: the entering variable moves by tau, the basic ones by -w tau
-    const double tau = -delta / w[r];
-    for (int i = 0; i < m; ++i) S.z[S.basic[i]] -= w[i] * tau;
-    S.z[q] += tau;
+    // primal: the entering variable moves by step, the basic ones by -w step
+    const double step = -delta / w[r];
+    for (int i = 0; i < m; ++i)
+      if (w[i] != 0.0) S.z[S.basic[i]] -= w[i] * step;
+    S.z[q] += step;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
+    S.push_eta(r, w);
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
-    // inverse: row r scaled, the others eliminated
-    {
-      double* rr       = &S.Binv[(size_t)r * m];
-      const double inv = 1.0 / w[r];
-      for (int k = 0; k < m; ++k) rr[k] *= inv;
-      for (int i = 0; i < m; ++i) {
-        if (i == r || w[i] == 0.0) continue;
-        double* bi     = &S.Binv[(size_t)i * m];
-        const double f = w[i];
-        for (int k = 0; k < m; ++k) bi[k] -= f * rr[k];
-      }
-    }
     S.iterations += 1;
-    if (++since_refactor >= 400) {  // (a refactorisation is O(m^3), a pivot O(m^2))
-      if (!S.refactor()) return 7;
-      S.recompute();
-      since_refactor = 0;
-      // a reduced cost that drifted to the wrong side of zero: put the variable on the bound that fits (boxed: always possible)
-      for (int j = 0; j < N; ++j) {
-        if (S.pos[j] >= 0 || S.L[j] == S.U[j]) continue;
-        const bool want_upper = S.d[j] < -tol_d;
-        const bool want_lower = S.d[j] > tol_d;
-        if ((want_upper && !S.atU[j]) || (want_lower && S.atU[j])) {
-          S.atU[j] = want_upper;
-          S.z[j]   = S.atU[j] ? S.U[j] : S.L[j];
-        }
-      }
-      S.recompute();
+    // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
+    // after kRefactorEvery pivots
+    extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.Ei.size();
+    // (the factorisation's count is of entries touched; its depth-first searches and pivot choices make an entry cost ~8 times
+    // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s)
+    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
+    if (++since_refactor >= kRefactorEvery || extra_ops >= rebuild_ops) {
+      S.rebuild(tol_d);
+      since_refactor = 0, extra_ops = 0;
     }
   }
 }
 
-}  // namespace
+// slack basis: B = -I, dual feasible by the choice of the nonbasic bounds (every bound is finite after boxing)
+void start_from_slacks(Simplex& S)
+{
+  const int m = S.m, n = S.n, N = S.N;
+  S.basic.resize(m), S.pos.assign(N, -1), S.atU.assign(N, 0);
+  S.z.assign(N, 0.0), S.d.assign(N, 0.0), S.y.assign(m, 0.0), S.beta.assign(N, 1.0);
+  for (int j = 0; j < n; ++j) {
+    S.atU[j] = S.g[j] < 0.0;
+    S.z[j]   = S.atU[j] ? S.U[j] : S.L[j];
+  }
+  std::vector<int> cand(m);
+  for (int r = 0; r < m; ++r) cand[r] = n + r;
+  S.factor(cand, nullptr);
+  S.recompute();
+}
+// a basis guessed from a point (x0, y0): the variables (structural and slack) that sit strictly between their bounds, the most
+// interior first; behind them -- a vertex of an LP is usually degenerate, fewer than m variables are inside -- the ones on a
+// bound whose reduced cost at y0 is smallest (the slack of row i has reduced cost y0_i); the first m of that list.  Dependent
+// ones and missing ones are replaced by slacks in the factorisation; the others go to their nearer bound, then to the bound
+// their reduced cost asks for
+void start_from_point(Simplex& S, const double* x0, const double* y0, double sense)
+{
+  const int m = S.m, n = S.n, N = S.N;
+  S.pos.assign(N, -1), S.atU.assign(N, 0);
+  S.z.assign(N, 0.0), S.d.assign(N, 0.0), S.y.assign(m, 0.0), S.beta.assign(N, 1.0);
+  for (int j = 0; j < n; ++j) S.z[j] = x0[j];
+  for (int i = 0; i < m; ++i) {
+    double s = 0.0;
+    for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) s += S.rv[k] * x0[S.rj[k]];
+    S.z[n + i] = s;
+  }
+  std::vector<double> d0(N, 0.0);
+  if (y0) {
+    std::vector<double> yi(m);
+    for (int i = 0; i < m; ++i) yi[i] = sense * y0[i], d0[n + i] = yi[i];
+    for (int j = 0; j < n; ++j) d0[j] = S.g[j] - S.col_dot(yi.data(), j);
+  }
+  // score = (relative) room to the nearer bound - (relative) size of the reduced cost: a basic variable has room and no reduced
+  // cost, a nonbasic one a reduced cost and no room, a degenerate basic one neither -- it ranks between the two, whatever the
+  // accuracy of the point is
+  double cmax = 0.0;
+  for (int j = 0; j < n; ++j) cmax = std::max(cmax, std::fabs(S.g[j]));
+  std::vector<std::pair<double, int>> inside;
+  size_t strictly = 0;
+  for (int j = 0; j < N; ++j) {  // (a fixed variable -- the slack of an equality row -- never enters, but it can be basic at a vertex)
+    const double room  = std::max(0.0, std::min(S.z[j] - S.L[j], S.U[j] - S.z[j])) / (1.0 + std::fabs(S.z[j]));
+    const double score = std::min(room, 1.0) - std::min(std::fabs(d0[j]) / (1.0 + cmax), 1.0);
+    strictly += score > 1e-3;
+    inside.emplace_back(-score, j);
+  }
+  std::sort(inside.begin(), inside.end());
+  std::vector<int> cand;
+  int nprio = 0;
+  for (size_t t = 0; t < inside.size() && (int)cand.size() < m; ++t) cand.push_back(inside[t].second), nprio += inside[t].first < -1e-3;
+  for (int j = 0; j < N; ++j) {
+    S.atU[j] = std::fabs(S.U[j] - S.z[j]) < std::fabs(S.z[j] - S.L[j]);
+    S.z[j]   = S.atU[j] ? S.U[j] : S.L[j];
+  }
+  S.basic.assign(m, 0);
+  std::vector<int> rejected;
+  S.factor(cand, &rejected, nprio);  // (rejected candidates are nonbasic at their nearer bound already)
+  if (S.debug) S.check_factor("start from a point");
+  S.recompute();
+  if (S.debug) {
+    int wrong = 0, inf0 = 0;
+    double worst = 0.0;
+    for (int j = 0; j < N; ++j) {
+      if (S.pos[j] >= 0 || S.L[j] == S.U[j]) continue;
+      const bool bad = (S.d[j] < -1e-9 && !S.atU[j]) || (S.d[j] > 1e-9 && S.atU[j]);
+      wrong += bad;
+      if (bad) worst = std::max(worst, std::fabs(S.d[j]));
+    }
+    for (int k = 0; k < m; ++k) {
+      const int b = S.basic[k];
+      inf0 += S.z[b] < S.L[b] - 1e-7 * (1 + std::fabs(S.L[b])) || S.z[b] > S.U[b] + 1e-7 * (1 + std::fabs(S.U[b]));
+    }
+    std::fprintf(stderr, "[simplex] start from a point: before the flips %d primal infeasible positions, %d reduced costs on the wrong side (largest %.3g); rejected:", inf0, wrong, worst);
+    for (int j : rejected) std::fprintf(stderr, " %d(%s, d0 %.3g, z0-L %.3g, U-z0 %.3g)", j, j >= n ? "slack" : "structural", d0[j], (j<n? x0[j]: 0.0) - S.L[j], S.U[j] - (j<n? x0[j]:0.0));
+    std::fprintf(stderr, "\n");
+  }
+  const bool moved = S.make_dual_feasible(1e-9, true);
+  if (moved) S.recompute();
+  if (S.debug) {
+    int infeasible = 0;
+    for (int k = 0; k < m; ++k) {
+      const int b = S.basic[k];
+      infeasible += S.z[b] < S.L[b] - 1e-7 * (1 + std::fabs(S.L[b])) || S.z[b] > S.U[b] + 1e-7 * (1 + std::fabs(S.U[b]));
+    }
+    std::fprintf(stderr, "[simplex] start from a point: %zu variables strictly inside their bounds, %zu candidates, %zu rejected, bounds flipped for dual feasibility: %d, primal infeasible positions: %d\n",
+                 strictly, cand.size(), rejected.size(), (int)moved, infeasible);
+  }
+}
 
-extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
-                                     int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
+int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
+          int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
 {
   if (!lp || !status) return -1;
   const auto t0 = std::chrono::steady_clock::now();
   const int m = lp->m, n = lp->n;
   const int64_t nnz = m > 0 ? lp->offsets[m] : 0;
-  *status = 8;  // too large for a dense basis inverse (or empty): the caller keeps to PDLP
+  *status = 8;  // too large (or empty): the caller keeps to PDLP
   if (iterations) *iterations = 0;
-  if (m <= 0 || n <= 0 || m > 3000 || (int64_t)n + m > 60000 || nnz > 400000) return 0;
+  int64_t max_rows = 200000, max_nnz = 4000000;
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_MAX_ROWS")) max_rows = std::atoll(e);
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_MAX_NNZ")) max_nnz = std::atoll(e);
+  if (m <= 0 || n <= 0 || m > max_rows || (int64_t)n + m > 20 * max_rows || nnz > max_nnz) return 0;
   Simplex S;
   S.m = m, S.n = n, S.N = n + m;
+  S.rp = lp->offsets, S.rj = lp->indices, S.rv = lp->values;
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_PRICING")) S.steepest = std::strcmp(e, "dantzig") != 0;
   // columns of A
   S.cp.assign(n + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) S.cp[lp->indices[k] + 1]++;
@@ -296,9 +692,12 @@ extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, i
   std::vector<int> first_pos;
   if (time_limit <= 0.0 || !std::isfinite(time_limit)) time_limit = 1e30;
   if (iteration_limit <= 0) iteration_limit = std::numeric_limits<int32_t>::max();
+  const bool debug = std::getenv("CUOPT_AMD_SIMPLEX_DEBUG") != nullptr;
+  S.debug = debug;
+  int total_iterations = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const double big = (attempt == 0 ? 1e5 : 1e8) * scale;
-    S.g.assign(S.N, 0.0), S.L.assign(S.N, 0.0), S.U.assign(S.N, 0.0);
+    S.g.assign(S.N, 0.0), S.L.assign(S.N, 0.0), S.U.assign(S.N, 0.0), S.g0.clear();
     S.boxedL.assign(S.N, 0), S.boxedU.assign(S.N, 0);
     for (int j = 0; j < S.N; ++j) {
       const double l = j < n ? lp->lb[j] : lp->lo[j - n], u = j < n ? lp->ub[j] : lp->hi[j - n];
@@ -310,15 +709,42 @@ extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, i
       S.L[j] = std::isfinite(l) ? l : -big, S.boxedL[j] = !std::isfinite(l);
       S.U[j] = std::isfinite(u) ? u : big, S.boxedU[j] = !std::isfinite(u);
     }
-    S.iterations = 0;
-    code         = run(S, iteration_limit, time_limit, t0, cancel);
-    if (iterations) *iterations += S.iterations;
-    if (code != 1) break;
-    if (!S.refactor()) {  // the numbers that go out come from a fresh inverse
-      code = 7;
-      break;
+    if (attempt == 0) {
+      if (x0) start_from_point(S, x0, y0, sense);
+      else start_from_slacks(S);
+    } else {
+      // the wider box: same basis, the nonbasic variables follow their (box) bounds out
+      for (int j = 0; j < S.N; ++j)
+        if (S.pos[j] < 0) S.z[j] = S.atU[j] ? S.U[j] : S.L[j];
+      S.rebuild(1e-9);
     }
-    S.recompute();
+    if (debug) {
+      int structurals = 0;
+      for (int k = 0; k < m; ++k) structurals += S.basic[k] < n;
+      std::fprintf(stderr, "[simplex] attempt %d box %.3g: start basis with %d structural columns, L %zu + U %zu off-diagonal entries\n", attempt, big, structurals, S.Li.size(), S.Ui.size());
+    }
+    // (a final fresh factorisation may repair the basis or find rounding-size infeasibilities: then the loop goes on)
+    for (int pass = 0; pass < 4; ++pass) {
+      S.iterations = 0;
+      code         = run(S, iteration_limit - total_iterations, time_limit, t0, cancel);
+      total_iterations += S.iterations;
+      if (code != 1) break;
+      const bool shifted = !S.g0.empty();
+      if (shifted) S.g.swap(S.g0), S.g0.clear();  // the true costs again: rebuild() puts what is dual infeasible now onto its bound
+      const std::vector<int> before(S.basic);
+      S.rebuild(1e-9);
+      std::vector<int> a(before), b(S.basic);
+      std::sort(a.begin(), a.end()), std::sort(b.begin(), b.end());
+      bool clean = a == b;
+      for (int k = 0; k < m && clean; ++k) {
+        const int v = S.basic[k];
+        clean = S.z[v] >= S.L[v] - 1e-6 * (1.0 + std::fabs(S.L[v])) && S.z[v] <= S.U[v] + 1e-6 * (1.0 + std::fabs(S.U[v]));
+      }
+      if (clean) break;
+      if (pass == 3) code = 7;
+    }
+    if (iterations) *iterations = total_iterations;
+    if (code != 1) break;
     // does the vertex lean on a box bound?
     bool leans = false;
     for (int j = 0; j < S.N && !leans; ++j) {
@@ -327,10 +753,11 @@ extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, i
     }
     double obj = 0.0;
     for (int j = 0; j < n; ++j) obj += S.g[j] * S.z[j];
-    if (std::getenv("CUOPT_AMD_SIMPLEX_DEBUG")) {
-      std::fprintf(stderr, "[simplex] attempt %d box %.3g: objective %.17g, leans %d, iterations %d, x =", attempt, big, obj, (int)leans, S.iterations);
+    if (debug) {
+      std::fprintf(stderr, "[simplex] attempt %d box %.3g: objective %.17g, leans %d, iterations %d, %.3f s, x =", attempt, big, obj, (int)leans, total_iterations,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       for (int j = 0; j < std::min(n, 8); ++j) std::fprintf(stderr, " %.6g", S.z[j]);
-      std::fprintf(stderr, "\n");
+      std::fprintf(stderr, "\n[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ftran %.2f, weights %.2f, rebuilds %.2f (factorisations %.2f)\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[4], S.tsec[5], S.tsec[7], S.tsec[6]);
     }
     if (!leans) break;
     if (attempt == 1) {
@@ -354,6 +781,7 @@ extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, i
     first_z = S.z, first_y = S.y, first_d = S.d, first_pos = S.pos;
   }
   *status = code;
+  if (iterations) *iterations = total_iterations;
   if (code == 1) {
     double obj = 0.0;
     for (int j = 0; j < n; ++j) obj += lp->c[j] * S.z[j];
@@ -366,4 +794,20 @@ extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, i
       for (int j = 0; j < n; ++j) rc[j] = sense * (S.pos[j] >= 0 ? 0.0 : S.d[j]);
   }
   return 0;
+}
+
+}  // namespace
+
+extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
+                                     int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
+{
+  return solve(lp, nullptr, nullptr, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+}
+
+extern "C" int cuoptamd_dual_simplex_from(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit,
+                                          const volatile int32_t* cancel, int32_t* status, int32_t* iterations, double* objective,
+                                          double* x, double* y, double* rc)
+{
+  if (!x0) return -1;
+  return solve(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
 }

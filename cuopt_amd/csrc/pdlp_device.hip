@@ -3099,6 +3099,7 @@ static void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const 
   const int64_t nnz = off[m];
   for (int32_t r = 0; r < m; ++r) {
     bool owner = false;
+    if (off[r + 1] - off[r] < kDenseMin) continue;  // (a 1e7-nonzero matrix of short rows: this scan was 8 ms of the set-up)
     for (int k = off[r]; k < off[r + 1];) {
       int e = k;
       while (e + 1 < off[r + 1] && idx[e + 1] == idx[e] + 1) ++e;
@@ -3180,7 +3181,7 @@ static void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const
     D->st_off[j + 1] = (int32_t)D->st_idx.size();
   }
 }
-constexpr int kLongExtract = 2048;  // rows longer than this leave the layouts when CUOPT_AMD_LONG_ROWS=1
+constexpr int kLongExtractDefault = 2048;  // rows longer than this leave the layouts when CUOPT_AMD_LONG_ROWS=1
 struct LongHost {
   bool on = false;
   std::vector<int32_t> row, row_ch, row_flag, ch_k0, ch_len, idx, perm;
@@ -3192,8 +3193,11 @@ static void extract_long_rows(int32_t rows, const int32_t* base_off, const int32
 {
   // opt-in (CUOPT_AMD_LONG_ROWS=1): measured on the power-law and block-angular workloads (profiles/r03_long_rows.txt) the two
   // extra launches cost more than the imbalance they remove
+  // (a value > 1 is the threshold itself: CUOPT_AMD_LONG_ROWS=256 leaves rows of at most 256 nonzeros, what the gather-free
+  // layout accepts)
   const char* env = getenv("CUOPT_AMD_LONG_ROWS");
   if (!env || atoi(env) == 0) return;
+  const int kLongExtract = atoi(env) > 1 ? atoi(env) : kLongExtractDefault;
   const bool full      = h_off.empty();
   const int32_t* off   = full ? base_off : h_off.data();
   const int32_t* idx   = full ? base_idx : h_idx.data();

@@ -188,14 +188,22 @@ typedef struct cuoptamd_warm_start {
   int32_t n_variables, n_constraints;
 } cuoptamd_warm_start;
 
-/* The second engine (the reference's: cpp/src/dual_simplex, LP/solve.cu:295-347): an own bounded dual simplex with a dense
- * basis inverse for SMALL LPs (m <= 3000, n + m <= 60000, nnz <= 400000), host code like the reference's.
+/* The second engine (the reference's: cpp/src/dual_simplex, LP/solve.cu:295-347): an own bounded dual simplex (sparse LU of the
+ * basis with product-form updates, dual steepest-edge pricing, Harris ratio test), host code like the reference's.  LPs of up to
+ * 200 000 rows and 4e6 nonzeros (CUOPT_AMD_SIMPLEX_MAX_ROWS / CUOPT_AMD_SIMPLEX_MAX_NNZ move the limits).
  * *status: 1 optimal (x, y, rc, objective filled; y and rc in the convention rc = c - A^T y), 2 primal infeasible,
  * 3 unbounded, 5 iteration limit, 6 time limit, 7 numerical trouble / the engine abstains (a vertex on the box of the infinite
  * bounds whose ray costs less than any dual tolerance), 8 too large for this engine (nothing was done), 9 cancelled
  * (*cancel became non-zero: the other engine of a Concurrent solve finished first).  time_limit <= 0 / iteration_limit <= 0: none. */
 int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
                           int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc);
+/* The same engine started from a basis guessed from the point x0 (n entries) and, optionally, the duals y0 (m entries, same
+ * convention as y; NULL: none) -- e.g. PDLP's solution: the variables and rows that sit strictly between their bounds there form
+ * the basis, then the ones on a bound with the smallest reduced cost at y0, completed / repaired with slacks.  This is the
+ * crossover of a first-order solution to a vertex (the reference: crossover = true, LP/solve.cu:466-547). */
+int cuoptamd_dual_simplex_from(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit,
+                               const volatile int32_t* cancel, int32_t* status, int32_t* iterations, double* objective, double* x,
+                               double* y, double* rc);
 
 const char* cuoptamd_last_error(void);
 

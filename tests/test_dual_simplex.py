@@ -1,6 +1,8 @@
 """CPU: the library's own small-LP dual simplex (cuopt_amd/csrc/dual_simplex.cpp, host code -- no GPU involved) against the verdicts and
 objectives of the REFERENCE's dual simplex held in the goldens (tests/golden/problems.json: the LP relaxations of datasets/mip and
 the LP fixtures; tests/golden/mps_parser.json: all 21 non-empty LP files of datasets/linear_programming)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,6 +131,58 @@ def test_limits_and_size_gate():
     p = synthetic.generate(300, 260, 6, seed=4)
     assert capi.dual_simplex(p, iteration_limit=3)["status"] == "IterationLimit"
     big = synthetic.generate(4000, 3000, 4, seed=4)
-    assert capi.dual_simplex(big)["status"] == "TooLarge"  # > 3000 rows: this engine is for small LPs, PDLP has the rest
+    os.environ["CUOPT_AMD_SIMPLEX_MAX_ROWS"] = "3000"
+    try:
+        assert capi.dual_simplex(big)["status"] == "TooLarge"  # beyond the engine's size limits nothing is done: PDLP has the rest
+    finally:
+        del os.environ["CUOPT_AMD_SIMPLEX_MAX_ROWS"]
+    assert capi.dual_simplex(big, time_limit=0.05)["status"] == "TimeLimit"
     r = capi.dual_simplex(p)
     assert r["status"] == "Optimal" and r["objective"] == pytest.approx(p["objective_star"], rel=1e-8)
+
+
+def test_mid_size_lps_through_the_sparse_factorisation():
+    """beyond what a dense basis inverse could hold: the sparse LU + product-form updates on random and structured LPs whose
+    optimum is known by construction"""
+    from cuopt_amd import synthetic
+    cases = [synthetic.generate(2500, 2000, 4, seed=9), synthetic.generate(1200, 2400, 5, seed=10),
+             synthetic.generate_structured("block_angular", 4000, 4000, 6, seed=3),
+             synthetic.generate_structured("staircase", 3000, 3000, 4, seed=3)]
+    for p in cases:
+        r = capi.dual_simplex(p, time_limit=200)
+        assert r["status"] == "Optimal", (p["m"], p["n"])
+        assert r["objective"] == pytest.approx(p["objective_star"], rel=1e-8, abs=1e-8)
+        _check_vertex(p, r, tol=1e-6)
+    # the same pivots under Dantzig pricing end at the same optimum (the steepest-edge weights only choose among infeasible rows)
+    os.environ["CUOPT_AMD_SIMPLEX_PRICING"] = "dantzig"
+    try:
+        r = capi.dual_simplex(cases[1], time_limit=200)
+    finally:
+        del os.environ["CUOPT_AMD_SIMPLEX_PRICING"]
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(cases[1]["objective_star"], rel=1e-8)
+
+
+def test_start_from_a_point_is_a_crossover():
+    """cuoptamd_dual_simplex_from: from the optimal vertex itself no pivot is needed; from a point 1e-4 away (what PDLP returns) far
+    fewer than from the slack basis; from a poor point the answer is still the optimum"""
+    from cuopt_amd import synthetic
+    rng = np.random.default_rng(5)
+    for p in (synthetic.generate(300, 260, 6, seed=4), synthetic.generate(1500, 1200, 4, seed=4)):
+        cold = capi.dual_simplex(p)
+        assert cold["status"] == "Optimal"
+        same = capi.dual_simplex(p, x0=cold["x"], y0=cold["y"])
+        assert same["status"] == "Optimal" and same["iterations"] <= cold["iterations"] // 20
+        assert same["objective"] == pytest.approx(cold["objective"], rel=1e-10)
+        near = capi.dual_simplex(p, x0=cold["x"] + 1e-4 * rng.standard_normal(p["n"]) * (1 + np.abs(cold["x"])),
+                                 y0=cold["y"] + 1e-4 * rng.standard_normal(p["m"]) * (1 + np.abs(cold["y"])))
+        assert near["status"] == "Optimal" and near["iterations"] <= cold["iterations"] // 4
+        assert near["objective"] == pytest.approx(cold["objective"], rel=1e-9)
+        _check_vertex(p, near, tol=1e-6)
+        poor = capi.dual_simplex(p, x0=rng.standard_normal(p["n"]), time_limit=120)  # no duals, nothing to do with the optimum
+        assert poor["status"] == "Optimal" and poor["objective"] == pytest.approx(cold["objective"], rel=1e-9)
+    # infeasible and unbounded LPs are recognised from a warm start as well
+    g = dict(m=1, n=2, offsets=np.array([0, 2], np.int32), indices=np.array([0, 1], np.int32), values=np.array([1.0, 1.0]),
+             c=np.array([1.0, 1.0]), lo=np.array([3.0]), hi=np.array([np.inf]), lb=np.zeros(2), ub=np.ones(2))
+    assert capi.dual_simplex(g, x0=np.array([1.0, 1.0]))["status"] == "PrimalInfeasible"
+    g.update(ub=np.full(2, np.inf), c=np.array([-1.0, 0.0]))
+    assert capi.dual_simplex(g, x0=np.array([5.0, 5.0]))["status"] == "Unbounded"
