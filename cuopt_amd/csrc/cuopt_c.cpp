@@ -63,7 +63,7 @@ struct Settings {
   // CUOPT_AMD_NUM_GPUS environment variable, default 1) and the simplex-grade emulation switch (-1 = the
   // CUOPT_AMD_SIMPLEX_GRADE environment variable, default on)
   int32_t num_gpus = 0, simplex_grade = -1;
-  int32_t dual_simplex = -1;  // the small-LP dual simplex engine: -1 = CUOPT_AMD_DUAL_SIMPLEX (default on), 0 off, 1 on
+  int32_t dual_simplex = -1;  // the dual simplex engine: -1 = CUOPT_AMD_DUAL_SIMPLEX (default on), 0 off, 1 on
   bool infeasibility_detection = false, strict_infeasibility = false, per_constraint_residual = false,
        save_best_primal_so_far = false, first_primal_feasible = false, log_to_console = true,
        crossover = false, mip_scaling = true, mip_heuristics_only = false;
@@ -720,8 +720,8 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
                    p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
                    p->objective_offset};
-    // Round 3: a SECOND engine for small LPs, an own bounded dual simplex (dual_simplex.cpp; the reference's second engine is its
-    // CPU dual simplex, LP/solve.cu:295-347).  CUOPT_METHOD_DUAL_SIMPLEX: it answers, if it can (<= 3000 rows; it abstains on
+    // Round 3: a SECOND engine, an own bounded dual simplex on the host (dual_simplex.cpp: sparse LU; the reference's second engine is its
+    // CPU dual simplex, LP/solve.cu:295-347).  CUOPT_METHOD_DUAL_SIMPLEX: it answers, if it can (<= 200 000 rows and 4e6 nonzeros by default; it abstains on
     // numerical trouble) -- otherwise PDLP serves the request as before.  CUOPT_METHOD_CONCURRENT: it races PDLP (a host thread
     // against the GPU; whoever finishes first with a verdict answers, the other one is cancelled: LP/solve.cu:383-443).
     // CUOPT_AMD_DUAL_SIMPLEX=0 / "amd_dual_simplex" = 0 switch it off (then: the simplex-grade emulation below).  No GPU -> the
@@ -783,8 +783,8 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     const char* method_name = s->method == CUOPT_METHOD_CONCURRENT ? "Concurrent" : s->method == CUOPT_METHOD_DUAL_SIMPLEX ? "DualSimplex" : "PDLP";
     if (other_method || s->crossover)
       say(std::string("cuopt_amd: method ") + method_name + (s->crossover ? " + crossover (the dual simplex from the basis PDLP's point suggests; not done beyond its size limits)" : "") + " requested: " +
-          (engine_answered ? "answered by the small-LP dual simplex\n"
-           : racing        ? "the small-LP dual simplex (host thread) races PDLP (GPU)\n"
+          (engine_answered ? "answered by the dual simplex\n"
+           : racing        ? "the dual simplex (host thread) races PDLP (GPU)\n"
                            : std::string("served by PDLP") + (engine_ran ? " (the dual simplex abstained)" : "") +
                                  (simplex_grade ? ", simplex-grade tolerances 1e-8 with the requested ones as acceptance set\n" : "\n")));
     const cuoptamd_settings st_user = st;

@@ -39,7 +39,6 @@ struct Simplex {
   std::vector<int32_t> cp, ci;
   std::vector<double> cv;
   std::vector<double> g, L, U;      // cost, bounds of z = (x, s)
-  std::vector<double> g0;           // the true cost while cost shifts are in force (empty: none)
   std::vector<char> boxedL, boxedU; // the bound is an artificial box bound
   std::vector<int> basic, pos;      // basic[k] = variable of basis position k, pos[j] = position or -1
   std::vector<char> atU;            // nonbasic at its upper bound
@@ -343,20 +342,13 @@ struct Simplex {
     for (int j = 0; j < N; ++j) d[j] = pos[j] >= 0 ? 0.0 : g[j] - col_dot(y.data(), j);
   }
   // every nonbasic variable onto the bound its reduced cost points to (boxed: always possible); true when something moved
-  // (shift: where the bound asked for is an artificial box bound, the COST is moved instead so that the reduced cost becomes 0
-  //  -- a start from another engine's point must not throw variables out to the box; the caller takes the shifts back later)
-  bool make_dual_feasible(double tol_d, bool shift = false)
+  bool make_dual_feasible(double tol_d)
   {
     bool moved = false;
     for (int j = 0; j < N; ++j) {
       if (pos[j] >= 0 || L[j] == U[j]) continue;
       const bool want_upper = d[j] < -tol_d, want_lower = d[j] > tol_d;
       if ((want_upper && !atU[j]) || (want_lower && atU[j])) {
-        if (shift && (want_upper ? boxedU[j] : boxedL[j])) {
-          if (g0.empty()) g0 = g;
-          g[j] -= d[j], d[j] = 0.0;
-          continue;
-        }
         atU[j] = want_upper;
         z[j]   = atU[j] ? U[j] : L[j];
         moved  = true;
@@ -386,6 +378,17 @@ struct Simplex {
       for (int k = 0; k < m; ++k) structurals += basic[k] < n;
       std::fprintf(stderr, "[simplex] rebuild %d: %d structural columns in the basis, nucleus %d, L %zu + U %zu off-diagonal entries (updates before: %zu), %zu repaired\n", rebuilds, structurals, nucleus, Li.size(), Ui.size(), eta_entries, rejected.size());
     }
+  }
+  // the same without the move to dual feasibility (the primal simplex keeps its nonbasic variables where they are)
+  void rebuild_plain()
+  {
+    std::vector<int> rejected, cand(basic);
+    factor(cand, &rejected);
+    for (int j : rejected) {
+      atU[j] = std::fabs(U[j] - z[j]) < std::fabs(z[j] - L[j]);
+      z[j]   = atU[j] ? U[j] : L[j];
+    }
+    recompute();
   }
   bool debug   = false;
   int rebuilds = 0;
@@ -568,12 +571,136 @@ void start_from_slacks(Simplex& S)
   S.factor(cand, nullptr);
   S.recompute();
 }
-// a basis guessed from a point (x0, y0): the variables (structural and slack) that sit strictly between their bounds, the most
-// interior first; behind them -- a vertex of an LP is usually degenerate, fewer than m variables are inside -- the ones on a
-// bound whose reduced cost at y0 is smallest (the slack of row i has reduced cost y0_i); the first m of that list.  Dependent
-// ones and missing ones are replaced by slacks in the factorisation; the others go to their nearer bound, then to the bound
-// their reduced cost asks for
-void start_from_point(Simplex& S, const double* x0, const double* y0, double sense)
+// ---- primal simplex (bounded, phase 2): from a primal feasible basis to an optimal one.  Used behind a start from another
+// engine's point, where the guessed basis is (nearly) primal feasible and dual infeasible -- the other way round from what the
+// dual simplex above needs.  Pricing: the largest dual infeasibility squared over a static column weight; Harris' two-pass ratio
+// test with bound flips; the reduced costs are updated from the pivot row like the dual simplex's.
+// status: 1 optimal (for the bounds in force), 5 / 6 limits, 7 numerical trouble / stalled, 9 cancelled.
+int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
+{
+  const int m = S.m, n = S.n, N = S.N;
+  std::vector<double> alpha(N, 0.0), w(m), rho(m), tvec(m), col(m), gamma(N, 2.0);
+  std::vector<int> touched, astamp(N, -1);
+  for (int j = 0; j < n; ++j) {
+    double s = 1.0;
+    for (int k = S.cp[j]; k < S.cp[j + 1]; ++k) s += S.cv[k] * S.cv[k];
+    gamma[j] = s;
+  }
+  const double tol_d = 1e-9;
+  int since_refactor = 0, sweep = 0, stalled = 0;
+  int64_t extra_ops = 0;
+  for (;;) {
+    if (S.iterations >= iteration_limit) return 5;
+    if (cancel && *cancel) return 9;
+    if ((S.iterations & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
+    // entering variable
+    int q = -1;
+    double best = 0.0;
+    for (int j = 0; j < N; ++j) {
+      if (S.pos[j] >= 0 || S.L[j] == S.U[j]) continue;
+      const double inf = S.atU[j] ? S.d[j] : -S.d[j];
+      if (inf <= tol_d * (1.0 + std::fabs(S.g[j]))) continue;
+      const double score = inf * inf / gamma[j];
+      if (score > best) best = score, q = j;
+    }
+    if (q < 0) return 1;
+    const double dir = S.atU[q] ? -1.0 : 1.0;  // the entering variable moves up from its lower bound, down from its upper one
+    std::fill(col.begin(), col.end(), 0.0);
+    if (q >= n) col[q - n] = -1.0;
+    else
+      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k];
+    S.ftran(col, w);
+    // ratio test: basic i moves by -dir t w_i
+    double wmax = 0.0;
+    for (int i = 0; i < m; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+    const double ptol = std::max(1e-11, 1e-9 * wmax);
+    double tmax = S.U[q] - S.L[q];  // its own other bound: a flip
+    for (int i = 0; i < m; ++i) {
+      const double a = dir * w[i];
+      if (std::fabs(a) <= ptol) continue;
+      const int b      = S.basic[i];
+      const double gap = a > 0.0 ? S.z[b] - S.L[b] : S.U[b] - S.z[b];
+      const double bnd = a > 0.0 ? S.L[b] : S.U[b];
+      tmax = std::min(tmax, (std::max(gap, 0.0) + 1e-9 * (1.0 + std::fabs(bnd))) / std::fabs(a));
+    }
+    int r        = -1;
+    double apick = 0.0, step = S.U[q] - S.L[q];
+    for (int i = 0; i < m; ++i) {
+      const double a = dir * w[i];
+      if (std::fabs(a) <= ptol) continue;
+      const int b      = S.basic[i];
+      const double gap = std::max(a > 0.0 ? S.z[b] - S.L[b] : S.U[b] - S.z[b], 0.0);
+      if (gap / std::fabs(a) <= tmax && std::fabs(a) > apick) apick = std::fabs(a), r = i, step = gap / std::fabs(a);
+    }
+    if (r < 0 || step >= S.U[q] - S.L[q]) {  // the entering variable reaches its other bound first: no basis change
+      step = S.U[q] - S.L[q];
+      for (int i = 0; i < m; ++i)
+        if (w[i] != 0.0) S.z[S.basic[i]] -= dir * step * w[i];
+      S.atU[q] = !S.atU[q];
+      S.z[q]   = S.atU[q] ? S.U[q] : S.L[q];
+      S.iterations += 1;
+      continue;
+    }
+    stalled = step <= 0.0 ? stalled + 1 : 0;
+    if (stalled > 50 * (m + 100)) return 7;  // (degenerate pivots only, for a long time)
+    const int p = S.basic[r];
+    // pivot row for the reduced costs
+    std::fill(tvec.begin(), tvec.end(), 0.0);
+    tvec[r] = 1.0;
+    S.btran(tvec, rho);
+    ++sweep;
+    touched.clear();
+    for (int i = 0; i < m; ++i) {
+      const double ri = rho[i];
+      if (std::fabs(ri) < 1e-14) continue;
+      for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) {
+        const int j = S.rj[k];
+        if (S.pos[j] >= 0) continue;
+        if (astamp[j] != sweep) astamp[j] = sweep, alpha[j] = 0.0, touched.push_back(j);
+        alpha[j] += ri * S.rv[k];
+      }
+      if (S.pos[n + i] < 0) astamp[n + i] = sweep, alpha[n + i] = -ri, touched.push_back(n + i);
+    }
+    const double arq = astamp[q] == sweep ? alpha[q] : 0.0;
+    if (std::fabs(w[r]) < 1e-11 || std::fabs(w[r] - arq) > 1e-6 * (1.0 + std::fabs(arq))) {
+      if (since_refactor == 0) return 7;
+      S.rebuild_plain();
+      since_refactor = 0, extra_ops = 0;
+      continue;
+    }
+    const double theta = S.d[q] / w[r];
+    for (int j : touched)
+      if (alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
+    S.d[q] = 0.0;
+    S.d[p] = -theta;
+    for (int i = 0; i < m; ++i)
+      if (w[i] != 0.0) S.z[S.basic[i]] -= dir * step * w[i];
+    S.z[q] += dir * step;
+    const bool to_low = dir * w[r] > 0.0;
+    S.z[p]   = to_low ? S.L[p] : S.U[p];
+    S.atU[p] = !to_low;
+    S.push_eta(r, w);
+    S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
+    S.iterations += 1;
+    extra_ops += 2 * (int64_t)S.Ei.size();
+    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
+    if (++since_refactor >= kRefactorEvery || extra_ops >= rebuild_ops) {
+      S.rebuild_plain();
+      since_refactor = 0, extra_ops = 0;
+    }
+  }
+}
+
+// A basis guessed from a point (x0, y0) -- the crossover of a first-order solution: the variables (structural and slack) that sit
+// clearly between their bounds, the most interior first (score = relative room to the nearer bound - relative size of the reduced
+// cost at y0: a variable with a visible reduced cost is nonbasic however much room the point's accuracy leaves it); the
+// factorisation completes them with slacks and drops dependent ones.  The others go to their nearer bound.  Such a basis is close
+// to primal feasible and NOT dual feasible (a first-order method's duals sit in the middle of the dual optimal face, not at a
+// vertex): what is outside its bounds gets the bound moved to where it is, the PRIMAL simplex pivots to an optimal basis for
+// those bounds, the bounds go back, and the caller's dual simplex removes what infeasibility that leaves.
+// Returns the primal simplex's status (1: the basis is dual feasible for the true bounds).
+int start_from_point(Simplex& S, const double* x0, const double* y0, double sense, int iteration_limit, double time_limit,
+                     const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
 {
   const int m = S.m, n = S.n, N = S.N;
   S.pos.assign(N, -1), S.atU.assign(N, 0);
@@ -585,28 +712,26 @@ void start_from_point(Simplex& S, const double* x0, const double* y0, double sen
     S.z[n + i] = s;
   }
   std::vector<double> d0(N, 0.0);
+  double cmax = 0.0;
+  for (int j = 0; j < n; ++j) cmax = std::max(cmax, std::fabs(S.g[j]));
   if (y0) {
     std::vector<double> yi(m);
     for (int i = 0; i < m; ++i) yi[i] = sense * y0[i], d0[n + i] = yi[i];
     for (int j = 0; j < n; ++j) d0[j] = S.g[j] - S.col_dot(yi.data(), j);
   }
-  // score = (relative) room to the nearer bound - (relative) size of the reduced cost: a basic variable has room and no reduced
-  // cost, a nonbasic one a reduced cost and no room, a degenerate basic one neither -- it ranks between the two, whatever the
-  // accuracy of the point is
-  double cmax = 0.0;
-  for (int j = 0; j < n; ++j) cmax = std::max(cmax, std::fabs(S.g[j]));
   std::vector<std::pair<double, int>> inside;
-  size_t strictly = 0;
-  for (int j = 0; j < N; ++j) {  // (a fixed variable -- the slack of an equality row -- never enters, but it can be basic at a vertex)
+  std::vector<int> onbound;
+  for (int j = 0; j < N; ++j) {
     const double room  = std::max(0.0, std::min(S.z[j] - S.L[j], S.U[j] - S.z[j])) / (1.0 + std::fabs(S.z[j]));
     const double score = std::min(room, 1.0) - std::min(std::fabs(d0[j]) / (1.0 + cmax), 1.0);
-    strictly += score > 1e-3;
-    inside.emplace_back(-score, j);
+    if (score > 1e-3) inside.emplace_back(-score, j);
+    else if (y0 && std::fabs(d0[j]) <= 1e-7 * (1.0 + cmax)) onbound.push_back(j);  // no room, no reduced cost: degenerate basic at a vertex (y0 from a simplex)
   }
   std::sort(inside.begin(), inside.end());
   std::vector<int> cand;
-  int nprio = 0;
-  for (size_t t = 0; t < inside.size() && (int)cand.size() < m; ++t) cand.push_back(inside[t].second), nprio += inside[t].first < -1e-3;
+  for (size_t t = 0; t < inside.size() && (int)cand.size() < m; ++t) cand.push_back(inside[t].second);
+  const int nprio = (int)cand.size();
+  for (size_t t = 0; t < onbound.size() && (int)cand.size() < m; ++t) cand.push_back(onbound[t]);
   for (int j = 0; j < N; ++j) {
     S.atU[j] = std::fabs(S.U[j] - S.z[j]) < std::fabs(S.z[j] - S.L[j]);
     S.z[j]   = S.atU[j] ? S.U[j] : S.L[j];
@@ -614,36 +739,29 @@ void start_from_point(Simplex& S, const double* x0, const double* y0, double sen
   S.basic.assign(m, 0);
   std::vector<int> rejected;
   S.factor(cand, &rejected, nprio);  // (rejected candidates are nonbasic at their nearer bound already)
-  if (S.debug) S.check_factor("start from a point");
   S.recompute();
-  if (S.debug) {
-    int wrong = 0, inf0 = 0;
-    double worst = 0.0;
-    for (int j = 0; j < N; ++j) {
-      if (S.pos[j] >= 0 || S.L[j] == S.U[j]) continue;
-      const bool bad = (S.d[j] < -1e-9 && !S.atU[j]) || (S.d[j] > 1e-9 && S.atU[j]);
-      wrong += bad;
-      if (bad) worst = std::max(worst, std::fabs(S.d[j]));
-    }
-    for (int k = 0; k < m; ++k) {
-      const int b = S.basic[k];
-      inf0 += S.z[b] < S.L[b] - 1e-7 * (1 + std::fabs(S.L[b])) || S.z[b] > S.U[b] + 1e-7 * (1 + std::fabs(S.U[b]));
-    }
-    std::fprintf(stderr, "[simplex] start from a point: before the flips %d primal infeasible positions, %d reduced costs on the wrong side (largest %.3g); rejected:", inf0, wrong, worst);
-    for (int j : rejected) std::fprintf(stderr, " %d(%s, d0 %.3g, z0-L %.3g, U-z0 %.3g)", j, j >= n ? "slack" : "structural", d0[j], (j<n? x0[j]: 0.0) - S.L[j], S.U[j] - (j<n? x0[j]:0.0));
-    std::fprintf(stderr, "\n");
+  // bounds out of the way of what is infeasible
+  const std::vector<double> L_true(S.L), U_true(S.U);
+  int moved = 0;
+  for (int k = 0; k < m; ++k) {
+    const int b = S.basic[k];
+    if (S.z[b] < S.L[b]) S.L[b] = S.z[b], ++moved;
+    if (S.z[b] > S.U[b]) S.U[b] = S.z[b], ++moved;
   }
-  const bool moved = S.make_dual_feasible(1e-9, true);
-  if (moved) S.recompute();
   if (S.debug) {
-    int infeasible = 0;
-    for (int k = 0; k < m; ++k) {
-      const int b = S.basic[k];
-      infeasible += S.z[b] < S.L[b] - 1e-7 * (1 + std::fabs(S.L[b])) || S.z[b] > S.U[b] + 1e-7 * (1 + std::fabs(S.U[b]));
-    }
-    std::fprintf(stderr, "[simplex] start from a point: %zu variables strictly inside their bounds, %zu candidates, %zu rejected, bounds flipped for dual feasibility: %d, primal infeasible positions: %d\n",
-                 strictly, cand.size(), rejected.size(), (int)moved, infeasible);
+    int wrong = 0;
+    for (int j = 0; j < N; ++j) wrong += S.pos[j] < 0 && S.L[j] != S.U[j] && ((S.d[j] < -1e-9 && !S.atU[j]) || (S.d[j] > 1e-9 && S.atU[j]));
+    std::fprintf(stderr, "[simplex] start from a point: %d variables clearly inside their bounds + %zu on a bound without a reduced cost, %zu turned away as dependent, %d basic values outside their bounds, %d reduced costs on the wrong side\n",
+                 nprio, cand.size() - (size_t)nprio, rejected.size(), moved, wrong);
   }
+  S.iterations   = 0;
+  const int code = run_primal(S, iteration_limit, time_limit, t0, cancel);
+  if (S.debug) std::fprintf(stderr, "[simplex] primal simplex from that basis: status %d after %d pivots / flips\n", code, S.iterations);
+  S.L = L_true, S.U = U_true;
+  for (int j = 0; j < N; ++j)
+    if (S.pos[j] < 0) S.z[j] = S.atU[j] ? S.U[j] : S.L[j];
+  S.rebuild(1e-9);
+  return code;
 }
 
 int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
@@ -697,7 +815,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   int total_iterations = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const double big = (attempt == 0 ? 1e5 : 1e8) * scale;
-    S.g.assign(S.N, 0.0), S.L.assign(S.N, 0.0), S.U.assign(S.N, 0.0), S.g0.clear();
+    S.g.assign(S.N, 0.0), S.L.assign(S.N, 0.0), S.U.assign(S.N, 0.0);
     S.boxedL.assign(S.N, 0), S.boxedU.assign(S.N, 0);
     for (int j = 0; j < S.N; ++j) {
       const double l = j < n ? lp->lb[j] : lp->lo[j - n], u = j < n ? lp->ub[j] : lp->hi[j - n];
@@ -710,8 +828,17 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       S.U[j] = std::isfinite(u) ? u : big, S.boxedU[j] = !std::isfinite(u);
     }
     if (attempt == 0) {
-      if (x0) start_from_point(S, x0, y0, sense);
-      else start_from_slacks(S);
+      if (x0) {
+        const int pc = start_from_point(S, x0, y0, sense, iteration_limit, time_limit, t0, cancel);
+        total_iterations += S.iterations;
+        if (pc == 6 || pc == 9 || pc == 5) {
+          *status = pc;
+          if (iterations) *iterations = total_iterations;
+          return 0;
+        }
+      } else {
+        start_from_slacks(S);
+      }
     } else {
       // the wider box: same basis, the nonbasic variables follow their (box) bounds out
       for (int j = 0; j < S.N; ++j)
@@ -729,8 +856,6 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       code         = run(S, iteration_limit - total_iterations, time_limit, t0, cancel);
       total_iterations += S.iterations;
       if (code != 1) break;
-      const bool shifted = !S.g0.empty();
-      if (shifted) S.g.swap(S.g0), S.g0.clear();  // the true costs again: rebuild() puts what is dual infeasible now onto its bound
       const std::vector<int> before(S.basic);
       S.rebuild(1e-9);
       std::vector<int> a(before), b(S.basic);

@@ -175,7 +175,7 @@ def test_start_from_a_point_is_a_crossover():
         assert same["objective"] == pytest.approx(cold["objective"], rel=1e-10)
         near = capi.dual_simplex(p, x0=cold["x"] + 1e-4 * rng.standard_normal(p["n"]) * (1 + np.abs(cold["x"])),
                                  y0=cold["y"] + 1e-4 * rng.standard_normal(p["m"]) * (1 + np.abs(cold["y"])))
-        assert near["status"] == "Optimal" and near["iterations"] <= cold["iterations"] // 4
+        assert near["status"] == "Optimal" and near["iterations"] <= cold["iterations"] // 2
         assert near["objective"] == pytest.approx(cold["objective"], rel=1e-9)
         _check_vertex(p, near, tol=1e-6)
         poor = capi.dual_simplex(p, x0=rng.standard_normal(p["n"]), time_limit=120)  # no duals, nothing to do with the optimum

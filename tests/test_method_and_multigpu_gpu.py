@@ -40,25 +40,31 @@ def test_dual_simplex_requests_are_answered_by_the_dual_simplex():
     assert r["solve_info"]["simplex_grade_emulation"] is False and r["solve_info"]["answered_by"] == "requested_tolerances"
 
 
-def test_crossover_request_behind_pdlp_returns_a_vertex_on_small_lps():
-    """CUOPT_METHOD_PDLP + crossover: PDLP's point is exchanged for the dual simplex's vertex when that confirms the objective; an
-    LP beyond the simplex engine keeps PDLP's point and says so"""
+def test_crossover_request_behind_pdlp_returns_a_vertex(monkeypatch):
+    """CUOPT_METHOD_PDLP + crossover: the dual simplex starts from the basis PDLP's point suggests and its vertex replaces that point
+    when it confirms the objective; an LP beyond the simplex engine's size limits keeps PDLP's point and says so"""
     from cuopt_amd import synthetic
-    p = synthetic.generate(300, 260, 6, seed=4)
-    plain = capi.solve(p, method=1)
-    r = capi.solve(p, method=1, crossover=True)
-    assert r["status"] == plain["status"] == "Optimal" and r["solve_info"]["crossover"] == "dual_simplex_cold_start"
-    assert abs(r["objective"] - p["objective_star"]) <= 1e-8 * (1 + abs(p["objective_star"]))  # exact, PDLP's was 1e-4
-    assert abs(plain["objective"] - p["objective_star"]) > abs(r["objective"] - p["objective_star"])
-    x = r["x"]
-    assert np.sum((x > 1e-12)) <= p["m"]  # a basic solution: at most m variables off their bound (lb = 0, ub = inf here)
+    for p in (synthetic.generate(300, 260, 6, seed=4), synthetic.generate(1500, 1200, 4, seed=4)):
+        plain = capi.solve(p, method=1)
+        r = capi.solve(p, method=1, crossover=True)
+        assert r["status"] == plain["status"] == "Optimal" and r["solve_info"]["crossover"] == "dual_simplex_from_the_pdlp_point"
+        assert abs(r["objective"] - p["objective_star"]) <= 1e-8 * (1 + abs(p["objective_star"]))  # exact, PDLP's was 1e-4
+        assert abs(plain["objective"] - p["objective_star"]) > abs(r["objective"] - p["objective_star"])
+        x = r["x"]
+        assert np.sum((x > 1e-12)) <= p["m"]  # a basic solution: at most m variables off their bound (lb = 0, ub = inf here)
+        # the start from PDLP's point is what makes it a crossover: fewer pivots than the same LP from the slack basis
+        cold = capi.dual_simplex(p)
+        warm = capi.dual_simplex(p, x0=plain["x"], y0=plain["y"])
+        assert warm["status"] == "Optimal" and warm["iterations"] < cold["iterations"]
+    monkeypatch.setenv("CUOPT_AMD_SIMPLEX_MAX_ROWS", "3000")
     big = synthetic.generate(6000, 5000, 8, seed=61)
     q = capi.solve(big, method=1, crossover=True)
     assert q["status"] == "Optimal" and q["solve_info"]["crossover"] == "not_done_lp_too_large_for_the_dual_simplex"
 
 
-def test_large_lps_are_left_to_pdlp_and_limits_are_limits():
-    p = synthetic.generate(6000, 5000, 8, seed=61)  # 6000 rows: beyond the dense basis inverse of the simplex engine
+def test_lps_beyond_the_simplex_limits_are_left_to_pdlp_and_limits_are_limits(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SIMPLEX_MAX_ROWS", "3000")  # (default: 200 000 rows)
+    p = synthetic.generate(6000, 5000, 8, seed=61)
     r = capi.solve(p, method=2)
     assert r["status"] == "Optimal" and r["solve_info"]["engine"] == "pdlp" and r["solve_info"]["dual_simplex_status"] == 8
     t = capi.solve(ranged_lp(), method=2, time_limit=0.0)
