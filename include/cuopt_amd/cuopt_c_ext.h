@@ -29,10 +29,12 @@ cuopt_int_t cuOptAmdGetPdlpStats(cuOptSolution solution, cuoptamd_result* stats)
 /* which engine / attempt answered the request, as one JSON object:
  * {"engine": "pdlp" | "dual_simplex", "requested_method": "Concurrent|DualSimplex|PDLP", "crossover_requested": bool,
  *  "simplex_grade_emulation": bool, "dual_simplex_consulted": bool, "dual_simplex_status": 1..9 (cuoptamd_dual_simplex),
+ *  "crossover": "none" | "dual_simplex_from_the_pdlp_point" | "not_done_..." | "not_needed_vertex_from_the_dual_simplex",
  *  "answered_by": "...", "gpus": N, "iterations": K, "simplex_grade_attempt_iterations": K0}
- * (the reference runs its dual simplex / crossover for such requests, LP/solve.cu:383-443,467-547; here small LPs have an own
- * dual simplex that answers DualSimplex requests and races PDLP under Concurrent, everything else -- and crossover -- is
- * served by PDLP, and the call says so instead of pretending) */
+ * (the reference runs its dual simplex / crossover for such requests, LP/solve.cu:383-443,467-547; here an own simplex code on
+ * the host -- cuoptamd_dual_simplex[_from], LPs of up to 200 000 rows -- answers DualSimplex requests, races PDLP under
+ * Concurrent and crosses PDLP's point over to a vertex; beyond its limits PDLP serves the request, and the call says so
+ * instead of pretending) */
 cuopt_int_t cuOptAmdGetSolveInfo(cuOptSolution solution, char* buffer, cuopt_int_t buffer_size);
 
 /* name of variable (kind 0) / constraint row (kind 1) `index` of a problem that came from cuOptReadProblem
