@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <numeric>
 #include <vector>
 
@@ -30,8 +31,11 @@ namespace {
 constexpr double kInf = std::numeric_limits<double>::infinity();
 constexpr int kRefactorEvery = 100;
 
+struct Cancelled {};  // thrown out of a factorisation when the other engine of a Concurrent solve has finished
+
 struct Simplex {
   int m = 0, n = 0, N = 0;
+  const volatile int32_t* cancel = nullptr;
   const int32_t* rp = nullptr;  // rows of A: the caller's CSR
   const int32_t* rj = nullptr;
   const double* rv  = nullptr;
@@ -169,6 +173,7 @@ struct Simplex {
     stamp = 0;
     for (const auto& oc : order) {
       const int j = cand[oc.first], forced = oc.second;
+      if ((stamp & 255) == 0 && cancel && *cancel) throw Cancelled{};  // (a large nucleus can take seconds: the caller is waiting)
       if (k == m) {
         if (rejected) rejected->push_back(j);
         continue;
@@ -780,6 +785,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   Simplex S;
   S.m = m, S.n = n, S.N = n + m;
   S.rp = lp->offsets, S.rj = lp->indices, S.rv = lp->values;
+  S.cancel = cancel;
   if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_PRICING")) S.steepest = std::strcmp(e, "dantzig") != 0;
   // columns of A
   S.cp.assign(n + 1, 0);
@@ -926,7 +932,15 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
 extern "C" int cuoptamd_dual_simplex(const cuoptamd_lp* lp, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
                                      int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
 {
-  return solve(lp, nullptr, nullptr, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  try {
+    return solve(lp, nullptr, nullptr, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  } catch (const Cancelled&) {
+    *status = 9;
+    return 0;
+  } catch (const std::bad_alloc&) {
+    *status = 8;  // no memory for the factorisation: too large for this engine
+    return 0;
+  }
 }
 
 extern "C" int cuoptamd_dual_simplex_from(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit,
@@ -934,5 +948,13 @@ extern "C" int cuoptamd_dual_simplex_from(const cuoptamd_lp* lp, const double* x
                                           double* x, double* y, double* rc)
 {
   if (!x0) return -1;
-  return solve(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  try {
+    return solve(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  } catch (const Cancelled&) {
+    *status = 9;
+    return 0;
+  } catch (const std::bad_alloc&) {
+    *status = 8;
+    return 0;
+  }
 }

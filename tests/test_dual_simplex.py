@@ -186,3 +186,28 @@ def test_start_from_a_point_is_a_crossover():
     assert capi.dual_simplex(g, x0=np.array([1.0, 1.0]))["status"] == "PrimalInfeasible"
     g.update(ub=np.full(2, np.inf), c=np.array([-1.0, 0.0]))
     assert capi.dual_simplex(g, x0=np.array([5.0, 5.0]))["status"] == "Unbounded"
+
+
+def test_cancel_is_honoured_within_milliseconds():
+    """the Concurrent method cancels the simplex when PDLP has answered: the flag is looked at every pivot AND inside a
+    factorisation (whose nucleus can take seconds on a large basis), so cuOptSolve never waits for this engine"""
+    import ctypes as C
+    import threading
+    import time
+    from cuopt_amd import synthetic
+    from cuopt_amd.capi import LP, _f64, _i32, _ptr, lib
+    p = synthetic.generate(12000, 10000, 5, seed=4)  # minutes of pivots from a cold start
+    k = dict(offsets=_i32(p["offsets"]), indices=_i32(p["indices"]), values=_f64(p["values"]), c=_f64(p["c"]), lo=_f64(p["lo"]),
+             hi=_f64(p["hi"]), lb=_f64(p["lb"]), ub=_f64(p["ub"]))
+    lp = LP(p["m"], p["n"], _ptr(k["offsets"]), _ptr(k["indices"]), _ptr(k["values"]), _ptr(k["c"]), _ptr(k["lo"]), _ptr(k["hi"]),
+            _ptr(k["lb"]), _ptr(k["ub"]), 0, 0.0)
+    cancel, status, its, obj = C.c_int32(0), C.c_int(0), C.c_int(0), C.c_double(0.0)
+    x, y, rc = np.zeros(p["n"]), np.zeros(p["m"]), np.zeros(p["n"])
+    worker = threading.Thread(target=lambda: lib.cuoptamd_dual_simplex(C.byref(lp), 0.0, 0, C.byref(cancel), C.byref(status), C.byref(its),
+                                                                      C.byref(obj), _ptr(x), _ptr(y), _ptr(rc)))
+    worker.start()
+    time.sleep(1.5)
+    t0 = time.time()
+    cancel.value = 1
+    worker.join()
+    assert time.time() - t0 < 0.5 and status.value == 9 and its.value > 100
