@@ -22,6 +22,7 @@
 #include <limits>
 #include <new>
 #include <numeric>
+#include <set>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
@@ -83,7 +84,7 @@ struct Simplex {
     //     with): pivot there -- nothing below the pivot, no elimination at all;
     //  2. row singletons (a row that ONE remaining column reaches): pivot there if the entry is not small for its column -- the
     //     column's other entries become multipliers, but no other column has an entry in that row: no fill;
-    //  3. what is left (the nucleus) in the order of the active column lengths, threshold partial pivoting, sparser row first.
+    //  3. what is left (the nucleus): right-looking with Markowitz' pivot choice, below.
     // (nprio >= 0: only the first nprio candidates are ordered this way; the others follow them, shortest first, so that of a
     // dependent set it is never one of the first nprio that is turned away because of one of the others)
     const int nc = nprio >= 0 ? std::min(nprio, (int)cand.size()) : (int)cand.size();
@@ -143,23 +144,12 @@ struct Simplex {
         if (ractive[i2] && --rcount[i2] == 1) queue.push_back(i2);
       });
     }
-    {
-      std::vector<int> rest;
-      for (int c = 0; c < nc; ++c)
-        if (!cdone[c]) {
-          int live = 0;
-          each_entry(c, [&](int i, double) { live += ractive[i]; });
-          ccount[c] = live;
-          rest.push_back(c);
-        }
-      std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return ccount[x] < ccount[y]; });
-      for (int c : rest) order.emplace_back(c, -1);
-      nucleus = (int)rest.size();
-      rest.clear();
-      for (int c = nc; c < (int)cand.size(); ++c) rest.push_back(c);
-      std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return col_count(cand[x]) < col_count(cand[y]); });
-      for (int c : rest) order.emplace_back(c, -1);
-    }
+    std::vector<int> nuc, tail;  // the nucleus (candidate numbers) and the candidates behind the first nprio
+    for (int c = 0; c < nc; ++c)
+      if (!cdone[c]) nuc.push_back(c);
+    nucleus = (int)nuc.size();
+    for (int c = nc; c < (int)cand.size(); ++c) tail.push_back(c);
+    std::stable_sort(tail.begin(), tail.end(), [&](int x, int y) { return col_count(cand[x]) < col_count(cand[y]); });
     rowcnt.swap(rcount);
     factor_ops = rstart[m];
     pinv.assign(m, -1), prow.assign(m, -1);
@@ -171,13 +161,10 @@ struct Simplex {
     nb.reserve(m);
     int k = 0;
     stamp = 0;
-    for (const auto& oc : order) {
-      const int j = cand[oc.first], forced = oc.second;
+    // One column against the pivots found so far (left-looking, Gilbert-Peierls): its entries in U are appended to Ui / Ux,
+    // what is left of it in the rows without a pivot stays in wx over `pattern`.  Returns the largest entry of the column itself.
+    auto eliminate = [&](int j) {
       if ((stamp & 255) == 0 && cancel && *cancel) throw Cancelled{};  // (a large nucleus can take seconds: the caller is waiting)
-      if (k == m) {
-        if (rejected) rejected->push_back(j);
-        continue;
-      }
       const int st = stamp++;
       pattern.clear();
       auto touch = [&](int i) {
@@ -225,6 +212,15 @@ struct Simplex {
         factor_ops += Lp[jj + 1] - Lp[jj] + 1;
       }
       factor_ops += (int64_t)pattern.size();
+      return colmax;
+    };
+    // ... and its pivot: `forced` if that row is acceptable, else threshold partial pivoting with the sparser row preferred
+    auto left_looking = [&](int j, int forced) {
+      if (k == m) {
+        if (rejected) rejected->push_back(j);
+        return;
+      }
+      const double colmax = eliminate(j);
       double best = 0.0;
       for (int i : pattern)
         if (pinv[i] < 0) best = std::max(best, std::fabs(wx[i]));
@@ -232,7 +228,7 @@ struct Simplex {
         Ui.resize(Up.back()), Ux.resize(Up.back());
         for (int i : pattern) wx[i] = 0.0;
         if (rejected) rejected->push_back(j);
-        continue;
+        return;
       }
       int piv = forced >= 0 && pinv[forced] < 0 && std::fabs(wx[forced]) >= 0.01 * best ? forced : -1;
       for (int i : pattern) {
@@ -247,7 +243,117 @@ struct Simplex {
       Lp.push_back((int)Li.size());
       for (int i : pattern) wx[i] = 0.0;
       pinv[piv] = k, prow[k] = piv, nb.push_back(j), ++k;
+    };
+    for (const auto& oc : order) left_looking(cand[oc.first], oc.second);
+    // ---- the nucleus: right-looking elimination with Markowitz' pivot choice.  Every nucleus column is first taken through the
+    // triangular part (its U entries there), what is left of it lives in `cols` (local row numbers); a pivot is the entry with the
+    // smallest (row count - 1)(column count - 1) among the entries within a factor 10 of their column's largest, looked for in
+    // the four shortest columns; the pivot row goes to the U columns of the columns it touches, the multipliers to L.
+    if (!nuc.empty() && k < m) {
+      struct Entry {
+        int r;
+        double v;
+      };
+      const int q = (int)nuc.size();
+      std::vector<int> rloc(m, -1), rglob;
+      for (int i = 0; i < m; ++i)
+        if (pinv[i] < 0) rloc[i] = (int)rglob.size(), rglob.push_back(i);
+      const int nr = (int)rglob.size();
+      std::vector<std::vector<Entry>> cols(q);
+      std::vector<std::vector<int>> rows(nr);
+      std::vector<std::vector<std::pair<int, double>>> ucol(q);
+      std::vector<double> cmax0(q, 0.0);
+      std::vector<int> rcnt(nr, 0), key(q, 0), where(nr, 0);
+      for (int c = 0; c < q; ++c) {
+        cmax0[c] = eliminate(cand[nuc[c]]);
+        for (int e = Up.back(); e < (int)Ui.size(); ++e) ucol[c].emplace_back(Ui[e], Ux[e]);
+        Ui.resize(Up.back()), Ux.resize(Up.back());
+        for (int i : pattern) {
+          if (pinv[i] < 0 && wx[i] != 0.0) cols[c].push_back({rloc[i], wx[i]}), rows[rloc[i]].push_back(c), rcnt[rloc[i]]++;
+          wx[i] = 0.0;
+        }
+      }
+      std::set<std::pair<int, int>> bycount;
+      for (int c = 0; c < q; ++c) key[c] = (int)cols[c].size(), bycount.emplace(key[c], c);
+      factor_ops += 40 * (int64_t)q + 2 * (int64_t)nr;
+      std::vector<char> gone(q, 0);
+      std::vector<Entry> lmul;
+      int polls = 0;
+      while (!bycount.empty() && k < m) {
+        if ((++polls & 63) == 0 && cancel && *cancel) throw Cancelled{};
+        int pc = -1, pr = -1;
+        double pval = 0.0;
+        int64_t pcost = std::numeric_limits<int64_t>::max();
+        int looked = 0;
+        for (auto it = bycount.begin(); it != bycount.end() && looked < 4; ++it, ++looked) {
+          const int c = it->second;
+          double colmax = 0.0;
+          for (const Entry& e : cols[c]) colmax = std::max(colmax, std::fabs(e.v));
+          factor_ops += 2 * (int64_t)cols[c].size() + 8;
+          if (colmax <= std::max(1e-11, 1e-9 * cmax0[c])) continue;  // (turned away below when it is the shortest one)
+          for (const Entry& e : cols[c]) {
+            if (std::fabs(e.v) < 0.1 * colmax) continue;
+            const int64_t cost = (int64_t)(rcnt[e.r] - 1) * (int64_t)(cols[c].size() - 1);
+            if (cost < pcost || (cost == pcost && std::fabs(e.v) > std::fabs(pval))) pcost = cost, pc = c, pr = e.r, pval = e.v;
+          }
+          if (pcost == 0) break;
+        }
+        if (pc < 0) {  // the shortest columns have nothing left: dependent on the pivots so far
+          const int c = bycount.begin()->second;
+          bycount.erase(bycount.begin());
+          gone[c] = 1;
+          for (const Entry& e : cols[c]) rcnt[e.r]--;
+          cols[c].clear();
+          if (rejected) rejected->push_back(cand[nuc[c]]);
+          continue;
+        }
+        bycount.erase({key[pc], pc});
+        gone[pc] = 1;
+        Ud.push_back(pval);
+        for (const auto& u : ucol[pc]) Ui.push_back(u.first), Ux.push_back(u.second);
+        Up.push_back((int)Ui.size());
+        lmul.clear();
+        for (const Entry& e : cols[pc]) {
+          rcnt[e.r]--;
+          if (e.r != pr) lmul.push_back({e.r, e.v / pval}), Li.push_back(rglob[e.r]), Lx.push_back(e.v / pval);
+        }
+        Lp.push_back((int)Li.size());
+        const int row = rglob[pr];
+        pinv[row] = k, prow[k] = row, nb.push_back(cand[nuc[pc]]);
+        for (int c : rows[pr]) {
+          if (gone[c]) continue;
+          std::vector<Entry>& col = cols[c];
+          size_t at = 0;
+          while (at < col.size() && col[at].r != pr) ++at;
+          if (at == col.size()) continue;
+          const double u = col[at].v;
+          col[at]        = col.back(), col.pop_back();
+          ucol[c].emplace_back(k, u);
+          if (u != 0.0 && !lmul.empty()) {
+            const size_t before = col.size();
+            for (size_t t = 0; t < before; ++t) where[col[t].r] = (int)t + 1;
+            for (const Entry& l : lmul) {
+              if (where[l.r]) col[where[l.r] - 1].v -= l.v * u;
+              else col.push_back({l.r, -l.v * u}), rows[l.r].push_back(c), rcnt[l.r]++;
+            }
+            for (size_t t = 0; t < before; ++t) where[col[t].r] = 0;
+            factor_ops += (int64_t)before + (int64_t)lmul.size();
+          }
+          bycount.erase({key[c], c});
+          key[c] = (int)col.size();
+          bycount.emplace(key[c], c);
+          factor_ops += 40 + (int64_t)at;  // (two walks through the ordered set)
+        }
+        rows[pr].clear(), cols[pc].clear();
+        ++k;
+      }
+      for (const auto& left : bycount)
+        if (rejected) rejected->push_back(cand[nuc[left.second]]);
+    } else if (!nuc.empty()) {
+      for (int c : nuc)
+        if (rejected) rejected->push_back(cand[c]);
     }
+    for (int c : tail) left_looking(cand[c], -1);
     for (int i = 0; i < m; ++i)
       if (pinv[i] < 0) {
         Ud.push_back(-1.0), Up.push_back((int)Ui.size()), Lp.push_back((int)Li.size());
@@ -368,7 +474,7 @@ struct Simplex {
     std::vector<int> rejected, cand(basic);
     const size_t eta_entries = Ei.size();
     factor(cand, &rejected);
-    if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+    if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(), ops_factor += factor_ops;
     for (int j : rejected) {  // left the basis: onto the nearer bound
       atU[j] = std::fabs(U[j] - z[j]) < std::fabs(z[j] - L[j]);
       z[j]   = atU[j] ? U[j] : L[j];
@@ -397,6 +503,7 @@ struct Simplex {
   }
   bool debug   = false;
   int rebuilds = 0;
+  int64_t ops_factor = 0, ops_solve = 0;
   double tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, updates, rebuild}
 };
 struct Lap {
@@ -551,6 +658,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
     // after kRefactorEvery pivots
     extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.Ei.size();
+    if (S.debug) S.ops_solve += (S.steepest ? 3 : 2) * ((int64_t)S.Ei.size() + (int64_t)S.Li.size() + (int64_t)S.Ui.size() + 2 * (int64_t)m);
     // (the factorisation's count is of entries touched; its depth-first searches and pivot choices make an entry cost ~8 times
     // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s)
     const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
@@ -888,7 +996,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       std::fprintf(stderr, "[simplex] attempt %d box %.3g: objective %.17g, leans %d, iterations %d, %.3f s, x =", attempt, big, obj, (int)leans, total_iterations,
                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       for (int j = 0; j < std::min(n, 8); ++j) std::fprintf(stderr, " %.6g", S.z[j]);
-      std::fprintf(stderr, "\n[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ftran %.2f, weights %.2f, rebuilds %.2f (factorisations %.2f)\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[4], S.tsec[5], S.tsec[7], S.tsec[6]);
+      std::fprintf(stderr, "\n[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ftran %.2f, weights %.2f, rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[4], S.tsec[5], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
     }
     if (!leans) break;
     if (attempt == 1) {
