@@ -4,13 +4,14 @@
 // the textbook bounded dual simplex (dual steepest-edge pricing on the primal infeasibilities, Harris' two-pass dual ratio
 // test) on
 //     min c.x   s.t.  A x - s = 0,   lb <= x <= ub,   lo <= s <= hi
-// The basis is kept as a SPARSE LU factorisation (left-looking, Gilbert-Peierls: the columns sorted by length, threshold
-// partial pivoting with the sparser row preferred; a dependent column is replaced by the slack of a row that found no
-// pivot) with product-form updates behind it, refactorised every 100 pivots.  The pivot row is formed from the ROWS of A
+// The basis is kept as a SPARSE LU factorisation (singleton columns and rows peeled off, the nucleus right-looking with
+// Markowitz' pivot choice under threshold partial pivoting; a dependent column is replaced by the slack of a row that found
+// no pivot) with product-form updates behind it, refactorised when the update file has cost as much as a factorisation, at
+// the latest every 100 pivots.  The pivot row is formed from the ROWS of A
 // (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
 // dual feasible once every nonbasic variable sits on the bound its reduced cost points to -- which is also what lets a
 // solve start from a basis guessed from another engine's solution (cuoptamd_dual_simplex_from: the crossover of a PDLP
-// solution).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
+// solution -- a primal simplex, below, takes that basis to optimality first).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
 // the LP is unbounded.  Host code: the reference's simplex is CPU code too; PDLP on the GPU stays the engine for large LPs.
 #include <algorithm>
 #include <chrono>
