@@ -3435,6 +3435,38 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       return timed || ws > ws_limit;
     };
     lap("row blocks + vectors");
+    // The A^T side's HOST work (waiting for the caller's transposition, the hot CSR, the layouts' construction) runs on a thread of
+    // its own next to the A side's construction and uploads; its uploads follow below, in the order they always had.
+    struct TSide {
+      std::thread worker;
+      std::vector<int32_t> rbt;
+      JagHost jat;
+      PbHost hbt;
+      PanelHost hat;
+      bool want_pb_layout = false;
+      ~TSide() { if (worker.joinable()) worker.join(); }
+    } ts;
+    const int32_t* T_off = at_offsets;
+    const int32_t* T_idx = at_indices;
+    ts.worker = std::thread([&] {
+      if (transpose_ready) transpose_ready(user);
+      if ((int64_t)at_offsets[n] != ctx->nnz) return;  // (reported below)
+      lat = long_rows(n, at_offsets);
+      if (DH.on) {
+        strip_transpose(DH, &DH, n, at_offsets, at_indices);
+        hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
+      }
+      if (one_gpu) extract_long_rows(n, at_offsets, at_indices, hT_off, hT_idx, hT_perm, nullptr, &LAT);
+      if (!hT_off.empty()) T_off = hT_off.data(), T_idx = hT_idx.data();
+      ts.rbt = build_row_blocks(n, T_off);
+      if (try_jag) ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
+      if (!ts.jat.ok && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
+        ts.want_pb_layout = true;
+        ts.hbt            = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
+      }
+      if (mode != "stream" && mode != "jag" && mode != "pb" && !ts.jat.ok && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T"))
+        ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
+    });
     if (try_jag) {
       JagHost ja = build_jag(m, n, A_off, A_idx, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag A");
@@ -3455,23 +3487,15 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       lap("upload panels A");
       HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
     }
-    if (transpose_ready) transpose_ready(user);
-    lap("wait for the transpose");
+    ts.worker.join();
+    lap("wait for the A^T side");
     if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
     TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
     TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
     TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
-    lat           = long_rows(n, at_offsets);
     ctx->at_nlong = (int)lat.size();
     if (ctx->at_nlong) TRY(upload_i32(ctx, &ctx->at_long, lat.data(), lat.size()));
-    if (DH.on) {
-      strip_transpose(DH, &DH, n, at_offsets, at_indices);
-      hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
-    }
-    if (one_gpu) extract_long_rows(n, at_offsets, at_indices, hT_off, hT_idx, hT_perm, nullptr, &LAT);
-    const bool hot_t     = !hT_off.empty();
-    const int32_t* T_off = hot_t ? hT_off.data() : at_offsets;
-    const int32_t* T_idx = hot_t ? hT_idx.data() : at_indices;
+    const bool hot_t = !hT_off.empty();
     ctx->hat_off = ctx->at_off, ctx->hat_idx = ctx->at_idx, ctx->hat_val = ctx->at_val;
     ctx->hot_nnz_at = (int64_t)T_off[n];
     if (hot_t) {
@@ -3488,30 +3512,23 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       if (timing) fprintf(stderr, "[cuopt_amd setup]   long rows of A^T: %d rows, %lld nonzeros in %d chunks\n", ctx->long_at.nrows, (long long)ctx->long_at.nent, ctx->long_at.nchunks);
     }
     if (DH.on || LAT.on) TRY(dev_alloc(ctx, &ctx->dense.add_n, (size_t)n));
-    std::vector<int32_t> rbt = build_row_blocks(n, T_off);
-    ctx->at_nb = (int)rbt.size() / 2 - 1;
-    TRY(upload_i32(ctx, &ctx->at_rb, rbt.data(), rbt.size()));
+    ctx->at_nb = (int)ts.rbt.size() / 2 - 1;
+    TRY(upload_i32(ctx, &ctx->at_rb, ts.rbt.data(), ts.rbt.size()));
     lap("upload A^T");
     if (try_jag) {
-      JagHost jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
-      lap("build_jag At");
-      TRY(upload_jag(ctx, &ctx->jat, jat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
+      TRY(upload_jag(ctx, &ctx->jat, ts.jat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload jag At");
     }
-    if (!ctx->jat.on && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
-      PbHost hb = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
-      lap("build_pb At");
-      if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", hb.why.c_str());
-      TRY(upload_pb(ctx, &ctx->pbat, hb));
+    if (ts.want_pb_layout) {
+      if (!ts.hbt.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", ts.hbt.why.c_str());
+      TRY(upload_pb(ctx, &ctx->pbat, ts.hbt));
       lap("upload pb At");
     }
-    if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->jat.on && !ctx->pbat.on && want_panels(n, m, T_off, T_idx, "A^T")) {
-      PanelHost hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
-      lap("build_panels At");
-      TRY(upload_panels(ctx, &ctx->pat, hat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
+    if (ts.hat.ok) {
+      TRY(upload_panels(ctx, &ctx->pat, ts.hat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload panels At");
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the worker's host arrays
   }
   {
     // small LPs: a whole batch of attempts inside one workgroup (CUOPT_AMD_SMALL=0 switches it off)
