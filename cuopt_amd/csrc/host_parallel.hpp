@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -17,6 +18,11 @@ namespace cuopt_amd {
 // threads the process may actually run on (cgroup / affinity aware), capped
 inline int host_threads(int cap = 16)
 {
+  static const int env_cap = [] {
+    const char* e = getenv("CUOPT_AMD_HOST_THREADS");  // (the set-up passes are memory bound: 16 is where they stop scaling on the boxes measured)
+    return e && atoi(e) > 0 ? atoi(e) : 0;
+  }();
+  if (env_cap) cap = env_cap;
   cpu_set_t set;
   int avail = (int)std::thread::hardware_concurrency();
   if (sched_getaffinity(0, sizeof(set), &set) == 0) avail = CPU_COUNT(&set);
