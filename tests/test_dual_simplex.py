@@ -211,3 +211,25 @@ def test_cancel_is_honoured_within_milliseconds():
     cancel.value = 1
     worker.join()
     assert time.time() - t0 < 0.5 and status.value == 9
+
+
+def test_dependent_columns_in_a_suggested_basis_are_replaced():
+    """a start point at which linearly dependent columns sit inside their bounds (here: duplicated columns, in the nucleus of the
+    factorisation and as singletons): the factorisation turns one of each dependent set away, slacks fill the holes, and the
+    solve ends at the optimum of the cold start"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    m, n = 40, 60
+    A = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.3)
+    A[:, 30:45] = A[:, 0:15]          # 15 duplicated columns
+    A[:, 45:50] = 2.0 * A[:, 15:20]   # 5 scaled copies
+    S = sp.csr_matrix(A)
+    x_in = rng.random(n) * 0.5 + 0.25
+    ax = A @ x_in
+    p = dict(m=m, n=n, offsets=S.indptr.astype(np.int32), indices=S.indices.astype(np.int32), values=S.data.astype(np.float64),
+             c=rng.standard_normal(n), lo=ax - 1.0, hi=ax + 1.0, lb=np.zeros(n), ub=np.ones(n))
+    cold = capi.dual_simplex(p)
+    assert cold["status"] == "Optimal"
+    warm = capi.dual_simplex(p, x0=x_in)  # every variable strictly inside (0, 1): 60 candidates for 40 rows, 20 of them dependent
+    assert warm["status"] == "Optimal" and warm["objective"] == pytest.approx(cold["objective"], rel=1e-9, abs=1e-9)
+    _check_vertex(p, warm, tol=1e-6)
