@@ -614,15 +614,13 @@ void cuoptamd_default_settings(cuoptamd_settings* s)
   s->relative_primal_tolerance_factor = s->relative_dual_tolerance_factor = -1.0;
 }
 
-void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
-                            const double* values, int32_t* t_offsets, int32_t* t_indices,
-                            double* t_values)
+// Plain parallel counting sort by column (small matrices, and the fallback of the blocked one below).  Thread t owns a
+// contiguous chunk of rows; because the chunks are ordered and every thread scans its rows in order, the row indices come out
+// ascending inside every column -- what cusparseCsr2cscEx2 produces for the reference (problem.cu:277-309) -- for any thread count.
+static void transpose_direct(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices, const double* values,
+                             int32_t* t_offsets, int32_t* t_indices, double* t_values, int T)
 {
-  // Parallel counting sort by column.  Thread t owns a contiguous chunk of rows; because the chunks are
-  // ordered and every thread scans its rows in order, the row indices come out ascending inside every
-  // column -- what cusparseCsr2cscEx2 produces for the reference (problem.cu:277-309) -- for any thread count.
   const int64_t nnz = offsets[m];
-  const int T       = nnz < (1 << 18) ? 1 : cuopt_amd::host_threads();
   std::vector<int32_t> row_cut(T + 1);
   for (int t = 0; t <= T; ++t) {  // chunks balanced by nonzeros
     const int64_t want = nnz * t / T;
@@ -669,6 +667,82 @@ void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const 
         t_values[q]     = values[k];
       }
   });
+}
+
+void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const int32_t* indices,
+                            const double* values, int32_t* t_offsets, int32_t* t_indices,
+                            double* t_values)
+{
+  const int64_t nnz = offsets[m];
+  const int T       = nnz < (1 << 18) ? 1 : cuopt_amd::host_threads();
+  // Large matrices: the direct scatter writes every entry to a random place of a 120 MB array (a cache line read and written
+  // per 12 bytes).  Blocked instead: (1) each thread deals its rows' entries into per-(thread, column block) buckets -- 256
+  // sequential write streams; (2) each column block is sorted by column from the buckets of all threads IN THREAD ORDER (rows
+  // stay ascending inside a column: the same output as the direct version, for any thread count) into its own contiguous piece
+  // of the result, which the cache holds.
+  constexpr int kBlocks = 256;
+  if (T == 1 || nnz < (1 << 22) || n < 16 * kBlocks || getenv("CUOPT_AMD_TRANSPOSE_DIRECT")) {
+    transpose_direct(m, n, offsets, indices, values, t_offsets, t_indices, t_values, T);
+    return;
+  }
+  const int32_t bw = (n + kBlocks - 1) / kBlocks;  // columns per block
+  std::vector<int32_t> row_cut(T + 1);
+  for (int t = 0; t <= T; ++t) {
+    const int64_t want = nnz * t / T;
+    row_cut[t]         = (int32_t)(std::lower_bound(offsets, offsets + m + 1, (int32_t)want) - offsets);
+  }
+  row_cut[0] = 0, row_cut[T] = m;
+  // bucket sizes: cnt[t][b]
+  std::vector<std::vector<int32_t>> cnt(T, std::vector<int32_t>(kBlocks + 1, 0));
+  cuopt_amd::parallel_tasks(T, [&](int t) {
+    int32_t* c = cnt[t].data();
+    for (int64_t k = offsets[row_cut[t]]; k < offsets[row_cut[t + 1]]; ++k) c[indices[k] / bw + 1] += 1;
+    for (int b = 0; b < kBlocks; ++b) c[b + 1] += c[b];  // -> the thread's bucket starts
+  });
+  struct Item {
+    int32_t col, row;
+    double val;
+  };
+  std::vector<cuopt_amd::PoolArray<Item>> bucket(T);
+  cuopt_amd::parallel_tasks(T, [&](int t) {
+    const int64_t mine = (int64_t)offsets[row_cut[t + 1]] - offsets[row_cut[t]];
+    bucket[t].reset((size_t)std::max<int64_t>(mine, 1));
+    Item* out = bucket[t].get();
+    std::vector<int32_t> at(cnt[t].begin(), cnt[t].end() - 1);
+    for (int32_t i = row_cut[t]; i < row_cut[t + 1]; ++i)
+      for (int32_t k = offsets[i]; k < offsets[i + 1]; ++k) out[at[indices[k] / bw]++] = Item{indices[k], i, values[k]};
+  });
+  // where each column block starts in the result
+  std::vector<int64_t> block_start(kBlocks + 1, 0);
+  for (int b = 0; b < kBlocks; ++b) {
+    int64_t s = 0;
+    for (int t = 0; t < T; ++t) s += cnt[t][b + 1] - cnt[t][b];
+    block_start[b + 1] = block_start[b] + s;
+  }
+  cuopt_amd::parallel_tasks(kBlocks, [&](int b) {
+    const int32_t j0 = (int32_t)std::min<int64_t>((int64_t)b * bw, n), j1 = (int32_t)std::min<int64_t>((int64_t)(b + 1) * bw, n);
+    std::vector<int32_t> cur((size_t)(j1 - j0) + 1, 0);
+    for (int t = 0; t < T; ++t) {
+      const Item* it = bucket[t].get();
+      for (int32_t e = cnt[t][b]; e < cnt[t][b + 1]; ++e) cur[it[e].col - j0 + 1] += 1;
+    }
+    int64_t pos = block_start[b];
+    for (int32_t j = j0; j < j1; ++j) {
+      const int32_t c = cur[j - j0 + 1];
+      t_offsets[j]    = (int32_t)pos;
+      cur[j - j0]     = (int32_t)pos;  // (cursor of column j; slot j - j0 + 1 is read before it is overwritten in the next round)
+      pos += c;
+    }
+    for (int t = 0; t < T; ++t) {
+      const Item* it = bucket[t].get();
+      for (int32_t e = cnt[t][b]; e < cnt[t][b + 1]; ++e) {
+        const int32_t q = cur[it[e].col - j0]++;
+        t_indices[q]    = it[e].row;
+        t_values[q]     = it[e].val;
+      }
+    }
+  });
+  t_offsets[n] = (int32_t)nnz;
 }
 
 void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32_t* bounds)

@@ -180,6 +180,26 @@ def test_csr_transpose_matches_scipy():
     assert np.all(np.diff(to) >= 0) and all(np.all(np.diff(ti[to[j]:to[j + 1]]) > 0) for j in range(30))
 
 
+def test_blocked_transposition_of_large_matrices_is_the_direct_one(monkeypatch):
+    """from 2^22 nonzeros on the host transposition deals the entries into column-block buckets first (cache-sized scatters):
+    the result is the direct counting sort's, entry for entry -- skewed columns, empty columns and rows included"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    m, n, nnz = 400_000, 300_000, 4_400_000
+    rows = rng.integers(0, m, size=nnz)
+    cols = np.where(rng.random(nnz) < 0.2, rng.integers(0, 50, size=nnz), rng.integers(1000, n - 1000, size=nnz))  # hot columns, empty ones
+    a = sp.csr_matrix((rng.standard_normal(nnz), (rows, cols)), shape=(m, n))  # (duplicates summed)
+    a.sort_indices()
+    blocked = capi.csr_transpose(m, n, a.indptr, a.indices, a.data)
+    monkeypatch.setenv("CUOPT_AMD_TRANSPOSE_DIRECT", "1")
+    direct = capi.csr_transpose(m, n, a.indptr, a.indices, a.data)
+    for x, y in zip(blocked, direct):
+        assert np.array_equal(x, y)
+    t = a.T.tocsr()
+    t.sort_indices()
+    assert np.array_equal(blocked[0], t.indptr) and np.array_equal(blocked[1], t.indices) and np.array_equal(blocked[2], t.data)
+
+
 def test_user_problem_file_round_trip(tmp_path):
     """CUOPT_USER_PROBLEM_FILE (solve.cu:586-589, test_lp_solver.py:675-700): cuOptSolve writes the problem as MPS before
     anything else happens (so this runs without a GPU: the solve itself then fails loudly); reading the file back
