@@ -897,17 +897,24 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   S.cancel = cancel;
   if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_PRICING")) S.steepest = std::strcmp(e, "dantzig") != 0;
   // columns of A
+  // (the other engine of a Concurrent solve may be done before this one has even copied the matrix: the flag is looked at here too)
+  auto cancelled = [&] { return cancel && *cancel; };
   S.cp.assign(n + 1, 0);
-  for (int64_t k = 0; k < nnz; ++k) S.cp[lp->indices[k] + 1]++;
+  for (int64_t k = 0; k < nnz; ++k) {
+    if ((k & 0xFFFFF) == 0 && cancelled()) { *status = 9; return 0; }
+    S.cp[lp->indices[k] + 1]++;
+  }
   for (int j = 0; j < n; ++j) S.cp[j + 1] += S.cp[j];
   S.ci.resize((size_t)nnz), S.cv.resize((size_t)nnz);
   {
     std::vector<int32_t> cur(S.cp.begin(), S.cp.end() - 1);
-    for (int i = 0; i < m; ++i)
+    for (int i = 0; i < m; ++i) {
+      if ((i & 0xFFFF) == 0 && cancelled()) { *status = 9; return 0; }
       for (int k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k) {
         const int q = cur[lp->indices[k]]++;
         S.ci[q] = i, S.cv[q] = lp->values[k];
       }
+    }
   }
   const double sense = lp->maximize ? -1.0 : 1.0;
   double scale = 1.0;
