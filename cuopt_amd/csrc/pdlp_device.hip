@@ -458,6 +458,11 @@ struct pdlpdev_ctx {
   int prof_used = 0;
   unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
   bool ticket_decision = false;
+  // The step decision off the critical path (CUOPT_AMD_FUSED_DECISION=1): see k_primal_decide
+  bool fused_decision   = false;
+  hipStream_t side      = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  pdlpdev_ctl* snap     = nullptr;  // two control-block snapshots, alternating by the attempt's place in its chunk
   int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
   // graphs
   int use_graph = 1;
@@ -1064,6 +1069,65 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   if (t != 0) return;
   apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
   *ctl = lc;
+}
+
+// The decision off the critical path (CUOPT_AMD_FUSED_DECISION=1).  Inside a chunk of attempts the primal step of attempt i + 1
+// does not wait for k_step_decision of attempt i: EVERY workgroup of this kernel forms that decision itself -- the same partials,
+// the same 1024-thread reduction, the same scalar rule, so the same bits in every workgroup and in k_step_decision, which runs
+// next to this kernel on a second stream (it alone writes the control block; the dual step waits for both).  The control block
+// this kernel starts from is the one the previous primal step ended with: it is handed on through two snapshot slots that
+// alternate by the attempt's place in the chunk (`in` is read by all workgroups, `out` written by one, never the same slot);
+// the first attempt of a chunk reads the control block itself (apply = 0: the chunk before ended with its decision applied).
+__global__ void __launch_bounds__(kDecisionThreads)
+k_primal_decide(int n, const pdlpdev_ctl* __restrict__ in, pdlpdev_ctl* __restrict__ out, int apply, const double* __restrict__ part_dy, int nb_dy,
+                const double* __restrict__ part_t, int nb_t, pdlpdev_step_params sp, double* __restrict__ x0, double* __restrict__ x1,
+                const double* __restrict__ aty0, const double* __restrict__ aty1, const double* __restrict__ c,
+                const double* __restrict__ lb, const double* __restrict__ ub, double* __restrict__ xbar, double* __restrict__ sumx)
+{
+  __shared__ double red[3 * 16];
+  __shared__ double pw[2];
+  __shared__ pdlpdev_ctl decided;
+  pdlpdev_ctl lc = *in;
+  const int t    = threadIdx.x;
+  if (apply && lc.error == 0 && lc.steps_taken < lc.target_steps) {  // (uniform) the attempt before this one ran: its decision
+    if (t >= kDecisionThreads - 2) {
+      const double knext = (double)(lc.k + 1) + 1.0;
+      pw[t - (kDecisionThreads - 2)] = pow(knext, t == kDecisionThreads - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int i = t; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
+#pragma unroll 4
+    for (int i = t; i < nb_t; i += kDecisionThreads) {
+      acc[1] += part_t[i];
+      acc[2] += part_t[nb_t + i];
+    }
+    block_sum_fast<3, kDecisionThreads / 64>(acc, red);
+    if (t == 0) {
+      apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
+      decided = lc;
+    }
+    __syncthreads();
+    lc = decided;
+  }
+  if (blockIdx.x == 0 && t == 0) *out = lc;
+  if (!(lc.error == 0 && lc.steps_taken < lc.target_steps)) return;
+  const int cur       = lc.cur;
+  const double tau    = lc.tau;
+  const double weight = lc.step_size;
+  const bool pend     = lc.pending_avg != 0;
+  const double* __restrict__ x   = cur ? x1 : x0;
+  double* __restrict__ xn        = cur ? x0 : x1;
+  const double* __restrict__ aty = cur ? aty1 : aty0;
+  for (int j = blockIdx.x * kDecisionThreads + t; j < n; j += gridDim.x * kDecisionThreads) {
+    const double xj       = x[j];
+    const double gradient = c[j] - aty[j];
+    double next           = xj - (tau * gradient);
+    next                  = dmax(dmin(next, ub[j]), lb[j]);
+    xn[j]                 = next;
+    xbar[j]               = next - xj + next;
+    if (pend) sumx[j] = sumx[j] + weight * xj;
+  }
 }
 
 // The decision in the TAIL of the A^T y' kernel (CUOPT_AMD_TICKET_DECISION=1, round-2 review item 8): every workgroup publishes
@@ -3617,6 +3681,14 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   {
     const char* tk = getenv("CUOPT_AMD_TICKET_DECISION");
     ctx->ticket_decision = tk && atoi(tk) == 1;
+    const char* fd = getenv("CUOPT_AMD_FUSED_DECISION");
+    if (fd && atoi(fd) == 1 && !ctx->ticket_decision) {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      TRY(dev_alloc(ctx, &ctx->snap, 2));
+      ctx->fused_decision = true;
+    }
   }
   lap("partial buffers");
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
@@ -3644,6 +3716,9 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
@@ -4562,6 +4637,35 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   return 0;
 }
 
+// single-GPU attempts with the decision next to the following primal step (k_primal_decide); captured into the chunk's graph as a
+// fork / join between the main stream and ctx->side
+static bool fused_decision_applies(const pdlpdev_ctx* ctx)
+{
+  return ctx->fused_decision && !ctx->comm && !ctx->owner && !ctx->rsag && !ctx->small_resident;
+}
+static int enqueue_chunk_fused(pdlpdev_ctx* ctx, int attempts)
+{
+  const int n = ctx->n;
+  const int g = std::max(1, std::min((n + kDecisionThreads - 1) / kDecisionThreads, 512));
+  for (int i = 0; i < attempts; ++i) {
+    if (i > 0) {
+      HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+      k_step_decision<<<1, kDecisionThreads, 0, ctx->side>>>(ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at, step_partials(ctx), nullptr, ctx->sp);
+      HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
+    k_primal_decide<<<g, kDecisionThreads, 0, ctx->stream>>>(n, i == 0 ? ctx->ctl : ctx->snap + (i & 1), ctx->snap + ((i + 1) & 1), i > 0 ? 1 : 0, ctx->part_a,
+                                                            dual_partials(ctx), ctx->part_at, step_partials(ctx), ctx->sp, ctx->x[0], ctx->x[1], ctx->aty[0],
+                                                            ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+    if (i > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    launch_a_dual(ctx);
+    launch_at_step(ctx);
+    if (i == attempts - 1) launch_decision(ctx);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
 {
   auto it = ctx->graphs.find(attempts);
@@ -4572,6 +4676,8 @@ static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
   hipGraph_t graph;
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
+  if (fused_decision_applies(ctx)) rc = enqueue_chunk_fused(ctx, attempts);
+  else
   for (int i = 0; i < attempts && rc == 0; ++i) rc = enqueue_attempt(ctx);
   hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
   if (rc != 0) return rc;
