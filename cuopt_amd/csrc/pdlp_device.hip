@@ -459,7 +459,8 @@ struct pdlpdev_ctx {
   unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
   bool ticket_decision = false;
   // The step decision off the critical path (CUOPT_AMD_FUSED_DECISION=1): see k_primal_decide
-  bool fused_decision   = false;
+  int fused_decision    = 0;  // 1: decision on a second stream next to the following primal step; 2: no decision kernel inside a chunk at all
+  pdlpdev_ctl* ctl_view = nullptr;  // the control block the loop kernels are launched with (ctl itself; inside a mode-2 chunk: a snapshot)
   hipStream_t side      = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   pdlpdev_ctl* snap     = nullptr;  // two control-block snapshots, alternating by the attempt's place in its chunk
@@ -1069,6 +1070,38 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   if (t != 0) return;
   apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
   *ctl = lc;
+}
+
+// the same decision from one control block into another (the end of a mode-2 chunk, below): `in` is the block the last primal step
+// of the chunk ended with, `out` the control block proper, which is written in every case (an inactive loop passes through)
+__global__ void __launch_bounds__(kDecisionThreads)
+k_step_decision_io(const pdlpdev_ctl* __restrict__ in, pdlpdev_ctl* __restrict__ out, const double* __restrict__ part_dy, int nb_dy,
+                   const double* __restrict__ part_t, int nb_t, pdlpdev_step_params sp)
+{
+  __shared__ double red[3 * 16];
+  __shared__ double pw[2];
+  pdlpdev_ctl lc = *in;
+  const int t    = threadIdx.x;
+  if (!(lc.error == 0 && lc.steps_taken < lc.target_steps)) {
+    if (t == 0) *out = lc;
+    return;
+  }
+  if (t >= kDecisionThreads - 2) {
+    const double knext = (double)(lc.k + 1) + 1.0;
+    pw[t - (kDecisionThreads - 2)] = pow(knext, t == kDecisionThreads - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
+  }
+  double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int i = t; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
+#pragma unroll 4
+  for (int i = t; i < nb_t; i += kDecisionThreads) {
+    acc[1] += part_t[i];
+    acc[2] += part_t[nb_t + i];
+  }
+  block_sum_fast<3, kDecisionThreads / 64>(acc, red);
+  if (t != 0) return;
+  apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
+  *out = lc;
 }
 
 // The decision off the critical path (CUOPT_AMD_FUSED_DECISION=1).  Inside a chunk of attempts the primal step of attempt i + 1
@@ -3098,8 +3131,8 @@ static int pb_products(pdlpdev_ctx* c, const pdlpdev_ctx::Pb& L, const double* v
   }
   const int grid   = (L.v.nwg + 7) & ~7;
   const size_t lds = sizeof(double) << L.v.panel_shift;
-  if (L.p_threads == 1024) launch_k(c, k_pb_products<1024>, grid, 1024, lds, L.v, c->ctl, v0, v1, mode, in_loop);
-  else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl, v0, v1, mode, in_loop);
+  if (L.p_threads == 1024) launch_k(c, k_pb_products<1024>, grid, 1024, lds, L.v, c->ctl_view, v0, v1, mode, in_loop);
+  else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl_view, v0, v1, mode, in_loop);
   return 0;
 }
 // ... and phase R with the epilogue of the call site
@@ -3682,12 +3715,13 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     const char* tk = getenv("CUOPT_AMD_TICKET_DECISION");
     ctx->ticket_decision = tk && atoi(tk) == 1;
     const char* fd = getenv("CUOPT_AMD_FUSED_DECISION");
-    if (fd && atoi(fd) == 1 && !ctx->ticket_decision) {
+    ctx->ctl_view = ctx->ctl;
+    if (fd && (atoi(fd) == 1 || atoi(fd) == 2) && !ctx->ticket_decision) {
       HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
       TRY(dev_alloc(ctx, &ctx->snap, 2));
-      ctx->fused_decision = true;
+      ctx->fused_decision = atoi(fd);
     }
   }
   lap("partial buffers");
@@ -4445,16 +4479,16 @@ static void dense_part(pdlpdev_ctx* ctx, int transpose, const double* v0, const 
   if (D.on) {
     DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
     if (transpose) {
-      launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
+      launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl_view, v0, v1, mode, in_loop, D.add_n);
     } else {
-      launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl, v0, v1, mode, in_loop);
-      launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl, in_loop, D.add_m);
+      launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl_view, v0, v1, mode, in_loop);
+      launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl_view, in_loop, D.add_m);
     }
   }
   if (L.on) {  // after the segments: a row that owns both starts from their share
     LongView W{L.row, L.row_ch, L.row_flag, L.ch_k0, L.ch_len, L.idx, L.val, L.part};
-    launch_k(ctx, k_long_rows, L.nchunks, kBlock, 0, W, ctx->ctl, v0, v1, mode, in_loop);
-    launch_k(ctx, k_long_rows_finish, (L.nrows + kBlock - 1) / kBlock, kBlock, 0, W, L.nrows, ctx->ctl, in_loop, transpose ? D.add_n : D.add_m);
+    launch_k(ctx, k_long_rows, L.nchunks, kBlock, 0, W, ctx->ctl_view, v0, v1, mode, in_loop);
+    launch_k(ctx, k_long_rows_finish, (L.nrows + kBlock - 1) / kBlock, kBlock, 0, W, L.nrows, ctx->ctl_view, in_loop, transpose ? D.add_n : D.add_m);
   }
 }
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
@@ -4465,26 +4499,26 @@ static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pde
   dense_part(ctx, 0, ctx->xbar, nullptr, 0, 1);
   if (ctx->pba.on) {
     (void)pb_products(ctx, ctx->pba, ctx->xbar, nullptr, 0, 1);
-    (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   } else if (ctx->ja.on)
-    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else if (ctx->pa.on)
-    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else
-    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
+    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
   dense_part(ctx, 1, ctx->y[0], ctx->y[1], 1, 1);
   if (ctx->pbat.on) {
     (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 1, 1);  // y' = the trial dual
-    (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl_view, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   } else if (ctx->jat.on)
-    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
-    launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else
-    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
+    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
 }
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
@@ -4641,12 +4675,31 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
 // fork / join between the main stream and ctx->side
 static bool fused_decision_applies(const pdlpdev_ctx* ctx)
 {
-  return ctx->fused_decision && !ctx->comm && !ctx->owner && !ctx->rsag && !ctx->small_resident;
+  return ctx->fused_decision != 0 && !ctx->comm && !ctx->owner && !ctx->rsag && !ctx->small_resident;
 }
 static int enqueue_chunk_fused(pdlpdev_ctx* ctx, int attempts)
 {
   const int n = ctx->n;
   const int g = std::max(1, std::min((n + kDecisionThreads - 1) / kDecisionThreads, 512));
+  if (ctx->fused_decision == 2) {
+    // no decision kernel inside the chunk: every kernel of attempt i reads the control block the primal step of attempt i ended
+    // with (its decision of attempt i - 1 included); one kernel at the end of the chunk brings the control block proper up to date
+    for (int i = 0; i < attempts; ++i) {
+      pdlpdev_ctl* out = ctx->snap + ((i + 1) & 1);
+      k_primal_decide<<<g, kDecisionThreads, 0, ctx->stream>>>(n, i == 0 ? ctx->ctl : ctx->snap + (i & 1), out, i > 0 ? 1 : 0, ctx->part_a, dual_partials(ctx),
+                                                              ctx->part_at, step_partials(ctx), ctx->sp, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c,
+                                                              ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+      ctx->ctl_view = out;
+      launch_a_dual(ctx);
+      launch_at_step(ctx);
+      ctx->ctl_view = ctx->ctl;
+      LAUNCH_CHECK();
+    }
+    k_step_decision_io<<<1, kDecisionThreads, 0, ctx->stream>>>(ctx->snap + (attempts & 1), ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at,
+                                                               step_partials(ctx), ctx->sp);
+    LAUNCH_CHECK();
+    return 0;
+  }
   for (int i = 0; i < attempts; ++i) {
     if (i > 0) {
       HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
