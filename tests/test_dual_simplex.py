@@ -33,7 +33,7 @@ def test_the_lp_relaxations_and_fixtures_of_the_goldens(golden_problems):
     for name, g in golden_problems.items():
         p, ref = g["problem"], g["meta"]["reference_dual_simplex"]
         if p["m"] > 500:
-            continue  # cod105 (1024 rows, 6.6 k pivots): below
+            continue  # cod105 (1024 rows, 4 k pivots): below
         r = capi.dual_simplex(p)
         if name == "mip-minrep_inf-relaxation":
             # 0.0210643 + 0.978936 > 1: the LP has a ray whose cost is -3e-6 per unit.  The reference's simplex calls it optimal
@@ -46,7 +46,8 @@ def test_the_lp_relaxations_and_fixtures_of_the_goldens(golden_problems):
 
 
 def test_the_largest_relaxation_of_the_goldens(golden_problems):
-    """cod105_max: 1024 x 1024, 57 k nonzeros, ~6.6 k pivots (the reference's simplex: 6347 pivots, 18.28571109; the optimum is 128/7)"""
+    """cod105_max: 1024 x 1024, 57 k nonzeros, ~4 k pivots under steepest-edge pricing (the reference's simplex: 6347 pivots, 18.28571109;
+    the optimum is 128/7)"""
     g = golden_problems["mip-cod105_max-relaxation"]
     r = capi.dual_simplex(g["problem"], time_limit=240)
     assert r["status"] == "Optimal"
