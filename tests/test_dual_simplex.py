@@ -234,3 +234,57 @@ def test_dependent_columns_in_a_suggested_basis_are_replaced():
     warm = capi.dual_simplex(p, x0=x_in)  # every variable strictly inside (0, 1): 60 candidates for 40 rows, 20 of them dependent
     assert warm["status"] == "Optimal" and warm["objective"] == pytest.approx(cold["objective"], rel=1e-9, abs=1e-9)
     _check_vertex(p, warm, tol=1e-6)
+
+
+def test_degenerate_classics():
+    """assignment and transportation problems (every vertex degenerate), a Klee-Minty cube and Beale's cycling example: the optimum
+    of HiGHS, cold and from a point near it"""
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(3)
+
+    def check(A, c, lo, hi, lb, ub):
+        A = sp.csr_matrix(A)
+        m, n = A.shape
+        p = dict(m=m, n=n, offsets=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32), values=A.data.astype(np.float64), c=np.asarray(c, float),
+                 lo=np.asarray(lo, float), hi=np.asarray(hi, float), lb=np.asarray(lb, float), ub=np.asarray(ub, float))
+        eq = p["lo"] == p["hi"]
+        kw = dict(bounds=list(zip(p["lb"], p["ub"])), method="highs")
+        if eq.any():
+            kw.update(A_eq=A[eq], b_eq=p["hi"][eq])
+        if (~eq).any():
+            kw.update(A_ub=A[~eq], b_ub=p["hi"][~eq])  # (the inequality rows below are all of the form a.x <= hi)
+        h = linprog(p["c"], **kw)
+        assert h.status == 0
+        for start in (None, h.x + 1e-4 * rng.standard_normal(n)):
+            r = capi.dual_simplex(p, time_limit=60, x0=start)
+            assert r["status"] == "Optimal" and r["objective"] == pytest.approx(h.fun, rel=1e-9, abs=1e-9)
+            _check_vertex(p, r, tol=1e-6)
+
+    for k in (12, 40):  # assignment
+        rows, cols = [], []
+        for i in range(k):
+            for j in range(k):
+                rows += [i, k + j]
+                cols += [i * k + j] * 2
+        A = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(2 * k, k * k))
+        check(A, rng.integers(1, 100, size=k * k), np.ones(2 * k), np.ones(2 * k), np.zeros(k * k), np.full(k * k, np.inf))
+    s, t = 15, 40  # transportation, integer supplies and demands
+    sup = rng.integers(5, 30, size=s).astype(float)
+    dem = rng.multinomial(int(sup.sum()), np.ones(t) / t).astype(float)
+    rows, cols = [], []
+    for i in range(s):
+        for j in range(t):
+            rows += [i, s + j]
+            cols += [i * t + j] * 2
+    A = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(s + t, s * t))
+    check(A, rng.integers(1, 50, size=s * t), np.concatenate([sup, dem]), np.concatenate([sup, dem]), np.zeros(s * t), np.full(s * t, np.inf))
+    n = 10  # Klee-Minty
+    K = np.zeros((n, n))
+    for i in range(n):
+        K[i, i] = 1.0
+        for j in range(i):
+            K[i, j] = 2.0 ** (i - j + 1)
+    check(K, -(2.0 ** (n - 1 - np.arange(n))), np.full(n, -np.inf), 5.0 ** (np.arange(n) + 1), np.zeros(n), np.full(n, np.inf))
+    B = np.array([[0.25, -8, -1, 9], [0.5, -12, -0.5, 3], [0, 0, 1, 0]])  # Beale
+    check(B, [-0.75, 20, -0.5, 6], np.full(3, -np.inf), [0.0, 0.0, 1.0], np.zeros(4), np.full(4, np.inf))
