@@ -31,7 +31,7 @@
 namespace {
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
-constexpr int kRefactorEvery = 100;
+constexpr int kRefactorEvery = 100;  // pivots between factorisations at the latest (250 from 20 000 rows on: a factorisation walks all of them)
 
 struct Cancelled {};  // thrown out of a factorisation when the other engine of a Concurrent solve has finished
 
@@ -57,6 +57,13 @@ struct Simplex {
   //      U by columns (pivot numbers above the diagonal), Ud the diagonal
   std::vector<int> Lp, Li, Up, Ui, pinv, prow;
   std::vector<double> Lx, Ux, Ud;
+  // the same factors by ROWS (pivot numbers), for the solves that start from a few nonzeros: LR[kk] = the entries L(prow[kk], k),
+  // k < kk; UR[j] = the entries U(j, k), k > j
+  std::vector<int> LRp, LRi, URp, URi;
+  std::vector<double> LRx, URx;
+  std::vector<int> vis, sstack, sptr, order;  // depth-first searches of the sparse solves
+  int vstamp       = 0;
+  int sparse_solve = 1;  // 0: always the dense loops (CUOPT_AMD_SIMPLEX_SOLVES=dense), 2: always the sparse ones, 1: by the size of the reach
   // product-form updates: position Er[e], pivot Ew[e], the other entries of the entering column in Ep/Ei/Ex
   std::vector<int> Ep, Ei, Er;
   std::vector<double> Ex, Ew;
@@ -363,9 +370,182 @@ struct Simplex {
     basic.swap(nb);
     std::fill(pos.begin(), pos.end(), -1);
     for (int q = 0; q < m; ++q) pos[basic[q]] = q;
+    // row-wise copies of L and U
+    LRp.assign(m + 1, 0), URp.assign(m + 1, 0);
+    for (int kk = 0; kk < m; ++kk)
+      for (int e = Lp[kk]; e < Lp[kk + 1]; ++e) LRp[pinv[Li[e]] + 1]++;
+    for (int kk = 0; kk < m; ++kk)
+      for (int e = Up[kk]; e < Up[kk + 1]; ++e) URp[Ui[e] + 1]++;
+    for (int i = 0; i < m; ++i) LRp[i + 1] += LRp[i], URp[i + 1] += URp[i];
+    LRi.resize(Li.size()), LRx.resize(Li.size()), URi.resize(Ui.size()), URx.resize(Ui.size());
+    {
+      std::vector<int> atl(LRp.begin(), LRp.end() - 1), atu(URp.begin(), URp.end() - 1);
+      for (int kk = 0; kk < m; ++kk) {
+        for (int e = Lp[kk]; e < Lp[kk + 1]; ++e) {
+          const int q2 = atl[pinv[Li[e]]]++;
+          LRi[q2] = kk, LRx[q2] = Lx[e];
+        }
+        for (int e = Up[kk]; e < Up[kk + 1]; ++e) {
+          const int q2 = atu[Ui[e]]++;
+          URi[q2] = kk, URx[q2] = Ux[e];
+        }
+      }
+    }
+    vis.assign(m, 0), vstamp = 0;
   }
+  // ---- solves that start from a few nonzeros (Gilbert-Peierls): a depth-first search over the factor's structure finds the pivots
+  // the right-hand side reaches, in topological order; only those are visited.  `from` (pivot numbers) seeds the search, `next(k, f)`
+  // calls f for every pivot k points to.  Gives up (returns false, nothing changed) once more than m / 6 pivots are reached:
+  // the dense loops are faster then.
+  template <class Next>
+  bool reach(const std::vector<int>& from, Next&& next)
+  {
+    order.clear();
+    if (sparse_solve == 0) return false;
+    const size_t limit = sparse_solve == 2 ? (size_t)m + 1 : (size_t)std::max(16, m / 6);
+    if (from.size() > limit) return false;
+    const int st = ++vstamp;
+    for (int start : from) {
+      if (vis[start] == st) continue;
+      vis[start] = st;
+      sstack.assign(1, start), sptr.assign(1, 0);
+      while (!sstack.empty()) {
+        const int k = sstack.back();
+        int child   = -1;
+        next(k, sptr.back(), child);  // advances the pointer, returns an unvisited neighbour in `child` or leaves it at -1
+        if (child >= 0) {
+          vis[child] = st;
+          sstack.push_back(child), sptr.push_back(0);
+        } else {
+          order.push_back(k);
+          sstack.pop_back(), sptr.pop_back();
+          if (order.size() > limit) return false;
+        }
+      }
+    }
+    return true;  // `order` is a postorder: reversed, every pivot comes before the ones it points to
+  }
+  // w = B^-1 a.  x holds a by ROW with its nonzero rows in xrows; on return x is all zero, w (by POSITION, zero on entry) holds the
+  // result with its nonzero positions in wlist.
+  void ftran(std::vector<double>& x, const std::vector<int>& xrows, std::vector<double>& w, std::vector<int>& wlist)
+  {
+    wlist.clear();
+    std::vector<int>& seed = seed_buf;
+    seed.clear();
+    for (int r : xrows) seed.push_back(pinv[r]);
+    bool sparse = reach(seed, [&](int k, int& ptr, int& child) {
+      while (Lp[k] + ptr < Lp[k + 1]) {
+        const int nx = pinv[Li[Lp[k] + ptr++]];
+        if (vis[nx] != vstamp) { child = nx; return; }
+      }
+    });
+    if (sparse) {
+      lorder.assign(order.rbegin(), order.rend());
+      // the pivots U reaches from there
+      sparse = reach(lorder, [&](int k, int& ptr, int& child) {
+        while (Up[k] + ptr < Up[k + 1]) {
+          const int nx = Ui[Up[k] + ptr++];
+          if (vis[nx] != vstamp) { child = nx; return; }
+        }
+      });
+    }
+    if (!sparse) {
+      ftran_dense(x, w);
+      std::fill(x.begin(), x.end(), 0.0);
+      for (int k = 0; k < m; ++k)
+        if (w[k] != 0.0) wlist.push_back(k);
+      return;
+    }
+    for (int k : lorder) {
+      const double xj = x[prow[k]];
+      if (xj == 0.0) continue;
+      for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
+    }
+    for (size_t t = order.size(); t-- > 0;) {
+      const int k = order[t];
+      double v    = x[prow[k]];
+      x[prow[k]]  = 0.0;
+      if (v == 0.0) continue;
+      v /= Ud[k];
+      for (int e = Up[k]; e < Up[k + 1]; ++e) x[prow[Ui[e]]] -= Ux[e] * v;
+      w[k] = v;
+      wlist.push_back(k);
+    }
+    const int ne = (int)Er.size();
+    if (ne) {
+      const int st = ++vstamp;
+      for (int k : wlist) vis[k] = st;
+      for (int e = 0; e < ne; ++e) {
+        const double xr = w[Er[e]];
+        if (xr == 0.0) continue;
+        const double t = xr / Ew[e];
+        for (int q = Ep[e]; q < Ep[e + 1]; ++q) {
+          const int i = Ei[q];
+          if (vis[i] != st) vis[i] = st, wlist.push_back(i);
+          w[i] -= Ex[q] * t;
+        }
+        w[Er[e]] = t;
+      }
+    }
+  }
+  // rho = B^-T t.  t by POSITION with its nonzero positions in tlist; on return t is all zero, rho (by ROW, zero on entry) holds the
+  // result with its nonzero rows in rlist.
+  void btran(std::vector<double>& t, std::vector<int>& tlist, std::vector<double>& rho, std::vector<int>& rlist)
+  {
+    rlist.clear();
+    if (!Er.empty()) {
+      const int st = ++vstamp;
+      for (int k : tlist) vis[k] = st;
+      for (int e = (int)Er.size() - 1; e >= 0; --e) {
+        double sum = t[Er[e]];
+        for (int q = Ep[e]; q < Ep[e + 1]; ++q) sum -= t[Ei[q]] * Ex[q];
+        sum /= Ew[e];
+        if (sum != 0.0 && vis[Er[e]] != st) vis[Er[e]] = st, tlist.push_back(Er[e]);
+        t[Er[e]] = sum;
+      }
+    }
+    bool sparse = reach(tlist, [&](int k, int& ptr, int& child) {
+      while (URp[k] + ptr < URp[k + 1]) {
+        const int nx = URi[URp[k] + ptr++];
+        if (vis[nx] != vstamp) { child = nx; return; }
+      }
+    });
+    if (sparse) {
+      lorder.assign(order.rbegin(), order.rend());
+      sparse = reach(lorder, [&](int k, int& ptr, int& child) {
+        while (LRp[k] + ptr < LRp[k + 1]) {
+          const int nx = LRi[LRp[k] + ptr++];
+          if (vis[nx] != vstamp) { child = nx; return; }
+        }
+      });
+    }
+    if (!sparse) {
+      btran_dense_core(t, rho);
+      std::fill(t.begin(), t.end(), 0.0);
+      for (int i = 0; i < m; ++i)
+        if (rho[i] != 0.0) rlist.push_back(i);
+      return;
+    }
+    for (int j : lorder) {  // U^T s = t, by the rows of U
+      double sv = t[j];
+      if (sv == 0.0) continue;
+      sv /= Ud[j];
+      t[j] = sv;
+      for (int e = URp[j]; e < URp[j + 1]; ++e) t[URi[e]] -= URx[e] * sv;
+    }
+    for (size_t q = order.size(); q-- > 0;) {  // L^T v = s, by the rows of L
+      const int kk   = order[q];
+      const double v = t[kk];
+      t[kk]          = 0.0;
+      if (v == 0.0) continue;
+      rho[prow[kk]] = v;
+      rlist.push_back(prow[kk]);
+      for (int e = LRp[kk]; e < LRp[kk + 1]; ++e) t[LRi[e]] -= LRx[e] * v;
+    }
+  }
+  std::vector<int> seed_buf, lorder;
   // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
-  void ftran(std::vector<double>& x, std::vector<double>& w) const
+  void ftran_dense(std::vector<double>& x, std::vector<double>& w) const
   {
     for (int k = 0; k < m; ++k) {
       const double xj = x[prow[k]];
@@ -390,13 +570,18 @@ struct Simplex {
     }
   }
   // rho = B^-T t : `t` by POSITION (destroyed), rho by ROW
-  void btran(std::vector<double>& t, std::vector<double>& rho) const
+  // (the update file first, then the factors)
+  void btran_dense(std::vector<double>& t, std::vector<double>& rho) const
   {
     for (int e = (int)Er.size() - 1; e >= 0; --e) {
       double s = t[Er[e]];
       for (int q = Ep[e]; q < Ep[e + 1]; ++q) s -= t[Ei[q]] * Ex[q];
       t[Er[e]] = s / Ew[e];
     }
+    btran_dense_core(t, rho);
+  }
+  void btran_dense_core(std::vector<double>& t, std::vector<double>& rho) const
+  {
     for (int k = 0; k < m; ++k) {
       double s = t[k];
       for (int e = Up[k]; e < Up[k + 1]; ++e) s -= Ux[e] * t[Ui[e]];
@@ -408,9 +593,9 @@ struct Simplex {
       rho[prow[k]] = s;
     }
   }
-  void push_eta(int r, const std::vector<double>& w)
+  void push_eta(int r, const std::vector<double>& w, const std::vector<int>& wlist)
   {
-    for (int i = 0; i < m; ++i)
+    for (int i : wlist)
       if (i != r && w[i] != 0.0) Ei.push_back(i), Ex.push_back(w[i]);
     Ep.push_back((int)Ei.size()), Er.push_back(r), Ew.push_back(w[r]);
   }
@@ -420,7 +605,7 @@ struct Simplex {
     std::vector<double> a(m), w(m), x(m), t(m), rho(m, 0.0);
     for (int i = 0; i < m; ++i) a[i] = std::sin(1.0 + i), t[i] = std::cos(2.0 + i);
     x = a;
-    ftran(x, w);
+    ftran_dense(x, w);
     std::vector<double> res(a);
     for (int k = 0; k < m; ++k) {
       const int j = basic[k];
@@ -431,7 +616,7 @@ struct Simplex {
     double e1 = 0.0, e2 = 0.0;
     for (int i = 0; i < m; ++i) e1 = std::max(e1, std::fabs(res[i]));
     x = t;
-    btran(x, rho);
+    btran_dense(x, rho);
     for (int k = 0; k < m; ++k) e2 = std::max(e2, std::fabs(col_dot(rho.data(), basic[k]) - t[k]));
     std::fprintf(stderr, "[simplex] %s: residual of B w = a %.3g, of B^T rho = t %.3g\n", where, e1, e2);
   }
@@ -447,10 +632,10 @@ struct Simplex {
       else
         for (int k = cp[j]; k < cp[j + 1]; ++k) rhs[ci[k]] -= cv[k] * v;
     }
-    ftran(rhs, w);
+    ftran_dense(rhs, w);
     for (int k = 0; k < m; ++k) z[basic[k]] = w[k];
     for (int k = 0; k < m; ++k) w[k] = g[basic[k]];
-    btran(w, y);
+    btran_dense(w, y);
     for (int j = 0; j < N; ++j) d[j] = pos[j] >= 0 ? 0.0 : g[j] - col_dot(y.data(), j);
   }
   // every nonbasic variable onto the bound its reduced cost points to (boxed: always possible); true when something moved
@@ -519,8 +704,10 @@ struct Lap {
 int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
 {
   const int m = S.m, n = S.n, N = S.N;
-  std::vector<double> alpha(N, 0.0), w(m), rho(m), tvec(m), tau(m), col(m);
-  std::vector<int> touched, astamp(N, -1);
+  // (w, rho, tau, tvec, col: all zero between pivots -- the solves hand their right-hand sides back zeroed, the results are cleared
+  //  through their index lists)
+  std::vector<double> alpha(N, 0.0), w(m, 0.0), rho(m, 0.0), tvec(m, 0.0), tau(m, 0.0), col(m, 0.0);
+  std::vector<int> touched, astamp(N, -1), wlist, rlist, taulist, tlist, clist;
   std::vector<int> passed(m, 0);  // iteration (+1) at which the position was passed over as "violated by rounding only"
   const double tol_d = 1e-9;
   int since_refactor = 0, sweep = 0;
@@ -537,8 +724,18 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     const double inf = std::max(lo, up);
     return inf > 1e-7 * (1.0 + std::fabs(lo > up ? S.L[b] : S.U[b])) ? inf : 0.0;
   };
+  // ... and the positions that ARE infeasible, as a list with lazy removal: the choice walks the list, not all m positions
+  std::vector<int> cand;
+  std::vector<char> incand(m, 0);
+  auto note = [&](int i) {
+    if (pinf[i] != 0.0 && !incand[i]) incand[i] = 1, cand.push_back(i);
+  };
   auto gather = [&] {
-    for (int i = 0; i < m; ++i) pinf[i] = infeasibility(i), bw[i] = S.beta[S.basic[i]];
+    cand.clear();
+    for (int i = 0; i < m; ++i) {
+      pinf[i] = infeasibility(i), bw[i] = S.beta[S.basic[i]], incand[i] = 0;
+      note(i);
+    }
   };
   auto rebuild = [&] {
     for (int i = 0; i < m; ++i) S.beta[S.basic[i]] = bw[i];
@@ -558,11 +755,17 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     double worst = 0.0, worst_inf = 0.0;
     { Lap lap(S, 0);
     const int skip = S.iterations + 1;
-    for (int i = 0; i < m; ++i) {
+    for (size_t c = 0; c < cand.size();) {
+      const int i      = cand[c];
       const double inf = pinf[i];
-      if (inf == 0.0 || passed[i] == skip) continue;
+      if (inf == 0.0) {  // feasible by now: out of the list
+        incand[i] = 0, cand[c] = cand.back(), cand.pop_back();
+        continue;
+      }
+      ++c;
+      if (passed[i] == skip) continue;
       const double score = S.steepest ? inf * inf / bw[i] : inf;
-      if (score > worst) worst = score, worst_inf = inf, r = i;
+      if (score > worst || (score == worst && i < r)) worst = score, worst_inf = inf, r = i;  // (ties: the lowest position, whatever the list's order)
     }
     }
     if (r < 0) {
@@ -574,14 +777,15 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     const double delta = to_low ? S.L[p] - S.z[p] : S.U[p] - S.z[p];  // change the leaving variable needs
     const double sigma = to_low ? 1.0 : -1.0;
     // row r of the inverse, then of the tableau (from the rows of A that row touches)
-    std::fill(tvec.begin(), tvec.end(), 0.0);
+    for (int i : rlist) rho[i] = 0.0;
     tvec[r] = 1.0;
-    { Lap lap(S, 1); S.btran(tvec, rho); }
+    tlist.assign(1, r);
+    { Lap lap(S, 1); S.btran(tvec, tlist, rho, rlist); }
     ++sweep;
     touched.clear();
     double amax = 0.0;
     { Lap lap(S, 2);
-    for (int i = 0; i < m; ++i) {
+    for (int i : rlist) {
       const double ri = rho[i];
       if (std::fabs(ri) < 1e-14) continue;
       for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) {
@@ -631,11 +835,12 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     }
     if (q < 0) return 7;
     // entering column
-    std::fill(col.begin(), col.end(), 0.0);
-    if (q >= n) col[q - n] = -1.0;
+    for (int i : wlist) w[i] = 0.0;
+    clist.clear();
+    if (q >= n) col[q - n] = -1.0, clist.push_back(q - n);
     else
-      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k];
-    { Lap lap(S, 4); S.ftran(col, w); }
+      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k], clist.push_back(S.ci[k]);
+    { Lap lap(S, 4); S.ftran(col, clist, w, wlist); }
     if (std::fabs(w[r]) < 1e-11 || std::fabs(w[r] - alpha[q]) > 1e-6 * (1.0 + std::fabs(alpha[q]))) {
       // the factorisation has drifted: rebuild it and look again
       if (since_refactor == 0) return 7;
@@ -646,12 +851,13 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     if (S.steepest) {
       Lap lap(S, 5);
       double br = 0.0;
-      for (int i = 0; i < m; ++i) br += rho[i] * rho[i];
+      for (int i : rlist) br += rho[i] * rho[i];
       S.beta[p] = br;  // exact, whatever the updates had made of it
-      col       = rho;
-      S.ftran(col, tau);
+      for (int i : taulist) tau[i] = 0.0;
+      for (int i : rlist) col[i] = rho[i];
+      S.ftran(col, rlist, tau, taulist);
       const double wr = w[r];
-      for (int i = 0; i < m; ++i) {
+      for (int i : wlist) {
         if (i == r || w[i] == 0.0) continue;
         const double kap = w[i] / wr;
         bw[i]            = std::max(bw[i] + kap * (kap * br - 2.0 * tau[i]), 1e-4);
@@ -671,11 +877,11 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     S.z[q] += step;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_eta(r, w);
+    S.push_eta(r, w, wlist);
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
-    for (int i = 0; i < m; ++i)
-      if (w[i] != 0.0 && i != r) S.z[S.basic[i]] -= w[i] * step, pinf[i] = infeasibility(i);
-    pinf[r] = infeasibility(r);
+    for (int i : wlist)
+      if (w[i] != 0.0 && i != r) S.z[S.basic[i]] -= w[i] * step, pinf[i] = infeasibility(i), note(i);
+    pinf[r] = infeasibility(r), note(r);
     S.iterations += 1;
     // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
     // after kRefactorEvery pivots
@@ -684,7 +890,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     // (the factorisation's count is of entries touched; its depth-first searches and pivot choices make an entry cost ~8 times
     // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s)
     const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
-    if (++since_refactor >= kRefactorEvery || extra_ops >= rebuild_ops) rebuild();
+    if (++since_refactor >= (m >= 20000 ? 250 : kRefactorEvery) || extra_ops >= rebuild_ops) rebuild();
   }
 }
 
@@ -711,8 +917,8 @@ void start_from_slacks(Simplex& S)
 int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
 {
   const int m = S.m, n = S.n, N = S.N;
-  std::vector<double> alpha(N, 0.0), w(m), rho(m), tvec(m), col(m), gamma(N, 2.0);
-  std::vector<int> touched, astamp(N, -1);
+  std::vector<double> alpha(N, 0.0), w(m, 0.0), rho(m, 0.0), tvec(m, 0.0), col(m, 0.0), gamma(N, 2.0);
+  std::vector<int> touched, astamp(N, -1), wlist, rlist, tlist, clist;
   for (int j = 0; j < n; ++j) {
     double s = 1.0;
     for (int k = S.cp[j]; k < S.cp[j + 1]; ++k) s += S.cv[k] * S.cv[k];
@@ -737,17 +943,18 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     }
     if (q < 0) return 1;
     const double dir = S.atU[q] ? -1.0 : 1.0;  // the entering variable moves up from its lower bound, down from its upper one
-    std::fill(col.begin(), col.end(), 0.0);
-    if (q >= n) col[q - n] = -1.0;
+    for (int i : wlist) w[i] = 0.0;
+    clist.clear();
+    if (q >= n) col[q - n] = -1.0, clist.push_back(q - n);
     else
-      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k];
-    S.ftran(col, w);
+      for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k], clist.push_back(S.ci[k]);
+    S.ftran(col, clist, w, wlist);
     // ratio test: basic i moves by -dir t w_i
     double wmax = 0.0;
-    for (int i = 0; i < m; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+    for (int i : wlist) wmax = std::max(wmax, std::fabs(w[i]));
     const double ptol = std::max(1e-11, 1e-9 * wmax);
     double tmax = S.U[q] - S.L[q];  // its own other bound: a flip
-    for (int i = 0; i < m; ++i) {
+    for (int i : wlist) {
       const double a = dir * w[i];
       if (std::fabs(a) <= ptol) continue;
       const int b      = S.basic[i];
@@ -757,7 +964,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     }
     int r        = -1;
     double apick = 0.0, step = S.U[q] - S.L[q];
-    for (int i = 0; i < m; ++i) {
+    for (int i : wlist) {
       const double a = dir * w[i];
       if (std::fabs(a) <= ptol) continue;
       const int b      = S.basic[i];
@@ -766,7 +973,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     }
     if (r < 0 || step >= S.U[q] - S.L[q]) {  // the entering variable reaches its other bound first: no basis change
       step = S.U[q] - S.L[q];
-      for (int i = 0; i < m; ++i)
+      for (int i : wlist)
         if (w[i] != 0.0) S.z[S.basic[i]] -= dir * step * w[i];
       S.atU[q] = !S.atU[q];
       S.z[q]   = S.atU[q] ? S.U[q] : S.L[q];
@@ -777,12 +984,13 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     if (stalled > 50 * (m + 100)) return 7;  // (degenerate pivots only, for a long time)
     const int p = S.basic[r];
     // pivot row for the reduced costs
-    std::fill(tvec.begin(), tvec.end(), 0.0);
+    for (int i : rlist) rho[i] = 0.0;
     tvec[r] = 1.0;
-    S.btran(tvec, rho);
+    tlist.assign(1, r);
+    S.btran(tvec, tlist, rho, rlist);
     ++sweep;
     touched.clear();
-    for (int i = 0; i < m; ++i) {
+    for (int i : rlist) {
       const double ri = rho[i];
       if (std::fabs(ri) < 1e-14) continue;
       for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) {
@@ -805,13 +1013,13 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
       if (alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
     S.d[q] = 0.0;
     S.d[p] = -theta;
-    for (int i = 0; i < m; ++i)
+    for (int i : wlist)
       if (w[i] != 0.0) S.z[S.basic[i]] -= dir * step * w[i];
     S.z[q] += dir * step;
     const bool to_low = dir * w[r] > 0.0;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_eta(r, w);
+    S.push_eta(r, w, wlist);
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
     S.iterations += 1;
     extra_ops += 2 * (int64_t)S.Ei.size();
@@ -914,6 +1122,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   S.rp = lp->offsets, S.rj = lp->indices, S.rv = lp->values;
   S.cancel = cancel;
   if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_PRICING")) S.steepest = std::strcmp(e, "dantzig") != 0;
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_SOLVES")) S.sparse_solve = std::strcmp(e, "dense") == 0 ? 0 : std::strcmp(e, "sparse") == 0 ? 2 : 1;
   // columns of A
   // (the other engine of a Concurrent solve may be done before this one has even copied the matrix: the flag is looked at here too)
   auto cancelled = [&] { return cancel && *cancel; };
