@@ -288,3 +288,21 @@ def test_degenerate_classics():
     check(K, -(2.0 ** (n - 1 - np.arange(n))), np.full(n, -np.inf), 5.0 ** (np.arange(n) + 1), np.zeros(n), np.full(n, np.inf))
     B = np.array([[0.25, -8, -1, 9], [0.5, -12, -0.5, 3], [0, 0, 1, 0]])  # Beale
     check(B, [-0.75, 20, -0.5, 6], np.full(3, -np.inf), [0.0, 0.0, 1.0], np.zeros(4), np.full(4, np.inf))
+
+
+def test_sparse_and_dense_solves_walk_the_same_pivots(monkeypatch):
+    """FTRAN / BTRAN through the depth-first reach (from the right-hand side's nonzeros) and through the dense loops are the same
+    arithmetic on the entries that are not zero: the same pivots, the same vertex -- cold, and through the primal simplex of a
+    start from a point"""
+    from cuopt_amd import synthetic
+    p = synthetic.generate(3000, 2400, 3, seed=5)
+    runs = {}
+    for mode in ("dense", "sparse", "auto"):
+        monkeypatch.setenv("CUOPT_AMD_SIMPLEX_SOLVES", mode)
+        cold = capi.dual_simplex(p, time_limit=120)
+        assert cold["status"] == "Optimal" and cold["objective"] == pytest.approx(p["objective_star"], rel=1e-8)
+        warm = capi.dual_simplex(p, time_limit=120, x0=cold["x"] * (1 + 1e-3 * np.cos(np.arange(p["n"]))))
+        assert warm["status"] == "Optimal"
+        runs[mode] = (cold["iterations"], cold["objective"], warm["iterations"], warm["objective"])
+    assert runs["dense"][0] == runs["sparse"][0] == runs["auto"][0] and runs["dense"][2] == runs["sparse"][2] == runs["auto"][2]
+    assert runs["dense"][1] == pytest.approx(runs["sparse"][1], rel=1e-12) and runs["dense"][3] == pytest.approx(runs["sparse"][3], rel=1e-12)
