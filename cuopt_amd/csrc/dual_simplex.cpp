@@ -7,8 +7,9 @@
 // The basis is kept as a SPARSE LU factorisation (singleton columns and rows peeled off, the nucleus right-looking with
 // Markowitz' pivot choice under threshold partial pivoting; a dependent column is replaced by the slack of a row that found
 // no pivot) with product-form updates behind it, refactorised when the update file has cost as much as a factorisation, at
-// the latest every 100 pivots.  The pivot row is formed from the ROWS of A
-// (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
+// the latest every 100 pivots (250 on large bases).  FTRAN / BTRAN start from the right-hand side's nonzeros (a depth-first
+// reach over the factors, kept by columns and by rows) and fall back to dense loops when the reach is large; the pivot row is
+// formed from the ROWS of A (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
 // dual feasible once every nonbasic variable sits on the bound its reduced cost points to -- which is also what lets a
 // solve start from a basis guessed from another engine's solution (cuoptamd_dual_simplex_from: the crossover of a PDLP
 // solution -- a primal simplex, below, takes that basis to optimality first).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
