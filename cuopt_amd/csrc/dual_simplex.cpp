@@ -96,6 +96,7 @@ struct Simplex {
     //  3. what is left (the nucleus): right-looking with Markowitz' pivot choice, below.
     // (nprio >= 0: only the first nprio candidates are ordered this way; the others follow them, shortest first, so that of a
     // dependent set it is never one of the first nprio that is turned away because of one of the others)
+    const auto tf0 = std::chrono::steady_clock::now();
     const int nc = nprio >= 0 ? std::min(nprio, (int)cand.size()) : (int)cand.size();
     std::vector<int> rstart(m + 1, 0), ccount(nc, 0), rcount(m, 0);
     auto each_entry = [&](int c, auto&& f) {
@@ -153,6 +154,7 @@ struct Simplex {
         if (ractive[i2] && --rcount[i2] == 1) queue.push_back(i2);
       });
     }
+    const auto tf1 = std::chrono::steady_clock::now();
     std::vector<int> nuc, tail;  // the nucleus (candidate numbers) and the candidates behind the first nprio
     for (int c = 0; c < nc; ++c)
       if (!cdone[c]) nuc.push_back(c);
@@ -229,6 +231,12 @@ struct Simplex {
         if (rejected) rejected->push_back(j);
         return;
       }
+      if (j >= n && pinv[j - n] < 0) {  // a slack whose row is free (most of a basis): -1 on the diagonal, nothing else
+        Ud.push_back(-1.0), Up.push_back((int)Ui.size()), Lp.push_back((int)Li.size());
+        pinv[j - n] = k, prow[k] = j - n, nb.push_back(j), ++k;
+        ++stamp;
+        return;
+      }
       const double colmax = eliminate(j);
       double best = 0.0;
       for (int i : pattern)
@@ -253,7 +261,9 @@ struct Simplex {
       for (int i : pattern) wx[i] = 0.0;
       pinv[piv] = k, prow[k] = piv, nb.push_back(j), ++k;
     };
+    const auto tf2 = std::chrono::steady_clock::now();
     for (const auto& oc : order) left_looking(cand[oc.first], oc.second);
+    const auto tf3 = std::chrono::steady_clock::now();
     // ---- the nucleus: right-looking elimination with Markowitz' pivot choice.  Every nucleus column is first taken through the
     // triangular part (its U entries there), what is left of it lives in `cols` (local row numbers); a pivot is the entry with the
     // smallest (row count - 1)(column count - 1) among the entries within a factor 10 of their column's largest, looked for in
@@ -371,6 +381,7 @@ struct Simplex {
     basic.swap(nb);
     std::fill(pos.begin(), pos.end(), -1);
     for (int q = 0; q < m; ++q) pos[basic[q]] = q;
+    const auto tf4 = std::chrono::steady_clock::now();
     // row-wise copies of L and U
     LRp.assign(m + 1, 0), URp.assign(m + 1, 0);
     for (int kk = 0; kk < m; ++kk)
@@ -393,7 +404,12 @@ struct Simplex {
       }
     }
     vis.assign(m, 0), vstamp = 0;
+    if (debug) {
+      auto ms = [](auto a, auto b) { return 1e3 * std::chrono::duration<double>(b - a).count(); };
+      fsec[0] += ms(tf0, tf1), fsec[1] += ms(tf1, tf2), fsec[2] += ms(tf2, tf3), fsec[3] += ms(tf3, tf4), fsec[4] += ms(tf4, std::chrono::steady_clock::now());
+    }
   }
+  double fsec[5] = {0, 0, 0, 0, 0};  // debug, ms: ordering / set-up / triangular part / nucleus + tail / row-wise copies
   // ---- solves that start from a few nonzeros (Gilbert-Peierls): a depth-first search over the factor's structure finds the pivots
   // the right-hand side reaches, in topological order; only those are visited.  `from` (pivot numbers) seeds the search, `next(k, f)`
   // calls f for every pivot k points to.  Gives up (returns false, nothing changed) once more than m / 6 pivots are reached:
@@ -545,6 +561,7 @@ struct Simplex {
     }
   }
   std::vector<int> seed_buf, lorder;
+  bool debug = false;
   // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
   void ftran_dense(std::vector<double>& x, std::vector<double>& w) const
   {
@@ -688,7 +705,6 @@ struct Simplex {
     }
     recompute();
   }
-  bool debug   = false;
   int rebuilds = 0;
   int64_t ops_factor = 0, ops_solve = 0;
   double tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, updates, rebuild}
@@ -1164,6 +1180,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   S.debug = debug;
   int total_iterations = 0;
   auto print_seconds = [&] {
+    std::fprintf(stderr, "[simplex] factorisation ms: ordering %.0f, set-up %.0f, triangular part %.0f, nucleus %.0f, row-wise copies %.0f\n", S.fsec[0], S.fsec[1], S.fsec[2], S.fsec[3], S.fsec[4]);
     std::fprintf(stderr, "[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ftran %.2f, weights %.2f, rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[4], S.tsec[5], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
   };
   for (int attempt = 0; attempt < 2; ++attempt) {
