@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
+#include "host_parallel.hpp"
 #include "mps_reader.hpp"
 
 namespace {
@@ -711,12 +712,12 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     // Concurrent / DualSimplex return the simplex VERTEX on small LPs (the CPU simplex wins the race there:
     // c_api_test.c:761-873 expects 32.0 +- 1e-3 at default settings), so for such requests on small LPs (<= 1e5
     // nonzeros, microseconds per iteration) PDLP aims at simplex-grade tolerances (1e-8) -- the "simplex-grade
-    // emulation", switched off by CUOPT_AMD_SIMPLEX_GRADE=0 or the integer parameter "amd_simplex_grade" = 0.
+    // emulation", switched off by the integer parameter "amd_simplex_grade" = 0.
     // The caller's own tolerances stay in force as the ACCEPTANCE set (cuoptamd_settings::accept_tolerance): the
     // first iterate that meets them is kept and returned as Optimal if the tight solve runs out of the caller's
     // iteration / time limit or of the emulation's budget, so limits behave as in the reference's Concurrent mode.
     const bool other_method  = s->method != CUOPT_METHOD_PDLP;
-    const bool grade_on      = (s->simplex_grade >= 0 ? s->simplex_grade : env_int("CUOPT_AMD_SIMPLEX_GRADE", 1)) != 0;
+    const bool grade_on      = (s->simplex_grade >= 0 ? s->simplex_grade : (int)cuopt_amd::tune_int("simplex_grade", 1)) != 0;
     cuoptamd_lp lp{p->m, p->n, p->offsets.data(), p->indices.data(), p->values.data(), p->c.data(),
                    p->lo.data(), p->hi.data(), p->lb.data(), p->ub.data(), p->maximize ? 1 : 0,
                    p->objective_offset};
@@ -824,7 +825,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     if (engine_answered) {
       take_simplex();
     } else if (gpus > 1) {
-      const int soft = env_int("CUOPT_AMD_SOFT_COMMUNICATOR", 0);
+      const int soft = (int)cuopt_amd::tune_int("soft_communicator", 0)  /* tests: ranks = contexts on one device */;
       const int rc   = cuoptamd_solve_sharded(&lp, &hyper, &st, gpus, soft, &res, sol->x.data(), sol->y.data(), sol->rc.data());
       if (rc != 0) {
         const std::string msg = cuoptamd_last_error();

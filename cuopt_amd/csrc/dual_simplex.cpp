@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
+#include "host_parallel.hpp"
 
 namespace {
 
@@ -837,7 +838,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
         rebuild();
         continue;
       }
-      if (std::getenv("CUOPT_AMD_SIMPLEX_DEBUG"))
+      if (S.debug)
         std::fprintf(stderr, "[simplex] infeasible position %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol);
       return 2;
     }
@@ -1138,8 +1139,11 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   S.m = m, S.n = n, S.N = n + m;
   S.rp = lp->offsets, S.rj = lp->indices, S.rv = lp->values;
   S.cancel = cancel;
-  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_PRICING")) S.steepest = std::strcmp(e, "dantzig") != 0;
-  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_SOLVES")) S.sparse_solve = std::strcmp(e, "dense") == 0 ? 0 : std::strcmp(e, "sparse") == 0 ? 2 : 1;
+  {  // CUOPT_AMD_TUNE="simplex_pricing=dantzig|steepest,simplex_solves=dense|sparse|auto" (tests compare the variants' pivots)
+    std::string e;
+    if (cuopt_amd::tune_get("simplex_pricing", &e)) S.steepest = e != "dantzig";
+    if (cuopt_amd::tune_get("simplex_solves", &e)) S.sparse_solve = e == "dense" ? 0 : e == "sparse" ? 2 : 1;
+  }
   // columns of A
   // (the other engine of a Concurrent solve may be done before this one has even copied the matrix: the flag is looked at here too)
   auto cancelled = [&] { return cancel && *cancel; };
@@ -1176,7 +1180,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   std::vector<int> first_pos;
   if (time_limit <= 0.0 || !std::isfinite(time_limit)) time_limit = 1e30;
   if (iteration_limit <= 0) iteration_limit = std::numeric_limits<int32_t>::max();
-  const bool debug = std::getenv("CUOPT_AMD_SIMPLEX_DEBUG") != nullptr;
+  const bool debug = cuopt_amd::tune_int("simplex_debug", 0) != 0;
   S.debug = debug;
   int total_iterations = 0;
   auto print_seconds = [&] {

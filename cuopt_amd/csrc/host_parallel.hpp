@@ -8,12 +8,42 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
 
 namespace cuopt_amd {
+
+// Knobs that only tests, harnesses and tuning sweeps turn live in ONE environment string, read at every query (set-up time only):
+//   CUOPT_AMD_TUNE="slab_bytes=65536,panel_nnz=4096,dense=0"
+// keys: slab_bytes, panel_nnz, panel_ws_bytes, panel_seg, jag_waves, dense, roctx, transpose_direct, fault_inject, soft_communicator,
+// simplex_grade, simplex_pricing, simplex_solves, simplex_debug (each documented where it is read).
+inline bool tune_get(const char* key, std::string* out)
+{
+  const char* e = getenv("CUOPT_AMD_TUNE");
+  if (!e) return false;
+  const std::string all(e), k(key);
+  size_t pos = 0;
+  while (pos <= all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    const std::string item = all.substr(pos, end - pos);
+    const size_t eq        = item.find('=');
+    if (item.substr(0, eq) == k) {
+      if (out) *out = eq == std::string::npos ? std::string("1") : item.substr(eq + 1);
+      return true;
+    }
+    pos = end + 1;
+  }
+  return false;
+}
+inline long long tune_int(const char* key, long long fallback)
+{
+  std::string v;
+  return tune_get(key, &v) ? atoll(v.c_str()) : fallback;
+}
 
 // threads the process may actually run on (cgroup / affinity aware), capped
 inline int host_threads(int cap = 16)

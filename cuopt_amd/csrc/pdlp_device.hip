@@ -193,8 +193,7 @@ static std::once_flag once;
 static void load()
 {
   std::call_once(once, [] {
-    const char* env = getenv("CUOPT_AMD_ROCTX");
-    if (env && atoi(env) == 0) return;
+    if (cuopt_amd::tune_int("roctx", 1) == 0) return;
     for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
       if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
         Push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
@@ -359,16 +358,6 @@ struct pdlpdev_ctx {
     double *add_m = nullptr, *add_n = nullptr;  // what the segments contribute to A v (per row) / A^T v (per column)
     int64_t hot_nnz = 0;
   } dense;
-  // Rows of more than kLongExtract nonzeros (hub constraints / hub variables) are taken out of the hot CSR of THEIR matrix (the other
-  // matrix keeps their entries: there they are one entry per row) and multiplied in chunks by k_long_rows; the layouts add the
-  // result like a dense segment's.  A panel or a row block is then never stretched by a single row.
-  struct LongRows {
-    bool on = false;
-    int nrows = 0, nchunks = 0;
-    int64_t nent = 0;
-    int32_t *row = nullptr, *row_ch = nullptr, *row_flag = nullptr, *ch_k0 = nullptr, *ch_len = nullptr, *idx = nullptr, *perm = nullptr;
-    double *val = nullptr, *part = nullptr;
-  } long_a, long_at;
   int64_t hot_nnz_at = 0;
   int32_t *ha_off = nullptr, *ha_idx = nullptr, *hat_off = nullptr, *hat_idx = nullptr;  // the CSR the hot loop multiplies:
   double *ha_val = nullptr, *hat_val = nullptr;                                          // a_* / at_* unless dense.on
@@ -456,14 +445,6 @@ struct pdlpdev_ctx {
   static constexpr int kProfPairs = 8;
   hipEvent_t prof_ev[2 * kProfPairs] = {};
   int prof_used = 0;
-  unsigned* ticket = nullptr;    // CUOPT_AMD_TICKET_DECISION=1: the decision in the tail of the A^T y' kernel (stream layout)
-  bool ticket_decision = false;
-  // The step decision off the critical path (CUOPT_AMD_FUSED_DECISION=1): see k_primal_decide
-  int fused_decision    = 0;  // 1: decision on a second stream next to the following primal step; 2: no decision kernel inside a chunk at all
-  pdlpdev_ctl* ctl_view = nullptr;  // the control block the loop kernels are launched with (ctl itself; inside a mode-2 chunk: a snapshot)
-  hipStream_t side      = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  pdlpdev_ctl* snap     = nullptr;  // two control-block snapshots, alternating by the attempt's place in its chunk
   int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
   // graphs
   int use_graph = 1;
@@ -1072,157 +1053,6 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   *ctl = lc;
 }
 
-// the same decision from one control block into another (the end of a mode-2 chunk, below): `in` is the block the last primal step
-// of the chunk ended with, `out` the control block proper, which is written in every case (an inactive loop passes through)
-__global__ void __launch_bounds__(kDecisionThreads)
-k_step_decision_io(const pdlpdev_ctl* __restrict__ in, pdlpdev_ctl* __restrict__ out, const double* __restrict__ part_dy, int nb_dy,
-                   const double* __restrict__ part_t, int nb_t, pdlpdev_step_params sp)
-{
-  __shared__ double red[3 * 16];
-  __shared__ double pw[2];
-  pdlpdev_ctl lc = *in;
-  const int t    = threadIdx.x;
-  if (!(lc.error == 0 && lc.steps_taken < lc.target_steps)) {
-    if (t == 0) *out = lc;
-    return;
-  }
-  if (t >= kDecisionThreads - 2) {
-    const double knext = (double)(lc.k + 1) + 1.0;
-    pw[t - (kDecisionThreads - 2)] = pow(knext, t == kDecisionThreads - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
-  }
-  double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int i = t; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
-#pragma unroll 4
-  for (int i = t; i < nb_t; i += kDecisionThreads) {
-    acc[1] += part_t[i];
-    acc[2] += part_t[nb_t + i];
-  }
-  block_sum_fast<3, kDecisionThreads / 64>(acc, red);
-  if (t != 0) return;
-  apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
-  *out = lc;
-}
-
-// The decision off the critical path (CUOPT_AMD_FUSED_DECISION=1).  Inside a chunk of attempts the primal step of attempt i + 1
-// does not wait for k_step_decision of attempt i: EVERY workgroup of this kernel forms that decision itself -- the same partials,
-// the same 1024-thread reduction, the same scalar rule, so the same bits in every workgroup and in k_step_decision, which runs
-// next to this kernel on a second stream (it alone writes the control block; the dual step waits for both).  The control block
-// this kernel starts from is the one the previous primal step ended with: it is handed on through two snapshot slots that
-// alternate by the attempt's place in the chunk (`in` is read by all workgroups, `out` written by one, never the same slot);
-// the first attempt of a chunk reads the control block itself (apply = 0: the chunk before ended with its decision applied).
-__global__ void __launch_bounds__(kDecisionThreads)
-k_primal_decide(int n, const pdlpdev_ctl* __restrict__ in, pdlpdev_ctl* __restrict__ out, int apply, const double* __restrict__ part_dy, int nb_dy,
-                const double* __restrict__ part_t, int nb_t, pdlpdev_step_params sp, double* __restrict__ x0, double* __restrict__ x1,
-                const double* __restrict__ aty0, const double* __restrict__ aty1, const double* __restrict__ c,
-                const double* __restrict__ lb, const double* __restrict__ ub, double* __restrict__ xbar, double* __restrict__ sumx)
-{
-  __shared__ double red[3 * 16];
-  __shared__ double pw[2];
-  __shared__ pdlpdev_ctl decided;
-  pdlpdev_ctl lc = *in;
-  const int t    = threadIdx.x;
-  if (apply && lc.error == 0 && lc.steps_taken < lc.target_steps) {  // (uniform) the attempt before this one ran: its decision
-    if (t >= kDecisionThreads - 2) {
-      const double knext = (double)(lc.k + 1) + 1.0;
-      pw[t - (kDecisionThreads - 2)] = pow(knext, t == kDecisionThreads - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
-    }
-    double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int i = t; i < nb_dy; i += kDecisionThreads) acc[0] += part_dy[i];
-#pragma unroll 4
-    for (int i = t; i < nb_t; i += kDecisionThreads) {
-      acc[1] += part_t[i];
-      acc[2] += part_t[nb_t + i];
-    }
-    block_sum_fast<3, kDecisionThreads / 64>(acc, red);
-    if (t == 0) {
-      apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw);
-      decided = lc;
-    }
-    __syncthreads();
-    lc = decided;
-  }
-  if (blockIdx.x == 0 && t == 0) *out = lc;
-  if (!(lc.error == 0 && lc.steps_taken < lc.target_steps)) return;
-  const int cur       = lc.cur;
-  const double tau    = lc.tau;
-  const double weight = lc.step_size;
-  const bool pend     = lc.pending_avg != 0;
-  const double* __restrict__ x   = cur ? x1 : x0;
-  double* __restrict__ xn        = cur ? x0 : x1;
-  const double* __restrict__ aty = cur ? aty1 : aty0;
-  for (int j = blockIdx.x * kDecisionThreads + t; j < n; j += gridDim.x * kDecisionThreads) {
-    const double xj       = x[j];
-    const double gradient = c[j] - aty[j];
-    double next           = xj - (tau * gradient);
-    next                  = dmax(dmin(next, ub[j]), lb[j]);
-    xn[j]                 = next;
-    xbar[j]               = next - xj + next;
-    if (pend) sumx[j] = sumx[j] + weight * xj;
-  }
-}
-
-// The decision in the TAIL of the A^T y' kernel (CUOPT_AMD_TICKET_DECISION=1, round-2 review item 8): every workgroup publishes
-// its partial sums (agent-scope release by the thread that wrote them) and takes a ticket; the workgroup that draws the last
-// one acquires, finishes the three sums in a fixed order and applies the rule -- no all-wait barrier, one launch less.
-struct DecisionTail {
-  unsigned* ticket;  // null: the decision stays in its own kernel
-  const double* part_dy;
-  int nb_dy;
-  pdlpdev_step_params sp;
-};
-template <int THREADS>
-__device__ __forceinline__ void decision_tail(pdlpdev_ctl* __restrict__ ctl, const DecisionTail& T, double* __restrict__ part_t, int nb_t, int my_part,
-                                              double* scratch /* >= 3 * 16 + 2 doubles of LDS, free at this point */)
-{
-  __shared__ int is_last;
-  __syncthreads();  // the workgroup's partials are written (thread 0), everybody is done with `scratch`
-  if (threadIdx.x == 0) {
-    // publish this workgroup's two partials write-through (system-scope stores: no L2 write-back of the whole XCD as an
-    // agent-scope release fence would cost -- measured: +13 us per attempt), wait for them, then take the ticket
-    if (my_part < nb_t) {
-      __hip_atomic_store(part_t + my_part, part_t[my_part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(part_t + nb_t + my_part, part_t[nb_t + my_part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    is_last = __hip_atomic_fetch_add(T.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  if (threadIdx.x == 0) *T.ticket = 0;
-  double* pw = scratch + 3 * 16;
-  const int k = ctl->k;
-  if (threadIdx.x == THREADS - 1 || threadIdx.x == THREADS - 2) {
-    const double knext = (double)(k + 1) + 1.0;
-    pw[threadIdx.x - (THREADS - 2)] = pow(knext, threadIdx.x == THREADS - 2 ? -T.sp.reduction_exponent : -T.sp.growth_exponent);
-  }
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < T.nb_dy; i += THREADS) acc[0] += T.part_dy[i];  // the previous kernel's: ordinary loads
-  for (int i = threadIdx.x; i < nb_t; i += THREADS) {
-    acc[1] += __hip_atomic_load(part_t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    acc[2] += __hip_atomic_load(part_t + nb_t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  block_sum_fast<3, THREADS / 64>(acc, scratch);
-  if (threadIdx.x != 0) return;
-  pdlpdev_ctl lc = *ctl;
-  apply_step_decision(&lc, acc[0], acc[1], acc[2], T.sp, pw);
-  *ctl = lc;
-}
-__global__ void __launch_bounds__(kBlock)
-k_spmv_at_step_decide(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                      const double* __restrict__ val, pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-                      const double* __restrict__ y1, const double* __restrict__ x0, const double* __restrict__ x1,
-                      double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part, DecisionTail T, const double* __restrict__ dadd)
-{
-  __shared__ double tail_scratch[3 * 16 + 2];
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part, dadd);
-  decision_tail<kBlock>(ctl, T, part, nb, xcd_remap(blockIdx.x, nb), tail_scratch);
-}
-
 // direct peer transport of a sharded solve: wait for every rank's three step-size sums (landed in this rank's block), add them
 // up in rank order -- the same bits on every rank -- and take the decision
 __global__ void __launch_bounds__(64)
@@ -1587,56 +1417,6 @@ k_dense_cols(DenseView D, int n, const pdlpdev_ctl* __restrict__ ctl, const doub
     if (j >= c0 && j < c0 + D.seg_len[sg]) acc += __builtin_nontemporal_load(D.val + D.seg_ptr[sg] + (j - c0)) * vec[D.seg_row[sg]];
   }
   if (j < n) add[j] = acc;
-}
-
-// ---- extracted long rows (pdlpdev_ctx::LongRows): rows of more than kLongExtract nonzeros leave the layouts; chunks of <= 4096
-// entries get a workgroup each (values and columns are coalesced streams, 16 gathers per lane in flight, fixed tree), a lane per
-// row adds the chunks up in order.  No panel / row block is stretched by one row any more.
-struct LongView {
-  const int32_t* __restrict__ row;
-  const int32_t* __restrict__ row_ch;
-  const int32_t* __restrict__ row_flag;  // 1: the row also owns dense segments, whose share is already in `add`
-  const int32_t* __restrict__ ch_k0;
-  const int32_t* __restrict__ ch_len;
-  const int32_t* __restrict__ idx;
-  const double* __restrict__ val;
-  double* __restrict__ part;
-};
-__global__ void __launch_bounds__(kBlock)
-k_long_rows(LongView L, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
-{
-  __shared__ double red[8];
-  if (in_loop && !loop_active(ctl)) return;
-  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
-  const int k0 = L.ch_k0[blockIdx.x], len = L.ch_len[blockIdx.x];
-  constexpr int U = kDenseChunk / kBlock;
-  double a[U];
-  int j[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int k = threadIdx.x + u * kBlock;
-    a[u] = 0.0, j[u] = 0;
-    if (k < len) {
-      a[u] = __builtin_nontemporal_load(L.val + k0 + k);
-      j[u] = __builtin_nontemporal_load(L.idx + k0 + k);
-    }
-  }
-  double acc[1] = {0.0};
-#pragma unroll
-  for (int u = 0; u < U; ++u) acc[0] += a[u] * vec[j[u]];
-  block_reduce<SumOp, 1>(acc, red);
-  if (threadIdx.x == 0) L.part[blockIdx.x] = acc[0];
-}
-__global__ void __launch_bounds__(kBlock)
-k_long_rows_finish(LongView L, int nrows, const pdlpdev_ctl* __restrict__ ctl, int in_loop, double* __restrict__ add)
-{
-  if (in_loop && !loop_active(ctl)) return;
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= nrows) return;
-  const int r = L.row[b];
-  double acc  = L.row_flag[b] ? add[r] : 0.0;
-  for (int q = L.row_ch[b]; q < L.row_ch[b + 1]; ++q) acc += L.part[q];
-  add[r] = acc;
 }
 
 // (plain SpMV: A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
@@ -2444,20 +2224,15 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   // the slabs in lockstep; a 513th panel runs alone afterwards: the power-law LP with 11.4 M nonzeros took 104 us per SpMV
   // with 570 panels of 20 K nonzeros and takes 75 with 512 of 22 K).  So the panel size follows the matrix, up to
   // 60 K nonzeros (beyond that the row-sum strip, kPanelMaxRows, and the 16-bit tile pointers set the limits).
-  const char* target_env = getenv("CUOPT_AMD_PANEL_NNZ");
-  const int64_t cap    = target_env ? std::max<int64_t>(2048, atoll(target_env)) : 60000;
-  const int64_t target = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz + 511) / 512));  // (own rows: recomputed below)
+  const int64_t cap = std::max<int64_t>(2048, cuopt_amd::tune_int("panel_nnz", 60000));  // (tests cut small matrices into many panels)
   // A panel takes rows while they fit under the target (a row above the target is a panel of its own): all panels run at
   // once, so the LARGEST one sets the kernel time -- letting a panel overshoot by its last row made panels of 42 K nonzeros
   // next to the average 22 K on the power-law LP (rows of up to 20 000 nonzeros) and cost 26 of its 117 us.  The target grows
   // (proportionally first, then in 1 % steps) until the panels fit the 512 resident slots again.
-  // rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels (CUOPT_AMD_PANEL_OWN_ROWS=0: they stay inside)
-  const char* own_env = getenv("CUOPT_AMD_PANEL_OWN_ROWS");
-  const bool own_on   = !(own_env && atoi(own_env) == 0);
+  // rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels
   std::vector<char> is_own(rows, 0);
   int64_t own_nnz = 0;
-  if (own_on)
-    for (int32_t i = 0; i < rows; ++i)
+  for (int32_t i = 0; i < rows; ++i)
       if (off[i + 1] - off[i] > kPanelOwnRow) is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];
   auto cut = [&](int64_t tgt) {
     P.row0.assign(1, 0);
@@ -2476,7 +2251,6 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
     }
   };
   int64_t tgt = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz - own_nnz + 511) / 512));
-  (void)target;
   cut(tgt);
   // (the rows with a workgroup of their own share the 512 resident slots with the panels: behind a full house they would run alone)
   const int slots = std::max(64, 512 - (int)P.own_row.size());
@@ -2621,12 +2395,11 @@ static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const i
   int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
   if (mode == 1 && G == 0) G = 64;
   if (G == 0) return H;
-  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_JAG_WAVES=16: 16384 columns, one workgroup per CU) measured
+  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_TUNE=jag_waves=16: 16384 columns, one workgroup per CU) measured
   // 1-3 % faster on the banded, block-angular and multi-band LPs with the column-set version of this layout -- inside the noise
   // of two runs, so the default stays with the geometry every profile of this round was taken with.
   int waves = 8;
-  if (const char* env = getenv("CUOPT_AMD_JAG_WAVES"))
-    if (atoi(env) == 16) waves = 16;
+  if (cuopt_amd::tune_int("jag_waves", 8) == 16) waves = 16;
   const int wcap = jag_window(waves), brows = waves * G;
   const int slots = cus * (waves == 16 ? 1 : 2);  // workgroups resident at once: 80 KiB of LDS each (160 KiB with 16 waves)
   // A workgroup's rows: consecutive, at most `brows`, and as many as keep their DISTINCT columns within the LDS window
@@ -3131,8 +2904,8 @@ static int pb_products(pdlpdev_ctx* c, const pdlpdev_ctx::Pb& L, const double* v
   }
   const int grid   = (L.v.nwg + 7) & ~7;
   const size_t lds = sizeof(double) << L.v.panel_shift;
-  if (L.p_threads == 1024) launch_k(c, k_pb_products<1024>, grid, 1024, lds, L.v, c->ctl_view, v0, v1, mode, in_loop);
-  else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl_view, v0, v1, mode, in_loop);
+  if (L.p_threads == 1024) launch_k(c, k_pb_products<1024>, grid, 1024, lds, L.v, c->ctl, v0, v1, mode, in_loop);
+  else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl, v0, v1, mode, in_loop);
   return 0;
 }
 // ... and phase R with the epilogue of the call site
@@ -3192,8 +2965,6 @@ static int sync_panel_values(pdlpdev_ctx* c)
   if (c->ha_val != c->a_val) k_permute<<<grid_for(hot), kBlock, 0, c->stream>>>(hot, c->dense.s_perm_a, c->a_val, c->ha_val);
   if (c->hat_val != c->at_val) k_permute<<<grid_for(hot_t), kBlock, 0, c->stream>>>(hot_t, c->dense.s_perm_at, c->at_val, c->hat_val);
   if (c->dense.on) k_permute<<<grid_for(c->dense.nent), kBlock, 0, c->stream>>>(c->dense.nent, c->dense.perm, c->a_val, c->dense.val);
-  if (c->long_a.on) k_permute<<<grid_for(c->long_a.nent), kBlock, 0, c->stream>>>(c->long_a.nent, c->long_a.perm, c->a_val, c->long_a.val);
-  if (c->long_at.on) k_permute<<<grid_for(c->long_at.nent), kBlock, 0, c->stream>>>(c->long_at.nent, c->long_at.perm, c->at_val, c->long_at.val);
   (void)hot, (void)hot_t;
   if (c->pa.on) k_permute<<<grid_for(c->pa.nent), kBlock, 0, c->stream>>>(c->pa.nent, c->pa.perm, c->ha_val, c->pa.val);
   if (c->pat.on) k_permute<<<grid_for(c->pat.nent), kBlock, 0, c->stream>>>(c->pat.nent, c->pat.perm, c->hat_val, c->pat.val);
@@ -3283,8 +3054,7 @@ static void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const 
   D->row_seg.push_back((int32_t)D->seg_row.size());
   D->seg_ptr.push_back((int32_t)D->nent);
   // worth a second code path only when the segments carry a visible share of the matrix
-  const char* env = getenv("CUOPT_AMD_DENSE");
-  const int want  = env ? atoi(env) : -1;  // 0 off, 1 on whenever a segment exists, default: >= 2 % of the nonzeros
+  const int want = (int)cuopt_amd::tune_int("dense", -1);  // CUOPT_AMD_TUNE=dense=..: 0 off, 1 on whenever a segment exists, default: >= 2 % of the nonzeros
   D->on = want != 0 && D->nent > 0 && (want == 1 || D->nent * 50 >= nnz) && D->seg_row.size() <= 65536;
   if (!D->on) return;
   for (size_t b = 0; b < D->row.size(); ++b) {
@@ -3343,51 +3113,6 @@ static void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const
     }
     D->st_off[j + 1] = (int32_t)D->st_idx.size();
   }
-}
-constexpr int kLongExtractDefault = 2048;  // rows longer than this leave the layouts when CUOPT_AMD_LONG_ROWS=1
-struct LongHost {
-  bool on = false;
-  std::vector<int32_t> row, row_ch, row_flag, ch_k0, ch_len, idx, perm;
-};
-// (h_off, h_idx, h_perm): the hot CSR so far -- empty: the full CSR (base_off, base_idx), identity permutation; rewritten without
-// the long rows' entries when there are any
-static void extract_long_rows(int32_t rows, const int32_t* base_off, const int32_t* base_idx, std::vector<int32_t>& h_off,
-                              std::vector<int32_t>& h_idx, std::vector<int32_t>& h_perm, const std::vector<int32_t>* first_seg, LongHost* L)
-{
-  // opt-in (CUOPT_AMD_LONG_ROWS=1): measured on the power-law and block-angular workloads (profiles/r03_long_rows.txt) the two
-  // extra launches cost more than the imbalance they remove
-  // (a value > 1 is the threshold itself: CUOPT_AMD_LONG_ROWS=256 leaves rows of at most 256 nonzeros, what the gather-free
-  // layout accepts)
-  const char* env = getenv("CUOPT_AMD_LONG_ROWS");
-  if (!env || atoi(env) == 0) return;
-  const int kLongExtract = atoi(env) > 1 ? atoi(env) : kLongExtractDefault;
-  const bool full      = h_off.empty();
-  const int32_t* off   = full ? base_off : h_off.data();
-  const int32_t* idx   = full ? base_idx : h_idx.data();
-  bool any = false;
-  for (int32_t r = 0; r < rows && !any; ++r) any = off[r + 1] - off[r] > kLongExtract;
-  if (!any) return;
-  std::vector<int32_t> n_off((size_t)rows + 1, 0), n_idx, n_perm;
-  n_idx.reserve((size_t)off[rows]), n_perm.reserve((size_t)off[rows]);
-  for (int32_t r = 0; r < rows; ++r) {
-    const int len = off[r + 1] - off[r];
-    if (len > kLongExtract) {
-      L->row.push_back(r);
-      L->row_flag.push_back(first_seg && (*first_seg)[r] >= 0 ? 1 : 0);
-      L->row_ch.push_back((int32_t)L->ch_k0.size());
-      for (int k0 = 0; k0 < len; k0 += kDenseChunk) {
-        L->ch_k0.push_back((int32_t)L->idx.size() + k0);
-        L->ch_len.push_back(std::min(kDenseChunk, len - k0));
-      }
-      for (int k = off[r]; k < off[r + 1]; ++k) L->idx.push_back(idx[k]), L->perm.push_back(full ? k : h_perm[k]);
-    } else {
-      for (int k = off[r]; k < off[r + 1]; ++k) n_idx.push_back(idx[k]), n_perm.push_back(full ? k : h_perm[k]);
-    }
-    n_off[r + 1] = (int32_t)n_idx.size();
-  }
-  L->row_ch.push_back((int32_t)L->ch_k0.size());
-  L->on = true;
-  h_off.swap(n_off), h_idx.swap(n_idx), h_perm.swap(n_perm);
 }
 static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
 
@@ -3480,44 +3205,23 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   std::vector<int32_t> la = long_rows(m, a_offsets), lat;  // alive until the stream is synchronised at the end
   ctx->a_nlong = (int)la.size();
   if (ctx->a_nlong) TRY(upload_i32(ctx, &ctx->a_long, la.data(), la.size()));
-  // dense row segments and rows of thousands of nonzeros leave the hot loop's copy of the matrix (single-GPU solves;
-  // CUOPT_AMD_DENSE=0 / CUOPT_AMD_LONG_ROWS=0 switch the two paths off)
+  // dense row segments leave the hot loop's copy of the matrix (single-GPU solves)
   const bool one_gpu = !g_create_sharded;
   g_create_sharded   = 0;
   DenseHost DH;
-  LongHost LA, LAT;
   std::vector<int32_t> hA_off, hA_idx, hA_perm, hT_off, hT_idx, hT_perm;  // the hot CSRs where they differ from the full ones
   if (one_gpu) find_dense_segments(m, n, a_offsets, a_indices, &DH);
   if (DH.on) hA_off.swap(DH.s_off), hA_idx.swap(DH.s_idx), hA_perm.swap(DH.s_perm);
-  if (one_gpu) extract_long_rows(m, a_offsets, a_indices, hA_off, hA_idx, hA_perm, DH.on ? &DH.first_seg : nullptr, &LA);
   const bool hot_a     = !hA_off.empty();
   const int32_t* A_off = hot_a ? hA_off.data() : a_offsets;
   const int32_t* A_idx = hot_a ? hA_idx.data() : a_indices;
   ctx->ha_off = ctx->a_off, ctx->ha_idx = ctx->a_idx, ctx->ha_val = ctx->a_val;
   ctx->dense.hot_nnz = (int64_t)A_off[m];
-  auto upload_long = [&](pdlpdev_ctx::LongRows& L, const LongHost& H) -> int {
-    L.nrows = (int)H.row.size(), L.nchunks = (int)H.ch_k0.size(), L.nent = (int64_t)H.idx.size();
-    TRY(upload_i32(ctx, &L.row, H.row.data(), H.row.size()));
-    TRY(upload_i32(ctx, &L.row_ch, H.row_ch.data(), H.row_ch.size()));
-    TRY(upload_i32(ctx, &L.row_flag, H.row_flag.data(), H.row_flag.size()));
-    TRY(upload_i32(ctx, &L.ch_k0, H.ch_k0.data(), H.ch_k0.size()));
-    TRY(upload_i32(ctx, &L.ch_len, H.ch_len.data(), H.ch_len.size()));
-    TRY(upload_i32(ctx, &L.idx, H.idx.data(), H.idx.size(), 8));
-    TRY(upload_i32(ctx, &L.perm, H.perm.data(), H.perm.size()));
-    TRY(dev_alloc(ctx, &L.val, (size_t)L.nent + 8));
-    TRY(dev_alloc(ctx, &L.part, (size_t)L.nchunks + 8));
-    L.on = true;
-    return 0;
-  };
   if (hot_a) {
     TRY(upload_i32(ctx, &ctx->ha_off, A_off, (size_t)m + 1));
     TRY(upload_i32(ctx, &ctx->ha_idx, A_idx, (size_t)ctx->dense.hot_nnz, 8));
     TRY(dev_alloc(ctx, &ctx->ha_val, (size_t)ctx->dense.hot_nnz + 8));
     TRY(upload_i32(ctx, &ctx->dense.s_perm_a, hA_perm.data(), hA_perm.size()));
-  }
-  if (LA.on) {
-    TRY(upload_long(ctx->long_a, LA));
-    if (timing) fprintf(stderr, "[cuopt_amd setup]   long rows of A: %d rows, %lld nonzeros in %d chunks\n", ctx->long_a.nrows, (long long)ctx->long_a.nent, ctx->long_a.nchunks);
   }
   if (DH.on) {
     pdlpdev_ctx::Dense& D = ctx->dense;
@@ -3541,7 +3245,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     D.on = true;
     if (timing) fprintf(stderr, "[cuopt_amd setup]   dense: %d segments in %d rows, %lld of %lld nonzeros stored index-free\n", D.nseg, D.nrows, (long long)D.nent, (long long)ctx->nnz);
   }
-  if (DH.on || LA.on) TRY(dev_alloc(ctx, &ctx->dense.add_m, (size_t)m));
+  if (DH.on) TRY(dev_alloc(ctx, &ctx->dense.add_m, (size_t)m));
   std::vector<int32_t> rba = build_row_blocks(m, A_off);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
@@ -3567,16 +3271,15 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   }
   TRY(dev_alloc(ctx, &ctx->rc_scratch, n));
   {
-    // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel | jag ; CUOPT_AMD_SLAB_BYTES.
+    // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel | jag ; CUOPT_AMD_TUNE=slab_bytes=...
     // auto is structural (reproducible): the jagged layout when filling its LDS column sets costs at most half of the gathers
     // they serve (build_jag), else slab-major panels iff the stream kernel's live gather set exceeds an XCD's L2
     // (gather_working_set), else the CSR stream.  "timed" times panels against the stream on the device (pick_layout).
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
     const std::string mode = mode_env ? mode_env : "auto";
-    const char* slab_env   = getenv("CUOPT_AMD_SLAB_BYTES");
     // 1.33 MiB of the gathered vector per slab: measured optimum on the 1e6 x 1e6 random LP (6 slabs: 71 us per
     // SpMV; 8 slabs of 1 MiB: 74 us; 4 slabs of 2 MiB: 75 us) -- fewer tiles per panel against L2 capacity
-    const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
+    const int64_t slab_bytes = std::max<int64_t>(64, cuopt_amd::tune_int("slab_bytes", 1398102));
     if (mode != "auto" && mode != "stream" && mode != "panel" && mode != "jag" && mode != "timed" && mode != "pb")
       return fail(-1, "CUOPT_AMD_SPMV_LAYOUT must be auto, stream, panel, jag, pb or timed");
     const bool force = mode == "panel";
@@ -3585,8 +3288,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     auto want_pb = [&](int32_t cols) { return mode == "pb" || (mode == "auto" && (int64_t)cols * 8 > 16 * slab_bytes); };
     const bool try_jag = mode == "auto" || mode == "jag" || timed;
     // auto, not jagged: panels when the CSR stream kernel's live gather set overflows what an XCD's L2 keeps of it
-    const char* ws_env     = getenv("CUOPT_AMD_PANEL_WS_BYTES");
-    const int64_t ws_limit = ws_env ? atoll(ws_env) : kPanelWorkingSetBytes;
+    const int64_t ws_limit = cuopt_amd::tune_int("panel_ws_bytes", kPanelWorkingSetBytes);
     auto want_panels = [&](int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, const char* name) {
       if (force) return true;
       if (!timed && (mode != "auto" || (int64_t)cols * 8 <= ws_limit)) return false;
@@ -3619,7 +3321,6 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
         strip_transpose(DH, &DH, n, at_offsets, at_indices);
         hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
       }
-      if (one_gpu) extract_long_rows(n, at_offsets, at_indices, hT_off, hT_idx, hT_perm, nullptr, &LAT);
       if (!hT_off.empty()) T_off = hT_off.data(), T_idx = hT_idx.data();
       ts.rbt = build_row_blocks(n, T_off);
       if (try_jag) ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
@@ -3667,14 +3368,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       TRY(dev_alloc(ctx, &ctx->hat_val, (size_t)ctx->hot_nnz_at + 8));
       TRY(upload_i32(ctx, &ctx->dense.s_perm_at, hT_perm.data(), hT_perm.size()));
     }
-    if (LAT.on) {
-      // a long column inside a 256-column tile the dense segments touch starts from what k_dense_cols just wrote there (possibly 0)
-      if (DH.on)
-        for (size_t b = 0; b < LAT.row.size(); ++b) LAT.row_flag[b] = std::binary_search(DH.tile_id.begin(), DH.tile_id.end(), LAT.row[b] / kBlock) ? 1 : 0;
-      TRY(upload_long(ctx->long_at, LAT));
-      if (timing) fprintf(stderr, "[cuopt_amd setup]   long rows of A^T: %d rows, %lld nonzeros in %d chunks\n", ctx->long_at.nrows, (long long)ctx->long_at.nent, ctx->long_at.nchunks);
-    }
-    if (DH.on || LAT.on) TRY(dev_alloc(ctx, &ctx->dense.add_n, (size_t)n));
+    if (DH.on) TRY(dev_alloc(ctx, &ctx->dense.add_n, (size_t)n));
     ctx->at_nb = (int)ts.rbt.size() / 2 - 1;
     TRY(upload_i32(ctx, &ctx->at_rb, ts.rbt.data(), ts.rbt.size()));
     lap("upload A^T");
@@ -3710,20 +3404,6 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(dev_alloc(ctx, &ctx->scal, kScalars));
   TRY(dev_alloc(ctx, &ctx->ctl, 1));
   TRY(dev_alloc(ctx, &ctx->ar_buf, (size_t)n + kSlicePad));
-  TRY(dev_alloc(ctx, &ctx->ticket, 4));
-  {
-    const char* tk = getenv("CUOPT_AMD_TICKET_DECISION");
-    ctx->ticket_decision = tk && atoi(tk) == 1;
-    const char* fd = getenv("CUOPT_AMD_FUSED_DECISION");
-    ctx->ctl_view = ctx->ctl;
-    if (fd && (atoi(fd) == 1 || atoi(fd) == 2) && !ctx->ticket_decision) {
-      HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-      TRY(dev_alloc(ctx, &ctx->snap, 2));
-      ctx->fused_decision = atoi(fd);
-    }
-  }
   lap("partial buffers");
   k_fill<<<grid_for(m), kBlock, 0, ctx->stream>>>(m, ctx->dr, 1.0);
   k_fill<<<grid_for(n), kBlock, 0, ctx->stream>>>(n, ctx->dc, 1.0);
@@ -3750,9 +3430,6 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
@@ -4074,10 +3751,8 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx
     const char* mode_env = getenv("CUOPT_AMD_SPMV_LAYOUT");
     std::string mode     = mode_env ? mode_env : "auto";
     if (mode == "timed") mode = "auto";
-    const char* slab_env     = getenv("CUOPT_AMD_SLAB_BYTES");
-    const int64_t slab_bytes = slab_env ? std::max<int64_t>(64, atoll(slab_env)) : (int64_t)1398102;
-    const char* ws_env       = getenv("CUOPT_AMD_PANEL_WS_BYTES");
-    const int64_t ws_limit   = ws_env ? atoll(ws_env) : kPanelWorkingSetBytes;
+    const int64_t slab_bytes = std::max<int64_t>(64, cuopt_amd::tune_int("slab_bytes", 1398102));
+    const int64_t ws_limit   = cuopt_amd::tune_int("panel_ws_bytes", kPanelWorkingSetBytes);
     if (nc > 0 && (mode == "auto" || mode == "jag")) {
       JagHost j = build_jag(nc, (int32_t)gcols, off, ridx.data(), mode == "jag" ? 1 : 0, ctx->cus);
       TRY(upload_jag(ctx, &ctx->joc, j, ctx->oc_off, ctx->oc_idx, ctx->oc_val));
@@ -4475,20 +4150,14 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 static void dense_part(pdlpdev_ctx* ctx, int transpose, const double* v0, const double* v1, int mode, int in_loop)
 {
   const pdlpdev_ctx::Dense& D    = ctx->dense;
-  const pdlpdev_ctx::LongRows& L = transpose ? ctx->long_at : ctx->long_a;
   if (D.on) {
     DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
     if (transpose) {
-      launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl_view, v0, v1, mode, in_loop, D.add_n);
+      launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
     } else {
-      launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl_view, v0, v1, mode, in_loop);
-      launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl_view, in_loop, D.add_m);
+      launch_k(ctx, k_dense_rows, D.nchunks, kBlock, 0, V, ctx->ctl, v0, v1, mode, in_loop);
+      launch_k(ctx, k_dense_rows_finish, (D.nrows + kBlock - 1) / kBlock, kBlock, 0, V, D.nrows, ctx->ctl, in_loop, D.add_m);
     }
-  }
-  if (L.on) {  // after the segments: a row that owns both starts from their share
-    LongView W{L.row, L.row_ch, L.row_flag, L.ch_k0, L.ch_len, L.idx, L.val, L.part};
-    launch_k(ctx, k_long_rows, L.nchunks, kBlock, 0, W, ctx->ctl_view, v0, v1, mode, in_loop);
-    launch_k(ctx, k_long_rows_finish, (L.nrows + kBlock - 1) / kBlock, kBlock, 0, W, L.nrows, ctx->ctl_view, in_loop, transpose ? D.add_n : D.add_m);
   }
 }
 // launch helpers: pick the layout (jagged rows with LDS column sets, slab-major panels, CSR stream)
@@ -4499,26 +4168,26 @@ static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pde
   dense_part(ctx, 0, ctx->xbar, nullptr, 0, 1);
   if (ctx->pba.on) {
     (void)pb_products(ctx, ctx->pba, ctx->xbar, nullptr, 0, 1);
-    (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    (void)pb_rows(ctx, k_pb_a_dual, ctx->pba, ctx->ctl, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   } else if (ctx->ja.on)
-    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else if (ctx->pa.on)
-    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else
-    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl_view, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
+    launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
 }
 static void launch_at_step(pdlpdev_ctx* ctx)
 {
   dense_part(ctx, 1, ctx->y[0], ctx->y[1], 1, 1);
   if (ctx->pbat.on) {
     (void)pb_products(ctx, ctx->pbat, ctx->y[0], ctx->y[1], 1, 1);  // y' = the trial dual
-    (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl_view, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    (void)pb_rows(ctx, k_pb_at_step, ctx->pbat, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   } else if (ctx->jat.on)
-    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
-    launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else
-    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl_view, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
+    launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
 }
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
 {
@@ -4648,15 +4317,8 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
   launch_a_dual(ctx);
   if (!ctx->comm) {
-    if (ctx->ticket_decision && !ctx->pbat.on && !ctx->jat.on && !ctx->pat.on) {
-      DecisionTail T{ctx->ticket, ctx->part_a, dual_partials(ctx), ctx->sp};
-      dense_part(ctx, 1, ctx->y[0], ctx->y[1], 1, 1);
-      launch_k(ctx, k_spmv_at_step_decide, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl,
-               ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, T, ctx->dense.add_n);
-    } else {
-      launch_at_step(ctx);
-      launch_decision(ctx);
-    }
+    launch_at_step(ctx);
+    launch_decision(ctx);
   } else {
     // partial A^T y' of this row block -> ar_buf[0..n), ||dy||^2 partial -> ar_buf[n]; ONE all-reduce
     launch_at_cur(ctx, ctx->ar_buf, 1);
@@ -4671,54 +4333,6 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
   return 0;
 }
 
-// single-GPU attempts with the decision next to the following primal step (k_primal_decide); captured into the chunk's graph as a
-// fork / join between the main stream and ctx->side
-static bool fused_decision_applies(const pdlpdev_ctx* ctx)
-{
-  return ctx->fused_decision != 0 && !ctx->comm && !ctx->owner && !ctx->rsag && !ctx->small_resident;
-}
-static int enqueue_chunk_fused(pdlpdev_ctx* ctx, int attempts)
-{
-  const int n = ctx->n;
-  const int g = std::max(1, std::min((n + kDecisionThreads - 1) / kDecisionThreads, 512));
-  if (ctx->fused_decision == 2) {
-    // no decision kernel inside the chunk: every kernel of attempt i reads the control block the primal step of attempt i ended
-    // with (its decision of attempt i - 1 included); one kernel at the end of the chunk brings the control block proper up to date
-    for (int i = 0; i < attempts; ++i) {
-      pdlpdev_ctl* out = ctx->snap + ((i + 1) & 1);
-      k_primal_decide<<<g, kDecisionThreads, 0, ctx->stream>>>(n, i == 0 ? ctx->ctl : ctx->snap + (i & 1), out, i > 0 ? 1 : 0, ctx->part_a, dual_partials(ctx),
-                                                              ctx->part_at, step_partials(ctx), ctx->sp, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c,
-                                                              ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
-      ctx->ctl_view = out;
-      launch_a_dual(ctx);
-      launch_at_step(ctx);
-      ctx->ctl_view = ctx->ctl;
-      LAUNCH_CHECK();
-    }
-    k_step_decision_io<<<1, kDecisionThreads, 0, ctx->stream>>>(ctx->snap + (attempts & 1), ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at,
-                                                               step_partials(ctx), ctx->sp);
-    LAUNCH_CHECK();
-    return 0;
-  }
-  for (int i = 0; i < attempts; ++i) {
-    if (i > 0) {
-      HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
-      HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-      k_step_decision<<<1, kDecisionThreads, 0, ctx->side>>>(ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_at, step_partials(ctx), nullptr, ctx->sp);
-      HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
-    }
-    k_primal_decide<<<g, kDecisionThreads, 0, ctx->stream>>>(n, i == 0 ? ctx->ctl : ctx->snap + (i & 1), ctx->snap + ((i + 1) & 1), i > 0 ? 1 : 0, ctx->part_a,
-                                                            dual_partials(ctx), ctx->part_at, step_partials(ctx), ctx->sp, ctx->x[0], ctx->x[1], ctx->aty[0],
-                                                            ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
-    if (i > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    launch_a_dual(ctx);
-    launch_at_step(ctx);
-    if (i == attempts - 1) launch_decision(ctx);
-    LAUNCH_CHECK();
-  }
-  return 0;
-}
-
 static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
 {
   auto it = ctx->graphs.find(attempts);
@@ -4729,8 +4343,6 @@ static int get_graph(pdlpdev_ctx* ctx, int attempts, hipGraphExec_t* out)
   hipGraph_t graph;
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  if (fused_decision_applies(ctx)) rc = enqueue_chunk_fused(ctx, attempts);
-  else
   for (int i = 0; i < attempts && rc == 0; ++i) rc = enqueue_attempt(ctx);
   hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
   if (rc != 0) return rc;
@@ -4773,12 +4385,10 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   int guard = 0;
   while (ctx->ctl_h->error == 0 && ctx->ctl_h->steps_taken < target_steps) {
     int remaining = target_steps - ctx->ctl_h->steps_taken;
-    // Sharded solves enqueue plain launches: capturing the RCCL all-reduce into the attempt graph was tried
-    // (CUOPT_AMD_GRAPH_COMM=1 enables it) and the process died inside the capture with the RCCL 2.26 that PyTorch
-    // bundles (one rank, ROCm 7.2) -- left off until it can be exercised on a multi-GPU node.  The in-process
-    // communicator synchronises on the host and can never be captured.
-    static const bool graph_comm = getenv("CUOPT_AMD_GRAPH_COMM") && atoi(getenv("CUOPT_AMD_GRAPH_COMM")) == 1;
-    if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || (graph_comm && !ctx->soft))) {
+    // Sharded solves over RCCL enqueue plain launches unless the caller asked for captured collectives
+    // (pdlpdev_set_graph_mode(ctx, 2); tools/rccl_capture_repro.cpp is the stand-alone probe of that capture).  The in-process
+    // communicator synchronises on the host and can never be captured; the direct peer transport is kernels only.
+    if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || (ctx->use_graph == 2 && !ctx->soft))) {
       while (remaining > 0) {
         int chunk = 1;
         while (chunk * 2 <= remaining && chunk < 64) chunk *= 2;

@@ -681,7 +681,7 @@ void cuoptamd_csr_transpose(int32_t m, int32_t n, const int32_t* offsets, const 
   // stay ascending inside a column: the same output as the direct version, for any thread count) into its own contiguous piece
   // of the result, which the cache holds.
   constexpr int kBlocks = 256;
-  if (T == 1 || nnz < (1 << 22) || n < 16 * kBlocks || getenv("CUOPT_AMD_TRANSPOSE_DIRECT")) {
+  if (T == 1 || nnz < (1 << 22) || n < 16 * kBlocks || cuopt_amd::tune_int("transpose_direct", 0)) {
     transpose_direct(m, n, offsets, indices, values, t_offsets, t_indices, t_values, T);
     return;
   }
@@ -832,11 +832,11 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
 // therefore agree on their status right before it (this hook, set per thread; max of the ranks' error codes), and a rank
 // that fails later aborts the communicators (pdlpdev_comm_abort).
 static thread_local std::function<int(int)> t_agree_before_comm;
-// test hook: CUOPT_AMD_FAULT_INJECT="<rank>:create" | "<rank>:advance" makes that rank of a sharded solve fail there
+// test hook: CUOPT_AMD_TUNE="fault_inject=<rank>:create" | "...=<rank>:advance" makes that rank of a sharded solve fail there
 static bool fault_injected(int rank, int world, const char* where)
 {
-  const char* env = std::getenv("CUOPT_AMD_FAULT_INJECT");
-  if (!env || world <= 1) return false;
+  std::string env;
+  if (world <= 1 || !cuopt_amd::tune_get("fault_inject", &env)) return false;
   const std::string want = std::to_string(rank) + ":" + where;
   return want == env;
 }

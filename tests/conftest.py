@@ -19,6 +19,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+def set_tune(monkeypatch, **kw):
+    """Merge keys into CUOPT_AMD_TUNE (the one string of test / harness knobs, host_parallel.hpp); value None removes a key."""
+    cur = dict(item.split("=", 1) for item in os.environ.get("CUOPT_AMD_TUNE", "").split(",") if "=" in item)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv("CUOPT_AMD_TUNE", ",".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("CUOPT_AMD_TUNE", raising=False)
+
+
 def _dec(v):
     return np.array([np.inf if x == "inf" else -np.inf if x == "-inf" else x for x in v], dtype=np.float64)
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import ROOT, decode_problem, write_mps
+from conftest import ROOT, decode_problem, write_mps, set_tune
 from cuopt_amd import capi
 
 INF = np.inf
@@ -191,7 +191,7 @@ def test_blocked_transposition_of_large_matrices_is_the_direct_one(monkeypatch):
     a = sp.csr_matrix((rng.standard_normal(nnz), (rows, cols)), shape=(m, n))  # (duplicates summed)
     a.sort_indices()
     blocked = capi.csr_transpose(m, n, a.indptr, a.indices, a.data)
-    monkeypatch.setenv("CUOPT_AMD_TRANSPOSE_DIRECT", "1")
+    set_tune(monkeypatch, transpose_direct="1")
     direct = capi.csr_transpose(m, n, a.indptr, a.indices, a.data)
     for x, y in zip(blocked, direct):
         assert np.array_equal(x, y)

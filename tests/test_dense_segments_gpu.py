@@ -4,6 +4,7 @@ streaming kernels of their own; every layout then works on the sparse remainder 
 two), everything else stays bit-identical to the oracle."""
 import numpy as np
 import pytest
+from conftest import set_tune
 
 from cuopt_amd import capi, synthetic
 from oracle import orcbind
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def dense_on(monkeypatch):
     """at this size the two dense rows hold 1.4 % of the nonzeros, under the 2 % from which the path switches itself on"""
-    monkeypatch.setenv("CUOPT_AMD_DENSE", "1")
+    set_tune(monkeypatch, dense="1")
 
 
 @pytest.fixture(scope="module")
@@ -42,7 +43,7 @@ def _touched(p):
 def test_products_against_the_oracle_in_every_layout(lp, layout, monkeypatch):
     p = lp
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
-    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(64 * 1024))
+    set_tune(monkeypatch, slab_bytes=str(64 * 1024))
     dev = capi.Device(p)
     rows, cols = _touched(p)
     assert rows.sum() >= 2 and cols.sum() >= 3000
@@ -64,7 +65,7 @@ def test_the_path_can_be_switched_off_and_gives_the_same_solve(lp, monkeypatch):
     p = lp
     got = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("CUOPT_AMD_DENSE", flag)
+        set_tune(monkeypatch, dense=flag)
         r = capi.Solver(p, tol=0.0, iteration_limit=80).advance()
         got[flag] = (r["steps_taken"], r["attempted_steps"], r["num_restarts"], r["primal_objective"], r["step_size"])
     assert got["0"][:3] == got["1"][:3]

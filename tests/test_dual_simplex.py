@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import decode_problem
+from conftest import decode_problem, set_tune
 from cuopt_amd import capi
 
 STATUS = {"OPTIMAL": "Optimal", "INFEASIBLE": "PrimalInfeasible", "UNBOUNDED": "Unbounded"}
@@ -155,11 +155,11 @@ def test_mid_size_lps_through_the_sparse_factorisation():
         assert r["objective"] == pytest.approx(p["objective_star"], rel=1e-8, abs=1e-8)
         _check_vertex(p, r, tol=1e-6)
     # the same pivots under Dantzig pricing end at the same optimum (the steepest-edge weights only choose among infeasible rows)
-    os.environ["CUOPT_AMD_SIMPLEX_PRICING"] = "dantzig"
+    os.environ["CUOPT_AMD_TUNE"] = "simplex_pricing=dantzig"
     try:
         r = capi.dual_simplex(cases[1], time_limit=200)
     finally:
-        del os.environ["CUOPT_AMD_SIMPLEX_PRICING"]
+        del os.environ["CUOPT_AMD_TUNE"]
     assert r["status"] == "Optimal" and r["objective"] == pytest.approx(cases[1]["objective_star"], rel=1e-8)
 
 
@@ -298,7 +298,7 @@ def test_sparse_and_dense_solves_walk_the_same_pivots(monkeypatch):
     p = synthetic.generate(3000, 2400, 3, seed=5)
     runs = {}
     for mode in ("dense", "sparse", "auto"):
-        monkeypatch.setenv("CUOPT_AMD_SIMPLEX_SOLVES", mode)
+        set_tune(monkeypatch, simplex_solves=mode)
         cold = capi.dual_simplex(p, time_limit=120)
         assert cold["status"] == "Optimal" and cold["objective"] == pytest.approx(p["objective_star"], rel=1e-8)
         warm = capi.dual_simplex(p, time_limit=120, x0=cold["x"] * (1 + 1e-3 * np.cos(np.arange(p["n"]))))

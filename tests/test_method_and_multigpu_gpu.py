@@ -4,10 +4,11 @@ crossover: LP/solve.cu:383-443,467-547) and the single-process multi-GPU path (S
 Round 3: small LPs have a second engine, the library's own bounded dual simplex (dual_simplex.cpp): a DualSimplex request is
 answered by it, a Concurrent request lets it race PDLP.  Where it is switched off (CUOPT_AMD_DUAL_SIMPLEX=0 / "amd_dual_simplex"
 = 0) or abstains, non-PDLP methods on small LPs run PDLP at simplex-grade tolerances with the caller's own tolerances as the
-acceptance set (the round-1/2 emulation; CUOPT_AMD_SIMPLEX_GRADE=0 / "amd_simplex_grade" = 0 switches that off too);
+acceptance set (the round-1/2 emulation; "amd_simplex_grade" = 0 switches that off too);
 cuOptAmdGetSolveInfo says what happened."""
 import numpy as np
 import pytest
+from conftest import set_tune
 
 from cuopt_amd import capi, synthetic
 
@@ -87,13 +88,13 @@ def test_solve_info_names_the_engine_and_the_attempt(monkeypatch):
 def test_simplex_grade_opt_out(monkeypatch):
     monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")
     on = capi.solve(ranged_lp())
-    monkeypatch.setenv("CUOPT_AMD_SIMPLEX_GRADE", "0")
+    set_tune(monkeypatch, simplex_grade="0")
     off = capi.solve(ranged_lp())
     assert on["solve_info"]["simplex_grade_emulation"] is True and off["solve_info"]["simplex_grade_emulation"] is False
     assert off["status"] == on["status"] == "Optimal"
     assert off["steps_taken"] <= on["steps_taken"]
     assert off["steps_taken"] == capi.solve(ranged_lp(), method=1)["steps_taken"]  # exactly a PDLP request
-    monkeypatch.delenv("CUOPT_AMD_SIMPLEX_GRADE")
+    set_tune(monkeypatch, simplex_grade=None)
     again = capi.solve(ranged_lp(), amd_simplex_grade=0)  # the parameter beats the environment default
     assert again["solve_info"]["simplex_grade_emulation"] is False
 
@@ -158,7 +159,7 @@ def test_cuoptsolve_shards_over_gpus_through_the_in_process_communicator(world, 
     dataflows (CUOPT_AMD_SHARD_DATAFLOW)"""
     p = synthetic.generate(6000, 5000, 8, seed=61)
     single = capi.solve(p, method=1, tol=1e-6)
-    monkeypatch.setenv("CUOPT_AMD_SOFT_COMMUNICATOR", "1")
+    set_tune(monkeypatch, soft_communicator="1")
     monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", dataflow)
     r = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=world)
     assert r["status"] == "Optimal" and r["gpus"] == world and r["solve_info"]["gpus"] == world
@@ -172,7 +173,7 @@ def test_cuoptsolve_shards_over_gpus_through_the_in_process_communicator(world, 
 
 
 def test_more_gpus_than_visible_is_a_loud_error(monkeypatch):
-    monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)
+    set_tune(monkeypatch, soft_communicator=None)
     n = capi.device_count()
     r = capi.solve(ranged_lp(), method=1, amd_num_gpus=min(n + 1, 16)) if n < 16 else None
     if r is not None:
@@ -184,7 +185,7 @@ def test_more_gpus_than_visible_is_a_loud_error(monkeypatch):
 def test_rccl_two_ranks_in_one_process(dataflow, monkeypatch):
     """two devices, two host threads, real RCCL; "owner+p2p": the exchanges of the owner-computes dataflow as direct stores into
     the peer's landing block (hipDeviceEnablePeerAccess) instead of collectives"""
-    monkeypatch.delenv("CUOPT_AMD_SOFT_COMMUNICATOR", raising=False)
+    set_tune(monkeypatch, soft_communicator=None)
     monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", dataflow.split("+")[0])
     monkeypatch.setenv("CUOPT_AMD_SHARD_TRANSPORT", "p2p" if dataflow.endswith("p2p") else "collective")
     p = synthetic.generate(6000, 5000, 8, seed=61)

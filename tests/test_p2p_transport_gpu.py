@@ -12,6 +12,7 @@ import subprocess
 import sys
 
 import pytest
+from conftest import set_tune
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,13 +77,13 @@ def test_a_failing_rank_ends_the_sharded_solve_instead_of_hanging_it(where, data
     solve: the other ranks must not wait for it in a collective -- the call returns CUOPT_RUNTIME_ERROR naming the rank"""
     from cuopt_amd import capi, synthetic
     p = synthetic.generate(3000, 2600, 8, seed=5)
-    monkeypatch.setenv("CUOPT_AMD_SOFT_COMMUNICATOR", "1")
+    set_tune(monkeypatch, soft_communicator="1")
     monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", dataflow)
-    monkeypatch.setenv("CUOPT_AMD_FAULT_INJECT", "1:" + where)
+    set_tune(monkeypatch, fault_inject="1:" + where)
     r = capi.solve(p, method=1, tol=1e-8, amd_num_gpus=3)
     assert r["return_code"] == capi.CUOPT_RUNTIME_ERROR
     assert "rank 1 of 3" in r["error_string"] and "injected fault" in r["error_string"]
-    monkeypatch.delenv("CUOPT_AMD_FAULT_INJECT")
+    set_tune(monkeypatch, fault_inject=None)
     ok = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=3)  # and the library is usable afterwards
     assert ok["status"] == "Optimal"
 
@@ -102,7 +103,7 @@ def test_a_rank_that_dies_under_the_peer_transport_ends_the_solve(monkeypatch):
     """with direct peer stores nobody sits in a collective: the surviving ranks' device-side waits run out of patience (5 s), the
     solve ends in CUOPT_RUNTIME_ERROR naming the rank that failed first-hand"""
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16", CUOPT_AMD_SHARD_DATAFLOW="owner", CUOPT_AMD_SHARD_TRANSPORT="p2p",
-               CUOPT_AMD_SOFT_COMMUNICATOR="1", CUOPT_AMD_FAULT_INJECT="1:advance")
+               CUOPT_AMD_TUNE="soft_communicator=1,fault_inject=1:advance")
     r = subprocess.run([sys.executable, "-c", FAULT_CHILD % dict(root=ROOT)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])

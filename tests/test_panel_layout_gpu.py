@@ -5,6 +5,7 @@ gather-free layout ("pb": products streamed through LDS-resident slices of the v
 products; tools/spmv_pb.hip), which sums EVERY row left to right whatever its length."""
 import numpy as np
 import pytest
+from conftest import set_tune
 
 from cuopt_amd import capi, synthetic
 from oracle import orcbind
@@ -18,10 +19,10 @@ pytestmark = pytest.mark.gpu
 def layout(request, monkeypatch):
     mode, slab = request.param
     if mode == "jag":  # both geometries of the jagged layout (8 waves / 8192-column window, 16 waves / 16384)
-        monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(slab))
+        set_tune(monkeypatch, jag_waves=str(slab))
         slab = 1 << 20
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
-    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(slab))
+    set_tune(monkeypatch, slab_bytes=str(slab))
     monkeypatch.setenv("CUOPT_AMD_SMALL", "0")  # these LPs are small: keep them on the multi-launch kernels under test
     return mode
 
@@ -135,15 +136,15 @@ def test_auto_layout_is_a_structural_rule(monkeypatch):
     rnd = synthetic.generate(70000, 70000, 8, seed=5)                 # touches every line of the 547 KiB vector
     wide = synthetic.generate(70000, 70000, 8, seed=5, band=9000)     # 512 K nonzeros = 65536 rows: band + rows wide
     narrow = synthetic.generate(140000, 8000, 8, seed=5)              # 62.5 KiB vector: fits one LDS window
-    monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(256 * 1024))
+    set_tune(monkeypatch, panel_ws_bytes=str(256 * 1024))
     for _ in range(3):
         assert capi.Device(rnd).layout()["A"]["layout"] == "panel"
         assert capi.Device(rnd).layout()["At"]["layout"] == "panel"
     assert capi.Device(narrow).layout()["A"]["layout"] == "jag"       # 8000 columns: the whole vector is one LDS window
     assert capi.Device(wide).layout()["A"]["layout"] in ("panel", "stream")
-    monkeypatch.setenv("CUOPT_AMD_PANEL_WS_BYTES", str(1 << 30))
+    set_tune(monkeypatch, panel_ws_bytes=str(1 << 30))
     assert capi.Device(rnd).layout()["A"]["layout"] == capi.Device(rnd).layout()["At"]["layout"] == "stream"
-    monkeypatch.delenv("CUOPT_AMD_PANEL_WS_BYTES")
+    set_tune(monkeypatch, panel_ws_bytes=None)
     assert capi.Device(rnd).layout()["A"]["layout"] == "stream"        # default limit: 4 MiB
     a = capi.Solver(rnd, tol=1e-6).advance()
     b = capi.Solver(rnd, tol=1e-6).advance()
@@ -228,7 +229,7 @@ def test_jagged_layout_with_hundreds_of_long_rows(waves, monkeypatch):
     row blocks -- the row block that contains such a row must leave it alone (its strip entry is marked after the zero fill, behind
     a barrier: the two used to race)"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
-    monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(waves))
+    set_tune(monkeypatch, jag_waves=str(waves))
     p = synthetic.generate_structured("powerlaw", m=200000, n=200000, k=8, seed=11)
     lens = np.diff(p["offsets"])
     assert (lens > 128).sum() > 300
@@ -257,7 +258,7 @@ def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch
     geometries, rectangular matrices, a ragged last workgroup, empty rows, rows of exactly 127 / 128 / 129 nonzeros (the
     boundary between the left-to-right and the tree path) and a few rows of thousands"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
-    monkeypatch.setenv("CUOPT_AMD_JAG_WAVES", str(waves))
+    set_tune(monkeypatch, jag_waves=str(waves))
     rng = np.random.default_rng(m + n)
     lens = rng.poisson(4.0, size=m).astype(np.int64)
     lens[rng.integers(0, m, size=200)] = 0
@@ -290,13 +291,11 @@ def test_jagged_layout_shapes_and_row_length_boundaries(m, n, waves, monkeypatch
     dev.close()
 
 
-@pytest.mark.parametrize("own", ["1", "0"])
-def test_panels_with_hub_rows_of_their_own(own, monkeypatch):
-    """rows of more than 4096 nonzeros get a workgroup each behind the panels (CUOPT_AMD_PANEL_OWN_ROWS=0: they stay inside the
-    panels, summed wave by wave): same numbers to the long-row tolerance, short rows bit-exact, same decisions"""
+def test_panels_with_hub_rows_of_their_own(monkeypatch):
+    """rows of more than 4096 nonzeros get a workgroup each behind the panels: same numbers to the long-row tolerance, short rows
+    bit-exact, same decisions"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
-    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(64 * 1024))
-    monkeypatch.setenv("CUOPT_AMD_PANEL_OWN_ROWS", own)
+    set_tune(monkeypatch, slab_bytes=str(64 * 1024))
     p = synthetic.generate_structured("powerlaw", m=200000, n=200000, k=10, seed=11)
     lens = np.diff(p["offsets"])
     assert (lens > 4096).sum() >= 2

@@ -8,6 +8,7 @@ import threading
 
 import numpy as np
 import pytest
+from conftest import set_tune
 
 from cuopt_amd import capi, synthetic
 
@@ -198,7 +199,7 @@ def test_sharded_solve_through_the_other_layouts(layout, monkeypatch):
     """row-block sharding on top of the jagged / panel layouts (every rank builds them for ITS row block and that block's
     transpose): same decisions on all ranks, same optimum as the single-rank solve"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
-    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(32 * 1024))
+    set_tune(monkeypatch, slab_bytes=str(32 * 1024))
     p = synthetic.generate(30000, 26000, 8, seed=71, band=900)
     single = capi.Solver(p, tol=1e-5).advance()
     out = run_sharded(p, 3, tol=1e-5)

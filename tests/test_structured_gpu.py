@@ -7,6 +7,7 @@ import pytest
 
 from cuopt_amd import capi, synthetic
 from oracle import orcbind
+from conftest import set_tune
 from test_solve_gpu import host_check
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +23,7 @@ def lp(request):
 def test_spmv_against_the_oracle_in_every_layout(lp, layout, monkeypatch):
     p = lp
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
-    monkeypatch.setenv("CUOPT_AMD_SLAB_BYTES", str(64 * 1024))  # several slabs even at this size
+    set_tune(monkeypatch, slab_bytes=64 * 1024)  # several slabs even at this size
     dev = capi.Device(p)
     rng = np.random.default_rng(2)
     x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
