@@ -198,6 +198,9 @@ def main():
             break
     dev.call("synchronize")
     barrier()
+    attempts_before = solver.advance(0)["attempted_steps"]
+    dev.call("synchronize")
+    barrier()
     t0 = time.perf_counter()
     r = solver.advance(timed_steps)
     dev.call("synchronize")
@@ -207,6 +210,7 @@ def main():
     assert r["status"] == 0 and steps_done == timed_steps, (r["status_name"], steps_done)
     its_per_s = timed_steps / elapsed
     attempts = r["attempted_steps"]
+    timed_attempts = attempts - attempts_before  # rejected attempts cost a full set of kernels too
 
     # ---- per-kernel timing with HIP events on the solver stream (dominant kernel -> roofline) --------
     r0, r1 = solver.row_range()
@@ -254,6 +258,17 @@ def main():
                     traffic_source=None if traffic is None else
                     "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                     "(scripts/r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
+    # Guard (round-3 review): the four kernels of an attempt, each timed on its own, must add up to the time of an attempt as the timed
+    # region saw it (the rest is the amortised major-iteration work and the graph's launch gaps).  A call site whose launches are not
+    # all summed (a multi-launch layout timed as one phase), or a timed region that skipped work, shows up here.
+    per_attempt_ms = 1e3 * elapsed / max(timed_attempts, 1)
+    ksum = sum(kernels[k] for k in ("PRIMAL", "SPMV_A_DUAL", "SPMV_AT_STEP", "STEP_DECISION"))
+    roofline["attempt_kernels_ms"] = round(ksum, 5)
+    roofline["ms_per_attempt"] = round(per_attempt_ms, 5)
+    roofline["attempt_kernels_over_ms_per_attempt"] = round(ksum / per_attempt_ms, 4)
+    if world == 1 and args.workload == "c3":  # the headline line is refused outright; the other workloads carry the ratio
+        assert 0.85 <= ksum / per_attempt_ms <= 1.05, \
+            "per-kernel times (%.5f ms) do not add up to the attempt (%.5f ms): %r" % (ksum, per_attempt_ms, kernels)
     solver.close()
 
     # ---- run to the default 1e-4 termination: wall clock incl. setup -----------------------------------

@@ -821,7 +821,7 @@ class Device:
         return out
 
     def layout(self):
-        out = np.zeros(6, np.int32)
+        out = np.zeros(8, np.int32)
         self._ck(lib.pdlpdev_layout_info(self.handle, _ptr(out)))
         names = {0: "stream", 1: "panel", 2: "resident", 3: "jag", 4: "pb"}
 
@@ -833,6 +833,8 @@ class Device:
                 d["padding_pct"] = int(out[k + 2])  # gather-free layout: padded entries over nonzeros - 1, in percent (workgroups = bins)
             else:
                 d["slabs"] = int(out[k + 2])
+                if out[k] == 1:
+                    d["row_sums"] = "by_nonzero" if out[6 + k // 3] else "by_row"  # by_nonzero: the long-tail variant (every row at rtol)
             return d
         return dict(A=side(0), At=side(3), resident=bool(out[0] == 2))
 

@@ -733,13 +733,15 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       int32_t status = 8, iterations = 0;
       double objective = 0.0, seconds = 0.0;
       std::vector<double> x, y, rc;
-      volatile int32_t cancel = 0;
+      int32_t cancel = 0;  // written / read through the atomic builtins only (the engine's C interface takes a plain int32_t*)
+      void set_cancel(int32_t v) { __atomic_store_n(&cancel, v, __ATOMIC_RELEASE); }
+      bool cancelled() const { return __atomic_load_n(&cancel, __ATOMIC_ACQUIRE) != 0; }
       std::atomic<int> done{0};
       bool conclusive() const { return status == 1 || status == 2 || status == 3; }
     } sx;
+    if (engine_on || s->crossover) sx.x.assign(p->n, 0.0), sx.y.assign(p->m, 0.0), sx.rc.assign(p->n, 0.0);  // (before any thread exists)
     auto run_simplex = [&](double tlim, int32_t itlim, const double* from_x = nullptr, const double* from_y = nullptr) {
       const auto t0 = std::chrono::steady_clock::now();
-      sx.x.assign(p->n, 0.0), sx.y.assign(p->m, 0.0), sx.rc.assign(p->n, 0.0);
       if (tlim <= 0.0 || itlim <= 0) {  // no budget at all: the limit is the verdict (0 means "none" to the engine's own interface)
         sx.status = tlim <= 0.0 ? 6 : 5;
         sx.done.store(1);
@@ -761,9 +763,11 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       engine_answered = sx.conclusive() || sx.status == 5 || sx.status == 6;  // its own limits count as its answer
     }
     const bool racing        = engine_on && s->method == CUOPT_METHOD_CONCURRENT;
-    const bool simplex_grade = other_method && grade_on && gpus == 1 && p->values.size() <= 100000 && !racing && !engine_answered;
+    // (also while racing: a simplex that abstains on a small LP leaves the request to PDLP at simplex-grade tolerances, as before round 3)
+    const bool simplex_grade = other_method && grade_on && gpus == 1 && p->values.size() <= 100000 && !engine_answered;
     st.iteration_limit         = s->iteration_limit;
-    st.time_limit              = s->time_limit;
+    // a simplex that used part of the caller's time and then abstained: PDLP gets what is left of it
+    st.time_limit              = engine_ran && std::isfinite(s->time_limit) ? std::max(1e-3, s->time_limit - sx.seconds) : s->time_limit;
     st.per_constraint_residual = s->per_constraint_residual;
     st.first_primal_feasible   = s->first_primal_feasible;
     // a simplex would prove infeasibility / unboundedness: the emulation runs PDLP WITH its infeasibility detection
@@ -843,20 +847,29 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       }
       if (racing) {
         // Concurrent: the simplex on a host thread, PDLP here in batches of a few major iterations; the first verdict wins
-        std::thread worker([&] { run_simplex(s->time_limit, s->iteration_limit); });
+        std::thread worker([&] {
+          try {
+            run_simplex(s->time_limit, s->iteration_limit);
+          } catch (...) {  // (the engine's entry points catch their own; nothing may leave a thread)
+            sx.status = 7;
+            sx.done.store(1);
+          }
+        });
         for (;;) {
           if (sx.done.load() && sx.conclusive()) break;
           rc = cuoptamd_solver_advance(solver, 400, &res);
           if (rc != 0 || res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION) break;
         }
         const bool pdlp_done = rc == 0 && res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION;
-        if (pdlp_done && !(sx.done.load() && sx.conclusive())) sx.cancel = 1;
+        // whenever the loop ends without a finished, conclusive simplex -- PDLP has its verdict, hit a limit, or FAILED -- the simplex
+        // is told to stop (round-3 advisor: after a failing advance the join used to wait for the simplex to finish on its own)
+        if (!(sx.done.load() && sx.conclusive())) sx.set_cancel(1);
         worker.join();
         engine_ran = sx.status != 8;
         // PDLP's Optimal / infeasibility verdicts stand; a limit or an error of PDLP's is overruled by a verdict of the simplex
         const bool pdlp_verdict = pdlp_done && (res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL || res.status == CUOPT_TERIMINATION_STATUS_INFEASIBLE ||
                                                 res.status == CUOPT_TERIMINATION_STATUS_UNBOUNDED);
-        if (rc == 0 && sx.conclusive() && !(pdlp_verdict && sx.cancel)) {
+        if (rc == 0 && sx.conclusive() && !(pdlp_verdict && sx.cancelled())) {
           engine_answered = true;
           cuoptamd_solver_destroy(solver);
           solver = nullptr;
@@ -900,7 +913,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     const char* crossover_by = "none";
     if (s->crossover && !engine_answered && gpus == 1 && res.status == CUOPT_TERIMINATION_STATUS_OPTIMAL && pdlpdev_device_count() >= 1 &&
         (s->dual_simplex >= 0 ? s->dual_simplex : env_int("CUOPT_AMD_DUAL_SIMPLEX", 1)) != 0) {
-      sx.cancel = 0;
+      sx.set_cancel(0);
       const std::vector<double> px(sol->x), py(sol->y);
       run_simplex(std::isfinite(s->time_limit) ? std::max(1e-3, s->time_limit - (res.setup_seconds + res.loop_seconds)) : s->time_limit, INT_MAX, px.data(), py.data());
       engine_ran = engine_ran || sx.status != 8;

@@ -32,6 +32,9 @@
 
 namespace {
 
+// the caller's cancel flag: written by another thread (a Concurrent solve), so every look at it is an atomic load
+inline bool flag_set(const volatile int32_t* flag) { return flag && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0; }
+
 constexpr double kInf = std::numeric_limits<double>::infinity();
 constexpr int kRefactorEvery = 100;  // pivots between factorisations at the latest (250 from 20 000 rows on: a factorisation walks all of them)
 
@@ -39,7 +42,7 @@ struct Cancelled {};  // thrown out of a factorisation when the other engine of 
 
 struct Simplex {
   int m = 0, n = 0, N = 0;
-  const volatile int32_t* cancel = nullptr;
+  const volatile int32_t* cancel = nullptr;  // the stop flag of the other engine: read through flag_set (an atomic load)
   const int32_t* rp = nullptr;  // rows of A: the caller's CSR
   const int32_t* rj = nullptr;
   const double* rv  = nullptr;
@@ -176,7 +179,7 @@ struct Simplex {
     // One column against the pivots found so far (left-looking, Gilbert-Peierls): its entries in U are appended to Ui / Ux,
     // what is left of it in the rows without a pivot stays in wx over `pattern`.  Returns the largest entry of the column itself.
     auto eliminate = [&](int j) {
-      if ((stamp & 255) == 0 && cancel && *cancel) throw Cancelled{};  // (a large nucleus can take seconds: the caller is waiting)
+      if ((stamp & 255) == 0 && flag_set(cancel)) throw Cancelled{};  // (a large nucleus can take seconds: the caller is waiting)
       const int st = stamp++;
       pattern.clear();
       auto touch = [&](int i) {
@@ -300,7 +303,7 @@ struct Simplex {
       std::vector<Entry> lmul;
       int polls = 0;
       while (!bycount.empty() && k < m) {
-        if ((++polls & 63) == 0 && cancel && *cancel) throw Cancelled{};
+        if ((++polls & 63) == 0 && flag_set(cancel)) throw Cancelled{};
         int pc = -1, pr = -1;
         double pval = 0.0;
         int64_t pcost = std::numeric_limits<int64_t>::max();
@@ -764,7 +767,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   gather();
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
-    if (cancel && *cancel) return 9;  // the other engine of a Concurrent solve has finished
+    if (flag_set(cancel)) return 9;  // the other engine of a Concurrent solve has finished
     if ((S.iterations & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
     // leaving position: the largest primal infeasibility, squared over its steepest-edge weight.  A position whose violation is
     // within 1e-6 and that has no entering candidate is rounding, not a proof of infeasibility (the box bounds put values of 1e6
@@ -838,8 +841,28 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
         rebuild();
         continue;
       }
+      // The row bounds z_p over the box: z_p + sum_j |alpha_j| * (room of j in its helping direction) stays short of the violated
+      // bound.  That is a proof for the LP itself only if it does not rest on an ARTIFICIAL bound: the violated bound of p and the
+      // bound every helping nonbasic variable is stopped by must be bounds of the LP (round-3 advisor: min x s.t. 1e-7 x >= 1 was
+      // "infeasible" inside the 1e5 box).  Resting on the box -> 10: the caller widens the box or abstains.  Entries below the pivot
+      // tolerance were left out of the ratio test; if what they could still add reaches the violation, the row proves nothing -> 7.
+      bool on_box  = to_low ? S.boxedL[p] != 0 : S.boxedU[p] != 0;
+      double reach = 0.0;
+      for (int j : touched) {
+        const double a = sigma * alpha[j];
+        if (a == 0.0) continue;
+        const bool up     = a < 0.0;  // the direction of j that moves z_p towards its bound
+        const double room = up ? S.U[j] - S.z[j] : S.z[j] - S.L[j];
+        const bool boxed  = up ? S.boxedU[j] != 0 : S.boxedL[j] != 0;
+        // a helping direction that only the box ends (at the bound already, or -- an entry under the pivot tolerance -- on its way
+        // there): in the LP itself that variable moves z_p as far as it likes.  (1e-12 amax: above the rounding of the row.)
+        if (boxed && std::fabs(a) > 1e-12 * amax) on_box = true;
+        if (room > 0.0) reach += std::fabs(a) * room;  // (only entries under the pivot tolerance still have room)
+      }
       if (S.debug)
-        std::fprintf(stderr, "[simplex] infeasible position %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol);
+        std::fprintf(stderr, "[simplex] infeasible position %d var %d value %.12g bounds [%.6g, %.6g] amax %.3g ptol %.3g: rests on the box %d, reach of the small entries %.3g of %.3g\n", r, p, S.z[p], S.L[p], S.U[p], amax, ptol, (int)on_box, reach, worst_inf);
+      if (on_box) return 10;
+      if (reach >= 0.5 * worst_inf) return 7;
       return 2;
     }
     int q        = -1;
@@ -947,7 +970,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
   int64_t extra_ops = 0;
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
-    if (cancel && *cancel) return 9;
+    if (flag_set(cancel)) return 9;
     if ((S.iterations & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
     // entering variable
     int q = -1;
@@ -1057,7 +1080,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
 // vertex): what is outside its bounds gets the bound moved to where it is, the PRIMAL simplex pivots to an optimal basis for
 // those bounds, the bounds go back, and the caller's dual simplex removes what infeasibility that leaves.
 // Returns the primal simplex's status (1: the basis is dual feasible for the true bounds).
-int start_from_point(Simplex& S, const double* x0, const double* y0, double sense, int iteration_limit, double time_limit,
+int start_from_point(Simplex& S, const double* x0, const double* y0, double /*sense*/, int iteration_limit, double time_limit,
                      const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
 {
   const int m = S.m, n = S.n, N = S.N;
@@ -1074,7 +1097,7 @@ int start_from_point(Simplex& S, const double* x0, const double* y0, double sens
   for (int j = 0; j < n; ++j) cmax = std::max(cmax, std::fabs(S.g[j]));
   if (y0) {
     std::vector<double> yi(m);
-    for (int i = 0; i < m; ++i) yi[i] = sense * y0[i], d0[n + i] = yi[i];
+    for (int i = 0; i < m; ++i) yi[i] = y0[i], d0[n + i] = yi[i];  // (y0: duals of the converted minimisation, like every dual this library returns)
     for (int j = 0; j < n; ++j) d0[j] = S.g[j] - S.col_dot(yi.data(), j);
   }
   std::vector<std::pair<double, int>> inside;
@@ -1146,7 +1169,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   }
   // columns of A
   // (the other engine of a Concurrent solve may be done before this one has even copied the matrix: the flag is looked at here too)
-  auto cancelled = [&] { return cancel && *cancel; };
+  auto cancelled = [&] { return flag_set(cancel); };
   S.cp.assign(n + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) {
     if ((k & 0xFFFFF) == 0 && cancelled()) { *status = 9; return 0; }
@@ -1178,6 +1201,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   int code        = 7;
   std::vector<double> first_z, first_y, first_d;  // the vertex of the first (smaller) box, kept while the second one is tried
   std::vector<int> first_pos;
+  bool have_first = false;
   if (time_limit <= 0.0 || !std::isfinite(time_limit)) time_limit = 1e30;
   if (iteration_limit <= 0) iteration_limit = std::numeric_limits<int32_t>::max();
   const bool debug = cuopt_amd::tune_int("simplex_debug", 0) != 0;
@@ -1243,6 +1267,10 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       if (pass == 3) code = 7;
     }
     if (iterations) *iterations = total_iterations;
+    if (code == 10) {  // "infeasible" only because of the artificial box: the wider one decides, from the same basis; after that: abstain
+      if (attempt == 0) continue;
+      code = 7;
+    }
     if (code != 1) break;
     // does the vertex lean on a box bound?
     bool leans = false;
@@ -1267,9 +1295,34 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       //   calls that LP optimal, HiGHS unbounded): this engine abstains (numerical trouble) and the caller's PDLP answers
       double cmax = 0.0;
       for (int j = 0; j < n; ++j) cmax = std::max(cmax, std::fabs(S.g[j]));
+      if (!have_first) {  // the smaller box ended without a vertex: nothing to compare with
+        code = 7;
+        break;
+      }
       const double rate = (prev_obj - obj) / (big * std::max(cmax, 1e-300));
       if (rate > 1e-4) {
-        code = 3;
+        // Unbounded only with a certificate: the direction between the two vertices must be a ray of the LP itself -- no finite
+        // bound of a variable or a row in its way, the objective falling along it.  Otherwise (an optimum beyond the wider box, for
+        // instance) the engine abstains and PDLP answers.
+        // The direction: how this basis' vertex moves when the box grows (the nonbasic variables on artificial bounds follow it, the
+        // basic ones answer linearly) -- an exact derivative, so the test can be strict (1e-12): 1e-9 x <= 1 stops x at 1e9.
+        const std::vector<double> z_at(S.z);
+        for (int j = 0; j < S.N; ++j)
+          if (S.pos[j] < 0 && (S.atU[j] ? S.boxedU[j] : S.boxedL[j])) S.z[j] = 2.0 * z_at[j];
+        S.recompute();
+        std::vector<double> dir(S.N);
+        double dmax = 0.0, cd = 0.0;
+        for (int j = 0; j < S.N; ++j) dir[j] = (S.z[j] - z_at[j]) / big, dmax = std::max(dmax, std::fabs(dir[j]));
+        S.z = z_at;
+        S.recompute();
+        bool ray = dmax > 0.0;
+        for (int j = 0; j < S.N && ray; ++j) {
+          const double dj = dir[j] / dmax;
+          if (!S.boxedL[j] && dj < -1e-12) ray = false;
+          if (!S.boxedU[j] && dj > 1e-12) ray = false;
+          if (j < n) cd += S.g[j] * dj;
+        }
+        code = ray && cd < -1e-9 * std::max(cmax, 1e-300) ? 3 : 7;
       } else if (rate < 1e-12) {
         S.z = first_z, S.y = first_y, S.d = first_d, S.pos = first_pos;
       } else {
@@ -1277,7 +1330,7 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
       }
       break;
     }
-    prev_obj = obj;
+    prev_obj = obj, have_first = true;
     first_z = S.z, first_y = S.y, first_d = S.d, first_pos = S.pos;
   }
   *status = code;
@@ -1288,11 +1341,13 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
     for (int j = 0; j < n; ++j) obj += lp->c[j] * S.z[j];
     if (objective) *objective = obj + lp->objective_offset;
     if (x) std::copy(S.z.begin(), S.z.begin() + n, x);
-    // duals / reduced costs of the user's problem (a maximisation was solved as the minimisation of -c)
+    // duals / reduced costs of the CONVERTED minimisation (a maximisation is solved as the minimisation of -c), unflipped: the
+    // convention of the reference's two engines (dual_simplex/solve.cpp:256 hands lp_solution.y on as it is) and of the PDLP path
+    // here (pdlp_solver.cpp negates c on the host and returns y, rc of that problem) -- one sign whichever engine answers
     if (y)
-      for (int i = 0; i < m; ++i) y[i] = sense * S.y[i];
+      for (int i = 0; i < m; ++i) y[i] = S.y[i];
     if (rc)
-      for (int j = 0; j < n; ++j) rc[j] = sense * (S.pos[j] >= 0 ? 0.0 : S.d[j]);
+      for (int j = 0; j < n; ++j) rc[j] = S.pos[j] >= 0 ? 0.0 : S.d[j];
   }
   return 0;
 }

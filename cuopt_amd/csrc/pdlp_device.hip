@@ -1291,6 +1291,7 @@ static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_
 }
 
 // panel-layout twins of (2) and (3): same epilogues, slab-major gather (pdlp_kernels.hpp)
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
                double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
@@ -1301,9 +1302,10 @@ k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* _
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0, ycopy, push};
-  panel_spmv_block(P, xbar, e, part);
+  panel_block<SEG>(P, xbar, e, part);
   if (push) p2pdev::publish(push);
 }
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
                 const double* __restrict__ y1, const double* __restrict__ x0,
@@ -1313,7 +1315,7 @@ k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* 
   if (!loop_active(ctl)) return;
   const int cur = ctl->cur;
   StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  panel_spmv_block(P, cur ? y0 : y1 /* y' */, e, part);
+  panel_block<SEG>(P, cur ? y0 : y1 /* y' */, e, part);
 }
 // jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column sets
 template <int WAVES>
@@ -1535,6 +1537,7 @@ k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
   csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr, dadd);
 }
 // panel twin of k_spmv_at_cur (A^T y of the iterate / of the trial iterate, optionally into `out_override`)
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_at_cur(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
                const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
@@ -1542,13 +1545,14 @@ k_panel_at_cur(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* _
 {
   const int cur = ctl->cur ^ (use_next ? 1 : 0);
   StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  panel_spmv_block(P, cur ? y1 : y0, e, nullptr);
+  panel_block<SEG>(P, cur ? y1 : y0, e, nullptr);
 }
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_plain(PanelView P, const double* __restrict__ vec, double* __restrict__ out)
 {
   StoreEpilogue e{out};
-  panel_spmv_block(P, vec, e, nullptr);
+  panel_block<SEG>(P, vec, e, nullptr);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -1727,6 +1731,7 @@ k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ 
   EvalDualEpilogue e{core};
   csr_stream_block(nb, rb, off, idx, val, yv, e, part, dadd);
 }
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
                     const double* __restrict__ x0, const double* __restrict__ x1,
@@ -1740,8 +1745,9 @@ k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
   const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  panel_spmv_block(P, xv, e, part);
+  panel_block<SEG>(P, xv, e, part);
 }
+template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
 k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
                   const double* __restrict__ x0, const double* __restrict__ x1,
@@ -1753,7 +1759,7 @@ k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
   core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalDualEpilogue e{core};
-  panel_spmv_block(P, yv, e, part);
+  panel_block<SEG>(P, yv, e, part);
 }
 __global__ void __launch_bounds__(kPbThreads)
 k_pb_eval_primal(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
@@ -2173,6 +2179,8 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 // ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
 struct PanelHost {
   bool ok = false, any_long = false;
+  bool seg = false;                        // long-tail variant: lane-major chunks, packed (row, column), no row pointers (panel_seg_block)
+  int32_t slab_w = 0;
   int W = 0, S = 0;                        // W: panels only
   std::vector<int32_t> own_row, own_ptr;   // rows of more than kPanelOwnRow nonzeros (a workgroup each, behind the panels); per panel
   std::vector<int32_t> row0, tile_ptr;
@@ -2262,8 +2270,18 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
     cut(tgt);
   }
   const int W = (int)P.row0.size() - 1;
-  P.W = W, P.S = S;
-  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
+  P.W = W, P.S = S, P.slab_w = slab_w;
+  int64_t long_nnz = 0;  // nonzeros in rows the row-per-lane kernel sums wave by wave
+  for (int32_t i = 0; i < rows; ++i)
+    if (!is_own[i] && off[i + 1] - off[i] > kLongRow) P.any_long = true, long_nnz += off[i + 1] - off[i];
+  // Long-tailed row lengths: row sums dealt by nonzero (panel_seg_block; every row at rtol 1e-12 instead of bit-exact short rows).
+  // auto: when more than 2 % of the panels' nonzeros sit in rows of more than kLongRow entries -- a structural, reproducible rule;
+  // CUOPT_AMD_TUNE=panel_seg=0|1 forces it off / on (tests, sweeps).
+  {
+    const long long want = cuopt_amd::tune_int("panel_seg", -1);
+    P.seg = want == 1 || (want != 0 && long_nnz * 50 > nnz - own_nnz);
+    if (slab_w > (1 << kSegColBits)) P.seg = false;
+  }
   P.own_ptr.assign((size_t)W + 1, 0);
   for (int w = 0, q = 0; w < W; ++w) {
     while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;
@@ -2286,8 +2304,40 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   P.tile_ptr[(size_t)W * S] = (int32_t)pos;
   // pass 2: placement + per-tile row pointers
-  P.nnz = (size_t)(nnz - own_nnz), P.rowptr_size = (size_t)S * ((size_t)rows + W);
+  P.nnz = (size_t)(nnz - own_nnz), P.rowptr_size = P.seg ? 0 : (size_t)S * ((size_t)rows + W);
   P.perm.reset(P.nnz), P.col.reset(P.nnz);
+  if (P.seg) {
+    // placement in (slab, row, CSR) order as below, every entry carrying its row within the panel; then each chunk of <= kPanelChunk
+    // entries of a tile is re-dealt lane-major: with R = ceil(len / 512) rounds, lane t owns the consecutive entries [t R, t R + R) and
+    // entry u of lane t sits in round u, after the entries of the lanes before it (round u holds a prefix of the lanes: no padding)
+    cuopt_amd::parallel_tasks(W, [&](int w) {
+      const int32_t a = P.row0[w], b = P.row0[w + 1];
+      std::vector<int32_t> cursor(S);
+      for (int s2 = 0; s2 < S; ++s2) cursor[s2] = P.tile_ptr[(size_t)w * S + s2];
+      for (int32_t i = a; i < b; ++i) {
+        if (is_own[i]) continue;
+        for (int32_t t = off[i]; t < off[i + 1]; ++t) {
+          const int s2    = idx[t] / slab_w;
+          const int32_t q = cursor[s2]++;
+          P.perm[q] = t, P.col[q] = (int32_t)(((uint32_t)(i - a) << kSegColBits) | (uint32_t)(idx[t] - s2 * slab_w));
+        }
+      }
+      int32_t tp[kPanelChunk], tc[kPanelChunk];
+      for (int s2 = 0; s2 < S; ++s2)
+        for (int32_t c0 = P.tile_ptr[(size_t)w * S + s2], c1 = P.tile_ptr[(size_t)w * S + s2 + 1]; c0 < c1; c0 += kPanelChunk) {
+          const int len = std::min<int32_t>(kPanelChunk, c1 - c0), R = (len + kPanelThreads - 1) / kPanelThreads;
+          if (R == 1) continue;  // one entry per lane: already in place
+          int base[kPanelPer + 1];
+          base[0] = 0;
+          for (int u = 0; u < R; ++u) base[u + 1] = base[u] + (len - u + R - 1) / R;
+          for (int l = 0; l < len; ++l) tp[base[l % R] + l / R] = P.perm[c0 + l], tc[base[l % R] + l / R] = P.col[c0 + l];
+          std::copy(tp, tp + len, &P.perm[c0]);
+          std::copy(tc, tc + len, &P.col[c0]);
+        }
+    }, nnz);
+    P.ok = true;
+    return P;
+  }
   P.rowptr.reset(P.rowptr_size);
   P.rp_base.resize((size_t)W * S);
   cuopt_amd::parallel_tasks(W, [&](int w) {
@@ -2944,6 +2994,7 @@ static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHo
   TRY(dev_alloc(c, &dst->val, h.nnz));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
   dst->v  = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
+  dst->v.seg = h.seg ? 1 : 0, dst->v.slab_w = h.slab_w;
   dst->nent = (int64_t)h.nnz;
   if (!h.own_row.empty()) {  // W becomes the number of workgroups / partials: the panels, then a workgroup per own row
     int32_t *own_row = nullptr, *own_ptr = nullptr;
@@ -2997,7 +3048,7 @@ static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb
         if (which == 0)
           k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out, (const double*)nullptr);
         else
-          k_panel_plain<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
+          (pn->v.seg ? k_panel_plain<true> : k_panel_plain<false>)<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
       }
       HIP_TRY(hipEventRecord(e1, c->stream));
       HIP_TRY(hipEventSynchronize(e1));
@@ -4172,7 +4223,7 @@ static void launch_a_dual(pdlpdev_ctx* ctx, double* ycopy = nullptr, const p2pde
   } else if (ctx->ja.on)
     (void)JAG_LAUNCH(ctx, k_jag_a_dual, ctx->ja.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else if (ctx->pa.on)
-    launch_k(ctx, k_panel_a_dual, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
+    launch_k(ctx, ctx->pa.v.seg ? k_panel_a_dual<true> : k_panel_a_dual<false>, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push);
   else
     launch_k(ctx, k_spmv_a_dual, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, ctx->xbar, ctx->y[0], ctx->y[1], ctx->lo, ctx->hi, ctx->sumy, ctx->part_a, ycopy, push, ctx->dense.add_m);
 }
@@ -4185,7 +4236,7 @@ static void launch_at_step(pdlpdev_ctx* ctx)
   } else if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else if (ctx->pat.on)
-    launch_k(ctx, k_panel_at_step, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
+    launch_k(ctx, ctx->pat.v.seg ? k_panel_at_step<true> : k_panel_at_step<false>, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at);
   else
     launch_k(ctx, k_spmv_at_step, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->part_at, ctx->dense.add_n);
 }
@@ -4198,7 +4249,7 @@ static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next)
   } else if (ctx->jat.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_cur, ctx->jat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else if (ctx->pat.on)
-    launch_k(ctx, k_panel_at_cur, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
+    launch_k(ctx, ctx->pat.v.seg ? k_panel_at_cur<true> : k_panel_at_cur<false>, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next);
   else
     launch_k(ctx, k_spmv_at_cur, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, ctx->y[0], ctx->y[1], ctx->aty[0], ctx->aty[1], out_override, use_next, ctx->dense.add_n);
 }
@@ -4213,7 +4264,7 @@ static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, dou
     } else if (ctx->jat.on)
       (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->jat.v, vec, out);
     else if (ctx->pat.on)
-      launch_k(ctx, k_panel_plain, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, vec, out);
+      launch_k(ctx, ctx->pat.v.seg ? k_panel_plain<true> : k_panel_plain<false>, ctx->pat.v.W, kPanelThreads, 0, ctx->pat.v, vec, out);
     else
       launch_k(ctx, k_spmv_plain, stream_grid(ctx->at_nb), kBlock, 0, ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, vec, out, ctx->dense.add_n);
   } else {
@@ -4223,7 +4274,7 @@ static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, dou
     } else if (ctx->ja.on)
       (void)JAG_LAUNCH(ctx, k_jag_plain, ctx->ja.v, vec, out);
     else if (ctx->pa.on)
-      launch_k(ctx, k_panel_plain, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, vec, out);
+      launch_k(ctx, ctx->pa.v.seg ? k_panel_plain<true> : k_panel_plain<false>, ctx->pa.v.W, kPanelThreads, 0, ctx->pa.v, vec, out);
     else
       launch_k(ctx, k_spmv_plain, stream_grid(ctx->a_nb), kBlock, 0, ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, vec, out, ctx->dense.add_m);
   }
@@ -4242,7 +4293,7 @@ static void launch_oc_step(pdlpdev_ctx* ctx)
   if (ctx->joc.on)
     (void)JAG_LAUNCH(ctx, k_jag_at_step, ctx->joc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
   else if (ctx->poc.on)
-    launch_k(ctx, k_panel_at_step, ctx->poc.v.W, kPanelThreads, 0, ctx->poc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
+    launch_k(ctx, ctx->poc.v.seg ? k_panel_at_step<true> : k_panel_at_step<false>, ctx->poc.v.W, kPanelThreads, 0, ctx->poc.v, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc);
   else
     launch_k(ctx, k_spmv_at_step, stream_grid(ctx->oc_nb), kBlock, 0, ctx->oc_nb, ctx->oc_rb, ctx->oc_off, ctx->oc_idx, ctx->oc_val, ctx->ctl, yg, yg, x0, x1, t0, t1, ctx->part_oc, (const double*)nullptr);
 }
@@ -4531,7 +4582,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   } else if (ctx->ja.on)
     (void)JAG_LAUNCH(ctx, k_jag_eval_primal, ctx->ja.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else if (ctx->pa.on)
-    k_panel_eval_primal<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
+    (ctx->pa.v.seg ? k_panel_eval_primal<true> : k_panel_eval_primal<false>)<<<ctx->pa.v.W, kPanelThreads, 0, s>>>(ctx->pa.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a);
   else
     k_eval_primal<<<stream_grid(ctx->a_nb), kBlock, 0, s>>>(ctx->a_nb, ctx->a_rb, ctx->ha_off, ctx->ha_idx, ctx->ha_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, ctx->dr, ctx->lo_u, ctx->hi_u, eps_rel_primal, linf_m, ctx->ax_u[which], ctx->part_a, ctx->dense.add_m);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_a, dual_partials(ctx), 3, 0u, sc + 0);
@@ -4551,7 +4602,7 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
     } else if (ctx->jat.on)
       (void)JAG_LAUNCH(ctx, k_jag_eval_dual, ctx->jat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else if (ctx->pat.on)
-      k_panel_eval_dual<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
+      (ctx->pat.v.seg ? k_panel_eval_dual<true> : k_panel_eval_dual<false>)<<<ctx->pat.v.W, kPanelThreads, 0, s>>>(ctx->pat.v, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at);
     else
       k_eval_dual<<<stream_grid(ctx->at_nb), kBlock, 0, s>>>(ctx->at_nb, ctx->at_rb, ctx->hat_off, ctx->hat_idx, ctx->hat_val, ctx->ctl, kw, ctx->x[0], ctx->x[1], altx, ctx->y[0], ctx->y[1], alty, core, ctx->part_at, ctx->dense.add_n);
     k_finalize<<<1, kBlock, 0, s>>>(ctx->part_at, step_partials(ctx), 4, 0u, sc + 4);
@@ -5004,7 +5055,7 @@ int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3])
   out[0] = ctx->dense.on ? 1 : 0, out[1] = ctx->dense.nseg, out[2] = ctx->dense.nent;
   return 0;
 }
-int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
+int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[8])
 {
   // per matrix: layout (0 CSR stream, 1 slab-major panels, 2 resident single-workgroup loop, 3 jagged rows + LDS column
   // sets), workgroups, slabs (panels) or percent of the global gathers the LDS sets save (jagged)
@@ -5014,6 +5065,7 @@ int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6])
   out[3] = ctx->pbat.on ? 4 : ctx->jat.on ? 3 : ctx->pat.on ? 1 : 0;
   out[4] = ctx->pbat.on ? ctx->pbat.v.B : ctx->jat.on ? ctx->jat.v.nblk : ctx->pat.on ? ctx->pat.v.W : ctx->at_nb;
   out[5] = ctx->pbat.on ? (int)(100.0 * (ctx->pbat.pad - 1.0) + 0.5) : ctx->jat.on ? (int)(100.0 * ctx->jat.saving + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
+  out[6] = ctx->pa.on && ctx->pa.v.seg, out[7] = ctx->pat.on && ctx->pat.v.seg;  // panels: the long-tail variant (row sums by nonzero)
   if (ctx->small_resident) out[0] = out[3] = 2;
   return 0;
 }

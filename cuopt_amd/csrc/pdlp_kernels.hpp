@@ -293,6 +293,9 @@ struct PanelView {
   const int32_t* __restrict__ col;       // permuted column indices
   const double* __restrict__ val;        // permuted values
   const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
+  // Long-tail variant (panel_seg_block below): `col` holds (row within the panel) << kSegColBits | (column - slab * slab_w), the entries of a
+  // chunk are stored lane-major (lane t's consecutive entries one per round), and there are no row pointers
+  int seg = 0, slab_w = 0;
   // Rows of more than kPanelOwnRow nonzeros are not in the panels: each gets a workgroup of its own BEHIND the panels in the same
   // grid (W = NP panels + the own rows; a 20 000-entry row inside a panel is one wave adding up 3 000-entry segments while seven
   // waves wait, and that panel sets the kernel time).  They are read from the CSR arrays the layout was built on.
@@ -354,6 +357,64 @@ __device__ __forceinline__ void panel_products(const double* __restrict__ vec, d
     default: CALL(8); break;          \
   }
 
+// ---- a row of its own (more than kPanelOwnRow nonzeros): the whole workgroup strides over it, 16 entries per thread in flight
+// (fixed tree, compared with a tolerance like every long row)
+template <class Epi>
+__device__ __forceinline__ void panel_own_row(const PanelView& P, const double* __restrict__ vec, Epi& epi, double* __restrict__ partials,
+                                              int w, int NP, double* scratch /* >= kPanelWaves doubles of LDS */)
+{
+  const int r  = P.own_row[w - NP];
+  const int k0 = P.csr_off[r], k1 = P.csr_off[r + 1];
+  double part[1] = {0.0};
+  constexpr int kLongU = 16;
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += kLongU * kPanelThreads) {
+    double a[kLongU];
+    int j[kLongU];
+#pragma unroll
+    for (int u = 0; u < kLongU; ++u) {
+      a[u] = 0.0, j[u] = 0;
+      if (k + u * kPanelThreads < k1) {
+        a[u] = __builtin_nontemporal_load(P.csr_val + k + u * kPanelThreads);
+        j[u] = __builtin_nontemporal_load(P.csr_idx + k + u * kPanelThreads);
+      }
+    }
+    double xv[kLongU];
+#pragma unroll
+    for (int u = 0; u < kLongU; ++u) xv[u] = k + u * kPanelThreads < k1 ? vec[j[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
+  }
+  block_reduce<SumOp, 1, kPanelWaves>(part, scratch);
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+  if (threadIdx.x == 0) {
+    epi.row(r, dense_plus(P.dense_add, r, part[0]), acc);
+    if constexpr (Epi::NQ > 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
+    }
+  }
+}
+// the fused epilogue over a panel's rows, natural order, from the row sums in LDS
+template <class Epi>
+__device__ __forceinline__ void panel_epilogue(const PanelView& P, Epi& epi, double* __restrict__ partials, const double* psum, double* red,
+                                               int w, int r0, int nr)
+{
+  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads)
+    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
+  if constexpr (Epi::NQ > 0) {
+    block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
+    }
+  }
+}
+
 template <class Epi>
 __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const double* __restrict__ vec,
                                                  Epi& epi, double* __restrict__ partials)
@@ -367,40 +428,7 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
   const int w  = blockIdx.x;
   const int NP = P.NP ? P.NP : P.W;
   if (w >= NP) {
-    // ---- a row of its own: the whole workgroup strides over it, 16 entries per thread in flight (fixed tree, compared with a
-    // tolerance like every long row)
-    const int r  = P.own_row[w - NP];
-    const int k0 = P.csr_off[r], k1 = P.csr_off[r + 1];
-    double part[1] = {0.0};
-    constexpr int kLongU = 16;
-    for (int k = k0 + (int)threadIdx.x; k < k1; k += kLongU * kPanelThreads) {
-      double a[kLongU];
-      int j[kLongU];
-#pragma unroll
-      for (int u = 0; u < kLongU; ++u) {
-        a[u] = 0.0, j[u] = 0;
-        if (k + u * kPanelThreads < k1) {
-          a[u] = __builtin_nontemporal_load(P.csr_val + k + u * kPanelThreads);
-          j[u] = __builtin_nontemporal_load(P.csr_idx + k + u * kPanelThreads);
-        }
-      }
-      double xv[kLongU];
-#pragma unroll
-      for (int u = 0; u < kLongU; ++u) xv[u] = k + u * kPanelThreads < k1 ? vec[j[u]] : 0.0;
-#pragma unroll
-      for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
-    }
-    block_reduce<SumOp, 1, kPanelWaves>(part, prod);
-    double acc[Epi::NQ > 0 ? Epi::NQ : 1];
-#pragma unroll
-    for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
-    if (threadIdx.x == 0) {
-      epi.row(r, dense_plus(P.dense_add, r, part[0]), acc);
-      if constexpr (Epi::NQ > 0) {
-#pragma unroll
-        for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
-      }
-    }
+    panel_own_row(P, vec, epi, partials, w, NP, prod);
     return;
   }
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
@@ -456,6 +484,9 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
     nxt = advance(cur);
     PANEL_REQUEST(nxt)  // in flight during the row sums below
     __syncthreads();
+#ifdef X_ROW_NOSUM
+    { psum[threadIdx.x] = psum[threadIdx.x] + prod[threadIdx.x]; cur = nxt; continue; }
+#endif
     if (!P.any_long) {  // (uniform) the common case: no extra instruction in the loop
 #pragma unroll
       for (int q = 0; q < kPanelRowsPer; ++q) {
@@ -523,20 +554,252 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 #undef PANEL_CALL_LOAD
 #undef PANEL_ROUNDS
   __syncthreads();
-  double acc[Epi::NQ > 0 ? Epi::NQ : 1];
+  panel_epilogue(P, epi, partials, psum, red, w, r0, nr);
+}
+// ------------------------------------------------------------------------------------------------
+// Long-tail variant of the panels: row sums dealt by NONZERO, not by row.
+// The panel kernel above gives every ROW of the panel a lane, which walks the row's segment of the staged chunk while its wave
+// waits for the longest one: on a matrix whose row lengths have a heavy tail (power law: 0.26 of the HBM roofline in round 3,
+// 21.6 M issue cycles against 14.0 M on the uniform matrix of the same size) that walk is what the kernel waits for.  Here
+//   * a lane owns R = ceil(len / 512) CONSECUTIVE entries of the chunk (stored lane-major by the host, so the loads stay one coalesced
+//     stream per round and nothing is staged through LDS), each carrying its row within the panel (12 bits) next to its column
+//     relative to the slab (20 bits): 12 bytes per nonzero and no row pointers at all;
+//   * the lane adds runs of equal rows left to right; a run that lies inside the lane goes straight to the row's LDS sum; the runs that
+//     cross lanes are joined by a segmented scan over the wave (fixed Hillis-Steele tree over ds_bpermute) and one 8-entry table of wave
+//     aggregates per chunk (one barrier per chunk instead of two);
+//   * rows that continue in the next chunk or the next slab simply meet again in the row's LDS sum.
+// The work of a chunk is the same whatever the row lengths are.  The additions of a row are no longer left to right across lanes:
+// this layout is compared with the oracle at rtol 1e-12 for EVERY row (the contract of rows > kLongRow in the other layouts), which is
+// why `auto` takes it only for long-tailed matrices (build_panels) and the uniform ones keep their bit-exact kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSegColBits = 20;                     // slab width < 2^20 columns (1.33 MiB slabs: 174 763)
+constexpr unsigned kSegColMask = (1u << kSegColBits) - 1u;
+template <int R>
+__device__ __forceinline__ void seg_load(const PanelView& P, double (&va)[kPanelPer], int (&pk)[kPanelPer], int c0, int len)
+{
+  int base = c0;
 #pragma unroll
-  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
-  for (int r = threadIdx.x; r < nr; r += kPanelThreads)
-    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
-  if constexpr (Epi::NQ > 0) {
-    block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * P.W + w] = acc[q];
-    }
+  for (int u = 0; u < R; ++u) {
+    const int n_u = (len - u + R - 1) / R;  // lanes that own an entry in round u: a prefix
+    const int t   = (int)threadIdx.x < n_u ? (int)threadIdx.x : n_u - 1;
+    va[u]         = __builtin_nontemporal_load(P.val + base + t);
+    pk[u]         = __builtin_nontemporal_load(P.col + base + t);
+    base += n_u;
   }
 }
+// the gathers of a loaded chunk (requested a whole row-sum phase ahead of their use) and the rows of its entries
+template <int R>
+__device__ __forceinline__ void seg_gather(const double* __restrict__ vec, int slab_base, const int (&pk)[kPanelPer], double (&x)[kPanelPer], int (&rid)[kPanelPer])
+{
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    x[u]   = vec[slab_base + (int)((unsigned)pk[u] & kSegColMask)];
+    rid[u] = (int)((unsigned)pk[u] >> kSegColBits);
+  }
+}
+// products of the lane's entries; the slots behind the lane's last entry repeat its row with a zero product
+template <int R>
+__device__ __forceinline__ void seg_products(const double (&va)[kPanelPer], const double (&x)[kPanelPer], const int (&rid_in)[kPanelPer], int cnt,
+                                             double (&p)[kPanelPer], int (&rid)[kPanelPer])
+{
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    p[u]   = va[u] * x[u];
+    rid[u] = rid_in[u];
+    if (u > 0 && u >= cnt) p[u] = 0.0, rid[u] = rid[u - 1];
+  }
+#pragma unroll
+  for (int u = R; u < kPanelPer; ++u) p[u] = 0.0, rid[u] = rid[R - 1];
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double seg_dpp(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// inclusive sums over the wave's lanes, restarting at every lane >= seg0 (seg0: the first lane of this lane's segment): four row_shr
+// steps inside the 16-lane DPP rows, then the row totals through row_bcast:15 / row_bcast:31 -- VALU only, a fixed tree
+__device__ __forceinline__ double seg_scan(double S, int lane, int seg0)
+{
+  double u;
+  u = seg_dpp<0x111, 0xf>(S); if ((lane & 15) >= 1 && lane - 1 >= seg0) S = S + u;
+  u = seg_dpp<0x112, 0xf>(S); if ((lane & 15) >= 2 && lane - 2 >= seg0) S = S + u;
+  u = seg_dpp<0x114, 0xf>(S); if ((lane & 15) >= 4 && lane - 4 >= seg0) S = S + u;
+  u = seg_dpp<0x118, 0xf>(S); if ((lane & 15) >= 8 && lane - 8 >= seg0) S = S + u;
+  u = seg_dpp<0x142, 0xa>(S); if ((lane & 16) && (lane | 15) - 16 >= seg0) S = S + u;  // rows 1, 3 <- the last lane of rows 0, 2
+  u = seg_dpp<0x143, 0xc>(S); if (lane >= 32 && 31 >= seg0) S = S + u;                 // rows 2, 3 <- lane 31
+  return S;
+}
+// one emission per run and chunk, and never two lanes at one row inside a chunk (chunks are separated by a barrier): the LDS atomic is
+// used as a fire-and-forget add (no read - wait - write chain in the lane), the result is the plain sum in a fixed order
+__device__ __forceinline__ void seg_emit(double* psum, int row, double v)
+{
+#ifdef X_SEG_NOEMIT
+  if (row == 123456) psum[0] = v;
+  return;
+#endif
+  __hip_atomic_fetch_add(psum + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class Epi>
+__device__ __forceinline__ void panel_seg_block(const PanelView& P, const double* __restrict__ vec, Epi& epi, double* __restrict__ partials)
+{
+  static_assert(kPanelPer == 8, "PANEL_DISPATCH enumerates 1..8 rounds");
+  static_assert(kPanelMaxRows <= (1 << (32 - kSegColBits)), "row within the panel must fit beside the column");
+  __shared__ double psum[kPanelMaxRows];
+  __shared__ double red[kPanelWaves * (Epi::NQ > 0 ? Epi::NQ : 1)];
+  __shared__ double agg_v[2][kPanelWaves];      // per chunk parity and wave: sum of the wave's open run at its last lane ...
+  __shared__ int agg_i[2][kPanelWaves][4];      // ... whether a run ends inside the wave, its first and its last row
+  __shared__ int tile_s[17];
+  const int w  = blockIdx.x;
+  const int NP = P.NP ? P.NP : P.W;
+  if (w >= NP) {
+    panel_own_row(P, vec, epi, partials, w, NP, psum);
+    return;
+  }
+  const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
+  if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
+  __syncthreads();
+  if (P.own_ptr)
+    for (int q = P.own_ptr[w] + (int)threadIdx.x; q < P.own_ptr[w + 1]; q += kPanelThreads) psum[P.own_row[q] - r0] = __longlong_as_double(kPanelNotMine);
+  auto advance = [&](PanelChunk c) -> PanelChunk {
+    if (c.valid && c.c1 < tile_s[c.s + 1]) {
+      c.c0 = c.c1;
+      c.c1 = c.c0 + kPanelChunk < tile_s[c.s + 1] ? c.c0 + kPanelChunk : tile_s[c.s + 1];
+      return c;
+    }
+    int s = c.s + 1;
+    while (s < P.S && tile_s[s + 1] == tile_s[s]) ++s;
+    c.valid = s < P.S;
+    c.s     = s;
+    if (c.valid) {
+      c.t0 = c.c0 = tile_s[s];
+      c.c1 = c.c0 + kPanelChunk < tile_s[s + 1] ? c.c0 + kPanelChunk : tile_s[s + 1];
+    }
+    return c;
+  };
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Three chunks in flight: the matrix stream of chunk i + 2 and the GATHERS of chunk i + 1 are requested before the row sums of
+  // chunk i, so the scan / barrier / emission phase of a chunk runs under the memory round trips of the next one (the row-per-lane
+  // kernel above only has the stream in flight there).
+  double va[kPanelPer], vb[kPanelPer], x[kPanelPer], p[kPanelPer];
+  int pk[kPanelPer], rid_b[kPanelPer], rid[kPanelPer];
+#define SEG_ROUNDS(c) (((c).c1 - (c).c0 + kPanelThreads - 1) / kPanelThreads)
+#define SEG_CALL_LOAD(R) seg_load<R>(P, va, pk, cc.c0, cc.c1 - cc.c0)
+#define SEG_CALL_GATHER(R) seg_gather<R>(vec, cb.s * P.slab_w, pk, x, rid_b)
+#define SEG_CALL_PRODUCTS(R) seg_products<R>(vb, x, rid_b, cnt_b, p, rid)
+#define SEG_COUNT(c, R) ({ int n_ = ((c).c1 - (c).c0) - (int)threadIdx.x * (R); n_ < 0 ? 0 : n_ > (R) ? (R) : n_; })
+  PanelChunk none{-1, 0, 0, 0, false};
+  PanelChunk ca = none, cb = none, cc = advance(none);  // ca: being summed, cb: gathers in flight, cc: stream in flight
+  if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
+  // prologue: chunk 0 through load -> gather -> products, chunk 1 gathered, chunk 2 loading
+  cb = cc;
+  if (cb.valid) {
+    PANEL_DISPATCH(SEG_ROUNDS(cb), SEG_CALL_GATHER)
+#pragma unroll
+    for (int u = 0; u < kPanelPer; ++u) vb[u] = va[u];
+    cc = advance(cb);
+    if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
+  }
+  int parity = 0;
+  for (;;) {
+    // cb's gathers are (being) answered: its products become the chunk to sum; the next chunk's gathers go out at once
+    ca = cb;
+    if (!ca.valid) break;
+    const int len = ca.c1 - ca.c0, R = SEG_ROUNDS(ca);
+    const int cnt = SEG_COUNT(ca, R);
+    {
+      const int cnt_b = cnt;
+      PANEL_DISPATCH(R, SEG_CALL_PRODUCTS)
+    }
+    cb = cc;
+    if (cb.valid) {
+      PANEL_DISPATCH(SEG_ROUNDS(cb), SEG_CALL_GATHER)
+#pragma unroll
+      for (int u = 0; u < kPanelPer; ++u) vb[u] = va[u];
+      cc = advance(cb);
+      if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
+    }
+#ifdef X_SEG_NOSUM
+    { double t_ = 0.0;
+#pragma unroll
+      for (int u = 0; u < kPanelPer; ++u) t_ += p[u] + (double)rid[u];
+      psum[threadIdx.x] = psum[threadIdx.x] + t_; parity ^= 1; (void)cnt; (void)len; continue; }
+#endif
+    // (1) the lane's open run at its end: v = its sum inside the lane, closed = some run ends inside the lane
+    double v    = p[0];
+    bool closed = false;
+#pragma unroll
+    for (int u = 1; u < kPanelPer; ++u) {
+      const bool b = rid[u] != rid[u - 1];
+      closed |= b;
+      v = b ? p[u] : v + p[u];
+    }
+    if (cnt == 0) v = 0.0;
+    const int my_first = rid[0], my_last = rid[kPanelPer - 1];
+    int prev_last      = __builtin_amdgcn_update_dpp(0, my_last, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    // a lane starts a segment of the scan when a run ends inside it or at its left edge (lane 0: the edge is the wave's affair)
+    const bool flag = cnt > 0 && (closed || (lane > 0 && my_first != prev_last));
+    const unsigned long long fm = __ballot(flag);
+    const unsigned long long at_or_below = fm & ((2ull << lane) - 1ull);
+    const int seg0 = at_or_below ? 63 - __builtin_clzll(at_or_below) : 0;
+    const double S = seg_scan(v, lane, seg0);
+    double carry_in = seg_dpp<0x138, 0xf>(S);  // the open run that reaches this lane from the lanes before it (lane 0: from the waves before)
+    if (lane == 63) {
+      agg_v[parity][wave]    = S;
+      agg_i[parity][wave][0] = fm != 0ull;
+      agg_i[parity][wave][2] = my_last;
+    }
+    if (lane == 0) agg_i[parity][wave][1] = my_first;
+    __syncthreads();  // also: every emission of the previous chunk is done
+    // (2) what reaches this wave from the waves before it (every lane repeats the short fold: LDS broadcasts)
+    double c  = 0.0;
+    int lastk = my_first;  // wave 0: nothing before it -- "the same run", with an empty carry
+    for (int q = 0; q < wave; ++q) {
+      const bool joined = q > 0 && agg_i[parity][q][1] == agg_i[parity][q - 1][2];
+      c                 = agg_i[parity][q][0] ? agg_v[parity][q] : (joined ? c : 0.0) + agg_v[parity][q];
+      lastk             = agg_i[parity][q][2];
+    }
+    const int first0     = __builtin_amdgcn_readfirstlane(my_first);
+    const bool join_wave = first0 == lastk;
+    const bool open_left = (fm & ((1ull << lane) - 1ull)) == 0ull;  // no run ends in the lanes before this one
+    if (lane == 0) carry_in = c, prev_last = lastk;
+    else if (open_left && join_wave) carry_in = carry_in + c;
+    // (3) the walk: a run that ends goes to its row's sum (one emission per run and chunk: no two lanes meet in a row)
+    if (cnt > 0) {
+      int key    = prev_last;
+      double sum = carry_in;
+#pragma unroll
+      for (int u = 0; u < kPanelPer; ++u) {
+        if (rid[u] != key) {
+          seg_emit(psum, key, sum);
+          key = rid[u], sum = 0.0;
+        }
+        sum = sum + p[u];
+      }
+      if ((int)threadIdx.x == (len - 1) / R) seg_emit(psum, key, sum);  // the chunk's last lane closes what is still open
+    }
+    parity ^= 1;
+  }
+#undef SEG_COUNT
+#undef SEG_CALL_PRODUCTS
+#undef SEG_CALL_GATHER
+#undef SEG_CALL_LOAD
+#undef SEG_ROUNDS
+  __syncthreads();
+  panel_epilogue(P, epi, partials, psum, red, w, r0, nr);
+}
 #undef PANEL_DISPATCH
+template <bool SEG, class Epi>
+__device__ __forceinline__ void panel_block(const PanelView& P, const double* __restrict__ vec, Epi& epi, double* __restrict__ partials)
+{
+  if constexpr (SEG) panel_seg_block(P, vec, epi, partials);
+  else panel_spmv_block(P, vec, epi, partials);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Sorted jagged rows ("jag"): the SpMV for STRUCTURED matrices, whose rows re-use a limited set of columns.

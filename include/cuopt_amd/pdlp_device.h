@@ -325,7 +325,7 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* offsets, const int32_t*
  * sets save).  Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default; a structural, reproducible rule:
  * DESIGN.md section 3) | stream | panel | jag | timed ; CUOPT_AMD_SLAB_BYTES (1.33 MiB), CUOPT_AMD_PANEL_WS_BYTES (4 MiB),
  * CUOPT_AMD_JAG_WAVES (8 | 16). */
-int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[6]);
+int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,8 @@ STATUS = {"OPTIMAL": "Optimal", "INFEASIBLE": "PrimalInfeasible", "UNBOUNDED": "
 
 
 def _check_vertex(p, r, tol=1e-7):
-    """primal feasible, reduced costs = c - A^T y, signs of the reduced costs / duals match the active bounds, strong duality"""
+    """primal feasible, reduced costs = (+-c) - A^T y of the converted minimisation (both engines return that convention, like the
+    reference's), signs of the reduced costs / duals match the active bounds"""
     import scipy.sparse as sp
     A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(p["m"], p["n"]))
     x, y, z = r["x"], r["y"], r["reduced_cost"]
@@ -22,9 +23,9 @@ def _check_vertex(p, r, tol=1e-7):
     assert np.all(ax >= p["lo"] - tol * scale) and np.all(ax <= p["hi"] + tol * scale)
     assert np.all(x >= p["lb"] - tol * scale) and np.all(x <= p["ub"] + tol * scale)
     sense = -1.0 if p.get("maximize") else 1.0
-    np.testing.assert_allclose(p["c"] - A.T @ y, z, atol=tol * (1 + np.abs(p["c"]).max()))
+    np.testing.assert_allclose(sense * p["c"] - A.T @ y, z, atol=tol * (1 + np.abs(p["c"]).max()))
     # minimisation form: a positive reduced cost needs x at its lower bound, a negative one at its upper bound
-    zs, ys = sense * z, sense * y
+    zs, ys = z, y
     assert np.all((zs <= tol) | (np.abs(x - p["lb"]) <= tol * scale)) and np.all((zs >= -tol) | (np.abs(x - p["ub"]) <= tol * scale))
     assert np.all((ys <= tol) | (np.abs(ax - p["lo"]) <= tol * scale)) and np.all((ys >= -tol) | (np.abs(ax - p["hi"]) <= tol * scale))
 
@@ -306,3 +307,58 @@ def test_sparse_and_dense_solves_walk_the_same_pivots(monkeypatch):
         runs[mode] = (cold["iterations"], cold["objective"], warm["iterations"], warm["objective"])
     assert runs["dense"][0] == runs["sparse"][0] == runs["auto"][0] and runs["dense"][2] == runs["sparse"][2] == runs["auto"][2]
     assert runs["dense"][1] == pytest.approx(runs["sparse"][1], rel=1e-12) and runs["dense"][3] == pytest.approx(runs["sparse"][3], rel=1e-12)
+
+
+def _lp(rows, c, lo, hi, lb, ub, maximize=False):
+    import scipy.sparse as sp
+    A = sp.csr_matrix(np.asarray(rows, float))
+    return dict(m=A.shape[0], n=A.shape[1], offsets=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32), values=A.data.astype(float),
+                c=np.asarray(c, float), lo=np.asarray(lo, float), hi=np.asarray(hi, float), lb=np.asarray(lb, float), ub=np.asarray(ub, float),
+                maximize=maximize, objective_offset=0.0)
+
+
+def test_infeasibility_is_never_proven_by_the_artificial_box():
+    """round-3 advisor (high): infinite bounds are boxed at 1e5 / 1e8 x the largest finite bound; a row without an entering candidate
+    is a proof of infeasibility only if no helping variable is stopped by such a box bound.  These LPs are feasible with optima beyond
+    the first box: the engine must answer them (second box) or abstain, never say Infeasible."""
+    INF = np.inf
+    # (a) min x  s.t. 1e-7 x >= 1, x >= 0: optimum 1e7
+    r = capi.dual_simplex(_lp([[1e-7]], [1.0], [1.0], [INF], [0.0], [INF]))
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(1e7, rel=1e-9)
+    # (b) x0 >= 1, x_{k+1} >= 10 x_k: min x_7 = 1e7
+    n = 8
+    rows = np.zeros((n - 1, n))
+    for k in range(n - 1):
+        rows[k, k + 1], rows[k, k] = 1.0, -10.0
+    c = np.zeros(n)
+    c[-1] = 1.0
+    r = capi.dual_simplex(_lp(rows, c, np.zeros(n - 1), np.full(n - 1, INF), np.concatenate([[1.0], np.zeros(n - 1)]), np.full(n, INF)))
+    assert r["status"] in ("Optimal", "NumericalError")
+    if r["status"] == "Optimal":
+        assert r["objective"] == pytest.approx(1e7, rel=1e-9)
+    # (c) feasible only far beyond both boxes: 1e-12 x >= 1 -> abstains (PDLP would answer), not Infeasible
+    r = capi.dual_simplex(_lp([[1e-12]], [1.0], [1.0], [INF], [0.0], [INF]))
+    assert r["status"] in ("Optimal", "NumericalError"), r["status"]
+    # (d) a genuinely infeasible LP keeps its verdict: x + y <= 1, x + y >= 2 inside finite AND infinite bounds
+    r = capi.dual_simplex(_lp([[1.0, 1.0], [1.0, 1.0]], [1.0, 1.0], [-INF, 2.0], [1.0, INF], [0.0, 0.0], [INF, INF]))
+    assert r["status"] == "PrimalInfeasible"
+    r = capi.dual_simplex(_lp([[1.0, 1.0], [1.0, 1.0]], [1.0, 1.0], [-INF, 2.0], [1.0, INF], [-INF, -INF], [INF, INF]))
+    assert r["status"] in ("PrimalInfeasible", "NumericalError")  # free variables: the row x + y is stopped by true row bounds only
+
+
+def test_unbounded_needs_a_ray_of_the_lp_itself():
+    """an optimum beyond the wider box must not be called Unbounded: min -x s.t. 1e-9 x <= 1 (optimum -1e9) against min -x, x >= 0"""
+    INF = np.inf
+    r = capi.dual_simplex(_lp([[1e-9]], [-1.0], [-INF], [1.0], [0.0], [INF]))
+    assert r["status"] in ("Optimal", "NumericalError"), r["status"]
+    r = capi.dual_simplex(_lp([[1.0, -1.0]], [-1.0, 0.0], [-INF], [5.0], [0.0, 0.0], [INF, INF]))
+    assert r["status"] == "Unbounded"
+
+
+def test_a_maximisation_returns_the_duals_of_the_converted_minimisation():
+    """both engines hand out y, reduced costs of min -c (the reference's convention, dual_simplex/solve.cpp:256): here the simplex"""
+    p = _lp([[1.0, 2.0], [3.0, 1.0]], [5.0, 8.0], [-np.inf, -np.inf], [12.0, 15.0], [0.0, 0.0], [10.0, 10.0], maximize=True)
+    r = capi.dual_simplex(p)
+    assert r["status"] == "Optimal"
+    _check_vertex(p, r)
+    assert np.all(r["y"] <= 1e-9)  # binding <= rows of a minimisation have non-positive multipliers in the c - A^T y convention

@@ -8,6 +8,7 @@
  * the same iteration count from both SpMV layouts over a fixed budget (same decisions)."""
 import numpy as np
 import pytest
+from conftest import set_tune
 import scipy.sparse as sp
 
 from cuopt_amd import capi, synthetic
@@ -142,23 +143,37 @@ def test_auto_takes_the_gather_free_layout_beyond_sixteen_slabs(monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["powerlaw", "block_angular"])
-def test_long_row_families_at_full_size(kind):
+def test_long_row_families_at_full_size(kind, monkeypatch):
     """bench.py --workload powerlaw / block_angular (1e6 x 1e6, ~1e7 nnz; rows of up to 20 000 / 5 000 nonzeros): the layout auto
-    picks -- panels with wave-shared long rows / jagged rows with long-row workgroups -- against the oracle's CSR sums (rows of at
-    most 128 nonzeros bit-exact, longer ones to the fixed-tree tolerance), <A x, y> = <x, A^T y>, and a solve to 1e-4 against the
-    optimum known by construction"""
+    picks -- panels with row sums dealt by nonzero (round 4: the long-tail variant, every row at rtol 1e-12) / jagged rows with
+    long-row workgroups -- against the oracle's CSR sums (where rows are summed by a lane: rows of at most 128 nonzeros bit-exact,
+    longer ones to the fixed-tree tolerance), <A x, y> = <x, A^T y>, a solve to 1e-4 against the optimum known by construction, and
+    (power law) the decisions of the row-per-lane panels over the first three major iterations"""
     p = synthetic.generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7)
     rng = np.random.default_rng(5)
     x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
     to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
     dev = capi.Device(p)
+    lay = dev.layout()
+    if kind == "powerlaw":
+        assert lay["A"]["layout"] == "panel" and lay["A"]["row_sums"] == "by_nonzero", lay
     ax, aty = dev.spmv(x, False, p["m"]), dev.spmv(y, True, p["n"])
-    for got, ref, lens in ((ax, orcbind.spmv(p["offsets"], p["indices"], p["values"], x), np.diff(p["offsets"])),
-                           (aty, orcbind.spmv(to, ti, tv, y), np.diff(to))):
-        np.testing.assert_array_equal(got[lens <= 128], ref[lens <= 128])
+    for side, got, ref, lens in (("A", ax, orcbind.spmv(p["offsets"], p["indices"], p["values"], x), np.diff(p["offsets"])),
+                                 ("At", aty, orcbind.spmv(to, ti, tv, y), np.diff(to))):
+        if lay[side].get("row_sums") != "by_nonzero":
+            np.testing.assert_array_equal(got[lens <= 128], ref[lens <= 128])
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * (1 + np.abs(ref).max()))
     assert float(ax @ y) == pytest.approx(float(x @ aty), rel=1e-10)
     dev.close()
     r = capi.solve(p, method=1, tol=1e-4, iteration_limit=20000)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 1e-3 * (1.0 + abs(p["objective_star"]))
+    if kind == "powerlaw":
+        got = {}
+        for seg in (0, 1):
+            set_tune(monkeypatch, panel_seg=seg)
+            s = capi.Solver(p, tol=0.0, iteration_limit=120)
+            q = s.advance()
+            got[seg] = (q["steps_taken"], q["attempted_steps"], q["num_restarts"], q["primal_objective"])
+            s.close()
+        assert got[0][:3] == got[1][:3] and got[0][3] == pytest.approx(got[1][3], rel=1e-9)

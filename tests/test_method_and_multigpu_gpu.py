@@ -27,11 +27,16 @@ def test_dual_simplex_requests_are_answered_by_the_dual_simplex():
     assert info["engine"] == "dual_simplex" and info["answered_by"] == "dual_simplex" and info["dual_simplex_status"] == 1
     assert info["requested_method"] == "DualSimplex" and info["crossover_requested"] is True and info["simplex_grade_emulation"] is False
     assert r["status"] == "Optimal" and r["objective"] == pytest.approx(32.0, abs=1e-9)  # a vertex: exact
-    # the vertex satisfies the LP exactly and carries duals in the c - A^T y convention
+    # the vertex satisfies the LP exactly and carries the duals of the converted minimisation (min -c: the convention of both engines,
+    # as in the reference): reduced costs = -c - A^T y
     x, y, z = r["x"], r["y"], r["reduced_cost"]
     A = np.array([[2.0, 3.0], [3.0, 1.0], [1.0, 2.0]])
     assert np.all(A @ x <= np.array([12.0, 6.0, 8.0]) + 1e-9) and (A @ x)[2] >= 2.0 - 1e-9
-    np.testing.assert_allclose(np.array([5.0, 8.0]) - A.T @ y, z, atol=1e-9)
+    np.testing.assert_allclose(-np.array([5.0, 8.0]) - A.T @ y, z, atol=1e-9)
+    # ... and PDLP answers the same LP with duals of the same sign (round-3 advisor: the engines used to disagree on a maximisation)
+    q = capi.solve(ranged_lp(), method=1, tol=1e-9)
+    np.testing.assert_allclose(q["y"], y, atol=1e-5)
+    np.testing.assert_allclose(q["reduced_cost"], z, atol=1e-5)
     # Concurrent (the default): the simplex races PDLP and wins on an LP of this size
     c = capi.solve(ranged_lp())
     assert c["solve_info"]["engine"] == "dual_simplex" and c["objective"] == pytest.approx(32.0, abs=1e-9)

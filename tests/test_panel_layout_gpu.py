@@ -22,7 +22,7 @@ def layout(request, monkeypatch):
         set_tune(monkeypatch, jag_waves=str(slab))
         slab = 1 << 20
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", mode)
-    set_tune(monkeypatch, slab_bytes=str(slab))
+    set_tune(monkeypatch, slab_bytes=str(slab), panel_seg=0)  # the row-per-lane panels (tests/test_panel_seg_gpu.py has the long-tail variant)
     monkeypatch.setenv("CUOPT_AMD_SMALL", "0")  # these LPs are small: keep them on the multi-launch kernels under test
     return mode
 
@@ -295,7 +295,7 @@ def test_panels_with_hub_rows_of_their_own(monkeypatch):
     """rows of more than 4096 nonzeros get a workgroup each behind the panels: same numbers to the long-row tolerance, short rows
     bit-exact, same decisions"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
-    set_tune(monkeypatch, slab_bytes=str(64 * 1024))
+    set_tune(monkeypatch, slab_bytes=str(64 * 1024), panel_seg=0)
     p = synthetic.generate_structured("powerlaw", m=200000, n=200000, k=10, seed=11)
     lens = np.diff(p["offsets"])
     assert (lens > 4096).sum() >= 2
