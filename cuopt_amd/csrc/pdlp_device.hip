@@ -235,24 +235,24 @@ struct Push {
   int world, rank, kind;
   size_t dst_off, flag_off;  // bytes inside every rank's block: this rank's slot of the exchange / the flag area
   unsigned long long* epoch;
-  unsigned* ticket;
   __device__ __forceinline__ double* slot(int q) const { return reinterpret_cast<double*>(P.base[q] + dst_off); }
 };
-// A producing kernel's store into a landing block: system scope = write-through, so that publishing needs no cache write-back
+// A producing kernel's store into a landing block: system scope = write-through, so that no cache write-back is needed before the
+// flag goes up
 __device__ __forceinline__ void put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// Called by EVERY workgroup at the end of a producing kernel: every thread waits for its own write-through stores, the
-// workgroup takes a ticket, and the workgroup that draws the last one advances this rank's epoch of the exchange and raises
-// its flag in every rank's block.  (A system-scope fence per thread instead -- the first version -- cost 380 us per attempt at
-// C3: every fence is a write-back of the XCD's L2.)
-__device__ __forceinline__ void publish(const Push* T)
+// Called once per workgroup at the end of a producing kernel: ONE thread of the grid counts the exchange.  The flag itself is raised
+// by the first workgroup of the NEXT kernel of the stream (raise, below): a kernel boundary is what guarantees that every store of
+// the producer has landed, for nothing.  (Round 3 published from the producer's tail -- every thread waited for its own stores, the
+// workgroup took a ticket, the last one raised the flags: at one rank that made k_primal 31.8 us instead of 13.)
+__device__ __forceinline__ void count_exchange(const Push* T)
 {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  if (__hip_atomic_fetch_add(&T->ticket[T->kind], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-  __hip_atomic_store(&T->ticket[T->kind], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long e = T->epoch[T->kind] + 1;
-  T->epoch[T->kind]          = e;
+  if (blockIdx.x == 0 && threadIdx.x == 0) T->epoch[T->kind] = T->epoch[T->kind] + 1;
+}
+// first thread of the consuming kernel: this rank's flag of the exchange goes up in every rank's block
+__device__ __forceinline__ void raise(const Push* T)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const unsigned long long e = T->epoch[T->kind];
   for (int q = 0; q < T->world; ++q) {
     unsigned long long* flag = reinterpret_cast<unsigned long long*>(T->P.base[q] + T->flag_off) + (size_t)T->kind * T->world + T->rank;
     __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -280,24 +280,40 @@ __device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int 
   __syncthreads();
   return ok;
 }
-// wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles).  Every
-// workgroup polls for itself (local memory, one load per rank per poll); patience is bounded: a peer that never arrives sets
-// the step error and the fault flag instead of hanging the device.
+// wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles) EXCEPT this rank's
+// own share [own0, own0 + own_count), which its producing kernel stored straight into dst.  Every workgroup polls for itself (local
+// memory, one load per rank per poll); patience is bounded: a peer that never arrives sets the step error and the fault flag instead
+// of hanging the device.  Four 16-byte requests per thread in flight (the landing block is fine-grained: every read is a trip to
+// memory, and one request at a time ran at 0.75 TB/s).
 __global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ ctl, double* __restrict__ dst, const double* __restrict__ land, int count,
-                                              const unsigned long long* __restrict__ flags, int world, int kind,
-                                              const unsigned long long* __restrict__ epoch, int* __restrict__ fault)
+                                              int own0, int own_count, const unsigned long long* __restrict__ flags, int world, int kind,
+                                              const unsigned long long* __restrict__ epoch, int* __restrict__ fault, const Push* __restrict__ push)
 {
   if (!active(ctl)) return;
+  raise(push);  // the producing kernel before this one in the stream is complete: its exchange is published here
   if (!wait_flags(flags, world, kind, epoch)) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
     return;
   }
-  // (count is a multiple of 16 entries and both buffers are 256-byte aligned: 16-byte requests)
+  // (count, own0 and own_count are multiples of 16 entries and both buffers are 256-byte aligned: 16-byte requests)
   typedef double v2 __attribute__((ext_vector_type(2)));
   const v2* __restrict__ src2 = reinterpret_cast<const v2*>(land);
   v2* __restrict__ dst2       = reinterpret_cast<v2*>(dst);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < (count >> 1); i += gridDim.x * 256) dst2[i] = __builtin_nontemporal_load(src2 + i);
-  if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[count - 1] = land[count - 1];
+  const int n2 = (count - own_count) >> 1, o2 = own0 >> 1, skip2 = own_count >> 1;  // pairs to copy; the own share is stepped over
+  constexpr int U = 4;
+  for (int i = blockIdx.x * 256 * U + threadIdx.x; i < n2; i += gridDim.x * 256 * U) {
+    v2 v[U];
+    int at[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = i + u * 256;
+      at[u]       = k < n2 ? (k < o2 ? k : k + skip2) : -1;
+      if (at[u] >= 0) v[u] = __builtin_nontemporal_load(src2 + at[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (at[u] >= 0) dst2[at[u]] = v[u];
+  }
 }
 }  // namespace p2pdev
 
@@ -434,7 +450,6 @@ struct pdlpdev_ctx {
     p2pdev::Peers peers{};           // base of every rank's block as THIS process addresses it
     std::vector<void*> opened;       // hipIpcOpenMemHandle mappings to close
     unsigned long long* epoch = nullptr;  // device: epochs of the three exchanges (xbar, y', scalars) as this rank counts them
-    unsigned* ticket = nullptr;      // device: last-workgroup tickets of the push kernels
     int* fault = nullptr;            // device: set when a wait ran out of patience (peer died)
     p2pdev::Push* push_dev = nullptr;  // device: the three exchanges' descriptors (xbar, y', scalars) for the producing kernels
   } p2p;
@@ -448,6 +463,7 @@ struct pdlpdev_ctx {
   int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
   // graphs
   int use_graph = 1;
+  bool graph_comm_failed = false;  // capturing the RCCL collectives into an attempt graph failed once: plain launches from then on
   char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
   char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
   size_t arena_used = 0;
@@ -842,11 +858,43 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
     xn[j]                 = next;
     const double xb       = next - xj + next;
     xbar[j]               = xb;
-    if (push)  // sharded solve, direct peer transport: this rank's slice of xbar lands in every rank's block
-      for (int q = 0; q < push->world; ++q) p2pdev::put(push->slot(q) + j, xb);
+    if (push)  // sharded solve, direct peer transport: this rank's slice of xbar lands in every OTHER rank's block (its own copy is
+               // the ordinary store above: write-through stores cost 17 us per attempt at C3 and buy nothing at home)
+      for (int q = 0; q < push->world; ++q)
+        if (q != push->rank) p2pdev::put(push->slot(q) + j, xb);
     if (pend) sumx[j] = sumx[j] + weight * xj;
   }
-  if (push) p2pdev::publish(push);
+  if (push) p2pdev::count_exchange(push);
+}
+
+// (1') the same step for cache-resident LPs (n <= kPrimalSmallN, one element per thread): every operand -- BOTH ping-pong buffers
+// of x and A^T y -- is requested before the control block is looked at, so the kernel is one round trip instead of two dependent ones
+// (control block -> which buffer -> operands).  At C2 that is about a fifth of the kernel; on large LPs the second buffer's
+// 16 bytes per column would cost bandwidth, so they keep k_primal.  Same arithmetic, same bits.
+constexpr int kPrimalSmallN = 1 << 18;
+__global__ void __launch_bounds__(kBlock)
+k_primal_small(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, double* __restrict__ x1,
+               const double* __restrict__ aty0, const double* __restrict__ aty1,
+               const double* __restrict__ c, const double* __restrict__ lb, const double* __restrict__ ub,
+               double* __restrict__ xbar, double* __restrict__ sumx)
+{
+  const int j  = blockIdx.x * kBlock + threadIdx.x;
+  const int jj = j < n ? j : n - 1;
+  const double xa = x0[jj], xb_ = x1[jj], ta = aty0[jj], tb = aty1[jj], cj = c[jj], lj = lb[jj], uj = ub[jj], sj = sumx[jj];
+  if (!loop_active(ctl)) return;
+  const int cur       = ctl->cur;
+  const double tau    = ctl->tau;
+  const double weight = ctl->step_size;
+  const bool pend     = ctl->pending_avg != 0;
+  if (j >= n) return;
+  double* __restrict__ xn = cur ? x0 : x1;
+  const double xj       = cur ? xb_ : xa;
+  const double gradient = cj - (cur ? tb : ta);
+  double next           = xj - (tau * gradient);
+  next                  = dmax(dmin(next, uj), lj);
+  xn[j]                 = next;
+  xbar[j]               = next - xj + next;
+  if (pend) sumx[j] = sj + weight * xj;
 }
 
 // (2) rows of A: v = A xbar (stream SpMV) -> dual projection (utils.cuh:97-112) -> ||dy||^2 partial,
@@ -878,7 +926,8 @@ struct DualEpilogue {
     yn[i]           = next;
     if (copy) copy[i] = next;
     if (push)
-      for (int q = 0; q < push->world; ++q) p2pdev::put(push->slot(q) + i, next);
+      for (int q = 0; q < push->world; ++q)
+        if (q != push->rank) p2pdev::put(push->slot(q) + i, next);  // (this rank's own rows: `copy`, an ordinary store)
     const double dy = next - yi;
     acc[0] += dy * dy;
     if (pend) sumy[i] = o.sum + weight * yi;
@@ -898,7 +947,7 @@ k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0, ycopy, push};
   csr_stream_block(nb, rb, off, idx, val, xbar, e, part, dadd);
-  if (push) p2pdev::publish(push);
+  if (push) p2pdev::count_exchange(push);
 }
 
 // (3) rows of A^T: AtY' = A^T y' (stream SpMV) fused with the step-size statistics
@@ -1055,11 +1104,34 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
 
 // direct peer transport of a sharded solve: wait for every rank's three step-size sums (landed in this rank's block), add them
 // up in rank order -- the same bits on every rank -- and take the decision
-__global__ void __launch_bounds__(64)
-k_step_decision_p2p(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ landed, const unsigned long long* __restrict__ flags, int world,
-                    const unsigned long long* __restrict__ epoch, int* __restrict__ fault, pdlpdev_step_params sp)
+// (one workgroup, so the whole scalar exchange lives in this kernel: its own three sums from the partials of the two SpMV kernels,
+// write-through stores into every rank's block, the flag, the wait for the others -- no ticket, no kernel boundary in between)
+__global__ void __launch_bounds__(kBlock)
+k_step_decision_p2p(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t,
+                    const double* __restrict__ landed, const unsigned long long* __restrict__ flags, int world,
+                    const unsigned long long* __restrict__ epoch, int* __restrict__ fault, pdlpdev_step_params sp, const p2pdev::Push* __restrict__ push)
 {
   if (!loop_active(ctl)) return;
+  {
+    __shared__ double red[3 * 8];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nb_dy; i += kBlock) acc[0] += part_dy[i];
+    for (int i = threadIdx.x; i < nb_t; i += kBlock) {
+      acc[1] += part_t[i];
+      acc[2] += part_t[nb_t + i];
+    }
+    block_reduce<SumOp, 3>(acc, red);
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < push->world; ++q) {
+        double* d = push->slot(q);
+        p2pdev::put(d, acc[0]), p2pdev::put(d + 1, acc[1]), p2pdev::put(d + 2, acc[2]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      push->epoch[push->kind] = push->epoch[push->kind] + 1;
+      p2pdev::raise(push);
+    }
+    __syncthreads();
+  }
   if (!p2pdev::wait_flags(flags, world, 2, epoch)) {
     if (threadIdx.x == 0) *fault = 1, ctl->error = 1;
     return;
@@ -1303,7 +1375,7 @@ k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* _
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0, ycopy, push};
   panel_block<SEG>(P, xbar, e, part);
-  if (push) p2pdev::publish(push);
+  if (push) p2pdev::count_exchange(push);
 }
 template <bool SEG>
 __global__ void __launch_bounds__(kPanelThreads)
@@ -1330,7 +1402,7 @@ k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __res
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
                  ctl->pending_avg != 0, ycopy, push};
   jag_block<decltype(e), WAVES>(J, xbar, e, part);
-  if (push) p2pdev::publish(push);
+  if (push) p2pdev::count_exchange(push);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -1454,7 +1526,7 @@ k_pb_a_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ 
   const int cur = ctl->cur;
   DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size, ctl->pending_avg != 0, ycopy, push};
   pb_rows_block(V, e, part, pb_lds);
-  if (push) p2pdev::publish(push);
+  if (push) p2pdev::count_exchange(push);
 }
 __global__ void __launch_bounds__(kPbThreads)
 k_pb_at_step(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -1583,10 +1655,8 @@ k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ 
 
 // sliced-primal dataflow: this rank's three step-size partial sums, side by side, for ONE small all-reduce
 __global__ void __launch_bounds__(kBlock)
-k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t, double* __restrict__ out,
-                 const pdlpdev_ctl* __restrict__ ctl, const p2pdev::Push* __restrict__ push)
+k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __restrict__ part_t, int nb_t, double* __restrict__ out)
 {
-  if (push && !loop_active(ctl)) return;
   __shared__ double red[3 * 8];
   double acc[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < nb_dy; i += kBlock) acc[0] += part_dy[i];
@@ -1597,13 +1667,7 @@ k_pack_step_sums(const double* __restrict__ part_dy, int nb_dy, const double* __
   block_reduce<SumOp, 3>(acc, red);
   if (threadIdx.x == 0) {
     out[0] = acc[0], out[1] = acc[1], out[2] = acc[2];
-    if (push)
-      for (int q = 0; q < push->world; ++q) {
-        double* d = push->slot(q);
-        p2pdev::put(d, acc[0]), p2pdev::put(d + 1, acc[1]), p2pdev::put(d + 2, acc[2]);
-      }
   }
-  if (push) p2pdev::publish(push);
 }
 
 // ================================================================================================
@@ -2179,7 +2243,7 @@ static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
 // ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
 struct PanelHost {
   bool ok = false, any_long = false;
-  bool seg = false;                        // long-tail variant: lane-major chunks, packed (row, column), no row pointers (panel_seg_block)
+  bool seg = false;                        // long-tail variant: packed (row, column) entries, no row pointers (panel_seg_block)
   int32_t slab_w = 0;
   int W = 0, S = 0;                        // W: panels only
   std::vector<int32_t> own_row, own_ptr;   // rows of more than kPanelOwnRow nonzeros (a workgroup each, behind the panels); per panel
@@ -2237,11 +2301,25 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   // once, so the LARGEST one sets the kernel time -- letting a panel overshoot by its last row made panels of 42 K nonzeros
   // next to the average 22 K on the power-law LP (rows of up to 20 000 nonzeros) and cost 26 of its 117 us.  The target grows
   // (proportionally first, then in 1 % steps) until the panels fit the 512 resident slots again.
-  // rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels
+  // Long-tailed row lengths: row sums dealt by nonzero (panel_seg_block; every row at rtol 1e-12 instead of bit-exact short rows).
+  // auto: when more than 2 % of the nonzeros sit in rows of more than kLongRow entries -- a structural, reproducible rule;
+  // CUOPT_AMD_TUNE=panel_seg=0|1 forces it off / on (tests, sweeps).
+  int64_t long_nnz = 0;  // nonzeros in rows the row-per-lane kernel sums wave by wave
+  for (int32_t i = 0; i < rows; ++i)
+    if (off[i + 1] - off[i] > kLongRow) long_nnz += off[i + 1] - off[i];
+  {
+    const long long want = cuopt_amd::tune_int("panel_seg", -1);
+    P.seg = want == 1 || (want != 0 && long_nnz * 50 > nnz);
+    if (slab_w > (1 << kSegColBits)) P.seg = false;
+  }
+  // Rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels (a lane, or a wave, would walk them for ever).  The
+  // long-tail variant deals every row by nonzero, so a row leaves the panels only when it is longer than a whole panel should be
+  // (it would be the one panel everybody waits for): up to there it is ordinary work, and no resident slot is spent on it.
+  const int64_t own_from = P.seg ? std::max<int64_t>(kPanelOwnRow, std::min<int64_t>(cap, (nnz + 511) / 512)) : kPanelOwnRow;
   std::vector<char> is_own(rows, 0);
   int64_t own_nnz = 0;
   for (int32_t i = 0; i < rows; ++i)
-      if (off[i + 1] - off[i] > kPanelOwnRow) is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];
+      if (off[i + 1] - off[i] > own_from) is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];
   auto cut = [&](int64_t tgt) {
     P.row0.assign(1, 0);
     int32_t start = 0;
@@ -2271,17 +2349,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S, P.slab_w = slab_w;
-  int64_t long_nnz = 0;  // nonzeros in rows the row-per-lane kernel sums wave by wave
-  for (int32_t i = 0; i < rows; ++i)
-    if (!is_own[i] && off[i + 1] - off[i] > kLongRow) P.any_long = true, long_nnz += off[i + 1] - off[i];
-  // Long-tailed row lengths: row sums dealt by nonzero (panel_seg_block; every row at rtol 1e-12 instead of bit-exact short rows).
-  // auto: when more than 2 % of the panels' nonzeros sit in rows of more than kLongRow entries -- a structural, reproducible rule;
-  // CUOPT_AMD_TUNE=panel_seg=0|1 forces it off / on (tests, sweeps).
-  {
-    const long long want = cuopt_amd::tune_int("panel_seg", -1);
-    P.seg = want == 1 || (want != 0 && long_nnz * 50 > nnz - own_nnz);
-    if (slab_w > (1 << kSegColBits)) P.seg = false;
-  }
+  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
   P.own_ptr.assign((size_t)W + 1, 0);
   for (int w = 0, q = 0; w < W; ++w) {
     while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;
@@ -2298,7 +2366,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   P.tile_ptr.resize((size_t)W * S + 1);
   int64_t pos = 0;
   for (size_t i = 0; i < (size_t)W * S; ++i) {
-    if (count[i] >= 65536) return P;  // 16-bit row pointers would overflow: keep the CSR stream layout
+    if (!P.seg && count[i] >= 65536) return P;  // 16-bit row pointers would overflow: keep the CSR stream layout
     P.tile_ptr[i] = (int32_t)pos;
     pos += count[i];
   }
@@ -2307,9 +2375,7 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   P.nnz = (size_t)(nnz - own_nnz), P.rowptr_size = P.seg ? 0 : (size_t)S * ((size_t)rows + W);
   P.perm.reset(P.nnz), P.col.reset(P.nnz);
   if (P.seg) {
-    // placement in (slab, row, CSR) order as below, every entry carrying its row within the panel; then each chunk of <= kPanelChunk
-    // entries of a tile is re-dealt lane-major: with R = ceil(len / 512) rounds, lane t owns the consecutive entries [t R, t R + R) and
-    // entry u of lane t sits in round u, after the entries of the lanes before it (round u holds a prefix of the lanes: no padding)
+    // placement in (slab, row, CSR) order as below, every entry carrying its row within the panel next to its column inside the slab
     cuopt_amd::parallel_tasks(W, [&](int w) {
       const int32_t a = P.row0[w], b = P.row0[w + 1];
       std::vector<int32_t> cursor(S);
@@ -2322,18 +2388,6 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
           P.perm[q] = t, P.col[q] = (int32_t)(((uint32_t)(i - a) << kSegColBits) | (uint32_t)(idx[t] - s2 * slab_w));
         }
       }
-      int32_t tp[kPanelChunk], tc[kPanelChunk];
-      for (int s2 = 0; s2 < S; ++s2)
-        for (int32_t c0 = P.tile_ptr[(size_t)w * S + s2], c1 = P.tile_ptr[(size_t)w * S + s2 + 1]; c0 < c1; c0 += kPanelChunk) {
-          const int len = std::min<int32_t>(kPanelChunk, c1 - c0), R = (len + kPanelThreads - 1) / kPanelThreads;
-          if (R == 1) continue;  // one entry per lane: already in place
-          int base[kPanelPer + 1];
-          base[0] = 0;
-          for (int u = 0; u < R; ++u) base[u + 1] = base[u] + (len - u + R - 1) / R;
-          for (int l = 0; l < len; ++l) tp[base[l % R] + l / R] = P.perm[c0 + l], tc[base[l % R] + l / R] = P.col[c0 + l];
-          std::copy(tp, tp + len, &P.perm[c0]);
-          std::copy(tc, tc + len, &P.col[c0]);
-        }
     }, nnz);
     P.ok = true;
     return P;
@@ -3677,7 +3731,6 @@ static int p2p_setup(pdlpdev_ctx* ctx)
   HIP_TRY(hipExtMallocWithFlags((void**)&P.base, P.bytes, hipDeviceMallocFinegrained));
   HIP_TRY(hipMemset(P.base, 0, P.bytes));
   TRY(dev_alloc(ctx, &P.epoch, 4));
-  TRY(dev_alloc(ctx, &P.ticket, 4));
   TRY(dev_alloc(ctx, &P.fault, 4));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->soft) {
@@ -3730,7 +3783,7 @@ static int p2p_setup(pdlpdev_ctx* ctx)
     p2pdev::Push h[p2pdev::kKinds];
     const size_t slot[p2pdev::kKinds] = {P.off_x + (size_t)ctx->rank * ctx->slice * sizeof(double), P.off_y + (size_t)ctx->rank * ctx->ypad * sizeof(double),
                                          P.off_s + (size_t)ctx->rank * 4 * sizeof(double)};
-    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch, P.ticket};
+    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch};
     TRY(dev_alloc(ctx, &P.push_dev, p2pdev::kKinds));
     HIP_TRY(hipMemcpyAsync(P.push_dev, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -4317,16 +4370,18 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
       pdlpdev_ctx::P2P& P = ctx->p2p;
       const int W = ctx->world;
       const unsigned long long* flags = reinterpret_cast<const unsigned long long*>(P.base + P.off_f);
-      auto pull = [&](int kind, double* dst, size_t land_off, int count) {
-        const int g = std::max(1, std::min((count + 2047) / 2048, 1024));
-        launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, flags, W, kind, P.epoch, P.fault);
+      auto pull = [&](int kind, double* dst, size_t land_off, int per_rank) {
+        const int count = W * per_rank, remote = count - per_rank;
+        const int g     = std::max(1, std::min((remote + 4095) / 4096, 1024));
+        launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, ctx->rank * per_rank, per_rank,
+                 flags, W, kind, P.epoch, P.fault, P.push_dev + kind);
       };
-      pull(0, ctx->xbar, P.off_x, W * ctx->slice);
-      launch_a_dual(ctx, nullptr, P.push_dev + 1);
-      pull(1, ctx->ygather, P.off_y, W * ctx->ypad);
+      pull(0, ctx->xbar, P.off_x, ctx->slice);  // (this rank's slice: k_primal's ordinary store, above)
+      launch_a_dual(ctx, ctx->ygather + (size_t)ctx->rank * ctx->ypad, P.push_dev + 1);
+      pull(1, ctx->ygather, P.off_y, ctx->ypad);
       launch_oc_step(ctx);
-      launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal, ctx->ctl, P.push_dev + 2);
-      launch_k(ctx, k_step_decision_p2p, 1, 64, 0, ctx->ctl, reinterpret_cast<const double*>(P.base + P.off_s), flags, W, P.epoch, P.fault, ctx->sp);
+      launch_k(ctx, k_step_decision_p2p, 1, kBlock, 0, ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx),
+               reinterpret_cast<const double*>(P.base + P.off_s), flags, W, P.epoch, P.fault, ctx->sp, P.push_dev + 2);
       LAUNCH_CHECK();
       return 0;
     }
@@ -4335,7 +4390,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     LAUNCH_CHECK();
     TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
     launch_oc_step(ctx);
-    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal, ctx->ctl, (const p2pdev::Push*)nullptr);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
     launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
@@ -4358,14 +4413,17 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     TRY(reduce_scatter(ctx, ctx->ar_buf, ctx->rs_buf, (size_t)ctx->slice));
     const int g = std::min(grid_for(len), kGenericBlocks);
     launch_k(ctx, k_step_stats, g, kBlock, 0, len, g, ctx->ctl, ctx->rs_buf, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs, ctx->part_g);
-    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_g, g, ctx->rs_scal, ctx->ctl, (const p2pdev::Push*)nullptr);
+    launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_g, g, ctx->rs_scal);
     LAUNCH_CHECK();
     TRY(allreduce(ctx, ctx->rs_scal, 3, rccl::kSum));
     launch_k(ctx, k_step_decision, 1, kDecisionThreads, 0, ctx->ctl, nullptr, 0, ctx->rs_scal + 1, 1, ctx->rs_scal, ctx->sp);
     LAUNCH_CHECK();
     return 0;
   }
-  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+  if (n <= kPrimalSmallN && n > 0)
+    launch_k(ctx, k_primal_small, (n + kBlock - 1) / kBlock, kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+  else
+    launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
   launch_a_dual(ctx);
   if (!ctx->comm) {
     launch_at_step(ctx);
@@ -4436,19 +4494,33 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
   int guard = 0;
   while (ctx->ctl_h->error == 0 && ctx->ctl_h->steps_taken < target_steps) {
     int remaining = target_steps - ctx->ctl_h->steps_taken;
-    // Sharded solves over RCCL enqueue plain launches unless the caller asked for captured collectives
-    // (pdlpdev_set_graph_mode(ctx, 2); tools/rccl_capture_repro.cpp is the stand-alone probe of that capture).  The in-process
-    // communicator synchronises on the host and can never be captured; the direct peer transport is kernels only.
-    if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || (ctx->use_graph == 2 && !ctx->soft))) {
+    // Sharded solves over RCCL replay attempt graphs too: the collectives are captured with the kernels around them (round 4:
+    // tools/rccl_capture_repro.cpp captures ncclAllGather + ncclAllReduce in every capture mode with both RCCL builds of this image,
+    // and bench.py --force-comm runs the owner dataflow through captured graphs at one rank; round 3's crash inside the capture did
+    // not reproduce after the prune).  A capture that fails is remembered and the solver goes on with plain launches -- the same
+    // sequence of collectives, so ranks that took different paths still meet.  The in-process communicator synchronises on the
+    // host and can never be captured; the direct peer transport is kernels only.
+    const bool rccl_graphs = ctx->comm && !ctx->p2p.on && !ctx->soft && !ctx->graph_comm_failed;
+    bool replayed = false;
+    if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || rccl_graphs)) {
+      replayed = true;
       while (remaining > 0) {
         int chunk = 1;
         while (chunk * 2 <= remaining && chunk < 64) chunk *= 2;
         hipGraphExec_t g;
-        TRY(get_graph(ctx, chunk, &g));
+        const int grc = get_graph(ctx, chunk, &g);
+        if (grc != 0 && rccl_graphs) {  // (nothing of this chunk was enqueued: a failed capture leaves the stream empty)
+          ctx->graph_comm_failed = true;
+          (void)hipGetLastError();
+          replayed = false;
+          break;
+        }
+        TRY(grc);
         HIP_TRY(hipGraphLaunch(g, ctx->stream));
         remaining -= chunk;
       }
-    } else {
+    }
+    if (!replayed) {
       for (int i = 0; i < remaining; ++i) TRY(enqueue_attempt(ctx));
     }
     const int before = ctx->ctl_h->steps_taken, asked = target_steps - before;
@@ -4979,7 +5051,10 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   auto one = [&]() {
     switch (kernel_id) {
       case PDLPDEV_K_PRIMAL:
-        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+        if (ctx->n <= kPrimalSmallN && ctx->n > 0)
+          launch_k(ctx, k_primal_small, (ctx->n + kBlock - 1) / kBlock, kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
+        else
+          launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
         break;
       case PDLPDEV_K_SPMV_A_DUAL: launch_a_dual(ctx); break;
       case PDLPDEV_K_SPMV_AT_STEP: launch_at_step(ctx); break;

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "cuopt_amd/pdlp_device.h"
 
 namespace pdlp {
@@ -141,6 +143,19 @@ __device__ __forceinline__ bool loop_active(const pdlpdev_ctl* ctl)
   return ctl->error == 0 && ctl->steps_taken < ctl->target_steps;
 }
 
+// An epilogue may split its row step into load(row) -> Ops and apply(row, sum, Ops): the operands of a lane's first row are then
+// requested together with the matrix stream instead of behind the row sums (one dependent round trip less per workgroup -- on a
+// cache-resident LP the kernels are chains of round trips, nothing else).  Same arithmetic, same bits.
+template <class E, class = void>
+struct epilogue_has_ops : std::false_type {};
+template <class E>
+struct epilogue_has_ops<E, std::void_t<typename E::Ops>> : std::true_type {};
+struct NoOps {};
+template <class E, bool = epilogue_has_ops<E>::value>
+struct epilogue_ops { using type = NoOps; };
+template <class E>
+struct epilogue_ops<E, true> { using type = typename E::Ops; };
+
 // block b executes on XCD (b % 8) (observed dispatch order, speed only): give each XCD one
 // contiguous range of row blocks so that neighbouring rows -- which in real LPs touch neighbouring
 // columns -- share that XCD's private 4 MiB L2 for the gathered vector.
@@ -197,6 +212,11 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
       ext0[q] = offsets[r];
       ext1[q] = offsets[r + 1];
     }
+    typename epilogue_ops<Epi>::type pre{};  // the epilogue's operands of the lane's first row, in flight with the matrix stream
+    if constexpr (epilogue_has_ops<Epi>::value) {
+      const int r = r0 + (int)threadIdx.x;
+      pre         = epi.load(r < r1 ? r : r1 - 1);
+    }
     vec4d a[kPasses];
     vec4i j[kPasses];
 #pragma unroll
@@ -238,6 +258,12 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
         }
         for (; k < e; ++k) s0 += prod[k];
         sum = (s0 + s1) + (s2 + s3);
+      }
+      if constexpr (epilogue_has_ops<Epi>::value) {
+        if (q == 0) {
+          epi.apply(r, dense_plus(dense_add, r, sum), pre, acc);
+          continue;
+        }
       }
       epi.row(r, dense_plus(dense_add, r, sum), acc);
     }
@@ -399,13 +425,13 @@ __device__ __forceinline__ void panel_own_row(const PanelView& P, const double* 
 // the fused epilogue over a panel's rows, natural order, from the row sums in LDS
 template <class Epi>
 __device__ __forceinline__ void panel_epilogue(const PanelView& P, Epi& epi, double* __restrict__ partials, const double* psum, double* red,
-                                               int w, int r0, int nr)
+                                               int w, int r0, int nr, const double* psum2 = nullptr /* long-tail variant: the edge runs' share */)
 {
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
   for (int r = threadIdx.x; r < nr; r += kPanelThreads)
-    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum[r]), acc);
+    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum2 ? psum[r] + psum2[r] : psum[r]), acc);
   if constexpr (Epi::NQ > 0) {
     block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
     if (threadIdx.x == 0) {
@@ -484,9 +510,6 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
     nxt = advance(cur);
     PANEL_REQUEST(nxt)  // in flight during the row sums below
     __syncthreads();
-#ifdef X_ROW_NOSUM
-    { psum[threadIdx.x] = psum[threadIdx.x] + prod[threadIdx.x]; cur = nxt; continue; }
-#endif
     if (!P.any_long) {  // (uniform) the common case: no extra instruction in the loop
 #pragma unroll
       for (int q = 0; q < kPanelRowsPer; ++q) {
@@ -561,56 +584,23 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 // The panel kernel above gives every ROW of the panel a lane, which walks the row's segment of the staged chunk while its wave
 // waits for the longest one: on a matrix whose row lengths have a heavy tail (power law: 0.26 of the HBM roofline in round 3,
 // 21.6 M issue cycles against 14.0 M on the uniform matrix of the same size) that walk is what the kernel waits for.  Here
-//   * a lane owns R = ceil(len / 512) CONSECUTIVE entries of the chunk (stored lane-major by the host, so the loads stay one coalesced
-//     stream per round and nothing is staged through LDS), each carrying its row within the panel (12 bits) next to its column
-//     relative to the slab (20 bits): 12 bytes per nonzero and no row pointers at all;
-//   * the lane adds runs of equal rows left to right; a run that lies inside the lane goes straight to the row's LDS sum; the runs that
-//     cross lanes are joined by a segmented scan over the wave (fixed Hillis-Steele tree over ds_bpermute) and one 8-entry table of wave
-//     aggregates per chunk (one barrier per chunk instead of two);
-//   * rows that continue in the next chunk or the next slab simply meet again in the row's LDS sum.
-// The work of a chunk is the same whatever the row lengths are.  The additions of a row are no longer left to right across lanes:
-// this layout is compared with the oracle at rtol 1e-12 for EVERY row (the contract of rows > kLongRow in the other layouts), which is
-// why `auto` takes it only for long-tailed matrices (build_panels) and the uniform ones keep their bit-exact kernels.
+//   * the storage is the panels' (chunk entry i <-> lane i % 512, round i / 512: neighbouring lanes hold neighbouring nonzeros, which
+//     is what lets the texture path merge the gathers of neighbouring columns -- a first version that gave each lane CONSECUTIVE
+//     entries lost 8 % on matrices with a diagonal for exactly that reason); each entry carries its row within the panel (12 bits)
+//     next to its column relative to the slab (20 bits): 12 bytes per nonzero and no row pointers at all; products stay in registers;
+//   * per round, a wave holds 64 consecutive entries: a segmented scan over the wave (DPP, fixed tree) sums the runs of equal rows;
+//     a run that lies inside the wave-round is added to its row's LDS sum by the lane that ends it (LDS atomic as a fire-and-forget
+//     add: one emission per run and chunk, so never two lanes at one row between two barriers);
+//   * the runs that touch the edges of a wave-round (at most two per wave and round) go to a table of 64 records per chunk; after the
+//     chunk's ONE barrier wave 0 joins neighbouring records of equal rows -- a second, 64-lane segmented scan in logical order --
+//     and adds the joined sums to a second LDS strip that only it writes (so no emission of the next chunk can race with it).
+// The work of a chunk is the same whatever the row lengths are; rows of any length need no special path.  The additions of a row are
+// no longer left to right: this layout is compared with the oracle at rtol 1e-12 for EVERY row (the contract of rows > kLongRow in
+// the other layouts), which is why `auto` takes it only for long-tailed matrices (build_panels) and the uniform ones keep their
+// bit-exact kernels.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSegColBits = 20;                     // slab width < 2^20 columns (1.33 MiB slabs: 174 763)
 constexpr unsigned kSegColMask = (1u << kSegColBits) - 1u;
-template <int R>
-__device__ __forceinline__ void seg_load(const PanelView& P, double (&va)[kPanelPer], int (&pk)[kPanelPer], int c0, int len)
-{
-  int base = c0;
-#pragma unroll
-  for (int u = 0; u < R; ++u) {
-    const int n_u = (len - u + R - 1) / R;  // lanes that own an entry in round u: a prefix
-    const int t   = (int)threadIdx.x < n_u ? (int)threadIdx.x : n_u - 1;
-    va[u]         = __builtin_nontemporal_load(P.val + base + t);
-    pk[u]         = __builtin_nontemporal_load(P.col + base + t);
-    base += n_u;
-  }
-}
-// the gathers of a loaded chunk (requested a whole row-sum phase ahead of their use) and the rows of its entries
-template <int R>
-__device__ __forceinline__ void seg_gather(const double* __restrict__ vec, int slab_base, const int (&pk)[kPanelPer], double (&x)[kPanelPer], int (&rid)[kPanelPer])
-{
-#pragma unroll
-  for (int u = 0; u < R; ++u) {
-    x[u]   = vec[slab_base + (int)((unsigned)pk[u] & kSegColMask)];
-    rid[u] = (int)((unsigned)pk[u] >> kSegColBits);
-  }
-}
-// products of the lane's entries; the slots behind the lane's last entry repeat its row with a zero product
-template <int R>
-__device__ __forceinline__ void seg_products(const double (&va)[kPanelPer], const double (&x)[kPanelPer], const int (&rid_in)[kPanelPer], int cnt,
-                                             double (&p)[kPanelPer], int (&rid)[kPanelPer])
-{
-#pragma unroll
-  for (int u = 0; u < R; ++u) {
-    p[u]   = va[u] * x[u];
-    rid[u] = rid_in[u];
-    if (u > 0 && u >= cnt) p[u] = 0.0, rid[u] = rid[u - 1];
-  }
-#pragma unroll
-  for (int u = R; u < kPanelPer; ++u) p[u] = 0.0, rid[u] = rid[R - 1];
-}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double seg_dpp(double v)
 {
@@ -632,26 +622,66 @@ __device__ __forceinline__ double seg_scan(double S, int lane, int seg0)
   u = seg_dpp<0x143, 0xc>(S); if (lane >= 32 && 31 >= seg0) S = S + u;                 // rows 2, 3 <- lane 31
   return S;
 }
-// one emission per run and chunk, and never two lanes at one row inside a chunk (chunks are separated by a barrier): the LDS atomic is
-// used as a fire-and-forget add (no read - wait - write chain in the lane), the result is the plain sum in a fixed order
-__device__ __forceinline__ void seg_emit(double* psum, int row, double v)
+__device__ __forceinline__ void seg_emit(double* strip, int row, double v)
 {
-#ifdef X_SEG_NOEMIT
-  if (row == 123456) psum[0] = v;
-  return;
-#endif
-  __hip_atomic_fetch_add(psum + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(strip + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-
+// the edge runs of one wave-round: the run that starts at lane 0 and -- unless that run fills the whole wave-round -- the run that
+// ends at lane 63
+struct SegRecord {
+  double lsum, rsum;
+  int lkey, rkey;  // rkey < 0: one run from edge to edge (lsum is its sum)
+};
+template <int R>
+__device__ __forceinline__ void seg_load(const PanelView& P, double (&va)[kPanelPer], int (&pk)[kPanelPer], int c0, int c1)
+{
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    int k = c0 + threadIdx.x + u * kPanelThreads;
+    if (u == R - 1) k = k < c1 ? k : c1 - 1;
+    va[u] = __builtin_nontemporal_load(P.val + k);
+    pk[u] = __builtin_nontemporal_load(P.col + k);
+  }
+}
+template <int R>
+__device__ __forceinline__ void seg_rounds(const double* __restrict__ vec, int slab_base, const double (&va)[kPanelPer], const int (&pk)[kPanelPer], int len,
+                                           double* psum, SegRecord* rec /* this wave's records of the chunk, one per round */, int lane)
+{
+  double x[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) x[u] = vec[slab_base + (int)((unsigned)pk[u] & kSegColMask)];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int i   = threadIdx.x + u * kPanelThreads;
+    const int key = (int)((unsigned)pk[u] >> kSegColBits);
+    const double v = (u < R - 1 || i < len) ? va[u] * x[u] : 0.0;  // lanes behind the chunk's end repeat its last entry's row with nothing to add
+    const int prev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0: -1, no row)
+    const unsigned long long starts = __ballot(key != prev);                       // bit t: a run starts at lane t (bit 0 always)
+    const unsigned long long below  = starts & ((2ull << lane) - 1ull);
+    const int seg0                  = 63 - __builtin_clzll(below);
+    const double S                  = seg_scan(v, lane, seg0);
+    const bool ends                 = lane == 63 || ((starts >> (lane + 1)) & 1ull);
+    if (ends) {
+      if (seg0 == 0) {  // the run that started at the wave-round's left edge
+        rec[u].lsum = S, rec[u].lkey = key;
+        if (lane == 63) rec[u].rkey = -1;
+      } else if (lane == 63) {
+        rec[u].rsum = S, rec[u].rkey = key;
+      } else {
+        seg_emit(psum, key, S);
+      }
+    }
+  }
+}
 template <class Epi>
 __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double* __restrict__ vec, Epi& epi, double* __restrict__ partials)
 {
-  static_assert(kPanelPer == 8, "PANEL_DISPATCH enumerates 1..8 rounds");
+  static_assert(kPanelPer == 8 && kPanelWaves == 8, "64 wave-rounds per chunk: one lane of wave 0 each");
   static_assert(kPanelMaxRows <= (1 << (32 - kSegColBits)), "row within the panel must fit beside the column");
-  __shared__ double psum[kPanelMaxRows];
+  __shared__ double psum[kPanelMaxRows];   // runs inside a wave-round (every wave emits)
+  __shared__ double psum2[kPanelMaxRows];  // runs that touch a wave-round's edge, joined (wave 0 alone emits)
   __shared__ double red[kPanelWaves * (Epi::NQ > 0 ? Epi::NQ : 1)];
-  __shared__ double agg_v[2][kPanelWaves];      // per chunk parity and wave: sum of the wave's open run at its last lane ...
-  __shared__ int agg_i[2][kPanelWaves][4];      // ... whether a run ends inside the wave, its first and its last row
+  __shared__ SegRecord rec[2][kPanelWaves * kPanelPer];  // [chunk parity][wave * 8 + round]
   __shared__ int tile_s[17];
   const int w  = blockIdx.x;
   const int NP = P.NP ? P.NP : P.W;
@@ -661,7 +691,7 @@ __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double
   }
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
   if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
-  for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
+  for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0, psum2[r] = 0.0;
   __syncthreads();
   if (P.own_ptr)
     for (int q = P.own_ptr[w] + (int)threadIdx.x; q < P.own_ptr[w + 1]; q += kPanelThreads) psum[P.own_row[q] - r0] = __longlong_as_double(kPanelNotMine);
@@ -683,115 +713,64 @@ __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double
   };
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Three chunks in flight: the matrix stream of chunk i + 2 and the GATHERS of chunk i + 1 are requested before the row sums of
-  // chunk i, so the scan / barrier / emission phase of a chunk runs under the memory round trips of the next one (the row-per-lane
-  // kernel above only has the stream in flight there).
-  double va[kPanelPer], vb[kPanelPer], x[kPanelPer], p[kPanelPer];
-  int pk[kPanelPer], rid_b[kPanelPer], rid[kPanelPer];
+  double va[kPanelPer];
+  int pk[kPanelPer];
 #define SEG_ROUNDS(c) (((c).c1 - (c).c0 + kPanelThreads - 1) / kPanelThreads)
-#define SEG_CALL_LOAD(R) seg_load<R>(P, va, pk, cc.c0, cc.c1 - cc.c0)
-#define SEG_CALL_GATHER(R) seg_gather<R>(vec, cb.s * P.slab_w, pk, x, rid_b)
-#define SEG_CALL_PRODUCTS(R) seg_products<R>(vb, x, rid_b, cnt_b, p, rid)
-#define SEG_COUNT(c, R) ({ int n_ = ((c).c1 - (c).c0) - (int)threadIdx.x * (R); n_ < 0 ? 0 : n_ > (R) ? (R) : n_; })
+#define SEG_CALL_LOAD(R) seg_load<R>(P, va, pk, nxt.c0, nxt.c1)
+#define SEG_CALL_ROUNDS(R) seg_rounds<R>(vec, cur.s * P.slab_w, va, pk, cur.c1 - cur.c0, psum, &rec[parity][wave * kPanelPer], lane)
   PanelChunk none{-1, 0, 0, 0, false};
-  PanelChunk ca = none, cb = none, cc = advance(none);  // ca: being summed, cb: gathers in flight, cc: stream in flight
-  if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
-  // prologue: chunk 0 through load -> gather -> products, chunk 1 gathered, chunk 2 loading
-  cb = cc;
-  if (cb.valid) {
-    PANEL_DISPATCH(SEG_ROUNDS(cb), SEG_CALL_GATHER)
-#pragma unroll
-    for (int u = 0; u < kPanelPer; ++u) vb[u] = va[u];
-    cc = advance(cb);
-    if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
-  }
+  PanelChunk nxt = advance(none);
+  if (nxt.valid) { PANEL_DISPATCH(SEG_ROUNDS(nxt), SEG_CALL_LOAD) }
+  PanelChunk cur = nxt;
   int parity = 0;
-  for (;;) {
-    // cb's gathers are (being) answered: its products become the chunk to sum; the next chunk's gathers go out at once
-    ca = cb;
-    if (!ca.valid) break;
-    const int len = ca.c1 - ca.c0, R = SEG_ROUNDS(ca);
-    const int cnt = SEG_COUNT(ca, R);
-    {
-      const int cnt_b = cnt;
-      PANEL_DISPATCH(R, SEG_CALL_PRODUCTS)
-    }
-    cb = cc;
-    if (cb.valid) {
-      PANEL_DISPATCH(SEG_ROUNDS(cb), SEG_CALL_GATHER)
-#pragma unroll
-      for (int u = 0; u < kPanelPer; ++u) vb[u] = va[u];
-      cc = advance(cb);
-      if (cc.valid) { PANEL_DISPATCH(SEG_ROUNDS(cc), SEG_CALL_LOAD) }
-    }
-#ifdef X_SEG_NOSUM
-    { double t_ = 0.0;
-#pragma unroll
-      for (int u = 0; u < kPanelPer; ++u) t_ += p[u] + (double)rid[u];
-      psum[threadIdx.x] = psum[threadIdx.x] + t_; parity ^= 1; (void)cnt; (void)len; continue; }
-#endif
-    // (1) the lane's open run at its end: v = its sum inside the lane, closed = some run ends inside the lane
-    double v    = p[0];
-    bool closed = false;
-#pragma unroll
-    for (int u = 1; u < kPanelPer; ++u) {
-      const bool b = rid[u] != rid[u - 1];
-      closed |= b;
-      v = b ? p[u] : v + p[u];
-    }
-    if (cnt == 0) v = 0.0;
-    const int my_first = rid[0], my_last = rid[kPanelPer - 1];
-    int prev_last      = __builtin_amdgcn_update_dpp(0, my_last, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    // a lane starts a segment of the scan when a run ends inside it or at its left edge (lane 0: the edge is the wave's affair)
-    const bool flag = cnt > 0 && (closed || (lane > 0 && my_first != prev_last));
-    const unsigned long long fm = __ballot(flag);
-    const unsigned long long at_or_below = fm & ((2ull << lane) - 1ull);
-    const int seg0 = at_or_below ? 63 - __builtin_clzll(at_or_below) : 0;
-    const double S = seg_scan(v, lane, seg0);
-    double carry_in = seg_dpp<0x138, 0xf>(S);  // the open run that reaches this lane from the lanes before it (lane 0: from the waves before)
-    if (lane == 63) {
-      agg_v[parity][wave]    = S;
-      agg_i[parity][wave][0] = fm != 0ull;
-      agg_i[parity][wave][2] = my_last;
-    }
-    if (lane == 0) agg_i[parity][wave][1] = my_first;
-    __syncthreads();  // also: every emission of the previous chunk is done
-    // (2) what reaches this wave from the waves before it (every lane repeats the short fold: LDS broadcasts)
-    double c  = 0.0;
-    int lastk = my_first;  // wave 0: nothing before it -- "the same run", with an empty carry
-    for (int q = 0; q < wave; ++q) {
-      const bool joined = q > 0 && agg_i[parity][q][1] == agg_i[parity][q - 1][2];
-      c                 = agg_i[parity][q][0] ? agg_v[parity][q] : (joined ? c : 0.0) + agg_v[parity][q];
-      lastk             = agg_i[parity][q][2];
-    }
-    const int first0     = __builtin_amdgcn_readfirstlane(my_first);
-    const bool join_wave = first0 == lastk;
-    const bool open_left = (fm & ((1ull << lane) - 1ull)) == 0ull;  // no run ends in the lanes before this one
-    if (lane == 0) carry_in = c, prev_last = lastk;
-    else if (open_left && join_wave) carry_in = carry_in + c;
-    // (3) the walk: a run that ends goes to its row's sum (one emission per run and chunk: no two lanes meet in a row)
-    if (cnt > 0) {
-      int key    = prev_last;
-      double sum = carry_in;
-#pragma unroll
-      for (int u = 0; u < kPanelPer; ++u) {
-        if (rid[u] != key) {
-          seg_emit(psum, key, sum);
-          key = rid[u], sum = 0.0;
+  while (cur.valid) {
+    const int R = SEG_ROUNDS(cur);
+    PANEL_DISPATCH(R, SEG_CALL_ROUNDS)   // gathers, products, the runs inside the wave-rounds, the edge records
+    nxt = advance(cur);
+    if (nxt.valid) { PANEL_DISPATCH(SEG_ROUNDS(nxt), SEG_CALL_LOAD) }  // the next chunk's stream, in flight over the barrier and the join
+    __syncthreads();  // the chunk's records are complete; every emission of the chunk before is done
+    if (wave == 0) {
+      // join the edge runs in logical order: lane l <-> wave-round (round l / 8, wave l % 8), two pieces each (the run from the
+      // left edge, the run to the right edge; one piece when a single run fills the wave-round)
+      const int u = lane >> 3, q = lane & 7;
+      const bool on = u < R;
+      SegRecord g{0.0, 0.0, 0, -1};
+      if (on) g = rec[parity][q * kPanelPer + u];
+      const bool single = g.rkey < 0;
+      const int my_first = g.lkey, my_last = single ? g.lkey : g.rkey;
+      const double open  = on ? (single ? g.lsum : g.rsum) : 0.0;  // the run still open at this lane's right edge
+      int prev_last      = __builtin_amdgcn_update_dpp(0, my_last, 0x138, 0xf, 0xf, false);
+      if (lane == 0) prev_last = my_first;
+      const bool flag = on && (!single || my_first != prev_last);  // a run ends inside this lane's pieces or at its left edge
+      const unsigned long long fm = __ballot(flag);
+      const unsigned long long at_or_below = fm & ((2ull << lane) - 1ull);
+      const int seg0  = at_or_below ? 63 - __builtin_clzll(at_or_below) : 0;
+      const double S  = seg_scan(open, lane, seg0);
+      double carry_in = seg_dpp<0x138, 0xf>(S);
+      if (lane == 0) carry_in = 0.0;
+      if (on) {
+        int key    = prev_last;
+        double sum = carry_in;
+        if (my_first != key) {
+          seg_emit(psum2, key, sum);
+          key = my_first, sum = 0.0;
         }
-        sum = sum + p[u];
+        sum = sum + g.lsum;
+        if (!single) {
+          seg_emit(psum2, key, sum);
+          key = g.rkey, sum = g.rsum;
+        }
+        if (lane == R * kPanelWaves - 1) seg_emit(psum2, key, sum);  // the chunk's last wave-round closes what is still open
       }
-      if ((int)threadIdx.x == (len - 1) / R) seg_emit(psum, key, sum);  // the chunk's last lane closes what is still open
     }
     parity ^= 1;
+    cur = nxt;
   }
-#undef SEG_COUNT
-#undef SEG_CALL_PRODUCTS
-#undef SEG_CALL_GATHER
+#undef SEG_CALL_ROUNDS
 #undef SEG_CALL_LOAD
 #undef SEG_ROUNDS
   __syncthreads();
-  panel_epilogue(P, epi, partials, psum, red, w, r0, nr);
+  panel_epilogue(P, epi, partials, psum, red, w, r0, nr, psum2);
 }
 #undef PANEL_DISPATCH
 template <bool SEG, class Epi>

@@ -319,12 +319,13 @@ int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols);
  * (cuoptamd_partition_rows).  After pdlpdev_scale_problem, before the first pdlpdev_run. */
 int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* offsets, const int32_t* indices, const double* values,
                         const int32_t* row_bounds);
-/* SpMV layout actually in use: out = {A: layout, workgroups, detail, A^T: layout, workgroups, detail}; layout 0 = CSR stream,
- * 1 = slab-major row panels (detail: slabs), 2 = small LP whose attempt batches run inside ONE resident workgroup
- * (CUOPT_AMD_SMALL=0/1 overrides), 3 = sorted jagged rows with LDS column sets (detail: percent of the global gathers the
- * sets save).  Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default; a structural, reproducible rule:
- * DESIGN.md section 3) | stream | panel | jag | timed ; CUOPT_AMD_SLAB_BYTES (1.33 MiB), CUOPT_AMD_PANEL_WS_BYTES (4 MiB),
- * CUOPT_AMD_JAG_WAVES (8 | 16). */
+/* SpMV layout actually in use: out = {A: layout, workgroups, detail, A^T: layout, workgroups, detail, A: row sums, A^T: row sums};
+ * layout 0 = CSR stream, 1 = slab-major row panels (detail: slabs; row sums 0 = a lane per row, short rows left to right, 1 = dealt
+ * by nonzero, the long-tail variant), 2 = small LP whose attempt batches run inside ONE resident workgroup (CUOPT_AMD_SMALL=0/1
+ * overrides), 3 = sorted jagged rows with LDS column sets (detail: percent of the global gathers the sets save), 4 = gather-free
+ * (detail: padding percent).  Chosen at create: environment CUOPT_AMD_SPMV_LAYOUT = auto (default; a structural, reproducible
+ * rule: DESIGN.md section 3) | stream | panel | jag | pb | timed ; geometry knobs through CUOPT_AMD_TUNE (slab_bytes, panel_nnz,
+ * panel_ws_bytes, panel_seg, jag_waves: INTEGRATION.md section 4). */
 int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[8]);
 
 #ifdef __cplusplus
