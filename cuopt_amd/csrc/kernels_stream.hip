@@ -1,0 +1,91 @@
+// gfx950 kernels of the stream layout (one translation unit per layout: a kernel change recompiles this file only).
+// Launched from pdlp_device.hip through the prototypes of pdlp_kernel_decls.hpp.
+#include <hip/hip_runtime.h>
+
+#include "pdlp_kernel_decls.hpp"
+#include "spmv_stream.hpp"
+
+__global__ void __launch_bounds__(kBlock)
+k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+              const int32_t* __restrict__ idx, const double* __restrict__ val,
+              const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
+              double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
+              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+              const p2pdev::Push* __restrict__ push, const double* __restrict__ dadd)
+{
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
+                 ctl->pending_avg != 0, ycopy, push};
+  csr_stream_block(nb, rb, off, idx, val, xbar, e, part, dadd);
+  if (push) p2pdev::count_exchange(push);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_spmv_at_step(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+               const int32_t* __restrict__ idx, const double* __restrict__ val,
+               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
+               const double* __restrict__ y1, const double* __restrict__ x0,
+               const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
+               double* __restrict__ part, const double* __restrict__ dadd)
+{
+  if (!loop_active(ctl)) return;
+  const int cur = ctl->cur;
+  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
+  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part, dadd);
+}
+
+// plain SpMV (A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
+__global__ void __launch_bounds__(kBlock)
+k_spmv_plain(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+             const int32_t* __restrict__ idx, const double* __restrict__ val,
+             const double* __restrict__ vec, double* __restrict__ out, const double* __restrict__ dadd)
+{
+  StoreEpilogue e{out};
+  csr_stream_block(nb, rb, off, idx, val, vec, e, nullptr, dadd);
+}
+
+// variants that pick the ping-pong buffer on the device
+__global__ void __launch_bounds__(kBlock)
+k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+              const int32_t* __restrict__ idx, const double* __restrict__ val,
+              const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
+              const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
+              double* __restrict__ out_override, int use_next, const double* __restrict__ dadd)
+{
+  const int cur = ctl->cur ^ (use_next ? 1 : 0);
+  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
+  csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr, dadd);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_eval_primal(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+              const int32_t* __restrict__ idx, const double* __restrict__ val,
+              const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0,
+              const double* __restrict__ x1, const double* __restrict__ avgx,
+              const double* __restrict__ y0, const double* __restrict__ y1,
+              const double* __restrict__ avgy, const double* __restrict__ dr,
+              const double* __restrict__ lo_u, const double* __restrict__ hi_u, double eps_rel,
+              double* __restrict__ linf_rows, double* __restrict__ ax_out, double* __restrict__ part, const double* __restrict__ dadd)
+{
+  const int cur = ctl->cur;
+  const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
+  csr_stream_block(nb, rb, off, idx, val, xv, e, part, dadd);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
+            const int32_t* __restrict__ idx, const double* __restrict__ val,
+            const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0,
+            const double* __restrict__ x1, const double* __restrict__ avgx,
+            const double* __restrict__ y0, const double* __restrict__ y1,
+            const double* __restrict__ avgy, EvalDualCore core, double* __restrict__ part, const double* __restrict__ dadd)
+{
+  const int cur = ctl->cur;
+  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
+  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
+  EvalDualEpilogue e{core};
+  csr_stream_block(nb, rb, off, idx, val, yv, e, part, dadd);
+}

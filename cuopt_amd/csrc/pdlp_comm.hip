@@ -1,0 +1,248 @@
+// Communicators, collectives and the direct peer transport's set-up of sharded solves (one translation unit: the multi-GPU side
+// of the device layer).  The kernels of an attempt are launched by the core (pdlp_device.hip), which calls the collectives below.
+#include "pdlp_ctx.hpp"
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// ---- multi-GPU ----------------------------------------------------------------------------------
+int pdlpdev_comm_unique_id(uint8_t id[128])
+{
+  TRY(rccl::load());
+  rccl::unique_id u;
+  RCCL_TRY(rccl::GetUniqueId(&u));
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+int pdlpdev_softcomm_create(int world, uint8_t id[128])
+{
+  if (world < 1 || world > 16) return fail(-1, "pdlpdev_softcomm_create: world must be in 1..16");
+  softcomm::Comm* c = new softcomm::Comm();
+  c->world = world;
+  c->bufs.assign(world, nullptr), c->scratch.assign(world, nullptr), c->scratch_size.assign(world, 0);
+  memset(id, 0, 128);
+  memcpy(id, softcomm::kMagic, 8);
+  memcpy(id + 8, &c, sizeof(c));
+  return 0;
+}
+// CUOPT_AMD_SHARD_DATAFLOW = owner (default) | allreduce | rsag : see the `rsag` / `owner` fields of the context
+int setup_dataflow(pdlpdev_ctx* ctx)
+{
+  const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
+  const std::string flow = env ? env : "owner";  // default since round 3: nothing but the slices themselves travels
+  if (flow == "allreduce") return 0;
+  if (flow != "rsag" && flow != "owner") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce, rsag or owner");
+  if (ctx->world > 16) return fail(-1, "the sliced-primal dataflows support up to 16 ranks");
+  if (!ctx->soft && (!rccl::ReduceScatter || !rccl::AllGather)) return fail(-3, "RCCL: ncclReduceScatter / ncclAllGather missing");
+  const int per = (ctx->n + ctx->world - 1) / ctx->world;
+  ctx->slice    = (per + 15) & ~15;
+  ctx->rsag     = true;  // both keep the primal side in slices inside the attempt loop
+  ctx->owner    = flow == "owner";  // ... the column block arrives with pdlpdev_owner_setup
+  TRY(dev_alloc(ctx, &ctx->rs_buf, (size_t)ctx->slice + 8));
+  TRY(dev_alloc(ctx, &ctx->rs_scal, 8 + 4 * 16));  // [0..3) this rank's sums, [4..7) the ranks' sums, [8..) landed scalars (p2p)
+  return 0;
+}
+int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128])
+{
+  if (memcmp(id, softcomm::kMagic, 8) == 0) {
+    softcomm::Comm* c = nullptr;
+    memcpy(&c, id + 8, sizeof(c));
+    if (!c || c->world != world) return fail(-1, "soft communicator: world mismatch");
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      c->refs += 1;
+    }
+    ctx->soft = c;
+    ctx->comm = reinterpret_cast<rccl::comm_t>(c);  // marks sharded mode; never passed to RCCL
+    ctx->rank = rank, ctx->world = world;
+    return setup_dataflow(ctx);
+  }
+  TRY(rccl::load());
+  HIP_TRY(hipSetDevice(ctx->device));
+  // A unique id bootstraps exactly ONE communicator per rank; solvers created later with the same (id, rank) -- bench.py
+  // makes two per process -- share it.  The ranks of a single-process sharded solve (cuoptamd_solve_sharded: one host
+  // thread per device) each get their own; ncclCommInitRank blocks until every rank has joined, so it runs outside the
+  // lock.  Communicators live until process exit.
+  std::string key((const char*)id, 128);
+  key.append((const char*)&rank, sizeof(rank));
+  rccl::comm_t comm = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(comm_cache::mu);
+    auto it = comm_cache::map.find(key);
+    if (it != comm_cache::map.end()) comm = it->second.comm, it->second.refs += 1;
+  }
+  if (!comm) {
+    rccl::unique_id u;
+    memcpy(u.internal, id, 128);
+    RCCL_TRY(rccl::CommInitRank(&comm, world, u, rank));
+    std::lock_guard<std::mutex> lock(comm_cache::mu);
+    comm_cache::map.emplace(key, comm_cache::Entry{comm, 1});
+  }
+  ctx->comm = comm, ctx->comm_key = key;
+  ctx->rank = rank, ctx->world = world;
+  return setup_dataflow(ctx);
+}
+// A rank of a sharded solve failed: nobody may wait for it.  Aborts every communicator this process created from `id`
+// (ncclCommAbort ends the collectives in flight; the in-process communicator wakes its barriers) -- the other ranks' next
+// collective returns an error instead of blocking.
+int pdlpdev_comm_abort(const uint8_t id[128])
+{
+  if (memcmp(id, softcomm::kMagic, 8) == 0) {
+    softcomm::Comm* c = nullptr;
+    memcpy(&c, id + 8, sizeof(c));
+    if (c) c->abort();
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(comm_cache::mu);
+  for (auto& kv : comm_cache::map)
+    if (kv.first.compare(0, 128, std::string((const char*)id, 128)) == 0 && !kv.second.aborted) {
+      kv.second.aborted = true;
+      if (rccl::CommAbort) (void)rccl::CommAbort(kv.second.comm);
+    }
+  return 0;
+}
+// recv[0..count) = sum over the ranks of send[rank * count ..][0..count)   (ncclReduceScatter)
+int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t count)
+{
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
+    c->bufs[r] = const_cast<double*>(send);
+    SOFT_BARRIER(c);
+    softcomm::Peers peers;
+    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q] + (size_t)r * count;
+    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
+    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, 0, recv);  // recv is nobody's input
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SOFT_BARRIER(c);  // nobody still reads the inputs
+    return 0;
+  }
+  RCCL_TRY(rccl::ReduceScatter(send, recv, count, rccl::kFloat64, rccl::kSum, ctx->comm, ctx->stream));
+  return 0;
+}
+// buf[q * count ..][0..count) = rank q's slice, in place (ncclAllGather with sendbuff = recvbuff + rank * count)
+int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count)
+{
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    c->bufs[r] = buf;
+    SOFT_BARRIER(c);
+    for (int q = 0; q < c->world; ++q)
+      if (q != r)
+        HIP_TRY(hipMemcpyAsync(buf + (size_t)q * count, c->bufs[q] + (size_t)q * count, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SOFT_BARRIER(c);  // nobody still reads my slice
+    return 0;
+  }
+  RCCL_TRY(rccl::AllGather(buf + (size_t)ctx->rank * count, buf, count, rccl::kFloat64, ctx->comm, ctx->stream));
+  return 0;
+}
+int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
+{
+  if (!ctx->comm) return 0;
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    const int r       = ctx->rank;
+    if (c->scratch_size[r] < count) {
+      if (c->scratch[r]) (void)hipFree(c->scratch[r]);
+      HIP_TRY(hipMalloc((void**)&c->scratch[r], count * sizeof(double)));
+      c->scratch_size[r] = count;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
+    c->bufs[r] = buf;
+    SOFT_BARRIER(c);                                // everybody's contribution is complete and published
+    softcomm::Peers peers;
+    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q];
+    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
+    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, op == rccl::kSum ? 0 : 1, c->scratch[r]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SOFT_BARRIER(c);                                // nobody still reads the inputs
+    HIP_TRY(hipMemcpyAsync(buf, c->scratch[r], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
+  RCCL_TRY(rccl::AllReduce(buf, buf, count, rccl::kFloat64, op, ctx->comm, ctx->stream));
+  return 0;
+}
+
+
+// Direct peer transport: allocate this rank's landing block and learn where the other ranks' blocks are.
+//   in-process communicator: the ranks are contexts of one process (tests: on ONE device) -> a table in the communicator;
+//   RCCL: one 128-byte record per rank {IPC handle, process id, pointer, device} all-gathered through the communicator:
+//   same process -> the pointer itself (peer access enabled), another process -> hipIpcOpenMemHandle.
+int p2p_setup(pdlpdev_ctx* ctx)
+{
+  pdlpdev_ctx::P2P& P = ctx->p2p;
+  const size_t W = (size_t)ctx->world;
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  P.off_x = 0;
+  P.off_y = align(P.off_x + W * (size_t)ctx->slice * sizeof(double));
+  P.off_s = align(P.off_y + W * (size_t)ctx->ypad * sizeof(double));
+  P.off_f = align(P.off_s + W * 4 * sizeof(double));
+  P.bytes = (P.off_f + p2pdev::kKinds * W * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+  HIP_TRY(hipExtMallocWithFlags((void**)&P.base, P.bytes, hipDeviceMallocFinegrained));
+  HIP_TRY(hipMemset(P.base, 0, P.bytes));
+  TRY(dev_alloc(ctx, &P.epoch, 4));
+  TRY(dev_alloc(ctx, &P.fault, 4));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (c->p2p_base.size() != W) c->p2p_base.assign(W, nullptr);
+      c->p2p_base[ctx->rank] = P.base;
+    }
+    SOFT_BARRIER(c);
+    for (size_t q = 0; q < W; ++q) P.peers.base[q] = (char*)c->p2p_base[q];
+    SOFT_BARRIER(c);  // everybody has read the table before anybody can overwrite it with the next solver's blocks
+  } else {
+    struct Rec {
+      hipIpcMemHandle_t handle;
+      unsigned long long pid, ptr, device;
+      char pad[128 - sizeof(hipIpcMemHandle_t) - 24];
+    };
+    static_assert(sizeof(Rec) == 128, "one record = 16 doubles on the wire");
+    std::vector<Rec> recs(W);
+    Rec mine;
+    memset(&mine, 0, sizeof(mine));
+    HIP_TRY(hipIpcGetMemHandle(&mine.handle, P.base));
+    mine.pid = (unsigned long long)getpid(), mine.ptr = (unsigned long long)(uintptr_t)P.base, mine.device = (unsigned long long)ctx->device;
+    double* wire = nullptr;
+    TRY(dev_alloc(ctx, &wire, W * 16));
+    HIP_TRY(hipMemcpyAsync(wire + (size_t)ctx->rank * 16, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    RCCL_TRY(rccl::AllGather(wire + (size_t)ctx->rank * 16, wire, 16, rccl::kFloat64, ctx->comm, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(recs.data(), wire, W * sizeof(Rec), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q < W; ++q) {
+      if ((int)q == ctx->rank) {
+        P.peers.base[q] = P.base;
+      } else if (recs[q].pid == mine.pid) {
+        if ((int)recs[q].device != ctx->device) {
+          const hipError_t e = hipDeviceEnablePeerAccess((int)recs[q].device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(-2, "hipDeviceEnablePeerAccess(%d): %s", (int)recs[q].device, hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+        P.peers.base[q] = (char*)(uintptr_t)recs[q].ptr;
+      } else {
+        void* mapped = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&mapped, recs[q].handle, hipIpcMemLazyEnablePeerAccess));
+        P.opened.push_back(mapped);
+        P.peers.base[q] = (char*)mapped;
+      }
+    }
+  }
+  {
+    p2pdev::Push h[p2pdev::kKinds];
+    const size_t slot[p2pdev::kKinds] = {P.off_x + (size_t)ctx->rank * ctx->slice * sizeof(double), P.off_y + (size_t)ctx->rank * ctx->ypad * sizeof(double),
+                                         P.off_s + (size_t)ctx->rank * 4 * sizeof(double)};
+    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch};
+    TRY(dev_alloc(ctx, &P.push_dev, p2pdev::kKinds));
+    HIP_TRY(hipMemcpyAsync(P.push_dev, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  P.on = true;
+  return 0;
+}

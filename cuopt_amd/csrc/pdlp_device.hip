@@ -1,555 +1,5 @@
-// HIP/gfx950 device layer of the MI355X-native PDLP solver: kernels + the `pdlpdev_*` C-ABI
-// declared in include/cuopt_amd/pdlp_device.h (which lists the reference code each entry point
-// replaces).  Hand-written for CDNA4: wave64, LDS-staged CSR stream SpMV with fused PDHG epilogues,
-// device-resident step acceptance (no host round trip per PDHG step), hipGraph replay.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
+#include "pdlp_ctx.hpp"
 
-#include <tuple>
-#include <utility>
-
-#include <dlfcn.h>
-#include <unistd.h>
-#include <mutex>
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <chrono>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "host_parallel.hpp"
-#include "pdlp_kernels.hpp"
-
-using namespace pdlp;
-
-// ================================================================================================
-// error plumbing
-// ================================================================================================
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...)
-{
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
-}
-#define HIP_TRY(expr)                                                                       \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-// ================================================================================================
-// RCCL, bound lazily so that the library loads (and the single-GPU path runs) without it
-// ================================================================================================
-namespace rccl {
-typedef struct ncclComm* comm_t;
-typedef struct { char internal[128]; } unique_id;
-enum { kFloat64 = 8 };           // ncclDouble
-enum { kSum = 0, kMax = 2 };     // ncclSum / ncclMax
-static void* lib;
-static int (*GetUniqueId)(unique_id*);
-static int (*CommInitRank)(comm_t*, int, unique_id, int);
-static int (*CommDestroy)(comm_t);
-static int (*CommAbort)(comm_t);
-static int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
-static int (*ReduceScatter)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
-static int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
-static const char* (*GetErrorString)(int);
-static std::mutex load_mutex;
-static int load()
-{
-  std::lock_guard<std::mutex> guard(load_mutex);
-  if (lib) return 0;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* nm : names) {
-    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
-  }
-  if (!lib) return fail(-3, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
-  *(void**)&GetUniqueId    = dlsym(lib, "ncclGetUniqueId");
-  *(void**)&CommInitRank   = dlsym(lib, "ncclCommInitRank");
-  *(void**)&CommDestroy    = dlsym(lib, "ncclCommDestroy");
-  *(void**)&CommAbort      = dlsym(lib, "ncclCommAbort");
-  *(void**)&AllReduce      = dlsym(lib, "ncclAllReduce");
-  *(void**)&ReduceScatter  = dlsym(lib, "ncclReduceScatter");
-  *(void**)&AllGather      = dlsym(lib, "ncclAllGather");
-  *(void**)&GetErrorString = dlsym(lib, "ncclGetErrorString");
-  if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce)
-    return fail(-3, "RCCL symbols missing");
-  return 0;
-}
-}  // namespace rccl
-#define RCCL_TRY(expr)                                                                     \
-  do {                                                                                     \
-    int r_ = (expr);                                                                       \
-    if (r_ != 0)                                                                           \
-      return fail(-4, "%s failed: %s", #expr,                                              \
-                  rccl::GetErrorString ? rccl::GetErrorString(r_) : "rccl error");         \
-  } while (0)
-
-
-// RCCL communicators of this process: one per (unique id, rank), shared by the solvers created with the same pair while
-// any of them is alive (reference count); the last solver to go destroys it -- a unique id bootstraps exactly one communicator
-// per rank, so a caller that creates a second solver after the first one is gone draws a new id.
-namespace comm_cache {
-struct Entry {
-  rccl::comm_t comm;
-  int refs;
-  bool aborted = false;
-};
-static std::mutex mu;
-static std::map<std::string, Entry> map;
-static void release(const std::string& key)
-{
-  rccl::comm_t dead = nullptr;
-  bool aborted      = false;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = map.find(key);
-    if (it == map.end() || --it->second.refs > 0) return;
-    dead = it->second.comm, aborted = it->second.aborted;
-    map.erase(it);
-  }
-  if (dead && !aborted && rccl::CommDestroy) (void)rccl::CommDestroy(dead);  // (ncclCommAbort already freed an aborted one)
-}
-}  // namespace comm_cache
-
-// ================================================================================================
-// in-process "soft" communicator (verification of the sharded path at world > 1 on one GPU)
-// ================================================================================================
-#include <condition_variable>
-#include <mutex>
-namespace softcomm {
-constexpr char kMagic[8] = {'C', 'U', 'O', 'P', 'T', 'S', 'F', 'T'};
-struct Comm {
-  int world = 0;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0, generation = 0;
-  int refs = 0;                  // solvers attached (the last one to leave frees the communicator)
-  bool aborted = false;          // a rank failed: every barrier returns false from now on, nobody waits for the missing rank
-  std::vector<double*> bufs;     // this round's buffer of every rank
-  std::vector<double*> scratch;  // per-rank result staging
-  std::vector<size_t> scratch_size;
-  std::vector<void*> p2p_base;   // direct-peer transport: every rank's landing block (same device, same process)
-  bool barrier()
-  {
-    std::unique_lock<std::mutex> lk(mu);
-    if (aborted) return false;
-    const int gen = generation;
-    if (++arrived == world) {
-      arrived = 0;
-      ++generation;
-      cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return gen != generation || aborted; });
-    }
-    return !aborted;
-  }
-  void abort()
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    aborted = true;
-    cv.notify_all();
-  }
-};
-#define SOFT_BARRIER(c)                                                                                   \
-  do {                                                                                                    \
-    if (!(c)->barrier()) return fail(-6, "in-process communicator: another rank failed, solve abandoned"); \
-  } while (0)
-struct Peers {
-  const double* p[16];
-};
-__global__ void __launch_bounds__(256) k_combine(Peers peers, int world, size_t count, int op, double* __restrict__ out)
-{
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-    double acc = peers.p[0][i];
-    for (int r = 1; r < world; ++r) {  // fixed rank order -> every rank computes the same bits
-      const double v = peers.p[r][i];
-      acc            = op == 0 ? acc + v : (v > acc ? v : acc);
-    }
-    out[i] = acc;
-  }
-}
-}  // namespace softcomm
-
-// ---- roctx ranges (the reference marks every phase with NVTX: LP/pdhg.cu:75,168,241, LP/pdlp.cu:541,1227) --------------
-// bound lazily like RCCL: without the library (or with CUOPT_AMD_ROCTX=0) the calls are no-ops
-namespace roctx {
-static int (*Push)(const char*) = nullptr;
-static int (*Pop)()             = nullptr;
-static std::once_flag once;
-static void load()
-{
-  std::call_once(once, [] {
-    if (cuopt_amd::tune_int("roctx", 1) == 0) return;
-    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-        Push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
-        Pop  = (int (*)())dlsym(h, "roctxRangePop");
-        if (Push && Pop) return;
-        Push = nullptr, Pop = nullptr;
-      }
-    }
-  });
-}
-struct Range {
-  explicit Range(const char* name)
-  {
-    load();
-    if (Push) Push(name);
-  }
-  ~Range()
-  {
-    if (Pop) Pop();
-  }
-};
-}  // namespace roctx
-
-// ================================================================================================
-// direct peer transport (owner-computes dataflow): push / pull kernels
-// ================================================================================================
-namespace p2pdev {
-struct Peers {
-  char* base[16];
-};
-constexpr int kKinds = 3;  // exchanges per attempt: xbar slices, y' row blocks, step-size scalars
-__device__ __forceinline__ bool active(const pdlpdev_ctl* ctl) { return ctl->error == 0 && ctl->steps_taken < ctl->target_steps; }
-
-// What a PRODUCING kernel (primal step, dual step, packing of the step-size sums) needs to store its results straight into
-// every rank's landing block and to raise this rank's flag there; lives in device memory (one per exchange), kernels take a
-// pointer (null: no peer transport) and read the table with scalar loads.
-struct Push {
-  Peers P;
-  int world, rank, kind;
-  size_t dst_off, flag_off;  // bytes inside every rank's block: this rank's slot of the exchange / the flag area
-  unsigned long long* epoch;
-  __device__ __forceinline__ double* slot(int q) const { return reinterpret_cast<double*>(P.base[q] + dst_off); }
-};
-// A producing kernel's store into a landing block: system scope = write-through, so that no cache write-back is needed before the
-// flag goes up
-__device__ __forceinline__ void put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// Called once per workgroup at the end of a producing kernel: ONE thread of the grid counts the exchange.  The flag itself is raised
-// by the first workgroup of the NEXT kernel of the stream (raise, below): a kernel boundary is what guarantees that every store of
-// the producer has landed, for nothing.  (Round 3 published from the producer's tail -- every thread waited for its own stores, the
-// workgroup took a ticket, the last one raised the flags: at one rank that made k_primal 31.8 us instead of 13.)
-__device__ __forceinline__ void count_exchange(const Push* T)
-{
-  if (blockIdx.x == 0 && threadIdx.x == 0) T->epoch[T->kind] = T->epoch[T->kind] + 1;
-}
-// first thread of the consuming kernel: this rank's flag of the exchange goes up in every rank's block
-__device__ __forceinline__ void raise(const Push* T)
-{
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const unsigned long long e = T->epoch[T->kind];
-  for (int q = 0; q < T->world; ++q) {
-    unsigned long long* flag = reinterpret_cast<unsigned long long*>(T->P.base[q] + T->flag_off) + (size_t)T->kind * T->world + T->rank;
-    __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-// lane q waits for rank q's flag of exchange `kind` (relaxed polls), then ONE lane acquires for the workgroup; false when
-// patience ran out (5 s: a peer died)
-__device__ __forceinline__ bool wait_flags(const unsigned long long* flags, int world, int kind, const unsigned long long* epoch)
-{
-  bool ok = true;
-  if ((int)threadIdx.x < world) {
-    const unsigned long long want = epoch[kind];
-    const unsigned long long* f   = flags + (size_t)kind * world + threadIdx.x;
-    const unsigned long long t0   = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 500000000ull) {  // 100 MHz
-        ok = false;
-        break;
-      }
-    }
-  }
-  ok = __syncthreads_and(ok);
-  if (threadIdx.x == 0) __threadfence_system();
-  __syncthreads();
-  return ok;
-}
-// wait until every rank's flag of exchange `kind` shows this rank's epoch, then landing -> dst (`count` doubles) EXCEPT this rank's
-// own share [own0, own0 + own_count), which its producing kernel stored straight into dst.  Every workgroup polls for itself (local
-// memory, one load per rank per poll); patience is bounded: a peer that never arrives sets the step error and the fault flag instead
-// of hanging the device.  Four 16-byte requests per thread in flight (the landing block is fine-grained: every read is a trip to
-// memory, and one request at a time ran at 0.75 TB/s).
-__global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ ctl, double* __restrict__ dst, const double* __restrict__ land, int count,
-                                              int own0, int own_count, const unsigned long long* __restrict__ flags, int world, int kind,
-                                              const unsigned long long* __restrict__ epoch, int* __restrict__ fault, const Push* __restrict__ push)
-{
-  if (!active(ctl)) return;
-  raise(push);  // the producing kernel before this one in the stream is complete: its exchange is published here
-  if (!wait_flags(flags, world, kind, epoch)) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
-    return;
-  }
-  // (count, own0 and own_count are multiples of 16 entries and both buffers are 256-byte aligned: 16-byte requests)
-  typedef double v2 __attribute__((ext_vector_type(2)));
-  const v2* __restrict__ src2 = reinterpret_cast<const v2*>(land);
-  v2* __restrict__ dst2       = reinterpret_cast<v2*>(dst);
-  const int n2 = (count - own_count) >> 1, o2 = own0 >> 1, skip2 = own_count >> 1;  // pairs to copy; the own share is stepped over
-  constexpr int U = 4;
-  for (int i = blockIdx.x * 256 * U + threadIdx.x; i < n2; i += gridDim.x * 256 * U) {
-    v2 v[U];
-    int at[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = i + u * 256;
-      at[u]       = k < n2 ? (k < o2 ? k : k + skip2) : -1;
-      if (at[u] >= 0) v[u] = __builtin_nontemporal_load(src2 + at[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (at[u] >= 0) dst2[at[u]] = v[u];
-  }
-}
-}  // namespace p2pdev
-
-// ================================================================================================
-// context
-// ================================================================================================
-constexpr size_t kSlicePad = 512;  // spare entries of the vectors that are exchanged in equal slices (sliced-primal dataflow)
-struct pdlpdev_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int32_t m = 0, n = 0;
-  int64_t nnz = 0;
-  // matrices (values are scaled in place by pdlpdev_scale_problem)
-  int32_t *a_off = nullptr, *a_idx = nullptr, *at_off = nullptr, *at_idx = nullptr;
-  double *a_val = nullptr, *at_val = nullptr;
-  int32_t *a_rb = nullptr, *at_rb = nullptr;  // row-block boundaries of the stream kernels
-  int a_nb = 0, at_nb = 0;
-  // slab-major row panels (optional second layout of the same nonzeros, see pdlp_kernels.hpp)
-  struct Panels {
-    bool on = false;
-    PanelView v{};
-    int32_t* perm = nullptr;  // position in CSR order of each panel-order nonzero
-    double* val   = nullptr;
-    int64_t nent  = 0;        // nonzeros inside the panels (rows with a workgroup of their own are read from the CSR)
-  } pa, pat;
-  int cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-  // rows of A / of A^T with more than kLongRow nonzeros (set-up kernels give each a workgroup instead of a lane)
-  int32_t *a_long = nullptr, *at_long = nullptr;
-  int a_nlong = 0, at_nlong = 0;
-  // sorted jagged rows with LDS column sets (third layout, structured matrices; pdlp_kernels.hpp)
-  struct Jag {
-    bool on = false;
-    JagView v{};
-    int32_t* perm = nullptr;  // position in CSR order of each jagged-order entry
-    double* val   = nullptr;
-    int64_t nent  = 0;
-    double saving = 0.0;      // share of the global gathers the LDS column sets save (build_jag)
-  } ja, jat;
-  // Dense row segments (runs of >= kDenseMin consecutive columns inside a row: budget / convexity / linking constraints that
-  // run through a block of variables) are stored INDEX-FREE, 8 bytes per entry instead of 12, and multiplied by two streaming
-  // kernels of their own (k_dense_rows: lane <-> entry, the vector read coalesced; k_dense_cols: lane <-> column, the rows that
-  // cover it in ascending order); the four layouts then work on the sparse remainder ("hot" CSR: ha_* / hat_*, the matrices
-  // without the segments' entries) and add what the segments contribute ahead of their fused epilogues (dense_plus).  The
-  // set-up kernels (norms, scaling) keep running on the full CSR.  Rows / columns a segment touches are compared with the
-  // oracle at the long-row tolerance (their sums are split in two).
-  struct Dense {
-    bool on = false;
-    int nrows = 0, nseg = 0, ntiles = 0;
-    int64_t nent = 0;
-    int32_t *row = nullptr, *row_seg = nullptr;  // rows that own segments, their segment ranges
-    int32_t *seg_row = nullptr, *seg_c0 = nullptr, *seg_len = nullptr, *seg_ptr = nullptr;  // nseg (+1)
-    int32_t *ch_seg = nullptr, *ch_k0 = nullptr, *row_ch = nullptr;  // chunks of the segments (k_dense_rows), per owning row
-    double* ch_part = nullptr;
-    int nchunks = 0;
-    int32_t *tile_ptr = nullptr, *tile_seg = nullptr, *tile_id = nullptr;  // per 256-column tile some segment overlaps: those segments, ascending rows
-    int32_t *perm = nullptr, *s_perm_a = nullptr, *s_perm_at = nullptr;  // positions in the FULL CSR of A / A / A^T
-    double* val = nullptr;                   // nent: the segments' values, row after row
-    double *add_m = nullptr, *add_n = nullptr;  // what the segments contribute to A v (per row) / A^T v (per column)
-    int64_t hot_nnz = 0;
-  } dense;
-  int64_t hot_nnz_at = 0;
-  int32_t *ha_off = nullptr, *ha_idx = nullptr, *hat_off = nullptr, *hat_idx = nullptr;  // the CSR the hot loop multiplies:
-  double *ha_val = nullptr, *hat_val = nullptr;                                          // a_* / at_* unless dense.on
-  // gather-free layout (fourth layout: huge unstructured matrices; pdlp_kernels.hpp "pb")
-  struct Pb {
-    bool on = false;
-    PbView v{};
-    int32_t* perm = nullptr;  // position in CSR order of each padded P-order entry (-1: padding)
-    double* val   = nullptr;
-    int64_t np    = 0;        // padded entries
-    int p_threads = 512;      // phase P workgroup: 512 (8192-column panels) or 1024 (16384)
-    double pad    = 1.0;      // padded entries / nonzeros
-  } pba, pbat;
-  // problem vectors: scaled working copies and the unscaled originals
-  double *c = nullptr, *lb = nullptr, *ub = nullptr, *lo = nullptr, *hi = nullptr;
-  double *c_u = nullptr, *lb_u = nullptr, *ub_u = nullptr, *lo_u = nullptr, *hi_u = nullptr;
-  double *dr = nullptr, *dc = nullptr;
-  bool scaled = false;
-  // iterate state
-  double *x[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *aty[2] = {nullptr, nullptr};
-  double *xbar = nullptr, *sumx = nullptr, *sumy = nullptr, *avgx = nullptr, *avgy = nullptr;
-  double *lrx = nullptr, *lry = nullptr, *rc[2] = {nullptr, nullptr};
-  double *tmp_n = nullptr, *tmp_m = nullptr;
-  double *ax_u[3] = {nullptr, nullptr, nullptr}, *aty_u[3] = {nullptr, nullptr, nullptr};  // unscaled A x / A^T y of pdlpdev_eval(which)
-  double* rc_scratch = nullptr;  // reduced costs of eval(LAST_RESTART): never returned
-  double *bestx = nullptr, *besty = nullptr, *bestrc = nullptr;  // save_best_primal_so_far snapshot (scaled x, y)
-  // reductions
-  double *part_a = nullptr, *part_at = nullptr;  // per-row-block partials (8 quantities each)
-  double *part_g = nullptr;                      // generic grid-stride partials
-  double *scal = nullptr;                        // device scalars (outputs of finalize kernels)
-  double *scal_h = nullptr;                      // pinned mirror
-  pdlpdev_ctl *ctl = nullptr, *ctl_h = nullptr;  // device control block + pinned mirror
-  pdlpdev_step_params sp = {0.3, 0.6, 0.5, 0.5};
-  // multi-GPU
-  rccl::comm_t comm = nullptr;  // non-null also marks "sharded mode" when the soft communicator is used
-  softcomm::Comm* soft = nullptr;
-  std::string comm_key;  // RCCL: this solver's entry of the communicator cache
-  int rank = 0, world = 1;
-  double* ar_buf = nullptr;  // n + pad doubles: A^T y partial + packed scalars
-  // "sliced primal" dataflow of a sharded solve (CUOPT_AMD_SHARD_DATAFLOW=rsag): inside the attempt loop a rank updates only
-  // its slice [rank * slice, rank * slice + slice) of the primal-side vectors; reduce-scatter(A^T y' partials) -> slice of
-  // A^T y', all-gather(xbar slices) -> the gathered vector of the next A xbar.  Outside the loop everything is replicated.
-  bool rsag = false;
-  int slice = 0;               // entries per rank, a multiple of 16; slice * world >= n
-  double* rs_buf = nullptr;    // slice + 8: this rank's part of the reduced A^T y'
-  double* rs_scal = nullptr;   // ||dy||^2, interaction, ||dx||^2 partial sums of this rank -> all-reduced
-  // "owner computes" dataflow (CUOPT_AMD_SHARD_DATAFLOW=owner): on top of the sliced primal update a rank also holds ITS
-  // COLUMNS of A (rows [rank * slice, ...) of A^T over ALL rows of A), so that A^T y' of its slice is complete on the rank:
-  // all-gather(xbar slices) -> local rows of A -> y' -> all-gather(y' row blocks) -> local columns of A -> slice of A^T y'
-  // and of the step-size sums.  No partial products travel, nothing is reduced but three scalars, and every column is summed
-  // over all rows in row order exactly as on one GPU.
-  bool owner = false;
-  int ypad = 0;               // entries per rank in the gathered dual vector: the largest row block, a multiple of 16
-  double* ygather = nullptr;  // world * ypad: rank q's y' at [q * ypad, ...); also the gather vector of the column block
-  int32_t oc_rows = 0;        // columns of A this rank owns (= rows of the column block)
-  int64_t oc_nnz = 0;
-  int32_t *oc_off = nullptr, *oc_idx = nullptr, *oc_rb = nullptr, *oc_long = nullptr;
-  double* oc_val = nullptr;
-  int oc_nb = 0, oc_nlong = 0;
-  Panels poc;
-  Jag joc;
-  double* part_oc = nullptr;
-  // direct peer transport of the owner-computes dataflow (CUOPT_AMD_SHARD_TRANSPORT=p2p): every rank owns one fine-grained
-  // LANDING block [xbar of all ranks | y' of all ranks | 4 step-size scalars per rank | 3 * world epoch flags]; a producer
-  // stores its slice into every rank's block (peer-mapped: same process -> the pointer itself after
-  // hipDeviceEnablePeerAccess, other process -> hipIpcOpenMemHandle) and then raises its flag there; a consumer waits for the
-  // world flags of the exchange, then copies the landed data into its ordinary vectors.  No collective call, no host between
-  // the kernels of an attempt -> the attempt graph replays as on one GPU.
-  struct P2P {
-    bool on = false;
-    char* base = nullptr;            // this rank's landing block
-    size_t bytes = 0;
-    size_t off_x = 0, off_y = 0, off_s = 0, off_f = 0;  // byte offsets inside every rank's block
-    p2pdev::Peers peers{};           // base of every rank's block as THIS process addresses it
-    std::vector<void*> opened;       // hipIpcOpenMemHandle mappings to close
-    unsigned long long* epoch = nullptr;  // device: epochs of the three exchanges (xbar, y', scalars) as this rank counts them
-    int* fault = nullptr;            // device: set when a wait ran out of patience (peer died)
-    p2pdev::Push* push_dev = nullptr;  // device: the three exchanges' descriptors (xbar, y', scalars) for the producing kernels
-  } p2p;
-  // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
-  // dispatch itself, what rocprofv3 --kernel-trace reports)
-  // (a call site may consist of several launches -- dense segments, phase P, phase R: each gets its own pair, the durations add up)
-  bool prof_armed = false;
-  static constexpr int kProfPairs = 8;
-  hipEvent_t prof_ev[2 * kProfPairs] = {};
-  int prof_used = 0;
-  int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
-  // graphs
-  int use_graph = 1;
-  bool graph_comm_failed = false;  // capturing the RCCL collectives into an attempt graph failed once: plain launches from then on
-  char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
-  char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
-  size_t arena_used = 0;
-  bool small_resident = false;  // whole attempt batches inside one workgroup (k_pdhg_small)
-  std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
-  std::vector<void*> allocs;
-  int64_t bytes = 0;
-};
-
-constexpr int kGenericBlocks = 1024;
-constexpr int kScalars       = 64;
-
-// Streams (an HSA queue each: ~2 ms to create), the pinned read-back block and the first arena chunk are handed from
-// a destroyed context to the next one created on the same device: back-to-back small solves (cuOptSolve in a loop,
-// MIP-style re-solves) otherwise spend more time in these three calls than in PDHG.  Never freed (a few per device).
-struct Recycled {
-  int device;
-  hipStream_t stream;
-  double* pinned;
-  char* chunk;
-};
-static std::mutex g_recycle_mutex;
-static std::vector<Recycled> g_recycled;
-static bool take_recycled(int device, Recycled* out)
-{
-  std::lock_guard<std::mutex> lock(g_recycle_mutex);
-  for (size_t i = 0; i < g_recycled.size(); ++i)
-    if (g_recycled[i].device == device) {
-      *out = g_recycled[i];
-      g_recycled.erase(g_recycled.begin() + i);
-      return true;
-    }
-  return false;
-}
-static bool give_recycled(const Recycled& r)
-{
-  std::lock_guard<std::mutex> lock(g_recycle_mutex);
-  if (g_recycled.size() >= 16) return false;
-  g_recycled.push_back(r);
-  return true;
-}
-
-// Zero-filled device memory.  Buffers under 256 KiB are carved out of 1 MiB chunks: a small LP (the MIP-style
-// re-solve case) needs ~60 buffers, and 60 hipMalloc + hipFree calls cost more than its whole solve.
-constexpr size_t kArenaChunk = (size_t)1 << 20, kArenaMaxItem = (size_t)256 << 10;
-template <class T>
-static int dev_alloc(pdlpdev_ctx* c, T** p, size_t count)
-{
-  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  c->bytes += (int64_t)bytes;
-  if (bytes <= kArenaMaxItem) {
-    const size_t need = (bytes + 255) & ~(size_t)255;
-    if (c->arena == nullptr || c->arena_used + need > kArenaChunk) {
-      HIP_TRY(hipMalloc((void**)&c->arena, kArenaChunk));
-      HIP_TRY(hipMemsetAsync(c->arena, 0, kArenaChunk, c->stream));
-      c->allocs.push_back(c->arena);
-      c->arena_used = 0;
-    }
-    *p = (T*)(c->arena + c->arena_used);
-    c->arena_used += need;
-    return 0;
-  }
-  static const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMalloc((void**)p, bytes));
-  const auto t1 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
-  if (timing && std::chrono::duration<double>(t1 - t0).count() > 1e-3)  // only the surprising ones
-    fprintf(stderr, "[cuopt_amd setup]     hipMalloc %10zu B: %.2f ms\n", bytes, 1e3 * std::chrono::duration<double>(t1 - t0).count());
-  c->allocs.push_back(*p);
-  return 0;
-}
-#define TRY(expr)          \
-  do {                     \
-    int rc_ = (expr);      \
-    if (rc_ != 0) return rc_; \
-  } while (0)
-
-// the stream kernels remap blockIdx so that each XCD owns a contiguous range of row blocks
-// (xcd_remap); the grid is padded to a multiple of 8 so the remap is a bijection.
-static inline int stream_grid(int nb) { return std::max(8, ((nb + 7) / 8) * 8); }
-static inline int grid_for(int64_t n, int per_thread = 1)
-{
-  int64_t g = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
-  return (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
-}
 
 // ================================================================================================
 // kernels: setup (scaling, norms).  One lane per row: these run a handful of times per solve.
@@ -867,125 +317,7 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
   if (push) p2pdev::count_exchange(push);
 }
 
-// (1') the same step for cache-resident LPs (n <= kPrimalSmallN, one element per thread): every operand -- BOTH ping-pong buffers
-// of x and A^T y -- is requested before the control block is looked at, so the kernel is one round trip instead of two dependent ones
-// (control block -> which buffer -> operands).  At C2 that is about a fifth of the kernel; on large LPs the second buffer's
-// 16 bytes per column would cost bandwidth, so they keep k_primal.  Same arithmetic, same bits.
-constexpr int kPrimalSmallN = 1 << 18;
-__global__ void __launch_bounds__(kBlock)
-k_primal_small(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, double* __restrict__ x1,
-               const double* __restrict__ aty0, const double* __restrict__ aty1,
-               const double* __restrict__ c, const double* __restrict__ lb, const double* __restrict__ ub,
-               double* __restrict__ xbar, double* __restrict__ sumx)
-{
-  const int j  = blockIdx.x * kBlock + threadIdx.x;
-  const int jj = j < n ? j : n - 1;
-  const double xa = x0[jj], xb_ = x1[jj], ta = aty0[jj], tb = aty1[jj], cj = c[jj], lj = lb[jj], uj = ub[jj], sj = sumx[jj];
-  if (!loop_active(ctl)) return;
-  const int cur       = ctl->cur;
-  const double tau    = ctl->tau;
-  const double weight = ctl->step_size;
-  const bool pend     = ctl->pending_avg != 0;
-  if (j >= n) return;
-  double* __restrict__ xn = cur ? x0 : x1;
-  const double xj       = cur ? xb_ : xa;
-  const double gradient = cj - (cur ? tb : ta);
-  double next           = xj - (tau * gradient);
-  next                  = dmax(dmin(next, uj), lj);
-  xn[j]                 = next;
-  xbar[j]               = next - xj + next;
-  if (pend) sumx[j] = sj + weight * xj;
-}
 
-// (2) rows of A: v = A xbar (stream SpMV) -> dual projection (utils.cuh:97-112) -> ||dy||^2 partial,
-//     plus the deferred dual averaging.
-struct DualEpilogue {
-  static constexpr int NQ = 1;
-  using Op = SumOp;
-  const double* __restrict__ y;
-  double* __restrict__ yn;
-  const double* __restrict__ lo;
-  const double* __restrict__ hi;
-  double* __restrict__ sumy;
-  double sigma, weight;
-  bool pend;
-  double* __restrict__ copy = nullptr;  // sharded solves, owner-computes dataflow: y' also goes to this rank's slot of the gathered dual
-  const p2pdev::Push* __restrict__ push = nullptr;  // ... or, with the direct peer transport, into every rank's landing block
-  // the row's operands, separable from the arithmetic so that a layout can request them before its row sums are ready
-  struct Ops {
-    double y, lo, hi, sum;
-  };
-  __device__ __forceinline__ Ops load(int i) const { return Ops{y[i], lo[i], hi[i], pend ? sumy[i] : 0.0}; }
-  __device__ __forceinline__ void apply(int i, double v, const Ops& o, double (&acc)[1])
-  {
-    const double yi = o.y;
-    double next     = yi - (sigma * v);
-    const double low = next + sigma * o.lo;
-    const double up  = next + sigma * o.hi;
-    next            = dmax(low, dmin(up, 0.0));
-    yn[i]           = next;
-    if (copy) copy[i] = next;
-    if (push)
-      for (int q = 0; q < push->world; ++q)
-        if (q != push->rank) p2pdev::put(push->slot(q) + i, next);  // (this rank's own rows: `copy`, an ordinary store)
-    const double dy = next - yi;
-    acc[0] += dy * dy;
-    if (pend) sumy[i] = o.sum + weight * yi;
-  }
-  __device__ __forceinline__ void row(int i, double v, double (&acc)[1]) { apply(i, v, load(i), acc); }
-};
-__global__ void __launch_bounds__(kBlock)
-k_spmv_a_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-              const int32_t* __restrict__ idx, const double* __restrict__ val,
-              const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
-              double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-              const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
-              const p2pdev::Push* __restrict__ push, const double* __restrict__ dadd)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy, push};
-  csr_stream_block(nb, rb, off, idx, val, xbar, e, part, dadd);
-  if (push) p2pdev::count_exchange(push);
-}
-
-// (3) rows of A^T: AtY' = A^T y' (stream SpMV) fused with the step-size statistics
-//     interaction = dx . (AtY' - AtY), ||dx||^2  (adaptive_step_size_strategy.cu:278-340)
-struct StepEpilogue {
-  static constexpr int NQ = 2;
-  using Op = SumOp;
-  const double* __restrict__ x;
-  const double* __restrict__ xn;
-  const double* __restrict__ aty;
-  double* __restrict__ atyn;
-  struct Ops {
-    double x, xn, aty;
-  };
-  __device__ __forceinline__ Ops load(int j) const { return Ops{x[j], xn[j], aty[j]}; }
-  __device__ __forceinline__ void apply(int j, double v, const Ops& o, double (&acc)[2])
-  {
-    atyn[j]         = v;
-    const double dx = o.xn - o.x;
-    const double t  = v - o.aty;
-    acc[0] += t * dx;
-    acc[1] += dx * dx;
-  }
-  __device__ __forceinline__ void row(int j, double v, double (&acc)[2]) { apply(j, v, load(j), acc); }
-};
-__global__ void __launch_bounds__(kBlock)
-k_spmv_at_step(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-               const int32_t* __restrict__ idx, const double* __restrict__ val,
-               const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-               const double* __restrict__ y1, const double* __restrict__ x0,
-               const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
-               double* __restrict__ part, const double* __restrict__ dadd)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y0 : y1 /* y' */, e, part, dadd);
-}
 
 // multi-GPU variant of (3): after the all-reduce of the A^T y' partial products
 __global__ void __launch_bounds__(kBlock)
@@ -1362,197 +694,7 @@ static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_
   return 0;
 }
 
-// panel-layout twins of (2) and (3): same epilogues, slab-major gather (pdlp_kernels.hpp)
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_a_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
-               double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-               const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
-               const p2pdev::Push* __restrict__ push)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy, push};
-  panel_block<SEG>(P, xbar, e, part);
-  if (push) p2pdev::count_exchange(push);
-}
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_at_step(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-                const double* __restrict__ y1, const double* __restrict__ x0,
-                const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
-                double* __restrict__ part)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  panel_block<SEG>(P, cur ? y0 : y1 /* y' */, e, part);
-}
-// jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column sets
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_a_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ xbar,
-             double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
-             const p2pdev::Push* __restrict__ push)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size,
-                 ctl->pending_avg != 0, ycopy, push};
-  jag_block<decltype(e), WAVES>(J, xbar, e, part);
-  if (push) p2pdev::count_exchange(push);
-}
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_at_step(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-              const double* __restrict__ y1, const double* __restrict__ x0,
-              const double* __restrict__ x1, double* __restrict__ aty0, double* __restrict__ aty1,
-              double* __restrict__ part)
-{
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  jag_block<decltype(e), WAVES>(J, cur ? y0 : y1 /* y' */, e, part);
-}
-// ---- dense row segments: index-free storage (pdlpdev_ctx::Dense) ---------------------------------------------------------
-struct DenseView {
-  const int32_t* __restrict__ row;
-  const int32_t* __restrict__ row_seg;
-  const int32_t* __restrict__ seg_row;
-  const int32_t* __restrict__ seg_c0;
-  const int32_t* __restrict__ seg_len;
-  const int32_t* __restrict__ seg_ptr;
-  const int32_t* __restrict__ tile_ptr;
-  const int32_t* __restrict__ tile_seg;
-  const int32_t* __restrict__ tile_id;  // the 256-column tiles some segment overlaps
-  const double* __restrict__ val;
-  const int32_t* __restrict__ ch_seg;   // chunks of <= kDenseChunk entries of a segment: one workgroup each ...
-  const int32_t* __restrict__ ch_k0;
-  const int32_t* __restrict__ row_ch;   // ... and per owning row its chunk range (added up in this order)
-  double* __restrict__ ch_part;
-};
-constexpr int kDenseChunk = 4096;
-// the gathered vector of a call site, picked on the device like the layouts do (see k_pb_products)
-__device__ __forceinline__ const double* pick_vector(const pdlpdev_ctl* ctl, const double* v0, const double* v1, int mode)
-{
-  if (mode == 0) return v0;
-  const bool cur = ctl->cur != 0;
-  return (cur == (mode == 1)) ? v0 : v1;
-}
-// rows of A, stage 1: one workgroup per chunk of a segment; lane <-> entry, values and vector are coalesced streams
-__global__ void __launch_bounds__(kBlock)
-k_dense_rows(DenseView D, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
-{
-  __shared__ double red[8];
-  if (in_loop && !loop_active(ctl)) return;
-  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
-  const int sg = D.ch_seg[blockIdx.x], k0 = D.ch_k0[blockIdx.x];
-  const int len = min(kDenseChunk, D.seg_len[sg] - k0);
-  const double* __restrict__ a = D.val + D.seg_ptr[sg] + k0;
-  const double* __restrict__ x = vec + D.seg_c0[sg] + k0;
-  double c[kDenseChunk / kBlock];
-#pragma unroll
-  for (int u = 0; u < kDenseChunk / kBlock; ++u) {
-    const int k = threadIdx.x + u * kBlock;
-    c[u]        = k < len ? __builtin_nontemporal_load(a + k) * x[k] : 0.0;
-  }
-  double acc[1] = {0.0};
-#pragma unroll
-  for (int u = 0; u < kDenseChunk / kBlock; ++u) acc[0] += c[u];
-  block_reduce<SumOp, 1>(acc, red);
-  if (threadIdx.x == 0) D.ch_part[blockIdx.x] = acc[0];
-}
-// stage 2: a lane per owning row adds up its chunks in order
-__global__ void __launch_bounds__(kBlock)
-k_dense_rows_finish(DenseView D, int nrows, const pdlpdev_ctl* __restrict__ ctl, int in_loop, double* __restrict__ add)
-{
-  if (in_loop && !loop_active(ctl)) return;
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= nrows) return;
-  double acc = 0.0;
-  for (int q = D.row_ch[b]; q < D.row_ch[b + 1]; ++q) acc += D.ch_part[q];
-  add[D.row[b]] = acc;
-}
-// rows of A^T (columns of A): lane <-> column of a 256-column tile; the segments that overlap the tile in ascending row order
-__global__ void __launch_bounds__(kBlock)
-k_dense_cols(DenseView D, int n, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode,
-             int in_loop, double* __restrict__ add)
-{
-  if (in_loop && !loop_active(ctl)) return;
-  const double* __restrict__ vec = pick_vector(ctl, v0, v1, mode);
-  const int tile = D.tile_id[blockIdx.x];
-  const int j    = tile * kBlock + (int)threadIdx.x;
-  double acc     = 0.0;
-  for (int q = D.tile_ptr[blockIdx.x]; q < D.tile_ptr[blockIdx.x + 1]; ++q) {
-    const int sg = D.tile_seg[q];
-    const int c0 = D.seg_c0[sg];
-    if (j >= c0 && j < c0 + D.seg_len[sg]) acc += __builtin_nontemporal_load(D.val + D.seg_ptr[sg] + (j - c0)) * vec[D.seg_row[sg]];
-  }
-  if (j < n) add[j] = acc;
-}
 
-// (plain SpMV: A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
-struct StoreEpilogue {
-  static constexpr int NQ = 0;
-  using Op = SumOp;
-  double* __restrict__ out;
-  __device__ __forceinline__ void row(int r, double v, double (&)[1]) { out[r] = v; }
-};
-// gather-free twins: phase P (one kernel, the gathered vector chosen on the device like the other layouts do) and phase R with
-// the same epilogues
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS)
-k_pb_products(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  if (in_loop && !loop_active(ctl)) return;
-  // mode 0: v0.  1: cur ? v0 : v1 (the trial iterate of a ping-pong pair).  2: cur ? v1 : v0 (the current one).
-  const double* vec = v0;
-  if (mode != 0) {
-    const bool cur = ctl->cur != 0;
-    vec            = (cur == (mode == 1)) ? v0 : v1;
-  }
-  pb_products_block<THREADS>(V, vec, pb_lds);
-}
-__global__ void __launch_bounds__(kPbThreads)
-k_pb_a_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
-            const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
-            const p2pdev::Push* __restrict__ push)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  DualEpilogue e{cur ? y1 : y0, cur ? y0 : y1, lo, hi, sumy, ctl->sigma, ctl->step_size, ctl->pending_avg != 0, ycopy, push};
-  pb_rows_block(V, e, part, pb_lds);
-  if (push) p2pdev::count_exchange(push);
-}
-__global__ void __launch_bounds__(kPbThreads)
-k_pb_at_step(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
-             double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  if (!loop_active(ctl)) return;
-  const int cur = ctl->cur;
-  StepEpilogue e{cur ? x1 : x0, cur ? x0 : x1, cur ? aty1 : aty0, cur ? aty0 : aty1};
-  pb_rows_block(V, e, part, pb_lds);
-}
-__global__ void __launch_bounds__(kPbThreads)
-k_pb_at_cur(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ aty0, double* __restrict__ aty1,
-            double* __restrict__ out_override, int use_next)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  const int cur = ctl->cur ^ (use_next ? 1 : 0);
-  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  pb_rows_block(V, e, nullptr, pb_lds);
-}
-__global__ void __launch_bounds__(kPbThreads) k_pb_plain(PbView V, double* __restrict__ out)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  StoreEpilogue e{out};
-  pb_rows_block(V, e, nullptr, pb_lds);
-}
 __global__ void __launch_bounds__(kBlock)
 k_permute_pad(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
 {
@@ -1587,62 +729,6 @@ k_flush_average(int n, int m, const pdlpdev_ctl* __restrict__ ctl, const double*
 }
 __global__ void k_clear_pending(pdlpdev_ctl* ctl) { ctl->pending_avg = 0; }
 
-// plain SpMV (A^T y at start / after restart-to-average; parity hook; multi-GPU partial products)
-__global__ void __launch_bounds__(kBlock)
-k_spmv_plain(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-             const int32_t* __restrict__ idx, const double* __restrict__ val,
-             const double* __restrict__ vec, double* __restrict__ out, const double* __restrict__ dadd)
-{
-  StoreEpilogue e{out};
-  csr_stream_block(nb, rb, off, idx, val, vec, e, nullptr, dadd);
-}
-// variants that pick the ping-pong buffer on the device
-__global__ void __launch_bounds__(kBlock)
-k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-              const int32_t* __restrict__ idx, const double* __restrict__ val,
-              const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-              const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
-              double* __restrict__ out_override, int use_next, const double* __restrict__ dadd)
-{
-  const int cur = ctl->cur ^ (use_next ? 1 : 0);
-  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr, dadd);
-}
-// panel twin of k_spmv_at_cur (A^T y of the iterate / of the trial iterate, optionally into `out_override`)
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_at_cur(PanelView P, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-               const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
-               double* __restrict__ out_override, int use_next)
-{
-  const int cur = ctl->cur ^ (use_next ? 1 : 0);
-  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  panel_block<SEG>(P, cur ? y1 : y0, e, nullptr);
-}
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_plain(PanelView P, const double* __restrict__ vec, double* __restrict__ out)
-{
-  StoreEpilogue e{out};
-  panel_block<SEG>(P, vec, e, nullptr);
-}
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_at_cur(JagView J, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ y0,
-             const double* __restrict__ y1, double* __restrict__ aty0, double* __restrict__ aty1,
-             double* __restrict__ out_override, int use_next)
-{
-  const int cur = ctl->cur ^ (use_next ? 1 : 0);
-  StoreEpilogue e{out_override ? out_override : (cur ? aty1 : aty0)};
-  jag_block<decltype(e), WAVES>(J, cur ? y1 : y0, e, nullptr);
-}
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_plain(JagView J, const double* __restrict__ vec, double* __restrict__ out)
-{
-  StoreEpilogue e{out};
-  jag_block<decltype(e), WAVES>(J, vec, e, nullptr);
-}
 __global__ void __launch_bounds__(kBlock)
 k_sum_partials_to(const double* __restrict__ part, int nb, double* __restrict__ out)
 {
@@ -1692,191 +778,7 @@ k_make_average(int n, int m, int mode, const pdlpdev_ctl* __restrict__ ctl,
   }
 }
 
-// Convergence information, primal side (convergence_information.cu:221-248 + row part of :323-366):
-// rows of the SCALED A against the SCALED iterate; (A x)_i = (A^ x^)_i / D_r,i and y_i = y^_i D_r,i
-// recover the unscaled quantities without a second copy of the matrix.
-struct EvalPrimalEpilogue {
-  static constexpr int NQ = 3;
-  using Op = SumOp;
-  const double* __restrict__ yhat;
-  const double* __restrict__ dr;
-  const double* __restrict__ lo_u;
-  const double* __restrict__ hi_u;
-  double eps_rel;
-  double* __restrict__ linf_rows;  // per-row r_p,i - eps*bcomb_i (max-reduced by a second pass)
-  double* __restrict__ ax_out;     // (A x)_i of the unscaled problem, kept for the infeasibility pass
-  __device__ __forceinline__ void row(int i, double v, double (&acc)[3])
-  {
-    const double d  = dr[i];
-    const double ax = v / d;
-    ax_out[i]       = ax;
-    const double yi = yhat[i] * d;
-    const double lo = lo_u[i], hi = hi_u[i];
-    const double rp = violation(ax, lo, hi);
-    acc[0] += rp * rp;
-    acc[1] += bound_value_product(yi, lo, hi);
-    acc[2] += yi * yi;
-    if (linf_rows) linf_rows[i] = rp - eps_rel * combine_bounds(lo, hi);  // relative_residual_t, utils.cuh:385-409
-  }
-};
-__global__ void __launch_bounds__(kBlock)
-k_eval_primal(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-              const int32_t* __restrict__ idx, const double* __restrict__ val,
-              const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0,
-              const double* __restrict__ x1, const double* __restrict__ avgx,
-              const double* __restrict__ y0, const double* __restrict__ y1,
-              const double* __restrict__ avgy, const double* __restrict__ dr,
-              const double* __restrict__ lo_u, const double* __restrict__ hi_u, double eps_rel,
-              double* __restrict__ linf_rows, double* __restrict__ ax_out, double* __restrict__ part, const double* __restrict__ dadd)
-{
-  const int cur = ctl->cur;
-  const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  csr_stream_block(nb, rb, off, idx, val, xv, e, part, dadd);
-}
 
-// dual side (convergence_information.cu:261-320,369-422): one column j per lane
-struct EvalDualCore {
-  const double* __restrict__ xhat;
-  const double* __restrict__ dc;
-  const double* __restrict__ c_u;
-  const double* __restrict__ lb_u;
-  const double* __restrict__ ub_u;
-  double eps_rel;
-  int rule_finite;
-  double* __restrict__ rc_out;
-  double* __restrict__ linf_rows;
-  double* __restrict__ aty_out;  // (A^T y)_j of the unscaled problem, kept for the infeasibility pass
-  // acc: 0 ||r_d||^2, 1 sum B(rc,lb,ub), 2 c.x, 3 ||x||^2
-  __device__ __forceinline__ void col(int j, double aty_scaled, double (&acc)[4])
-  {
-    const double d    = dc[j];
-    const double aty  = aty_scaled / d;
-    aty_out[j]        = aty;
-    const double cj   = c_u[j];
-    const double g    = cj - aty;
-    const double xj   = xhat[j] * d;
-    const double lb   = lb_u[j], ub = ub_u[j];
-    const double bv   = g > 0.0 ? lb : ub;  // bound_value_gradient, utils.cuh:195-202
-    double rc;
-    if (g == 0.0)
-      rc = g;
-    else if (rule_finite)  // copy_gradient_if_finite_bounds, utils.cuh:231-239
-      rc = dfinite(bv) ? g : 0.0;
-    else  // copy_gradient_if_should_be_reduced_cost, utils.cuh:221-229
-      rc = fabs(xj - bv) <= fabs(xj) ? g : 0.0;
-    const double rd = g - rc;
-    rc_out[j]       = rc;
-    acc[0] += rd * rd;
-    acc[1] += bound_value_product(rc, lb, ub);
-    acc[2] += cj * xj;
-    acc[3] += xj * xj;
-    if (linf_rows) linf_rows[j] = rd - eps_rel * cj;  // the dual "rhs" is c_j itself (signed), :204-208
-  }
-};
-struct EvalDualEpilogue {
-  static constexpr int NQ = 4;
-  using Op = SumOp;
-  EvalDualCore core;
-  __device__ __forceinline__ void row(int j, double v, double (&acc)[4]) { core.col(j, v, acc); }
-};
-__global__ void __launch_bounds__(kBlock)
-k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
-            const int32_t* __restrict__ idx, const double* __restrict__ val,
-            const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0,
-            const double* __restrict__ x1, const double* __restrict__ avgx,
-            const double* __restrict__ y0, const double* __restrict__ y1,
-            const double* __restrict__ avgy, EvalDualCore core, double* __restrict__ part, const double* __restrict__ dadd)
-{
-  const int cur = ctl->cur;
-  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalDualEpilogue e{core};
-  csr_stream_block(nb, rb, off, idx, val, yv, e, part, dadd);
-}
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_eval_primal(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
-                    const double* __restrict__ x0, const double* __restrict__ x1,
-                    const double* __restrict__ avgx, const double* __restrict__ y0,
-                    const double* __restrict__ y1, const double* __restrict__ avgy,
-                    const double* __restrict__ dr, const double* __restrict__ lo_u,
-                    const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows,
-                    double* __restrict__ ax_out, double* __restrict__ part)
-{
-  const int cur = ctl->cur;
-  const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  panel_block<SEG>(P, xv, e, part);
-}
-template <bool SEG>
-__global__ void __launch_bounds__(kPanelThreads)
-k_panel_eval_dual(PanelView P, const pdlpdev_ctl* __restrict__ ctl, int which,
-                  const double* __restrict__ x0, const double* __restrict__ x1,
-                  const double* __restrict__ avgx, const double* __restrict__ y0,
-                  const double* __restrict__ y1, const double* __restrict__ avgy, EvalDualCore core,
-                  double* __restrict__ part)
-{
-  const int cur = ctl->cur;
-  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalDualEpilogue e{core};
-  panel_block<SEG>(P, yv, e, part);
-}
-__global__ void __launch_bounds__(kPbThreads)
-k_pb_eval_primal(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
-                 const double* __restrict__ avgy, const double* __restrict__ dr, const double* __restrict__ lo_u,
-                 const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows, double* __restrict__ ax_out,
-                 double* __restrict__ part)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  const int cur    = ctl->cur;
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  pb_rows_block(V, e, part, pb_lds);
-}
-__global__ void __launch_bounds__(kPbThreads)
-k_pb_eval_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0, const double* __restrict__ x1,
-               const double* __restrict__ avgx, EvalDualCore core, double* __restrict__ part)
-{
-  extern __shared__ __attribute__((aligned(16))) double pb_lds[];
-  const int cur = ctl->cur;
-  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  EvalDualEpilogue e{core};
-  pb_rows_block(V, e, part, pb_lds);
-}
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_eval_primal(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
-                  const double* __restrict__ x0, const double* __restrict__ x1,
-                  const double* __restrict__ avgx, const double* __restrict__ y0,
-                  const double* __restrict__ y1, const double* __restrict__ avgy,
-                  const double* __restrict__ dr, const double* __restrict__ lo_u,
-                  const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows,
-                  double* __restrict__ ax_out, double* __restrict__ part)
-{
-  const int cur = ctl->cur;
-  const double* xv = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalPrimalEpilogue e{yv, dr, lo_u, hi_u, eps_rel, linf_rows, ax_out};
-  jag_block<decltype(e), WAVES>(J, xv, e, part);
-}
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_jag_eval_dual(JagView J, const pdlpdev_ctl* __restrict__ ctl, int which,
-                const double* __restrict__ x0, const double* __restrict__ x1,
-                const double* __restrict__ avgx, const double* __restrict__ y0,
-                const double* __restrict__ y1, const double* __restrict__ avgy, EvalDualCore core,
-                double* __restrict__ part)
-{
-  const int cur = ctl->cur;
-  core.xhat     = which == PDLPDEV_AVERAGE ? avgx : (cur ? x1 : x0);
-  const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
-  EvalDualEpilogue e{core};
-  jag_block<decltype(e), WAVES>(J, yv, e, part);
-}
 // multi-GPU: same per-column rule after the all-reduce of A^T y
 __global__ void __launch_bounds__(kBlock)
 k_eval_dual_elementwise(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, int which,
@@ -3548,249 +2450,7 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   delete ctx;
 }
 
-// ---- multi-GPU ----------------------------------------------------------------------------------
-int pdlpdev_comm_unique_id(uint8_t id[128])
-{
-  TRY(rccl::load());
-  rccl::unique_id u;
-  RCCL_TRY(rccl::GetUniqueId(&u));
-  memcpy(id, u.internal, 128);
-  return 0;
-}
-int pdlpdev_softcomm_create(int world, uint8_t id[128])
-{
-  if (world < 1 || world > 16) return fail(-1, "pdlpdev_softcomm_create: world must be in 1..16");
-  softcomm::Comm* c = new softcomm::Comm();
-  c->world = world;
-  c->bufs.assign(world, nullptr), c->scratch.assign(world, nullptr), c->scratch_size.assign(world, 0);
-  memset(id, 0, 128);
-  memcpy(id, softcomm::kMagic, 8);
-  memcpy(id + 8, &c, sizeof(c));
-  return 0;
-}
-// CUOPT_AMD_SHARD_DATAFLOW = owner (default) | allreduce | rsag : see the `rsag` / `owner` fields of the context
-static int setup_dataflow(pdlpdev_ctx* ctx)
-{
-  const char* env = getenv("CUOPT_AMD_SHARD_DATAFLOW");
-  const std::string flow = env ? env : "owner";  // default since round 3: nothing but the slices themselves travels
-  if (flow == "allreduce") return 0;
-  if (flow != "rsag" && flow != "owner") return fail(-1, "CUOPT_AMD_SHARD_DATAFLOW must be allreduce, rsag or owner");
-  if (ctx->world > 16) return fail(-1, "the sliced-primal dataflows support up to 16 ranks");
-  if (!ctx->soft && (!rccl::ReduceScatter || !rccl::AllGather)) return fail(-3, "RCCL: ncclReduceScatter / ncclAllGather missing");
-  const int per = (ctx->n + ctx->world - 1) / ctx->world;
-  ctx->slice    = (per + 15) & ~15;
-  ctx->rsag     = true;  // both keep the primal side in slices inside the attempt loop
-  ctx->owner    = flow == "owner";  // ... the column block arrives with pdlpdev_owner_setup
-  TRY(dev_alloc(ctx, &ctx->rs_buf, (size_t)ctx->slice + 8));
-  TRY(dev_alloc(ctx, &ctx->rs_scal, 8 + 4 * 16));  // [0..3) this rank's sums, [4..7) the ranks' sums, [8..) landed scalars (p2p)
-  return 0;
-}
-int pdlpdev_comm_init(pdlpdev_ctx* ctx, int rank, int world, const uint8_t id[128])
-{
-  if (memcmp(id, softcomm::kMagic, 8) == 0) {
-    softcomm::Comm* c = nullptr;
-    memcpy(&c, id + 8, sizeof(c));
-    if (!c || c->world != world) return fail(-1, "soft communicator: world mismatch");
-    {
-      std::lock_guard<std::mutex> lk(c->mu);
-      c->refs += 1;
-    }
-    ctx->soft = c;
-    ctx->comm = reinterpret_cast<rccl::comm_t>(c);  // marks sharded mode; never passed to RCCL
-    ctx->rank = rank, ctx->world = world;
-    return setup_dataflow(ctx);
-  }
-  TRY(rccl::load());
-  HIP_TRY(hipSetDevice(ctx->device));
-  // A unique id bootstraps exactly ONE communicator per rank; solvers created later with the same (id, rank) -- bench.py
-  // makes two per process -- share it.  The ranks of a single-process sharded solve (cuoptamd_solve_sharded: one host
-  // thread per device) each get their own; ncclCommInitRank blocks until every rank has joined, so it runs outside the
-  // lock.  Communicators live until process exit.
-  std::string key((const char*)id, 128);
-  key.append((const char*)&rank, sizeof(rank));
-  rccl::comm_t comm = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(comm_cache::mu);
-    auto it = comm_cache::map.find(key);
-    if (it != comm_cache::map.end()) comm = it->second.comm, it->second.refs += 1;
-  }
-  if (!comm) {
-    rccl::unique_id u;
-    memcpy(u.internal, id, 128);
-    RCCL_TRY(rccl::CommInitRank(&comm, world, u, rank));
-    std::lock_guard<std::mutex> lock(comm_cache::mu);
-    comm_cache::map.emplace(key, comm_cache::Entry{comm, 1});
-  }
-  ctx->comm = comm, ctx->comm_key = key;
-  ctx->rank = rank, ctx->world = world;
-  return setup_dataflow(ctx);
-}
-// A rank of a sharded solve failed: nobody may wait for it.  Aborts every communicator this process created from `id`
-// (ncclCommAbort ends the collectives in flight; the in-process communicator wakes its barriers) -- the other ranks' next
-// collective returns an error instead of blocking.
-int pdlpdev_comm_abort(const uint8_t id[128])
-{
-  if (memcmp(id, softcomm::kMagic, 8) == 0) {
-    softcomm::Comm* c = nullptr;
-    memcpy(&c, id + 8, sizeof(c));
-    if (c) c->abort();
-    return 0;
-  }
-  std::lock_guard<std::mutex> lock(comm_cache::mu);
-  for (auto& kv : comm_cache::map)
-    if (kv.first.compare(0, 128, std::string((const char*)id, 128)) == 0 && !kv.second.aborted) {
-      kv.second.aborted = true;
-      if (rccl::CommAbort) (void)rccl::CommAbort(kv.second.comm);
-    }
-  return 0;
-}
-// recv[0..count) = sum over the ranks of send[rank * count ..][0..count)   (ncclReduceScatter)
-static int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t count)
-{
-  if (ctx->soft) {
-    softcomm::Comm* c = ctx->soft;
-    const int r       = ctx->rank;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
-    c->bufs[r] = const_cast<double*>(send);
-    SOFT_BARRIER(c);
-    softcomm::Peers peers;
-    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q] + (size_t)r * count;
-    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
-    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, 0, recv);  // recv is nobody's input
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    SOFT_BARRIER(c);  // nobody still reads the inputs
-    return 0;
-  }
-  RCCL_TRY(rccl::ReduceScatter(send, recv, count, rccl::kFloat64, rccl::kSum, ctx->comm, ctx->stream));
-  return 0;
-}
-// buf[q * count ..][0..count) = rank q's slice, in place (ncclAllGather with sendbuff = recvbuff + rank * count)
-static int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count)
-{
-  if (ctx->soft) {
-    softcomm::Comm* c = ctx->soft;
-    const int r       = ctx->rank;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    c->bufs[r] = buf;
-    SOFT_BARRIER(c);
-    for (int q = 0; q < c->world; ++q)
-      if (q != r)
-        HIP_TRY(hipMemcpyAsync(buf + (size_t)q * count, c->bufs[q] + (size_t)q * count, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    SOFT_BARRIER(c);  // nobody still reads my slice
-    return 0;
-  }
-  RCCL_TRY(rccl::AllGather(buf + (size_t)ctx->rank * count, buf, count, rccl::kFloat64, ctx->comm, ctx->stream));
-  return 0;
-}
-static int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
-{
-  if (!ctx->comm) return 0;
-  if (ctx->soft) {
-    softcomm::Comm* c = ctx->soft;
-    const int r       = ctx->rank;
-    if (c->scratch_size[r] < count) {
-      if (c->scratch[r]) (void)hipFree(c->scratch[r]);
-      HIP_TRY(hipMalloc((void**)&c->scratch[r], count * sizeof(double)));
-      c->scratch_size[r] = count;
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my contribution is complete
-    c->bufs[r] = buf;
-    SOFT_BARRIER(c);                                // everybody's contribution is complete and published
-    softcomm::Peers peers;
-    for (int q = 0; q < c->world; ++q) peers.p[q] = c->bufs[q];
-    const int g = (int)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 1024));
-    softcomm::k_combine<<<g, 256, 0, ctx->stream>>>(peers, c->world, count, op == rccl::kSum ? 0 : 1, c->scratch[r]);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    SOFT_BARRIER(c);                                // nobody still reads the inputs
-    HIP_TRY(hipMemcpyAsync(buf, c->scratch[r], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    return 0;
-  }
-  RCCL_TRY(rccl::AllReduce(buf, buf, count, rccl::kFloat64, op, ctx->comm, ctx->stream));
-  return 0;
-}
-
 static inline int oc_partials(const pdlpdev_ctx* ctx) { return ctx->joc.on ? ctx->joc.v.nblk + ctx->joc.v.nlong : ctx->poc.on ? ctx->poc.v.W : ctx->oc_nb; }
-
-// Direct peer transport: allocate this rank's landing block and learn where the other ranks' blocks are.
-//   in-process communicator: the ranks are contexts of one process (tests: on ONE device) -> a table in the communicator;
-//   RCCL: one 128-byte record per rank {IPC handle, process id, pointer, device} all-gathered through the communicator:
-//   same process -> the pointer itself (peer access enabled), another process -> hipIpcOpenMemHandle.
-static int p2p_setup(pdlpdev_ctx* ctx)
-{
-  pdlpdev_ctx::P2P& P = ctx->p2p;
-  const size_t W = (size_t)ctx->world;
-  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  P.off_x = 0;
-  P.off_y = align(P.off_x + W * (size_t)ctx->slice * sizeof(double));
-  P.off_s = align(P.off_y + W * (size_t)ctx->ypad * sizeof(double));
-  P.off_f = align(P.off_s + W * 4 * sizeof(double));
-  P.bytes = (P.off_f + p2pdev::kKinds * W * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
-  HIP_TRY(hipExtMallocWithFlags((void**)&P.base, P.bytes, hipDeviceMallocFinegrained));
-  HIP_TRY(hipMemset(P.base, 0, P.bytes));
-  TRY(dev_alloc(ctx, &P.epoch, 4));
-  TRY(dev_alloc(ctx, &P.fault, 4));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->soft) {
-    softcomm::Comm* c = ctx->soft;
-    {
-      std::lock_guard<std::mutex> lk(c->mu);
-      if (c->p2p_base.size() != W) c->p2p_base.assign(W, nullptr);
-      c->p2p_base[ctx->rank] = P.base;
-    }
-    SOFT_BARRIER(c);
-    for (size_t q = 0; q < W; ++q) P.peers.base[q] = (char*)c->p2p_base[q];
-    SOFT_BARRIER(c);  // everybody has read the table before anybody can overwrite it with the next solver's blocks
-  } else {
-    struct Rec {
-      hipIpcMemHandle_t handle;
-      unsigned long long pid, ptr, device;
-      char pad[128 - sizeof(hipIpcMemHandle_t) - 24];
-    };
-    static_assert(sizeof(Rec) == 128, "one record = 16 doubles on the wire");
-    std::vector<Rec> recs(W);
-    Rec mine;
-    memset(&mine, 0, sizeof(mine));
-    HIP_TRY(hipIpcGetMemHandle(&mine.handle, P.base));
-    mine.pid = (unsigned long long)getpid(), mine.ptr = (unsigned long long)(uintptr_t)P.base, mine.device = (unsigned long long)ctx->device;
-    double* wire = nullptr;
-    TRY(dev_alloc(ctx, &wire, W * 16));
-    HIP_TRY(hipMemcpyAsync(wire + (size_t)ctx->rank * 16, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
-    RCCL_TRY(rccl::AllGather(wire + (size_t)ctx->rank * 16, wire, 16, rccl::kFloat64, ctx->comm, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(recs.data(), wire, W * sizeof(Rec), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (size_t q = 0; q < W; ++q) {
-      if ((int)q == ctx->rank) {
-        P.peers.base[q] = P.base;
-      } else if (recs[q].pid == mine.pid) {
-        if ((int)recs[q].device != ctx->device) {
-          const hipError_t e = hipDeviceEnablePeerAccess((int)recs[q].device, 0);
-          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(-2, "hipDeviceEnablePeerAccess(%d): %s", (int)recs[q].device, hipGetErrorString(e));
-          (void)hipGetLastError();
-        }
-        P.peers.base[q] = (char*)(uintptr_t)recs[q].ptr;
-      } else {
-        void* mapped = nullptr;
-        HIP_TRY(hipIpcOpenMemHandle(&mapped, recs[q].handle, hipIpcMemLazyEnablePeerAccess));
-        P.opened.push_back(mapped);
-        P.peers.base[q] = (char*)mapped;
-      }
-    }
-  }
-  {
-    p2pdev::Push h[p2pdev::kKinds];
-    const size_t slot[p2pdev::kKinds] = {P.off_x + (size_t)ctx->rank * ctx->slice * sizeof(double), P.off_y + (size_t)ctx->rank * ctx->ypad * sizeof(double),
-                                         P.off_s + (size_t)ctx->rank * 4 * sizeof(double)};
-    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch};
-    TRY(dev_alloc(ctx, &P.push_dev, p2pdev::kKinds));
-    HIP_TRY(hipMemcpyAsync(P.push_dev, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-  }
-  P.on = true;
-  return 0;
-}
 int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols)
 {
   if (!ctx->owner) return fail(-1, "pdlpdev_owner_slice: the solver does not run the owner-computes dataflow");
@@ -4420,10 +3080,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     LAUNCH_CHECK();
     return 0;
   }
-  if (n <= kPrimalSmallN && n > 0)
-    launch_k(ctx, k_primal_small, (n + kBlock - 1) / kBlock, kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
-  else
-    launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
   launch_a_dual(ctx);
   if (!ctx->comm) {
     launch_at_step(ctx);
@@ -5051,10 +3708,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   auto one = [&]() {
     switch (kernel_id) {
       case PDLPDEV_K_PRIMAL:
-        if (ctx->n <= kPrimalSmallN && ctx->n > 0)
-          launch_k(ctx, k_primal_small, (ctx->n + kBlock - 1) / kBlock, kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx);
-        else
-          launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
         break;
       case PDLPDEV_K_SPMV_A_DUAL: launch_a_dual(ctx); break;
       case PDLPDEV_K_SPMV_AT_STEP: launch_at_step(ctx); break;

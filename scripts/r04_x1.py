@@ -12,7 +12,11 @@ import numpy as np
 from cuopt_amd import capi, synthetic
 wl = %(wl)r
 structured = wl in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
-cfg = dict(kind=wl, m=1_000_000, n=1_000_000, k=10, seed=7) if structured else dict(synthetic.CONFIGS[wl])
+if wl.startswith("rand:"):
+    _, mm, kk = wl.split(":")
+    cfg = dict(m=int(mm), n=int(mm), k=int(kk), seed=5)
+else:
+    cfg = dict(kind=wl, m=1_000_000, n=1_000_000, k=10, seed=7) if structured else dict(synthetic.CONFIGS[wl])
 p = synthetic.generate_structured(**cfg) if structured else synthetic.generate(**cfg)
 dev = capi.Device(p)
 out = dict(layout=dev.layout())
