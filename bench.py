@@ -241,7 +241,7 @@ def main():
     # command (profiles/r03_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile
     traffic, traffic_file = None, None
-    for rnd in ("r03", "r02"):  # the newest committed PMC summary of this workload
+    for rnd in ("r04", "r03", "r02"):  # the newest committed PMC summary of this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, args.workload))))
             if world == 1 and kname in pmc:
@@ -260,7 +260,7 @@ def main():
                                                  / HBM_PEAK_GBS / max(world, 1), 4),
                     traffic_source=None if traffic is None else
                     "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                    "(scripts/r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
+                    "(scripts/r04_pmc.sh / r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
     # Guard (round-3 review): the four kernels of an attempt, each timed on its own, must add up to the time of an attempt as the timed
     # region saw it (the rest is the amortised major-iteration work and the graph's launch gaps).  A call site whose launches are not
     # all summed (a multi-launch layout timed as one phase), or a timed region that skipped work, shows up here.
