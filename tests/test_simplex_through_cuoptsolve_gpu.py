@@ -1,0 +1,99 @@
+"""GPU: the second engine reached the way a caller reaches it -- cuOptSolve with CUOPT_METHOD_DUAL_SIMPLEX / the default Concurrent --
+on more than the handful of LPs of tests/test_method_and_multigpu_gpu.py (round-3 review: the engine's parity lived in CPU-marked
+tests): the LP relaxations of the reference's MIP data sets against the reference's own dual simplex (goldens), random ranged / free /
+boxed LPs against HiGHS, the advisor's box cases, a maximisation's duals from both engines, and a cancelled race."""
+import numpy as np
+import pytest
+
+from cuopt_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+
+
+def _lp(rows, c, lo, hi, lb, ub, maximize=False):
+    import scipy.sparse as sp
+    A = sp.csr_matrix(np.asarray(rows, float))
+    return dict(m=A.shape[0], n=A.shape[1], offsets=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32), values=A.data.astype(float),
+                c=np.asarray(c, float), lo=np.asarray(lo, float), hi=np.asarray(hi, float), lb=np.asarray(lb, float), ub=np.asarray(ub, float),
+                maximize=maximize, objective_offset=0.0)
+
+
+def test_golden_relaxations_through_the_dual_simplex_method(golden_problems):
+    seen = 0
+    for name, g in golden_problems.items():
+        p, ref = dict(g["problem"]), g["meta"].get("reference_dual_simplex")
+        if ref is None or p["m"] > 500 or name == "mip-minrep_inf-relaxation":
+            continue
+        p.pop("var_types", None)
+        r = capi.solve(p, method=2)
+        assert r["solve_info"]["dual_simplex_consulted"] is True, name
+        want = {"OPTIMAL": "Optimal", "INFEASIBLE": "PrimalInfeasible", "UNBOUNDED": "Unbounded"}[ref["status"]]
+        assert r["status"] in (want, {"PrimalInfeasible": "Infeasible"}.get(want, want)), (name, r["status"])
+        if ref["status"] == "OPTIMAL":
+            assert r["solve_info"]["engine"] == "dual_simplex", (name, r["solve_info"])
+            assert r["objective"] == pytest.approx(ref["objective"], rel=1e-9, abs=1e-9), name
+        seen += 1
+    assert seen >= 8
+
+
+def test_random_lps_against_highs_through_both_methods():
+    from scipy.optimize import linprog
+    import scipy.sparse as sp
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        m, n = int(rng.integers(20, 60)), int(rng.integers(30, 90))
+        A = sp.random(m, n, density=0.15, random_state=int(rng.integers(1 << 30)), data_rvs=rng.standard_normal, format="csr")
+        x0 = rng.random(n)
+        ax = A @ x0
+        lo = np.where(rng.random(m) < 0.3, -INF, ax - rng.random(m))
+        hi = np.where(rng.random(m) < 0.3, INF, ax + rng.random(m))
+        lb = np.where(rng.random(n) < 0.2, -INF, 0.0)
+        ub = np.where(rng.random(n) < 0.5, INF, 2.0)
+        c = rng.standard_normal(n)
+        p = dict(m=m, n=n, offsets=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32), values=A.data.copy(), c=c, lo=lo, hi=hi,
+                 lb=lb, ub=ub, maximize=bool(trial % 2), objective_offset=0.0)
+        A_ub = sp.vstack([A[np.isfinite(hi)], -A[np.isfinite(lo)]])
+        b_ub = np.concatenate([hi[np.isfinite(hi)], -lo[np.isfinite(lo)]])
+        h = linprog(-c if p["maximize"] else c, A_ub=A_ub, b_ub=b_ub, bounds=list(zip(np.where(np.isfinite(lb), lb, None), np.where(np.isfinite(ub), ub, None))), method="highs")
+        for method in (2, 0):  # DualSimplex, Concurrent
+            r = capi.solve(p, method=method)
+            if h.status == 0:
+                assert r["status"] == "Optimal", (trial, method, r["status"])
+                assert r["objective"] == pytest.approx(-h.fun if p["maximize"] else h.fun, rel=1e-6, abs=1e-6), (trial, method)
+            elif h.status == 3:
+                assert r["status"] in ("Unbounded", "DualInfeasible", "NumericalError"), (trial, method, r["status"])
+            elif h.status == 2:
+                assert r["status"] in ("Infeasible", "PrimalInfeasible"), (trial, method, r["status"])
+
+
+def test_a_feasible_lp_beyond_the_first_box_is_never_called_infeasible():
+    """round-3 advisor (high), through the front door: the default method must answer min x s.t. 1e-7 x >= 1"""
+    for method in (0, 2):
+        r = capi.solve(_lp([[1e-7]], [1.0], [1.0], [INF], [0.0], [INF]), method=method)
+        assert r["status"] == "Optimal", (method, r["status"])
+        assert r["objective"] == pytest.approx(1e7, rel=1e-3)
+
+
+def test_maximisation_duals_have_one_sign_whichever_engine_answers():
+    p = _lp([[1.0, 2.0], [3.0, 1.0]], [5.0, 8.0], [-INF, -INF], [12.0, 15.0], [0.0, 0.0], [10.0, 10.0], maximize=True)
+    s = capi.solve(p, method=2)
+    q = capi.solve(p, method=1, tol=1e-9)
+    assert s["solve_info"]["engine"] == "dual_simplex" and q["solve_info"]["engine"] == "pdlp"
+    assert s["objective"] == pytest.approx(q["objective"], rel=1e-6)
+    np.testing.assert_allclose(s["y"], q["y"], atol=1e-5)  # a non-degenerate vertex: one dual solution
+    np.testing.assert_allclose(s["reduced_cost"], q["reduced_cost"], atol=1e-5)
+    A = np.array([[1.0, 2.0], [3.0, 1.0]])
+    np.testing.assert_allclose(-p["c"] - A.T @ s["y"], s["reduced_cost"], atol=1e-9)  # duals of min -c
+
+
+def test_concurrent_race_on_a_mid_size_lp_ends_with_one_answer_and_no_stray_thread():
+    """PDLP wins on an LP of this size long before the simplex: the simplex is cancelled, the call returns promptly"""
+    import time
+    p = synthetic.generate(20000, 20000, 8, seed=3)
+    t0 = time.perf_counter()
+    r = capi.solve(p, method=0, tol=1e-4)
+    dt = time.perf_counter() - t0
+    assert r["status"] == "Optimal" and dt < 30.0, (r["status"], dt)
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-3 * (1 + abs(p["objective_star"]))
+    assert "answered_by" in r["solve_info"]
