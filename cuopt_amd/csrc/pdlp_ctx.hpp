@@ -316,6 +316,8 @@ struct pdlpdev_ctx {
     int32_t *perm = nullptr, *s_perm_a = nullptr, *s_perm_at = nullptr;  // positions in the FULL CSR of A / A / A^T
     double* val = nullptr;                   // nent: the segments' values, row after row
     double *add_m = nullptr, *add_n = nullptr;  // what the segments contribute to A v (per row) / A^T v (per column)
+    int32_t* tile_slot = nullptr;               // per 256-column tile: its index in tile_ptr, -1 where no segment overlaps it
+    bool fused_a = false, fused_at = false;     // the panel kernels of that side add the segments themselves (no launches in front)
     int64_t hot_nnz = 0;
   } dense;
   int64_t hot_nnz_at = 0;
@@ -407,6 +409,7 @@ struct pdlpdev_ctx {
   int rejected_in_a_row = 0;  // attempts enqueued since the last accepted step (pdlpdev_run's guard against endless rejections)
   // graphs
   int use_graph = 1;
+  bool comm_warm = false;          // one attempt went out eagerly over this communicator (before the first capture)
   bool graph_comm_failed = false;  // capturing the RCCL collectives into an attempt graph failed once: plain launches from then on
   char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
   char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`

@@ -1184,7 +1184,7 @@ static int64_t gather_working_set(int32_t rows, int32_t cols, const int32_t* off
   return total / samples;
 }
 static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
-                              int64_t slab_bytes, bool force)
+                              int64_t slab_bytes, bool force, const std::vector<int32_t>* dense_first_seg = nullptr)
 {
   PanelHost P;
   const int64_t nnz = off[rows];
@@ -1221,7 +1221,8 @@ static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, co
   std::vector<char> is_own(rows, 0);
   int64_t own_nnz = 0;
   for (int32_t i = 0; i < rows; ++i)
-      if (off[i + 1] - off[i] > own_from) is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];
+      if (off[i + 1] - off[i] > own_from || (dense_first_seg && (*dense_first_seg)[i] >= 0))  // (rows that own dense segments: their
+        is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];                // workgroup adds the segments too)
   auto cut = [&](int64_t tgt) {
     P.row0.assign(1, 0);
     int32_t start = 0;
@@ -2028,7 +2029,7 @@ static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb
 constexpr int kDenseMin = 256;  // consecutive columns of one row from which index-free storage is used
 struct DenseHost {
   bool on = false;
-  std::vector<int32_t> row, row_seg, seg_row, seg_c0, seg_len, seg_ptr, tile_id, tile_ptr, tile_seg, perm;
+  std::vector<int32_t> row, row_seg, seg_row, seg_c0, seg_len, seg_ptr, tile_id, tile_ptr, tile_seg, tile_slot, perm;
   std::vector<int32_t> s_off, s_idx, s_perm;     // A without the segments' entries (+ where each entry sits in the full CSR)
   std::vector<int32_t> st_off, st_idx, st_perm;  // A^T likewise
   std::vector<int32_t> first_seg;                // per row of A: first segment (seg_row ascending), -1 none
@@ -2092,7 +2093,8 @@ static void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const 
   std::vector<int32_t> cnt(ntiles_all, 0);
   for (size_t q = 0; q < D->seg_row.size(); ++q)
     for (int t = D->seg_c0[q] / kBlock; t <= (D->seg_c0[q] + D->seg_len[q] - 1) / kBlock; ++t) cnt[t]++;
-  std::vector<int32_t> slot(ntiles_all, -1);
+  std::vector<int32_t>& slot = D->tile_slot;
+  slot.assign(ntiles_all, -1);
   D->tile_ptr.push_back(0);
   for (int t = 0; t < ntiles_all; ++t)
     if (cnt[t]) {
@@ -2352,9 +2354,25 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       lap("upload pb A");
     }
     if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, A_off, A_idx, "A")) {
-      PanelHost ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed);
+      PanelHost ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed, DH.on ? &DH.first_seg : nullptr);
       lap("build_panels A");
       TRY(upload_panels(ctx, &ctx->pa, ha, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
+      if (ctx->pa.on && DH.on) {
+        // segments of the own rows, in own-row order (the rows that own segments are a subset of the own rows and both lists ascend)
+        std::vector<int32_t> own_seg(ha.own_row.size() + 1, 0);
+        for (size_t i = 0; i < ha.own_row.size(); ++i) {
+          const int32_t f = DH.first_seg[ha.own_row[i]];
+          int32_t cnt     = 0;
+          for (int32_t q = f; f >= 0 && q < (int32_t)DH.seg_row.size() && DH.seg_row[q] == ha.own_row[i]; ++q) ++cnt;
+          own_seg[i + 1] = own_seg[i] + cnt;
+        }
+        int32_t* d_own_seg = nullptr;
+        TRY(upload_i32(ctx, &d_own_seg, own_seg.data(), own_seg.size()));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        PanelView& v = ctx->pa.v;
+        v.dn_own_seg = d_own_seg, v.dn_seg_c0 = ctx->dense.seg_c0, v.dn_seg_len = ctx->dense.seg_len, v.dn_seg_ptr = ctx->dense.seg_ptr;
+        v.dn_seg_row = ctx->dense.seg_row, v.dn_val = ctx->dense.val;
+      }
       lap("upload panels A");
       HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
     }
@@ -2390,6 +2408,28 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     }
     if (ts.hat.ok) {
       TRY(upload_panels(ctx, &ctx->pat, ts.hat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
+      if (ctx->pat.on && DH.on) {
+        // per panel of the column side: the segments that reach into its column range, ascending rows (= segment numbers)
+        const std::vector<int32_t>& row0 = ts.hat.row0;
+        std::vector<int32_t> pan_ptr(row0.size(), 0), pan_seg;
+        bool fits = true;
+        for (size_t w = 0; w + 1 < row0.size(); ++w) {
+          for (size_t q = 0; q < DH.seg_row.size(); ++q)
+            if (DH.seg_c0[q] < row0[w + 1] && DH.seg_c0[q] + DH.seg_len[q] > row0[w]) pan_seg.push_back((int32_t)q);
+          pan_ptr[w + 1] = (int32_t)pan_seg.size();
+          fits           = fits && pan_ptr[w + 1] - pan_ptr[w] <= kPanelDenseSegs;
+        }
+        if (fits && ts.hat.own_row.empty()) {  // (else: k_dense_cols in front of the panels, as for the other layouts)
+          int32_t *d_ptr = nullptr, *d_seg = nullptr;
+          TRY(upload_i32(ctx, &d_ptr, pan_ptr.data(), pan_ptr.size()));
+          TRY(upload_i32(ctx, &d_seg, pan_seg.data(), pan_seg.size()));
+          HIP_TRY(hipStreamSynchronize(ctx->stream));
+          PanelView& v = ctx->pat.v;
+          v.dn_pan_ptr = d_ptr, v.dn_pan_seg = d_seg;
+          v.dn_seg_c0 = ctx->dense.seg_c0, v.dn_seg_len = ctx->dense.seg_len, v.dn_seg_ptr = ctx->dense.seg_ptr;
+          v.dn_seg_row = ctx->dense.seg_row, v.dn_val = ctx->dense.val;
+        }
+      }
       lap("upload panels At");
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the worker's host arrays
@@ -2405,6 +2445,9 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   // every layout adds what the dense segments / the extracted long rows contribute ahead of its epilogue (null: nothing to add)
   ctx->pa.v.dense_add = ctx->ja.v.dense_add = ctx->pba.v.dense_add = ctx->dense.add_m;
   ctx->pat.v.dense_add = ctx->jat.v.dense_add = ctx->pbat.v.dense_add = ctx->dense.add_n;
+  // ... except the panels, whose kernels add the segments themselves (own-row workgroups / the column epilogue): no launch in front
+  if (ctx->pa.v.dn_own_seg) ctx->pa.v.dense_add = nullptr;
+  if (ctx->pat.v.dn_pan_ptr) ctx->pat.v.dense_add = nullptr;
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pba.on ? ctx->pba.v.B : 0, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pbat.on ? ctx->pbat.v.B : 0, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));
@@ -2913,8 +2956,9 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 // dense row segments: their share of A v (transpose = 0) / A^T v lands in dense.add_m / add_n right before the layout's kernel adds it
 static void dense_part(pdlpdev_ctx* ctx, int transpose, const double* v0, const double* v1, int mode, int in_loop)
 {
-  const pdlpdev_ctx::Dense& D    = ctx->dense;
-  if (D.on) {
+  const pdlpdev_ctx::Dense& D = ctx->dense;
+  const bool fused            = transpose ? (ctx->pat.on && ctx->pat.v.dn_pan_ptr != nullptr) : (ctx->pa.on && ctx->pa.v.dn_own_seg != nullptr);
+  if (D.on && !fused) {
     DenseView V{D.row, D.row_seg, D.seg_row, D.seg_c0, D.seg_len, D.seg_ptr, D.tile_ptr, D.tile_seg, D.tile_id, D.val, D.ch_seg, D.ch_k0, D.row_ch, D.ch_part};
     if (transpose) {
       launch_k(ctx, k_dense_cols, D.ntiles, kBlock, 0, V, ctx->n, ctx->ctl, v0, v1, mode, in_loop, D.add_n);
@@ -3159,6 +3203,13 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
     // host and can never be captured; the direct peer transport is kernels only.
     const bool rccl_graphs = ctx->comm && !ctx->p2p.on && !ctx->soft && !ctx->graph_comm_failed;
     bool replayed = false;
+    if (rccl_graphs && ctx->use_graph && !ctx->comm_warm) {
+      // the very first attempt of a solver over RCCL goes out as plain launches: whatever a collective sets up lazily on its first call
+      // (channels, proxies) must not happen inside a stream capture
+      TRY(enqueue_attempt(ctx));
+      ctx->comm_warm = true;
+      remaining -= 1;
+    }
     if (ctx->use_graph && (!ctx->comm || ctx->p2p.on || rccl_graphs)) {
       replayed = true;
       while (remaining > 0) {

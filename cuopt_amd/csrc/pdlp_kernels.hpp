@@ -197,8 +197,24 @@ struct PanelView {
   const int32_t* __restrict__ csr_off = nullptr;
   const int32_t* __restrict__ csr_idx = nullptr;
   const double* __restrict__ csr_val  = nullptr;
+  // Dense row segments folded into the panel kernels (round 4; until then two launches of their own in front of every product):
+  //  * rows of A that own segments are "own rows": their workgroup, behind the panels of the same grid, adds the sparse remainder of
+  //    the row AND its segments (values index-free, the vector read coalesced) and runs the row's epilogue -- dn_own_seg[i] ...
+  //    dn_own_seg[i + 1] are the segments of own row i (the rows that own segments are exactly a subset of the own rows, in order);
+  //  * columns (rows of the A^T panels): the epilogue adds what the segments that cover the column contribute: the (at most
+  //    kPanelDenseSegs) segments that reach into the panel's column range are listed per panel (dn_pan_ptr / dn_pan_seg, ascending
+  //    rows = the order k_dense_cols adds them in) and copied to LDS with their vector entries before the chunks start.
+  const int32_t* __restrict__ dn_own_seg   = nullptr;
+  const int32_t* __restrict__ dn_pan_ptr   = nullptr;
+  const int32_t* __restrict__ dn_pan_seg   = nullptr;
+  const int32_t* __restrict__ dn_seg_row   = nullptr;
+  const int32_t* __restrict__ dn_seg_c0    = nullptr;
+  const int32_t* __restrict__ dn_seg_len   = nullptr;
+  const int32_t* __restrict__ dn_seg_ptr   = nullptr;
+  const double* __restrict__ dn_val        = nullptr;
 };
 constexpr int kPanelOwnRow = 4096;
+constexpr int kPanelDenseSegs = 32;  // dense segments per panel of the column side that the epilogue handles itself (more: k_dense_cols)
 constexpr long long kPanelNotMine = 0x7FF8C0DEC0DEC0DELL;  // a NaN no arithmetic produces: "this row is summed elsewhere"
 
 // (the panel skeleton: spmv_panel.hpp)

@@ -78,6 +78,25 @@ __device__ __forceinline__ void panel_own_row(const PanelView& P, const double* 
 #pragma unroll
     for (int u = 0; u < kLongU; ++u) part[0] = part[0] + a[u] * xv[u];
   }
+  if (P.dn_own_seg) {  // the row's dense segments: values and vector are coalesced streams, 8 entries per thread in flight
+    for (int sg = P.dn_own_seg[w - NP]; sg < P.dn_own_seg[w - NP + 1]; ++sg) {
+      const int len = P.dn_seg_len[sg];
+      const double* __restrict__ a = P.dn_val + P.dn_seg_ptr[sg];
+      const double* __restrict__ x = vec + P.dn_seg_c0[sg];
+      constexpr int kSegU = 8;
+      for (int k = (int)threadIdx.x; k < len; k += kSegU * kPanelThreads) {
+        double av[kSegU], xv[kSegU];
+#pragma unroll
+        for (int u = 0; u < kSegU; ++u) {
+          const int i = k + u * kPanelThreads;
+          av[u] = i < len ? __builtin_nontemporal_load(a + i) : 0.0;
+          xv[u] = i < len ? x[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSegU; ++u) part[0] = part[0] + av[u] * xv[u];
+      }
+    }
+  }
   block_reduce<SumOp, 1, kPanelWaves>(part, scratch);
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
@@ -90,16 +109,52 @@ __device__ __forceinline__ void panel_own_row(const PanelView& P, const double* 
     }
   }
 }
+// the dense segments that reach into a panel of the column side, in LDS: first column, length, where the values start, and the
+// gathered vector's entry of the segment's row
+struct PanelDenseSegs {
+  int n;
+  int c0[kPanelDenseSegs], len[kPanelDenseSegs], ptr[kPanelDenseSegs];
+  double y[kPanelDenseSegs];
+};
+__device__ __forceinline__ void panel_dense_prepare(const PanelView& P, int w, const double* __restrict__ vec, PanelDenseSegs* D)
+{
+  if (!P.dn_pan_ptr) return;  // (uniform)
+  const int q0 = P.dn_pan_ptr[w], n = P.dn_pan_ptr[w + 1] - q0;
+  if (threadIdx.x == 0) D->n = n;
+  if ((int)threadIdx.x < n) {
+    const int sg = P.dn_pan_seg[q0 + threadIdx.x];
+    D->c0[threadIdx.x] = P.dn_seg_c0[sg], D->len[threadIdx.x] = P.dn_seg_len[sg], D->ptr[threadIdx.x] = P.dn_seg_ptr[sg];
+    D->y[threadIdx.x]  = vec[P.dn_seg_row[sg]];
+  }
+}
+// what the dense segments contribute to column j of the panel, ascending rows: the sum k_dense_cols formed.  Added in the epilogue
+// (as cheap as the kernel it replaces, one launch less; starting the rows' LDS sums from it at the head of the kernel instead was
+// measured 5 us SLOWER: one more barrier in front of the first chunk)
+__device__ __forceinline__ double panel_dense_col(const PanelView& P, const PanelDenseSegs* D, int j)
+{
+  double add   = 0.0;
+  const int ns = D->n;
+  for (int q = 0; q < ns; ++q) {
+    const int k = j - D->c0[q];
+    if (k >= 0 && k < D->len[q]) add += __builtin_nontemporal_load(P.dn_val + D->ptr[q] + k) * D->y[q];
+  }
+  return add;
+}
 // the fused epilogue over a panel's rows, natural order, from the row sums in LDS
 template <class Epi>
 __device__ __forceinline__ void panel_epilogue(const PanelView& P, Epi& epi, double* __restrict__ partials, const double* psum, double* red,
-                                               int w, int r0, int nr, const double* psum2 = nullptr /* long-tail variant: the edge runs' share */)
+                                               int w, int r0, int nr, const PanelDenseSegs* D,
+                                               const double* psum2 = nullptr /* long-tail variant: the edge runs' share */)
 {
   double acc[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) acc[q] = Epi::Op::identity();
   for (int r = threadIdx.x; r < nr; r += kPanelThreads)
-    if (__double_as_longlong(psum[r]) != kPanelNotMine) epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, psum2 ? psum[r] + psum2[r] : psum[r]), acc);
+    if (__double_as_longlong(psum[r]) != kPanelNotMine) {
+      double v = psum2 ? psum[r] + psum2[r] : psum[r];
+      if (P.dn_pan_ptr) v = v + panel_dense_col(P, D, r0 + r);
+      epi.row(r0 + r, dense_plus(P.dense_add, r0 + r, v), acc);
+    }
   if constexpr (Epi::NQ > 0) {
     block_reduce<typename Epi::Op, Epi::NQ, kPanelWaves>(acc, red);
     if (threadIdx.x == 0) {
@@ -125,7 +180,9 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
     panel_own_row(P, vec, epi, partials, w, NP, prod);
     return;
   }
+  __shared__ PanelDenseSegs dseg;
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
+  panel_dense_prepare(P, w, vec, &dseg);  // (visible after the barriers of the chunk loop / before the epilogue)
   if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
   if (threadIdx.x < P.S) base_s[threadIdx.x] = P.rp_base[w * P.S + threadIdx.x];
   for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0;
@@ -245,7 +302,7 @@ __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const doubl
 #undef PANEL_CALL_LOAD
 #undef PANEL_ROUNDS
   __syncthreads();
-  panel_epilogue(P, epi, partials, psum, red, w, r0, nr);
+  panel_epilogue(P, epi, partials, psum, red, w, r0, nr, &dseg);
 }
 // ------------------------------------------------------------------------------------------------
 // Long-tail variant of the panels: row sums dealt by NONZERO, not by row.
@@ -355,7 +412,9 @@ __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double
     panel_own_row(P, vec, epi, partials, w, NP, psum);
     return;
   }
+  __shared__ PanelDenseSegs dseg;
   const int r0 = P.row0[w], nr = P.row0[w + 1] - r0;
+  panel_dense_prepare(P, w, vec, &dseg);
   if (threadIdx.x <= P.S) tile_s[threadIdx.x] = P.tile_ptr[w * P.S + threadIdx.x];
   for (int r = threadIdx.x; r < nr; r += kPanelThreads) psum[r] = 0.0, psum2[r] = 0.0;
   __syncthreads();
@@ -436,7 +495,7 @@ __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double
 #undef SEG_CALL_LOAD
 #undef SEG_ROUNDS
   __syncthreads();
-  panel_epilogue(P, epi, partials, psum, red, w, r0, nr, psum2);
+  panel_epilogue(P, epi, partials, psum, red, w, r0, nr, &dseg, psum2);
 }
 #undef PANEL_DISPATCH
 template <bool SEG, class Epi>
