@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pdlp_kernel_decls.hpp"
+#include "pdlp_layouts.hpp"
 #include "spmv_pb.hpp"
 
 // gather-free twins: phase P (one kernel, the gathered vector chosen on the device like the other layouts do) and phase R with
@@ -90,3 +91,201 @@ k_pb_eval_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const d
 // explicit instantiations (the launch sites live in another translation unit)
 template __global__ void k_pb_products<512>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);
 template __global__ void k_pb_products<1024>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);
+
+// ================================================================================================
+// host side of the layout
+// ================================================================================================
+PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced)
+{
+  PbHost H;
+  H.rows = rows, H.cols = cols;
+  const int64_t nnz = rows > 0 ? off[rows] : 0;
+  H.nnz = nnz;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) { H.why = "empty matrix"; return H; }
+  int longest = 0;
+  for (int32_t r = 0; r < rows; ++r) longest = std::max(longest, off[r + 1] - off[r]);
+  // a row is summed by ONE lane, left to right: fine up to a few hundred entries, a serial chain beyond
+  if (longest > (forced ? kPbCap / 2 : 256)) { H.why = "a row with " + std::to_string(longest) + " nonzeros"; return H; }
+  H.panel_shift = cols > (1 << 21) ? 14 : 13;
+  H.p_threads   = H.panel_shift == 14 ? 1024 : 512;
+  const int SP  = 1 << H.panel_shift;
+  const int S   = (cols + SP - 1) >> H.panel_shift;
+  H.S           = S;
+  const int threads = cuopt_amd::host_threads();
+  // bins: consecutive rows, <= target nonzeros and <= kPbMaxRows rows; the target is lowered until every bin's padded image fits
+  double target = 0.93 * kPbCap;
+  int G = 8;
+  std::vector<int32_t> row0;
+  for (int iter = 0; iter < 24; ++iter) {
+    row0.assign(1, 0);
+    while (row0.back() < rows) {
+      const int32_t r0 = row0.back();
+      const int64_t lim = (int64_t)off[r0] + (int64_t)target;
+      int32_t r1 = (int32_t)(std::upper_bound(off + r0, off + rows + 1, (int32_t)std::min<int64_t>(lim, nnz)) - off) - 1;
+      r1 = std::min(std::max(r1, r0 + 1), std::min(rows, r0 + kPbMaxRows));
+      row0.push_back(r1);
+    }
+    const int B = (int)row0.size() - 1;
+    if (iter == 0) G = nnz / ((int64_t)S * B) >= 24 ? 8 : 4;
+    std::vector<int> worst(threads * 4, 0);
+    cuopt_amd::parallel_tasks((int)worst.size(), [&](int t) {
+      std::vector<int> cnt(S, 0);
+      std::vector<int> touched;
+      int w = 0;
+      for (int b = t; b < B; b += (int)worst.size()) {
+        touched.clear();
+        int padded = 0;
+        for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) {
+          const int s_ = idx[k] >> H.panel_shift;
+          if (cnt[s_] % G == 0) padded += G;
+          if (cnt[s_]++ == 0) touched.push_back(s_);
+        }
+        for (int s_ : touched) cnt[s_] = 0;
+        w = std::max(w, padded);
+      }
+      worst[t] = w;
+    }, nnz);
+    const int maxpad = *std::max_element(worst.begin(), worst.end());
+    if (maxpad <= kPbCap) break;
+    if (iter == 23) { H.why = "bins do not converge"; return H; }
+    target *= std::min(0.97, 0.99 * (double)kPbCap / (double)maxpad);
+  }
+  H.gshift   = G == 8 ? 3 : 2;
+  H.bin_row0 = row0;
+  const int B = (int)row0.size() - 1;
+  H.B         = B;
+  // chunk sizes (bin-major), the bins' images, P order (panel-major) starts
+  cuopt_amd::PoolArray<int32_t> cnt((size_t)B * S), lstart((size_t)B * S);
+  H.bin_e0.assign(B + 1, 0);
+  std::vector<int32_t> bin_size(B);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    for (int b = t; b < B; b += threads * 4) {
+      int32_t* c = cnt.get() + (size_t)b * S;
+      std::fill(c, c + S, 0);
+      for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) c[idx[k] >> H.panel_shift]++;
+      int32_t at = 0;
+      int32_t* l = lstart.get() + (size_t)b * S;
+      for (int s_ = 0; s_ < S; ++s_) {
+        l[s_] = at;
+        at += (c[s_] + G - 1) / G * G;
+      }
+      bin_size[b] = at;
+    }
+  }, nnz);
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    H.bin_e0[b] = (int32_t)total;
+    total += bin_size[b];
+    if (total >= ((int64_t)1 << 31) - 65536) { H.why = "more than 2^31 padded entries"; return H; }
+  }
+  H.bin_e0[B] = (int32_t)total;
+  H.np        = total;
+  cuopt_amd::PoolArray<int32_t> pstart((size_t)S * B + 1);
+  {
+    int64_t at = 0;
+    for (int s_ = 0; s_ < S; ++s_)
+      for (int b = 0; b < B; ++b) {
+        pstart[(size_t)s_ * B + b] = (int32_t)at;
+        at += (cnt[(size_t)b * S + s_] + G - 1) / G * G;
+      }
+    pstart[(size_t)S * B] = (int32_t)at;
+  }
+  H.perm.reset((size_t)total + 64), H.lidx.reset((size_t)total + 64), H.piece_dst.reset((size_t)(total >> H.gshift) + 64);
+  H.pos.reset((size_t)nnz + 128), H.sr.reset((size_t)rows + 64);
+  H.bin_grp.assign(B + 1, 0);
+  for (int b = 0; b < B; ++b) H.bin_grp[b + 1] = H.bin_grp[b] + (row0[b + 1] - row0[b] + 63) / 64;
+  H.grp_pos.assign((size_t)H.bin_grp[B] + 1, 0);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    // padding slots first (a chunk's tail), then the entries
+    for (int64_t i = (int64_t)t * total / (threads * 4), e = (int64_t)(t + 1) * total / (threads * 4); i < e; ++i) H.perm[i] = -1, H.lidx[i] = 0;
+  }, total);
+  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
+    std::vector<int32_t> cur(S);
+    std::vector<uint16_t> epos;
+    std::vector<int32_t> order;
+    for (int b = t; b < B; b += threads * 4) {
+      const int32_t r0 = row0[b], nr = row0[b + 1] - r0, k0 = off[r0];
+      std::fill(cur.begin(), cur.end(), 0);
+      epos.resize((size_t)(off[r0 + nr] - k0));
+      const int32_t* l = lstart.get() + (size_t)b * S;
+      for (int32_t r = r0; r < r0 + nr; ++r)
+        for (int k = off[r]; k < off[r + 1]; ++k) {
+          const int s_     = idx[k] >> H.panel_shift;
+          const int rank   = cur[s_]++;
+          const int32_t pp = pstart[(size_t)s_ * B + b] + rank;
+          H.perm[pp]       = k;
+          H.lidx[pp]       = (uint16_t)(idx[k] & (SP - 1));
+          epos[k - k0]     = (uint16_t)(l[s_] + rank);
+        }
+      // pieces of this bin's chunks
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int np_ = (cnt[(size_t)b * S + s_] + G - 1) / G;
+        const int32_t p0 = pstart[(size_t)s_ * B + b] >> H.gshift, d0 = (H.bin_e0[b] + l[s_]) >> H.gshift;
+        for (int i = 0; i < np_; ++i) H.piece_dst[p0 + i] = d0 + i;
+      }
+      // rows sorted by length (descending, stable), groups of 64, jagged diagonals of positions
+      order.resize(nr);
+      for (int i = 0; i < nr; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return off[r0 + x + 1] - off[r0 + x] > off[r0 + y + 1] - off[r0 + y]; });
+      int32_t at = k0;  // the bin's positions start where its nonzeros start
+      for (int i = 0; i < nr; ++i) H.sr[r0 + i] = ((uint32_t)(off[r0 + order[i] + 1] - off[r0 + order[i]]) << 16) | (uint32_t)order[i];
+      for (int g0 = 0, g = 0; g0 < nr; g0 += 64, ++g) {
+        H.grp_pos[H.bin_grp[b] + g] = at;
+        const int g1   = std::min(nr, g0 + 64);
+        const int kmax = off[r0 + order[g0] + 1] - off[r0 + order[g0]];
+        for (int k = 0; k < kmax; ++k)
+          for (int i = g0; i < g1; ++i) {
+            const int32_t r = r0 + order[i];
+            if (off[r + 1] - off[r] <= k) break;
+            H.pos[at++] = epos[off[r] + k - k0];
+          }
+      }
+    }
+  }, nnz);
+  H.grp_pos[H.bin_grp[B]] = (int32_t)nnz;
+  for (int i = 0; i < 128; ++i) H.pos[(size_t)nnz + i] = 0;
+  // P workgroups: every panel's entries in Q parts (pieces are not split)
+  const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
+  for (int s_ = 0; s_ < S; ++s_) {
+    const int64_t e0 = pstart[(size_t)s_ * B], e1 = pstart[(size_t)(s_ + 1) * B];
+    const int64_t per = std::max<int64_t>(G, ((e1 - e0 + Q - 1) / Q + G - 1) / G * G);
+    for (int64_t e = e0; e < e1; e += per) {
+      H.wg_e0.push_back((int32_t)e);
+      H.wg_panel.push_back(s_);
+    }
+  }
+  H.wg_e0.push_back((int32_t)total);
+  H.ok = true;
+  return H;
+}
+
+int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h)
+{
+  if (!h.ok) return 0;
+  int32_t *piece_dst = nullptr, *wg_e0 = nullptr, *wg_panel = nullptr, *bin_row0 = nullptr, *bin_e0 = nullptr, *bin_grp = nullptr, *grp_pos = nullptr;
+  uint16_t *lidx = nullptr, *pos = nullptr;
+  uint32_t* sr = nullptr;
+  double* prod = nullptr;
+  TRY(upload_i32(c, &dst->perm, h.perm.get(), (size_t)h.np, 64));
+  TRY(upload_i32(c, &piece_dst, h.piece_dst.get(), (size_t)(h.np >> h.gshift), 64));
+  TRY(upload_i32(c, &wg_e0, h.wg_e0.data(), h.wg_e0.size()));
+  TRY(upload_i32(c, &wg_panel, h.wg_panel.data(), h.wg_panel.size()));
+  TRY(upload_i32(c, &bin_row0, h.bin_row0.data(), h.bin_row0.size()));
+  TRY(upload_i32(c, &bin_e0, h.bin_e0.data(), h.bin_e0.size()));
+  TRY(upload_i32(c, &bin_grp, h.bin_grp.data(), h.bin_grp.size()));
+  TRY(upload_i32(c, &grp_pos, h.grp_pos.data(), h.grp_pos.size()));
+  TRY(dev_alloc(c, &lidx, (size_t)h.np + 64));
+  HIP_TRY(hipMemcpyAsync(lidx, h.lidx.get(), (size_t)h.np * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &pos, (size_t)h.nnz + 128));
+  HIP_TRY(hipMemcpyAsync(pos, h.pos.get(), ((size_t)h.nnz + 128) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &sr, (size_t)h.rows + 64));
+  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), (size_t)h.rows * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &dst->val, (size_t)h.np + 64));
+  TRY(dev_alloc(c, &prod, (size_t)h.np + 256));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's PbHost
+  dst->v = PbView{h.rows, h.cols, h.S, h.B, h.gshift, h.panel_shift, (int)h.wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
+                  bin_row0, bin_e0, sr, bin_grp, grp_pos, pos, prod};
+  dst->np = h.np, dst->p_threads = h.p_threads, dst->pad = (double)h.np / (double)h.nnz;
+  dst->on = true;
+  return 0;
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pdlp_kernel_decls.hpp"
+#include "pdlp_layouts.hpp"
 #include "spmv_stream.hpp"
 
 __global__ void __launch_bounds__(kBlock)
@@ -88,4 +89,39 @@ k_eval_dual(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ 
   const double* yv = which == PDLPDEV_AVERAGE ? avgy : (cur ? y1 : y0);
   EvalDualEpilogue e{core};
   csr_stream_block(nb, rb, off, idx, val, yv, e, part, dadd);
+}
+
+// ================================================================================================
+// host side of the layout
+// ================================================================================================
+// ================================================================================================
+// host side of the device layer
+// ================================================================================================
+// Greedy partition of the rows into stream blocks: at most kNnzBlock nonzeros and
+// kMaxRowsPerBlock rows per block; a row longer than the LDS tile gets a block of its own.
+std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
+{
+  const int64_t tile = kNnzBlock;  // (smaller tiles for small LPs were measured: no gain at 1e6 nnz)
+  std::vector<int32_t> rb;
+  rb.push_back(0);
+  int32_t start = 0;
+  while (start < rows) {
+    int32_t end   = start;
+    int64_t count = 0;
+    while (end < rows && end - start < kMaxRowsPerBlock) {
+      const int64_t len = (int64_t)off[end + 1] - off[end];
+      if (count + len > tile) break;
+      count += len;
+      ++end;
+    }
+    if (end == start) end = start + 1;  // long row: alone
+    rb.push_back(end);
+    start = end;
+  }
+  // second half: the nonzero position where each block starts (off[rb[b]]), so that a workgroup learns its row range
+  // AND its nonzero range in one round trip instead of two dependent ones
+  const size_t nb1 = rb.size();
+  rb.resize(2 * nb1);
+  for (size_t b = 0; b < nb1; ++b) rb[nb1 + b] = off[rb[b]];
+  return rb;
 }

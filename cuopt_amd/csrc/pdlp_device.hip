@@ -1,4 +1,5 @@
 #include "pdlp_ctx.hpp"
+#include "pdlp_layouts.hpp"
 
 
 // ================================================================================================
@@ -1109,539 +1110,11 @@ k_unscale(int n, const double* __restrict__ v, const double* __restrict__ d, dou
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = v[i] * d[i];
 }
 
-// ================================================================================================
-// host side of the device layer
-// ================================================================================================
-// Greedy partition of the rows into stream blocks: at most kNnzBlock nonzeros and
-// kMaxRowsPerBlock rows per block; a row longer than the LDS tile gets a block of its own.
-static std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
-{
-  const int64_t tile = kNnzBlock;  // (smaller tiles for small LPs were measured: no gain at 1e6 nnz)
-  std::vector<int32_t> rb;
-  rb.push_back(0);
-  int32_t start = 0;
-  while (start < rows) {
-    int32_t end   = start;
-    int64_t count = 0;
-    while (end < rows && end - start < kMaxRowsPerBlock) {
-      const int64_t len = (int64_t)off[end + 1] - off[end];
-      if (count + len > tile) break;
-      count += len;
-      ++end;
-    }
-    if (end == start) end = start + 1;  // long row: alone
-    rb.push_back(end);
-    start = end;
-  }
-  // second half: the nonzero position where each block starts (off[rb[b]]), so that a workgroup learns its row range
-  // AND its nonzero range in one round trip instead of two dependent ones
-  const size_t nb1 = rb.size();
-  rb.resize(2 * nb1);
-  for (size_t b = 0; b < nb1; ++b) rb[nb1 + b] = off[rb[b]];
-  return rb;
-}
 
 
-// ---- slab-major row panels: host-side construction (structure only; values are permuted on the device)
-struct PanelHost {
-  bool ok = false, any_long = false;
-  bool seg = false;                        // long-tail variant: packed (row, column) entries, no row pointers (panel_seg_block)
-  int32_t slab_w = 0;
-  int W = 0, S = 0;                        // W: panels only
-  std::vector<int32_t> own_row, own_ptr;   // rows of more than kPanelOwnRow nonzeros (a workgroup each, behind the panels); per panel
-  std::vector<int32_t> row0, tile_ptr;
-  std::vector<int64_t> rp_base;
-  // the three big arrays are deliberately NOT zero-filled (every entry is written by pass 2)
-  cuopt_amd::PoolArray<int32_t> perm, col;
-  cuopt_amd::PoolArray<uint16_t> rowptr;
-  size_t nnz = 0, rowptr_size = 0;
-};
-// Bytes of the gathered vector that the CSR stream kernel keeps live in ONE XCD's L2: an XCD owns a contiguous range of
-// row blocks and has 32 CUs x 8 workgroups x 2048 nonzeros = 512 K nonzeros of consecutive rows in flight, so what it
-// re-reads from L2 is the set of 128-byte lines those rows touch.  Estimated on up to four evenly spaced windows of that
-// size (exact when the matrix is smaller), mean over the windows.  Structural and reproducible: this, not a timing, is
-// what 'auto' decides on.
-constexpr int64_t kPanelWorkingSetBytes = 4 * (int64_t)1048576;  // an XCD's L2; calibration: profiles/r02_layout_rule.txt
-static int64_t gather_working_set(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx)
-{
-  const int64_t nnz = off[rows], window = 512 * 1024;
-  if (rows <= 0 || cols <= 0 || nnz <= 0) return 0;
-  const int samples = nnz <= window ? 1 : (int)std::min<int64_t>(4, (nnz + window - 1) / window);
-  std::vector<uint8_t> seen((size_t)(cols >> 4) + 1);
-  int64_t total = 0;
-  for (int s = 0; s < samples; ++s) {
-    const int64_t first = samples == 1 ? 0 : (nnz - window) * s / (samples - 1);
-    const int64_t last  = std::min(nnz, first + window);
-    std::fill(seen.begin(), seen.end(), 0);
-    int64_t lines = 0;
-    for (int64_t k = first; k < last; ++k) {
-      uint8_t& b = seen[(size_t)(idx[k] >> 4)];
-      lines += !b;
-      b = 1;
-    }
-    total += lines * 128;
-  }
-  return total / samples;
-}
-static PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
-                              int64_t slab_bytes, bool force, const std::vector<int32_t>* dense_first_seg = nullptr)
-{
-  PanelHost P;
-  const int64_t nnz = off[rows];
-  if (rows <= 0 || cols <= 0 || nnz <= 0) return P;
-  // worth it only when the gathered vector overflows an XCD's L2 (4 MiB, shared with the matrix stream)
-  if (!force && (int64_t)cols * 8 <= 2 * (int64_t)1048576) return P;
-  int S = (int)(((int64_t)cols * 8 + slab_bytes - 1) / slab_bytes);
-  S     = std::max(1, std::min(S, 16));
-  const int32_t slab_w = (cols + S - 1) / S;
-  // panels: two 512-thread workgroups per CU = 512 resident panels, and ALL panels should be resident at once (they walk
-  // the slabs in lockstep; a 513th panel runs alone afterwards: the power-law LP with 11.4 M nonzeros took 104 us per SpMV
-  // with 570 panels of 20 K nonzeros and takes 75 with 512 of 22 K).  So the panel size follows the matrix, up to
-  // 60 K nonzeros (beyond that the row-sum strip, kPanelMaxRows, and the 16-bit tile pointers set the limits).
-  const int64_t cap = std::max<int64_t>(2048, cuopt_amd::tune_int("panel_nnz", 60000));  // (tests cut small matrices into many panels)
-  // A panel takes rows while they fit under the target (a row above the target is a panel of its own): all panels run at
-  // once, so the LARGEST one sets the kernel time -- letting a panel overshoot by its last row made panels of 42 K nonzeros
-  // next to the average 22 K on the power-law LP (rows of up to 20 000 nonzeros) and cost 26 of its 117 us.  The target grows
-  // (proportionally first, then in 1 % steps) until the panels fit the 512 resident slots again.
-  // Long-tailed row lengths: row sums dealt by nonzero (panel_seg_block; every row at rtol 1e-12 instead of bit-exact short rows).
-  // auto: when more than 2 % of the nonzeros sit in rows of more than kLongRow entries -- a structural, reproducible rule;
-  // CUOPT_AMD_TUNE=panel_seg=0|1 forces it off / on (tests, sweeps).
-  int64_t long_nnz = 0;  // nonzeros in rows the row-per-lane kernel sums wave by wave
-  for (int32_t i = 0; i < rows; ++i)
-    if (off[i + 1] - off[i] > kLongRow) long_nnz += off[i + 1] - off[i];
-  {
-    const long long want = cuopt_amd::tune_int("panel_seg", -1);
-    P.seg = want == 1 || (want != 0 && long_nnz * 50 > nnz);
-    if (slab_w > (1 << kSegColBits)) P.seg = false;
-  }
-  // Rows beyond kPanelOwnRow nonzeros get a workgroup each behind the panels (a lane, or a wave, would walk them for ever).  The
-  // long-tail variant deals every row by nonzero, so a row leaves the panels only when it is longer than a whole panel should be
-  // (it would be the one panel everybody waits for): up to there it is ordinary work, and no resident slot is spent on it.
-  const int64_t own_from = P.seg ? std::max<int64_t>(kPanelOwnRow, std::min<int64_t>(cap, (nnz + 511) / 512)) : kPanelOwnRow;
-  std::vector<char> is_own(rows, 0);
-  int64_t own_nnz = 0;
-  for (int32_t i = 0; i < rows; ++i)
-      if (off[i + 1] - off[i] > own_from || (dense_first_seg && (*dense_first_seg)[i] >= 0))  // (rows that own dense segments: their
-        is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];                // workgroup adds the segments too)
-  auto cut = [&](int64_t tgt) {
-    P.row0.assign(1, 0);
-    int32_t start = 0;
-    while (start < rows) {
-      int32_t end = start;
-      int64_t cnt = 0;
-      while (end < rows && end - start < kPanelMaxRows) {
-        const int64_t len = is_own[end] ? 0 : off[end + 1] - off[end];
-        if (cnt > 0 && cnt + len > tgt) break;
-        cnt += len;
-        ++end;
-      }
-      P.row0.push_back(end);
-      start = end;
-    }
-  };
-  int64_t tgt = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz - own_nnz + 511) / 512));
-  cut(tgt);
-  // (the rows with a workgroup of their own share the 512 resident slots with the panels: behind a full house they would run alone)
-  const int slots = std::max(64, 512 - (int)P.own_row.size());
-  tgt             = std::max<int64_t>(2048, std::min<int64_t>(cap, (nnz - own_nnz + slots - 1) / slots));
-  cut(tgt);
-  for (int it = 0; it < 64 && (int)P.row0.size() - 1 > slots && tgt < cap; ++it) {
-    const int64_t w = (int64_t)P.row0.size() - 1;
-    tgt = std::min<int64_t>(cap, it == 0 ? (int64_t)((double)tgt * (double)w / (double)slots * 1.002) + 1 : tgt + tgt / 100 + 1);
-    cut(tgt);
-  }
-  const int W = (int)P.row0.size() - 1;
-  P.W = W, P.S = S, P.slab_w = slab_w;
-  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
-  P.own_ptr.assign((size_t)W + 1, 0);
-  for (int w = 0, q = 0; w < W; ++w) {
-    while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;
-    P.own_ptr[w + 1] = q;
-  }
-  // pass 1: nonzeros per (panel, slab) -- panels are independent, so both passes run over host threads
-  std::vector<int64_t> count((size_t)W * S + 1, 0);
-  cuopt_amd::parallel_tasks(W, [&](int w) {
-    int64_t* cw = &count[(size_t)w * S];
-    for (int32_t i = P.row0[w]; i < P.row0[w + 1]; ++i)
-      if (!is_own[i])
-        for (int64_t t = off[i]; t < off[i + 1]; ++t) cw[idx[t] / slab_w] += 1;
-  }, nnz);
-  P.tile_ptr.resize((size_t)W * S + 1);
-  int64_t pos = 0;
-  for (size_t i = 0; i < (size_t)W * S; ++i) {
-    if (!P.seg && count[i] >= 65536) return P;  // 16-bit row pointers would overflow: keep the CSR stream layout
-    P.tile_ptr[i] = (int32_t)pos;
-    pos += count[i];
-  }
-  P.tile_ptr[(size_t)W * S] = (int32_t)pos;
-  // pass 2: placement + per-tile row pointers
-  P.nnz = (size_t)(nnz - own_nnz), P.rowptr_size = P.seg ? 0 : (size_t)S * ((size_t)rows + W);
-  P.perm.reset(P.nnz), P.col.reset(P.nnz);
-  if (P.seg) {
-    // placement in (slab, row, CSR) order as below, every entry carrying its row within the panel next to its column inside the slab
-    cuopt_amd::parallel_tasks(W, [&](int w) {
-      const int32_t a = P.row0[w], b = P.row0[w + 1];
-      std::vector<int32_t> cursor(S);
-      for (int s2 = 0; s2 < S; ++s2) cursor[s2] = P.tile_ptr[(size_t)w * S + s2];
-      for (int32_t i = a; i < b; ++i) {
-        if (is_own[i]) continue;
-        for (int32_t t = off[i]; t < off[i + 1]; ++t) {
-          const int s2    = idx[t] / slab_w;
-          const int32_t q = cursor[s2]++;
-          P.perm[q] = t, P.col[q] = (int32_t)(((uint32_t)(i - a) << kSegColBits) | (uint32_t)(idx[t] - s2 * slab_w));
-        }
-      }
-    }, nnz);
-    P.ok = true;
-    return P;
-  }
-  P.rowptr.reset(P.rowptr_size);
-  P.rp_base.resize((size_t)W * S);
-  cuopt_amd::parallel_tasks(W, [&](int w) {
-    const int32_t a = P.row0[w], b = P.row0[w + 1], nr = b - a;
-    const int64_t rp = (int64_t)S * ((int64_t)a + w);  // rowptr entries of all earlier panels
-    std::vector<int32_t> cursor(S);
-    for (int s2 = 0; s2 < S; ++s2) {
-      cursor[s2]                    = P.tile_ptr[(size_t)w * S + s2];
-      P.rp_base[(size_t)w * S + s2] = rp + (int64_t)s2 * (nr + 1);
-    }
-    for (int32_t i = a; i < b; ++i) {
-      for (int s2 = 0; s2 < S; ++s2)
-        P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + (i - a))] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
-      if (is_own[i]) continue;
-      for (int32_t t = off[i]; t < off[i + 1]; ++t) {
-        const int s2 = idx[t] / slab_w;
-        const int32_t q = cursor[s2]++;
-        P.perm[q] = t, P.col[q] = idx[t];
-      }
-    }
-    for (int s2 = 0; s2 < S; ++s2)
-      P.rowptr[(size_t)(P.rp_base[(size_t)w * S + s2] + nr)] = (uint16_t)(cursor[s2] - P.tile_ptr[(size_t)w * S + s2]);
-  }, nnz);
-  P.ok = true;
-  return P;
-}
-
-static int upload_i32(pdlpdev_ctx* c, int32_t** dst, const int32_t* src, size_t count, size_t pad = 0)
-{
-  TRY(dev_alloc(c, dst, count + pad));
-  if (count) HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  return 0;
-}
-static int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t count, size_t pad = 0)
-{
-  TRY(dev_alloc(c, dst, count + pad));
-  if (count && src)
-    HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  return 0;
-}
 
 
-// ---- sorted jagged rows: host-side construction (structure only; values are permuted on the device) -------------
-struct JagHost {
-  bool ok = false;
-  int rows = 0, waves = 8, ngroups = 0, nblk = 0;
-  std::vector<int32_t> row0, tile_e, tile_sr, win, set_ptr, set_col, lr_ptr, lr_row;
-  cuopt_amd::PoolArray<uint32_t> sr;
-  cuopt_amd::PoolArray<uint16_t> slot;
-  cuopt_amd::PoolArray<int32_t> perm;
-  size_t nsr = 0, nent = 0;
-  double saving = 0.0;  // share of the global gathers the LDS column sets save: 1 - (cost of filling the sets) / nonzeros
-};
-// open-addressing set of column indices with O(1) clear (a stamp per slot)
-struct ColumnSet {
-  std::vector<int32_t> key, payload;
-  std::vector<uint32_t> stamp;
-  uint32_t now = 0, mask;
-  explicit ColumnSet(int capacity_log2)
-      : key((size_t)1 << capacity_log2), payload((size_t)1 << capacity_log2), stamp((size_t)1 << capacity_log2, 0), mask((1u << capacity_log2) - 1) {}
-  int32_t& at(int32_t c)  // payload of a column that is in the set
-  {
-    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
-    while (key[h] != c || stamp[h] != now) h = (h + 1) & mask;
-    return payload[h];
-  }
-  void clear() { ++now; }
-  bool contains(int32_t c) const
-  {
-    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
-    while (stamp[h] == now) {
-      if (key[h] == c) return true;
-      h = (h + 1) & mask;
-    }
-    return false;
-  }
-  bool insert(int32_t c)  // true when c was not there
-  {
-    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
-    while (stamp[h] == now) {
-      if (key[h] == c) return false;
-      h = (h + 1) & mask;
-    }
-    stamp[h] = now, key[h] = c;
-    return true;
-  }
-};
-// one set per host thread and capacity (the tasks of a parallel_tasks call share their thread's)
-static ColumnSet& thread_column_set(int capacity_log2, int which)
-{
-  thread_local std::unique_ptr<ColumnSet> sets[2][2];
-  std::unique_ptr<ColumnSet>& p = sets[capacity_log2 == 16][which];
-  if (!p) p.reset(new ColumnSet(capacity_log2));
-  return *p;
-}
-// `mode`: 0 = use the layout when filling the LDS column sets costs at most half of the gathers they serve, 1 = always
-static JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode, int cus)
-{
-  JagHost H;
-  const int64_t nnz = rows > 0 ? off[rows] : 0;
-  if (rows <= 0 || cols <= 0 || nnz <= 0) return H;
-  // one wave per group of up to G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
-  // (below ~1.3e5 rows the layout has fewer workgroups than the chip has CUs and the CSR stream kernel's many small workgroups
-  // win by 8 % on banded 7e4- and 1e5-row LPs; from 2e5 rows on the jagged layout wins: 28.9 k vs 26.9 k it/s)
-  int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
-  if (mode == 1 && G == 0) G = 64;
-  if (G == 0) return H;
-  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_TUNE=jag_waves=16: 16384 columns, one workgroup per CU) measured
-  // 1-3 % faster on the banded, block-angular and multi-band LPs with the column-set version of this layout -- inside the noise
-  // of two runs, so the default stays with the geometry every profile of this round was taken with.
-  int waves = 8;
-  if (cuopt_amd::tune_int("jag_waves", 8) == 16) waves = 16;
-  const int wcap = jag_window(waves), brows = waves * G;
-  const int slots = cus * (waves == 16 ? 1 : 2);  // workgroups resident at once: 80 KiB of LDS each (160 KiB with 16 waves)
-  // A workgroup's rows: consecutive, at most `brows`, and as many as keep their DISTINCT columns within the LDS window
-  // (rows longer than kLongRow do not count: they gather from global memory in workgroups of their own).  Greedy from
-  // `first`; returns the end of the block.
-  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit, int32_t row_cap) -> int32_t {
-    set.clear();
-    int32_t distinct = 0, r = first;
-    const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + row_cap, limit);
-    for (; r < last; ++r) {
-      const int32_t len = off[r + 1] - off[r];
-      if (len > kLongRow) continue;
-      if (distinct + len > wcap) {  // may overflow: count the new columns before inserting any
-        int32_t fresh = 0;
-        for (int32_t k = off[r]; k < off[r + 1]; ++k) fresh += !set.contains(idx[k]);
-        if (distinct + fresh > wcap) break;
-      }
-      for (int32_t k = off[r]; k < off[r + 1]; ++k) distinct += set.insert(idx[k]);
-    }
-    return std::max(r, first + 1);  // a row of <= kLongRow nonzeros always fits an empty set
-  };
-  // cost of a block in gather equivalents: what filling its LDS set costs (a contiguous range is a coalesced copy, a list
-  // costs one request per run of consecutive columns) against the gathers it serves.  Also decides range vs list.
-  struct BlockSet {
-    int32_t wbase = 0, wlen = 0;  // contiguous range, or ...
-    std::vector<int32_t> cols;    // ... sorted distinct columns
-    int64_t refs = 0, cost = 0;
-  };
-  auto block_set = [&](int32_t r0, int32_t r1, ColumnSet& set) -> BlockSet {
-    BlockSet B;
-    int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
-    for (int32_t r = r0; r < r1; ++r) {
-      if (off[r + 1] - off[r] > kLongRow) continue;
-      for (int32_t k = off[r]; k < off[r + 1]; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
-      B.refs += off[r + 1] - off[r];
-    }
-    if (hi < 0) return B;
-    if ((int64_t)hi - lo + 1 <= wcap) {
-      B.wbase = lo, B.wlen = hi - lo + 1;
-      B.cost  = 1 + B.wlen / 16;
-      return B;
-    }
-    set.clear();
-    for (int32_t r = r0; r < r1; ++r)
-      if (off[r + 1] - off[r] <= kLongRow)
-        for (int32_t k = off[r]; k < off[r + 1]; ++k)
-          if (set.insert(idx[k])) B.cols.push_back(idx[k]);
-    std::sort(B.cols.begin(), B.cols.end());  // only the distinct columns (<= the LDS window) are sorted
-    int64_t runs = 0;
-    for (size_t i = 0; i < B.cols.size(); ++i) runs += i == 0 || B.cols[i] != B.cols[i - 1] + 1;
-    B.cost = runs + (int64_t)B.cols.size() / 16;
-    return B;
-  };
-  if (mode == 0) {  // estimate on ~48 blocks first: a random matrix is turned away after a few milliseconds
-    const int samples = (int)std::min<int64_t>(48, std::max<int64_t>(1, rows / brows));
-    std::vector<int64_t> refs(samples, 0), cost(samples, 0);
-    cuopt_amd::parallel_tasks(samples, [&](int t) {
-      ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
-      const int32_t first = (int32_t)((int64_t)rows * t / samples);
-      const int32_t last  = block_end(set, first, rows, brows);
-      const BlockSet B    = block_set(first, last, set);
-      refs[t] = B.refs, cost[t] = B.cost;
-    }, nnz);
-    int64_t r = 0, c = 0;
-    for (int t = 0; t < samples; ++t) r += refs[t], c += cost[t];
-    H.saving = r ? 1.0 - (double)c / (double)r : 0.0;
-    if (H.saving < 0.35) return H;
-  }
-  // the partition: chunks of rows are cut independently (a chunk boundary is a block boundary), in parallel
-  const int32_t chunk_rows = 8 * brows;
-  const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
-  auto partition = [&](int32_t row_cap) {
-    std::vector<std::vector<int32_t>> cuts(nchunks);
-    cuopt_amd::parallel_tasks(nchunks, [&](int t) {
-      ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
-      const int32_t c0 = (int32_t)((int64_t)t * chunk_rows), c1 = (int32_t)std::min<int64_t>((int64_t)c0 + chunk_rows, rows);
-      for (int32_t r = c0; r < c1;) cuts[t].push_back(r = block_end(set, r, c1, row_cap));
-    }, nnz);
-    std::vector<int32_t> row0(1, 0);
-    for (auto& v : cuts) row0.insert(row0.end(), v.begin(), v.end());
-    return row0;
-  };
-  H.row0 = partition(brows);
-  // All workgroups of a round run at once (`slots` of them fit the chip) and the kernel lasts rounds x the largest block.  When
-  // the column sets cut the blocks short (block-angular LP: 672 blocks on 512 slots, the second round a third full), smaller
-  // blocks that fill the same number of rounds are strictly better: 2 x t(980 rows) instead of 2 x t(1490 rows).
-  if (slots > 0 && (int)H.row0.size() - 1 > slots) {
-    const int nb = (int)H.row0.size() - 1, rounds = (nb + slots - 1) / slots;
-    if ((double)nb < 0.9 * (double)rounds * (double)slots) {
-      int32_t cap = (int32_t)std::ceil((double)rows / (0.97 * (double)rounds * (double)slots));
-      cap         = std::max<int32_t>(64, (cap + 63) & ~63);  // whole passes of 64 rows
-      if (cap < brows) {
-        std::vector<int32_t> alt = partition(cap);
-        if (((int)alt.size() - 1 + slots - 1) / slots <= rounds) H.row0.swap(alt);
-      }
-    }
-  }
-  const int nblk    = (int)H.row0.size() - 1;
-  const int ngroups = nblk * waves;  // every wave of every workgroup has a (possibly empty) share of the sorted passes
-  H.rows = rows, H.waves = waves, H.ngroups = ngroups, H.nblk = nblk;
-  // Per workgroup: rows with 1..kLongRow nonzeros sorted by length (descending, stable), cut into passes of 64, the
-  // passes dealt to the waves in snake order (0..7, 7..0, ...): every wave gets the same share of long and short
-  // passes, and a pass holds rows of nearly equal length.  pass 1 sizes everything (and builds the column sets), pass 2 fills.
-  H.tile_e.assign((size_t)ngroups + 1, 0), H.tile_sr.assign((size_t)ngroups + 1, 0), H.lr_ptr.assign((size_t)nblk + 1, 0);
-  H.set_ptr.assign((size_t)nblk + 1, 0), H.win.assign((size_t)2 * nblk, 0);
-  auto wave_of_pass = [waves](int p) { return ((p / waves) & 1) ? waves - 1 - (p % waves) : p % waves; };
-  // sorted order of a workgroup's short rows (local row numbers), number of them returned
-  auto sort_block = [&](int b, std::vector<int32_t>& order) -> int32_t {
-    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
-    int32_t bucket[kLongRow + 2] = {0};
-    for (int32_t r = r0; r < r1; ++r) {
-      const int32_t len = off[r + 1] - off[r];
-      if (len >= 1 && len <= kLongRow) bucket[kLongRow - len]++;  // longest first
-    }
-    int32_t start[kLongRow + 2];
-    int32_t run = 0;
-    for (int i = 0; i <= kLongRow; ++i) start[i] = run, run += bucket[i];
-    order.resize((size_t)run);
-    for (int32_t r = r0; r < r1; ++r) {
-      const int32_t len = off[r + 1] - off[r];
-      if (len >= 1 && len <= kLongRow) order[start[kLongRow - len]++] = r - r0;
-    }
-    return run;
-  };
-  std::vector<int32_t> gsr((size_t)nblk * waves, 0);
-  std::vector<int64_t> gent((size_t)nblk * waves, 0);
-  std::vector<int32_t> nlong(nblk, 0);
-  std::vector<BlockSet> sets(nblk);
-  cuopt_amd::parallel_tasks(nblk, [&](int b) {
-    std::vector<int32_t> order;
-    ColumnSet& set = thread_column_set(waves == 16 ? 16 : 15, 0);
-    const int32_t ns = sort_block(b, order);
-    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
-    for (int32_t r = r0; r < r1; ++r) nlong[b] += off[r + 1] - off[r] > kLongRow;
-    for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
-      const int w = wave_of_pass(p);
-      for (int32_t i = i0; i < std::min(ns, i0 + 64); ++i) {
-        gsr[(size_t)b * waves + w] += 1;
-        gent[(size_t)b * waves + w] += off[r0 + order[i] + 1] - off[r0 + order[i]];
-      }
-    }
-    sets[b] = block_set(r0, r1, set);
-  }, nnz);
-  int64_t refs = 0, cost = 0;
-  for (int b = 0; b < nblk; ++b) {
-    refs += sets[b].refs, cost += sets[b].cost;
-    H.win[2 * b] = sets[b].wbase, H.win[2 * b + 1] = sets[b].wlen;
-    H.set_ptr[b + 1] = H.set_ptr[b] + (int32_t)sets[b].cols.size();
-    H.lr_ptr[b + 1]  = H.lr_ptr[b] + nlong[b];
-  }
-  H.saving = refs ? 1.0 - (double)cost / (double)refs : 0.0;
-  if (mode == 0 && H.saving < 0.5) return H;
-  for (int g = 0; g < ngroups; ++g) {
-    H.tile_sr[g + 1] = H.tile_sr[g] + gsr[g];
-    H.tile_e[g + 1]  = (int32_t)(H.tile_e[g] + gent[g]);
-  }
-  H.nsr = (size_t)H.tile_sr[ngroups], H.nent = (size_t)H.tile_e[ngroups];
-  H.sr.reset(H.nsr + 1), H.slot.reset(H.nent + 1), H.perm.reset(H.nent + 1);
-  H.lr_row.assign((size_t)H.lr_ptr[nblk], 0);
-  H.set_col.assign((size_t)H.set_ptr[nblk], 0);
-  cuopt_amd::parallel_tasks(nblk, [&](int b) {
-    std::vector<int32_t> order;
-    const int32_t ns = sort_block(b, order);
-    const int32_t r0 = H.row0[b], r1 = H.row0[b + 1];
-    const BlockSet& B = sets[b];
-    std::copy(B.cols.begin(), B.cols.end(), H.set_col.begin() + H.set_ptr[b]);
-    ColumnSet& map = thread_column_set(waves == 16 ? 16 : 15, 1);  // column -> slot of a list-mode set
-    if (!B.wlen) {
-      map.clear();
-      for (size_t i = 0; i < B.cols.size(); ++i) {
-        map.insert(B.cols[i]);
-        map.at(B.cols[i]) = (int32_t)i;
-      }
-    }
-    auto slot_of = [&](int32_t c) -> uint16_t { return B.wlen ? (uint16_t)(c - B.wbase) : (uint16_t)map.at(c); };
-    int32_t nl = H.lr_ptr[b];
-    for (int32_t r = r0; r < r1; ++r)
-      if (off[r + 1] - off[r] > kLongRow) H.lr_row[nl++] = r;
-    int32_t srpos[16];
-    int64_t epos[16];
-    for (int w = 0; w < waves; ++w) {
-      const int g = b * waves + w;
-      srpos[w] = H.tile_sr[g], epos[w] = H.tile_e[g];
-    }
-    for (int32_t i0 = 0, p = 0; i0 < ns; i0 += 64, ++p) {
-      const int w = wave_of_pass(p);
-      const int32_t i1 = std::min(ns, i0 + 64);
-      for (int32_t i = i0; i < i1; ++i) {
-        const int32_t len = off[r0 + order[i] + 1] - off[r0 + order[i]];
-        H.sr[srpos[w]++] = ((uint32_t)(len - 1) << 16) | (uint32_t)order[i];
-      }
-      const int32_t kmax = off[r0 + order[i0] + 1] - off[r0 + order[i0]];
-      int64_t e = epos[w];
-      for (int32_t k = 0; k < kmax; ++k)
-        for (int32_t i = i0; i < i1; ++i) {
-          const int32_t r = r0 + order[i];
-          if (off[r + 1] - off[r] <= k) break;  // sorted: the rest of the pass is shorter still
-          H.slot[e] = slot_of(idx[off[r] + k]), H.perm[e] = off[r] + k, ++e;
-        }
-      epos[w] = e;
-    }
-  }, nnz);
-  H.ok = true;
-  return H;
-}
-static int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, const int32_t* d_off, const int32_t* d_idx,
-                      const double* d_val)
-{
-  dst->saving = h.saving;
-  if (!h.ok) return 0;
-  int32_t *row0 = nullptr, *tile_e = nullptr, *tile_sr = nullptr, *win = nullptr, *set_ptr = nullptr, *set_col = nullptr,
-          *lr_ptr = nullptr, *lr_row = nullptr;
-  uint32_t* sr   = nullptr;
-  uint16_t* slot = nullptr;
-  TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
-  TRY(upload_i32(c, &tile_e, h.tile_e.data(), h.tile_e.size()));
-  TRY(upload_i32(c, &tile_sr, h.tile_sr.data(), h.tile_sr.size()));
-  TRY(upload_i32(c, &win, h.win.data(), h.win.size()));
-  TRY(upload_i32(c, &set_ptr, h.set_ptr.data(), h.set_ptr.size()));
-  TRY(upload_i32(c, &set_col, h.set_col.data(), h.set_col.size(), 8));
-  TRY(upload_i32(c, &lr_ptr, h.lr_ptr.data(), h.lr_ptr.size()));
-  TRY(upload_i32(c, &lr_row, h.lr_row.data(), h.lr_row.size()));
-  TRY(upload_i32(c, &dst->perm, h.perm.get(), h.nent, 8));
-  TRY(dev_alloc(c, &sr, h.nsr + 8));
-  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), h.nsr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &slot, h.nent + 64));
-  HIP_TRY(hipMemcpyAsync(slot, h.slot.get(), h.nent * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &dst->val, h.nent + 8));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's JagHost
-  dst->v    = JagView{h.rows, h.waves, h.ngroups, h.nblk, (int)h.lr_row.size(), row0, tile_e, tile_sr, sr, slot, dst->val,
-                      win, set_ptr, set_col, lr_ptr, lr_row, d_off, d_idx, d_val};
-  dst->nent = (int64_t)h.nent;
-  dst->on   = true;
-  return 0;
-}
+
 // Every hot-loop launch goes through here so that pdlpdev_time_kernel can ask for the dispatch's own start / stop
 // timestamps (hipExtLaunchKernel) without putting event records between the kernels of an attempt.
 template <size_t... I, typename Tuple>
@@ -1687,214 +1160,6 @@ static int jag_launch(pdlpdev_ctx* c, void (*kernel)(JagView, KArgs...), const J
   ((VIEW).waves == 16 ? jag_launch(ctx, KERNEL<16>, VIEW, __VA_ARGS__) : jag_launch(ctx, KERNEL<8>, VIEW, __VA_ARGS__))
 
 
-// ---- gather-free layout: host-side construction (structure only; values are permuted on the device) -----------------
-// Parallel over bins on the host pool's threads; every pass is O(nnz).  Geometry: panels of 8192 columns (16384 when the
-// gathered vector has more than 2 M entries: fewer, longer chunks), pieces of 8 entries unless the chunks (nnz / (panels x bins))
-// are shorter than 24 entries (then 4: at 1e8 nonzeros -- chunks of 13 -- 8-entry pieces pad by 33 % and run 20 % slower), bins filled to kPbCap padded entries (found by iterating on the per-bin nonzero target:
-// the padding of a bin depends on how its entries spread over the panels).
-struct PbHost {
-  bool ok = false;
-  std::string why;
-  int rows = 0, cols = 0, S = 0, B = 0, gshift = 3, panel_shift = 13, p_threads = 512;
-  int64_t np = 0, nnz = 0;
-  std::vector<int32_t> bin_row0, bin_e0, wg_e0, wg_panel, bin_grp, grp_pos;
-  cuopt_amd::PoolArray<int32_t> perm, piece_dst;
-  cuopt_amd::PoolArray<uint16_t> lidx, pos;
-  cuopt_amd::PoolArray<uint32_t> sr;
-};
-static PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced)
-{
-  PbHost H;
-  H.rows = rows, H.cols = cols;
-  const int64_t nnz = rows > 0 ? off[rows] : 0;
-  H.nnz = nnz;
-  if (rows <= 0 || cols <= 0 || nnz <= 0) { H.why = "empty matrix"; return H; }
-  int longest = 0;
-  for (int32_t r = 0; r < rows; ++r) longest = std::max(longest, off[r + 1] - off[r]);
-  // a row is summed by ONE lane, left to right: fine up to a few hundred entries, a serial chain beyond
-  if (longest > (forced ? kPbCap / 2 : 256)) { H.why = "a row with " + std::to_string(longest) + " nonzeros"; return H; }
-  H.panel_shift = cols > (1 << 21) ? 14 : 13;
-  H.p_threads   = H.panel_shift == 14 ? 1024 : 512;
-  const int SP  = 1 << H.panel_shift;
-  const int S   = (cols + SP - 1) >> H.panel_shift;
-  H.S           = S;
-  const int threads = cuopt_amd::host_threads();
-  // bins: consecutive rows, <= target nonzeros and <= kPbMaxRows rows; the target is lowered until every bin's padded image fits
-  double target = 0.93 * kPbCap;
-  int G = 8;
-  std::vector<int32_t> row0;
-  for (int iter = 0; iter < 24; ++iter) {
-    row0.assign(1, 0);
-    while (row0.back() < rows) {
-      const int32_t r0 = row0.back();
-      const int64_t lim = (int64_t)off[r0] + (int64_t)target;
-      int32_t r1 = (int32_t)(std::upper_bound(off + r0, off + rows + 1, (int32_t)std::min<int64_t>(lim, nnz)) - off) - 1;
-      r1 = std::min(std::max(r1, r0 + 1), std::min(rows, r0 + kPbMaxRows));
-      row0.push_back(r1);
-    }
-    const int B = (int)row0.size() - 1;
-    if (iter == 0) G = nnz / ((int64_t)S * B) >= 24 ? 8 : 4;
-    std::vector<int> worst(threads * 4, 0);
-    cuopt_amd::parallel_tasks((int)worst.size(), [&](int t) {
-      std::vector<int> cnt(S, 0);
-      std::vector<int> touched;
-      int w = 0;
-      for (int b = t; b < B; b += (int)worst.size()) {
-        touched.clear();
-        int padded = 0;
-        for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) {
-          const int s_ = idx[k] >> H.panel_shift;
-          if (cnt[s_] % G == 0) padded += G;
-          if (cnt[s_]++ == 0) touched.push_back(s_);
-        }
-        for (int s_ : touched) cnt[s_] = 0;
-        w = std::max(w, padded);
-      }
-      worst[t] = w;
-    }, nnz);
-    const int maxpad = *std::max_element(worst.begin(), worst.end());
-    if (maxpad <= kPbCap) break;
-    if (iter == 23) { H.why = "bins do not converge"; return H; }
-    target *= std::min(0.97, 0.99 * (double)kPbCap / (double)maxpad);
-  }
-  H.gshift   = G == 8 ? 3 : 2;
-  H.bin_row0 = row0;
-  const int B = (int)row0.size() - 1;
-  H.B         = B;
-  // chunk sizes (bin-major), the bins' images, P order (panel-major) starts
-  cuopt_amd::PoolArray<int32_t> cnt((size_t)B * S), lstart((size_t)B * S);
-  H.bin_e0.assign(B + 1, 0);
-  std::vector<int32_t> bin_size(B);
-  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
-    for (int b = t; b < B; b += threads * 4) {
-      int32_t* c = cnt.get() + (size_t)b * S;
-      std::fill(c, c + S, 0);
-      for (int k = off[row0[b]]; k < off[row0[b + 1]]; ++k) c[idx[k] >> H.panel_shift]++;
-      int32_t at = 0;
-      int32_t* l = lstart.get() + (size_t)b * S;
-      for (int s_ = 0; s_ < S; ++s_) {
-        l[s_] = at;
-        at += (c[s_] + G - 1) / G * G;
-      }
-      bin_size[b] = at;
-    }
-  }, nnz);
-  int64_t total = 0;
-  for (int b = 0; b < B; ++b) {
-    H.bin_e0[b] = (int32_t)total;
-    total += bin_size[b];
-    if (total >= ((int64_t)1 << 31) - 65536) { H.why = "more than 2^31 padded entries"; return H; }
-  }
-  H.bin_e0[B] = (int32_t)total;
-  H.np        = total;
-  cuopt_amd::PoolArray<int32_t> pstart((size_t)S * B + 1);
-  {
-    int64_t at = 0;
-    for (int s_ = 0; s_ < S; ++s_)
-      for (int b = 0; b < B; ++b) {
-        pstart[(size_t)s_ * B + b] = (int32_t)at;
-        at += (cnt[(size_t)b * S + s_] + G - 1) / G * G;
-      }
-    pstart[(size_t)S * B] = (int32_t)at;
-  }
-  H.perm.reset((size_t)total + 64), H.lidx.reset((size_t)total + 64), H.piece_dst.reset((size_t)(total >> H.gshift) + 64);
-  H.pos.reset((size_t)nnz + 128), H.sr.reset((size_t)rows + 64);
-  H.bin_grp.assign(B + 1, 0);
-  for (int b = 0; b < B; ++b) H.bin_grp[b + 1] = H.bin_grp[b] + (row0[b + 1] - row0[b] + 63) / 64;
-  H.grp_pos.assign((size_t)H.bin_grp[B] + 1, 0);
-  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
-    // padding slots first (a chunk's tail), then the entries
-    for (int64_t i = (int64_t)t * total / (threads * 4), e = (int64_t)(t + 1) * total / (threads * 4); i < e; ++i) H.perm[i] = -1, H.lidx[i] = 0;
-  }, total);
-  cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
-    std::vector<int32_t> cur(S);
-    std::vector<uint16_t> epos;
-    std::vector<int32_t> order;
-    for (int b = t; b < B; b += threads * 4) {
-      const int32_t r0 = row0[b], nr = row0[b + 1] - r0, k0 = off[r0];
-      std::fill(cur.begin(), cur.end(), 0);
-      epos.resize((size_t)(off[r0 + nr] - k0));
-      const int32_t* l = lstart.get() + (size_t)b * S;
-      for (int32_t r = r0; r < r0 + nr; ++r)
-        for (int k = off[r]; k < off[r + 1]; ++k) {
-          const int s_     = idx[k] >> H.panel_shift;
-          const int rank   = cur[s_]++;
-          const int32_t pp = pstart[(size_t)s_ * B + b] + rank;
-          H.perm[pp]       = k;
-          H.lidx[pp]       = (uint16_t)(idx[k] & (SP - 1));
-          epos[k - k0]     = (uint16_t)(l[s_] + rank);
-        }
-      // pieces of this bin's chunks
-      for (int s_ = 0; s_ < S; ++s_) {
-        const int np_ = (cnt[(size_t)b * S + s_] + G - 1) / G;
-        const int32_t p0 = pstart[(size_t)s_ * B + b] >> H.gshift, d0 = (H.bin_e0[b] + l[s_]) >> H.gshift;
-        for (int i = 0; i < np_; ++i) H.piece_dst[p0 + i] = d0 + i;
-      }
-      // rows sorted by length (descending, stable), groups of 64, jagged diagonals of positions
-      order.resize(nr);
-      for (int i = 0; i < nr; ++i) order[i] = i;
-      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return off[r0 + x + 1] - off[r0 + x] > off[r0 + y + 1] - off[r0 + y]; });
-      int32_t at = k0;  // the bin's positions start where its nonzeros start
-      for (int i = 0; i < nr; ++i) H.sr[r0 + i] = ((uint32_t)(off[r0 + order[i] + 1] - off[r0 + order[i]]) << 16) | (uint32_t)order[i];
-      for (int g0 = 0, g = 0; g0 < nr; g0 += 64, ++g) {
-        H.grp_pos[H.bin_grp[b] + g] = at;
-        const int g1   = std::min(nr, g0 + 64);
-        const int kmax = off[r0 + order[g0] + 1] - off[r0 + order[g0]];
-        for (int k = 0; k < kmax; ++k)
-          for (int i = g0; i < g1; ++i) {
-            const int32_t r = r0 + order[i];
-            if (off[r + 1] - off[r] <= k) break;
-            H.pos[at++] = epos[off[r] + k - k0];
-          }
-      }
-    }
-  }, nnz);
-  H.grp_pos[H.bin_grp[B]] = (int32_t)nnz;
-  for (int i = 0; i < 128; ++i) H.pos[(size_t)nnz + i] = 0;
-  // P workgroups: every panel's entries in Q parts (pieces are not split)
-  const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
-  for (int s_ = 0; s_ < S; ++s_) {
-    const int64_t e0 = pstart[(size_t)s_ * B], e1 = pstart[(size_t)(s_ + 1) * B];
-    const int64_t per = std::max<int64_t>(G, ((e1 - e0 + Q - 1) / Q + G - 1) / G * G);
-    for (int64_t e = e0; e < e1; e += per) {
-      H.wg_e0.push_back((int32_t)e);
-      H.wg_panel.push_back(s_);
-    }
-  }
-  H.wg_e0.push_back((int32_t)total);
-  H.ok = true;
-  return H;
-}
-static int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h)
-{
-  if (!h.ok) return 0;
-  int32_t *piece_dst = nullptr, *wg_e0 = nullptr, *wg_panel = nullptr, *bin_row0 = nullptr, *bin_e0 = nullptr, *bin_grp = nullptr, *grp_pos = nullptr;
-  uint16_t *lidx = nullptr, *pos = nullptr;
-  uint32_t* sr = nullptr;
-  double* prod = nullptr;
-  TRY(upload_i32(c, &dst->perm, h.perm.get(), (size_t)h.np, 64));
-  TRY(upload_i32(c, &piece_dst, h.piece_dst.get(), (size_t)(h.np >> h.gshift), 64));
-  TRY(upload_i32(c, &wg_e0, h.wg_e0.data(), h.wg_e0.size()));
-  TRY(upload_i32(c, &wg_panel, h.wg_panel.data(), h.wg_panel.size()));
-  TRY(upload_i32(c, &bin_row0, h.bin_row0.data(), h.bin_row0.size()));
-  TRY(upload_i32(c, &bin_e0, h.bin_e0.data(), h.bin_e0.size()));
-  TRY(upload_i32(c, &bin_grp, h.bin_grp.data(), h.bin_grp.size()));
-  TRY(upload_i32(c, &grp_pos, h.grp_pos.data(), h.grp_pos.size()));
-  TRY(dev_alloc(c, &lidx, (size_t)h.np + 64));
-  HIP_TRY(hipMemcpyAsync(lidx, h.lidx.get(), (size_t)h.np * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &pos, (size_t)h.nnz + 128));
-  HIP_TRY(hipMemcpyAsync(pos, h.pos.get(), ((size_t)h.nnz + 128) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &sr, (size_t)h.rows + 64));
-  HIP_TRY(hipMemcpyAsync(sr, h.sr.get(), (size_t)h.rows * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &dst->val, (size_t)h.np + 64));
-  TRY(dev_alloc(c, &prod, (size_t)h.np + 256));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays die with the caller's PbHost
-  dst->v = PbView{h.rows, h.cols, h.S, h.B, h.gshift, h.panel_shift, (int)h.wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
-                  bin_row0, bin_e0, sr, bin_grp, grp_pos, pos, prod};
-  dst->np = h.np, dst->p_threads = h.p_threads, dst->pad = (double)h.np / (double)h.nnz;
-  dst->on = true;
-  return 0;
-}
 // the two launches of a gather-free SpMV: phase P with the gathered vector picked on the device (mode: see k_pb_products), ...
 static int pb_products(pdlpdev_ctx* c, const pdlpdev_ctx::Pb& L, const double* v0, const double* v1, int mode, int in_loop)
 {
@@ -1933,38 +1198,6 @@ static int pb_rows(pdlpdev_ctx* c, void (*kernel)(PbView, KArgs...), const pdlpd
   return 0;
 }
 
-static int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h, const int32_t* d_off, const int32_t* d_idx,
-                         const double* d_val)
-{
-  if (!h.ok) return 0;
-  int32_t *row0 = nullptr, *tile_ptr = nullptr, *col = nullptr;
-  uint16_t* rowptr = nullptr;
-  int64_t* rp_base = nullptr;
-  TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
-  TRY(upload_i32(c, &tile_ptr, h.tile_ptr.data(), h.tile_ptr.size()));
-  TRY(upload_i32(c, &col, h.col.get(), h.nnz));
-  TRY(upload_i32(c, &dst->perm, h.perm.get(), h.nnz));
-  TRY(dev_alloc(c, &rowptr, h.rowptr_size));
-  HIP_TRY(hipMemcpyAsync(rowptr, h.rowptr.get(), h.rowptr_size * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &rp_base, h.rp_base.size()));
-  HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &dst->val, h.nnz));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die with the caller's PanelHost
-  dst->v  = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
-  dst->v.seg = h.seg ? 1 : 0, dst->v.slab_w = h.slab_w;
-  dst->nent = (int64_t)h.nnz;
-  if (!h.own_row.empty()) {  // W becomes the number of workgroups / partials: the panels, then a workgroup per own row
-    int32_t *own_row = nullptr, *own_ptr = nullptr;
-    TRY(upload_i32(c, &own_row, h.own_row.data(), h.own_row.size()));
-    TRY(upload_i32(c, &own_ptr, h.own_ptr.data(), h.own_ptr.size()));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dst->v.NP = h.W, dst->v.W = h.W + (int)h.own_row.size();
-    dst->v.own_row = own_row, dst->v.own_ptr = own_ptr;
-    dst->v.csr_off = d_off, dst->v.csr_idx = d_idx, dst->v.csr_val = d_val;
-  }
-  dst->on = true;
-  return 0;
-}
 // panel values <- current CSR values (after upload and again after scale_problem)
 static int sync_panel_values(pdlpdev_ctx* c)
 {
@@ -1986,143 +1219,7 @@ static int sync_panel_values(pdlpdev_ctx* c)
   return 0;
 }
 
-// CUOPT_AMD_SPMV_LAYOUT=timed: both layouts of a matrix are timed on the device (plain SpMV, 1 warm-up + 3 launches each)
-// and the slower one is dropped.  This is how the structural rule of 'auto' (gather_working_set) was calibrated; it is
-// not the default because two close timings make the choice -- and with it the grouping of the reduction partials, the
-// step sizes and the iteration count -- differ from run to run.
-static int pick_layout(pdlpdev_ctx* c, pdlpdev_ctx::Panels* pn, int rows, int nb, const int32_t* rb, const int32_t* off,
-                       const int32_t* idx, const double* val, const double* vec, double* out, const char* name)
-{
-  if (!pn->on) return 0;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  float ms_stream = 1e30f, ms_panel = 1e30f;
-  for (int round = 0; round < 2; ++round)  // interleaved rounds, minimum per layout: robust to one-off stalls
-    for (int which = 0; which < 2; ++which) {
-      for (int rep = 0; rep < 4; ++rep) {
-        if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
-        if (which == 0)
-          k_spmv_plain<<<stream_grid(nb), kBlock, 0, c->stream>>>(nb, rb, off, idx, val, vec, out, (const double*)nullptr);
-        else
-          (pn->v.seg ? k_panel_plain<true> : k_panel_plain<false>)<<<pn->v.W, kPanelThreads, 0, c->stream>>>(pn->v, vec, out);
-      }
-      HIP_TRY(hipEventRecord(e1, c->stream));
-      HIP_TRY(hipEventSynchronize(e1));
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-      if (which == 0)
-        ms_stream = std::min(ms_stream, ms);
-      else
-        ms_panel = std::min(ms_panel, ms);
-    }
-  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
-  if (getenv("CUOPT_AMD_TIMING"))
-    fprintf(stderr, "[cuopt_amd setup]   layout %-3s: stream %.1f us, panels %.1f us -> %s\n", name, ms_stream * 1e3 / 3,
-            ms_panel * 1e3 / 3, ms_stream <= ms_panel ? "stream" : "panels");
-  if (ms_stream <= ms_panel) pn->on = false;
-  (void)rows;
-  return 0;
-}
 
-// ---- dense row segments: detection and the sparse remainder (host) -----------------------------------------------------------
-constexpr int kDenseMin = 256;  // consecutive columns of one row from which index-free storage is used
-struct DenseHost {
-  bool on = false;
-  std::vector<int32_t> row, row_seg, seg_row, seg_c0, seg_len, seg_ptr, tile_id, tile_ptr, tile_seg, tile_slot, perm;
-  std::vector<int32_t> s_off, s_idx, s_perm;     // A without the segments' entries (+ where each entry sits in the full CSR)
-  std::vector<int32_t> st_off, st_idx, st_perm;  // A^T likewise
-  std::vector<int32_t> first_seg;                // per row of A: first segment (seg_row ascending), -1 none
-  std::vector<int32_t> ch_seg, ch_k0, row_ch;    // chunks of <= kDenseChunk entries, per owning row
-  int64_t nent = 0;
-};
-static void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t* idx, DenseHost* D)
-{
-  const int64_t nnz = off[m];
-  for (int32_t r = 0; r < m; ++r) {
-    bool owner = false;
-    if (off[r + 1] - off[r] < kDenseMin) continue;  // (a 1e7-nonzero matrix of short rows: this scan was 8 ms of the set-up)
-    for (int k = off[r]; k < off[r + 1];) {
-      int e = k;
-      while (e + 1 < off[r + 1] && idx[e + 1] == idx[e] + 1) ++e;
-      const int len = e - k + 1;
-      if (len >= kDenseMin) {
-        if (!owner) {
-          D->row.push_back(r);
-          D->row_seg.push_back((int32_t)D->seg_row.size());
-          owner = true;
-        }
-        D->seg_row.push_back(r), D->seg_c0.push_back(idx[k]), D->seg_len.push_back(len), D->seg_ptr.push_back((int32_t)D->nent);
-        for (int q = k; q <= e; ++q) D->perm.push_back(q);
-        D->nent += len;
-      }
-      k = e + 1;
-    }
-  }
-  D->row_seg.push_back((int32_t)D->seg_row.size());
-  D->seg_ptr.push_back((int32_t)D->nent);
-  // worth a second code path only when the segments carry a visible share of the matrix
-  const int want = (int)cuopt_amd::tune_int("dense", -1);  // CUOPT_AMD_TUNE=dense=..: 0 off, 1 on whenever a segment exists, default: >= 2 % of the nonzeros
-  D->on = want != 0 && D->nent > 0 && (want == 1 || D->nent * 50 >= nnz) && D->seg_row.size() <= 65536;
-  if (!D->on) return;
-  for (size_t b = 0; b < D->row.size(); ++b) {
-    D->row_ch.push_back((int32_t)D->ch_seg.size());
-    for (int32_t q = D->row_seg[b]; q < D->row_seg[b + 1]; ++q)
-      for (int32_t k0 = 0; k0 < D->seg_len[q]; k0 += kDenseChunk) D->ch_seg.push_back(q), D->ch_k0.push_back(k0);
-  }
-  D->row_ch.push_back((int32_t)D->ch_seg.size());
-  // sparse remainder of A
-  D->first_seg.assign(m, -1);
-  for (size_t b = 0; b < D->row.size(); ++b) D->first_seg[D->row[b]] = D->row_seg[b];
-  D->s_off.assign((size_t)m + 1, 0);
-  D->s_idx.reserve((size_t)(nnz - D->nent)), D->s_perm.reserve((size_t)(nnz - D->nent));
-  auto covered = [&](int32_t r, int32_t c) {
-    const int32_t f = D->first_seg[r];
-    if (f < 0) return false;
-    for (int32_t q = f; q < (int32_t)D->seg_row.size() && D->seg_row[q] == r; ++q)
-      if (c >= D->seg_c0[q] && c < D->seg_c0[q] + D->seg_len[q]) return true;
-    return false;
-  };
-  for (int32_t r = 0; r < m; ++r) {
-    for (int k = off[r]; k < off[r + 1]; ++k)
-      if (!covered(r, idx[k])) D->s_idx.push_back(idx[k]), D->s_perm.push_back(k);
-    D->s_off[r + 1] = (int32_t)D->s_idx.size();
-  }
-  // 256-column tiles of A^T's side
-  const int ntiles_all = (n + kBlock - 1) / kBlock;
-  std::vector<int32_t> cnt(ntiles_all, 0);
-  for (size_t q = 0; q < D->seg_row.size(); ++q)
-    for (int t = D->seg_c0[q] / kBlock; t <= (D->seg_c0[q] + D->seg_len[q] - 1) / kBlock; ++t) cnt[t]++;
-  std::vector<int32_t>& slot = D->tile_slot;
-  slot.assign(ntiles_all, -1);
-  D->tile_ptr.push_back(0);
-  for (int t = 0; t < ntiles_all; ++t)
-    if (cnt[t]) {
-      slot[t] = (int32_t)D->tile_id.size();
-      D->tile_id.push_back(t);
-      D->tile_ptr.push_back(D->tile_ptr.back() + cnt[t]);
-    }
-  D->tile_seg.assign((size_t)D->tile_ptr.back(), 0);
-  std::vector<int32_t> cur(D->tile_ptr.begin(), D->tile_ptr.end() - 1);
-  for (size_t q = 0; q < D->seg_row.size(); ++q)  // segments in ascending row order: the order A^T's rows list them in
-    for (int t = D->seg_c0[q] / kBlock; t <= (D->seg_c0[q] + D->seg_len[q] - 1) / kBlock; ++t) D->tile_seg[cur[slot[t]]++] = (int32_t)q;
-}
-// the sparse remainder of A^T (entry (j, i) goes when row i of A holds column j in a segment)
-static void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const int32_t* t_off, const int32_t* t_idx)
-{
-  (void)Din;
-  D->st_off.assign((size_t)n + 1, 0);
-  for (int32_t j = 0; j < n; ++j) {
-    for (int k = t_off[j]; k < t_off[j + 1]; ++k) {
-      const int32_t r = t_idx[k], f = D->first_seg[r];
-      bool cov = false;
-      for (int32_t q = f; f >= 0 && q < (int32_t)D->seg_row.size() && D->seg_row[q] == r; ++q)
-        if (j >= D->seg_c0[q] && j < D->seg_c0[q] + D->seg_len[q]) { cov = true; break; }
-      if (!cov) D->st_idx.push_back(r), D->st_perm.push_back(k);
-    }
-    D->st_off[j + 1] = (int32_t)D->st_idx.size();
-  }
-}
 static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
 
 extern "C" {
