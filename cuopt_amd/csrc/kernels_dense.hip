@@ -68,6 +68,12 @@ void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t
   for (int32_t r = 0; r < m; ++r) {
     bool owner = false;
     if (off[r + 1] - off[r] < kDenseMin) continue;  // (a 1e7-nonzero matrix of short rows: this scan was 8 ms of the set-up)
+    // The C API neither sorts rows nor merges duplicates, and the sparse remainder is cut out by COLUMN RANGE below: a row whose
+    // indices are not strictly increasing (a stray duplicate of a column inside a run would vanish from both copies: round-3
+    // advisor) keeps all its entries in the sparse layouts.
+    bool canonical = true;
+    for (int k = off[r]; k + 1 < off[r + 1] && canonical; ++k) canonical = idx[k + 1] > idx[k];
+    if (!canonical) continue;
     for (int k = off[r]; k < off[r + 1];) {
       int e = k;
       while (e + 1 < off[r + 1] && idx[e + 1] == idx[e] + 1) ++e;

@@ -97,3 +97,33 @@ def test_scaling_still_sees_the_whole_matrix(lp):
     np.testing.assert_allclose(dev.download("DROW", p["m"]), dr, rtol=1e-12)  # (long rows: fixed-tree norms)
     np.testing.assert_allclose(dev.download("DCOL", p["n"]), dc, rtol=1e-12)
     dev.close()
+
+
+def test_a_row_with_a_duplicate_inside_a_run_keeps_every_entry(monkeypatch):
+    """round-3 advisor: the C API does not canonicalise rows; a duplicate of a column INSIDE a run of consecutive columns must not
+    vanish from the hot-loop matrix (the row then stays out of the index-free storage altogether)"""
+    n, m = 3000, 40
+    rng = np.random.default_rng(3)
+    rows_idx, rows_val = [], []
+    for r in range(m):
+        if r == 7:
+            cols = np.concatenate([[5], np.arange(0, 301)])  # stray duplicate of column 5 in front of the run 0..300
+        elif r == 9:
+            cols = np.arange(100, 500)  # a clean run: index-free
+        else:
+            cols = np.sort(rng.choice(n, size=6, replace=False))
+        rows_idx.append(cols)
+        rows_val.append(rng.standard_normal(len(cols)))
+    off = np.concatenate([[0], np.cumsum([len(c) for c in rows_idx])]).astype(np.int32)
+    p = dict(m=m, n=n, offsets=off, indices=np.concatenate(rows_idx).astype(np.int32), values=np.concatenate(rows_val), c=rng.standard_normal(n),
+             lo=np.full(m, -np.inf), hi=np.full(m, 50.0), lb=np.zeros(n), ub=np.full(n, 3.0), maximize=False, objective_offset=0.0)
+    monkeypatch.setenv("CUOPT_AMD_SMALL", "0")
+    dev = capi.Device(p)
+    info = dev.dense_info()
+    assert info["on"] and info["segments"] == 1, info  # row 9 only
+    x = rng.standard_normal(n)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(m, n))  # (scipy adds duplicates up: what the LP means)
+    np.testing.assert_allclose(dev.spmv(x, False, m), A @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dev.spmv(rng.standard_normal(m) * 0 + 1.0, True, n), A.T @ np.ones(m), rtol=1e-12, atol=1e-12)
+    dev.close()
