@@ -112,3 +112,20 @@ def test_solve_to_tolerance_through_the_long_tail_panels(monkeypatch):
     r = capi.solve(p, method=1, tol=1e-6)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+
+
+def test_sharded_solve_through_the_long_tail_panels(monkeypatch):
+    """the row blocks and the column blocks of a sharded solve (owner-computes dataflow, in-process communicator) through panels
+    whose row sums are dealt by nonzero: same optimum as one GPU.  (The peer transport needs a process of its own -- hardware queues
+    are fixed at HIP start-up: tests/test_p2p_transport_gpu.py)"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", "owner")
+    monkeypatch.setenv("CUOPT_AMD_SHARD_TRANSPORT", "collective")
+    set_tune(monkeypatch, panel_seg=1, slab_bytes=32 * 1024, soft_communicator=1)
+    p = synthetic.generate_structured("powerlaw", m=40000, n=40000, k=8, seed=9)
+    single = capi.solve(p, method=1, tol=1e-6)
+    r = capi.solve(p, method=1, tol=1e-6, amd_num_gpus=3)
+    assert r["status"] == "Optimal" and r["gpus"] == 3
+    scale = 1 + abs(p["objective_star"])
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * scale
+    assert abs(r["objective"] - single["objective"]) <= 2e-5 * scale
