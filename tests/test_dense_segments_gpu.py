@@ -1,6 +1,6 @@
 """GPU: dense row segments (runs of >= 256 consecutive columns inside a row) are stored index-free and multiplied by two
 streaming kernels of their own; every layout then works on the sparse remainder and adds their share ahead of its epilogue
-(pdlp_device.hip "dense").  Rows / columns a segment touches are compared at the long-row tolerance (their sums are split in
+(kernels_dense.hip; folded into the panel kernels where panels are the layout: spmv_panel.hpp).  Rows / columns a segment touches are compared at the long-row tolerance (their sums are split in
 two), everything else stays bit-identical to the oracle."""
 import numpy as np
 import pytest

@@ -1,4 +1,4 @@
-"""GPU: the gather-free SpMV layout ("pb", pdlp_kernels.hpp): several source panels and bins, both piece sizes, both panel
+"""GPU: the gather-free SpMV layout ("pb", spmv_pb.hpp): several source panels and bins, both piece sizes, both panel
 widths, the automatic choice for gathered vectors beyond the panels' 16 slabs, a full solve."""
 import numpy as np
 import pytest

@@ -1,5 +1,5 @@
-"""GPU: the long-tail variant of the slab-major panels (pdlp_kernels.hpp: panel_seg_block) -- row sums dealt by NONZERO (lane-major
-chunks, a segmented scan over the wave, wave aggregates per chunk) instead of by row.  Its contract is the one every layout has for
+"""GPU: the long-tail variant of the slab-major panels (spmv_panel.hpp: panel_seg_block) -- row sums dealt by NONZERO (per round a
+segmented scan over the wave's 64 consecutive entries, edge runs joined by wave 0 once per chunk) instead of by row.  Its contract is the one every layout has for
 rows of more than 128 nonzeros: EVERY row within rtol 1e-12 of the oracle's left-to-right CSR sum (the additions of a row are a
 fixed tree, run-to-run reproducible, but no longer sequential across lanes), and the PDLP decisions of the row-per-lane panels over
 the first major iterations.  `auto` takes it only where more than 2 % of the nonzeros sit in rows of more than 128 entries."""
