@@ -6,7 +6,7 @@
 //     min c.x   s.t.  A x - s = 0,   lb <= x <= ub,   lo <= s <= hi
 // The basis is kept as a SPARSE LU factorisation (singleton columns and rows peeled off, the nucleus right-looking with
 // Markowitz' pivot choice under threshold partial pivoting; a dependent column is replaced by the slack of a row that found
-// no pivot) with product-form updates behind it, refactorised when the update file has cost as much as a factorisation, at
+// no pivot) with middle-product-form updates between L and U (spike and row of U^-1: see ftran), refactorised when the update file has cost as much as a factorisation, at
 // the latest every 100 pivots (250 on large bases).  FTRAN / BTRAN start from the right-hand side's nonzeros (a depth-first
 // reach over the factors, kept by columns and by rows) and fall back to dense loops when the reach is large; the pivot row is
 // formed from the ROWS of A (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
@@ -69,9 +69,6 @@ struct Simplex {
   std::vector<int> vis, sstack, sptr, order;  // depth-first searches of the sparse solves
   int vstamp       = 0;
   int sparse_solve = 1;  // 0: always the dense loops (CUOPT_AMD_SIMPLEX_SOLVES=dense), 2: always the sparse ones, 1: by the size of the reach
-  // product-form updates: position Er[e], pivot Ew[e], the other entries of the entering column in Ep/Ei/Ex
-  std::vector<int> Ep, Ei, Er;
-  std::vector<double> Ex, Ew;
   // work space
   std::vector<double> wx;
   std::vector<int> inpat, pattern, mark, topo, dstack, dptr, rowcnt;
@@ -170,7 +167,7 @@ struct Simplex {
     pinv.assign(m, -1), prow.assign(m, -1);
     Lp.assign(1, 0), Up.assign(1, 0);
     Li.clear(), Lx.clear(), Ui.clear(), Ux.clear(), Ud.clear();
-    Ep.assign(1, 0), Ei.clear(), Ex.clear(), Er.clear(), Ew.clear();
+    clear_updates();
     wx.assign(m, 0.0), inpat.assign(m, -1), mark.assign(m, -1);
     std::vector<int> nb;
     nb.reserve(m);
@@ -446,11 +443,58 @@ struct Simplex {
     }
     return true;  // `order` is a postorder: reversed, every pivot comes before the ones it points to
   }
+  // ---- updates between two factorisations: the MIDDLE product form.  B = L M_1 ... M_K U with M_k = I + v_k e~_k^T,
+  //      v_k = (L M_1 ... M_(k-1))^-1 a_q - U e_p  (the entering column after the L solve -- the "spike" -- minus the column of U it
+  //      replaces) and e~_k = U^-T e_p (row p of U^-1): both fall out of the pivot's own solves half way (the spike before FTRAN's U
+  //      stage, e~ behind BTRAN's U^T stage), and both are far sparser than the fully transformed column B^-1 a_q the plain product
+  //      form stores (10 000-row block-angular LP: ~300 + ~1000 entries against ~8000 per pivot) -- every solve walks the whole update
+  //      file, so that is what a pivot costs.  M_k^-1 x = x - v_k (e~_k . x) / w_p, w_p = e~_k . spike = the pivot element.  L and U never
+  //      change.  Vectors are kept by ROW (position k <-> row prow[k]).
+  std::vector<int> Mvp, Mvi, Mep, Mei;
+  std::vector<double> Mvx, Mex, Mw;
+  std::vector<int> spike_i, et_i, rmark, plist;   // what the last FTRAN (keep = true) / BTRAN left half way, row marks of the sparse stages
+  std::vector<double> spike_x, et_x, scr;
+  int rstamp = 0;
+  size_t update_entries() const { return Mvi.size() + Mei.size(); }
+  void clear_updates() { Mvp.assign(1, 0), Mep.assign(1, 0), Mvi.clear(), Mvx.clear(), Mei.clear(), Mex.clear(), Mw.clear(); }
+  // x (by ROW) <- M_K^-1 ... M_1^-1 x; with `track` the rows that become nonzero are appended to plist (marked with rstamp)
+  void apply_updates_forward(std::vector<double>& x, bool track)
+  {
+    const int nu = (int)Mw.size();
+    for (int e = 0; e < nu; ++e) {
+      double dot = 0.0;
+      for (int q = Mep[e]; q < Mep[e + 1]; ++q) dot += Mex[q] * x[Mei[q]];
+      if (dot == 0.0) continue;
+      const double t = dot / Mw[e];
+      for (int q = Mvp[e]; q < Mvp[e + 1]; ++q) {
+        const int i = Mvi[q];
+        if (track && rmark[i] != rstamp) rmark[i] = rstamp, plist.push_back(i);
+        x[i] -= Mvx[q] * t;
+      }
+    }
+  }
+  // t (by POSITION) <- M_1^-T ... M_K^-T t; with `track` the positions that become nonzero are appended to plist
+  void apply_updates_backward(std::vector<double>& t, bool track)
+  {
+    for (int e = (int)Mw.size() - 1; e >= 0; --e) {
+      double dot = 0.0;
+      for (int q = Mvp[e]; q < Mvp[e + 1]; ++q) dot += Mvx[q] * t[pinv[Mvi[q]]];
+      if (dot == 0.0) continue;
+      const double s = dot / Mw[e];
+      for (int q = Mep[e]; q < Mep[e + 1]; ++q) {
+        const int k = pinv[Mei[q]];
+        if (track && rmark[k] != rstamp) rmark[k] = rstamp, plist.push_back(k);
+        t[k] -= Mex[q] * s;
+      }
+    }
+  }
   // w = B^-1 a.  x holds a by ROW with its nonzero rows in xrows; on return x is all zero, w (by POSITION, zero on entry) holds the
-  // result with its nonzero positions in wlist.
-  void ftran(std::vector<double>& x, const std::vector<int>& xrows, std::vector<double>& w, std::vector<int>& wlist)
+  // result with its nonzero positions in wlist.  keep: the vector between the update stage and the U stage (the spike of an entering
+  // column) is copied to spike_i / spike_x.
+  void ftran(std::vector<double>& x, const std::vector<int>& xrows, std::vector<double>& w, std::vector<int>& wlist, bool keep = false)
   {
     wlist.clear();
+    if ((int)rmark.size() != m) rmark.assign(m, 0), scr.assign(m, 0.0);
     std::vector<int>& seed = seed_buf;
     seed.clear();
     for (int r : xrows) seed.push_back(pinv[r]);
@@ -460,120 +504,158 @@ struct Simplex {
         if (vis[nx] != vstamp) { child = nx; return; }
       }
     });
+    // ---- L
     if (sparse) {
       lorder.assign(order.rbegin(), order.rend());
-      // the pivots U reaches from there
-      sparse = reach(lorder, [&](int k, int& ptr, int& child) {
+      for (int k : lorder) {
+        const double xj = x[prow[k]];
+        if (xj == 0.0) continue;
+        for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
+      }
+      ++rstamp;
+      plist.clear();
+      for (int k : lorder) rmark[prow[k]] = rstamp, plist.push_back(prow[k]);
+    } else {
+      for (int k = 0; k < m; ++k) {
+        const double xj = x[prow[k]];
+        if (xj == 0.0) continue;
+        for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
+      }
+    }
+    // ---- the updates
+    if (!Mw.empty()) apply_updates_forward(x, sparse);
+    if (keep) {
+      spike_i.clear(), spike_x.clear();
+      if (sparse) {
+        for (int i : plist)
+          if (x[i] != 0.0) spike_i.push_back(i), spike_x.push_back(x[i]);
+      } else {
+        for (int i = 0; i < m; ++i)
+          if (x[i] != 0.0) spike_i.push_back(i), spike_x.push_back(x[i]);
+      }
+    }
+    // ---- U
+    if (sparse) {
+      seed.clear();
+      for (int i : plist)
+        if (x[i] != 0.0) seed.push_back(pinv[i]);
+      sparse = reach(seed, [&](int k, int& ptr, int& child) {
         while (Up[k] + ptr < Up[k + 1]) {
           const int nx = Ui[Up[k] + ptr++];
           if (vis[nx] != vstamp) { child = nx; return; }
         }
       });
-    }
-    if (!sparse) {
-      ftran_dense(x, w);
-      std::fill(x.begin(), x.end(), 0.0);
-      for (int k = 0; k < m; ++k)
-        if (w[k] != 0.0) wlist.push_back(k);
-      return;
-    }
-    for (int k : lorder) {
-      const double xj = x[prow[k]];
-      if (xj == 0.0) continue;
-      for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
-    }
-    for (size_t t = order.size(); t-- > 0;) {
-      const int k = order[t];
-      double v    = x[prow[k]];
-      x[prow[k]]  = 0.0;
-      if (v == 0.0) continue;
-      v /= Ud[k];
-      for (int e = Up[k]; e < Up[k + 1]; ++e) x[prow[Ui[e]]] -= Ux[e] * v;
-      w[k] = v;
-      wlist.push_back(k);
-    }
-    const int ne = (int)Er.size();
-    if (ne) {
-      const int st = ++vstamp;
-      for (int k : wlist) vis[k] = st;
-      for (int e = 0; e < ne; ++e) {
-        const double xr = w[Er[e]];
-        if (xr == 0.0) continue;
-        const double t = xr / Ew[e];
-        for (int q = Ep[e]; q < Ep[e + 1]; ++q) {
-          const int i = Ei[q];
-          if (vis[i] != st) vis[i] = st, wlist.push_back(i);
-          w[i] -= Ex[q] * t;
+      if (sparse) {
+        for (size_t t = order.size(); t-- > 0;) {
+          const int k = order[t];
+          double v    = x[prow[k]];
+          x[prow[k]]  = 0.0;
+          if (v == 0.0) continue;
+          v /= Ud[k];
+          for (int e = Up[k]; e < Up[k + 1]; ++e) x[prow[Ui[e]]] -= Ux[e] * v;
+          w[k] = v;
+          wlist.push_back(k);
         }
-        w[Er[e]] = t;
+        for (int i : plist) x[i] = 0.0;  // (rows the L stage / the updates touched that cancelled to a value the U stage never met)
+        return;
       }
     }
+    for (int k = m - 1; k >= 0; --k) {
+      double v = x[prow[k]];
+      if (v != 0.0) {
+        v /= Ud[k];
+        for (int e = Up[k]; e < Up[k + 1]; ++e) x[prow[Ui[e]]] -= Ux[e] * v;
+        w[k] = v;
+        wlist.push_back(k);
+      }
+    }
+    std::fill(x.begin(), x.end(), 0.0);
   }
   // rho = B^-T t.  t by POSITION with its nonzero positions in tlist; on return t is all zero, rho (by ROW, zero on entry) holds the
-  // result with its nonzero rows in rlist.
+  // result with its nonzero rows in rlist.  The vector behind the U^T stage (row p of U^-1 when t = e_p) is copied to et_i / et_x.
   void btran(std::vector<double>& t, std::vector<int>& tlist, std::vector<double>& rho, std::vector<int>& rlist)
   {
     rlist.clear();
-    if (!Er.empty()) {
-      const int st = ++vstamp;
-      for (int k : tlist) vis[k] = st;
-      for (int e = (int)Er.size() - 1; e >= 0; --e) {
-        double sum = t[Er[e]];
-        for (int q = Ep[e]; q < Ep[e + 1]; ++q) sum -= t[Ei[q]] * Ex[q];
-        sum /= Ew[e];
-        if (sum != 0.0 && vis[Er[e]] != st) vis[Er[e]] = st, tlist.push_back(Er[e]);
-        t[Er[e]] = sum;
-      }
-    }
+    if ((int)rmark.size() != m) rmark.assign(m, 0), scr.assign(m, 0.0);
     bool sparse = reach(tlist, [&](int k, int& ptr, int& child) {
       while (URp[k] + ptr < URp[k + 1]) {
         const int nx = URi[URp[k] + ptr++];
         if (vis[nx] != vstamp) { child = nx; return; }
       }
     });
+    // ---- U^T
+    et_i.clear(), et_x.clear();
     if (sparse) {
       lorder.assign(order.rbegin(), order.rend());
-      sparse = reach(lorder, [&](int k, int& ptr, int& child) {
+      for (int j : lorder) {  // by the rows of U
+        double sv = t[j];
+        if (sv == 0.0) continue;
+        sv /= Ud[j];
+        t[j] = sv;
+        for (int e = URp[j]; e < URp[j + 1]; ++e) t[URi[e]] -= URx[e] * sv;
+      }
+      ++rstamp;
+      plist.clear();
+      for (int j : lorder) {
+        rmark[j] = rstamp, plist.push_back(j);
+        if (t[j] != 0.0) et_i.push_back(prow[j]), et_x.push_back(t[j]);
+      }
+    } else {
+      for (int k = 0; k < m; ++k) {
+        double sv = t[k];
+        for (int e = Up[k]; e < Up[k + 1]; ++e) sv -= Ux[e] * t[Ui[e]];
+        t[k] = sv / Ud[k];
+        if (t[k] != 0.0) et_i.push_back(prow[k]), et_x.push_back(t[k]);
+      }
+    }
+    // ---- the updates, last one first
+    if (!Mw.empty()) apply_updates_backward(t, sparse);
+    // ---- L^T
+    if (sparse) {
+      std::vector<int>& seed = seed_buf;
+      seed.clear();
+      for (int k : plist)
+        if (t[k] != 0.0) seed.push_back(k);
+      sparse = reach(seed, [&](int k, int& ptr, int& child) {
         while (LRp[k] + ptr < LRp[k + 1]) {
           const int nx = LRi[LRp[k] + ptr++];
           if (vis[nx] != vstamp) { child = nx; return; }
         }
       });
+      if (sparse) {
+        for (size_t q = order.size(); q-- > 0;) {  // by the rows of L
+          const int kk   = order[q];
+          const double v = t[kk];
+          t[kk]          = 0.0;
+          if (v == 0.0) continue;
+          rho[prow[kk]] = v;
+          rlist.push_back(prow[kk]);
+          for (int e = LRp[kk]; e < LRp[kk + 1]; ++e) t[LRi[e]] -= LRx[e] * v;
+        }
+        for (int k : plist) t[k] = 0.0;
+        return;
+      }
     }
-    if (!sparse) {
-      btran_dense_core(t, rho);
-      std::fill(t.begin(), t.end(), 0.0);
-      for (int i = 0; i < m; ++i)
-        if (rho[i] != 0.0) rlist.push_back(i);
-      return;
+    for (int k = m - 1; k >= 0; --k) {
+      double sv = t[k];
+      for (int e = Lp[k]; e < Lp[k + 1]; ++e) sv -= Lx[e] * rho[Li[e]];
+      rho[prow[k]] = sv;
     }
-    for (int j : lorder) {  // U^T s = t, by the rows of U
-      double sv = t[j];
-      if (sv == 0.0) continue;
-      sv /= Ud[j];
-      t[j] = sv;
-      for (int e = URp[j]; e < URp[j + 1]; ++e) t[URi[e]] -= URx[e] * sv;
-    }
-    for (size_t q = order.size(); q-- > 0;) {  // L^T v = s, by the rows of L
-      const int kk   = order[q];
-      const double v = t[kk];
-      t[kk]          = 0.0;
-      if (v == 0.0) continue;
-      rho[prow[kk]] = v;
-      rlist.push_back(prow[kk]);
-      for (int e = LRp[kk]; e < LRp[kk + 1]; ++e) t[LRi[e]] -= LRx[e] * v;
-    }
+    std::fill(t.begin(), t.end(), 0.0);
+    for (int i = 0; i < m; ++i)
+      if (rho[i] != 0.0) rlist.push_back(i);
   }
   std::vector<int> seed_buf, lorder;
   bool debug = false;
   // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
-  void ftran_dense(std::vector<double>& x, std::vector<double>& w) const
+  void ftran_dense(std::vector<double>& x, std::vector<double>& w)
   {
     for (int k = 0; k < m; ++k) {
       const double xj = x[prow[k]];
       if (xj == 0.0) continue;
       for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
     }
+    if (!Mw.empty()) apply_updates_forward(x, false);
     for (int k = m - 1; k >= 0; --k) {
       double v = x[prow[k]];
       if (v != 0.0) {
@@ -582,44 +664,44 @@ struct Simplex {
       }
       w[k] = v;
     }
-    const int ne = (int)Er.size();
-    for (int e = 0; e < ne; ++e) {
-      const double xr = w[Er[e]];
-      if (xr == 0.0) continue;
-      const double t = xr / Ew[e];
-      for (int q = Ep[e]; q < Ep[e + 1]; ++q) w[Ei[q]] -= Ex[q] * t;
-      w[Er[e]] = t;
-    }
   }
   // rho = B^-T t : `t` by POSITION (destroyed), rho by ROW
-  // (the update file first, then the factors)
-  void btran_dense(std::vector<double>& t, std::vector<double>& rho) const
-  {
-    for (int e = (int)Er.size() - 1; e >= 0; --e) {
-      double s = t[Er[e]];
-      for (int q = Ep[e]; q < Ep[e + 1]; ++q) s -= t[Ei[q]] * Ex[q];
-      t[Er[e]] = s / Ew[e];
-    }
-    btran_dense_core(t, rho);
-  }
-  void btran_dense_core(std::vector<double>& t, std::vector<double>& rho) const
+  void btran_dense(std::vector<double>& t, std::vector<double>& rho)
   {
     for (int k = 0; k < m; ++k) {
-      double s = t[k];
-      for (int e = Up[k]; e < Up[k + 1]; ++e) s -= Ux[e] * t[Ui[e]];
-      t[k] = s / Ud[k];
+      double sv = t[k];
+      for (int e = Up[k]; e < Up[k + 1]; ++e) sv -= Ux[e] * t[Ui[e]];
+      t[k] = sv / Ud[k];
     }
+    if (!Mw.empty()) apply_updates_backward(t, false);
     for (int k = m - 1; k >= 0; --k) {
-      double s = t[k];
-      for (int e = Lp[k]; e < Lp[k + 1]; ++e) s -= Lx[e] * rho[Li[e]];
-      rho[prow[k]] = s;
+      double sv = t[k];
+      for (int e = Lp[k]; e < Lp[k + 1]; ++e) sv -= Lx[e] * rho[Li[e]];
+      rho[prow[k]] = sv;
     }
   }
-  void push_eta(int r, const std::vector<double>& w, const std::vector<int>& wlist)
+  // the pivot at position r: the last FTRAN with keep = true left the entering column's spike, the last BTRAN (of e_r) row r of U^-1
+  void push_update(int r, double pivot)
   {
-    for (int i : wlist)
-      if (i != r && w[i] != 0.0) Ei.push_back(i), Ex.push_back(w[i]);
-    Ep.push_back((int)Ei.size()), Er.push_back(r), Ew.push_back(w[r]);
+    // v = spike - U e_r
+    for (size_t q = 0; q < spike_i.size(); ++q) scr[spike_i[q]] = spike_x[q];
+    ++rstamp;
+    plist.clear();
+    for (int i : spike_i) rmark[i] = rstamp, plist.push_back(i);
+    auto sub = [&](int row, double v) {
+      if (rmark[row] != rstamp) rmark[row] = rstamp, plist.push_back(row);
+      scr[row] -= v;
+    };
+    for (int e = Up[r]; e < Up[r + 1]; ++e) sub(prow[Ui[e]], Ux[e]);
+    sub(prow[r], Ud[r]);
+    for (int i : plist) {
+      if (scr[i] != 0.0) Mvi.push_back(i), Mvx.push_back(scr[i]);
+      scr[i] = 0.0;
+    }
+    Mvp.push_back((int)Mvi.size());
+    Mei.insert(Mei.end(), et_i.begin(), et_i.end()), Mex.insert(Mex.end(), et_x.begin(), et_x.end());
+    Mep.push_back((int)Mei.size());
+    Mw.push_back(pivot);
   }
   // debug: || B w - a || and || B^T rho - t || for one right-hand side each
   void check_factor(const char* where)
@@ -680,7 +762,7 @@ struct Simplex {
   {
     const auto t_in = std::chrono::steady_clock::now();
     std::vector<int> rejected, cand(basic);
-    const size_t eta_entries = Ei.size();
+    const size_t eta_entries = update_entries();
     factor(cand, &rejected);
     if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(), ops_factor += factor_ops;
     for (int j : rejected) {  // left the basis: onto the nearer bound
@@ -881,7 +963,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     if (q >= n) col[q - n] = -1.0, clist.push_back(q - n);
     else
       for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k], clist.push_back(S.ci[k]);
-    { Lap lap(S, 4); S.ftran(col, clist, w, wlist); }
+    { Lap lap(S, 4); S.ftran(col, clist, w, wlist, true); }
     if (std::fabs(w[r]) < 1e-11 || std::fabs(w[r] - alpha[q]) > 1e-6 * (1.0 + std::fabs(alpha[q]))) {
       // the factorisation has drifted: rebuild it and look again
       if (since_refactor == 0) return 7;
@@ -918,7 +1000,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     S.z[q] += step;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_eta(r, w, wlist);
+    S.push_update(r, w[r]);
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
     for (int i : wlist)
       if (w[i] != 0.0 && i != r) S.z[S.basic[i]] -= w[i] * step, pinf[i] = infeasibility(i), note(i);
@@ -926,8 +1008,8 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     S.iterations += 1;
     // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
     // after kRefactorEvery pivots
-    extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.Ei.size();
-    if (S.debug) S.ops_solve += (S.steepest ? 3 : 2) * ((int64_t)S.Ei.size() + (int64_t)S.Li.size() + (int64_t)S.Ui.size() + 2 * (int64_t)m);
+    extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.update_entries();
+    if (S.debug) S.ops_solve += (S.steepest ? 3 : 2) * ((int64_t)S.update_entries() + (int64_t)S.Li.size() + (int64_t)S.Ui.size() + 2 * (int64_t)m);
     // (the factorisation's count is of entries touched; its depth-first searches and pivot choices make an entry cost ~8 times
     // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s)
     const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
@@ -989,7 +1071,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     if (q >= n) col[q - n] = -1.0, clist.push_back(q - n);
     else
       for (int k = S.cp[q]; k < S.cp[q + 1]; ++k) col[S.ci[k]] += S.cv[k], clist.push_back(S.ci[k]);
-    S.ftran(col, clist, w, wlist);
+    S.ftran(col, clist, w, wlist, true);
     // ratio test: basic i moves by -dir t w_i
     double wmax = 0.0;
     for (int i : wlist) wmax = std::max(wmax, std::fabs(w[i]));
@@ -1060,10 +1142,10 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     const bool to_low = dir * w[r] > 0.0;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_eta(r, w, wlist);
+    S.push_update(r, w[r]);
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
     S.iterations += 1;
-    extra_ops += 2 * (int64_t)S.Ei.size();
+    extra_ops += 2 * (int64_t)S.update_entries();
     const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
     if (++since_refactor >= kRefactorEvery || extra_ops >= rebuild_ops) {
       S.rebuild_plain();
