@@ -335,6 +335,26 @@ struct pdlpdev_ctx {
   } pba, pbat;
   // problem vectors: scaled working copies and the unscaled originals
   double *c = nullptr, *lb = nullptr, *ub = nullptr, *lo = nullptr, *hi = nullptr;
+  // all lower (upper) bounds are the same 0 or infinity: k_primal takes the constant instead of streaming the array
+  struct UniformBounds {
+    int lb_same = 0, ub_same = 0;
+    double lb = 0.0, ub = 0.0;
+  } ubd;
+  void note_uniform_bounds(const double* lb_host, const double* ub_host)  // (null: that side is unchanged)
+  {
+    auto same = [&](const double* v, int* flag, double* value) {
+      if (!v) return;
+      *flag = 0;
+      if (n <= 0) return;
+      const double v0 = v[0];
+      if (!(v0 == 0.0 || std::isinf(v0))) return;
+      for (int32_t j = 1; j < n; ++j)
+        if (v[j] != v0) return;
+      *flag = 1, *value = v0;
+    };
+    same(lb_host, &ubd.lb_same, &ubd.lb);
+    same(ub_host, &ubd.ub_same, &ubd.ub);
+  }
   double *c_u = nullptr, *lb_u = nullptr, *ub_u = nullptr, *lo_u = nullptr, *hi_u = nullptr;
   double *dr = nullptr, *dc = nullptr;
   bool scaled = false;

@@ -291,8 +291,10 @@ __global__ void __launch_bounds__(kBlock)
 k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, double* __restrict__ x1,
          const double* __restrict__ aty0, const double* __restrict__ aty1,
          const double* __restrict__ c, const double* __restrict__ lb, const double* __restrict__ ub,
-         double* __restrict__ xbar, double* __restrict__ sumx, const p2pdev::Push* __restrict__ push)
+         double* __restrict__ xbar, double* __restrict__ sumx, const p2pdev::Push* __restrict__ push, pdlpdev_ctx::UniformBounds ubd)
 {
+  // (ubd: every lower / upper bound is the same 0 or infinity -- x >= 0 is the usual LP -- so the bound arrays, 16 of the kernel's
+  //  72 bytes per column, are not read at all; scaling keeps 0 and infinity what they are)
   if (!loop_active(ctl)) return;
   const int cur       = ctl->cur;
   const double tau    = ctl->tau;
@@ -305,7 +307,7 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
     const double xj       = x[j];
     const double gradient = c[j] - aty[j];
     double next           = xj - (tau * gradient);
-    next                  = dmax(dmin(next, ub[j]), lb[j]);
+    next                  = dmax(dmin(next, ubd.ub_same ? ubd.ub : ub[j]), ubd.lb_same ? ubd.lb : lb[j]);
     xn[j]                 = next;
     const double xb       = next - xj + next;
     xbar[j]               = xb;
@@ -1358,6 +1360,7 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   TRY(upload_f64(ctx, &ctx->c, c, n)); TRY(upload_f64(ctx, &ctx->c_u, c, n));
   TRY(upload_f64(ctx, &ctx->lb, lb, n)); TRY(upload_f64(ctx, &ctx->lb_u, lb, n));
   TRY(upload_f64(ctx, &ctx->ub, ub, n)); TRY(upload_f64(ctx, &ctx->ub_u, ub, n));
+  ctx->note_uniform_bounds(lb, ub);
   TRY(upload_f64(ctx, &ctx->lo, lo, m)); TRY(upload_f64(ctx, &ctx->lo_u, lo, m));
   TRY(upload_f64(ctx, &ctx->hi, hi, m)); TRY(upload_f64(ctx, &ctx->hi_u, hi, m));
   TRY(dev_alloc(ctx, &ctx->dr, m)); TRY(dev_alloc(ctx, &ctx->dc, n));
@@ -1822,6 +1825,16 @@ int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const do
   };
   TRY(put(lb, ctx->lb_u, ctx->lb, nb));
   TRY(put(ub, ctx->ub_u, ctx->ub, nb));
+  {
+    const pdlpdev_ctx::UniformBounds before = ctx->ubd;
+    ctx->note_uniform_bounds(lb, ub);
+    const pdlpdev_ctx::UniformBounds& now = ctx->ubd;
+    if (before.lb_same != now.lb_same || before.ub_same != now.ub_same || (now.lb_same && before.lb != now.lb) || (now.ub_same && before.ub != now.ub)) {
+      // the attempt graphs carry k_primal's arguments by value: captured again on the next run
+      for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+      ctx->graphs.clear();
+    }
+  }
   TRY(put(lo, ctx->lo_u, ctx->lo, mb));
   TRY(put(hi, ctx->hi_u, ctx->hi, mb));
   if (lb || ub || lo || hi)
@@ -2161,7 +2174,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     const size_t cs = (size_t)ctx->rank * ctx->slice;
     const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
     launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
-             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, ctx->p2p.on ? ctx->p2p.push_dev : (const p2pdev::Push*)nullptr);
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, ctx->p2p.on ? ctx->p2p.push_dev : (const p2pdev::Push*)nullptr, ctx->ubd);
     LAUNCH_CHECK();
     if (ctx->p2p.on) {
       // direct peer stores + epoch flags instead of collectives: the producing kernels (the primal step above, the dual step,
@@ -2205,7 +2218,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     const size_t cs = (size_t)ctx->rank * ctx->slice;
     const int len   = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->slice, (int64_t)n - (int64_t)cs));
     launch_k(ctx, k_primal, grid_for(len), kBlock, 0, len, ctx->ctl, ctx->x[0] + cs, ctx->x[1] + cs, ctx->aty[0] + cs, ctx->aty[1] + cs,
-             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, (const p2pdev::Push*)nullptr);
+             ctx->c + cs, ctx->lb + cs, ctx->ub + cs, ctx->xbar + cs, ctx->sumx + cs, (const p2pdev::Push*)nullptr, ctx->ubd);
     LAUNCH_CHECK();
     TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
     launch_a_dual(ctx);
@@ -2221,7 +2234,7 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
     LAUNCH_CHECK();
     return 0;
   }
-  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+  launch_k(ctx, k_primal, grid_for(n), kBlock, 0, n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr, ctx->ubd);
   launch_a_dual(ctx);
   if (!ctx->comm) {
     launch_at_step(ctx);
@@ -2802,6 +2815,14 @@ int64_t pdlpdev_upload(pdlpdev_ctx* ctx, int id, const void* host, int64_t eleme
     return -1;
   }
   count = std::min(count, elements);
+  if ((id == PDLPDEV_BUF_LB && ctx->ubd.lb_same) || (id == PDLPDEV_BUF_UB && ctx->ubd.ub_same)) {
+    // bounds written behind the solver's back: the arrays are read again (and the attempt graphs, which carry the flags by value,
+    // are captured again)
+    if (id == PDLPDEV_BUF_LB) ctx->ubd.lb_same = 0;
+    else ctx->ubd.ub_same = 0;
+    for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+    ctx->graphs.clear();
+  }
   if (count > 0) {
     if (hipMemcpyAsync(dst, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return -2;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -2;
@@ -2856,7 +2877,7 @@ int pdlpdev_time_kernel(pdlpdev_ctx* ctx, int kernel_id, int reps, double* avg_m
   auto one = [&]() {
     switch (kernel_id) {
       case PDLPDEV_K_PRIMAL:
-        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr);
+        launch_k(ctx, k_primal, grid_for(ctx->n), kBlock, 0, ctx->n, ctx->ctl, ctx->x[0], ctx->x[1], ctx->aty[0], ctx->aty[1], ctx->c, ctx->lb, ctx->ub, ctx->xbar, ctx->sumx, (const p2pdev::Push*)nullptr, ctx->ubd);
         break;
       case PDLPDEV_K_SPMV_A_DUAL: launch_a_dual(ctx); break;
       case PDLPDEV_K_SPMV_AT_STEP: launch_at_step(ctx); break;
