@@ -273,7 +273,7 @@ _proto("pdlpdev_make_average", c_int, c_void_p, c_int)
 _proto("pdlpdev_eval", c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p)
 _proto("pdlpdev_restart", c_int, c_void_p, c_int, c_int, c_void_p)
 _proto("pdlpdev_save_best", c_int, c_void_p, c_int)
-_proto("pdlpdev_trust_region_bounds", c_int, c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_void_p)
+_proto("pdlpdev_trust_region_bounds", c_int, c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_int, c_void_p)
 _proto("pdlpdev_eval_infeasibility", c_int, c_void_p, c_int, c_int, c_void_p)
 _proto("pdlpdev_get_solution", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_download", C.c_int64, c_void_p, c_int, c_void_p, C.c_int64)
@@ -809,9 +809,10 @@ class Device:
         return dict(zip(["max_primal_ray_infeasibility", "primal_ray_linear_objective",
                          "max_dual_ray_infeasibility", "dual_ray_linear_objective"], out.tolist()))
 
-    def trust_region_bounds(self, which, wp, wd, pds=0.5, dds=0.5, primal_weight=1.0, radius=-1.0):
+    def trust_region_bounds(self, which, wp, wd, pds=0.5, dds=0.5, primal_weight=1.0, radius=-1.0, scaled_iterates=False):
         out = np.zeros(6)
-        self._ck(lib.pdlpdev_trust_region_bounds(self.handle, which, wp, wd, pds, dds, primal_weight, radius, _ptr(out)))
+        self._ck(lib.pdlpdev_trust_region_bounds(self.handle, which, wp, wd, pds, dds, primal_weight, radius,
+                                                 int(scaled_iterates), _ptr(out)))
         return dict(zip(["primal_distance2", "dual_distance2", "distance", "lagrangian", "lower_bound",
                          "upper_bound"], out.tolist()))
 

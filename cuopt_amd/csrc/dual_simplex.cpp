@@ -793,7 +793,8 @@ struct Simplex {
   }
   int rebuilds = 0;
   int64_t ops_factor = 0, ops_solve = 0;
-  double tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, updates, rebuild}
+  double dens[6] = {0, 0, 0, 0, 0, 0};
+  double tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, factorisations, rebuild, duals + primal values, update file}
 };
 struct Lap {
   double* acc;
@@ -840,13 +841,50 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       note(i);
     }
   };
+  // The rows of A with the NONBASIC columns first: a pivot row rho^T A_N is needed for nonbasic columns only, and in the later
+  // part of a solve most structural columns a row meets are basic.  prj / prv: a copy of the caller's rows, row i's nonbasic entries
+  // in [rp[i], pend[i]); where[e] = place of the column-wise entry e in that copy, cent[k] the way back -- a column that enters or
+  // leaves the basis swaps its entries across the boundary of their rows (its length in work).  Laid out again from pos[] with
+  // every factorisation (which may have replaced dependent columns).
+  std::vector<int> prj(S.rj, S.rj + S.rp[m]), pend(m), where((size_t)S.rp[m]), cent((size_t)S.rp[m]);
+  std::vector<double> prv(S.rv, S.rv + S.rp[m]);
+  {
+    std::vector<int> cur(S.cp.begin(), S.cp.end() - 1);  // (the columns were filled by a scan of the rows: same order)
+    for (int i = 0; i < m; ++i)
+      for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) cent[k] = cur[S.rj[k]]++, where[cent[k]] = k;
+  }
+  auto swap_entries = [&](int a, int b) {
+    if (a == b) return;
+    std::swap(prj[a], prj[b]), std::swap(prv[a], prv[b]), std::swap(cent[a], cent[b]);
+    where[cent[a]] = a, where[cent[b]] = b;
+  };
+  auto partition_rows = [&] {
+    for (int i = 0; i < m; ++i) {
+      int lo = S.rp[i], hi = S.rp[i + 1];
+      while (lo < hi) {
+        if (S.pos[prj[lo]] < 0) ++lo;
+        else swap_entries(lo, --hi);
+      }
+      pend[i] = lo;
+    }
+  };
+  auto column_to_basic = [&](int j) {  // (structural columns only; the slacks are not stored)
+    for (int e = S.cp[j]; e < S.cp[j + 1]; ++e) swap_entries(where[e], --pend[S.ci[e]]);
+  };
+  auto column_to_nonbasic = [&](int j) {
+    for (int e = S.cp[j]; e < S.cp[j + 1]; ++e) swap_entries(where[e], pend[S.ci[e]]++);
+  };
   auto rebuild = [&] {
     for (int i = 0; i < m; ++i) S.beta[S.basic[i]] = bw[i];
     S.rebuild(tol_d);
     since_refactor = 0, extra_ops = 0;
     gather();
+    partition_rows();
   };
   gather();
+  partition_rows();
+  std::vector<int> cand_j;  // the ratio test's candidates (sign-eligible entries of the pivot row), compact: column, |alpha|, |d|
+  std::vector<double> cand_a, cand_d;
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
     if (flag_set(cancel)) return 9;  // the other engine of a Concurrent solve has finished
@@ -891,28 +929,30 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     for (int i : rlist) {
       const double ri = rho[i];
       if (std::fabs(ri) < 1e-14) continue;
-      for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) {
-        const int j = S.rj[k];
-        if (S.pos[j] >= 0) continue;
+      for (int k = S.rp[i], ke = pend[i]; k < ke; ++k) {
+        const int j = prj[k];
         if (astamp[j] != sweep) astamp[j] = sweep, alpha[j] = 0.0, touched.push_back(j);
-        alpha[j] += ri * S.rv[k];
+        alpha[j] += ri * prv[k];
       }
       if (S.pos[n + i] < 0) astamp[n + i] = sweep, alpha[n + i] = -ri, touched.push_back(n + i);
     }
     }
+    cand_j.clear(), cand_a.clear(), cand_d.clear();
+    double ptol = 0.0, tmax = kInf;
+    { Lap lap(S, 3);
     for (int j : touched) {
-      if (S.L[j] == S.U[j]) alpha[j] = 0.0;  // a fixed variable never enters
-      amax = std::max(amax, std::fabs(alpha[j]));
-    }
-    const double ptol = std::max(1e-11, 1e-9 * amax);
-    // Harris: pass 1 the largest step that keeps every reduced cost within tol_d of its sign, pass 2 the largest pivot under it
-    double tmax = kInf;
-    for (int j : touched) {
+      if (S.L[j] == S.U[j]) {  // a fixed variable never enters
+        alpha[j] = 0.0;
+        continue;
+      }
       const double a = sigma * alpha[j];
-      if (std::fabs(a) <= ptol) continue;
-      const bool eligible = S.atU[j] ? a > 0.0 : a < 0.0;
-      if (!eligible) continue;
-      tmax = std::min(tmax, (std::fabs(S.d[j]) + tol_d) / std::fabs(a));
+      amax = std::max(amax, std::fabs(a));
+      if (S.atU[j] ? a > 0.0 : a < 0.0) cand_j.push_back(j), cand_a.push_back(std::fabs(a)), cand_d.push_back(std::fabs(S.d[j]));
+    }
+    ptol = std::max(1e-11, 1e-9 * amax);
+    // Harris: pass 1 the largest step that keeps every reduced cost within tol_d of its sign, pass 2 the largest pivot under it
+    for (size_t c = 0; c < cand_j.size(); ++c)
+      if (cand_a[c] > ptol) tmax = std::min(tmax, (cand_d[c] + tol_d) / cand_a[c]);
     }
     if (tmax == kInf && worst_inf <= 1e-6 * (1.0 + std::fabs(to_low ? S.L[p] : S.U[p]))) {
       passed[r] = S.iterations + 1;
@@ -949,12 +989,9 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     }
     int q        = -1;
     double apick = 0.0;
-    for (int j : touched) {
-      const double a = sigma * alpha[j];
-      if (std::fabs(a) <= ptol) continue;
-      const bool eligible = S.atU[j] ? a > 0.0 : a < 0.0;
-      if (!eligible) continue;
-      if (std::fabs(S.d[j]) / std::fabs(a) <= tmax && std::fabs(a) > apick) apick = std::fabs(a), q = j;
+    { Lap lap(S, 3);
+    for (size_t c = 0; c < cand_j.size(); ++c)
+      if (cand_a[c] > ptol && cand_a[c] > apick && cand_d[c] / cand_a[c] <= tmax) apick = cand_a[c], q = cand_j[c];
     }
     if (q < 0) return 7;
     // entering column
@@ -990,6 +1027,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       bw[r] = 1.0;
     }
     // duals: d_j -= theta alpha_rj, the entering variable's becomes 0, the leaving one's -theta
+    Lap lap_values(S, 8);
     const double theta = S.d[q] / alpha[q];
     for (int j : touched)
       if (alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
@@ -1000,12 +1038,15 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     S.z[q] += step;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_update(r, w[r]);
+    { Lap lap(S, 9); S.push_update(r, w[r]); }
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
+    if (q < n) column_to_basic(q);
+    if (p < n) column_to_nonbasic(p);
     for (int i : wlist)
       if (w[i] != 0.0 && i != r) S.z[S.basic[i]] -= w[i] * step, pinf[i] = infeasibility(i), note(i);
     pinf[r] = infeasibility(r), note(r);
     S.iterations += 1;
+    if (S.debug) S.dens[0] += rlist.size(), S.dens[1] += wlist.size(), S.dens[2] += taulist.size(), S.dens[3] += touched.size(), S.dens[4] += S.update_entries(), S.dens[5] += S.Li.size() + S.Ui.size();
     // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
     // after kRefactorEvery pivots
     extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.update_entries();
@@ -1142,7 +1183,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     const bool to_low = dir * w[r] > 0.0;
     S.z[p]   = to_low ? S.L[p] : S.U[p];
     S.atU[p] = !to_low;
-    S.push_update(r, w[r]);
+    { Lap lap(S, 9); S.push_update(r, w[r]); }
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
     S.iterations += 1;
     extra_ops += 2 * (int64_t)S.update_entries();
@@ -1290,11 +1331,12 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   S.debug = debug;
   int total_iterations = 0;
   auto print_seconds = [&] {
+    std::fprintf(stderr, "[simplex] per pivot: rho %.0f, w %.0f, tau %.0f, touched %.0f, update entries %.0f, L+U %.0f (m %d)\n", S.dens[0] / std::max(1, S.iterations), S.dens[1] / std::max(1, S.iterations), S.dens[2] / std::max(1, S.iterations), S.dens[3] / std::max(1, S.iterations), S.dens[4] / std::max(1, S.iterations), S.dens[5] / std::max(1, S.iterations), S.m);
     std::fprintf(stderr, "[simplex] factorisation ms: ordering %.0f, set-up %.0f, triangular part %.0f, nucleus %.0f, row-wise copies %.0f\n", S.fsec[0], S.fsec[1], S.fsec[2], S.fsec[3], S.fsec[4]);
-    std::fprintf(stderr, "[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ftran %.2f, weights %.2f, rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[4], S.tsec[5], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
+    std::fprintf(stderr, "[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ratio test %.2f, ftran %.2f, weights %.2f, values %.2f (update file %.2f), rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[3], S.tsec[4], S.tsec[5], S.tsec[8], S.tsec[9], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
   };
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const double big = (attempt == 0 ? 1e5 : 1e8) * scale;
+    const double big = (attempt == 0 ? (double)cuopt_amd::tune_int("simplex_box", 100000) : 1e8) * scale;
     S.g.assign(S.N, 0.0), S.L.assign(S.N, 0.0), S.U.assign(S.N, 0.0);
     S.boxedL.assign(S.N, 0), S.boxedU.assign(S.N, 0);
     for (int j = 0; j < S.N; ++j) {

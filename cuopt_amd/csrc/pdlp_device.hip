@@ -215,6 +215,11 @@ __global__ void __launch_bounds__(kBlock) k_div_inplace(int n, double* __restric
 {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] = v[i] / d[i];
 }
+__global__ void __launch_bounds__(kBlock) k_div_to(int n, double* __restrict__ out, const double* __restrict__ v,
+                                                   const double* __restrict__ d)
+{
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = v[i] / d[i];
+}
 __global__ void __launch_bounds__(kBlock) k_clamp(int n, double* __restrict__ x,
                                                   const double* __restrict__ lb,
                                                   const double* __restrict__ ub)
@@ -920,14 +925,14 @@ __device__ __forceinline__ TrElem tr_element(const TrPoint& P, int k)
 {
   TrElem e;
   if (k < P.n) {
-    e.center = P.xhat[k] * P.dc[k];
+    e.center = P.dc ? P.xhat[k] * P.dc[k] : P.xhat[k];
     e.grad   = P.c_u[k] - P.aty[k];
     e.obj    = e.grad;
     e.sub    = 0.0;
     e.lb = P.lb_u[k], e.ub = P.ub_u[k], e.w = P.wp;
   } else {
     const int i      = k - P.n;
-    const double yi  = P.yhat[i] * P.dr[i];
+    const double yi  = P.dr ? P.yhat[i] * P.dr[i] : P.yhat[i];
     const double lo = P.lo_u[i], hi = P.hi_u[i], pp = P.ax[i];
     double sub;
     if (yi < 0.0)
@@ -974,13 +979,13 @@ __global__ void __launch_bounds__(kBlock) k_tr_stats(TrPoint P, int nbg, double*
   for (int k = P.first + blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
     const TrElem e = tr_element(P, k);
     if (k < P.n) {
-      const double d = (P.lrx[k] - P.xhat[k]) * P.dc[k];
+      const double d = P.dc ? (P.lrx[k] - P.xhat[k]) * P.dc[k] : P.lrx[k] - P.xhat[k];
       sm[0] += d * d;
       sm[2] += P.c_u[k] * e.center;
       sm[3] += e.center * P.aty[k];
     } else {
       const int i    = k - P.n;
-      const double d = (P.lry[i] - P.yhat[i]) * P.dr[i];
+      const double d = P.dr ? (P.lry[i] - P.yhat[i]) * P.dr[i] : P.lry[i] - P.yhat[i];
       sm[1] += d * d;
       sm[4] += e.center * e.sub;  // y . subgradient
     }
@@ -1915,25 +1920,45 @@ int pdlpdev_set_initial(pdlpdev_ctx* ctx, const double* x, const double* y)
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+}  // extern "C"
+static void launch_plain(pdlpdev_ctx* ctx, int transpose, const double* vec, double* out);
+extern "C" {
 // update_step_size_on_initial_solution (pdlp.cu:878-948): the quantities of one compute_step_sizes call with
-// delta_primal = x0, delta_dual = y' = y0 and a zero A^T y -- on the SCALED iterate that set_initial left in the current
-// buffers.  out = {interaction x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|, max|y0|}.  Leaves A^T y0 in the current A^T y
-// buffer (which is what the loop needs next anyway).
-int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5])
+// delta_primal = x0, delta_dual = y' = y0 and a zero A^T y.  out = {interaction x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|,
+// max|y0|}.
+//   x0_unscaled == y0_unscaled == nullptr: on the SCALED iterate that set_initial left in the current buffers; leaves A^T y0
+//     in the current A^T y buffer (which is what the loop needs next anyway).
+//   both given (compute_initial_step_size_before_scaling, pdlp.cu:929-947): the caller's vectors as they came, against the
+//     SCALED matrix; they pass through the next-iterate buffers, which the first attempt overwrites before it reads them,
+//     and the current A^T y buffer is left alone.
+int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5], const double* x0_unscaled, const double* y0_unscaled)
 {
   HIP_TRY(hipSetDevice(ctx->device));
-  TRY(pdlpdev_compute_aty(ctx));
-  TRY(fetch_ctl(ctx, nullptr));
-  const int cur = ctx->ctl_h->cur;
+  if ((x0_unscaled == nullptr) != (y0_unscaled == nullptr)) return fail(-1, "initial_solution_stats: both unscaled vectors or none");
   hipStream_t s = ctx->stream;
   const int n = ctx->n, m = ctx->m;
+  TRY(fetch_ctl(ctx, nullptr));
+  const int cur = ctx->ctl_h->cur;
+  const double *xv = ctx->x[cur], *yv = ctx->y[cur], *atyv = ctx->aty[cur];
+  if (x0_unscaled) {
+    const int nxt = 1 - cur;
+    HIP_TRY(hipMemcpyAsync(ctx->x[nxt], x0_unscaled, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->y[nxt], y0_unscaled, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+    double* prod = ctx->comm ? ctx->ar_buf : ctx->aty[nxt];
+    launch_plain(ctx, 1, ctx->y[nxt], prod);
+    LAUNCH_CHECK();
+    if (ctx->comm) TRY(allreduce(ctx, prod, (size_t)n, rccl::kSum));
+    xv = ctx->x[nxt], yv = ctx->y[nxt], atyv = prod;
+  } else {
+    TRY(pdlpdev_compute_aty(ctx));
+  }
   const int g = std::min(grid_for(n), kGenericBlocks);
-  k_dot<<<g, kBlock, 0, s>>>(n, ctx->x[cur], ctx->aty[cur], ctx->part_g);
+  k_dot<<<g, kBlock, 0, s>>>(n, xv, atyv, ctx->part_g);
   k_finalize<<<1, kBlock, 0, s>>>(ctx->part_g, g, 1, 0u, ctx->scal + 48);
-  TRY(reduce_vec(ctx, 1, n, ctx->x[cur], nullptr, 49));
-  TRY(reduce_vec(ctx, 1, m, ctx->y[cur], nullptr, 50));
-  TRY(reduce_vec(ctx, 0, n, ctx->x[cur], nullptr, 51));
-  TRY(reduce_vec(ctx, 0, m, ctx->y[cur], nullptr, 52));
+  TRY(reduce_vec(ctx, 1, n, xv, nullptr, 49));
+  TRY(reduce_vec(ctx, 1, m, yv, nullptr, 50));
+  TRY(reduce_vec(ctx, 0, n, xv, nullptr, 51));
+  TRY(reduce_vec(ctx, 0, m, yv, nullptr, 52));
   LAUNCH_CHECK();
   if (ctx->comm) {  // the dual side is sharded
     TRY(allreduce(ctx, ctx->scal + 50, 1, rccl::kSum));
@@ -2619,15 +2644,36 @@ int pdlpdev_eval_infeasibility(pdlpdev_ctx* ctx, int which, int rc_rule_finite_b
 }
 
 int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double wp, double wd, double pds, double dds,
-                                double primal_weight, double radius, double out[6])
+                                double primal_weight, double radius, int scaled_iterates, double out[6])
 {
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(fetch_ctl(ctx, nullptr));
   const int cur = ctx->ctl_h->cur;
   hipStream_t s = ctx->stream;
-  TrPoint P{which == PDLPDEV_CURRENT ? ctx->x[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgx : ctx->lrx),
-            which == PDLPDEV_CURRENT ? ctx->y[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgy : ctx->lry),
-            ctx->lrx, ctx->lry, ctx->dc, ctx->dr, ctx->aty_u[which], ctx->ax_u[which], ctx->c_u, ctx->lb_u,
+  const double* px = which == PDLPDEV_CURRENT ? ctx->x[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgx : ctx->lrx);
+  const double* py = which == PDLPDEV_CURRENT ? ctx->y[cur] : (which == PDLPDEV_AVERAGE ? ctx->avgy : ctx->lry);
+  if (scaled_iterates) {
+    // rescale_for_restart (pdlp.cu:1144-1149): the restart strategy sees the SCALED iterates, yet its problem is the unscaled
+    // one (pdlp.cu:99-103).  This context keeps the scaled matrix only: A v = D_r^-1 (A^ (D_c^-1 v)), A^T v alike.  The
+    // next-iterate buffers are free between attempts.
+    const int nxt = 1 - cur, n = ctx->n, m = ctx->m;
+    k_div_to<<<grid_for(n), kBlock, 0, s>>>(n, ctx->x[nxt], px, ctx->dc);
+    k_div_to<<<grid_for(m), kBlock, 0, s>>>(m, ctx->y[nxt], py, ctx->dr);
+    launch_plain(ctx, 0, ctx->x[nxt], ctx->ax_u[which]);
+    k_div_inplace<<<grid_for(m), kBlock, 0, s>>>(m, ctx->ax_u[which], ctx->dr);
+    if (ctx->comm) {
+      launch_plain(ctx, 1, ctx->y[nxt], ctx->ar_buf);
+      LAUNCH_CHECK();
+      TRY(allreduce(ctx, ctx->ar_buf, (size_t)n, rccl::kSum));
+      k_div_to<<<grid_for(n), kBlock, 0, s>>>(n, ctx->aty_u[which], ctx->ar_buf, ctx->dc);
+    } else {
+      launch_plain(ctx, 1, ctx->y[nxt], ctx->aty_u[which]);
+      k_div_inplace<<<grid_for(n), kBlock, 0, s>>>(n, ctx->aty_u[which], ctx->dc);
+    }
+    LAUNCH_CHECK();
+  }
+  TrPoint P{px, py, ctx->lrx, ctx->lry, scaled_iterates ? nullptr : ctx->dc, scaled_iterates ? nullptr : ctx->dr,
+            ctx->aty_u[which], ctx->ax_u[which], ctx->c_u, ctx->lb_u,
             ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->n, ctx->m, wp, wd, (ctx->comm && ctx->rank != 0) ? ctx->n : 0};
   // sharded: the dual coordinates are this rank's rows, the primal ones are replicated and counted by rank 0 only;
   // every pass ends in a sum (and one max) over the ranks (pdlp_restart_strategy.cu:277-364 works on whole vectors)

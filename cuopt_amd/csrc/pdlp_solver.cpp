@@ -481,16 +481,18 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     bool restart = s->ctl.its_since_restart >= H.artificial_restart_threshold * s->total_iterations;
     // compute_localized_duality_gaps :982-1030 (A x / A^T y of both iterates are those of the evaluations above)
     double avg[6], cur[6];
-    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_AVERAGE, wp, wd, pds, dds, w, -1.0, avg));
-    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_CURRENT, wp, wd, pds, dds, w, -1.0, cur));
+    // rescale_for_restart: scaled iterates meet the unscaled problem the reference's restart strategy is built on (pdlp.cu:99-103)
+    const int scaled = H.rescale_for_restart ? 1 : 0;
+    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_AVERAGE, wp, wd, pds, dds, w, -1.0, scaled, avg));
+    DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_CURRENT, wp, wd, pds, dds, w, -1.0, scaled, cur));
     const double ng_avg = (avg[5] - avg[4]) / avg[2], ng_cur = (cur[5] - cur[4]) / cur[2];
     const bool to_average = ng_cur / cur[2] >= ng_avg / avg[2];  // pick_restart_candidate_kernel :841-856
     const double* cand    = to_average ? avg : cur;
     const double ng_cand  = to_average ? ng_avg : ng_cur;
     if (!restart) {  // should_do_adaptive_restart_normalized_duality_gap :905-937
       double ev_lr[PDLPDEV_EV_COUNT], lr[6];
-      DEV(pdlpdev_eval(dev, PDLPDEV_LAST_RESTART, rule_finite, -1.0, -1.0, ev_lr));
-      DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_LAST_RESTART, wp, wd, pds, dds, w, cand[2], lr));
+      if (!scaled) DEV(pdlpdev_eval(dev, PDLPDEV_LAST_RESTART, rule_finite, -1.0, -1.0, ev_lr));
+      DEV(pdlpdev_trust_region_bounds(dev, PDLPDEV_LAST_RESTART, wp, wd, pds, dds, w, cand[2], scaled, lr));
       const double ng_lr = (lr[5] - lr[4]) / cand[2];
       const double ratio = ng_cand / ng_lr;  // adaptive_restart_triggered :876-903
       if (ratio < H.necessary_reduction_for_restart &&
@@ -502,7 +504,7 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
       s->result.num_restarts += 1;
       const bool really_average = to_average && !H.never_restart_to_average;
       double dist2[2];
-      DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, 1, dist2));
+      DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, scaled ? 0 : 1, dist2));
       // the reference measures the distances of the PICKED candidate even when never_restart_to_average
       // redirects the copy; only Fast1 sets that flag and it uses the KKT restart
       s->last_restart_was_average = really_average;
@@ -781,10 +783,10 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
     // update_{step_size,primal_weight}_on_initial_solution (pdlp.cu:878-979; off in every preset, toggled by the
     // reference's initial_solution_test, pdlp_test.cu:245-523: no change without BOTH iterates or with an all-zero one)
     if (hyper->update_step_size_on_initial_solution && init_x && init_y) {
-      if (hyper->compute_initial_step_size_before_scaling)
-        return fail(-7, "update_step_size_on_initial_solution with compute_initial_step_size_before_scaling is not implemented");
+      // compute_initial_step_size_before_scaling: the caller's vectors as they came, against the scaled matrix (pdlp.cu:929-947)
+      const bool before = hyper->compute_initial_step_size_before_scaling != 0;
       double st[5];
-      DEV(pdlpdev_initial_solution_stats(s->dev, st));
+      DEV(pdlpdev_initial_solution_stats(s->dev, st, before ? init_x : nullptr, before ? init_y + s->row_begin : nullptr));
       if (st[3] != 0.0 && st[4] != 0.0) {
         // one compute_step_sizes with delta = the initial iterate and A^T y = 0 (adaptive_step_size_strategy.cu:91-188);
         // the kernel's own increment of the device iteration counter is not undone
@@ -802,7 +804,7 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
           s->step_error = true;  // valid_step_size = -1: the first loop trip is a major iteration that reports it
         }
       }
-      s->need_aty = false;  // A^T y0 was just computed
+      if (!before) s->need_aty = false;  // A^T y0 (scaled) was just computed
     }
     if (hyper->update_primal_weight_on_initial_solution) {
       // update_distance (pdlp_restart_strategy.cu:440-465): distance to the (zero) anchors, anchors <- iterate, new weight;
@@ -849,8 +851,6 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   HostRange range("pdlp: solver set-up (partition, transpose, scaling, initial step)");
   if (!out || !lp || !hyper || !settings) return fail(-1, "cuoptamd_solver_create: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(-1, "cuoptamd_solver_create: bad rank/world");
-  if (hyper->restart_strategy == 2 && hyper->rescale_for_restart)
-    return fail(-7, "trust-region restart is implemented for rescale_for_restart = false only (every preset that uses it)");
   const auto t0 = clock_type::now();
   const bool timing = std::getenv("CUOPT_AMD_TIMING") != nullptr;
   auto lap = [&, last = t0](const char* what) mutable {

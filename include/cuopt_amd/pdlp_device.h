@@ -203,9 +203,11 @@ int pdlpdev_set_k(pdlpdev_ctx* ctx, int32_t k);
 int pdlpdev_set_initial(pdlpdev_ctx* ctx, const double* x, const double* y);
 /* x <- clamp(x, lb, ub) on the scaled problem (pdlp.cu:1041-1056) */
 int pdlpdev_project_primal(pdlpdev_ctx* ctx);
-/* {x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|, max|y0|} of the scaled initial iterate (update_step_size_on_initial_solution,
- * pdlp.cu:878-948); leaves A^T y0 in the current A^T y buffer */
-int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5]);
+/* {x0.(A^T y0), ||x0||^2, ||y0||^2, max|x0|, max|y0|} of the initial iterate (update_step_size_on_initial_solution,
+ * pdlp.cu:878-948).  Both pointers NULL: the scaled iterate that pdlpdev_set_initial stored; leaves A^T y0 in the current
+ * A^T y buffer.  Both given (compute_initial_step_size_before_scaling, pdlp.cu:929-947): these vectors as they are (host
+ * memory; y0 = this rank's rows) against the scaled matrix; the current buffers are left alone. */
+int pdlpdev_initial_solution_stats(pdlpdev_ctx* ctx, double out[5], const double* x0_unscaled, const double* y0_unscaled);
 
 /* ---- the hot loop ---------------------------------------------------------------------------- */
 /* AtY <- A^T y for the current iterate (pdhg.cu:119-134); needed before the first step and after
@@ -266,11 +268,14 @@ int pdlpdev_restart(pdlpdev_ctx* ctx, int which, int unscaled_distances, double 
  *        radius (< 0: use the point's own distance_traveled)
  *   out: {primal_distance^2, dual_distance^2, distance_traveled, lagrangian, lower_bound, upper_bound}
  * The breakpoint search of the reference (sort + median bisection in a cooperative kernel) is replaced by a
- * monotone fixed-point iteration t <- sqrt((r^2 - low(t)) / high(t)) of streaming passes: same threshold. */
+ * monotone fixed-point iteration t <- sqrt((r^2 - low(t)) / high(t)) of streaming passes: same threshold.
+ * scaled_iterates != 0 (rescale_for_restart, pdlp.cu:1144-1149; no preset pairs it with this restart): the point and the
+ * anchors are taken in SCALED space as they are stored, against the same unscaled problem (the reference builds its restart
+ * strategy on the unscaled problem, pdlp.cu:99-103); A x / A^T y of the point are computed here, no pdlpdev_eval needed. */
 int pdlpdev_trust_region_bounds(pdlpdev_ctx* ctx, int which, double primal_norm_weight,
                                 double dual_norm_weight, double primal_distance_smoothing,
                                 double dual_distance_smoothing, double primal_weight, double radius,
-                                double out[6]);
+                                int scaled_iterates, double out[6]);
 
 /* save_best_primal_so_far (pdlp.cu:390-466): keeps a copy of iterate `which` (CURRENT or AVERAGE) and of its
  * reduced costs; retrieved with pdlpdev_get_solution(PDLPDEV_BEST) */

@@ -56,7 +56,7 @@ typedef struct cuoptamd_hyper {
   double initial_primal_weight_b_scaling;
   int32_t major_iteration;
   int32_t min_iteration_restart;
-  int32_t restart_strategy; /* 0 none, 1 KKT, 2 trust region (Methodical1; with rescale_for_restart = 0 only) */
+  int32_t restart_strategy; /* 0 none, 1 KKT, 2 trust region (Methodical1) */
   int32_t never_restart_to_average;
   double reduction_exponent;
   double growth_exponent;

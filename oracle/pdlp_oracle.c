@@ -912,13 +912,12 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
       for (int j = 0; j < n; ++j) nzx |= x[j] != 0.0;
       for (int i = 0; i < m; ++i) nzy |= y[i] != 0.0;
       if (init_x && init_y && nzx && nzy) {
-        if (H[ORC_H_STEP_SIZE_BEFORE_SCALING] != 0.0) { /* unscaled vectors against the scaled matrix: no preset does it */
-          rc = -2;
-          goto done;
-        }
-        /* delta_primal = x0, delta_dual = potential_next_dual = y0 (scaled, :917-926), current A^T y = 0 */
-        for (int j = 0; j < n; ++j) dx[j] = x[j] / Dc[j];
-        for (int i = 0; i < m; ++i) dy[i] = y[i] / Dr[i];
+        /* delta_primal = x0, delta_dual = potential_next_dual = y0, current A^T y = 0 (:905-920); scaled first (:923-931)
+         * unless the step size is computed before scaling -- then the vectors as they came meet the scaled matrix and
+         * are scaled afterwards (:940-947; the deltas are overwritten by the first step either way) */
+        const int before = H[ORC_H_STEP_SIZE_BEFORE_SCALING] != 0.0;
+        for (int j = 0; j < n; ++j) dx[j] = before ? x[j] : x[j] / Dc[j];
+        for (int i = 0; i < m; ++i) dy[i] = before ? y[i] : y[i] / Dr[i];
         orc_spmv(n, t_offsets, t_indices, P.At, dy, atyn);
         /* compute_step_sizes with the device iteration counter incremented by the kernel
          * (adaptive_step_size_strategy.cu:91-188: *pdhg_iteration += 1 is NOT undone by the host's --) */
@@ -1074,10 +1073,9 @@ int orc_pdlp_solve(int m, int n, const int* offsets, const int* indices, const d
       }
       /* ---- compute_restart -> run_kkt_restart, pdlp_restart_strategy.cu:467-641 ---- */
       if ((int)H[ORC_H_RESTART_STRATEGY] == 2) { /* run_trust_region_restart :277-364 */
-        if (H[ORC_H_RESCALE_FOR_RESTART] != 0.0) {
-          rc = -1; /* only the preset combination (unscaled iterates + unscaled problem) is restated */
-          goto done;
-        }
+        /* the restart strategy is built on the UNSCALED problem (pdlp.cu:99-103), whatever space the iterates are in: with
+         * rescale_for_restart (no preset pairs it with this strategy) the scaled iterates and anchors meet the unscaled
+         * matrix, objective and bounds below */
         if (its_since_restart != 0) {
           const double wp = tau == 0.0 ? 0.0 : 1.0 / tau, wd = sigma == 0.0 ? 0.0 : 1.0 / sigma;
           const double pds = H[ORC_H_PRIMAL_DISTANCE_SMOOTHING], dds = H[ORC_H_DUAL_DISTANCE_SMOOTHING];

@@ -274,3 +274,46 @@ def test_initial_solution_test_of_the_reference(golden_problems):
     assert not same(s, step0) and same(w, w0)
     s, w = _initial(golden_problems, 1, 1, 1, 1)
     assert not same(s, step0) and not same(w, w0)
+
+
+def test_trust_region_restart_on_scaled_iterates_in_the_oracle(golden_problems):
+    """Methodical1 + rescale_for_restart (pdlp.cu:1144-1149 with the restart strategy of pdlp.cu:99-103): not a preset, but a
+    combination the reference accepts; the restatement reaches afiro's pinned optimum with it, along a different walk"""
+    p = golden_problems["afiro"]["problem"]
+    h = orcbind.hyper_preset(2)
+    h[orcbind.H["ORC_H_RESCALE_FOR_RESTART"]] = 1.0
+    o = orcbind.solve(p, mode=2, hyper=h, tol=1e-8, iteration_limit=500000)
+    base = orcbind.solve(p, mode=2, tol=1e-8, iteration_limit=500000)
+    assert o["status"] == base["status"] == "Optimal"
+    assert o["primal_objective"] == pytest.approx(-464.7531, rel=1e-6)
+    assert int(o["steps_taken"]) != int(base["steps_taken"])
+
+
+def test_initial_step_size_before_scaling_meets_the_scaled_matrix(golden_problems):
+    """pdlp.cu:905-947 with compute_initial_step_size_before_scaling: the caller's vectors, unscaled, go through one
+    compute_step_sizes against the SCALED matrix (adaptive_step_size_strategy.cu:91-188) -- restated here with numpy"""
+    p = golden_problems["afiro"]["problem"]
+    m, n = int(p["m"]), int(p["n"])
+    h = orcbind.hyper_preset(2)
+    h[orcbind.H["ORC_H_STEP_SIZE_BEFORE_SCALING"]] = 1.0
+    base = orcbind.solve(p, mode=2, hyper=h, tol=0.0, iteration_limit=0)
+    h[orcbind.H["ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION"]] = 1.0
+    rng = np.random.default_rng(5)
+    x0, y0 = rng.uniform(0.5, 2.0, n), rng.uniform(-1.0, 1.0, m)
+    o = orcbind.solve(p, mode=2, hyper=h, tol=0.0, iteration_limit=0, init_x=x0, init_y=y0)
+    dr, dc = orcbind.compute_scaling(m, n, p["offsets"], p["indices"], p["values"], h)
+    rows = np.repeat(np.arange(m), np.diff(p["offsets"]))
+    scaled = np.asarray(p["values"]) * dr[rows] * dc[np.asarray(p["indices"])]
+    aty = np.zeros(n)
+    np.add.at(aty, np.asarray(p["indices"]), scaled * y0[rows])
+    inter = abs(float(x0 @ aty))
+    w, s0 = base["initial_primal_weight"], base["initial_step_size"]
+    H = lambda name: h[orcbind.H[name]]
+    movement = H("ORC_H_PRIMAL_DISTANCE_SMOOTHING") * w * float(x0 @ x0) + H("ORC_H_DUAL_DISTANCE_SMOOTHING") / w * float(y0 @ y0)
+    want = min((1.0 - 2.0 ** -H("ORC_H_REDUCTION_EXPONENT")) * movement / inter, (1.0 + 2.0 ** -H("ORC_H_GROWTH_EXPONENT")) * s0)
+    assert o["initial_step_size"] == pytest.approx(want, rel=1e-12)
+    assert o["initial_primal_weight"] == w
+    # and it is not what the scaled vectors give
+    h[orcbind.H["ORC_H_STEP_SIZE_BEFORE_SCALING"]] = 0.0
+    after = orcbind.solve(p, mode=2, hyper=h, tol=0.0, iteration_limit=0, init_x=x0, init_y=y0)
+    assert after["initial_step_size"] != pytest.approx(o["initial_step_size"], rel=1e-3)

@@ -70,7 +70,7 @@ def test_initial_step_and_weight_goldens(golden_problems):
     assert r["status_name"] == "IterationLimit" and r["steps_taken"] == 0
     assert r["initial_step_size"] == pytest.approx(pin["oracle_stable2_step_size"], rel=1e-13)
     assert r["initial_primal_weight"] == pytest.approx(pin["oracle_stable2_primal_weight"], rel=1e-12)
-    # Methodical1's scaling preset with the KKT restart (its trust-region restart is not implemented)
+    # Methodical1's scaling preset, here with the KKT restart
     h = capi.hyper_preset(2)
     h.restart_strategy = 1
     r = capi.Solver(p, hyper=h, iteration_limit=0).advance()
@@ -391,6 +391,30 @@ def test_methodical1_trust_region_restart(golden_problems):
     assert rr["status"] == oo["status"] == "Optimal"
     assert abs(rr["objective"] - q["objective_star"]) <= 4e-5 * (1 + abs(q["objective_star"]))
     assert 0.5 * oo["steps_taken"] - 128 <= rr["steps_taken"] <= 2.0 * oo["steps_taken"] + 128
+
+
+def test_trust_region_restart_on_scaled_iterates(golden_problems):
+    """Methodical1 with rescale_for_restart switched on (no preset does it): the restart strategy, built on the unscaled
+    problem (pdlp.cu:99-103), is handed the scaled iterates (pdlp.cu:1144-1149).  Same walk as the oracle's restatement."""
+    h, oh = capi.hyper_preset(2), orcbind.hyper_preset(2)
+    h.rescale_for_restart = 1
+    oh[orcbind.H["ORC_H_RESCALE_FOR_RESTART"]] = 1.0
+    q = synthetic.generate(3000, 2600, 9, seed=17)
+    for its in (64, 128, 320):
+        rr = capi.Solver(q, hyper=h, tol=0.0, iteration_limit=its).advance()
+        oo = orcbind.solve(q, mode=2, hyper=oh, tol=0.0, iteration_limit=its)
+        assert (rr["steps_taken"], rr["attempted_steps"]) == (int(oo["steps_taken"]), int(oo["attempted_steps"]))
+        assert rr["num_restarts"] == int(oo["num_restarts"])
+        assert rr["primal_weight"] == pytest.approx(oo["final_primal_weight"], rel=1e-6)
+    for p, star in ((q, q["objective_star"]), (golden_problems["afiro"]["problem"], -464.7531)):
+        rr = capi.Solver(p, hyper=h, tol=1e-6, iteration_limit=200000).advance()
+        oo = orcbind.solve(p, mode=2, hyper=oh, tol=1e-6, iteration_limit=200000)
+        assert rr["status_name"] == oo["status"] == "Optimal"
+        assert abs(rr["primal_objective"] - star) <= 1e-4 * (1 + abs(star))
+        assert 0.5 * oo["steps_taken"] - 128 <= rr["steps_taken"] <= 2.0 * oo["steps_taken"] + 128
+    # the walk differs from the preset's (unscaled iterates): the switch is not ignored
+    base = orcbind.solve(q, mode=2, tol=1e-6)
+    assert int(base["steps_taken"]) != int(orcbind.solve(q, mode=2, hyper=oh, tol=1e-6)["steps_taken"])
 
 
 @pytest.mark.parametrize("name", ["mip-50v-10-free-bound-relaxation", "mip-neos5-free-bound-relaxation",
@@ -724,6 +748,34 @@ def test_initial_solution_test_of_the_reference_on_the_device(golden_problems):
     h.update_step_size_on_initial_solution = h.update_primal_weight_on_initial_solution = 1
     r = capi.Solver(p, hyper=h, tol=1e-6, init_x=np.full(p["n"], 1.0), init_y=np.full(p["m"], 1.0)).advance()
     assert r["status_name"] == "Optimal" and r["primal_objective"] == pytest.approx(-464.7531, rel=1e-4)
+
+
+def test_initial_step_size_before_scaling_on_the_device(golden_problems):
+    """pdlp.cu:905-947 with compute_initial_step_size_before_scaling (no preset sets it together with
+    update_step_size_on_initial_solution): the unscaled vectors meet the scaled matrix; step size and the run that follows
+    are the oracle's, on afiro and on an LP of the non-resident path"""
+    for p, tol in ((golden_problems["afiro"]["problem"], 1e-6), (synthetic.generate(3000, 4000, 6, seed=31), 1e-4)):
+        rng = np.random.default_rng(5)
+        x0, y0 = rng.uniform(0.5, 2.0, p["n"]), rng.uniform(-1.0, 1.0, p["m"])
+        for uw in (0, 1):
+            h, oh = capi.hyper_preset(2), orcbind.hyper_preset(2)
+            h.update_step_size_on_initial_solution = h.compute_initial_step_size_before_scaling = 1
+            h.update_primal_weight_on_initial_solution = uw
+            oh[orcbind.H["ORC_H_UPDATE_STEP_SIZE_ON_INITIAL_SOLUTION"]] = oh[orcbind.H["ORC_H_STEP_SIZE_BEFORE_SCALING"]] = 1.0
+            oh[orcbind.H["ORC_H_UPDATE_PRIMAL_WEIGHT_ON_INITIAL_SOLUTION"]] = float(uw)
+            s = capi.Solver(p, hyper=h, tol=tol, iteration_limit=20000, init_x=x0, init_y=y0)
+            r = s.advance()
+            s.close()
+            o = orcbind.solve(p, mode=2, hyper=oh, tol=tol, iteration_limit=20000, init_x=x0, init_y=y0)
+            assert r["initial_step_size"] == pytest.approx(o["initial_step_size"], rel=1e-9)
+            assert r["initial_primal_weight"] == pytest.approx(o["initial_primal_weight"], rel=1e-9)
+            assert r["status_name"] == o["status"] == "Optimal"
+            # (same start to 1e-9; the walks part ways at the first restart decision that rounding tips, as in every long solve)
+            assert 0.5 * o["steps_taken"] - 128 <= r["steps_taken"] <= 2.0 * o["steps_taken"] + 128
+            rr = capi.Solver(p, hyper=h, tol=0.0, iteration_limit=64, init_x=x0, init_y=y0).advance()
+            oo = orcbind.solve(p, mode=2, hyper=oh, tol=0.0, iteration_limit=64, init_x=x0, init_y=y0)
+            assert (rr["steps_taken"], rr["attempted_steps"]) == (int(oo["steps_taken"]), int(oo["attempted_steps"]))
+            assert r["primal_objective"] == pytest.approx(o["primal_objective"], rel=10 * tol, abs=10 * tol)
 
 
 def test_relative_tolerance_factors(golden_problems):
