@@ -15,6 +15,7 @@
 // solution -- a primal simplex, below, takes that basis to optimality first).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
 // the LP is unbounded.  Host code: the reference's simplex is CPU code too; PDLP on the GPU stays the engine for large LPs.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -22,9 +23,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <new>
 #include <numeric>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "cuopt_amd/pdlp_solver.h"
@@ -66,8 +69,16 @@ struct Simplex {
   // k < kk; UR[j] = the entries U(j, k), k > j
   std::vector<int> LRp, LRi, URp, URi;
   std::vector<double> LRx, URx;
-  std::vector<int> vis, sstack, sptr, order;  // depth-first searches of the sparse solves
-  int vstamp       = 0;
+  // Scratch of one solve.  W0 serves every solve of the thread that owns the Simplex (its fields are reachable under their plain
+  // names below); a second thread solving against the same (unchanging) factors brings its own -- run()'s weight solve does.
+  struct SolveWork {
+    std::vector<int> vis, sstack, sptr, order, seed, lorder, plist, rmark;
+    int vstamp = 0, rstamp = 0;
+  };
+  SolveWork W0;
+  std::vector<int>&vis = W0.vis, &sstack = W0.sstack, &sptr = W0.sptr, &order = W0.order;  // depth-first searches of the sparse solves
+  std::vector<int>&seed_buf = W0.seed, &lorder = W0.lorder, &plist = W0.plist, &rmark = W0.rmark;
+  int &vstamp = W0.vstamp, &rstamp = W0.rstamp;
   int sparse_solve = 1;  // 0: always the dense loops (CUOPT_AMD_SIMPLEX_SOLVES=dense), 2: always the sparse ones, 1: by the size of the reach
   // work space
   std::vector<double> wx;
@@ -416,8 +427,10 @@ struct Simplex {
   // calls f for every pivot k points to.  Gives up (returns false, nothing changed) once more than m / 6 pivots are reached:
   // the dense loops are faster then.
   template <class Next>
-  bool reach(const std::vector<int>& from, Next&& next)
+  bool reach(SolveWork& W, const std::vector<int>& from, Next&& next)
   {
+    std::vector<int>&vis = W.vis, &sstack = W.sstack, &sptr = W.sptr, &order = W.order;
+    int& vstamp = W.vstamp;
     order.clear();
     if (sparse_solve == 0) return false;
     const size_t limit = sparse_solve == 2 ? (size_t)m + 1 : (size_t)std::max(16, m / 6);
@@ -452,14 +465,15 @@ struct Simplex {
   //      change.  Vectors are kept by ROW (position k <-> row prow[k]).
   std::vector<int> Mvp, Mvi, Mep, Mei;
   std::vector<double> Mvx, Mex, Mw;
-  std::vector<int> spike_i, et_i, rmark, plist;   // what the last FTRAN (keep = true) / BTRAN left half way, row marks of the sparse stages
+  std::vector<int> spike_i, et_i;   // what the last FTRAN (keep = true) / BTRAN left half way
   std::vector<double> spike_x, et_x, scr;
-  int rstamp = 0;
   size_t update_entries() const { return Mvi.size() + Mei.size(); }
   void clear_updates() { Mvp.assign(1, 0), Mep.assign(1, 0), Mvi.clear(), Mvx.clear(), Mei.clear(), Mex.clear(), Mw.clear(); }
   // x (by ROW) <- M_K^-1 ... M_1^-1 x; with `track` the rows that become nonzero are appended to plist (marked with rstamp)
-  void apply_updates_forward(std::vector<double>& x, bool track)
+  void apply_updates_forward(SolveWork& W, std::vector<double>& x, bool track)
   {
+    std::vector<int>&plist = W.plist, &rmark = W.rmark;
+    const int rstamp = W.rstamp;
     const int nu = (int)Mw.size();
     for (int e = 0; e < nu; ++e) {
       double dot = 0.0;
@@ -491,14 +505,18 @@ struct Simplex {
   // w = B^-1 a.  x holds a by ROW with its nonzero rows in xrows; on return x is all zero, w (by POSITION, zero on entry) holds the
   // result with its nonzero positions in wlist.  keep: the vector between the update stage and the U stage (the spike of an entering
   // column) is copied to spike_i / spike_x.
-  void ftran(std::vector<double>& x, const std::vector<int>& xrows, std::vector<double>& w, std::vector<int>& wlist, bool keep = false)
+  void ftran(std::vector<double>& x, const std::vector<int>& xrows, std::vector<double>& w, std::vector<int>& wlist, bool keep = false, SolveWork* work = nullptr)
   {
+    SolveWork& W = work ? *work : W0;
+    std::vector<int>&vis = W.vis, &order = W.order, &seed = W.seed, &lorder = W.lorder, &plist = W.plist, &rmark = W.rmark;
+    int &vstamp = W.vstamp, &rstamp = W.rstamp;
     wlist.clear();
-    if ((int)rmark.size() != m) rmark.assign(m, 0), scr.assign(m, 0.0);
-    std::vector<int>& seed = seed_buf;
+    if ((int)rmark.size() != m) rmark.assign(m, 0);
+    if ((int)vis.size() != m) vis.assign(m, 0), vstamp = 0;
+    if (!work && (int)scr.size() != m) scr.assign(m, 0.0);
     seed.clear();
     for (int r : xrows) seed.push_back(pinv[r]);
-    bool sparse = reach(seed, [&](int k, int& ptr, int& child) {
+    bool sparse = reach(W, seed, [&](int k, int& ptr, int& child) {
       while (Lp[k] + ptr < Lp[k + 1]) {
         const int nx = pinv[Li[Lp[k] + ptr++]];
         if (vis[nx] != vstamp) { child = nx; return; }
@@ -523,7 +541,7 @@ struct Simplex {
       }
     }
     // ---- the updates
-    if (!Mw.empty()) apply_updates_forward(x, sparse);
+    if (!Mw.empty()) apply_updates_forward(W, x, sparse);
     if (keep) {
       spike_i.clear(), spike_x.clear();
       if (sparse) {
@@ -539,7 +557,7 @@ struct Simplex {
       seed.clear();
       for (int i : plist)
         if (x[i] != 0.0) seed.push_back(pinv[i]);
-      sparse = reach(seed, [&](int k, int& ptr, int& child) {
+      sparse = reach(W, seed, [&](int k, int& ptr, int& child) {
         while (Up[k] + ptr < Up[k + 1]) {
           const int nx = Ui[Up[k] + ptr++];
           if (vis[nx] != vstamp) { child = nx; return; }
@@ -577,7 +595,7 @@ struct Simplex {
   {
     rlist.clear();
     if ((int)rmark.size() != m) rmark.assign(m, 0), scr.assign(m, 0.0);
-    bool sparse = reach(tlist, [&](int k, int& ptr, int& child) {
+    bool sparse = reach(W0, tlist, [&](int k, int& ptr, int& child) {
       while (URp[k] + ptr < URp[k + 1]) {
         const int nx = URi[URp[k] + ptr++];
         if (vis[nx] != vstamp) { child = nx; return; }
@@ -616,7 +634,7 @@ struct Simplex {
       seed.clear();
       for (int k : plist)
         if (t[k] != 0.0) seed.push_back(k);
-      sparse = reach(seed, [&](int k, int& ptr, int& child) {
+      sparse = reach(W0, seed, [&](int k, int& ptr, int& child) {
         while (LRp[k] + ptr < LRp[k + 1]) {
           const int nx = LRi[LRp[k] + ptr++];
           if (vis[nx] != vstamp) { child = nx; return; }
@@ -645,7 +663,6 @@ struct Simplex {
     for (int i = 0; i < m; ++i)
       if (rho[i] != 0.0) rlist.push_back(i);
   }
-  std::vector<int> seed_buf, lorder;
   bool debug = false;
   // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
   void ftran_dense(std::vector<double>& x, std::vector<double>& w)
@@ -655,7 +672,7 @@ struct Simplex {
       if (xj == 0.0) continue;
       for (int e = Lp[k]; e < Lp[k + 1]; ++e) x[Li[e]] -= Lx[e] * xj;
     }
-    if (!Mw.empty()) apply_updates_forward(x, false);
+    if (!Mw.empty()) apply_updates_forward(W0, x, false);
     for (int k = m - 1; k >= 0; --k) {
       double v = x[prow[k]];
       if (v != 0.0) {
@@ -803,6 +820,60 @@ struct Lap {
   ~Lap() { if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// The steepest-edge weights need tau = B^-1 rho, a solve whose result nobody reads before the pivot's end.  On LPs where a solve is
+// worth a hand-over it runs on a helper thread -- own scratch, the same factors and update file, which nothing writes until the
+// pivot is done -- next to the pivot row, the ratio test and the entering column's solve.  One job at a time; the helper spins
+// briefly, then yields, while it waits for the next one.
+struct TauHelper {
+  Simplex& S;
+  std::vector<double> rhs;  // rho by ROW (handed back zeroed by the solve)
+  std::vector<int> rows;
+  std::vector<double>* tau  = nullptr;
+  std::vector<int>* taulist = nullptr;
+  Simplex::SolveWork W;
+  std::atomic<int> state{0};  // 0 idle, 1 posted, 2 done, 3 quit
+  std::thread th;
+  explicit TauHelper(Simplex& s) : S(s), rhs(s.m, 0.0) {}
+  bool start()
+  {
+    try {
+      th = std::thread([this] { loop(); });
+    } catch (...) {
+      return false;
+    }
+    return true;
+  }
+  static void relax(int& spins)
+  {
+    if (++spins < 4000) __builtin_ia32_pause();
+    else std::this_thread::yield();
+  }
+  void loop()
+  {
+    for (;;) {
+      int spins = 0, st;
+      while ((st = state.load(std::memory_order_acquire)) != 1 && st != 3) relax(spins);
+      if (st == 3) return;
+      S.ftran(rhs, rows, *tau, *taulist, false, &W);
+      state.store(2, std::memory_order_release);
+    }
+  }
+  void post() { state.store(1, std::memory_order_release); }
+  void wait()
+  {
+    int spins = 0;
+    while (state.load(std::memory_order_acquire) != 2) relax(spins);
+    state.store(0, std::memory_order_relaxed);
+  }
+  ~TauHelper()
+  {
+    if (!th.joinable()) return;
+    if (state.load(std::memory_order_acquire) == 1) wait();
+    state.store(3, std::memory_order_release);
+    th.join();
+  }
+};
+
 // status: 1 optimal, 2 primal infeasible, 5 iteration limit, 6 time limit, 7 numerical trouble, 9 cancelled.  Continues from
 // the basis and the nonbasic bounds S holds (factorised, recomputed, dual feasible).
 int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::steady_clock::time_point& t0, const volatile int32_t* cancel)
@@ -883,6 +954,16 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   };
   gather();
   partition_rows();
+  std::unique_ptr<TauHelper> helper;
+  if (S.steepest && m >= cuopt_amd::tune_int("simplex_helper_rows", 2000) && std::thread::hardware_concurrency() >= 2) {
+    helper.reset(new TauHelper(S));
+    helper->tau = &tau, helper->taulist = &taulist;
+    if (!helper->start()) helper.reset();
+  }
+  bool tau_posted = false;
+  auto finish_tau = [&] {
+    if (tau_posted) helper->wait(), tau_posted = false;
+  };
   std::vector<int> cand_j;  // the ratio test's candidates (sign-eligible entries of the pivot row), compact: column, |alpha|, |d|
   std::vector<double> cand_a, cand_d;
   for (;;) {
@@ -922,6 +1003,12 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     tvec[r] = 1.0;
     tlist.assign(1, r);
     { Lap lap(S, 1); S.btran(tvec, tlist, rho, rlist); }
+    if (helper) {  // tau = B^-1 rho starts now (see TauHelper); every way out of this pivot passes finish_tau()
+      for (int i : taulist) tau[i] = 0.0;
+      for (int i : rlist) helper->rhs[i] = rho[i];
+      helper->rows = rlist;
+      helper->post(), tau_posted = true;
+    }
     ++sweep;
     touched.clear();
     double amax = 0.0;
@@ -956,9 +1043,11 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     }
     if (tmax == kInf && worst_inf <= 1e-6 * (1.0 + std::fabs(to_low ? S.L[p] : S.U[p]))) {
       passed[r] = S.iterations + 1;
+      finish_tau();
       continue;
     }
     if (tmax == kInf) {  // no entering variable: the row proves primal infeasibility
+      finish_tau();
       if (since_refactor != 0) {  // ... if a fresh factorisation says so too
         rebuild();
         continue;
@@ -993,7 +1082,10 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     for (size_t c = 0; c < cand_j.size(); ++c)
       if (cand_a[c] > ptol && cand_a[c] > apick && cand_d[c] / cand_a[c] <= tmax) apick = cand_a[c], q = cand_j[c];
     }
-    if (q < 0) return 7;
+    if (q < 0) {
+      finish_tau();
+      return 7;
+    }
     // entering column
     for (int i : wlist) w[i] = 0.0;
     clist.clear();
@@ -1003,6 +1095,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     { Lap lap(S, 4); S.ftran(col, clist, w, wlist, true); }
     if (std::fabs(w[r]) < 1e-11 || std::fabs(w[r] - alpha[q]) > 1e-6 * (1.0 + std::fabs(alpha[q]))) {
       // the factorisation has drifted: rebuild it and look again
+      finish_tau();
       if (since_refactor == 0) return 7;
       rebuild();
       continue;
@@ -1013,9 +1106,13 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       double br = 0.0;
       for (int i : rlist) br += rho[i] * rho[i];
       S.beta[p] = br;  // exact, whatever the updates had made of it
-      for (int i : taulist) tau[i] = 0.0;
-      for (int i : rlist) col[i] = rho[i];
-      S.ftran(col, rlist, tau, taulist);
+      if (tau_posted) {
+        finish_tau();
+      } else {
+        for (int i : taulist) tau[i] = 0.0;
+        for (int i : rlist) col[i] = rho[i];
+        S.ftran(col, rlist, tau, taulist);
+      }
       const double wr = w[r];
       for (int i : wlist) {
         if (i == r || w[i] == 0.0) continue;
