@@ -2,14 +2,15 @@
 // crossover requests (the reference runs its CPU dual simplex there: LP/solve.cu:295-347 run_dual_simplex, :383-443
 // run_concurrent; cpp/src/dual_simplex/).  Own implementation, nothing of the reference's simplex is linked or restated:
 // the textbook bounded dual simplex (dual steepest-edge pricing on the primal infeasibilities, Harris' two-pass dual ratio
-// test) on
+// test as a long-step rule: groups of breakpoints the row's infeasibility outlasts are flipped to their other bounds) on
 //     min c.x   s.t.  A x - s = 0,   lb <= x <= ub,   lo <= s <= hi
 // The basis is kept as a SPARSE LU factorisation (singleton columns and rows peeled off, the nucleus right-looking with
 // Markowitz' pivot choice under threshold partial pivoting; a dependent column is replaced by the slack of a row that found
 // no pivot) with middle-product-form updates between L and U (spike and row of U^-1: see ftran), refactorised when the update file has cost as much as a factorisation, at
 // the latest every 100 pivots (250 on large bases).  FTRAN / BTRAN start from the right-hand side's nonzeros (a depth-first
 // reach over the factors, kept by columns and by rows) and fall back to dense loops when the reach is large; the pivot row is
-// formed from the ROWS of A (only rows with a nonzero in row r of the inverse are visited).  Infinite bounds are boxed (+-BIG) so that ANY basis is
+// formed from the ROWS of A (only rows with a nonzero in row r of the inverse are visited, their nonbasic entries kept in front);
+// two solves of a pivot whose results nothing needs before its end run on a helper thread on larger LPs (SolveHelper).  Infinite bounds are boxed (+-BIG) so that ANY basis is
 // dual feasible once every nonbasic variable sits on the bound its reduced cost points to -- which is also what lets a
 // solve start from a basis guessed from another engine's solution (cuoptamd_dual_simplex_from: the crossover of a PDLP
 // solution -- a primal simplex, below, takes that basis to optimality first).  A solution that leans on a box bound is solved again with a 1000 times larger box, and if it still does,
@@ -304,20 +305,44 @@ struct Simplex {
           wx[i] = 0.0;
         }
       }
-      std::set<std::pair<int, int>> bycount;
-      for (int c = 0; c < q; ++c) key[c] = (int)cols[c].size(), bycount.emplace(key[c], c);
+      const auto tn1 = std::chrono::steady_clock::now();
+      if (debug) nsec[0] += std::chrono::duration<double>(tn1 - tf3).count();
+      // the columns by (count, index): a binary heap with lazy deletion -- an entry is current while its version is the column's
+      // (same order as an ordered set gives, without its two tree walks and a node per changed count)
+      struct ByCount {
+        int cnt, c, ver;
+        bool operator<(const ByCount& o) const { return cnt != o.cnt ? cnt > o.cnt : c > o.c; }  // (std::*_heap keep the LARGEST on top)
+      };
+      std::vector<ByCount> heap;
+      heap.reserve(4 * (size_t)q);
+      std::vector<int> ver(q, 0);
+      auto heap_push = [&](int c) { heap.push_back({key[c], c, ver[c]}), std::push_heap(heap.begin(), heap.end()); };
+      auto heap_pop_current = [&]() -> int {  // the shortest current column, taken out; -1 when there is none
+        while (!heap.empty()) {
+          std::pop_heap(heap.begin(), heap.end());
+          const ByCount t = heap.back();
+          heap.pop_back();
+          if (t.ver == ver[t.c]) return t.c;
+        }
+        return -1;
+      };
+      for (int c = 0; c < q; ++c) key[c] = (int)cols[c].size(), heap_push(c);
       factor_ops += 40 * (int64_t)q + 2 * (int64_t)nr;
       std::vector<char> gone(q, 0);
       std::vector<Entry> lmul;
       int polls = 0;
-      while (!bycount.empty() && k < m) {
+      int shortest[4];
+      while (k < m) {
         if ((++polls & 63) == 0 && flag_set(cancel)) throw Cancelled{};
         int pc = -1, pr = -1;
         double pval = 0.0;
         int64_t pcost = std::numeric_limits<int64_t>::max();
         int looked = 0;
-        for (auto it = bycount.begin(); it != bycount.end() && looked < 4; ++it, ++looked) {
-          const int c = it->second;
+        const auto ts0 = std::chrono::steady_clock::now();
+        for (; looked < 4; ++looked) {
+          const int c = heap_pop_current();
+          if (c < 0) break;
+          shortest[looked] = c;
           double colmax = 0.0;
           for (const Entry& e : cols[c]) colmax = std::max(colmax, std::fabs(e.v));
           factor_ops += 2 * (int64_t)cols[c].size() + 8;
@@ -327,18 +352,26 @@ struct Simplex {
             const int64_t cost = (int64_t)(rcnt[e.r] - 1) * (int64_t)(cols[c].size() - 1);
             if (cost < pcost || (cost == pcost && std::fabs(e.v) > std::fabs(pval))) pcost = cost, pc = c, pr = e.r, pval = e.v;
           }
-          if (pcost == 0) break;
+          if (pcost == 0) {
+            ++looked;
+            break;
+          }
         }
+        if (looked == 0) break;  // no column left
+        const auto ts1 = std::chrono::steady_clock::now();
+        if (debug) nsec[1] += std::chrono::duration<double>(ts1 - ts0).count();
+        for (int t = 0; t < looked; ++t)  // back with the ones that were only looked at (the pivot column / the one turned away stays out)
+          if (shortest[t] != (pc < 0 ? shortest[0] : pc)) heap_push(shortest[t]);
         if (pc < 0) {  // the shortest columns have nothing left: dependent on the pivots so far
-          const int c = bycount.begin()->second;
-          bycount.erase(bycount.begin());
+          const int c = shortest[0];
+          ++ver[c];
           gone[c] = 1;
           for (const Entry& e : cols[c]) rcnt[e.r]--;
           cols[c].clear();
           if (rejected) rejected->push_back(cand[nuc[c]]);
           continue;
         }
-        bycount.erase({key[pc], pc});
+        ++ver[pc];
         gone[pc] = 1;
         Ud.push_back(pval);
         for (const auto& u : ucol[pc]) Ui.push_back(u.first), Ux.push_back(u.second);
@@ -370,16 +403,15 @@ struct Simplex {
             for (size_t t = 0; t < before; ++t) where[col[t].r] = 0;
             factor_ops += (int64_t)before + (int64_t)lmul.size();
           }
-          bycount.erase({key[c], c});
-          key[c] = (int)col.size();
-          bycount.emplace(key[c], c);
-          factor_ops += 40 + (int64_t)at;  // (two walks through the ordered set)
+          if ((int)col.size() != key[c]) key[c] = (int)col.size(), ++ver[c], heap_push(c);
+          factor_ops += 40 + (int64_t)at;  // (the 40: the count order's upkeep, as the refactorisation rule was calibrated)
         }
         rows[pr].clear(), cols[pc].clear();
         ++k;
+        if (debug) nsec[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count();
       }
-      for (const auto& left : bycount)
-        if (rejected) rejected->push_back(cand[nuc[left.second]]);
+      for (int c = heap_pop_current(); c >= 0; c = heap_pop_current())
+        if (rejected) rejected->push_back(cand[nuc[c]]);
     } else if (!nuc.empty()) {
       for (int c : nuc)
         if (rejected) rejected->push_back(cand[c]);
@@ -421,6 +453,7 @@ struct Simplex {
       fsec[0] += ms(tf0, tf1), fsec[1] += ms(tf1, tf2), fsec[2] += ms(tf2, tf3), fsec[3] += ms(tf3, tf4), fsec[4] += ms(tf4, std::chrono::steady_clock::now());
     }
   }
+  double nsec[3] = {0, 0, 0};
   double fsec[5] = {0, 0, 0, 0, 0};  // debug, ms: ordering / set-up / triangular part / nucleus + tail / row-wise copies
   // ---- solves that start from a few nonzeros (Gilbert-Peierls): a depth-first search over the factor's structure finds the pivots
   // the right-hand side reaches, in topological order; only those are visited.  `from` (pivot numbers) seeds the search, `next(k, f)`
@@ -811,6 +844,7 @@ struct Simplex {
   int rebuilds = 0;
   int64_t ops_factor = 0, ops_solve = 0;
   double dens[6] = {0, 0, 0, 0, 0, 0};
+  int64_t bf_pass = 0, bf_grp = 0;
   double tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, factorisations, rebuild, duals + primal values, update file}
 };
 struct Lap {
@@ -820,20 +854,27 @@ struct Lap {
   ~Lap() { if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-// The steepest-edge weights need tau = B^-1 rho, a solve whose result nobody reads before the pivot's end.  On LPs where a solve is
-// worth a hand-over it runs on a helper thread -- own scratch, the same factors and update file, which nothing writes until the
-// pivot is done -- next to the pivot row, the ratio test and the entering column's solve.  One job at a time; the helper spins
-// briefly, then yields, while it waits for the next one.
-struct TauHelper {
+// Two solves of a pivot have results nobody reads before its end: tau = B^-1 rho for the steepest-edge weights, and the change of
+// the basic variables behind a set of bound flips.  On LPs where a solve is worth a hand-over they run on a helper thread -- own
+// scratch, the same factors and update file, which nothing writes until the pivot is done -- next to the pivot row, the ratio test
+// and the entering column's solve.  One job per slot at a time; the helper spins briefly, then yields, while it waits.
+struct SolveHelper {
+  struct Job {
+    std::vector<double> rhs;  // by ROW (handed back zeroed by the solve)
+    std::vector<int> rows;
+    std::vector<double>* out = nullptr;
+    std::vector<int>* outlist = nullptr;
+    std::atomic<int> state{0};  // 0 idle, 1 posted, 2 done
+  };
   Simplex& S;
-  std::vector<double> rhs;  // rho by ROW (handed back zeroed by the solve)
-  std::vector<int> rows;
-  std::vector<double>* tau  = nullptr;
-  std::vector<int>* taulist = nullptr;
+  Job job[2];
   Simplex::SolveWork W;
-  std::atomic<int> state{0};  // 0 idle, 1 posted, 2 done, 3 quit
+  std::atomic<int> quit{0};
   std::thread th;
-  explicit TauHelper(Simplex& s) : S(s), rhs(s.m, 0.0) {}
+  explicit SolveHelper(Simplex& s) : S(s)
+  {
+    for (Job& j : job) j.rhs.assign(s.m, 0.0);
+  }
   bool start()
   {
     try {
@@ -850,26 +891,36 @@ struct TauHelper {
   }
   void loop()
   {
+    int spins = 0;
     for (;;) {
-      int spins = 0, st;
-      while ((st = state.load(std::memory_order_acquire)) != 1 && st != 3) relax(spins);
-      if (st == 3) return;
-      S.ftran(rhs, rows, *tau, *taulist, false, &W);
-      state.store(2, std::memory_order_release);
+      bool worked = false;
+      for (Job& j : job)
+        if (j.state.load(std::memory_order_acquire) == 1) {
+          S.ftran(j.rhs, j.rows, *j.out, *j.outlist, false, &W);
+          j.state.store(2, std::memory_order_release);
+          worked = true;
+        }
+      if (worked) {
+        spins = 0;
+        continue;
+      }
+      if (quit.load(std::memory_order_acquire)) return;
+      relax(spins);
     }
   }
-  void post() { state.store(1, std::memory_order_release); }
-  void wait()
+  void post(int slot) { job[slot].state.store(1, std::memory_order_release); }
+  void wait(int slot)
   {
     int spins = 0;
-    while (state.load(std::memory_order_acquire) != 2) relax(spins);
-    state.store(0, std::memory_order_relaxed);
+    while (job[slot].state.load(std::memory_order_acquire) != 2) relax(spins);
+    job[slot].state.store(0, std::memory_order_relaxed);
   }
-  ~TauHelper()
+  ~SolveHelper()
   {
     if (!th.joinable()) return;
-    if (state.load(std::memory_order_acquire) == 1) wait();
-    state.store(3, std::memory_order_release);
+    for (int slot = 0; slot < 2; ++slot)
+      if (job[slot].state.load(std::memory_order_acquire) == 1) wait(slot);
+    quit.store(1, std::memory_order_release);
     th.join();
   }
 };
@@ -954,15 +1005,35 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   };
   gather();
   partition_rows();
-  std::unique_ptr<TauHelper> helper;
-  if (S.steepest && m >= cuopt_amd::tune_int("simplex_helper_rows", 2000) && std::thread::hardware_concurrency() >= 2) {
-    helper.reset(new TauHelper(S));
-    helper->tau = &tau, helper->taulist = &taulist;
+  const bool use_flips = cuopt_amd::tune_int("simplex_flips", 1) != 0;
+  std::vector<int> flips, fwlist, fstamp(m, 0);
+  std::vector<double> fw(m, 0.0);
+  int fstamp_now = 0;
+  std::unique_ptr<SolveHelper> helper;
+  if (m >= cuopt_amd::tune_int("simplex_helper_rows", 2000) && std::thread::hardware_concurrency() >= 2) {
+    helper.reset(new SolveHelper(S));
+    helper->job[0].out = &tau, helper->job[0].outlist = &taulist;
+    helper->job[1].out = &fw, helper->job[1].outlist = &fwlist;
     if (!helper->start()) helper.reset();
   }
-  bool tau_posted = false;
-  auto finish_tau = [&] {
-    if (tau_posted) helper->wait(), tau_posted = false;
+  bool tau_posted = false, flips_posted = false;
+  auto finish_tau = [&] {  // (every way out of a pivot passes here: nothing of the helper's is in flight when the factors change)
+    if (tau_posted) helper->wait(0), tau_posted = false;
+    if (flips_posted) helper->wait(1), flips_posted = false;
+  };
+  auto flip_rhs = [&](std::vector<double>& dst, std::vector<int>& rows) {  // sum_j N_j (other bound_j - bound_j) over the flips, by row
+    rows.clear();
+    ++fstamp_now;
+    auto add = [&](int i, double v) {
+      if (fstamp[i] != fstamp_now) fstamp[i] = fstamp_now, rows.push_back(i);
+      dst[i] += v;
+    };
+    for (int j : flips) {
+      const double dx = S.atU[j] ? S.L[j] - S.U[j] : S.U[j] - S.L[j];
+      if (j >= n) add(j - n, -dx);
+      else
+        for (int k = S.cp[j]; k < S.cp[j + 1]; ++k) add(S.ci[k], S.cv[k] * dx);
+    }
   };
   std::vector<int> cand_j;  // the ratio test's candidates (sign-eligible entries of the pivot row), compact: column, |alpha|, |d|
   std::vector<double> cand_a, cand_d;
@@ -996,18 +1067,18 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     }
     const int p        = S.basic[r];
     const bool to_low  = S.z[p] < S.L[p];
-    const double delta = to_low ? S.L[p] - S.z[p] : S.U[p] - S.z[p];  // change the leaving variable needs
+    double delta = to_low ? S.L[p] - S.z[p] : S.U[p] - S.z[p];  // change the leaving variable needs
     const double sigma = to_low ? 1.0 : -1.0;
     // row r of the inverse, then of the tableau (from the rows of A that row touches)
     for (int i : rlist) rho[i] = 0.0;
     tvec[r] = 1.0;
     tlist.assign(1, r);
     { Lap lap(S, 1); S.btran(tvec, tlist, rho, rlist); }
-    if (helper) {  // tau = B^-1 rho starts now (see TauHelper); every way out of this pivot passes finish_tau()
+    if (helper && S.steepest) {  // tau = B^-1 rho starts now (see SolveHelper); every way out of this pivot passes finish_tau()
       for (int i : taulist) tau[i] = 0.0;
-      for (int i : rlist) helper->rhs[i] = rho[i];
-      helper->rows = rlist;
-      helper->post(), tau_posted = true;
+      for (int i : rlist) helper->job[0].rhs[i] = rho[i];
+      helper->job[0].rows = rlist;
+      helper->post(0), tau_posted = true;
     }
     ++sweep;
     touched.clear();
@@ -1076,6 +1147,35 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       if (reach >= 0.5 * worst_inf) return 7;
       return 2;
     }
+    // Bound flipping (the long-step rule; the reference's simplex: phase2.cpp:348-470): the row's infeasibility |delta| is the slope of
+    // the dual objective along this step; passing the breakpoint of candidate j costs |alpha_j| (U_j - L_j) of it.  While the slope
+    // stays positive behind a whole Harris group, the group is FLIPPED to its other bounds instead of one of it entering, and the
+    // test moves on to the next group: one pivot does the work of several.  Not across a group that holds a degenerate breakpoint
+    // (|d_j| within the tolerance: passing those for free is what cycles on dual degenerate LPs), and never ONTO an artificial
+    // bound (in the LP itself that range is infinite).
+    flips.clear();
+    if (use_flips) {
+      Lap lap(S, 3);
+      double slope = std::fabs(delta);
+      for (int passes = 0; passes < 64; ++passes) {
+        double sum = 0.0, tnext = kInf;
+        bool stop = false;
+        for (size_t c = 0; c < cand_j.size() && !stop; ++c) {
+          if (cand_a[c] <= ptol) continue;
+          if (cand_d[c] / cand_a[c] <= tmax) {
+            const int j = cand_j[c];
+            if (cand_d[c] <= tol_d || (S.atU[j] ? S.boxedL[j] != 0 : S.boxedU[j] != 0)) stop = true;
+            sum += cand_a[c] * (S.U[j] - S.L[j]);
+          } else {
+            tnext = std::min(tnext, (cand_d[c] + tol_d) / cand_a[c]);
+          }
+        }
+        if (stop || tnext == kInf || slope - sum < 0.0) break;  // the entering variable comes from this group
+        for (size_t c = 0; c < cand_j.size(); ++c)
+          if (cand_a[c] > ptol && cand_d[c] / cand_a[c] <= tmax) flips.push_back(cand_j[c]), cand_a[c] = 0.0;  // out of the test
+        slope -= sum, tmax = tnext;
+      }
+    }
     int q        = -1;
     double apick = 0.0;
     { Lap lap(S, 3);
@@ -1085,6 +1185,11 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     if (q < 0) {
       finish_tau();
       return 7;
+    }
+    if (helper && !flips.empty()) {  // the basic variables' answer to the flips: the helper's second job (behind tau)
+      for (int i : fwlist) fw[i] = 0.0;
+      flip_rhs(helper->job[1].rhs, helper->job[1].rows);
+      helper->post(1), flips_posted = true;
     }
     // entering column
     for (int i : wlist) w[i] = 0.0;
@@ -1107,7 +1212,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       for (int i : rlist) br += rho[i] * rho[i];
       S.beta[p] = br;  // exact, whatever the updates had made of it
       if (tau_posted) {
-        finish_tau();
+        helper->wait(0), tau_posted = false;
       } else {
         for (int i : taulist) tau[i] = 0.0;
         for (int i : rlist) col[i] = rho[i];
@@ -1130,6 +1235,23 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       if (alpha[j] != 0.0) S.d[j] -= theta * alpha[j];
     S.d[q] = 0.0;
     S.d[p] = -theta;
+    // the flipped variables jump to their other bounds (their reduced costs have just changed sign); the basic ones follow:
+    // z_B -= B^-1 sum_j N_j (new_j - old_j), the leaving variable among them -- the slope left says it is still short of its bound
+    if (!flips.empty()) {
+      if (flips_posted) {
+        helper->wait(1), flips_posted = false;
+      } else {
+        for (int i : fwlist) fw[i] = 0.0;
+        flip_rhs(col, clist);
+        Lap lap(S, 4);
+        S.ftran(col, clist, fw, fwlist);
+      }
+      for (int j : flips) S.atU[j] = !S.atU[j], S.z[j] = S.atU[j] ? S.U[j] : S.L[j];
+      for (int i : fwlist)
+        if (fw[i] != 0.0) S.z[S.basic[i]] -= fw[i], pinf[i] = infeasibility(i), note(i);
+      delta = to_low ? S.L[p] - S.z[p] : S.U[p] - S.z[p];
+      if (S.debug) ++S.bf_pass, S.bf_grp += (int64_t)flips.size();
+    }
     // primal: the entering variable moves by step, the basic ones by -w step
     const double step = -delta / w[r];
     S.z[q] += step;
@@ -1429,6 +1551,8 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   int total_iterations = 0;
   auto print_seconds = [&] {
     std::fprintf(stderr, "[simplex] per pivot: rho %.0f, w %.0f, tau %.0f, touched %.0f, update entries %.0f, L+U %.0f (m %d)\n", S.dens[0] / std::max(1, S.iterations), S.dens[1] / std::max(1, S.iterations), S.dens[2] / std::max(1, S.iterations), S.dens[3] / std::max(1, S.iterations), S.dens[4] / std::max(1, S.iterations), S.dens[5] / std::max(1, S.iterations), S.m);
+    std::fprintf(stderr, "[simplex] pivots with bound flips: %lld (flips %lld)\n", (long long)S.bf_pass, (long long)S.bf_grp);
+    std::fprintf(stderr, "[simplex] nucleus s: columns through the triangular part %.2f, pivot search %.2f, elimination %.2f\n", S.nsec[0], S.nsec[1], S.nsec[2]);
     std::fprintf(stderr, "[simplex] factorisation ms: ordering %.0f, set-up %.0f, triangular part %.0f, nucleus %.0f, row-wise copies %.0f\n", S.fsec[0], S.fsec[1], S.fsec[2], S.fsec[3], S.fsec[4]);
     std::fprintf(stderr, "[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ratio test %.2f, ftran %.2f, weights %.2f, values %.2f (update file %.2f), rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[3], S.tsec[4], S.tsec[5], S.tsec[8], S.tsec[9], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
   };

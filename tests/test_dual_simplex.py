@@ -309,6 +309,32 @@ def test_sparse_and_dense_solves_walk_the_same_pivots(monkeypatch):
     assert runs["dense"][1] == pytest.approx(runs["sparse"][1], rel=1e-12) and runs["dense"][3] == pytest.approx(runs["sparse"][3], rel=1e-12)
 
 
+def test_bound_flipping_ratio_test_and_the_helper_thread(monkeypatch):
+    """The long-step rule (phase2.cpp:348-470 is the reference's): a Harris group whose breakpoints the row's infeasibility outlasts is
+    flipped to its other bounds instead of one of it entering.  Same optimum with and without it, fewer pivots with it where the
+    start leans on bounds far away (the boxed infinite bounds of a cold start; 0/1 boxes); the two solves a pivot hands to the helper
+    thread (weights, the basic variables' answer to the flips) give the same pivots as the same solves done in line."""
+    from cuopt_amd import synthetic
+    rng = np.random.default_rng(12)
+    boxed = synthetic.generate(600, 900, 5, seed=8)
+    boxed = dict(boxed, lb=np.zeros(900), ub=np.where(rng.random(900) < 0.7, 1.0 + np.abs(boxed["x_star"]), np.inf))  # (x_star stays feasible)
+    cases = [("block angular", synthetic.generate_structured("block_angular", 3000, 3000, 6, seed=3), True),
+             ("random", synthetic.generate(1500, 1200, 5, seed=2), False), ("boxed", boxed, False)]
+    for name, p, expect_fewer in cases:
+        out = {}
+        for flips, helper_rows in ((0, 1 << 30), (1, 1 << 30), (1, 1)):
+            set_tune(monkeypatch, simplex_flips=flips, simplex_helper_rows=helper_rows)
+            r = capi.dual_simplex(p, time_limit=200)
+            assert r["status"] == "Optimal", (name, flips)
+            _check_vertex(p, r, tol=1e-6)
+            out[(flips, helper_rows == 1)] = (r["iterations"], r["objective"])
+        assert out[(1, False)] == out[(1, True)], name  # the helper changes who solves, not what
+        assert out[(0, False)][1] == pytest.approx(out[(1, False)][1], rel=1e-9, abs=1e-9), name
+        if expect_fewer:
+            assert out[(1, False)][0] < 0.8 * out[(0, False)][0], (name, out)
+    set_tune(monkeypatch, simplex_flips=None, simplex_helper_rows=None)
+
+
 def _lp(rows, c, lo, hi, lb, ub, maximize=False):
     import scipy.sparse as sp
     A = sp.csr_matrix(np.asarray(rows, float))
