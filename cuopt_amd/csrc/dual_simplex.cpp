@@ -884,10 +884,11 @@ struct SolveHelper {
     }
     return true;
   }
-  static void relax(int& spins)
-  {
+  static void relax(int& spins)  // a short spin (a pivot's jobs follow each other within microseconds), then yields, then naps:
+  {                               // an idle helper next to a slow main loop must not keep a core busy for the length of the solve
     if (++spins < 4000) __builtin_ia32_pause();
-    else std::this_thread::yield();
+    else if (spins < 8000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
   void loop()
   {
@@ -912,7 +913,10 @@ struct SolveHelper {
   void wait(int slot)
   {
     int spins = 0;
-    while (job[slot].state.load(std::memory_order_acquire) != 2) relax(spins);
+    while (job[slot].state.load(std::memory_order_acquire) != 2) {  // (the helper is at work on it: no naps on this side)
+      if (++spins < 4000) __builtin_ia32_pause();
+      else std::this_thread::yield();
+    }
     job[slot].state.store(0, std::memory_order_relaxed);
   }
   ~SolveHelper()
