@@ -33,6 +33,7 @@
 
 #include "cuopt_amd/pdlp_solver.h"
 #include "host_parallel.hpp"
+#include "simplex_presolve.hpp"
 
 namespace {
 
@@ -1491,8 +1492,54 @@ int start_from_point(Simplex& S, const double* x0, const double* y0, double /*se
   return code;
 }
 
+int solve_core(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
+               int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc);
+
+// The engine behind a presolve (simplex_presolve.hpp: empty rows and columns, singleton rows, fixed columns) and the way back.
+// CUOPT_AMD_TUNE="simplex_presolve=0" solves the LP as it comes.
 int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
           int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
+{
+  if (!lp || !status) return -1;
+  const int m = lp->m, n = lp->n;
+  if (m <= 0 || n <= 0 || lp->offsets[m] > 40000000 || cuopt_amd::tune_int("simplex_presolve", 1) == 0)
+    return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  cuopt_amd::SimplexPresolve P;
+  if (!P.run(lp)) return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  const bool debug = cuopt_amd::tune_int("simplex_debug", 0) != 0;
+  if (debug)
+    std::fprintf(stderr, "[simplex] presolve: %d of %d rows and %d of %d columns removed%s\n", P.removed_rows, m, P.removed_cols, n, P.infeasible ? ", infeasible" : "");
+  if (iterations) *iterations = 0;
+  if (P.infeasible) {
+    *status = 2;
+    return 0;
+  }
+  if (P.reduced.m == 0 && P.reduced.n > 0)  // columns whose cost points to an infinite bound are all that is left: the engine's call
+    return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  std::vector<double> px((size_t)n, 0.0), py((size_t)m, 0.0), prc((size_t)n, 0.0);
+  if (P.reduced.n == 0) {
+    *status = 1;  // nothing left to decide
+  } else {
+    std::vector<double> cx0, cy0;
+    if (x0) {
+      for (int j : P.cols) cx0.push_back(x0[j]);
+      if (y0)
+        for (int i : P.rows) cy0.push_back(y0[i]);
+    }
+    const int ret = solve_core(&P.reduced, x0 ? cx0.data() : nullptr, x0 && y0 ? cy0.data() : nullptr, time_limit, iteration_limit, cancel, status,
+                               iterations, nullptr, px.data(), py.data(), prc.data());
+    if (ret != 0 || *status != 1) return ret;
+  }
+  const double obj = P.undo(lp, px.data(), py.data(), prc.data());
+  if (objective) *objective = obj;
+  if (x) std::copy(px.begin(), px.end(), x);
+  if (y) std::copy(py.begin(), py.end(), y);
+  if (rc) std::copy(prc.begin(), prc.end(), rc);
+  return 0;
+}
+
+int solve_core(const cuoptamd_lp* lp, const double* x0, const double* y0, double time_limit, int32_t iteration_limit, const volatile int32_t* cancel,
+               int32_t* status, int32_t* iterations, double* objective, double* x, double* y, double* rc)
 {
   if (!lp || !status) return -1;
   const auto t0 = std::chrono::steady_clock::now();

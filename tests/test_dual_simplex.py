@@ -388,3 +388,74 @@ def test_a_maximisation_returns_the_duals_of_the_converted_minimisation():
     assert r["status"] == "Optimal"
     _check_vertex(p, r)
     assert np.all(r["y"] <= 1e-9)  # binding <= rows of a minimisation have non-positive multipliers in the c - A^T y convention
+
+
+def test_presolve_and_the_way_back(monkeypatch):
+    """simplex_presolve.hpp (the reference's simplex removes empty rows / columns and fixed variables first, presolve.cpp:26-212,585-662;
+    singleton rows are added here): same verdicts and optima with and without it, and the restored duals are a vertex's -- a bound
+    that came from a singleton row hands its multiplier to that row"""
+    inf = np.inf
+    # x0 >= 2 through a singleton row (active: the row carries the dual), -x1 >= -3 (an upper bound through a negative entry), a
+    # singleton equality that fixes x2 and makes row 3 a singleton in turn, an empty row, an empty column with a cost
+    p = _lp([[1, 0, 0, 0, 0], [0, -1, 0, 0, 0], [0, 0, 2, 0, 0], [0, 0, 1, 1, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 0]],
+            c=[1, -1, 1, 1, -2], lo=[2, -3, 4, 5, -1, -inf], hi=[inf, inf, 4, inf, 1, 100], lb=[0, 0, 0, 0, 0], ub=[inf, inf, inf, inf, 7])
+    for pre in (0, 1):
+        set_tune(monkeypatch, simplex_presolve=pre)
+        r = capi.dual_simplex(p)
+        assert r["status"] == "Optimal" and r["iterations"] == (0 if pre else r["iterations"])
+        assert r["objective"] == pytest.approx(2 - 3 + 2 + 3 - 14) and np.allclose(r["x"], [2, 3, 2, 3, 7])
+        _check_vertex(p, r)
+        assert r["y"][0] == pytest.approx(1.0) and r["y"][1] == pytest.approx(1.0) and r["y"][4] == 0.0 and r["reduced_cost"][4] == pytest.approx(-2.0)
+    # the same as a maximisation of -c; infeasible by an empty row, by crossing singleton rows
+    q = dict(p, c=-p["c"], maximize=True)
+    set_tune(monkeypatch, simplex_presolve=1)
+    r = capi.dual_simplex(q)
+    assert r["status"] == "Optimal" and r["objective"] == pytest.approx(10.0)
+    _check_vertex(q, r)
+    assert capi.dual_simplex(dict(p, lo=np.array([2, -3, 4, 5, 0.5, -inf])))["status"] == "PrimalInfeasible"
+    assert capi.dual_simplex(_lp([[1, 0], [1, 0], [1, 1]], [1, 1], [3, -inf, 0], [inf, 2, 10], [0, 0], [inf, inf]))["status"] == "PrimalInfeasible"
+    # an empty column whose cost points to an infinite bound is the engine's to judge: unbounded here, infeasible there
+    assert capi.dual_simplex(_lp([[1, 0], [1, 0]], [1, -1], [1, -inf], [inf, 5], [0, 0], [inf, inf]))["status"] == "Unbounded"
+    assert capi.dual_simplex(_lp([[1, 0], [1, 0]], [1, -1], [6, -inf], [inf, 5], [0, 0], [inf, inf]))["status"] == "PrimalInfeasible"
+    # random LPs with such rows and columns mixed in: HiGHS agrees, with and without
+    from scipy.optimize import linprog
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    for trial in range(6):
+        m, n = 40 + 10 * trial, 60 + 5 * trial
+        A = sp.random(m, n, density=0.08, random_state=trial, format="lil")
+        for i in rng.choice(m, 8, replace=False):  # singleton rows
+            A[i, :] = 0
+            A[i, rng.integers(n)] = rng.choice([-2.0, 0.5, 1.0, 3.0])
+        A[rng.choice(m, 2, replace=False), :] = 0  # empty rows
+        for j in rng.choice(n, 3, replace=False):  # empty columns
+            A[:, j] = 0
+        A = sp.csr_matrix(A)
+        A.eliminate_zeros()
+        xs = rng.uniform(0, 2, n)
+        ax = A @ xs
+        lo = np.where(rng.random(m) < 0.6, ax - rng.uniform(0, 1, m), -inf)
+        hi = np.where(rng.random(m) < 0.6, ax + rng.uniform(0, 1, m), inf)
+        eq = rng.random(m) < 0.15
+        lo, hi = np.where(eq, ax, lo), np.where(eq, ax, hi)
+        lb, ub = np.zeros(n), np.where(rng.random(n) < 0.5, 3.0, inf)
+        fixed = rng.choice(n, 4, replace=False)
+        lb[fixed] = ub[fixed] = xs[fixed]
+        c = rng.standard_normal(n)
+        c[np.diff(A.tocsc().indptr) == 0] = np.abs(c[np.diff(A.tocsc().indptr) == 0])  # (empty columns: towards their finite bound)
+        p = dict(m=m, n=n, offsets=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32), values=A.data, c=c, lo=lo, hi=hi, lb=lb, ub=ub,
+                 maximize=False, objective_offset=0.5)
+        Aub = sp.vstack([A[np.isfinite(hi)], -A[np.isfinite(lo)]])
+        bub = np.concatenate([hi[np.isfinite(hi)], -lo[np.isfinite(lo)]])
+        ref = linprog(c, A_ub=Aub, b_ub=bub, bounds=list(zip(lb, [None if not np.isfinite(u) else u for u in ub])), method="highs")
+        out = []
+        for pre in (0, 1):
+            set_tune(monkeypatch, simplex_presolve=pre)
+            r = capi.dual_simplex(p)
+            if ref.status == 0:
+                assert r["status"] == "Optimal" and r["objective"] == pytest.approx(ref.fun + 0.5, rel=1e-8, abs=1e-8), (trial, pre)
+                _check_vertex(p, r, tol=1e-6)
+            else:
+                assert r["status"] in ("PrimalInfeasible", "Unbounded", "NumericalError"), (trial, pre, ref.status)
+            out.append(r["iterations"])
+    set_tune(monkeypatch, simplex_presolve=None)
