@@ -887,8 +887,8 @@ struct SolveHelper {
   }
   static void relax(int& spins)  // a short spin (a pivot's jobs follow each other within microseconds), then yields, then naps:
   {                               // an idle helper next to a slow main loop must not keep a core busy for the length of the solve
-    if (++spins < 4000) __builtin_ia32_pause();
-    else if (spins < 8000) std::this_thread::yield();
+    if (++spins < 20000) __builtin_ia32_pause();  // (about a millisecond: the next pivot's job is usually here by then)
+    else if (spins < 40000) std::this_thread::yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
   void loop()
