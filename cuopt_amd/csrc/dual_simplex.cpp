@@ -41,7 +41,7 @@ namespace {
 inline bool flag_set(const volatile int32_t* flag) { return flag && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0; }
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
-constexpr int kRefactorEvery = 100;  // pivots between factorisations at the latest (250 from 20 000 rows on: a factorisation walks all of them)
+constexpr int kRefactorEvery = 100;  // pivots between factorisations at the latest in the primal simplex; the dual simplex: 500 (the entry counts decide before that)
 
 struct Cancelled {};  // thrown out of a factorisation when the other engine of a Concurrent solve has finished
 
@@ -87,6 +87,7 @@ struct Simplex {
   std::vector<int> inpat, pattern, mark, topo, dstack, dptr, rowcnt;
   int stamp = 0, nucleus = 0;
   int64_t factor_ops = 0;  // work of the last factorisation (entries touched): what a refactorisation is weighed against
+  int64_t factor_flops = 0;  // ... its share in the elimination's inner loops (multiply-adds on contiguous columns: cheap per entry), counted apart
 
   int col_count(int j) const { return j >= n ? 1 : cp[j + 1] - cp[j]; }
   double col_dot(const double* row, int j) const  // row . M_j
@@ -176,7 +177,7 @@ struct Simplex {
     for (int c = nc; c < (int)cand.size(); ++c) tail.push_back(c);
     std::stable_sort(tail.begin(), tail.end(), [&](int x, int y) { return col_count(cand[x]) < col_count(cand[y]); });
     rowcnt.swap(rcount);
-    factor_ops = rstart[m];
+    factor_ops = rstart[m], factor_flops = 0;
     pinv.assign(m, -1), prow.assign(m, -1);
     Lp.assign(1, 0), Up.assign(1, 0);
     Li.clear(), Lx.clear(), Ui.clear(), Ux.clear(), Ud.clear();
@@ -402,7 +403,7 @@ struct Simplex {
               else col.push_back({l.r, -l.v * u}), rows[l.r].push_back(c), rcnt[l.r]++;
             }
             for (size_t t = 0; t < before; ++t) where[col[t].r] = 0;
-            factor_ops += (int64_t)before + (int64_t)lmul.size();
+            factor_flops += (int64_t)before + (int64_t)lmul.size();
           }
           if ((int)col.size() != key[c]) key[c] = (int)col.size(), ++ver[c], heap_push(c);
           factor_ops += 40 + (int64_t)at;  // (the 40: the count order's upkeep, as the refactorisation rule was calibrated)
@@ -815,7 +816,7 @@ struct Simplex {
     std::vector<int> rejected, cand(basic);
     const size_t eta_entries = update_entries();
     factor(cand, &rejected);
-    if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(), ops_factor += factor_ops;
+    if (debug) tsec[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(), ops_factor += factor_ops + factor_flops;
     for (int j : rejected) {  // left the basis: onto the nearer bound
       atU[j] = std::fabs(U[j] - z[j]) < std::fabs(z[j] - L[j]);
       z[j]   = atU[j] ? U[j] : L[j];
@@ -1040,6 +1041,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
         for (int k = S.cp[j]; k < S.cp[j + 1]; ++k) add(S.ci[k], S.cv[k] * dx);
     }
   };
+  const int refactor_cap = (int)cuopt_amd::tune_int("simplex_refactor", 500);
   std::vector<int> cand_j;  // the ratio test's candidates (sign-eligible entries of the pivot row), compact: column, |alpha|, |d|
   std::vector<double> cand_a, cand_d;
   for (;;) {
@@ -1276,9 +1278,11 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.update_entries();
     if (S.debug) S.ops_solve += (S.steepest ? 3 : 2) * ((int64_t)S.update_entries() + (int64_t)S.Li.size() + (int64_t)S.Ui.size() + 2 * (int64_t)m);
     // (the factorisation's count is of entries touched; its depth-first searches and pivot choices make an entry cost ~8 times
-    // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s)
-    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
-    if (++since_refactor >= (m >= 20000 ? 250 : kRefactorEvery) || extra_ops >= rebuild_ops) rebuild();
+    // what one costs in a solve: calibrated on a 10 000-row block-angular LP, 79 s -> 58 s; the multiply-adds of the nucleus'
+    // elimination run over contiguous columns and cost about two solve entries each -- counted apart since a random 4000 x 3000
+    // LP, whose nucleus fills in to 400 000 entries, spent 56 % of its time refactorising at a cap of 100 pivots: 15.5 -> 10.9 s)
+    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * S.factor_flops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
+    if (++since_refactor >= refactor_cap || extra_ops >= rebuild_ops) rebuild();
   }
 }
 
@@ -1411,7 +1415,7 @@ int run_primal(Simplex& S, int iteration_limit, double time_limit, const std::ch
     S.pos[p] = -1, S.pos[q] = r, S.basic[r] = q;
     S.iterations += 1;
     extra_ops += 2 * (int64_t)S.update_entries();
-    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
+    const int64_t rebuild_ops = 8 * S.factor_ops + 2 * S.factor_flops + 2 * (int64_t)S.cp[n] + 4 * ((int64_t)S.Li.size() + (int64_t)S.Ui.size()) + 8 * (int64_t)m;
     if (++since_refactor >= kRefactorEvery || extra_ops >= rebuild_ops) {
       S.rebuild_plain();
       since_refactor = 0, extra_ops = 0;
