@@ -1506,10 +1506,19 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
 {
   if (!lp || !status) return -1;
   const int m = lp->m, n = lp->n;
-  if (m <= 0 || n <= 0 || lp->offsets[m] > 40000000 || cuopt_amd::tune_int("simplex_presolve", 1) == 0)
+  // (an LP beyond the engine's limits is turned away by solve_core as it comes: no presolve is spent on it)
+  int64_t max_rows = 200000, max_nnz = 4000000;
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_MAX_ROWS")) max_rows = std::atoll(e);
+  if (const char* e = std::getenv("CUOPT_AMD_SIMPLEX_MAX_NNZ")) max_nnz = std::atoll(e);
+  if (m <= 0 || n <= 0 || m > max_rows || (int64_t)n + m > 20 * max_rows || lp->offsets[m] > max_nnz || cuopt_amd::tune_int("simplex_presolve", 1) == 0)
     return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
   cuopt_amd::SimplexPresolve P;
-  if (!P.run(lp)) return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  if (!P.run(lp, cancel)) return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  if (P.cancelled) {
+    *status = 9;
+    if (iterations) *iterations = 0;
+    return 0;
+  }
   const bool debug = cuopt_amd::tune_int("simplex_debug", 0) != 0;
   if (debug)
     std::fprintf(stderr, "[simplex] presolve: %d of %d rows and %d of %d columns removed%s\n", P.removed_rows, m, P.removed_cols, n, P.infeasible ? ", infeasible" : "");

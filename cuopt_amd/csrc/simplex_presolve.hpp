@@ -41,31 +41,41 @@ struct SimplexPresolve {
 
   static bool finite(double v) { return std::isfinite(v); }
 
-  // false: nothing to remove (use the LP as it is)
-  bool run(const cuoptamd_lp* lp)
+  bool cancelled = false;
+  // false: nothing to remove (use the LP as it is).  `cancel`: the flag of a Concurrent solve's other engine -- looked at while the
+  // matrix is walked (run() returns true with `cancelled` set)
+  bool run(const cuoptamd_lp* lp, const volatile int32_t* cancel = nullptr)
   {
+    auto stop = [&] { return cancel && __atomic_load_n(const_cast<const int32_t*>(cancel), __ATOMIC_ACQUIRE) != 0 ? (cancelled = true) : false; };
     const int m = lp->m, n = lp->n;
     const double sense = lp->maximize ? -1.0 : 1.0;
     const int64_t nnz = lp->offsets[m];
     // columns of A
     std::vector<int32_t> cp(n + 1, 0), ci((size_t)nnz);
     std::vector<double> cv((size_t)nnz);
-    for (int64_t k = 0; k < nnz; ++k) cp[lp->indices[k] + 1]++;
+    for (int64_t k = 0; k < nnz; ++k) {
+      if ((k & 0xFFFF) == 0 && stop()) return true;
+      cp[lp->indices[k] + 1]++;
+    }
     for (int j = 0; j < n; ++j) cp[j + 1] += cp[j];
     {
       std::vector<int32_t> cur(cp.begin(), cp.end() - 1);
-      for (int i = 0; i < m; ++i)
+      for (int i = 0; i < m; ++i) {
+        if ((i & 0xFFF) == 0 && stop()) return true;
         for (int k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k) {
           const int q = cur[lp->indices[k]]++;
           ci[q] = i, cv[q] = lp->values[k];
         }
+      }
     }
     std::vector<double> rlo(lp->lo, lp->lo + m), rhi(lp->hi, lp->hi + m), xl(lp->lb, lp->lb + n), xu(lp->ub, lp->ub + n);
     std::vector<int> rcount(m, 0), ccount(n, 0);
     std::vector<char> ralive(m, 1), calive(n, 1);
-    for (int i = 0; i < m; ++i)
+    for (int i = 0; i < m; ++i) {
+      if ((i & 0xFFF) == 0 && stop()) return true;
       for (int k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k)
         if (lp->values[k] != 0.0) rcount[i]++, ccount[lp->indices[k]]++;
+    }
     std::vector<int> rq, cq;  // rows / columns to look at
     for (int i = 0; i < m; ++i)
       if (rcount[i] <= 1) rq.push_back(i);
@@ -138,6 +148,7 @@ struct SimplexPresolve {
       if (calive[j]) cnew[j] = (int)cols.size(), cols.push_back(j);
     off.assign(1, 0);
     for (int i = 0; i < m; ++i) {
+      if ((i & 0xFFF) == 0 && stop()) return true;
       if (!ralive[i]) continue;
       rows.push_back(i);
       for (int k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k)
