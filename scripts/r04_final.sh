@@ -1,5 +1,5 @@
 # round 4, final tree: the whole GPU suite, smoke, every bench workload (one line each), rocprof kernel stats of c3 / dense_rows
-O=$GRAFT_REPO_ROOT/gpurun_out/r04_final; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r04_final2; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 5 1200 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; tail -4 $O/pytest_all.log; grep -E "^FAILED" $O/pytest_all.log | head
 timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
