@@ -41,6 +41,10 @@ namespace {
 inline bool flag_set(const volatile int32_t* flag) { return flag && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0; }
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
+// threshold partial pivoting in the nucleus: a pivot is at least this share of its column's largest entry.  0.1 -> 0.01 leaves Markowitz
+// more choice: 15 % fewer entries in L + U of a random 4000 x 3000 LP's bases (11.6 -> 9.3 s), 7-25 % less time on staircase / power-law
+// LPs; the drift check behind every entering column's solve is what watches the growth this allows
+constexpr double kPivotThreshold = 0.01;
 constexpr int kRefactorEvery = 100;  // pivots between factorisations at the latest in the primal simplex; the dual simplex: 500 (the entry counts decide before that)
 
 struct Cancelled {};  // thrown out of a factorisation when the other engine of a Concurrent solve has finished
@@ -281,7 +285,7 @@ struct Simplex {
     const auto tf3 = std::chrono::steady_clock::now();
     // ---- the nucleus: right-looking elimination with Markowitz' pivot choice.  Every nucleus column is first taken through the
     // triangular part (its U entries there), what is left of it lives in `cols` (local row numbers); a pivot is the entry with the
-    // smallest (row count - 1)(column count - 1) among the entries within a factor 10 of their column's largest, looked for in
+    // smallest (row count - 1)(column count - 1) among the entries within a factor 100 of their column's largest, looked for in
     // the four shortest columns; the pivot row goes to the U columns of the columns it touches, the multipliers to L.
     if (!nuc.empty() && k < m) {
       struct Entry {
@@ -350,7 +354,7 @@ struct Simplex {
           factor_ops += 2 * (int64_t)cols[c].size() + 8;
           if (colmax <= std::max(1e-11, 1e-9 * cmax0[c])) continue;  // (turned away below when it is the shortest one)
           for (const Entry& e : cols[c]) {
-            if (std::fabs(e.v) < 0.1 * colmax) continue;
+            if (std::fabs(e.v) < kPivotThreshold * colmax) continue;
             const int64_t cost = (int64_t)(rcnt[e.r] - 1) * (int64_t)(cols[c].size() - 1);
             if (cost < pcost || (cost == pcost && std::fabs(e.v) > std::fabs(pval))) pcost = cost, pc = c, pr = e.r, pval = e.v;
           }
