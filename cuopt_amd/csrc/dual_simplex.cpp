@@ -658,11 +658,15 @@ struct Simplex {
         if (t[j] != 0.0) et_i.push_back(prow[j]), et_x.push_back(t[j]);
       }
     } else {
-      for (int k = 0; k < m; ++k) {
-        double sv = t[k];
-        for (int e = Up[k]; e < Up[k + 1]; ++e) sv -= Ux[e] * t[Ui[e]];
-        t[k] = sv / Ud[k];
-        if (t[k] != 0.0) et_i.push_back(prow[k]), et_x.push_back(t[k]);
+      // (too many pivots reached for the search to pay: all of them in their natural order, by the ROWS of U as above -- a position
+      //  that is still zero costs a load, not its row; the dot-product form over U's columns touched every entry of U)
+      for (int j = 0; j < m; ++j) {
+        double sv = t[j];
+        if (sv == 0.0) continue;
+        sv /= Ud[j];
+        t[j] = sv;
+        for (int e = URp[j]; e < URp[j + 1]; ++e) t[URi[e]] -= URx[e] * sv;
+        if (sv != 0.0) et_i.push_back(prow[j]), et_x.push_back(sv);
       }
     }
     // ---- the updates, last one first
@@ -693,14 +697,14 @@ struct Simplex {
         return;
       }
     }
-    for (int k = m - 1; k >= 0; --k) {
-      double sv = t[k];
-      for (int e = Lp[k]; e < Lp[k + 1]; ++e) sv -= Lx[e] * rho[Li[e]];
-      rho[prow[k]] = sv;
+    for (int kk = m - 1; kk >= 0; --kk) {  // by the rows of L, every position; zeros skipped
+      const double v = t[kk];
+      if (v == 0.0) continue;
+      t[kk]         = 0.0;
+      rho[prow[kk]] = v;
+      rlist.push_back(prow[kk]);
+      for (int e = LRp[kk]; e < LRp[kk + 1]; ++e) t[LRi[e]] -= LRx[e] * v;
     }
-    std::fill(t.begin(), t.end(), 0.0);
-    for (int i = 0; i < m; ++i)
-      if (rho[i] != 0.0) rlist.push_back(i);
   }
   bool debug = false;
   // w = B^-1 a : `x` holds a by ROW and is destroyed, w comes back by POSITION
