@@ -344,7 +344,7 @@ struct Simplex {
         double pval = 0.0;
         int64_t pcost = std::numeric_limits<int64_t>::max();
         int looked = 0;
-        const auto ts0 = std::chrono::steady_clock::now();
+        const auto ts0 = debug ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         for (; looked < 4; ++looked) {
           const int c = heap_pop_current();
           if (c < 0) break;
@@ -364,7 +364,7 @@ struct Simplex {
           }
         }
         if (looked == 0) break;  // no column left
-        const auto ts1 = std::chrono::steady_clock::now();
+        const auto ts1 = debug ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         if (debug) nsec[1] += std::chrono::duration<double>(ts1 - ts0).count();
         for (int t = 0; t < looked; ++t)  // back with the ones that were only looked at (the pivot column / the one turned away stays out)
           if (shortest[t] != (pc < 0 ? shortest[0] : pc)) heap_push(shortest[t]);
@@ -459,7 +459,7 @@ struct Simplex {
       fsec[0] += ms(tf0, tf1), fsec[1] += ms(tf1, tf2), fsec[2] += ms(tf2, tf3), fsec[3] += ms(tf3, tf4), fsec[4] += ms(tf4, std::chrono::steady_clock::now());
     }
   }
-  double nsec[3] = {0, 0, 0};
+  double nsec[3] = {0, 0, 0};  // debug, s: nucleus columns through the triangular part / pivot search / elimination
   double fsec[5] = {0, 0, 0, 0, 0};  // debug, ms: ordering / set-up / triangular part / nucleus + tail / row-wise copies
   // ---- solves that start from a few nonzeros (Gilbert-Peierls): a depth-first search over the factor's structure finds the pivots
   // the right-hand side reaches, in topological order; only those are visited.  `from` (pivot numbers) seeds the search, `next(k, f)`
@@ -853,8 +853,8 @@ struct Simplex {
   }
   int rebuilds = 0;
   int64_t ops_factor = 0, ops_solve = 0;
-  double dens[6] = {0, 0, 0, 0, 0, 0};
-  int64_t bf_pass = 0, bf_grp = 0;
+  double dens[6] = {0, 0, 0, 0, 0, 0};  // debug: sums over the pivots of |rho|, |w|, |tau|, |pivot row|, update entries, entries of L + U
+  int64_t dens_pivots = 0, bf_pass = 0, bf_grp = 0;  // ... the pivots counted, those with bound flips, the flips
   double tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, factorisations, rebuild, duals + primal values, update file}
 };
 struct Lap {
@@ -1280,7 +1280,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
       if (w[i] != 0.0 && i != r) S.z[S.basic[i]] -= w[i] * step, pinf[i] = infeasibility(i), note(i);
     pinf[r] = infeasibility(r), note(r);
     S.iterations += 1;
-    if (S.debug) S.dens[0] += rlist.size(), S.dens[1] += wlist.size(), S.dens[2] += taulist.size(), S.dens[3] += touched.size(), S.dens[4] += S.update_entries(), S.dens[5] += S.Li.size() + S.Ui.size();
+    if (S.debug) ++S.dens_pivots, S.dens[0] += rlist.size(), S.dens[1] += wlist.size(), S.dens[2] += taulist.size(), S.dens[3] += touched.size(), S.dens[4] += S.update_entries(), S.dens[5] += S.Li.size() + S.Ui.size();
     // a fresh factorisation when the update file has cost as much as one costs (every solve walks the whole file), at the latest
     // after kRefactorEvery pivots
     extra_ops += (S.steepest ? 3 : 2) * (int64_t)S.update_entries();
@@ -1622,7 +1622,8 @@ int solve_core(const cuoptamd_lp* lp, const double* x0, const double* y0, double
   S.debug = debug;
   int total_iterations = 0;
   auto print_seconds = [&] {
-    std::fprintf(stderr, "[simplex] per pivot: rho %.0f, w %.0f, tau %.0f, touched %.0f, update entries %.0f, L+U %.0f (m %d)\n", S.dens[0] / std::max(1, S.iterations), S.dens[1] / std::max(1, S.iterations), S.dens[2] / std::max(1, S.iterations), S.dens[3] / std::max(1, S.iterations), S.dens[4] / std::max(1, S.iterations), S.dens[5] / std::max(1, S.iterations), S.m);
+    const double np = (double)std::max<int64_t>(1, S.dens_pivots);
+    std::fprintf(stderr, "[simplex] per pivot: rho %.0f, w %.0f, tau %.0f, touched %.0f, update entries %.0f, L+U %.0f (m %d)\n", S.dens[0] / np, S.dens[1] / np, S.dens[2] / np, S.dens[3] / np, S.dens[4] / np, S.dens[5] / np, S.m);
     std::fprintf(stderr, "[simplex] pivots with bound flips: %lld (flips %lld)\n", (long long)S.bf_pass, (long long)S.bf_grp);
     std::fprintf(stderr, "[simplex] nucleus s: columns through the triangular part %.2f, pivot search %.2f, elimination %.2f\n", S.nsec[0], S.nsec[1], S.nsec[2]);
     std::fprintf(stderr, "[simplex] factorisation ms: ordering %.0f, set-up %.0f, triangular part %.0f, nucleus %.0f, row-wise copies %.0f\n", S.fsec[0], S.fsec[1], S.fsec[2], S.fsec[3], S.fsec[4]);
