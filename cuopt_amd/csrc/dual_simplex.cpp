@@ -854,7 +854,7 @@ struct Simplex {
   int rebuilds = 0;
   int64_t ops_factor = 0, ops_solve = 0;
   double dens[6] = {0, 0, 0, 0, 0, 0};  // debug: sums over the pivots of |rho|, |w|, |tau|, |pivot row|, update entries, entries of L + U
-  int64_t dens_pivots = 0, bf_pass = 0, bf_grp = 0;  // ... the pivots counted, those with bound flips, the flips
+  int64_t dens_pivots = 0, bf_pass = 0, bf_grp = 0, bf_rounds = 0;  // ... the pivots counted, those with bound flips, the flips
   double tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // debug: seconds in {pricing, btran, pivot row, ratio test, ftran, weights, factorisations, rebuild, duals + primal values, update file}
 };
 struct Lap {
@@ -1050,6 +1050,8 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     }
   };
   const int refactor_cap = (int)cuopt_amd::tune_int("simplex_refactor", 500);
+  std::vector<char> fixedv(N);  // L == U, one byte per variable: the candidate pass of the ratio test reads this instead of two bounds
+  for (int j = 0; j < N; ++j) fixedv[j] = S.L[j] == S.U[j];
   std::vector<int> cand_j;  // the ratio test's candidates (sign-eligible entries of the pivot row), compact: column, |alpha|, |d|
   std::vector<double> cand_a, cand_d;
   for (;;) {
@@ -1114,7 +1116,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
     double ptol = 0.0, tmax = kInf;
     { Lap lap(S, 3);
     for (int j : touched) {
-      if (S.L[j] == S.U[j]) {  // a fixed variable never enters
+      if (fixedv[j]) {  // a fixed variable never enters
         alpha[j] = 0.0;
         continue;
       }
@@ -1189,6 +1191,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
         for (size_t c = 0; c < cand_j.size(); ++c)
           if (cand_a[c] > ptol && cand_d[c] / cand_a[c] <= tmax) flips.push_back(cand_j[c]), cand_a[c] = 0.0;  // out of the test
         slope -= sum, tmax = tnext;
+        if (S.debug) ++S.bf_rounds;
       }
     }
     int q        = -1;
@@ -1624,7 +1627,7 @@ int solve_core(const cuoptamd_lp* lp, const double* x0, const double* y0, double
   auto print_seconds = [&] {
     const double np = (double)std::max<int64_t>(1, S.dens_pivots);
     std::fprintf(stderr, "[simplex] per pivot: rho %.0f, w %.0f, tau %.0f, touched %.0f, update entries %.0f, L+U %.0f (m %d)\n", S.dens[0] / np, S.dens[1] / np, S.dens[2] / np, S.dens[3] / np, S.dens[4] / np, S.dens[5] / np, S.m);
-    std::fprintf(stderr, "[simplex] pivots with bound flips: %lld (flips %lld)\n", (long long)S.bf_pass, (long long)S.bf_grp);
+    std::fprintf(stderr, "[simplex] pivots with bound flips: %lld (flips %lld, groups passed %lld)\n", (long long)S.bf_pass, (long long)S.bf_grp, (long long)S.bf_rounds);
     std::fprintf(stderr, "[simplex] nucleus s: columns through the triangular part %.2f, pivot search %.2f, elimination %.2f\n", S.nsec[0], S.nsec[1], S.nsec[2]);
     std::fprintf(stderr, "[simplex] factorisation ms: ordering %.0f, set-up %.0f, triangular part %.0f, nucleus %.0f, row-wise copies %.0f\n", S.fsec[0], S.fsec[1], S.fsec[2], S.fsec[3], S.fsec[4]);
     std::fprintf(stderr, "[simplex] seconds: pricing %.2f, btran %.2f, pivot row %.2f, ratio test %.2f, ftran %.2f, weights %.2f, values %.2f (update file %.2f), rebuilds %.2f (factorisations %.2f); ns per counted entry: factorisation %.2f, solves %.2f\n", S.tsec[0], S.tsec[1], S.tsec[2], S.tsec[3], S.tsec[4], S.tsec[5], S.tsec[8], S.tsec[9], S.tsec[7], S.tsec[6], 1e9 * S.tsec[6] / std::max<int64_t>(S.ops_factor, 1), 1e9 * (S.tsec[1] + S.tsec[4] + S.tsec[5]) / std::max<int64_t>(S.ops_solve, 1));
