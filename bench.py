@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10"])
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
@@ -199,6 +200,11 @@ def main():
         steady = len(warm_rates) >= 3 and all(abs(warm_rates[-i] - warm_rates[-i - 1]) <= 0.02 * warm_rates[-i] for i in (1, 2))
         if steady or warm_wall > 4.0 or len(warm_rates) >= 100:
             break
+    # (iv) the timed region lasts at least --min-seconds (default 2 s) whatever --steps says, so that an outside observer (the
+    # driver's rocm-smi samples, its own clock) sees the GPU leg: timed_steps is rounded up from the steady rate of the warm-up
+    # batches (max-reduced over the ranks: same decision everywhere); `steps` is echoed as given, `timed_steps` as run.
+    steady_rate = max_over_ranks(warm_rates[-1])
+    timed_steps = max(timed_steps, int(np.ceil(args.min_seconds * steady_rate / period)) * period)
     dev.call("synchronize")
     barrier()
     attempts_before = solver.advance(0)["attempted_steps"]

@@ -82,6 +82,18 @@ struct SimplexPresolve {
     for (int j = 0; j < n; ++j)
       if (ccount[j] == 0 || xl[j] == xu[j]) cq.push_back(j);
     auto crossed = [](double l, double u) { return l > u + 1e-9 * (1.0 + std::fabs(l) + std::fabs(u)); };
+    // a column (or row) whose OWN bounds cross is a verdict before any reduction: an empty column would otherwise be removed at
+    // the bound its cost points to and the LP would come back Optimal with x outside its bounds
+    for (int j = 0; j < n; ++j)
+      if (crossed(xl[j], xu[j])) {
+        infeasible = true;
+        return true;
+      }
+    for (int i = 0; i < m; ++i)
+      if (crossed(rlo[i], rhi[i])) {
+        infeasible = true;
+        return true;
+      }
     while (!rq.empty() || !cq.empty()) {
       while (!rq.empty()) {
         const int i = rq.back();
@@ -118,6 +130,10 @@ struct SimplexPresolve {
         const int j = cq.back();
         cq.pop_back();
         if (!calive[j]) continue;
+        if (crossed(xl[j], xu[j])) {  // (bounds tightened by singleton rows since the column was queued)
+          infeasible = true;
+          return true;
+        }
         double v;
         Kind kind;
         if (xl[j] == xu[j]) {

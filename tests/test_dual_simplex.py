@@ -414,6 +414,13 @@ def test_presolve_and_the_way_back(monkeypatch):
     _check_vertex(q, r)
     assert capi.dual_simplex(dict(p, lo=np.array([2, -3, 4, 5, 0.5, -inf])))["status"] == "PrimalInfeasible"
     assert capi.dual_simplex(_lp([[1, 0], [1, 0], [1, 1]], [1, 1], [3, -inf, 0], [inf, 2, 10], [0, 0], [inf, inf]))["status"] == "PrimalInfeasible"
+    # (round-4 advisor) a column whose OWN bounds cross -- empty (x1 in [2, 1], both rows on x0 only) or not -- is infeasible with and
+    # without the presolve; it used to be removed at the bound its cost points to and reported Optimal with x outside its bounds
+    for pre in (0, 1):
+        set_tune(monkeypatch, simplex_presolve=pre)
+        assert capi.dual_simplex(_lp([[1, 0], [1, 0]], [1, 1], [1, -inf], [inf, 5], [0, 2], [inf, 1]))["status"] == "PrimalInfeasible"
+        assert capi.dual_simplex(_lp([[1, 1], [1, 0]], [1, 1], [1, -inf], [inf, 5], [0, 2], [inf, 1]))["status"] == "PrimalInfeasible"
+    set_tune(monkeypatch, simplex_presolve=1)
     # an empty column whose cost points to an infinite bound is the engine's to judge: unbounded here, infeasible there
     assert capi.dual_simplex(_lp([[1, 0], [1, 0]], [1, -1], [1, -inf], [inf, 5], [0, 0], [inf, inf]))["status"] == "Unbounded"
     assert capi.dual_simplex(_lp([[1, 0], [1, 0]], [1, -1], [6, -inf], [inf, 5], [0, 0], [inf, inf]))["status"] == "PrimalInfeasible"
