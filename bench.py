@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled"],
+                    help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
@@ -148,15 +150,19 @@ def main():
 
     comm_id = fresh_comm_id()
 
-    structured = args.workload in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
-    if args.workload == "hard":
+    shuffle = args.workload.endswith("_shuffled")
+    base = args.workload[:-len("_shuffled")] if shuffle else args.workload
+    structured = base in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
+    if base == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)
     elif structured:
-        cfg = dict(kind=args.workload, m=1_000_000, n=1_000_000, k=10, seed=7)
+        cfg = dict(kind=base, m=1_000_000, n=1_000_000, k=10, seed=7)
     else:
-        cfg = dict(synthetic.CONFIGS[args.workload])
+        cfg = dict(synthetic.CONFIGS[base])
     t_gen = time.time()
     p = synthetic.generate_structured(**cfg) if structured else synthetic.generate(**cfg)
+    if shuffle:
+        p = synthetic.shuffled(p, seed=5)
     t_gen = time.time() - t_gen
     m, n, nnz = p["m"], p["n"], int(len(p["values"]))
 
@@ -179,6 +185,7 @@ def main():
     timed_steps = max((max(args.steps, 1) + period - 1) // period, 5) * period  # at least five periods: a stable clock
     solver.advance(pre)
     layout = dev.layout()
+    reorder = solver.reorder_info()
     dataflow = capi.lib.pdlpdev_shard_dataflow(dev.handle)  # read while the solver (and its device context) is alive
     transport = ", direct peer stores" if world > 1 and capi.lib.pdlpdev_shard_transport(dev.handle) == 1 else ""
     # ... and (iii) starts at the device's steady clocks: a GPU that sat idle while the LP was generated runs its first tens of
@@ -247,7 +254,7 @@ def main():
     # command (profiles/r03_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile
     traffic, traffic_file = None, None
-    for rnd in ("r04", "r03", "r02"):  # the newest committed PMC summary of this workload
+    for rnd in ("r05", "r04", "r03", "r02"):  # the newest committed PMC summary of this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, args.workload))))
             if world == 1 and kname in pmc:
@@ -335,14 +342,14 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic %s sparse LP S(m=%d,n=%d,k=%d,seed=%d%s), nnz=%d, longest row %d, CSR fp64/int32, "
                                    "Stable2 preset, tolerances 0 (fixed iteration budget)"
-                                   % (args.workload, "structured (cuopt_amd/synthetic.py generate_structured)" if structured else "random",
+                                   % (args.workload, ("structured (cuopt_amd/synthetic.py generate_structured)" if structured else "random") + (", rows and columns shuffled (synthetic.shuffled, seed 5)" if shuffle else ""),
                                       m, n, cfg["k"], cfg["seed"], (",hard" if cfg.get("hard") else "") + (",band=%d" % cfg["band"] if cfg.get("band") else ""),
                                       nnz, int(np.diff(p["offsets"]).max())),
                        "rows": m, "cols": n, "nnz": nnz,
                        "parallelism": ("row-block x%d + RCCL %s" % (world, {1: "all-reduce (replicated primal)", 2: "reduce-scatter / all-gather (sliced primal)",
                                                                        3: "owner computes: all-gather(xbar) + all-gather(y'), rows and columns of A per rank"}.get(dataflow, "?") + transport)) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
-            "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
+            "spmv_layout": layout, "setup_reordering": reorder, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"],
         }
         sys.stdout.flush()

@@ -242,6 +242,7 @@ _proto("cuoptamd_solver_get_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_solver_set_warm_start", c_int, c_void_p, P(WarmStart))
 _proto("cuoptamd_warm_start_remap", c_int, P(WarmStart), P(c_int), c_int, P(c_int), c_int, P(WarmStart))
 _proto("cuoptamd_solver_row_range", c_int, c_void_p, P(c_int), P(c_int))
+_proto("cuoptamd_solver_reorder_info", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_partition_rows", None, c_int, c_void_p, c_int, c_void_p)
 _proto("cuoptamd_csr_transpose", None, c_int, c_int, *([c_void_p] * 6))
 
@@ -287,6 +288,16 @@ _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
 _proto("pdlpdev_shard_transport", c_int, c_void_p)
 _proto("pdlpdev_dense_info", c_int, c_void_p, c_void_p)
 _proto("pdlpdev_layout_info", c_int, c_void_p, c_void_p)
+# device-side set-up (round 5)
+_proto("pdlpdev_analyze", c_int, P(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int)
+_proto("pdlpdev_analysis_info", c_int, c_void_p, c_void_p)
+_proto("pdlpdev_analysis_maps", c_int, c_void_p, c_void_p, c_void_p)
+_proto("pdlpdev_analysis_download", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)
+_proto("pdlpdev_create_from_analysis", c_int, P(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("pdlpdev_analysis_destroy", None, c_void_p)
+_proto("pdlpdev_debug_sort_pairs", c_int, c_int, C.c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
+_proto("pdlpdev_debug_scan", c_int, c_int, C.c_int64, c_void_p, c_void_p)
+_proto("pdlpdev_debug_layout_checksums", c_int, c_void_p, c_void_p)
 
 # ids of pdlp_device.h
 BUF = {n: i for i, n in enumerate(
@@ -689,6 +700,20 @@ class Solver:
         lib.cuoptamd_solver_row_range(self.handle, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def reorder_info(self, maps=False):
+        """what the set-up's analysis pass found: {"reordered", "method" (none | levels | cells), estimates ...}; maps=True adds
+        row_new2old / col_new2old when the device works on a permuted LP"""
+        info = np.zeros(10, dtype=np.int32)
+        rows = np.zeros(self.m, dtype=np.int32) if maps else None
+        cols = np.zeros(self.n, dtype=np.int32) if maps else None
+        on = lib.cuoptamd_solver_reorder_info(self.handle, _ptr(info), _ptr(rows), _ptr(cols))
+        out = dict(reordered=bool(on == 1), method={0: "none", 1: "levels", 2: "cells"}.get(int(info[1]), "?"),
+                   estimate_natural=(info[2] / 1e4, info[3] / 1e4), estimate_levels=(info[4] / 1e4, info[5] / 1e4),
+                   estimate_cells=(info[6] / 1e4, info[7] / 1e4), search_levels=int(info[8]), cell_rounds=int(info[9]))
+        if maps and on == 1:
+            out["row_new2old"], out["col_new2old"] = rows, cols
+        return out
+
     def close(self):
         if self.handle:
             lib.cuoptamd_solver_destroy(self.handle)
@@ -745,13 +770,95 @@ def partition_rows(m, offsets, world):
 
 
 # ---- device layer ------------------------------------------------------------------------------------
+class Analysis:
+    """pdlpdev_analysis: ONE upload of A, the transpose and the structure-finding analysis pass on the device (pdlp_device.h
+    "device-side set-up").  The arrays of `p` stay referenced until the object is consumed by Device(analysis=...) or closed."""
+
+    def __init__(self, p, reorder=True, device=0):
+        self.m, self.n = int(p["m"]), int(p["n"])
+        self._keep = (_i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"]))
+        self.nnz = len(self._keep[2])
+        self.handle = c_void_p()
+        rc = lib.pdlpdev_analyze(C.byref(self.handle), device, self.m, self.n, _ptr(self._keep[0]), _ptr(self._keep[1]),
+                                 _ptr(self._keep[2]), 1 if reorder else 0)
+        if rc != 0:
+            msg = lib.pdlpdev_last_error().decode()
+            self.close()
+            raise CuOptError(rc, msg)
+
+    def info(self):
+        out = np.zeros(10, np.int32)
+        lib.pdlpdev_analysis_info(self.handle, _ptr(out))
+        return dict(permuted=bool(out[0]), method={0: "none", 1: "levels", 2: "cells"}.get(int(out[1]), "?"),
+                    estimate_natural=(out[2] / 1e4, out[3] / 1e4), estimate_levels=(out[4] / 1e4, out[5] / 1e4),
+                    estimate_cells=(out[6] / 1e4, out[7] / 1e4), search_levels=int(out[8]), cell_rounds=int(out[9]))
+
+    def maps(self):
+        """(row_new2old, col_new2old) or None when the device holds the matrix as given"""
+        r, c = np.zeros(self.m, np.int32), np.zeros(self.n, np.int32)
+        return (r, c) if lib.pdlpdev_analysis_maps(self.handle, _ptr(r), _ptr(c)) == 1 else None
+
+    def download(self, transposed=False):
+        rows = self.n if transposed else self.m
+        off, idx, val = np.zeros(rows + 1, np.int32), np.zeros(self.nnz, np.int32), np.zeros(self.nnz)
+        rc = lib.pdlpdev_analysis_download(self.handle, int(transposed), _ptr(off), _ptr(idx), _ptr(val))
+        if rc != 0:
+            raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+        return off, idx, val
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.pdlpdev_analysis_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_sort_pairs(keys, vals=None, bits=32, device=0):
+    """the set-up's stable LSD radix sort (test hook)"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    v = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint32)
+    ko, vo = np.zeros_like(keys), np.zeros_like(keys)
+    rc = lib.pdlpdev_debug_sort_pairs(device, len(keys), _ptr(keys), _ptr(v), int(bits), _ptr(ko), _ptr(vo))
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return ko, vo
+
+
+def device_exclusive_scan(values, device=0):
+    a = np.ascontiguousarray(values, dtype=np.int32)
+    out = np.zeros(len(a) + 1, np.int32)
+    rc = lib.pdlpdev_debug_scan(device, len(a), _ptr(a), _ptr(out))
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return out
+
+
 class Device:
     """pdlpdev_ctx: direct access to the HIP kernels (kernel-level parity tests, timing)."""
 
-    def __init__(self, p=None, handle=None, owner=True, device=0):
+    def __init__(self, p=None, handle=None, owner=True, device=0, analysis=None):
         self.owner = owner
         if handle is not None:
             self.handle = handle
+            return
+        if analysis is not None:
+            # the device-side set-up: p's vectors must be in the order of the matrices the analysis holds (the caller permutes them)
+            c, lo, hi, lb, ub = (_f64(p[k]) for k in ("c", "lo", "hi", "lb", "ub"))
+            self.handle = c_void_p()
+            rc = lib.pdlpdev_create_from_analysis(C.byref(self.handle), analysis.handle, _ptr(c), _ptr(lo), _ptr(hi), _ptr(lb), _ptr(ub))
+            msg = lib.pdlpdev_last_error().decode() if rc != 0 else ""
+            analysis.close()
+            if rc != 0:
+                if self.handle:
+                    lib.pdlpdev_destroy(self.handle)
+                self.handle = None
+                raise CuOptError(rc, msg)
+            self.m, self.n, self.nnz = int(p["m"]), int(p["n"]), len(p["values"])
             return
         m, n = int(p["m"]), int(p["n"])
         off, idx, val = _i32(p["offsets"]), _i32(p["indices"]), _f64(p["values"])
@@ -838,6 +945,12 @@ class Device:
                     d["row_sums"] = "by_nonzero" if out[6 + k // 3] else "by_row"  # by_nonzero: the long-tail variant (every row at rtol)
             return d
         return dict(A=side(0), At=side(3), resident=bool(out[0] == 2))
+
+    def layout_checksums(self):
+        """FNV-1a of A^T and of every panel / jagged layout array on the device (parity of the device-side set-up)"""
+        out = np.zeros(16, np.uint64)
+        self._ck(lib.pdlpdev_debug_layout_checksums(self.handle, _ptr(out)))
+        return out
 
     def dense_info(self):
         out = np.zeros(3, np.int64)

@@ -4,6 +4,7 @@
 
 #include "pdlp_kernel_decls.hpp"
 #include "pdlp_layouts.hpp"
+#include "pdlp_setup.hpp"
 #include "spmv_jag.hpp"
 
 // jagged-layout twins of (2) and (3) and of the plain / ping-pong SpMV: same epilogues, LDS column sets
@@ -183,76 +184,109 @@ static ColumnSet& thread_column_set(int capacity_log2, int which)
   return *p;
 }
 
+
+// one wave per group of up to G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
+// (below ~1.3e5 rows the layout has fewer workgroups than the chip has CUs and the CSR stream kernel's many small workgroups
+// win by 8 % on banded 7e4- and 1e5-row LPs; from 2e5 rows on the jagged layout wins: 28.9 k vs 26.9 k it/s)
+bool jag_geometry(int32_t rows, int mode, int* G_out, int* waves_out, int* wcap_out, int* brows_out)
+{
+  int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
+  if (mode == 1 && G == 0) G = 64;
+  if (G == 0) return false;
+  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_TUNE=jag_waves=16: 16384 columns, one workgroup per CU) measured
+  // 1-3 % faster on the banded, block-angular and multi-band LPs with the column-set version of this layout -- inside the noise
+  // of two runs, so the default stays with the geometry every profile of this round was taken with.
+  int waves = 8;
+  if (cuopt_amd::tune_int("jag_waves", 8) == 16) waves = 16;
+  *G_out = G, *waves_out = waves, *wcap_out = jag_window(waves), *brows_out = waves * G;
+  return true;
+}
+
+// A workgroup's rows: consecutive, at most `row_cap`, and as many as keep their DISTINCT columns within the LDS window
+// (rows longer than kLongRow do not count: they gather from global memory in workgroups of their own).  Greedy from
+// `first`; returns the end of the block.
+static int32_t jag_block_end(ColumnSet& set, const int32_t* off, const int32_t* idx, int wcap, int32_t first, int32_t limit, int32_t row_cap)
+{
+  set.clear();
+  int32_t distinct = 0, r = first;
+  const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + row_cap, limit);
+  for (; r < last; ++r) {
+    const int32_t len = off[r + 1] - off[r];
+    if (len > kLongRow) continue;
+    if (distinct + len > wcap) {  // may overflow: count the new columns before inserting any
+      int32_t fresh = 0;
+      for (int32_t k = off[r]; k < off[r + 1]; ++k) fresh += !set.contains(idx[k]);
+      if (distinct + fresh > wcap) break;
+    }
+    for (int32_t k = off[r]; k < off[r + 1]; ++k) distinct += set.insert(idx[k]);
+  }
+  return std::max(r, first + 1);  // a row of <= kLongRow nonzeros always fits an empty set
+}
+
+// cost of a block in gather equivalents: what filling its LDS set costs (a contiguous range is a coalesced copy, a list
+// costs one request per run of consecutive columns) against the gathers it serves.  Also decides range vs list.
+struct BlockSet {
+  int32_t wbase = 0, wlen = 0;  // contiguous range, or ...
+  std::vector<int32_t> cols;    // ... sorted distinct columns
+  int64_t refs = 0, cost = 0;
+};
+static BlockSet jag_block_set(ColumnSet& set, const int32_t* off, const int32_t* idx, int wcap, int32_t r0, int32_t r1)
+{
+  BlockSet B;
+  int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+  for (int32_t r = r0; r < r1; ++r) {
+    if (off[r + 1] - off[r] > kLongRow) continue;
+    for (int32_t k = off[r]; k < off[r + 1]; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
+    B.refs += off[r + 1] - off[r];
+  }
+  if (hi < 0) return B;
+  if ((int64_t)hi - lo + 1 <= wcap) {
+    B.wbase = lo, B.wlen = hi - lo + 1;
+    B.cost  = 1 + B.wlen / 16;
+    return B;
+  }
+  set.clear();
+  for (int32_t r = r0; r < r1; ++r)
+    if (off[r + 1] - off[r] <= kLongRow)
+      for (int32_t k = off[r]; k < off[r + 1]; ++k)
+        if (set.insert(idx[k])) B.cols.push_back(idx[k]);
+  std::sort(B.cols.begin(), B.cols.end());  // only the distinct columns (<= the LDS window) are sorted
+  int64_t runs = 0;
+  for (size_t i = 0; i < B.cols.size(); ++i) runs += i == 0 || B.cols[i] != B.cols[i - 1] + 1;
+  B.cost = runs + (int64_t)B.cols.size() / 16;
+  return B;
+}
+
+// The sampled estimate of build_jag on a MINI CSR: `nsamples` blocks of `brows` consecutive rows each (what the device's analysis
+// pass extracts from a matrix under a candidate permutation, kernels_setup.hip).  Returns the saving 1 - cost / refs.
+double jag_estimate_on_samples(int nsamples, int32_t brows, int wcap, const int32_t* soff, const int32_t* sidx)
+{
+  std::vector<int64_t> refs(nsamples, 0), cost(nsamples, 0);
+  cuopt_amd::parallel_tasks(nsamples, [&](int t) {
+    ColumnSet& set = thread_column_set(wcap > 8192 ? 16 : 15, 0);
+    const int32_t first = t * brows;
+    const int32_t last  = jag_block_end(set, soff, sidx, wcap, first, first + brows, brows);
+    const BlockSet B    = jag_block_set(set, soff, sidx, wcap, first, last);
+    refs[t] = B.refs, cost[t] = B.cost;
+  }, (int64_t)soff[(size_t)nsamples * brows]);
+  int64_t r = 0, c = 0;
+  for (int t = 0; t < nsamples; ++t) r += refs[t], c += cost[t];
+  return r ? 1.0 - (double)c / (double)r : 0.0;
+}
+
 // `mode`: 0 = use the layout when filling the LDS column sets costs at most half of the gathers they serve, 1 = always
 JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int mode, int cus)
 {
   JagHost H;
   const int64_t nnz = rows > 0 ? off[rows] : 0;
   if (rows <= 0 || cols <= 0 || nnz <= 0) return H;
-  // one wave per group of up to G rows, `waves` groups per workgroup: keep a few hundred workgroups on the chip
-  // (below ~1.3e5 rows the layout has fewer workgroups than the chip has CUs and the CSR stream kernel's many small workgroups
-  // win by 8 % on banded 7e4- and 1e5-row LPs; from 2e5 rows on the jagged layout wins: 28.9 k vs 26.9 k it/s)
-  int G = rows >= 786432 ? 256 : rows >= 196608 ? 128 : rows >= 131072 ? 64 : 0;
-  if (mode == 1 && G == 0) G = 64;
-  if (G == 0) return H;
-  // 8 waves / 8192 columns by default.  The wide geometry (CUOPT_AMD_TUNE=jag_waves=16: 16384 columns, one workgroup per CU) measured
-  // 1-3 % faster on the banded, block-angular and multi-band LPs with the column-set version of this layout -- inside the noise
-  // of two runs, so the default stays with the geometry every profile of this round was taken with.
-  int waves = 8;
-  if (cuopt_amd::tune_int("jag_waves", 8) == 16) waves = 16;
-  const int wcap = jag_window(waves), brows = waves * G;
+  int G = 0, waves = 8, wcap = 0, brows = 0;
+  if (!jag_geometry(rows, mode, &G, &waves, &wcap, &brows)) return H;
   const int slots = cus * (waves == 16 ? 1 : 2);  // workgroups resident at once: 80 KiB of LDS each (160 KiB with 16 waves)
-  // A workgroup's rows: consecutive, at most `brows`, and as many as keep their DISTINCT columns within the LDS window
-  // (rows longer than kLongRow do not count: they gather from global memory in workgroups of their own).  Greedy from
-  // `first`; returns the end of the block.
-  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit, int32_t row_cap) -> int32_t {
-    set.clear();
-    int32_t distinct = 0, r = first;
-    const int32_t last = (int32_t)std::min<int64_t>((int64_t)first + row_cap, limit);
-    for (; r < last; ++r) {
-      const int32_t len = off[r + 1] - off[r];
-      if (len > kLongRow) continue;
-      if (distinct + len > wcap) {  // may overflow: count the new columns before inserting any
-        int32_t fresh = 0;
-        for (int32_t k = off[r]; k < off[r + 1]; ++k) fresh += !set.contains(idx[k]);
-        if (distinct + fresh > wcap) break;
-      }
-      for (int32_t k = off[r]; k < off[r + 1]; ++k) distinct += set.insert(idx[k]);
-    }
-    return std::max(r, first + 1);  // a row of <= kLongRow nonzeros always fits an empty set
+  auto block_end = [&](ColumnSet& set, int32_t first, int32_t limit, int32_t row_cap) {
+    return jag_block_end(set, off, idx, wcap, first, limit, row_cap);
   };
-  // cost of a block in gather equivalents: what filling its LDS set costs (a contiguous range is a coalesced copy, a list
-  // costs one request per run of consecutive columns) against the gathers it serves.  Also decides range vs list.
-  struct BlockSet {
-    int32_t wbase = 0, wlen = 0;  // contiguous range, or ...
-    std::vector<int32_t> cols;    // ... sorted distinct columns
-    int64_t refs = 0, cost = 0;
-  };
-  auto block_set = [&](int32_t r0, int32_t r1, ColumnSet& set) -> BlockSet {
-    BlockSet B;
-    int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
-    for (int32_t r = r0; r < r1; ++r) {
-      if (off[r + 1] - off[r] > kLongRow) continue;
-      for (int32_t k = off[r]; k < off[r + 1]; ++k) lo = std::min(lo, idx[k]), hi = std::max(hi, idx[k]);
-      B.refs += off[r + 1] - off[r];
-    }
-    if (hi < 0) return B;
-    if ((int64_t)hi - lo + 1 <= wcap) {
-      B.wbase = lo, B.wlen = hi - lo + 1;
-      B.cost  = 1 + B.wlen / 16;
-      return B;
-    }
-    set.clear();
-    for (int32_t r = r0; r < r1; ++r)
-      if (off[r + 1] - off[r] <= kLongRow)
-        for (int32_t k = off[r]; k < off[r + 1]; ++k)
-          if (set.insert(idx[k])) B.cols.push_back(idx[k]);
-    std::sort(B.cols.begin(), B.cols.end());  // only the distinct columns (<= the LDS window) are sorted
-    int64_t runs = 0;
-    for (size_t i = 0; i < B.cols.size(); ++i) runs += i == 0 || B.cols[i] != B.cols[i - 1] + 1;
-    B.cost = runs + (int64_t)B.cols.size() / 16;
-    return B;
-  };
+  auto block_set = [&](int32_t r0, int32_t r1, ColumnSet& set) { return jag_block_set(set, off, idx, wcap, r0, r1); };
   if (mode == 0) {  // estimate on ~48 blocks first: a random matrix is turned away after a few milliseconds
     const int samples = (int)std::min<int64_t>(48, std::max<int64_t>(1, rows / brows));
     std::vector<int64_t> refs(samples, 0), cost(samples, 0);

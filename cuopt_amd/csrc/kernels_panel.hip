@@ -4,6 +4,7 @@
 
 #include "pdlp_kernel_decls.hpp"
 #include "pdlp_layouts.hpp"
+#include "pdlp_setup.hpp"
 #include "spmv_panel.hpp"
 
 // panel-layout twins of (2) and (3): same epilogues, slab-major gather (pdlp_kernels.hpp)
@@ -162,14 +163,37 @@ int64_t gather_working_set(int32_t rows, int32_t cols, const int32_t* off, const
   return total / samples;
 }
 
-PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
-                              int64_t slab_bytes, bool force, const std::vector<int32_t>* dense_first_seg)
+// the same estimate from the windows alone (`sparse` holds the index entries of the windows back to back): for a matrix whose index
+// array lives on the device (kernels_setup.hip analysis_fetch_idx_windows cuts the windows exactly as above)
+int64_t gather_working_set_windows(int32_t cols, const int32_t* sparse, const std::vector<std::pair<int64_t, int64_t>>& windows)
 {
-  PanelHost P;
-  const int64_t nnz = off[rows];
-  if (rows <= 0 || cols <= 0 || nnz <= 0) return P;
+  if (windows.empty() || cols <= 0) return 0;
+  std::vector<uint8_t> seen((size_t)(cols >> 4) + 1);
+  int64_t total = 0;
+  size_t at = 0;
+  for (const auto& w : windows) {
+    std::fill(seen.begin(), seen.end(), 0);
+    int64_t lines = 0;
+    for (int64_t k = w.first; k < w.second; ++k, ++at) {
+      uint8_t& b = seen[(size_t)(sparse[at] >> 4)];
+      lines += !b;
+      b = 1;
+    }
+    total += lines * 128;
+  }
+  return total / (int64_t)windows.size();
+}
+
+// Geometry, long-tail decision, own rows and the cut into panels: everything build_panels decides from the ROW OFFSETS alone (shared
+// with the device-side construction, kernels_setup.hip build_panels_device).  false: the layout does not apply.
+bool panel_plan(PanelHost* out, int32_t rows, int32_t cols, const int32_t* off, int64_t slab_bytes, bool force,
+                const std::vector<int32_t>* dense_first_seg, std::vector<char>* is_own_out, int64_t* own_nnz_out, int64_t* own_from_out)
+{
+  PanelHost& P = *out;
+  const int64_t nnz = rows > 0 ? off[rows] : 0;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) return false;
   // worth it only when the gathered vector overflows an XCD's L2 (4 MiB, shared with the matrix stream)
-  if (!force && (int64_t)cols * 8 <= 2 * (int64_t)1048576) return P;
+  if (!force && (int64_t)cols * 8 <= 2 * (int64_t)1048576) return false;
   int S = (int)(((int64_t)cols * 8 + slab_bytes - 1) / slab_bytes);
   S     = std::max(1, std::min(S, 16));
   const int32_t slab_w = (cols + S - 1) / S;
@@ -197,7 +221,8 @@ PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int
   // long-tail variant deals every row by nonzero, so a row leaves the panels only when it is longer than a whole panel should be
   // (it would be the one panel everybody waits for): up to there it is ordinary work, and no resident slot is spent on it.
   const int64_t own_from = P.seg ? std::max<int64_t>(kPanelOwnRow, std::min<int64_t>(cap, (nnz + 511) / 512)) : kPanelOwnRow;
-  std::vector<char> is_own(rows, 0);
+  std::vector<char>& is_own = *is_own_out;
+  is_own.assign((size_t)rows, 0);
   int64_t own_nnz = 0;
   for (int32_t i = 0; i < rows; ++i)
       if (off[i + 1] - off[i] > own_from || (dense_first_seg && (*dense_first_seg)[i] >= 0))  // (rows that own dense segments: their
@@ -237,6 +262,20 @@ PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int
     while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;
     P.own_ptr[w + 1] = q;
   }
+  *own_nnz_out = own_nnz, *own_from_out = own_from;
+  return true;
+}
+
+PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
+                              int64_t slab_bytes, bool force, const std::vector<int32_t>* dense_first_seg)
+{
+  PanelHost P;
+  std::vector<char> is_own;
+  int64_t own_nnz = 0, own_from = 0;
+  if (!panel_plan(&P, rows, cols, off, slab_bytes, force, dense_first_seg, &is_own, &own_nnz, &own_from)) return P;
+  const int64_t nnz = off[rows];
+  const int W = P.W, S = P.S;
+  const int32_t slab_w = P.slab_w;
   // pass 1: nonzeros per (panel, slab) -- panels are independent, so both passes run over host threads
   std::vector<int64_t> count((size_t)W * S + 1, 0);
   cuopt_amd::parallel_tasks(W, [&](int w) {

@@ -1,0 +1,1379 @@
+// Device-side set-up (see pdlp_setup.hpp): radix sort / scan primitives, CSR transpose, the structure-finding analysis pass, the
+// permuted CSR pair and the slab-major panel construction, all from ONE upload of A.  gfx950, wave64.
+#include <hip/hip_runtime.h>
+
+#include "pdlp_setup.hpp"
+
+namespace {
+
+constexpr int kT = 256;  // threads per workgroup of the set-up kernels
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over the THREADS values of a workgroup; every thread gets its prefix, *total (optional, same for all) the sum.
+// scratch: THREADS / 64 + 1 ints of LDS.  Ends with a barrier (scratch may be reused right after).
+template <int THREADS>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(v, lane);
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  int base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) {
+    const int s = scratch[w];
+    if (w < wave) base += s;
+    sum += s;
+  }
+  __syncthreads();
+  if (total) *total = sum;
+  return base + inc - v;
+}
+
+// ================================================================================================
+// exclusive scan of int32: out[i] = sum_{j < i} in[j] for i in [0, n]  (n + 1 outputs; out[n] = total)
+// ================================================================================================
+constexpr int kScanTile = 1024 * 4;
+
+__global__ void __launch_bounds__(1024) k_scan_local(const int32_t* __restrict__ in, int32_t* __restrict__ out, int64_t n,
+                                                     int32_t* __restrict__ block_sums)
+{
+  __shared__ int scratch[17];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 4;
+  int v[4], s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = base + q;
+    v[q] = i < n ? in[i] : 0;
+    s += v[q];
+  }
+  int total = 0;
+  int pre = block_exclusive_scan<1024>(s, scratch, &total);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = base + q;
+    if (i <= n) out[i] = pre;
+    pre += v[q];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_sums(int32_t* __restrict__ block_sums, int nb)
+{
+  __shared__ int scratch[17];
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nb ? block_sums[i] : 0;
+    int total = 0;
+    const int pre = block_exclusive_scan<1024>(v, scratch, &total);
+    if (i < nb) block_sums[i] = carry + pre;
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_add(int32_t* __restrict__ out, int64_t n, const int32_t* __restrict__ block_sums)
+{
+  const int add = block_sums[blockIdx.x];
+  if (add == 0) return;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (base + q <= n) out[base + q] += add;
+}
+
+// block_sums: >= (n + 1) / 4096 + 1 ints
+int dev_exclusive_scan(hipStream_t s, const int32_t* in, int32_t* out, int64_t n, int32_t* block_sums)
+{
+  const int nb = (int)((n + 1 + kScanTile - 1) / kScanTile);
+  k_scan_local<<<nb, 1024, 0, s>>>(in, out, n, block_sums);
+  if (nb > 1) {
+    k_scan_sums<<<1, 1024, 0, s>>>(block_sums, nb);
+    k_scan_add<<<nb, 1024, 0, s>>>(out, n, block_sums);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ================================================================================================
+// stable LSD radix sort of (key, value) pairs of uint32, 8 bits per pass
+// ================================================================================================
+constexpr int kRsTile = 4096;  // items per workgroup: 4 waves x 16 rounds x 64 lanes, wave w owns items [w * 1024, (w + 1) * 1024) of the tile
+
+__global__ void __launch_bounds__(kT) k_rs_hist(const uint32_t* __restrict__ keys, int64_t n, int shift, int nblk,
+                                                int32_t* __restrict__ hist /* [256][nblk] */)
+{
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+#pragma unroll 4
+  for (int r = 0; r < kRsTile / kT; ++r) {
+    const int64_t i = base + r * kT + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of the digit's row of the histogram in place, its total to totals[digit]
+__global__ void __launch_bounds__(1024) k_rs_scan_digit(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ totals)
+{
+  __shared__ int scratch[17];
+  int32_t* row = hist + (size_t)blockIdx.x * nblk;
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nblk ? row[i] : 0;
+    int total = 0;
+    const int pre = block_exclusive_scan<1024>(v, scratch, &total);
+    if (i < nblk) row[i] = carry + pre;
+    carry += total;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// vals_in == nullptr: the value of item i is i
+__global__ void __launch_bounds__(kT) k_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                   uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int64_t n, int shift,
+                                                   int nblk, const int32_t* __restrict__ hist, const int32_t* __restrict__ totals)
+{
+  __shared__ int wcount[4][256];
+  __shared__ int gbase[256];
+  __shared__ int scratch[5];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wcount[q][t] = 0;
+  {
+    // where digit t starts in the output: exclusive scan of the digit totals, + this workgroup's offset inside the digit
+    const int pre = block_exclusive_scan<kT>(totals[t], scratch, nullptr);
+    gbase[t]      = pre + hist[(size_t)t * nblk + blockIdx.x];
+  }
+  __syncthreads();
+  constexpr int R = kRsTile / kT;  // 16 rounds
+  uint32_t key[R], val[R];
+  int rk[R];
+  const int64_t base = (int64_t)blockIdx.x * kRsTile + (int64_t)w * (kRsTile / 4);
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i  = base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r]           = valid ? kin[i] : 0xFFFFFFFFu;
+    val[r]           = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;
+    const unsigned d = (key[r] >> shift) & 255u;
+    // lanes of this wave that hold the same digit (a ballot per bit of the digit)
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit              = (d >> b) & 1u;
+      const unsigned long long bl = __ballot(valid && bit);
+      same &= bit ? bl : ~bl;
+    }
+    const int rank = __popcll(same & below), cnt = __popcll(same);
+    int pre = 0;
+    if (valid && rank == 0) pre = atomicAdd(&wcount[w][d], cnt);  // the group's first lane reserves the group's slots
+    pre   = __shfl(pre, same ? __ffsll((long long)same) - 1 : 0, 64);
+    rk[r] = pre + rank;  // position among this wave's items of digit d, in item order
+  }
+  __syncthreads();
+  {
+    // offsets of the waves inside (workgroup, digit): wave order = item order
+    const int c0 = wcount[0][t], c1 = wcount[1][t], c2 = wcount[2][t];
+    wcount[0][t] = 0, wcount[1][t] = c0, wcount[2][t] = c0 + c1, wcount[3][t] = c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    if (i < n) {
+      const unsigned d = (key[r] >> shift) & 255u;
+      const int64_t p  = (int64_t)gbase[d] + wcount[w][d] + rk[r];
+      kout[p] = key[r], vout[p] = val[r];
+    }
+  }
+}
+
+struct SortBufs {
+  uint32_t *k[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr};
+  int32_t *hist = nullptr, *totals = nullptr;
+  int64_t capacity = 0;
+};
+
+int sort_bufs_take(DevArena& ar, SortBufs* B, int64_t n)
+{
+  const int nblk = (int)((n + kRsTile - 1) / kRsTile) + 1;
+  B->k[0] = ar.take<uint32_t>((size_t)n), B->k[1] = ar.take<uint32_t>((size_t)n);
+  B->v[0] = ar.take<uint32_t>((size_t)n), B->v[1] = ar.take<uint32_t>((size_t)n);
+  B->hist = ar.take<int32_t>((size_t)256 * nblk), B->totals = ar.take<int32_t>(256);
+  B->capacity = n;
+  if (!B->k[0] || !B->k[1] || !B->v[0] || !B->v[1] || !B->hist || !B->totals) return fail(-2, "device set-up: workspace too small for the sort buffers");
+  return 0;
+}
+
+int bits_for(uint32_t max_key)
+{
+  int b = 1;
+  while (b < 32 && (max_key >> b)) ++b;
+  return b;
+}
+
+// Sorts n pairs by the low `bits` bits of the keys (stable).  keys_in / vals_in are not modified (vals_in null: iota); the result is in
+// B.k[*slot], B.v[*slot].
+int radix_sort_pairs(hipStream_t s, int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, SortBufs& B, int bits, int* slot)
+{
+  if (n > B.capacity) return fail(-2, "device set-up: sort buffers too small");
+  const int passes = std::max(1, (bits + 7) / 8);
+  const int nblk   = (int)std::max<int64_t>(1, (n + kRsTile - 1) / kRsTile);
+  const uint32_t* kin = keys_in;
+  const uint32_t* vin = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    const int o = p & 1;
+    k_rs_hist<<<nblk, kT, 0, s>>>(kin, n, 8 * p, nblk, B.hist);
+    k_rs_scan_digit<<<256, 1024, 0, s>>>(B.hist, nblk, B.totals);
+    k_rs_scatter<<<nblk, kT, 0, s>>>(kin, vin, B.k[o], B.v[o], n, 8 * p, nblk, B.hist, B.totals);
+    kin = B.k[o], vin = B.v[o];
+  }
+  *slot = (passes - 1) & 1;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ================================================================================================
+// CSR -> CSR of the transpose
+// ================================================================================================
+// off_out[j] = first position of key >= j in the ascending keys (j in [0, nkeys]): the row offsets of a CSR from its sorted row ids
+__global__ void __launch_bounds__(kT) k_offsets_from_sorted(const uint32_t* __restrict__ keys, int64_t n, int32_t nkeys, int32_t* __restrict__ off_out)
+{
+  for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q <= n; q += (int64_t)gridDim.x * kT) {
+    const int64_t prev = q == 0 ? -1 : (int64_t)keys[q - 1];
+    const int64_t cur  = q == n ? (int64_t)nkeys : (int64_t)keys[q];
+    for (int64_t j = prev + 1; j <= cur; ++j) off_out[j] = (int32_t)q;
+  }
+}
+
+__device__ __forceinline__ int32_t row_of(const int32_t* __restrict__ off, int32_t rows, int64_t k)
+{
+  // largest r with off[r] <= k (rows may be empty: upper bound - 1)
+  int32_t lo = 0, hi = rows;  // invariant: off[lo] <= k < off[hi]
+  while (hi - lo > 1) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if ((int64_t)off[mid] <= k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// one entry of the transpose per thread: src[q] = position in the source CSR
+__global__ void __launch_bounds__(kT) k_transpose_finish(const uint32_t* __restrict__ src, int64_t nnz, const int32_t* __restrict__ a_off,
+                                                         int32_t rows, const double* __restrict__ a_val, int32_t* __restrict__ t_idx,
+                                                         double* __restrict__ t_val)
+{
+  for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * kT) {
+    const uint32_t k = src[q];
+    t_idx[q] = row_of(a_off, rows, (int64_t)k);
+    t_val[q] = a_val[k];
+  }
+}
+
+inline int grid_of(int64_t n, int cap = 4096) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kT - 1) / kT, cap)); }
+
+// A (rows x cols, CSR on the device) -> its transpose; rows ascending inside every row of the result (what cusparseCsr2cscEx2
+// gives the reference, problem.cu:277-309): the stable sort by column keeps the source order, and the source is in row order
+int dev_transpose(hipStream_t s, DevArena& ar, int32_t rows, int32_t cols, int64_t nnz, const DevCsr& A, const DevCsr& T)
+{
+  const size_t mark = ar.mark();
+  SortBufs B;
+  TRY(sort_bufs_take(ar, &B, std::max<int64_t>(nnz, 1)));
+  int slot = 0;
+  if (nnz > 0) TRY(radix_sort_pairs(s, nnz, (const uint32_t*)A.idx, nullptr, B, bits_for((uint32_t)std::max(cols - 1, 1)), &slot));
+  k_offsets_from_sorted<<<grid_of(nnz + 1), kT, 0, s>>>(B.k[slot], nnz, cols, T.off);
+  if (nnz > 0) k_transpose_finish<<<grid_of(nnz), kT, 0, s>>>(B.v[slot], nnz, A.off, rows, A.val, T.idx, T.val);
+  HIP_TRY(hipGetLastError());
+  ar.release(mark);  // (stream order: the next user of the arena is enqueued behind these kernels)
+  return 0;
+}
+
+// ================================================================================================
+// the analysis pass: breadth-first levels and seeded cells on the bipartite row-column graph
+// ================================================================================================
+constexpr int32_t kUnvisited = 0x7fffffff, kHub = -1;
+constexpr int kStage = 4096;  // vertices a workgroup stages in LDS before it reserves room in the next frontier
+
+__global__ void __launch_bounds__(kT) k_bfs_init(int32_t count, const int32_t* __restrict__ off, int32_t hub_len, int32_t* __restrict__ lev)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t len = off[i + 1] - off[i];
+    lev[i]            = len > hub_len ? kHub : kUnvisited;
+  }
+}
+
+__global__ void k_bfs_seed(int32_t* __restrict__ lev, int32_t start, int32_t* __restrict__ frontier, int32_t* __restrict__ counts)
+{
+  lev[start] = 0, frontier[0] = start, counts[0] = 1;
+}
+
+// appends the workgroup's staged vertices to the next frontier (one reservation per workgroup and flush)
+__device__ __forceinline__ void flush_stage(int* stage, int* stage_n, int32_t* __restrict__ out, int32_t* __restrict__ out_count)
+{
+  __shared__ int base;
+  __syncthreads();
+  const int cnt = min(*stage_n, kStage);
+  if (threadIdx.x == 0) base = cnt ? atomicAdd(out_count, cnt) : 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += kT) out[base + i] = stage[i];
+  __syncthreads();
+  if (threadIdx.x == 0) *stage_n = 0;
+  __syncthreads();
+}
+
+// one level of the breadth-first search: the vertices of `fr` (one side of the bipartite graph) claim their unvisited neighbours
+// (the other side) for level `level`
+__global__ void __launch_bounds__(kT) k_bfs_expand(const int32_t* __restrict__ fr, const int32_t* __restrict__ fr_count,
+                                                   const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                   int32_t* __restrict__ lev_other, int32_t* __restrict__ out,
+                                                   int32_t* __restrict__ out_count, int32_t level)
+{
+  __shared__ int stage[kStage];
+  __shared__ int stage_n;
+  if (threadIdx.x == 0) stage_n = 0;
+  __syncthreads();
+  const int32_t count = *fr_count;
+  for (int32_t i0 = blockIdx.x * kT; i0 < count; i0 += gridDim.x * kT) {
+    const int32_t i = i0 + threadIdx.x;
+    if (i < count) {
+      const int32_t v = fr[i];
+      for (int32_t k = off[v]; k < off[v + 1]; ++k) {
+        const int32_t u = idx[k];
+        if (lev_other[u] != kUnvisited) continue;
+        if (atomicCAS(&lev_other[u], kUnvisited, level) == kUnvisited) {
+          const int p = atomicAdd(&stage_n, 1);
+          if (p < kStage) stage[p] = u;
+          else out[atomicAdd(out_count, 1)] = u;  // (rare: more than kStage claims in one round of the workgroup)
+        }
+      }
+    }
+    flush_stage(stage, &stage_n, out, out_count);
+  }
+}
+
+// farthest visited vertex of one side: max over (level << 32 | ~id): the smallest id among the deepest
+__global__ void __launch_bounds__(kT) k_find_far(int32_t count, const int32_t* __restrict__ lev, unsigned long long* __restrict__ best)
+{
+  unsigned long long mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t l = lev[i];
+    if (l >= 0 && l != kUnvisited) {
+      const unsigned long long key = ((unsigned long long)(uint32_t)l << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+      mine = key > mine ? key : mine;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(mine, o, 64);
+    mine = other > mine ? other : mine;
+  }
+  if ((threadIdx.x & 63) == 0 && mine) atomicMax(best, mine);
+}
+
+// positions for the barycentre sweeps: the level of a visited vertex, -1 otherwise
+__global__ void __launch_bounds__(kT) k_level_to_pos(int32_t count, const int32_t* __restrict__ lev, float* __restrict__ pos)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t l = lev[i];
+    pos[i]          = (l >= 0 && l != kUnvisited) ? (float)l : -1.0f;
+  }
+}
+
+// pos_out[v] = mean of the neighbours' positions (visited, non-hub neighbours only; CSR order: reproducible), own position kept
+// when there is none; hubs and unvisited vertices keep -1
+__global__ void __launch_bounds__(kT) k_barycentre(int32_t count, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                   const float* __restrict__ pos_self, const float* __restrict__ pos_other,
+                                                   float* __restrict__ pos_out)
+{
+  for (int64_t v = (int64_t)blockIdx.x * kT + threadIdx.x; v < count; v += (int64_t)gridDim.x * kT) {
+    const float own = pos_self[v];
+    float out       = own;
+    if (own >= 0.0f) {
+      float sum = 0.0f;
+      int cnt   = 0;
+      for (int32_t k = off[v]; k < off[v + 1]; ++k) {
+        const float p = pos_other[idx[k]];
+        if (p >= 0.0f) sum += p, ++cnt;
+      }
+      if (cnt) out = sum / (float)cnt;
+    }
+    pos_out[v] = out;
+  }
+}
+
+__global__ void __launch_bounds__(kT) k_pos_to_key(int32_t count, const float* __restrict__ pos, float scale, uint32_t last_key, uint32_t* __restrict__ key)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const float p = pos[i];
+    key[i]        = p >= 0.0f ? min((uint32_t)(p * scale), last_key - 1u) : last_key;
+  }
+}
+
+// ---- seeded cells: a breadth-first search from many seeds at once; a vertex joins the cell that reaches it first, ties to the
+// smaller cell id (atomicMin on depth << 24 | cell: all claims of one round carry the same depth) -> a reproducible partition
+constexpr uint32_t kCellUnvisited = 0xFFFFFFFFu, kCellHub = 0u;
+
+__global__ void __launch_bounds__(kT) k_cell_init(int32_t count, const int32_t* __restrict__ off, int32_t hub_len, uint32_t* __restrict__ key)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t len = off[i + 1] - off[i];
+    key[i]            = len > hub_len ? kCellHub : kCellUnvisited;
+  }
+}
+
+// seed t (cell id t + 1): the first row of [t * spacing, (t + 1) * spacing) that has entries and is no hub
+__global__ void __launch_bounds__(kT) k_cell_seed(int32_t rows, int32_t spacing, int32_t ncells, const int32_t* __restrict__ off,
+                                                  uint32_t* __restrict__ key, int32_t* __restrict__ frontier, int32_t* __restrict__ counts)
+{
+  const int32_t t = blockIdx.x * kT + threadIdx.x;
+  int32_t seed    = -1;
+  if (t < ncells) {
+    const int64_t r0 = (int64_t)t * spacing, r1 = min((int64_t)rows, r0 + spacing);
+    for (int64_t r = r0; r < r1 && r < r0 + 64; ++r)
+      if (off[r + 1] > off[r] && key[r] == kCellUnvisited) {
+        seed = (int32_t)r;
+        break;
+      }
+  }
+  const unsigned long long have = __ballot(seed >= 0);
+  if (have) {
+    const int lane = threadIdx.x & 63;
+    int base       = 0;
+    if (lane == __ffsll((long long)have) - 1) base = atomicAdd(counts, __popcll(have));
+    base = __shfl(base, __ffsll((long long)have) - 1, 64);
+    if (seed >= 0) {
+      key[seed] = (uint32_t)(t + 1);  // depth 0
+      frontier[base + __popcll(have & (lane == 0 ? 0ull : (~0ull >> (64 - lane))))] = seed;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kT) k_cell_expand(const int32_t* __restrict__ fr, const int32_t* __restrict__ fr_count,
+                                                    const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                    const uint32_t* __restrict__ key_self, uint32_t* __restrict__ key_other,
+                                                    int32_t* __restrict__ out, int32_t* __restrict__ out_count)
+{
+  __shared__ int stage[kStage];
+  __shared__ int stage_n;
+  if (threadIdx.x == 0) stage_n = 0;
+  __syncthreads();
+  const int32_t count = *fr_count;
+  for (int32_t i0 = blockIdx.x * kT; i0 < count; i0 += gridDim.x * kT) {
+    const int32_t i = i0 + threadIdx.x;
+    if (i < count) {
+      const int32_t v     = fr[i];
+      const uint32_t kv   = key_self[v];
+      const uint32_t cand = (((kv >> 24) + 1u) << 24) | (kv & 0xFFFFFFu);
+      if ((kv >> 24) < 254u)
+        for (int32_t k = off[v]; k < off[v + 1]; ++k) {
+          const int32_t u = idx[k];
+          if (key_other[u] <= cand) continue;  // a hub (0), an earlier round, or a smaller cell of this round
+          if (atomicMin(&key_other[u], cand) == kCellUnvisited) {
+            const int p = atomicAdd(&stage_n, 1);
+            if (p < kStage) stage[p] = u;
+            else out[atomicAdd(out_count, 1)] = u;
+          }
+        }
+    }
+    flush_stage(stage, &stage_n, out, out_count);
+  }
+}
+
+// sort key of a vertex inside the cell ordering: (rank of its cell, depth); hubs and vertices no cell reached go last.  rank: the
+// cells' order (null: by cell id) -- cells that belong together (quotient graph, below) are neighbours in it
+__global__ void __launch_bounds__(kT) k_cell_to_key(int32_t count, const uint32_t* __restrict__ cell, const int32_t* __restrict__ rank,
+                                                    uint32_t* __restrict__ key)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const uint32_t c = cell[i];
+    if (c == kCellHub || c == kCellUnvisited) {
+      key[i] = 0xFFFFFFFFu;
+    } else {
+      const uint32_t id = c & 0xFFFFFFu;
+      key[i]            = ((rank ? (uint32_t)rank[id] : id) << 8) | (c >> 24);
+    }
+  }
+}
+
+// quotient graph of the cells: W[a * K + b] = nonzeros whose row lies in cell a and whose column lies in cell b (ids 1 ... K - 1)
+__global__ void __launch_bounds__(kT) k_cell_quotient(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                      const uint32_t* __restrict__ cell_r, const uint32_t* __restrict__ cell_c, int32_t K,
+                                                      int32_t* __restrict__ W)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < rows; i += (int64_t)gridDim.x * kT) {
+    const uint32_t cr = cell_r[i];
+    if (cr == kCellHub || cr == kCellUnvisited) continue;
+    const int32_t a = (int32_t)(cr & 0xFFFFFFu);
+    int32_t last_b = -1, run = 0;
+    for (int32_t k = off[i]; k < off[i + 1]; ++k) {
+      const uint32_t cc = cell_c[idx[k]];
+      if (cc == kCellHub || cc == kCellUnvisited) continue;
+      const int32_t b = (int32_t)(cc & 0xFFFFFFu);
+      if (b != last_b) {
+        if (run) atomicAdd(&W[(size_t)a * K + last_b], run);
+        last_b = b, run = 0;
+      }
+      ++run;
+    }
+    if (run) atomicAdd(&W[(size_t)a * K + last_b], run);
+  }
+}
+
+__global__ void __launch_bounds__(kT) k_invert_perm(int32_t count, const uint32_t* __restrict__ new2old, int32_t* __restrict__ old2new)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) old2new[new2old[i]] = (int32_t)i;
+}
+
+// ---- sampled row blocks of P M Q for the jagged layout's cost estimate -------------------------------------------------------
+// row q of the sample = new row first[q / brows] + q % brows of the permuted matrix (null maps: identity); long rows count 0
+__global__ void __launch_bounds__(kT) k_sample_lens(int32_t nq, int32_t brows, const int32_t* __restrict__ first, int32_t rows,
+                                                    const uint32_t* __restrict__ row_new2old, const int32_t* __restrict__ off,
+                                                    int32_t* __restrict__ lens)
+{
+  for (int32_t q = blockIdx.x * kT + threadIdx.x; q < nq; q += gridDim.x * kT) {
+    const int64_t r_new = (int64_t)first[q / brows] + q % brows;
+    int32_t len         = 0;
+    if (r_new < rows) {
+      const int32_t r = row_new2old ? (int32_t)row_new2old[r_new] : (int32_t)r_new;
+      len             = off[r + 1] - off[r];
+      if (len > kLongRow) len = 0;
+    }
+    lens[q] = len;
+  }
+}
+
+__global__ void __launch_bounds__(kT) k_sample_fill(int32_t nq, int32_t brows, const int32_t* __restrict__ first, int32_t rows,
+                                                    const uint32_t* __restrict__ row_new2old, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ idx, const int32_t* __restrict__ col_old2new,
+                                                    const int32_t* __restrict__ soff, int32_t* __restrict__ sidx)
+{
+  for (int32_t q = blockIdx.x * kT + threadIdx.x; q < nq; q += gridDim.x * kT) {
+    const int32_t len = soff[q + 1] - soff[q];
+    if (len == 0) continue;
+    const int64_t r_new = (int64_t)first[q / brows] + q % brows;
+    const int32_t r     = row_new2old ? (int32_t)row_new2old[r_new] : (int32_t)r_new;
+    const int32_t k0    = off[r];
+    for (int32_t k = 0; k < len; ++k) {
+      const int32_t c   = idx[k0 + k];
+      sidx[soff[q] + k] = col_old2new ? col_old2new[c] : c;
+    }
+  }
+}
+
+// ---- the permuted CSR pair ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kT) k_new_labels(int64_t nnz, const int32_t* __restrict__ off, int32_t rows, const int32_t* __restrict__ idx,
+                                                   const int32_t* __restrict__ row_old2new, const int32_t* __restrict__ col_old2new,
+                                                   uint32_t* __restrict__ newrow, uint32_t* __restrict__ newcol)
+{
+  for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kT) {
+    newrow[k] = (uint32_t)row_old2new[row_of(off, rows, k)];
+    newcol[k] = (uint32_t)col_old2new[idx[k]];
+  }
+}
+
+__global__ void __launch_bounds__(kT) k_gather_u32(int64_t n, const uint32_t* __restrict__ src, const uint32_t* __restrict__ at, uint32_t* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) out[i] = src[at[i]];
+}
+
+__global__ void __launch_bounds__(kT) k_emit_csr(int64_t n, const uint32_t* __restrict__ src_pos, const uint32_t* __restrict__ label,
+                                                 const double* __restrict__ val, int32_t* __restrict__ out_idx, double* __restrict__ out_val)
+{
+  for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q < n; q += (int64_t)gridDim.x * kT) {
+    const uint32_t k = src_pos[q];
+    out_idx[q] = (int32_t)label[k], out_val[q] = val[k];
+  }
+}
+
+// ================================================================================================
+// slab-major panels on the device
+// ================================================================================================
+__global__ void __launch_bounds__(kT) k_panel_count(const int32_t* __restrict__ row0, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ idx, int S, int32_t slab_w, int64_t own_from,
+                                                    int32_t* __restrict__ count /* [W][S] */)
+{
+  __shared__ int c[16];
+  if (threadIdx.x < 16) c[threadIdx.x] = 0;
+  __syncthreads();
+  const int w = blockIdx.x;
+  const int32_t a = row0[w], b = row0[w + 1];
+  // rows that stay in the panel are contiguous in the CSR except for the own rows: walk row by row, a wave per row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int32_t i = a + wave; i < b; i += kT / 64) {
+    const int32_t k0 = off[i], k1 = off[i + 1];
+    if ((int64_t)(k1 - k0) > own_from) continue;
+    for (int32_t k = k0 + lane; k < k1; k += 64) atomicAdd(&c[idx[k] / slab_w], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < S) count[(size_t)w * S + threadIdx.x] = c[threadIdx.x];
+}
+
+// placement in (slab, row, CSR) order.  LDS: per (slab, row) the number of entries, then its exclusive prefix over the rows of the slab
+// (= the uint16 row pointers the row kernel reads); thread <-> row.
+template <bool SEG>
+__global__ void __launch_bounds__(512) k_panel_place(const int32_t* __restrict__ row0, const int32_t* __restrict__ off,
+                                                     const int32_t* __restrict__ idx, int S, int32_t slab_w, int64_t own_from,
+                                                     const int32_t* __restrict__ tile_ptr, const int64_t* __restrict__ rp_base,
+                                                     uint16_t* __restrict__ rowptr, int32_t* __restrict__ perm, int32_t* __restrict__ col)
+{
+  extern __shared__ unsigned short cnt[];  // [S][nr + 1]
+  __shared__ int scratch[9];
+  const int w = blockIdx.x;
+  const int32_t a = row0[w], nr = row0[w + 1] - a;
+  const int stride = nr + 1;
+  for (int i = threadIdx.x; i < S * stride; i += 512) cnt[i] = 0;
+  __syncthreads();
+  for (int32_t r = threadIdx.x; r < nr; r += 512) {
+    const int32_t k0 = off[a + r], k1 = off[a + r + 1];
+    if ((int64_t)(k1 - k0) > own_from) continue;
+    for (int32_t k = k0; k < k1; ++k) cnt[(idx[k] / slab_w) * stride + r] += 1;  // (slab, row) is this thread's alone
+  }
+  __syncthreads();
+  // exclusive prefix over the rows, slab by slab (nr + 1 entries: the last one is the tile's size)
+  for (int s2 = 0; s2 < S; ++s2) {
+    int carry = 0;
+    for (int r0 = 0; r0 < stride; r0 += 512) {
+      const int r = r0 + threadIdx.x;
+      const int v = r < nr ? (int)cnt[s2 * stride + r] : 0;
+      int total   = 0;
+      const int pre = block_exclusive_scan<512>(v, scratch, &total);
+      if (r < stride) cnt[s2 * stride + r] = (unsigned short)(carry + pre);
+      carry += total;
+    }
+  }
+  __syncthreads();
+  if (!SEG)
+    for (int s2 = 0; s2 < S; ++s2) {
+      uint16_t* dst = rowptr + rp_base[(size_t)w * S + s2];
+      for (int r = threadIdx.x; r < stride; r += 512) dst[r] = cnt[s2 * stride + r];
+    }
+  __syncthreads();  // (the row pointers are out: the prefixes turn into cursors)
+  for (int32_t r = threadIdx.x; r < nr; r += 512) {
+    const int32_t k0 = off[a + r], k1 = off[a + r + 1];
+    if ((int64_t)(k1 - k0) > own_from) continue;
+    for (int32_t k = k0; k < k1; ++k) {  // CSR order inside (slab, row), whatever the column order of the row is
+      const int32_t c = idx[k];
+      const int s2    = c / slab_w;
+      const int32_t q = tile_ptr[(size_t)w * S + s2] + (int32_t)(cnt[s2 * stride + r]++);
+      perm[q] = k;
+      col[q]  = SEG ? (int32_t)(((uint32_t)r << kSegColBits) | (uint32_t)(c - s2 * slab_w)) : c;
+    }
+  }
+}
+
+struct Lap {
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  std::string* out;
+  hipStream_t s;
+  explicit Lap(std::string* o, hipStream_t st) : out(o), s(st) {}
+  double operator()(const char* what, bool sync = true)
+  {
+    if (sync) (void)hipStreamSynchronize(s);
+    const auto now  = std::chrono::steady_clock::now();
+    const double ms = 1e3 * std::chrono::duration<double>(now - last).count();
+    last            = now;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s %.2f ms; ", what, ms);
+    *out += buf;
+    return ms;
+  }
+};
+
+}  // namespace
+
+// ================================================================================================
+// host-side structure mirrors
+// ================================================================================================
+const int32_t* analysis_host_off(pdlpdev_analysis* an)
+{
+  if (!an->permuted) return an->h_off;
+  if (!an->have_hp) (void)analysis_host_idx(an);
+  return an->hp_off.get();
+}
+const int32_t* analysis_host_idx(pdlpdev_analysis* an)
+{
+  if (!an->permuted) return an->h_idx;
+  if (!an->have_hp) {
+    an->hp_off.reset((size_t)an->m + 1), an->hp_idx.reset((size_t)std::max<int64_t>(an->nnz, 1));
+    (void)hipMemcpyAsync(an->hp_off.get(), an->A.off, ((size_t)an->m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    (void)hipMemcpyAsync(an->hp_idx.get(), an->A.idx, (size_t)an->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    (void)hipStreamSynchronize(an->stream);
+    an->have_hp = true;
+  }
+  return an->hp_idx.get();
+}
+const int32_t* analysis_host_t_off(pdlpdev_analysis* an)
+{
+  if (!an->have_hpt_off) {
+    an->hpt_off.reset((size_t)an->n + 1);
+    (void)hipMemcpyAsync(an->hpt_off.get(), an->At.off, ((size_t)an->n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    (void)hipStreamSynchronize(an->stream);
+    an->have_hpt_off = true;
+  }
+  return an->hpt_off.get();
+}
+const int32_t* analysis_host_t_idx(pdlpdev_analysis* an)
+{
+  if (!an->have_hpt_idx) {
+    an->hpt_idx.reset((size_t)std::max<int64_t>(an->nnz, 1));
+    (void)hipMemcpyAsync(an->hpt_idx.get(), an->At.idx, (size_t)an->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    (void)hipStreamSynchronize(an->stream);
+    an->have_hpt_idx = true;
+  }
+  return an->hpt_idx.get();
+}
+
+// ================================================================================================
+// the ordering search
+// ================================================================================================
+namespace {
+
+struct Side {  // one side of the bipartite graph: its vertices' adjacency
+  int32_t count;
+  const int32_t *off, *idx;
+};
+
+// jagged-layout estimate of P M Q for M = A (side 0) or A^T (side 1) under candidate maps (null: identity); < 0: not applicable
+int estimate_saving(pdlpdev_analysis* an, int side, const uint32_t* d_row_new2old, const int32_t* d_col_old2new, double* saving)
+{
+  const int32_t rows = side == 0 ? an->m : an->n;
+  const DevCsr& M    = side == 0 ? an->A : an->At;
+  int G = 0, waves = 8, wcap = 0, brows = 0;
+  *saving = 0.0;
+  if (!jag_geometry(rows, 0, &G, &waves, &wcap, &brows)) return 0;
+  const int samples = (int)std::min<int64_t>(48, std::max<int64_t>(1, rows / brows));
+  std::vector<int32_t> first(samples);
+  for (int t = 0; t < samples; ++t) first[t] = (int32_t)((int64_t)rows * t / samples);
+  const int32_t nq = samples * brows;
+  DevArena& ar     = an->arena;
+  const size_t mark = ar.mark();
+  int32_t* d_first = ar.take<int32_t>(samples);
+  int32_t* d_lens  = ar.take<int32_t>((size_t)nq + 1);
+  int32_t* d_soff  = ar.take<int32_t>((size_t)nq + 1);
+  int32_t* d_bs    = ar.take<int32_t>((size_t)nq / kScanTile + 2);
+  int32_t* d_sidx  = ar.take<int32_t>((size_t)nq * kLongRow);
+  if (!d_first || !d_lens || !d_soff || !d_bs || !d_sidx) return fail(-2, "device set-up: workspace too small for the layout estimate");
+  hipStream_t s = an->stream;
+  HIP_TRY(hipMemcpyAsync(d_first, first.data(), samples * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  k_sample_lens<<<grid_of(nq), kT, 0, s>>>(nq, brows, d_first, rows, d_row_new2old, M.off, d_lens);
+  TRY(dev_exclusive_scan(s, d_lens, d_soff, nq, d_bs));
+  k_sample_fill<<<grid_of(nq), kT, 0, s>>>(nq, brows, d_first, rows, d_row_new2old, M.off, M.idx, d_col_old2new, d_soff, d_sidx);
+  std::vector<int32_t> soff((size_t)nq + 1);
+  HIP_TRY(hipMemcpyAsync(soff.data(), d_soff, ((size_t)nq + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> sidx((size_t)std::max(soff[nq], 1));
+  HIP_TRY(hipMemcpyAsync(sidx.data(), d_sidx, (size_t)soff[nq] * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  ar.release(mark);
+  if (d_col_old2new)  // a permuted row's columns arrive in the old order
+    cuopt_amd::parallel_tasks(samples, [&](int t) {
+      for (int32_t q = t * brows; q < (t + 1) * brows; ++q) std::sort(sidx.begin() + soff[q], sidx.begin() + soff[q + 1]);
+    }, soff[nq]);
+  *saving = jag_estimate_on_samples(samples, brows, wcap, soff.data(), sidx.data());
+  return 0;
+}
+
+struct Bfs {
+  int32_t *lev_r = nullptr, *lev_c = nullptr;
+  int32_t *fr_r = nullptr, *fr_c = nullptr;
+  int32_t* counts = nullptr;  // frontier size per level
+  int max_levels  = 0;
+};
+
+// level-synchronous search from one row; returns the number of levels run (the last non-empty level index + 1) and the sizes
+int run_bfs(pdlpdev_analysis* an, const Bfs& B, int32_t start_row, int level_cap, bool stop_when_small_world, std::vector<int32_t>* sizes,
+            bool* small_world)
+{
+  hipStream_t s = an->stream;
+  const int32_t m = an->m, n = an->n;
+  k_bfs_init<<<grid_of(m), kT, 0, s>>>(m, an->A.off, kLongRow, B.lev_r);
+  k_bfs_init<<<grid_of(n), kT, 0, s>>>(n, an->At.off, kLongRow, B.lev_c);
+  HIP_TRY(hipMemsetAsync(B.counts, 0, ((size_t)B.max_levels + 2) * sizeof(int32_t), s));
+  k_bfs_seed<<<1, 1, 0, s>>>(B.lev_r, start_row, B.fr_r, B.counts);
+  sizes->clear();
+  *small_world = false;
+  const int grid = 512;
+  int level = 0;  // level of the frontier about to be expanded (rows: even, columns: odd)
+  int batch = 8;
+  int64_t reached = 1;
+  const int64_t all = (int64_t)m + n;
+  for (;;) {
+    const int upto = std::min(level + batch, std::min(level_cap, B.max_levels));
+    for (; level < upto; ++level) {
+      if ((level & 1) == 0)
+        k_bfs_expand<<<grid, kT, 0, s>>>(B.fr_r, B.counts + level, an->A.off, an->A.idx, B.lev_c, B.fr_c, B.counts + level + 1, level + 1);
+      else
+        k_bfs_expand<<<grid, kT, 0, s>>>(B.fr_c, B.counts + level, an->At.off, an->At.idx, B.lev_r, B.fr_r, B.counts + level + 1, level + 1);
+    }
+    const size_t have = sizes->size();
+    sizes->resize((size_t)level + 1);
+    HIP_TRY(hipMemcpyAsync(sizes->data() + have, B.counts + have, ((size_t)level + 1 - have) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = std::max<size_t>(have, 1); i < sizes->size(); ++i) reached += (*sizes)[i];
+    if (sizes->back() == 0) break;
+    if (level >= level_cap || level >= B.max_levels) break;
+    // a graph whose search covers most of it within a dozen levels has no level structure worth ordering by
+    if (stop_when_small_world && level <= 16 && reached * 2 > all) {
+      *small_world = true;
+      break;
+    }
+    batch = std::min(batch * 2, 128);
+  }
+  while (!sizes->empty() && sizes->back() == 0) sizes->pop_back();
+  an->bfs_reached = reached;
+  HIP_TRY(hipGetLastError());
+  return (int)sizes->size();
+}
+
+int keys_to_perm(pdlpdev_analysis* an, SortBufs& SB, int32_t count, const uint32_t* d_keys, int bits, uint32_t* d_new2old, int32_t* d_old2new)
+{
+  int slot = 0;
+  TRY(radix_sort_pairs(an->stream, count, d_keys, nullptr, SB, bits, &slot));
+  HIP_TRY(hipMemcpyAsync(d_new2old, SB.v[slot], (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, an->stream));
+  k_invert_perm<<<grid_of(count), kT, 0, an->stream>>>(count, d_new2old, d_old2new);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// Looks for a row / column order under which the jagged layout applies.  On success (an->method != 0) the device holds the maps in
+// d_maps = {row new2old, col new2old, row old2new, col old2new} (arena memory, valid until the caller releases its mark).
+static int find_ordering(pdlpdev_analysis* an, uint32_t** d_row_new2old, uint32_t** d_col_new2old, int32_t** d_row_old2new,
+                         int32_t** d_col_old2new, Lap& lap)
+{
+  const int32_t m = an->m, n = an->n;
+  DevArena& ar = an->arena;
+  hipStream_t s = an->stream;
+  an->method = 0;
+  const int level_cap = (int)cuopt_amd::tune_int("reorder_level_cap", 8192);
+  Bfs B;
+  B.max_levels = level_cap + 2;
+  B.lev_r = ar.take<int32_t>(m), B.lev_c = ar.take<int32_t>(n);
+  B.fr_r = ar.take<int32_t>(m), B.fr_c = ar.take<int32_t>(n);
+  B.counts = ar.take<int32_t>((size_t)B.max_levels + 2);
+  uint32_t* row_n2o = ar.take<uint32_t>(m);
+  uint32_t* col_n2o = ar.take<uint32_t>(n);
+  int32_t* row_o2n  = ar.take<int32_t>(m);
+  int32_t* col_o2n  = ar.take<int32_t>(n);
+  uint32_t* key_r   = ar.take<uint32_t>(m);
+  uint32_t* key_c   = ar.take<uint32_t>(n);
+  unsigned long long* d_best = ar.take<unsigned long long>(1);
+  SortBufs SB;
+  TRY(sort_bufs_take(ar, &SB, std::max(m, n)));
+  if (!B.lev_r || !B.lev_c || !B.fr_r || !B.fr_c || !B.counts || !row_n2o || !col_n2o || !row_o2n || !col_o2n || !key_r || !key_c || !d_best)
+    return fail(-2, "device set-up: workspace too small for the ordering search");
+  *d_row_new2old = row_n2o, *d_col_new2old = col_n2o, *d_row_old2new = row_o2n, *d_col_old2new = col_o2n;
+  const double accept = 0.5;  // the full construction's own threshold (build_jag)
+
+  // ---- candidate 1: breadth-first levels from a pseudo-peripheral row + barycentre sweeps (band-like structure) ----
+  int32_t start = 0;
+  {
+    // the first row that has entries and is no hub (host offsets of the unpermuted A are the caller's)
+    const int32_t* off = an->h_off;
+    while (start < m && (off[start + 1] == off[start] || off[start + 1] - off[start] > kLongRow)) ++start;
+    if (start >= m) return 0;
+  }
+  std::vector<int32_t> sizes;
+  bool small_world = false;
+  int levels = run_bfs(an, B, start, level_cap, true, &sizes, &small_world);
+  if (levels < 0) return levels;
+  lap("search 1");
+  if (!small_world && levels >= 24 && an->bfs_reached * 10 >= ((int64_t)m + n) * 8) {
+    HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s));
+    k_find_far<<<grid_of(m), kT, 0, s>>>(m, B.lev_r, d_best);
+    unsigned long long best = 0;
+    HIP_TRY(hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int32_t far = (int32_t)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
+    levels = run_bfs(an, B, far, level_cap, false, &sizes, &small_world);
+    if (levels < 0) return levels;
+    an->bfs_levels = levels;
+    lap("search 2");
+    // positions: level, then two barycentre sweeps each way (the order inside a level follows the neighbours' positions)
+    float* pos_r  = (float*)key_r;  // (the key arrays double as position buffers until the keys are formed)
+    float* pos_c  = (float*)key_c;
+    float* pos_r2 = ar.take<float>(m);
+    float* pos_c2 = ar.take<float>(n);
+    if (!pos_r2 || !pos_c2) return fail(-2, "device set-up: workspace too small for the ordering search");
+    k_level_to_pos<<<grid_of(m), kT, 0, s>>>(m, B.lev_r, pos_r);
+    k_level_to_pos<<<grid_of(n), kT, 0, s>>>(n, B.lev_c, pos_c);
+    const int sweeps = (int)cuopt_amd::tune_int("reorder_sweeps", 2);
+    for (int it = 0; it < sweeps; ++it) {
+      k_barycentre<<<grid_of(n), kT, 0, s>>>(n, an->At.off, an->At.idx, pos_c, pos_r, pos_c2);
+      k_barycentre<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, pos_r, pos_c2, pos_r2);
+      HIP_TRY(hipMemcpyAsync(pos_r, pos_r2, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(pos_c, pos_c2, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    const float scale       = 64.0f;
+    const uint32_t last_key = (uint32_t)((levels + 2) * 64);
+    uint32_t* kr            = (uint32_t*)pos_r2;
+    uint32_t* kc            = (uint32_t*)pos_c2;
+    k_pos_to_key<<<grid_of(m), kT, 0, s>>>(m, pos_r, scale, last_key, kr);
+    k_pos_to_key<<<grid_of(n), kT, 0, s>>>(n, pos_c, scale, last_key, kc);
+    TRY(keys_to_perm(an, SB, m, kr, bits_for(last_key), row_n2o, row_o2n));
+    TRY(keys_to_perm(an, SB, n, kc, bits_for(last_key), col_n2o, col_o2n));
+    lap("levels -> order");
+    TRY(estimate_saving(an, 0, row_n2o, col_o2n, &an->saving_levels[0]));
+    if (an->saving_levels[0] >= accept) TRY(estimate_saving(an, 1, col_n2o, row_o2n, &an->saving_levels[1]));
+    lap("estimate 1");
+    if (an->saving_levels[0] >= accept && an->saving_levels[1] >= accept) {
+      an->method = 1;
+      return 0;
+    }
+  }
+  // ---- candidate 2: seeded cells (block-like structure behind linking rows / columns) ----
+  {
+    int G = 0, waves = 8, wcap = 0, brows = 0;
+    if (!jag_geometry(m, 0, &G, &waves, &wcap, &brows)) return 0;
+    const int32_t spacing = (int32_t)std::max<long long>(64, cuopt_amd::tune_int("reorder_cell_rows", brows));
+    const int32_t ncells  = (int32_t)std::min<int64_t>(((int64_t)m + spacing - 1) / spacing, (1 << 24) - 2);
+    const int rounds_cap  = 48;
+    HIP_TRY(hipMemsetAsync(B.counts, 0, ((size_t)rounds_cap + 2) * sizeof(int32_t), s));
+    k_cell_init<<<grid_of(m), kT, 0, s>>>(m, an->A.off, kLongRow, key_r);
+    k_cell_init<<<grid_of(n), kT, 0, s>>>(n, an->At.off, kLongRow, key_c);
+    k_cell_seed<<<(ncells + kT - 1) / kT, kT, 0, s>>>(m, spacing, ncells, an->A.off, key_r, B.fr_r, B.counts);
+    int level = 0;
+    std::vector<int32_t> csz;
+    for (;;) {
+      const int upto = std::min(level + 8, rounds_cap);
+      for (; level < upto; ++level) {
+        if ((level & 1) == 0)
+          k_cell_expand<<<512, kT, 0, s>>>(B.fr_r, B.counts + level, an->A.off, an->A.idx, key_r, key_c, B.fr_c, B.counts + level + 1);
+        else
+          k_cell_expand<<<512, kT, 0, s>>>(B.fr_c, B.counts + level, an->At.off, an->At.idx, key_c, key_r, B.fr_r, B.counts + level + 1);
+      }
+      csz.resize((size_t)level + 1);
+      HIP_TRY(hipMemcpyAsync(csz.data(), B.counts, ((size_t)level + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (csz.back() == 0 || level >= rounds_cap) break;
+    }
+    an->cell_rounds = level;
+    // Cells that belong together become neighbours in the order: the quotient graph (cells x cells, weight = nonzeros between them)
+    // comes to the host; cells joined by an edge that carries >= 5 % of the lighter cell's nonzeros form a group (the cells of one
+    // diagonal block reference each other's columns all the time; across blocks there are only the linking columns), groups in the
+    // order of their first cell, cells inside a group in breadth-first order over the strong edges (a chain of cells stays a chain).
+    int32_t* d_rank = nullptr;
+    const int32_t K = ncells + 1;
+    if (K <= 4096) {
+      int32_t* W = ar.take<int32_t>((size_t)K * K);
+      d_rank     = ar.take<int32_t>((size_t)K);
+      if (!W || !d_rank) return fail(-2, "device set-up: workspace too small for the cells' quotient graph");
+      HIP_TRY(hipMemsetAsync(W, 0, (size_t)K * K * sizeof(int32_t), s));
+      k_cell_quotient<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, key_r, key_c, K, W);
+      std::vector<int32_t> hw((size_t)K * K);
+      HIP_TRY(hipMemcpyAsync(hw.data(), W, hw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      std::vector<int64_t> tot(K, 0);
+      auto sym = [&](int a, int b) { return (int64_t)hw[(size_t)a * K + b] + (a == b ? 0 : hw[(size_t)b * K + a]); };
+      for (int a = 1; a < K; ++a)
+        for (int b = 1; b < K; ++b) tot[a] += a == b ? hw[(size_t)a * K + a] : sym(a, b);
+      std::vector<int32_t> rank(K, 0), order;
+      std::vector<char> seen(K, 0);
+      order.reserve(K);
+      for (int a0 = 1; a0 < K; ++a0) {
+        if (seen[a0]) continue;
+        size_t head = order.size();
+        order.push_back(a0), seen[a0] = 1;
+        while (head < order.size()) {
+          const int a = order[head++];
+          // strong neighbours, the heaviest edge first (ties: the smaller id) -- a fixed rule
+          std::vector<std::pair<int64_t, int>> nb;
+          for (int b = 1; b < K; ++b)
+            if (!seen[b] && b != a) {
+              const int64_t w = sym(a, b);
+              if (w > 0 && w * 20 >= std::min(tot[a], tot[b])) nb.emplace_back(-w, b);
+            }
+          std::sort(nb.begin(), nb.end());
+          for (auto& e : nb) order.push_back(e.second), seen[e.second] = 1;
+        }
+      }
+      for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (int32_t)i;
+      HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    uint32_t* kr = (uint32_t*)B.lev_r;  // (the level arrays are free now)
+    uint32_t* kc = (uint32_t*)B.lev_c;
+    k_cell_to_key<<<grid_of(m), kT, 0, s>>>(m, key_r, d_rank, kr);
+    k_cell_to_key<<<grid_of(n), kT, 0, s>>>(n, key_c, d_rank, kc);
+    TRY(keys_to_perm(an, SB, m, kr, 32, row_n2o, row_o2n));
+    TRY(keys_to_perm(an, SB, n, kc, 32, col_n2o, col_o2n));
+    lap("cells -> order");
+    TRY(estimate_saving(an, 0, row_n2o, col_o2n, &an->saving_cells[0]));
+    if (an->saving_cells[0] >= accept) TRY(estimate_saving(an, 1, col_n2o, row_o2n, &an->saving_cells[1]));
+    lap("estimate 2");
+    if (an->saving_cells[0] >= accept && an->saving_cells[1] >= accept) an->method = 2;
+  }
+  return 0;
+}
+
+// P A Q and its transpose on the device from A and the maps; replaces an->A / an->At
+static int build_permuted_pair(pdlpdev_analysis* an, const int32_t* d_row_o2n, const int32_t* d_col_o2n)
+{
+  const int32_t m = an->m, n = an->n;
+  const int64_t nnz = an->nnz;
+  DevArena& ar = an->arena;
+  hipStream_t s = an->stream;
+  const size_t mark = ar.mark();
+  uint32_t* newrow = ar.take<uint32_t>((size_t)nnz);
+  uint32_t* newcol = ar.take<uint32_t>((size_t)nnz);
+  uint32_t* gkeys  = ar.take<uint32_t>((size_t)nnz);
+  SortBufs SB;
+  TRY(sort_bufs_take(ar, &SB, nnz));
+  if (!newrow || !newcol || !gkeys) return fail(-2, "device set-up: workspace too small for the permuted matrices");
+  // the new matrices (the old A^T is dropped first: its memory is reused through the allocator)
+  DevCsr NA, NT;
+  HIP_TRY(hipMalloc((void**)&NA.off, ((size_t)m + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&NA.idx, ((size_t)nnz + 8) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&NA.val, ((size_t)nnz + 8) * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&NT.off, ((size_t)n + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&NT.idx, ((size_t)nnz + 8) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&NT.val, ((size_t)nnz + 8) * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(NA.idx + nnz, 0, 8 * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(NA.val + nnz, 0, 8 * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(NT.idx + nnz, 0, 8 * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(NT.val + nnz, 0, 8 * sizeof(double), s));
+  k_new_labels<<<grid_of(nnz), kT, 0, s>>>(nnz, an->A.off, m, an->A.idx, d_row_o2n, d_col_o2n, newrow, newcol);
+  const int bits_r = bits_for((uint32_t)std::max(m - 1, 1)), bits_c = bits_for((uint32_t)std::max(n - 1, 1));
+  int slot = 0;
+  // by new column (source order inside), then stable by new row: (new row, new column) order = P A Q
+  TRY(radix_sort_pairs(s, nnz, newcol, nullptr, SB, bits_c, &slot));
+  k_gather_u32<<<grid_of(nnz), kT, 0, s>>>(nnz, newrow, SB.v[slot], gkeys);
+  // (the values of one sort are the input values of the next; its first pass writes to slot 0, so they move to a buffer of their own)
+  uint32_t* carry = ar.take<uint32_t>((size_t)nnz);
+  if (!carry) return fail(-2, "device set-up: workspace too small for the permuted matrices");
+  HIP_TRY(hipMemcpyAsync(carry, SB.v[slot], (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  TRY(radix_sort_pairs(s, nnz, gkeys, carry, SB, bits_r, &slot));
+  k_offsets_from_sorted<<<grid_of(nnz + 1), kT, 0, s>>>(SB.k[slot], nnz, m, NA.off);
+  k_emit_csr<<<grid_of(nnz), kT, 0, s>>>(nnz, SB.v[slot], newcol, an->A.val, NA.idx, NA.val);
+  // ... then stable by new column again: (new column, new row) order = its transpose
+  HIP_TRY(hipMemcpyAsync(carry, SB.v[slot], (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  k_gather_u32<<<grid_of(nnz), kT, 0, s>>>(nnz, newcol, carry, gkeys);
+  TRY(radix_sort_pairs(s, nnz, gkeys, carry, SB, bits_c, &slot));
+  k_offsets_from_sorted<<<grid_of(nnz + 1), kT, 0, s>>>(SB.k[slot], nnz, n, NT.off);
+  k_emit_csr<<<grid_of(nnz), kT, 0, s>>>(nnz, SB.v[slot], newrow, an->A.val, NT.idx, NT.val);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  // swap in
+  for (void* p : {(void*)an->A.off, (void*)an->A.idx, (void*)an->A.val, (void*)an->At.off, (void*)an->At.idx, (void*)an->At.val}) {
+    an->owned.erase(std::remove(an->owned.begin(), an->owned.end(), p), an->owned.end());
+    (void)hipFree(p);
+  }
+  an->A = NA, an->At = NT;
+  for (void* p : {(void*)NA.off, (void*)NA.idx, (void*)NA.val, (void*)NT.off, (void*)NT.idx, (void*)NT.val}) an->owned.push_back(p);
+  an->have_hp = an->have_hpt_off = an->have_hpt_idx = false;
+  ar.release(mark);
+  return 0;
+}
+
+extern "C" {
+
+void pdlpdev_analysis_destroy(pdlpdev_analysis* an)
+{
+  if (!an) return;
+  (void)hipSetDevice(an->device);
+  if (an->stream) (void)hipStreamSynchronize(an->stream);
+  for (void* p : an->owned) (void)hipFree(p);
+  if (an->bundle_owned && an->stream) {
+    // the stream goes back to the pool the contexts draw from (an HSA queue costs ~2 ms to create)
+    if (!(an->pinned && an->chunk && give_recycled(Recycled{an->device, an->stream, an->pinned, an->chunk}))) {
+      if (an->pinned) (void)hipHostFree(an->pinned);
+      if (an->chunk) (void)hipFree(an->chunk);
+      (void)hipStreamDestroy(an->stream);
+    }
+  }
+  delete an;
+}
+
+// Uploads A (host CSR, m x n), builds A^T on the device and -- flags bit 0 -- looks for a row / column order under which the jagged
+// layout applies (accepted only when the layout's own cost estimate passes for BOTH matrices; then A and A^T on the device are the
+// permuted pair).  The host arrays must stay valid until the analysis is consumed (pdlpdev_create_from_analysis) or destroyed.
+int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_off, const int32_t* a_idx,
+                    const double* a_val, int flags)
+{
+  roctx::Range range("pdlp: device analysis (upload, transpose, ordering)");
+  if (!out || m < 0 || n < 0 || !a_off) return fail(-1, "pdlpdev_analyze: bad argument");
+  if (pdlpdev_device_count() <= device)
+    return fail(-5, "pdlpdev_analyze: no HIP device %d visible (this solver has no CPU fallback)", device);
+  HIP_TRY(hipSetDevice(device));
+  pdlpdev_analysis* an = new pdlpdev_analysis();
+  *out       = an;
+  an->device = device, an->m = m, an->n = n, an->nnz = a_off[m];
+  an->h_off = a_off, an->h_idx = a_idx, an->h_val = a_val;
+  {
+    Recycled r;
+    if (take_recycled(device, &r)) {
+      an->stream = r.stream, an->pinned = r.pinned, an->chunk = r.chunk;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&an->stream, hipStreamNonBlocking));
+      HIP_TRY(hipHostMalloc((void**)&an->pinned, kScalars * sizeof(double) + sizeof(pdlpdev_ctl)));
+      HIP_TRY(hipMalloc((void**)&an->chunk, kArenaChunk));
+    }
+  }
+  hipStream_t s     = an->stream;
+  const int64_t nnz = an->nnz;
+  Lap lap(&an->laps, s);
+  auto dmalloc = [&](void** p, size_t bytes) -> int {
+    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    an->owned.push_back(*p);
+    return 0;
+  };
+  TRY(dmalloc((void**)&an->A.off, ((size_t)m + 1) * sizeof(int32_t)));
+  TRY(dmalloc((void**)&an->A.idx, ((size_t)nnz + 8) * sizeof(int32_t)));
+  TRY(dmalloc((void**)&an->A.val, ((size_t)nnz + 8) * sizeof(double)));
+  TRY(dmalloc((void**)&an->At.off, ((size_t)n + 1) * sizeof(int32_t)));
+  TRY(dmalloc((void**)&an->At.idx, ((size_t)nnz + 8) * sizeof(int32_t)));
+  TRY(dmalloc((void**)&an->At.val, ((size_t)nnz + 8) * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(an->A.off, a_off, ((size_t)m + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (nnz) {
+    HIP_TRY(hipMemcpyAsync(an->A.idx, a_idx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(an->A.val, a_val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemsetAsync(an->A.idx + nnz, 0, 8 * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(an->A.val + nnz, 0, 8 * sizeof(double), s));
+  HIP_TRY(hipMemsetAsync(an->At.idx + nnz, 0, 8 * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(an->At.val + nnz, 0, 8 * sizeof(double), s));
+  // workspace: the permuted pair's three sorts are the largest user (7 arrays of nnz words + histograms); the ordering search needs
+  // ~14 arrays of max(m, n) words
+  {
+    const bool reorder = (flags & 1) != 0;
+    const size_t words = (size_t)std::max<int64_t>(nnz, 1);
+    const size_t verts = (size_t)std::max(m, n) + 64;
+    size_t bytes = 4 * (words * (reorder ? 9 : 4) + (words / kRsTile + 2) * 256 + 4096) + (reorder ? 4 * verts * 20 + 48ull * 4096 * kLongRow * 4 + 4096ull * 4096 * 4 : 0) + (1 << 20);
+    an->arena.cap = bytes;
+    TRY(dmalloc((void**)&an->arena.base, bytes));
+  }
+  an->ms_upload = lap("upload A");
+  TRY(dev_transpose(s, an->arena, m, n, nnz, an->A, an->At));
+  an->ms_transpose = lap("transpose");
+  if ((flags & 1) && nnz > 0) {
+    const size_t mark = an->arena.mark();
+    // the order the matrix came in: nothing to look for when the jagged layout already applies
+    TRY(estimate_saving(an, 0, nullptr, nullptr, &an->saving_natural[0]));
+    TRY(estimate_saving(an, 1, nullptr, nullptr, &an->saving_natural[1]));
+    an->estimated = true;
+    lap("estimate 0");
+    int G = 0, waves = 0, wcap = 0, brows = 0;
+    const bool big_enough = jag_geometry(m, 0, &G, &waves, &wcap, &brows) && jag_geometry(n, 0, &G, &waves, &wcap, &brows);
+    if (big_enough && !(an->saving_natural[0] >= 0.35 && an->saving_natural[1] >= 0.35)) {
+      uint32_t *rn2o = nullptr, *cn2o = nullptr;
+      int32_t *ro2n = nullptr, *co2n = nullptr;
+      TRY(find_ordering(an, &rn2o, &cn2o, &ro2n, &co2n, lap));
+      if (an->method != 0) {
+        an->row_new2old.resize(m), an->col_new2old.resize(n);
+        HIP_TRY(hipMemcpyAsync(an->row_new2old.data(), rn2o, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(an->col_new2old.data(), cn2o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TRY(build_permuted_pair(an, ro2n, co2n));
+        an->permuted = true;
+        an->ms_permute = lap("permuted pair");
+      }
+    }
+    an->arena.release(mark);
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (getenv("CUOPT_AMD_TIMING"))
+    fprintf(stderr, "[cuopt_amd setup]   analysis: %s| natural %.2f/%.2f levels(%d) %.2f/%.2f cells(%d) %.2f/%.2f -> method %d\n", an->laps.c_str(),
+            an->saving_natural[0], an->saving_natural[1], an->bfs_levels, an->saving_levels[0], an->saving_levels[1], an->cell_rounds,
+            an->saving_cells[0], an->saving_cells[1], an->method);
+  return 0;
+}
+
+// out = {permuted, method, natural A, natural A^T, levels A, levels A^T, cells A, cells A^T (x 1e4), search levels, cell rounds}
+int pdlpdev_analysis_info(pdlpdev_analysis* an, int32_t out[10])
+{
+  if (!an) return fail(-1, "pdlpdev_analysis_info: null");
+  out[0] = an->permuted, out[1] = an->method;
+  out[2] = (int32_t)(1e4 * an->saving_natural[0]), out[3] = (int32_t)(1e4 * an->saving_natural[1]);
+  out[4] = (int32_t)(1e4 * an->saving_levels[0]), out[5] = (int32_t)(1e4 * an->saving_levels[1]);
+  out[6] = (int32_t)(1e4 * an->saving_cells[0]), out[7] = (int32_t)(1e4 * an->saving_cells[1]);
+  out[8] = an->bfs_levels, out[9] = an->cell_rounds;
+  return 0;
+}
+
+// the maps of an accepted ordering: row_new2old[m], col_new2old[n] (either may be null); returns 1 when permuted, 0 when not
+int pdlpdev_analysis_maps(pdlpdev_analysis* an, int32_t* row_new2old, int32_t* col_new2old)
+{
+  if (!an) return fail(-1, "pdlpdev_analysis_maps: null");
+  if (!an->permuted) return 0;
+  if (row_new2old) memcpy(row_new2old, an->row_new2old.data(), (size_t)an->m * sizeof(int32_t));
+  if (col_new2old) memcpy(col_new2old, an->col_new2old.data(), (size_t)an->n * sizeof(int32_t));
+  return 1;
+}
+
+// the matrices the device holds, as host CSR (parity tests; the sharded path slices the permuted matrix): which = 0 A, 1 A^T; any
+// pointer may be null
+int pdlpdev_analysis_download(pdlpdev_analysis* an, int which, int32_t* off, int32_t* idx, double* val)
+{
+  if (!an) return fail(-1, "pdlpdev_analysis_download: null");
+  const DevCsr& M    = which ? an->At : an->A;
+  const int32_t rows = which ? an->n : an->m;
+  HIP_TRY(hipSetDevice(an->device));
+  if (off) HIP_TRY(hipMemcpyAsync(off, M.off, ((size_t)rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream));
+  if (idx && an->nnz) HIP_TRY(hipMemcpyAsync(idx, M.idx, (size_t)an->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream));
+  if (val && an->nnz) HIP_TRY(hipMemcpyAsync(val, M.val, (size_t)an->nnz * sizeof(double), hipMemcpyDeviceToHost, an->stream));
+  HIP_TRY(hipStreamSynchronize(an->stream));
+  return 0;
+}
+
+// test hook: sorts n (key, value) pairs on the device (stable, by the low `bits` bits); vals null: iota
+int pdlpdev_debug_sort_pairs(int device, int64_t n, const uint32_t* keys, const uint32_t* vals, int bits, uint32_t* keys_out, uint32_t* vals_out)
+{
+  HIP_TRY(hipSetDevice(device));
+  DevArena ar;
+  ar.cap = (size_t)(6 * n + (n / kRsTile + 2) * 256 + 4096) * 4 + (1 << 16);
+  HIP_TRY(hipMalloc((void**)&ar.base, ar.cap));
+  uint32_t* dk = ar.take<uint32_t>((size_t)n);
+  uint32_t* dv = ar.take<uint32_t>((size_t)n);
+  SortBufs B;
+  int rc = sort_bufs_take(ar, &B, n);
+  int slot = 0;
+  if (rc == 0 && dk && dv) {
+    (void)hipMemcpy(dk, keys, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (vals) (void)hipMemcpy(dv, vals, (size_t)n * 4, hipMemcpyHostToDevice);
+    rc = radix_sort_pairs(nullptr, n, dk, vals ? dv : nullptr, B, bits, &slot);
+    if (rc == 0) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(keys_out, B.k[slot], (size_t)n * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(vals_out, B.v[slot], (size_t)n * 4, hipMemcpyDeviceToHost);
+    }
+  }
+  (void)hipFree(ar.base);
+  return rc;
+}
+
+// test hook: exclusive scan of n ints -> n + 1 outputs
+int pdlpdev_debug_scan(int device, int64_t n, const int32_t* in, int32_t* out)
+{
+  HIP_TRY(hipSetDevice(device));
+  int32_t *din = nullptr, *dout = nullptr, *bs = nullptr;
+  HIP_TRY(hipMalloc((void**)&din, (size_t)std::max<int64_t>(n, 1) * 4));
+  HIP_TRY(hipMalloc((void**)&dout, (size_t)(n + 1) * 4));
+  HIP_TRY(hipMalloc((void**)&bs, (size_t)(n / kScanTile + 2) * 4));
+  (void)hipMemcpy(din, in, (size_t)n * 4, hipMemcpyHostToDevice);
+  int rc = dev_exclusive_scan(nullptr, din, dout, n, bs);
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(out, dout, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(din), (void)hipFree(dout), (void)hipFree(bs);
+  return rc;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// up to four windows of a device-resident index array (gather_working_set of a matrix the host does not hold)
+// ================================================================================================
+int analysis_fetch_idx_windows(pdlpdev_analysis* an, int transposed, int64_t nnz, std::vector<int32_t>* sparse,
+                               std::vector<std::pair<int64_t, int64_t>>* windows)
+{
+  const int64_t window = 512 * 1024;
+  const int samples    = nnz <= window ? 1 : (int)std::min<int64_t>(4, (nnz + window - 1) / window);
+  windows->clear();
+  sparse->clear();
+  const int32_t* d_idx = transposed ? an->At.idx : an->A.idx;
+  for (int s = 0; s < samples; ++s) {
+    const int64_t first = samples == 1 ? 0 : (nnz - window) * s / (samples - 1);
+    const int64_t last  = std::min(nnz, first + window);
+    windows->emplace_back(first, last);
+  }
+  size_t total = 0;
+  for (auto& w : *windows) total += (size_t)(w.second - w.first);
+  sparse->resize(total);
+  size_t at = 0;
+  for (auto& w : *windows) {
+    HIP_TRY(hipMemcpyAsync(sparse->data() + at, d_idx + w.first, (size_t)(w.second - w.first) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream));
+    at += (size_t)(w.second - w.first);
+  }
+  HIP_TRY(hipStreamSynchronize(an->stream));
+  return 0;
+}
+
+// ================================================================================================
+// slab-major panels from a device-resident CSR (returns 1: not built here, use build_panels on the host)
+// ================================================================================================
+int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, int32_t cols, const int32_t* h_off,
+                        const int32_t* d_off, const int32_t* d_idx, const double* d_val, int64_t slab_bytes, bool force)
+{
+  PanelHost h;
+  std::vector<char> is_own;
+  int64_t own_nnz = 0, own_from = 0;
+  if (!panel_plan(&h, rows, cols, h_off, slab_bytes, force, nullptr, &is_own, &own_nnz, &own_from)) return 0;
+  const int W = h.W, S = h.S;
+  const int64_t nnz = h_off[rows];
+  h.nnz = (size_t)(nnz - own_nnz), h.rowptr_size = h.seg ? 0 : (size_t)S * ((size_t)rows + W);
+  int32_t *row0 = nullptr, *tile_ptr = nullptr, *col = nullptr, *count = nullptr;
+  uint16_t* rowptr = nullptr;
+  int64_t* rp_base = nullptr;
+  TRY(upload_i32(c, &row0, h.row0.data(), h.row0.size()));
+  TRY(dev_alloc(c, &count, (size_t)W * S + 1));
+  k_panel_count<<<W, kT, 0, c->stream>>>(row0, d_off, d_idx, S, h.slab_w, own_from, count);
+  std::vector<int32_t> hc((size_t)W * S);
+  HIP_TRY(hipMemcpyAsync(hc.data(), count, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  h.tile_ptr.resize((size_t)W * S + 1);
+  int64_t pos = 0;
+  for (size_t i = 0; i < (size_t)W * S; ++i) {
+    if (!h.seg && hc[i] >= 65536) return 0;  // 16-bit row pointers would overflow: keep the CSR stream layout
+    if (hc[i] >= 65536) return 1;            // (long-tail variant with a tile beyond the kernel's 16-bit cursors: the host constructs it)
+    h.tile_ptr[i] = (int32_t)pos;
+    pos += hc[i];
+  }
+  h.tile_ptr[(size_t)W * S] = (int32_t)pos;
+  h.rp_base.assign((size_t)W * S, 0);
+  if (!h.seg)
+    for (int w = 0; w < W; ++w) {
+      const int64_t a = h.row0[w], nr = h.row0[w + 1] - a, rp = (int64_t)S * (a + w);
+      for (int s2 = 0; s2 < S; ++s2) h.rp_base[(size_t)w * S + s2] = rp + (int64_t)s2 * (nr + 1);
+    }
+  TRY(upload_i32(c, &tile_ptr, h.tile_ptr.data(), h.tile_ptr.size()));
+  TRY(dev_alloc(c, &col, h.nnz));
+  TRY(dev_alloc(c, &dst->perm, h.nnz));
+  TRY(dev_alloc(c, &rowptr, h.rowptr_size));
+  TRY(dev_alloc(c, &rp_base, h.rp_base.size()));
+  HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  TRY(dev_alloc(c, &dst->val, h.nnz));
+  {
+    const size_t lds = (size_t)S * (kPanelMaxRows + 1) * sizeof(unsigned short);
+    static std::mutex mu;
+    static std::vector<int> done;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (std::find(done.begin(), done.end(), c->device) == done.end()) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_panel_place<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (kPanelMaxRows + 1) * 2));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_panel_place<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (kPanelMaxRows + 1) * 2));
+        done.push_back(c->device);
+      }
+    }
+    if (h.seg) k_panel_place<true><<<W, 512, lds, c->stream>>>(row0, d_off, d_idx, S, h.slab_w, own_from, tile_ptr, rp_base, rowptr, dst->perm, col);
+    else k_panel_place<false><<<W, 512, lds, c->stream>>>(row0, d_off, d_idx, S, h.slab_w, own_from, tile_ptr, rp_base, rowptr, dst->perm, col);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (the host vectors die here)
+  dst->v = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
+  dst->v.seg = h.seg ? 1 : 0, dst->v.slab_w = h.slab_w;
+  dst->nent  = (int64_t)h.nnz;
+  if (!h.own_row.empty()) {
+    int32_t *own_row = nullptr, *own_ptr = nullptr;
+    TRY(upload_i32(c, &own_row, h.own_row.data(), h.own_row.size()));
+    TRY(upload_i32(c, &own_ptr, h.own_ptr.data(), h.own_ptr.size()));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dst->v.NP = h.W, dst->v.W = h.W + (int)h.own_row.size();
+    dst->v.own_row = own_row, dst->v.own_ptr = own_ptr;
+    dst->v.csr_off = d_off, dst->v.csr_idx = d_idx, dst->v.csr_val = d_val;
+  }
+  dst->on = true;
+  return 0;
+}

@@ -1,5 +1,6 @@
 #include "pdlp_ctx.hpp"
 #include "pdlp_layouts.hpp"
+#include "pdlp_setup.hpp"
 
 
 // ================================================================================================
@@ -1229,6 +1230,12 @@ static int sync_panel_values(pdlpdev_ctx* c)
 
 static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
 
+static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
+                       const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
+                       const int32_t* at_indices, const double* at_values,
+                       void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
+                       const double* hi, const double* lb, const double* ub, pdlpdev_analysis* an);
+
 extern "C" {
 
 const char* pdlpdev_last_error(void) { return g_err.c_str(); }
@@ -1266,6 +1273,32 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
                               void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
                               const double* hi, const double* lb, const double* ub)
 {
+  if (!a_offsets || !at_offsets) return fail(-1, "pdlpdev_create: bad argument");
+  return create_impl(out, device, m, n, a_offsets, a_indices, a_values, at_offsets, at_indices, at_values, transpose_ready, user, c, lo,
+                     hi, lb, ub, nullptr);
+}
+
+// The context of an analysed matrix (pdlpdev_analyze): A and A^T are already on the device (the analysis' arrays are adopted, nothing
+// of the matrix crosses PCIe again), the layouts are built from them -- panels on the device, the others on the host from the
+// structure it holds or fetches.  c / lo / hi / lb / ub are in the order of the matrices the device holds (the caller applies
+// pdlpdev_analysis_maps when the analysis permuted them).  The analysis must be destroyed afterwards (pdlpdev_analysis_destroy).
+int pdlpdev_create_from_analysis(pdlpdev_ctx** out, pdlpdev_analysis* an, const double* c, const double* lo, const double* hi,
+                                 const double* lb, const double* ub)
+{
+  if (!an || an->adopted) return fail(-1, "pdlpdev_create_from_analysis: no (or an already consumed) analysis");
+  const int32_t* a_off = analysis_host_off(an);
+  const int32_t* a_idx = analysis_host_idx(an);
+  const int32_t* t_off = analysis_host_t_off(an);
+  return create_impl(out, an->device, an->m, an->n, a_off, a_idx, nullptr, t_off, nullptr, nullptr, nullptr, nullptr, c, lo, hi, lb, ub, an);
+}
+}  // extern "C"
+
+static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
+                       const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
+                       const int32_t* at_indices, const double* at_values,
+                       void (*transpose_ready)(void*), void* user, const double* c, const double* lo,
+                       const double* hi, const double* lb, const double* ub, pdlpdev_analysis* an)
+{
   roctx::Range range("pdlp: device set-up (upload, layouts)");
   if (!out || m < 0 || n < 0 || !a_offsets || !at_offsets) return fail(-1, "pdlpdev_create: bad argument");
   if (pdlpdev_device_count() <= device)
@@ -1290,7 +1323,11 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   *out = ctx;
   {
     Recycled r;
-    if (take_recycled(device, &r)) {
+    if (an && an->bundle_owned && an->stream && an->pinned && an->chunk) {  // the analysis' stream, pinned block and chunk move here
+      ctx->stream = an->stream, ctx->scal_h = an->pinned, ctx->arena = an->chunk, ctx->first_chunk = an->chunk;
+      an->bundle_owned = false;
+      HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
+    } else if (take_recycled(device, &r)) {
       ctx->stream = r.stream, ctx->scal_h = r.pinned, ctx->arena = r.chunk, ctx->first_chunk = r.chunk;
       HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
     } else {
@@ -1305,9 +1342,21 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   const size_t nnz = (size_t)ctx->nnz;
   // Everything that needs A only comes first; the caller may still be transposing on other threads (A^T is not
   // touched before transpose_ready returns).
-  TRY(upload_i32(ctx, &ctx->a_off, a_offsets, (size_t)m + 1));
-  TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz, 8));  // +8: the vector loads of the stream kernel may over-read
-  TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz, 8));
+  if (an) {
+    // adopted: both matrices are the analysis' device arrays (allocated with the 8 spare entries the stream kernel may over-read)
+    ctx->a_off = an->A.off, ctx->a_idx = an->A.idx, ctx->a_val = an->A.val;
+    ctx->at_off = an->At.off, ctx->at_idx = an->At.idx, ctx->at_val = an->At.val;
+    for (void* p : {(void*)an->A.off, (void*)an->A.idx, (void*)an->A.val, (void*)an->At.off, (void*)an->At.idx, (void*)an->At.val}) {
+      an->owned.erase(std::remove(an->owned.begin(), an->owned.end(), p), an->owned.end());
+      ctx->allocs.push_back(p);
+    }
+    an->adopted = true;
+    ctx->bytes += (int64_t)(2 * (nnz + 8) * 12 + ((size_t)m + n + 2) * 4);
+  } else {
+    TRY(upload_i32(ctx, &ctx->a_off, a_offsets, (size_t)m + 1));
+    TRY(upload_i32(ctx, &ctx->a_idx, a_indices, nnz, 8));  // +8: the vector loads of the stream kernel may over-read
+    TRY(upload_f64(ctx, &ctx->a_val, a_values, nnz, 8));
+  }
   lap("alloc + upload A");
   auto long_rows = [](int32_t rows, const int32_t* off) {
     std::vector<int32_t> v;
@@ -1407,7 +1456,15 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       if (force) return true;
       if (!timed && (mode != "auto" || (int64_t)cols * 8 <= ws_limit)) return false;
       if (timed && !getenv("CUOPT_AMD_TIMING")) return true;
-      const int64_t ws = gather_working_set(rows, cols, off, idx);
+      int64_t ws = 0;
+      if (idx) {
+        ws = gather_working_set(rows, cols, off, idx);
+      } else {  // (A^T of an analysed matrix: its indices live on the device; the same four windows are fetched)
+        std::vector<int32_t> sparse;
+        std::vector<std::pair<int64_t, int64_t>> windows;
+        if (analysis_fetch_idx_windows(an, 1, (int64_t)off[rows], &sparse, &windows) != 0) return false;
+        ws = gather_working_set_windows(cols, sparse.data(), windows);
+      }
       if (getenv("CUOPT_AMD_TIMING"))
         fprintf(stderr, "[cuopt_amd setup]   layout %-3s: live gather set of the stream kernel %.2f MiB (limit %.2f) -> %s\n", name,
                 ws / 1048576.0, ws_limit / 1048576.0, ws > ws_limit ? "panels" : "stream");
@@ -1422,31 +1479,46 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       JagHost jat;
       PbHost hbt;
       PanelHost hat;
-      bool want_pb_layout = false;
+      bool want_pb_layout = false, want_dev_panels = false;
       ~TSide() { if (worker.joinable()) worker.join(); }
     } ts;
     const int32_t* T_off = at_offsets;
     const int32_t* T_idx = at_indices;
+    // An analysed matrix's A^T lives on the device: its index array comes to the host only for the constructions that still run there
+    // (jagged, gather-free, dense segments); the analysis' sampled estimate already says whether the jagged layout is worth a look.
+    auto t_idx_host = [&]() -> const int32_t* { return an ? analysis_host_t_idx(an) : at_indices; };
+    const bool skip_jag_a  = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[0] < 0.35;
+    const bool skip_jag_at = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[1] < 0.35;
     ts.worker = std::thread([&] {
       if (transpose_ready) transpose_ready(user);
       if ((int64_t)at_offsets[n] != ctx->nnz) return;  // (reported below)
       lat = long_rows(n, at_offsets);
       if (DH.on) {
-        strip_transpose(DH, &DH, n, at_offsets, at_indices);
+        strip_transpose(DH, &DH, n, at_offsets, t_idx_host());
         hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
       }
       if (!hT_off.empty()) T_off = hT_off.data(), T_idx = hT_idx.data();
       ts.rbt = build_row_blocks(n, T_off);
-      if (try_jag) ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
+      if (try_jag && !skip_jag_at) {
+        if (!T_idx) T_idx = t_idx_host();
+        ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
+      } else if (an) {
+        ts.jat.saving = an->saving_natural[1];
+      }
       if (!ts.jat.ok && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
         ts.want_pb_layout = true;
+        if (!T_idx) T_idx = t_idx_host();
         ts.hbt            = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
       }
-      if (mode != "stream" && mode != "jag" && mode != "pb" && !ts.jat.ok && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T"))
-        ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
+      if (mode != "stream" && mode != "jag" && mode != "pb" && !ts.jat.ok && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T")) {
+        if (an && !DH.on) ts.want_dev_panels = true;  // (built on the device by the main thread, below)
+        else ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
+      }
     });
     if (try_jag) {
-      JagHost ja = build_jag(m, n, A_off, A_idx, mode == "jag" ? 1 : 0, ctx->cus);
+      JagHost ja;
+      if (skip_jag_a) ja.saving = an->saving_natural[0];
+      else ja = build_jag(m, n, A_off, A_idx, mode == "jag" ? 1 : 0, ctx->cus);
       lap("build_jag A");
       TRY(upload_jag(ctx, &ctx->ja, ja, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
       lap("upload jag A");
@@ -1459,9 +1531,14 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       lap("upload pb A");
     }
     if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, A_off, A_idx, "A")) {
-      PanelHost ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed, DH.on ? &DH.first_seg : nullptr);
-      lap("build_panels A");
-      TRY(upload_panels(ctx, &ctx->pa, ha, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
+      PanelHost ha;
+      int on_device = an && !DH.on ? build_panels_device(ctx, &ctx->pa, m, n, A_off, ctx->ha_off, ctx->ha_idx, ctx->ha_val, slab_bytes, force || !timed) : 1;
+      if (on_device < 0) return on_device;
+      if (on_device == 1) {
+        ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed, DH.on ? &DH.first_seg : nullptr);
+        lap("build_panels A");
+        TRY(upload_panels(ctx, &ctx->pa, ha, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
+      }
       if (ctx->pa.on && DH.on) {
         // segments of the own rows, in own-row order (the rows that own segments are a subset of the own rows and both lists ascend)
         std::vector<int32_t> own_seg(ha.own_row.size() + 1, 0);
@@ -1484,9 +1561,11 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
     ts.worker.join();
     lap("wait for the A^T side");
     if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
-    TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
-    TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
-    TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
+    if (!an) {
+      TRY(upload_i32(ctx, &ctx->at_off, at_offsets, (size_t)n + 1));
+      TRY(upload_i32(ctx, &ctx->at_idx, at_indices, nnz, 8));
+      TRY(upload_f64(ctx, &ctx->at_val, at_values, nnz, 8));
+    }
     ctx->at_nlong = (int)lat.size();
     if (ctx->at_nlong) TRY(upload_i32(ctx, &ctx->at_long, lat.data(), lat.size()));
     const bool hot_t = !hT_off.empty();
@@ -1510,6 +1589,12 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
       if (!ts.hbt.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", ts.hbt.why.c_str());
       TRY(upload_pb(ctx, &ctx->pbat, ts.hbt));
       lap("upload pb At");
+    }
+    if (ts.want_dev_panels) {
+      const int on_device = build_panels_device(ctx, &ctx->pat, n, m, T_off, ctx->hat_off, ctx->hat_idx, ctx->hat_val, slab_bytes, force || !timed);
+      if (on_device < 0) return on_device;
+      if (on_device == 1) ts.hat = build_panels(n, m, T_off, t_idx_host(), slab_bytes, force || !timed);
+      lap("panels At on the device");
     }
     if (ts.hat.ok) {
       TRY(upload_panels(ctx, &ctx->pat, ts.hat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
@@ -1578,6 +1663,8 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+
+extern "C" {
 
 void pdlpdev_destroy(pdlpdev_ctx* ctx)
 {
@@ -3011,6 +3098,49 @@ int pdlpdev_layout_info(pdlpdev_ctx* ctx, int32_t out[8])
   out[5] = ctx->pbat.on ? (int)(100.0 * (ctx->pbat.pad - 1.0) + 0.5) : ctx->jat.on ? (int)(100.0 * ctx->jat.saving + 0.5) : ctx->pat.on ? ctx->pat.v.S : 1;
   out[6] = ctx->pa.on && ctx->pa.v.seg, out[7] = ctx->pat.on && ctx->pat.v.seg;  // panels: the long-tail variant (row sums by nonzero)
   if (ctx->small_resident) out[0] = out[3] = 2;
+  return 0;
+}
+
+// FNV-1a of a device array (parity tests: the device-side set-up must produce the host constructions' arrays bit for bit)
+static uint64_t checksum_device(pdlpdev_ctx* ctx, const void* dev, size_t bytes)
+{
+  if (!dev || bytes == 0) return 0;
+  std::vector<unsigned char> h(bytes);
+  if (hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+  uint64_t f = 1469598103934665603ull;
+  for (unsigned char b : h) f = (f ^ b) * 1099511628211ull;
+  (void)ctx;
+  return f;
+}
+int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16])
+{
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  const size_t nnz = (size_t)ctx->nnz;
+  out[0] = checksum_device(ctx, ctx->at_off, ((size_t)ctx->n + 1) * 4);
+  out[1] = checksum_device(ctx, ctx->at_idx, nnz * 4);
+  out[2] = checksum_device(ctx, ctx->at_val, nnz * 8);
+  auto panels = [&](const pdlpdev_ctx::Panels& P, int32_t rows, uint64_t* o) {
+    if (!P.on) return;
+    const int NP = P.v.NP ? P.v.NP : P.v.W;
+    o[0] = checksum_device(ctx, P.v.row0, ((size_t)NP + 1) * 4);
+    o[1] = checksum_device(ctx, P.v.tile_ptr, ((size_t)NP * P.v.S + 1) * 4);
+    o[2] = P.v.seg ? 0 : checksum_device(ctx, P.v.rowptr, (size_t)P.v.S * ((size_t)rows + NP) * 2);
+    o[3] = checksum_device(ctx, P.v.col, (size_t)P.nent * 4);
+    o[4] = checksum_device(ctx, P.perm, (size_t)P.nent * 4);
+  };
+  panels(ctx->pa, ctx->m, out + 3);
+  panels(ctx->pat, ctx->n, out + 8);
+  auto jag = [&](const pdlpdev_ctx::Jag& J) -> uint64_t {
+    if (!J.on) return 0;
+    return checksum_device(ctx, J.v.slot, (size_t)J.nent * 2) ^ (checksum_device(ctx, J.perm, (size_t)J.nent * 4) * 3) ^
+           (checksum_device(ctx, J.v.row0, ((size_t)J.v.nblk + 1) * 4) * 5);
+  };
+  out[13] = jag(ctx->ja), out[14] = jag(ctx->jat);
+  out[15] = (uint64_t)ctx->pa.on | (uint64_t)ctx->pat.on << 1 | (uint64_t)ctx->ja.on << 2 | (uint64_t)ctx->jat.on << 3 |
+            (uint64_t)(ctx->pa.on && ctx->pa.v.seg) << 4 | (uint64_t)(ctx->pat.on && ctx->pat.v.seg) << 5 | (uint64_t)ctx->pba.on << 6 |
+            (uint64_t)ctx->pbat.on << 7;
   return 0;
 }
 

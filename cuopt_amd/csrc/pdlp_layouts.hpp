@@ -84,6 +84,7 @@ inline int upload_f64(pdlpdev_ctx* c, double** dst, const double* src, size_t co
 // ---- defined in kernels_<layout>.hip -----------------------------------------------------------------------------------------
 std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off);
 int64_t gather_working_set(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx);
+int64_t gather_working_set_windows(int32_t cols, const int32_t* sparse, const std::vector<std::pair<int64_t, int64_t>>& windows);
 PanelHost build_panels(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx,
                               int64_t slab_bytes, bool force, const std::vector<int32_t>* dense_first_seg = nullptr);
 int upload_panels(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, const PanelHost& h, const int32_t* d_off, const int32_t* d_idx,

@@ -116,6 +116,27 @@ struct cuoptamd_solver {
   cuoptamd_result result{};
   clock_type::time_point solve_start;
   bool started = false;
+  // Set-up reordering (pdlpdev_analyze): the device works on P A Q -- row i of its matrix is row row_new2old[i] of the caller's,
+  // column j is column col_new2old[j].  Everything that crosses this interface (bounds, initial iterates, solutions, warm-start
+  // snapshots) is in the CALLER's order; empty maps = the matrix as given.
+  std::vector<int32_t> row_new2old, col_new2old;
+  int reorder_method = 0;
+  int32_t analysis_info[10] = {0};
+  // caller's order -> device order (nullptr stays nullptr; the identity passes the caller's pointer through)
+  const double* cols_in(const double* v, std::vector<double>& tmp) const { return to_device_order(col_new2old, v, tmp); }
+  const double* rows_in(const double* v, std::vector<double>& tmp) const { return to_device_order(row_new2old, v, tmp); }
+  static const double* to_device_order(const std::vector<int32_t>& new2old, const double* v, std::vector<double>& tmp)
+  {
+    if (!v || new2old.empty()) return v;
+    tmp.resize(new2old.size());
+    for (size_t i = 0; i < new2old.size(); ++i) tmp[i] = v[new2old[i]];
+    return tmp.data();
+  }
+  // device order -> caller's order for entries [first, last) of the device order (the rows a sharded rank owns; everything for columns)
+  static void to_caller_order(const std::vector<int32_t>& new2old, const double* dev, double* user, size_t first, size_t last)
+  {
+    for (size_t i = first; i < last; ++i) user[new2old[i]] = dev[i];
+  }
 };
 
 namespace {
@@ -778,6 +799,8 @@ static int start_run(cuoptamd_solver* s, const double* init_x, const double* ini
   s->result.initial_primal_weight = weight;
   DEV(pdlpdev_set_step(s->dev, step, weight));
   if (settings->initial_k >= 0) DEV(pdlpdev_set_k(s->dev, settings->initial_k));
+  std::vector<double> init_x_tmp, init_y_tmp;
+  init_x = s->cols_in(init_x, init_x_tmp), init_y = s->rows_in(init_y, init_y_tmp);
   if (init_x || init_y) {
     DEV(pdlpdev_set_initial(s->dev, init_x, init_y ? init_y + s->row_begin : nullptr));
     // update_{step_size,primal_weight}_on_initial_solution (pdlp.cu:878-979; off in every preset, toggled by the
@@ -879,17 +902,77 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   }
   s->maximize               = lp->maximize != 0;
   s->best_quality.objective = s->maximize ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();  // pdlp.cu:183-185
+  // ---- device-side set-up (round 5): ONE upload of A; A^T, the analysis pass that looks for structure the matrix arrives without
+  // and the panels are built on the GPU (pdlp_device.h "device-side set-up").  CUOPT_AMD_TUNE: device_setup=0 keeps the host
+  // transposition + four uploads (the tests' reference construction), reorder=0 skips the ordering search,
+  // device_setup_min_nnz=... moves the size from which it is used (small LPs: the resident path, nothing to gain).
+  const int64_t nnz_g  = lp->offsets[m];
+  const bool sharded   = world > 1 || comm_id != nullptr;
+  const bool dev_setup = nnz_g >= cuopt_amd::tune_int("device_setup_min_nnz", 200000) && cuopt_amd::tune_int("device_setup", 1) != 0;
+  const bool reorder   = dev_setup && cuopt_amd::tune_int("reorder", 1) != 0;
+  struct AnalysisGuard {
+    pdlpdev_analysis* an = nullptr;
+    void drop() { if (an) pdlpdev_analysis_destroy(an); an = nullptr; }
+    ~AnalysisGuard() { drop(); }
+  } ag;
+  cuoptamd_lp plp = *lp;  // the LP in the order the device works in (the caller's, or P A Q with permuted vectors)
+  plp.c           = c.data();
+  std::vector<double> pc, plo, phi, plb, pub;
+  cuopt_amd::PoolArray<int32_t> poff, pidx;
+  cuopt_amd::PoolArray<double> pval;
+  int setup_rc = 0;
+  if (dev_setup && (!sharded || reorder)) {
+    setup_rc = pdlpdev_analyze(&ag.an, device, m, n, lp->offsets, lp->indices, lp->values, reorder ? 1 : 0);
+    if (setup_rc != 0) fail(setup_rc, "pdlpdev_analyze: %s", pdlpdev_last_error());
+    if (setup_rc == 0) {
+      s->row_new2old.resize((size_t)m), s->col_new2old.resize((size_t)n);
+      const int permuted = pdlpdev_analysis_maps(ag.an, s->row_new2old.data(), s->col_new2old.data());
+      (void)pdlpdev_analysis_info(ag.an, s->analysis_info);
+      s->reorder_method = permuted == 1 ? s->analysis_info[1] : 0;
+      if (permuted != 1) {
+        s->row_new2old.clear(), s->col_new2old.clear();
+      } else {
+        auto gather = [](const std::vector<int32_t>& new2old, const double* src, std::vector<double>& dst) {
+          dst.resize(new2old.size());
+          for (size_t i = 0; i < new2old.size(); ++i) dst[i] = src[new2old[i]];
+          return dst.data();
+        };
+        plp.c = gather(s->col_new2old, c.data(), pc), plp.lb = gather(s->col_new2old, lp->lb, plb), plp.ub = gather(s->col_new2old, lp->ub, pub);
+        plp.lo = gather(s->row_new2old, lp->lo, plo), plp.hi = gather(s->row_new2old, lp->hi, phi);
+        if (sharded) {  // the ranks slice the permuted matrix on the host (every rank found the same order: the search is deterministic)
+          poff.reset((size_t)m + 1), pidx.reset((size_t)std::max<int64_t>(nnz_g, 1)), pval.reset((size_t)std::max<int64_t>(nnz_g, 1));
+          setup_rc = pdlpdev_analysis_download(ag.an, 0, poff.get(), pidx.get(), pval.get());
+          if (setup_rc != 0) fail(setup_rc, "pdlpdev_analysis_download: %s", pdlpdev_last_error());
+          plp.offsets = poff.get(), plp.indices = pidx.get(), plp.values = pval.get();
+        }
+      }
+      if (timing)
+        std::fprintf(stderr, "[cuopt_amd setup] ordering: method %d (estimates x1e4: natural %d/%d, levels %d/%d over %d levels, cells %d/%d in %d rounds)\n",
+                     s->reorder_method, s->analysis_info[2], s->analysis_info[3], s->analysis_info[4], s->analysis_info[5], s->analysis_info[8],
+                     s->analysis_info[6], s->analysis_info[7], s->analysis_info[9]);
+    }
+    if (sharded) ag.drop();  // (a sharded rank uploads its slice below; the full matrix leaves the device first)
+    lap("device analysis");
+  }
+  const cuoptamd_lp* L = &plp;
   // this rank's row block
   std::vector<int32_t> bounds(world + 1);
-  cuoptamd_partition_rows(m, lp->offsets, world, bounds.data());
+  cuoptamd_partition_rows(m, L->offsets, world, bounds.data());
   s->row_begin = bounds[rank], s->row_end = bounds[rank + 1];
   const int32_t ml = s->row_end - s->row_begin;
-  const int32_t k0 = lp->offsets[s->row_begin];
+  if (ag.an && setup_rc == 0) {
+    // single GPU: the analysis' device arrays become the context's
+    pdlpdev_create_hint(0);
+    int rc = pdlpdev_create_from_analysis(&s->dev, ag.an, L->c, L->lo, L->hi, L->lb, L->ub);
+    ag.drop();
+    if (rc != 0) return fail(rc, "pdlpdev_create_from_analysis: %s", pdlpdev_last_error());
+  } else {
+  const int32_t k0 = L->offsets[s->row_begin];
   std::vector<int32_t> off(ml + 1);
-  for (int32_t i = 0; i <= ml; ++i) off[i] = lp->offsets[s->row_begin + i] - k0;
+  for (int32_t i = 0; i <= ml; ++i) off[i] = L->offsets[s->row_begin + i] - k0;
   const int64_t nnz_l = off[ml];
-  const int32_t* idx  = lp->indices + k0;
-  const double* val   = lp->values + k0;
+  const int32_t* idx  = L->indices + k0;
+  const double* val   = L->values + k0;
   std::vector<int32_t> t_off(n + 1);
   cuopt_amd::PoolArray<int32_t> t_idx((size_t)std::max<int64_t>(nnz_l, 1));  // no zero fill of 120 MB, pooled
   cuopt_amd::PoolArray<double> t_val((size_t)std::max<int64_t>(nnz_l, 1));
@@ -902,7 +985,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     void join() { if (worker.joinable()) worker.join(); }
     ~TransposeJob() { join(); }
   } job;
-  {
+  if (setup_rc == 0) {
     const int32_t* off_p = off.data();
     int32_t* t_off_p     = t_off.data();
     int32_t* t_idx_p     = t_idx.get();
@@ -911,17 +994,19 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   }
   {
     pdlpdev_create_hint(world > 1 || comm_id != nullptr);
-    int rc = pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
-                                       &TransposeJob::wait, &job, c.data(), lp->lo + s->row_begin, lp->hi + s->row_begin,
-                                       lp->lb, lp->ub);
+    int rc = setup_rc;
+    if (rc == 0)
+      rc = pdlpdev_create_overlapped(&s->dev, device, ml, n, off.data(), idx, val, t_off.data(), t_idx.get(), t_val.get(),
+                                     &TransposeJob::wait, &job, L->c, L->lo + s->row_begin, L->hi + s->row_begin, L->lb, L->ub);
     if (rc == 0 && fault_injected(rank, world, "create")) rc = -6;
     job.join();
-    if (rc != 0) fail(rc, "pdlpdev_create: %s", rc == -6 ? "injected fault (CUOPT_AMD_FAULT_INJECT)" : pdlpdev_last_error());
+    if (rc != 0 && rc != setup_rc) fail(rc, "pdlpdev_create: %s", rc == -6 ? "injected fault (CUOPT_AMD_FAULT_INJECT)" : pdlpdev_last_error());
     if (t_agree_before_comm) {
       const int all = t_agree_before_comm(rc);
       if (rc == 0 && all != 0) return fail(all, "another rank of the sharded solve failed during set-up");
     }
     if (rc != 0) return rc;
+  }
   }
   lap("pdlpdev_create (upload+panels)");
   if (comm_id) DEV(pdlpdev_comm_init(s->dev, rank, world, comm_id));
@@ -960,20 +1045,20 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     int32_t cb = 0, nc = 0;
     DEV(pdlpdev_owner_slice(s->dev, &cb, &nc));
     std::vector<int32_t> coff((size_t)nc + 1, 0);
-    const int64_t nnz_g = lp->offsets[m];
+    const int64_t nnz_g = L->offsets[m];
     for (int64_t k = 0; k < nnz_g; ++k) {
-      const int32_t j = lp->indices[k] - cb;
+      const int32_t j = L->indices[k] - cb;
       if (j >= 0 && j < nc) ++coff[j + 1];
     }
     for (int32_t j = 0; j < nc; ++j) coff[j + 1] += coff[j];
     std::vector<int32_t> cidx((size_t)std::max<int32_t>(coff[nc], 1)), cur(coff.begin(), coff.end() - 1);
     std::vector<double> cval((size_t)std::max<int32_t>(coff[nc], 1));
     for (int32_t i = 0; i < m; ++i)  // rows ascending: every column lists its rows in the order an unsharded solve sums them
-      for (int32_t k = lp->offsets[i]; k < lp->offsets[i + 1]; ++k) {
-        const int32_t j = lp->indices[k] - cb;
+      for (int32_t k = L->offsets[i]; k < L->offsets[i + 1]; ++k) {
+        const int32_t j = L->indices[k] - cb;
         if (j >= 0 && j < nc) {
           const int32_t p = cur[j]++;
-          cidx[p] = i, cval[p] = lp->values[k];
+          cidx[p] = i, cval[p] = L->values[k];
         }
       }
     DEV(pdlpdev_owner_setup(s->dev, coff.data(), cidx.data(), cval.data(), bounds.data()));
@@ -1018,7 +1103,11 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
   s->returned_which = PDLPDEV_CURRENT, s->finished = false, s->warm_started = false, s->started = false;
   s->result = blank;
   if (s->empty_problem) return 0;
-  DEV(pdlpdev_reset(s->dev, lb, ub, lo ? lo + s->row_begin : nullptr, hi ? hi + s->row_begin : nullptr));
+  {
+    std::vector<double> tlb, tub, tlo, thi;  // the new bounds in the device's order
+    lb = s->cols_in(lb, tlb), ub = s->cols_in(ub, tub), lo = s->rows_in(lo, tlo), hi = s->rows_in(hi, thi);
+    DEV(pdlpdev_reset(s->dev, lb, ub, lo ? lo + s->row_begin : nullptr, hi ? hi + s->row_begin : nullptr));
+  }
   // ||b||, ||c|| of the termination rule: from the problem again (the previous settings may have overridden them)
   DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
   if (lo || hi) {
@@ -1124,7 +1213,16 @@ int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, doubl
     return 0;
   }
   if (y && s->world > 1) std::fill(y, y + s->m_global, 0.0);  // other ranks' rows stay 0
-  DEV(pdlpdev_get_solution(s->dev, s->returned_which, x, y ? y + s->row_begin : nullptr, rc));
+  if (s->row_new2old.empty()) {
+    DEV(pdlpdev_get_solution(s->dev, s->returned_which, x, y ? y + s->row_begin : nullptr, rc));
+    return 0;
+  }
+  // the device's order -> the caller's
+  std::vector<double> tx(x ? (size_t)s->n : 0), ty(y ? (size_t)s->m_global : 0), trc(rc ? (size_t)s->n : 0);
+  DEV(pdlpdev_get_solution(s->dev, s->returned_which, x ? tx.data() : nullptr, y ? ty.data() + s->row_begin : nullptr, rc ? trc.data() : nullptr));
+  if (x) cuoptamd_solver::to_caller_order(s->col_new2old, tx.data(), x, 0, (size_t)s->n);
+  if (rc) cuoptamd_solver::to_caller_order(s->col_new2old, trc.data(), rc, 0, (size_t)s->n);
+  if (y) cuoptamd_solver::to_caller_order(s->row_new2old, ty.data(), y, (size_t)s->row_begin, (size_t)s->row_end);
   return 0;
 }
 
@@ -1182,9 +1280,12 @@ int cuoptamd_solve_sharded(const cuoptamd_lp* lp, const cuoptamd_hyper* hyper, c
         std::vector<double> yl(y ? (size_t)lp->m : 0);
         me.rc = cuoptamd_solver_get_solution(solver, g == 0 ? x : nullptr, y ? yl.data() : nullptr, g == 0 ? rc : nullptr);
         if (me.rc == 0 && y) {
-          int32_t r0 = 0, r1 = 0;
-          cuoptamd_solver_row_range(solver, &r0, &r1);
-          std::copy(yl.begin() + r0, yl.begin() + r1, y + r0);
+          // a rank's rows are a contiguous block of the DEVICE's order -- scattered in the caller's when the set-up reordered the
+          // LP; what the rank does not own is exactly zero, and no two ranks own the same row
+          static std::mutex y_mutex;
+          std::lock_guard<std::mutex> lock(y_mutex);
+          for (int32_t i = 0; i < lp->m; ++i)
+            if (yl[i] != 0.0) y[i] = yl[i];
         }
       }
       if (me.rc != 0 && me.error.empty()) me.error = cuoptamd_last_error();
@@ -1214,6 +1315,43 @@ int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
     if (s->world > 1) std::fill(v, v + s->m_global, 0.0);
     return v + s->row_begin;
   };
+  if (!s->row_new2old.empty()) {
+    // A reordered LP: every vector leaves in the CALLER's order (a snapshot can be restored into any solver of the same LP, whatever
+    // order its own set-up found).  Device order -> temporaries -> scatter.
+    std::vector<double> tn((size_t)n), tm((size_t)s->m_global);
+    auto cols = [&](double* user) { if (user) cuoptamd_solver::to_caller_order(s->col_new2old, tn.data(), user, 0, (size_t)n); };
+    auto rows = [&](double* user) {
+      if (!user) return;
+      if (s->world > 1) std::fill(user, user + s->m_global, 0.0);
+      cuoptamd_solver::to_caller_order(s->row_new2old, tm.data(), user, (size_t)s->row_begin, (size_t)s->row_end);
+    };
+    for (int which : {PDLPDEV_CURRENT, PDLPDEV_AVERAGE}) {
+      double* ux = which == PDLPDEV_CURRENT ? ws->current_primal_solution : ws->initial_primal_average;
+      double* uy = which == PDLPDEV_CURRENT ? ws->current_dual_solution : ws->initial_dual_average;
+      DEV(pdlpdev_get_solution(s->dev, which, ux ? tn.data() : nullptr, uy ? tm.data() + s->row_begin : nullptr, nullptr));
+      cols(ux), rows(uy);
+    }
+    auto get_n = [&](int id, double* user) -> int {
+      if (!user) return 0;
+      if (pdlpdev_download(s->dev, id, tn.data(), n) != n) return fail(-2, "download failed: %s", pdlpdev_last_error());
+      cols(user);
+      return 0;
+    };
+    auto get_m = [&](int id, double* user) -> int {
+      if (!user) return 0;
+      if (pdlpdev_download(s->dev, id, tm.data() + s->row_begin, ml) != ml) return fail(-2, "download failed: %s", pdlpdev_last_error());
+      rows(user);
+      return 0;
+    };
+    int rc;
+    if ((rc = get_n(PDLPDEV_BUF_X, ws->current_primal_solution_scaled))) return rc;
+    if ((rc = get_m(PDLPDEV_BUF_Y, ws->current_dual_solution_scaled))) return rc;
+    if ((rc = get_n(PDLPDEV_BUF_ATY, ws->current_ATY))) return rc;
+    if ((rc = get_n(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions))) return rc;
+    if ((rc = get_m(PDLPDEV_BUF_SUM_Y, ws->sum_dual_solutions))) return rc;
+    if ((rc = get_n(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution))) return rc;
+    if ((rc = get_m(PDLPDEV_BUF_LAST_RESTART_Y, ws->last_restart_duality_gap_dual_solution))) return rc;
+  } else {
   DEV(pdlpdev_get_solution(s->dev, PDLPDEV_CURRENT, ws->current_primal_solution, own_rows(ws->current_dual_solution), nullptr));
   DEV(pdlpdev_get_solution(s->dev, PDLPDEV_AVERAGE, ws->initial_primal_average, own_rows(ws->initial_dual_average), nullptr));
   auto get = [&](int id, double* dst, int64_t count) -> int {
@@ -1229,6 +1367,7 @@ int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws)
   if ((rc = get(PDLPDEV_BUF_SUM_Y, own_rows(ws->sum_dual_solutions), ml))) return rc;
   if ((rc = get(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
   if ((rc = get(PDLPDEV_BUF_LAST_RESTART_Y, own_rows(ws->last_restart_duality_gap_dual_solution), ml))) return rc;
+  }
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
   ws->initial_primal_weight         = s->ctl.primal_weight;
   ws->initial_step_size             = s->ctl.step_size;
@@ -1251,22 +1390,24 @@ int cuoptamd_solver_set_warm_start(cuoptamd_solver* s, const cuoptamd_warm_start
   // iterate: unscaled in the snapshot -> scale_solutions (initial_scaling.cu:410-427), then the usual projection
   // (a sharded solver takes the FULL snapshot and keeps its own rows of the m-sized vectors)
   auto own_rows = [&](const double* v) -> const double* { return v ? v + s->row_begin : nullptr; };
-  DEV(pdlpdev_set_initial(s->dev, ws->current_primal_solution, own_rows(ws->current_dual_solution)));
-  if (s->H.project_initial_primal) DEV(pdlpdev_project_primal(s->dev));
   auto put = [&](int id, const double* src, int64_t count) -> int {
     if (!src) return 0;
     if (pdlpdev_upload(s->dev, id, src, count) != count) return fail(-2, "upload failed: %s", pdlpdev_last_error());
     return 0;
   };
   const int64_t n = s->n, ml = s->row_end - s->row_begin;
+  // (a reordered LP: the snapshot is in the caller's order; every vector goes through the maps on its way in)
+  std::vector<double> t[9];
+  DEV(pdlpdev_set_initial(s->dev, s->cols_in(ws->current_primal_solution, t[0]), own_rows(s->rows_in(ws->current_dual_solution, t[1]))));
+  if (s->H.project_initial_primal) DEV(pdlpdev_project_primal(s->dev));
   int rc;
-  if ((rc = put(PDLPDEV_BUF_X, ws->current_primal_solution_scaled, n))) return rc;  // bit-exact iterate if given
-  if ((rc = put(PDLPDEV_BUF_Y, own_rows(ws->current_dual_solution_scaled), ml))) return rc;
-  if ((rc = put(PDLPDEV_BUF_ATY, ws->current_ATY, n))) return rc;
-  if ((rc = put(PDLPDEV_BUF_SUM_X, ws->sum_primal_solutions, n))) return rc;
-  if ((rc = put(PDLPDEV_BUF_SUM_Y, own_rows(ws->sum_dual_solutions), ml))) return rc;
-  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_X, ws->last_restart_duality_gap_primal_solution, n))) return rc;
-  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_Y, own_rows(ws->last_restart_duality_gap_dual_solution), ml))) return rc;
+  if ((rc = put(PDLPDEV_BUF_X, s->cols_in(ws->current_primal_solution_scaled, t[2]), n))) return rc;  // bit-exact iterate if given
+  if ((rc = put(PDLPDEV_BUF_Y, own_rows(s->rows_in(ws->current_dual_solution_scaled, t[3])), ml))) return rc;
+  if ((rc = put(PDLPDEV_BUF_ATY, s->cols_in(ws->current_ATY, t[4]), n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_SUM_X, s->cols_in(ws->sum_primal_solutions, t[5]), n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_SUM_Y, own_rows(s->rows_in(ws->sum_dual_solutions, t[6])), ml))) return rc;
+  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_X, s->cols_in(ws->last_restart_duality_gap_primal_solution, t[7]), n))) return rc;
+  if ((rc = put(PDLPDEV_BUF_LAST_RESTART_Y, own_rows(s->rows_in(ws->last_restart_duality_gap_dual_solution, t[8])), ml))) return rc;
   DEV(pdlpdev_set_step(s->dev, ws->initial_step_size, ws->initial_primal_weight));
   DEV(pdlpdev_set_loop_state(s->dev, ws->sum_solution_weight, ws->iterations_since_last_restart, ws->total_pdhg_iterations));
   DEV(pdlpdev_get_ctl(s->dev, &s->ctl));
@@ -1390,6 +1531,16 @@ int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_h
 }
 
 pdlpdev_ctx* cuoptamd_solver_device(cuoptamd_solver* s) { return s ? s->dev : nullptr; }
+
+int cuoptamd_solver_reorder_info(cuoptamd_solver* s, int32_t info[10], int32_t* row_new2old, int32_t* col_new2old)
+{
+  if (!s) return fail(-1, "cuoptamd_solver_reorder_info: null solver");
+  if (info) std::copy(s->analysis_info, s->analysis_info + 10, info);
+  if (s->row_new2old.empty()) return 0;
+  if (row_new2old) std::copy(s->row_new2old.begin(), s->row_new2old.end(), row_new2old);
+  if (col_new2old) std::copy(s->col_new2old.begin(), s->col_new2old.end(), col_new2old);
+  return 1;
+}
 
 int cuoptamd_solver_row_range(cuoptamd_solver* s, int32_t* row_begin, int32_t* row_end)
 {

@@ -179,3 +179,22 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
     cols = np.concatenate([cols, c_forced])
     vals = rng.standard_normal(len(rows))
     return _finish(m, n, rows, cols, vals, rng, dict(seed=seed, k=k, kind=kind, hard=False, band=0))
+
+
+def shuffled(p, seed=5):
+    """The same LP under a seeded random row AND column permutation -- how a structured model arrives when its MPS file lists rows
+    and columns in modelling order rather than in the order of its structure.  Row i of the result is row rp[i] of p, column j is
+    column cp[j]; indices ascend inside every row; the known optimal pair moves along.  `shuffle` = (rp, cp) is kept for tests."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    m, n = p["m"], p["n"]
+    rp, cp = rng.permutation(m), rng.permutation(n)
+    a = sp.csr_matrix((p["values"], p["indices"], p["offsets"]), shape=(m, n))[rp][:, cp].tocsr()
+    a.sort_indices()
+    out = dict(p)
+    out.update(offsets=a.indptr.astype(np.int32), indices=a.indices.astype(np.int32), values=np.ascontiguousarray(a.data, dtype=np.float64),
+               c=np.ascontiguousarray(p["c"][cp]), lb=np.ascontiguousarray(p["lb"][cp]), ub=np.ascontiguousarray(p["ub"][cp]),
+               lo=np.ascontiguousarray(p["lo"][rp]), hi=np.ascontiguousarray(p["hi"][rp]), shuffle=(rp, cp))
+    if "x_star" in p:
+        out["x_star"], out["y_star"] = p["x_star"][cp], p["y_star"][rp]
+    return out

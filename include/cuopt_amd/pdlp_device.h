@@ -154,6 +154,45 @@ int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t 
                               const double* hi, const double* lb, const double* ub);
 void pdlpdev_destroy(pdlpdev_ctx* ctx);
 
+/* ---- device-side set-up (round 5): ONE upload of A, everything O(nnz) in front of the first step on the GPU ---------------------
+ * Replaces, for a matrix of >= ~2e5 nonzeros, the host transposition + four uploads of pdlpdev_create:
+ *   - A^T is built on the device from the resident A (the reference: raft::sparse::linalg::csr_transpose,
+ *     cpp/src/mip/problem/problem.cu:277-309) -- a stable radix sort by column, rows ascending inside a column;
+ *   - flags bit 0: an ANALYSIS PASS looks for structure the matrix arrives without (the reference hands its analysis to the closed
+ *     cusparseSpMV_preprocess, cpp/src/linear_programming/cusparse_view.cu:92-115,254-265): when the jagged layout does not apply to
+ *     the matrix as given, two candidate orders are formed on the bipartite row-column graph (rows / columns of more than 128 entries
+ *     left out) -- breadth-first levels from a pseudo-peripheral row refined by barycentre sweeps (band / staircase structure), and
+ *     cells grown from seeds spaced one row block apart (block structure behind linking rows / columns) -- and a candidate is
+ *     accepted only if the jagged layout's OWN sampled cost estimate passes for both P A Q and its transpose; then the device holds
+ *     the permuted pair (three stable sorts) and pdlpdev_analysis_maps returns P and Q.  Everything is deterministic (fixed seeds,
+ *     atomicMin on packed (depth, cell) keys): the same matrix gets the same order and layout on every run.  A uniformly random
+ *     matrix is turned away by the estimates after a few milliseconds;
+ *   - pdlpdev_create_from_analysis adopts the device arrays (nothing of the matrix crosses PCIe again) and builds the slab-major
+ *     panels on the device; the other layouts are constructed on the host from the structure it holds or fetches.
+ * The host arrays passed to pdlpdev_analyze must stay valid until the analysis is consumed or destroyed. */
+typedef struct pdlpdev_analysis pdlpdev_analysis; /* opaque */
+int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_offsets, const int32_t* a_indices,
+                    const double* a_values, int flags);
+/* out = {permuted, method (0 none | 1 levels | 2 cells), estimate natural A, natural A^T, levels A, levels A^T, cells A, cells A^T
+ * (savings x 1e4), search levels, cell rounds} */
+int pdlpdev_analysis_info(pdlpdev_analysis* an, int32_t out[10]);
+/* row_new2old[m], col_new2old[n] of an accepted order (row i of the device's matrix is row row_new2old[i] of the caller's); either
+ * pointer may be NULL; returns 1 when the device holds a permuted pair, 0 when it holds the matrix as given */
+int pdlpdev_analysis_maps(pdlpdev_analysis* an, int32_t* row_new2old, int32_t* col_new2old);
+/* the matrices the device holds as host CSR: which = 0 A (m x n), 1 A^T; any pointer may be NULL */
+int pdlpdev_analysis_download(pdlpdev_analysis* an, int which, int32_t* offsets, int32_t* indices, double* values);
+/* c / lo / hi / lb / ub in the order of the matrices the device holds */
+int pdlpdev_create_from_analysis(pdlpdev_ctx** out, pdlpdev_analysis* an, const double* c, const double* lo, const double* hi,
+                                 const double* lb, const double* ub);
+void pdlpdev_analysis_destroy(pdlpdev_analysis* an);
+/* parity hooks of the set-up primitives (tests): stable sort of n (key, value) pairs by the low `bits` bits (vals NULL: iota);
+ * exclusive scan of n ints -> n + 1 outputs; FNV-1a checksums of the layout arrays of a context (out[16]: A^T offsets, indices,
+ * values; per side panel row0, tile_ptr, rowptr, col, perm; jagged slot / descriptors / perm) */
+int pdlpdev_debug_sort_pairs(int device, int64_t n, const uint32_t* keys, const uint32_t* vals, int bits, uint32_t* keys_out,
+                             uint32_t* vals_out);
+int pdlpdev_debug_scan(int device, int64_t n, const int32_t* in, int32_t* out);
+int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16]);
+
 /* ---- multi-GPU (row-block sharding, one context per rank) ----------------------------------- */
 /* 128-byte RCCL unique id, generated on rank 0 and handed to every rank by the launcher. */
 int pdlpdev_comm_unique_id(uint8_t id[128]);

@@ -266,8 +266,13 @@ int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_h
 
 /* the device context (for kernel timing and buffer downloads in benches/tests) */
 pdlpdev_ctx* cuoptamd_solver_device(cuoptamd_solver* s);
-/* rows [row_begin, row_end) of A held by this rank */
+/* rows [row_begin, row_end) of A held by this rank (of the matrix in the DEVICE's order when the set-up reordered it) */
 int cuoptamd_solver_row_range(cuoptamd_solver* s, int32_t* row_begin, int32_t* row_end);
+/* Set-up reordering (pdlp_device.h "device-side set-up"): info = pdlpdev_analysis_info's ten numbers (info[0] = 1: the device works
+ * on P A Q; info[1]: 1 breadth-first levels, 2 seeded cells); row_new2old[m] / col_new2old[n] (either may be NULL) receive the maps
+ * when the LP was reordered.  Returns 1 when reordered, 0 when the device holds the LP as given.  Everything that crosses this
+ * interface -- bounds, initial iterates, solutions, warm starts -- stays in the CALLER's order either way. */
+int cuoptamd_solver_reorder_info(cuoptamd_solver* s, int32_t info[10], int32_t* row_new2old, int32_t* col_new2old);
 
 /* contiguous row-block partition balanced by nonzeros: fills bounds[0..world] */
 void cuoptamd_partition_rows(int32_t m, const int32_t* offsets, int world, int32_t* bounds);
