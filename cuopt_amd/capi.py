@@ -701,15 +701,15 @@ class Solver:
         return a.value, b.value
 
     def reorder_info(self, maps=False):
-        """what the set-up's analysis pass found: {"reordered", "method" (none | levels | cells), estimates ...}; maps=True adds
+        """what the set-up's analysis pass found: {"reordered", "method" (none | chains | groups), estimates ...}; maps=True adds
         row_new2old / col_new2old when the device works on a permuted LP"""
         info = np.zeros(10, dtype=np.int32)
         rows = np.zeros(self.m, dtype=np.int32) if maps else None
         cols = np.zeros(self.n, dtype=np.int32) if maps else None
         on = lib.cuoptamd_solver_reorder_info(self.handle, _ptr(info), _ptr(rows), _ptr(cols))
-        out = dict(reordered=bool(on == 1), method={0: "none", 1: "levels", 2: "cells"}.get(int(info[1]), "?"),
-                   estimate_natural=(info[2] / 1e4, info[3] / 1e4), estimate_levels=(info[4] / 1e4, info[5] / 1e4),
-                   estimate_cells=(info[6] / 1e4, info[7] / 1e4), search_levels=int(info[8]), cell_rounds=int(info[9]))
+        out = dict(reordered=bool(on == 1), method={0: "none", 1: "chains", 2: "groups"}.get(int(info[1]), "?"),
+                   estimate_natural=(info[2] / 1e4, info[3] / 1e4), estimate_chains=(info[4] / 1e4, info[5] / 1e4),
+                   estimate_groups=(info[6] / 1e4, info[7] / 1e4), search_levels=int(info[8]), cell_rounds=int(info[9]))
         if maps and on == 1:
             out["row_new2old"], out["col_new2old"] = rows, cols
         return out
@@ -789,9 +789,9 @@ class Analysis:
     def info(self):
         out = np.zeros(10, np.int32)
         lib.pdlpdev_analysis_info(self.handle, _ptr(out))
-        return dict(permuted=bool(out[0]), method={0: "none", 1: "levels", 2: "cells"}.get(int(out[1]), "?"),
-                    estimate_natural=(out[2] / 1e4, out[3] / 1e4), estimate_levels=(out[4] / 1e4, out[5] / 1e4),
-                    estimate_cells=(out[6] / 1e4, out[7] / 1e4), search_levels=int(out[8]), cell_rounds=int(out[9]))
+        return dict(permuted=bool(out[0]), method={0: "none", 1: "chains", 2: "groups"}.get(int(out[1]), "?"),
+                    estimate_natural=(out[2] / 1e4, out[3] / 1e4), estimate_chains=(out[4] / 1e4, out[5] / 1e4),
+                    estimate_groups=(out[6] / 1e4, out[7] / 1e4), search_levels=int(out[8]), cell_rounds=int(out[9]))
 
     def maps(self):
         """(row_new2old, col_new2old) or None when the device holds the matrix as given"""

@@ -305,21 +305,7 @@ int dev_transpose(hipStream_t s, DevArena& ar, int32_t rows, int32_t cols, int64
 // ================================================================================================
 // the analysis pass: breadth-first levels and seeded cells on the bipartite row-column graph
 // ================================================================================================
-constexpr int32_t kUnvisited = 0x7fffffff, kHub = -1;
 constexpr int kStage = 4096;  // vertices a workgroup stages in LDS before it reserves room in the next frontier
-
-__global__ void __launch_bounds__(kT) k_bfs_init(int32_t count, const int32_t* __restrict__ off, int32_t hub_len, int32_t* __restrict__ lev)
-{
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
-    const int32_t len = off[i + 1] - off[i];
-    lev[i]            = len > hub_len ? kHub : kUnvisited;
-  }
-}
-
-__global__ void k_bfs_seed(int32_t* __restrict__ lev, int32_t start, int32_t* __restrict__ frontier, int32_t* __restrict__ counts)
-{
-  lev[start] = 0, frontier[0] = start, counts[0] = 1;
-}
 
 // appends the workgroup's staged vertices to the next frontier (one reservation per workgroup and flush)
 __device__ __forceinline__ void flush_stage(int* stage, int* stage_n, int32_t* __restrict__ out, int32_t* __restrict__ out_count)
@@ -333,64 +319,6 @@ __device__ __forceinline__ void flush_stage(int* stage, int* stage_n, int32_t* _
   __syncthreads();
   if (threadIdx.x == 0) *stage_n = 0;
   __syncthreads();
-}
-
-// one level of the breadth-first search: the vertices of `fr` (one side of the bipartite graph) claim their unvisited neighbours
-// (the other side) for level `level`
-__global__ void __launch_bounds__(kT) k_bfs_expand(const int32_t* __restrict__ fr, const int32_t* __restrict__ fr_count,
-                                                   const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                                                   int32_t* __restrict__ lev_other, int32_t* __restrict__ out,
-                                                   int32_t* __restrict__ out_count, int32_t level)
-{
-  __shared__ int stage[kStage];
-  __shared__ int stage_n;
-  if (threadIdx.x == 0) stage_n = 0;
-  __syncthreads();
-  const int32_t count = *fr_count;
-  for (int32_t i0 = blockIdx.x * kT; i0 < count; i0 += gridDim.x * kT) {
-    const int32_t i = i0 + threadIdx.x;
-    if (i < count) {
-      const int32_t v = fr[i];
-      for (int32_t k = off[v]; k < off[v + 1]; ++k) {
-        const int32_t u = idx[k];
-        if (lev_other[u] != kUnvisited) continue;
-        if (atomicCAS(&lev_other[u], kUnvisited, level) == kUnvisited) {
-          const int p = atomicAdd(&stage_n, 1);
-          if (p < kStage) stage[p] = u;
-          else out[atomicAdd(out_count, 1)] = u;  // (rare: more than kStage claims in one round of the workgroup)
-        }
-      }
-    }
-    flush_stage(stage, &stage_n, out, out_count);
-  }
-}
-
-// farthest visited vertex of one side: max over (level << 32 | ~id): the smallest id among the deepest
-__global__ void __launch_bounds__(kT) k_find_far(int32_t count, const int32_t* __restrict__ lev, unsigned long long* __restrict__ best)
-{
-  unsigned long long mine = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
-    const int32_t l = lev[i];
-    if (l >= 0 && l != kUnvisited) {
-      const unsigned long long key = ((unsigned long long)(uint32_t)l << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-      mine = key > mine ? key : mine;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(mine, o, 64);
-    mine = other > mine ? other : mine;
-  }
-  if ((threadIdx.x & 63) == 0 && mine) atomicMax(best, mine);
-}
-
-// positions for the barycentre sweeps: the level of a visited vertex, -1 otherwise
-__global__ void __launch_bounds__(kT) k_level_to_pos(int32_t count, const int32_t* __restrict__ lev, float* __restrict__ pos)
-{
-  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
-    const int32_t l = lev[i];
-    pos[i]          = (l >= 0 && l != kUnvisited) ? (float)l : -1.0f;
-  }
 }
 
 // pos_out[v] = mean of the neighbours' positions (visited, non-hub neighbours only; CSR order: reproducible), own position kept
@@ -412,6 +340,15 @@ __global__ void __launch_bounds__(kT) k_barycentre(int32_t count, const int32_t*
       if (cnt) out = sum / (float)cnt;
     }
     pos_out[v] = out;
+  }
+}
+
+// start of the barycentre sweeps: the coordinate of a vertex's cell along the quotient graph's chain (-1: hub / not reached)
+__global__ void __launch_bounds__(kT) k_cell_pos(int32_t count, const int32_t* __restrict__ label, const float* __restrict__ coord, float* __restrict__ pos)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t l = label[i];
+    pos[i]          = l < 0 ? -1.0f : coord[l];
   }
 }
 
@@ -493,36 +430,77 @@ __global__ void __launch_bounds__(kT) k_cell_expand(const int32_t* __restrict__ 
   }
 }
 
-// sort key of a vertex inside the cell ordering: (rank of its cell, depth); hubs and vertices no cell reached go last.  rank: the
-// cells' order (null: by cell id) -- cells that belong together (quotient graph, below) are neighbours in it
-__global__ void __launch_bounds__(kT) k_cell_to_key(int32_t count, const uint32_t* __restrict__ cell, const int32_t* __restrict__ rank,
-                                                    uint32_t* __restrict__ key)
+// label of a vertex: its cell's id, or (map != null) what the map makes of it -- the cell's group; -1: hub / not reached
+__global__ void __launch_bounds__(kT) k_cell_label(int32_t count, const uint32_t* __restrict__ cell, const int32_t* __restrict__ map,
+                                                   int32_t* __restrict__ label)
 {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
     const uint32_t c = cell[i];
-    if (c == kCellHub || c == kCellUnvisited) {
-      key[i] = 0xFFFFFFFFu;
-    } else {
-      const uint32_t id = c & 0xFFFFFFu;
-      key[i]            = ((rank ? (uint32_t)rank[id] : id) << 8) | (c >> 24);
-    }
+    label[i]         = (c == kCellHub || c == kCellUnvisited) ? -1 : map ? map[c & 0xFFFFFFu] : (int32_t)(c & 0xFFFFFFu);
+  }
+}
+__global__ void __launch_bounds__(kT) k_map_label(int32_t count, const int32_t* __restrict__ label, const int32_t* __restrict__ map,
+                                                  int32_t* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t l = label[i];
+    out[i]          = l < 0 ? -1 : map[l];
   }
 }
 
-// quotient graph of the cells: W[a * K + b] = nonzeros whose row lies in cell a and whose column lies in cell b (ids 1 ... K - 1)
+// One sweep of majority voting: a labelled vertex takes the label most of its neighbours carry (the first 32 entries vote; ties: the
+// own label, then the smaller one).  The searches of neighbouring cells leak across linking columns -- a tenth of the rows of a
+// block-angular LP end up in a foreign block's cell -- and a vertex whose neighbours sit elsewhere almost unanimously is moved there.
+__global__ void __launch_bounds__(kT) k_vote(int32_t count, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                             const int32_t* __restrict__ label_self, const int32_t* __restrict__ label_other,
+                                             int32_t* __restrict__ label_out)
+{
+  for (int64_t v = (int64_t)blockIdx.x * kT + threadIdx.x; v < count; v += (int64_t)gridDim.x * kT) {
+    const int32_t own = label_self[v];
+    int32_t best      = own;
+    if (own >= 0) {
+      int32_t l[32];
+      int nl = 0;
+      const int32_t k0 = off[v], k1 = min(off[v + 1], k0 + 32);
+      for (int32_t k = k0; k < k1; ++k) {
+        const int32_t x = label_other[idx[k]];
+        if (x >= 0) l[nl++] = x;
+      }
+      int best_cnt = 0;
+      for (int i = 0; i < nl; ++i) best_cnt += l[i] == own;
+      for (int i = 0; i < nl; ++i) {
+        int c = 0;
+        for (int j = 0; j < nl; ++j) c += l[j] == l[i];
+        if (c > best_cnt || (c == best_cnt && best != own && l[i] < best)) best = l[i], best_cnt = c;
+      }
+    }
+    label_out[v] = best;
+  }
+}
+
+// sort key in group mode: (group of the vertex's cell, the cell's rank, depth) -- 12 + 12 + 8 bits (at most 4096 cells)
+__global__ void __launch_bounds__(kT) k_group_key(int32_t count, const uint32_t* __restrict__ cell, const int32_t* __restrict__ label,
+                                                  const int32_t* __restrict__ group_of, const int32_t* __restrict__ rank, uint32_t* __restrict__ key)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < count; i += (int64_t)gridDim.x * kT) {
+    const int32_t l = label[i];
+    if (l < 0) key[i] = 0xFFFFFFFFu;
+    else key[i] = ((uint32_t)group_of[l] << 20) | ((uint32_t)rank[l] << 8) | min(cell[i] >> 24, 255u);
+  }
+}
+
+// quotient graph of the cells: W[a * K + b] = nonzeros whose row carries label a and whose column carries label b (ids 1 ... K - 1)
 __global__ void __launch_bounds__(kT) k_cell_quotient(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                                                      const uint32_t* __restrict__ cell_r, const uint32_t* __restrict__ cell_c, int32_t K,
+                                                      const int32_t* __restrict__ label_r, const int32_t* __restrict__ label_c, int32_t K,
                                                       int32_t* __restrict__ W)
 {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < rows; i += (int64_t)gridDim.x * kT) {
-    const uint32_t cr = cell_r[i];
-    if (cr == kCellHub || cr == kCellUnvisited) continue;
-    const int32_t a = (int32_t)(cr & 0xFFFFFFu);
+    const int32_t a = label_r[i];
+    if (a < 0) continue;
     int32_t last_b = -1, run = 0;
     for (int32_t k = off[i]; k < off[i + 1]; ++k) {
-      const uint32_t cc = cell_c[idx[k]];
-      if (cc == kCellHub || cc == kCellUnvisited) continue;
-      const int32_t b = (int32_t)(cc & 0xFFFFFFu);
+      const int32_t b = label_c[idx[k]];
+      if (b < 0) continue;
       if (b != last_b) {
         if (run) atomicAdd(&W[(size_t)a * K + last_b], run);
         last_b = b, run = 0;
@@ -611,12 +589,19 @@ __global__ void __launch_bounds__(kT) k_panel_count(const int32_t* __restrict__ 
   __syncthreads();
   const int w = blockIdx.x;
   const int32_t a = row0[w], b = row0[w + 1];
-  // rows that stay in the panel are contiguous in the CSR except for the own rows: walk row by row, a wave per row
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int32_t i = a + wave; i < b; i += kT / 64) {
+  for (int32_t i = a + threadIdx.x; i < b; i += kT) {  // thread <-> row, as in the placement
     const int32_t k0 = off[i], k1 = off[i + 1];
     if ((int64_t)(k1 - k0) > own_from) continue;
-    for (int32_t k = k0 + lane; k < k1; k += 64) atomicAdd(&c[idx[k] / slab_w], 1);
+    int s_cur = -1, run = 0;
+    for (int32_t k = k0; k < k1; ++k) {
+      const int s2 = idx[k] / slab_w;
+      if (s2 != s_cur) {
+        if (run) atomicAdd(&c[s_cur], run);
+        s_cur = s2, run = 0;
+      }
+      ++run;
+    }
+    if (run) atomicAdd(&c[s_cur], run);
   }
   __syncthreads();
   if (threadIdx.x < S) count[(size_t)w * S + threadIdx.x] = c[threadIdx.x];
@@ -787,58 +772,6 @@ int estimate_saving(pdlpdev_analysis* an, int side, const uint32_t* d_row_new2ol
   return 0;
 }
 
-struct Bfs {
-  int32_t *lev_r = nullptr, *lev_c = nullptr;
-  int32_t *fr_r = nullptr, *fr_c = nullptr;
-  int32_t* counts = nullptr;  // frontier size per level
-  int max_levels  = 0;
-};
-
-// level-synchronous search from one row; returns the number of levels run (the last non-empty level index + 1) and the sizes
-int run_bfs(pdlpdev_analysis* an, const Bfs& B, int32_t start_row, int level_cap, bool stop_when_small_world, std::vector<int32_t>* sizes,
-            bool* small_world)
-{
-  hipStream_t s = an->stream;
-  const int32_t m = an->m, n = an->n;
-  k_bfs_init<<<grid_of(m), kT, 0, s>>>(m, an->A.off, kLongRow, B.lev_r);
-  k_bfs_init<<<grid_of(n), kT, 0, s>>>(n, an->At.off, kLongRow, B.lev_c);
-  HIP_TRY(hipMemsetAsync(B.counts, 0, ((size_t)B.max_levels + 2) * sizeof(int32_t), s));
-  k_bfs_seed<<<1, 1, 0, s>>>(B.lev_r, start_row, B.fr_r, B.counts);
-  sizes->clear();
-  *small_world = false;
-  const int grid = 512;
-  int level = 0;  // level of the frontier about to be expanded (rows: even, columns: odd)
-  int batch = 8;
-  int64_t reached = 1;
-  const int64_t all = (int64_t)m + n;
-  for (;;) {
-    const int upto = std::min(level + batch, std::min(level_cap, B.max_levels));
-    for (; level < upto; ++level) {
-      if ((level & 1) == 0)
-        k_bfs_expand<<<grid, kT, 0, s>>>(B.fr_r, B.counts + level, an->A.off, an->A.idx, B.lev_c, B.fr_c, B.counts + level + 1, level + 1);
-      else
-        k_bfs_expand<<<grid, kT, 0, s>>>(B.fr_c, B.counts + level, an->At.off, an->At.idx, B.lev_r, B.fr_r, B.counts + level + 1, level + 1);
-    }
-    const size_t have = sizes->size();
-    sizes->resize((size_t)level + 1);
-    HIP_TRY(hipMemcpyAsync(sizes->data() + have, B.counts + have, ((size_t)level + 1 - have) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = std::max<size_t>(have, 1); i < sizes->size(); ++i) reached += (*sizes)[i];
-    if (sizes->back() == 0) break;
-    if (level >= level_cap || level >= B.max_levels) break;
-    // a graph whose search covers most of it within a dozen levels has no level structure worth ordering by
-    if (stop_when_small_world && level <= 16 && reached * 2 > all) {
-      *small_world = true;
-      break;
-    }
-    batch = std::min(batch * 2, 128);
-  }
-  while (!sizes->empty() && sizes->back() == 0) sizes->pop_back();
-  an->bfs_reached = reached;
-  HIP_TRY(hipGetLastError());
-  return (int)sizes->size();
-}
-
 int keys_to_perm(pdlpdev_analysis* an, SortBufs& SB, int32_t count, const uint32_t* d_keys, int bits, uint32_t* d_new2old, int32_t* d_old2new)
 {
   int slot = 0;
@@ -851,8 +784,20 @@ int keys_to_perm(pdlpdev_analysis* an, SortBufs& SB, int32_t count, const uint32
 
 }  // namespace
 
-// Looks for a row / column order under which the jagged layout applies.  On success (an->method != 0) the device holds the maps in
-// d_maps = {row new2old, col new2old, row old2new, col old2new} (arena memory, valid until the caller releases its mark).
+// Looks for a row / column order under which the jagged layout applies.  On success (an->method != 0) the device holds the maps
+// {row new2old, col new2old, row old2new, col old2new} (arena memory, valid until the caller releases its mark).
+//
+// One search serves band-like and block-like structure.  CELLS are grown breadth-first from seeds spaced one row block apart on the
+// bipartite row-column graph (rows / columns of more than kLongRow entries neither expand nor get claimed): a handful of rounds
+// whatever the graph's diameter (a full level-synchronous search of a band of half-width 2000 over a million rows is ~1100 dependent
+// levels: 17-60 ms as launches, no better as one resident workgroup -- measured, profiles/r05_setup.txt).  The QUOTIENT graph of
+// the cells (a few hundred nodes) comes to the host: cells joined by strong edges form groups, and the groups' shape decides --
+//  * long chains (a band, a staircase: the cells line up along the diagonal): the position of a cell along its chain (breadth-first
+//    levels from a pseudo-peripheral cell) is the start value of a few BARYCENTRE sweeps over the real graph (a vertex moves to the
+//    mean position of its neighbours): the fuzzy cell boundaries dissolve into a smooth one-dimensional embedding -- method 1;
+//  * small tight groups (diagonal blocks behind linking rows / columns): two sweeps of MAJORITY voting at group level pull back the
+//    tenth of the vertices that a neighbouring block's cell reached first through a linking column -- method 2.
+// The candidate is accepted only if the jagged layout's own sampled cost estimate passes for P A Q and for its transpose.
 static int find_ordering(pdlpdev_analysis* an, uint32_t** d_row_new2old, uint32_t** d_col_new2old, int32_t** d_row_old2new,
                          int32_t** d_col_old2new, Lap& lap)
 {
@@ -860,163 +805,187 @@ static int find_ordering(pdlpdev_analysis* an, uint32_t** d_row_new2old, uint32_
   DevArena& ar = an->arena;
   hipStream_t s = an->stream;
   an->method = 0;
-  const int level_cap = (int)cuopt_amd::tune_int("reorder_level_cap", 8192);
-  Bfs B;
-  B.max_levels = level_cap + 2;
-  B.lev_r = ar.take<int32_t>(m), B.lev_c = ar.take<int32_t>(n);
-  B.fr_r = ar.take<int32_t>(m), B.fr_c = ar.take<int32_t>(n);
-  B.counts = ar.take<int32_t>((size_t)B.max_levels + 2);
+  int G = 0, waves = 8, wcap = 0, brows = 0;
+  if (!jag_geometry(m, 0, &G, &waves, &wcap, &brows)) return 0;
+  const int32_t spacing = (int32_t)std::max<long long>(64, cuopt_amd::tune_int("reorder_cell_rows", brows));
+  const int32_t ncells  = (int32_t)(((int64_t)m + spacing - 1) / spacing);
+  const int32_t K       = ncells + 1;
+  if (K > 4096) return 0;  // (beyond 8 M rows the quotient graph would need a sparse form: not built)
+  const int rounds_cap = 48;
+  int32_t* fr_r   = ar.take<int32_t>(m);
+  int32_t* fr_c   = ar.take<int32_t>(n);
+  int32_t* counts = ar.take<int32_t>((size_t)rounds_cap + 2);
   uint32_t* row_n2o = ar.take<uint32_t>(m);
   uint32_t* col_n2o = ar.take<uint32_t>(n);
   int32_t* row_o2n  = ar.take<int32_t>(m);
   int32_t* col_o2n  = ar.take<int32_t>(n);
+  uint32_t* cell_r  = ar.take<uint32_t>(m);
+  uint32_t* cell_c  = ar.take<uint32_t>(n);
   uint32_t* key_r   = ar.take<uint32_t>(m);
   uint32_t* key_c   = ar.take<uint32_t>(n);
-  unsigned long long* d_best = ar.take<unsigned long long>(1);
+  int32_t* lab_r    = ar.take<int32_t>(m);
+  int32_t* lab_c    = ar.take<int32_t>(n);
+  int32_t* W        = ar.take<int32_t>((size_t)K * K);
+  int32_t* d_rank   = ar.take<int32_t>((size_t)K);
+  int32_t* d_group  = ar.take<int32_t>((size_t)K);
+  float* d_coord    = ar.take<float>((size_t)K);
   SortBufs SB;
   TRY(sort_bufs_take(ar, &SB, std::max(m, n)));
-  if (!B.lev_r || !B.lev_c || !B.fr_r || !B.fr_c || !B.counts || !row_n2o || !col_n2o || !row_o2n || !col_o2n || !key_r || !key_c || !d_best)
+  if (!fr_r || !fr_c || !counts || !row_n2o || !col_n2o || !row_o2n || !col_o2n || !cell_r || !cell_c || !key_r || !key_c || !lab_r || !lab_c || !W || !d_rank ||
+      !d_group || !d_coord)
     return fail(-2, "device set-up: workspace too small for the ordering search");
   *d_row_new2old = row_n2o, *d_col_new2old = col_n2o, *d_row_old2new = row_o2n, *d_col_old2new = col_o2n;
   const double accept = 0.5;  // the full construction's own threshold (build_jag)
 
-  // ---- candidate 1: breadth-first levels from a pseudo-peripheral row + barycentre sweeps (band-like structure) ----
-  int32_t start = 0;
-  {
-    // the first row that has entries and is no hub (host offsets of the unpermuted A are the caller's)
-    const int32_t* off = an->h_off;
-    while (start < m && (off[start + 1] == off[start] || off[start + 1] - off[start] > kLongRow)) ++start;
-    if (start >= m) return 0;
-  }
-  std::vector<int32_t> sizes;
-  bool small_world = false;
-  int levels = run_bfs(an, B, start, level_cap, true, &sizes, &small_world);
-  if (levels < 0) return levels;
-  lap("search 1");
-  if (!small_world && levels >= 24 && an->bfs_reached * 10 >= ((int64_t)m + n) * 8) {
-    HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s));
-    k_find_far<<<grid_of(m), kT, 0, s>>>(m, B.lev_r, d_best);
-    unsigned long long best = 0;
-    HIP_TRY(hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+  // ---- cells
+  HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)rounds_cap + 2) * sizeof(int32_t), s));
+  HIP_TRY(hipMemsetAsync(W, 0, (size_t)K * K * sizeof(int32_t), s));
+  k_cell_init<<<grid_of(m), kT, 0, s>>>(m, an->A.off, kLongRow, cell_r);
+  k_cell_init<<<grid_of(n), kT, 0, s>>>(n, an->At.off, kLongRow, cell_c);
+  k_cell_seed<<<(ncells + kT - 1) / kT, kT, 0, s>>>(m, spacing, ncells, an->A.off, cell_r, fr_r, counts);
+  int level = 0;
+  std::vector<int32_t> csz;
+  for (;;) {
+    const int upto = std::min(level + 8, rounds_cap);
+    for (; level < upto; ++level) {
+      if ((level & 1) == 0)
+        k_cell_expand<<<512, kT, 0, s>>>(fr_r, counts + level, an->A.off, an->A.idx, cell_r, cell_c, fr_c, counts + level + 1);
+      else
+        k_cell_expand<<<512, kT, 0, s>>>(fr_c, counts + level, an->At.off, an->At.idx, cell_c, cell_r, fr_r, counts + level + 1);
+    }
+    csz.resize((size_t)level + 1);
+    HIP_TRY(hipMemcpyAsync(csz.data(), counts, ((size_t)level + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const int32_t far = (int32_t)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
-    levels = run_bfs(an, B, far, level_cap, false, &sizes, &small_world);
-    if (levels < 0) return levels;
-    an->bfs_levels = levels;
-    lap("search 2");
-    // positions: level, then two barycentre sweeps each way (the order inside a level follows the neighbours' positions)
-    float* pos_r  = (float*)key_r;  // (the key arrays double as position buffers until the keys are formed)
-    float* pos_c  = (float*)key_c;
-    float* pos_r2 = ar.take<float>(m);
-    float* pos_c2 = ar.take<float>(n);
-    if (!pos_r2 || !pos_c2) return fail(-2, "device set-up: workspace too small for the ordering search");
-    k_level_to_pos<<<grid_of(m), kT, 0, s>>>(m, B.lev_r, pos_r);
-    k_level_to_pos<<<grid_of(n), kT, 0, s>>>(n, B.lev_c, pos_c);
-    const int sweeps = (int)cuopt_amd::tune_int("reorder_sweeps", 2);
-    for (int it = 0; it < sweeps; ++it) {
-      k_barycentre<<<grid_of(n), kT, 0, s>>>(n, an->At.off, an->At.idx, pos_c, pos_r, pos_c2);
-      k_barycentre<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, pos_r, pos_c2, pos_r2);
-      HIP_TRY(hipMemcpyAsync(pos_r, pos_r2, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, s));
-      HIP_TRY(hipMemcpyAsync(pos_c, pos_c2, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (csz.back() == 0 || level >= rounds_cap) break;
+  }
+  an->cell_rounds = level;
+  // Two sweeps of majority voting at CELL level before the cells are compared: a search that reached a neighbouring block through a
+  // linking column first holds a foothold there (a tenth of the rows of a block-angular LP sit in a foreign block's cell, and a cell
+  // with footholds in many blocks would glue their groups together); a vertex whose neighbours carry another label almost
+  // unanimously takes it.  On a band the same sweeps sharpen the cells' fuzzy borders.
+  {
+    int32_t* lab_r2 = (int32_t*)fr_r;  // (the frontiers are free now)
+    int32_t* lab_c2 = (int32_t*)fr_c;
+    int32_t *lr = lab_r, *lc = lab_c;
+    k_cell_label<<<grid_of(m), kT, 0, s>>>(m, cell_r, nullptr, lr);
+    k_cell_label<<<grid_of(n), kT, 0, s>>>(n, cell_c, nullptr, lc);
+    const int votes = (int)cuopt_amd::tune_int("reorder_votes", 2);
+    for (int it = 0; it < votes; ++it) {
+      k_vote<<<grid_of(n), kT, 0, s>>>(n, an->At.off, an->At.idx, lc, lr, lab_c2);
+      k_vote<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, lr, lab_c2, lab_r2);
+      std::swap(lr, lab_r2), std::swap(lc, lab_c2);
     }
-    const float scale       = 64.0f;
-    const uint32_t last_key = (uint32_t)((levels + 2) * 64);
-    uint32_t* kr            = (uint32_t*)pos_r2;
-    uint32_t* kc            = (uint32_t*)pos_c2;
-    k_pos_to_key<<<grid_of(m), kT, 0, s>>>(m, pos_r, scale, last_key, kr);
-    k_pos_to_key<<<grid_of(n), kT, 0, s>>>(n, pos_c, scale, last_key, kc);
-    TRY(keys_to_perm(an, SB, m, kr, bits_for(last_key), row_n2o, row_o2n));
-    TRY(keys_to_perm(an, SB, n, kc, bits_for(last_key), col_n2o, col_o2n));
-    lap("levels -> order");
-    TRY(estimate_saving(an, 0, row_n2o, col_o2n, &an->saving_levels[0]));
-    if (an->saving_levels[0] >= accept) TRY(estimate_saving(an, 1, col_n2o, row_o2n, &an->saving_levels[1]));
-    lap("estimate 1");
-    if (an->saving_levels[0] >= accept && an->saving_levels[1] >= accept) {
-      an->method = 1;
-      return 0;
+    if (lr != lab_r) {  // (an odd number of sweeps: the labels end in the spare buffers)
+      HIP_TRY(hipMemcpyAsync(lab_r, lr, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(lab_c, lc, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     }
   }
-  // ---- candidate 2: seeded cells (block-like structure behind linking rows / columns) ----
-  {
-    int G = 0, waves = 8, wcap = 0, brows = 0;
-    if (!jag_geometry(m, 0, &G, &waves, &wcap, &brows)) return 0;
-    const int32_t spacing = (int32_t)std::max<long long>(64, cuopt_amd::tune_int("reorder_cell_rows", brows));
-    const int32_t ncells  = (int32_t)std::min<int64_t>(((int64_t)m + spacing - 1) / spacing, (1 << 24) - 2);
-    const int rounds_cap  = 48;
-    HIP_TRY(hipMemsetAsync(B.counts, 0, ((size_t)rounds_cap + 2) * sizeof(int32_t), s));
-    k_cell_init<<<grid_of(m), kT, 0, s>>>(m, an->A.off, kLongRow, key_r);
-    k_cell_init<<<grid_of(n), kT, 0, s>>>(n, an->At.off, kLongRow, key_c);
-    k_cell_seed<<<(ncells + kT - 1) / kT, kT, 0, s>>>(m, spacing, ncells, an->A.off, key_r, B.fr_r, B.counts);
-    int level = 0;
-    std::vector<int32_t> csz;
-    for (;;) {
-      const int upto = std::min(level + 8, rounds_cap);
-      for (; level < upto; ++level) {
-        if ((level & 1) == 0)
-          k_cell_expand<<<512, kT, 0, s>>>(B.fr_r, B.counts + level, an->A.off, an->A.idx, key_r, key_c, B.fr_c, B.counts + level + 1);
-        else
-          k_cell_expand<<<512, kT, 0, s>>>(B.fr_c, B.counts + level, an->At.off, an->At.idx, key_c, key_r, B.fr_r, B.counts + level + 1);
-      }
-      csz.resize((size_t)level + 1);
-      HIP_TRY(hipMemcpyAsync(csz.data(), B.counts, ((size_t)level + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (csz.back() == 0 || level >= rounds_cap) break;
+  k_cell_quotient<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, lab_r, lab_c, K, W);
+  std::vector<int32_t> hw((size_t)K * K);
+  HIP_TRY(hipMemcpyAsync(hw.data(), W, hw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  lap("cells");
+
+  // ---- the quotient graph on the host: strong edges (>= 5 % of the lighter cell's nonzeros), groups, a chain coordinate per group
+  auto sym = [&](int a, int b) { return (int64_t)hw[(size_t)a * K + b] + (a == b ? 0 : hw[(size_t)b * K + a]); };
+  std::vector<int64_t> tot(K, 0);
+  for (int a = 1; a < K; ++a)
+    for (int b = 1; b < K; ++b) tot[a] += a == b ? hw[(size_t)a * K + a] : sym(a, b);
+  std::vector<std::vector<std::pair<int64_t, int>>> strong(K);  // (-weight, neighbour): sorted = the heaviest first, ties to the smaller id
+  int64_t strong_edges = 0;
+  for (int a = 1; a < K; ++a) {
+    if (tot[a] == 0) continue;
+    for (int b = 1; b < K; ++b) {
+      if (b == a || tot[b] == 0) continue;
+      const int64_t w = sym(a, b);
+      if (w > 0 && w * 20 >= std::min(tot[a], tot[b])) strong[a].emplace_back(-w, b);
     }
-    an->cell_rounds = level;
-    // Cells that belong together become neighbours in the order: the quotient graph (cells x cells, weight = nonzeros between them)
-    // comes to the host; cells joined by an edge that carries >= 5 % of the lighter cell's nonzeros form a group (the cells of one
-    // diagonal block reference each other's columns all the time; across blocks there are only the linking columns), groups in the
-    // order of their first cell, cells inside a group in breadth-first order over the strong edges (a chain of cells stays a chain).
-    int32_t* d_rank = nullptr;
-    const int32_t K = ncells + 1;
-    if (K <= 4096) {
-      int32_t* W = ar.take<int32_t>((size_t)K * K);
-      d_rank     = ar.take<int32_t>((size_t)K);
-      if (!W || !d_rank) return fail(-2, "device set-up: workspace too small for the cells' quotient graph");
-      HIP_TRY(hipMemsetAsync(W, 0, (size_t)K * K * sizeof(int32_t), s));
-      k_cell_quotient<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, key_r, key_c, K, W);
-      std::vector<int32_t> hw((size_t)K * K);
-      HIP_TRY(hipMemcpyAsync(hw.data(), W, hw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      std::vector<int64_t> tot(K, 0);
-      auto sym = [&](int a, int b) { return (int64_t)hw[(size_t)a * K + b] + (a == b ? 0 : hw[(size_t)b * K + a]); };
-      for (int a = 1; a < K; ++a)
-        for (int b = 1; b < K; ++b) tot[a] += a == b ? hw[(size_t)a * K + a] : sym(a, b);
-      std::vector<int32_t> rank(K, 0), order;
-      std::vector<char> seen(K, 0);
-      order.reserve(K);
-      for (int a0 = 1; a0 < K; ++a0) {
-        if (seen[a0]) continue;
-        size_t head = order.size();
-        order.push_back(a0), seen[a0] = 1;
-        while (head < order.size()) {
-          const int a = order[head++];
-          // strong neighbours, the heaviest edge first (ties: the smaller id) -- a fixed rule
-          std::vector<std::pair<int64_t, int>> nb;
-          for (int b = 1; b < K; ++b)
-            if (!seen[b] && b != a) {
-              const int64_t w = sym(a, b);
-              if (w > 0 && w * 20 >= std::min(tot[a], tot[b])) nb.emplace_back(-w, b);
-            }
-          std::sort(nb.begin(), nb.end());
-          for (auto& e : nb) order.push_back(e.second), seen[e.second] = 1;
-        }
-      }
-      for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (int32_t)i;
-      HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, s));
-      HIP_TRY(hipStreamSynchronize(s));
+    std::sort(strong[a].begin(), strong[a].end());
+    strong_edges += (int64_t)strong[a].size();
+  }
+  if (strong_edges == 0) return 0;  // no two cells belong together: a matrix without structure to find (the uniformly random case)
+  auto levels_from = [&](int a0, std::vector<int32_t>& lev, std::vector<int32_t>& members) {  // breadth-first over the strong edges
+    members.assign(1, a0);
+    lev[a0] = 0;
+    for (size_t head = 0; head < members.size(); ++head) {
+      const int a = members[head];
+      for (auto& e : strong[a])
+        if (lev[e.second] < 0) lev[e.second] = lev[a] + 1, members.push_back(e.second);
     }
-    uint32_t* kr = (uint32_t*)B.lev_r;  // (the level arrays are free now)
-    uint32_t* kc = (uint32_t*)B.lev_c;
-    k_cell_to_key<<<grid_of(m), kT, 0, s>>>(m, key_r, d_rank, kr);
-    k_cell_to_key<<<grid_of(n), kT, 0, s>>>(n, key_c, d_rank, kc);
-    TRY(keys_to_perm(an, SB, m, kr, 32, row_n2o, row_o2n));
-    TRY(keys_to_perm(an, SB, n, kc, 32, col_n2o, col_o2n));
-    lap("cells -> order");
-    TRY(estimate_saving(an, 0, row_n2o, col_o2n, &an->saving_cells[0]));
-    if (an->saving_cells[0] >= accept) TRY(estimate_saving(an, 1, col_n2o, row_o2n, &an->saving_cells[1]));
-    lap("estimate 2");
-    if (an->saving_cells[0] >= accept && an->saving_cells[1] >= accept) an->method = 2;
+  };
+  std::vector<int32_t> rank(K, 0), group_of(K, 0), lev(K, -1), members, order;
+  std::vector<float> coord(K, 0.0f);
+  order.reserve(K);
+  int ngroups = 0;
+  int64_t cells_in_chains = 0, cells_total = 0;
+  float base = 0.0f;
+  for (int a0 = 1; a0 < K; ++a0) {
+    if (lev[a0] >= 0 || tot[a0] == 0) continue;
+    levels_from(a0, lev, members);
+    // again from the deepest cell (the smallest id among them): the levels run along the chain from one of its ends
+    int far = a0;
+    for (int c : members)
+      if (lev[c] > lev[far] || (lev[c] == lev[far] && c < far)) far = c;
+    for (int c : members) lev[c] = -1;
+    levels_from(far, lev, members);
+    int depth = 0;
+    for (int c : members) depth = std::max(depth, (int)lev[c]);
+    const int g = ngroups++;
+    for (int c : members) group_of[c] = g, coord[c] = base + (float)lev[c], order.push_back(c);
+    base += (float)depth + 2.0f;
+    cells_total += (int64_t)members.size();
+    if (depth >= 8) cells_in_chains += (int64_t)members.size();
+  }
+  for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (int32_t)i;
+  HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_group, group_of.data(), (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_coord, coord.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  an->bfs_levels = (int)base;
+  const bool chains = cells_in_chains * 2 >= cells_total;
+  lap("quotient");
+
+  for (int attempt = 0; attempt < 2 && an->method == 0; ++attempt) {
+    const bool chain_mode = attempt == 0 ? chains : !chains;
+    if (attempt == 1 && !(chain_mode ? cells_in_chains > 0 : true)) break;
+    double* saving = chain_mode ? an->saving_levels : an->saving_cells;
+    if (chain_mode) {
+      // positions along the chains, then barycentre sweeps each way
+      float* pos_r  = (float*)key_r;
+      float* pos_c  = (float*)key_c;
+      float* pos_r2 = (float*)fr_r;  // (the frontiers are free now)
+      float* pos_c2 = (float*)fr_c;
+      k_cell_pos<<<grid_of(m), kT, 0, s>>>(m, lab_r, d_coord, pos_r);
+      k_cell_pos<<<grid_of(n), kT, 0, s>>>(n, lab_c, d_coord, pos_c);
+      const int sweeps = (int)cuopt_amd::tune_int("reorder_sweeps", 3);
+      for (int it = 0; it < sweeps; ++it) {
+        k_barycentre<<<grid_of(n), kT, 0, s>>>(n, an->At.off, an->At.idx, pos_c, pos_r, pos_c2);
+        k_barycentre<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, pos_r, pos_c2, pos_r2);
+        std::swap(pos_r, pos_r2), std::swap(pos_c, pos_c2);
+      }
+      const float scale       = 256.0f;
+      const uint32_t last_key = (uint32_t)((base + 2.0f) * scale);
+      uint32_t* kr            = (uint32_t*)pos_r2;
+      uint32_t* kc            = (uint32_t*)pos_c2;
+      k_pos_to_key<<<grid_of(m), kT, 0, s>>>(m, pos_r, scale, last_key, kr);
+      k_pos_to_key<<<grid_of(n), kT, 0, s>>>(n, pos_c, scale, last_key, kc);
+      TRY(keys_to_perm(an, SB, m, kr, bits_for(last_key), row_n2o, row_o2n));
+      TRY(keys_to_perm(an, SB, n, kc, bits_for(last_key), col_n2o, col_o2n));
+      lap("chain -> order");
+    } else {
+      // keys (group of the vertex's cell, the cell's rank, depth): the cells of a group are neighbours, the groups follow each other
+      uint32_t* kr = (uint32_t*)fr_r;
+      uint32_t* kc = (uint32_t*)fr_c;
+      k_group_key<<<grid_of(m), kT, 0, s>>>(m, cell_r, lab_r, d_group, d_rank, kr);
+      k_group_key<<<grid_of(n), kT, 0, s>>>(n, cell_c, lab_c, d_group, d_rank, kc);
+      TRY(keys_to_perm(an, SB, m, kr, 32, row_n2o, row_o2n));
+      TRY(keys_to_perm(an, SB, n, kc, 32, col_n2o, col_o2n));
+      lap("groups -> order");
+    }
+    TRY(estimate_saving(an, 0, row_n2o, col_o2n, &saving[0]));
+    if (saving[0] >= accept) TRY(estimate_saving(an, 1, col_n2o, row_o2n, &saving[1]));
+    lap("estimate");
+    if (saving[0] >= accept && saving[1] >= accept) an->method = chain_mode ? 1 : 2;
   }
   return 0;
 }

@@ -1411,12 +1411,26 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   std::vector<int32_t> rba = build_row_blocks(m, A_off);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
-  TRY(upload_f64(ctx, &ctx->c, c, n)); TRY(upload_f64(ctx, &ctx->c_u, c, n));
-  TRY(upload_f64(ctx, &ctx->lb, lb, n)); TRY(upload_f64(ctx, &ctx->lb_u, lb, n));
-  TRY(upload_f64(ctx, &ctx->ub, ub, n)); TRY(upload_f64(ctx, &ctx->ub_u, ub, n));
+  // every problem vector crosses PCIe once: the unscaled copy is made on the device, and a bound vector that is one value
+  // throughout (all lower bounds 0, all upper bounds +inf: most LPs) is not uploaded at all
   ctx->note_uniform_bounds(lb, ub);
-  TRY(upload_f64(ctx, &ctx->lo, lo, m)); TRY(upload_f64(ctx, &ctx->lo_u, lo, m));
-  TRY(upload_f64(ctx, &ctx->hi, hi, m)); TRY(upload_f64(ctx, &ctx->hi_u, hi, m));
+  auto upload_pair = [&](double** work, double** keep, const double* src, size_t count, bool uniform, double value) -> int {
+    TRY(dev_alloc(ctx, work, count));
+    TRY(dev_alloc(ctx, keep, count));
+    if (count == 0) return 0;
+    if (uniform) {
+      k_fill<<<grid_for((int64_t)count), kBlock, 0, ctx->stream>>>((int64_t)count, *work, value);
+    } else {
+      HIP_TRY(hipMemcpyAsync(*work, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(*keep, *work, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  };
+  TRY(upload_pair(&ctx->c, &ctx->c_u, c, (size_t)n, false, 0.0));
+  TRY(upload_pair(&ctx->lb, &ctx->lb_u, lb, (size_t)n, ctx->ubd.lb_same != 0, ctx->ubd.lb));
+  TRY(upload_pair(&ctx->ub, &ctx->ub_u, ub, (size_t)n, ctx->ubd.ub_same != 0, ctx->ubd.ub));
+  TRY(upload_pair(&ctx->lo, &ctx->lo_u, lo, (size_t)m, false, 0.0));
+  TRY(upload_pair(&ctx->hi, &ctx->hi_u, hi, (size_t)m, false, 0.0));
   TRY(dev_alloc(ctx, &ctx->dr, m)); TRY(dev_alloc(ctx, &ctx->dc, n));
   // x, A^T y, xbar, sum_x carry kSlicePad spare entries: the sliced-primal dataflow of a sharded solve all-gathers them in
   // equal slices of a multiple of 16 entries per rank (slice * world may exceed n by up to 16 * 16 - 1)

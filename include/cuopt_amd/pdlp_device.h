@@ -160,21 +160,23 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx);
  *     cpp/src/mip/problem/problem.cu:277-309) -- a stable radix sort by column, rows ascending inside a column;
  *   - flags bit 0: an ANALYSIS PASS looks for structure the matrix arrives without (the reference hands its analysis to the closed
  *     cusparseSpMV_preprocess, cpp/src/linear_programming/cusparse_view.cu:92-115,254-265): when the jagged layout does not apply to
- *     the matrix as given, two candidate orders are formed on the bipartite row-column graph (rows / columns of more than 128 entries
- *     left out) -- breadth-first levels from a pseudo-peripheral row refined by barycentre sweeps (band / staircase structure), and
- *     cells grown from seeds spaced one row block apart (block structure behind linking rows / columns) -- and a candidate is
- *     accepted only if the jagged layout's OWN sampled cost estimate passes for both P A Q and its transpose; then the device holds
- *     the permuted pair (three stable sorts) and pdlpdev_analysis_maps returns P and Q.  Everything is deterministic (fixed seeds,
- *     atomicMin on packed (depth, cell) keys): the same matrix gets the same order and layout on every run.  A uniformly random
- *     matrix is turned away by the estimates after a few milliseconds;
+ *     the matrix as given, CELLS are grown breadth-first from seeds spaced one row block apart on the bipartite row-column graph
+ *     (rows / columns of more than 128 entries left out; a handful of rounds whatever the diameter), and the cells' QUOTIENT graph
+ *     decides how they are laid out: long chains of cells (band / staircase structure) give every vertex a start position that a few
+ *     barycentre sweeps over the real graph turn into a smooth one-dimensional embedding (method 1, "chains"); small tight groups
+ *     (diagonal blocks behind linking rows / columns) are cleaned up by majority voting at group level (method 2, "groups").  A
+ *     candidate is accepted only if the jagged layout's OWN sampled cost estimate passes for both P A Q and its transpose; then the
+ *     device holds the permuted pair (three stable sorts) and pdlpdev_analysis_maps returns P and Q.  Everything is deterministic
+ *     (seeds at fixed positions, atomicMin on packed (depth, cell) keys, fixed tie rules on the host): the same matrix gets the same
+ *     order and layout on every run.  A uniformly random matrix has no strong edge in its quotient graph and is turned away there;
  *   - pdlpdev_create_from_analysis adopts the device arrays (nothing of the matrix crosses PCIe again) and builds the slab-major
  *     panels on the device; the other layouts are constructed on the host from the structure it holds or fetches.
  * The host arrays passed to pdlpdev_analyze must stay valid until the analysis is consumed or destroyed. */
 typedef struct pdlpdev_analysis pdlpdev_analysis; /* opaque */
 int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_offsets, const int32_t* a_indices,
                     const double* a_values, int flags);
-/* out = {permuted, method (0 none | 1 levels | 2 cells), estimate natural A, natural A^T, levels A, levels A^T, cells A, cells A^T
- * (savings x 1e4), search levels, cell rounds} */
+/* out = {permuted, method (0 none | 1 chains | 2 groups), estimate natural A, natural A^T, chains A, chains A^T, groups A, groups A^T
+ * (savings x 1e4), length of the chains (quotient levels), cell rounds} */
 int pdlpdev_analysis_info(pdlpdev_analysis* an, int32_t out[10]);
 /* row_new2old[m], col_new2old[n] of an accepted order (row i of the device's matrix is row row_new2old[i] of the caller's); either
  * pointer may be NULL; returns 1 when the device holds a permuted pair, 0 when it holds the matrix as given */

@@ -106,7 +106,7 @@ def test_the_analysis_pass_finds_the_order_and_builds_p_a_q(shuffled_lp):
     an = capi.Analysis(q, reorder=True)
     info = an.info()
     assert info["permuted"], info
-    assert info["method"] == ("cells" if kind == "block_angular" else "levels"), info
+    assert info["method"] == ("groups" if kind == "block_angular" else "chains"), info
     assert min(info["estimate_natural"]) < 0.35  # the shuffled matrix itself is no case for the jagged layout
     rn2o, cn2o = an.maps()
     assert sorted(rn2o.tolist()) == list(range(q["m"])) and sorted(cn2o.tolist()) == list(range(q["n"]))
@@ -171,16 +171,19 @@ def test_a_reordered_solve_answers_in_the_caller_s_order(shuffled_lp):
     assert abs(r["primal_objective"] - q["objective_star"]) <= 2e-4 * scale
     host_check(q, dict(r, x=x, y=y, reduced_cost=z, objective=r["primal_objective"]), eps=1e-5)
     # warm-start snapshots are in the caller's order: restoring one into a fresh (reordered) solver continues bit for bit
-    a = capi.Solver(q, mode=1, tol=0.0, iteration_limit=120)
-    a.advance(80)
-    ws = a.get_warm_start()
+    # (the pattern of pdlp_test.cu:803-854: iterations to a coarse tolerance + iterations from its snapshot = iterations from scratch)
+    full = capi.Solver(q, mode=1, tol=1e-4)
+    r_full = full.advance()
+    a = capi.Solver(q, mode=1, tol=1e-2)
     ra = a.advance()
-    b = capi.Solver(q, mode=1, tol=0.0, iteration_limit=120)
-    b.set_warm_start(ws)
+    ws = a.get_warm_start()
+    assert ws["current_primal_solution"].shape == (q["n"],) and ws["total_pdlp_iterations"] == ra["steps_taken"]
+    b = capi.Solver(q, mode=1, tol=1e-4, warm_start=ws)
     rb = b.advance()
-    assert (ra["steps_taken"], ra["attempted_steps"]) == (rb["steps_taken"], rb["attempted_steps"])
-    assert ra["primal_objective"] == rb["primal_objective"] and ra["step_size"] == rb["step_size"]
-    np.testing.assert_array_equal(a.solution()[0], b.solution()[0])
+    assert ra["steps_taken"] + rb["steps_taken"] == r_full["steps_taken"]
+    assert rb["primal_objective"] == r_full["primal_objective"]
+    np.testing.assert_array_equal(full.solution()[0], b.solution()[0])
+    full.close()
     s.close(), a.close(), b.close()
 
 
