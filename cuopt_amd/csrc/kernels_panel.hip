@@ -210,8 +210,25 @@ bool panel_plan(PanelHost* out, int32_t rows, int32_t cols, const int32_t* off, 
   // auto: when more than 2 % of the nonzeros sit in rows of more than kLongRow entries -- a structural, reproducible rule;
   // CUOPT_AMD_TUNE=panel_seg=0|1 forces it off / on (tests, sweeps).
   int64_t long_nnz = 0;  // nonzeros in rows the row-per-lane kernel sums wave by wave
-  for (int32_t i = 0; i < rows; ++i)
-    if (off[i + 1] - off[i] > kLongRow) long_nnz += off[i + 1] - off[i];
+  int32_t max_len  = 0;
+  {
+    // (one pass over the offsets on the host pool's threads: at 1e6 rows every serial pass of this function was ~1 ms of the set-up)
+    constexpr int kParts = 16;
+    int64_t part_long[kParts] = {0};
+    int32_t part_max[kParts]  = {0};
+    cuopt_amd::parallel_tasks(kParts, [&](int t) {
+      const int32_t a = (int32_t)((int64_t)rows * t / kParts), b = (int32_t)((int64_t)rows * (t + 1) / kParts);
+      int64_t ln = 0;
+      int32_t mx = 0;
+      for (int32_t i = a; i < b; ++i) {
+        const int32_t len = off[i + 1] - off[i];
+        if (len > kLongRow) ln += len;
+        mx = std::max(mx, len);
+      }
+      part_long[t] = ln, part_max[t] = mx;
+    }, (int64_t)rows * 8);
+    for (int t = 0; t < kParts; ++t) long_nnz += part_long[t], max_len = std::max(max_len, part_max[t]);
+  }
   {
     const long long want = cuopt_amd::tune_int("panel_seg", -1);
     P.seg = want == 1 || (want != 0 && long_nnz * 50 > nnz);
@@ -224,12 +241,28 @@ bool panel_plan(PanelHost* out, int32_t rows, int32_t cols, const int32_t* off, 
   std::vector<char>& is_own = *is_own_out;
   is_own.assign((size_t)rows, 0);
   int64_t own_nnz = 0;
-  for (int32_t i = 0; i < rows; ++i)
+  const bool any_own = max_len > own_from || dense_first_seg != nullptr;
+  if (any_own)
+    for (int32_t i = 0; i < rows; ++i)
       if (off[i + 1] - off[i] > own_from || (dense_first_seg && (*dense_first_seg)[i] >= 0))  // (rows that own dense segments: their
         is_own[i] = 1, P.own_row.push_back(i), own_nnz += off[i + 1] - off[i];                // workgroup adds the segments too)
   auto cut = [&](int64_t tgt) {
     P.row0.assign(1, 0);
     int32_t start = 0;
+    if (!any_own) {
+      // every row counts: the greedy rule below as a search over the offsets (same panels: rows are taken while they fit under the
+      // target, a first non-empty row above the target is taken alone)
+      while (start < rows) {
+        const int32_t last = (int32_t)std::min<int64_t>(rows, (int64_t)start + kPanelMaxRows);
+        const int64_t lim  = (int64_t)off[start] + tgt;
+        int32_t end = (int32_t)(std::upper_bound(off + start, off + last + 1, lim, [](int64_t v, int32_t o) { return v < (int64_t)o; }) - off) - 1;
+        if (end < last && off[end] == off[start]) ++end;  // (nothing but empty rows so far: the row that does not fit goes in alone)
+        end = std::max(end, start + 1);
+        P.row0.push_back(end);
+        start = end;
+      }
+      return;
+    }
     while (start < rows) {
       int32_t end = start;
       int64_t cnt = 0;
@@ -256,7 +289,8 @@ bool panel_plan(PanelHost* out, int32_t rows, int32_t cols, const int32_t* off, 
   }
   const int W = (int)P.row0.size() - 1;
   P.W = W, P.S = S, P.slab_w = slab_w;
-  for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
+  if (!any_own) P.any_long = max_len > kLongRow;
+  else for (int32_t i = 0; i < rows && !P.any_long; ++i) P.any_long = !is_own[i] && off[i + 1] - off[i] > kLongRow;
   P.own_ptr.assign((size_t)W + 1, 0);
   for (int w = 0, q = 0; w < W; ++w) {
     while (q < (int)P.own_row.size() && P.own_row[q] < P.row0[w + 1]) ++q;

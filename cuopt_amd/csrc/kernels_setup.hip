@@ -272,14 +272,33 @@ __device__ __forceinline__ int32_t row_of(const int32_t* __restrict__ off, int32
   return lo;
 }
 
+// row id of every nonzero, in CSR order: a workgroup owns 4096 consecutive entries, narrows the row range once (two searches), and
+// its threads search inside it (coalesced, a dozen steps over lines the whole workgroup shares)
+__global__ void __launch_bounds__(kT) k_row_ids(int64_t nnz, const int32_t* __restrict__ off, int32_t rows, uint32_t* __restrict__ rowid)
+{
+  __shared__ int32_t range[2];
+  const int64_t k0 = (int64_t)blockIdx.x * 4096, k1 = min(nnz, k0 + 4096);
+  if (threadIdx.x < 2) range[threadIdx.x] = row_of(off, rows, threadIdx.x == 0 ? k0 : k1 - 1);
+  __syncthreads();
+  const int32_t r_lo = range[0], r_hi = range[1] + 1;  // off[r_lo] <= k < off[r_hi] for every k of the workgroup
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += kT) {
+    int32_t lo = r_lo, hi = r_hi;
+    while (hi - lo > 1) {
+      const int32_t mid = lo + ((hi - lo) >> 1);
+      if ((int64_t)off[mid] <= k) lo = mid; else hi = mid;
+    }
+    rowid[k] = (uint32_t)lo;
+  }
+}
+
 // one entry of the transpose per thread: src[q] = position in the source CSR
-__global__ void __launch_bounds__(kT) k_transpose_finish(const uint32_t* __restrict__ src, int64_t nnz, const int32_t* __restrict__ a_off,
-                                                         int32_t rows, const double* __restrict__ a_val, int32_t* __restrict__ t_idx,
+__global__ void __launch_bounds__(kT) k_transpose_finish(const uint32_t* __restrict__ src, int64_t nnz, const uint32_t* __restrict__ rowid,
+                                                         const double* __restrict__ a_val, int32_t* __restrict__ t_idx,
                                                          double* __restrict__ t_val)
 {
   for (int64_t q = (int64_t)blockIdx.x * kT + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * kT) {
     const uint32_t k = src[q];
-    t_idx[q] = row_of(a_off, rows, (int64_t)k);
+    t_idx[q] = (int32_t)rowid[k];
     t_val[q] = a_val[k];
   }
 }
@@ -296,7 +315,11 @@ int dev_transpose(hipStream_t s, DevArena& ar, int32_t rows, int32_t cols, int64
   int slot = 0;
   if (nnz > 0) TRY(radix_sort_pairs(s, nnz, (const uint32_t*)A.idx, nullptr, B, bits_for((uint32_t)std::max(cols - 1, 1)), &slot));
   k_offsets_from_sorted<<<grid_of(nnz + 1), kT, 0, s>>>(B.k[slot], nnz, cols, T.off);
-  if (nnz > 0) k_transpose_finish<<<grid_of(nnz), kT, 0, s>>>(B.v[slot], nnz, A.off, rows, A.val, T.idx, T.val);
+  if (nnz > 0) {
+    uint32_t* rowid = B.k[slot ^ 1];  // (the sort's other key buffer is free)
+    k_row_ids<<<(int)((nnz + 4095) / 4096), kT, 0, s>>>(nnz, A.off, rows, rowid);
+    k_transpose_finish<<<grid_of(nnz), kT, 0, s>>>(B.v[slot], nnz, rowid, A.val, T.idx, T.val);
+  }
   HIP_TRY(hipGetLastError());
   ar.release(mark);  // (stream order: the next user of the arena is enqueued behind these kernels)
   return 0;
@@ -489,11 +512,25 @@ __global__ void __launch_bounds__(kT) k_group_key(int32_t count, const uint32_t*
   }
 }
 
-// quotient graph of the cells: W[a * K + b] = nonzeros whose row carries label a and whose column carries label b (ids 1 ... K - 1)
+// quotient graph of the cells: W[a * K + b] = nonzeros whose row carries label a and whose column carries label b (ids 1 ... K - 1).
+// A few thousand pairs carry almost all the weight (the cells of one block, neighbours along a band -- or, on a random matrix, the
+// few labels the vote left): every workgroup first adds into a 2048-slot LDS table keyed by the pair, only what collides there and
+// the table's final sums go to global atomics (one hot address was 3 ms of serialised atomics on the 1e6 x 1e6 random LP).
+constexpr int kQuotSlots = 2048;
 __global__ void __launch_bounds__(kT) k_cell_quotient(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                                       const int32_t* __restrict__ label_r, const int32_t* __restrict__ label_c, int32_t K,
                                                       int32_t* __restrict__ W)
 {
+  __shared__ int32_t key[kQuotSlots], val[kQuotSlots];
+  for (int i = threadIdx.x; i < kQuotSlots; i += kT) key[i] = -1, val[i] = 0;
+  __syncthreads();
+  auto add = [&](int32_t a, int32_t b, int32_t run) {
+    const int32_t pair = a * K + b;  // (K <= 4096: fits)
+    const uint32_t h   = ((uint32_t)pair * 2654435761u) >> 21;  // 11 bits
+    const int32_t seen = atomicCAS(&key[h], -1, pair);
+    if (seen == -1 || seen == pair) atomicAdd(&val[h], run);
+    else atomicAdd(&W[(size_t)pair], run);
+  };
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < rows; i += (int64_t)gridDim.x * kT) {
     const int32_t a = label_r[i];
     if (a < 0) continue;
@@ -502,13 +539,16 @@ __global__ void __launch_bounds__(kT) k_cell_quotient(int32_t rows, const int32_
       const int32_t b = label_c[idx[k]];
       if (b < 0) continue;
       if (b != last_b) {
-        if (run) atomicAdd(&W[(size_t)a * K + last_b], run);
+        if (run) add(a, last_b, run);
         last_b = b, run = 0;
       }
       ++run;
     }
-    if (run) atomicAdd(&W[(size_t)a * K + last_b], run);
+    if (run) add(a, last_b, run);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kQuotSlots; i += kT)
+    if (key[i] >= 0 && val[i]) atomicAdd(&W[(size_t)key[i]], val[i]);
 }
 
 __global__ void __launch_bounds__(kT) k_invert_perm(int32_t count, const uint32_t* __restrict__ new2old, int32_t* __restrict__ old2new)
@@ -552,13 +592,138 @@ __global__ void __launch_bounds__(kT) k_sample_fill(int32_t nq, int32_t brows, c
   }
 }
 
+// ---- the jagged layout's sampled cost estimate, on the device -------------------------------------------------------------------
+// One workgroup per sampled row block restates build_jag's estimate (kernels_jag.hip jag_block_end + jag_block_set) exactly: rows are
+// taken in order while the DISTINCT columns they touch fit the LDS window (a row that would overflow ends the block; rows of more than
+// kLongRow entries do not count), then the block's column set is priced -- a contiguous range as one coalesced copy, a list as one
+// request per run of consecutive columns -- against the gathers it serves.  The set is an open-addressing table in LDS (2 x window
+// slots); chunks of 64 rows whose lengths cannot overflow the window whatever they contain are inserted in parallel, the rows near the
+// limit one by one with the host's two-step check (count the new columns first).  Runs need no sort: a column starts a run iff its
+// predecessor is not in the set.  out[2 * sample] = gathers served, out[2 * sample + 1] = cost.
+constexpr int kEstThreads = 1024, kEstChunk = 64;
+constexpr int32_t kEstEmpty = -1;
+
+__device__ __forceinline__ bool est_insert(int32_t* tab, uint32_t mask, int32_t c)
+{
+  uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+  for (;;) {
+    const int32_t seen = atomicCAS(&tab[h], kEstEmpty, c);
+    if (seen == kEstEmpty) return true;
+    if (seen == c) return false;
+    h = (h + 1) & mask;
+  }
+}
+__device__ __forceinline__ bool est_contains(const int32_t* tab, uint32_t mask, int32_t c)
+{
+  uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+  for (;;) {
+    const int32_t seen = tab[h];
+    if (seen == kEstEmpty) return false;
+    if (seen == c) return true;
+    h = (h + 1) & mask;
+  }
+}
+
+__global__ void __launch_bounds__(kEstThreads) k_jag_estimate(int32_t brows, int32_t wcap, const int32_t* __restrict__ first, int32_t rows,
+                                                             const uint32_t* __restrict__ row_new2old, const int32_t* __restrict__ off,
+                                                             const int32_t* __restrict__ idx, const int32_t* __restrict__ col_old2new,
+                                                             long long* __restrict__ out)
+{
+  extern __shared__ int32_t tab[];  // 2 * wcap slots
+  __shared__ int32_t pre[kEstChunk + 1], rowid[kEstChunk];
+  __shared__ int distinct, fresh, stop, lo, hi, runs, parallel;
+  __shared__ long long refs;
+  const uint32_t mask = (uint32_t)(2 * wcap - 1);
+  const int t = threadIdx.x;
+  for (int i = t; i < 2 * wcap; i += kEstThreads) tab[i] = kEstEmpty;
+  if (t == 0) distinct = 0, stop = 0, lo = 0x7fffffff, hi = -1, runs = 0, refs = 0;
+  __syncthreads();
+  const int64_t r0 = first[blockIdx.x];
+  const int64_t r1 = min((int64_t)rows, r0 + brows);
+  auto old_row = [&](int64_t r_new) { return row_new2old ? (int32_t)row_new2old[r_new] : (int32_t)r_new; };
+  auto column  = [&](int32_t k) { const int32_t c = idx[k]; return col_old2new ? col_old2new[c] : c; };
+  for (int64_t c0 = r0; c0 < r1 && !stop; c0 += kEstChunk) {
+    const int nr = (int)min((int64_t)kEstChunk, r1 - c0);
+    if (t < nr) {
+      const int32_t r = old_row(c0 + t);
+      rowid[t]        = r;
+      const int32_t len = off[r + 1] - off[r];
+      pre[t + 1]        = len > kLongRow ? 0 : len;  // (long rows do not count)
+    }
+    if (t == 0) pre[0] = 0;
+    __syncthreads();
+    if (t == 0) {
+      for (int i = 0; i < nr; ++i) pre[i + 1] += pre[i];
+      parallel = distinct + pre[nr] <= wcap;  // (decided by one thread: `distinct` moves while the chunk is inserted)
+    }
+    __syncthreads();
+    const int total = pre[nr];
+    if (parallel) {
+      // no row of the chunk can overflow the window: all entries at once
+      int added = 0;
+      for (int e = t; e < total; e += kEstThreads) {
+        int a = 0, b = nr;  // the row of entry e: largest i with pre[i] <= e
+        while (b - a > 1) {
+          const int mid = (a + b) >> 1;
+          if (pre[mid] <= e) a = mid; else b = mid;
+        }
+        const int32_t c = column(off[rowid[a]] + (e - pre[a]));
+        atomicMin(&lo, c), atomicMax(&hi, c);
+        added += est_insert(tab, mask, c);
+      }
+      if (added) atomicAdd(&distinct, added);
+      if (t == 0) refs += total;
+      __syncthreads();
+    } else {
+      // near the limit: row by row, the host's rule (count the new columns before inserting any)
+      for (int i = 0; i < nr; ++i) {
+        const int len = pre[i + 1] - pre[i];
+        if (len == 0) continue;  // (uniform: pre is shared)
+        const int32_t c = t < len ? column(off[rowid[i]] + t) : 0;
+        if (t == 0) fresh = 0;
+        __syncthreads();
+        const bool check = distinct + len > wcap;  // (`distinct` rests between the barriers around the inserts)
+        if (check && t < len && !est_contains(tab, mask, c)) atomicAdd(&fresh, 1);
+        __syncthreads();
+        if (t == 0 && check && distinct + fresh > wcap) stop = 1;
+        __syncthreads();
+        if (stop) break;
+        if (t < len) {
+          atomicMin(&lo, c), atomicMax(&hi, c);
+          if (est_insert(tab, mask, c)) atomicAdd(&distinct, 1);
+        }
+        if (t == 0) refs += len;
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  long long cost = 0;
+  if (hi >= 0) {
+    if ((long long)hi - lo + 1 <= wcap) {
+      cost = 1 + (hi - lo + 1) / 16;
+    } else {
+      int mine = 0;
+      for (int i = t; i < 2 * wcap; i += kEstThreads) {
+        const int32_t c = tab[i];
+        if (c != kEstEmpty && (c == 0 || !est_contains(tab, mask, c - 1))) ++mine;
+      }
+      if (mine) atomicAdd(&runs, mine);
+      __syncthreads();
+      cost = (long long)runs + distinct / 16;
+    }
+  }
+  if (t == 0) out[2 * blockIdx.x] = refs, out[2 * blockIdx.x + 1] = cost;
+}
+
 // ---- the permuted CSR pair ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kT) k_new_labels(int64_t nnz, const int32_t* __restrict__ off, int32_t rows, const int32_t* __restrict__ idx,
+__global__ void __launch_bounds__(kT) k_new_labels(int64_t nnz, const uint32_t* __restrict__ rowid, const int32_t* __restrict__ idx,
                                                    const int32_t* __restrict__ row_old2new, const int32_t* __restrict__ col_old2new,
                                                    uint32_t* __restrict__ newrow, uint32_t* __restrict__ newcol)
 {
   for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kT) {
-    newrow[k] = (uint32_t)row_old2new[row_of(off, rows, k)];
+    newrow[k] = (uint32_t)row_old2new[rowid[k]];
     newcol[k] = (uint32_t)col_old2new[idx[k]];
   }
 }
@@ -746,6 +911,33 @@ int estimate_saving(pdlpdev_analysis* an, int side, const uint32_t* d_row_new2ol
   const int32_t nq = samples * brows;
   DevArena& ar     = an->arena;
   const size_t mark = ar.mark();
+  if (cuopt_amd::tune_int("estimate_host", 0) == 0) {
+    // on the device: one workgroup per sampled block (k_jag_estimate); 2 x 48 numbers come back
+    int32_t* d_first  = ar.take<int32_t>(samples);
+    long long* d_out  = ar.take<long long>((size_t)2 * samples);
+    if (!d_first || !d_out) return fail(-2, "device set-up: workspace too small for the layout estimate");
+    hipStream_t s = an->stream;
+    const size_t lds = (size_t)2 * wcap * sizeof(int32_t);
+    static std::mutex mu;
+    static std::vector<int> done;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (std::find(done.begin(), done.end(), an->device) == done.end()) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_jag_estimate, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4));
+        done.push_back(an->device);
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(d_first, first.data(), samples * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    k_jag_estimate<<<samples, kEstThreads, lds, s>>>(brows, wcap, d_first, rows, d_row_new2old, M.off, M.idx, d_col_old2new, d_out);
+    std::vector<long long> h((size_t)2 * samples);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    ar.release(mark);
+    long long r = 0, c = 0;
+    for (int t = 0; t < samples; ++t) r += h[2 * t], c += h[2 * t + 1];
+    *saving = r ? 1.0 - (double)c / (double)r : 0.0;
+    return 0;
+  }
   int32_t* d_first = ar.take<int32_t>(samples);
   int32_t* d_lens  = ar.take<int32_t>((size_t)nq + 1);
   int32_t* d_soff  = ar.take<int32_t>((size_t)nq + 1);
@@ -1016,7 +1208,8 @@ static int build_permuted_pair(pdlpdev_analysis* an, const int32_t* d_row_o2n, c
   HIP_TRY(hipMemsetAsync(NA.val + nnz, 0, 8 * sizeof(double), s));
   HIP_TRY(hipMemsetAsync(NT.idx + nnz, 0, 8 * sizeof(int32_t), s));
   HIP_TRY(hipMemsetAsync(NT.val + nnz, 0, 8 * sizeof(double), s));
-  k_new_labels<<<grid_of(nnz), kT, 0, s>>>(nnz, an->A.off, m, an->A.idx, d_row_o2n, d_col_o2n, newrow, newcol);
+  k_row_ids<<<(int)((nnz + 4095) / 4096), kT, 0, s>>>(nnz, an->A.off, m, gkeys);  // (gkeys: free until the first gather)
+  k_new_labels<<<grid_of(nnz), kT, 0, s>>>(nnz, gkeys, an->A.idx, d_row_o2n, d_col_o2n, newrow, newcol);
   const int bits_r = bits_for((uint32_t)std::max(m - 1, 1)), bits_c = bits_for((uint32_t)std::max(n - 1, 1));
   int slot = 0;
   // by new column (source order inside), then stable by new row: (new row, new column) order = P A Q

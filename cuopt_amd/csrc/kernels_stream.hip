@@ -106,14 +106,11 @@ std::vector<int32_t> build_row_blocks(int32_t rows, const int32_t* off)
   rb.push_back(0);
   int32_t start = 0;
   while (start < rows) {
-    int32_t end   = start;
-    int64_t count = 0;
-    while (end < rows && end - start < kMaxRowsPerBlock) {
-      const int64_t len = (int64_t)off[end + 1] - off[end];
-      if (count + len > tile) break;
-      count += len;
-      ++end;
-    }
+    // rows while they fit the tile (at most kMaxRowsPerBlock): the last offset within off[start] + tile -- a search, not a walk
+    // (at 1e6 rows the walk was ~2 ms of the set-up, twice)
+    const int32_t last = (int32_t)std::min<int64_t>(rows, (int64_t)start + kMaxRowsPerBlock);
+    const int64_t lim  = (int64_t)off[start] + tile;
+    int32_t end = (int32_t)(std::upper_bound(off + start, off + last + 1, lim, [](int64_t v, int32_t o) { return v < (int64_t)o; }) - off) - 1;
     if (end == start) end = start + 1;  // long row: alone
     rb.push_back(end);
     start = end;

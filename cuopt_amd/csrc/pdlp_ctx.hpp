@@ -431,6 +431,10 @@ struct pdlpdev_ctx {
   int use_graph = 1;
   bool comm_warm = false;          // one attempt went out eagerly over this communicator (before the first capture)
   bool graph_comm_failed = false;  // capturing the RCCL collectives into an attempt graph failed once: plain launches from then on
+  // one allocation for the ~40 problem / iterate vectors of a large LP (each hipMalloc + memset pair costs ~0.1 ms: 3 ms of a 25 ms
+  // set-up at 1e6 x 1e6); dev_alloc draws from it while it lasts
+  char* slab = nullptr;
+  size_t slab_cap = 0, slab_used = 0;
   char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
   char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
   size_t arena_used = 0;
@@ -492,6 +496,14 @@ inline int dev_alloc(pdlpdev_ctx* c, T** p, size_t count)
     *p = (T*)(c->arena + c->arena_used);
     c->arena_used += need;
     return 0;
+  }
+  {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (c->slab && c->slab_used + need <= c->slab_cap) {
+      *p = (T*)(c->slab + c->slab_used);
+      c->slab_used += need;
+      return 0;
+    }
   }
   static const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();

@@ -1359,9 +1359,14 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   }
   lap("alloc + upload A");
   auto long_rows = [](int32_t rows, const int32_t* off) {
-    std::vector<int32_t> v;
-    for (int32_t r = 0; r < rows; ++r)
-      if (off[r + 1] - off[r] > kLongRow) v.push_back(r);
+    constexpr int kParts = 16;
+    std::vector<int32_t> part[kParts], v;
+    cuopt_amd::parallel_tasks(kParts, [&](int t) {
+      const int32_t a = (int32_t)((int64_t)rows * t / kParts), b = (int32_t)((int64_t)rows * (t + 1) / kParts);
+      for (int32_t r = a; r < b; ++r)
+        if (off[r + 1] - off[r] > kLongRow) part[t].push_back(r);
+    }, (int64_t)rows * 8);
+    for (int t = 0; t < kParts; ++t) v.insert(v.end(), part[t].begin(), part[t].end());
     return v;
   };
   std::vector<int32_t> la = long_rows(m, a_offsets), lat;  // alive until the stream is synchronised at the end
@@ -1411,6 +1416,18 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   std::vector<int32_t> rba = build_row_blocks(m, A_off);
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
+  if ((int64_t)m + n >= 262144) {
+    // the vectors below (24 of n (+ pad), 15 of m entries) out of one zero-filled allocation
+    const size_t bytes = (24 * ((size_t)n + kSlicePad + 32) + 15 * ((size_t)m + 32)) * sizeof(double);
+    if (hipMalloc((void**)&ctx->slab, bytes) == hipSuccess) {
+      ctx->allocs.push_back(ctx->slab);
+      ctx->slab_cap = bytes, ctx->slab_used = 0;
+      HIP_TRY(hipMemsetAsync(ctx->slab, 0, bytes, ctx->stream));
+    } else {
+      ctx->slab = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   // every problem vector crosses PCIe once: the unscaled copy is made on the device, and a bound vector that is one value
   // throughout (all lower bounds 0, all upper bounds +inf: most LPs) is not uploaded at all
   ctx->note_uniform_bounds(lb, ub);
@@ -1447,6 +1464,8 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     TRY(dev_alloc(ctx, &ctx->aty_u[i], n));
   }
   TRY(dev_alloc(ctx, &ctx->rc_scratch, n));
+  const size_t slab_rest = ctx->slab_cap - ctx->slab_used;  // (kept for the n-sized buffers allocated after the layouts)
+  ctx->slab_cap = ctx->slab_used;
   {
     // layout choice: CUOPT_AMD_SPMV_LAYOUT = auto (default) | stream | panel | jag ; CUOPT_AMD_TUNE=slab_bytes=...
     // auto is structural (reproducible): the jagged layout when filling its LDS column sets costs at most half of the gathers
@@ -1652,6 +1671,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   // ... except the panels, whose kernels add the segments themselves (own-row workgroups / the column epilogue): no launch in front
   if (ctx->pa.v.dn_own_seg) ctx->pa.v.dense_add = nullptr;
   if (ctx->pat.v.dn_pan_ptr) ctx->pat.v.dense_add = nullptr;
+  ctx->slab_cap += slab_rest;
   TRY(dev_alloc(ctx, &ctx->part_a, (size_t)8 * std::max({ctx->a_nb, ctx->pba.on ? ctx->pba.v.B : 0, ctx->pa.on ? ctx->pa.v.W : 0, ctx->ja.on ? ctx->ja.v.nblk + ctx->ja.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_at, (size_t)8 * std::max({ctx->at_nb, ctx->pbat.on ? ctx->pbat.v.B : 0, ctx->pat.on ? ctx->pat.v.W : 0, ctx->jat.on ? ctx->jat.v.nblk + ctx->jat.v.nlong : 0, 1})));
   TRY(dev_alloc(ctx, &ctx->part_g, (size_t)8 * 2048));

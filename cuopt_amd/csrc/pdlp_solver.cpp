@@ -934,7 +934,10 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
       } else {
         auto gather = [](const std::vector<int32_t>& new2old, const double* src, std::vector<double>& dst) {
           dst.resize(new2old.size());
-          for (size_t i = 0; i < new2old.size(); ++i) dst[i] = src[new2old[i]];
+          const size_t count = new2old.size(), chunk = (count + 15) / 16;
+          cuopt_amd::parallel_tasks(16, [&](int t) {
+            for (size_t i = (size_t)t * chunk; i < std::min(count, ((size_t)t + 1) * chunk); ++i) dst[i] = src[new2old[i]];
+          }, (int64_t)count * 16);
           return dst.data();
         };
         plp.c = gather(s->col_new2old, c.data(), pc), plp.lb = gather(s->col_new2old, lp->lb, plb), plp.ub = gather(s->col_new2old, lp->ub, pub);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised runner for the round-5 GPU sessions (replaces the per-run scripts of earlier rounds).
 #   scripts/r05_gpu.sh <tag> <step> [<step> ...]      outputs under gpurun_out/<tag>/
-# steps: setup_tests | probe:<workloads,comma separated> | tests:<pytest -k expression or file> | bench:<workload> | prof:<workload> | pmc:<workload>
+# steps: setup_tests | profsetup:<workload> | probe:<workloads,comma separated> | tests:<pytest -k expression or file> | bench:<workload> | prof:<workload> | pmc:<workload>
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -16,6 +16,7 @@ for step in "$@"; do
     probe) timeout 1500 python scripts/r05_setup_probe.py $(echo "$arg" | tr ',' ' ') > "$OUT/probe.log" 2>&1; grep -E "RESULT|RATE|analysis:|ordering:|Traceback|Error" "$OUT/probe.log" | cut -c1-400 ;;
     bench) timeout 900 python bench.py --workload "$arg" > "$OUT/bench_$arg.json" 2> "$OUT/bench_$arg.err"; cut -c1-600 "$OUT/bench_$arg.json" ;;
     prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$arg" -- python "$OLDPWD/bench.py" --workload "$arg" --no-cpu-baseline --no-convergence-run > "$OLDPWD/$OUT/prof_$arg.json" 2> "$OLDPWD/$OUT/prof_$arg.err"); find "$OUT/prof_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 12 ;;
+    profsetup) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/profsetup_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/profsetup_$arg.log" 2>&1); find "$OUT/profsetup_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 45 | cut -c1-200 ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -131,6 +131,19 @@ def test_the_analysis_pass_finds_the_order_and_builds_p_a_q(shuffled_lp):
     an.close(), an2.close()
 
 
+def test_the_estimate_on_the_device_is_the_host_s(shuffled_lp, monkeypatch):
+    """k_jag_estimate restates build_jag's sampled estimate (greedy row blocks, range / list pricing) on the device: the same numbers
+    as the host evaluation of the same samples, for the matrix as given and for the accepted candidate"""
+    kind, q = shuffled_lp
+    infos = []
+    for host in (1, None):
+        set_tune(monkeypatch, estimate_host=host)
+        an = capi.Analysis(q, reorder=True)
+        infos.append(an.info())
+        an.close()
+    assert infos[0] == infos[1], infos
+
+
 def test_a_random_matrix_is_turned_away():
     p = synthetic.generate(262144, 262144, 10, seed=9)
     an = capi.Analysis(p, reorder=True)
