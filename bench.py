@@ -160,9 +160,21 @@ def main():
     else:
         cfg = dict(synthetic.CONFIGS[base])
     t_gen = time.time()
-    p = synthetic.generate_structured(**cfg) if structured else synthetic.generate(**cfg)
-    if shuffle:
-        p = synthetic.shuffled(p, seed=5)
+    # (profiling sessions run the same workload through several rocprofv3 passes: CUOPT_AMD_LP_CACHE=<dir> keeps the generated LP
+    # between them -- the generator is deterministic, the cache only saves its minute of host time)
+    cache = os.environ.get("CUOPT_AMD_LP_CACHE")
+    cache_file = os.path.join(cache, "%s.npz" % args.workload) if cache else None
+    if cache_file and os.path.exists(cache_file):
+        z = np.load(cache_file, allow_pickle=False)
+        p = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+    else:
+        p = synthetic.generate_structured(**cfg) if structured else synthetic.generate(**cfg)
+        if shuffle:
+            p = synthetic.shuffled(p, seed=5)
+            p.pop("shuffle", None)
+        if cache_file and rank == 0:
+            os.makedirs(cache, exist_ok=True)
+            np.savez(cache_file, **{k: v for k, v in p.items() if isinstance(v, (np.ndarray, int, float, bool, np.integer, np.floating))})
     t_gen = time.time() - t_gen
     m, n, nnz = p["m"], p["n"], int(len(p["values"]))
 

@@ -1,10 +1,13 @@
 // Tiny host-side fork/join helper for the O(nnz) setup passes (transpose, panel construction).
 #pragma once
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -59,16 +62,109 @@ inline int host_threads(int cap = 16)
   return std::max(1, std::min(avail, cap));
 }
 
-// fn(task) for task in [0, tasks), statically chunked over the threads
+// A small persistent pool for the set-up's fork/join passes.  Creating and joining 16 std::threads costs 0.3-0.5 ms per parallel
+// region, and a set-up at 1e6 x 1e6 runs a dozen of them (19 ms in all): the workers are created once and sleep on a condition
+// variable between regions.  One region at a time (a second caller -- the A^T side's thread next to the A side's -- runs its tasks
+// on threads of its own, as before the pool existed); the caller takes part in its region.  The workers are never joined (no
+// ordering issues at exit); a forked child starts with a fresh pool.
+class TaskPool {
+ public:
+  static TaskPool& instance()
+  {
+    static TaskPool* pool = new TaskPool();
+    return *pool;
+  }
+  // false: the pool is busy with another region (the caller falls back to threads of its own)
+  template <class F>
+  bool run(int workers_wanted, int tasks, F& fn)
+  {
+    std::unique_lock<std::mutex> region(region_, std::try_to_lock);
+    if (!region.owns_lock()) return false;
+    ensure_workers(workers_wanted - 1);
+    std::function<void(int)> call = [&fn](int t) { fn(t); };
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &call, tasks_ = tasks, next_ = 0, done_ = 0, active_ = std::min<int>((int)threads_.size(), workers_wanted - 1);
+      ++generation_;
+    }
+    cv_work_.notify_all();
+    work(call, tasks);
+    std::unique_lock<std::mutex> lk(m_);
+    job_ = nullptr;  // (no worker joins from here on; those inside hold `call` until they leave)
+    cv_done_.wait(lk, [&] { return done_ == tasks_ && inflight_ == 0; });
+    return true;
+  }
+
+ private:
+  void work(std::function<void(int)>& call, int tasks)
+  {
+    for (;;) {
+      int t;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (next_ >= tasks) return;
+        t = next_++;
+      }
+      call(t);
+      std::lock_guard<std::mutex> lk(m_);
+      if (++done_ == tasks_) cv_done_.notify_all();
+    }
+  }
+  void ensure_workers(int count)
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    while ((int)threads_.size() < count) {
+      const int id = (int)threads_.size();
+      threads_.emplace_back([this, id] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(int)>* call = nullptr;
+          int tasks = 0;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_work_.wait(lk, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (id >= active_ || !job_) continue;
+            call = job_, tasks = tasks_;
+            ++inflight_;
+          }
+          work(*call, tasks);
+          {
+            std::lock_guard<std::mutex> lk(m_);
+            if (--inflight_ == 0) cv_done_.notify_all();
+          }
+        }
+      });
+      threads_.back().detach();
+    }
+  }
+  TaskPool()
+  {
+    pthread_atfork(nullptr, nullptr, [] {
+      // the child has none of the parent's threads: a fresh pool object (the old one's mutexes may be held by threads that do not exist)
+      new (&instance()) TaskPool(0);
+    });
+  }
+  explicit TaskPool(int) {}
+  std::mutex region_, m_;
+  std::condition_variable cv_work_, cv_done_;
+  std::vector<std::thread> threads_;
+  std::function<void(int)>* job_ = nullptr;
+  int tasks_ = 0, next_ = 0, done_ = 0, active_ = 0, inflight_ = 0;
+  uint64_t generation_ = 0;
+};
+
+// fn(task) for task in [0, tasks): dealt to the pool's threads one task at a time (the caller works too)
 template <class F>
 inline void parallel_tasks(int tasks, F&& fn, int64_t work_hint = 1 << 30)
 {
   int nt = std::min(host_threads(), tasks);
-  if (work_hint < (1 << 18)) nt = 1;  // not worth a thread launch
+  if (work_hint < (1 << 18)) nt = 1;  // not worth waking a thread
   if (nt <= 1) {
     for (int t = 0; t < tasks; ++t) fn(t);
     return;
   }
+  if (TaskPool::instance().run(nt, tasks, fn)) return;
   std::vector<std::thread> pool;
   pool.reserve(nt);
   for (int w = 0; w < nt; ++w)

@@ -1051,6 +1051,32 @@ static int find_ordering(pdlpdev_analysis* an, uint32_t** d_row_new2old, uint32_
     if (csz.back() == 0 || level >= rounds_cap) break;
   }
   an->cell_rounds = level;
+  {
+    // The cells as the searches left them: if no two of them belong together already (no pair shares 5 % of the lighter one's
+    // nonzeros), there is no structure for the vote to sharpen -- the uniformly random matrix leaves here.  (After the vote a random
+    // graph WOULD show strong edges: label propagation manufactures communities.)
+    k_cell_label<<<grid_of(m), kT, 0, s>>>(m, cell_r, nullptr, lab_r);
+    k_cell_label<<<grid_of(n), kT, 0, s>>>(n, cell_c, nullptr, lab_c);
+    k_cell_quotient<<<grid_of(m), kT, 0, s>>>(m, an->A.off, an->A.idx, lab_r, lab_c, K, W);
+    std::vector<int32_t> hw0((size_t)K * K);
+    HIP_TRY(hipMemcpyAsync(hw0.data(), W, hw0.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(W, 0, (size_t)K * K * sizeof(int32_t), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int64_t> tot0(K, 0);
+    auto sym0 = [&](int a, int b) { return (int64_t)hw0[(size_t)a * K + b] + (a == b ? 0 : hw0[(size_t)b * K + a]); };
+    for (int a = 1; a < K; ++a)
+      for (int b = 1; b < K; ++b) tot0[a] += a == b ? hw0[(size_t)a * K + a] : sym0(a, b);
+    bool any = false;
+    for (int a = 1; a < K && !any; ++a)
+      for (int b = a + 1; b < K && !any; ++b) {
+        const int64_t w = sym0(a, b);
+        any = w > 0 && w * 20 >= std::min(tot0[a], tot0[b]);
+      }
+    if (!any) {
+      lap("cells");
+      return 0;
+    }
+  }
   // Two sweeps of majority voting at CELL level before the cells are compared: a search that reached a neighbouring block through a
   // linking column first holds a foothold there (a tenth of the rows of a block-angular LP sit in a foreign block's cell, and a cell
   // with footholds in many blocks would glue their groups together); a vertex whose neighbours carry another label almost
@@ -1326,7 +1352,8 @@ int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, co
     const size_t mark = an->arena.mark();
     // the order the matrix came in: nothing to look for when the jagged layout already applies
     TRY(estimate_saving(an, 0, nullptr, nullptr, &an->saving_natural[0]));
-    TRY(estimate_saving(an, 1, nullptr, nullptr, &an->saving_natural[1]));
+    if (an->saving_natural[0] >= 0.35 || !(flags & 1)) TRY(estimate_saving(an, 1, nullptr, nullptr, &an->saving_natural[1]));
+    else an->saving_natural[1] = -2.0;  // (not evaluated: the ordering search runs anyway; create reads "< 0.35" as "no jagged layout")
     an->estimated = true;
     lap("estimate 0");
     int G = 0, waves = 0, wcap = 0, brows = 0;
@@ -1436,6 +1463,68 @@ int pdlpdev_debug_scan(int device, int64_t n, const int32_t* in, int32_t* out)
 }  // extern "C"
 
 // ================================================================================================
+// gather_working_set (kernels_panel.hip) on a device-resident index array: the 128-byte lines of the gathered vector that up to four
+// windows of 512 K consecutive nonzeros touch -- same windows, same count, no index array on the host
+// ================================================================================================
+namespace {
+// one workgroup per window, the bitmap of touched lines in LDS (cols / 16 bits: 7.8 KB at 1e6 columns; a global bitmap with
+// atomicOr serialised on a few thousand words: 1.4 ms per call)
+constexpr int kWsThreads = 1024;
+__global__ void __launch_bounds__(kWsThreads) k_ws_lines(const int32_t* __restrict__ idx, int64_t nnz, int64_t window, int samples, int words,
+                                                         int32_t* __restrict__ lines)
+{
+  extern __shared__ uint32_t bitmap[];
+  __shared__ int total;
+  const int s = blockIdx.x;
+  for (int i = threadIdx.x; i < words; i += kWsThreads) bitmap[i] = 0u;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const int64_t first = samples == 1 ? 0 : (nnz - window) * s / (samples - 1);
+  const int64_t last  = min(nnz, first + window);
+  int mine = 0;
+  for (int64_t k = first + threadIdx.x; k < last; k += kWsThreads) {
+    const uint32_t line = (uint32_t)idx[k] >> 4, bit = 1u << (line & 31u);
+    if (!(atomicOr(&bitmap[line >> 5], bit) & bit)) ++mine;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) lines[s] = total;
+}
+}  // namespace
+
+// returns 1 when the bitmap does not fit a workgroup's LDS (more than ~2e7 columns: the caller counts on the host)
+int gather_working_set_device(pdlpdev_ctx* c, const int32_t* d_idx, int64_t nnz, int32_t cols, int64_t* bytes)
+{
+  *bytes = 0;
+  if (cols <= 0 || nnz <= 0) return 0;
+  const int64_t window = 512 * 1024;
+  const int samples    = nnz <= window ? 1 : (int)std::min<int64_t>(4, (nnz + window - 1) / window);
+  const size_t words   = ((size_t)(cols >> 4) >> 5) + 1;
+  if (words * 4 > 150 * 1024) return 1;
+  int32_t* lines = nullptr;
+  TRY(dev_alloc(c, &lines, (size_t)samples));
+  {
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(done.begin(), done.end(), c->device) == done.end()) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_ws_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      done.push_back(c->device);
+    }
+  }
+  k_ws_lines<<<samples, kWsThreads, words * 4, c->stream>>>(d_idx, nnz, window, samples, (int)words, lines);
+  int32_t h[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h, lines, samples * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int64_t total = 0;
+  for (int s = 0; s < samples; ++s) total += (int64_t)h[s] * 128;
+  *bytes = total / samples;
+  return 0;
+}
+
+// ================================================================================================
 // up to four windows of a device-resident index array (gather_working_set of a matrix the host does not hold)
 // ================================================================================================
 int analysis_fetch_idx_windows(pdlpdev_analysis* an, int transposed, int64_t nnz, std::vector<int32_t>* sparse,
@@ -1472,7 +1561,16 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
   PanelHost h;
   std::vector<char> is_own;
   int64_t own_nnz = 0, own_from = 0;
+  const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto plap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cuopt_amd setup]     panels: %-18s %6.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   if (!panel_plan(&h, rows, cols, h_off, slab_bytes, force, nullptr, &is_own, &own_nnz, &own_from)) return 0;
+  plap("plan");
   const int W = h.W, S = h.S;
   const int64_t nnz = h_off[rows];
   h.nnz = (size_t)(nnz - own_nnz), h.rowptr_size = h.seg ? 0 : (size_t)S * ((size_t)rows + W);
@@ -1485,6 +1583,7 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
   std::vector<int32_t> hc((size_t)W * S);
   HIP_TRY(hipMemcpyAsync(hc.data(), count, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  plap("count");
   h.tile_ptr.resize((size_t)W * S + 1);
   int64_t pos = 0;
   for (size_t i = 0; i < (size_t)W * S; ++i) {
@@ -1501,12 +1600,23 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
       for (int s2 = 0; s2 < S; ++s2) h.rp_base[(size_t)w * S + s2] = rp + (int64_t)s2 * (nr + 1);
     }
   TRY(upload_i32(c, &tile_ptr, h.tile_ptr.data(), h.tile_ptr.size()));
-  TRY(dev_alloc(c, &col, h.nnz));
-  TRY(dev_alloc(c, &dst->perm, h.nnz));
-  TRY(dev_alloc(c, &rowptr, h.rowptr_size));
+  {
+    // columns, permutation, row pointers and values out of ONE allocation (every entry is written by the kernels below / k_permute:
+    // no memset; four hipMalloc + memset pairs of 12-80 MB were ~1.5 ms per side)
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_col = pad((h.nnz + 8) * sizeof(int32_t)), b_rp = pad((h.rowptr_size + 8) * sizeof(uint16_t)), b_val = pad((h.nnz + 8) * sizeof(double));
+    char* block = nullptr;
+    HIP_TRY(hipMalloc((void**)&block, 2 * b_col + b_rp + b_val));
+    c->allocs.push_back(block);
+    c->bytes += (int64_t)(2 * b_col + b_rp + b_val);
+    dst->val  = (double*)block;
+    col       = (int32_t*)(block + b_val);
+    dst->perm = (int32_t*)(block + b_val + b_col);
+    rowptr    = (uint16_t*)(block + b_val + 2 * b_col);
+  }
   TRY(dev_alloc(c, &rp_base, h.rp_base.size()));
   HIP_TRY(hipMemcpyAsync(rp_base, h.rp_base.data(), h.rp_base.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-  TRY(dev_alloc(c, &dst->val, h.nnz));
+  plap("alloc");
   {
     const size_t lds = (size_t)S * (kPanelMaxRows + 1) * sizeof(unsigned short);
     static std::mutex mu;
@@ -1524,6 +1634,7 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));  // (the host vectors die here)
+  plap("place");
   dst->v = PanelView{h.W, h.S, h.any_long ? 1 : 0, row0, tile_ptr, rowptr, rp_base, col, dst->val};
   dst->v.seg = h.seg ? 1 : 0, dst->v.slab_w = h.slab_w;
   dst->nent  = (int64_t)h.nnz;

@@ -348,8 +348,19 @@ struct pdlpdev_ctx {
       if (n <= 0) return;
       const double v0 = v[0];
       if (!(v0 == 0.0 || std::isinf(v0))) return;
-      for (int32_t j = 1; j < n; ++j)
-        if (v[j] != v0) return;
+      // (16 MB of bounds at n = 1e6: the scan runs on the host pool's threads)
+      constexpr int kParts = 16;
+      bool differs[kParts] = {false};
+      cuopt_amd::parallel_tasks(kParts, [&](int t) {
+        const int32_t a = (int32_t)((int64_t)n * t / kParts), b = (int32_t)((int64_t)n * (t + 1) / kParts);
+        for (int32_t j = a; j < b; ++j)
+          if (v[j] != v0) {
+            differs[t] = true;
+            return;
+          }
+      }, (int64_t)n * 4);
+      for (bool d : differs)
+        if (d) return;
       *flag = 1, *value = v0;
     };
     same(lb_host, &ubd.lb_same, &ubd.lb);

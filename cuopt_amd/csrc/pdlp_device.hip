@@ -1377,7 +1377,9 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   g_create_sharded   = 0;
   DenseHost DH;
   std::vector<int32_t> hA_off, hA_idx, hA_perm, hT_off, hT_idx, hT_perm;  // the hot CSRs where they differ from the full ones
+  lap("long rows A");
   if (one_gpu) find_dense_segments(m, n, a_offsets, a_indices, &DH);
+  lap("dense scan");
   if (DH.on) hA_off.swap(DH.s_off), hA_idx.swap(DH.s_idx), hA_perm.swap(DH.s_perm);
   const bool hot_a     = !hA_off.empty();
   const int32_t* A_off = hot_a ? hA_off.data() : a_offsets;
@@ -1414,6 +1416,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   }
   if (DH.on) TRY(dev_alloc(ctx, &ctx->dense.add_m, (size_t)m));
   std::vector<int32_t> rba = build_row_blocks(m, A_off);
+  lap("row blocks A");
   ctx->a_nb = (int)rba.size() / 2 - 1;
   TRY(upload_i32(ctx, &ctx->a_rb, rba.data(), rba.size()));
   if ((int64_t)m + n >= 262144) {
@@ -1430,7 +1433,9 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   }
   // every problem vector crosses PCIe once: the unscaled copy is made on the device, and a bound vector that is one value
   // throughout (all lower bounds 0, all upper bounds +inf: most LPs) is not uploaded at all
+  lap("slab");
   ctx->note_uniform_bounds(lb, ub);
+  lap("uniform bounds");
   auto upload_pair = [&](double** work, double** keep, const double* src, size_t count, bool uniform, double value) -> int {
     TRY(dev_alloc(ctx, work, count));
     TRY(dev_alloc(ctx, keep, count));
@@ -1448,6 +1453,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   TRY(upload_pair(&ctx->ub, &ctx->ub_u, ub, (size_t)n, ctx->ubd.ub_same != 0, ctx->ubd.ub));
   TRY(upload_pair(&ctx->lo, &ctx->lo_u, lo, (size_t)m, false, 0.0));
   TRY(upload_pair(&ctx->hi, &ctx->hi_u, hi, (size_t)m, false, 0.0));
+  lap("vector uploads");
   TRY(dev_alloc(ctx, &ctx->dr, m)); TRY(dev_alloc(ctx, &ctx->dc, n));
   // x, A^T y, xbar, sum_x carry kSlicePad spare entries: the sliced-primal dataflow of a sharded solve all-gathers them in
   // equal slices of a multiple of 16 entries per rank (slice * world may exceed n by up to 16 * 16 - 1)
@@ -1485,14 +1491,30 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     const bool try_jag = mode == "auto" || mode == "jag" || timed;
     // auto, not jagged: panels when the CSR stream kernel's live gather set overflows what an XCD's L2 keeps of it
     const int64_t ws_limit = cuopt_amd::tune_int("panel_ws_bytes", kPanelWorkingSetBytes);
+    int64_t ws_at_device = 0, ws_a_device = -1;  // (counted by the main thread: the A^T side's worker must not allocate from the context)
+    bool ws_at_on_host = false;
+    if (an && (mode == "auto" || timed) && (int64_t)m * 8 > ws_limit) {
+      const int rc = gather_working_set_device(ctx, ctx->at_idx, ctx->nnz, m, &ws_at_device);
+      if (rc < 0) return rc;
+      ws_at_on_host = rc == 1;  // (beyond ~2e7 rows the bitmap leaves the LDS: the four windows come to the host)
+    }
+    if (an && !DH.on && (mode == "auto" || timed) && (int64_t)n * 8 > ws_limit) {
+      const int rc = gather_working_set_device(ctx, ctx->a_idx, ctx->nnz, n, &ws_a_device);
+      if (rc < 0) return rc;
+      if (rc == 1) ws_a_device = -1;
+    }
     auto want_panels = [&](int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, const char* name) {
       if (force) return true;
       if (!timed && (mode != "auto" || (int64_t)cols * 8 <= ws_limit)) return false;
       if (timed && !getenv("CUOPT_AMD_TIMING")) return true;
       int64_t ws = 0;
-      if (idx) {
+      if (idx == A_idx && ws_a_device >= 0) {
+        ws = ws_a_device;  // (same windows, counted on the device)
+      } else if (idx) {
         ws = gather_working_set(rows, cols, off, idx);
-      } else {  // (A^T of an analysed matrix: its indices live on the device; the same four windows are fetched)
+      } else if (!ws_at_on_host) {  // (A^T of an analysed matrix: its indices live on the device; the same four windows were counted there)
+        ws = ws_at_device;
+      } else {
         std::vector<int32_t> sparse;
         std::vector<std::pair<int64_t, int64_t>> windows;
         if (analysis_fetch_idx_windows(an, 1, (int64_t)off[rows], &sparse, &windows) != 0) return false;
@@ -1522,16 +1544,22 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     auto t_idx_host = [&]() -> const int32_t* { return an ? analysis_host_t_idx(an) : at_indices; };
     const bool skip_jag_a  = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[0] < 0.35;
     const bool skip_jag_at = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[1] < 0.35;
-    ts.worker = std::thread([&] {
+    auto at_side = [&] {
+      const auto w0 = std::chrono::steady_clock::now();
+      auto wlap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[cuopt_amd setup]   A^T thread: %-22s at %6.2f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
+      };
       if (transpose_ready) transpose_ready(user);
       if ((int64_t)at_offsets[n] != ctx->nnz) return;  // (reported below)
       lat = long_rows(n, at_offsets);
+      wlap("long rows");
       if (DH.on) {
         strip_transpose(DH, &DH, n, at_offsets, t_idx_host());
         hT_off.swap(DH.st_off), hT_idx.swap(DH.st_idx), hT_perm.swap(DH.st_perm);
       }
       if (!hT_off.empty()) T_off = hT_off.data(), T_idx = hT_idx.data();
       ts.rbt = build_row_blocks(n, T_off);
+      wlap("row blocks");
       if (try_jag && !skip_jag_at) {
         if (!T_idx) T_idx = t_idx_host();
         ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
@@ -1547,7 +1575,12 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
         if (an && !DH.on) ts.want_dev_panels = true;  // (built on the device by the main thread, below)
         else ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
       }
-    });
+      wlap("layouts");
+    };
+    // (an analysed matrix: nothing to wait for and little left to do on the host -- the A^T side runs inline, behind the A side;
+    // a thread of its own took 3 ms to do 0.5 ms of work next to the main thread's HIP calls)
+    const bool at_thread = !an || (try_jag && !skip_jag_at) || DH.on || want_pb(m);  // (host constructions worth a thread)
+    if (at_thread) ts.worker = std::thread(at_side);
     if (try_jag) {
       JagHost ja;
       if (skip_jag_a) ja.saving = an->saving_natural[0];
@@ -1591,7 +1624,8 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       lap("upload panels A");
       HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staged copies have left the host arrays (back to the pool)
     }
-    ts.worker.join();
+    if (!at_thread) at_side();
+    else ts.worker.join();
     lap("wait for the A^T side");
     if ((int64_t)at_offsets[n] != ctx->nnz) return fail(-1, "pdlpdev_create: A and A^T disagree on nnz");
     if (!an) {

@@ -73,6 +73,8 @@ const int32_t* analysis_host_t_idx(pdlpdev_analysis* an); // A^T: nnz
 // up to four windows of the device's index array (gather_working_set of a matrix whose indices live on the device)
 int analysis_fetch_idx_windows(pdlpdev_analysis* an, int transposed, int64_t nnz, std::vector<int32_t>* host_idx_sparse,
                                std::vector<std::pair<int64_t, int64_t>>* windows);
+// gather_working_set on a device-resident index array (same windows, same count)
+int gather_working_set_device(pdlpdev_ctx* c, const int32_t* d_idx, int64_t nnz, int32_t cols, int64_t* bytes);
 // slab-major panels built on the device from a resident CSR; same arrays, bit for bit, as build_panels + upload_panels
 int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, int32_t cols, const int32_t* h_off,
                         const int32_t* d_off, const int32_t* d_idx, const double* d_val, int64_t slab_bytes, bool force);

@@ -8,15 +8,27 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export CUOPT_AMD_LP_CACHE=/tmp/lpcache
 for step in "$@"; do
   kind=${step%%:*}; arg=${step#*:}
   case $kind in
     setup_tests) timeout 1500 python -m pytest tests/test_device_setup_gpu.py -q -m gpu -x > "$OUT/setup_tests.log" 2>&1; tail -n 25 "$OUT/setup_tests.log" ;;
     tests) timeout 2400 python -m pytest $arg -q -m gpu > "$OUT/tests_$(echo "$arg" | tr -c 'A-Za-z0-9' _).log" 2>&1; tail -n 15 "$OUT"/tests_*.log ;;
     probe) timeout 1500 python scripts/r05_setup_probe.py $(echo "$arg" | tr ',' ' ') > "$OUT/probe.log" 2>&1; grep -E "RESULT|RATE|analysis:|ordering:|Traceback|Error" "$OUT/probe.log" | cut -c1-400 ;;
-    bench) timeout 900 python bench.py --workload "$arg" > "$OUT/bench_$arg.json" 2> "$OUT/bench_$arg.err"; cut -c1-600 "$OUT/bench_$arg.json" ;;
-    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$arg" -- python "$OLDPWD/bench.py" --workload "$arg" --no-cpu-baseline --no-convergence-run > "$OLDPWD/$OUT/prof_$arg.json" 2> "$OLDPWD/$OUT/prof_$arg.err"); find "$OUT/prof_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 12 ;;
+    bench) timeout 900 python bench.py --workload "$arg" > "$OUT/bench_$arg.json" 2> "$OUT/bench_$arg.err"; cut -c1-700 "$OUT/bench_$arg.json" ;;
+    benchfast) timeout 900 python bench.py --workload "$arg" --no-cpu-baseline > "$OUT/bench_$arg.json" 2> "$OUT/bench_$arg.err"; cut -c1-700 "$OUT/bench_$arg.json" ;;
+    prof) R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof_$arg" -- bash -c "cd $R && python bench.py --workload $arg --no-cpu-baseline --no-convergence-run --steps 400 --warmup 80 --min-seconds 0.2" > "$R/$OUT/prof_$arg.json" 2> "$R/$OUT/prof_$arg.err")
+          F=$(find "$OUT/prof_$arg" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/r05_bench_${arg}_kernel_stats.csv" && head -n 8 "$F" | cut -c1-160; rm -rf "$OUT/prof_$arg" ;;
+    pmc) R=$PWD; i=0
+         for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS"; do
+           i=$((i+1))
+           (cd /tmp && timeout -k 5 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/${arg}_pmc_$i" -- bash -c "cd $R && python bench.py --workload $arg --no-cpu-baseline --no-convergence-run --steps 200 --warmup 40 --min-seconds 0.05" > "$R/$OUT/${arg}_pmc_$i.log" 2>&1)
+         done
+         python scripts/pmc_summary.py "$OUT/r05_pmc_$arg.json" "$OUT/${arg}_pmc_1" "$OUT/${arg}_pmc_2" "$OUT/${arg}_pmc_3" "$OUT/${arg}_pmc_4" > "$OUT/r05_pmc_${arg}_summary.txt"
+         grep -E "traffic MB|FETCH_SIZE|WRITE_SIZE" "$OUT/r05_pmc_${arg}_summary.txt" | head -12 | cut -c1-120
+         rm -rf "$OUT/${arg}"_pmc_? ;;
     profsetup) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/profsetup_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/profsetup_$arg.log" 2>&1); find "$OUT/profsetup_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 45 | cut -c1-200 ;;
+    apitrace) (cd /tmp && timeout 900 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace -d "$OLDPWD/$OUT/apitrace_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/apitrace_$arg.log" 2>&1); ls -la "$OUT/apitrace_$arg"/* | head ;;
     *) echo "unknown step $step" ;;
   esac
 done
