@@ -286,6 +286,7 @@ _proto("cuoptamd_dual_simplex", c_int, c_void_p, c_double, c_int, c_void_p, c_vo
 _proto("cuoptamd_dual_simplex_from", c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("pdlpdev_shard_dataflow", c_int, c_void_p)
 _proto("pdlpdev_shard_transport", c_int, c_void_p)
+_proto("pdlpdev_shard_wire_bytes", c_int, c_void_p, c_void_p)
 _proto("pdlpdev_dense_info", c_int, c_void_p, c_void_p)
 _proto("pdlpdev_layout_info", c_int, c_void_p, c_void_p)
 # device-side set-up (round 5)
@@ -945,6 +946,12 @@ class Device:
                     d["row_sums"] = "by_nonzero" if out[6 + k // 3] else "by_row"  # by_nonzero: the long-tail variant (every row at rtol)
             return d
         return dict(A=side(0), At=side(3), resident=bool(out[0] == 2))
+
+    def wire_bytes(self):
+        """sharded solve, owner-computes dataflow: bytes this rank receives per attempt for the two vector exchanges"""
+        out = np.zeros(3, np.int64)
+        self._ck(lib.pdlpdev_shard_wire_bytes(self.handle, _ptr(out)))
+        return dict(halo=bool(out[0]), bytes=int(out[1]), bytes_allgather=int(out[2]))
 
     def layout_checksums(self):
         """FNV-1a of A^T and of every panel / jagged layout array on the device (parity of the device-side set-up)"""

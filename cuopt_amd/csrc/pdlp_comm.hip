@@ -169,6 +169,87 @@ int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op)
 }
 
 
+// ---- halo exchange (pdlp_ctx.hpp Halo) -------------------------------------------------------------------------------------------
+// need[q * 4 + {0, 1}]: the columns [lo, hi) of rank q's slice that this rank's rows reference; need[q * 4 + {2, 3}]: the positions
+// [lo, hi) of rank q's rows in the gathered dual that this rank's columns reference (empty: lo >= hi).  Every rank learns the whole
+// table (one all-gather of 4 * world numbers per rank), so that it knows what to send, and all ranks take the same decision.
+int halo_setup(pdlpdev_ctx* ctx, const int32_t* need)
+{
+  const int W = ctx->world, me = ctx->rank;
+  pdlpdev_ctx::Halo& H = ctx->halo;
+  H.on = false;
+  const size_t per = (size_t)4 * W;
+  double* wire = nullptr;
+  TRY(dev_alloc(ctx, &wire, per * W + 16));
+  std::vector<double> mine(per), all(per * W);
+  for (size_t i = 0; i < per; ++i) mine[i] = (double)need[i];
+  HIP_TRY(hipMemcpyAsync(wire + (size_t)me * per, mine.data(), per * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TRY(all_gather(ctx, wire, per));
+  HIP_TRY(hipMemcpyAsync(all.data(), wire, per * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  auto range = [&](int r, int q, int kind, int32_t* off, int32_t* cnt) {  // what rank r needs from rank q
+    const int32_t lo = (int32_t)all[(size_t)r * per + (size_t)q * 4 + 2 * kind], hi = (int32_t)all[(size_t)r * per + (size_t)q * 4 + 2 * kind + 1];
+    *off = lo, *cnt = r != q && hi > lo ? hi - lo : 0;
+  };
+  int64_t worst = 0;  // the largest volume any rank receives per attempt (entries)
+  for (int r = 0; r < W; ++r) {
+    int64_t v = 0;
+    for (int q = 0; q < W; ++q)
+      for (int kind = 0; kind < 2; ++kind) {
+        int32_t off, cnt;
+        range(r, q, kind, &off, &cnt);
+        v += cnt;
+      }
+    worst = std::max(worst, v);
+  }
+  const int64_t full = (int64_t)(W - 1) * ((int64_t)ctx->slice + ctx->ypad);
+  H.bytes_allgather  = 8 * full;
+  const long long want = cuopt_amd::tune_int("shard_halo", -1);
+  const bool use = W > 1 && !ctx->p2p.on && want != 0 && (want == 1 || worst * 4 <= full);
+  if (!ctx->soft && use && (!rccl::Send || !rccl::Recv || !rccl::GroupStart || !rccl::GroupEnd)) return fail(-3, "RCCL: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd missing");
+  for (int kind = 0; kind < 2; ++kind) {
+    H.recv_off[kind].assign(W, 0), H.recv_cnt[kind].assign(W, 0), H.send_off[kind].assign(W, 0), H.send_cnt[kind].assign(W, 0);
+    for (int q = 0; q < W; ++q) {
+      range(me, q, kind, &H.recv_off[kind][q], &H.recv_cnt[kind][q]);
+      range(q, me, kind, &H.send_off[kind][q], &H.send_cnt[kind][q]);
+    }
+  }
+  H.bytes = 0;
+  for (int kind = 0; kind < 2; ++kind)
+    for (int q = 0; q < W; ++q) H.bytes += 8 * (int64_t)H.recv_cnt[kind][q];
+  H.on = use;
+  if (getenv("CUOPT_AMD_TIMING"))
+    fprintf(stderr, "[cuopt_amd setup]   rank %d: halo %s: %lld B per attempt against %lld B for the two all-gathers\n", me, use ? "on" : "off", (long long)H.bytes,
+            (long long)H.bytes_allgather);
+  return 0;
+}
+
+// the ranges of `buf` (kind 0: xbar, kind 1: the gathered y') this rank needs arrive from their owners, the ranges others need leave
+int halo_exchange(pdlpdev_ctx* ctx, int kind, double* buf)
+{
+  const pdlpdev_ctx::Halo& H = ctx->halo;
+  const int W = ctx->world, me = ctx->rank;
+  if (ctx->soft) {
+    softcomm::Comm* c = ctx->soft;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // my part is complete
+    c->bufs[me] = buf;
+    SOFT_BARRIER(c);
+    for (int q = 0; q < W; ++q)
+      if (H.recv_cnt[kind][q] > 0)  // (the peers' buffers share this one's geometry: the same offsets)
+        HIP_TRY(hipMemcpyAsync(buf + H.recv_off[kind][q], c->bufs[q] + H.recv_off[kind][q], (size_t)H.recv_cnt[kind][q] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SOFT_BARRIER(c);  // nobody still reads my part
+    return 0;
+  }
+  RCCL_TRY(rccl::GroupStart());
+  for (int q = 0; q < W; ++q) {
+    if (H.send_cnt[kind][q] > 0) RCCL_TRY(rccl::Send(buf + H.send_off[kind][q], (size_t)H.send_cnt[kind][q], rccl::kFloat64, q, ctx->comm, ctx->stream));
+    if (H.recv_cnt[kind][q] > 0) RCCL_TRY(rccl::Recv(buf + H.recv_off[kind][q], (size_t)H.recv_cnt[kind][q], rccl::kFloat64, q, ctx->comm, ctx->stream));
+  }
+  RCCL_TRY(rccl::GroupEnd());
+  return 0;
+}
+
 // Direct peer transport: allocate this rank's landing block and learn where the other ranks' blocks are.
 //   in-process communicator: the ranks are contexts of one process (tests: on ONE device) -> a table in the communicator;
 //   RCCL: one 128-byte record per rank {IPC handle, process id, pointer, device} all-gathered through the communicator:

@@ -68,6 +68,10 @@ inline int (*CommAbort)(comm_t);
 inline int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
 inline int (*ReduceScatter)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
 inline int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t);
+inline int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t);  // halo exchange of a sharded structured LP
+inline int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t);
+inline int (*GroupStart)();
+inline int (*GroupEnd)();
 inline const char* (*GetErrorString)(int);
 inline std::mutex load_mutex;
 inline int load()
@@ -87,6 +91,10 @@ inline int load()
   *(void**)&AllReduce      = dlsym(lib, "ncclAllReduce");
   *(void**)&ReduceScatter  = dlsym(lib, "ncclReduceScatter");
   *(void**)&AllGather      = dlsym(lib, "ncclAllGather");
+  *(void**)&Send           = dlsym(lib, "ncclSend");
+  *(void**)&Recv           = dlsym(lib, "ncclRecv");
+  *(void**)&GroupStart     = dlsym(lib, "ncclGroupStart");
+  *(void**)&GroupEnd       = dlsym(lib, "ncclGroupEnd");
   *(void**)&GetErrorString = dlsym(lib, "ncclGetErrorString");
   if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce)
     return fail(-3, "RCCL symbols missing");
@@ -413,6 +421,19 @@ struct pdlpdev_ctx {
   Panels poc;
   Jag joc;
   double* part_oc = nullptr;
+  // HALO exchange of the owner-computes dataflow (round 5).  A rank's rows touch only the columns of its own slice plus, on a
+  // structured LP (a band, a staircase -- as given or as the set-up's reordering found it), a few thousand columns at the edges of
+  // its neighbours' slices; its columns likewise touch its own rows plus the edges of the neighbours' row blocks.  Then the two
+  // all-gathers of an attempt (7/8 of n + m doubles received per rank at 8 ranks) shrink to neighbour messages of the ranges
+  // actually referenced: per peer ONE contiguous range of xbar (global column numbers) and one of the gathered y' -- kilobytes.
+  // Decided at pdlpdev_owner_setup from the matrices themselves (every rank learns every rank's needs through one all-gather of
+  // the range table); used when the ranges sum to at most a quarter of the all-gathers' volume (CUOPT_AMD_TUNE=shard_halo=0|1
+  // forces it off / on).  Values are the same doubles either way: iterates are bit-identical to the all-gather's.
+  struct Halo {
+    bool on = false;
+    std::vector<int32_t> recv_off[2], recv_cnt[2], send_off[2], send_cnt[2];  // [kind 0 xbar | kind 1 y'][peer]: offsets into the buffer
+    int64_t bytes = 0, bytes_allgather = 0;  // received per attempt by this rank: the halo's ranges / the two all-gathers
+  } halo;
   // direct peer transport of the owner-computes dataflow (CUOPT_AMD_SHARD_TRANSPORT=p2p): every rank owns one fine-grained
   // LANDING block [xbar of all ranks | y' of all ranks | 4 step-size scalars per rank | 3 * world epoch flags]; a producer
   // stores its slice into every rank's block (peer-mapped: same process -> the pointer itself after
@@ -547,3 +568,5 @@ int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t co
 int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count);
 int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op);
 int p2p_setup(pdlpdev_ctx* ctx);
+int halo_setup(pdlpdev_ctx* ctx, const int32_t* need /* [world][4]: xbar lo, hi (columns), y' lo, hi (positions in ygather) */);
+int halo_exchange(pdlpdev_ctx* ctx, int kind, double* buf);

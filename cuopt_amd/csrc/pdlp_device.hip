@@ -1228,6 +1228,23 @@ static int sync_panel_values(pdlpdev_ctx* c)
 }
 
 
+// per slice of the gathered vector: the smallest and largest index this matrix references there (halo exchange, pdlp_ctx.hpp Halo)
+__global__ void __launch_bounds__(kBlock) k_slice_ranges(int64_t nnz, const int32_t* __restrict__ idx, int32_t slice, int world,
+                                                         int32_t* __restrict__ lo, int32_t* __restrict__ hi)
+{
+  __shared__ int32_t slo[16], shi[16];
+  if (threadIdx.x < 16) slo[threadIdx.x] = 0x7fffffff, shi[threadIdx.x] = -1;
+  __syncthreads();
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kBlock) {
+    const int32_t j = idx[k];
+    const int q     = min(j / slice, world - 1);
+    if (j < slo[q]) atomicMin(&slo[q], j);
+    if (j > shi[q]) atomicMax(&shi[q], j);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < world && shi[threadIdx.x] >= 0) atomicMin(&lo[threadIdx.x], slo[threadIdx.x]), atomicMax(&hi[threadIdx.x], shi[threadIdx.x]);
+}
+
 static thread_local int g_create_sharded = 0;  // pdlpdev_create_hint: the next context will run behind a communicator
 
 static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
@@ -1839,6 +1856,32 @@ int pdlpdev_owner_setup(pdlpdev_ctx* ctx, const int32_t* off, const int32_t* idx
   if (ctx->poc.on) k_permute<<<grid_for(ctx->poc.nent), kBlock, 0, s>>>(ctx->poc.nent, ctx->poc.perm, ctx->oc_val, ctx->poc.val);
   if (ctx->joc.on) k_permute<<<grid_for(ctx->joc.nent), kBlock, 0, s>>>(ctx->joc.nent, ctx->joc.perm, ctx->oc_val, ctx->joc.val);
   HIP_TRY(hipGetLastError());
+  {
+    // what this rank references outside its own slice / rows: per peer one range of xbar (the rank's rows of A, on the device) and
+    // one of the gathered y' (the column block, here on the host)
+    const int W = ctx->world;
+    std::vector<int32_t> need((size_t)4 * W, 0), xl(W, 0x7fffffff), xh(W, -1);
+    int32_t *d_lo = nullptr, *d_hi = nullptr;
+    TRY(dev_alloc(ctx, &d_lo, 16));
+    TRY(dev_alloc(ctx, &d_hi, 16));
+    HIP_TRY(hipMemcpyAsync(d_lo, xl.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_hi, xh.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (ctx->nnz > 0) k_slice_ranges<<<grid_for(ctx->nnz, 8), kBlock, 0, s>>>(ctx->nnz, ctx->a_idx, ctx->slice, W, d_lo, d_hi);
+    HIP_TRY(hipMemcpyAsync(xl.data(), d_lo, W * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(xh.data(), d_hi, W * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int32_t> yl(W, 0x7fffffff), yh(W, -1);
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int32_t pos = ridx[(size_t)k];
+      const int q       = pos / ctx->ypad;
+      yl[q] = std::min(yl[q], pos), yh[q] = std::max(yh[q], pos);
+    }
+    for (int q = 0; q < W; ++q) {
+      need[(size_t)4 * q + 0] = xh[q] >= 0 ? xl[q] : 0, need[(size_t)4 * q + 1] = xh[q] >= 0 ? xh[q] + 1 : 0;
+      need[(size_t)4 * q + 2] = yh[q] >= 0 ? yl[q] : 0, need[(size_t)4 * q + 3] = yh[q] >= 0 ? yh[q] + 1 : 0;
+    }
+    TRY(halo_setup(ctx, need.data()));
+  }
   HIP_TRY(hipStreamSynchronize(s));  // the host arrays are the caller's
   return 0;
 }
@@ -2379,10 +2422,12 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
       LAUNCH_CHECK();
       return 0;
     }
-    TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
+    if (ctx->halo.on) TRY(halo_exchange(ctx, 0, ctx->xbar));  // (a structured LP: the ranges the rows reference, from their owners)
+    else TRY(all_gather(ctx, ctx->xbar, (size_t)ctx->slice));
     launch_a_dual(ctx, ctx->ygather + (size_t)ctx->rank * ctx->ypad);
     LAUNCH_CHECK();
-    TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
+    if (ctx->halo.on) TRY(halo_exchange(ctx, 1, ctx->ygather));
+    else TRY(all_gather(ctx, ctx->ygather, (size_t)ctx->ypad));
     launch_oc_step(ctx);
     launch_k(ctx, k_pack_step_sums, 1, kBlock, 0, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx), ctx->rs_scal);
     LAUNCH_CHECK();
@@ -3149,6 +3194,11 @@ int pdlpdev_synchronize(pdlpdev_ctx* ctx)
 int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx) { return ctx->bytes; }
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx) { return !ctx->comm ? 0 : ctx->owner ? 3 : ctx->rsag ? 2 : 1; }
 int pdlpdev_shard_transport(pdlpdev_ctx* ctx) { return ctx->p2p.on ? 1 : 0; }
+int pdlpdev_shard_wire_bytes(pdlpdev_ctx* ctx, int64_t out[3])
+{
+  out[0] = ctx->halo.on ? 1 : 0, out[1] = ctx->halo.on ? ctx->halo.bytes : ctx->halo.bytes_allgather, out[2] = ctx->halo.bytes_allgather;
+  return 0;
+}
 int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3])
 {
   out[0] = ctx->dense.on ? 1 : 0, out[1] = ctx->dense.nseg, out[2] = ctx->dense.nent;

@@ -358,6 +358,12 @@ int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3]);
  * (CUOPT_AMD_SHARD_TRANSPORT=p2p; peers of the same process are addressed directly, other processes through HIP IPC handles
  * exchanged over the communicator) */
 int pdlpdev_shard_transport(pdlpdev_ctx* ctx);
+/* owner-computes dataflow, bytes this rank RECEIVES per attempt for the two vector exchanges: out = {halo exchange in use, bytes with
+ * the exchange in use, bytes of the two all-gathers}.  Halo exchange (round 5): on a structured LP a rank's rows reference, outside
+ * its own slice of xbar, only a few thousand columns at the edges of its neighbours' slices (likewise its columns and y'): per peer
+ * ONE contiguous range travels (ncclSend / ncclRecv in a group, or the in-process communicator's copies) instead of the all-gather;
+ * chosen at pdlpdev_owner_setup when the ranges sum to at most a quarter of the all-gathers (CUOPT_AMD_TUNE=shard_halo=0|1). */
+int pdlpdev_shard_wire_bytes(pdlpdev_ctx* ctx, int64_t out[3]);
 /* owner-computes dataflow: the columns [*col_begin, *col_begin + *ncols) of A this rank owns ... */
 int pdlpdev_owner_slice(pdlpdev_ctx* ctx, int32_t* col_begin, int32_t* ncols);
 /* ... and their nonzeros over ALL rows of A: rows [col_begin, col_begin + ncols) of the global A^T as CSR (indices = global
