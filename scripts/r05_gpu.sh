@@ -29,6 +29,27 @@ for step in "$@"; do
          rm -rf "$OUT/${arg}"_pmc_? ;;
     profsetup) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/profsetup_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/profsetup_$arg.log" 2>&1); find "$OUT/profsetup_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 45 | cut -c1-200 ;;
     apitrace) (cd /tmp && timeout 900 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace -d "$OLDPWD/$OUT/apitrace_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/apitrace_$arg.log" 2>&1); ls -la "$OUT/apitrace_$arg"/* | head ;;
+    yardstick) python scripts/r05_dump_csr.py "$arg" /tmp/csr_$arg > "$OUT/yardstick_$arg.log" 2>&1
+               /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-deprecated-declarations tools/rocsparse_yardstick.cpp -lrocsparse -o /tmp/rocsparse_yardstick >> "$OUT/yardstick_$arg.log" 2>&1
+               for alg in default csr_rowsplit; do timeout 60 /tmp/rocsparse_yardstick /tmp/csr_$arg $alg >> "$OUT/r05_rocsparse_yardstick_$arg.txt" 2>&1; done; cat "$OUT/r05_rocsparse_yardstick_$arg.txt" ;;
+    gatherprobe) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/gather_probe.hip -o /tmp/gather_probe > "$OUT/gather_probe_build.log" 2>&1
+               timeout 600 /tmp/gather_probe planes > "$OUT/r05_gather_planes.txt" 2>&1; cat "$OUT/r05_gather_planes.txt"
+               R=$PWD; (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/$OUT/gcal_fetch" -- /tmp/gather_probe calibrate > "$R/$OUT/r05_gather_calibration.txt" 2>&1)
+               (cd /tmp && timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$R/$OUT/gcal_req" -- /tmp/gather_probe calibrate > /dev/null 2>&1)
+               python - "$OUT" >> "$OUT/r05_gather_calibration.txt" <<'PYEOF'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("gcal_fetch", "gcal_req"):
+    for f in glob.glob("%s/%s/*/*_counter_collection.csv" % (out, d)):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("counters per launch, in launch order (3 launches per configuration: strides 64 / 128 / 256 B, then the 512 MB stream):")
+for k, cs in acc.items():
+    for c, v in cs.items():
+        print("  %-18s %-24s %s" % (k, c, " ".join("%.0f" % x for x in v)))
+PYEOF
+               cat "$OUT/r05_gather_calibration.txt"; rm -rf "$OUT/gcal_fetch" "$OUT/gcal_req" ;;
     *) echo "unknown step $step" ;;
   esac
 done

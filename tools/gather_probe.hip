@@ -1,0 +1,119 @@
+// Two questions the round-4 review left open about the gather that bounds the unstructured SpMV, in one harness:
+//
+// (1) CALIBRATION of rocprofv3's FETCH_SIZE for scattered 8-byte reads.  The guide's rule (FETCH_SIZE x 2) is calibrated on wide
+//     coalesced streams; the 1.47x "wasted traffic" of k_panel_a_dual rests on applying it to gather misses.  Kernels with a KNOWN
+//     miss count: G gathers of 8 bytes, one per `stride` bytes of a buffer far larger than L2 + Infinity Cache (every line is touched
+//     once per launch and cannot survive to the next), next to a coalesced stream of known size.  Run under
+//       rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- /tmp/gather_probe calibrate
+//     and read FETCH_SIZE per gather: 64 B at strides >= 128 and 32 B at stride 64 means the fabric moves whole 128-byte lines that the
+//     counter tallies at 64 (the stream's factor holds for gathers); 64 B at stride 64 too would mean 64-byte sectors are fetched on
+//     their own and the x2 overstates the gather share.
+//
+// (2) The vector-side idea DESIGN 9.2 listed last: the gathered fp64 vector as two fp32 PLANES (hi = (float)x, lo = (float)(x - hi)),
+//     so that an L2-resident slab holds twice the columns.  (The sum hi + lo carries 48 of the 53 mantissa bits: NOT exact -- it
+//     would break the bit-exact contract of the short-row sums -- so it would have to win clearly.)  `planes` times, over the same
+//     1e7 random indices: one 8-byte gather per nonzero inside windows of W bytes of an fp64 vector, against TWO 4-byte gathers (hi
+//     and lo planes, windows of W / 2 bytes each: the same columns in half the bytes per plane).
+//   hipcc -O3 --offload-arch=gfx950 tools/gather_probe.hip -o /tmp/gather_probe && /tmp/gather_probe planes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#define OK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { std::printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+__global__ void __launch_bounds__(256) k_gather_stride(const double* __restrict__ v, long long gathers, long long stride_doubles, double* __restrict__ out)
+{
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < gathers; i += (long long)gridDim.x * 256) acc += v[i * stride_doubles];
+  if (acc == 123.456) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_stream(const double4* __restrict__ v, long long quads, double* __restrict__ out)
+{
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long long)gridDim.x * 256) {
+    const double4 q = v[i];
+    acc += q.x + q.y + q.z + q.w;
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+// one 8-byte gather per index / two 4-byte gathers per index (hi and lo planes); idx[k] is a column inside the window of its slab
+__global__ void __launch_bounds__(256) k_gather64(const int* __restrict__ idx, long long n, const double* __restrict__ v, double* __restrict__ out)
+{
+  double acc = 0.0;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) acc += v[__builtin_nontemporal_load(idx + k)];
+  if (acc == 123.456) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_gather32x2(const int* __restrict__ idx, long long n, const float* __restrict__ hi, const float* __restrict__ lo, double* __restrict__ out)
+{
+  double acc = 0.0;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+    const int j = __builtin_nontemporal_load(idx + k);
+    acc += (double)hi[j] + (double)lo[j];
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
+static float time_ms(hipStream_t s, hipEvent_t e0, hipEvent_t e1) { float ms = 0; (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); (void)s; return ms; }
+
+int main(int argc, char** argv)
+{
+  const bool calibrate = argc > 1 && !std::strcmp(argv[1], "calibrate");
+  hipStream_t s; OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
+  double* out; OK(hipMalloc((void**)&out, 64));
+  if (calibrate) {
+    const long long G = 8000000;             // gathers per launch
+    const size_t bytes = (size_t)G * 256 + 4096;  // 2 GB: stride up to 256 B, far beyond L2 (32 MiB) + Infinity Cache (256 MiB)
+    double* buf; OK(hipMalloc((void**)&buf, bytes)); OK(hipMemset(buf, 0, bytes));
+    std::printf("calibration kernels (read their FETCH_SIZE from the rocprofv3 counter table):\n");
+    for (long long stride : {64LL, 128LL, 256LL}) {
+      for (int rep = 0; rep < 3; ++rep) {
+        OK(hipEventRecord(e0, s));
+        k_gather_stride<<<4096, 256, 0, s>>>(buf, G, stride / 8, out);
+        OK(hipEventRecord(e1, s));
+        const float ms = time_ms(s, e0, e1);
+        if (rep == 2) std::printf("  k_gather_stride  stride %4lld B: %lld gathers of 8 B, %.1f us  (expected: one missed line each)\n", stride, G, 1e3 * ms);
+      }
+    }
+    const long long quads = (long long)(512ull << 20) / 32;  // a 512 MB coalesced stream: FETCH_SIZE should read 256 MB
+    for (int rep = 0; rep < 3; ++rep) {
+      OK(hipEventRecord(e0, s));
+      k_stream<<<4096, 256, 0, s>>>((const double4*)buf, quads, out);
+      OK(hipEventRecord(e1, s));
+      const float ms = time_ms(s, e0, e1);
+      if (rep == 2) std::printf("  k_stream         512 MB coalesced (32 B per lane), %.1f us = %.2f TB/s\n", 1e3 * ms, 512.0 / 1024 / 1024 * 1.048576 / (ms * 1e-3) / 1e6 * 1e6 / 1e6);
+    }
+    return 0;
+  }
+  // ---- planes: 1e7 random gathers, slab by slab as the panel layout orders them
+  const long long nnz = 10000000;
+  const int n = 1000000;
+  std::printf("%-34s %12s %12s %12s\n", "window of the gathered vector", "fp64 8 B us", "2 x fp32 us", "ratio");
+  for (int window_cols : {4096, 65536, 174763, 349526, 1000000}) {  // 32 KiB (L1), 512 KiB, 1.33 MiB (the slab), 2.67 MiB, the whole vector
+    std::vector<int> h((size_t)nnz);
+    unsigned long long state = 88172645463325252ull;
+    const int slabs = (n + window_cols - 1) / window_cols;
+    for (long long k = 0; k < nnz; ++k) {
+      state ^= state << 13, state ^= state >> 7, state ^= state << 17;
+      const int slab = (int)(k * slabs / nnz);  // entries walk the slabs in order, random inside a slab
+      const int lo = slab * window_cols, width = std::min(window_cols, n - lo);
+      h[(size_t)k] = lo + (int)(state % (unsigned long long)width);
+    }
+    int* idx; double* v; float *hi, *lo;
+    OK(hipMalloc((void**)&idx, (size_t)nnz * 4)); OK(hipMalloc((void**)&v, (size_t)n * 8)); OK(hipMalloc((void**)&hi, (size_t)n * 4)); OK(hipMalloc((void**)&lo, (size_t)n * 4));
+    OK(hipMemcpy(idx, h.data(), (size_t)nnz * 4, hipMemcpyHostToDevice)); OK(hipMemset(v, 0, (size_t)n * 8)); OK(hipMemset(hi, 0, (size_t)n * 4)); OK(hipMemset(lo, 0, (size_t)n * 4));
+    float t64 = 0, t32 = 0;
+    for (int rep = -2; rep < 10; ++rep) {
+      OK(hipEventRecord(e0, s)); k_gather64<<<2048, 256, 0, s>>>(idx, nnz, v, out); OK(hipEventRecord(e1, s));
+      float a = time_ms(s, e0, e1);
+      OK(hipEventRecord(e0, s)); k_gather32x2<<<2048, 256, 0, s>>>(idx, nnz, hi, lo, out); OK(hipEventRecord(e1, s));
+      float b = time_ms(s, e0, e1);
+      if (rep >= 0) t64 += a, t32 += b;
+    }
+    char name[64];
+    std::snprintf(name, sizeof(name), "%d columns (%.2f MiB of fp64)", window_cols, window_cols * 8.0 / 1048576.0);
+    std::printf("%-34s %12.1f %12.1f %12.2f\n", name, 100.0 * t64, 100.0 * t32, t32 / t64);
+    (void)hipFree(idx); (void)hipFree(v); (void)hipFree(hi); (void)hipFree(lo);
+  }
+  return 0;
+}
