@@ -61,8 +61,8 @@ struct Settings {
   int32_t iteration_limit = INT_MAX, pdlp_solver_mode = CUOPT_PDLP_SOLVER_MODE_STABLE2,
           method = CUOPT_METHOD_CONCURRENT, num_cpu_threads = -1;
   // extensions of this library (not in the reference's registry): row blocks / GPUs of one solve (0 = the
-  // CUOPT_AMD_NUM_GPUS environment variable, default 1) and the simplex-grade emulation switch (-1 = the
-  // CUOPT_AMD_SIMPLEX_GRADE environment variable, default on)
+  // CUOPT_AMD_NUM_GPUS environment variable, default 1) and the simplex-grade emulation switch (-1 = the key simplex_grade of
+  // the CUOPT_AMD_TUNE environment string, default on)
   int32_t num_gpus = 0, simplex_grade = -1;
   int32_t dual_simplex = -1;  // the dual simplex engine: -1 = CUOPT_AMD_DUAL_SIMPLEX (default on), 0 off, 1 on
   bool infeasibility_detection = false, strict_infeasibility = false, per_constraint_residual = false,

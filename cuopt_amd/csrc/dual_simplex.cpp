@@ -85,7 +85,7 @@ struct Simplex {
   std::vector<int>&vis = W0.vis, &sstack = W0.sstack, &sptr = W0.sptr, &order = W0.order;  // depth-first searches of the sparse solves
   std::vector<int>&seed_buf = W0.seed, &lorder = W0.lorder, &plist = W0.plist, &rmark = W0.rmark;
   int &vstamp = W0.vstamp, &rstamp = W0.rstamp;
-  int sparse_solve = 1;  // 0: always the dense loops (CUOPT_AMD_SIMPLEX_SOLVES=dense), 2: always the sparse ones, 1: by the size of the reach
+  int sparse_solve = 1;  // 0: always the dense loops (CUOPT_AMD_TUNE=simplex_solves=dense), 2: always the sparse ones, 1: by the size of the reach
   // work space
   std::vector<double> wx;
   std::vector<int> inpat, pattern, mark, topo, dstack, dptr, rowcnt;
@@ -879,7 +879,7 @@ struct SolveHelper {
   Simplex& S;
   Job job[2];
   Simplex::SolveWork W;
-  std::atomic<int> quit{0};
+  std::atomic<int> quit{0}, failed{0};
   std::thread th;
   explicit SolveHelper(Simplex& s) : S(s)
   {
@@ -894,9 +894,19 @@ struct SolveHelper {
     }
     return true;
   }
+  static inline void cpu_relax()
+  {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+  }
   static void relax(int& spins)  // a short spin (a pivot's jobs follow each other within microseconds), then yields, then naps:
   {                               // an idle helper next to a slow main loop must not keep a core busy for the length of the solve
-    if (++spins < 20000) __builtin_ia32_pause();  // (about a millisecond: the next pivot's job is usually here by then)
+    if (++spins < 20000) cpu_relax();  // (about a millisecond: the next pivot's job is usually here by then)
     else if (spins < 40000) std::this_thread::yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
@@ -907,7 +917,11 @@ struct SolveHelper {
       bool worked = false;
       for (Job& j : job)
         if (j.state.load(std::memory_order_acquire) == 1) {
-          S.ftran(j.rhs, j.rows, *j.out, *j.outlist, false, &W);
+          try {  // (nothing may leave a thread: a bad_alloc inside the solve's lists ends the ENGINE with status 7, not the process)
+            S.ftran(j.rhs, j.rows, *j.out, *j.outlist, false, &W);
+          } catch (...) {
+            failed.store(1, std::memory_order_release);
+          }
           j.state.store(2, std::memory_order_release);
           worked = true;
         }
@@ -924,7 +938,7 @@ struct SolveHelper {
   {
     int spins = 0;
     while (job[slot].state.load(std::memory_order_acquire) != 2) {  // (the helper is at work on it: no naps on this side)
-      if (++spins < 4000) __builtin_ia32_pause();
+      if (++spins < 4000) cpu_relax();
       else std::this_thread::yield();
     }
     job[slot].state.store(0, std::memory_order_relaxed);
@@ -1024,7 +1038,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   std::vector<double> fw(m, 0.0);
   int fstamp_now = 0;
   std::unique_ptr<SolveHelper> helper;
-  if (m >= cuopt_amd::tune_int("simplex_helper_rows", 2000) && std::thread::hardware_concurrency() >= 2) {
+  if (m >= cuopt_amd::tune_int("simplex_helper_rows", 2000) && cuopt_amd::host_threads() >= 2) {  // (cgroup / affinity aware: under a one-CPU quota the two would only take turns)
     helper.reset(new SolveHelper(S));
     helper->job[0].out = &tau, helper->job[0].outlist = &taulist;
     helper->job[1].out = &fw, helper->job[1].outlist = &fwlist;
@@ -1056,6 +1070,7 @@ int run(Simplex& S, int iteration_limit, double time_limit, const std::chrono::s
   std::vector<double> cand_a, cand_d;
   for (;;) {
     if (S.iterations >= iteration_limit) return 5;
+    if (helper && helper->failed.load(std::memory_order_acquire)) return 7;  // the helper's solve threw (out of memory): the engine gives up
     if (flag_set(cancel)) return 9;  // the other engine of a Concurrent solve has finished
     if ((S.iterations & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > time_limit) return 6;
     // leaving position: the largest primal infeasibility, squared over its steepest-edge weight.  A position whose violation is
@@ -1524,7 +1539,19 @@ int solve(const cuoptamd_lp* lp, const double* x0, const double* y0, double time
   if (m <= 0 || n <= 0 || m > max_rows || (int64_t)n + m > 20 * max_rows || lp->offsets[m] > max_nnz || cuopt_amd::tune_int("simplex_presolve", 1) == 0)
     return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
   cuopt_amd::SimplexPresolve P;
-  if (!P.run(lp, cancel)) return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
+  const auto t_pre = std::chrono::steady_clock::now();
+  const bool reduced = P.run(lp, cancel);
+  // (the presolve's own time counts against the caller's limit: two column-wise copies of a 4e6-nonzero LP are not free)
+  if (time_limit > 0.0) {
+    const double spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pre).count();
+    if (spent >= time_limit) {
+      *status = 6;
+      if (iterations) *iterations = 0;
+      return 0;
+    }
+    time_limit -= spent;
+  }
+  if (!reduced) return solve_core(lp, x0, y0, time_limit, iteration_limit, cancel, status, iterations, objective, x, y, rc);
   if (P.cancelled) {
     *status = 9;
     if (iterations) *iterations = 0;

@@ -250,7 +250,7 @@ constexpr unsigned kSegColMask = (1u << kSegColBits) - 1u;
 // ------------------------------------------------------------------------------------------------
 // Two geometries: 8 waves + a window of 8192 entries (80 KiB of LDS, two workgroups per CU), or 16 waves + 16384 entries
 // (160 KiB, one workgroup per CU: the same 16 waves per CU, twice the rows sharing a window twice as wide) -- chosen per
-// matrix at set-up (8 waves unless CUOPT_AMD_JAG_WAVES=16: see build_jag).
+// matrix at set-up (8 waves unless CUOPT_AMD_TUNE=jag_waves=16: see build_jag).
 constexpr int kJagMaxGroup = 256;   // rows per wave (2 KiB of row sums)
 #ifndef CUOPT_AMD_JAG_U
 #define CUOPT_AMD_JAG_U 8

@@ -1003,7 +1003,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
                                      &TransposeJob::wait, &job, L->c, L->lo + s->row_begin, L->hi + s->row_begin, L->lb, L->ub);
     if (rc == 0 && fault_injected(rank, world, "create")) rc = -6;
     job.join();
-    if (rc != 0 && rc != setup_rc) fail(rc, "pdlpdev_create: %s", rc == -6 ? "injected fault (CUOPT_AMD_FAULT_INJECT)" : pdlpdev_last_error());
+    if (rc != 0 && rc != setup_rc) fail(rc, "pdlpdev_create: %s", rc == -6 ? "injected fault (CUOPT_AMD_TUNE=fault_inject)" : pdlpdev_last_error());
     if (t_agree_before_comm) {
       const int all = t_agree_before_comm(rc);
       if (rc == 0 && all != 0) return fail(all, "another rank of the sharded solve failed during set-up");
@@ -1155,7 +1155,7 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
   for (;;) {
     const int32_t it = s->total_iterations;
     if (it >= H.major_iteration && fault_injected(s->rank, s->world, "advance"))
-      return leave(fail(-6, "injected fault (CUOPT_AMD_FAULT_INJECT)"));
+      return leave(fail(-6, "injected fault (CUOPT_AMD_TUNE=fault_inject)"));
     const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
     // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
     const bool artificial = H.artificial_restart_in_main_loop &&

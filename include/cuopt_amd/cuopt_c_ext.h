@@ -6,8 +6,8 @@
  *                            0 (default) = the CUOPT_AMD_NUM_GPUS environment variable, else 1.
  *   CUOPT_AMD_SIMPLEX_GRADE  1 / 0: serve Concurrent / DualSimplex requests on small LPs (<= 1e5 nonzeros) at
  *                            simplex-grade tolerances (1e-8) with the requested tolerances as acceptance set
- *                            (cuoptamd_settings::accept_tolerance).  -1 (default) = the CUOPT_AMD_SIMPLEX_GRADE
- *                            environment variable, else on.
+ *                            (cuoptamd_settings::accept_tolerance).  -1 (default) = the key simplex_grade of the
+ *                            CUOPT_AMD_TUNE environment string (CUOPT_AMD_TUNE=simplex_grade=0), else on.
  */
 #ifndef CUOPT_AMD_CUOPT_C_EXT_H
 #define CUOPT_AMD_CUOPT_C_EXT_H

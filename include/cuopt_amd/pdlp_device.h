@@ -350,7 +350,7 @@ int64_t pdlpdev_device_bytes(pdlpdev_ctx* ctx);
  * all-gather(y' row blocks) + a 3-scalar all-reduce, no partial products on the wire (CUOPT_AMD_SHARD_DATAFLOW=owner) */
 int pdlpdev_shard_dataflow(pdlpdev_ctx* ctx);
 /* dense row segments (runs of >= 256 consecutive columns inside a row, stored index-free and multiplied by their own streaming
- * kernels; CUOPT_AMD_DENSE = 0 off | 1 whenever a segment exists | default: when they hold >= 2 % of the nonzeros; single-GPU
+ * kernels; CUOPT_AMD_TUNE=dense=0 off | dense=1 whenever a segment exists | default: when they hold >= 2 % of the nonzeros; single-GPU
  * solves): out = {in use, segments, entries} */
 int pdlpdev_dense_info(pdlpdev_ctx* ctx, int64_t out[3]);
 /* transport of the owner-computes dataflow's exchanges: 0 = collectives (RCCL all-gather / 3-scalar all-reduce, or the in-process
