@@ -60,6 +60,24 @@ def reference_dual_simplex_block(root, cutoff_s=15.0):
     return out
 
 
+def shader_clock_mhz():
+    """current sclk of GPU 0 as rocm-smi reports it (None when the tool is absent): printed at both ends of the timed region so that a
+    box running below its steady clocks shows up in the line (round 4: 11 % between two boxes on c3x10, unexplained)"""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for k, v in card.items():
+            if "sclk" in k.lower():
+                m = re.search(r"(\d+)\s*mhz", str(v).lower())
+                if m:
+                    return int(m.group(1))
+    except Exception:
+        pass
+    return None
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record: libraries loaded below write banners to file descriptor 1 (RCCL prints its
     # version block there when the first communicator is created), so everything else is sent to stderr
@@ -224,6 +242,7 @@ def main():
     # batches (max-reduced over the ranks: same decision everywhere); `steps` is echoed as given, `timed_steps` as run.
     steady_rate = max_over_ranks(warm_rates[-1])
     timed_steps = max(timed_steps, int(np.ceil(args.min_seconds * steady_rate / period)) * period)
+    sclk_start = shader_clock_mhz() if rank == 0 else None
     dev.call("synchronize")
     barrier()
     attempts_before = solver.advance(0)["attempted_steps"]
@@ -234,6 +253,7 @@ def main():
     dev.call("synchronize")
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    sclk_end = shader_clock_mhz() if rank == 0 else None
     steps_done = r["steps_taken"] - pre
     assert r["status"] == 0 and steps_done == timed_steps, (r["status_name"], steps_done)
     its_per_s = timed_steps / elapsed
@@ -283,6 +303,7 @@ def main():
                     iteration_fused_floor_bytes=synthetic.iteration_bytes_min(m, n, nnz),
                     iteration_frac_of_peak=round(synthetic.iteration_bytes_min(m, n, nnz) * its_per_s / 1e9
                                                  / HBM_PEAK_GBS / max(world, 1), 4),
+                    traffic_calibrated=None if traffic is None else True,  # streams: MI355X_MICROARCH.md (FETCH_SIZE x 2); scattered 8-byte reads: profiles/r05_gather_calibration.txt (one 128-B line per miss, tallied at 64 B); WRITE_SIZE: k_primal 71.5 vs 72 MB
                     traffic_source=None if traffic is None else
                     "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                     "(scripts/r04_pmc.sh / r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
@@ -362,7 +383,7 @@ def main():
                                                                        3: "owner computes: all-gather(xbar) + all-gather(y'), rows and columns of A per rank"}.get(dataflow, "?") + transport)) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
             "spmv_layout": layout, "setup_reordering": reorder, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
-            "device": info["name"], "compute_units": info["compute_units"],
+            "device": info["name"], "compute_units": info["compute_units"], "sclk_mhz": {"before_timed_region": sclk_start, "after_timed_region": sclk_end},
         }
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())

@@ -225,7 +225,7 @@ constexpr unsigned kSegColMask = (1u << kSegColBits) - 1u;
 
 // ------------------------------------------------------------------------------------------------
 // Sorted jagged rows ("jag"): the SpMV for STRUCTURED matrices, whose rows re-use a limited set of columns.
-// Measured (tools/spmv_tune2.hip, profiles/r02_spmv_tune2.txt): an 8-byte gather through the vector
+// Measured (the round-2 harness: profiles/r02_spmv_tune2.txt, index in profiles/r05_harness_variants.txt): an 8-byte gather through the vector
 // memory path costs ~1.85 clocks of the CU's texture-address unit per lane even when it hits L1
 // (1e7 gathers never finish under 30 us), and every L1 miss occupies one of a CU's limited miss slots
 // for an L2 round trip.  A workgroup of this layout therefore copies EVERY column its rows use into LDS
@@ -283,7 +283,7 @@ struct JagView {
 
 // ------------------------------------------------------------------------------------------------
 // Gather-free layout ("pb": products, then rows) for UNSTRUCTURED matrices whose gathered vector is far beyond the caches.
-// Harness and measurements: tools/spmv_pb.hip, profiles/r03_pb_*.  out = M v in two pure streams, no global gather at all:
+// Measurements of the round-3 harness: profiles/r03_pb_* (index: profiles/r05_harness_variants.txt).  out = M v in two pure streams, no global gather at all:
 //   phase P: the columns are cut into SOURCE PANELS (8192 or 16384 columns); a workgroup copies its panel's slice of v into
 //     LDS and streams the panel's nonzeros -- value + 16-bit column within the panel -- in (panel, bin, row, column) order;
 //     the products go, in pieces of G entries (aligned 8 G-byte blocks, piece table: 4 B per piece), to where phase R reads

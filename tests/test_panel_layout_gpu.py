@@ -2,7 +2,7 @@
 sorted jagged-row layout with LDS column windows (used for structured matrices) must give the same numbers
 as the CSR stream layout: bit-exact rows (every row is still summed left to right), same PDLP decisions.  So must the
 gather-free layout ("pb": products streamed through LDS-resident slices of the vector, rows summed from an LDS image of their
-products; tools/spmv_pb.hip), which sums EVERY row left to right whatever its length."""
+products: kernels_pb.hip), which sums EVERY row left to right whatever its length."""
 import numpy as np
 import pytest
 from conftest import set_tune
