@@ -242,18 +242,32 @@ def main():
     # batches (max-reduced over the ranks: same decision everywhere); `steps` is echoed as given, `timed_steps` as run.
     steady_rate = max_over_ranks(warm_rates[-1])
     timed_steps = max(timed_steps, int(np.ceil(args.min_seconds * steady_rate / period)) * period)
-    sclk_start = shader_clock_mhz() if rank == 0 else None
     dev.call("synchronize")
     barrier()
     attempts_before = solver.advance(0)["attempted_steps"]
     dev.call("synchronize")
     barrier()
+    # (the shader clock is sampled by a host thread WHILE the timed region runs: a reading taken in front of it would idle the GPU)
+    import threading
+    sclk_samples, sclk_stop = [], threading.Event()
+
+    def sample_clock():
+        while not sclk_stop.is_set():
+            v = shader_clock_mhz()
+            if v is not None:
+                sclk_samples.append(v)
+            sclk_stop.wait(0.4)
+    sampler = threading.Thread(target=sample_clock, daemon=True) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     r = solver.advance(timed_steps)
     dev.call("synchronize")
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    sclk_end = shader_clock_mhz() if rank == 0 else None
+    sclk_stop.set()
+    if sampler:
+        sampler.join(timeout=30)
     steps_done = r["steps_taken"] - pre
     assert r["status"] == 0 and steps_done == timed_steps, (r["status_name"], steps_done)
     its_per_s = timed_steps / elapsed
@@ -383,7 +397,7 @@ def main():
                                                                        3: "owner computes: all-gather(xbar) + all-gather(y'), rows and columns of A per rank"}.get(dataflow, "?") + transport)) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
             "spmv_layout": layout, "setup_reordering": reorder, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
-            "device": info["name"], "compute_units": info["compute_units"], "sclk_mhz": {"before_timed_region": sclk_start, "after_timed_region": sclk_end},
+            "device": info["name"], "compute_units": info["compute_units"], "sclk_mhz_during_timed_region": {"samples": len(sclk_samples), "min": min(sclk_samples) if sclk_samples else None, "max": max(sclk_samples) if sclk_samples else None},
         }
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
