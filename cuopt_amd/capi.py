@@ -299,6 +299,7 @@ _proto("pdlpdev_analysis_destroy", None, c_void_p)
 _proto("pdlpdev_debug_sort_pairs", c_int, c_int, C.c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
 _proto("pdlpdev_debug_scan", c_int, c_int, C.c_int64, c_void_p, c_void_p)
 _proto("pdlpdev_debug_layout_checksums", c_int, c_void_p, c_void_p)
+_proto("pdlpdev_synthetic_lp", c_int, c_int, c_int, c_int, c_int, C.c_uint64, *([c_void_p] * 8))
 
 # ids of pdlp_device.h
 BUF = {n: i for i, n in enumerate(
@@ -817,6 +818,18 @@ class Analysis:
             self.close()
         except Exception:
             pass
+
+
+def synthetic_lp_on_device(m, n, k, seed=1, device=0):
+    """S(m, n, k) generated on the device (pdlpdev_synthetic_lp): a problem dict like cuopt_amd.synthetic.generate's"""
+    nnz = int(m) * int(k)
+    off, idx, val = np.zeros(m + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+    c, lo, hi, xs, ys = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(m)
+    rc = lib.pdlpdev_synthetic_lp(device, int(m), int(n), int(k), int(seed), _ptr(off), _ptr(idx), _ptr(val), _ptr(c), _ptr(lo), _ptr(hi), _ptr(xs), _ptr(ys))
+    if rc != 0:
+        raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+    return dict(m=int(m), n=int(n), offsets=off, indices=idx, values=val, c=c, lo=lo, hi=hi, lb=np.zeros(n), ub=np.full(n, np.inf), maximize=False,
+                objective_offset=0.0, x_star=xs, y_star=ys, objective_star=float(c @ xs), seed=seed, k=k, hard=False, band=0)
 
 
 def device_sort_pairs(keys, vals=None, bits=32, device=0):

@@ -1338,7 +1338,13 @@ int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, co
   // workspace: the permuted pair's three sorts are the largest user (7 arrays of nnz words + histograms); the ordering search needs
   // ~14 arrays of max(m, n) words
   {
-    const bool reorder = (flags & 1) != 0;
+    bool reorder = (flags & 1) != 0;
+    {
+      // (the ordering search keeps a dense quotient graph of m / row-block cells: beyond 4096 cells -- 8 M rows -- it does not run,
+      // and its 5 extra arrays of nnz words are not reserved: 20 GB at 1e9 nonzeros)
+      int G = 0, waves = 0, wcap = 0, brows = 0;
+      if (!jag_geometry(m, 0, &G, &waves, &wcap, &brows) || (int64_t)m / brows + 2 > 4096) reorder = false;
+    }
     const size_t words = (size_t)std::max<int64_t>(nnz, 1);
     const size_t verts = (size_t)std::max(m, n) + 64;
     size_t bytes = 4 * (words * (reorder ? 9 : 4) + (words / kRsTile + 2) * 256 + 4096) + (reorder ? 4 * verts * 20 + 48ull * 4096 * kLongRow * 4 + 4096ull * 4096 * 4 : 0) + (1 << 20);
@@ -1648,5 +1654,96 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
     dst->v.csr_off = d_off, dst->v.csr_idx = d_idx, dst->v.csr_val = d_val;
   }
   dst->on = true;
+  return 0;
+}
+
+// ================================================================================================
+// synthetic LP generated ON THE DEVICE (scale checks near the reference's stated capacity, docs/cuopt/source/faq.rst:368-370: the
+// host generator of cuopt_amd/synthetic.py needs minutes and tens of GB at 1e9 nonzeros).  Same recipe -- a known primal-dual optimal
+// pair by construction, equalities on the first half of the rows, '>=' rows with slack on the second -- with the columns of a row
+// drawn one per stratum of n / k columns (distinct and ascending by construction).  Deterministic in (seed, m, n, k) except for the
+// low bits of c = A^T y* + z* (atomic adds); the known optimum is computed from the c that is returned.
+// ================================================================================================
+namespace {
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ double unit(unsigned long long h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }  // [0, 1)
+__device__ __forceinline__ double normal(unsigned long long h)
+{
+  const double u1 = 1.0 - unit(mix64(h)), u2 = unit(mix64(h ^ 0xD1B54A32D192ED03ull));
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+__global__ void __launch_bounds__(kT) k_gen_cols(int32_t n, unsigned long long seed, double* __restrict__ xs, double* __restrict__ c)
+{
+  for (int64_t j = (int64_t)blockIdx.x * kT + threadIdx.x; j < n; j += (int64_t)gridDim.x * kT) {
+    const unsigned long long h = mix64(seed ^ (0x1000000000ull + (unsigned long long)j));
+    const double x = unit(h) < 0.5 ? 0.0 : 1.0 - unit(mix64(h ^ 1));
+    xs[j] = x;
+    c[j]  = x > 0.0 ? 0.0 : unit(mix64(h ^ 2));  // z*: the reduced cost of a variable at its bound
+  }
+}
+__global__ void __launch_bounds__(kT) k_gen_rows(int32_t m, int32_t n, int32_t k, unsigned long long seed, const double* __restrict__ xs,
+                                                 int32_t* __restrict__ off, int32_t* __restrict__ idx, double* __restrict__ val,
+                                                 double* __restrict__ ys, double* __restrict__ lo, double* __restrict__ hi, double* __restrict__ c)
+{
+  const int64_t stratum = n / k;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < m; i += (int64_t)gridDim.x * kT) {
+    const unsigned long long hr = mix64(seed ^ (0x2000000000ull + (unsigned long long)i));
+    double y = normal(hr);
+    const bool equality = i < m / 2;
+    if (!equality) y = unit(mix64(hr ^ 7)) < 0.3 ? 0.0 : fabs(y);
+    ys[i] = y;
+    double ax = 0.0;
+    const int64_t base = i * (int64_t)k;
+    for (int t = 0; t < k; ++t) {
+      const unsigned long long he = mix64(seed ^ ((unsigned long long)i * 64ull + (unsigned long long)t) ^ 0x3000000000000ull);
+      const int64_t width = t == k - 1 ? (int64_t)n - stratum * t : stratum;
+      const int32_t j     = (int32_t)(stratum * t + (int64_t)(he % (unsigned long long)width));
+      const double a      = normal(he ^ 0x55);
+      idx[base + t] = j, val[base + t] = a;
+      ax += a * xs[j];
+      if (y != 0.0) atomicAdd(&c[j], a * y);  // c = A^T y* + z*
+    }
+    off[i] = (int32_t)base;
+    if (i == m - 1) off[m] = (int32_t)(base + k);
+    if (equality) {
+      lo[i] = ax, hi[i] = ax;
+    } else {
+      lo[i] = ax - (y > 0.0 ? 0.0 : unit(mix64(hr ^ 9))), hi[i] = INFINITY;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pdlpdev_synthetic_lp(int device, int32_t m, int32_t n, int32_t k, uint64_t seed, int32_t* offsets, int32_t* indices, double* values,
+                                    double* c, double* lo, double* hi, double* x_star, double* y_star)
+{
+  if (m <= 0 || n <= 0 || k <= 0 || k > n || (int64_t)m * k >= ((int64_t)1 << 31)) return fail(-1, "pdlpdev_synthetic_lp: bad sizes (m * k must stay below 2^31)");
+  if (pdlpdev_device_count() <= device) return fail(-5, "pdlpdev_synthetic_lp: no HIP device %d visible", device);
+  HIP_TRY(hipSetDevice(device));
+  const int64_t nnz = (int64_t)m * k;
+  int32_t *d_off = nullptr, *d_idx = nullptr;
+  double *d_val = nullptr, *d_c = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_xs = nullptr, *d_ys = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_off, ((size_t)m + 1) * 4)); HIP_TRY(hipMalloc((void**)&d_idx, (size_t)nnz * 4)); HIP_TRY(hipMalloc((void**)&d_val, (size_t)nnz * 8));
+  HIP_TRY(hipMalloc((void**)&d_c, (size_t)n * 8)); HIP_TRY(hipMalloc((void**)&d_xs, (size_t)n * 8));
+  HIP_TRY(hipMalloc((void**)&d_lo, (size_t)m * 8)); HIP_TRY(hipMalloc((void**)&d_hi, (size_t)m * 8)); HIP_TRY(hipMalloc((void**)&d_ys, (size_t)m * 8));
+  k_gen_cols<<<grid_of(n), kT>>>(n, seed, d_xs, d_c);
+  k_gen_rows<<<grid_of(m), kT>>>(m, n, k, seed, d_xs, d_off, d_idx, d_val, d_ys, d_lo, d_hi, d_c);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(offsets, d_off, ((size_t)m + 1) * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(indices, d_idx, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(values, d_val, (size_t)nnz * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(c, d_c, (size_t)n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(lo, d_lo, (size_t)m * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hi, d_hi, (size_t)m * 8, hipMemcpyDeviceToHost));
+  if (x_star) HIP_TRY(hipMemcpy(x_star, d_xs, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (y_star) HIP_TRY(hipMemcpy(y_star, d_ys, (size_t)m * 8, hipMemcpyDeviceToHost));
+  for (void* p : {(void*)d_off, (void*)d_idx, (void*)d_val, (void*)d_c, (void*)d_lo, (void*)d_hi, (void*)d_xs, (void*)d_ys}) (void)hipFree(p);
   return 0;
 }

@@ -194,6 +194,13 @@ int pdlpdev_debug_sort_pairs(int device, int64_t n, const uint32_t* keys, const 
                              uint32_t* vals_out);
 int pdlpdev_debug_scan(int device, int64_t n, const int32_t* in, int32_t* out);
 int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16]);
+/* A synthetic LP of the S(m, n, k) family GENERATED ON THE DEVICE and handed back in host arrays (scale checks near the reference's
+ * stated capacity, docs/cuopt/source/faq.rst:368-370: 1e9 nonzeros take the host generator minutes and tens of GB): k entries per row,
+ * one per stratum of n / k columns, values ~ N(0, 1); equalities on the first half of the rows, '>=' rows with slack on the second;
+ * x >= 0; (x_star, y_star) is optimal by construction, objective = c . x_star.  m * k < 2^31.  offsets[m + 1], indices / values[m * k],
+ * c / x_star[n], lo / hi / y_star[m] (x_star, y_star may be NULL). */
+int pdlpdev_synthetic_lp(int device, int32_t m, int32_t n, int32_t k, uint64_t seed, int32_t* offsets, int32_t* indices, double* values,
+                         double* c, double* lo, double* hi, double* x_star, double* y_star);
 
 /* ---- multi-GPU (row-block sharding, one context per rank) ----------------------------------- */
 /* 128-byte RCCL unique id, generated on rank 0 and handed to every rank by the launcher. */

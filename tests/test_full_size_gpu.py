@@ -178,3 +178,46 @@ def test_long_row_families_at_full_size(kind, monkeypatch):
             s.close()
         # (120 iterations of a chaotic map apart: the two orders of summation agree on every decision and on the objective to 1e-6)
         assert got[0][:3] == got[1][:3] and got[0][3] == pytest.approx(got[1][3], rel=1e-6)
+
+
+def _free_hbm_and_ram():
+    import psutil
+    info = capi.device_info(0)
+    return info.get("hbm_bytes", 0), psutil.virtual_memory().available
+
+
+def test_a_billion_nonzeros_near_the_reference_s_stated_capacity():
+    """docs/cuopt/source/faq.rst:368-370 names 10 M x 10 M / 2 B nonzeros on one 80 GB GPU.  Here: 3e7 x 3e7 with 33 nonzeros per row =
+    9.9e8 nonzeros (m * k stays below 2^31: the C API's indices are int32), generated on the device (pdlpdev_synthetic_lp), through
+    `auto`: the device-side transposition, whichever layout the rule picks, a solve to 1e-4 against the optimum known by construction,
+    SpMV spot-checked on sampled rows against plain numpy sums of the generated CSR (left to right: bit-exact), peak HBM reported."""
+    hbm, ram = _free_hbm_and_ram()
+    if hbm < 200e9 or ram < 120e9:
+        pytest.skip("needs >= 200 GB of HBM and >= 120 GB of host memory (found %.0f / %.0f GB)" % (hbm / 1e9, ram / 1e9))
+    m = n = 30_000_000
+    p = capi.synthetic_lp_on_device(m, n, 33, seed=2)
+    assert int(p["offsets"][-1]) == 990_000_000 and np.all(np.diff(p["indices"][:33 * 1000].reshape(1000, 33), axis=1) > 0)
+    s = capi.Solver(p, mode=1, tol=1e-4)
+    dev = s.device
+    lay = dev.layout()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n)
+    got = dev.spmv(x, False, m)
+    # (the solver's matrix is the SCALED one: entry (i, j) is (a_ij * D_r,i) * D_c,j, k_scale_matrix_blocks' order of the two products)
+    dr, dc = dev.download("DROW", m), dev.download("DCOL", n)
+    rows = rng.integers(0, m, size=2000)
+    for i in rows:
+        k0, k1 = int(p["offsets"][i]), int(p["offsets"][i + 1])
+        acc = 0.0
+        for a, j in zip(p["values"][k0:k1], p["indices"][k0:k1]):
+            acc = acc + ((a * dr[i]) * dc[j]) * x[j]
+        assert got[i] == acc, (i, got[i], acc)
+    y = rng.standard_normal(m)
+    aty = dev.spmv(y, True, n)
+    assert float(x @ aty) == pytest.approx(float(got @ y), rel=1e-9)  # <x, A^T y> = <A x, y>
+    r = s.advance()
+    assert r["status_name"] == "Optimal", r["status_name"]
+    assert abs(r["primal_objective"] - p["objective_star"]) <= 1e-3 * (1 + abs(p["objective_star"]))
+    print("1e9 nonzeros: layout %s, %d iterations, set-up %.1f s, loop %.1f s, device memory %.1f GB" % (
+        lay, r["steps_taken"], r["setup_seconds"], r["loop_seconds"], capi.lib.pdlpdev_device_bytes(dev.handle) / 1e9))
+    s.close()
