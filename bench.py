@@ -78,6 +78,146 @@ def shader_clock_mhz():
     return None
 
 
+def cpu_baseline_block(p):
+    """the C oracle's PDLP loop on the same LP, bounded iteration budget (kind "port": cuOpt ships no CPU PDLP).  Thread counts
+    16 / 32 / 64 / 128 are tried once each on a 12-iteration calibration run and the best one gets the ~20 s sample; box cores and
+    threads used are both reported."""
+    # threads pinned to neighbouring cores; the oracle touches its arrays first from the threads that work on them
+    # (oracle/pdlp_oracle.c dalloc / copy_rows_*), so a multi-socket box reads mostly local memory
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    from oracle import orcbind
+    if not orcbind.available():
+        return None
+    try:
+        box_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        box_cores = os.cpu_count() or 1
+    sweep = {}
+    for t in sorted({min(t, box_cores) for t in (16, 32, 64, 128)}):
+        o = orcbind.solve(p, tol=0.0, iteration_limit=12, num_threads=t)
+        sweep[t] = o["steps_taken"] / max(o["loop_seconds"], 1e-9)
+    cores = max(sweep, key=sweep.get)
+    # (all 12 calibration steps are major iterations: an under-estimate of the rate, so the sample is bounded)
+    budget = int(min(max(20.0 * sweep[cores], 40), 4000))
+    o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
+    cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
+               box_cores=box_cores, kind="port",
+               thread_sweep_calibration_its_per_s={str(k): round(v, 2) for k, v in sweep.items()},
+               sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d of %d cores), %d iterations of the same "
+               "LP: loop %.2fs + setup %.2fs" % (cores, box_cores, o["steps_taken"], o["loop_seconds"],
+                                               o["solve_seconds"] - o["loop_seconds"]))
+    cpu["reference_dual_simplex"] = reference_dual_simplex_block(ROOT)
+    return cpu
+
+
+def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
+    """--workload c3_batch<K>: K LPs over ONE matrix and objective (different variable bounds: the MIP heuristics' re-solve pattern,
+    BASELINE config 5 at the headline size) advance in lockstep (cuoptamd_batch_*; kernels_batch.hip).  value = AGGREGATE PDLP
+    iterations/s over the K LPs; every LP's trajectory is bit-identical to its own single solve (tests/test_shared_batch_gpu.py)."""
+    from cuopt_amd import capi, synthetic
+    m, n, nnz = p["m"], p["n"], int(len(p["values"]))
+    rng = np.random.default_rng(8)
+
+    def bounds(l):
+        lb, ub = np.array(p["lb"], float), np.array(p["ub"], float)
+        if l:
+            for j in rng.choice(n, size=n // 10, replace=False):
+                ub[j] = p["x_star"][j] + 0.3 * rng.random()
+        return lb, ub
+    parent = capi.Solver(p, mode=1, tol=0.0, device=local_rank)
+    setup_s = parent.advance(0)["setup_seconds"]
+    dev = parent.device
+    dev.call("prepare_graphs")
+    period = max(int(parent.hyper.major_iteration), 1)
+    pre = ((max(args.warmup, 2 * period, int(parent.hyper.min_iteration_restart) + period) + period - 1) // period) * period
+    # the single solve's rate in this very process (the yardstick of the aggregate)
+    parent.advance(pre)
+    rates = []
+    for _ in range(4):
+        dev.call("synchronize")
+        t0 = time.perf_counter()
+        parent.advance(25 * period)
+        dev.call("synchronize")
+        rates.append(25 * period / (time.perf_counter() - t0))
+    single = max(rates[1:])
+    parent.reset(tol=0.0)
+    t0 = time.perf_counter()
+    clones = [parent.clone(*bounds(l)) for l in range(1, K)]
+    clone_s = (time.perf_counter() - t0) / max(K - 1, 1)
+    batch = capi.SharedMatrixBatch([parent] + clones)
+    layout = dev.layout()
+    batch.advance(pre)
+    warm_rates, warm_wall = [], 0.0
+    while True:
+        dev.call("synchronize")
+        tb = time.perf_counter()
+        batch.advance(5 * period)
+        dev.call("synchronize")
+        dt = time.perf_counter() - tb
+        pre += 5 * period
+        warm_wall += dt
+        warm_rates.append(5 * period / dt)
+        if (len(warm_rates) >= 3 and all(abs(warm_rates[-i] - warm_rates[-i - 1]) <= 0.02 * warm_rates[-i] for i in (1, 2))) or warm_wall > 4.0:
+            break
+    timed_steps = max((max(args.steps, 1) + period - 1) // period, 5) * period
+    timed_steps = max(timed_steps, int(np.ceil(args.min_seconds * warm_rates[-1] / period)) * period)
+    attempts_before = sum(r["attempted_steps"] for r in batch.advance(0))
+    dev.call("synchronize")
+    t0 = time.perf_counter()
+    rs = batch.advance(timed_steps)
+    dev.call("synchronize")
+    elapsed = time.perf_counter() - t0
+    assert all(r["status"] == 0 and r["steps_taken"] == pre + timed_steps for r in rs), [(r["status_name"], r["steps_taken"]) for r in rs]
+    attempts = sum(r["attempted_steps"] for r in rs) - attempts_before
+    kernels = batch.time_kernels(20)
+    bytes_alg = {
+        # the matrix once, every gathered vector entry of every LP once, the per-LP epilogue streams, the interleaved copy of y'
+        "a_dual": 12 * nnz + 4 * (m + 1) + K * (8 * n + 8 * (4 * m + 2 * m)) + 8 * K * m,
+        "at_step": 12 * nnz + 4 * (n + 1) + K * (8 * m + 8 * (3 * n + n)),
+        "primal": K * 8 * (6 * n + 3 * n),  # x,c,AtY,lb,ub,sum_x r ; x',sum_x w ; xbar interleaved w
+    }
+    dom = "a_dual" if kernels["a_dual"] >= kernels["at_step"] else "at_step"
+    achieved = bytes_alg[dom] / (kernels[dom] * 1e-3) / 1e9
+    ksum = sum(kernels.values())
+    floor_k = 24 * nnz + 4 * (m + n + 2) + K * 8 * (14 * n + 7 * m) + 2 * 8 * K * (n + m)
+    per_attempt_ms = 1e3 * elapsed / max(attempts / K, 1)
+    roofline = dict(bound="hbm", kernel="kb_" + dom + "<%d>" % K, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, algorithmic_bytes_per_launch=bytes_alg[dom],
+                    avg_launch_ms=round(kernels[dom], 5), per_kernel_ms={k: round(v, 5) for k, v in kernels.items()},
+                    per_kernel_gbs={k: round(bytes_alg[k] / (kernels[k] * 1e-3) / 1e9, 1) for k in bytes_alg},
+                    attempt_kernels_ms=round(ksum, 5), ms_per_lockstep_attempt=round(per_attempt_ms, 5),
+                    attempt_kernels_over_ms_per_attempt=round(ksum / per_attempt_ms, 4),
+                    lockstep_iteration_floor_bytes=floor_k,
+                    iteration_frac_of_peak=round(floor_k * (timed_steps / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
+                    floor_note="fused floor of a lockstep iteration: the matrix twice (A, A^T) ONCE for all LPs, every LP's own 14 n + 7 m "
+                               "vector streams, the two interleaved gather vectors written and read once")
+    cpu = None if args.no_cpu_baseline else cpu_baseline_block(p)
+    if cpu is not None:
+        cpu["note"] = "the oracle solves one LP at a time: its aggregate over K LPs is this rate"
+    info = capi.device_info(local_rank)
+    out = {
+        "metric": "pdlp_iterations_per_sec", "value": round(K * timed_steps / elapsed, 2), "unit": "iterations/s (aggregate over %d LPs)" % K,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
+        "ms_per_step": round(1e3 * elapsed / timed_steps, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d LPs over the matrix and objective of c3 (synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d), nnz=%d); LP 0 = c3, "
+                               "the others with a tenth of the upper bounds tightened (seeded); lockstep batch, Stable2 preset, tolerances 0 (fixed "
+                               "iteration budget)" % (args.workload, K, m, n, cfg["k"], cfg["seed"], nnz),
+                   "rows": m, "cols": n, "nnz": nnz, "lps": K, "parallelism": "single GPU, %d LPs in lockstep" % K},
+        "single_lp_its_per_s_same_process": round(single, 1), "aggregate_over_single": round(K * timed_steps / elapsed / single, 3),
+        "clone_seconds_per_lp": round(clone_s, 4),
+        "roofline": roofline, "cpu_baseline": cpu, "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4),
+        "generate_seconds": round(t_gen, 2), "device": info["name"], "compute_units": info["compute_units"],
+    }
+    sys.stdout.flush()
+    os.write(record_fd, (json.dumps(out) + "\n").encode())
+    batch.close()
+    for c in clones:
+        c.close()
+    parent.close()
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record: libraries loaded below write banners to file descriptor 1 (RCCL prints its
     # version block there when the first communicator is created), so everything else is sent to stderr
@@ -89,7 +229,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
-                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100"],
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch8", "c3_batch4", "c3_batch2"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,6 +310,9 @@ def main():
 
     shuffle = args.workload.endswith("_shuffled")
     base = args.workload[:-len("_shuffled")] if shuffle else args.workload
+    batch_k = int(base[len("c3_batch"):]) if base.startswith("c3_batch") else 0
+    if batch_k:
+        base = "c3"
     structured = base in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
     if base == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)
@@ -183,7 +326,7 @@ def main():
     # (profiling sessions run the same workload through several rocprofv3 passes: CUOPT_AMD_LP_CACHE=<dir> keeps the generated LP
     # between them -- the generator is deterministic, the cache only saves its minute of host time)
     cache = os.environ.get("CUOPT_AMD_LP_CACHE")
-    cache_file = os.path.join(cache, "%s.npz" % args.workload) if cache else None
+    cache_file = os.path.join(cache, "%s.npz" % (base if batch_k else args.workload)) if cache else None
     if cache_file and os.path.exists(cache_file):
         z = np.load(cache_file, allow_pickle=False)
         p = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
@@ -202,6 +345,11 @@ def main():
             np.savez(cache_file, **{k: v for k, v in p.items() if isinstance(v, (np.ndarray, int, float, bool, np.integer, np.floating))})
     t_gen = time.time() - t_gen
     m, n, nnz = p["m"], p["n"], int(len(p["values"]))
+    if batch_k:
+        if world != 1:
+            sys.exit("bench.py: the shared-matrix batch runs on one GPU")
+        batch_line(args, p, cfg, batch_k, local_rank, record_fd, t_gen)
+        return
 
     # ---- fixed-budget run: iterations / second ------------------------------------------------------
     # A PDLP iteration carries its amortised share of the major-iteration work (every `major_iteration` = 40 steps;
@@ -357,35 +505,9 @@ def main():
         s2.close()
 
     # ---- CPU baseline: the C oracle's PDLP loop on the same LP, bounded iteration budget -----------------
-    # (kind "port": cuOpt ships no CPU PDLP).  Thread counts 16 / 32 / 64 / 128 are tried once each on a 12-iteration
-    # calibration run and the best one gets the ~20 s sample; box cores and threads used are both reported.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # threads pinned to neighbouring cores; the oracle touches its arrays first from the threads that work on them
-        # (oracle/pdlp_oracle.c dalloc / copy_rows_*), so a multi-socket box reads mostly local memory
-        os.environ.setdefault("OMP_PROC_BIND", "close")
-        os.environ.setdefault("OMP_PLACES", "cores")
-        from oracle import orcbind
-        if orcbind.available():
-            try:
-                box_cores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                box_cores = os.cpu_count() or 1
-            sweep = {}
-            for t in sorted({min(t, box_cores) for t in (16, 32, 64, 128)}):
-                o = orcbind.solve(p, tol=0.0, iteration_limit=12, num_threads=t)
-                sweep[t] = o["steps_taken"] / max(o["loop_seconds"], 1e-9)
-            cores = max(sweep, key=sweep.get)
-            # (all 12 calibration steps are major iterations: an under-estimate of the rate, so the sample is bounded)
-            budget = int(min(max(20.0 * sweep[cores], 40), 4000))
-            o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
-            cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
-                       box_cores=box_cores, kind="port",
-                       thread_sweep_calibration_its_per_s={str(k): round(v, 2) for k, v in sweep.items()},
-                       sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d of %d cores), %d iterations of the same "
-                       "LP: loop %.2fs + setup %.2fs" % (cores, box_cores, o["steps_taken"], o["loop_seconds"],
-                                                       o["solve_seconds"] - o["loop_seconds"]))
-            cpu["reference_dual_simplex"] = reference_dual_simplex_block(ROOT)
+        cpu = cpu_baseline_block(p)
 
     if rank == 0:
         info = capi.device_info(local_rank)

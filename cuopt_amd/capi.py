@@ -299,6 +299,13 @@ _proto("pdlpdev_analysis_destroy", None, c_void_p)
 _proto("pdlpdev_debug_sort_pairs", c_int, c_int, C.c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p)
 _proto("pdlpdev_debug_scan", c_int, c_int, C.c_int64, c_void_p, c_void_p)
 _proto("pdlpdev_debug_layout_checksums", c_int, c_void_p, c_void_p)
+# shared-matrix batch (round 5)
+_proto("cuoptamd_solver_clone", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(c_void_p))
+_proto("cuoptamd_batch_create", c_int, c_void_p, c_int, P(c_void_p))
+_proto("cuoptamd_batch_advance", c_int, c_void_p, c_int, c_void_p)
+_proto("cuoptamd_batch_destroy", None, c_void_p)
+_proto("cuoptamd_batch_device", c_void_p, c_void_p)
+_proto("pdlpdev_batch_time_kernels", c_int, c_void_p, c_int, c_void_p)
 _proto("pdlpdev_synthetic_lp", c_int, c_int, c_int, c_int, c_int, C.c_uint64, *([c_void_p] * 8))
 
 # ids of pdlp_device.h
@@ -716,9 +723,73 @@ class Solver:
             out["row_new2old"], out["col_new2old"] = rows, cols
         return out
 
+    def clone(self, lb=None, ub=None, lo=None, hi=None, **setting_overrides):
+        """cuoptamd_solver_clone: a solver for this LP under other bounds (None = this solver's current ones) that shares the
+        matrices on the device; bit for bit a solver freshly created on that LP.  Close the clones before this solver."""
+        arrays = [None if a is None else _f64(a) for a in (lb, ub, lo, hi)]
+        child = Solver.__new__(Solver)
+        child._keep, child.m, child.n, child.hyper = self._keep, self.m, self.n, self.hyper
+        child.settings = default_settings(**setting_overrides) if setting_overrides else self.settings
+        child._parent = self  # (keeps the parent alive)
+        child.handle = c_void_p()
+        rc = lib.cuoptamd_solver_clone(self.handle, _ptr(arrays[0]), _ptr(arrays[1]), _ptr(arrays[2]), _ptr(arrays[3]),
+                                       C.byref(child.settings) if setting_overrides else None, C.byref(child.handle))
+        if rc != 0:
+            child.handle = None
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        child.result = Result()
+        return child
+
     def close(self):
         if self.handle:
             lib.cuoptamd_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SharedMatrixBatch:
+    """cuoptamd_batch: K = 2, 4 or 8 Solvers over ONE matrix (a parent and its clones) advance in lockstep, the matrix streamed once
+    per attempt for all of them; every LP's trajectory is bit-identical to its own Solver.advance.  CuOptError(-7) when the layouts
+    are not eligible (the caller then advances the solvers one by one)."""
+
+    def __init__(self, solvers):
+        self.solvers = list(solvers)
+        k = len(self.solvers)
+        arr = (c_void_p * k)(*[s.handle.value for s in self.solvers])
+        self.handle = c_void_p()
+        rc = lib.cuoptamd_batch_create(arr, k, C.byref(self.handle))
+        if rc != 0:
+            self.handle = None
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+
+    def advance(self, iterations=2 ** 31 - 1):
+        k = len(self.solvers)
+        results = (Result * k)()
+        rc = lib.cuoptamd_batch_advance(self.handle, int(iterations), results)
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        out = []
+        for s, r in zip(self.solvers, results):
+            C.memmove(C.byref(s.result), C.byref(r), C.sizeof(Result))
+            out.append(s.result.as_dict())
+        return out
+
+    def time_kernels(self, reps=20):
+        """average dispatch time (ms) of the four kernels of a batched attempt: dict primal / a_dual / at_step / decisions"""
+        out = np.zeros(4)
+        rc = lib.pdlpdev_batch_time_kernels(c_void_p(lib.cuoptamd_batch_device(self.handle)), int(reps), _ptr(out))
+        if rc != 0:
+            raise CuOptError(rc, lib.pdlpdev_last_error().decode())
+        return dict(zip(("primal", "a_dual", "at_step", "decisions"), out.tolist()))
+
+    def close(self):
+        if self.handle:
+            lib.cuoptamd_batch_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -471,9 +471,20 @@ struct pdlpdev_ctx {
   char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
   size_t arena_used = 0;
   bool small_resident = false;  // whole attempt batches inside one workgroup (k_pdhg_small)
+  bool shared_with_parent = false;  // pdlpdev_clone_shared: matrices, layouts, scaling vectors, c and the stream are another context's
   std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
   std::vector<void*> allocs;
   int64_t bytes = 0;
+};
+
+// one LP's arguments of k_step_decision_batch (pdlp_device.hip; launched by kernels_batch.hip)
+struct pdlpdev_decision_args {
+  pdlpdev_ctl* ctl;
+  const double* part_dy;
+  int nb_dy;
+  const double* part_t;
+  int nb_t;
+  pdlpdev_step_params sp;
 };
 
 constexpr int kGenericBlocks = 1024;

@@ -413,10 +413,9 @@ constexpr int kDecisionThreads = 1024;  // one wide workgroup: every partial is 
 // Latency is all that matters here (one workgroup on the critical path of every attempt): the control block is
 // read once into registers (uniform -> scalar loads) and written back once, the two pow() of the step-size rule
 // are evaluated by the last wave while the others fetch partials, the sums use DPP lane permutes.
-__global__ void __launch_bounds__(kDecisionThreads)
-k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
-                const double* __restrict__ part_t, int nb_t, const double* __restrict__ dy2_reduced,
-                pdlpdev_step_params sp)
+__device__ __forceinline__ void step_decision_workgroup(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
+                                                        const double* __restrict__ part_t, int nb_t, const double* __restrict__ dy2_reduced,
+                                                        const pdlpdev_step_params& sp)
 {
   __shared__ double red[3 * 16];
   __shared__ double pw[2];
@@ -441,6 +440,20 @@ k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_d
   if (t != 0) return;
   apply_step_decision(&lc, dy2_reduced ? dy2_reduced[0] : acc[0], acc[1], acc[2], sp, pw);
   *ctl = lc;
+}
+__global__ void __launch_bounds__(kDecisionThreads)
+k_step_decision(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ part_dy, int nb_dy,
+                const double* __restrict__ part_t, int nb_t, const double* __restrict__ dy2_reduced,
+                pdlpdev_step_params sp)
+{
+  step_decision_workgroup(ctl, part_dy, nb_dy, part_t, nb_t, dy2_reduced, sp);
+}
+// the decisions of the K LPs of a shared-matrix batch (kernels_batch.hip): workgroup <-> LP, each exactly k_step_decision
+__global__ void __launch_bounds__(kDecisionThreads)
+k_step_decision_batch(const pdlpdev_decision_args* __restrict__ args)
+{
+  const pdlpdev_decision_args a = args[blockIdx.x];
+  step_decision_workgroup(a.ctl, a.part_dy, a.nb_dy, a.part_t, a.nb_t, nullptr, a.sp);
 }
 
 // direct peer transport of a sharded solve: wait for every rank's three step-size sums (landed in this rank's block), add them
@@ -1761,11 +1774,11 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
   for (void* p : ctx->allocs) (void)hipFree(p);
-  const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk;
+  const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk && !ctx->shared_with_parent;
   if (!(whole && give_recycled(Recycled{ctx->device, ctx->stream, ctx->scal_h, ctx->first_chunk}))) {
     if (ctx->first_chunk) (void)hipFree(ctx->first_chunk);
     if (ctx->scal_h) (void)hipHostFree(ctx->scal_h);  // ctl_h lives in the same block
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream && !ctx->shared_with_parent) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
 }

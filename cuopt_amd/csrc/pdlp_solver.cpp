@@ -1127,16 +1127,88 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
   return 0;
 }
 
+// One trip of the main loop up to the attempts (pdlp.cu:1099-1222): the major iteration when one is due (termination checks, restart,
+// primal weight), the iteration budget, then what the attempts need (a cleared step error, A^T y of a fresh iterate).  *stop: the
+// solve is over or the budget is used up (s->result says which); otherwise *target = the accepted-step count (the device's) the
+// attempts run to.  cuoptamd_solver_advance runs one LP through it, cuoptamd_batch_advance K of them in lockstep.
+static int advance_to_attempts(cuoptamd_solver* s, int32_t budget_end, int32_t* target_out, bool* stop)
+{
+  const cuoptamd_hyper& H = s->H;
+  *stop = false;
+  const int32_t it = s->total_iterations;
+  if (it >= H.major_iteration && fault_injected(s->rank, s->world, "advance")) return fail(-6, "injected fault (CUOPT_AMD_TUNE=fault_inject)");
+  const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
+  // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
+  const bool artificial = H.artificial_restart_in_main_loop && s->ctl.its_since_restart >= H.artificial_restart_threshold * it;
+  if ((major || artificial || s->step_error) && s->major_done_at != it) {
+    bool terminated = false;
+    int rc          = major_iteration(s, &terminated);
+    if (rc != 0) return rc;
+    s->major_done_at = it;
+    if (terminated) {
+      s->finished = true;
+      log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->result.steps_taken, s->result.primal_objective,
+               s->result.dual_objective, s->result.gap, s->result.l2_primal_residual, s->result.l2_dual_residual,
+               seconds_since(s->solve_start));
+      log_line(s, "PDLP finished: status %d, %d iterations, %d restarts\n", s->result.status, s->result.steps_taken,
+               s->result.num_restarts);
+      *stop = true;
+      return 0;
+    }
+  }
+  if (it >= budget_end) {
+    s->result.status          = kNoTermination;
+    s->result.steps_taken     = s->ctl.steps_taken;
+    s->result.attempted_steps = s->ctl.attempts;
+    s->result.step_size       = s->ctl.step_size;
+    s->result.primal_weight   = s->ctl.primal_weight;
+    *stop = true;
+    return 0;
+  }
+  // ---- take_step(s) up to the next major iteration (pdlp.cu:1187-1222), no host round trips ----
+  int32_t next_major;
+  if (it + 1 <= H.min_iteration_restart || H.artificial_restart_in_main_loop)
+    next_major = it + 1;
+  else
+    next_major = (it / H.major_iteration + 1) * H.major_iteration;
+  const int32_t target = std::min(next_major, budget_end);
+  if (s->step_error) {  // take_step re-arms valid_step_size = 0 (pdlp.cu:1190)
+    s->step_error = false;
+    int rc = pdlpdev_clear_error(s->dev);
+    if (rc != 0) return fail(rc, "pdlpdev_clear_error: %s", pdlpdev_last_error());
+  }
+  if (s->need_aty) {
+    int rc = pdlpdev_compute_aty(s->dev);
+    if (rc != 0) return fail(rc, "pdlpdev_compute_aty: %s", pdlpdev_last_error());
+    s->need_aty = false;
+  }
+  *target_out = target - s->iteration_offset;
+  return 0;
+}
+static void advance_after_attempts(cuoptamd_solver* s)  // (s->ctl: the control block the attempts left)
+{
+  s->total_iterations = s->iteration_offset + s->ctl.steps_taken;
+  if (s->ctl.error) s->step_error = true;
+}
+static void advance_begin(cuoptamd_solver* s, clock_type::time_point t0)
+{
+  if (s->started) return;
+  s->started     = true;
+  s->solve_start = t0;
+  log_line(s, "PDLP on gfx950: %d constraints, %d variables\n", s->m_global, s->n);
+  log_line(s, "   Iter    Primal Obj.      Dual Obj.    Gap        Primal Res.  Dual Res.   Time\n");  // pdlp.cu:1077-1080
+}
+static int32_t advance_budget_end(const cuoptamd_solver* s, int32_t max_new_iterations)
+{
+  const int64_t budget_end64 = (int64_t)s->total_iterations + std::max<int64_t>(max_new_iterations, 0);
+  return (int32_t)std::min<int64_t>(budget_end64, std::numeric_limits<int32_t>::max());
+}
+
 int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result)
 {
   if (!s) return fail(-1, "cuoptamd_solver_advance: null solver");
   const auto t0 = clock_type::now();
-  if (!s->started) {
-    s->started     = true;
-    s->solve_start = t0;
-    log_line(s, "PDLP on gfx950: %d constraints, %d variables\n", s->m_global, s->n);
-    log_line(s, "   Iter    Primal Obj.      Dual Obj.    Gap        Primal Res.  Dual Res.   Time\n");  // pdlp.cu:1077-1080
-  }
+  advance_begin(s, t0);
   auto leave = [&](int rc) {
     s->result.gpus = s->world;
     s->result.loop_seconds += seconds_since(t0);
@@ -1149,61 +1221,121 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
     return leave(0);
   }
   if (s->finished) return leave(0);
-  const cuoptamd_hyper& H = s->H;
-  const int64_t budget_end64 = (int64_t)s->total_iterations + std::max<int64_t>(max_new_iterations, 0);
-  const int32_t budget_end   = (int32_t)std::min<int64_t>(budget_end64, std::numeric_limits<int32_t>::max());
+  const int32_t budget_end = advance_budget_end(s, max_new_iterations);
   for (;;) {
-    const int32_t it = s->total_iterations;
-    if (it >= H.major_iteration && fault_injected(s->rank, s->world, "advance"))
-      return leave(fail(-6, "injected fault (CUOPT_AMD_TUNE=fault_inject)"));
-    const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
-    // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
-    const bool artificial = H.artificial_restart_in_main_loop &&
-                            s->ctl.its_since_restart >= H.artificial_restart_threshold * it;
-    if ((major || artificial || s->step_error) && s->major_done_at != it) {
-      bool terminated = false;
-      int rc          = major_iteration(s, &terminated);
-      if (rc != 0) return leave(rc);
-      s->major_done_at = it;
-      if (terminated) {
-        s->finished = true;
-        log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->result.steps_taken, s->result.primal_objective,
-                 s->result.dual_objective, s->result.gap, s->result.l2_primal_residual, s->result.l2_dual_residual,
-                 seconds_since(s->solve_start));
-        log_line(s, "PDLP finished: status %d, %d iterations, %d restarts\n", s->result.status, s->result.steps_taken,
-                 s->result.num_restarts);
-        return leave(0);
-      }
-    }
-    if (it >= budget_end) {
-      s->result.status          = kNoTermination;
-      s->result.steps_taken     = s->ctl.steps_taken;
-      s->result.attempted_steps = s->ctl.attempts;
-      s->result.step_size       = s->ctl.step_size;
-      s->result.primal_weight   = s->ctl.primal_weight;
-      return leave(0);
-    }
-    // ---- take_step(s) up to the next major iteration (pdlp.cu:1187-1222), no host round trips ----
-    int32_t next_major;
-    if (it + 1 <= H.min_iteration_restart || H.artificial_restart_in_main_loop)
-      next_major = it + 1;
-    else
-      next_major = (it / H.major_iteration + 1) * H.major_iteration;
-    const int32_t target = std::min(next_major, budget_end);
-    if (s->step_error) {  // take_step re-arms valid_step_size = 0 (pdlp.cu:1190)
-      s->step_error = false;
-      int rc = pdlpdev_clear_error(s->dev);
-      if (rc != 0) return leave(fail(rc, "pdlpdev_clear_error: %s", pdlpdev_last_error()));
-    }
-    if (s->need_aty) {
-      int rc = pdlpdev_compute_aty(s->dev);
-      if (rc != 0) return leave(fail(rc, "pdlpdev_compute_aty: %s", pdlpdev_last_error()));
-      s->need_aty = false;
-    }
-    int rc = pdlpdev_run(s->dev, target - s->iteration_offset, &s->ctl);
+    int32_t target = 0;
+    bool stop      = false;
+    int rc         = advance_to_attempts(s, budget_end, &target, &stop);
+    if (rc != 0 || stop) return leave(rc);
+    rc = pdlpdev_run(s->dev, target, &s->ctl);
     if (rc != 0) return leave(fail(rc, "pdlpdev_run: %s", pdlpdev_last_error()));
-    s->total_iterations = s->iteration_offset + s->ctl.steps_taken;
-    if (s->ctl.error) s->step_error = true;
+    advance_after_attempts(s);
+  }
+}
+
+// ---- K LPs over ONE matrix and objective in lockstep (kernels_batch.hip) --------------------------------------------------------
+struct cuoptamd_batch {
+  int K = 0;
+  cuoptamd_solver* s[8] = {nullptr};
+  pdlpdev_batch* dev = nullptr;
+};
+
+int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const double* ub, const double* lo, const double* hi,
+                          const cuoptamd_settings* settings, cuoptamd_solver** out)
+{
+  if (!parent || !out) return fail(-1, "cuoptamd_solver_clone: null argument");
+  if (parent->empty_problem || !parent->dev || parent->world != 1) return fail(-7, "cuoptamd_solver_clone: not for empty or sharded solvers");
+  pdlpdev_ctx* dev = nullptr;
+  int rc           = pdlpdev_clone_shared(&dev, parent->dev);
+  if (rc != 0) {
+    if (dev) pdlpdev_destroy(dev);
+    return fail(rc, "pdlpdev_clone_shared: %s", pdlpdev_last_error());
+  }
+  cuoptamd_solver* s = new cuoptamd_solver(*parent);
+  s->dev             = dev;
+  rc = cuoptamd_solver_reset(s, lb, ub, lo, hi, settings, nullptr, nullptr);
+  if (rc != 0) {
+    cuoptamd_solver_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+int cuoptamd_batch_create(cuoptamd_solver** solvers, int K, cuoptamd_batch** out)
+{
+  if (!solvers || !out || K < 1 || K > 8) return fail(-1, "cuoptamd_batch_create: 2, 4 or 8 solvers");
+  pdlpdev_ctx* ctx[8];
+  for (int l = 0; l < K; ++l) {
+    if (!solvers[l] || !solvers[l]->dev) return fail(-1, "cuoptamd_batch_create: null solver");
+    ctx[l] = solvers[l]->dev;
+  }
+  pdlpdev_batch* dev = nullptr;
+  int rc             = pdlpdev_batch_create(&dev, ctx, K);
+  if (rc != 0) {
+    if (dev) pdlpdev_batch_destroy(dev);
+    return fail(rc, "%s", pdlpdev_last_error());
+  }
+  cuoptamd_batch* b = new cuoptamd_batch();
+  b->K = K, b->dev = dev;
+  for (int l = 0; l < K; ++l) b->s[l] = solvers[l];
+  *out = b;
+  return 0;
+}
+
+pdlpdev_batch* cuoptamd_batch_device(cuoptamd_batch* b) { return b ? b->dev : nullptr; }
+
+void cuoptamd_batch_destroy(cuoptamd_batch* b)
+{
+  if (!b) return;
+  pdlpdev_batch_destroy(b->dev);
+  delete b;
+}
+
+// every LP of the batch up to max_new_iterations further iterations (or to its verdict); results[l] as cuoptamd_solver_advance's.
+// An LP that finishes rests while the others go on; each LP's trajectory is the one its own cuoptamd_solver_advance would take.
+int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuoptamd_result* results)
+{
+  if (!b) return fail(-1, "cuoptamd_batch_advance: null batch");
+  const auto t0 = clock_type::now();
+  const int K   = b->K;
+  int32_t budget_end[8], target[8];
+  bool done[8];
+  for (int l = 0; l < K; ++l) {
+    cuoptamd_solver* s = b->s[l];
+    advance_begin(s, t0);
+    done[l]       = s->finished;
+    budget_end[l] = advance_budget_end(s, max_new_iterations);
+  }
+  auto leave = [&](int rc) {
+    const double dt = seconds_since(t0);
+    for (int l = 0; l < K; ++l) {
+      b->s[l]->result.gpus = 1;
+      b->s[l]->result.loop_seconds += dt;  // (wall time of the batch: the LPs ran side by side)
+      if (results) results[l] = b->s[l]->result;
+    }
+    return rc;
+  };
+  pdlpdev_ctl ctl[8];
+  for (;;) {
+    bool any = false;
+    for (int l = 0; l < K; ++l) {
+      target[l] = 0;
+      if (done[l]) continue;
+      bool stop = false;
+      int rc    = advance_to_attempts(b->s[l], budget_end[l], &target[l], &stop);
+      if (rc != 0) return leave(rc);
+      if (stop) done[l] = true, target[l] = 0;
+      else any = true;
+    }
+    if (!any) return leave(0);
+    int rc = pdlpdev_batch_run(b->dev, target, ctl);
+    if (rc != 0) return leave(fail(rc, "pdlpdev_batch_run: %s", pdlpdev_last_error()));
+    for (int l = 0; l < K; ++l)
+      if (target[l] > 0) {
+        b->s[l]->ctl = ctl[l];
+        advance_after_attempts(b->s[l]);
+      }
   }
 }
 

@@ -267,6 +267,26 @@ int pdlpdev_compute_aty(pdlpdev_ctx* ctx);
  * done.  Returns the control block in *ctl. */
 int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl);
 int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
+/* ---- K LPs over ONE matrix and objective advance together (round 5; the MIP heuristics' pattern, cpp/src/mip/relaxed_lp/
+ * relaxed_lp.cu:53-127: the same A and c under different bounds; the reference builds a solver per call and its batch entry point,
+ * cython_solve.cu:264-296, is a thread pool of independent solves).
+ * pdlpdev_clone_shared: a context for another LP over the parent's matrices, layouts, scaling vectors and c (shared, read-only: the
+ * parent must outlive its clones and must not be reset or re-scaled while they exist); iterates, bounds, sums, control block are the
+ * clone's own.  It starts with the parent's bounds: pdlpdev_reset(clone, lb, ub, lo, hi) gives it its own.  Single GPU only.
+ * pdlpdev_batch_create: K = 2, 4 or 8 such contexts (ctx[0] may be the parent).  The two products of an attempt then serve all K LPs
+ * from ONE pass over the matrix: the K gathered vectors are interleaved, a row belongs to a group of K lanes, one 64-byte request
+ * fetches a column's entry of eight LPs.  Each LP's trajectory is BIT-IDENTICAL to the one pdlpdev_run gives it (same row sums, same
+ * epilogue expressions, the panel kernels' per-workgroup reduction trees reproduced).  -7: not eligible -- both matrices must be in
+ * the row-sum variant of the panel layout with no row beyond 128 entries and no dense segments, columns ascending within rows.
+ * pdlpdev_batch_run: attempts until LP l holds targets[l] accepted steps (<= 0: LP l rests); ctl[l] receives its control block. */
+typedef struct pdlpdev_batch pdlpdev_batch;
+int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent);
+int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K);
+int pdlpdev_batch_run(pdlpdev_batch* batch, const int32_t* targets, pdlpdev_ctl* ctl);
+void pdlpdev_batch_destroy(pdlpdev_batch* batch);
+/* average dispatch durations (ms) of the four kernels of a batched attempt {primal, A / dual, A^T / step, decisions}: whole attempts in
+ * the loop's order, every LP forced active, the dispatches' own timestamps; state is put back (bench.py's roofline of the batch line) */
+int pdlpdev_batch_time_kernels(pdlpdev_batch* batch, int reps, double avg_ms[4]);
 /* re-arm the loop after the step-size error flag was raised (take_step resets valid_step_size_,
  * pdlp.cu:1190) */
 int pdlpdev_clear_error(pdlpdev_ctx* ctx);

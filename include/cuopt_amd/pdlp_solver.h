@@ -236,6 +236,26 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
  * "budget exhausted, not terminated"; calling again continues exactly where it stopped. */
 int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuoptamd_result* result);
 
+/* ---- shared-matrix batch (round 5): K LPs that differ in their bounds only are solved in lockstep, the matrix streamed once per
+ * attempt for all of them (pdlpdev_batch_* in pdlp_device.h; the MIP heuristics' re-solve pattern, relaxed_lp.cu:53-127).
+ * cuoptamd_solver_clone: a solver for the parent's LP with other bounds (NULL = the parent's CURRENT ones; settings NULL = the
+ * parent's) that shares the parent's matrices on the device; behaves bit for bit like a solver freshly created on that LP.  Destroy
+ * the clones before the parent; do not reset the parent while clones exist.  -7: empty or sharded parent.
+ * cuoptamd_batch_create: K = 2, 4 or 8 solvers over one matrix (a parent and its clones, none advanced by hand in between is NOT
+ * required: a batch may be created over solvers in any state).  -7 when the layouts are not eligible (pdlp_device.h): the caller
+ * falls back to cuoptamd_solver_advance per solver or to cuoptamd_batch_solve.
+ * cuoptamd_batch_advance: every solver up to max_new_iterations further iterations or to its verdict; results[l] as
+ * cuoptamd_solver_advance would fill it (loop_seconds: the wall time of the batch).  Solutions through the solvers' own getters.
+ * cuoptamd_batch_destroy leaves the solvers alive. */
+typedef struct cuoptamd_batch cuoptamd_batch;
+int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const double* ub, const double* lo, const double* hi,
+                          const cuoptamd_settings* settings, cuoptamd_solver** out);
+int cuoptamd_batch_create(cuoptamd_solver** solvers, int K, cuoptamd_batch** out);
+int cuoptamd_batch_advance(cuoptamd_batch* batch, int32_t max_new_iterations, cuoptamd_result* results);
+void cuoptamd_batch_destroy(cuoptamd_batch* batch);
+/* the device-layer batch behind it (pdlpdev_batch_time_kernels) */
+struct pdlpdev_batch* cuoptamd_batch_device(cuoptamd_batch* batch);
+
 /* Fills *ws (get_filled_warmed_start_data, pdlp.cu:468-489) from a solver whose last advance terminated.
  * Single-GPU solvers only. */
 int cuoptamd_solver_get_warm_start(cuoptamd_solver* s, cuoptamd_warm_start* ws);

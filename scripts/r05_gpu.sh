@@ -50,6 +50,30 @@ for k, cs in acc.items():
         print("  %-18s %-24s %s" % (k, c, " ".join("%.0f" % x for x in v)))
 PYEOF
                cat "$OUT/r05_gather_calibration.txt"; rm -rf "$OUT/gcal_fetch" "$OUT/gcal_req" ;;
+    batchprobe) timeout 900 python scripts/r05_batch_probe.py $(echo "$arg" | tr ',' ' ') > "$OUT/batchprobe.log" 2>&1; grep -E "RATE|Traceback|Error|assert" "$OUT/batchprobe.log" | cut -c1-300 ;;
+    batchprof) R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/batchprof" -- env BATCH_PROBE_GRAPH=0 python "$R/scripts/r05_batch_probe.py" $arg > "$R/$OUT/batchprof.log" 2>&1)
+          F=$(find "$OUT/batchprof" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/r05_batch_${arg}_kernel_stats.csv" && head -n 12 "$F" | cut -c1-160; rm -rf "$OUT/batchprof" ;;
+    batchspmv) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/batch_spmv_probe.hip -o /tmp/batch_spmv_probe > "$OUT/batch_spmv_build.log" 2>&1
+               for a in $(echo "$arg" | tr ',' ' '); do timeout 300 /tmp/batch_spmv_probe $a >> "$OUT/r05_batch_spmv_probe.txt" 2>&1; done; cat "$OUT/r05_batch_spmv_probe.txt" ;;
+    batchspmvpmc) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/batch_spmv_probe.hip -o /tmp/batch_spmv_probe > "$OUT/batch_spmv_build.log" 2>&1
+               R=$PWD; i=0
+               for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+                 i=$((i+1))
+                 (cd /tmp && timeout -k 5 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/bsp_pmc_$i" -- /tmp/batch_spmv_probe $arg > "$R/$OUT/bsp_pmc_$i.log" 2>&1)
+               done
+               python - "$OUT" > "$OUT/r05_batch_spmv_pmc.txt" <<'PYEOF'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("%s/bsp_pmc_*/*/*_counter_collection.csv" % out):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print("   %-32s mean %.4g  (first %.4g, n %d)" % (c, sum(v) / len(v), v[0], len(v)))
+PYEOF
+               cat "$OUT/r05_batch_spmv_pmc.txt" | cut -c1-150; rm -rf "$OUT"/bsp_pmc_? ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -1,0 +1,134 @@
+"""GPU: K LPs over ONE matrix in lockstep (cuoptamd_solver_clone / cuoptamd_batch_*; kernels_batch.hip) -- BASELINE config 5's
+pattern: the MIP heuristics re-solve the same A and c under different bounds (cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-127); the
+reference's batch entry point is a thread pool of independent solves (cython_solve.cu:264-296), each of which must give what a
+single solve gives.  Pinned here: every LP of a batch takes, BIT FOR BIT, the trajectory of a solver freshly created on that LP
+-- iterates, step sizes, restarts, verdicts -- although the two products of an attempt serve all K LPs from one pass over the
+matrix (interleaved gather vectors, the panel kernels' reduction trees reproduced)."""
+import numpy as np
+import pytest
+
+from cuopt_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+LIMIT = 4000
+
+
+def variants(p, k, seed=3):
+    """k LPs over p's matrix: the first is p itself, the others tighten some bounds around the known optimum (feasible, same
+    optimal value, different trajectories) -- and one of them loosens nothing but fixes a few variables at 0 (may change the
+    optimum: verdicts need not agree between the LPs, only with their own single solves)"""
+    rng = np.random.default_rng(seed)
+    x = p["x_star"]
+    out = [(np.array(p["lb"], float), np.array(p["ub"], float))]
+    for l in range(1, k):
+        lb, ub = np.array(p["lb"], float), np.array(p["ub"], float)
+        cols = rng.choice(p["n"], size=p["n"] // (4 + l), replace=False)
+        for j in cols:
+            if l % 3 == 2:
+                ub[j] = lb[j] if np.isfinite(lb[j]) else ub[j]
+            elif rng.random() < 0.5:
+                ub[j] = x[j] + 0.3 * rng.random()
+            else:
+                lb[j] = max(lb[j], x[j] - 0.3 * rng.random())
+        out.append((lb, ub))
+    return out
+
+
+KEYS_INT = ("status", "steps_taken", "attempted_steps", "num_restarts", "num_major_iterations")
+KEYS_F64 = ("primal_objective", "dual_objective", "gap", "l2_primal_residual", "l2_dual_residual", "step_size", "primal_weight",
+            "initial_step_size", "initial_primal_weight")
+
+
+def same(a, b, sa, sb, what):
+    for k in KEYS_INT + KEYS_F64:
+        assert a[k] == b[k], (what, k, a[k], b[k])
+    for u, v, name in zip(sa, sb, "xyz"):
+        np.testing.assert_array_equal(u, v, err_msg="%s: %s" % (what, name))
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_batch_trajectories_are_bit_identical_to_single_solves(k, monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(30000, 24000, 10, seed=21)
+    bounds = variants(p, k)
+    # the single solves: the state after 130 iterations (mid-way between two major iterations) and the end
+    single = []
+    for lb, ub in bounds:
+        s = capi.Solver(dict(p, lb=lb, ub=ub), tol=1e-5, iteration_limit=LIMIT)
+        lay = s.device.layout()
+        assert lay["A"]["layout"] == "panel" and lay["At"]["layout"] == "panel", lay
+        a = s.advance(130)
+        sa = s.solution()
+        b = s.advance()
+        single.append((a, sa, b, s.solution()))
+        s.close()
+    parent = capi.Solver(dict(p, lb=bounds[0][0], ub=bounds[0][1]), tol=1e-5, iteration_limit=LIMIT)
+    solvers = [parent] + [parent.clone(lb=lb, ub=ub) for lb, ub in bounds[1:]]
+    batch = capi.SharedMatrixBatch(solvers)
+    got = batch.advance(130)
+    for l in range(k):
+        same(got[l], single[l][0], solvers[l].solution(), single[l][1], "LP %d after 130 iterations" % l)
+    got = batch.advance()
+    for l in range(k):
+        same(got[l], single[l][2], solvers[l].solution(), single[l][3], "LP %d at the end" % l)
+    assert got[0]["status_name"] == "Optimal"
+    assert len({g["steps_taken"] for g in got}) > 1  # (the LPs finish at different times: some rested while others went on)
+    # a second round through the same objects: the clones reset to other bounds, the batch re-created
+    batch.close()
+    for l in range(1, k):
+        lb, ub = bounds[(l + 1) % k if (l + 1) % k else 1]
+        solvers[l].reset(lb=lb, ub=ub, tol=1e-5, iteration_limit=LIMIT)
+    parent.reset(tol=1e-5, iteration_limit=LIMIT)
+    batch = capi.SharedMatrixBatch(solvers)
+    got = batch.advance()
+    same(got[0], single[0][2], parent.solution(), single[0][3], "parent, second round")
+    for l in range(1, k):
+        src = (l + 1) % k if (l + 1) % k else 1
+        same(got[l], single[src][2], solvers[l].solution(), single[src][3], "LP %d, second round" % l)
+    batch.close()
+    for s in solvers[1:]:
+        s.close()
+    parent.close()
+
+
+def test_clone_alone_is_a_fresh_solver_and_row_bounds_travel(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(9000, 7000, 8, seed=4)
+    lo = np.where(np.isfinite(p["lo"]), p["lo"] - 0.25, p["lo"])
+    hi = np.where(np.isfinite(p["hi"]), p["hi"] + 0.5, p["hi"])
+    parent = capi.Solver(p, tol=1e-6, iteration_limit=LIMIT)
+    child = parent.clone(lo=lo, hi=hi)
+    fresh = capi.Solver(dict(p, lo=lo, hi=hi), tol=1e-6, iteration_limit=LIMIT)
+    a, b = child.advance(), fresh.advance()
+    same(a, b, child.solution(), fresh.solution(), "clone with new row bounds")
+    # the parent is untouched by its clone's solve
+    c = parent.advance()
+    again = capi.Solver(p, tol=1e-6, iteration_limit=LIMIT)
+    d = again.advance()
+    same(c, d, parent.solution(), again.solution(), "parent after the clone's solve")
+    # the two in a batch of 2 (different row bounds)
+    parent.reset(tol=1e-6, iteration_limit=LIMIT)
+    child.reset(tol=1e-6, iteration_limit=LIMIT)
+    batch = capi.SharedMatrixBatch([parent, child])
+    got = batch.advance()
+    same(got[0], d, parent.solution(), again.solution(), "batch of 2: parent")
+    same(got[1], b, child.solution(), fresh.solution(), "batch of 2: clone")
+    batch.close(), child.close(), parent.close()
+
+
+def test_not_eligible_layouts_are_refused():
+    p = synthetic.generate(20000, 20000, 10, seed=2, band=500)
+    parent = capi.Solver(p, tol=1e-4, iteration_limit=200)
+    lay = parent.device.layout()
+    assert not (lay["A"]["layout"] == "panel" and lay["At"]["layout"] == "panel"), lay  # (a band: jagged rows or the CSR stream)
+    child = parent.clone()
+    with pytest.raises(capi.CuOptError) as e:
+        capi.SharedMatrixBatch([parent, child])
+    assert e.value.code == -7
+    # ... and the solvers are still good one by one
+    a, b = parent.advance(), child.advance()
+    same(a, b, parent.solution(), child.solution(), "clone of a solver outside the panels")
+    child.close(), parent.close()
+    with pytest.raises(capi.CuOptError):
+        capi.SharedMatrixBatch([capi.Solver(synthetic.generate(600, 500, 6, seed=1))] * 3)  # K = 3
