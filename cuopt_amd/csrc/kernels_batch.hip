@@ -1,20 +1,30 @@
 // Shared-matrix batched PDHG (round 5; BASELINE config 5's pattern: the MIP heuristics re-solve the SAME A and c under different bounds,
 // cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-127; the reference builds a solver per call, its batch entry point -- cython_solve.cu:264-296 --
-// is a thread pool of independent solves).  K LPs that share the matrix advance together:
+// is a thread pool of independent solves).  K = 2, 4 or 8 LPs that share the matrix advance together:
 //   * every LP keeps a full context of its own (pdlpdev_clone_shared: the matrices, their layouts, D_r, D_c and c are the parent's,
-//     read-only; iterates, bounds, sums, control block, partials are the clone's) -- everything outside the two products runs through
-//     the single-LP kernels, untouched: the primal step, the step decision, the major iterations;
-//   * the two products of an attempt serve all K LPs at once.  The gather that bounds the unstructured SpMV is request-rate bound
-//     (one 128-byte line per miss for 8 useful bytes: profiles/r05_gather_calibration.txt), so the K gathered vectors are
-//     INTERLEAVED (v[j * K + l]) and a ROW belongs to a group of K lanes: lane l adds up LP l's row sum left to right (the single
-//     solve's order for rows of <= 128 entries), a nonzero's value and column are one broadcast load for the group, its gather ONE
-//     64-byte request that serves eight LPs; the matrix is streamed once per K LPs.
-//   * the trajectories are BIT-IDENTICAL to the single solves': the fused epilogues are the single kernels' expressions, and the
-//     per-workgroup partial sums reproduce the panel kernels' grouping exactly -- workgroup <-> row panel (the single layout's own
-//     panel boundaries), "virtual thread" t = row mod 512 accumulates its rows in ascending order, the 512 accumulators of an LP go
-//     through the same wave tree (ds_swizzle butterflies) and the same wave-by-wave sum as block_reduce.  Hence the restriction:
-//     both matrices in the row-sum variant of the panels, no row longer than 128 entries, no dense segments (else: not eligible, the
-//     caller keeps its independent solves).
+//     read-only; iterates, bounds, sums, control block, partials are the clone's): the major iterations -- KKT evaluation, restarts,
+//     the primal weight -- run through the single-LP code, untouched, LP by LP;
+//   * an attempt is FOUR launches for all K LPs: kb_primal (the K primal steps, xbar written interleaved), kb_a_dual and kb_at_step
+//     (the two products, fused with the K dual steps / step-size sums), k_step_decision_batch (K workgroups, each k_step_decision);
+//   * the two products serve all K LPs from ONE pass over the matrix.  The K gathered vectors are INTERLEAVED (v[j * K + l]): a
+//     nonzero's gather is one 64-byte request (K = 8) for all LPs instead of K requests of 8 bytes -- the request rate is what bounds
+//     the unstructured single-LP product (profiles/r05_gather_calibration.txt);
+//   * the trajectories are BIT-IDENTICAL to the single solves': rows are summed left to right (the single kernels' order for rows
+//     of <= 128 entries), the fused epilogues are the single kernels' expressions, and the per-workgroup partial sums reproduce the
+//     panel kernels' grouping exactly -- workgroup <-> row panel (the single layout's own boundaries), lane t of an LP's wave
+//     accumulates rows t, t + 512, ... in ascending order, the same wave tree (ds_swizzle butterflies) and wave-by-wave sum as
+//     block_reduce.  Hence the restriction: both matrices in the row-sum variant of the panels, no row beyond 128 entries, no dense
+//     segments, columns ascending within rows (else: not eligible, the caller keeps its independent solves).
+// What it buys (C3, 1e6 x 1e6, 1e7 nonzeros; profiles/r05_bench_lines.jsonl, c3_batch8): 10.3 k iterations/s aggregate over 8 LPs
+// against 6.0 k for one -- 1.71x; K = 4: 1.24x; K = 2: 0.80x (two single solves are faster).  Why not more: only the MATRIX is
+// shared.  A lockstep iteration of 8 LPs moves 1.85 GB at the fused floor (0.24 GB of matrix once, 8 x 0.18 GB of vectors, the
+// interleaved copies) against 0.42 GB for one LP: at EQUAL fractions of the HBM roofline the ceiling is 8 x 0.42 / 1.85 = 1.80x, and
+// both run at 0.30 of it.  The products themselves sit at ~300 us whatever their internal structure (row walk / LDS-staged chunks /
+// autonomous waves, 1 to 32 gathers in flight, 2 or 4 workgroups per CU: tools/batch_spmv_probe.hip, profiles/r05_batch_spmv_probe.txt):
+// 1e7 gathered 128-byte lines from beyond L2 (the interleaved vector is 64 MB; an XCD's L2 holds 4) + 0.5 GB of streams ~ 1.8 GB
+// at ~6 TB/s.  The single-LP panels avoid those line fills by sweeping 1.33 MB column slabs in step across the chip; eight
+// interleaved vectors would need 46 slabs and a sweep synchronised to +-3 %: with the epilogue phases in between it does not hold
+// (window-major orders in the probe: no gain once the epilogue is in).
 #include <hip/hip_runtime.h>
 
 #include "pdlp_ctx.hpp"

@@ -152,11 +152,11 @@ __global__ void __launch_bounds__(T) k_v1(const int* row0, const int* off, const
 // V5: the panel kernel's structure, K wide.  The matrix is read coalesced, a chunk of CH entries at a time, and handed round through
 // LDS; the K lanes of a group gather one entry's 64 bytes; the products go to LDS; lane (g, l) adds its rows' products left to right
 // from there (row sums in registers).  One barrier per chunk: the next chunk's gathers fly while the previous chunk's row sums run.
-template <bool EPI>
+template <bool EPI, int CH = 512>
 __global__ void __launch_bounds__(T) k_v5(const int* row0, const int* off, const int* idx, const double* val, Lps P, const double* xK, double* yK)
 {
-  constexpr int CH = 512, PER = CH / G;
-  __shared__ double prod[2][CH][K];
+  constexpr int PER = CH / G;
+  __shared__ double prod[2][CH][K];  // (>= 32 KB: the final reduction's accs[K][T] lives here)
   __shared__ int scol[2][CH];
   __shared__ double sval[2][CH];
   const int w = blockIdx.x, l = threadIdx.x % K, g = threadIdx.x / K, tid = threadIdx.x;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(T) k_v5(const int* row0, const int* off, const
     }
     const int eb0 = off[r0 + b0], eb1 = off[r0 + (b0 + T < nr ? b0 + T : nr)];
     const int nch = (eb1 - eb0 + CH - 1) / CH;
-    if (eb0 + tid < eb1) scol[0][tid] = idx[eb0 + tid], sval[0][tid] = val[eb0 + tid];
+    if (tid < CH && eb0 + tid < eb1) scol[0][tid] = idx[eb0 + tid], sval[0][tid] = val[eb0 + tid];
     __syncthreads();
     auto rowsum = [&](int cc) {
       const int c0 = eb0 + cc * CH, c1 = c0 + CH < eb1 ? c0 + CH : eb1, pb = cc & 1;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(T) k_v5(const int* row0, const int* off, const
         const int ee = g + G * i < cnt ? g + G * i : 0;
         pv[i]        = xK[(size_t)scol[buf][ee] * K + l];
       }
-      const int en = c0 + CH + tid < eb1 ? c0 + CH + tid : c0;
+      const int en = tid < CH && c0 + CH + tid < eb1 ? c0 + CH + tid : c0;
       const int ncol = idx[en];
       const double nval = val[en];
       if (c > 0) rowsum(c - 1);
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(T) k_v5(const int* row0, const int* off, const
         const int ee = g + G * i < cnt ? g + G * i : 0;
         prod[buf][g + G * i][l] = sval[buf][ee] * pv[i];
       }
-      scol[buf ^ 1][tid] = ncol, sval[buf ^ 1][tid] = nval;
+      if (tid < CH) scol[buf ^ 1][tid] = ncol, sval[buf ^ 1][tid] = nval;
       __syncthreads();
     }
     if (nch > 0) rowsum(nch - 1);
@@ -518,6 +518,8 @@ int main(int argc, char** argv)
   }
   run("v5 staged through LDS", [&] { k_v5<true><<<W, T>>>(d_row0, d_off, d_idx, d_val, P, d_xK, d_yK); }, false);
   run("v5 without epilogue", [&] { k_v5<false><<<W, T>>>(d_row0, d_off, d_idx, d_val, P, d_xK, d_yK); }, false);
+  run("v5, chunks of 256", [&] { k_v5<true, 256><<<W, T>>>(d_row0, d_off, d_idx, d_val, P, d_xK, d_yK); }, false);
+  run("v5, chunks of 256, no epilogue", [&] { k_v5<false, 256><<<W, T>>>(d_row0, d_off, d_idx, d_val, P, d_xK, d_yK); }, false);
   {  // feasibility of a column-window sweep: every panel's entries re-ordered window-major (the row sums are then meaningless: timing only)
     std::vector<int> widx(nnz + 1);
     std::vector<double> wval(nnz + 1);
