@@ -1637,12 +1637,95 @@ int cuoptamd_warm_start_remap(const cuoptamd_warm_start* in, const int32_t* var_
   return 0;
 }
 
+}  // extern "C"
+
+// cuoptamd_batch_solve's path for LPs over one matrix and objective.  kNotShared: they are not (or the layouts are not the batch's):
+// nothing was done, the caller solves them independently.
+static constexpr int kNotShared = 12345;
+static int shared_matrix_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper, const cuoptamd_settings* settings, int device,
+                                     cuoptamd_result* results, double** x, double** y, double** rc)
+{
+  const cuoptamd_lp& L0 = lps[0];
+  if (L0.m <= 0 || L0.n <= 0) return kNotShared;
+  const size_t nnz = (size_t)L0.offsets[L0.m];
+  for (int i = 1; i < count; ++i) {
+    const cuoptamd_lp& L = lps[i];
+    if (L.m != L0.m || L.n != L0.n || L.maximize != L0.maximize || L.objective_offset != L0.objective_offset) return kNotShared;
+    auto same = [](const void* a, const void* b, size_t bytes) { return a == b || memcmp(a, b, bytes) == 0; };
+    if (!same(L.offsets, L0.offsets, ((size_t)L0.m + 1) * sizeof(int32_t)) || !same(L.indices, L0.indices, nnz * sizeof(int32_t)) ||
+        !same(L.values, L0.values, nnz * sizeof(double)) || !same(L.c, L0.c, (size_t)L0.n * sizeof(double)))
+      return kNotShared;
+  }
+  struct Slots {  // slot 0: the parent (created on LP 0), slots 1..7: clones of it -- destroyed before it
+    std::vector<cuoptamd_solver*> s;
+    ~Slots() { for (size_t i = s.size(); i-- > 0;) cuoptamd_solver_destroy(s[i]); }
+  } slots;
+  {
+    cuoptamd_solver* parent = nullptr;
+    int rc_ = cuoptamd_solver_create(&parent, &L0, hyper, settings, nullptr, nullptr, device, 0, 1, nullptr);
+    if (parent) slots.s.push_back(parent);
+    if (rc_ != 0) return rc_;
+  }
+  // the solver of slot q takes LP i: the parent as created (i = 0), a new clone, or an existing solver reset to LP i's bounds
+  auto take = [&](int q, int i) -> int {
+    const cuoptamd_lp& L = lps[i];
+    if (i == 0) return 0;
+    if (q < (int)slots.s.size()) return cuoptamd_solver_reset(slots.s[q], L.lb, L.ub, L.lo, L.hi, settings, nullptr, nullptr);
+    cuoptamd_solver* s = nullptr;
+    int rc_ = cuoptamd_solver_clone(slots.s[0], L.lb, L.ub, L.lo, L.hi, settings, &s);
+    if (rc_ == 0) slots.s.push_back(s);
+    return rc_;
+  };
+  auto solution = [&](int q, int i) { return cuoptamd_solver_get_solution(slots.s[q], x ? x[i] : nullptr, y ? y[i] : nullptr, rc ? rc[i] : nullptr); };
+  int done = 0;
+  bool lockstep = true;
+  while (done < count) {
+    const int left = count - done;
+    const int K    = lockstep && left >= 8 ? 8 : lockstep && left >= 4 ? 4 : 1;
+    for (int q = 0; q < K; ++q) {
+      int rc_ = take(q, done + q);
+      if (rc_ == -7 && done == 0) return kNotShared;  // (a resident small-LP solver has no clones: nothing is lost, solve independently)
+      if (rc_ != 0) return rc_;
+    }
+    cuoptamd_batch* b = nullptr;
+    if (K > 1) {
+      int rc_ = cuoptamd_batch_create(slots.s.data(), K, &b);
+      if (rc_ == -7) lockstep = false;  // the layouts are not the batch's: the clones still save the set-ups, one LP after the other
+      else if (rc_ != 0) return rc_;
+    }
+    if (b) {
+      int rc_ = cuoptamd_batch_advance(b, std::numeric_limits<int32_t>::max(), &results[done]);
+      cuoptamd_batch_destroy(b);
+      if (rc_ != 0) return rc_;
+    } else {
+      for (int q = 0; q < K; ++q) {
+        int rc_ = cuoptamd_solver_advance(slots.s[q], std::numeric_limits<int32_t>::max(), &results[done + q]);
+        if (rc_ != 0) return rc_;
+      }
+    }
+    for (int q = 0; q < K; ++q) {
+      int rc_ = solution(q, done + q);
+      if (rc_ != 0) return rc_;
+    }
+    done += K;
+  }
+  return 0;
+}
+
+extern "C" {
+
 int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper,
                          const cuoptamd_settings* settings, int device, int max_threads,
                          cuoptamd_result* results, double** x, double** y, double** rc)
 {
   if (count < 0 || (count > 0 && (!lps || !hyper || !settings || !results)))
     return fail(-1, "cuoptamd_batch_solve: null argument");
+  // LPs that share matrix and objective (the MIP heuristics' re-solves: the same A and c under other bounds) go through ONE set-up and
+  // advance in lockstep, eight or four at a time (cuoptamd_batch_*): each gets, bit for bit, the answer of its own solve
+  if (count >= 4 && cuopt_amd::tune_int("shared_batch", 1) != 0) {
+    int rc_ = shared_matrix_batch_solve(count, lps, hyper, settings, device, results, x, y, rc);
+    if (rc_ != kNotShared) return rc_;
+  }
   const int nt = std::max(1, std::min<int>(count, max_threads > 0 ? max_threads : cuopt_amd::host_threads()));
   std::vector<int> codes(count, 0);
   std::vector<std::string> messages(count);

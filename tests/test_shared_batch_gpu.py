@@ -132,3 +132,25 @@ def test_not_eligible_layouts_are_refused():
     child.close(), parent.close()
     with pytest.raises(capi.CuOptError):
         capi.SharedMatrixBatch([capi.Solver(synthetic.generate(600, 500, 6, seed=1))] * 3)  # K = 3
+
+
+def test_batch_solve_routes_lps_over_one_matrix_through_the_lockstep_batch(monkeypatch):
+    """cuoptamd_batch_solve (the C entry under BatchSolve): LPs that share matrix and objective go through one set-up and the
+    lockstep batch -- 8 + 4 + 1 here -- and every answer is the one the independent solves give"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(12000, 10000, 8, seed=9)
+    lps = [dict(p, lb=lb, ub=ub) for lb, ub in variants(p, 13, seed=5)]
+    together = capi.batch_solve(lps, tol=1e-5, iteration_limit=LIMIT)
+    monkeypatch.setenv("CUOPT_AMD_TUNE", "shared_batch=0")
+    apart = capi.batch_solve(lps, tol=1e-5, iteration_limit=LIMIT, max_threads=2)
+    assert len(together) == len(apart) == 13
+    for l, (a, b) in enumerate(zip(together, apart)):
+        for k in KEYS_INT + KEYS_F64:
+            assert a[k] == b[k], (l, k, a[k], b[k])
+        for name in ("x", "y", "reduced_cost"):
+            np.testing.assert_array_equal(a[name], b[name], err_msg="LP %d: %s" % (l, name))
+    assert together[0]["status_name"] == "Optimal"
+    # LPs over different matrices keep the independent path
+    q = synthetic.generate(12000, 10000, 8, seed=10)
+    mixed = capi.batch_solve([lps[0], q, lps[1], lps[2]], tol=1e-5, iteration_limit=LIMIT)
+    assert mixed[0]["steps_taken"] == apart[0]["steps_taken"] and mixed[1]["status_name"] == "Optimal"
