@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
-                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch8", "c3_batch4", "c3_batch2"],
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -753,7 +753,7 @@ class Solver:
 
 
 class SharedMatrixBatch:
-    """cuoptamd_batch: K = 2, 4 or 8 Solvers over ONE matrix (a parent and its clones) advance in lockstep, the matrix streamed once
+    """cuoptamd_batch: K = 2, 4, 8 or 16 Solvers over ONE matrix (a parent and its clones) advance in lockstep, the matrix streamed once
     per attempt for all of them; every LP's trajectory is bit-identical to its own Solver.advance.  CuOptError(-7) when the layouts
     are not eligible (the caller then advances the solvers one by one)."""
 

@@ -1,6 +1,6 @@
 // Shared-matrix batched PDHG (round 5; BASELINE config 5's pattern: the MIP heuristics re-solve the SAME A and c under different bounds,
 // cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-127; the reference builds a solver per call, its batch entry point -- cython_solve.cu:264-296 --
-// is a thread pool of independent solves).  K = 2, 4 or 8 LPs that share the matrix advance together:
+// is a thread pool of independent solves).  K = 2, 4, 8 or 16 LPs that share the matrix advance together:
 //   * every LP keeps a full context of its own (pdlpdev_clone_shared: the matrices, their layouts, D_r, D_c and c are the parent's,
 //     read-only; iterates, bounds, sums, control block, partials are the clone's): the major iterations -- KKT evaluation, restarts,
 //     the primal weight -- run through the single-LP code, untouched, LP by LP;
@@ -15,16 +15,17 @@
 //     accumulates rows t, t + 512, ... in ascending order, the same wave tree (ds_swizzle butterflies) and wave-by-wave sum as
 //     block_reduce.  Hence the restriction: both matrices in the row-sum variant of the panels, no row beyond 128 entries, no dense
 //     segments, columns ascending within rows (else: not eligible, the caller keeps its independent solves).
-// What it buys (C3, 1e6 x 1e6, 1e7 nonzeros; profiles/r05_bench_lines.jsonl, c3_batch8): 10.3 k iterations/s aggregate over 8 LPs
-// against 6.0 k for one -- 1.71x; K = 4: 1.24x; K = 2: 0.80x (two single solves are faster).  Why not more: only the MATRIX is
-// shared.  A lockstep iteration of 8 LPs moves 1.85 GB at the fused floor (0.24 GB of matrix once, 8 x 0.18 GB of vectors, the
-// interleaved copies) against 0.42 GB for one LP: at EQUAL fractions of the HBM roofline the ceiling is 8 x 0.42 / 1.85 = 1.80x, and
-// both run at 0.30 of it.  The products themselves sit at ~300 us whatever their internal structure (row walk / LDS-staged chunks /
-// autonomous waves, 1 to 32 gathers in flight, 2 or 4 workgroups per CU: tools/batch_spmv_probe.hip, profiles/r05_batch_spmv_probe.txt):
-// 1e7 gathered 128-byte lines from beyond L2 (the interleaved vector is 64 MB; an XCD's L2 holds 4) + 0.5 GB of streams ~ 1.8 GB
-// at ~6 TB/s.  The single-LP panels avoid those line fills by sweeping 1.33 MB column slabs in step across the chip; eight
-// interleaved vectors would need 46 slabs and a sweep synchronised to +-3 %: with the epilogue phases in between it does not hold
-// (window-major orders in the probe: no gain once the epilogue is in).
+// What it buys (C3, 1e6 x 1e6, 1e7 nonzeros; profiles/r05_bench_lines.jsonl, c3_batch16 / c3_batch8): 14.7 k iterations/s aggregate
+// over 16 LPs, 10.7 k over 8, against 6.0 k for one -- 2.43x / 1.77x; K = 4: 1.24x; K = 2: 0.80x (two single solves are faster).
+// Why not more: only the MATRIX is shared.  A lockstep iteration of 8 LPs moves 1.85 GB at the fused floor (0.24 GB of matrix once,
+// 8 x 0.18 GB of vectors, the interleaved copies) against 0.42 GB for one LP: at EQUAL fractions of the HBM roofline the ceiling is
+// 8 x 0.42 / 1.85 = 1.80x (16 LPs: 1.92x); the single solve and the batch of 8 run at 0.31 of their floors, the batch of 16 at 0.40.
+// The K = 8 products sit at ~300 us whatever their internal structure (row walk / LDS-staged chunks / autonomous waves, 1 to 32
+// gathers in flight, 2 or 4 workgroups per CU: tools/batch_spmv_probe.hip, profiles/r05_batch_spmv_probe.txt): 1e7 gathered
+// 128-byte lines from beyond L2 (the interleaved vector is 64 MB; an XCD's L2 holds 4) + 0.5 GB of streams ~ 1.8 GB at ~6 TB/s --
+// K = 16 uses the whole line a miss fetches.  The single-LP panels avoid those line fills by sweeping 1.33 MB column slabs in step
+// across the chip; eight interleaved vectors would need 46 slabs and a sweep synchronised to +-3 %: with the epilogue phases in
+// between it does not hold (window-major orders in the probe: no gain once the epilogue is in).
 #include <hip/hip_runtime.h>
 
 #include "pdlp_ctx.hpp"
@@ -40,7 +41,7 @@ namespace {
 
 constexpr int kBT = kPanelThreads;  // threads per workgroup = the panel kernels' (the partial sums reproduce their tree)
 static_assert(kBT == 512, "8 waves of 64 lanes: the reduction below mirrors block_reduce<.., kPanelWaves>");
-constexpr int kBChunk = 512;        // matrix entries staged per pass
+constexpr int kBatchMax = 16;       // LPs per batch
 
 struct BatchLp {  // what the batched kernels need of one LP, in device memory
   pdlpdev_ctl* ctl;
@@ -52,39 +53,53 @@ struct BatchLp {  // what the batched kernels need of one LP, in device memory
   double *part_a, *part_at;
 };
 
+// wave <-> LP in the element-wise phases: K <= 8: 8 / K waves share an LP (wave w: LP w % K, every (8 / K)-th piece of 64 rows from
+// piece w / K on); K = 16: a wave serves two LPs one after the other (w and w + 8)
+template <int K>
+struct WaveLps {
+  static constexpr int PASSES = K > 8 ? K / 8 : 1;  // LPs per wave
+  static constexpr int NSUB   = K > 8 ? 1 : 8 / K;  // waves per LP
+  static __device__ __forceinline__ int lp(int wave, int pass) { return K > 8 ? wave + 8 * pass : wave % K; }
+  static __device__ __forceinline__ int sub(int wave) { return K > 8 ? 0 : wave / K; }
+};
+
 // ---- (1) the primal step of K LPs (k_primal's expressions, LP by LP) with xbar written INTERLEAVED ------------------------------
-// wave <-> LP (K < 8: 8 / K waves share an LP), lane <-> column: every per-LP stream is read and written in 512-byte pieces;
-// the tile of xbar goes through LDS (one padded row per column) and leaves as whole 64-byte entries of the interleaved vector.
+// wave <-> LP, lane <-> column: every per-LP stream is read and written in 512-byte pieces; the tile of xbar goes through LDS (one
+// padded row per column) and leaves as whole entries of the interleaved vector.
 template <int K>
 __global__ void __launch_bounds__(kBT) kb_primal(const BatchLp* __restrict__ lp, int n, double* __restrict__ xK)
 {
   __shared__ double tile[kBT][K + 1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = wave % K, sub = wave / K;
-  constexpr int NSUB = 8 / K;
-  const BatchLp L = lp[l];
-  const bool active = loop_active(L.ctl);
-  const int cur       = L.ctl->cur;
-  const double tau    = L.ctl->tau;
-  const double weight = L.ctl->step_size;
-  const bool pend     = L.ctl->pending_avg != 0;
-  const double* __restrict__ x   = cur ? L.x1 : L.x0;
-  double* __restrict__ xn        = cur ? L.x0 : L.x1;
-  const double* __restrict__ aty = cur ? L.aty1 : L.aty0;
+  using WL = WaveLps<K>;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WL::sub(wave);
   for (int t0 = blockIdx.x * kBT; t0 < n; t0 += gridDim.x * kBT) {
 #pragma unroll
-    for (int q = sub; q < 8; q += NSUB) {
-      const int jl = lane + 64 * q, j = t0 + jl;
-      double xb    = 0.0;
-      if (active && j < n) {
-        const double xj       = x[j];
-        const double gradient = L.c[j] - aty[j];
-        double next           = xj - (tau * gradient);
-        next                  = dmax(dmin(next, L.ubd.ub_same ? L.ubd.ub : L.ub[j]), L.ubd.lb_same ? L.ubd.lb : L.lb[j]);
-        xn[j]                 = next;
-        xb                    = next - xj + next;
-        if (pend) L.sumx[j] = L.sumx[j] + weight * xj;
+    for (int pass = 0; pass < WL::PASSES; ++pass) {
+      const int l       = WL::lp(wave, pass);
+      const BatchLp L   = lp[l];
+      const bool active = loop_active(L.ctl);
+      const int cur       = L.ctl->cur;
+      const double tau    = L.ctl->tau;
+      const double weight = L.ctl->step_size;
+      const bool pend     = L.ctl->pending_avg != 0;
+      const double* __restrict__ x   = cur ? L.x1 : L.x0;
+      double* __restrict__ xn        = cur ? L.x0 : L.x1;
+      const double* __restrict__ aty = cur ? L.aty1 : L.aty0;
+#pragma unroll
+      for (int q = sub; q < 8; q += WL::NSUB) {
+        const int jl = lane + 64 * q, j = t0 + jl;
+        double xb    = 0.0;
+        if (active && j < n) {
+          const double xj       = x[j];
+          const double gradient = L.c[j] - aty[j];
+          double next           = xj - (tau * gradient);
+          next                  = dmax(dmin(next, L.ubd.ub_same ? L.ubd.ub : L.ub[j]), L.ubd.lb_same ? L.ubd.lb : L.lb[j]);
+          xn[j]                 = next;
+          xb                    = next - xj + next;
+          if (pend) L.sumx[j] = L.sumx[j] + weight * xj;
+        }
+        tile[jl][l] = xb;
       }
-      tile[jl][l] = xb;
     }
     __syncthreads();
     for (int f = threadIdx.x; f < kBT * K; f += kBT) {
@@ -98,30 +113,45 @@ __global__ void __launch_bounds__(kBT) kb_primal(const BatchLp* __restrict__ lp,
 // ---- (2), (3) the two products for K LPs ----------------------------------------------------------------------------------------
 // The panel kernels' structure, K wide.  A workgroup owns the rows of ONE panel of the single-LP layout (same boundaries: the
 // partial sums below are then the panel kernels' own) and walks them in blocks of 512 rows.  Per block the matrix entries -- one
-// contiguous CSR range -- are read coalesced, 512 at a time, and handed round through LDS; a GROUP of K lanes fetches one
-// entry's K vector values with one 64-byte request (lane l = LP l) and leaves the K products in LDS; lane (g, l) then adds the
-// products of ITS rows (g, g + G, ...) left to right in registers -- the CSR order, the order every single-LP kernel uses for
-// rows of up to 128 entries.  One barrier per chunk: the next chunk's gathers are in flight during the previous chunk's row sums.
-// The fused epilogue runs wave <-> LP, lane <-> row (the row sums cross over through LDS): every per-LP stream is read and
-// written in 512-byte pieces, and lane t of an LP's wave holds exactly the panel kernels' "thread t" accumulators (rows t,
-// t + 512, ... of the panel in ascending order), so the wave tree and the wave-by-wave sum of block_reduce apply unchanged.
+// contiguous CSR range -- are read coalesced, a chunk at a time, and handed round through LDS; a GROUP of K / 2 lanes fetches one
+// entry's K vector values (lane h: the LPs 2h and 2h + 1, one 16-byte load; K = 8: one 64-byte request per entry, K = 16: the whole
+// 128-byte line a miss fetches anyway) and leaves the K products in LDS; lane (g, h) then adds the products of ITS rows (g, g + G,
+// ...) left to right in registers -- the CSR order, the order every single-LP kernel uses for rows of up to 128 entries.  One
+// barrier per chunk, two chunks of gathers in flight.  The fused epilogue runs wave <-> LP, lane <-> row (the row sums cross over
+// through LDS): every per-LP stream is read and written in 512-byte pieces, and lane t of an LP's wave holds exactly the panel
+// kernels' "thread t" accumulators (rows t, t + 512, ... of the panel in ascending order), so the wave tree and the wave-by-wave
+// sum of block_reduce apply unchanged.
+template <int K>
+struct BatchGeometry {
+  static constexpr int KL    = K / 2;              // lanes per entry
+  static constexpr int G     = kBT / KL;           // groups per workgroup
+  static constexpr int CHUNK = K > 8 ? 256 : 512;  // matrix entries staged per pass (64 KB of products in two buffers)
+  static constexpr int PER   = CHUNK / G;          // entries per lane and chunk
+  static constexpr int RU    = kBT / G;            // rows per lane and block of 512 rows
+};
 template <int K>
 struct alignas(16) BatchShared {
-  double prod[2][kBChunk][K];
-  int scol[2][kBChunk];
-  double sval[2][kBChunk];
+  using Geo = BatchGeometry<K>;
+  union {
+    struct {
+      double prod[2][Geo::CHUNK][K];
+      int scol[2][Geo::CHUNK];
+      double sval[2][Geo::CHUNK];
+    } p;
+    double sums[kBT][K + 1];  // the epilogue's view of a block: row sums / new iterates, one padded row per matrix row
+  } u;
   double red[2][K][8];
 };
-static_assert(sizeof(BatchShared<8>) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(BatchShared<8>) <= 80 * 1024 && sizeof(BatchShared<16>) <= 80 * 1024, "two workgroups per CU");
 
 // row sums of the block [b0, b0 + 512) of panel rows [r0, r0 + nr): lane (g, h) -- group g of K / 2 lanes, lane h of it = the LPs 2h and
-// 2h + 1 (one 16-byte piece of an entry's 8 K bytes) -- ends with s[u][0..1] = the sums of row b0 + g + G * u for its two LPs
+// 2h + 1 -- ends with s[u][0..1] = the sums of row b0 + g + G * u for its two LPs
 template <int K>
 __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int nr, int b0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                                                 const double* __restrict__ val, const double* __restrict__ vK, double (&s)[K / 2][2])
+                                                 const double* __restrict__ val, const double* __restrict__ vK, double (&s)[BatchGeometry<K>::RU][2])
 {
-  constexpr int KL = K / 2, G = kBT / KL, PER = kBChunk / G, RU = kBT / G;
-  static_assert(PER == KL && RU == KL, "512 entries per chunk, 512 rows per block");
+  using Geo = BatchGeometry<K>;
+  constexpr int KL = Geo::KL, G = Geo::G, PER = Geo::PER, RU = Geo::RU, CH = Geo::CHUNK;
   const int tid = threadIdx.x, h = tid % KL, g = tid / KL;
   int k0[RU], k1[RU];
 #pragma unroll
@@ -133,23 +163,26 @@ __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int 
     s[u][0] = 0.0, s[u][1] = 0.0;
   }
   const int eb0 = off[r0 + b0], eb1 = off[r0 + (b0 + kBT < nr ? b0 + kBT : nr)];
-  const int nch = (eb1 - eb0 + kBChunk - 1) / kBChunk;
+  const int nch = (eb1 - eb0 + CH - 1) / CH;
+  const bool stager = CH == kBT || tid < CH;  // (chunks of 256: the first four waves fetch and stage)
   // chunks 0 and 1 staged (past the block's last entry: column 0 with value 0 -- gathered, multiplied, never added);
   // chunk 0's gathers on their way
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    const int e   = eb0 + c * kBChunk + tid;
-    const bool in = e < eb1;
-    S.scol[c][tid] = in ? idx[e] : 0, S.sval[c][tid] = in ? val[e] : 0.0;
+    const int e   = eb0 + c * CH + tid;
+    const bool in = stager && e < eb1;
+    const int cl  = idx[in ? e : eb0];
+    const double vl = val[in ? e : eb0];
+    if (stager) S.u.p.scol[c][tid] = in ? cl : 0, S.u.p.sval[c][tid] = in ? vl : 0.0;
   }
   __syncthreads();
   auto rowsum = [&](int cc) {
-    const int c0 = eb0 + cc * kBChunk, c1 = c0 + kBChunk < eb1 ? c0 + kBChunk : eb1, pb = cc & 1;
+    const int c0 = eb0 + cc * CH, c1 = c0 + CH < eb1 ? c0 + CH : eb1, pb = cc & 1;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int a = k0[u] > c0 ? k0[u] : c0, e = k1[u] < c1 ? k1[u] : c1;
       for (int k = a; k < e; ++k) {
-        const double2 p = *(const double2*)&S.prod[pb][k - c0][2 * h];
+        const double2 p = *(const double2*)&S.u.p.prod[pb][k - c0][2 * h];
         s[u][0] = s[u][0] + p.x, s[u][1] = s[u][1] + p.y;
       }
     }
@@ -159,16 +192,16 @@ __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int 
   auto request = [&](int cc, double2 (&p)[PER], double (&v)[PER]) {  // chunk cc: its entries' values, its gathers
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      v[i] = S.sval[cc & 1][g + G * i];
-      p[i] = *(const double2*)(vK + ((unsigned)S.scol[cc & 1][g + G * i] * (unsigned)K + 2u * h));
+      v[i] = S.u.p.sval[cc & 1][g + G * i];
+      p[i] = *(const double2*)(vK + ((unsigned)S.u.p.scol[cc & 1][g + G * i] * (unsigned)K + 2u * h));
     }
   };
   // the entries of chunk c + 2 wait in registers for one trip before they go to LDS: every wait below is for loads issued a whole
   // trip earlier (the vector memory counter completes in order: a load consumed in the trip that issued it would drag the trip's
   // gathers along)
   auto fetch = [&](int cc, int& col, double& v) {
-    const int e   = eb0 + cc * kBChunk + tid;
-    const bool in = e < eb1;
+    const int e   = eb0 + cc * CH + tid;
+    const bool in = stager && e < eb1;
     const int cl  = idx[in ? e : eb0];
     const double vl = val[in ? e : eb0];
     col = in ? cl : 0, v = in ? vl : 0.0;
@@ -184,8 +217,8 @@ __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int 
     fetch(c + 3, col_ld, val_ld);  //  bookkeeping of the compiler stays exact only in straight-line code)
     rowsum(c - 1);                // (c = 0: an empty range)
 #pragma unroll
-    for (int i = 0; i < PER; ++i) *(double2*)&S.prod[c & 1][g + G * i][2 * h] = double2{curv[i] * cur[i].x, curv[i] * cur[i].y};
-    S.scol[c & 1][tid] = col_st, S.sval[c & 1][tid] = val_st;  // (chunk c + 2 takes chunk c's place: read one barrier ago)
+    for (int i = 0; i < PER; ++i) *(double2*)&S.u.p.prod[c & 1][g + G * i][2 * h] = double2{curv[i] * cur[i].x, curv[i] * cur[i].y};
+    if (stager) S.u.p.scol[c & 1][tid] = col_st, S.u.p.sval[c & 1][tid] = val_st;  // (chunk c + 2 takes chunk c's place: read one barrier ago)
     __syncthreads();
   };
   request(0, pv, sv);
@@ -199,31 +232,32 @@ __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int 
 
 // the row sums of a block cross over: lane (g, h) -> sums[row][LP] (padded rows), for the epilogue's wave <-> LP, lane <-> row
 template <int K>
-__device__ __forceinline__ double (*batch_cross_over(BatchShared<K>& S, const double (&s)[K / 2][2]))[K + 1]
+__device__ __forceinline__ void batch_cross_over(BatchShared<K>& S, const double (&s)[BatchGeometry<K>::RU][2])
 {
-  constexpr int KL = K / 2, G = kBT / KL;
-  double(*sums)[K + 1] = (double(*)[K + 1]) & S.prod[0][0][0];
-  const int h = threadIdx.x % KL, g = threadIdx.x / KL;
+  using Geo = BatchGeometry<K>;
+  const int h = threadIdx.x % Geo::KL, g = threadIdx.x / Geo::KL;
   __syncthreads();  // (the last chunk's products are read)
 #pragma unroll
-  for (int u = 0; u < KL; ++u) sums[g + G * u][2 * h] = s[u][0], sums[g + G * u][2 * h + 1] = s[u][1];
+  for (int u = 0; u < Geo::RU; ++u) S.u.sums[g + Geo::G * u][2 * h] = s[u][0], S.u.sums[g + Geo::G * u][2 * h + 1] = s[u][1];
   __syncthreads();
-  return sums;
 }
 
-// block_reduce<SumOp, NQ, 8> of the panel kernels for every LP: acc[q][j] = the sums of virtual threads lane + 64 j
+// block_reduce<SumOp, NQ, 8> of the panel kernels for every LP: acc[pass][q][j] = the sums of virtual threads lane + 64 j of LP (wave, pass)
 template <int K, int NQ>
-__device__ __forceinline__ void batch_panel_partials(BatchShared<K>& S, const double (&acc)[NQ][8], const BatchLp* __restrict__ lp, bool a_side, int W, int w)
+__device__ __forceinline__ void batch_panel_partials(BatchShared<K>& S, const double (&acc)[WaveLps<K>::PASSES][NQ][8], const BatchLp* __restrict__ lp, bool a_side,
+                                                     int W, int w)
 {
-  constexpr int NSUB = 8 / K;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = wave % K, sub = wave / K;
+  using WL = WaveLps<K>;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WL::sub(wave);
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+  for (int pass = 0; pass < WL::PASSES; ++pass)
 #pragma unroll
-    for (int j = sub; j < 8; j += NSUB) {
-      const double v = wave_reduce<SumOp>(acc[q][j]);
-      if (lane == 0) S.red[q][l][j] = v;
-    }
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = sub; j < 8; j += WL::NSUB) {
+        const double v = wave_reduce<SumOp>(acc[pass][q][j]);
+        if (lane == 0) S.red[q][WL::lp(wave, pass)][j] = v;
+      }
   __syncthreads();
   if (threadIdx.x < K * NQ) {
     const int q = threadIdx.x / K, ll = threadIdx.x % K;
@@ -243,51 +277,55 @@ __global__ void __launch_bounds__(kBT) kb_a_dual(int W, const int32_t* __restric
                                                  double* __restrict__ yK)
 {
   __shared__ BatchShared<K> S;
-  constexpr int NSUB = 8 / K;
-  const int w = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = wave % K, sub = wave / K;
+  using WL = WaveLps<K>;
+  const int w = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WL::sub(wave);
   const int r0 = row0[w], nr = row0[w + 1] - r0;
-  const BatchLp L    = lp[l];
-  const bool active  = loop_active(L.ctl);
-  const int cur      = L.ctl->cur;
-  const double sigma = L.ctl->sigma, weight = L.ctl->step_size;
-  const bool pend    = L.ctl->pending_avg != 0;
-  const double* __restrict__ y = cur ? L.y1 : L.y0;
-  double* __restrict__ yn      = cur ? L.y0 : L.y1;
-  double acc[1][8];
+  double acc[WL::PASSES][1][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[0][j] = 0.0;
+  for (int pass = 0; pass < WL::PASSES; ++pass)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[pass][0][j] = 0.0;
   for (int b0 = 0; b0 < nr; b0 += kBT) {
-    double s[K / 2][2];
+    double s[BatchGeometry<K>::RU][2];
     batch_block_sums<K>(S, r0, nr, b0, off, idx, val, xK, s);
-    double(*sums)[K + 1] = batch_cross_over<K>(S, s);
-    if (active) {
+    batch_cross_over<K>(S, s);
+#pragma unroll
+    for (int pass = 0; pass < WL::PASSES; ++pass) {
+      const int l      = WL::lp(wave, pass);
+      const BatchLp L  = lp[l];
+      if (!loop_active(L.ctl)) continue;
+      const int cur      = L.ctl->cur;
+      const double sigma = L.ctl->sigma, weight = L.ctl->step_size;
+      const bool pend    = L.ctl->pending_avg != 0;
+      const double* __restrict__ y = cur ? L.y1 : L.y0;
+      double* __restrict__ yn      = cur ? L.y0 : L.y1;
       double yv[8], lov[8], hiv[8], sy[8];
 #pragma unroll
-      for (int j = sub; j < 8; j += NSUB) {
+      for (int j = sub; j < 8; j += WL::NSUB) {
         const int r = b0 + lane + 64 * j, i = r0 + (r < nr ? r : 0);
         yv[j] = y[i], lov[j] = L.lo[i], hiv[j] = L.hi[i], sy[j] = pend ? L.sumy[i] : 0.0;
       }
 #pragma unroll
-      for (int j = sub; j < 8; j += NSUB) {
+      for (int j = sub; j < 8; j += WL::NSUB) {
         const int r = b0 + lane + 64 * j;
         if (r < nr) {
           const int i      = r0 + r;
           const double yi  = yv[j];
-          double next      = yi - (sigma * sums[lane + 64 * j][l]);
+          double next      = yi - (sigma * S.u.sums[lane + 64 * j][l]);
           const double low = next + sigma * lov[j];
           const double up  = next + sigma * hiv[j];
           next             = dmax(low, dmin(up, 0.0));
           yn[i]            = next;
-          sums[lane + 64 * j][l] = next;
+          S.u.sums[lane + 64 * j][l] = next;
           const double dy = next - yi;
-          acc[0][j] += dy * dy;
+          acc[pass][0][j] += dy * dy;
           if (pend) L.sumy[i] = sy[j] + weight * yi;
         }
       }
     }
     __syncthreads();
     const int rows = nr - b0 < kBT ? nr - b0 : kBT;
-    for (int f = threadIdx.x; f < rows * K; f += kBT) yK[(size_t)(r0 + b0) * K + f] = sums[f / K][f % K];
+    for (int f = threadIdx.x; f < rows * K; f += kBT) yK[(size_t)(r0 + b0) * K + f] = S.u.sums[f / K][f % K];
     __syncthreads();
   }
   batch_panel_partials<K, 1>(S, acc, lp, true, W, w);
@@ -299,40 +337,44 @@ __global__ void __launch_bounds__(kBT) kb_at_step(int W, const int32_t* __restri
                                                   const double* __restrict__ val, const BatchLp* __restrict__ lp, const double* __restrict__ yK)
 {
   __shared__ BatchShared<K> S;
-  constexpr int NSUB = 8 / K;
-  const int w = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = wave % K, sub = wave / K;
+  using WL = WaveLps<K>;
+  const int w = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WL::sub(wave);
   const int r0 = row0[w], nr = row0[w + 1] - r0;
-  const BatchLp L   = lp[l];
-  const bool active = loop_active(L.ctl);
-  const int cur     = L.ctl->cur;
-  const double* __restrict__ x   = cur ? L.x1 : L.x0;
-  const double* __restrict__ xn  = cur ? L.x0 : L.x1;
-  const double* __restrict__ aty = cur ? L.aty1 : L.aty0;
-  double* __restrict__ atyn      = cur ? L.aty0 : L.aty1;
-  double acc[2][8];
+  double acc[WL::PASSES][2][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[0][j] = 0.0, acc[1][j] = 0.0;
+  for (int pass = 0; pass < WL::PASSES; ++pass)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[pass][0][j] = 0.0, acc[pass][1][j] = 0.0;
   for (int b0 = 0; b0 < nr; b0 += kBT) {
-    double s[K / 2][2];
+    double s[BatchGeometry<K>::RU][2];
     batch_block_sums<K>(S, r0, nr, b0, off, idx, val, yK, s);
-    double(*sums)[K + 1] = batch_cross_over<K>(S, s);
-    if (active) {
+    batch_cross_over<K>(S, s);
+#pragma unroll
+    for (int pass = 0; pass < WL::PASSES; ++pass) {
+      const int l     = WL::lp(wave, pass);
+      const BatchLp L = lp[l];
+      if (!loop_active(L.ctl)) continue;
+      const int cur = L.ctl->cur;
+      const double* __restrict__ x   = cur ? L.x1 : L.x0;
+      const double* __restrict__ xn  = cur ? L.x0 : L.x1;
+      const double* __restrict__ aty = cur ? L.aty1 : L.aty0;
+      double* __restrict__ atyn      = cur ? L.aty0 : L.aty1;
       double xv[8], xnv[8], av[8];
 #pragma unroll
-      for (int j = sub; j < 8; j += NSUB) {
+      for (int j = sub; j < 8; j += WL::NSUB) {
         const int r = b0 + lane + 64 * j, i = r0 + (r < nr ? r : 0);
         xv[j] = x[i], xnv[j] = xn[i], av[j] = aty[i];
       }
 #pragma unroll
-      for (int j = sub; j < 8; j += NSUB) {
+      for (int j = sub; j < 8; j += WL::NSUB) {
         const int r = b0 + lane + 64 * j;
         if (r < nr) {
-          const double v  = sums[lane + 64 * j][l];
+          const double v  = S.u.sums[lane + 64 * j][l];
           atyn[r0 + r]    = v;
           const double dx = xnv[j] - xv[j];
           const double t  = v - av[j];
-          acc[0][j] += t * dx;
-          acc[1][j] += dx * dx;
+          acc[pass][0][j] += t * dx;
+          acc[pass][1][j] += dx * dx;
         }
       }
     }
@@ -355,7 +397,7 @@ __global__ void __launch_bounds__(256) kb_check_sorted(int rows, const int32_t* 
 struct pdlpdev_batch {
   int K = 0, device = 0;
   hipStream_t stream = nullptr;
-  pdlpdev_ctx* ctx[8] = {nullptr};
+  pdlpdev_ctx* ctx[kBatchMax] = {nullptr};
   BatchLp* lp_dev = nullptr;
   pdlpdev_decision_args* dargs_dev = nullptr;
   double *xK = nullptr, *yK = nullptr;
@@ -403,7 +445,10 @@ static int batch_enqueue_attempt(pdlpdev_batch* b, hipEvent_t* ev = nullptr)
 
 static int batch_enqueue(pdlpdev_batch* b, hipEvent_t* ev = nullptr)
 {
-  return b->K == 8 ? batch_enqueue_attempt<8>(b, ev) : b->K == 4 ? batch_enqueue_attempt<4>(b, ev) : batch_enqueue_attempt<2>(b, ev);
+  return b->K == 16  ? batch_enqueue_attempt<16>(b, ev)
+         : b->K == 8 ? batch_enqueue_attempt<8>(b, ev)
+         : b->K == 4 ? batch_enqueue_attempt<4>(b, ev)
+                     : batch_enqueue_attempt<2>(b, ev);
 }
 
 static int batch_graph(pdlpdev_batch* b, int attempts, hipGraphExec_t* out)
@@ -500,11 +545,11 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
   return 0;
 }
 
-// K = 2, 4 or 8 contexts over ONE matrix (ctx[0] and its clones, or contexts that alias the same arrays) advance together.  -7: the
+// K = 2, 4, 8 or 16 contexts over ONE matrix (ctx[0] and its clones, or contexts that alias the same arrays) advance together.  -7: the
 // layouts are not the ones whose reduction trees the batched products reproduce (the caller keeps its independent solves).
 int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
 {
-  if (!out || !ctx || (K != 2 && K != 4 && K != 8)) return fail(-1, "pdlpdev_batch_create: K must be 2, 4 or 8");
+  if (!out || !ctx || (K != 2 && K != 4 && K != 8 && K != 16)) return fail(-1, "pdlpdev_batch_create: K must be 2, 4, 8 or 16");
   pdlpdev_ctx* c0 = ctx[0];
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = ctx[l];
@@ -580,7 +625,7 @@ int pdlpdev_batch_run(pdlpdev_batch* b, const int32_t* targets, pdlpdev_ctl* ctl
   int guard = 0;
   for (;;) {
     int remaining = 0;
-    int before[8], asked[8];
+    int before[kBatchMax], asked[kBatchMax];
     for (int l = 0; l < K; ++l) {
       before[l] = b->ctx[l]->ctl_h->steps_taken;
       asked[l]  = wants(l) ? targets[l] - before[l] : 0;
@@ -630,8 +675,8 @@ int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
   const int K   = b->K;
   if (reps < 1) reps = 1;
   TRY(batch_fetch_ctl(b));
-  pdlpdev_ctl saved[8], forced[8];
-  double *sx[8] = {nullptr}, *sy[8] = {nullptr};
+  pdlpdev_ctl saved[kBatchMax], forced[kBatchMax];
+  double *sx[kBatchMax] = {nullptr}, *sy[kBatchMax] = {nullptr};
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = b->ctx[l];
     saved[l] = forced[l] = *c->ctl_h;

@@ -1236,7 +1236,7 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
 // ---- K LPs over ONE matrix and objective in lockstep (kernels_batch.hip) --------------------------------------------------------
 struct cuoptamd_batch {
   int K = 0;
-  cuoptamd_solver* s[8] = {nullptr};
+  cuoptamd_solver* s[16] = {nullptr};
   pdlpdev_batch* dev = nullptr;
 };
 
@@ -1264,8 +1264,8 @@ int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const doubl
 
 int cuoptamd_batch_create(cuoptamd_solver** solvers, int K, cuoptamd_batch** out)
 {
-  if (!solvers || !out || K < 1 || K > 8) return fail(-1, "cuoptamd_batch_create: 2, 4 or 8 solvers");
-  pdlpdev_ctx* ctx[8];
+  if (!solvers || !out || K < 1 || K > 16) return fail(-1, "cuoptamd_batch_create: 2, 4, 8 or 16 solvers");
+  pdlpdev_ctx* ctx[16];
   for (int l = 0; l < K; ++l) {
     if (!solvers[l] || !solvers[l]->dev) return fail(-1, "cuoptamd_batch_create: null solver");
     ctx[l] = solvers[l]->dev;
@@ -1299,8 +1299,8 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
   if (!b) return fail(-1, "cuoptamd_batch_advance: null batch");
   const auto t0 = clock_type::now();
   const int K   = b->K;
-  int32_t budget_end[8], target[8];
-  bool done[8];
+  int32_t budget_end[16], target[16];
+  bool done[16];
   for (int l = 0; l < K; ++l) {
     cuoptamd_solver* s = b->s[l];
     advance_begin(s, t0);
@@ -1316,7 +1316,7 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
     }
     return rc;
   };
-  pdlpdev_ctl ctl[8];
+  pdlpdev_ctl ctl[16];
   for (;;) {
     bool any = false;
     for (int l = 0; l < K; ++l) {
@@ -1656,7 +1656,7 @@ static int shared_matrix_batch_solve(int32_t count, const cuoptamd_lp* lps, cons
         !same(L.values, L0.values, nnz * sizeof(double)) || !same(L.c, L0.c, (size_t)L0.n * sizeof(double)))
       return kNotShared;
   }
-  struct Slots {  // slot 0: the parent (created on LP 0), slots 1..7: clones of it -- destroyed before it
+  struct Slots {  // slot 0: the parent (created on LP 0), slots 1..15: clones of it -- destroyed before it
     std::vector<cuoptamd_solver*> s;
     ~Slots() { for (size_t i = s.size(); i-- > 0;) cuoptamd_solver_destroy(s[i]); }
   } slots;
@@ -1681,7 +1681,7 @@ static int shared_matrix_batch_solve(int32_t count, const cuoptamd_lp* lps, cons
   bool lockstep = true;
   while (done < count) {
     const int left = count - done;
-    const int K    = lockstep && left >= 8 ? 8 : lockstep && left >= 4 ? 4 : 1;
+    const int K    = lockstep && left >= 16 ? 16 : lockstep && left >= 8 ? 8 : lockstep && left >= 4 ? 4 : 1;
     for (int q = 0; q < K; ++q) {
       int rc_ = take(q, done + q);
       if (rc_ == -7 && done == 0) return kNotShared;  // (a resident small-LP solver has no clones: nothing is lost, solve independently)
@@ -1721,7 +1721,7 @@ int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_h
   if (count < 0 || (count > 0 && (!lps || !hyper || !settings || !results)))
     return fail(-1, "cuoptamd_batch_solve: null argument");
   // LPs that share matrix and objective (the MIP heuristics' re-solves: the same A and c under other bounds) go through ONE set-up and
-  // advance in lockstep, eight or four at a time (cuoptamd_batch_*): each gets, bit for bit, the answer of its own solve
+  // advance in lockstep, sixteen, eight or four at a time (cuoptamd_batch_*): each gets, bit for bit, the answer of its own solve
   if (count >= 4 && cuopt_amd::tune_int("shared_batch", 1) != 0) {
     int rc_ = shared_matrix_batch_solve(count, lps, hyper, settings, device, results, x, y, rc);
     if (rc_ != kNotShared) return rc_;

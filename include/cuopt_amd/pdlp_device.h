@@ -273,7 +273,7 @@ int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
  * pdlpdev_clone_shared: a context for another LP over the parent's matrices, layouts, scaling vectors and c (shared, read-only: the
  * parent must outlive its clones and must not be reset or re-scaled while they exist); iterates, bounds, sums, control block are the
  * clone's own.  It starts with the parent's bounds: pdlpdev_reset(clone, lb, ub, lo, hi) gives it its own.  Single GPU only.
- * pdlpdev_batch_create: K = 2, 4 or 8 such contexts (ctx[0] may be the parent).  The two products of an attempt then serve all K LPs
+ * pdlpdev_batch_create: K = 2, 4, 8 or 16 such contexts (ctx[0] may be the parent).  The two products of an attempt then serve all K LPs
  * from ONE pass over the matrix: the K gathered vectors are interleaved, a row belongs to a group of K lanes, one 64-byte request
  * fetches a column's entry of eight LPs.  Each LP's trajectory is BIT-IDENTICAL to the one pdlpdev_run gives it (same row sums, same
  * epilogue expressions, the panel kernels' per-workgroup reduction trees reproduced).  -7: not eligible -- both matrices must be in

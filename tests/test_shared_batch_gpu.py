@@ -47,7 +47,7 @@ def same(a, b, sa, sb, what):
         np.testing.assert_array_equal(u, v, err_msg="%s: %s" % (what, name))
 
 
-@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("k", [2, 4, 8, 16])
 def test_batch_trajectories_are_bit_identical_to_single_solves(k, monkeypatch):
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
     p = synthetic.generate(30000, 24000, 10, seed=21)
@@ -136,14 +136,14 @@ def test_not_eligible_layouts_are_refused():
 
 def test_batch_solve_routes_lps_over_one_matrix_through_the_lockstep_batch(monkeypatch):
     """cuoptamd_batch_solve (the C entry under BatchSolve): LPs that share matrix and objective go through one set-up and the
-    lockstep batch -- 8 + 4 + 1 here -- and every answer is the one the independent solves give"""
+    lockstep batch -- 16 + 8 + 4 + 1 here -- and every answer is the one the independent solves give"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
     p = synthetic.generate(12000, 10000, 8, seed=9)
-    lps = [dict(p, lb=lb, ub=ub) for lb, ub in variants(p, 13, seed=5)]
+    lps = [dict(p, lb=lb, ub=ub) for lb, ub in variants(p, 29, seed=5)]
     together = capi.batch_solve(lps, tol=1e-5, iteration_limit=LIMIT)
     monkeypatch.setenv("CUOPT_AMD_TUNE", "shared_batch=0")
     apart = capi.batch_solve(lps, tol=1e-5, iteration_limit=LIMIT, max_threads=2)
-    assert len(together) == len(apart) == 13
+    assert len(together) == len(apart) == 29
     for l, (a, b) in enumerate(zip(together, apart)):
         for k in KEYS_INT + KEYS_F64:
             assert a[k] == b[k], (l, k, a[k], b[k])
