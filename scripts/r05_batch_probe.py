@@ -1,5 +1,5 @@
 """Shared-matrix batch on C3: aggregate PDLP iterations/s of K LPs in lockstep against K single solves one after the other.
-usage: python scripts/r05_batch_probe.py [K ...]   (default 2 4 8)"""
+usage: python scripts/r05_batch_probe.py [K ...]   (default 2 4 8 16)"""
 import os
 import sys
 import time
@@ -24,7 +24,7 @@ def load():
 
 
 def main():
-    ks = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
+    ks = [int(a) for a in sys.argv[1:]] or [2, 4, 8, 16]
     p = load()
     rng = np.random.default_rng(8)
     x = p["x_star"]
