@@ -793,7 +793,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
                            : std::string("served by PDLP") + (engine_ran ? " (the dual simplex abstained)" : "") +
                                  (simplex_grade ? ", simplex-grade tolerances 1e-8 with the requested ones as acceptance set\n" : "\n")));
     const cuoptamd_settings st_user = st;
-    constexpr int32_t kSimplexGradeBudget = 50000;
+    const int32_t kSimplexGradeBudget = (int32_t)std::max<long long>(1, cuopt_amd::tune_int("simplex_grade_budget", 50000));  // (tests shrink it)
     bool tightened = false;
     if (simplex_grade) {
       double* tols[6]   = {&st.absolute_gap_tolerance,    &st.relative_gap_tolerance,  &st.absolute_primal_tolerance,
@@ -811,6 +811,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
     cuoptamd_result res{};
     double first_attempt_seconds = 0.0;
     int32_t first_attempt_steps = 0, first_attempt_attempts = 0;  // work of a simplex-grade attempt that a second solve followed
+    bool second_leg = false;  // ... inside a Concurrent race (the simplex kept running)
     std::string answered = simplex_grade && tightened ? "simplex_grade_1e-8" : "requested_tolerances";
     sol->x.assign(p->n, 0.0), sol->y.assign(p->m, 0.0), sol->rc.assign(p->n, 0.0);
     auto take_simplex = [&]() {  // the dual simplex's verdict as the solve's result
@@ -856,9 +857,28 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
           }
         });
         for (;;) {
-          if (sx.done.load() && sx.conclusive()) break;
-          rc = cuoptamd_solver_advance(solver, 400, &res);
-          if (rc != 0 || res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION) break;
+          for (;;) {
+            if (sx.done.load() && sx.conclusive()) break;
+            rc = cuoptamd_solver_advance(solver, 400, &res);
+            if (rc != 0 || res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION) break;
+          }
+          // The simplex-grade attempt ran out of ITS OWN budget (not a limit of the caller's) with nothing accepted and the simplex is
+          // still at work: the race goes on -- PDLP at the requested tolerances with what is left of the caller's limits against the
+          // same simplex run (round-4 advisor: the internal budget used to cancel the simplex and a second, unraced solve followed)
+          const bool own_budget = rc == 0 && tightened && !second_leg && res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT &&
+                                  !res.accepted_at_looser_tolerances && st_user.iteration_limit > kSimplexGradeBudget &&
+                                  !(sx.done.load() && sx.conclusive());
+          if (!own_budget) break;
+          first_attempt_seconds = res.setup_seconds + res.loop_seconds;
+          first_attempt_steps = res.steps_taken, first_attempt_attempts = res.attempted_steps;
+          cuoptamd_settings st_rest = st_user;
+          if (st_user.iteration_limit != INT_MAX) st_rest.iteration_limit = std::max(0, st_user.iteration_limit - res.steps_taken);
+          if (std::isfinite(st_rest.time_limit)) st_rest.time_limit = std::max(0.0, st_rest.time_limit - first_attempt_seconds);
+          if (!(st_rest.iteration_limit > 0 && st_rest.time_limit > 0.0)) break;
+          second_leg = true;
+          answered   = "requested_tolerances_after_simplex_grade_budget";
+          rc         = cuoptamd_solver_reset(solver, nullptr, nullptr, nullptr, nullptr, &st_rest, nullptr, nullptr);
+          if (rc != 0) break;
         }
         const bool pdlp_done = rc == 0 && res.status != CUOPT_TERIMINATION_STATUS_NO_TERMINATION;
         // whenever the loop ends without a finished, conclusive simplex -- PDLP has its verdict, hit a limit, or FAILED -- the simplex
@@ -881,7 +901,7 @@ cuopt_int_t cuOptSolve(cuOptOptimizationProblem problem, cuOptSolverSettings set
       if (!engine_answered) {
       const bool on_limit = res.status == CUOPT_TERIMINATION_STATUS_ITERATION_LIMIT || res.status == CUOPT_TERIMINATION_STATUS_TIME_LIMIT;
       if (rc == 0 && res.accepted_at_looser_tolerances) answered = "requested_tolerances_kept_during_simplex_grade_attempt";
-      if (rc == 0 && tightened && on_limit && !res.accepted_at_looser_tolerances) {
+      if (rc == 0 && tightened && on_limit && !res.accepted_at_looser_tolerances && !second_leg) {
         // the tight attempt ended on a limit and no iterate met even the requested tolerances: whatever is left of the
         // caller's limits goes to a plain solve at the requested tolerances (same solver object: matrices and scaling kept)
         first_attempt_seconds = res.setup_seconds + res.loop_seconds;

@@ -252,3 +252,21 @@ def test_create_problem_from_device_arrays():
     L.cuOptDestroyProblem(C.byref(prob))
     for d in held:
         hip.hipFree(d)
+
+
+def test_the_emulations_own_budget_does_not_end_the_race(monkeypatch):
+    """when the simplex-grade attempt of a Concurrent solve ran out of ITS OWN iteration budget (not a limit of the
+    caller's) the simplex was cancelled and an unraced second solve followed.  Now the race goes on: PDLP at the requested
+    tolerances against the same simplex run; whoever answers, the verdict and the objective are right."""
+    p = synthetic.generate(400, 300, 6, seed=9, hard=True)  # far more than 10 iterations to anything
+    set_tune(monkeypatch, simplex_grade_budget="10")
+    r = capi.solve(p)  # default method: Concurrent
+    assert r["status"] == "Optimal"
+    assert r["solve_info"]["answered_by"] in ("dual_simplex", "requested_tolerances_after_simplex_grade_budget"), r["solve_info"]
+    assert abs(r["objective"] - p["objective_star"]) <= 5e-4 * (1 + abs(p["objective_star"]))
+    if r["solve_info"]["answered_by"] != "dual_simplex":
+        assert r["solve_info"]["simplex_grade_attempt_iterations"] == 10
+    # with the simplex out of the race the same budget leads to the second solve as before
+    monkeypatch.setenv("CUOPT_AMD_DUAL_SIMPLEX", "0")
+    q = capi.solve(p)
+    assert q["status"] == "Optimal" and q["solve_info"]["answered_by"] == "requested_tolerances_after_simplex_grade_budget"
