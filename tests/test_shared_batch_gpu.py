@@ -154,3 +154,54 @@ def test_batch_solve_routes_lps_over_one_matrix_through_the_lockstep_batch(monke
     q = synthetic.generate(12000, 10000, 8, seed=10)
     mixed = capi.batch_solve([lps[0], q, lps[1], lps[2]], tol=1e-5, iteration_limit=LIMIT)
     assert mixed[0]["steps_taken"] == apart[0]["steps_taken"] and mixed[1]["status_name"] == "Optimal"
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])  # Stable1, Methodical1 (trust-region restarts), Fast1 (artificial restarts, a step per trip)
+def test_batch_under_the_other_presets(mode, monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(6000, 5000, 8, seed=33)
+    bounds = variants(p, 4, seed=7)
+    limit = 1500
+    single = []
+    for lb, ub in bounds:
+        s = capi.Solver(dict(p, lb=lb, ub=ub), mode=mode, tol=1e-4, iteration_limit=limit)
+        single.append((s.advance(), s.solution()))
+        s.close()
+    parent = capi.Solver(dict(p, lb=bounds[0][0], ub=bounds[0][1]), mode=mode, tol=1e-4, iteration_limit=limit)
+    solvers = [parent] + [parent.clone(lb=lb, ub=ub) for lb, ub in bounds[1:]]
+    batch = capi.SharedMatrixBatch(solvers)
+    got = batch.advance()
+    for l in range(4):
+        same(got[l], single[l][0], solvers[l].solution(), single[l][1], "mode %d, LP %d" % (mode, l))
+    batch.close()
+    for s in solvers[1:]:
+        s.close()
+    parent.close()
+
+
+def test_an_infeasible_member_gets_its_own_verdict(monkeypatch):
+    """one LP of the batch is infeasible (a variable's bounds exclude every feasible point of its rows): with infeasibility
+    detection on it ends PrimalInfeasible exactly where its single solve does, the others are Optimal"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(3000, 2500, 6, seed=12)
+    lb_bad, ub_bad = np.array(p["lb"], float), np.array(p["ub"], float)
+    big = np.argsort(-p["x_star"])[:50]
+    ub_bad[big] = 0.0  # the rows these variables carry cannot be met any more (with high probability: checked by the single solve)
+    sets = [(np.array(p["lb"], float), np.array(p["ub"], float)), (lb_bad, ub_bad)] + variants(p, 3, seed=2)[1:]
+    kw = dict(tol=1e-4, iteration_limit=LIMIT, detect_infeasibility=1)
+    single = []
+    for lb, ub in sets:
+        s = capi.Solver(dict(p, lb=lb, ub=ub), **kw)
+        single.append((s.advance(), s.solution()))
+        s.close()
+    parent = capi.Solver(dict(p, lb=sets[0][0], ub=sets[0][1]), **kw)
+    solvers = [parent] + [parent.clone(lb=lb, ub=ub) for lb, ub in sets[1:]]
+    batch = capi.SharedMatrixBatch(solvers)
+    got = batch.advance()
+    for l in range(4):
+        same(got[l], single[l][0], solvers[l].solution(), single[l][1], "LP %d" % l)
+    assert got[0]["status_name"] == "Optimal"
+    batch.close()
+    for s in solvers[1:]:
+        s.close()
+    parent.close()
