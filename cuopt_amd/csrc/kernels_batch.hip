@@ -490,6 +490,7 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
   *out           = c;
   c->allocs.clear(), c->graphs.clear();
   c->shared_with_parent = true;
+  c->parent = nullptr;  // (set once the clone is complete: a failed clone is destroyed without touching the parent's count)
   c->bytes = 0, c->slab = nullptr, c->slab_cap = c->slab_used = 0, c->arena = nullptr, c->arena_used = 0, c->first_chunk = nullptr;
   c->bestx = c->besty = c->bestrc = nullptr;
   c->prof_armed = false, c->prof_used = 0, c->rejected_in_a_row = 0;
@@ -518,7 +519,9 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
     return 0;
   };
   TRY(own_copy(&c->lb, n)); TRY(own_copy(&c->lb_u, n)); TRY(own_copy(&c->ub, n)); TRY(own_copy(&c->ub_u, n));
-  TRY(own_copy(&c->lo, m)); TRY(own_copy(&c->lo_u, m)); TRY(own_copy(&c->hi, m)); TRY(own_copy(&c->hi_u, m));
+  // (lo, hi and their unscaled twins stay the parent's until a reset brings other row bounds: pdlpdev_reset makes the copies then)
+  c->rows_aliased = true, c->parent = parent, c->clones_alive = 0;
+  parent->clones_alive += 1;
   for (int i = 0; i < 2; ++i) {
     TRY(dev_alloc(c, &c->x[i], (size_t)n + kSlicePad)); TRY(dev_alloc(c, &c->y[i], m));
     TRY(dev_alloc(c, &c->aty[i], (size_t)n + kSlicePad)); TRY(dev_alloc(c, &c->rc[i], n));

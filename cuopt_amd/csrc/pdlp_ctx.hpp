@@ -472,6 +472,11 @@ struct pdlpdev_ctx {
   size_t arena_used = 0;
   bool small_resident = false;  // whole attempt batches inside one workgroup (k_pdhg_small)
   bool shared_with_parent = false;  // pdlpdev_clone_shared: matrices, layouts, scaling vectors, c and the stream are another context's
+  pdlpdev_ctx* parent = nullptr;    // ... that one
+  bool rows_aliased = false;        // ... and so are the row bounds (lo, hi and their unscaled twins) until a reset brings other ones:
+                                    // K clones that differ in their VARIABLE bounds read one copy (the batched dual step then fetches
+                                    // lo / hi once for all LPs -- the caches see the same addresses)
+  int clones_alive = 0;             // contexts that alias this one's arrays
   std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
   std::vector<void*> allocs;
   int64_t bytes = 0;

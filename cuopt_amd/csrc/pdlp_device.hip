@@ -1770,6 +1770,7 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (ctx->shared_with_parent && ctx->parent) ctx->parent->clones_alive -= 1;
   for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
@@ -2050,6 +2051,17 @@ int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const do
       for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
       ctx->graphs.clear();
     }
+  }
+  if ((lo || hi) && (ctx->rows_aliased || ctx->clones_alive > 0)) {
+    // row bounds shared with clones (or with the parent): this context gets arrays of its own first; the others keep the old ones
+    for (double** v : {&ctx->lo, &ctx->lo_u, &ctx->hi, &ctx->hi_u}) {
+      const double* src = *v;
+      TRY(dev_alloc(ctx, v, (size_t)ctx->m));
+      HIP_TRY(hipMemcpyAsync(*v, src, mb, hipMemcpyDeviceToDevice, s));
+    }
+    ctx->rows_aliased = false;
+    for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);  // (the attempt graphs carry the old arrays' addresses)
+    ctx->graphs.clear();
   }
   TRY(put(lo, ctx->lo_u, ctx->lo, mb));
   TRY(put(hi, ctx->hi_u, ctx->hi, mb));

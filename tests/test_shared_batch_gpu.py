@@ -205,3 +205,29 @@ def test_an_infeasible_member_gets_its_own_verdict(monkeypatch):
     for s in solvers[1:]:
         s.close()
     parent.close()
+
+
+def test_row_bounds_are_shared_until_someone_changes_them(monkeypatch):
+    """clones read the parent's row bounds (one copy for all LPs of a batch); a reset with other row bounds -- of a clone or of the
+    parent -- gives that solver arrays of its own and leaves the others alone"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(5000, 4000, 8, seed=17)
+    lo2 = np.where(np.isfinite(p["lo"]), p["lo"] - 0.5, p["lo"])
+    hi2 = np.where(np.isfinite(p["hi"]), p["hi"] + 0.5, p["hi"])
+    kw = dict(tol=1e-6, iteration_limit=LIMIT)
+    ref = capi.Solver(p, **kw)
+    a = ref.advance()
+    sa = ref.solution()
+    ref2 = capi.Solver(dict(p, lo=lo2, hi=hi2), **kw)
+    b = ref2.advance()
+    sb = ref2.solution()
+    parent = capi.Solver(p, **kw)
+    child = parent.clone()
+    parent.reset(lo=lo2, hi=hi2, **kw)  # the parent moves away; the clone keeps the bounds it was created with
+    same(child.advance(), a, child.solution(), sa, "clone after the parent's row bounds changed")
+    same(parent.advance(), b, parent.solution(), sb, "parent with new row bounds")
+    child.reset(lo=lo2, hi=hi2, **kw)
+    parent.reset(lo=p["lo"], hi=p["hi"], **kw)
+    same(child.advance(), b, child.solution(), sb, "clone with new row bounds")
+    same(parent.advance(), a, parent.solution(), sa, "parent back on the first row bounds")
+    child.close(), parent.close()
