@@ -476,7 +476,8 @@ static int batch_graph(pdlpdev_batch* b, int attempts, hipGraphExec_t* out)
 extern "C" {
 
 // A context for ANOTHER LP over the same matrix and objective: matrices, layouts, scaling vectors and c are the parent's (which must
-// outlive the clone and must not be reset while clones exist); the iterate, bounds, sums, control block and partial buffers are the
+// outlive the clone; resets of either side are fine: row bounds are shared until a reset changes them); the iterate, variable bounds, sums,
+// control block and partial buffers are the
 // clone's own.  The clone starts with the parent's (scaled) bounds: pdlpdev_reset(clone, lb, ub, lo, hi) gives it its own, bit for
 // bit the state of a freshly created context of that LP (tests/test_persistent_resolve_gpu.py pins reset against a fresh solver).
 int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)

@@ -271,7 +271,8 @@ int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
  * relaxed_lp.cu:53-127: the same A and c under different bounds; the reference builds a solver per call and its batch entry point,
  * cython_solve.cu:264-296, is a thread pool of independent solves).
  * pdlpdev_clone_shared: a context for another LP over the parent's matrices, layouts, scaling vectors and c (shared, read-only: the
- * parent must outlive its clones and must not be reset or re-scaled while they exist); iterates, bounds, sums, control block are the
+ * parent must outlive its clones and must not be re-scaled while they exist; pdlpdev_reset of either side is fine -- row bounds are
+ * shared until a reset changes them, the changing side then gets arrays of its own); iterates, variable bounds, sums, control block are the
  * clone's own.  It starts with the parent's bounds: pdlpdev_reset(clone, lb, ub, lo, hi) gives it its own.  Single GPU only.
  * pdlpdev_batch_create: K = 2, 4, 8 or 16 such contexts (ctx[0] may be the parent).  The two products of an attempt then serve all K LPs
  * from ONE pass over the matrix: the K gathered vectors are interleaved, a row belongs to a group of K lanes, one 64-byte request

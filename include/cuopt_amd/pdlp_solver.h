@@ -240,7 +240,7 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
  * attempt for all of them (pdlpdev_batch_* in pdlp_device.h; the MIP heuristics' re-solve pattern, relaxed_lp.cu:53-127).
  * cuoptamd_solver_clone: a solver for the parent's LP with other bounds (NULL = the parent's CURRENT ones; settings NULL = the
  * parent's) that shares the parent's matrices on the device; behaves bit for bit like a solver freshly created on that LP.  Destroy
- * the clones before the parent; do not reset the parent while clones exist.  -7: empty or sharded parent.
+ * the clones before the parent (cuoptamd_solver_reset of either is fine while both exist).  -7: empty, resident or sharded parent.
  * cuoptamd_batch_create: K = 2, 4, 8 or 16 solvers over one matrix (a parent and its clones, none advanced by hand in between is NOT
  * required: a batch may be created over solvers in any state).  -7 when the layouts are not eligible (pdlp_device.h): the caller
  * falls back to cuoptamd_solver_advance per solver or to cuoptamd_batch_solve.
