@@ -142,8 +142,9 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
         rates.append(25 * period / (time.perf_counter() - t0))
     single = max(rates[1:])
     parent.reset(tol=0.0)
+    sets = [bounds(l) for l in range(1, K)]
     t0 = time.perf_counter()
-    clones = [parent.clone(*bounds(l)) for l in range(1, K)]
+    clones = [parent.clone(lb, ub) for lb, ub in sets]
     clone_s = (time.perf_counter() - t0) / max(K - 1, 1)
     batch = capi.SharedMatrixBatch([parent] + clones)
     layout = dev.layout()
@@ -192,6 +193,36 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
                     iteration_frac_of_peak=round(floor_k * (timed_steps / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
                     floor_note="fused floor of a lockstep iteration: the matrix twice (A, A^T) ONCE for all LPs, every LP's own 14 n + 7 m "
                                "vector streams, the two interleaved gather vectors written and read once")
+    batch.close()
+    for c in clones:
+        c.close()
+    parent.close()
+    # ---- wall clock to the default 1e-4 verdicts, set-ups included: one set-up + K - 1 clones + the lockstep solve against K
+    # solves one after the other, each with its own set-up (what K calls of cuOptSolve cost)
+    conv = None
+    if not args.no_convergence_run:
+        all_sets = [bounds(0)] + sets
+        t0 = time.perf_counter()
+        par = capi.Solver(dict(p, lb=all_sets[0][0], ub=all_sets[0][1]), mode=1, device=local_rank)
+        cl = [par.clone(lb, ub) for lb, ub in all_sets[1:]]
+        bt = capi.SharedMatrixBatch([par] + cl)
+        rb = bt.advance()
+        par.device.call("synchronize")
+        wall_batch = time.perf_counter() - t0
+        bt.close()
+        for c in cl:
+            c.close()
+        par.close()
+        t0 = time.perf_counter()
+        rs1 = []
+        for lb, ub in all_sets:
+            s1 = capi.Solver(dict(p, lb=lb, ub=ub), mode=1, device=local_rank)
+            rs1.append(s1.advance())
+            s1.close()
+        wall_seq = time.perf_counter() - t0
+        conv = dict(statuses=[r["status_name"] for r in rb], iterations=[r["steps_taken"] for r in rb],
+                    same_as_the_single_solves=all(a["steps_taken"] == b["steps_taken"] and a["primal_objective"] == b["primal_objective"] for a, b in zip(rb, rs1)),
+                    wall_s_lockstep=round(wall_batch, 4), wall_s_one_after_the_other=round(wall_seq, 4), ratio=round(wall_seq / wall_batch, 3))
     cpu = None if args.no_cpu_baseline else cpu_baseline_block(p)
     if cpu is not None:
         cpu["note"] = "the oracle solves one LP at a time: its aggregate over K LPs is this rate"
@@ -207,15 +238,11 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
                    "rows": m, "cols": n, "nnz": nnz, "lps": K, "parallelism": "single GPU, %d LPs in lockstep" % K},
         "single_lp_its_per_s_same_process": round(single, 1), "aggregate_over_single": round(K * timed_steps / elapsed / single, 3),
         "clone_seconds_per_lp": round(clone_s, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4),
+        "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv, "spmv_layout": layout, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4),
         "generate_seconds": round(t_gen, 2), "device": info["name"], "compute_units": info["compute_units"],
     }
     sys.stdout.flush()
     os.write(record_fd, (json.dumps(out) + "\n").encode())
-    batch.close()
-    for c in clones:
-        c.close()
-    parent.close()
 
 
 def main():

@@ -1111,6 +1111,8 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
     lb = s->cols_in(lb, tlb), ub = s->cols_in(ub, tub), lo = s->rows_in(lo, tlo), hi = s->rows_in(hi, thi);
     DEV(pdlpdev_reset(s->dev, lb, ub, lo ? lo + s->row_begin : nullptr, hi ? hi + s->row_begin : nullptr));
   }
+  const bool timing = std::getenv("CUOPT_AMD_TIMING") != nullptr;
+  const double t_reset = seconds_since(t0);
   // ||b||, ||c|| of the termination rule: from the problem again (the previous settings may have overridden them)
   DEV(pdlpdev_problem_norms(s->dev, &s->norm_c, &s->norm_b));
   if (lo || hi) {
@@ -1122,8 +1124,12 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
     s->computed_weight = (bn > 0.0 && cn > 0.0) ? s->H.primal_importance * (cn / bn) : s->H.primal_importance;
   }
   DEV(pdlpdev_set_graph_mode(s->dev, s->S.use_graph));
+  const double t_norms = seconds_since(t0);
   { int rc = start_run(s, init_x, init_y); if (rc) return rc; }
   s->result.setup_seconds = seconds_since(t0);
+  if (timing)
+    fprintf(stderr, "[cuopt_amd setup] reset: bounds to the device %.2f ms, norms + weight %.2f ms, initial iterate / step %.2f ms\n", 1e3 * t_reset,
+            1e3 * (t_norms - t_reset), 1e3 * (s->result.setup_seconds - t_norms));
   return 0;
 }
 
@@ -1245,15 +1251,19 @@ int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const doubl
 {
   if (!parent || !out) return fail(-1, "cuoptamd_solver_clone: null argument");
   if (parent->empty_problem || !parent->dev || parent->world != 1) return fail(-7, "cuoptamd_solver_clone: not for empty or sharded solvers");
+  const bool timing = std::getenv("CUOPT_AMD_TIMING") != nullptr;
+  const auto t0     = clock_type::now();
   pdlpdev_ctx* dev = nullptr;
   int rc           = pdlpdev_clone_shared(&dev, parent->dev);
   if (rc != 0) {
     if (dev) pdlpdev_destroy(dev);
     return fail(rc, "pdlpdev_clone_shared: %s", pdlpdev_last_error());
   }
+  const double t_dev = seconds_since(t0);
   cuoptamd_solver* s = new cuoptamd_solver(*parent);
   s->dev             = dev;
   rc = cuoptamd_solver_reset(s, lb, ub, lo, hi, settings, nullptr, nullptr);
+  if (timing) fprintf(stderr, "[cuopt_amd setup] clone: device context %.2f ms, reset to its bounds %.2f ms\n", 1e3 * t_dev, 1e3 * (seconds_since(t0) - t_dev));
   if (rc != 0) {
     cuoptamd_solver_destroy(s);
     return rc;

@@ -48,8 +48,9 @@ def main():
     print("RATE single %.1f it/s" % single, flush=True)
     for k in ks:
         parent.reset(tol=0.0, use_graph=graph)
+        sets = [bounds(l) for l in range(1, k)]
         t0 = time.perf_counter()
-        clones = [parent.clone(*bounds(l)) for l in range(1, k)]
+        clones = [parent.clone(lb, ub) for lb, ub in sets]
         t_clone = (time.perf_counter() - t0) / max(k - 1, 1)
         batch = capi.SharedMatrixBatch([parent] + clones)
         batch.advance(400)
