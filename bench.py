@@ -232,7 +232,7 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "warmup_done": pre,
         "ms_per_step": round(1e3 * elapsed / timed_steps, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %d LPs over the matrix and objective of c3 (synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d), nnz=%d); LP 0 = c3, "
+        "config": {"workload": "%s: %d LPs over the matrix and objective of the base workload (synthetic random sparse LP S(m=%d,n=%d,k=%d,seed=%d), nnz=%d); LP 0 = the base LP, "
                                "the others with a tenth of the upper bounds tightened (seeded); lockstep batch, Stable2 preset, tolerances 0 (fixed "
                                "iteration budget)" % (args.workload, K, m, n, cfg["k"], cfg["seed"], nnz),
                    "rows": m, "cols": n, "nnz": nnz, "lps": K, "parallelism": "single GPU, %d LPs in lockstep" % K},
@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
-                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2"],
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,9 +337,9 @@ def main():
 
     shuffle = args.workload.endswith("_shuffled")
     base = args.workload[:-len("_shuffled")] if shuffle else args.workload
-    batch_k = int(base[len("c3_batch"):]) if base.startswith("c3_batch") else 0
+    batch_k = int(base.split("_batch")[1]) if "_batch" in base else 0
     if batch_k:
-        base = "c3"
+        base = base.split("_batch")[0]
     structured = base in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
     if base == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)

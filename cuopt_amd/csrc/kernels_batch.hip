@@ -13,8 +13,9 @@
 //     of <= 128 entries), the fused epilogues are the single kernels' expressions, and the per-workgroup partial sums reproduce the
 //     panel kernels' grouping exactly -- workgroup <-> row panel (the single layout's own boundaries), lane t of an LP's wave
 //     accumulates rows t, t + 512, ... in ascending order, the same wave tree (ds_swizzle butterflies) and wave-by-wave sum as
-//     block_reduce.  Hence the restriction: both matrices in the row-sum variant of the panels, no row beyond 128 entries, no dense
-//     segments, columns ascending within rows (else: not eligible, the caller keeps its independent solves).
+//     block_reduce (CSR stream layout: workgroup <-> row block, 256 "threads", four waves).  Hence the restriction: each matrix in
+//     the row-sum variant of the panels or in the CSR stream layout, no row beyond 128 entries, no dense segments, columns ascending
+//     within rows (else: not eligible, the caller keeps its independent solves).
 // What it buys (C3, 1e6 x 1e6, 1e7 nonzeros; profiles/r05_bench_lines.jsonl, c3_batch16 / c3_batch8): 14.7 k iterations/s aggregate
 // over 16 LPs, 10.7 k over 8, against 6.0 k for one -- 2.43x / 1.77x; K = 4: 1.24x; K = 2: 0.80x (two single solves are faster).
 // Why not more: only the MATRIX is shared.  A lockstep iteration of 8 LPs moves 1.85 GB at the fused floor (0.24 GB of matrix once,
@@ -242,28 +243,31 @@ __device__ __forceinline__ void batch_cross_over(BatchShared<K>& S, const double
   __syncthreads();
 }
 
-// block_reduce<SumOp, NQ, 8> of the panel kernels for every LP: acc[pass][q][j] = the sums of virtual threads lane + 64 j of LP (wave, pass)
-template <int K, int NQ>
-__device__ __forceinline__ void batch_panel_partials(BatchShared<K>& S, const double (&acc)[WaveLps<K>::PASSES][NQ][8], const BatchLp* __restrict__ lp, bool a_side,
+// block_reduce<SumOp, NQ, VW> of the single-LP kernels for every LP: acc[pass][q][v] = the sums of virtual threads lane + 64 v of LP
+// (wave, pass).  VW = 8: the panel kernels' 512 threads; VW = 4: the CSR stream kernels' 256 (row t of a block belongs to thread t mod 256).
+template <int K, int NQ, int VW>
+__device__ __forceinline__ void batch_block_partials(BatchShared<K>& S, const double (&acc)[WaveLps<K>::PASSES][NQ][8], const BatchLp* __restrict__ lp, bool a_side,
                                                      int W, int w)
 {
   using WL = WaveLps<K>;
+  static_assert(WL::NSUB <= VW, "a wave owns whole virtual waves");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WL::sub(wave);
 #pragma unroll
   for (int pass = 0; pass < WL::PASSES; ++pass)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int j = sub; j < 8; j += WL::NSUB) {
-        const double v = wave_reduce<SumOp>(acc[pass][q][j]);
-        if (lane == 0) S.red[q][WL::lp(wave, pass)][j] = v;
-      }
+      for (int v = 0; v < VW; ++v)
+        if (v % WL::NSUB == sub) {  // (rows lane + 64 j, j = sub mod NSUB, are this wave's: virtual waves j mod VW)
+          const double r = wave_reduce<SumOp>(acc[pass][q][v]);
+          if (lane == 0) S.red[q][WL::lp(wave, pass)][v] = r;
+        }
   __syncthreads();
   if (threadIdx.x < K * NQ) {
     const int q = threadIdx.x / K, ll = threadIdx.x % K;
     if (loop_active(lp[ll].ctl)) {
       double total = S.red[q][ll][0];
-      for (int vw = 1; vw < 8; ++vw) total = total + S.red[q][ll][vw];
+      for (int vw = 1; vw < VW; ++vw) total = total + S.red[q][ll][vw];
       (a_side ? lp[ll].part_a : lp[ll].part_at)[(size_t)q * W + w] = total;
     }
   }
@@ -271,7 +275,7 @@ __device__ __forceinline__ void batch_panel_partials(BatchShared<K>& S, const do
 
 // rows of A for K LPs: y' = proj(y - sigma A xbar), ||dy||^2 partials, the deferred dual averaging (DualEpilogue, pdlp_epilogues.hpp);
 // y' also goes, interleaved, to the vector the column side gathers from
-template <int K>
+template <int K, int VW>
 __global__ void __launch_bounds__(kBT) kb_a_dual(int W, const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ val, const BatchLp* __restrict__ lp, const double* __restrict__ xK,
                                                  double* __restrict__ yK)
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(kBT) kb_a_dual(int W, const int32_t* __restric
           yn[i]            = next;
           S.u.sums[lane + 64 * j][l] = next;
           const double dy = next - yi;
-          acc[pass][0][j] += dy * dy;
+          acc[pass][0][j % VW] += dy * dy;
           if (pend) L.sumy[i] = sy[j] + weight * yi;
         }
       }
@@ -328,11 +332,11 @@ __global__ void __launch_bounds__(kBT) kb_a_dual(int W, const int32_t* __restric
     for (int f = threadIdx.x; f < rows * K; f += kBT) yK[(size_t)(r0 + b0) * K + f] = S.u.sums[f / K][f % K];
     __syncthreads();
   }
-  batch_panel_partials<K, 1>(S, acc, lp, true, W, w);
+  batch_block_partials<K, 1, VW>(S, acc, lp, true, W, w);
 }
 
 // rows of A^T for K LPs: AtY' = A^T y', interaction and ||dx||^2 partials (StepEpilogue)
-template <int K>
+template <int K, int VW>
 __global__ void __launch_bounds__(kBT) kb_at_step(int W, const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                                   const double* __restrict__ val, const BatchLp* __restrict__ lp, const double* __restrict__ yK)
 {
@@ -373,14 +377,14 @@ __global__ void __launch_bounds__(kBT) kb_at_step(int W, const int32_t* __restri
           atyn[r0 + r]    = v;
           const double dx = xnv[j] - xv[j];
           const double t  = v - av[j];
-          acc[pass][0][j] += t * dx;
-          acc[pass][1][j] += dx * dx;
+          acc[pass][0][j % VW] += t * dx;
+          acc[pass][1][j % VW] += dx * dx;
         }
       }
     }
     __syncthreads();
   }
-  batch_panel_partials<K, 2>(S, acc, lp, false, W, w);
+  batch_block_partials<K, 2, VW>(S, acc, lp, false, W, w);
 }
 
 // columns ascending within every row?  (the panels add a row's products slab by slab = by ascending column; the batched products
@@ -401,6 +405,13 @@ struct pdlpdev_batch {
   BatchLp* lp_dev = nullptr;
   pdlpdev_decision_args* dargs_dev = nullptr;
   double *xK = nullptr, *yK = nullptr;
+  // the row blocks whose partial sums the products reproduce: the panels of the single-LP layout (512 "threads"), or the row blocks
+  // of the CSR stream kernels (256)
+  struct Side {
+    int W = 0;
+    const int32_t* row0 = nullptr;
+    bool panel = false;
+  } a_side, t_side;
   std::map<int, hipGraphExec_t> graphs;
 };
 
@@ -419,10 +430,9 @@ static int batch_enqueue_attempt(pdlpdev_batch* b, hipEvent_t* ev = nullptr)
   hipStream_t s   = b->stream;
   pdlpdev_ctx* c0 = b->ctx[0];
   int n           = c0->n;
-  const PanelView& A = c0->pa.v;
-  const PanelView& T = c0->pat.v;
-  int aw = A.W, tw = T.W;
-  const int32_t *arow0 = A.row0, *trow0 = T.row0;
+  int aw = b->a_side.W, tw = b->t_side.W;
+  const int32_t *arow0 = b->a_side.row0, *trow0 = b->t_side.row0;
+  const bool ap = b->a_side.panel, tp = b->t_side.panel;
   const int pgrid = std::min((n + kBT - 1) / kBT, 4096);
   if (ev) {
     void* a0[] = {&b->lp_dev, &n, &b->xK};
@@ -430,14 +440,16 @@ static int batch_enqueue_attempt(pdlpdev_batch* b, hipEvent_t* ev = nullptr)
     void* a2[] = {&tw, &trow0, &c0->hat_off, &c0->hat_idx, &c0->hat_val, &b->lp_dev, &b->yK};
     void* a3[] = {&b->dargs_dev};
     HIP_TRY(hipExtLaunchKernel((const void*)kb_primal<K>, dim3(pgrid), dim3(kBT), a0, 0, s, ev[0], ev[1], 0));
-    HIP_TRY(hipExtLaunchKernel((const void*)kb_a_dual<K>, dim3(aw), dim3(kBT), a1, 0, s, ev[2], ev[3], 0));
-    HIP_TRY(hipExtLaunchKernel((const void*)kb_at_step<K>, dim3(tw), dim3(kBT), a2, 0, s, ev[4], ev[5], 0));
+    HIP_TRY(hipExtLaunchKernel(ap ? (const void*)kb_a_dual<K, 8> : (const void*)kb_a_dual<K, 4>, dim3(aw), dim3(kBT), a1, 0, s, ev[2], ev[3], 0));
+    HIP_TRY(hipExtLaunchKernel(tp ? (const void*)kb_at_step<K, 8> : (const void*)kb_at_step<K, 4>, dim3(tw), dim3(kBT), a2, 0, s, ev[4], ev[5], 0));
     HIP_TRY(hipExtLaunchKernel((const void*)k_step_decision_batch, dim3(K), dim3(1024), a3, 0, s, ev[6], ev[7], 0));
     return 0;
   }
   kb_primal<K><<<pgrid, kBT, 0, s>>>(b->lp_dev, n, b->xK);
-  kb_a_dual<K><<<aw, kBT, 0, s>>>(aw, arow0, c0->ha_off, c0->ha_idx, c0->ha_val, b->lp_dev, b->xK, b->yK);
-  kb_at_step<K><<<tw, kBT, 0, s>>>(tw, trow0, c0->hat_off, c0->hat_idx, c0->hat_val, b->lp_dev, b->yK);
+  if (ap) kb_a_dual<K, 8><<<aw, kBT, 0, s>>>(aw, arow0, c0->ha_off, c0->ha_idx, c0->ha_val, b->lp_dev, b->xK, b->yK);
+  else kb_a_dual<K, 4><<<aw, kBT, 0, s>>>(aw, arow0, c0->ha_off, c0->ha_idx, c0->ha_val, b->lp_dev, b->xK, b->yK);
+  if (tp) kb_at_step<K, 8><<<tw, kBT, 0, s>>>(tw, trow0, c0->hat_off, c0->hat_idx, c0->hat_val, b->lp_dev, b->yK);
+  else kb_at_step<K, 4><<<tw, kBT, 0, s>>>(tw, trow0, c0->hat_off, c0->hat_idx, c0->hat_val, b->lp_dev, b->yK);
   k_step_decision_batch<<<K, 1024, 0, s>>>(b->dargs_dev);
   LAUNCH_CHECK();
   return 0;
@@ -560,12 +572,26 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
     if (!c || c->ha_off != c0->ha_off || c->hat_off != c0->hat_off || c->pa.v.row0 != c0->pa.v.row0 || c->stream != c0->stream)
       return fail(-1, "pdlpdev_batch_create: the contexts do not share one matrix (pdlpdev_clone_shared)");
   }
-  const PanelView& A = c0->pa.v;
-  const PanelView& T = c0->pat.v;
-  if (!c0->pa.on || !c0->pat.on || A.seg || T.seg || A.own_row || T.own_row || A.any_long || T.any_long || A.dense_add || T.dense_add || c0->dense.on ||
-      c0->comm || c0->small_resident || c0->a_nlong || c0->at_nlong)
-    return fail(-7, "pdlpdev_batch_create: not eligible (the batched products reproduce the row-sum panels' reductions: both matrices in that layout, "
-                    "no row of more than %d entries, no dense segments, one GPU)", kLongRow);
+  // per side: the row-sum variant of the panels, or the CSR stream layout -- the two whose rows are summed left to right by one lane and
+  // whose per-block reduction the batched products reproduce
+  pdlpdev_batch::Side side[2];
+  for (int t = 0; t < 2; ++t) {
+    const pdlpdev_ctx::Panels& P = t ? c0->pat : c0->pa;
+    const bool jag = t ? c0->jat.on : c0->ja.on, pb = t ? c0->pbat.on : c0->pba.on;
+    const int nlong = t ? c0->at_nlong : c0->a_nlong;
+    bool ok = !jag && !pb && nlong == 0;
+    if (ok && P.on) {
+      ok      = !P.v.seg && !P.v.own_row && !P.v.any_long && !P.v.dense_add;
+      side[t] = pdlpdev_batch::Side{P.v.W, P.v.row0, true};
+    } else if (ok) {
+      side[t] = pdlpdev_batch::Side{t ? c0->at_nb : c0->a_nb, t ? c0->at_rb : c0->a_rb, false};
+      ok      = side[t].W > 0 && side[t].row0 != nullptr;
+    }
+    if (!ok || c0->dense.on || c0->comm || c0->small_resident)
+      return fail(-7, "pdlpdev_batch_create: not eligible (the batched products reproduce the reductions of the row-sum panels and of the CSR stream "
+                      "kernels: both matrices in one of these layouts, no row of more than %d entries, no dense segments, one GPU, not the resident "
+                      "small-LP loop)", kLongRow);
+  }
   HIP_TRY(hipSetDevice(c0->device));
   {
     int* bad = nullptr;
@@ -582,13 +608,14 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
   pdlpdev_batch* b = new pdlpdev_batch();
   *out      = b;
   b->K = K, b->device = c0->device, b->stream = c0->stream;
+  b->a_side = side[0], b->t_side = side[1];
   std::vector<BatchLp> h(K);
   std::vector<pdlpdev_decision_args> dargs(K);
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = ctx[l];
     b->ctx[l]      = c;
     h[l] = BatchLp{c->ctl, c->y[0], c->y[1], c->sumy, c->lo, c->hi, c->x[0], c->x[1], c->aty[0], c->aty[1], c->sumx, c->c, c->lb, c->ub, c->ubd, c->part_a, c->part_at};
-    dargs[l] = pdlpdev_decision_args{c->ctl, c->part_a, c->pa.v.W, c->part_at, c->pat.v.W, c->sp};
+    dargs[l] = pdlpdev_decision_args{c->ctl, c->part_a, side[0].W, c->part_at, side[1].W, c->sp};
   }
   HIP_TRY(hipMalloc((void**)&b->lp_dev, K * sizeof(BatchLp)));
   HIP_TRY(hipMalloc((void**)&b->xK, ((size_t)c0->n * K + 64) * sizeof(double)));

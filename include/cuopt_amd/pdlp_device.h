@@ -277,8 +277,9 @@ int pdlpdev_get_ctl(pdlpdev_ctx* ctx, pdlpdev_ctl* ctl);
  * pdlpdev_batch_create: K = 2, 4, 8 or 16 such contexts (ctx[0] may be the parent).  The two products of an attempt then serve all K LPs
  * from ONE pass over the matrix: the K gathered vectors are interleaved, a row belongs to a group of K lanes, one 64-byte request
  * fetches a column's entry of eight LPs.  Each LP's trajectory is BIT-IDENTICAL to the one pdlpdev_run gives it (same row sums, same
- * epilogue expressions, the panel kernels' per-workgroup reduction trees reproduced).  -7: not eligible -- both matrices must be in
- * the row-sum variant of the panel layout with no row beyond 128 entries and no dense segments, columns ascending within rows.
+ * epilogue expressions, the single kernels' per-block reduction trees reproduced).  -7: not eligible -- each matrix must be in the
+ * row-sum variant of the panel layout or in the CSR stream layout, with no row beyond 128 entries and no dense segments, columns
+ * ascending within rows; not the resident small-LP loop, not a sharded context.
  * pdlpdev_batch_run: attempts until LP l holds targets[l] accepted steps (<= 0: LP l rests); ctl[l] receives its control block. */
 typedef struct pdlpdev_batch pdlpdev_batch;
 int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent);

@@ -11,12 +11,13 @@ from cuopt_amd import capi, synthetic  # noqa: E402
 
 
 def load():
+    base = os.environ.get("BATCH_PROBE_BASE", "c3")
     cache = os.environ.get("CUOPT_AMD_LP_CACHE")
-    f = os.path.join(cache, "c3.npz") if cache else None
+    f = os.path.join(cache, "%s.npz" % base) if cache else None
     if f and os.path.exists(f):
         z = np.load(f, allow_pickle=False)
         return {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
-    p = synthetic.generate(**synthetic.CONFIGS["c3"])
+    p = synthetic.generate(**synthetic.CONFIGS[base])
     if f:
         os.makedirs(cache, exist_ok=True)
         np.savez(f, **{k: v for k, v in p.items() if isinstance(v, (np.ndarray, int, float, bool, np.integer, np.floating))})

@@ -51,7 +51,7 @@ for k, cs in acc.items():
 PYEOF
                cat "$OUT/r05_gather_calibration.txt"; rm -rf "$OUT/gcal_fetch" "$OUT/gcal_req" ;;
     batchprobe) timeout 900 python scripts/r05_batch_probe.py $(echo "$arg" | tr ',' ' ') > "$OUT/batchprobe.log" 2>&1; grep -E "RATE|Traceback|Error|assert" "$OUT/batchprobe.log" | cut -c1-300 ;;
-    batchprof) R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/batchprof" -- env BATCH_PROBE_GRAPH=0 python "$R/scripts/r05_batch_probe.py" $arg > "$R/$OUT/batchprof.log" 2>&1)
+    batchprof) R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/batchprof" -- env BATCH_PROBE_GRAPH=0 BATCH_PROBE_BASE=${BATCH_PROBE_BASE:-c3} python "$R/scripts/r05_batch_probe.py" $arg > "$R/$OUT/batchprof.log" 2>&1)
           F=$(find "$OUT/batchprof" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/r05_batch_${arg}_kernel_stats.csv" && head -n 12 "$F" | cut -c1-160; rm -rf "$OUT/batchprof" ;;
     batchspmv) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/batch_spmv_probe.hip -o /tmp/batch_spmv_probe > "$OUT/batch_spmv_build.log" 2>&1
                for a in $(echo "$arg" | tr ',' ' '); do timeout 300 /tmp/batch_spmv_probe $a >> "$OUT/r05_batch_spmv_probe.txt" 2>&1; done; cat "$OUT/r05_batch_spmv_probe.txt" ;;

@@ -47,9 +47,10 @@ def same(a, b, sa, sb, what):
         np.testing.assert_array_equal(u, v, err_msg="%s: %s" % (what, name))
 
 
+@pytest.mark.parametrize("layout", ["panel", "stream"])
 @pytest.mark.parametrize("k", [2, 4, 8, 16])
-def test_batch_trajectories_are_bit_identical_to_single_solves(k, monkeypatch):
-    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+def test_batch_trajectories_are_bit_identical_to_single_solves(k, layout, monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", layout)
     p = synthetic.generate(30000, 24000, 10, seed=21)
     bounds = variants(p, k)
     # the single solves: the state after 130 iterations (mid-way between two major iterations) and the end
@@ -57,7 +58,7 @@ def test_batch_trajectories_are_bit_identical_to_single_solves(k, monkeypatch):
     for lb, ub in bounds:
         s = capi.Solver(dict(p, lb=lb, ub=ub), tol=1e-5, iteration_limit=LIMIT)
         lay = s.device.layout()
-        assert lay["A"]["layout"] == "panel" and lay["At"]["layout"] == "panel", lay
+        assert lay["A"]["layout"] == layout and lay["At"]["layout"] == layout, lay
         a = s.advance(130)
         sa = s.solution()
         b = s.advance()
@@ -117,11 +118,12 @@ def test_clone_alone_is_a_fresh_solver_and_row_bounds_travel(monkeypatch):
     batch.close(), child.close(), parent.close()
 
 
-def test_not_eligible_layouts_are_refused():
+def test_not_eligible_layouts_are_refused(monkeypatch):
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
     p = synthetic.generate(20000, 20000, 10, seed=2, band=500)
     parent = capi.Solver(p, tol=1e-4, iteration_limit=200)
     lay = parent.device.layout()
-    assert not (lay["A"]["layout"] == "panel" and lay["At"]["layout"] == "panel"), lay  # (a band: jagged rows or the CSR stream)
+    assert lay["A"]["layout"] == "jag" or lay["At"]["layout"] == "jag", lay  # (a band: jagged rows with LDS column sets)
     child = parent.clone()
     with pytest.raises(capi.CuOptError) as e:
         capi.SharedMatrixBatch([parent, child])
