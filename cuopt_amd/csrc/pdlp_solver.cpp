@@ -1656,12 +1656,12 @@ static int shared_matrix_batch_solve(int32_t count, const cuoptamd_lp* lps, cons
                                      cuoptamd_result* results, double** x, double** y, double** rc)
 {
   const cuoptamd_lp& L0 = lps[0];
-  if (L0.m <= 0 || L0.n <= 0) return kNotShared;
+  if (L0.m <= 0 || L0.n <= 0 || !L0.offsets || !L0.lb || !L0.ub || !L0.lo || !L0.hi) return kNotShared;
   const size_t nnz = (size_t)L0.offsets[L0.m];
   for (int i = 1; i < count; ++i) {
     const cuoptamd_lp& L = lps[i];
     if (L.m != L0.m || L.n != L0.n || L.maximize != L0.maximize || L.objective_offset != L0.objective_offset) return kNotShared;
-    auto same = [](const void* a, const void* b, size_t bytes) { return a == b || memcmp(a, b, bytes) == 0; };
+    auto same = [](const void* a, const void* b, size_t bytes) { return a == b || (a && b && memcmp(a, b, bytes) == 0); };
     if (!same(L.offsets, L0.offsets, ((size_t)L0.m + 1) * sizeof(int32_t)) || !same(L.indices, L0.indices, nnz * sizeof(int32_t)) ||
         !same(L.values, L0.values, nnz * sizeof(double)) || !same(L.c, L0.c, (size_t)L0.n * sizeof(double)))
       return kNotShared;
