@@ -572,6 +572,8 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
     if (!c || c->ha_off != c0->ha_off || c->hat_off != c0->hat_off || c->pa.v.row0 != c0->pa.v.row0 || c->stream != c0->stream)
       return fail(-1, "pdlpdev_batch_create: the contexts do not share one matrix (pdlpdev_clone_shared)");
   }
+  if ((int64_t)std::max(c0->m, c0->n) * K >= ((int64_t)1 << 32))
+    return fail(-7, "pdlpdev_batch_create: not eligible (the interleaved vectors are addressed with 32-bit element offsets: max(m, n) * K < 2^32)");
   // per side: the row-sum variant of the panels, or the CSR stream layout -- the two whose rows are summed left to right by one lane and
   // whose per-block reduction the batched products reproduce
   pdlpdev_batch::Side side[2];
