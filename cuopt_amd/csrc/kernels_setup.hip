@@ -1658,6 +1658,410 @@ int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, 
 }
 
 // ================================================================================================
+// gather-free layout from a device-resident CSR (returns 1: not built here -- nothing was allocated, the host constructs it; 0: built or
+// "does not fit" with dst->on false and *why set).  Every array is bit-identical to build_pb's (kernels_pb.hip), which stays the tests'
+// reference construction:
+//   * the bins (consecutive rows, a nonzero target lowered until every bin's padded image fits) are cut on the HOST from the offsets --
+//     a chain of binary searches, one per bin; whether a target fits is decided on the device (the padded size of every bin);
+//   * a workgroup per bin SORTS the bin's entries by (source panel, position in the bin) -- unique 32-bit words, a bitonic sort in LDS --
+//     which is the order phase P stores them in: an entry's rank inside its (bin, panel) chunk is its distance from the chunk's first
+//     position, the chunk's place in the bin's image the sum of the padded chunks in front of it (one scan of the run ends);
+//   * chunk sizes go to a B x S table (16-bit), its transposed exclusive scan gives the panel-major starts of phase P;
+//   * a second kernel per bin sorts the rows by length (descending, ties by row: what std::stable_sort leaves) and lays the entries'
+//     positions out along the jagged diagonals of every group of 64 rows -- a wave per group, one ballot per diagonal.
+// ================================================================================================
+namespace {
+constexpr int kPbBinT  = 1024;
+constexpr int kPbSortN = 16384;  // words a bin's sort may take (>= kPbCap)
+static_assert(kPbCap <= kPbSortN && kPbMaxRows <= 1024, "a bin's entries / rows fit the LDS sorts");
+
+// ascending bitonic sort of n (a power of two) words in LDS by the whole workgroup
+template <int T>
+__device__ __forceinline__ void lds_bitonic_sort(uint32_t* w, int n)
+{
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += T) {
+        const int x = i ^ j;
+        if (x > i) {
+          const uint32_t a = w[i], b = w[x];
+          if ((a > b) == ((i & k) == 0)) w[i] = b, w[x] = a;
+        }
+      }
+      __syncthreads();
+    }
+}
+// exclusive max-scan over the workgroup's threads (values >= 0)
+template <int T>
+__device__ __forceinline__ int block_exclusive_max(int v, int* scratch)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc = o > inc ? o : inc;
+  }
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w)
+    if (w < wave) base = scratch[w] > base ? scratch[w] : base;
+  __syncthreads();
+  int ex = __shfl_up(inc, 1, 64);
+  if (lane == 0) ex = 0;
+  return ex > base ? ex : base;
+}
+
+__global__ void __launch_bounds__(kT) k_max_row_len(int32_t rows, const int32_t* __restrict__ off, int* __restrict__ out)
+{
+  int best = 0;
+  for (int64_t r = (int64_t)blockIdx.x * kT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kT) best = max(best, off[r + 1] - off[r]);
+  for (int d = 1; d < 64; d <<= 1) best = max(best, __shfl_xor(best, d, 64));
+  if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+
+// One bin.  MODE 0: its padded size only (the target search).  1: + the chunk sizes.  2: placement (phase P order, local columns,
+// pieces, every entry's position in the bin's image).
+constexpr int kPbItems = (kPbCap + kPbBinT - 1) / kPbBinT;  // positions per thread
+template <int MODE>
+__global__ void __launch_bounds__(kPbBinT)
+k_pb_bin(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int panel_shift, int gshift, int S, int B,
+         int32_t* __restrict__ bin_size, int* __restrict__ maxpad, uint16_t* __restrict__ cnt, const int32_t* __restrict__ pstart,
+         const int32_t* __restrict__ bin_e0, int32_t* __restrict__ perm, uint16_t* __restrict__ lidx, int32_t* __restrict__ piece_dst,
+         uint16_t* __restrict__ epos)
+{
+  __shared__ uint32_t w[kPbSortN];
+  __shared__ int scratch[kPbBinT / 64 + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = row0[b], r1 = row0[b + 1];
+  const int k0 = off[r0], n = off[r1] - k0;
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int i = tid; i < n2; i += kPbBinT) w[i] = i < n ? ((uint32_t)(idx[k0 + i] >> panel_shift) << 14 | (uint32_t)i) : 0xFFFFFFFFu;
+  __syncthreads();
+  lds_bitonic_sort<kPbBinT>(w, n2);
+  const int G = 1 << gshift;
+  // thread t looks after the sorted positions [t * kPbItems, (t + 1) * kPbItems)
+  const int p0 = tid * kPbItems;
+  // (1) the first position of every position's chunk: a max-scan of the chunk starts
+  int rs[kPbItems];
+  int last = 0;
+#pragma unroll
+  for (int q = 0; q < kPbItems; ++q) {
+    const int i = p0 + q;
+    const bool start = i < n && (i == 0 || (w[i] >> 14) != (w[i - 1] >> 14));
+    last  = start ? i : last;
+    rs[q] = last;  // (so far: the latest start inside this thread's range, 0 if none)
+  }
+  const int before = block_exclusive_max<kPbBinT>(last, scratch);
+#pragma unroll
+  for (int q = 0; q < kPbItems; ++q) rs[q] = rs[q] > before ? rs[q] : before;
+  // (2) the padding in front of every position: a chunk's padding counts from its last entry on
+  int padv[kPbItems], sum = 0;
+#pragma unroll
+  for (int q = 0; q < kPbItems; ++q) {
+    const int i = p0 + q;
+    const bool end = i < n && (i == n - 1 || (w[i] >> 14) != (w[i + 1] >> 14));
+    padv[q] = end ? (G - ((i - rs[q] + 1) & (G - 1))) & (G - 1) : 0;
+    sum += padv[q];
+  }
+  int total = 0;
+  int P = block_exclusive_scan<kPbBinT>(sum, scratch, &total);
+  if (MODE <= 1) {
+    if (tid == 0) {
+      bin_size[b] = n + total;
+      atomicMax(maxpad, n + total);
+    }
+    if (MODE == 0) return;
+  }
+#pragma unroll
+  for (int q = 0; q < kPbItems; ++q) {
+    const int i = p0 + q;
+    if (i < n) {
+      const int s_ = (int)(w[i] >> 14), e = (int)(w[i] & 0x3FFF), k = k0 + e;
+      const bool end = i == n - 1 || (w[i] >> 14) != (w[i + 1] >> 14);
+      if (MODE == 1) {
+        if (end) cnt[(size_t)b * S + s_] = (uint16_t)(i - rs[q] + 1);
+      } else {
+        const int32_t ps = pstart[(size_t)s_ * B + b];
+        const int32_t pp = ps + (i - rs[q]);
+        perm[pp]         = k;
+        lidx[pp]         = (uint16_t)(idx[k] & ((1 << panel_shift) - 1));
+        epos[k]          = (uint16_t)(i + P);  // = the chunk's place in the image (its first position + the padding in front) + the rank
+        if (end) {
+          const int np_ = (i - rs[q] + 1 + G - 1) >> gshift;
+          const int32_t q0 = ps >> gshift, d0 = (bin_e0[b] + rs[q] + P) >> gshift;
+          for (int t = 0; t < np_; ++t) piece_dst[q0 + t] = d0 + t;
+        }
+      }
+    }
+    P += padv[q];
+  }
+}
+
+// A bin's padded size (and, WRITE, its chunk sizes) from an LDS histogram over the panels: what the target search and the chunk table
+// need, without the sort -- when the panel counters fit (S <= kPbHistMax)
+constexpr int kPbHistMax = 12288;
+template <bool WRITE>
+__global__ void __launch_bounds__(512)
+k_pb_bin_hist(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int panel_shift, int gshift, int S,
+              int32_t* __restrict__ bin_size, int* __restrict__ maxpad, uint16_t* __restrict__ cnt)
+{
+  extern __shared__ int hist[];
+  __shared__ int scratch[9];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int k0 = off[row0[b]], k1 = off[row0[b + 1]];
+  for (int i = tid; i < S; i += 512) hist[i] = 0;
+  __syncthreads();
+  for (int k = k0 + tid; k < k1; k += 512) atomicAdd(&hist[idx[k] >> panel_shift], 1);
+  __syncthreads();
+  const int G = 1 << gshift;
+  int sum = 0;
+  for (int i = tid; i < S; i += 512) {
+    const int c_ = hist[i];
+    sum += (c_ + G - 1) / G * G;
+    if (WRITE) cnt[(size_t)b * S + i] = (uint16_t)c_;
+  }
+  int total = 0;
+  (void)block_exclusive_scan<512>(sum, scratch, &total);
+  if (tid == 0) {
+    bin_size[b] = total;
+    atomicMax(maxpad, total);
+  }
+}
+
+// padded chunk sizes, panel-major (the order phase P stores the chunks in)
+__global__ void __launch_bounds__(kT) k_pb_chunk_sizes(const uint16_t* __restrict__ cnt, int S, int B, int gshift, int32_t* __restrict__ out)
+{
+  const int G = 1 << gshift;
+  const int64_t total = (int64_t)S * B;
+  for (int64_t t = (int64_t)blockIdx.x * kT + threadIdx.x; t < total; t += (int64_t)gridDim.x * kT) {
+    const int64_t s_ = t / B, b = t % B;
+    out[t] = ((int)cnt[(size_t)b * S + s_] + G - 1) / G * G;
+  }
+}
+__global__ void __launch_bounds__(kT) k_pb_panel_starts(const int32_t* __restrict__ pstart, int S, int B, int32_t* __restrict__ out)
+{
+  for (int s_ = blockIdx.x * kT + threadIdx.x; s_ <= S; s_ += gridDim.x * kT) out[s_] = pstart[(size_t)s_ * B];
+}
+
+// One bin's rows by length (descending, ties by row), the groups of 64 and the jagged diagonals of the entries' positions
+__global__ void __launch_bounds__(1024)
+k_pb_rows(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const uint16_t* __restrict__ epos, const int32_t* __restrict__ bin_grp,
+          uint32_t* __restrict__ sr, int32_t* __restrict__ grp_pos, uint16_t* __restrict__ pos)
+{
+  __shared__ uint32_t w[1024];
+  __shared__ int scratch[17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = row0[b], nr = row0[b + 1] - r0;
+  int n2 = 1;
+  while (n2 < nr) n2 <<= 1;
+  if (tid < n2) w[tid] = tid < nr ? ((uint32_t)(0xFFFF - (off[r0 + tid + 1] - off[r0 + tid])) << 10 | (uint32_t)tid) : 0xFFFFFFFFu;
+  __syncthreads();
+  lds_bitonic_sort<1024>(w, n2);
+  const bool live = tid < nr;
+  const int row   = live ? (int)(w[tid] & 1023) : 0;
+  const int len   = live ? 0xFFFF - (int)(w[tid] >> 10) : 0;
+  if (live) sr[r0 + tid] = (uint32_t)len << 16 | (uint32_t)row;
+  const int at = off[r0] + block_exclusive_scan<1024>(len, scratch, nullptr);  // where this row's group would start if it were a group's first
+  const int lane = tid & 63, g = tid >> 6;
+  if (lane == 0 && live) grp_pos[bin_grp[b] + g] = at;
+  // the group's diagonals: diagonal k holds the k-th entry of every row that has one -- a prefix of the (sorted) group
+  int D          = __shfl(at, 0, 64);
+  const int kmax = __shfl(len, 0, 64);
+  const int k_row = off[r0 + row];
+  for (int k = 0; k < kmax; ++k) {
+    const unsigned long long mask = __ballot(len > k);
+    if (len > k) pos[D + lane] = epos[k_row + k];
+    D += __popcll(mask);
+  }
+}
+}  // namespace
+
+int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
+                    int cus, bool forced, std::string* why)
+{
+  const int64_t nnz = rows > 0 ? h_off[rows] : 0;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) { *why = "empty matrix"; return 0; }
+  hipStream_t s = c->stream;
+  const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto plap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cuopt_amd setup]     gather-free: %-14s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  std::vector<void*> tmp;  // device temporaries of this construction
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() { for (void* p : v) (void)hipFree(p); }
+  } free_tmp{tmp};
+  auto talloc = [&](void** p, size_t bytes) -> int {
+    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  int* d_scal = nullptr;  // [0] longest row, [1] largest padded bin
+  TRY(talloc((void**)&d_scal, 2 * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d_scal, 0, 2 * sizeof(int), s));
+  k_max_row_len<<<grid_of(rows), kT, 0, s>>>(rows, d_off, d_scal);
+  int h_scal[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int longest = h_scal[0];
+  // a row is summed by ONE lane, left to right: fine up to a few hundred entries, a serial chain beyond
+  if (longest > (forced ? kPbCap / 2 : 256)) { *why = "a row with " + std::to_string(longest) + " nonzeros"; return 0; }
+  const int panel_shift = cols > (1 << 21) ? 14 : 13;
+  const int S           = (int)(((int64_t)cols + (1 << panel_shift) - 1) >> panel_shift);
+  if (S >= (1 << 18)) return 1;  // (the sort's words hold 18 bits of panel number)
+  const bool use_hist = S <= kPbHistMax && cuopt_amd::tune_int("pb_hist", 1) != 0;  // (the panel counters of a bin fit in LDS; tests switch it off)
+  // bins: consecutive rows, <= target nonzeros and <= kPbMaxRows rows; the target is lowered until every bin's padded image fits
+  double target = 0.93 * kPbCap;
+  int G = 8, gshift = 3;
+  std::vector<int32_t> row0;
+  int32_t *d_row0 = nullptr, *d_bin_size = nullptr;
+  int B = 0;
+  for (int iter = 0; iter < 24; ++iter) {
+    row0.assign(1, 0);
+    while (row0.back() < rows) {
+      const int32_t r0 = row0.back();
+      const int64_t lim = (int64_t)h_off[r0] + (int64_t)target;
+      // (std::upper_bound over the whole offset array is two dozen cache misses per bin on a cold 40 MB array -- 30 ms at 1e7 rows:
+      //  the answer lies within kPbMaxRows rows of r0, and near r0 + target / (nonzeros per row): bracket it from there)
+      const int32_t key = (int32_t)std::min<int64_t>(lim, nnz);
+      const int32_t cap = (int32_t)std::min<int64_t>((int64_t)rows + 1, (int64_t)r0 + kPbMaxRows + 2);
+      int32_t lo_ = r0, hi_ = cap;  // the first index in [lo_, hi_) whose offset exceeds the key (hi_: none in the bracket)
+      {
+        int32_t g = (int32_t)std::min<int64_t>((int64_t)cap - 1, (int64_t)r0 + (int64_t)(target * (double)rows / (double)nnz));
+        int32_t step = 8;
+        if (h_off[g] > key) {
+          hi_ = g;
+          while (hi_ - step > r0 && h_off[hi_ - step] > key) hi_ -= step, step *= 2;
+          lo_ = std::max(r0, hi_ - step);
+        } else {
+          lo_ = g + 1;
+          while (lo_ + step < cap && h_off[lo_ + step - 1] <= key) lo_ += step, step *= 2;
+          hi_ = std::min(cap, lo_ + step);
+        }
+      }
+      int32_t r1 = (int32_t)(std::upper_bound(h_off + lo_, h_off + hi_, key) - h_off) - 1;
+      r1 = std::min(std::max(r1, r0 + 1), std::min(rows, r0 + kPbMaxRows));
+      row0.push_back(r1);
+    }
+    B = (int)row0.size() - 1;
+    if (iter == 0) {
+      G      = nnz / ((int64_t)S * B) >= 24 ? 8 : 4;
+      gshift = G == 8 ? 3 : 2;
+      // (a lower target means more bins, at most one per row)
+      TRY(talloc((void**)&d_row0, ((size_t)rows + 1) * sizeof(int32_t)));
+      TRY(talloc((void**)&d_bin_size, ((size_t)rows + 1) * sizeof(int32_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(d_row0, row0.data(), ((size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_scal + 1, 0, sizeof(int), s));
+    if (use_hist) k_pb_bin_hist<false><<<B, 512, (size_t)S * sizeof(int), s>>>(d_row0, d_off, d_idx, panel_shift, gshift, S, d_bin_size, d_scal + 1, nullptr);
+    else k_pb_bin<0><<<B, kPbBinT, 0, s>>>(d_row0, d_off, d_idx, panel_shift, gshift, S, B, d_bin_size, d_scal + 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_scal + 1, d_scal + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int maxpad = h_scal[1];
+    if (maxpad <= kPbCap) break;
+    if (iter == 23) { *why = "bins do not converge"; return 0; }
+    target *= std::min(0.97, 0.99 * (double)kPbCap / (double)maxpad);
+  }
+  plap("bins");
+  // chunk sizes (bin-major, 16-bit), the bins' images, the panel-major starts of phase P
+  uint16_t* d_cnt = nullptr;
+  TRY(talloc((void**)&d_cnt, (size_t)B * S * sizeof(uint16_t)));
+  HIP_TRY(hipMemsetAsync(d_scal + 1, 0, sizeof(int), s));
+  if (use_hist) {
+    k_pb_bin_hist<true><<<B, 512, (size_t)S * sizeof(int), s>>>(d_row0, d_off, d_idx, panel_shift, gshift, S, d_bin_size, d_scal + 1, d_cnt);
+  } else {
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)B * S * sizeof(uint16_t), s));
+    k_pb_bin<1><<<B, kPbBinT, 0, s>>>(d_row0, d_off, d_idx, panel_shift, gshift, S, B, d_bin_size, d_scal + 1, d_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> bin_size(B), bin_e0((size_t)B + 1, 0);
+  HIP_TRY(hipMemcpyAsync(bin_size.data(), d_bin_size, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    bin_e0[b] = (int32_t)total;
+    total += bin_size[b];
+    if (total >= ((int64_t)1 << 31) - 65536) { *why = "more than 2^31 padded entries"; return 0; }
+  }
+  bin_e0[B] = (int32_t)total;
+  const int64_t cells = (int64_t)S * B;
+  int32_t *d_sizes = nullptr, *d_pstart = nullptr, *d_bs = nullptr;
+  TRY(talloc((void**)&d_sizes, (size_t)cells * sizeof(int32_t)));
+  TRY(talloc((void**)&d_pstart, ((size_t)cells + 1) * sizeof(int32_t)));
+  TRY(talloc((void**)&d_bs, ((size_t)(cells + 1) / 4096 + 2) * sizeof(int32_t)));
+  k_pb_chunk_sizes<<<grid_of(cells), kT, 0, s>>>(d_cnt, S, B, gshift, d_sizes);
+  TRY(dev_exclusive_scan(s, d_sizes, d_pstart, cells, d_bs));
+  plap("chunk table");
+  // the layout's own arrays
+  int32_t *piece_dst = nullptr, *wg_e0 = nullptr, *wg_panel = nullptr, *bin_row0 = nullptr, *d_bin_e0 = nullptr, *bin_grp = nullptr, *grp_pos = nullptr;
+  uint16_t *lidx = nullptr, *pos = nullptr, *d_epos = nullptr;
+  uint32_t* sr = nullptr;
+  double* prod = nullptr;
+  TRY(dev_alloc(c, &dst->perm, (size_t)total + 64));
+  TRY(dev_alloc(c, &piece_dst, (size_t)(total >> gshift) + 64));
+  TRY(dev_alloc(c, &lidx, (size_t)total + 64));
+  TRY(dev_alloc(c, &pos, (size_t)nnz + 128));
+  TRY(dev_alloc(c, &sr, (size_t)rows + 64));
+  TRY(dev_alloc(c, &dst->val, (size_t)total + 64));
+  TRY(dev_alloc(c, &prod, (size_t)total + 256));
+  TRY(talloc((void**)&d_epos, ((size_t)nnz + 64) * sizeof(uint16_t)));
+  HIP_TRY(hipMemsetAsync(dst->perm, 0xFF, (size_t)total * sizeof(int32_t), s));  // padding slots: -1 (their lidx: 0, dev_alloc's zero fill)
+  TRY(upload_i32(c, &bin_row0, row0.data(), row0.size()));
+  TRY(upload_i32(c, &d_bin_e0, bin_e0.data(), bin_e0.size()));
+  std::vector<int32_t> h_bin_grp((size_t)B + 1, 0);
+  for (int b = 0; b < B; ++b) h_bin_grp[b + 1] = h_bin_grp[b] + (row0[b + 1] - row0[b] + 63) / 64;
+  TRY(upload_i32(c, &bin_grp, h_bin_grp.data(), h_bin_grp.size()));
+  TRY(dev_alloc(c, &grp_pos, (size_t)h_bin_grp[B] + 1));
+  plap("alloc");
+  k_pb_bin<2><<<B, kPbBinT, 0, s>>>(bin_row0, d_off, d_idx, panel_shift, gshift, S, B, nullptr, nullptr, nullptr, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, d_epos);
+  HIP_TRY(hipGetLastError());
+  plap("place");
+  k_pb_rows<<<B, 1024, 0, s>>>(bin_row0, d_off, d_epos, bin_grp, sr, grp_pos, pos);
+  HIP_TRY(hipGetLastError());
+  const int32_t nnz32 = (int32_t)nnz;
+  HIP_TRY(hipMemcpyAsync(grp_pos + h_bin_grp[B], &nnz32, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  plap("rows");
+  // P workgroups: every panel's entries in Q parts (pieces are not split)
+  int32_t* d_pan = nullptr;
+  TRY(talloc((void**)&d_pan, ((size_t)S + 1) * sizeof(int32_t)));
+  k_pb_panel_starts<<<grid_of(S + 1), kT, 0, s>>>(d_pstart, S, B, d_pan);
+  std::vector<int32_t> pan((size_t)S + 1);
+  HIP_TRY(hipMemcpyAsync(pan.data(), d_pan, pan.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> h_wg_e0, h_wg_panel;
+  const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
+  for (int s_ = 0; s_ < S; ++s_) {
+    const int64_t e0 = pan[s_], e1 = pan[s_ + 1];
+    const int64_t per = std::max<int64_t>(G, ((e1 - e0 + Q - 1) / Q + G - 1) / G * G);
+    for (int64_t e = e0; e < e1; e += per) {
+      h_wg_e0.push_back((int32_t)e);
+      h_wg_panel.push_back(s_);
+    }
+  }
+  h_wg_e0.push_back((int32_t)total);
+  TRY(upload_i32(c, &wg_e0, h_wg_e0.data(), h_wg_e0.size()));
+  TRY(upload_i32(c, &wg_panel, h_wg_panel.data(), h_wg_panel.size()));
+  HIP_TRY(hipStreamSynchronize(s));  // (the host vectors die here)
+  const int p_threads = panel_shift == 14 ? 1024 : 512;
+  dst->v = PbView{rows, cols, S, B, gshift, panel_shift, (int)h_wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
+                  bin_row0, d_bin_e0, sr, bin_grp, grp_pos, pos, prod};
+  dst->np = total, dst->p_threads = p_threads, dst->pad = (double)total / (double)nnz;
+  dst->on = true;
+  plap("P workgroups");
+  return 0;
+}
+
+// ================================================================================================
 // synthetic LP generated ON THE DEVICE (scale checks near the reference's stated capacity, docs/cuopt/source/faq.rst:368-370: the
 // host generator of cuopt_amd/synthetic.py needs minutes and tens of GB at 1e9 nonzeros).  Same recipe -- a known primal-dual optimal
 // pair by construction, equalities on the first half of the rows, '>=' rows with slack on the second -- with the columns of a row

@@ -1564,7 +1564,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       JagHost jat;
       PbHost hbt;
       PanelHost hat;
-      bool want_pb_layout = false, want_dev_panels = false;
+      bool want_pb_layout = false, want_dev_panels = false, want_dev_pb = false, panels_pending = false;
       ~TSide() { if (worker.joinable()) worker.join(); }
     } ts;
     const int32_t* T_off = at_offsets;
@@ -1574,6 +1574,9 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     auto t_idx_host = [&]() -> const int32_t* { return an ? analysis_host_t_idx(an) : at_indices; };
     const bool skip_jag_a  = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[0] < 0.35;
     const bool skip_jag_at = an && an->estimated && !an->permuted && mode != "jag" && an->saving_natural[1] < 0.35;
+    // the gather-free layout is built on the device when the matrices are there (CUOPT_AMD_TUNE=pb_device=0: the host construction,
+    // the tests' reference)
+    const bool pb_on_device = an && !DH.on && cuopt_amd::tune_int("pb_device", 1) != 0;
     auto at_side = [&] {
       const auto w0 = std::chrono::steady_clock::now();
       auto wlap = [&](const char* what) {
@@ -1598,6 +1601,12 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       }
       if (!ts.jat.ok && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
         ts.want_pb_layout = true;
+        if (pb_on_device) {
+          ts.want_dev_pb = true;  // (built on the device by the main thread, below; whether panels are wanted instead is known after that)
+          ts.panels_pending = mode != "stream" && mode != "jag" && mode != "pb";
+          wlap("layouts");
+          return;
+        }
         if (!T_idx) T_idx = t_idx_host();
         ts.hbt            = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
       }
@@ -1609,7 +1618,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     };
     // (an analysed matrix: nothing to wait for and little left to do on the host -- the A^T side runs inline, behind the A side;
     // a thread of its own took 3 ms to do 0.5 ms of work next to the main thread's HIP calls)
-    const bool at_thread = !an || (try_jag && !skip_jag_at) || DH.on || want_pb(m);  // (host constructions worth a thread)
+    const bool at_thread = !an || (try_jag && !skip_jag_at) || DH.on || (want_pb(m) && !pb_on_device);  // (host constructions worth a thread)
     if (at_thread) ts.worker = std::thread(at_side);
     if (try_jag) {
       JagHost ja;
@@ -1620,11 +1629,21 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       lap("upload jag A");
     }
     if (!ctx->ja.on && want_pb(n) && (mode == "pb" || want_panels(m, n, A_off, A_idx, "A"))) {
-      PbHost hb = build_pb(m, n, A_off, A_idx, ctx->cus, mode == "pb");
-      lap("build_pb A");
-      if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", hb.why.c_str());
-      TRY(upload_pb(ctx, &ctx->pba, hb));
-      lap("upload pb A");
+      int on_device = 1;
+      if (pb_on_device) {
+        std::string why;
+        on_device = build_pb_device(ctx, &ctx->pba, m, n, A_off, ctx->ha_off, ctx->ha_idx, ctx->cus, mode == "pb", &why);
+        if (on_device < 0) return on_device;
+        lap("pb A on the device");
+        if (on_device == 0 && !ctx->pba.on && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", why.c_str());
+      }
+      if (on_device == 1) {
+        PbHost hb = build_pb(m, n, A_off, A_idx, ctx->cus, mode == "pb");
+        lap("build_pb A");
+        if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", hb.why.c_str());
+        TRY(upload_pb(ctx, &ctx->pba, hb));
+        lap("upload pb A");
+      }
     }
     if (mode != "stream" && mode != "jag" && mode != "pb" && !ctx->ja.on && !ctx->pba.on && want_panels(m, n, A_off, A_idx, "A")) {
       PanelHost ha;
@@ -1681,6 +1700,20 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     if (try_jag) {
       TRY(upload_jag(ctx, &ctx->jat, ts.jat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload jag At");
+    }
+    if (ts.want_dev_pb) {
+      std::string why;
+      int on_device = build_pb_device(ctx, &ctx->pbat, n, m, T_off, ctx->hat_off, ctx->hat_idx, ctx->cus, mode == "pb", &why);
+      if (on_device < 0) return on_device;
+      if (on_device == 1) {
+        if (!T_idx) T_idx = t_idx_host();
+        ts.hbt = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
+      } else {
+        ts.want_pb_layout = false;  // (nothing to upload)
+        if (!ctx->pbat.on && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", why.c_str());
+      }
+      lap("pb At on the device");
+      if (ts.panels_pending && !ctx->pbat.on && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T")) ts.want_dev_panels = true;
     }
     if (ts.want_pb_layout) {
       if (!ts.hbt.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A^T does not fit the gather-free layout (%s)", ts.hbt.why.c_str());
@@ -3275,6 +3308,22 @@ int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16])
   };
   panels(ctx->pa, ctx->m, out + 3);
   panels(ctx->pat, ctx->n, out + 8);
+  auto gather_free = [&](const pdlpdev_ctx::Pb& P, int64_t side_nnz, uint64_t* o) {  // (a side is in ONE layout: the panels' slots)
+    if (!P.on) return;
+    const PbView& v = P.v;
+    int32_t groups = 0;
+    (void)hipMemcpy(&groups, v.bin_grp + v.B, sizeof(int32_t), hipMemcpyDeviceToHost);
+    o[0] = checksum_device(ctx, P.perm, (size_t)P.np * 4);
+    o[1] = checksum_device(ctx, v.lidx, (size_t)P.np * 2);
+    o[2] = checksum_device(ctx, v.piece_dst, (size_t)(P.np >> v.gshift) * 4);
+    o[3] = checksum_device(ctx, v.pos, (size_t)side_nnz * 2) ^ (checksum_device(ctx, v.sr, (size_t)v.rows * 4) * 3);
+    o[4] = checksum_device(ctx, v.wg_e0, ((size_t)v.nwg + 1) * 4) ^ (checksum_device(ctx, v.wg_panel, (size_t)v.nwg * 4) * 3) ^
+           (checksum_device(ctx, v.bin_row0, ((size_t)v.B + 1) * 4) * 5) ^ (checksum_device(ctx, v.bin_e0, ((size_t)v.B + 1) * 4) * 7) ^
+           (checksum_device(ctx, v.bin_grp, ((size_t)v.B + 1) * 4) * 11) ^ (checksum_device(ctx, v.grp_pos, ((size_t)groups + 1) * 4) * 13) ^
+           (uint64_t)v.S * 17 ^ (uint64_t)v.gshift * 19 ^ (uint64_t)v.panel_shift * 23 ^ (uint64_t)P.p_threads * 29;
+  };
+  gather_free(ctx->pba, ctx->dense.on ? ctx->dense.hot_nnz : ctx->nnz, out + 3);
+  gather_free(ctx->pbat, ctx->dense.on ? ctx->hot_nnz_at : ctx->nnz, out + 8);
   auto jag = [&](const pdlpdev_ctx::Jag& J) -> uint64_t {
     if (!J.on) return 0;
     return checksum_device(ctx, J.v.slot, (size_t)J.nent * 2) ^ (checksum_device(ctx, J.perm, (size_t)J.nent * 4) * 3) ^

@@ -90,6 +90,46 @@ def test_panels_built_on_the_device_are_the_host_construction(family, monkeypatc
     host.close(), dev.close()
 
 
+@pytest.mark.parametrize("shape", ["square", "wide", "ragged", "square_sorted_counts"])
+def test_gather_free_layout_built_on_the_device_is_the_host_construction(shape, monkeypatch):
+    """every array of the gather-free layout (phase-P order + local columns + pieces, the rows by length, the jagged diagonals of
+    positions, bins, groups, P workgroups): FNV-1a checksums of the host construction (build_pb, CUOPT_AMD_TUNE=pb_device=0) against
+    the device construction (sorts and scans per bin), on both matrices; then the products and a solve"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    if shape == "square_sorted_counts":  # the chunk sizes from the sort instead of the LDS histogram (the path of > 12 288 panels)
+        set_tune(monkeypatch, pb_hist=0)
+    if shape.startswith("square"):
+        p = synthetic.generate(120000, 100000, 9, seed=4)
+    elif shape == "wide":
+        p = synthetic.generate(40000, 300000, 8, seed=6)  # (37 panels of 8192 columns on the A side, rows of ~60 entries on it)
+    else:
+        p = synthetic.generate_structured("powerlaw", m=60000, n=60000, k=8, seed=5)  # (row lengths up to the forced limit)
+    set_tune(monkeypatch, pb_device=0)
+    try:
+        host = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+    except capi.CuOptError as e:
+        assert shape == "ragged", e  # a row beyond the layout's limit: both constructions must refuse alike
+        set_tune(monkeypatch, pb_device=None)
+        with pytest.raises(capi.CuOptError):
+            capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+        return
+    set_tune(monkeypatch, pb_device=None)
+    dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+    a, b = host.layout_checksums(), dev.layout_checksums()
+    assert (int(a[15]) >> 6) & 3 == 3, "both sides gather-free"
+    np.testing.assert_array_equal(a, b)
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    np.testing.assert_array_equal(host.spmv(x, False, p["m"]), dev.spmv(x, False, p["m"]))
+    np.testing.assert_array_equal(host.spmv(y, True, p["n"]), dev.spmv(y, True, p["n"]))
+    host.close(), dev.close()
+    r = capi.Solver(p, tol=1e-4, iteration_limit=4000)
+    assert r.device.layout()["A"]["layout"] == "pb"
+    out = r.advance()
+    assert out["status_name"] == "Optimal" and abs(out["primal_objective"] - p["objective_star"]) <= 2e-3 * (1 + abs(p["objective_star"]))
+    r.close()
+
+
 def _family(kind, m):
     if kind == "banded":
         return synthetic.generate(m, m, 10, seed=2, band=2000)
