@@ -2062,6 +2062,442 @@ int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t 
 }
 
 // ================================================================================================
+// jagged rows + LDS column sets from a device-resident CSR (returns 1: not built here -- nothing was allocated, the host constructs it;
+// 0: built, or "not worth it" with dst->on false and dst->saving set).  Every array is bit-identical to build_jag's (kernels_jag.hip),
+// which stays the tests' reference construction:
+//   * the partition: chunks of 8 * brows rows are cut independently, a workgroup per chunk grows block after block exactly like the
+//     sampled estimate does (k_jag_estimate: rows in order while their DISTINCT columns fit the LDS window, an open-addressing table in
+//     LDS, the host's two-step check near the limit) and prices every block's column set;
+//   * per block: its short rows sorted by length (descending, ties by row: a bitonic sort of unique words), passes of 64 dealt to the
+//     waves in snake order; the sizes go to the host for the prefix sums (a few thousand numbers), a second kernel fills the row
+//     descriptors, the 16-bit LDS slots and the permutation along the jagged diagonals (a wave per pass, one ballot per diagonal);
+//     a list-mode block's distinct columns are collected through the LDS table, sorted there, and searched for every entry's slot.
+// ================================================================================================
+namespace {
+constexpr int kJagCutT = 1024, kJagStride = 512;
+struct JagBlockMeta {
+  int32_t end;           // first row behind the block
+  int32_t wbase, wlen;   // contiguous column set (wlen 0: a list)
+  int32_t ncols;         // distinct columns of a list-mode block
+  long long refs, cost;
+};
+
+// One chunk of rows [c0, c1): blocks cut greedily from c0 on (jag_block_end with `row_cap` rows at most), each priced (jag_block_set).
+__global__ void __launch_bounds__(kJagCutT)
+k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                JagBlockMeta* __restrict__ meta /* [rows]: the blocks of chunk t from meta[t * chunk_rows] on */, int32_t* __restrict__ count)
+{
+  extern __shared__ int32_t tab[];  // 2 * wcap slots
+  __shared__ int32_t pre[kJagStride + 1];
+  __shared__ int distinct, fresh, stop, lo, hi, runs, parallel, end_row, scratch[kJagCutT / 64 + 1];
+  __shared__ long long refs;
+  const uint32_t mask = (uint32_t)(2 * wcap - 1);
+  const int t = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * chunk_rows, c1 = min((int64_t)rows, c0 + chunk_rows);
+  int nblocks = 0;
+  for (int64_t first = c0; first < c1;) {
+    for (int i = t; i < 2 * wcap; i += kJagCutT) tab[i] = kEstEmpty;
+    if (t == 0) distinct = 0, stop = 0, lo = 0x7fffffff, hi = -1, runs = 0, refs = 0;
+    __syncthreads();
+    const int64_t last = min(c1, first + row_cap);
+    if (t == 0) end_row = (int)last;
+    __syncthreads();
+    for (int64_t q0 = first; q0 < last && !stop;) {
+      // a stride of up to kJagStride rows whose lengths cannot overflow the window whatever they contain goes in at once (a band's
+      // block: four strides instead of 32 chunks); else a chunk of 64 rows, in parallel or row by row as in k_jag_estimate
+      int nr = (int)min((int64_t)kJagStride, last - q0);
+      {
+        int len = 0;
+        if (t < nr) {
+          len = off[q0 + t + 1] - off[q0 + t];
+          len = len > kLongRow ? 0 : len;  // (long rows do not count)
+        }
+        int total_all = 0;
+        const int ex = block_exclusive_scan<kJagCutT>(t < kJagStride ? len : 0, scratch, &total_all);
+        if (t < nr) pre[t] = ex;
+        if (t == 0) pre[nr] = total_all, parallel = distinct + total_all <= wcap;
+        __syncthreads();
+        if (!parallel && nr > kEstChunk) {  // (the first 64 rows alone: their prefix sums are already there)
+          nr = kEstChunk;
+          if (t == 0) parallel = distinct + pre[nr] <= wcap;
+          __syncthreads();
+        }
+      }
+      const int total = pre[nr];
+      if (parallel) {
+        int added = 0, mn = 0x7fffffff, mx = -1;
+        for (int e = t; e < total; e += kJagCutT) {
+          int a = 0, b = nr;
+          while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (pre[mid] <= e) a = mid; else b = mid;
+          }
+          const int32_t c = idx[off[q0 + a] + (e - pre[a])];
+          mn = c < mn ? c : mn, mx = c > mx ? c : mx;
+          added += est_insert(tab, mask, c);
+        }
+        // (one LDS atomic per wave: every entry hammering the same two words was most of this kernel's time)
+        for (int d = 1; d < 64; d <<= 1) {
+          added += __shfl_xor(added, d, 64);
+          mn = min(mn, __shfl_xor(mn, d, 64)), mx = max(mx, __shfl_xor(mx, d, 64));
+        }
+        if ((t & 63) == 0) {
+          if (added) atomicAdd(&distinct, added);
+          if (mx >= 0) atomicMin(&lo, mn), atomicMax(&hi, mx);
+        }
+        if (t == 0) refs += total;
+        __syncthreads();
+      } else {
+        for (int i = 0; i < nr; ++i) {
+          const int len = pre[i + 1] - pre[i];
+          if (len == 0) continue;
+          const int32_t c = t < len ? idx[off[q0 + i] + t] : 0;
+          if (t == 0) fresh = 0;
+          __syncthreads();
+          const bool check = distinct + len > wcap;
+          if (check && t < len && !est_contains(tab, mask, c)) atomicAdd(&fresh, 1);
+          __syncthreads();
+          if (t == 0 && check && distinct + fresh > wcap) stop = 1, end_row = (int)(q0 + i);
+          __syncthreads();
+          if (stop) break;
+          if (t < len) {
+            atomicMin(&lo, c), atomicMax(&hi, c);
+            if (est_insert(tab, mask, c)) atomicAdd(&distinct, 1);
+          }
+          if (t == 0) refs += len;
+          __syncthreads();
+        }
+      }
+      __syncthreads();
+      q0 += nr;
+    }
+    __syncthreads();
+    const int64_t end = max((int64_t)end_row, first + 1);  // (a row of <= kLongRow nonzeros always fits an empty set)
+    long long cost = 0;
+    int32_t wbase = 0, wlen = 0, ncols = 0;
+    if (hi >= 0) {
+      if ((long long)hi - lo + 1 <= wcap) {
+        wbase = lo, wlen = hi - lo + 1;
+        cost  = 1 + wlen / 16;
+      } else {
+        int mine = 0;
+        for (int i = t; i < 2 * wcap; i += kJagCutT) {
+          const int32_t c = tab[i];
+          if (c != kEstEmpty && (c == 0 || !est_contains(tab, mask, c - 1))) ++mine;
+        }
+        if (mine) atomicAdd(&runs, mine);
+        __syncthreads();
+        cost  = (long long)runs + distinct / 16;
+        ncols = distinct;
+      }
+    }
+    if (t == 0) meta[c0 + nblocks] = JagBlockMeta{(int32_t)end, wbase, wlen, ncols, refs, cost};
+    ++nblocks;
+    first = end;
+    __syncthreads();
+  }
+  if (t == 0) count[blockIdx.x] = nblocks;
+}
+
+constexpr int kJagSortN = 4096;  // rows of a block (16 waves x 256)
+__device__ __forceinline__ int jag_wave_of_pass(int p, int waves) { return ((p / waves) & 1) ? waves - 1 - (p % waves) : p % waves; }
+
+// the block's short rows as sorted words ((kLongRow - len) << 12 | local row; rows without a place in the passes sort behind them):
+// returns their number
+__device__ __forceinline__ int jag_sort_rows(uint32_t* w, int r0, int nr, const int32_t* __restrict__ off)
+{
+  __shared__ int ns_s;
+  int n2 = 1;
+  while (n2 < nr) n2 <<= 1;
+  if (threadIdx.x == 0) ns_s = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n2; i += kJagCutT) {
+    uint32_t word = 0xFFFFFFFFu;
+    if (i < nr) {
+      const int len = off[r0 + i + 1] - off[r0 + i];
+      if (len >= 1 && len <= kLongRow) word = (uint32_t)(kLongRow - len) << 12 | (uint32_t)i, ++mine;
+    }
+    w[i] = word;
+  }
+  if (mine) atomicAdd(&ns_s, mine);
+  __syncthreads();
+  lds_bitonic_sort<kJagCutT>(w, n2);
+  return ns_s;
+}
+
+// sizes: rows and entries of every (block, wave) share, the block's long rows
+__global__ void __launch_bounds__(kJagCutT)
+k_jag_block_sizes(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, int waves, int32_t* __restrict__ gsr, int32_t* __restrict__ gent,
+                  int32_t* __restrict__ nlong)
+{
+  __shared__ uint32_t w[kJagSortN];
+  __shared__ int sr_s[16], ent_s[16], long_s;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int r0 = row0[b], nr = row0[b + 1] - r0;
+  if (t < 16) sr_s[t] = 0, ent_s[t] = 0;
+  if (t == 0) long_s = 0;
+  __syncthreads();
+  int nl = 0;
+  for (int i = t; i < nr; i += kJagCutT) nl += off[r0 + i + 1] - off[r0 + i] > kLongRow;
+  if (nl) atomicAdd(&long_s, nl);
+  const int ns = jag_sort_rows(w, r0, nr, off);
+  for (int base = 0; base < ns; base += kJagCutT) {
+    const int i = base + t;
+    const int len = i < ns ? kLongRow - (int)(w[i] >> 12) : 0;
+    int cnt = i < ns ? 1 : 0, ent = len;
+    for (int d = 1; d < 64; d <<= 1) cnt += __shfl_xor(cnt, d, 64), ent += __shfl_xor(ent, d, 64);
+    if ((t & 63) == 0 && cnt) {
+      const int wv = jag_wave_of_pass(i >> 6, waves);
+      atomicAdd(&sr_s[wv], cnt), atomicAdd(&ent_s[wv], ent);
+    }
+  }
+  __syncthreads();
+  if (t < waves) gsr[(size_t)b * waves + t] = sr_s[t], gent[(size_t)b * waves + t] = ent_s[t];
+  if (t == 0) nlong[b] = long_s;
+}
+
+// fill: row descriptors, LDS slots and permutation along the jagged diagonals; a list-mode block's column list; the long rows
+__global__ void __launch_bounds__(kJagCutT)
+k_jag_block_fill(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int waves, int32_t wcap,
+                 const int32_t* __restrict__ win, const int32_t* __restrict__ set_ptr, const int32_t* __restrict__ tile_sr, const int32_t* __restrict__ tile_e,
+                 const int32_t* __restrict__ lr_ptr, uint32_t* __restrict__ sr, uint16_t* __restrict__ slot, int32_t* __restrict__ perm,
+                 int32_t* __restrict__ set_col, int32_t* __restrict__ lr_row)
+{
+  extern __shared__ int32_t lds[];  // list mode: 2 * wcap table slots, then wcap sorted columns
+  __shared__ uint32_t w[kJagSortN];
+  __shared__ int sr_base[64], e_base[64], pass_cnt[64], pass_ent[64], ncols_s, scratch[17];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int r0 = row0[b], nr = row0[b + 1] - r0;
+  const int32_t wbase = win[2 * b], wlen = win[2 * b + 1];
+  int32_t* tab  = lds;
+  int32_t* cols = lds + 2 * wcap;
+  const uint32_t mask = (uint32_t)(2 * wcap - 1);
+  int ncols = 0;
+  if (!wlen) {
+    // the distinct columns of the block's short rows, sorted
+    for (int i = t; i < 2 * wcap; i += kJagCutT) tab[i] = kEstEmpty;
+    if (t == 0) ncols_s = 0;
+    __syncthreads();
+    for (int i = 0; i < nr; ++i) {  // (a row per trip: rows are short, the lanes take its entries)
+      const int k0 = off[r0 + i], len = off[r0 + i + 1] - k0;
+      if (len > kLongRow) continue;
+      if (t < len) (void)est_insert(tab, mask, idx[k0 + t]);
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * wcap; i += kJagCutT)
+      if (tab[i] != kEstEmpty) cols[atomicAdd(&ncols_s, 1)] = tab[i];
+    __syncthreads();
+    ncols = ncols_s;
+    int n2 = 1;
+    while (n2 < ncols) n2 <<= 1;
+    for (int i = ncols + t; i < n2; i += kJagCutT) cols[i] = 0x7fffffff;
+    __syncthreads();
+    lds_bitonic_sort<kJagCutT>((uint32_t*)cols, n2);  // (columns are non-negative: the unsigned order is theirs)
+    for (int i = t; i < ncols; i += kJagCutT) set_col[set_ptr[b] + i] = cols[i];
+  }
+  // long rows, in row order
+  {
+    int carry = 0;
+    for (int base = 0; base < nr; base += kJagCutT) {
+      const int i = base + t;
+      const int is_long = i < nr && off[r0 + i + 1] - off[r0 + i] > kLongRow;
+      int total = 0;
+      const int pre = block_exclusive_scan<kJagCutT>(is_long, scratch, &total);
+      if (is_long) lr_row[lr_ptr[b] + carry + pre] = r0 + i;
+      carry += total;
+    }
+  }
+  const int ns = jag_sort_rows(w, r0, nr, off);
+  const int npass = (ns + 63) >> 6;
+  if (t < 64) pass_cnt[t] = 0, pass_ent[t] = 0;
+  __syncthreads();
+  for (int base = 0; base < ns; base += kJagCutT) {
+    const int i = base + t;
+    int cnt = i < ns ? 1 : 0, ent = i < ns ? kLongRow - (int)(w[i] >> 12) : 0;
+    for (int d = 1; d < 64; d <<= 1) cnt += __shfl_xor(cnt, d, 64), ent += __shfl_xor(ent, d, 64);
+    if ((t & 63) == 0 && cnt) pass_cnt[i >> 6] = cnt, pass_ent[i >> 6] = ent;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int srpos[16], epos[16];
+    for (int wv = 0; wv < waves; ++wv) srpos[wv] = tile_sr[(size_t)b * waves + wv], epos[wv] = tile_e[(size_t)b * waves + wv];
+    for (int p = 0; p < npass; ++p) {
+      const int wv = jag_wave_of_pass(p, waves);
+      sr_base[p] = srpos[wv], e_base[p] = epos[wv];
+      srpos[wv] += pass_cnt[p], epos[wv] += pass_ent[p];
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63;
+  for (int p = t >> 6; p < npass; p += kJagCutT / 64) {
+    const int i    = p * 64 + lane;
+    const bool live = i < ns;
+    const int row  = live ? (int)(w[i] & 4095) : 0;
+    const int len  = live ? kLongRow - (int)(w[i] >> 12) : 0;
+    if (live) sr[sr_base[p] + lane] = (uint32_t)(len - 1) << 16 | (uint32_t)row;
+    const int k_row = off[r0 + row];
+    const int kmax  = __shfl(len, 0, 64);
+    int e = e_base[p];
+    for (int k = 0; k < kmax; ++k) {
+      const unsigned long long m_ = __ballot(len > k);
+      if (len > k) {
+        const int32_t c = idx[k_row + k];
+        int s_;
+        if (wlen) {
+          s_ = c - wbase;
+        } else {
+          int a = 0, z = ncols;  // the slot of c in the sorted list
+          while (z - a > 1) {
+            const int mid = (a + z) >> 1;
+            if (cols[mid] <= c) a = mid; else z = mid;
+          }
+          s_ = a;
+        }
+        slot[e + lane] = (uint16_t)s_;
+        perm[e + lane] = k_row + k;
+      }
+      e += __popcll(m_);
+    }
+  }
+}
+}  // namespace
+
+int build_jag_device(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
+                     const double* d_val, int mode, int cus)
+{
+  const int64_t nnz = rows > 0 ? h_off[rows] : 0;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) return 0;
+  int G = 0, waves = 8, wcap = 0, brows = 0;
+  if (!jag_geometry(rows, mode, &G, &waves, &wcap, &brows)) return 0;
+  if (waves != 8) return 1;  // (the 16-wave geometry's table + list do not fit one workgroup's LDS: CUOPT_AMD_TUNE=jag_waves=16 builds on the host)
+  hipStream_t s = c->stream;
+  const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto plap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cuopt_amd setup]     jagged: %-18s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  std::vector<void*> tmp;
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() { for (void* p : v) (void)hipFree(p); }
+  } free_tmp{tmp};
+  auto talloc = [&](void** p, size_t bytes) -> int {
+    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  {
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(done.begin(), done.end(), c->device) == done.end()) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_jag_cut_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 4));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_jag_block_fill, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8192 * 4));
+      done.push_back(c->device);
+    }
+  }
+  const int slots = cus * 2;  // workgroups resident at once: 80 KiB of LDS each
+  const int32_t chunk_rows = 8 * brows;
+  const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
+  JagBlockMeta* d_meta = nullptr;
+  int32_t* d_count     = nullptr;
+  TRY(talloc((void**)&d_meta, ((size_t)rows + 1) * sizeof(JagBlockMeta)));
+  TRY(talloc((void**)&d_count, (size_t)nchunks * sizeof(int32_t)));
+  std::vector<JagBlockMeta> blocks;
+  auto partition = [&](int32_t row_cap, std::vector<JagBlockMeta>* out) -> int {
+    k_jag_cut_chunk<<<nchunks, kJagCutT, (size_t)2 * wcap * sizeof(int32_t), s>>>(chunk_rows, row_cap, wcap, rows, d_off, d_idx, d_meta, d_count);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> count(nchunks);
+    HIP_TRY(hipMemcpyAsync(count.data(), d_count, (size_t)nchunks * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    out->clear();
+    for (int t = 0; t < nchunks; ++t) {
+      const size_t at = out->size();
+      out->resize(at + count[t]);
+      HIP_TRY(hipMemcpyAsync(out->data() + at, d_meta + (size_t)t * chunk_rows, (size_t)count[t] * sizeof(JagBlockMeta), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+  };
+  TRY(partition(brows, &blocks));
+  // (as build_jag: when the column sets cut the blocks short of a whole round of resident workgroups, smaller blocks that fill the same
+  // number of rounds are strictly better)
+  if (slots > 0 && (int)blocks.size() > slots) {
+    const int nb = (int)blocks.size(), rounds = (nb + slots - 1) / slots;
+    if ((double)nb < 0.9 * (double)rounds * (double)slots) {
+      int32_t cap = (int32_t)std::ceil((double)rows / (0.97 * (double)rounds * (double)slots));
+      cap         = std::max<int32_t>(64, (cap + 63) & ~63);
+      if (cap < brows) {
+        std::vector<JagBlockMeta> alt;
+        TRY(partition(cap, &alt));
+        if (((int)alt.size() + slots - 1) / slots <= rounds) blocks.swap(alt);
+      }
+    }
+  }
+  plap("partition");
+  const int nblk = (int)blocks.size(), ngroups = nblk * waves;
+  std::vector<int32_t> row0((size_t)nblk + 1, 0), win((size_t)2 * nblk, 0), set_ptr((size_t)nblk + 1, 0);
+  long long refs = 0, cost = 0;
+  for (int b = 0; b < nblk; ++b) {
+    row0[b + 1] = blocks[b].end;
+    refs += blocks[b].refs, cost += blocks[b].cost;
+    win[2 * b] = blocks[b].wbase, win[2 * b + 1] = blocks[b].wlen;
+    set_ptr[b + 1] = set_ptr[b] + blocks[b].ncols;
+  }
+  dst->saving = refs ? 1.0 - (double)cost / (double)refs : 0.0;
+  if (mode == 0 && dst->saving < 0.5) return 0;
+  int32_t *d_row0 = nullptr, *d_gsr = nullptr, *d_gent = nullptr, *d_nlong = nullptr;
+  TRY(upload_i32(c, &d_row0, row0.data(), row0.size()));
+  TRY(talloc((void**)&d_gsr, (size_t)ngroups * sizeof(int32_t)));
+  TRY(talloc((void**)&d_gent, (size_t)ngroups * sizeof(int32_t)));
+  TRY(talloc((void**)&d_nlong, (size_t)nblk * sizeof(int32_t)));
+  k_jag_block_sizes<<<nblk, kJagCutT, 0, s>>>(d_row0, d_off, waves, d_gsr, d_gent, d_nlong);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> gsr(ngroups), gent(ngroups), nlong(nblk);
+  HIP_TRY(hipMemcpyAsync(gsr.data(), d_gsr, (size_t)ngroups * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(gent.data(), d_gent, (size_t)ngroups * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(nlong.data(), d_nlong, (size_t)nblk * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> tile_e((size_t)ngroups + 1, 0), tile_sr((size_t)ngroups + 1, 0), lr_ptr((size_t)nblk + 1, 0);
+  for (int g = 0; g < ngroups; ++g) {
+    tile_sr[g + 1] = tile_sr[g] + gsr[g];
+    tile_e[g + 1]  = (int32_t)((int64_t)tile_e[g] + gent[g]);
+  }
+  for (int b = 0; b < nblk; ++b) lr_ptr[b + 1] = lr_ptr[b] + nlong[b];
+  const size_t nsr = (size_t)tile_sr[ngroups], nent = (size_t)tile_e[ngroups];
+  plap("sizes");
+  int32_t *tile_e_d = nullptr, *tile_sr_d = nullptr, *win_d = nullptr, *set_ptr_d = nullptr, *set_col_d = nullptr, *lr_ptr_d = nullptr, *lr_row_d = nullptr;
+  uint32_t* sr_d    = nullptr;
+  uint16_t* slot_d  = nullptr;
+  TRY(upload_i32(c, &tile_e_d, tile_e.data(), tile_e.size()));
+  TRY(upload_i32(c, &tile_sr_d, tile_sr.data(), tile_sr.size()));
+  TRY(upload_i32(c, &win_d, win.data(), win.size()));
+  TRY(upload_i32(c, &set_ptr_d, set_ptr.data(), set_ptr.size()));
+  TRY(upload_i32(c, &lr_ptr_d, lr_ptr.data(), lr_ptr.size()));
+  TRY(dev_alloc(c, &set_col_d, (size_t)set_ptr[nblk] + 8));
+  TRY(dev_alloc(c, &lr_row_d, (size_t)lr_ptr[nblk] + 1));
+  TRY(dev_alloc(c, &dst->perm, nent + 8));
+  TRY(dev_alloc(c, &sr_d, nsr + 8));
+  TRY(dev_alloc(c, &slot_d, nent + 64));
+  TRY(dev_alloc(c, &dst->val, nent + 8));
+  k_jag_block_fill<<<nblk, kJagCutT, (size_t)3 * wcap * sizeof(int32_t), s>>>(d_row0, d_off, d_idx, waves, wcap, win_d, set_ptr_d, tile_sr_d, tile_e_d, lr_ptr_d, sr_d,
+                                                                               slot_d, dst->perm, set_col_d, lr_row_d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));  // (the host vectors die here)
+  plap("fill");
+  dst->v    = JagView{rows, waves, ngroups, nblk, lr_ptr[nblk], d_row0, tile_e_d, tile_sr_d, sr_d, slot_d, dst->val,
+                      win_d, set_ptr_d, set_col_d, lr_ptr_d, lr_row_d, d_off, d_idx, d_val};
+  dst->nent = (int64_t)nent;
+  dst->on   = true;
+  return 0;
+}
+
+// ================================================================================================
 // synthetic LP generated ON THE DEVICE (scale checks near the reference's stated capacity, docs/cuopt/source/faq.rst:368-370: the
 // host generator of cuopt_amd/synthetic.py needs minutes and tens of GB at 1e9 nonzeros).  Same recipe -- a known primal-dual optimal
 // pair by construction, equalities on the first half of the rows, '>=' rows with slack on the second -- with the columns of a row

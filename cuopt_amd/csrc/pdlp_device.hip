@@ -1317,7 +1317,9 @@ int pdlpdev_create_from_analysis(pdlpdev_ctx** out, pdlpdev_analysis* an, const 
 {
   if (!an || an->adopted) return fail(-1, "pdlpdev_create_from_analysis: no (or an already consumed) analysis");
   const int32_t* a_off = analysis_host_off(an);
-  const int32_t* a_idx = analysis_host_idx(an);
+  // (a permuted matrix's indices live on the device: they come to the host only if a host construction asks for them -- 88 MB at 1e7
+  // nonzeros; the caller's own array otherwise)
+  const int32_t* a_idx = an->permuted ? nullptr : analysis_host_idx(an);
   const int32_t* t_off = analysis_host_t_off(an);
   return create_impl(out, an->device, an->m, an->n, a_off, a_idx, nullptr, t_off, nullptr, nullptr, nullptr, nullptr, c, lo, hi, lb, ub, an);
 }
@@ -1408,12 +1410,19 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   DenseHost DH;
   std::vector<int32_t> hA_off, hA_idx, hA_perm, hT_off, hT_idx, hT_perm;  // the hot CSRs where they differ from the full ones
   lap("long rows A");
-  if (one_gpu) find_dense_segments(m, n, a_offsets, a_indices, &DH);
+  auto a_idx_host = [&]() -> const int32_t* { return a_indices ? a_indices : (an ? analysis_host_idx(an) : nullptr); };
+  if (one_gpu) {
+    // (the scan reads the indices of rows with at least kDenseMin entries only: none of them, no indices needed)
+    bool any_candidate = false;
+    for (int32_t r : la) any_candidate = any_candidate || a_offsets[r + 1] - a_offsets[r] >= kDenseMin;
+    find_dense_segments(m, n, a_offsets, any_candidate ? a_idx_host() : a_indices, &DH);
+  }
   lap("dense scan");
   if (DH.on) hA_off.swap(DH.s_off), hA_idx.swap(DH.s_idx), hA_perm.swap(DH.s_perm);
   const bool hot_a     = !hA_off.empty();
   const int32_t* A_off = hot_a ? hA_off.data() : a_offsets;
-  const int32_t* A_idx = hot_a ? hA_idx.data() : a_indices;
+  const int32_t* A_idx = hot_a ? hA_idx.data() : a_indices;  // (null: an analysed, permuted matrix whose indices stayed on the device)
+  auto A_idx_host = [&]() -> const int32_t* { return A_idx ? A_idx : a_idx_host(); };
   ctx->ha_off = ctx->a_off, ctx->ha_idx = ctx->a_idx, ctx->ha_val = ctx->a_val;
   ctx->dense.hot_nnz = (int64_t)A_off[m];
   if (hot_a) {
@@ -1538,8 +1547,11 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       if (!timed && (mode != "auto" || (int64_t)cols * 8 <= ws_limit)) return false;
       if (timed && !getenv("CUOPT_AMD_TIMING")) return true;
       int64_t ws = 0;
-      if (idx == A_idx && ws_a_device >= 0) {
+      const bool a_side = name[1] == '\0';
+      if (a_side && ws_a_device >= 0) {
         ws = ws_a_device;  // (same windows, counted on the device)
+      } else if (a_side && !idx) {
+        ws = gather_working_set(rows, cols, off, A_idx_host());
       } else if (idx) {
         ws = gather_working_set(rows, cols, off, idx);
       } else if (!ws_at_on_host) {  // (A^T of an analysed matrix: its indices live on the device; the same four windows were counted there)
@@ -1564,7 +1576,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       JagHost jat;
       PbHost hbt;
       PanelHost hat;
-      bool want_pb_layout = false, want_dev_panels = false, want_dev_pb = false, panels_pending = false;
+      bool want_pb_layout = false, want_dev_panels = false, want_dev_pb = false, panels_pending = false, want_dev_jag = false;
       ~TSide() { if (worker.joinable()) worker.join(); }
     } ts;
     const int32_t* T_off = at_offsets;
@@ -1577,11 +1589,33 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     // the gather-free layout is built on the device when the matrices are there (CUOPT_AMD_TUNE=pb_device=0: the host construction,
     // the tests' reference)
     const bool pb_on_device = an && !DH.on && cuopt_amd::tune_int("pb_device", 1) != 0;
+    // ... and so is the jagged layout (CUOPT_AMD_TUNE=jag_device=0: on the host)
+    const bool jag_on_device = an && !DH.on && cuopt_amd::tune_int("jag_device", 1) != 0;
+    const auto w0 = std::chrono::steady_clock::now();
+    auto wlap = [&](const char* what) {
+      if (timing) fprintf(stderr, "[cuopt_amd setup]   A^T thread: %-22s at %6.2f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
+    };
+    // stage 2 of the A^T side: which layout when it is not the jagged one (the gather-free layout / the panels, built below)
+    auto at_side_rest = [&] {
+      const bool jat_ok = ts.jat.ok || ctx->jat.on;
+      if (!jat_ok && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
+        ts.want_pb_layout = true;
+        if (pb_on_device) {
+          ts.want_dev_pb = true;  // (built on the device by the main thread, below; whether panels are wanted instead is known after that)
+          ts.panels_pending = mode != "stream" && mode != "jag" && mode != "pb";
+          wlap("layouts");
+          return;
+        }
+        if (!T_idx) T_idx = t_idx_host();
+        ts.hbt            = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
+      }
+      if (mode != "stream" && mode != "jag" && mode != "pb" && !jat_ok && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T")) {
+        if (an && !DH.on) ts.want_dev_panels = true;  // (built on the device by the main thread, below)
+        else ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
+      }
+      wlap("layouts");
+    };
     auto at_side = [&] {
-      const auto w0 = std::chrono::steady_clock::now();
-      auto wlap = [&](const char* what) {
-        if (timing) fprintf(stderr, "[cuopt_amd setup]   A^T thread: %-22s at %6.2f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
-      };
       if (transpose_ready) transpose_ready(user);
       if ((int64_t)at_offsets[n] != ctx->nnz) return;  // (reported below)
       lat = long_rows(n, at_offsets);
@@ -1594,39 +1628,37 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       ts.rbt = build_row_blocks(n, T_off);
       wlap("row blocks");
       if (try_jag && !skip_jag_at) {
+        if (jag_on_device) {
+          ts.want_dev_jag = true;  // (built on the device by the main thread, below; the rest of this side's decisions follow it)
+          return;
+        }
         if (!T_idx) T_idx = t_idx_host();
         ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
       } else if (an) {
         ts.jat.saving = an->saving_natural[1];
       }
-      if (!ts.jat.ok && want_pb(m) && (mode == "pb" || want_panels(n, m, T_off, T_idx, "A^T"))) {
-        ts.want_pb_layout = true;
-        if (pb_on_device) {
-          ts.want_dev_pb = true;  // (built on the device by the main thread, below; whether panels are wanted instead is known after that)
-          ts.panels_pending = mode != "stream" && mode != "jag" && mode != "pb";
-          wlap("layouts");
-          return;
-        }
-        if (!T_idx) T_idx = t_idx_host();
-        ts.hbt            = build_pb(n, m, T_off, T_idx, ctx->cus, mode == "pb");
-      }
-      if (mode != "stream" && mode != "jag" && mode != "pb" && !ts.jat.ok && !ts.hbt.ok && want_panels(n, m, T_off, T_idx, "A^T")) {
-        if (an && !DH.on) ts.want_dev_panels = true;  // (built on the device by the main thread, below)
-        else ts.hat = build_panels(n, m, T_off, T_idx, slab_bytes, force || !timed);
-      }
-      wlap("layouts");
+      at_side_rest();
     };
     // (an analysed matrix: nothing to wait for and little left to do on the host -- the A^T side runs inline, behind the A side;
     // a thread of its own took 3 ms to do 0.5 ms of work next to the main thread's HIP calls)
-    const bool at_thread = !an || (try_jag && !skip_jag_at) || DH.on || (want_pb(m) && !pb_on_device);  // (host constructions worth a thread)
+    const bool at_thread = !an || (try_jag && !skip_jag_at && !jag_on_device) || DH.on || (want_pb(m) && !pb_on_device);  // (host constructions worth a thread)
     if (at_thread) ts.worker = std::thread(at_side);
     if (try_jag) {
       JagHost ja;
-      if (skip_jag_a) ja.saving = an->saving_natural[0];
-      else ja = build_jag(m, n, A_off, A_idx, mode == "jag" ? 1 : 0, ctx->cus);
-      lap("build_jag A");
-      TRY(upload_jag(ctx, &ctx->ja, ja, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
-      lap("upload jag A");
+      int on_device = 1;
+      if (skip_jag_a) {
+        ja.saving = an->saving_natural[0];
+      } else if (jag_on_device) {
+        on_device = build_jag_device(ctx, &ctx->ja, m, n, A_off, ctx->ha_off, ctx->ha_idx, ctx->ha_val, mode == "jag" ? 1 : 0, ctx->cus);
+        if (on_device < 0) return on_device;
+        lap("jag A on the device");
+      }
+      if (on_device == 1) {
+        if (!skip_jag_a) ja = build_jag(m, n, A_off, A_idx_host(), mode == "jag" ? 1 : 0, ctx->cus);
+        lap("build_jag A");
+        TRY(upload_jag(ctx, &ctx->ja, ja, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
+        lap("upload jag A");
+      }
     }
     if (!ctx->ja.on && want_pb(n) && (mode == "pb" || want_panels(m, n, A_off, A_idx, "A"))) {
       int on_device = 1;
@@ -1638,7 +1670,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
         if (on_device == 0 && !ctx->pba.on && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", why.c_str());
       }
       if (on_device == 1) {
-        PbHost hb = build_pb(m, n, A_off, A_idx, ctx->cus, mode == "pb");
+        PbHost hb = build_pb(m, n, A_off, A_idx_host(), ctx->cus, mode == "pb");
         lap("build_pb A");
         if (!hb.ok && mode == "pb") return fail(-1, "CUOPT_AMD_SPMV_LAYOUT=pb: A does not fit the gather-free layout (%s)", hb.why.c_str());
         TRY(upload_pb(ctx, &ctx->pba, hb));
@@ -1650,7 +1682,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       int on_device = an && !DH.on ? build_panels_device(ctx, &ctx->pa, m, n, A_off, ctx->ha_off, ctx->ha_idx, ctx->ha_val, slab_bytes, force || !timed) : 1;
       if (on_device < 0) return on_device;
       if (on_device == 1) {
-        ha = build_panels(m, n, A_off, A_idx, slab_bytes, force || !timed, DH.on ? &DH.first_seg : nullptr);
+        ha = build_panels(m, n, A_off, A_idx_host(), slab_bytes, force || !timed, DH.on ? &DH.first_seg : nullptr);
         lap("build_panels A");
         TRY(upload_panels(ctx, &ctx->pa, ha, ctx->ha_off, ctx->ha_idx, ctx->ha_val));
       }
@@ -1697,10 +1729,23 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     ctx->at_nb = (int)ts.rbt.size() / 2 - 1;
     TRY(upload_i32(ctx, &ctx->at_rb, ts.rbt.data(), ts.rbt.size()));
     lap("upload A^T");
-    if (try_jag) {
+    bool jat_on_device = false;
+    if (ts.want_dev_jag) {
+      int on_device = build_jag_device(ctx, &ctx->jat, n, m, T_off, ctx->hat_off, ctx->hat_idx, ctx->hat_val, mode == "jag" ? 1 : 0, ctx->cus);
+      if (on_device < 0) return on_device;
+      if (on_device == 1) {
+        if (!T_idx) T_idx = t_idx_host();
+        ts.jat = build_jag(n, m, T_off, T_idx, mode == "jag" ? 1 : 0, ctx->cus);
+      } else {
+        jat_on_device = true;
+      }
+      lap("jag At on the device");
+    }
+    if (try_jag && !jat_on_device) {
       TRY(upload_jag(ctx, &ctx->jat, ts.jat, ctx->hat_off, ctx->hat_idx, ctx->hat_val));
       lap("upload jag At");
     }
+    if (ts.want_dev_jag) at_side_rest();  // (the decisions that waited for the jagged layout's verdict)
     if (ts.want_dev_pb) {
       std::string why;
       int on_device = build_pb_device(ctx, &ctx->pbat, n, m, T_off, ctx->hat_off, ctx->hat_idx, ctx->cus, mode == "pb", &why);
@@ -3326,8 +3371,15 @@ int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16])
   gather_free(ctx->pbat, ctx->dense.on ? ctx->hot_nnz_at : ctx->nnz, out + 8);
   auto jag = [&](const pdlpdev_ctx::Jag& J) -> uint64_t {
     if (!J.on) return 0;
+    int32_t nsr = 0, nset = 0;
+    (void)hipMemcpy(&nsr, J.v.tile_sr + J.v.ngroups, sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&nset, J.v.set_ptr + J.v.nblk, sizeof(int32_t), hipMemcpyDeviceToHost);
     return checksum_device(ctx, J.v.slot, (size_t)J.nent * 2) ^ (checksum_device(ctx, J.perm, (size_t)J.nent * 4) * 3) ^
-           (checksum_device(ctx, J.v.row0, ((size_t)J.v.nblk + 1) * 4) * 5);
+           (checksum_device(ctx, J.v.row0, ((size_t)J.v.nblk + 1) * 4) * 5) ^ (checksum_device(ctx, J.v.sr, (size_t)nsr * 4) * 7) ^
+           (checksum_device(ctx, J.v.tile_e, ((size_t)J.v.ngroups + 1) * 4) * 11) ^ (checksum_device(ctx, J.v.tile_sr, ((size_t)J.v.ngroups + 1) * 4) * 13) ^
+           (checksum_device(ctx, J.v.win, (size_t)J.v.nblk * 8) * 17) ^ (checksum_device(ctx, J.v.set_ptr, ((size_t)J.v.nblk + 1) * 4) * 19) ^
+           (checksum_device(ctx, J.v.set_col, (size_t)nset * 4) * 23) ^ (checksum_device(ctx, J.v.lr_ptr, ((size_t)J.v.nblk + 1) * 4) * 29) ^
+           (checksum_device(ctx, J.v.lr_row, (size_t)J.v.nlong * 4) * 31) ^ (uint64_t)J.v.waves * 37;
   };
   out[13] = jag(ctx->ja), out[14] = jag(ctx->jat);
   out[15] = (uint64_t)ctx->pa.on | (uint64_t)ctx->pat.on << 1 | (uint64_t)ctx->ja.on << 2 | (uint64_t)ctx->jat.on << 3 |

@@ -76,6 +76,10 @@ int analysis_fetch_idx_windows(pdlpdev_analysis* an, int transposed, int64_t nnz
 // gather_working_set on a device-resident index array (same windows, same count)
 int gather_working_set_device(pdlpdev_ctx* c, const int32_t* d_idx, int64_t nnz, int32_t cols, int64_t* bytes);
 // slab-major panels built on the device from a resident CSR; same arrays, bit for bit, as build_panels + upload_panels
+// jagged rows + LDS column sets from the device-resident CSR (kernels_setup.hip): 0 built / not worth it (dst->on says which, dst->saving
+// the layout's estimate), 1 not handled here (the host construction takes over), < 0 error
+int build_jag_device(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
+                     const double* d_val, int mode, int cus);
 // gather-free layout from the device-resident CSR (kernels_setup.hip): 0 built or does not fit (dst->on says which, *why the reason),
 // 1 not handled here (nothing allocated: the host construction takes over), < 0 error
 int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,

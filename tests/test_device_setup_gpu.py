@@ -130,6 +130,33 @@ def test_gather_free_layout_built_on_the_device_is_the_host_construction(shape, 
     r.close()
 
 
+@pytest.mark.parametrize("kind", ["banded", "staircase", "block_angular", "multiband", "random_forced", "powerlaw_forced"])
+def test_jagged_layout_built_on_the_device_is_the_host_construction(kind, monkeypatch):
+    """every array of the jagged layout (block boundaries, the column sets -- contiguous windows and sorted lists --, row descriptors,
+    16-bit LDS slots and the permutation along the jagged diagonals, the long-row lists): FNV-1a checksums of the host construction
+    (build_jag, CUOPT_AMD_TUNE=jag_device=0) against the device construction, on both matrices; then the products"""
+    if kind.endswith("_forced"):
+        monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "jag")
+        p = synthetic.generate(150000, 140000, 9, seed=4) if kind == "random_forced" else synthetic.generate_structured("powerlaw", m=140000, n=140000, k=8, seed=5)
+    elif kind == "banded":
+        p = synthetic.generate(262144, 262144, 10, seed=2, band=2000)
+    else:
+        p = synthetic.generate_structured(kind, m=262144, n=262144, k=10, seed=7)
+    set_tune(monkeypatch, jag_device=0)
+    host = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+    set_tune(monkeypatch, jag_device=None)
+    dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+    a, b = host.layout_checksums(), dev.layout_checksums()
+    assert (int(a[15]) >> 2) & 3 == 3, ("both sides jagged", host.layout())
+    np.testing.assert_array_equal(a, b)
+    assert host.layout() == dev.layout()
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    np.testing.assert_array_equal(host.spmv(x, False, p["m"]), dev.spmv(x, False, p["m"]))
+    np.testing.assert_array_equal(host.spmv(y, True, p["n"]), dev.spmv(y, True, p["n"]))
+    host.close(), dev.close()
+
+
 def _family(kind, m):
     if kind == "banded":
         return synthetic.generate(m, m, 10, seed=2, band=2000)
