@@ -27,7 +27,7 @@ for step in "$@"; do
          python scripts/pmc_summary.py "$OUT/r05_pmc_$arg.json" "$OUT/${arg}_pmc_1" "$OUT/${arg}_pmc_2" "$OUT/${arg}_pmc_3" "$OUT/${arg}_pmc_4" > "$OUT/r05_pmc_${arg}_summary.txt"
          grep -E "traffic MB|FETCH_SIZE|WRITE_SIZE" "$OUT/r05_pmc_${arg}_summary.txt" | head -12 | cut -c1-120
          rm -rf "$OUT/${arg}"_pmc_? ;;
-    profsetup) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/profsetup_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/profsetup_$arg.log" 2>&1); find "$OUT/profsetup_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 45 | cut -c1-200 ;;
+    profsetup) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/profsetup_$arg" -- env PROBE_NO_RATE=1 python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/profsetup_$arg.log" 2>&1); find "$OUT/profsetup_$arg" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 45 | cut -c1-200 ;;
     apitrace) (cd /tmp && timeout 900 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace -d "$OLDPWD/$OUT/apitrace_$arg" -- python "$OLDPWD/scripts/r05_setup_probe.py" "$arg" > "$OLDPWD/$OUT/apitrace_$arg.log" 2>&1); ls -la "$OUT/apitrace_$arg"/* | head ;;
     yardstick) python scripts/r05_dump_csr.py "$arg" /tmp/csr_$arg > "$OUT/yardstick_$arg.log" 2>&1
                /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-deprecated-declarations tools/rocsparse_yardstick.cpp -lrocsparse -o /tmp/rocsparse_yardstick >> "$OUT/yardstick_$arg.log" 2>&1

@@ -32,6 +32,8 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
             name, r["status_name"], r["steps_taken"], wall, r["setup_seconds"], r["loop_seconds"], r["primal_objective"], p["objective_star"],
             s.device.layout(), s.reorder_info()), flush=True)
         s.close()
+    if os.environ.get("PROBE_NO_RATE"):  # (profsetup: rocprofv3 7.2 falls over the 256-node replay graphs of a fixed-budget run)
+        continue
     s = capi.Solver(p, mode=1, tol=0.0)
     s.advance(400)
     s.device.call("synchronize")
