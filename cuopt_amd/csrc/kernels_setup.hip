@@ -851,19 +851,35 @@ struct Lap {
 const int32_t* analysis_host_off(pdlpdev_analysis* an)
 {
   if (!an->permuted) return an->h_off;
-  if (!an->have_hp) (void)analysis_host_idx(an);
+  if (!an->have_hp_off) {  // (the offsets alone: 4 MB at 1e6 rows; the indices -- 40 MB -- only when a host construction asks for them)
+    an->hp_off.reset((size_t)an->m + 1);
+    (void)hipMemcpyAsync(an->hp_off.get(), an->A.off, ((size_t)an->m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    (void)hipStreamSynchronize(an->stream);
+    an->have_hp_off = true;
+  }
   return an->hp_off.get();
 }
 const int32_t* analysis_host_idx(pdlpdev_analysis* an)
 {
   if (!an->permuted) return an->h_idx;
   if (!an->have_hp) {
-    an->hp_off.reset((size_t)an->m + 1), an->hp_idx.reset((size_t)std::max<int64_t>(an->nnz, 1));
-    (void)hipMemcpyAsync(an->hp_off.get(), an->A.off, ((size_t)an->m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+    an->hp_idx.reset((size_t)std::max<int64_t>(an->nnz, 1));
     (void)hipMemcpyAsync(an->hp_idx.get(), an->A.idx, (size_t)an->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
     (void)hipStreamSynchronize(an->stream);
     an->have_hp = true;
   }
+  return an->hp_idx.get();
+}
+// the indices of a few rows only (the dense-segment scan looks at rows of 256+ entries): the other entries of the returned array are
+// unspecified.  A later analysis_host_idx fetches everything.
+const int32_t* analysis_host_idx_rows(pdlpdev_analysis* an, const int32_t* h_off, const std::vector<int32_t>& rows)
+{
+  if (!an->permuted) return an->h_idx;
+  if (an->have_hp) return an->hp_idx.get();
+  an->hp_idx.reset((size_t)std::max<int64_t>(an->nnz, 1));
+  for (int32_t r : rows)
+    (void)hipMemcpyAsync(an->hp_idx.get() + h_off[r], an->A.idx + h_off[r], (size_t)(h_off[r + 1] - h_off[r]) * sizeof(int32_t), hipMemcpyDeviceToHost, an->stream);
+  (void)hipStreamSynchronize(an->stream);
   return an->hp_idx.get();
 }
 const int32_t* analysis_host_t_off(pdlpdev_analysis* an)
@@ -1263,7 +1279,7 @@ static int build_permuted_pair(pdlpdev_analysis* an, const int32_t* d_row_o2n, c
   }
   an->A = NA, an->At = NT;
   for (void* p : {(void*)NA.off, (void*)NA.idx, (void*)NA.val, (void*)NT.off, (void*)NT.idx, (void*)NT.val}) an->owned.push_back(p);
-  an->have_hp = an->have_hpt_off = an->have_hpt_idx = false;
+  an->have_hp = an->have_hp_off = an->have_hpt_off = an->have_hpt_idx = false;
   ar.release(mark);
   return 0;
 }
@@ -2126,15 +2142,15 @@ k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows,
       const int total = pre[nr];
       if (parallel) {
         int added = 0, mn = 0x7fffffff, mx = -1;
-        for (int e = t; e < total; e += kJagCutT) {
-          int a = 0, b = nr;
-          while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (pre[mid] <= e) a = mid; else b = mid;
+        // two lanes per row (rows are short: no search for an entry's row, a handful of inserts per lane)
+        for (int r = t >> 1; r < nr; r += kJagCutT / 2) {
+          const int len = pre[r + 1] - pre[r];
+          const int k0  = off[q0 + r];
+          for (int k = t & 1; k < len; k += 2) {
+            const int32_t c = idx[k0 + k];
+            mn = c < mn ? c : mn, mx = c > mx ? c : mx;
+            added += est_insert(tab, mask, c);
           }
-          const int32_t c = idx[off[q0 + a] + (e - pre[a])];
-          mn = c < mn ? c : mn, mx = c > mx ? c : mx;
-          added += est_insert(tab, mask, c);
         }
         // (one LDS atomic per wave: every entry hammering the same two words was most of this kernel's time)
         for (int d = 1; d < 64; d <<= 1) {
@@ -2148,24 +2164,38 @@ k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows,
         if (t == 0) refs += total;
         __syncthreads();
       } else {
-        for (int i = 0; i < nr; ++i) {
-          const int len = pre[i + 1] - pre[i];
-          if (len == 0) continue;
-          const int32_t c = t < len ? idx[off[q0 + i] + t] : 0;
-          if (t == 0) fresh = 0;
-          __syncthreads();
-          const bool check = distinct + len > wcap;
-          if (check && t < len && !est_contains(tab, mask, c)) atomicAdd(&fresh, 1);
-          __syncthreads();
-          if (t == 0 && check && distinct + fresh > wcap) stop = 1, end_row = (int)(q0 + i);
-          __syncthreads();
-          if (stop) break;
-          if (t < len) {
-            atomicMin(&lo, c), atomicMax(&hi, c);
-            if (est_insert(tab, mask, c)) atomicAdd(&distinct, 1);
+        // near the limit: row by row, the host's rule (count the new columns before inserting any) -- by ONE wave, without
+        // workgroup barriers (a row has at most kLongRow = 128 entries: two per lane; the table's operations of one wave are ordered)
+        if (t < 64) {
+          int dist = distinct, mn = 0x7fffffff, mx = -1;
+          long long rf = 0;
+          int stopped = 0, stop_at = 0;
+          for (int i = 0; i < nr && !stopped; ++i) {
+            const int len = pre[i + 1] - pre[i];
+            if (len == 0) continue;
+            const int k0 = off[q0 + i];
+            const int32_t c0_ = t < len ? idx[k0 + t] : 0, c1_ = t + 64 < len ? idx[k0 + t + 64] : 0;
+            if (dist + len > wcap) {
+              int fr = (t < len && !est_contains(tab, mask, c0_)) + (t + 64 < len && !est_contains(tab, mask, c1_));
+              for (int d = 1; d < 64; d <<= 1) fr += __shfl_xor(fr, d, 64);
+              if (dist + fr > wcap) {
+                stopped = 1, stop_at = i;
+                break;
+              }
+            }
+            int add = 0;
+            if (t < len) add += est_insert(tab, mask, c0_), mn = min(mn, c0_), mx = max(mx, c0_);
+            if (t + 64 < len) add += est_insert(tab, mask, c1_), mn = min(mn, c1_), mx = max(mx, c1_);
+            for (int d = 1; d < 64; d <<= 1) add += __shfl_xor(add, d, 64);
+            dist += add;
+            rf += len;
           }
-          if (t == 0) refs += len;
-          __syncthreads();
+          for (int d = 1; d < 64; d <<= 1) mn = min(mn, __shfl_xor(mn, d, 64)), mx = max(mx, __shfl_xor(mx, d, 64));
+          if (t == 0) {
+            distinct = dist, refs += rf;
+            if (mx >= 0) lo = min(lo, mn), hi = max(hi, mx);
+            if (stopped) stop = 1, end_row = (int)(q0 + stop_at);
+          }
         }
       }
       __syncthreads();

@@ -1413,9 +1413,20 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   auto a_idx_host = [&]() -> const int32_t* { return a_indices ? a_indices : (an ? analysis_host_idx(an) : nullptr); };
   if (one_gpu) {
     // (the scan reads the indices of rows with at least kDenseMin entries only: none of them, no indices needed)
-    bool any_candidate = false;
-    for (int32_t r : la) any_candidate = any_candidate || a_offsets[r + 1] - a_offsets[r] >= kDenseMin;
-    find_dense_segments(m, n, a_offsets, any_candidate ? a_idx_host() : a_indices, &DH);
+    std::vector<int32_t> candidates;
+    for (int32_t r : la)
+      if (a_offsets[r + 1] - a_offsets[r] >= kDenseMin) candidates.push_back(r);
+    // (no candidate: no segment can exist, and the pass over 1e6 rows was 0.26 ms.  A permuted matrix's indices live on the device:
+    //  a few candidate rows -- the linking rows of a block-angular LP -- come over on their own instead of the whole 40 MB array)
+    if (!candidates.empty()) {
+      const int32_t* scan_idx = a_indices ? a_indices : (an && candidates.size() <= 64 ? analysis_host_idx_rows(an, a_offsets, candidates) : a_idx_host());
+      find_dense_segments(m, n, a_offsets, scan_idx, &DH);
+      if (DH.on && !a_indices) {  // (segments found after all: the host constructions behind them read every row)
+        DenseHost again;
+        find_dense_segments(m, n, a_offsets, a_idx_host(), &again);
+        DH = std::move(again);
+      }
+    }
   }
   lap("dense scan");
   if (DH.on) hA_off.swap(DH.s_off), hA_idx.swap(DH.s_idx), hA_perm.swap(DH.s_perm);

@@ -56,7 +56,7 @@ struct pdlpdev_analysis {
   int64_t bfs_reached = 0;
   // host mirrors of the structure the device holds (lazily downloaded; the unpermuted A is the caller's own arrays)
   cuopt_amd::PoolArray<int32_t> hp_off, hp_idx, hpt_off, hpt_idx;
-  bool have_hp = false, have_hpt_off = false, have_hpt_idx = false;
+  bool have_hp = false, have_hp_off = false, have_hpt_off = false, have_hpt_idx = false;
   // temporaries
   DevArena arena;
   std::vector<void*> owned;  // hipMalloc'ed blocks this object frees (the arena; A / A^T unless adopted)
@@ -68,6 +68,7 @@ struct pdlpdev_analysis {
 // host structure of the (possibly permuted) matrices, downloaded on first use
 const int32_t* analysis_host_off(pdlpdev_analysis* an);   // A: m + 1
 const int32_t* analysis_host_idx(pdlpdev_analysis* an);   // A: nnz
+const int32_t* analysis_host_idx_rows(pdlpdev_analysis* an, const int32_t* h_off, const std::vector<int32_t>& rows);
 const int32_t* analysis_host_t_off(pdlpdev_analysis* an); // A^T: n + 1
 const int32_t* analysis_host_t_idx(pdlpdev_analysis* an); // A^T: nnz
 // up to four windows of the device's index array (gather_working_set of a matrix whose indices live on the device)
