@@ -917,7 +917,7 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   } ag;
   cuoptamd_lp plp = *lp;  // the LP in the order the device works in (the caller's, or P A Q with permuted vectors)
   plp.c           = c.data();
-  std::vector<double> pc, plo, phi, plb, pub;
+  cuopt_amd::PoolArray<double> pc, plo, phi, plb, pub;  // (pooled, not zero-filled: five 8 MB vectors at 1e6 x 1e6 were 5 ms of first touches)
   cuopt_amd::PoolArray<int32_t> poff, pidx;
   cuopt_amd::PoolArray<double> pval;
   int setup_rc = 0;
@@ -932,13 +932,14 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
       if (permuted != 1) {
         s->row_new2old.clear(), s->col_new2old.clear();
       } else {
-        auto gather = [](const std::vector<int32_t>& new2old, const double* src, std::vector<double>& dst) {
-          dst.resize(new2old.size());
+        auto gather = [](const std::vector<int32_t>& new2old, const double* src, cuopt_amd::PoolArray<double>& dst) {
+          dst.reset(new2old.size());
+          double* out = dst.get();
           const size_t count = new2old.size(), chunk = (count + 15) / 16;
           cuopt_amd::parallel_tasks(16, [&](int t) {
-            for (size_t i = (size_t)t * chunk; i < std::min(count, ((size_t)t + 1) * chunk); ++i) dst[i] = src[new2old[i]];
+            for (size_t i = (size_t)t * chunk; i < std::min(count, ((size_t)t + 1) * chunk); ++i) out[i] = src[new2old[i]];
           }, (int64_t)count * 16);
-          return dst.data();
+          return (const double*)out;
         };
         plp.c = gather(s->col_new2old, c.data(), pc), plp.lb = gather(s->col_new2old, lp->lb, plb), plp.ub = gather(s->col_new2old, lp->ub, pub);
         plp.lo = gather(s->row_new2old, lp->lo, plo), plp.hi = gather(s->row_new2old, lp->hi, phi);
