@@ -125,10 +125,14 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
             for j in rng.choice(n, size=n // 10, replace=False):
                 ub[j] = p["x_star"][j] + 0.3 * rng.random()
         return lb, ub
-    parent = capi.Solver(p, mode=1, tol=0.0, device=local_rank)
+    # (BENCH_USE_GRAPH=0: plain launches instead of replay graphs -- rocprofv3 7.2 falls over a process that instantiates a second
+    #  family of graphs after destroying a first; the counter passes of scripts/r05_gpu.sh pmc:c3_batch8 set it)
+    graph = int(os.environ.get("BENCH_USE_GRAPH", "1"))
+    parent = capi.Solver(p, mode=1, tol=0.0, device=local_rank, use_graph=graph)
     setup_s = parent.advance(0)["setup_seconds"]
     dev = parent.device
-    dev.call("prepare_graphs")
+    if graph:
+        dev.call("prepare_graphs")
     period = max(int(parent.hyper.major_iteration), 1)
     pre = ((max(args.warmup, 2 * period, int(parent.hyper.min_iteration_restart) + period) + period - 1) // period) * period
     # the single solve's rate in this very process (the yardstick of the aggregate)
@@ -141,7 +145,7 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
         dev.call("synchronize")
         rates.append(25 * period / (time.perf_counter() - t0))
     single = max(rates[1:])
-    parent.reset(tol=0.0)
+    parent.reset(tol=0.0, use_graph=graph)
     sets = [bounds(l) for l in range(1, K)]
     t0 = time.perf_counter()
     clones = [parent.clone(lb, ub) for lb, ub in sets]

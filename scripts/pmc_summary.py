@@ -15,7 +15,7 @@ def main(out, dirs):
         for f in glob.glob(d + "/*/*_counter_collection.csv"):
             acc = collections.defaultdict(lambda: collections.defaultdict(list))
             for r in csv.DictReader(open(f)):
-                acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))  # templated kernels: "void k_x<8>" -> "k_x"
+                acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))  # templated kernels: "void k_x<8>" -> "k_x"
             for k, cs in acc.items():
                 for c, v in cs.items():
                     table[k][c] = dict(avg=sum(v) / len(v), launches=len(v))

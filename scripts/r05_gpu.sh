@@ -22,7 +22,7 @@ for step in "$@"; do
     pmc) R=$PWD; i=0
          for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS"; do
            i=$((i+1))
-           (cd /tmp && timeout -k 5 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/${arg}_pmc_$i" -- bash -c "cd $R && python bench.py --workload $arg --no-cpu-baseline --no-convergence-run --steps 200 --warmup 40 --min-seconds 0.05" > "$R/$OUT/${arg}_pmc_$i.log" 2>&1)
+           (cd /tmp && timeout -k 5 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/${arg}_pmc_$i" -- bash -c "cd $R && BENCH_USE_GRAPH=${BENCH_USE_GRAPH:-1} python bench.py --workload $arg --no-cpu-baseline --no-convergence-run --steps 200 --warmup 40 --min-seconds 0.05" > "$R/$OUT/${arg}_pmc_$i.log" 2>&1)
          done
          python scripts/pmc_summary.py "$OUT/r05_pmc_$arg.json" "$OUT/${arg}_pmc_1" "$OUT/${arg}_pmc_2" "$OUT/${arg}_pmc_3" "$OUT/${arg}_pmc_4" > "$OUT/r05_pmc_${arg}_summary.txt"
          grep -E "traffic MB|FETCH_SIZE|WRITE_SIZE" "$OUT/r05_pmc_${arg}_summary.txt" | head -12 | cut -c1-120
