@@ -1161,6 +1161,8 @@ void pdlpdev_analysis_destroy(pdlpdev_analysis* an)
   (void)hipSetDevice(an->device);
   if (an->stream) (void)hipStreamSynchronize(an->stream);
   for (void* p : an->owned) (void)hipFree(p);
+  for (double* p : an->pref_dev)
+    if (p) (void)hipFree(p);
   if (an->bundle_owned && an->stream) {
     // the stream goes back to the pool the contexts draw from (an HSA queue costs ~2 ms to create)
     if (!(an->pinned && an->chunk && give_recycled(Recycled{an->device, an->stream, an->pinned, an->chunk}))) {
@@ -1177,6 +1179,16 @@ void pdlpdev_analysis_destroy(pdlpdev_analysis* an)
 // permuted pair).  The host arrays must stay valid until the analysis is consumed (pdlpdev_create_from_analysis) or destroyed.
 int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_off, const int32_t* a_idx,
                     const double* a_val, int flags)
+{
+  return pdlpdev_analyze_with_vectors(out, device, m, n, a_off, a_idx, a_val, flags, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// ... and, when given, sends the problem vectors (c, lb, ub: n; lo, hi: m -- in the caller's order) to the device on a helper thread
+// while the analysis' kernels run; pdlpdev_create_from_analysis picks them up when it is handed the same host pointers and the
+// analysis did not permute the matrix.
+int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_off, const int32_t* a_idx,
+                                 const double* a_val, int flags, const double* c, const double* lo, const double* hi, const double* lb,
+                                 const double* ub)
 {
   roctx::Range range("pdlp: device analysis (upload, transpose, ordering)");
   if (!out || m < 0 || n < 0 || !a_off) return fail(-1, "pdlpdev_analyze: bad argument");
@@ -1237,6 +1249,30 @@ int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, co
     TRY(dmalloc((void**)&an->arena.base, bytes));
   }
   an->ms_upload = lap("upload A");
+  // (PCIe is idle from here on: the vectors cross it now, next to the transposition and the ordering search)
+  struct Prefetch {
+    std::thread worker;
+    ~Prefetch() { if (worker.joinable()) worker.join(); }
+  } prefetch;
+  if (c || lo || hi || lb || ub) {
+    const double* src[5]  = {c, lb, ub, lo, hi};
+    const size_t count[5] = {(size_t)n, (size_t)n, (size_t)n, (size_t)m, (size_t)m};
+    for (int i = 0; i < 5; ++i) an->pref_src[i] = src[i];
+    prefetch.worker = std::thread([an, device, count] {
+      if (hipSetDevice(device) != hipSuccess) return;
+      for (int i = 0; i < 5; ++i) {
+        if (!an->pref_src[i] || count[i] == 0) continue;
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, count[i] * sizeof(double)) != hipSuccess) continue;
+        if (hipMemcpy(d, an->pref_src[i], count[i] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+          (void)hipFree(d);
+          continue;
+        }
+        an->pref_dev[i] = d;  // (read after the join below)
+      }
+      (void)hipGetLastError();
+    });
+  }
   TRY(dev_transpose(s, an->arena, m, n, nnz, an->A, an->At));
   an->ms_transpose = lap("transpose");
   if ((flags & 1) && nnz > 0) {
@@ -1265,6 +1301,7 @@ int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, co
     an->arena.release(mark);
   }
   HIP_TRY(hipStreamSynchronize(s));
+  if (prefetch.worker.joinable()) prefetch.worker.join();
   if (getenv("CUOPT_AMD_TIMING"))
     fprintf(stderr, "[cuopt_amd setup]   analysis: %s| natural %.2f/%.2f levels(%d) %.2f/%.2f cells(%d) %.2f/%.2f -> method %d\n", an->laps.c_str(),
             an->saving_natural[0], an->saving_natural[1], an->bfs_levels, an->saving_levels[0], an->saving_levels[1], an->cell_rounds,

@@ -244,6 +244,8 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     if (count == 0) return 0;
     if (uniform) {
       k_fill<<<grid_for((int64_t)count), kBlock, 0, ctx->stream>>>((int64_t)count, *work, value);
+    } else if (const double* on_device = an ? an->prefetched(src) : nullptr) {  // (sent ahead while the analysis ran: kernels_setup.hip)
+      HIP_TRY(hipMemcpyAsync(*work, on_device, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     } else {
       HIP_TRY(hipMemcpyAsync(*work, src, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }

@@ -922,7 +922,10 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
   cuopt_amd::PoolArray<double> pval;
   int setup_rc = 0;
   if (dev_setup && (!sharded || reorder)) {
-    setup_rc = pdlpdev_analyze(&ag.an, device, m, n, lp->offsets, lp->indices, lp->values, reorder ? 1 : 0);
+    // (single GPU: the vectors travel while the analysis runs; a sharded rank uploads its own slices later)
+    setup_rc = sharded ? pdlpdev_analyze(&ag.an, device, m, n, lp->offsets, lp->indices, lp->values, reorder ? 1 : 0)
+                       : pdlpdev_analyze_with_vectors(&ag.an, device, m, n, lp->offsets, lp->indices, lp->values, reorder ? 1 : 0, c.data(), lp->lo,
+                                                      lp->hi, lp->lb, lp->ub);
     if (setup_rc != 0) fail(setup_rc, "pdlpdev_analyze: %s", pdlpdev_last_error());
     if (setup_rc == 0) {
       s->row_new2old.resize((size_t)m), s->col_new2old.resize((size_t)n);

@@ -175,6 +175,12 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx);
 typedef struct pdlpdev_analysis pdlpdev_analysis; /* opaque */
 int pdlpdev_analyze(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_offsets, const int32_t* a_indices,
                     const double* a_values, int flags);
+/* the same, and the problem vectors (c, lb, ub: n; lo, hi: m, in the caller's order; any may be NULL) go to the device on a helper
+ * thread while the analysis' kernels run: pdlpdev_create_from_analysis picks them up when it is handed the same host pointers and the
+ * analysis did not permute the matrix (a permuted LP's vectors are permuted by the caller and uploaded by the create call). */
+int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, int32_t n, const int32_t* a_offsets, const int32_t* a_indices,
+                                 const double* a_values, int flags, const double* c, const double* lo, const double* hi, const double* lb,
+                                 const double* ub);
 /* out = {permuted, method (0 none | 1 chains | 2 groups), estimate natural A, natural A^T, chains A, chains A^T, groups A, groups A^T
  * (savings x 1e4), length of the chains (quotient levels), cell rounds} */
 int pdlpdev_analysis_info(pdlpdev_analysis* an, int32_t out[10]);
