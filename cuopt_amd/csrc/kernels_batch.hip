@@ -27,6 +27,7 @@
 // K = 16 uses the whole line a miss fetches.  The single-LP panels avoid those line fills by sweeping 1.33 MB column slabs in step
 // across the chip; eight interleaved vectors would need 46 slabs and a sweep synchronised to +-3 %: with the epilogue phases in
 // between it does not hold (window-major orders in the probe: no gain once the epilogue is in).
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include "pdlp_ctx.hpp"
@@ -53,6 +54,7 @@ struct BatchLp {  // what the batched kernels need of one LP, in device memory
   pdlpdev_ctx::UniformBounds ubd;
   double *part_a, *part_at;
 };
+static_assert(sizeof(BatchLp) == 16 * sizeof(void*) + 2 * sizeof(int) + 2 * sizeof(double), "no padding: batch_refresh_table compares entries with memcmp");
 
 // wave <-> LP in the element-wise phases: K <= 8: 8 / K waves share an LP (wave w: LP w % K, every (8 / K)-th piece of 64 rows from
 // piece w / K on); K = 16: a wave serves two LPs one after the other (w and w + 8)
@@ -224,6 +226,7 @@ __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int 
   };
   request(0, pv, sv);
   fetch(2, colA, valA);
+  __syncthreads();  // (trip 0 puts chunk 2 where chunk 0's entries are: every lane has read them first)
   for (int c = 0; c < nch; c += 2) {
     trip(c, pv, sv, pvn, svn, colA, valA, colB, valB);
     if (c + 1 < nch) trip(c + 1, pvn, svn, pv, sv, colB, valB, colA, valA);
@@ -412,8 +415,30 @@ struct pdlpdev_batch {
     const int32_t* row0 = nullptr;
     bool panel = false;
   } a_side, t_side;
+  std::vector<BatchLp> lp_host;  // what lp_dev holds
   std::map<int, hipGraphExec_t> graphs;
 };
+
+static BatchLp batch_lp_of(const pdlpdev_ctx* c)
+{
+  return BatchLp{c->ctl, c->y[0], c->y[1], c->sumy, c->lo, c->hi, c->x[0], c->x[1], c->aty[0], c->aty[1], c->sumx, c->c, c->lb, c->ub, c->ubd, c->part_a, c->part_at};
+}
+
+// A reset that gives a member row bounds of its own moves its lo / hi (pdlpdev_reset: copy on change): the table the kernels read
+// follows (the kernels -- and the captured graphs -- take the table's address, not its contents).
+static int batch_refresh_table(pdlpdev_batch* b)
+{
+  bool changed = false;
+  for (int l = 0; l < b->K; ++l) {
+    const BatchLp now = batch_lp_of(b->ctx[l]);
+    if (memcmp(&now, &b->lp_host[l], sizeof(BatchLp)) != 0) b->lp_host[l] = now, changed = true;
+  }
+  if (changed) {
+    HIP_TRY(hipMemcpyAsync(b->lp_dev, b->lp_host.data(), b->K * sizeof(BatchLp), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return 0;
+}
 
 static int batch_fetch_ctl(pdlpdev_batch* b)
 {
@@ -611,22 +636,26 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
   *out      = b;
   b->K = K, b->device = c0->device, b->stream = c0->stream;
   b->a_side = side[0], b->t_side = side[1];
-  std::vector<BatchLp> h(K);
+  std::vector<BatchLp>& h = b->lp_host;
+  h.resize(K);
   std::vector<pdlpdev_decision_args> dargs(K);
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = ctx[l];
     b->ctx[l]      = c;
-    h[l] = BatchLp{c->ctl, c->y[0], c->y[1], c->sumy, c->lo, c->hi, c->x[0], c->x[1], c->aty[0], c->aty[1], c->sumx, c->c, c->lb, c->ub, c->ubd, c->part_a, c->part_at};
+    h[l]     = batch_lp_of(c);
     dargs[l] = pdlpdev_decision_args{c->ctl, c->part_a, side[0].W, c->part_at, side[1].W, c->sp};
   }
   HIP_TRY(hipMalloc((void**)&b->lp_dev, K * sizeof(BatchLp)));
   HIP_TRY(hipMalloc((void**)&b->xK, ((size_t)c0->n * K + 64) * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&b->yK, ((size_t)c0->m * K + 64) * sizeof(double)));
-  HIP_TRY(hipMemcpy(b->lp_dev, h.data(), K * sizeof(BatchLp), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&b->dargs_dev, K * sizeof(pdlpdev_decision_args)));
-  HIP_TRY(hipMemcpy(b->dargs_dev, dargs.data(), K * sizeof(pdlpdev_decision_args), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(b->xK, 0, ((size_t)c0->n * K + 64) * sizeof(double)));
-  HIP_TRY(hipMemset(b->yK, 0, ((size_t)c0->m * K + 64) * sizeof(double)));
+  // everything on the batch's OWN stream (a non-blocking one: work of the null stream -- hipMemset, hipMemcpy -- is not ordered
+  // with it, and a memset that the queue scheduler lets wait can land attempts later, in the middle of a product's vectors)
+  HIP_TRY(hipMemcpyAsync(b->lp_dev, h.data(), K * sizeof(BatchLp), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->dargs_dev, dargs.data(), K * sizeof(pdlpdev_decision_args), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemsetAsync(b->xK, 0, ((size_t)c0->n * K + 64) * sizeof(double), b->stream));
+  HIP_TRY(hipMemsetAsync(b->yK, 0, ((size_t)c0->m * K + 64) * sizeof(double), b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));  // (h, dargs: host memory that goes away with this call)
   return 0;
 }
 
@@ -647,8 +676,10 @@ void pdlpdev_batch_destroy(pdlpdev_batch* b)
 // rests too: its lanes and its per-LP kernels turn into no-ops).  ctl[l] receives LP l's control block.
 int pdlpdev_batch_run(pdlpdev_batch* b, const int32_t* targets, pdlpdev_ctl* ctl)
 {
+  if (!b || !targets) return fail(-1, "pdlpdev_batch_run: null argument");
   roctx::Range range("pdlp: batched PDHG attempts");
   HIP_TRY(hipSetDevice(b->device));
+  TRY(batch_refresh_table(b));
   const int K = b->K;
   for (int l = 0; l < K; ++l)
     if (targets[l] > 0) k_set_target<<<1, 1, 0, b->stream>>>(b->ctx[l]->ctl, targets[l]);
@@ -703,7 +734,9 @@ int pdlpdev_batch_run(pdlpdev_batch* b, const int32_t* targets, pdlpdev_ctl* ctl
 // are put back afterwards (the "other" iterate buffers are scratch between attempts).
 int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
 {
+  if (!b || !avg_ms) return fail(-1, "pdlpdev_batch_time_kernels: null argument");
   HIP_TRY(hipSetDevice(b->device));
+  TRY(batch_refresh_table(b));
   hipStream_t s = b->stream;
   const int K   = b->K;
   if (reps < 1) reps = 1;

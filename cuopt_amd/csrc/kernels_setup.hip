@@ -1,5 +1,7 @@
 // Device-side set-up (see pdlp_setup.hpp): radix sort / scan primitives, CSR transpose, the structure-finding analysis pass and the
 // permuted CSR pair, all from ONE upload of A (the layouts' constructions: kernels_layout_build.hip).  gfx950, wave64.
+#include <system_error>
+#include <thread>
 #include <hip/hip_runtime.h>
 
 #include "pdlp_setup.hpp"
@@ -1258,7 +1260,7 @@ int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, 
     const double* src[5]  = {c, lb, ub, lo, hi};
     const size_t count[5] = {(size_t)n, (size_t)n, (size_t)n, (size_t)m, (size_t)m};
     for (int i = 0; i < 5; ++i) an->pref_src[i] = src[i];
-    prefetch.worker = std::thread([an, device, count] {
+    auto upload_vectors = [an, device, count] {
       if (hipSetDevice(device) != hipSuccess) return;
       for (int i = 0; i < 5; ++i) {
         if (!an->pref_src[i] || count[i] == 0) continue;
@@ -1271,7 +1273,11 @@ int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, 
         an->pref_dev[i] = d;  // (read after the join below)
       }
       (void)hipGetLastError();
-    });
+    };
+    try {
+      prefetch.worker = std::thread(upload_vectors);
+    } catch (const std::system_error&) {  // (no thread to be had: create uploads the vectors itself, as it does without the prefetch)
+    }
   }
   TRY(dev_transpose(s, an->arena, m, n, nnz, an->A, an->At));
   an->ms_transpose = lap("transpose");

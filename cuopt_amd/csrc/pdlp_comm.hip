@@ -265,7 +265,7 @@ int p2p_setup(pdlpdev_ctx* ctx)
   P.off_f = align(P.off_s + W * 4 * sizeof(double));
   P.bytes = (P.off_f + p2pdev::kKinds * W * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
   HIP_TRY(hipExtMallocWithFlags((void**)&P.base, P.bytes, hipDeviceMallocFinegrained));
-  HIP_TRY(hipMemset(P.base, 0, P.bytes));
+  HIP_TRY(hipMemsetAsync(P.base, 0, P.bytes, ctx->stream));  // (on the context's stream -- a non-blocking one, which the null stream's work is not ordered with)
   TRY(dev_alloc(ctx, &P.epoch, 4));
   TRY(dev_alloc(ctx, &P.fault, 4));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -233,3 +233,60 @@ def test_row_bounds_are_shared_until_someone_changes_them(monkeypatch):
     same(child.advance(), b, child.solution(), sb, "clone with new row bounds")
     same(parent.advance(), a, parent.solution(), sa, "parent back on the first row bounds")
     child.close(), parent.close()
+
+
+def test_members_may_be_reset_while_the_batch_lives(monkeypatch):
+    """a reset of a member between two advances of ONE batch object -- new variable bounds (their uniform-bound summary travels with
+    the LP's table entry) and new row bounds (the member's lo / hi move to arrays of its own) -- is seen by the next advance"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(6000, 5000, 8, seed=29)
+    bounds = variants(p, 4, seed=5)
+    lo2 = np.where(np.isfinite(p["lo"]), p["lo"] - 0.5, p["lo"])
+    hi2 = np.where(np.isfinite(p["hi"]), p["hi"] + 0.5, p["hi"])
+    kw = dict(tol=1e-6, iteration_limit=LIMIT)
+    def single(lb, ub, lo, hi):
+        s = capi.Solver(dict(p, lb=lb, ub=ub, lo=lo, hi=hi), **kw)
+        r = s.advance()
+        out = (r, s.solution())
+        s.close()
+        return out
+    parent = capi.Solver(dict(p, lb=bounds[0][0], ub=bounds[0][1]), **kw)
+    solvers = [parent] + [parent.clone(lb=lb, ub=ub) for lb, ub in bounds[1:]]
+    batch = capi.SharedMatrixBatch(solvers)
+    got = batch.advance()
+    for l in range(4):
+        r, sol = single(bounds[l][0], bounds[l][1], p["lo"], p["hi"])
+        same(got[l], r, solvers[l].solution(), sol, "LP %d, first round" % l)
+    # second round through the SAME batch: LP 1 takes LP 3's variable bounds, LP 2 other row bounds, LP 3 both; the parent starts over
+    solvers[1].reset(lb=bounds[3][0], ub=bounds[3][1], **kw)
+    solvers[2].reset(lb=bounds[2][0], ub=bounds[2][1], lo=lo2, hi=hi2, **kw)
+    solvers[3].reset(lb=bounds[1][0], ub=bounds[1][1], lo=lo2, hi=hi2, **kw)
+    parent.reset(**kw)
+    got = batch.advance()
+    want = [(bounds[0], (p["lo"], p["hi"])), (bounds[3], (p["lo"], p["hi"])), (bounds[2], (lo2, hi2)), (bounds[1], (lo2, hi2))]
+    for l, ((lb, ub), (lo, hi)) in enumerate(want):
+        r, sol = single(lb, ub, lo, hi)
+        same(got[l], r, solvers[l].solution(), sol, "LP %d, second round of the same batch" % l)
+    batch.close()
+    for s in solvers[1:]:
+        s.close()
+    parent.close()
+
+
+def test_batches_repeat_themselves_next_to_other_processes():
+    """four processes share the GPU, each solving the same LPs singly and as lockstep batches: whatever the interleaving of their
+    kernels, a batch gives the single solves' results (scripts/r05_contention_probe.py).  Pins the barrier between the first chunk's
+    reads and the third chunk's staging in batch_block_sums: waves of a workgroup drift far enough apart to need it only when the
+    scheduler takes them off the compute unit -- i.e. next to other processes' kernels"""
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts", "r05_contention_probe.py")
+    procs = [subprocess.Popen([sys.executable, probe, "4", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-2000:]
+        rounds = [ln for ln in out.splitlines() if " round " in ln]
+        assert len(rounds) == 2, out[-2000:]
+        for ln in rounds:
+            assert "False" not in ln, ln
