@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised runner for the round-5 GPU sessions (replaces the per-run scripts of earlier rounds).
 #   scripts/r05_gpu.sh <tag> <step> [<step> ...]      outputs under gpurun_out/<tag>/
-# steps: setup_tests | profsetup:<workload> | probe:<workloads,comma separated> | tests:<pytest -k expression or file> | bench:<workload> | prof:<workload> | pmc:<workload>
+# steps: contention:<rounds> | setup_tests | profsetup:<workload> | probe:<workloads,comma separated> | tests:<pytest -k expression or file> | bench:<workload> | prof:<workload> | pmc:<workload>
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -50,6 +50,9 @@ for k, cs in acc.items():
         print("  %-18s %-24s %s" % (k, c, " ".join("%.0f" % x for x in v)))
 PYEOF
                cat "$OUT/r05_gather_calibration.txt"; rm -rf "$OUT/gcal_fetch" "$OUT/gcal_req" ;;
+    contention) python -c "from cuopt_amd import synthetic; synthetic.generate(30000, 24000, 10, seed=21)"
+               for k in 4 8; do for i in 1 2 3 4 5 6; do timeout 150 python scripts/r05_contention_probe.py $k ${arg:-3} > "$OUT/contention_k${k}_$i.log" 2>&1 & done; wait; done
+               cat "$OUT"/contention_k*.log > "$OUT/r05_batch_contention.txt"; grep -c " round " "$OUT/r05_batch_contention.txt"; grep -v "batch equals singles \[True\(, True\)*\]" "$OUT/r05_batch_contention.txt" | cut -c1-300 ;;
     batchprobe) timeout 900 python scripts/r05_batch_probe.py $(echo "$arg" | tr ',' ' ') > "$OUT/batchprobe.log" 2>&1; grep -E "RATE|Traceback|Error|assert" "$OUT/batchprobe.log" | cut -c1-300 ;;
     batchprof) R=$PWD; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/batchprof" -- env BATCH_PROBE_GRAPH=0 BATCH_PROBE_BASE=${BATCH_PROBE_BASE:-c3} python "$R/scripts/r05_batch_probe.py" $arg > "$R/$OUT/batchprof.log" 2>&1)
           F=$(find "$OUT/batchprof" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/r05_batch_${arg}_kernel_stats.csv" && head -n 12 "$F" | cut -c1-160; rm -rf "$OUT/batchprof" ;;
