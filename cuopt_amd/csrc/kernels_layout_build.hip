@@ -586,7 +586,7 @@ k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows,
 {
   extern __shared__ int32_t tab[];  // 2 * wcap slots
   __shared__ int32_t pre[kJagStride + 1];
-  __shared__ int distinct, fresh, stop, lo, hi, runs, parallel, end_row, scratch[kJagCutT / 64 + 1];
+  __shared__ int distinct, stop, lo, hi, runs, parallel, parallel64, end_row, scratch[kJagCutT / 64 + 1];
   __shared__ long long refs;
   const uint32_t mask = (uint32_t)(2 * wcap - 1);
   const int t = threadIdx.x;
@@ -603,6 +603,7 @@ k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows,
       // a stride of up to kJagStride rows whose lengths cannot overflow the window whatever they contain goes in at once (a band's
       // block: four strides instead of 32 chunks); else a chunk of 64 rows, in parallel or row by row as in k_jag_estimate
       int nr = (int)min((int64_t)kJagStride, last - q0);
+      bool par;
       {
         int len = 0;
         if (t < nr) {
@@ -614,14 +615,17 @@ k_jag_cut_chunk(int32_t chunk_rows, int32_t row_cap, int32_t wcap, int32_t rows,
         if (t < nr) pre[t] = ex;
         if (t == 0) pre[nr] = total_all, parallel = distinct + total_all <= wcap;
         __syncthreads();
-        if (!parallel && nr > kEstChunk) {  // (the first 64 rows alone: their prefix sums are already there)
+        par = parallel != 0;
+        if (!par && nr > kEstChunk) {  // (the first 64 rows alone: their prefix sums are already there)
           nr = kEstChunk;
-          if (t == 0) parallel = distinct + pre[nr] <= wcap;
+          // (a second word: a wave that has not yet read the stride's answer must not find this one in its place)
+          if (t == 0) parallel64 = distinct + pre[nr] <= wcap;
           __syncthreads();
+          par = parallel64 != 0;
         }
       }
       const int total = pre[nr];
-      if (parallel) {
+      if (par) {
         int added = 0, mn = 0x7fffffff, mx = -1;
         // two lanes per row (rows are short: no search for an entry's row, a handful of inserts per lane)
         for (int r = t >> 1; r < nr; r += kJagCutT / 2) {
