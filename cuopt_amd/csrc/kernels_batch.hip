@@ -621,15 +621,19 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
   }
   HIP_TRY(hipSetDevice(c0->device));
   {
-    int* bad = nullptr;
-    HIP_TRY(hipMalloc((void**)&bad, sizeof(int)));
+    struct Flag {  // (released on every way out)
+      int* p = nullptr;
+      ~Flag() { if (p) (void)hipFree(p); }
+    } flag;
+    HIP_TRY(hipMalloc((void**)&flag.p, sizeof(int)));
+    int* bad = flag.p;
     HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), c0->stream));
     kb_check_sorted<<<2048, 256, 0, c0->stream>>>(c0->m, c0->ha_off, c0->ha_idx, bad);
     kb_check_sorted<<<2048, 256, 0, c0->stream>>>(c0->n, c0->hat_off, c0->hat_idx, bad);
+    LAUNCH_CHECK();
     int h = 0;
     HIP_TRY(hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, c0->stream));
     HIP_TRY(hipStreamSynchronize(c0->stream));
-    (void)hipFree(bad);
     if (h) return fail(-7, "pdlpdev_batch_create: not eligible (column indices are not ascending within the rows)");
   }
   pdlpdev_batch* b = new pdlpdev_batch();
@@ -742,7 +746,18 @@ int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
   if (reps < 1) reps = 1;
   TRY(batch_fetch_ctl(b));
   pdlpdev_ctl saved[kBatchMax], forced[kBatchMax];
-  double *sx[kBatchMax] = {nullptr}, *sy[kBatchMax] = {nullptr};
+  struct Scratch {  // (copies of the running sums, the dispatches' events: released on every way out)
+    double *sx[kBatchMax] = {nullptr}, *sy[kBatchMax] = {nullptr};
+    hipEvent_t ev[8] = {nullptr};
+    ~Scratch()
+    {
+      for (double* p : sx) if (p) (void)hipFree(p);
+      for (double* p : sy) if (p) (void)hipFree(p);
+      for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+  } scratch;
+  double **sx = scratch.sx, **sy = scratch.sy;
+  hipEvent_t* ev = scratch.ev;
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = b->ctx[l];
     saved[l] = forced[l] = *c->ctl_h;
@@ -756,8 +771,7 @@ int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
     for (int l = 0; l < K; ++l) HIP_TRY(hipMemcpyAsync(b->ctx[l]->ctl, &forced[l], sizeof(pdlpdev_ctl), hipMemcpyHostToDevice, s));
     return 0;
   };
-  hipEvent_t ev[8];
-  for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int q = 0; q < 8; ++q) HIP_TRY(hipEventCreate(&ev[q]));
   double sum[4] = {0.0, 0.0, 0.0, 0.0};
   TRY(arm());
   TRY(batch_enqueue(b));  // warm
@@ -772,7 +786,6 @@ int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
     }
   }
   for (int q = 0; q < 4; ++q) avg_ms[q] = sum[q] / reps;
-  for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = b->ctx[l];
     HIP_TRY(hipMemcpyAsync(c->ctl, &saved[l], sizeof(pdlpdev_ctl), hipMemcpyHostToDevice, s));
@@ -780,7 +793,6 @@ int pdlpdev_batch_time_kernels(pdlpdev_batch* b, int reps, double avg_ms[4])
     HIP_TRY(hipMemcpyAsync(c->sumy, sy[l], (size_t)c->m * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
-  for (int l = 0; l < K; ++l) (void)hipFree(sx[l]), (void)hipFree(sy[l]);
   return 0;
 }
 

@@ -614,6 +614,8 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   if (ctx->shared_with_parent && ctx->parent) ctx->parent->clones_alive -= 1;
+  if (ctx->clones_alive > 0)  // (a contract of pdlpdev_clone_shared; said aloud, since what follows frees the clones' matrices)
+    fprintf(stderr, "[cuopt_amd] pdlpdev_destroy: %d clone(s) of this context are still alive -- they alias its matrices and must be destroyed first\n", ctx->clones_alive);
   for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);

@@ -290,3 +290,28 @@ def test_batches_repeat_themselves_next_to_other_processes():
         assert len(rounds) == 2, out[-2000:]
         for ln in rounds:
             assert "False" not in ln, ln
+
+
+def test_timing_the_kernels_leaves_the_batch_where_it_was(monkeypatch):
+    """pdlpdev_batch_time_kernels (bench.py's roofline leg) forces every LP active for its measurement and puts control blocks and
+    running sums back: the solves go on as if nothing had happened"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(6000, 5000, 8, seed=31)
+    bounds = variants(p, 4, seed=7)
+    kw = dict(tol=1e-6, iteration_limit=LIMIT)
+    parent = capi.Solver(dict(p, lb=bounds[0][0], ub=bounds[0][1]), **kw)
+    solvers = [parent] + [parent.clone(lb=lb, ub=ub) for lb, ub in bounds[1:]]
+    batch = capi.SharedMatrixBatch(solvers)
+    batch.advance(130)
+    t = batch.time_kernels(3)
+    assert all(v > 0.0 for v in t.values()), t
+    got = batch.advance()
+    for l, (lb, ub) in enumerate(bounds):
+        s = capi.Solver(dict(p, lb=lb, ub=ub), **kw)
+        r = s.advance()
+        same(got[l], r, solvers[l].solution(), s.solution(), "LP %d after the timed attempts" % l)
+        s.close()
+    batch.close()
+    for s in solvers[1:]:
+        s.close()
+    parent.close()
