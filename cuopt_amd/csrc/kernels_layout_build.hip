@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(kT) k_panel_count(const int32_t* __restrict__ 
     if (run) atomicAdd(&c[s_cur], run);
   }
   __syncthreads();
-  if (threadIdx.x < S) count[(size_t)w * S + threadIdx.x] = c[threadIdx.x];
+  if ((int)threadIdx.x < S) count[(size_t)w * S + threadIdx.x] = c[threadIdx.x];
 }
 
 // placement in (slab, row, CSR) order.  LDS: per (slab, row) the number of entries, then its exclusive prefix over the rows of the slab
