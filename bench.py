@@ -126,7 +126,7 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
                 ub[j] = p["x_star"][j] + 0.3 * rng.random()
         return lb, ub
     # (BENCH_USE_GRAPH=0: plain launches instead of replay graphs -- rocprofv3 7.2 falls over a process that instantiates a second
-    #  family of graphs after destroying a first; the counter passes of scripts/r05_gpu.sh pmc:c3_batch8 set it)
+    #  family of graphs after destroying a first; the counter passes of scripts/gpu_session.sh pmc:c3_batch8 set it)
     graph = int(os.environ.get("BENCH_USE_GRAPH", "1"))
     parent = capi.Solver(p, mode=1, tol=0.0, device=local_rank, use_graph=graph)
     setup_s = parent.advance(0)["setup_seconds"]

@@ -1,4 +1,4 @@
-"""Dumps a bench workload's A and A^T as raw arrays for tools/rocsparse_yardstick.cpp:  python scripts/r05_dump_csr.py c3 /tmp/c3csr"""
+"""Dumps a bench workload's A and A^T as raw arrays for tools/rocsparse_yardstick.cpp:  python scripts/dump_csr.py c3 /tmp/c3csr"""
 import os
 import sys
 

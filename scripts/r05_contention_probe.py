@@ -1,5 +1,5 @@
 """Several of these processes side by side on one GPU: do single solves and lockstep batches repeat themselves bit for bit while other
-processes' kernels are interleaved with theirs?  (scripts/r05_gpu.sh ... contention)"""
+processes' kernels are interleaved with theirs?  (scripts/gpu_session.sh ... contention)"""
 import os
 import sys
 

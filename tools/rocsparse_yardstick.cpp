@@ -1,6 +1,6 @@
 // An OUTSIDE yardstick for the "0.31 is this part's floor for a uniformly random matrix" claim (round-4 review, task 4): rocSPARSE's CSR
 // SpMV (adaptive, LRB, row split, nonzero split and the library's default, each with its analysis / preprocess step) on the SAME
-// matrices the solver multiplies -- C3's A and A^T, dumped as raw arrays by scripts/r05_dump_csr.py -- inside the same kind of loop
+// matrices the solver multiplies -- C3's A and A^T, dumped as raw arrays by scripts/dump_csr.py -- inside the same kind of loop
 // pdlpdev_time_kernel uses: the two products alternate, with a 512 MB memset between them so that neither the 120 MB matrix nor the
 // vectors survive in the 256 MiB Infinity Cache from one launch to the next (the solver's four kernels evict each other the same
 // way).  Never linked into the product: a harness, like the rest of tools/.
