@@ -55,13 +55,14 @@ constexpr unsigned kPadLevel = 127u;
 
 struct TallView {
   int rows, cols;       // of the matrix
-  int NP, S, SW, NS;    // row panels, column ranges, slab width (columns), slabs per range (a multiple of the prefetch depth)
+  int NP, S, SW, NS;    // row panels, column ranges, slab width (columns), STEPS per workgroup (the largest count, a multiple of the prefetch depths)
   int R, CWID;          // rows per panel, columns per range (NS * SW)
   int G;                // workgroups in the grid (NP * S rounded up to 8)
   const double* val;    // entries of all workgroups, each workgroup's stream 64-aligned
   const uint32_t* pk;
   const long long* gbase;  // [G] first entry of the workgroup's stream
-  const int* cp;           // [G * (NS + 1)] cell boundaries inside the stream
+  const int2* cq;          // [G * (NS + 1)] per step: its first entry inside the stream, the length q <= 64 of a consumer wave's share (the step holds CW * q slots)
+  const int* sl;           // [G * (NS + 1)] per step: its slab (a cell of more than 64 * CW entries takes several steps over the same slab)
   int rows_pad;            // stride of the partial vectors
 };
 
@@ -89,104 +90,139 @@ __device__ __forceinline__ void step_barrier()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int LW, int CW, int D, int XL /* double2 loads per loader lane and slab */>
+// One entry of a consumer's share: one ds_read_b64 of the slab, one addition into the row's accumulator.  ATOMIC: ds_add_f64 (fire and
+// forget); otherwise read - add - write by the lane (no other wave touches the row during the step, and the LDS executes one wave's
+// operations in order).
+template <bool ATOMIC, int DBG>
+__device__ __forceinline__ void tall_consume(double cv, uint32_t cpk, bool in_share, const double* xs, double* acc)
+{
+  const unsigned lvl = cpk >> kLvlShift;
+  const bool act     = in_share && lvl != kPadLevel;
+  const int row      = (int)(cpk & ((1u << kRowBits) - 1u));
+  const int col      = (int)((cpk >> kRowBits) & ((1u << kColBits) - 1u));
+  const double pr    = cv * ((DBG & 4) ? (double)col : (act ? xs[col] : 0.0));
+  if (DBG & 8) { if (pr == 1.2345) acc[row] = pr; return; }
+  if (!__ballot(act && lvl > 0u)) {  // (uniform) no row has two entries in this part of the share
+    if (act) {
+      if (ATOMIC) lds_add(acc + row, pr);
+      else acc[row] = acc[row] + pr;
+    }
+  } else {
+    for (unsigned d = 0; __ballot(act && lvl >= d); ++d)
+      if (act && lvl == d) {
+        if (ATOMIC) lds_add(acc + row, pr);
+        else acc[row] = acc[row] + pr;
+      }
+  }
+}
+
+template <int LW, int CW, int D, int XL /* 16-byte loads per loader lane and slab */, int P /* steps the entry stream runs ahead */, bool ATOMIC, int DBG = 0 /* timing experiments: 1 no slab writes, 2 no slab loads, 4 no slab reads, 8 no additions, 16 no entry loads */>
 __global__ __launch_bounds__((LW + CW) * 64) void k_tall(TallView V, const double* __restrict__ x, double* __restrict__ partial)
 {
   extern __shared__ double lds[];
-  constexpr int T = (LW + CW) * 64;
+  constexpr int T   = (LW + CW) * 64;
+  constexpr int TAB = (P > D ? P : D) + 2;      // table entries read beyond the last step
   int p, q;
   if (!tall_where(V, blockIdx.x, &p, &q)) return;
   const int g     = blockIdx.x;
   double* acc     = lds;                        // [R]
   double* xb      = lds + ((V.R + 1) & ~1);     // [2][SW]
-  int* cps        = (int*)(xb + 2 * V.SW);      // [NS + 1]
+  int2* cqs       = (int2*)(xb + 2 * V.SW);     // [NS + TAB]
+  int* sls        = (int*)(cqs + V.NS + TAB);   // [NS + TAB]
   const int r0    = p * V.R;
   const int nr    = min(V.R, V.rows - r0);
   const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane  = threadIdx.x & 63;
   for (int i = threadIdx.x; i < V.R; i += T) acc[i] = 0.0;
-  for (int i = threadIdx.x; i <= V.NS; i += T) cps[i] = V.cp[(size_t)g * (V.NS + 1) + i];
-  const double* xr = x + (size_t)q * V.CWID;    // (the vector is padded to S * CWID + (D + 1) * SW entries)
+  for (int i = threadIdx.x; i < V.NS + TAB; i += T) {
+    cqs[i] = i <= V.NS ? V.cq[(size_t)g * (V.NS + 1) + i] : make_int2(0, 0);
+    sls[i] = V.sl[(size_t)g * (V.NS + 1) + (i <= V.NS ? i : V.NS)];
+  }
+  const double* xr = x + (size_t)q * V.CWID;
+  __syncthreads();                              // the tables
   if (wave < LW) {
-    // ---- loader: slab s + 1 is written to LDS behind barrier s; D slabs in flight in registers
+    // ---- loader: the slab of step s + 1 is written to LDS behind barrier s; D slabs in flight in registers
     d2 st[D][XL];
-    const int t = wave * 64 + lane;             // 0 .. LW * 64: double2 index inside a slab, stride LW * 64
+    const int t = wave * 64 + lane;             // 0 .. LW * 64: 16-byte index inside a slab, stride LW * 64
+    {
+      const double* src = xr + (size_t)__builtin_amdgcn_readfirstlane(sls[0]) * V.SW;
 #pragma unroll
-    for (int u = 0; u < XL; ++u) {              // slab 0 straight into its buffer
-      d2 v = *(const d2*)(xr + 2 * (t + u * LW * 64));
-      *(d2*)(xb + 2 * (t + u * LW * 64)) = v;
+      for (int u = 0; u < XL; ++u) {            // step 0's slab straight into its buffer
+        d2 v = *(const d2*)(src + 2 * (t + u * LW * 64));
+        *(d2*)(xb + 2 * (t + u * LW * 64)) = v;
+      }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d) {
+      const double* src = xr + (size_t)__builtin_amdgcn_readfirstlane(sls[d + 1]) * V.SW;
 #pragma unroll
-      for (int u = 0; u < XL; ++u) st[d][u] = *(const d2*)(xr + (size_t)(d + 1) * V.SW + 2 * (t + u * LW * 64));
-    step_barrier();                             // barrier 0: slab 0, the zeroed accumulators and the cell table are visible
+      for (int u = 0; u < XL; ++u) st[d][u] = *(const d2*)(src + 2 * (t + u * LW * 64));
+    }
+    // (table look-ups out of the step's dependent chain: lane l keeps entry w + l of a 64-entry window, v_readlane picks)
+    int tsl = sls[min(lane, V.NS + TAB - 1)];
+    step_barrier();                             // barrier 0: step 0's slab and the zeroed accumulators are visible
     for (int s0 = 0; s0 < V.NS; s0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const int s = s0 + d;                   // step s: park slab s + 1 (registers d), request slab s + 1 + D into the same registers
+        const int s = s0 + d;                   // step s: park the slab of step s + 1 (registers d), request the one of step s + 1 + D
+        if (((s + 1 + D) & 63) == 0) tsl = sls[min(s + 1 + D + lane, V.NS + TAB - 1)];
         double* dst = xb + ((s + 1) & 1) * V.SW;
 #pragma unroll
-        for (int u = 0; u < XL; ++u) *(d2*)(dst + 2 * (t + u * LW * 64)) = st[d][u];
+        for (int u = 0; u < XL; ++u) {
+          if (DBG & 1) { if (st[d][u].x == 1.2345) *(d2*)(dst + 2 * (t + u * LW * 64)) = st[d][u]; }
+          else *(d2*)(dst + 2 * (t + u * LW * 64)) = st[d][u];
+        }
+        const double* src = xr + (size_t)__builtin_amdgcn_readlane(tsl, (s + 1 + D) & 63) * V.SW;
 #pragma unroll
-        for (int u = 0; u < XL; ++u) st[d][u] = *(const d2*)(xr + (size_t)(s + 1 + D) * V.SW + 2 * (t + u * LW * 64));
+        for (int u = 0; u < XL; ++u) {
+          if (DBG & 2) st[d][u].x = st[d][u].x + 1.0;
+          else st[d][u] = *(const d2*)(src + 2 * (t + u * LW * 64));
+        }
         step_barrier();                         // barrier s + 1
       }
     }
   } else {
-    // ---- consumer c owns the chunks k = c, c + CW, ... of the workgroup's stream
-    const int c           = wave - LW;
+    // ---- consumer c: of every step the share [c * q, (c + 1) * q) of its CW * q slots (q <= 64: lane <-> entry), requested P steps
+    // ahead into a ring of registers.  Straight-line code (every lane always loads, lanes beyond the share re-read the step's first
+    // entry; no branch contains a load), so that the compiler's own counted vmcnt waits keep P - 1 steps of loads in flight.
+    const int c = wave - LW;
     const double* __restrict__ val = V.val + V.gbase[g];
     const uint32_t* __restrict__ pk = V.pk + V.gbase[g];
-    int k                 = c;
-    // two chunks in registers: the one being consumed and the next one, requested a chunk ago.  The pair is a static ping-pong (the
-    // loop body exists twice, selected by a scalar parity) -- a rotation "cur = next; next = load" makes the compiler copy the freshly
-    // requested registers, i.e. wait for the load it has just issued.
-    double v0             = __builtin_nontemporal_load(val + (size_t)k * 64 + lane);
-    uint32_t p0           = __builtin_nontemporal_load(pk + (size_t)k * 64 + lane);
-    double v1             = __builtin_nontemporal_load(val + (size_t)(k + CW) * 64 + lane);
-    uint32_t p1           = __builtin_nontemporal_load(pk + (size_t)(k + CW) * 64 + lane);
-    int par               = 0;
+    double rv[P];
+    uint32_t rp[P];
+#pragma unroll
+    for (int d = 0; d < P; ++d) {
+      const int base = __builtin_amdgcn_readfirstlane(cqs[d].x), qn = __builtin_amdgcn_readfirstlane(cqs[d].y);
+      const int i    = lane < qn ? base + c * qn + lane : base;
+      rv[d] = __builtin_nontemporal_load(val + i);
+      rp[d] = __builtin_nontemporal_load(pk + i);
+    }
+    int tq = 0, nb = cqs[min(lane, V.NS + TAB - 1)].x, nq = cqs[min(lane, V.NS + TAB - 1)].y;
     step_barrier();                             // barrier 0
-#define TALL_CONSUME(cv, cpk)                                                                  \
-  {                                                                                            \
-    const int idx      = k * 64 + lane;                                                        \
-    const unsigned lvl = (cpk) >> kLvlShift;                                                   \
-    const bool act     = idx >= lo && idx < hi && lvl != kPadLevel;                            \
-    const int row      = (int)((cpk) & ((1u << kRowBits) - 1u));                               \
-    const int col      = (int)(((cpk) >> kRowBits) & ((1u << kColBits) - 1u));                 \
-    const double pr    = (cv) * (act ? xs[col] : 0.0);                                         \
-    if (!__ballot(act && lvl > 0u)) { /* (uniform) no row has two entries in this part of the cell */ \
-      if (act) lds_add(acc + row, pr);                                                         \
-    } else {                                                                                   \
-      for (unsigned d = 0; __ballot(act && lvl >= d); ++d)                                     \
-        if (act && lvl == d) lds_add(acc + row, pr);                                           \
-    }                                                                                          \
-  }
-    for (int s = 0; s < V.NS; ++s) {
-      const int lo = __builtin_amdgcn_readfirstlane(cps[s]), hi = __builtin_amdgcn_readfirstlane(cps[s + 1]);
-      const double* xs = xb + (s & 1) * V.SW;
-      while (k * 64 < hi) {
-        if (par == 0) {
-          TALL_CONSUME(v0, p0)
-          if (k * 64 + 64 > hi) break;
-          k += CW;                              // the chunk is finished: its registers take the chunk after the next
-          v0  = __builtin_nontemporal_load(val + (size_t)(k + CW) * 64 + lane);
-          p0  = __builtin_nontemporal_load(pk + (size_t)(k + CW) * 64 + lane);
-          par = 1;
-        } else {
-          TALL_CONSUME(v1, p1)
-          if (k * 64 + 64 > hi) break;
-          k += CW;
-          v1  = __builtin_nontemporal_load(val + (size_t)(k + CW) * 64 + lane);
-          p1  = __builtin_nontemporal_load(pk + (size_t)(k + CW) * 64 + lane);
-          par = 0;
+    for (int s0 = 0; s0 < V.NS; s0 += P) {
+#pragma unroll
+      for (int d = 0; d < P; ++d) {
+        const int s      = s0 + d;
+        const double* xs = xb + (s & 1) * V.SW;
+        if ((s & 63) == 0) tq = cqs[min(s + lane, V.NS + TAB - 1)].y;
+        if (((s + P) & 63) == 0) {
+          const int2 e = cqs[min(s + P + lane, V.NS + TAB - 1)];
+          nb = e.x, nq = e.y;
         }
+        const int qs     = __builtin_amdgcn_readlane(tq, s & 63);
+        tall_consume<ATOMIC, DBG>(rv[d], rp[d], lane < qs, xs, acc);
+        const int nbase = __builtin_amdgcn_readlane(nb, (s + P) & 63), qn = __builtin_amdgcn_readlane(nq, (s + P) & 63);
+        const int i     = lane < qn ? nbase + c * qn + lane : nbase;
+        if (!(DBG & 16)) {
+          rv[d] = __builtin_nontemporal_load(val + i);
+          rp[d] = __builtin_nontemporal_load(pk + i);
+        } else {
+          rp[d] = (rp[d] & ~((1u << kRowBits) - 1u)) | ((rp[d] + 77u) & 8191u);
+        }
+        step_barrier();                         // barrier s + 1
       }
-      step_barrier();                           // barrier s + 1
     }
   }
-#undef TALL_CONSUME
   // (the last barrier of either branch: every addition is done)
   double* out = partial + (size_t)q * V.rows_pad + r0;
   for (int i = threadIdx.x; i < nr; i += T) out[i] = acc[i];
@@ -228,31 +264,39 @@ struct TallHost {
   std::vector<double> val;
   std::vector<uint32_t> pk;
   std::vector<long long> gbase;
-  std::vector<int> cp;
-  long long pads = 0, entries = 0, max_cell = 0, dup_entries = 0;
+  std::vector<int2> cq;
+  std::vector<int> sl;
+  long long pads = 0, entries = 0, max_cell = 0, dup_entries = 0, split_steps = 0;
+  int slabs = 0, min_steps = 0;
   double build_s = 0;
 };
 
-static bool build_tall(int rows, int cols, const std::vector<int>& off, const std::vector<int>& idx, const std::vector<double>& a, int NP, int S, int SW, int D,
-                       int tail_chunks, TallHost* H)
+static int lcm_int(int a, int b) { int x = a, y = b; while (y) { int t = x % y; x = y; y = t; } return a / x * b; }
+
+static bool build_tall(int rows, int cols, const std::vector<int>& off, const std::vector<int>& idx, const std::vector<double>& a, int NP, int S, int SW, int D, int P,
+                       int CW, int rot, TallHost* H)
 {
   const auto t0 = std::chrono::steady_clock::now();
   TallView& V = H->V;
   V.rows = rows, V.cols = cols, V.NP = NP, V.S = S, V.SW = SW;
   V.R  = (rows + NP - 1) / NP;
   if (V.R > (1 << kRowBits) || SW > (1 << kColBits)) return false;
-  int cw = (cols + S - 1) / S;
-  V.NS   = (cw + SW - 1) / SW;
-  V.NS   = (V.NS + D - 1) / D * D;
-  V.CWID = V.NS * SW;
-  // (ranges of NS * SW columns: the last range may be partly or wholly beyond the matrix -- the vector is padded)
+  const int cw    = (cols + S - 1) / S;
+  const int mult  = lcm_int(D, P);
+  const int slabs = (cw + SW - 1) / SW;
+  H->slabs = slabs;
+  V.CWID   = slabs * SW;
+  // (ranges of slabs * SW columns: the last range may be partly beyond the matrix -- the vector is padded)
   V.G        = S <= 8 ? ((NP + 8 / S - 1) / (8 / S)) * 8 : NP * S;
   V.rows_pad = (rows + 63) & ~63;
   H->gbase.assign(V.G, 0);
-  H->cp.assign((size_t)V.G * (V.NS + 1), 0);
   H->val.clear(), H->pk.clear();
   H->val.reserve(idx.size() + idx.size() / 8), H->pk.reserve(idx.size() + idx.size() / 8);
-  std::vector<std::vector<std::pair<uint32_t, double>>> cell((size_t)V.NS);  // (row << 11 | col in slab, value), pushed row by row = sorted
+  std::vector<std::vector<std::pair<uint32_t, double>>> cell((size_t)slabs);  // (row << 11 | col in slab, value), pushed row by row = sorted
+  std::vector<std::vector<int2>> wg_cq(V.G);
+  std::vector<std::vector<int>> wg_sl(V.G);
+  std::vector<int> run_len;
+  const uint32_t kPad = kPadLevel << kLvlShift;
   for (int b = 0; b < V.G; ++b) {
     int p, q;
     {
@@ -273,37 +317,95 @@ static bool build_tall(int rows, int cols, const std::vector<int>& off, const st
         cell[s].push_back({(uint32_t)(r - r0) << kColBits | (uint32_t)(*j - c0 - s * SW), a[(size_t)(j - idx.data())]});
       }
     }
-    int* cp   = H->cp.data() + (size_t)b * (V.NS + 1);
     long long pos = 0;  // inside the workgroup's stream
-    for (int s = 0; s < V.NS; ++s) {
-      cp[s] = (int)pos;
+    // rot: the workgroups of one XCD (they share the column range) start their walk at different slabs, so that at any moment
+    // they read different lines of the range instead of all the same 16 KB (a fixed order per workgroup: still deterministic)
+    const int first_slab = rot ? (int)(((long long)(b >> 3) * slabs) / std::max(1, V.G / 8)) % slabs : 0;
+    for (int sv = 0; sv < slabs; ++sv) {
+      const int s   = (sv + first_slab) % slabs;
       const auto& c = cell[s];
       H->max_cell = std::max<long long>(H->max_cell, (long long)c.size());
+      H->entries += (long long)c.size();
+      // the runs of equal rows (an entry alone is a run of one); a run never leaves its wave's share
+      run_len.clear();
       for (size_t i = 0; i < c.size();) {
         size_t e = i + 1;
         while (e < c.size() && (c[e].first >> kColBits) == (c[i].first >> kColBits)) ++e;
-        const size_t len = e - i;
-        if (len >= kPadLevel) return false;  // (a row with 127 entries inside one slab: not this layout's matrix)
-        if (len > 1) {
-          H->dup_entries += (long long)len;
-          if (pos / 64 != (pos + (long long)len - 1) / 64) {  // the run would straddle a chunk: pad to the chunk's end
-            while (pos % 64) { H->val.push_back(0.0), H->pk.push_back(kPadLevel << kLvlShift), ++pos, ++H->pads; }
-          }
-        }
-        for (size_t u = i; u < e; ++u) {
-          const uint32_t row = c[u].first >> kColBits, col = c[u].first & ((1u << kColBits) - 1u);
-          H->val.push_back(c[u].second);
-          H->pk.push_back(row | col << kRowBits | (uint32_t)(u - i) << kLvlShift);
-          ++pos;
-        }
+        run_len.push_back((int)(e - i));
+        if (e - i > 64) return false;  // (a row with more than 64 entries inside one slab: not this layout's matrix)
+        if (e - i > 1) H->dup_entries += (long long)(e - i);
         i = e;
       }
-      H->entries += (long long)c.size();
+      // steps over this slab: consecutive groups of runs, each group dealt to the CW consumer waves in shares of q <= 64 slots
+      size_t ri = 0, ei = 0;
+      bool first = true;
+      while (first || ri < run_len.size()) {
+        first = false;
+        // the longest prefix of the remaining runs that fits CW shares of 64, then the smallest q that still holds it
+        size_t rj = ri;
+        {
+          int w = 0, fill = 0;
+          for (; rj < run_len.size(); ++rj) {
+            const int L = run_len[rj];
+            if (fill + L > 64) { ++w, fill = 0; }
+            if (w >= CW) break;
+            fill += L;
+          }
+        }
+        int cnt = 0, longest = 0;
+        for (size_t k = ri; k < rj; ++k) cnt += run_len[k], longest = std::max(longest, run_len[k]);
+        int qs = std::max((cnt + CW - 1) / CW, longest);
+        for (;; ++qs) {
+          int w = 0, fill = 0;
+          bool fits = true;
+          for (size_t k = ri; k < rj; ++k) {
+            const int L = run_len[k];
+            if (fill + L > qs) { ++w, fill = 0; }
+            if (w >= CW) { fits = false; break; }
+            fill += L;
+          }
+          if (fits) break;
+        }
+        wg_cq[b].push_back(make_int2((int)pos, qs));
+        wg_sl[b].push_back(s);
+        if (ri > 0) ++H->split_steps;
+        int w = 0, fill = 0;
+        for (size_t k = ri; k < rj; ++k) {
+          const int L = run_len[k];
+          if (fill + L > qs) {
+            for (; fill < qs; ++fill) { H->val.push_back(0.0), H->pk.push_back(kPad), ++H->pads; }
+            ++w, fill = 0;
+          }
+          for (int u = 0; u < L; ++u, ++ei) {
+            const uint32_t row = c[ei].first >> kColBits, col = c[ei].first & ((1u << kColBits) - 1u);
+            H->val.push_back(c[ei].second);
+            H->pk.push_back(row | col << kRowBits | (uint32_t)u << kLvlShift);
+          }
+          fill += L;
+        }
+        for (long long k = (long long)w * qs + fill; k < (long long)CW * qs; ++k) { H->val.push_back(0.0), H->pk.push_back(kPad), ++H->pads; }
+        pos += (long long)CW * qs;
+        ri = rj;
+      }
     }
-    cp[V.NS] = (int)pos;
-    while (H->val.size() % 64) H->val.push_back(0.0), H->pk.push_back(kPadLevel << kLvlShift);
+    wg_cq[b].push_back(make_int2((int)pos, 0));  // (an empty step: the requests beyond the last step read its first slot -- one pad)
+    H->val.push_back(0.0), H->pk.push_back(kPad);
   }
-  for (int i = 0; i < 64 * tail_chunks; ++i) H->val.push_back(0.0), H->pk.push_back(kPadLevel << kLvlShift);  // chunks requested beyond the last stream
+  int ns = 0, ns_min = 1 << 30;
+  for (int b = 0; b < V.G; ++b) ns = std::max(ns, (int)wg_sl[b].size()), ns_min = wg_sl[b].empty() ? ns_min : std::min(ns_min, (int)wg_sl[b].size());
+  H->min_steps = ns_min;
+  V.NS = (ns + mult - 1) / mult * mult;
+  H->cq.assign((size_t)V.G * (V.NS + 1), make_int2(0, 0));
+  H->sl.assign((size_t)V.G * (V.NS + 1), 0);
+  for (int b = 0; b < V.G; ++b) {
+    if (wg_cq[b].empty()) continue;
+    const int2 last = wg_cq[b].back();
+    for (int s = 0; s <= V.NS; ++s) {
+      H->cq[(size_t)b * (V.NS + 1) + s] = s < (int)wg_sl[b].size() ? wg_cq[b][s] : last;
+      H->sl[(size_t)b * (V.NS + 1) + s] = s < (int)wg_sl[b].size() ? wg_sl[b][s] : slabs - 1;
+    }
+  }
+  for (int i = 0; i < 256; ++i) H->val.push_back(0.0), H->pk.push_back(kPad);
   H->build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return true;
 }
@@ -313,7 +415,8 @@ struct TallDev {
   double* val = nullptr;
   uint32_t* pk = nullptr;
   long long* gbase = nullptr;
-  int* cp = nullptr;
+  int2* cq = nullptr;
+  int* sl = nullptr;
   double* partial = nullptr;
   size_t lds_bytes = 0;
 };
@@ -321,39 +424,44 @@ static void upload(const TallHost& H, TallDev* Dv)
 {
   Dv->V = H.V;
   OK(hipMalloc((void**)&Dv->val, H.val.size() * 8)); OK(hipMalloc((void**)&Dv->pk, H.pk.size() * 4));
-  OK(hipMalloc((void**)&Dv->gbase, H.gbase.size() * 8)); OK(hipMalloc((void**)&Dv->cp, H.cp.size() * 4));
+  OK(hipMalloc((void**)&Dv->gbase, H.gbase.size() * 8)); OK(hipMalloc((void**)&Dv->cq, H.cq.size() * 8)); OK(hipMalloc((void**)&Dv->sl, H.sl.size() * 4));
   OK(hipMalloc((void**)&Dv->partial, (size_t)H.V.S * H.V.rows_pad * 8));
   OK(hipMemcpy(Dv->val, H.val.data(), H.val.size() * 8, hipMemcpyHostToDevice));
   OK(hipMemcpy(Dv->pk, H.pk.data(), H.pk.size() * 4, hipMemcpyHostToDevice));
   OK(hipMemcpy(Dv->gbase, H.gbase.data(), H.gbase.size() * 8, hipMemcpyHostToDevice));
-  OK(hipMemcpy(Dv->cp, H.cp.data(), H.cp.size() * 4, hipMemcpyHostToDevice));
-  Dv->V.val = Dv->val, Dv->V.pk = Dv->pk, Dv->V.gbase = Dv->gbase, Dv->V.cp = Dv->cp;
-  Dv->lds_bytes = (size_t)((H.V.R + 1) & ~1) * 8 + (size_t)2 * H.V.SW * 8 + (size_t)(H.V.NS + 1) * 4 + 16;
+  OK(hipMemcpy(Dv->cq, H.cq.data(), H.cq.size() * 8, hipMemcpyHostToDevice));
+  OK(hipMemcpy(Dv->sl, H.sl.data(), H.sl.size() * 4, hipMemcpyHostToDevice));
+  Dv->V.val = Dv->val, Dv->V.pk = Dv->pk, Dv->V.gbase = Dv->gbase, Dv->V.cq = Dv->cq, Dv->V.sl = Dv->sl;
+  Dv->lds_bytes = (size_t)((H.V.R + 1) & ~1) * 8 + (size_t)2 * H.V.SW * 8 + (size_t)(H.V.NS + 1 + 16) * 12 + 16;
 }
 static void release(TallDev* Dv)
 {
-  (void)hipFree(Dv->val); (void)hipFree(Dv->pk); (void)hipFree(Dv->gbase); (void)hipFree(Dv->cp); (void)hipFree(Dv->partial);
+  (void)hipFree(Dv->val); (void)hipFree(Dv->pk); (void)hipFree(Dv->gbase); (void)hipFree(Dv->cq); (void)hipFree(Dv->sl); (void)hipFree(Dv->partial);
 }
 
 typedef void (*tall_fn)(TallView, const double*, double*);
-struct Variant { int LW, CW, D, SW; tall_fn fn; };
-#define VARIANT(LW, CW, D, SW) Variant{LW, CW, D, SW, k_tall<LW, CW, D, (SW) / (2 * 64 * (LW))>}
+struct Variant { int LW, CW, D, SW, P, XM, atomic; tall_fn fn; };
+#define VARIANT(LW, CW, D, SW, P, AT) Variant{LW, CW, D, SW, P, 1, AT, k_tall<LW, CW, D, (SW) / (2 * 64 * (LW)), P, (AT) != 0>}
+#define VARIANT_DBG(LW, CW, D, SW, P, DBG) Variant{LW, CW, D, SW, P, 1, 100 + DBG, k_tall<LW, CW, D, (SW) / (2 * 64 * (LW)), P, true, DBG>}
 static const Variant kVariants[] = {
-  VARIANT(4, 12, 3, 2048), VARIANT(4, 12, 2, 2048), VARIANT(4, 12, 4, 2048), VARIANT(4, 4, 3, 2048), VARIANT(4, 8, 3, 2048), VARIANT(2, 6, 3, 2048),
-  VARIANT(8, 8, 3, 2048),  VARIANT(2, 14, 3, 2048), VARIANT(4, 12, 3, 1024), VARIANT(4, 4, 3, 1024), VARIANT(2, 6, 3, 1024), VARIANT(2, 6, 4, 1024),
-  VARIANT(4, 12, 6, 1024), VARIANT(2, 14, 6, 1024), VARIANT(1, 7, 4, 1024),  VARIANT(1, 7, 8, 512),  VARIANT(2, 6, 8, 512),
+  VARIANT(4, 8, 4, 2048, 8, 1),  VARIANT(4, 8, 4, 2048, 8, 0),  VARIANT(8, 8, 8, 2048, 8, 1),  VARIANT(8, 8, 8, 2048, 8, 0),  VARIANT(4, 12, 4, 2048, 8, 1), VARIANT(4, 12, 6, 2048, 12, 1),
+  VARIANT(4, 6, 4, 2048, 8, 1),  VARIANT(4, 8, 6, 2048, 12, 1), VARIANT(4, 8, 2, 2048, 2, 1),  VARIANT(4, 8, 4, 2048, 4, 1),  VARIANT(8, 8, 12, 2048, 12, 1), VARIANT(8, 8, 16, 2048, 16, 1),
+  VARIANT(4, 4, 4, 1024, 8, 1),  VARIANT(2, 6, 8, 1024, 8, 1),  VARIANT(4, 8, 8, 1024, 8, 1),  VARIANT(4, 12, 8, 1024, 8, 1),
+  // timing experiments (wrong results by construction): what each part of a step costs
+  VARIANT_DBG(4, 8, 4, 2048, 8, 1), VARIANT_DBG(4, 8, 4, 2048, 8, 2), VARIANT_DBG(4, 8, 4, 2048, 8, 3), VARIANT_DBG(4, 8, 4, 2048, 8, 4), VARIANT_DBG(4, 8, 4, 2048, 8, 8),
+  VARIANT_DBG(4, 8, 4, 2048, 8, 12), VARIANT_DBG(4, 8, 4, 2048, 8, 16), VARIANT_DBG(4, 8, 4, 2048, 8, 28), VARIANT_DBG(4, 8, 4, 2048, 8, 31), VARIANT_DBG(4, 8, 4, 2048, 8, 15),
 };
-static const Variant* find_variant(int LW, int CW, int D, int SW)
+static const Variant* find_variant(int LW, int CW, int D, int SW, int P, int XM, int AT)
 {
   for (const auto& v : kVariants)
-    if (v.LW == LW && v.CW == CW && v.D == D && v.SW == SW) return &v;
+    if (v.LW == LW && v.CW == CW && v.D == D && v.SW == SW && v.P == P && v.XM == XM && v.atomic == AT) return &v;
   return nullptr;
 }
 
 int main(int argc, char** argv)
 {
   std::setvbuf(stdout, nullptr, _IONBF, 0);
-  if (argc < 2) { std::printf("usage: %s <dir> [NP S SW LW CW D [reps]]\n", argv[0]); return 2; }
+  if (argc < 2) { std::printf("usage: %s <dir> [NP S SW LW CW D P XM atomic [reps]]\n", argv[0]); return 2; }
   const std::string dir = argv[1];
   int m = 0, n = 0;
   {
@@ -394,33 +502,37 @@ int main(int argc, char** argv)
   hipEvent_t ev[6];
   for (auto& v : ev) OK(hipEventCreate(&v));
   std::printf("tall row panels with LDS accumulators x column ranges, x slabs streamed coalesced into LDS: %d x %d, %zu nonzeros\n", m, n, idx[0].size());
-  std::printf("%4s %2s %5s %2s %2s %2s | %6s %7s %8s %8s | %9s %9s %9s %9s | %9s | %s\n", "NP", "S", "SW", "LW", "CW", "D", "R", "LDS KB", "pads", "dup ent", "A us", "comb us", "AT us", "comb us",
-              "pair us", "max rel err (A, AT)");
-  struct Cfg { int NP, S, SW, LW, CW, D; };
+  std::printf("%4s %2s %5s %2s %2s %2s %2s %2s %2s | %6s %7s %8s %8s | %9s %9s %9s %9s | %9s | %s\n", "NP", "S", "SW", "LW", "CW", "D", "P", "XM", "at", "R", "LDS KB", "pads", "dup ent", "A us",
+              "comb us", "AT us", "comb us", "pair us", "max rel err (A, AT)");
+  struct Cfg { int NP, S, SW, LW, CW, D, P, XM, AT; };
   std::vector<Cfg> cfgs;
   int reps = 20;
-  if (argc >= 8) {
-    cfgs.push_back({std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), std::atoi(argv[7])});
-    if (argc >= 9) reps = std::atoi(argv[8]);
+  const int rot = std::getenv("TALL_ROT") ? std::atoi(std::getenv("TALL_ROT")) : 0;
+  std::printf("slab walk of the workgroups of an XCD: %s\n", rot ? "staggered (TALL_ROT=1)" : "in lockstep from slab 0");
+  if (argc >= 11) {
+    cfgs.push_back({std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]), std::atoi(argv[8]), std::atoi(argv[9]), std::atoi(argv[10])});
+    if (argc >= 12) reps = std::atoi(argv[11]);
   } else {
-    cfgs = {{64, 4, 2048, 4, 12, 3}, {64, 4, 2048, 4, 12, 2}, {64, 4, 2048, 4, 12, 4}, {64, 4, 2048, 4, 4, 3}, {64, 4, 2048, 4, 8, 3}, {64, 4, 2048, 2, 6, 3},
-            {64, 4, 2048, 8, 8, 3}, {64, 4, 2048, 2, 14, 3}, {64, 4, 1024, 4, 12, 3}, {64, 4, 1024, 4, 12, 6}, {64, 4, 1024, 2, 14, 6}, {64, 4, 1024, 2, 6, 4},
-            {128, 2, 2048, 4, 12, 3}, {128, 2, 2048, 4, 4, 3}, {128, 4, 1024, 2, 6, 4}, {128, 4, 1024, 1, 7, 4}, {128, 4, 512, 1, 7, 8}, {128, 4, 512, 2, 6, 8},
-            {128, 2, 1024, 2, 6, 4}};
+    const bool dbg = std::getenv("TALL_DBG") != nullptr;
+    for (const auto& v : kVariants) {
+      if ((v.atomic >= 100) != dbg) continue;
+      if (v.SW == 2048) cfgs.push_back({64, 4, v.SW, v.LW, v.CW, v.D, v.P, v.XM, v.atomic});
+      else cfgs.push_back({128, 4, v.SW, v.LW, v.CW, v.D, v.P, v.XM, v.atomic}), cfgs.push_back({64, 4, v.SW, v.LW, v.CW, v.D, v.P, v.XM, v.atomic});
+    }
   }
   for (const Cfg& c : cfgs) {
-    const Variant* var = find_variant(c.LW, c.CW, c.D, c.SW);
-    if (!var) { std::printf("no kernel instance for LW %d CW %d D %d SW %d\n", c.LW, c.CW, c.D, c.SW); continue; }
+    const Variant* var = find_variant(c.LW, c.CW, c.D, c.SW, c.P, c.XM, c.AT);
+    if (!var) { std::printf("no kernel instance for LW %d CW %d D %d SW %d P %d XM %d atomic %d\n", c.LW, c.CW, c.D, c.SW, c.P, c.XM, c.AT); continue; }
     TallHost H[2];
     TallDev Dv[2];
     bool ok = true;
     for (int t = 0; t < 2 && ok; ++t) {
-      ok = build_tall(rows[t], cols[t], off[t], idx[t], val[t], c.NP, c.S, c.SW, c.D, 2 * c.CW + 2, &H[t]);
+      ok = build_tall(rows[t], cols[t], off[t], idx[t], val[t], c.NP, c.S, c.SW, c.D, c.P, c.CW, rot, &H[t]);
       if (ok) upload(H[t], &Dv[t]);
-      if (ok && ((size_t)c.S * H[t].V.CWID + (size_t)(c.D + 1) * c.SW > vec_pad)) ok = false;
+      if (ok && ((size_t)c.S * H[t].V.CWID + (size_t)c.SW > vec_pad)) ok = false;
     }
     if (!ok || Dv[0].lds_bytes > 163840 || Dv[1].lds_bytes > 163840) {
-      std::printf("%4d %2d %5d %2d %2d %2d | not representable (R %d, LDS %zu B)\n", c.NP, c.S, c.SW, c.LW, c.CW, c.D, H[0].V.R, Dv[0].lds_bytes);
+      std::printf("%4d %2d %5d %2d %2d %2d %2d %2d %2d | not representable (R %d, LDS %zu B)\n", c.NP, c.S, c.SW, c.LW, c.CW, c.D, c.P, c.XM, c.AT, H[0].V.R, Dv[0].lds_bytes);
       for (int t = 0; t < 2; ++t) release(&Dv[t]);
       continue;
     }
@@ -482,9 +594,9 @@ int main(int argc, char** argv)
         }
       if (r >= 0) { float ms = 0; OK(hipEventElapsedTime(&ms, ev[0], ev[4])); us[4] += 1e3 * ms; }
     }
-    std::printf("%4d %2d %5d %2d %2d %2d | %6d %7.1f %8lld %8lld | %9.1f %9.1f %9.1f %9.1f | %9.1f | %.2e %.2e %s  (build %.1f s, max cell %lld, NS %d, G %d)\n", c.NP, c.S, c.SW, c.LW,
-                c.CW, c.D, H[0].V.R, lds / 1024.0, H[0].pads + H[1].pads, H[0].dup_entries + H[1].dup_entries, us[0] / reps, us[1] / reps, us[2] / reps, us[3] / reps,
-                us[4] / reps / 2, err[0], err[1], same ? "repro" : "NOT REPRODUCIBLE", H[0].build_s + H[1].build_s, std::max(H[0].max_cell, H[1].max_cell), H[0].V.NS, H[0].V.G);
+    std::printf("%4d %2d %5d %2d %2d %2d %2d %2d %2d | %6d %7.1f %8lld %8lld | %9.1f %9.1f %9.1f %9.1f | %9.1f | %.2e %.2e %s  (build %.1f s, max cell %lld, split steps %lld, NS %d, G %d)\n", c.NP, c.S, c.SW, c.LW,
+                c.CW, c.D, c.P, c.XM, c.AT, H[0].V.R, lds / 1024.0, H[0].pads + H[1].pads, H[0].dup_entries + H[1].dup_entries, us[0] / reps, us[1] / reps, us[2] / reps, us[3] / reps,
+                us[4] / reps / 2, err[0], err[1], same ? "repro" : "NOT REPRODUCIBLE", H[0].build_s + H[1].build_s, std::max(H[0].max_cell, H[1].max_cell), H[0].split_steps + H[1].split_steps, H[0].V.NS, H[0].V.G);
     for (int t = 0; t < 2; ++t) release(&Dv[t]);
   }
   std::printf("(times: hipEvent pairs around single launches inside the touch -> A -> combine -> A^T -> combine sequence; 'pair' = (A + comb + AT + comb) / 2;\n"
