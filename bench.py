@@ -249,6 +249,174 @@ def batch_line(args, p, cfg, K, local_rank, record_fd, t_gen):
     os.write(record_fd, (json.dumps(out) + "\n").encode())
 
 
+def small_batch_line(args, K, local_rank, record_fd):
+    """--workload c5_batch<K>: BASELINE config 5 at branch-and-bound scale.  K copies of the 50v-10 LP relaxation (datasets/mip/
+    50v-10-free-bound.mps, 233 x 2013, 2745 nonzeros: tests/golden/problems.json) are K open nodes of a branch-and-bound tree: every
+    round tightens, in each node, the bound of one integer variable that the node's relaxation left fractional (down-branch in even
+    nodes, up-branch in odd ones) and re-solves from the previous primal / dual -- cpp/src/mip/relaxed_lp/relaxed_lp.cu:74-108.  The K
+    persistent solvers advance as ONE small-LP batch (cuoptamd_batch_* over resident solvers: a workgroup per LP, one launch per phase
+    of the loop).  value = aggregate PDLP iterations/s inside the batch's advance calls; lps_per_sec = re-solves per second for the
+    whole pipeline (reset + advance + solution read-back).  Beside it: the same re-solves through a pool of 16 host threads, one
+    solver and one stream each (what cuoptamd_batch_solve did before round 6), and the reference's dual simplex (1 thread)."""
+    import concurrent.futures
+    import ctypes as C
+    from cuopt_amd import capi
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "problems.json")))["mip-50v-10-free-bound-relaxation"]
+    dec = lambda v: np.array([np.inf if x == "inf" else -np.inf if x == "-inf" else x for x in v], dtype=np.float64)
+    base = dict(m=gold["m"], n=gold["n"], offsets=np.array(gold["offsets"], np.int32), indices=np.array(gold["indices"], np.int32),
+                values=dec(gold["values"]), c=dec(gold["c"]), lo=dec(gold["lo"]), hi=dec(gold["hi"]), lb=dec(gold["lb"]), ub=dec(gold["ub"]),
+                maximize=bool(gold["maximize"]), objective_offset=float(gold["objective_offset"]))
+    integer = np.array([t == "I" for t in gold["var_types"]])
+    m, n, nnz = base["m"], base["n"], int(len(base["values"]))
+    rounds, limit = 6, 4000
+    kw = dict(mode=1, device=local_rank, iteration_limit=limit)
+
+    def make(count, share_stream):
+        out = []
+        for i in range(count):
+            if share_stream and out:
+                capi.lib.pdlpdev_create_share_stream(C.c_void_p(capi.lib.cuoptamd_solver_device(out[0].handle)))
+            out.append(capi.Solver(base, **kw))
+        capi.lib.pdlpdev_create_share_stream(None)
+        return out
+
+    def branch(l, lb, ub, x, rng):
+        """the node's next child: an integer variable with a fractional relaxation value (a random integer one when all are integral)"""
+        frac = np.abs(x - np.round(x))
+        cand = np.flatnonzero(integer & (frac > 1e-3) & (ub - lb >= 1.0))
+        if len(cand) == 0:
+            cand = np.flatnonzero(integer & (ub - lb >= 1.0))
+        if len(cand) == 0:
+            return
+        j = int(rng.choice(cand))
+        if l % 2 == 0:
+            ub[j] = max(np.floor(x[j]), lb[j])
+        else:
+            lb[j] = min(np.ceil(x[j]), ub[j])
+
+    def run(solvers, advance_all, label, batch=None, executor=None):
+        """the node sequence through `solvers`; advance_all(list of solvers) -> list of results.  Same seeds, same branches.  batch: resets
+        and solution read-backs go through the batch's one-launch calls (cuoptamd_batch_reset / cuoptamd_batch_get_solutions)."""
+        rng = np.random.default_rng(17)
+        k = len(solvers)
+        lbs, ubs = [base["lb"].copy() for _ in range(k)], [base["ub"].copy() for _ in range(k)]
+        prev = [None] * k
+        t = dict(reset=0.0, advance=0.0, solution=0.0)
+        its, statuses, objs = 0, {}, []
+        for r in range(rounds + 1):  # round 0: the root relaxation in every node (cold)
+            t0 = time.perf_counter()
+            if r and executor is not None:  # the pool's way: every worker takes a node through reset, solve and read-back on its own
+                for l in range(k):
+                    branch(l, lbs[l], ubs[l], prev[l][0], rng)
+
+                def node(l):
+                    solvers[l].reset(lb=lbs[l], ub=ubs[l], init_x=prev[l][0], init_y=prev[l][1])
+                    return solvers[l].advance(), solvers[l].solution()
+                t1 = time.perf_counter()
+                both = list(executor.map(node, range(k)))
+                rs, prev = [q[0] for q in both], [q[1] for q in both]
+                t2 = t3 = time.perf_counter()
+                t["reset"] += t1 - t0
+                t["advance"] += t2 - t1
+                its += sum(q["steps_taken"] for q in rs)
+                for q in rs:
+                    statuses[q["status_name"]] = statuses.get(q["status_name"], 0) + 1
+                objs.append([q["primal_objective"] for q in rs])
+                continue
+            if r:
+                for l, s in enumerate(solvers):
+                    branch(l, lbs[l], ubs[l], prev[l][0], rng)
+                    if batch is None:
+                        s.reset(lb=lbs[l], ub=ubs[l], init_x=prev[l][0], init_y=prev[l][1])
+                if batch is not None:
+                    batch.reset(lb=lbs, ub=ubs, init_x=[v[0] for v in prev], init_y=[v[1] for v in prev])
+            t1 = time.perf_counter()
+            rs = advance_all(solvers)
+            t2 = time.perf_counter()
+            if batch is not None:
+                prev = batch.solutions()
+            else:
+                for l, s in enumerate(solvers):
+                    prev[l] = s.solution()
+            t3 = time.perf_counter()
+            if r:  # the re-solves are what is measured
+                t["reset"] += t1 - t0
+                t["advance"] += t2 - t1
+                t["solution"] += t3 - t2
+                its += sum(q["steps_taken"] for q in rs)
+                for q in rs:
+                    statuses[q["status_name"]] = statuses.get(q["status_name"], 0) + 1
+                objs.append([q["primal_objective"] for q in rs])
+        total = sum(t.values())
+        return dict(label=label, lps=k * rounds, iterations=its, seconds={a: round(b, 4) for a, b in t.items()}, lps_per_sec=round(k * rounds / total, 1),
+                    lps_per_sec_advance_only=round(k * rounds / t["advance"], 1), its_per_sec_advance=round(its / t["advance"], 1), statuses=statuses), objs, (lbs, ubs)
+
+    t0 = time.perf_counter()
+    solvers = make(K, True)
+    batch = capi.SmallBatch(solvers)
+    create_s = time.perf_counter() - t0
+    layout = solvers[0].device.layout()
+    run(solvers[:], lambda ss: batch.advance(), "warm-up", batch)  # clocks, code objects, the allocator's pools
+    batch.reset(lb=[base["lb"]] * K, ub=[base["ub"]] * K)
+    got, objs, (lbs, ubs) = run(solvers, lambda ss: batch.advance(), "small-LP batch: %d workgroups per launch" % K, batch)
+    batch.close()
+    for s in reversed(solvers):
+        s.close()
+    # ---- the same node sequences through a pool of host threads (one solver + one stream per LP; 16 threads)
+    kp = min(K, 64)
+    pool_solvers = make(kp, False)
+    ex = concurrent.futures.ThreadPoolExecutor(max_workers=16)
+    adv = lambda ss: list(ex.map(lambda s: s.advance(), ss))
+    run(pool_solvers, adv, "warm-up")
+    for s in pool_solvers:
+        s.reset(lb=base["lb"], ub=base["ub"])
+    pool, pobjs, _ = run(pool_solvers, adv, "thread pool: 16 host threads over %d solvers (one stream each); a worker takes a node through reset, solve and read-back "
+                         "('advance' = all three, 'reset' = choosing the branches)" % kp, executor=ex)
+    ex.shutdown()
+    for s in pool_solvers:
+        s.close()
+    same = all(a[:kp] == b for a, b in zip(objs, pobjs))
+    # ---- the reference's dual simplex (oracle/_ref, 1 thread) on a bounded sample of the LAST round's nodes (cold: it has no warm start here)
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import refbind
+            if refbind.available():
+                t0, cnt = time.perf_counter(), 0
+                for l in range(min(K, 24)):
+                    refbind.dual_simplex(dict(base, lb=lbs[l], ub=ubs[l]), time_limit=20.0)
+                    cnt += 1
+                    if time.perf_counter() - t0 > 20.0:
+                        break
+                dt = time.perf_counter() - t0
+                cpu = dict(value=round(cnt / dt, 2), unit="LP relaxations/s", cores=1, kind="reference",
+                           sample="cpp/src/dual_simplex compiled in place (oracle/_ref), 1 thread, cold solves of %d nodes of the last round: %.2f s" % (cnt, dt))
+        except Exception as e:
+            cpu = dict(error=repr(e))
+    info = capi.device_info(local_rank)
+    bytes_iter = 24 * nnz + 4 * (m + n + 2) + 8 * (14 * n + 7 * m)
+    eq = bytes_iter * got["its_per_sec_advance"] / 1e9
+    out = {
+        "metric": "pdlp_iterations_per_sec", "value": got["its_per_sec_advance"], "unit": "iterations/s (aggregate over %d LPs, inside the batch's advance calls)" % K,
+        "lps_per_sec": got["lps_per_sec"], "lps_per_sec_unit": "warm-started re-solves to 1e-4 per second, whole pipeline (reset + advance + solution read-back)",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "timed_steps": got["iterations"], "ms_per_step": round(1e3 * got["seconds"]["advance"] / max(got["iterations"], 1), 6),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "datasets/mip/50v-10-free-bound.mps (LP relaxation; tests/golden/problems.json)",
+        "config": {"workload": "%s: %d branch-and-bound nodes of the 50v-10 LP relaxation (233 x 2013, 2745 nonzeros), %d rounds of one bound tightening per node + warm-started "
+                               "re-solve to the default 1e-4 (iteration limit %d), Stable2 preset; persistent solvers, one small-LP batch" % (args.workload, K, rounds, limit),
+                   "rows": m, "cols": n, "nnz": nnz, "lps": K, "rounds": rounds, "parallelism": "single GPU, %d LPs in %d workgroups per launch" % (K, K)},
+        "batch": got, "thread_pool": pool, "batch_over_thread_pool_lps_per_sec": round(got["lps_per_sec"] / pool["lps_per_sec"], 2),
+        "batch_over_thread_pool_advance_only": round(got["lps_per_sec_advance_only"] / pool["lps_per_sec_advance_only"], 2),
+        "same_objectives_as_the_thread_pool": same, "create_seconds_per_lp": round(create_s / K, 5),
+        "roofline": dict(bound="hbm", kernel="k_pdhg_resident_batch", achieved=round(eq, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(eq / HBM_PEAK_GBS, 5), traffic=None,
+                         note="the LP lives in registers and LDS of its workgroup: NOTHING is re-read from HBM inside the loop, so the HBM roofline does not bound this kernel -- "
+                              "`achieved` is what a streaming implementation would have to move for the same iterations (fused floor %d B per iteration per LP); the loop is bound by "
+                              "LDS / barrier latency: 5 barriers and ~13 dependent phases per attempt (DESIGN 4b)" % bytes_iter),
+        "cpu_baseline": cpu, "spmv_layout": layout, "device": info["name"], "compute_units": info["compute_units"],
+    }
+    sys.stdout.flush()
+    os.write(record_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record: libraries loaded below write banners to file descriptor 1 (RCCL prints its
     # version block there when the first communicator is created), so everything else is sent to stderr
@@ -260,7 +428,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
-                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c5_batch256", "c5_batch64", "c5_batch1024", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -339,6 +507,11 @@ def main():
 
     comm_id = fresh_comm_id()
 
+    if args.workload.startswith("c5_batch"):
+        if world != 1:
+            sys.exit("bench.py: the small-LP batch runs on one GPU")
+        small_batch_line(args, int(args.workload[len("c5_batch"):]), local_rank, record_fd)
+        return
     shuffle = args.workload.endswith("_shuffled")
     base = args.workload[:-len("_shuffled")] if shuffle else args.workload
     batch_k = int(base.split("_batch")[1]) if "_batch" in base else 0

@@ -304,7 +304,11 @@ _proto("cuoptamd_solver_clone", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c
 _proto("cuoptamd_batch_create", c_int, c_void_p, c_int, P(c_void_p))
 _proto("cuoptamd_batch_advance", c_int, c_void_p, c_int, c_void_p)
 _proto("cuoptamd_batch_destroy", None, c_void_p)
+_proto("cuoptamd_batch_reset", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuoptamd_batch_get_solutions", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_batch_device", c_void_p, c_void_p)
+_proto("pdlpdev_create_share_stream", None, c_void_p)
+_proto("pdlpdev_resident_size", c_int, c_int, c_int, C.c_int64)
 _proto("pdlpdev_batch_time_kernels", c_int, c_void_p, c_int, c_void_p)
 _proto("pdlpdev_synthetic_lp", c_int, c_int, c_int, c_int, c_int, C.c_uint64, *([c_void_p] * 8))
 
@@ -754,8 +758,9 @@ class Solver:
 
 class SharedMatrixBatch:
     """cuoptamd_batch: K = 2, 4, 8 or 16 Solvers over ONE matrix (a parent and its clones) advance in lockstep, the matrix streamed once
-    per attempt for all of them; every LP's trajectory is bit-identical to its own Solver.advance.  CuOptError(-7) when the layouts
-    are not eligible (the caller then advances the solvers one by one)."""
+    per attempt for all of them -- or (round 6) ANY number of Solvers on the resident small-LP path, whatever their matrices, one
+    workgroup each in one launch per phase; every LP's trajectory is bit-identical to its own Solver.advance.  CuOptError(-7) when
+    the solvers are eligible for neither (the caller then advances them one by one)."""
 
     def __init__(self, solvers):
         self.solvers = list(solvers)
@@ -779,6 +784,40 @@ class SharedMatrixBatch:
             out.append(s.result.as_dict())
         return out
 
+    def reset(self, lb=None, ub=None, init_x=None, init_y=None):
+        """cuoptamd_batch_reset: per solver new variable bounds and / or a start (lists of arrays or None, entries may be None), one
+        launch for all of them; afterwards every solver is what Solver.reset(lb=, ub=, init_x=, init_y=) would have made it"""
+        k = len(self.solvers)
+        keep = []
+
+        def ptrs(vs):
+            if vs is None:
+                return None
+            arr = (c_void_p * k)()
+            for i, v in enumerate(vs):
+                if v is not None:
+                    a = _f64(v)
+                    keep.append(a)
+                    arr[i] = a.ctypes.data
+            return arr
+        rc = lib.cuoptamd_batch_reset(self.handle, ptrs(lb), ptrs(ub), ptrs(init_x), ptrs(init_y))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        for s in self.solvers:
+            s.result = Result()
+
+    def solutions(self):
+        """cuoptamd_batch_get_solutions: [(x, y, reduced costs)] of every solver, one launch"""
+        k = len(self.solvers)
+        xs = [np.zeros(s.n) for s in self.solvers]
+        ys = [np.zeros(s.m) for s in self.solvers]
+        zs = [np.zeros(s.n) for s in self.solvers]
+        arr = lambda vs: (c_void_p * k)(*[v.ctypes.data for v in vs])
+        rc = lib.cuoptamd_batch_get_solutions(self.handle, arr(xs), arr(ys), arr(zs))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        return list(zip(xs, ys, zs))
+
     def time_kernels(self, reps=20):
         """average dispatch time (ms) of the four kernels of a batched attempt: dict primal / a_dual / at_step / decisions"""
         out = np.zeros(4)
@@ -797,6 +836,9 @@ class SharedMatrixBatch:
             self.close()
         except Exception:
             pass
+
+
+SmallBatch = SharedMatrixBatch  # (the same cuoptamd_batch object; the name the small-LP tests and bench use)
 
 
 def batch_solve(problems, mode=1, max_threads=0, device=0, **setting_overrides):

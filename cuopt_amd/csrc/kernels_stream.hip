@@ -59,6 +59,22 @@ k_spmv_at_cur(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict_
   csr_stream_block(nb, rb, off, idx, val, cur ? y1 : y0, e, nullptr, dadd);
 }
 
+// the same for several contexts in one launch (the small-LP batch, kernels_resident.hip)
+__global__ void __launch_bounds__(kBlock) k_spmv_at_cur_batch(const StreamAtCurArgs* __restrict__ args, const int2* __restrict__ blk)
+{
+  const int2 b            = blk[blockIdx.x];
+  const StreamAtCurArgs A = args[b.x];
+  const int cur           = A.ctl->cur;
+  StoreEpilogue e{cur ? A.aty1 : A.aty0};
+  csr_stream_block(A.nb, A.rb, A.off, A.idx, A.val, cur ? A.y1 : A.y0, e, nullptr, nullptr, b.y);
+}
+int launch_stream_at_cur_batch(hipStream_t s, const StreamAtCurArgs* args, const int2* blk, int blocks)
+{
+  k_spmv_at_cur_batch<<<blocks, kBlock, 0, s>>>(args, blk);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_eval_primal(int nb, const int32_t* __restrict__ rb, const int32_t* __restrict__ off,
               const int32_t* __restrict__ idx, const double* __restrict__ val,

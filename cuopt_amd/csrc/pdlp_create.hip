@@ -22,6 +22,9 @@ extern "C" {
 
 const char* pdlpdev_last_error(void) { return g_err.c_str(); }
 void pdlpdev_create_hint(int sharded) { g_create_sharded = sharded; }
+static thread_local pdlpdev_ctx* g_create_stream_donor = nullptr;
+void pdlpdev_create_share_stream(pdlpdev_ctx* donor) { g_create_stream_donor = donor; }
+int pdlpdev_resident_size(int32_t m, int32_t n, int64_t nnz) { return resident_tier(m, n, nnz) >= 0 ? 1 : 0; }
 
 int pdlpdev_device_count(void)
 {
@@ -111,6 +114,13 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
       ctx->stream = an->stream, ctx->scal_h = an->pinned, ctx->arena = an->chunk, ctx->first_chunk = an->chunk;
       an->bundle_owned = false;
       HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
+    } else if (g_create_stream_donor && g_create_stream_donor->device == device) {  // pdlpdev_create_share_stream
+      ctx->stream = g_create_stream_donor->stream, ctx->stream_borrowed = true;
+      g_create_stream_donor = nullptr;
+      HIP_TRY(hipHostMalloc((void**)&ctx->scal_h, kScalars * sizeof(double) + sizeof(pdlpdev_ctl)));
+      HIP_TRY(hipMalloc((void**)&ctx->arena, kArenaChunk));
+      HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
+      ctx->first_chunk = ctx->arena;
     } else if (take_recycled(device, &r)) {
       ctx->stream = r.stream, ctx->scal_h = r.pinned, ctx->arena = r.chunk, ctx->first_chunk = r.chunk;
       HIP_TRY(hipMemsetAsync(ctx->arena, 0, kArenaChunk, ctx->stream));
@@ -620,11 +630,11 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (ctx->p2p.base) (void)hipFree(ctx->p2p.base);
   if (ctx->comm && !ctx->soft) comm_cache::release(ctx->comm_key);
   for (void* p : ctx->allocs) (void)hipFree(p);
-  const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk && !ctx->shared_with_parent;
+  const bool whole = ctx->stream && ctx->scal_h && ctx->first_chunk && !ctx->shared_with_parent && !ctx->stream_borrowed;
   if (!(whole && give_recycled(Recycled{ctx->device, ctx->stream, ctx->scal_h, ctx->first_chunk}))) {
     if (ctx->first_chunk) (void)hipFree(ctx->first_chunk);
     if (ctx->scal_h) (void)hipHostFree(ctx->scal_h);  // ctl_h lives in the same block
-    if (ctx->stream && !ctx->shared_with_parent) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream && !ctx->shared_with_parent && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
 }

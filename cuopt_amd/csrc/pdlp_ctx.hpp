@@ -469,6 +469,7 @@ struct pdlpdev_ctx {
   size_t slab_cap = 0, slab_used = 0;
   char* arena = nullptr;  // current small-buffer chunk (dev_alloc)
   char* first_chunk = nullptr;  // recycled with the stream, not in `allocs`
+  bool stream_borrowed = false; // pdlpdev_create_share_stream: the stream is another context's
   size_t arena_used = 0;
   bool small_resident = false;  // whole attempt batches inside one workgroup (k_pdhg_small)
   bool shared_with_parent = false;  // pdlpdev_clone_shared: matrices, layouts, scaling vectors, c and the stream are another context's
@@ -498,6 +499,23 @@ constexpr int kScalars       = 64;
 // Streams (an HSA queue each: ~2 ms to create), the pinned read-back block and the first arena chunk are handed from
 // a destroyed context to the next one created on the same device: back-to-back small solves (cuOptSolve in a loop,
 // MIP-style re-solves) otherwise spend more time in these three calls than in PDHG.  Never freed (a few per device).
+// hipFuncSetAttribute is per device and must happen before the first launch that asks for > 64 KiB of LDS:
+// one flag per (kernel instantiation, device), taken under a lock (batch solves create contexts from many threads)
+struct PerDeviceOnce {
+  std::mutex m;
+  bool done[64] = {};
+  template <class F>
+  int run(int device, F&& f)
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (device < 0 || device >= 64) return f();
+    if (done[device]) return 0;
+    const int rc = f();
+    if (rc == 0) done[device] = true;
+    return rc;
+  }
+};
+
 struct Recycled {
   int device;
   hipStream_t stream;

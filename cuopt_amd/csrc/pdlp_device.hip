@@ -267,25 +267,12 @@ __global__ void __launch_bounds__(kBlock) k_dot(int64_t n, const double* __restr
   block_reduce<SumOp, 1>(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
 }
-// out[dst + q] = reduce(part[q*nb .. q*nb+nb)) ; op_mask bit q set => max
+// out[q] = reduce(part[q*nb .. q*nb+nb)) ; op_mask bit q set => max
 __global__ void __launch_bounds__(kBlock) k_finalize(const double* __restrict__ part, int nb, int nq,
                                                      unsigned op_mask, double* __restrict__ out)
 {
   __shared__ double red[8];
-  for (int q = 0; q < nq; ++q) {
-    const bool is_max = (op_mask >> q) & 1u;
-    double acc[1] = {0.0};
-    for (int i = threadIdx.x; i < nb; i += kBlock) {
-      const double v = part[(size_t)q * nb + i];
-      acc[0] = is_max ? (v > acc[0] ? v : acc[0]) : acc[0] + v;
-    }
-    if (is_max)
-      block_reduce<MaxOp, 1>(acc, red);
-    else
-      block_reduce<SumOp, 1>(acc, red);
-    if (threadIdx.x == 0) out[q] = acc[0];
-    __syncthreads();
-  }
+  finalize_rows(part, nb, nq, op_mask, out, red);
 }
 
 // ================================================================================================
@@ -354,58 +341,6 @@ k_step_stats(int n, int nbg, const pdlpdev_ctl* __restrict__ ctl, const double* 
   if (threadIdx.x == 0) {
     part[blockIdx.x]       = acc[0];
     part[nbg + blockIdx.x] = acc[1];
-  }
-}
-
-// (4) one workgroup: finish the three reductions in a fixed order, then the scalar logic of
-//     compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188),
-//     the accept/flip of update_solution (pdhg.cu:237-250) and add_weight_sums
-//     (weighted_average_solution.cu:63-71).
-// The scalar rule of compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188) +
-// the accept/flip of update_solution (pdhg.cu:237-250) + add_weight_sums (weighted_average_solution.cu:63-71).
-// One thread.
-// `pw` (optional): pow(k + 2, -reduction_exponent), pow(k + 2, -growth_exponent) for the k the attempt
-// started with, computed off the critical path by the caller.
-__device__ __forceinline__ void apply_step_decision(pdlpdev_ctl* ctl, double dy2, double interaction, double dx2,
-                                                    const pdlpdev_step_params& sp, const double* pw = nullptr)
-{
-  const double w = ctl->primal_weight;
-  double step    = ctl->step_size;
-  const double movement = sp.primal_distance_smoothing * w * dx2 + (sp.dual_distance_smoothing / w) * dy2;
-  ctl->last_interaction = interaction;
-  ctl->last_movement    = movement;
-  ctl->last_dx2         = dx2;
-  ctl->last_dy2         = dy2;
-  ctl->attempts += 1;
-  bool accepted;
-  // pdlp_constants.hpp:39-47 (movement <= 0 or >= 1e100), written so that a NaN -- which the reference's comparisons let through
-  // into an endless series of rejected steps -- takes the same "invalid step size" exit (-> NumericalError at the next check)
-  if (!(movement > 0.0) || !(movement < 1.0e100) || interaction != interaction) {
-    // reference: flag -1, k and eta untouched; take_step still averages and swaps
-    // (pdlp.cu:1193-1221) and the next loop trip is forced to be a major iteration.
-    ctl->error = 1;
-    accepted   = true;
-  } else {
-    const double inter = fabs(interaction);
-    ctl->k += 1;
-    const double kc    = (double)ctl->k;
-    const double limit = inter > 0.0 ? movement / inter : __builtin_huge_val();
-    accepted           = step <= limit;
-    const double s1    = (1.0 - (pw ? pw[0] : pow(kc + 1.0, -sp.reduction_exponent))) * limit;
-    const double s2    = (1.0 + (pw ? pw[1] : pow(kc + 1.0, -sp.growth_exponent))) * step;
-    step               = dmin(s1, s2);
-    ctl->step_size     = step;
-    ctl->tau           = step / w;
-    ctl->sigma         = step * w;
-  }
-  if (accepted) {
-    ctl->cur ^= 1;
-    ctl->pending_avg = 1;
-    ctl->sum_weights += step;  // the ALREADY UPDATED step size (pdlp.cu:1216-1220)
-    ctl->steps_taken += 1;
-    ctl->its_since_restart += 1;
-  } else {
-    ctl->pending_avg = 0;
   }
 }
 
@@ -498,224 +433,6 @@ k_step_decision_p2p(pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ pa
   apply_step_decision(&lc, sum[0], sum[1], sum[2], sp);
   *ctl = lc;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Small LPs (MIP-style repeated re-solves, BASELINE config 5): the whole batch of PDHG attempts between two
-// major iterations runs inside ONE workgroup, with the LP on chip.  At this size a 4-launch attempt is pure
-// launch latency (~15 us) and even L2 round trips (3-4 dependent ones per phase) cost more than the arithmetic,
-// so nothing is re-read from memory inside the loop:
-//   * lane t keeps nonzeros t, t+T, ... of A and of A^T (value + column) in registers;
-//   * lane t owns rows / columns t, t+T, ...: their CSR extents and every per-element vector
-//     (x, A^T y, c, bounds, running sums ...) live in its registers;
-//   * the two gathered vectors (xbar, y'), the nonzero products and the constant vectors (c, bounds) sit in LDS.
-// Products are val * vec[col] and every row is added up by its owner in CSR order, so x', y', A^T y' are
-// bit-identical to the multi-launch kernels (and the oracle); the three step-size sums use a different,
-// fixed reduction tree.  T lanes, Q elements and U nonzeros per lane: m, n <= Q*T, nnz <= U*T.
-// ------------------------------------------------------------------------------------------------
-struct SmallView {
-  int m, n, nnz;
-  const int32_t *a_off, *a_idx, *at_off, *at_idx;
-  const double *a_val, *at_val, *c, *lb, *ub, *lo, *hi;
-  double *x0, *x1, *y0, *y1, *aty0, *aty1, *sumx, *sumy;
-};
-// prod[a..b) added up strictly left to right; eight LDS reads are in flight before the first add
-__device__ __forceinline__ double lds_row_sum(const double* prod, int a, int b)
-{
-  double acc = 0.0;
-  for (int k = a; k < b; k += 8) {
-    double p[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = prod[k + i < b ? k + i : a];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc = k + i < b ? acc + p[i] : acc;
-  }
-  return acc;
-}
-template <int T, int Q, int U>
-__global__ void __launch_bounds__(T)
-k_pdhg_resident(SmallView V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_ctl* __restrict__ ctl_host, pdlpdev_step_params sp,
-                int target_steps, int max_attempts)
-{
-  extern __shared__ double lds[];
-  double* xbar_s = lds;               // Q*T
-  double* yn_s   = xbar_s + Q * T;    // Q*T
-  double* c_s    = yn_s + Q * T;      // constants, read with stride 1 by their owners
-  double* lb_s   = c_s + Q * T;
-  double* ub_s   = lb_s + Q * T;
-  double* lo_s   = ub_s + Q * T;
-  double* hi_s   = lo_s + Q * T;
-  double* prod   = hi_s + Q * T;      // U*T
-  // two sets (attempt parity) of cross-wave partials: a wave may start the next attempt's reduction while a slower
-  // one still reads this attempt's table -- the barriers in between only order the *other* buffers
-  __shared__ double red[2][3 * 16];
-  __shared__ double pw[2][2];  // the two powers of the step-size rule, computed by the last wave while rows are summed
-  const int t = threadIdx.x;
-  // Every lane keeps its own copy of the control block and repeats the (uniform) step decision: no broadcast
-  // through LDS and no barrier between the reduction and the next primal step.
-  pdlpdev_ctl lc = *ctl;
-  lc.target_steps = target_steps;
-  double a_val[U], at_val[U];
-  int a_col[U], at_col[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int k  = t + u * T;
-    const bool in = k < V.nnz;
-    a_val[u]  = in ? V.a_val[k] : 0.0;
-    a_col[u]  = in ? V.a_idx[k] : 0;
-    at_val[u] = in ? V.at_val[k] : 0.0;
-    at_col[u] = in ? V.at_idx[k] : 0;
-  }
-  const int cur0 = lc.cur;
-  int r0[Q], r1[Q], c0[Q], c1[Q];  // CSR extents of the owned rows of A and of A^T (empty when out of range)
-  double x[Q], xn[Q], aty[Q], atyn[Q], sumx[Q], y[Q], yn[Q], sumy[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int e = t + q * T;
-    const bool row = e < V.m, col = e < V.n;
-    r0[q] = row ? V.a_off[e] : 0, r1[q] = row ? V.a_off[e + 1] : 0;
-    c0[q] = col ? V.at_off[e] : 0, c1[q] = col ? V.at_off[e + 1] : 0;
-    c_s[e] = col ? V.c[e] : 0.0, lb_s[e] = col ? V.lb[e] : 0.0, ub_s[e] = col ? V.ub[e] : 0.0;
-    x[q]    = col ? (cur0 ? V.x1 : V.x0)[e] : 0.0;
-    aty[q]  = col ? (cur0 ? V.aty1 : V.aty0)[e] : 0.0;
-    sumx[q] = col ? V.sumx[e] : 0.0;
-    lo_s[e] = row ? V.lo[e] : 0.0, hi_s[e] = row ? V.hi[e] : 0.0;
-    y[q]    = row ? (cur0 ? V.y1 : V.y0)[e] : 0.0;
-    sumy[q] = row ? V.sumy[e] : 0.0;
-    xn[q] = x[q], atyn[q] = aty[q], yn[q] = y[q];
-  }
-  const int used = (V.nnz + T - 1) / T;  // nonzero slots in use (uniform): tiny LPs skip the empty ones
-  for (int attempt = 0; attempt < max_attempts; ++attempt) {
-    if (lc.error != 0 || lc.steps_taken >= lc.target_steps) break;  // uniform: every lane holds the same lc
-    const int cur       = lc.cur;
-    const double tau = lc.tau, sigma = lc.sigma, weight = lc.step_size;
-    const bool pend     = lc.pending_avg != 0;
-    const double knext  = (double)(lc.k + 1) + 1.0;
-    const int par       = attempt & 1;
-    // primal projection (utils.cuh:80-95) + deferred averaging
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int j = t + q * T;
-      if (j < V.n) {
-        const double gradient = c_s[j] - aty[q];
-        double next           = x[q] - (tau * gradient);
-        next                  = dmax(dmin(next, ub_s[j]), lb_s[j]);
-        xn[q]                 = next;
-        xbar_s[j]             = next - x[q] + next;
-        if (pend) sumx[q] = sumx[q] + weight * x[q];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u < used) prod[t + u * T] = a_val[u] * xbar_s[a_col[u]];
-    __syncthreads();
-    // y' = proj(y - sigma A xbar) (utils.cuh:97-112), ||dy||^2
-    double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int i = t + q * T;
-      if (i < V.m) {
-        const double ax = lds_row_sum(prod, r0[q], r1[q]);
-        double next      = y[q] - (sigma * ax);
-        const double low = next + sigma * lo_s[i];
-        const double up  = next + sigma * hi_s[i];
-        next             = dmax(low, dmin(up, 0.0));
-        yn[q]            = next;
-        yn_s[i]          = next;
-        const double dy  = next - y[q];
-        acc[0] += dy * dy;
-        if (pend) sumy[q] = sumy[q] + weight * y[q];
-      }
-    }
-    if (t >= T - 2) pw[par][t - (T - 2)] = pow(knext, t == T - 2 ? -sp.reduction_exponent : -sp.growth_exponent);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u < used) prod[t + u * T] = at_val[u] * yn_s[at_col[u]];
-    __syncthreads();
-    // A^T y' + interaction / ||dx||^2 (adaptive_step_size_strategy.cu:278-340)
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int j = t + q * T;
-      if (j < V.n) {
-        const double v = lds_row_sum(prod, c0[q], c1[q]);
-        atyn[q]          = v;
-        const double dx  = xn[q] - x[q];
-        const double dty = v - aty[q];
-        acc[1] += dty * dx;
-        acc[2] += dx * dx;
-      }
-    }
-    block_sum_fast<3, T / 64>(acc, red[par]);
-    apply_step_decision(&lc, acc[0], acc[1], acc[2], sp, pw[par]);
-    if (lc.cur != cur) {  // accepted: the candidate becomes the iterate
-#pragma unroll
-      for (int q = 0; q < Q; ++q) x[q] = xn[q], aty[q] = atyn[q], y[q] = yn[q];
-    }
-  }
-  {
-    const int cur = lc.cur;
-    double* xo    = cur ? V.x1 : V.x0;
-    double* yo    = cur ? V.y1 : V.y0;
-    double* atyo  = cur ? V.aty1 : V.aty0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int e = t + q * T;
-      if (e < V.n) xo[e] = x[q], atyo[e] = aty[q], V.sumx[e] = sumx[q];
-      if (e < V.m) yo[e] = y[q], V.sumy[e] = sumy[q];
-    }
-  }
-  if (t == 0) *ctl = lc, *ctl_host = lc;  // the pinned mirror saves the read-back copy
-}
-// the three instantiations, smallest first: (lanes, elements per lane, nonzeros per lane)
-struct ResidentTier { int T, Q, U; };
-constexpr ResidentTier kResidentTiers[3] = {{256, 2, 8}, {512, 2, 16}, {512, 4, 8}};
-int resident_tier(int m, int n, int64_t nnz)
-{
-  for (int i = 0; i < 3; ++i) {
-    const ResidentTier& r = kResidentTiers[i];
-    if (m <= r.Q * r.T && n <= r.Q * r.T && nnz <= (int64_t)r.U * r.T) return i;
-  }
-  return -1;
-}
-static size_t resident_lds_bytes(int tier)
-{
-  const ResidentTier& r = kResidentTiers[tier];
-  return sizeof(double) * (size_t)r.T * (7 * r.Q + r.U);
-}
-// hipFuncSetAttribute is per device and must happen before the first launch that asks for > 64 KiB of LDS:
-// one flag per (kernel instantiation, device), taken under a lock (batch solves create contexts from many threads)
-struct PerDeviceOnce {
-  std::mutex m;
-  bool done[64] = {};
-  template <class F>
-  int run(int device, F&& f)
-  {
-    std::lock_guard<std::mutex> lock(m);
-    if (device < 0 || device >= 64) return f();
-    if (done[device]) return 0;
-    const int rc = f();
-    if (rc == 0) done[device] = true;
-    return rc;
-  }
-};
-template <int T, int Q, int U>
-static int launch_resident(hipStream_t s, int tier, const SmallView& V, pdlpdev_ctl* ctl, pdlpdev_ctl* ctl_host,
-                           const pdlpdev_step_params& sp, int target_steps)
-{
-  static PerDeviceOnce once;  // per instantiation
-  int device = 0;
-  HIP_TRY(hipGetDevice(&device));
-  TRY(once.run(device, [&]() -> int {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_pdhg_resident<T, Q, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)resident_lds_bytes(tier)));
-    return 0;
-  }));
-  k_pdhg_resident<T, Q, U><<<1, T, resident_lds_bytes(tier), s>>>(V, ctl, ctl_host, sp, target_steps, 1 << 14);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 
 __global__ void __launch_bounds__(kBlock)
 k_permute_pad(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src, double* __restrict__ dst)
@@ -1057,8 +774,7 @@ __global__ void __launch_bounds__(kBlock) k_tr_final(TrPoint P, double t, int nb
   }
 }
 
-// restart: squared distances to the last-restart anchors, candidate -> iterate/anchors, sums <- 0
-// (pdlp_restart_strategy.cu:593-623,752-839)
+// restart (restart_block, pdlp_kernels.hpp)
 __global__ void __launch_bounds__(kBlock)
 k_restart(int n, int m, int which, int unscaled, const double* __restrict__ dc, const double* __restrict__ dr,
           const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0,
@@ -1068,36 +784,8 @@ k_restart(int n, int m, int which, int unscaled, const double* __restrict__ dc, 
           double* __restrict__ part)
 {
   __shared__ double red[12];
-  const int cur = ctl->cur;
-  double* __restrict__ x = cur ? x1 : x0;
-  double* __restrict__ y = cur ? y1 : y0;
-  double acc[2] = {0.0, 0.0};
-  const int tot = n > m ? n : m;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < tot; i += gridDim.x * kBlock) {
-    if (i < n) {
-      const double cand = which == PDLPDEV_AVERAGE ? avgx[i] : x[i];
-      double d          = lrx[i] - 1.0 * cand;
-      if (unscaled) d *= dc[i];
-      acc[0] += d * d;
-      if (which == PDLPDEV_AVERAGE) x[i] = cand;
-      lrx[i]  = cand;
-      sumx[i] = 0.0;
-    }
-    if (i < m) {
-      const double cand = which == PDLPDEV_AVERAGE ? avgy[i] : y[i];
-      double d          = lry[i] - 1.0 * cand;
-      if (unscaled) d *= dr[i];
-      acc[1] += d * d;
-      if (which == PDLPDEV_AVERAGE) y[i] = cand;
-      lry[i]  = cand;
-      sumy[i] = 0.0;
-    }
-  }
-  block_reduce<SumOp, 2>(acc, red);
-  if (threadIdx.x == 0) {
-    part[blockIdx.x]             = acc[0];
-    part[gridDim.x + blockIdx.x] = acc[1];
-  }
+  const RestartView R{n, m, which, unscaled, dc, dr, ctl, x0, x1, y0, y1, avgx, avgy, lrx, lry, sumx, sumy, part};
+  restart_block(R, blockIdx.x, gridDim.x, red);
 }
 __global__ void k_restart_ctl(pdlpdev_ctl* ctl)
 {
@@ -1683,91 +1371,6 @@ int pdlpdev_project_primal(pdlpdev_ctx* ctx)
 // ---- hot loop -------------------------------------------------------------------------------------
 }  // extern "C"
 static void launch_at_cur(pdlpdev_ctx* ctx, double* out_override, int use_next);
-// single-workgroup head of a major iteration (pdlpdev_major_eval) for LPs on the resident path
-struct MajorSmallArgs {
-  int m, n, mode, rule_finite, want_linf;
-  double eps_p, eps_d;
-  const int32_t *a_off, *a_idx, *at_off, *at_idx;
-  const double *a_val, *at_val;
-  pdlpdev_ctl* ctl;
-  double *x0, *x1, *y0, *y1, *sumx, *sumy, *avgx, *avgy;
-  const double *dr, *dc, *c_u, *lb_u, *ub_u, *lo_u, *hi_u;
-  double *linf_m, *linf_n, *ax_cur, *ax_avg, *aty_cur, *aty_avg, *rc_cur, *rc_avg;
-  double* sc;  // current at sc[0..9), average at sc[32..41)  (pinned host memory: no read-back copy)
-};
-constexpr int kMajorThreads = 1024;
-// M vec for a matrix of <= 8192 nonzeros: all products in parallel into LDS, then every row is added up left to
-// right by one lane (same order as every other SpMV here)
-template <class Epi, int NQ>
-__device__ __forceinline__ void small_rows(int rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
-                                           const double* __restrict__ val, const double* vec, double* prod, Epi& e,
-                                           double (&acc)[NQ])
-{
-  const int nnz = off[rows];
-  for (int k = threadIdx.x; k < nnz; k += kMajorThreads) prod[k] = val[k] * vec[idx[k]];
-  __syncthreads();
-  for (int r = threadIdx.x; r < rows; r += kMajorThreads) e.row(r, lds_row_sum(prod, off[r], off[r + 1]), acc);
-}
-__global__ void __launch_bounds__(kMajorThreads) k_major_small(MajorSmallArgs A)
-{
-  extern __shared__ double prod[];  // nnz doubles
-  __shared__ double red[4 * kMajorThreads / 64];
-  const int t = threadIdx.x;
-  const int cur = A.ctl->cur;
-  double* x = cur ? A.x1 : A.x0;
-  double* y = cur ? A.y1 : A.y0;
-  const bool pend = A.ctl->pending_avg != 0;
-  const double w = A.ctl->step_size, sw = A.ctl->sum_weights;
-  for (int j = t; j < A.n; j += kMajorThreads) {
-    double sx = A.sumx[j];
-    if (pend) A.sumx[j] = sx = sx + w * x[j];
-    A.avgx[j] = A.mode == 0 ? x[j] : (A.mode == 1 ? 0.0 : sx / sw);
-  }
-  for (int i = t; i < A.m; i += kMajorThreads) {
-    double sy = A.sumy[i];
-    if (pend) A.sumy[i] = sy = sy + w * y[i];
-    A.avgy[i] = A.mode == 0 ? y[i] : (A.mode == 1 ? 0.0 : sy / sw);
-  }
-  __syncthreads();  // also orders the global writes above against the reads below (one workgroup)
-  if (t == 0) A.ctl->pending_avg = 0;
-  for (int which = 0; which < 2; ++which) {
-    const double* xv = which ? A.avgx : x;
-    const double* yv = which ? A.avgy : y;
-    double* sc       = A.sc + 32 * which;
-    {
-      EvalPrimalEpilogue e{yv, A.dr, A.lo_u, A.hi_u, A.eps_p, A.want_linf ? A.linf_m : nullptr, which ? A.ax_avg : A.ax_cur};
-      double acc[3] = {0.0, 0.0, 0.0};
-      small_rows(A.m, A.a_off, A.a_idx, A.a_val, xv, prod, e, acc);
-      block_sum_fast<3, kMajorThreads / 64>(acc, red);
-      if (t == 0) sc[0] = acc[0], sc[1] = acc[1], sc[2] = acc[2];
-      __syncthreads();
-      if (A.want_linf) {
-        double mx[1] = {0.0};
-        for (int i = t; i < A.m; i += kMajorThreads) mx[0] = dmax(mx[0], A.linf_m[i]);  // own writes
-        block_reduce<MaxOp, 1, kMajorThreads / 64>(mx, red);
-        if (t == 0) sc[3] = mx[0];
-        __syncthreads();
-      }
-    }
-    {
-      EvalDualEpilogue e{EvalDualCore{xv, A.dc, A.c_u, A.lb_u, A.ub_u, A.eps_d, A.rule_finite, which ? A.rc_avg : A.rc_cur,
-                                      A.want_linf ? A.linf_n : nullptr, which ? A.aty_avg : A.aty_cur}};
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      small_rows(A.n, A.at_off, A.at_idx, A.at_val, yv, prod, e, acc);
-      block_sum_fast<4, kMajorThreads / 64>(acc, red);
-      if (t == 0) sc[4] = acc[0], sc[5] = acc[1], sc[6] = acc[2], sc[7] = acc[3];
-      __syncthreads();
-      if (A.want_linf) {
-        double mx[1] = {0.0};
-        for (int j = t; j < A.n; j += kMajorThreads) mx[0] = dmax(mx[0], A.linf_n[j]);
-        block_reduce<MaxOp, 1, kMajorThreads / 64>(mx, red);
-        if (t == 0) sc[8] = mx[0];
-        __syncthreads();
-      }
-    }
-  }
-}
-
 extern "C" {
 int pdlpdev_compute_aty(pdlpdev_ctx* ctx)
 {
@@ -2005,21 +1608,8 @@ int pdlpdev_run(pdlpdev_ctx* ctx, int32_t target_steps, pdlpdev_ctl* ctl)
 {
   roctx::Range range("pdlp: PDHG attempts");
   HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->small_resident && !ctx->comm) {
-    // one launch runs attempts until the target is reached (rejected attempts included); the cap only bounds
-    // a pathological rejection streak, in which case the loop below relaunches.  The kernel takes the target as
-    // an argument and leaves the control block in pinned host memory: one launch + one synchronize per call.
-    SmallView V{ctx->m, ctx->n, (int)ctx->nnz, ctx->a_off, ctx->a_idx, ctx->at_off, ctx->at_idx, ctx->a_val, ctx->at_val,
-                ctx->c, ctx->lb, ctx->ub, ctx->lo, ctx->hi, ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->aty[0],
-                ctx->aty[1], ctx->sumx, ctx->sumy};
-    const int tier = resident_tier(ctx->m, ctx->n, ctx->nnz);
-    for (int guard = 0; guard < 1000; ++guard) {
-      if (tier == 0) TRY((launch_resident<256, 2, 8>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
-      if (tier == 1) TRY((launch_resident<512, 2, 16>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
-      if (tier == 2) TRY((launch_resident<512, 4, 8>(ctx->stream, tier, V, ctx->ctl, ctx->ctl_h, ctx->sp, target_steps)));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      if (ctx->ctl_h->error != 0 || ctx->ctl_h->steps_taken >= target_steps) break;
-    }
+  if (ctx->small_resident && !ctx->comm) {  // the whole loop inside one workgroup (kernels_resident.hip)
+    TRY(resident_run(ctx, target_steps));
     if (ctl) *ctl = *ctx->ctl_h;
     return 0;
   }
@@ -2245,17 +1835,6 @@ static int enqueue_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, 
   LAUNCH_CHECK();
   return 0;
 }
-static void read_eval(const double* h, bool want_linf, double out[PDLPDEV_EV_COUNT])
-{
-  out[PDLPDEV_EV_PRES2]         = h[0];
-  out[PDLPDEV_EV_DUAL_SUM]      = h[1] + h[5];
-  out[PDLPDEV_EV_Y2]            = h[2];
-  out[PDLPDEV_EV_LINF_PRES_REL] = want_linf ? h[3] : 0.0;
-  out[PDLPDEV_EV_DRES2]         = h[4];
-  out[PDLPDEV_EV_CX]            = h[6];
-  out[PDLPDEV_EV_X2]            = h[7];
-  out[PDLPDEV_EV_LINF_DRES_REL] = want_linf ? h[8] : 0.0;
-}
 int pdlpdev_eval(pdlpdev_ctx* ctx, int which, int rc_rule_finite_bounds, double eps_rel_primal,
                  double eps_rel_dual, double out[PDLPDEV_EV_COUNT])
 {
@@ -2276,21 +1855,7 @@ int pdlpdev_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bo
   HIP_TRY(hipSetDevice(ctx->device));
   const bool want_linf = eps_rel_primal >= 0.0 && eps_rel_dual >= 0.0;
   if (ctx->small_resident && !ctx->comm) {
-    MajorSmallArgs A{ctx->m, ctx->n, average_mode, rc_rule_finite_bounds, want_linf ? 1 : 0, eps_rel_primal, eps_rel_dual,
-                     ctx->a_off, ctx->a_idx, ctx->at_off, ctx->at_idx, ctx->a_val, ctx->at_val, ctx->ctl,
-                     ctx->x[0], ctx->x[1], ctx->y[0], ctx->y[1], ctx->sumx, ctx->sumy, ctx->avgx, ctx->avgy,
-                     ctx->dr, ctx->dc, ctx->c_u, ctx->lb_u, ctx->ub_u, ctx->lo_u, ctx->hi_u, ctx->tmp_m, ctx->tmp_n,
-                     ctx->ax_u[PDLPDEV_CURRENT], ctx->ax_u[PDLPDEV_AVERAGE], ctx->aty_u[PDLPDEV_CURRENT],
-                     ctx->aty_u[PDLPDEV_AVERAGE], ctx->rc[0], ctx->rc[1], ctx->scal_h};
-    const size_t lds = sizeof(double) * (size_t)std::max<int64_t>(ctx->nnz, 1);
-    static PerDeviceOnce once;
-    TRY(once.run(ctx->device, [&]() -> int {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_major_small, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-      return 0;
-    }));
-    k_major_small<<<1, kMajorThreads, lds, ctx->stream>>>(A);
-    LAUNCH_CHECK();
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(resident_major_eval(ctx, average_mode, rc_rule_finite_bounds, want_linf ? 1 : 0, eps_rel_primal, eps_rel_dual));
   } else {
     TRY(pdlpdev_flush_average(ctx));
     TRY(pdlpdev_make_average(ctx, average_mode));

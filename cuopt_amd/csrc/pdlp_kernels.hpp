@@ -353,4 +353,118 @@ __device__ __forceinline__ double bound_value_product(double value, double lower
   return dfinite(bound) ? value * bound : 0.0;
 }
 
+// ---- scalar logic shared by the multi-launch loop, the resident small-LP loop and the batches -------------------------------------
+// The scalar rule of compute_step_sizes_from_movement_and_interaction (adaptive_step_size_strategy.cu:91-188) +
+// the accept/flip of update_solution (pdhg.cu:237-250) + add_weight_sums (weighted_average_solution.cu:63-71).
+// One thread.
+// `pw` (optional): pow(k + 2, -reduction_exponent), pow(k + 2, -growth_exponent) for the k the attempt
+// started with, computed off the critical path by the caller.
+__device__ __forceinline__ void apply_step_decision(pdlpdev_ctl* ctl, double dy2, double interaction, double dx2,
+                                                    const pdlpdev_step_params& sp, const double* pw = nullptr)
+{
+  const double w = ctl->primal_weight;
+  double step    = ctl->step_size;
+  const double movement = sp.primal_distance_smoothing * w * dx2 + (sp.dual_distance_smoothing / w) * dy2;
+  ctl->last_interaction = interaction;
+  ctl->last_movement    = movement;
+  ctl->last_dx2         = dx2;
+  ctl->last_dy2         = dy2;
+  ctl->attempts += 1;
+  bool accepted;
+  // pdlp_constants.hpp:39-47 (movement <= 0 or >= 1e100), written so that a NaN -- which the reference's comparisons let through
+  // into an endless series of rejected steps -- takes the same "invalid step size" exit (-> NumericalError at the next check)
+  if (!(movement > 0.0) || !(movement < 1.0e100) || interaction != interaction) {
+    // reference: flag -1, k and eta untouched; take_step still averages and swaps
+    // (pdlp.cu:1193-1221) and the next loop trip is forced to be a major iteration.
+    ctl->error = 1;
+    accepted   = true;
+  } else {
+    const double inter = fabs(interaction);
+    ctl->k += 1;
+    const double kc    = (double)ctl->k;
+    const double limit = inter > 0.0 ? movement / inter : __builtin_huge_val();
+    accepted           = step <= limit;
+    const double s1    = (1.0 - (pw ? pw[0] : pow(kc + 1.0, -sp.reduction_exponent))) * limit;
+    const double s2    = (1.0 + (pw ? pw[1] : pow(kc + 1.0, -sp.growth_exponent))) * step;
+    step               = dmin(s1, s2);
+    ctl->step_size     = step;
+    ctl->tau           = step / w;
+    ctl->sigma         = step * w;
+  }
+  if (accepted) {
+    ctl->cur ^= 1;
+    ctl->pending_avg = 1;
+    ctl->sum_weights += step;  // the ALREADY UPDATED step size (pdlp.cu:1216-1220)
+    ctl->steps_taken += 1;
+    ctl->its_since_restart += 1;
+  } else {
+    ctl->pending_avg = 0;
+  }
+}
+
+
+// out[q] = reduce(part[q * nb .. q * nb + nb)) ; op_mask bit q set => max.  One workgroup of kBlock threads (k_finalize; the
+// small-LP batch runs it once per LP inside one launch: same tree, same bits).
+__device__ __forceinline__ void finalize_rows(const double* __restrict__ part, int nb, int nq, unsigned op_mask, double* __restrict__ out, double* red /* >= 8 */)
+{
+  for (int q = 0; q < nq; ++q) {
+    const bool is_max = (op_mask >> q) & 1u;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+      const double v = part[(size_t)q * nb + i];
+      acc[0] = is_max ? (v > acc[0] ? v : acc[0]) : acc[0] + v;
+    }
+    if (is_max)
+      block_reduce<MaxOp, 1>(acc, red);
+    else
+      block_reduce<SumOp, 1>(acc, red);
+    if (threadIdx.x == 0) out[q] = acc[0];
+    __syncthreads();
+  }
+}
+
+// restart: squared distances to the last-restart anchors, candidate -> iterate / anchors, sums <- 0
+// (pdlp_restart_strategy.cu:593-623,752-839).  Workgroup `bid` of `nblocks` (k_restart: blockIdx.x of gridDim.x).
+struct RestartView {
+  int n, m, which, unscaled;
+  const double *dc, *dr;
+  const pdlpdev_ctl* ctl;
+  double *x0, *x1, *y0, *y1;
+  const double *avgx, *avgy;
+  double *lrx, *lry, *sumx, *sumy, *part;
+};
+__device__ __forceinline__ void restart_block(const RestartView& R, int bid, int nblocks, double* red /* >= 12 */)
+{
+  const int cur = R.ctl->cur;
+  double* __restrict__ x = cur ? R.x1 : R.x0;
+  double* __restrict__ y = cur ? R.y1 : R.y0;
+  double acc[2] = {0.0, 0.0};
+  const int tot = R.n > R.m ? R.n : R.m;
+  for (int i = bid * kBlock + threadIdx.x; i < tot; i += nblocks * kBlock) {
+    if (i < R.n) {
+      const double cand = R.which == PDLPDEV_AVERAGE ? R.avgx[i] : x[i];
+      double d          = R.lrx[i] - 1.0 * cand;
+      if (R.unscaled) d *= R.dc[i];
+      acc[0] += d * d;
+      if (R.which == PDLPDEV_AVERAGE) x[i] = cand;
+      R.lrx[i]  = cand;
+      R.sumx[i] = 0.0;
+    }
+    if (i < R.m) {
+      const double cand = R.which == PDLPDEV_AVERAGE ? R.avgy[i] : y[i];
+      double d          = R.lry[i] - 1.0 * cand;
+      if (R.unscaled) d *= R.dr[i];
+      acc[1] += d * d;
+      if (R.which == PDLPDEV_AVERAGE) y[i] = cand;
+      R.lry[i]  = cand;
+      R.sumy[i] = 0.0;
+    }
+  }
+  block_reduce<SumOp, 2>(acc, red);
+  if (threadIdx.x == 0) {
+    R.part[bid]           = acc[0];
+    R.part[nblocks + bid] = acc[1];
+  }
+}
+
 }  // namespace pdlp

@@ -98,3 +98,32 @@ PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* i
 int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h);
 void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t* idx, DenseHost* D);
 void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const int32_t* t_off, const int32_t* t_idx);
+
+// ---- the resident small-LP path (kernels_resident.hip) ----------------------------------------------------------------------------
+int resident_tier(int m, int n, int64_t nnz);
+int resident_run(pdlpdev_ctx* ctx, int32_t target_steps);  // attempts inside one workgroup until the target (pdlpdev_run's small branch)
+int resident_major_eval(pdlpdev_ctx* ctx, int average_mode, int rc_rule_finite_bounds, int want_linf, double eps_rel_primal, double eps_rel_dual);
+// the nine scalars an evaluation leaves (device or pinned) -> the PDLPDEV_EV_* array
+inline void read_eval(const double* h, bool want_linf, double out[PDLPDEV_EV_COUNT])
+{
+  out[PDLPDEV_EV_PRES2]         = h[0];
+  out[PDLPDEV_EV_DUAL_SUM]      = h[1] + h[5];
+  out[PDLPDEV_EV_Y2]            = h[2];
+  out[PDLPDEV_EV_LINF_PRES_REL] = want_linf ? h[3] : 0.0;
+  out[PDLPDEV_EV_DRES2]         = h[4];
+  out[PDLPDEV_EV_CX]            = h[6];
+  out[PDLPDEV_EV_X2]            = h[7];
+  out[PDLPDEV_EV_LINF_DRES_REL] = want_linf ? h[8] : 0.0;
+}
+
+// A^T y of the current iterate for SEVERAL stream-layout contexts in one launch (kernels_stream.hip): block i of the grid is row block
+// blk[i].y of context blk[i].x -- k_spmv_at_cur's body, so the sums are the single launch's
+struct StreamAtCurArgs {
+  int nb;
+  const int32_t *rb, *off, *idx;
+  const double* val;
+  const pdlpdev_ctl* ctl;
+  const double *y0, *y1;
+  double *aty0, *aty1;
+};
+int launch_stream_at_cur_batch(hipStream_t s, const StreamAtCurArgs* args, const int2* blk, int blocks);

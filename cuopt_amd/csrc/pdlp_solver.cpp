@@ -325,13 +325,10 @@ struct HostRange {  // roctx range of a host-side phase (LP/pdlp.cu:541,1227 are
   ~HostRange() { pdlpdev_range_pop(); }
 };
 
-int major_iteration(cuoptamd_solver* s, bool* terminated)
+// The head of a major iteration asks the device for: pending average + average iterate + both convergence evaluations
+// (pdlpdev_major_eval; one launch for K LPs of a small-LP batch) ...
+pdlpdev_small_eval major_eval_request(const cuoptamd_solver* s)
 {
-  HostRange range("pdlp: major iteration (termination + restart logic)");
-  const cuoptamd_hyper& H = s->H;
-  pdlpdev_ctx* dev        = s->dev;
-  *terminated             = false;
-  s->result.num_major_iterations += 1;
   // pdlp.cu:1110-1122: with 0 or 1 steps the average IS the iterate (avoids a*x/x != x);
   // right after a restart the sums are empty and the reference yields zeros.
   int mode = 2;
@@ -339,13 +336,71 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
     mode = 0;
   else if (s->ctl.its_since_restart == 0)
     mode = 1;
-  const int rule_finite = H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
+  pdlpdev_small_eval r;
+  r.mode        = mode;
+  r.rule_finite = s->H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
   // the l-infinity residuals are only consumed by the per-constraint verdict (termination_strategy.cu:189-205)
-  const double eps_p = s->S.per_constraint_residual ? s->S.relative_primal_tolerance : -1.0;
-  const double eps_d = s->S.per_constraint_residual ? s->S.relative_dual_tolerance : -1.0;
+  r.eps_p = s->S.per_constraint_residual ? s->S.relative_primal_tolerance : -1.0;
+  r.eps_d = s->S.per_constraint_residual ? s->S.relative_dual_tolerance : -1.0;
+  return r;
+}
+// ... and, when the KKT rule decides to restart, for pdlpdev_restart(which, unscaled) -- whose distances then give the new primal
+// weight (major_restart_done).  The plan is what the head hands back to whoever talks to the device.
+struct MajorPlan {
+  bool restart = false;
+  int which = PDLPDEV_CURRENT, unscaled = 0;
+  bool really_average = false;
+  double candidate = 0.0;
+};
+int major_head(cuoptamd_solver* s, const double* ev, const double* ev_avg, bool* terminated, MajorPlan* plan);
+double major_restart_done(cuoptamd_solver* s, const MajorPlan& plan, const double dist2[2]);
+
+int major_iteration(cuoptamd_solver* s, bool* terminated)
+{
+  HostRange range("pdlp: major iteration (termination + restart logic)");
+  pdlpdev_ctx* dev = s->dev;
+  const pdlpdev_small_eval rq = major_eval_request(s);
   double ev[PDLPDEV_EV_COUNT], ev_avg[PDLPDEV_EV_COUNT];
-  // pending average + average iterate + both convergence evaluations, one read-back
-  DEV(pdlpdev_major_eval(dev, mode, rule_finite, eps_p, eps_d, ev, ev_avg));
+  DEV(pdlpdev_major_eval(dev, rq.mode, rq.rule_finite, rq.eps_p, rq.eps_d, ev, ev_avg));
+  MajorPlan plan;
+  int rc = major_head(s, ev, ev_avg, terminated, &plan);
+  if (rc != 0 || *terminated || !plan.restart) return rc;
+  double dist2[2];
+  DEV(pdlpdev_restart(dev, plan.which, plan.unscaled, dist2));
+  const double nw = major_restart_done(s, plan, dist2);
+  if (nw > 0.0) DEV(pdlpdev_set_step(dev, -1.0, nw));
+  return 0;
+}
+
+// compute_new_primal_weight (pdlp_restart_strategy.cu:684-750, safe guard pdlp_constants.hpp:34-35) + the bookkeeping behind a KKT
+// restart; returns the new primal weight (<= 0: unchanged) for pdlpdev_set_step
+double major_restart_done(cuoptamd_solver* s, const MajorPlan& plan, const double dist2[2])
+{
+  const double w = s->ctl.primal_weight;
+  double nw      = -1.0;
+  s->last_restart_was_average = plan.really_average;
+  if (plan.really_average) s->need_aty = true;  // pdhg.cu:183-184
+  s->ctl.its_since_restart = 0;
+  s->ctl.sum_weights       = 0.0;
+  const double pd = std::sqrt(dist2[0]), dd = std::sqrt(dist2[1]);
+  const double guard = 1.0e-10;
+  if (!(pd < guard || pd >= 1.0 / guard || dd < guard || dd >= 1.0 / guard)) {
+    const double theta = s->H.primal_weight_update_smoothing;
+    nw                 = std::exp(theta * std::log(dd / pd) + (1.0 - theta) * std::log(w));
+    s->ctl.primal_weight = nw;
+  }
+  s->last_restart_kkt = plan.candidate;
+  return nw;
+}
+
+int major_head(cuoptamd_solver* s, const double* ev, const double* ev_avg, bool* terminated, MajorPlan* plan)
+{
+  const cuoptamd_hyper& H = s->H;
+  pdlpdev_ctx* dev        = s->dev;
+  *terminated             = false;
+  *plan                   = MajorPlan();
+  s->result.num_major_iterations += 1;
+  const int rule_finite = H.handle_some_primal_gradients_on_finite_bounds_as_residuals == 0;
   s->conv_current = to_convergence(s, ev);
   s->conv_average = to_convergence(s, ev_avg);
   if (s->S.detect_infeasibility) {
@@ -471,25 +526,13 @@ int major_iteration(cuoptamd_solver* s, bool* terminated)
         else if (candidate < H.necessary_reduction_for_restart * s->last_restart_kkt && candidate > s->last_candidate_kkt)
           restart = true;
       }
-      if (restart) {
+      if (restart) {  // the device part (pdlpdev_restart, then the new weight) is the caller's: major_iteration / the small-LP batch
         s->result.num_restarts += 1;
-        const bool really_average = to_average && !H.never_restart_to_average;
-        double dist2[2];
-        DEV(pdlpdev_restart(dev, really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT, !H.rescale_for_restart, dist2));
-        s->last_restart_was_average = really_average;
-        if (really_average) s->need_aty = true;  // pdhg.cu:183-184
-        s->ctl.its_since_restart = 0;
-        s->ctl.sum_weights       = 0.0;
-        // compute_new_primal_weight (:684-750), safe guard pdlp_constants.hpp:34-35
-        const double pd = std::sqrt(dist2[0]), dd = std::sqrt(dist2[1]);
-        const double guard = 1.0e-10;
-        if (!(pd < guard || pd >= 1.0 / guard || dd < guard || dd >= 1.0 / guard)) {
-          const double theta = H.primal_weight_update_smoothing;
-          const double nw    = std::exp(theta * std::log(dd / pd) + (1.0 - theta) * std::log(w));
-          DEV(pdlpdev_set_step(dev, -1.0, nw));
-          s->ctl.primal_weight = nw;
-        }
-        s->last_restart_kkt = candidate;
+        plan->restart        = true;
+        plan->really_average = to_average && !H.never_restart_to_average;
+        plan->which          = plan->really_average ? PDLPDEV_AVERAGE : PDLPDEV_CURRENT;
+        plan->unscaled       = !H.rescale_for_restart;
+        plan->candidate      = candidate;
       }
       s->last_candidate_kkt = candidate;
     }
@@ -1087,17 +1130,9 @@ void cuoptamd_solver_destroy(cuoptamd_solver* s)
   delete s;
 }
 
-int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub, const double* lo, const double* hi,
-                          const cuoptamd_settings* settings, const double* init_x, const double* init_y)
+// loop state as freshly constructed (cuoptamd_solver_reset, cuoptamd_batch_reset)
+static void reset_host_state(cuoptamd_solver* s)
 {
-  if (!s) return fail(-1, "cuoptamd_solver_reset: null solver");
-  const auto t0 = clock_type::now();
-  if (settings) {
-    s->S = *settings;
-    if (settings->log_file && settings->log_file[0]) s->log_path = settings->log_file;
-    s->S.log_file = nullptr;
-  }
-  // loop state as freshly constructed
   const cuoptamd_result blank{};
   s->total_iterations = 0, s->iteration_offset = 0, s->attempt_offset = 0, s->major_done_at = -1;
   s->step_error = false, s->need_aty = true, s->last_restart_was_average = false;
@@ -1109,6 +1144,19 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
   s->conv_current = Convergence{}, s->conv_average = Convergence{};
   s->returned_which = PDLPDEV_CURRENT, s->finished = false, s->warm_started = false, s->started = false;
   s->result = blank;
+}
+
+int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub, const double* lo, const double* hi,
+                          const cuoptamd_settings* settings, const double* init_x, const double* init_y)
+{
+  if (!s) return fail(-1, "cuoptamd_solver_reset: null solver");
+  const auto t0 = clock_type::now();
+  if (settings) {
+    s->S = *settings;
+    if (settings->log_file && settings->log_file[0]) s->log_path = settings->log_file;
+    s->S.log_file = nullptr;
+  }
+  reset_host_state(s);
   if (s->empty_problem) return 0;
   {
     std::vector<double> tlb, tub, tlo, thi;  // the new bounds in the device's order
@@ -1141,39 +1189,38 @@ int cuoptamd_solver_reset(cuoptamd_solver* s, const double* lb, const double* ub
 // primal weight), the iteration budget, then what the attempts need (a cleared step error, A^T y of a fresh iterate).  *stop: the
 // solve is over or the budget is used up (s->result says which); otherwise *target = the accepted-step count (the device's) the
 // attempts run to.  cuoptamd_solver_advance runs one LP through it, cuoptamd_batch_advance K of them in lockstep.
-static int advance_to_attempts(cuoptamd_solver* s, int32_t budget_end, int32_t* target_out, bool* stop)
+static bool major_due(const cuoptamd_solver* s)
 {
   const cuoptamd_hyper& H = s->H;
-  *stop = false;
   const int32_t it = s->total_iterations;
-  if (it >= H.major_iteration && fault_injected(s->rank, s->world, "advance")) return fail(-6, "injected fault (CUOPT_AMD_TUNE=fault_inject)");
   const bool major = (it % H.major_iteration == 0 && it > 0) || it <= H.min_iteration_restart;
   // should_do_artificial_restart (pdlp_restart_strategy.cu:939-961), Fast1 only
   const bool artificial = H.artificial_restart_in_main_loop && s->ctl.its_since_restart >= H.artificial_restart_threshold * it;
-  if ((major || artificial || s->step_error) && s->major_done_at != it) {
-    bool terminated = false;
-    int rc          = major_iteration(s, &terminated);
-    if (rc != 0) return rc;
-    s->major_done_at = it;
-    if (terminated) {
-      s->finished = true;
-      log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->result.steps_taken, s->result.primal_objective,
-               s->result.dual_objective, s->result.gap, s->result.l2_primal_residual, s->result.l2_dual_residual,
-               seconds_since(s->solve_start));
-      log_line(s, "PDLP finished: status %d, %d iterations, %d restarts\n", s->result.status, s->result.steps_taken,
-               s->result.num_restarts);
-      *stop = true;
-      return 0;
-    }
-  }
+  return (major || artificial || s->step_error) && s->major_done_at != it;
+}
+static void major_was_done(cuoptamd_solver* s, bool terminated)
+{
+  s->major_done_at = s->total_iterations;
+  if (!terminated) return;
+  s->finished = true;
+  log_line(s, "%7d %+.8e %+.8e  %8.2e   %8.2e     %8.2e   %.3fs\n", s->result.steps_taken, s->result.primal_objective,
+           s->result.dual_objective, s->result.gap, s->result.l2_primal_residual, s->result.l2_dual_residual,
+           seconds_since(s->solve_start));
+  log_line(s, "PDLP finished: status %d, %d iterations, %d restarts\n", s->result.status, s->result.steps_taken,
+           s->result.num_restarts);
+}
+// the iteration budget, then the accepted-step count (the device's) the next attempts run to; false: the budget is used up
+static bool next_target(cuoptamd_solver* s, int32_t budget_end, int32_t* target_out)
+{
+  const cuoptamd_hyper& H = s->H;
+  const int32_t it = s->total_iterations;
   if (it >= budget_end) {
     s->result.status          = kNoTermination;
     s->result.steps_taken     = s->ctl.steps_taken;
     s->result.attempted_steps = s->ctl.attempts;
     s->result.step_size       = s->ctl.step_size;
     s->result.primal_weight   = s->ctl.primal_weight;
-    *stop = true;
-    return 0;
+    return false;
   }
   // ---- take_step(s) up to the next major iteration (pdlp.cu:1187-1222), no host round trips ----
   int32_t next_major;
@@ -1181,7 +1228,27 @@ static int advance_to_attempts(cuoptamd_solver* s, int32_t budget_end, int32_t* 
     next_major = it + 1;
   else
     next_major = (it / H.major_iteration + 1) * H.major_iteration;
-  const int32_t target = std::min(next_major, budget_end);
+  *target_out = std::min(next_major, budget_end) - s->iteration_offset;
+  return true;
+}
+static int advance_to_attempts(cuoptamd_solver* s, int32_t budget_end, int32_t* target_out, bool* stop)
+{
+  *stop = false;
+  if (s->total_iterations >= s->H.major_iteration && fault_injected(s->rank, s->world, "advance")) return fail(-6, "injected fault (CUOPT_AMD_TUNE=fault_inject)");
+  if (major_due(s)) {
+    bool terminated = false;
+    int rc          = major_iteration(s, &terminated);
+    if (rc != 0) return rc;
+    major_was_done(s, terminated);
+    if (terminated) {
+      *stop = true;
+      return 0;
+    }
+  }
+  if (!next_target(s, budget_end, target_out)) {
+    *stop = true;
+    return 0;
+  }
   if (s->step_error) {  // take_step re-arms valid_step_size = 0 (pdlp.cu:1190)
     s->step_error = false;
     int rc = pdlpdev_clear_error(s->dev);
@@ -1192,7 +1259,6 @@ static int advance_to_attempts(cuoptamd_solver* s, int32_t budget_end, int32_t* 
     if (rc != 0) return fail(rc, "pdlpdev_compute_aty: %s", pdlpdev_last_error());
     s->need_aty = false;
   }
-  *target_out = target - s->iteration_offset;
   return 0;
 }
 static void advance_after_attempts(cuoptamd_solver* s)  // (s->ctl: the control block the attempts left)
@@ -1246,8 +1312,9 @@ int cuoptamd_solver_advance(cuoptamd_solver* s, int32_t max_new_iterations, cuop
 // ---- K LPs over ONE matrix and objective in lockstep (kernels_batch.hip) --------------------------------------------------------
 struct cuoptamd_batch {
   int K = 0;
-  cuoptamd_solver* s[16] = {nullptr};
-  pdlpdev_batch* dev = nullptr;
+  std::vector<cuoptamd_solver*> s;
+  pdlpdev_batch* dev = nullptr;          // K <= 16 LPs over ONE matrix in lockstep (kernels_batch.hip), or ...
+  pdlpdev_small_batch* small = nullptr;  // ... K resident small LPs, one workgroup each (kernels_resident.hip)
 };
 
 int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const double* ub, const double* lo, const double* hi,
@@ -1278,21 +1345,27 @@ int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const doubl
 
 int cuoptamd_batch_create(cuoptamd_solver** solvers, int K, cuoptamd_batch** out)
 {
-  if (!solvers || !out || K < 1 || K > 16) return fail(-1, "cuoptamd_batch_create: 2, 4, 8 or 16 solvers");
-  pdlpdev_ctx* ctx[16];
+  if (!solvers || !out || K < 1) return fail(-1, "cuoptamd_batch_create: null argument");
+  std::vector<pdlpdev_ctx*> ctx(K);
   for (int l = 0; l < K; ++l) {
     if (!solvers[l] || !solvers[l]->dev) return fail(-1, "cuoptamd_batch_create: null solver");
     ctx[l] = solvers[l]->dev;
   }
-  pdlpdev_batch* dev = nullptr;
-  int rc             = pdlpdev_batch_create(&dev, ctx, K);
+  // small LPs first: any number of them, any matrices, a workgroup each
+  pdlpdev_small_batch* small = nullptr;
+  int rc                     = pdlpdev_small_batch_create(&small, ctx.data(), K);
+  pdlpdev_batch* dev         = nullptr;
+  if (rc == -7) {  // not the resident path: 2, 4, 8 or 16 LPs over one matrix in lockstep
+    if (K > 16) return fail(-7, "cuoptamd_batch_create: more than 16 LPs need the resident small-LP path (%s)", pdlpdev_last_error());
+    rc = pdlpdev_batch_create(&dev, ctx.data(), K);
+  }
   if (rc != 0) {
     if (dev) pdlpdev_batch_destroy(dev);
     return fail(rc, "%s", pdlpdev_last_error());
   }
   cuoptamd_batch* b = new cuoptamd_batch();
-  b->K = K, b->dev = dev;
-  for (int l = 0; l < K; ++l) b->s[l] = solvers[l];
+  b->K = K, b->dev = dev, b->small = small;
+  b->s.assign(solvers, solvers + K);
   *out = b;
   return 0;
 }
@@ -1302,9 +1375,100 @@ pdlpdev_batch* cuoptamd_batch_device(cuoptamd_batch* b) { return b ? b->dev : nu
 void cuoptamd_batch_destroy(cuoptamd_batch* b)
 {
   if (!b) return;
-  pdlpdev_batch_destroy(b->dev);
+  if (b->dev) pdlpdev_batch_destroy(b->dev);
+  if (b->small) pdlpdev_small_batch_destroy(b->small);
   delete b;
 }
+
+// K resident small LPs: every phase of the loop that touches the device is ONE launch over the LPs that are in it
+// (pdlpdev_small_batch_*), the scalar logic in between runs per LP on the host exactly as in cuoptamd_solver_advance
+static int small_batch_advance(cuoptamd_batch* b, const std::vector<int32_t>& budget_end, std::vector<char>& done)
+{
+  const int K = b->K;
+  std::vector<pdlpdev_small_eval> req(K), ahead(K);
+  std::vector<double> ev((size_t)K * PDLPDEV_EV_COUNT), ev_avg((size_t)K * PDLPDEV_EV_COUNT), dist2(2 * (size_t)K), weight(K);
+  std::vector<int32_t> which(K), unscaled(K), target(K), clear(K), aty(K), evaluated(K, 0);
+  std::vector<char> due(K);
+  std::vector<MajorPlan> plan(K);
+  std::vector<pdlpdev_ctl> ctl(K);
+  auto same_request = [](const pdlpdev_small_eval& a, const pdlpdev_small_eval& c) {
+    return a.mode == c.mode && a.rule_finite == c.rule_finite && a.eps_p == c.eps_p && a.eps_d == c.eps_d;
+  };
+  for (;;) {
+    // ---- major iterations that are due: one evaluation launch (unless the evaluation already ran behind the attempts), the heads on
+    // the host, one restart launch
+    bool any = false, launch = false;
+    for (int l = 0; l < K; ++l) {
+      req[l].mode = -1, due[l] = 0;
+      if (done[l] || !major_due(b->s[l])) continue;
+      due[l] = 1, any = true;
+      const pdlpdev_small_eval rq = major_eval_request(b->s[l]);
+      if (evaluated[l] && same_request(rq, ahead[l])) continue;  // ev / ev_avg of LP l are in place
+      req[l] = rq, launch = true;
+    }
+    std::fill(evaluated.begin(), evaluated.end(), 0);
+    std::fill(weight.begin(), weight.end(), -1.0);
+    if (any) {
+      HostRange range("pdlp: major iterations of a small-LP batch");
+      int rc = launch ? pdlpdev_small_batch_major_eval(b->small, req.data(), ev.data(), ev_avg.data()) : 0;
+      if (rc != 0) return fail(rc, "pdlpdev_small_batch_major_eval: %s", pdlpdev_last_error());
+      bool any_restart = false;
+      for (int l = 0; l < K; ++l) {
+        which[l] = -1, unscaled[l] = 0;
+        if (!due[l]) continue;
+        bool terminated = false;
+        rc = major_head(b->s[l], &ev[(size_t)l * PDLPDEV_EV_COUNT], &ev_avg[(size_t)l * PDLPDEV_EV_COUNT], &terminated, &plan[l]);
+        if (rc != 0) return rc;
+        major_was_done(b->s[l], terminated);
+        if (terminated) done[l] = 1;
+        else if (plan[l].restart) which[l] = plan[l].which, unscaled[l] = plan[l].unscaled, any_restart = true;
+      }
+      if (any_restart) {
+        rc = pdlpdev_small_batch_restart(b->small, which.data(), unscaled.data(), dist2.data());
+        if (rc != 0) return fail(rc, "pdlpdev_small_batch_restart: %s", pdlpdev_last_error());
+        for (int l = 0; l < K; ++l)
+          if (which[l] >= 0) weight[l] = major_restart_done(b->s[l], plan[l], &dist2[2 * (size_t)l]);
+      }
+    }
+    // ---- budgets and targets; what the attempts need first (new weights, a cleared step error, A^T y of a fresh iterate)
+    any = false;
+    bool any_prepare = false;
+    for (int l = 0; l < K; ++l) {
+      target[l] = 0, clear[l] = 0, aty[l] = 0, ahead[l].mode = -1;
+      if (weight[l] > 0.0) any_prepare = true;  // (also for an LP whose budget ends here: the device keeps what a later call continues from)
+      if (done[l]) continue;
+      cuoptamd_solver* s = b->s[l];
+      if (!next_target(s, budget_end[l], &target[l])) {
+        done[l] = 1, target[l] = 0;
+        continue;
+      }
+      any = true;
+      if (s->step_error) s->step_error = false, clear[l] = 1, any_prepare = true;
+      if (s->need_aty) s->need_aty = false, aty[l] = 1, any_prepare = true;
+      // the major iteration these attempts end in (when the target is a boundary of the schedule, the usual case): its evaluation is
+      // enqueued right behind them.  The request is what major_eval_request will say once the attempts are done -- verified then.
+      const cuoptamd_hyper& H = s->H;
+      const int32_t it_after = target[l] + s->iteration_offset;
+      if ((it_after % H.major_iteration == 0 && it_after > 0) || it_after <= H.min_iteration_restart) {
+        ahead[l]      = major_eval_request(s);
+        ahead[l].mode = (target[l] <= 1 && !s->warm_started) ? 0 : 2;
+      }
+    }
+    if (any_prepare) {
+      int rc = pdlpdev_small_batch_prepare(b->small, clear.data(), weight.data(), aty.data());
+      if (rc != 0) return fail(rc, "pdlpdev_small_batch_prepare: %s", pdlpdev_last_error());
+    }
+    if (!any) return 0;
+    int rc = pdlpdev_small_batch_run(b->small, target.data(), ctl.data(), ahead.data(), ev.data(), ev_avg.data(), evaluated.data());
+    if (rc != 0) return fail(rc, "pdlpdev_small_batch_run: %s", pdlpdev_last_error());
+    for (int l = 0; l < K; ++l)
+      if (target[l] > 0) {
+        b->s[l]->ctl = ctl[l];
+        advance_after_attempts(b->s[l]);
+      }
+  }
+}
+
 
 // every LP of the batch up to max_new_iterations further iterations (or to its verdict); results[l] as cuoptamd_solver_advance's.
 // An LP that finishes rests while the others go on; each LP's trajectory is the one its own cuoptamd_solver_advance would take.
@@ -1313,11 +1477,12 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
   if (!b) return fail(-1, "cuoptamd_batch_advance: null batch");
   const auto t0 = clock_type::now();
   const int K   = b->K;
-  int32_t budget_end[16], target[16];
-  bool done[16];
+  std::vector<int32_t> budget_end(K), target(K);
+  std::vector<char> done(K);
   for (int l = 0; l < K; ++l) {
     cuoptamd_solver* s = b->s[l];
     advance_begin(s, t0);
+    if (s->empty_problem && !s->finished) s->result.status = kNumericalError, s->finished = true;
     done[l]       = s->finished;
     budget_end[l] = advance_budget_end(s, max_new_iterations);
   }
@@ -1330,7 +1495,8 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
     }
     return rc;
   };
-  pdlpdev_ctl ctl[16];
+  if (b->small) return leave(small_batch_advance(b, budget_end, done));
+  std::vector<pdlpdev_ctl> ctl(K);
   for (;;) {
     bool any = false;
     for (int l = 0; l < K; ++l) {
@@ -1343,7 +1509,7 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
       else any = true;
     }
     if (!any) return leave(0);
-    int rc = pdlpdev_batch_run(b->dev, target, ctl);
+    int rc = pdlpdev_batch_run(b->dev, target.data(), ctl.data());
     if (rc != 0) return leave(fail(rc, "pdlpdev_batch_run: %s", pdlpdev_last_error()));
     for (int l = 0; l < K; ++l)
       if (target[l] > 0) {
@@ -1351,6 +1517,76 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
         advance_after_attempts(b->s[l]);
       }
   }
+}
+
+// cuoptamd_solver_reset(lb[l], ub[l], NULL, NULL, NULL, init_x[l], init_y[l]) for every solver of a small-LP batch in ONE launch (the MIP
+// heuristics' re-solve: other variable bounds, the previous primal / dual as the start; relaxed_lp.cu:74-108).  Arrays and entries may
+// be NULL (all four entries NULL: that solver is reset to a cold start under its current bounds).  -7: not a small-LP batch, or a
+// solver whose preset updates step size / primal weight from the initial iterate (none does): use cuoptamd_solver_reset per solver.
+int cuoptamd_batch_reset(cuoptamd_batch* b, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y)
+{
+  if (!b) return fail(-1, "cuoptamd_batch_reset: null batch");
+  if (!b->small) return fail(-7, "cuoptamd_batch_reset: a batch of resident small LPs only");
+  const auto t0 = clock_type::now();
+  const int K   = b->K;
+  std::vector<int32_t> take(K, 1), k(K, -1);
+  std::vector<double> step(K), weight(K);
+  std::vector<pdlpdev_ctl> ctl(K);
+  int project = -1;
+  for (int l = 0; l < K; ++l) {
+    cuoptamd_solver* s = b->s[l];
+    if (s->empty_problem) { take[l] = 0; continue; }
+    if (s->H.update_step_size_on_initial_solution || s->H.update_primal_weight_on_initial_solution || !s->row_new2old.empty())
+      return fail(-7, "cuoptamd_batch_reset: solver %d needs cuoptamd_solver_reset", l);
+    if (project >= 0 && project != (s->H.project_initial_primal ? 1 : 0)) return fail(-7, "cuoptamd_batch_reset: the solvers' presets differ");
+    project   = s->H.project_initial_primal ? 1 : 0;
+    step[l]   = s->S.initial_step_size >= 0.0 ? s->S.initial_step_size : s->computed_step;      // start_run
+    weight[l] = s->S.initial_primal_weight >= 0.0 ? s->S.initial_primal_weight : s->computed_weight;
+    k[l]      = s->S.initial_k;
+  }
+  for (int l = 0; l < K; ++l) reset_host_state(b->s[l]);
+  int rc = pdlpdev_small_batch_reset(b->small, take.data(), lb, ub, init_x, init_y, step.data(), weight.data(), k.data(), std::max(project, 0), ctl.data());
+  if (rc != 0) return fail(rc, "pdlpdev_small_batch_reset: %s", pdlpdev_last_error());
+  const double dt = seconds_since(t0);
+  for (int l = 0; l < K; ++l) {
+    cuoptamd_solver* s = b->s[l];
+    if (!take[l]) continue;
+    if (s->S.relative_primal_tolerance_factor >= 0.0) s->norm_b = s->S.relative_primal_tolerance_factor;
+    if (s->S.relative_dual_tolerance_factor >= 0.0) s->norm_c = s->S.relative_dual_tolerance_factor;
+    s->ctl = ctl[l];
+    s->result.initial_step_size = step[l], s->result.initial_primal_weight = weight[l];
+    s->result.norm_b = s->norm_b, s->result.norm_c = s->norm_c;
+    s->result.step_size = step[l], s->result.primal_weight = weight[l];
+    s->result.setup_seconds = dt;
+  }
+  return 0;
+}
+
+// cuoptamd_solver_get_solution for every solver of a small-LP batch in one launch (arrays and entries may be NULL)
+int cuoptamd_batch_get_solutions(cuoptamd_batch* b, double* const* x, double* const* y, double* const* rc)
+{
+  if (!b) return fail(-1, "cuoptamd_batch_get_solutions: null batch");
+  if (!b->small) {
+    for (int l = 0; l < b->K; ++l) {
+      int rc_ = cuoptamd_solver_get_solution(b->s[l], x ? x[l] : nullptr, y ? y[l] : nullptr, rc ? rc[l] : nullptr);
+      if (rc_ != 0) return rc_;
+    }
+    return 0;
+  }
+  std::vector<int32_t> which(b->K);
+  for (int l = 0; l < b->K; ++l) {
+    cuoptamd_solver* s = b->s[l];
+    which[l] = -1;
+    if (s->empty_problem || !s->dev) {
+      if (x && x[l]) std::fill(x[l], x[l] + s->n, 0.0);
+      if (rc && rc[l]) std::fill(rc[l], rc[l] + s->n, 0.0);
+    } else {
+      which[l] = s->returned_which;
+    }
+  }
+  int rc_ = pdlpdev_small_batch_get_solutions(b->small, which.data(), x, y, rc);
+  if (rc_ != 0) return fail(rc_, "pdlpdev_small_batch_get_solutions: %s", pdlpdev_last_error());
+  return 0;
 }
 
 int cuoptamd_solver_get_solution(cuoptamd_solver* s, double* x, double* y, double* rc)
@@ -1726,6 +1962,59 @@ static int shared_matrix_batch_solve(int32_t count, const cuoptamd_lp* lps, cons
   return 0;
 }
 
+// cuoptamd_batch_solve's path for LPs of resident size, whatever their matrices: every LP gets a solver (created on the worker threads,
+// the solvers of one worker share a stream), then ALL of them advance as one cuoptamd_batch -- a workgroup per LP, one launch per
+// phase of the loop (kernels_resident.hip) -- instead of one host thread per LP driving its own launches.  kNotShared: not this path.
+static int small_lp_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper, const cuoptamd_settings* settings, int device,
+                                int max_threads, cuoptamd_result* results, double** x, double** y, double** rc)
+{
+  for (int i = 0; i < count; ++i) {
+    const cuoptamd_lp& L = lps[i];
+    if (L.m <= 0 || L.n <= 0 || !L.offsets || !pdlpdev_resident_size(L.m, L.n, L.offsets[L.m])) return kNotShared;
+  }
+  const int nt = std::max(1, std::min<int>(std::min<int>(count, 16), max_threads > 0 ? max_threads : cuopt_amd::host_threads()));
+  std::vector<cuoptamd_solver*> sv(count, nullptr);
+  std::vector<int> codes(count, 0);
+  std::vector<std::string> messages(count);
+  auto on_workers = [&](const std::function<void(int, int)>& body) {  // body(worker, LP) for LP = worker, worker + nt, ...
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nt; ++w)
+      pool.emplace_back([&, w] {
+        for (int i = w; i < count; i += nt) body(w, i);
+      });
+    for (auto& t : pool) t.join();
+  };
+  auto destroy_all = [&]() {
+    for (int i = count; i-- > 0;) cuoptamd_solver_destroy(sv[i]);  // (a worker's first solver lent its stream to the later ones)
+  };
+  auto first_error = [&]() -> int {
+    for (int i = 0; i < count; ++i)
+      if (codes[i] != 0) return fail(codes[i], "LP %d of the batch: %s", i, messages[i].c_str());
+    return 0;
+  };
+  on_workers([&](int w, int i) {
+    if (i != w && sv[w]) pdlpdev_create_share_stream(sv[w]->dev);
+    codes[i] = cuoptamd_solver_create(&sv[i], &lps[i], hyper, settings, nullptr, nullptr, device, 0, 1, nullptr);
+    pdlpdev_create_share_stream(nullptr);
+    if (codes[i] != 0) messages[i] = cuoptamd_last_error();
+  });
+  int rc_ = first_error();
+  if (rc_ == 0) {
+    cuoptamd_batch* b = nullptr;
+    rc_ = cuoptamd_batch_create(sv.data(), count, &b);
+    if (rc_ == 0 && !b->small) rc_ = -7;  // (a lockstep batch of big LPs is shared_matrix_batch_solve's business)
+    if (rc_ == 0) rc_ = cuoptamd_batch_advance(b, std::numeric_limits<int32_t>::max(), results);
+    if (rc_ == 0) rc_ = cuoptamd_batch_get_solutions(b, x, y, rc);
+    cuoptamd_batch_destroy(b);
+    if (rc_ == -7) {  // e.g. CUOPT_AMD_SMALL=0: the solvers are not on the resident path
+      destroy_all();
+      return kNotShared;
+    }
+  }
+  destroy_all();
+  return rc_;
+}
+
 extern "C" {
 
 int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_hyper* hyper,
@@ -1734,6 +2023,11 @@ int cuoptamd_batch_solve(int32_t count, const cuoptamd_lp* lps, const cuoptamd_h
 {
   if (count < 0 || (count > 0 && (!lps || !hyper || !settings || !results)))
     return fail(-1, "cuoptamd_batch_solve: null argument");
+  // small LPs (the size of MIP relaxations): all of them at once, a workgroup each (round 6)
+  if (count >= 2 && cuopt_amd::tune_int("small_batch", 1) != 0) {
+    int rc_ = small_lp_batch_solve(count, lps, hyper, settings, device, max_threads, results, x, y, rc);
+    if (rc_ != kNotShared) return rc_;
+  }
   // LPs that share matrix and objective (the MIP heuristics' re-solves: the same A and c under other bounds) go through ONE set-up and
   // advance in lockstep, sixteen, eight or four at a time (cuoptamd_batch_*): each gets, bit for bit, the answer of its own solve
   if (count >= 4 && cuopt_amd::tune_int("shared_batch", 1) != 0) {

@@ -20,11 +20,12 @@ __device__ __forceinline__ void csr_stream_block(int nb, const int32_t* __restri
                                                  const int32_t* __restrict__ indices,
                                                  const double* __restrict__ values,
                                                  const double* __restrict__ vec, Epi& epi,
-                                                 double* __restrict__ partials, const double* __restrict__ dense_add = nullptr)
+                                                 double* __restrict__ partials, const double* __restrict__ dense_add = nullptr,
+                                                 int block = -1 /* >= 0: this row block (batched launches over several matrices) */)
 {
   __shared__ __attribute__((aligned(32))) double prod[kNnzTile];
   __shared__ double red[4 * (Epi::NQ > 0 ? Epi::NQ : 1) + 4];
-  const int b = xcd_remap(blockIdx.x, nb);
+  const int b = block >= 0 ? block : xcd_remap(blockIdx.x, nb);
   if (b >= nb) return;
   const int r0 = row_blocks[b], r1 = row_blocks[b + 1];
   const int k0 = row_blocks[nb + 1 + b], k1 = row_blocks[nb + 2 + b];  // = offsets[r0], offsets[r1] (build_row_blocks)

@@ -147,6 +147,12 @@ int pdlpdev_create(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const in
 /* the NEXT context created by this thread will run behind a communicator (sharded solve): paths that exist on one GPU only --
  * dense row segments, the resident small-LP kernel -- are not set up */
 void pdlpdev_create_hint(int sharded);
+/* the NEXT context created by this thread runs on `donor`'s stream instead of one of its own (NULL: back to own streams).  For
+ * hundreds of small contexts that one host thread drives one after the other or that advance together as a pdlpdev_small_batch:
+ * a stream is a hardware queue (~2 ms to create, a few per process).  The donor must be destroyed after its borrowers. */
+void pdlpdev_create_share_stream(pdlpdev_ctx* donor);
+/* 1: an LP of this size takes the resident small-LP path (one workgroup, pdlpdev_small_batch eligible) unless CUOPT_AMD_SMALL=0 */
+int pdlpdev_resident_size(int32_t m, int32_t n, int64_t nnz);
 int pdlpdev_create_overlapped(pdlpdev_ctx** out, int device, int32_t m, int32_t n, const int32_t* a_offsets,
                               const int32_t* a_indices, const double* a_values, const int32_t* at_offsets,
                               const int32_t* at_indices, const double* at_values,
@@ -295,6 +301,42 @@ void pdlpdev_batch_destroy(pdlpdev_batch* batch);
 /* average dispatch durations (ms) of the four kernels of a batched attempt {primal, A / dual, A^T / step, decisions}: whole attempts in
  * the loop's order, every LP forced active, the dispatches' own timestamps; state is put back (bench.py's roofline of the batch line) */
 int pdlpdev_batch_time_kernels(pdlpdev_batch* batch, int reps, double avg_ms[4]);
+/* ---- K SMALL LPs in K workgroups (round 6; BASELINE config 5 at branch-and-bound scale: the reference's batch entry,
+ * cpp/src/linear_programming/utilities/cython_solve.cu:264-296, is a thread pool of independent solves, and the MIP heuristics fire
+ * thousands of relaxations, cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-127).  An LP on the resident small-LP path runs its whole loop in
+ * ONE workgroup on ONE of the chip's 256 CUs; a batch of K such contexts (any matrices, any resident tier, one device) advances with
+ * one launch per phase: blockIdx <-> LP.  Every kernel body is the single LP's, so each LP's trajectory is BIT-IDENTICAL to the one
+ * pdlpdev_run / pdlpdev_major_eval / pdlpdev_restart give it.  -7: a context is not on the resident path.  The contexts must be idle
+ * (no per-context call in flight) while a batch call runs; the batch holds plain pointers -- destroy it before its contexts. */
+typedef struct pdlpdev_small_batch pdlpdev_small_batch;
+typedef struct pdlpdev_small_eval {
+  int32_t mode;        /* average mode of pdlpdev_major_eval (0, 1, 2); < 0: this LP is not evaluated */
+  int32_t rule_finite; /* rc_rule_finite_bounds */
+  double eps_p, eps_d; /* eps_rel_primal / eps_rel_dual (negative: no l-infinity residuals) */
+} pdlpdev_small_eval;
+int pdlpdev_small_batch_create(pdlpdev_small_batch** out, pdlpdev_ctx** ctx, int K);
+void pdlpdev_small_batch_destroy(pdlpdev_small_batch* batch);
+/* pdlpdev_run for every LP with targets[l] > 0 (the others rest); ctl[l] receives its control block.  eval_after (may be NULL): for LPs
+ * with eval_after[l].mode >= 0 the pdlpdev_major_eval that follows the attempts is enqueued behind them (one synchronisation for
+ * both) and runs iff the attempts reached targets[l] or raised the step-size error: evaluated[l] = 1 and out_current / out_average
+ * (PDLPDEV_EV_COUNT doubles per LP) are filled then. */
+int pdlpdev_small_batch_run(pdlpdev_small_batch* batch, const int32_t* targets, pdlpdev_ctl* ctl, const pdlpdev_small_eval* eval_after,
+                            double* out_current, double* out_average, int32_t* evaluated);
+/* pdlpdev_major_eval for every LP with req[l].mode >= 0; PDLPDEV_EV_COUNT doubles per LP in out_current / out_average */
+int pdlpdev_small_batch_major_eval(pdlpdev_small_batch* batch, const pdlpdev_small_eval* req, double* out_current, double* out_average);
+/* pdlpdev_restart for every LP with which[l] >= 0; dist2[2 l], dist2[2 l + 1] */
+int pdlpdev_small_batch_restart(pdlpdev_small_batch* batch, const int32_t* which, const int32_t* unscaled_distances, double* dist2);
+/* in front of the next attempts: pdlpdev_clear_error where clear_error[l] != 0, pdlpdev_set_step(-1, primal_weight[l]) where
+ * primal_weight[l] > 0, pdlpdev_compute_aty where compute_aty[l] != 0 (any array may be NULL) */
+int pdlpdev_small_batch_prepare(pdlpdev_small_batch* batch, const int32_t* clear_error, const double* primal_weight, const int32_t* compute_aty);
+/* the re-solve pattern (relaxed_lp.cu:74-108) for every LP with take[l] != 0, in one launch: what pdlpdev_reset(lb[l], ub[l], NULL, NULL) +
+ * pdlpdev_set_step(step[l], weight[l]) + pdlpdev_set_k(k[l] when >= 0) + pdlpdev_set_initial(x0[l], y0[l]) + pdlpdev_project_primal (when
+ * project != 0) + pdlpdev_get_ctl do for one LP, bit for bit.  lb / ub / x0 / y0 / k may be NULL, and so may their entries (unchanged
+ * bounds, a zero start).  Row bounds do not change here. */
+int pdlpdev_small_batch_reset(pdlpdev_small_batch* batch, const int32_t* take, const double* const* lb, const double* const* ub, const double* const* x0,
+                              const double* const* y0, const double* step, const double* weight, const int32_t* k, int project, pdlpdev_ctl* ctl);
+/* pdlpdev_get_solution(which[l], x[l], y[l], rc[l]) for every LP with which[l] >= 0 in one launch (arrays and entries may be NULL) */
+int pdlpdev_small_batch_get_solutions(pdlpdev_small_batch* batch, const int32_t* which, double* const* x, double* const* y, double* const* rc);
 /* re-arm the loop after the step-size error flag was raised (take_step resets valid_step_size_,
  * pdlp.cu:1190) */
 int pdlpdev_clear_error(pdlpdev_ctx* ctx);

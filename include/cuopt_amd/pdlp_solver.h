@@ -252,6 +252,14 @@ int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const doubl
                           const cuoptamd_settings* settings, cuoptamd_solver** out);
 int cuoptamd_batch_create(cuoptamd_solver** solvers, int K, cuoptamd_batch** out);
 int cuoptamd_batch_advance(cuoptamd_batch* batch, int32_t max_new_iterations, cuoptamd_result* results);
+/* ---- small-LP batch (round 6): cuoptamd_batch_create over solvers on the resident small-LP path takes ANY number of them, whatever their
+ * matrices -- one workgroup per LP, one launch per phase of the loop (pdlpdev_small_batch_* in pdlp_device.h; BASELINE config 5 at
+ * branch-and-bound scale, cython_solve.cu:264-296 / relaxed_lp.cu:53-127).  Bit-identical to cuoptamd_solver_advance per solver.
+ * cuoptamd_batch_reset: cuoptamd_solver_reset(lb[l], ub[l], NULL, NULL, NULL, init_x[l], init_y[l]) for every solver in one launch
+ * (arrays and entries may be NULL); -7 when the batch is not a small-LP batch.
+ * cuoptamd_batch_get_solutions: cuoptamd_solver_get_solution for every solver in one launch (any batch; arrays / entries may be NULL). */
+int cuoptamd_batch_reset(cuoptamd_batch* batch, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y);
+int cuoptamd_batch_get_solutions(cuoptamd_batch* batch, double* const* x, double* const* y, double* const* rc);
 void cuoptamd_batch_destroy(cuoptamd_batch* batch);
 /* the device-layer batch behind it (pdlpdev_batch_time_kernels) */
 struct pdlpdev_batch* cuoptamd_batch_device(cuoptamd_batch* batch);
