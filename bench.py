@@ -281,73 +281,68 @@ def small_batch_line(args, K, local_rank, record_fd):
         return out
 
     def branch(l, lb, ub, x, rng):
-        """the node's next child: an integer variable with a fractional relaxation value (a random integer one when all are integral)"""
+        """the node's next child: an integer variable with a fractional relaxation value (a random integer one when all are integral);
+        returns the variable (-1: none)"""
         frac = np.abs(x - np.round(x))
         cand = np.flatnonzero(integer & (frac > 1e-3) & (ub - lb >= 1.0))
         if len(cand) == 0:
             cand = np.flatnonzero(integer & (ub - lb >= 1.0))
         if len(cand) == 0:
-            return
+            return -1
         j = int(rng.choice(cand))
         if l % 2 == 0:
             ub[j] = max(np.floor(x[j]), lb[j])
         else:
             lb[j] = min(np.ceil(x[j]), ub[j])
+        return j
 
-    def run(solvers, advance_all, label, batch=None, executor=None):
-        """the node sequence through `solvers`; advance_all(list of solvers) -> list of results.  Same seeds, same branches.  batch: resets
-        and solution read-backs go through the batch's one-launch calls (cuoptamd_batch_reset / cuoptamd_batch_get_solutions)."""
+    def run(solvers, label, batch=None, executor=None):
+        """the node sequence through `solvers`, same seeds and branches whoever solves.  batch: one cuoptamd_batch_branch per round (a
+        variable and its new bounds per node, the start taken from the node's own last solution on the device), one
+        cuoptamd_batch_advance, one cuoptamd_batch_solution_views.  executor: a worker of the pool takes a node through
+        cuoptamd_solver_reset (full bounds + the solution read back), cuoptamd_solver_advance and cuoptamd_solver_get_solution.
+        The choice of the branching variables is the caller's tree logic: timed, reported, not part of either rate."""
         rng = np.random.default_rng(17)
         k = len(solvers)
         lbs, ubs = [base["lb"].copy() for _ in range(k)], [base["ub"].copy() for _ in range(k)]
-        prev = [None] * k
-        t = dict(reset=0.0, advance=0.0, solution=0.0)
+        t = dict(choose_branches=0.0, reset=0.0, advance=0.0, solution=0.0)
         its, statuses, objs = 0, {}, []
+        prev = None
         for r in range(rounds + 1):  # round 0: the root relaxation in every node (cold)
             t0 = time.perf_counter()
-            if r and executor is not None:  # the pool's way: every worker takes a node through reset, solve and read-back on its own
+            var = np.full(k, -1, np.int32)
+            if r:
                 for l in range(k):
-                    branch(l, lbs[l], ubs[l], prev[l][0], rng)
-
+                    var[l] = branch(l, lbs[l], ubs[l], prev[l][0], rng)
+            t1 = time.perf_counter()
+            if executor is not None:
                 def node(l):
-                    solvers[l].reset(lb=lbs[l], ub=ubs[l], init_x=prev[l][0], init_y=prev[l][1])
+                    if r:
+                        solvers[l].reset(lb=lbs[l], ub=ubs[l], init_x=prev[l][0], init_y=prev[l][1])
                     return solvers[l].advance(), solvers[l].solution()
-                t1 = time.perf_counter()
                 both = list(executor.map(node, range(k)))
                 rs, prev = [q[0] for q in both], [q[1] for q in both]
-                t2 = t3 = time.perf_counter()
-                t["reset"] += t1 - t0
-                t["advance"] += t2 - t1
-                its += sum(q["steps_taken"] for q in rs)
-                for q in rs:
-                    statuses[q["status_name"]] = statuses.get(q["status_name"], 0) + 1
-                objs.append([q["primal_objective"] for q in rs])
-                continue
-            if r:
-                for l, s in enumerate(solvers):
-                    branch(l, lbs[l], ubs[l], prev[l][0], rng)
-                    if batch is None:
-                        s.reset(lb=lbs[l], ub=ubs[l], init_x=prev[l][0], init_y=prev[l][1])
-                if batch is not None:
-                    batch.reset(lb=lbs, ub=ubs, init_x=[v[0] for v in prev], init_y=[v[1] for v in prev])
-            t1 = time.perf_counter()
-            rs = advance_all(solvers)
-            t2 = time.perf_counter()
-            if batch is not None:
-                prev = batch.solutions()
+                t2, t3 = t1, time.perf_counter()  # (the worker's reset + advance + read-back: all under "advance")
+                t4 = t3
             else:
-                for l, s in enumerate(solvers):
-                    prev[l] = s.solution()
-            t3 = time.perf_counter()
+                if r:
+                    jv = np.maximum(var, 0)
+                    batch.branch(var, np.array([lbs[l][jv[l]] for l in range(k)]), np.array([ubs[l][jv[l]] for l in range(k)]))
+                t2 = time.perf_counter()
+                rs = batch.advance()
+                t3 = time.perf_counter()
+                prev = batch.solution_views()
+                t4 = time.perf_counter()
             if r:  # the re-solves are what is measured
-                t["reset"] += t1 - t0
-                t["advance"] += t2 - t1
-                t["solution"] += t3 - t2
+                t["choose_branches"] += t1 - t0
+                t["reset"] += t2 - t1
+                t["advance"] += t3 - t2
+                t["solution"] += t4 - t3
                 its += sum(q["steps_taken"] for q in rs)
                 for q in rs:
                     statuses[q["status_name"]] = statuses.get(q["status_name"], 0) + 1
                 objs.append([q["primal_objective"] for q in rs])
-        total = sum(t.values())
+        total = t["reset"] + t["advance"] + t["solution"]
         return dict(label=label, lps=k * rounds, iterations=its, seconds={a: round(b, 4) for a, b in t.items()}, lps_per_sec=round(k * rounds / total, 1),
                     lps_per_sec_advance_only=round(k * rounds / t["advance"], 1), its_per_sec_advance=round(its / t["advance"], 1), statuses=statuses), objs, (lbs, ubs)
 
@@ -356,9 +351,10 @@ def small_batch_line(args, K, local_rank, record_fd):
     batch = capi.SmallBatch(solvers)
     create_s = time.perf_counter() - t0
     layout = solvers[0].device.layout()
-    run(solvers[:], lambda ss: batch.advance(), "warm-up", batch)  # clocks, code objects, the allocator's pools
+    run(solvers, "warm-up", batch=batch)  # clocks, code objects, the allocator's pools
     batch.reset(lb=[base["lb"]] * K, ub=[base["ub"]] * K)
-    got, objs, (lbs, ubs) = run(solvers, lambda ss: batch.advance(), "small-LP batch: %d workgroups per launch" % K, batch)
+    got, objs, (lbs, ubs) = run(solvers, "small-LP batch: %d workgroups per launch; per round one cuoptamd_batch_branch, one cuoptamd_batch_advance, "
+                                "one cuoptamd_batch_solution_views" % K, batch=batch)
     batch.close()
     for s in reversed(solvers):
         s.close()
@@ -366,12 +362,11 @@ def small_batch_line(args, K, local_rank, record_fd):
     kp = min(K, 64)
     pool_solvers = make(kp, False)
     ex = concurrent.futures.ThreadPoolExecutor(max_workers=16)
-    adv = lambda ss: list(ex.map(lambda s: s.advance(), ss))
-    run(pool_solvers, adv, "warm-up")
+    run(pool_solvers, "warm-up", executor=ex)
     for s in pool_solvers:
         s.reset(lb=base["lb"], ub=base["ub"])
-    pool, pobjs, _ = run(pool_solvers, adv, "thread pool: 16 host threads over %d solvers (one stream each); a worker takes a node through reset, solve and read-back "
-                         "('advance' = all three, 'reset' = choosing the branches)" % kp, executor=ex)
+    pool, pobjs, _ = run(pool_solvers, "thread pool: 16 host threads over %d solvers (one stream each); a worker takes a node through reset, solve and read-back "
+                         "(all three under 'advance')" % kp, executor=ex)
     ex.shutdown()
     for s in pool_solvers:
         s.close()
@@ -405,7 +400,7 @@ def small_batch_line(args, K, local_rank, record_fd):
                                "re-solve to the default 1e-4 (iteration limit %d), Stable2 preset; persistent solvers, one small-LP batch" % (args.workload, K, rounds, limit),
                    "rows": m, "cols": n, "nnz": nnz, "lps": K, "rounds": rounds, "parallelism": "single GPU, %d LPs in %d workgroups per launch" % (K, K)},
         "batch": got, "thread_pool": pool, "batch_over_thread_pool_lps_per_sec": round(got["lps_per_sec"] / pool["lps_per_sec"], 2),
-        "batch_over_thread_pool_advance_only": round(got["lps_per_sec_advance_only"] / pool["lps_per_sec_advance_only"], 2),
+
         "same_objectives_as_the_thread_pool": same, "create_seconds_per_lp": round(create_s / K, 5),
         "roofline": dict(bound="hbm", kernel="k_pdhg_resident_batch", achieved=round(eq, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(eq / HBM_PEAK_GBS, 5), traffic=None,
                          note="the LP lives in registers and LDS of its workgroup: NOTHING is re-read from HBM inside the loop, so the HBM roofline does not bound this kernel -- "

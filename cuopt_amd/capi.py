@@ -306,6 +306,8 @@ _proto("cuoptamd_batch_advance", c_int, c_void_p, c_int, c_void_p)
 _proto("cuoptamd_batch_destroy", None, c_void_p)
 _proto("cuoptamd_batch_reset", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_batch_get_solutions", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuoptamd_batch_branch", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+_proto("cuoptamd_batch_solution_views", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_batch_device", c_void_p, c_void_p)
 _proto("pdlpdev_create_share_stream", None, c_void_p)
 _proto("pdlpdev_resident_size", c_int, c_int, c_int, C.c_int64)
@@ -805,6 +807,31 @@ class SharedMatrixBatch:
             raise CuOptError(rc, lib.cuoptamd_last_error().decode())
         for s in self.solvers:
             s.result = Result()
+
+    def branch(self, var, lb, ub):
+        """cuoptamd_batch_branch: variable var[l] of solver l gets the bounds [lb[l], ub[l]] (var[l] < 0: none), every solver starts again
+        from the primal / dual its last solve returned; one launch, nothing but the three arrays crosses PCIe"""
+        v, a, c = _i32(var), _f64(lb), _f64(ub)
+        rc = lib.cuoptamd_batch_branch(self.handle, _ptr(v), _ptr(a), _ptr(c))
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        for s in self.solvers:
+            s.result = Result()
+
+    def solution_views(self):
+        """cuoptamd_batch_solution_views: [(x, y, reduced costs)] as numpy views of the batch's pinned staging block -- no copies; valid
+        until the next reset / branch / solutions call of this batch"""
+        k = len(self.solvers)
+        px, py, pz = (c_void_p * k)(), (c_void_p * k)(), (c_void_p * k)()
+        rc = lib.cuoptamd_batch_solution_views(self.handle, px, py, pz)
+        if rc != 0:
+            raise CuOptError(rc, lib.cuoptamd_last_error().decode())
+        key = (tuple(px), tuple(py), tuple(pz))  # (the staging block does not move: the numpy views are built once)
+        if getattr(self, "_view_key", None) != key:
+            view = lambda p, n: np.ctypeslib.as_array(C.cast(p, P(c_double)), shape=(n,)) if p else np.zeros(n)
+            self._views = [(view(px[i], s.n), view(py[i], s.m), view(pz[i], s.n)) for i, s in enumerate(self.solvers)]
+            self._view_key = key
+        return self._views
 
     def solutions(self):
         """cuoptamd_batch_get_solutions: [(x, y, reduced costs)] of every solver, one launch"""

@@ -439,6 +439,9 @@ __global__ void __launch_bounds__(kBlock) k_ctl_ops_batch(const CtlOp* __restric
 // pdlpdev_project_primal + pdlpdev_get_ctl do one call after the other -- the same expressions, element by element.
 struct SmallResetArgs {
   int n, m, k, project;
+  int var, warm;          // var >= 0: the bounds of this ONE variable become [var_lb, var_ub] (a branch); warm (PDLPDEV_CURRENT / AVERAGE /
+  double var_lb, var_ub;  // BEST, < 0 none): start from that iterate of the LP itself -- unscaled and scaled again like a trip through the host
+  const double *bestx, *besty;
   const double *lb_new, *ub_new, *x0, *y0;  // staging (device-visible host memory); NULL: bounds unchanged / start from zero
   double *lb_u, *ub_u, *lb, *ub;
   const double *dc, *dr;
@@ -449,18 +452,28 @@ struct SmallResetArgs {
 __global__ void __launch_bounds__(512) k_small_reset_batch(const SmallResetArgs* __restrict__ args, const int* __restrict__ list)
 {
   const SmallResetArgs& A = args[list[blockIdx.x]];
+  const int cur    = A.ctl->cur;  // (read by every thread before thread 0 rewrites the control block: the loops below end in a barrier-free
+  __syncthreads();                //  store by thread 0 only after this barrier)
+  const double* wx = A.warm == PDLPDEV_BEST ? A.bestx : A.warm == PDLPDEV_AVERAGE ? A.avgx : A.x[cur];
+  const double* wy = A.warm == PDLPDEV_BEST ? A.besty : A.warm == PDLPDEV_AVERAGE ? A.avgy : A.y[cur];
   for (int j = threadIdx.x; j < A.n; j += 512) {
     if (A.lb_new) A.lb_u[j] = A.lb_new[j], A.lb[j] = A.lb_new[j] / A.dc[j];  // k_scale_bounds
     if (A.ub_new) A.ub_u[j] = A.ub_new[j], A.ub[j] = A.ub_new[j] / A.dc[j];
+    if (j == A.var) {
+      A.lb_u[j] = A.var_lb, A.lb[j] = A.var_lb / A.dc[j];
+      A.ub_u[j] = A.var_ub, A.ub[j] = A.var_ub / A.dc[j];
+    }
     const double lo = A.lb[j], hi = A.ub[j];
     double x = A.x0 ? A.x0[j] / A.dc[j] : 0.0;  // k_div_inplace (set_initial) on a zeroed iterate
+    if (A.warm >= 0) x = (wx[j] * A.dc[j]) / A.dc[j];  // k_unscale (what the caller would have read back), then set_initial
     double avg = 0.0;
     if (A.project) x = dmin(dmax(x, lo), hi), avg = dmin(dmax(avg, lo), hi);  // k_clamp on the iterate and on the average
     A.x[0][j] = x, A.x[1][j] = 0.0, A.aty[0][j] = 0.0, A.aty[1][j] = 0.0, A.rc[0][j] = 0.0, A.rc[1][j] = 0.0;
     A.xbar[j] = 0.0, A.sumx[j] = 0.0, A.avgx[j] = avg, A.lrx[j] = 0.0;
   }
   for (int i = threadIdx.x; i < A.m; i += 512) {
-    A.y[0][i] = A.y0 ? A.y0[i] / A.dr[i] : 0.0, A.y[1][i] = 0.0;
+    const double y = A.warm >= 0 ? (wy[i] * A.dr[i]) / A.dr[i] : (A.y0 ? A.y0[i] / A.dr[i] : 0.0);
+    A.y[0][i] = y, A.y[1][i] = 0.0;
     A.sumy[i] = 0.0, A.avgy[i] = 0.0, A.lry[i] = 0.0;
   }
   if (threadIdx.x == 0) {
@@ -727,7 +740,8 @@ int pdlpdev_small_batch_prepare(pdlpdev_small_batch* b, const int32_t* clear_err
 // pdlpdev_reset(lb, ub, NULL, NULL), pdlpdev_set_step, pdlpdev_set_k, pdlpdev_set_initial, pdlpdev_project_primal and pdlpdev_get_ctl
 // do for one LP, bit for bit, in ONE launch.
 int pdlpdev_small_batch_reset(pdlpdev_small_batch* b, const int32_t* take, const double* const* lb, const double* const* ub, const double* const* x0,
-                              const double* const* y0, const double* step, const double* weight, const int32_t* k, int project, pdlpdev_ctl* ctl)
+                              const double* const* y0, const double* step, const double* weight, const int32_t* k, int project, pdlpdev_ctl* ctl,
+                              const int32_t* var, const double* var_lb, const double* var_ub, const int32_t* warm)
 {
   HIP_TRY(hipSetDevice(b->device));
   int count = 0;
@@ -745,7 +759,12 @@ int pdlpdev_small_batch_reset(pdlpdev_small_batch* b, const int32_t* take, const
     if (x0 && x0[l]) memcpy(st + 2 * n, x0[l], n * sizeof(double)), sx = st + 2 * n;
     if (y0 && y0[l]) memcpy(st + 3 * n, y0[l], m * sizeof(double)), sy = st + 3 * n;
     c->note_uniform_bounds(lb ? lb[l] : nullptr, ub ? ub[l] : nullptr);
-    b->reset[l] = SmallResetArgs{c->n, c->m, k ? k[l] : -1, project, slb, sub, sx, sy, c->lb_u, c->ub_u, c->lb, c->ub, c->dc, c->dr,
+    const int v = var ? var[l] : -1, wm = warm ? warm[l] : -1;
+    if (v >= c->n) return fail(-1, "pdlpdev_small_batch_reset: LP %d has no variable %d", l, v);
+    if (v >= 0) c->ubd.lb_same = 0, c->ubd.ub_same = 0;  // (one bound differs from the others now, or may)
+    if (wm == PDLPDEV_BEST && !c->bestx) return fail(-1, "pdlpdev_small_batch_reset: LP %d saved no best iterate to start from", l);
+    b->reset[l] = SmallResetArgs{c->n, c->m, k ? k[l] : -1, project, v, wm, v >= 0 ? var_lb[l] : 0.0, v >= 0 ? var_ub[l] : 0.0, c->bestx, c->besty,
+                                 slb, sub, sx, sy, c->lb_u, c->ub_u, c->lb, c->ub, c->dc, c->dr,
                                  {c->x[0], c->x[1]}, {c->aty[0], c->aty[1]}, {c->rc[0], c->rc[1]}, {c->y[0], c->y[1]}, c->xbar, c->sumx, c->avgx, c->lrx,
                                  c->sumy, c->avgy, c->lry, c->ctl, c->ctl_h, step[l], weight[l]};
     b->list[count++] = l;
@@ -757,6 +776,35 @@ int pdlpdev_small_batch_reset(pdlpdev_small_batch* b, const int32_t* take, const
   if (ctl)
     for (int l = 0; l < b->K; ++l)
       if (take[l]) ctl[l] = *b->ctx[l]->ctl_h;
+  return 0;
+}
+
+// the same without the copies: x_view[l] / y_view[l] / rc_view[l] point INTO the batch's pinned staging block (valid until the next
+// pdlpdev_small_batch_reset / _get_solutions / _solution_views call of this batch)
+int pdlpdev_small_batch_solution_views(pdlpdev_small_batch* b, const int32_t* which, const double** x_view, const double** y_view, const double** rc_view)
+{
+  HIP_TRY(hipSetDevice(b->device));
+  int count = 0;
+  for (int l = 0; l < b->K; ++l) {
+    if (x_view) x_view[l] = nullptr;
+    if (y_view) y_view[l] = nullptr;
+    if (rc_view) rc_view[l] = nullptr;
+    if (which[l] < 0) continue;
+    pdlpdev_ctx* c = b->ctx[l];
+    if (which[l] == PDLPDEV_BEST && !c->bestx) return fail(-1, "pdlpdev_small_batch_solution_views: LP %d saved no best iterate", l);
+    const size_t n = (size_t)c->n;
+    double* st     = b->staging + b->stage_off[l];
+    b->sol[l] = SmallSolutionArgs{c->n, c->m, which[l], c->ctl, c->x[0], c->x[1], c->y[0], c->y[1], c->avgx, c->avgy, c->bestx, c->besty, c->bestrc,
+                                  c->rc[0], c->rc[1], c->dc, c->dr, x_view ? st : nullptr, y_view ? st + 2 * n : nullptr, rc_view ? st + n : nullptr};
+    if (x_view) x_view[l] = st;
+    if (rc_view) rc_view[l] = st + n;
+    if (y_view) y_view[l] = st + 2 * n;
+    b->list[count++] = l;
+  }
+  if (!count) return 0;
+  k_small_solution_batch<<<count, 512, 0, b->stream>>>(b->sol, b->list);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 

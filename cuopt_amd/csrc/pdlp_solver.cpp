@@ -1523,13 +1523,14 @@ int cuoptamd_batch_advance(cuoptamd_batch* b, int32_t max_new_iterations, cuopta
 // heuristics' re-solve: other variable bounds, the previous primal / dual as the start; relaxed_lp.cu:74-108).  Arrays and entries may
 // be NULL (all four entries NULL: that solver is reset to a cold start under its current bounds).  -7: not a small-LP batch, or a
 // solver whose preset updates step size / primal weight from the initial iterate (none does): use cuoptamd_solver_reset per solver.
-int cuoptamd_batch_reset(cuoptamd_batch* b, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y)
+static int batch_reset_impl(cuoptamd_batch* b, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y,
+                            const int32_t* var, const double* var_lb, const double* var_ub, bool warm_from_own)
 {
   if (!b) return fail(-1, "cuoptamd_batch_reset: null batch");
   if (!b->small) return fail(-7, "cuoptamd_batch_reset: a batch of resident small LPs only");
   const auto t0 = clock_type::now();
   const int K   = b->K;
-  std::vector<int32_t> take(K, 1), k(K, -1);
+  std::vector<int32_t> take(K, 1), k(K, -1), warm(K, -1);
   std::vector<double> step(K), weight(K);
   std::vector<pdlpdev_ctl> ctl(K);
   int project = -1;
@@ -1543,9 +1544,11 @@ int cuoptamd_batch_reset(cuoptamd_batch* b, const double* const* lb, const doubl
     step[l]   = s->S.initial_step_size >= 0.0 ? s->S.initial_step_size : s->computed_step;      // start_run
     weight[l] = s->S.initial_primal_weight >= 0.0 ? s->S.initial_primal_weight : s->computed_weight;
     k[l]      = s->S.initial_k;
+    if (warm_from_own) warm[l] = s->returned_which;  // what cuoptamd_solver_get_solution would have handed the caller
   }
   for (int l = 0; l < K; ++l) reset_host_state(b->s[l]);
-  int rc = pdlpdev_small_batch_reset(b->small, take.data(), lb, ub, init_x, init_y, step.data(), weight.data(), k.data(), std::max(project, 0), ctl.data());
+  int rc = pdlpdev_small_batch_reset(b->small, take.data(), lb, ub, init_x, init_y, step.data(), weight.data(), k.data(), std::max(project, 0), ctl.data(), var,
+                                     var_lb, var_ub, warm_from_own ? warm.data() : nullptr);
   if (rc != 0) return fail(rc, "pdlpdev_small_batch_reset: %s", pdlpdev_last_error());
   const double dt = seconds_since(t0);
   for (int l = 0; l < K; ++l) {
@@ -1560,6 +1563,20 @@ int cuoptamd_batch_reset(cuoptamd_batch* b, const double* const* lb, const doubl
     s->result.setup_seconds = dt;
   }
   return 0;
+}
+
+int cuoptamd_batch_reset(cuoptamd_batch* b, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y)
+{
+  return batch_reset_impl(b, lb, ub, init_x, init_y, nullptr, nullptr, nullptr, false);
+}
+
+// One branch-and-bound step in every node of the batch, one launch, three scalars per node across PCIe: the bounds of variable var[l]
+// of solver l become [lb[l], ub[l]] (var[l] < 0: unchanged), and the solver starts again from the primal / dual its LAST solve
+// returned -- exactly cuoptamd_solver_reset(full lb, full ub, NULL, NULL, NULL, x, y) with (x, y) = cuoptamd_solver_get_solution,
+// without the two trips through the host (relaxed_lp.cu:74-108 keeps bounds and lp_state on the device in the same way).
+int cuoptamd_batch_branch(cuoptamd_batch* b, const int32_t* var, const double* lb, const double* ub)
+{
+  return batch_reset_impl(b, nullptr, nullptr, nullptr, nullptr, var, lb, ub, true);
 }
 
 // cuoptamd_solver_get_solution for every solver of a small-LP batch in one launch (arrays and entries may be NULL)
@@ -1586,6 +1603,19 @@ int cuoptamd_batch_get_solutions(cuoptamd_batch* b, double* const* x, double* co
   }
   int rc_ = pdlpdev_small_batch_get_solutions(b->small, which.data(), x, y, rc);
   if (rc_ != 0) return fail(rc_, "pdlpdev_small_batch_get_solutions: %s", pdlpdev_last_error());
+  return 0;
+}
+
+// the same without the copies: x[l] / y[l] / rc[l] receive pointers INTO the batch's pinned staging block (any of the three arrays may
+// be NULL), valid until the next cuoptamd_batch_reset / _branch / _get_solutions / _solution_views of this batch.  Small-LP batches only.
+int cuoptamd_batch_solution_views(cuoptamd_batch* b, const double** x, const double** y, const double** rc)
+{
+  if (!b) return fail(-1, "cuoptamd_batch_solution_views: null batch");
+  if (!b->small) return fail(-7, "cuoptamd_batch_solution_views: a batch of resident small LPs only");
+  std::vector<int32_t> which(b->K);
+  for (int l = 0; l < b->K; ++l) which[l] = (b->s[l]->empty_problem || !b->s[l]->dev) ? -1 : b->s[l]->returned_which;
+  int rc_ = pdlpdev_small_batch_solution_views(b->small, which.data(), x, y, rc);
+  if (rc_ != 0) return fail(rc_, "pdlpdev_small_batch_solution_views: %s", pdlpdev_last_error());
   return 0;
 }
 

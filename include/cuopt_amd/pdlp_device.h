@@ -334,7 +334,13 @@ int pdlpdev_small_batch_prepare(pdlpdev_small_batch* batch, const int32_t* clear
  * project != 0) + pdlpdev_get_ctl do for one LP, bit for bit.  lb / ub / x0 / y0 / k may be NULL, and so may their entries (unchanged
  * bounds, a zero start).  Row bounds do not change here. */
 int pdlpdev_small_batch_reset(pdlpdev_small_batch* batch, const int32_t* take, const double* const* lb, const double* const* ub, const double* const* x0,
-                              const double* const* y0, const double* step, const double* weight, const int32_t* k, int project, pdlpdev_ctl* ctl);
+                              const double* const* y0, const double* step, const double* weight, const int32_t* k, int project, pdlpdev_ctl* ctl,
+                              const int32_t* var, const double* var_lb, const double* var_ub, const int32_t* warm);
+/* (var / var_lb / var_ub, may be NULL: a BRANCH -- the bounds of variable var[l] >= 0 of LP l become [var_lb[l], var_ub[l]], nothing
+ *  crosses PCIe but three scalars; warm, may be NULL: warm[l] = PDLPDEV_CURRENT / AVERAGE / BEST starts LP l from that iterate of ITS
+ *  OWN last solve, unscaled and scaled again on the device exactly as a read-back + set_initial would -- x0 / y0 are ignored then) */
+/* the solutions without the copies: pointers into the batch's pinned staging block, valid until the next reset / solutions call */
+int pdlpdev_small_batch_solution_views(pdlpdev_small_batch* batch, const int32_t* which, const double** x_view, const double** y_view, const double** rc_view);
 /* pdlpdev_get_solution(which[l], x[l], y[l], rc[l]) for every LP with which[l] >= 0 in one launch (arrays and entries may be NULL) */
 int pdlpdev_small_batch_get_solutions(pdlpdev_small_batch* batch, const int32_t* which, double* const* x, double* const* y, double* const* rc);
 /* re-arm the loop after the step-size error flag was raised (take_step resets valid_step_size_,

@@ -260,6 +260,13 @@ int cuoptamd_batch_advance(cuoptamd_batch* batch, int32_t max_new_iterations, cu
  * cuoptamd_batch_get_solutions: cuoptamd_solver_get_solution for every solver in one launch (any batch; arrays / entries may be NULL). */
 int cuoptamd_batch_reset(cuoptamd_batch* batch, const double* const* lb, const double* const* ub, const double* const* init_x, const double* const* init_y);
 int cuoptamd_batch_get_solutions(cuoptamd_batch* batch, double* const* x, double* const* y, double* const* rc);
+/* cuoptamd_batch_branch: one branch-and-bound step per node in ONE launch -- the bounds of variable var[l] of solver l become
+ * [lb[l], ub[l]] (var[l] < 0: none) and the solver starts again from the primal / dual its last solve returned, all on the device
+ * (relaxed_lp.cu:74-108); bit for bit cuoptamd_solver_reset(full bounds, solution of cuoptamd_solver_get_solution).
+ * cuoptamd_batch_solution_views: the solutions as pointers into the batch's pinned staging block (no copies; valid until the next
+ * reset / branch / solutions call of the batch). */
+int cuoptamd_batch_branch(cuoptamd_batch* batch, const int32_t* var, const double* lb, const double* ub);
+int cuoptamd_batch_solution_views(cuoptamd_batch* batch, const double** x, const double** y, const double** rc);
 void cuoptamd_batch_destroy(cuoptamd_batch* batch);
 /* the device-layer batch behind it (pdlpdev_batch_time_kernels) */
 struct pdlpdev_batch* cuoptamd_batch_device(cuoptamd_batch* batch);

@@ -159,6 +159,45 @@ def test_re_solves_through_one_batch(golden_problems):
     batch.close()
 
 
+def test_branching_on_the_device_equals_the_trip_through_the_host(golden_problems):
+    """cuoptamd_batch_branch (one variable's bounds + a start from the solver's own last solution, all on the device) against
+    Solver.reset(full bounds, the solution read back) per solver: same re-solves bit for bit, over three levels of a tree"""
+    rng = np.random.default_rng(23)
+    base = relaxation(golden_problems, "mip-50v-10-free-bound-relaxation")
+    K = 24
+    ones = [capi.Solver(base, tol=1e-5, iteration_limit=LIMIT) for _ in range(K)]
+    many = [capi.Solver(base, tol=1e-5, iteration_limit=LIMIT) for _ in range(K)]
+    batch = capi.SmallBatch(many)
+    lbs, ubs = [np.array(base["lb"], float) for _ in range(K)], [np.array(base["ub"], float) for _ in range(K)]
+    want = [(s.advance(), s.solution()) for s in ones]
+    batch.advance()
+    for level in range(3):
+        views = batch.solution_views()
+        var, lo, hi = np.full(K, -1, np.int32), np.zeros(K), np.zeros(K)
+        for l in range(K):
+            np.testing.assert_array_equal(views[l][0], want[l][1][0])
+            if l % 5 == 4:
+                continue  # this node is re-solved as it is
+            x = views[l][0]
+            cand = np.flatnonzero(np.isfinite(lbs[l]) & np.isfinite(ubs[l]) & (ubs[l] - lbs[l] >= 1.0))
+            j = int(rng.choice(cand))
+            if l % 2:
+                lbs[l][j] = min(np.ceil(x[j]), ubs[l][j])
+            else:
+                ubs[l][j] = max(np.floor(x[j]), lbs[l][j])
+            var[l], lo[l], hi[l] = j, lbs[l][j], ubs[l][j]
+        for l, s in enumerate(ones):
+            s.reset(lb=lbs[l], ub=ubs[l], init_x=want[l][1][0], init_y=want[l][1][1])
+        want = [(s.advance(), s.solution()) for s in ones]
+        batch.branch(var, lo, hi)
+        got = batch.advance()
+        sols = batch.solutions()
+        for l in range(K):
+            same(dict(want[l][0], setup_seconds=0), dict(got[l], setup_seconds=0))
+            for u, v in zip(want[l][1], sols[l]):
+                np.testing.assert_array_equal(u, v)
+    batch.close()
+
 def test_who_is_turned_away(golden_problems):
     big = synthetic.generate(3000, 3000, 6, seed=2)  # not resident
     small = relaxation(golden_problems, "afiro")
