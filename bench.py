@@ -346,6 +346,21 @@ def small_batch_line(args, K, local_rank, record_fd):
         return dict(label=label, lps=k * rounds, iterations=its, seconds={a: round(b, 4) for a, b in t.items()}, lps_per_sec=round(k * rounds / total, 1),
                     lps_per_sec_advance_only=round(k * rounds / t["advance"], 1), its_per_sec_advance=round(its / t["advance"], 1), statuses=statuses), objs, (lbs, ubs)
 
+    def thread_pool_leg():
+        kp = min(K, 64)
+        pool_solvers = make(kp, False)
+        ex = concurrent.futures.ThreadPoolExecutor(max_workers=16)
+        run(pool_solvers, "warm-up", executor=ex)
+        for s in pool_solvers:
+            s.reset(lb=base["lb"], ub=base["ub"])
+        pool, pobjs, _ = run(pool_solvers, "thread pool: 16 host threads over %d solvers (one stream each); a worker takes a node through reset, solve and read-back "
+                             "(all three under 'advance')" % kp, executor=ex)
+        ex.shutdown()
+        for s in pool_solvers:
+            s.close()
+        same = all(a[:kp] == b for a, b in zip(objs, pobjs))
+        return pool, same
+
     t0 = time.perf_counter()
     solvers = make(K, True)
     batch = capi.SmallBatch(solvers)
@@ -359,18 +374,10 @@ def small_batch_line(args, K, local_rank, record_fd):
     for s in reversed(solvers):
         s.close()
     # ---- the same node sequences through a pool of host threads (one solver + one stream per LP; 16 threads)
-    kp = min(K, 64)
-    pool_solvers = make(kp, False)
-    ex = concurrent.futures.ThreadPoolExecutor(max_workers=16)
-    run(pool_solvers, "warm-up", executor=ex)
-    for s in pool_solvers:
-        s.reset(lb=base["lb"], ub=base["ub"])
-    pool, pobjs, _ = run(pool_solvers, "thread pool: 16 host threads over %d solvers (one stream each); a worker takes a node through reset, solve and read-back "
-                         "(all three under 'advance')" % kp, executor=ex)
-    ex.shutdown()
-    for s in pool_solvers:
-        s.close()
-    same = all(a[:kp] == b for a, b in zip(objs, pobjs))
+    # (--no-convergence-run skips this leg: rocprofv3 7.2 crashes in a process that launches from sixteen threads)
+    pool, same = None, None
+    if not args.no_convergence_run:
+        pool, same = thread_pool_leg()
     # ---- the reference's dual simplex (oracle/_ref, 1 thread) on a bounded sample of the LAST round's nodes (cold: it has no warm start here)
     cpu = None
     if not args.no_cpu_baseline:
@@ -399,7 +406,7 @@ def small_batch_line(args, K, local_rank, record_fd):
         "config": {"workload": "%s: %d branch-and-bound nodes of the 50v-10 LP relaxation (233 x 2013, 2745 nonzeros), %d rounds of one bound tightening per node + warm-started "
                                "re-solve to the default 1e-4 (iteration limit %d), Stable2 preset; persistent solvers, one small-LP batch" % (args.workload, K, rounds, limit),
                    "rows": m, "cols": n, "nnz": nnz, "lps": K, "rounds": rounds, "parallelism": "single GPU, %d LPs in %d workgroups per launch" % (K, K)},
-        "batch": got, "thread_pool": pool, "batch_over_thread_pool_lps_per_sec": round(got["lps_per_sec"] / pool["lps_per_sec"], 2),
+        "batch": got, "thread_pool": pool, "batch_over_thread_pool_lps_per_sec": None if pool is None else round(got["lps_per_sec"] / pool["lps_per_sec"], 2),
 
         "same_objectives_as_the_thread_pool": same, "create_seconds_per_lp": round(create_s / K, 5),
         "roofline": dict(bound="hbm", kernel="k_pdhg_resident_batch", achieved=round(eq, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(eq / HBM_PEAK_GBS, 5), traffic=None,

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -78,10 +79,26 @@ class TaskPool {
   template <class F>
   bool run(int workers_wanted, int tasks, F& fn)
   {
+    if (in_region()) return false;  // a task of a running region asks for a region of its own: never try_lock a mutex this thread may hold
     std::unique_lock<std::mutex> region(region_, std::try_to_lock);
     if (!region.owns_lock()) return false;
+    struct Mark {
+      Mark() { in_region() = true; }
+      ~Mark() { in_region() = false; }
+    } mark;
     ensure_workers(workers_wanted - 1);
-    std::function<void(int)> call = [&fn](int t) { fn(t); };
+    std::exception_ptr failure;
+    std::mutex failure_m;
+    // (a task that throws -- bad_alloc in a set-up pass -- must not end a detached worker, i.e. the process: the first exception is
+    //  kept and rethrown by the caller of the region once every task has been accounted for)
+    std::function<void(int)> call = [&fn, &failure, &failure_m](int t) {
+      try {
+        fn(t);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(failure_m);
+        if (!failure) failure = std::current_exception();
+      }
+    };
     {
       std::lock_guard<std::mutex> lk(m_);
       job_ = &call, tasks_ = tasks, next_ = 0, done_ = 0, active_ = std::min<int>((int)threads_.size(), workers_wanted - 1);
@@ -92,10 +109,17 @@ class TaskPool {
     std::unique_lock<std::mutex> lk(m_);
     job_ = nullptr;  // (no worker joins from here on; those inside hold `call` until they leave)
     cv_done_.wait(lk, [&] { return done_ == tasks_ && inflight_ == 0; });
+    lk.unlock();
+    if (failure) std::rethrow_exception(failure);
     return true;
   }
 
  private:
+  static bool& in_region()
+  {
+    static thread_local bool flag = false;
+    return flag;
+  }
   void work(std::function<void(int)>& call, int tasks)
   {
     for (;;) {

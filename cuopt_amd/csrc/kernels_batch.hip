@@ -407,6 +407,7 @@ struct pdlpdev_batch {
   pdlpdev_ctx* ctx[kBatchMax] = {nullptr};
   BatchLp* lp_dev = nullptr;
   pdlpdev_decision_args* dargs_dev = nullptr;
+  std::vector<pdlpdev_decision_args> dargs_host;  // (refreshed with the table: pdlpdev_set_step_params of a member after the batch was made)
   double *xK = nullptr, *yK = nullptr;
   // the row blocks whose partial sums the products reproduce: the panels of the single-LP layout (512 "threads"), or the row blocks
   // of the CSR stream kernels (256)
@@ -433,10 +434,13 @@ static int batch_refresh_table(pdlpdev_batch* b)
     const BatchLp now = batch_lp_of(b->ctx[l]);
     if (memcmp(&now, &b->lp_host[l], sizeof(BatchLp)) != 0) b->lp_host[l] = now, changed = true;
   }
-  if (changed) {
-    HIP_TRY(hipMemcpyAsync(b->lp_dev, b->lp_host.data(), b->K * sizeof(BatchLp), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-  }
+  bool sp_changed = false;  // (the step-size exponents travel by value in the decision kernel's arguments)
+  for (int l = 0; l < b->K; ++l)
+    if (memcmp(&b->dargs_host[l].sp, &b->ctx[l]->sp, sizeof(pdlpdev_step_params)) != 0) b->dargs_host[l].sp = b->ctx[l]->sp, sp_changed = true;
+  if (changed) HIP_TRY(hipMemcpyAsync(b->lp_dev, b->lp_host.data(), b->K * sizeof(BatchLp), hipMemcpyHostToDevice, b->stream));
+  if (sp_changed)  // (the attempt graphs carry the POINTER to this table, not its contents: no re-capture)
+    HIP_TRY(hipMemcpyAsync(b->dargs_dev, b->dargs_host.data(), b->K * sizeof(pdlpdev_decision_args), hipMemcpyHostToDevice, b->stream));
+  if (changed || sp_changed) HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
@@ -529,6 +533,8 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
   c->allocs.clear(), c->graphs.clear();
   c->shared_with_parent = true;
   c->parent = nullptr;  // (set once the clone is complete: a failed clone is destroyed without touching the parent's count)
+  c->scal_h = nullptr, c->ctl_h = nullptr;  // (the parent's pinned block until the clone has its own: a clone that fails below must not free it)
+  c->clones_alive = 0, c->batches_alive = 0, c->rows_private = false;
   c->bytes = 0, c->slab = nullptr, c->slab_cap = c->slab_used = 0, c->arena = nullptr, c->arena_used = 0, c->first_chunk = nullptr;
   c->bestx = c->besty = c->bestrc = nullptr;
   c->prof_armed = false, c->prof_used = 0, c->rejected_in_a_row = 0;
@@ -560,6 +566,7 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
   // (lo, hi and their unscaled twins stay the parent's until a reset brings other row bounds: pdlpdev_reset makes the copies then)
   c->rows_aliased = true, c->parent = parent, c->clones_alive = 0;
   parent->clones_alive += 1;
+  parent->rows_private = false;  // (this clone aliases the parent's CURRENT row bounds)
   for (int i = 0; i < 2; ++i) {
     TRY(dev_alloc(c, &c->x[i], (size_t)n + kSlicePad)); TRY(dev_alloc(c, &c->y[i], m));
     TRY(dev_alloc(c, &c->aty[i], (size_t)n + kSlicePad)); TRY(dev_alloc(c, &c->rc[i], n));
@@ -592,6 +599,9 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
 {
   if (!out || !ctx || (K != 2 && K != 4 && K != 8 && K != 16)) return fail(-1, "pdlpdev_batch_create: K must be 2, 4, 8 or 16");
   pdlpdev_ctx* c0 = ctx[0];
+  for (int l = 0; l < K; ++l)
+    for (int q = 0; q < l; ++q)
+      if (ctx[q] == ctx[l]) return fail(-1, "pdlpdev_batch_create: LP %d and LP %d are the same context (two lanes would share one set of iterates)", q, l);
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = ctx[l];
     if (!c || c->ha_off != c0->ha_off || c->hat_off != c0->hat_off || c->pa.v.row0 != c0->pa.v.row0 || c->stream != c0->stream)
@@ -642,12 +652,14 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
   b->a_side = side[0], b->t_side = side[1];
   std::vector<BatchLp>& h = b->lp_host;
   h.resize(K);
-  std::vector<pdlpdev_decision_args> dargs(K);
+  std::vector<pdlpdev_decision_args>& dargs = b->dargs_host;
+  dargs.resize(K);
   for (int l = 0; l < K; ++l) {
     pdlpdev_ctx* c = ctx[l];
     b->ctx[l]      = c;
     h[l]     = batch_lp_of(c);
     dargs[l] = pdlpdev_decision_args{c->ctl, c->part_a, side[0].W, c->part_at, side[1].W, c->sp};
+    c->batches_alive += 1;
   }
   HIP_TRY(hipMalloc((void**)&b->lp_dev, K * sizeof(BatchLp)));
   HIP_TRY(hipMalloc((void**)&b->xK, ((size_t)c0->n * K + 64) * sizeof(double)));
@@ -659,13 +671,15 @@ int pdlpdev_batch_create(pdlpdev_batch** out, pdlpdev_ctx** ctx, int K)
   HIP_TRY(hipMemcpyAsync(b->dargs_dev, dargs.data(), K * sizeof(pdlpdev_decision_args), hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemsetAsync(b->xK, 0, ((size_t)c0->n * K + 64) * sizeof(double), b->stream));
   HIP_TRY(hipMemsetAsync(b->yK, 0, ((size_t)c0->m * K + 64) * sizeof(double), b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));  // (h, dargs: host memory that goes away with this call)
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
 void pdlpdev_batch_destroy(pdlpdev_batch* b)
 {
   if (!b) return;
+  for (int l = 0; l < b->K; ++l)
+    if (b->ctx[l]) b->ctx[l]->batches_alive -= 1;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (auto& kv : b->graphs) (void)hipGraphExecDestroy(kv.second);

@@ -587,6 +587,7 @@ int pdlpdev_small_batch_create(pdlpdev_small_batch** out, pdlpdev_ctx** ctx, int
   HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   TRY(major_lds_attribute(b->device));
   for (int l = 0; l < K; ++l) HIP_TRY(hipStreamSynchronize(ctx[l]->stream));  // whatever the set-ups left in flight
+  for (int l = 0; l < K; ++l) ctx[l]->batches_alive += 1;
   *out = b.release();
   return 0;
 }
@@ -594,6 +595,7 @@ int pdlpdev_small_batch_create(pdlpdev_small_batch** out, pdlpdev_ctx** ctx, int
 void pdlpdev_small_batch_destroy(pdlpdev_small_batch* b)
 {
   if (!b) return;
+  for (pdlpdev_ctx* c : b->ctx) c->batches_alive -= 1;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream), (void)hipStreamDestroy(b->stream);
   if (b->pinned) (void)hipHostFree(b->pinned);

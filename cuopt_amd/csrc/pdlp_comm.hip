@@ -205,8 +205,13 @@ int halo_setup(pdlpdev_ctx* ctx, const int32_t* need)
   const int64_t full = (int64_t)(W - 1) * ((int64_t)ctx->slice + ctx->ypad);
   H.bytes_allgather  = 8 * full;
   const long long want = cuopt_amd::tune_int("shard_halo", -1);
-  const bool use = W > 1 && !ctx->p2p.on && want != 0 && (want == 1 || worst * 4 <= full);
-  if (!ctx->soft && use && (!rccl::Send || !rccl::Recv || !rccl::GroupStart || !rccl::GroupEnd)) return fail(-3, "RCCL: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd missing");
+  bool use = W > 1 && !ctx->p2p.on && want != 0 && (want == 1 || worst * 4 <= full);
+  if (!ctx->soft && use && (!rccl::Send || !rccl::Recv || !rccl::GroupStart || !rccl::GroupEnd)) {
+    // only an EXPLICIT shard_halo=1 makes the missing entry points an error; the automatic rule falls back to the all-gathers (every
+    // rank loads the same library, so every rank takes this branch)
+    if (want == 1) return fail(-3, "RCCL: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd missing (CUOPT_AMD_TUNE=shard_halo=1 asked for the halo exchange)");
+    use = false;
+  }
   for (int kind = 0; kind < 2; ++kind) {
     H.recv_off[kind].assign(W, 0), H.recv_cnt[kind].assign(W, 0), H.send_off[kind].assign(W, 0), H.send_cnt[kind].assign(W, 0);
     for (int q = 0; q < W; ++q) {

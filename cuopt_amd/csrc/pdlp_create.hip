@@ -624,6 +624,8 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   if (ctx->shared_with_parent && ctx->parent) ctx->parent->clones_alive -= 1;
+  if (ctx->batches_alive > 0)  // (a batch holds plain pointers to its members: destroy it first)
+    fprintf(stderr, "[cuopt_amd] pdlpdev_destroy: %d batch(es) still hold this context -- destroy the batch before its members\n", ctx->batches_alive);
   if (ctx->clones_alive > 0)  // (a contract of pdlpdev_clone_shared; said aloud, since what follows frees the clones' matrices)
     fprintf(stderr, "[cuopt_amd] pdlpdev_destroy: %d clone(s) of this context are still alive -- they alias its matrices and must be destroyed first\n", ctx->clones_alive);
   for (void* mapped : ctx->p2p.opened) (void)hipIpcCloseMemHandle(mapped);

@@ -478,6 +478,8 @@ struct pdlpdev_ctx {
                                     // K clones that differ in their VARIABLE bounds read one copy (the batched dual step then fetches
                                     // lo / hi once for all LPs -- the caches see the same addresses)
   int clones_alive = 0;             // contexts that alias this one's arrays
+  bool rows_private = false;        // a parent whose lo / hi were re-allocated by a reset AFTER its last clone was made: no clone aliases them
+  int batches_alive = 0;            // pdlpdev_batch / pdlpdev_small_batch objects that hold this context's pointer
   std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
   std::vector<void*> allocs;
   int64_t bytes = 0;

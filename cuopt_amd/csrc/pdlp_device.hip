@@ -1216,7 +1216,7 @@ int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const do
       ctx->graphs.clear();
     }
   }
-  if ((lo || hi) && (ctx->rows_aliased || ctx->clones_alive > 0)) {
+  if ((lo || hi) && (ctx->rows_aliased || (ctx->clones_alive > 0 && !ctx->rows_private))) {
     // row bounds shared with clones (or with the parent): this context gets arrays of its own first; the others keep the old ones
     for (double** v : {&ctx->lo, &ctx->lo_u, &ctx->hi, &ctx->hi_u}) {
       const double* src = *v;
@@ -1224,6 +1224,7 @@ int pdlpdev_reset(pdlpdev_ctx* ctx, const double* lb, const double* ub, const do
       HIP_TRY(hipMemcpyAsync(*v, src, mb, hipMemcpyDeviceToDevice, s));
     }
     ctx->rows_aliased = false;
+    ctx->rows_private = true;  // (until pdlpdev_clone_shared makes another clone of this context: that one aliases the new arrays)
     for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);  // (the attempt graphs carry the old arrays' addresses)
     ctx->graphs.clear();
   }

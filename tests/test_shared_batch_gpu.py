@@ -235,6 +235,37 @@ def test_row_bounds_are_shared_until_someone_changes_them(monkeypatch):
     child.close(), parent.close()
 
 
+def test_a_parent_reset_again_and_again_next_to_a_clone_does_not_grow(monkeypatch):
+    """(round-5 advisor) the copy-on-change of shared row bounds happens ONCE per clone generation, not at every reset of the parent:
+    a MIP loop that keeps resetting the parent next to live clones must not collect 32 m bytes per reset -- and the clone made AFTER
+    such a reset aliases the parent's new arrays, so the parent's next reset copies again (and both keep their own bounds)"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "panel")
+    p = synthetic.generate(5000, 4000, 8, seed=19)
+    kw = dict(tol=1e-6, iteration_limit=LIMIT)
+    bounds = [(np.where(np.isfinite(p["lo"]), p["lo"] - 0.1 * k, p["lo"]), np.where(np.isfinite(p["hi"]), p["hi"] + 0.1 * k, p["hi"])) for k in range(1, 7)]
+    parent = capi.Solver(p, **kw)
+    first = parent.clone()
+    used = []
+    for lo, hi in bounds[:4]:
+        parent.reset(lo=lo, hi=hi, **kw)
+        used.append(capi.lib.pdlpdev_device_bytes(parent.device.handle))
+    assert used[0] == used[1] == used[2] == used[3], used  # one copy (at the first reset), then in place
+    second = parent.clone()  # aliases the arrays the parent holds NOW (bounds[3])
+    parent.reset(lo=bounds[4][0], hi=bounds[4][1], **kw)
+    grown = capi.lib.pdlpdev_device_bytes(parent.device.handle)
+    assert grown > used[3]  # the parent moved off the arrays its second clone reads ...
+    parent.reset(lo=bounds[5][0], hi=bounds[5][1], **kw)
+    assert capi.lib.pdlpdev_device_bytes(parent.device.handle) == grown  # ... once
+    ref = {}
+    for name, q in (("first", p), ("second", dict(p, lo=bounds[3][0], hi=bounds[3][1])), ("parent", dict(p, lo=bounds[5][0], hi=bounds[5][1]))):
+        s = capi.Solver(q, **kw)
+        ref[name] = (s.advance(), s.solution())
+        s.close()
+    same(first.advance(), ref["first"][0], first.solution(), ref["first"][1], "the first clone still reads the original row bounds")
+    same(second.advance(), ref["second"][0], second.solution(), ref["second"][1], "the second clone reads the bounds of its creation")
+    same(parent.advance(), ref["parent"][0], parent.solution(), ref["parent"][1], "the parent on its latest bounds")
+    first.close(), second.close(), parent.close()
+
 def test_members_may_be_reset_while_the_batch_lives(monkeypatch):
     """a reset of a member between two advances of ONE batch object -- new variable bounds (their uniform-bound summary travels with
     the LP's table entry) and new row bounds (the member's lo / hi move to arrays of its own) -- is seen by the next advance"""
