@@ -93,8 +93,21 @@ def cpu_baseline_block(p):
         box_cores = len(os.sched_getaffinity(0))
     except AttributeError:
         box_cores = os.cpu_count() or 1
+    # The GPU boxes run this command inside a cgroup with a CPU-time QUOTA (measured: cpu.max = "1600000 100000" = 16 CPUs' worth on a
+    # 2 x 64-core EPYC 9575F with 256 hardware threads visible): more threads than the quota are throttled by the scheduler -- the
+    # oracle's loop ran at 33 / 18 / 7.7 / 2.9 it/s with 16 / 32 / 64 / 128 threads while nr_throttled climbed (profiles/
+    # r06_cpu_baseline_threads.txt).  That, not first touch or binding, is the "negative scaling" of the round-5 line: the baseline uses
+    # what the box grants.
+    quota_cores = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota_cores = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    usable = min(box_cores, quota_cores) if quota_cores else box_cores
     sweep = {}
-    for t in sorted({min(t, box_cores) for t in (16, 32, 64, 128)}):
+    for t in sorted({max(1, min(t, usable)) for t in (usable // 2, usable, 16, 32, 64, 128)}):
         o = orcbind.solve(p, tol=0.0, iteration_limit=12, num_threads=t)
         sweep[t] = o["steps_taken"] / max(o["loop_seconds"], 1e-9)
     cores = max(sweep, key=sweep.get)
@@ -102,10 +115,10 @@ def cpu_baseline_block(p):
     budget = int(min(max(20.0 * sweep[cores], 40), 4000))
     o = orcbind.solve(p, tol=0.0, iteration_limit=budget, num_threads=cores)
     cpu = dict(value=round(o["steps_taken"] / o["loop_seconds"], 3), unit="iterations/s", cores=cores,
-               box_cores=box_cores, kind="port",
+               box_cores=box_cores, cgroup_cpu_quota_cores=quota_cores, kind="port",
                thread_sweep_calibration_its_per_s={str(k): round(v, 2) for k, v in sweep.items()},
-               sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d of %d cores), %d iterations of the same "
-               "LP: loop %.2fs + setup %.2fs" % (cores, box_cores, o["steps_taken"], o["loop_seconds"],
+               sample="oracle/pdlp_oracle.c PDLP loop (OpenMP, %d threads; the box shows %d hardware threads and grants a CPU quota of %s), %d iterations of the same "
+               "LP: loop %.2fs + setup %.2fs" % (cores, box_cores, "%d cores" % quota_cores if quota_cores else "all of them", o["steps_taken"], o["loop_seconds"],
                                                o["solve_seconds"] - o["loop_seconds"]))
     cpu["reference_dual_simplex"] = reference_dual_simplex_block(ROOT)
     return cpu
@@ -429,10 +442,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10",
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10", "banded4",
                              "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c5_batch256", "c5_batch64", "c5_batch1024", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
-    ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound on the duration of the timed region (timed_steps is rounded up)")
+    ap.add_argument("--min-seconds", type=float, default=10.0, help="lower bound on the duration of the timed region (timed_steps is rounded up): long enough for an outside observer that samples the GPU every few seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL path even with one rank")
@@ -522,6 +535,8 @@ def main():
     structured = base in ("staircase", "block_angular", "powerlaw", "multiband", "dense_rows")
     if base == "hard":
         cfg = dict(synthetic.CONFIGS["c3"], hard=True)
+    elif base == "banded4":
+        cfg = dict(synthetic.CONFIGS["banded4"])
     elif structured:
         cfg = dict(kind=base, m=1_000_000, n=1_000_000, k=10, seed=7)
     elif base == "c3x100":
@@ -579,6 +594,17 @@ def main():
     reorder = solver.reorder_info()
     dataflow = capi.lib.pdlpdev_shard_dataflow(dev.handle)  # read while the solver (and its device context) is alive
     transport = ", direct peer stores" if world > 1 and capi.lib.pdlpdev_shard_transport(dev.handle) == 1 else ""
+    sharding = None
+    if dist is not None:  # what a multi-rank line needs to be read without the code: ranks, dataflow, transport, halo, bytes on the wire
+        wire = np.zeros(3, dtype=np.int64)
+        capi.lib.pdlpdev_shard_wire_bytes(dev.handle, wire.ctypes.data_as(capi.C.c_void_p))
+        sharding = dict(rccl_nranks=world,
+                        dataflow={0: "none", 1: "all-reduce of the A^T y' partials (replicated primal)", 2: "reduce-scatter + all-gather (sliced primal)",
+                                  3: "owner computes: all-gather(xbar slices) + all-gather(y' row blocks)"}.get(dataflow, str(dataflow)),
+                        transport="direct peer stores into landing blocks + epoch flags (p2p)" if capi.lib.pdlpdev_shard_transport(dev.handle) == 1 else "RCCL collectives",
+                        halo_exchange=bool(wire[0]), bytes_received_per_attempt_this_rank=int(wire[1] if wire[0] else wire[2]),
+                        bytes_of_the_two_all_gathers=int(wire[2]),
+                        collectives_in_graphs=bool(args.graph_comm))
     # ... and (iii) starts at the device's steady clocks: a GPU that sat idle while the LP was generated runs its first tens of
     # milliseconds below them (measured: the same 200 timed steps gave 4.7 k it/s right after start-up and 5.7 k once warm), so
     # untimed batches of five periods run until two consecutive batches agree within 2 % (at most 4 s).  Every rank takes the same
@@ -661,7 +687,7 @@ def main():
     # command (profiles/r03_pmc_<workload>.json, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md); the
     # counters cannot be read from inside the process, so this is null for workloads without a profile
     traffic, traffic_file = None, None
-    for rnd in ("r05", "r04", "r03", "r02"):  # the newest committed PMC summary of this workload
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):  # the newest committed PMC summary of this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, args.workload))))
             if world == 1 and kname in pmc:
@@ -680,8 +706,9 @@ def main():
                                                  / HBM_PEAK_GBS / max(world, 1), 4),
                     traffic_calibrated=None if traffic is None else True,  # streams: MI355X_MICROARCH.md (FETCH_SIZE x 2); scattered 8-byte reads: profiles/r05_gather_calibration.txt (one 128-B line per miss, tallied at 64 B); WRITE_SIZE: k_primal 71.5 vs 72 MB
                     traffic_source=None if traffic is None else
-                    "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                    "(scripts/r04_pmc.sh / r03_profiles.sh / r02_final_profiles.sh; 2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section)" % traffic_file)
+                    "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload %s` on the tree of round %s (scripts/gpu_session.sh pmc:%s; "
+                    "2*FETCH+WRITE KiB, MI355X_MICROARCH.md HBM section) -- NOT measured by this run: counters cannot be read from inside the process%s"
+                    % (traffic_file, args.workload, traffic_file.split("/")[1][1:3], args.workload, "" if traffic_file.startswith("profiles/r06") else "; an OLDER round's pass, kept because the kernel's timing has not moved since"))
     # Guard (round-3 review): the four kernels of an attempt, each timed on its own, must add up to the time of an attempt as the timed
     # region saw it (the rest is the amortised major-iteration work and the graph's launch gaps).  A call site whose launches are not
     # all summed (a multi-launch layout timed as one phase), or a timed region that skipped work, shows up here.
@@ -730,7 +757,7 @@ def main():
                        "rows": m, "cols": n, "nnz": nnz,
                        "parallelism": ("row-block x%d + RCCL %s" % (world, {1: "all-reduce (replicated primal)", 2: "reduce-scatter / all-gather (sliced primal)",
                                                                        3: "owner computes: all-gather(xbar) + all-gather(y'), rows and columns of A per rank"}.get(dataflow, "?") + transport)) if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv,
+            "roofline": roofline, "cpu_baseline": cpu, "time_to_1e-4": conv, "sharding": sharding,
             "spmv_layout": layout, "setup_reordering": reorder, "attempted_steps": attempts, "setup_seconds": round(setup_s, 4), "generate_seconds": round(t_gen, 2),
             "device": info["name"], "compute_units": info["compute_units"], "sclk_mhz_during_timed_region": {"samples": len(sclk_samples), "min": min(sclk_samples) if sclk_samples else None, "max": max(sclk_samples) if sclk_samples else None},
         }

@@ -79,6 +79,7 @@ CONFIGS = {
     "c2": dict(m=100_000, n=100_000, k=10, seed=1),        # 1e5 x 1e5, 1e6 nnz
     "c3": dict(m=1_000_000, n=1_000_000, k=10, seed=2),    # 1e6 x 1e6, 1e7 nnz
     "banded": dict(m=1_000_000, n=1_000_000, k=10, seed=2, band=2000),  # same size, structured columns
+    "banded4": dict(m=4_000_000, n=4_000_000, k=10, seed=2, band=2000),  # 4e7 nnz banded: where the 8-GPU model of DESIGN 5 crosses 3.5x
     "c3x10": dict(m=10_000_000, n=10_000_000, k=10, seed=2),   # 1e7 x 1e7, 1e8 nnz: ten times C3 (robustness / capacity check)
 }
 
