@@ -1,5 +1,7 @@
 // Communicators, collectives and the direct peer transport's set-up of sharded solves (one translation unit: the multi-GPU side
 // of the device layer).  The kernels of an attempt are launched by the core (pdlp_device.hip), which calls the collectives below.
+#include <limits>
+
 #include "pdlp_ctx.hpp"
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
@@ -205,8 +207,8 @@ int halo_setup(pdlpdev_ctx* ctx, const int32_t* need)
   const int64_t full = (int64_t)(W - 1) * ((int64_t)ctx->slice + ctx->ypad);
   H.bytes_allgather  = 8 * full;
   const long long want = cuopt_amd::tune_int("shard_halo", -1);
-  bool use = W > 1 && !ctx->p2p.on && want != 0 && (want == 1 || worst * 4 <= full);
-  if (!ctx->soft && use && (!rccl::Send || !rccl::Recv || !rccl::GroupStart || !rccl::GroupEnd)) {
+  bool use = W > 1 && want != 0 && (want == 1 || worst * 4 <= full);
+  if (!ctx->soft && !ctx->p2p.on && use && (!rccl::Send || !rccl::Recv || !rccl::GroupStart || !rccl::GroupEnd)) {
     // only an EXPLICIT shard_halo=1 makes the missing entry points an error; the automatic rule falls back to the all-gathers (every
     // rank loads the same library, so every rank takes this branch)
     if (want == 1) return fail(-3, "RCCL: ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd missing (CUOPT_AMD_TUNE=shard_halo=1 asked for the halo exchange)");
@@ -223,6 +225,7 @@ int halo_setup(pdlpdev_ctx* ctx, const int32_t* need)
   for (int kind = 0; kind < 2; ++kind)
     for (int q = 0; q < W; ++q) H.bytes += 8 * (int64_t)H.recv_cnt[kind][q];
   H.on = use;
+  if (use && ctx->p2p.on) TRY(p2p_push_ranges(ctx));  // the peer stores carry the halo too: only what the peer's rows / columns reference
   if (getenv("CUOPT_AMD_TIMING"))
     fprintf(stderr, "[cuopt_amd setup]   rank %d: halo %s: %lld B per attempt against %lld B for the two all-gathers\n", me, use ? "on" : "off", (long long)H.bytes,
             (long long)H.bytes_allgather);
@@ -259,6 +262,26 @@ int halo_exchange(pdlpdev_ctx* ctx, int kind, double* buf)
 //   in-process communicator: the ranks are contexts of one process (tests: on ONE device) -> a table in the communicator;
 //   RCCL: one 128-byte record per rank {IPC handle, process id, pointer, device} all-gathered through the communicator:
 //   same process -> the pointer itself (peer access enabled), another process -> hipIpcOpenMemHandle.
+// halo exchange over the direct peer transport: the two vector exchanges' descriptors learn, per destination rank, which entries of
+// THIS rank's share it needs (halo_setup's send ranges, buffer coordinates -> coordinates of the producing kernel's loop)
+int p2p_push_ranges(pdlpdev_ctx* ctx)
+{
+  pdlpdev_ctx::P2P& P = ctx->p2p;
+  const pdlpdev_ctx::Halo& H = ctx->halo;
+  const int64_t origin[2] = {(int64_t)ctx->rank * ctx->slice, (int64_t)ctx->rank * ctx->ypad};
+  for (int kind = 0; kind < 2; ++kind)
+    for (int q = 0; q < ctx->world; ++q) {
+      const int64_t lo = (int64_t)H.send_off[kind][q] - origin[kind];
+      P.push_host[kind].lo[q] = H.send_cnt[kind][q] > 0 ? (int)lo : 0;
+      P.push_host[kind].hi[q] = H.send_cnt[kind][q] > 0 ? (int)(lo + H.send_cnt[kind][q]) : 0;
+    }
+  HIP_TRY(hipMemcpyAsync(P.push_dev, P.push_host, sizeof(P.push_host), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);  // (the pull kernels of the attempt graphs change)
+  ctx->graphs.clear();
+  return 0;
+}
+
 int p2p_setup(pdlpdev_ctx* ctx)
 {
   pdlpdev_ctx::P2P& P = ctx->p2p;
@@ -324,7 +347,11 @@ int p2p_setup(pdlpdev_ctx* ctx)
     p2pdev::Push h[p2pdev::kKinds];
     const size_t slot[p2pdev::kKinds] = {P.off_x + (size_t)ctx->rank * ctx->slice * sizeof(double), P.off_y + (size_t)ctx->rank * ctx->ypad * sizeof(double),
                                          P.off_s + (size_t)ctx->rank * 4 * sizeof(double)};
-    for (int k = 0; k < p2pdev::kKinds; ++k) h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch};
+    for (int k = 0; k < p2pdev::kKinds; ++k) {
+      h[k] = p2pdev::Push{P.peers, ctx->world, ctx->rank, k, slot[k], P.off_f, P.epoch, {}, {}};
+      for (int q = 0; q < 16; ++q) h[k].lo[q] = 0, h[k].hi[q] = std::numeric_limits<int>::max();
+      P.push_host[k] = h[k];
+    }
     TRY(dev_alloc(ctx, &P.push_dev, p2pdev::kKinds));
     HIP_TRY(hipMemcpyAsync(P.push_dev, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -267,6 +267,23 @@ static __global__ void __launch_bounds__(256) k_pull(pdlpdev_ctl* __restrict__ c
       if (at[u] >= 0) dst2[at[u]] = v[u];
   }
 }
+// the halo exchange's consumer: per peer ONE range [off, off + cnt) of the landed vector (buffer coordinates) instead of everything
+struct PullRanges {
+  int off[16], cnt[16];
+};
+static __global__ void __launch_bounds__(256) k_pull_ranges(pdlpdev_ctl* __restrict__ ctl, double* __restrict__ dst, const double* __restrict__ land, PullRanges R,
+                                                     const unsigned long long* __restrict__ flags, int world, int kind, const unsigned long long* __restrict__ epoch,
+                                                     int* __restrict__ fault, const Push* __restrict__ push)
+{
+  if (!active(ctl)) return;
+  raise(push);
+  if (!wait_flags(flags, world, kind, epoch)) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *fault = 1, ctl->error = 1;
+    return;
+  }
+  for (int q = 0; q < world; ++q)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R.cnt[q]; i += gridDim.x * 256) dst[R.off[q] + i] = __builtin_nontemporal_load(land + R.off[q] + i);
+}
 }  // namespace p2pdev
 
 // ================================================================================================
@@ -450,6 +467,7 @@ struct pdlpdev_ctx {
     unsigned long long* epoch = nullptr;  // device: epochs of the three exchanges (xbar, y', scalars) as this rank counts them
     int* fault = nullptr;            // device: set when a wait ran out of patience (peer died)
     p2pdev::Push* push_dev = nullptr;  // device: the three exchanges' descriptors (xbar, y', scalars) for the producing kernels
+    p2pdev::Push push_host[p2pdev::kKinds];  // their host copies (the halo set-up narrows the ranges afterwards)
   } p2p;
   // pdlpdev_time_kernel: the next launch through launch_k carries these events (kernel start / stop timestamps of the
   // dispatch itself, what rocprofv3 --kernel-trace reports)
@@ -604,5 +622,6 @@ int reduce_scatter(pdlpdev_ctx* ctx, const double* send, double* recv, size_t co
 int all_gather(pdlpdev_ctx* ctx, double* buf, size_t count);
 int allreduce(pdlpdev_ctx* ctx, double* buf, size_t count, int op);
 int p2p_setup(pdlpdev_ctx* ctx);
+int p2p_push_ranges(pdlpdev_ctx* ctx);
 int halo_setup(pdlpdev_ctx* ctx, const int32_t* need /* [world][4]: xbar lo, hi (columns), y' lo, hi (positions in ygather) */);
 int halo_exchange(pdlpdev_ctx* ctx, int kind, double* buf);

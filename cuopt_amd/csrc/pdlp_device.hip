@@ -307,7 +307,7 @@ k_primal(int n, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ x0, do
     if (push)  // sharded solve, direct peer transport: this rank's slice of xbar lands in every OTHER rank's block (its own copy is
                // the ordinary store above: write-through stores cost 17 us per attempt at C3 and buy nothing at home)
       for (int q = 0; q < push->world; ++q)
-        if (q != push->rank) p2pdev::put(push->slot(q) + j, xb);
+        if (push->wants(q, j)) p2pdev::put(push->slot(q) + j, xb);
     if (pend) sumx[j] = sumx[j] + weight * xj;
   }
   if (push) p2pdev::count_exchange(push);
@@ -1518,9 +1518,19 @@ static int enqueue_attempt(pdlpdev_ctx* ctx)
         launch_k(ctx, p2pdev::k_pull, g, 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), count, ctx->rank * per_rank, per_rank,
                  flags, W, kind, P.epoch, P.fault, P.push_dev + kind);
       };
-      pull(0, ctx->xbar, P.off_x, ctx->slice);  // (this rank's slice: k_primal's ordinary store, above)
+      // (halo exchange: only the ranges this rank's rows / columns reference were stored into its block, and only they are copied)
+      auto pull_ranges = [&](int kind, double* dst, size_t land_off) {
+        p2pdev::PullRanges R{};
+        int most = 0;
+        for (int q = 0; q < W; ++q) R.off[q] = ctx->halo.recv_off[kind][q], R.cnt[q] = ctx->halo.recv_cnt[kind][q], most = std::max(most, R.cnt[q]);
+        launch_k(ctx, p2pdev::k_pull_ranges, std::max(1, std::min((most + 255) / 256, 64)), 256, 0, ctx->ctl, dst, reinterpret_cast<const double*>(P.base + land_off), R, flags, W,
+                 kind, P.epoch, P.fault, P.push_dev + kind);
+      };
+      if (ctx->halo.on) pull_ranges(0, ctx->xbar, P.off_x);
+      else pull(0, ctx->xbar, P.off_x, ctx->slice);  // (this rank's slice: k_primal's ordinary store, above)
       launch_a_dual(ctx, ctx->ygather + (size_t)ctx->rank * ctx->ypad, P.push_dev + 1);
-      pull(1, ctx->ygather, P.off_y, ctx->ypad);
+      if (ctx->halo.on) pull_ranges(1, ctx->ygather, P.off_y);
+      else pull(1, ctx->ygather, P.off_y, ctx->ypad);
       launch_oc_step(ctx);
       launch_k(ctx, k_step_decision_p2p, 1, kBlock, 0, ctx->ctl, ctx->part_a, dual_partials(ctx), ctx->part_oc, oc_partials(ctx),
                reinterpret_cast<const double*>(P.base + P.off_s), flags, W, P.epoch, P.fault, ctx->sp, P.push_dev + 2);

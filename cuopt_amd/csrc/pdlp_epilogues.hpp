@@ -20,7 +20,11 @@ struct Push {
   int world, rank, kind;
   size_t dst_off, flag_off;  // bytes inside every rank's block: this rank's slot of the exchange / the flag area
   unsigned long long* epoch;
+  // halo exchange through the peer stores (round 6): rank q needs the entries [lo[q], hi[q]) of this rank's share only -- what its rows
+  // (kind 0: xbar) or columns (kind 1: y') reference, found at set-up (halo_setup); everything: [0, INT_MAX)
+  int lo[16], hi[16];
   __device__ __forceinline__ double* slot(int q) const { return reinterpret_cast<double*>(P.base[q] + dst_off); }
+  __device__ __forceinline__ bool wants(int q, int i) const { return q != rank && i >= lo[q] && i < hi[q]; }
 };
 // A producing kernel's store into a landing block: system scope = write-through, so that no cache write-back is needed before the
 // flag goes up
@@ -97,7 +101,7 @@ struct DualEpilogue {
     if (copy) copy[i] = next;
     if (push)
       for (int q = 0; q < push->world; ++q)
-        if (q != push->rank) p2pdev::put(push->slot(q) + i, next);  // (this rank's own rows: `copy`, an ordinary store)
+        if (push->wants(q, i)) p2pdev::put(push->slot(q) + i, next);  // (this rank's own rows: `copy`, an ordinary store)
     const double dy = next - yi;
     acc[0] += dy * dy;
     if (pend) sumy[i] = o.sum + weight * yi;

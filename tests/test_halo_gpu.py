@@ -64,6 +64,26 @@ def test_halo_exchange_is_the_all_gather_bit_for_bit(band, world, monkeypatch):
         assert max(o[3]["bytes"] for o in halo) <= 0.01 * halo[0][3]["bytes_allgather"]
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_halo_through_the_peer_store_transport(band, world, monkeypatch):
+    """(round 6) the direct peer transport carries the halo too: a producing kernel stores into a peer's landing block only what that
+    peer's rows / columns reference, the consumer copies only those ranges -- bit for bit the all-gathers' iterates, the halo's bytes"""
+    monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", "owner")
+    set_tune(monkeypatch, shard_halo=0)
+    full = run_ranks(band, world, tol=0.0, iteration_limit=120)
+    monkeypatch.setenv("CUOPT_AMD_SHARD_TRANSPORT", "p2p")
+    p2p_full = run_ranks(band, world, tol=0.0, iteration_limit=120)
+    set_tune(monkeypatch, shard_halo=None)
+    p2p_halo = run_ranks(band, world, tol=0.0, iteration_limit=120)
+    for (rf, xf, yf, wf, _), (rp, xp, yp, wp, _), (rh, xh, yh, wh, _) in zip(full, p2p_full, p2p_halo):
+        assert not wf["halo"] and not wp["halo"] and wh["halo"], (wf, wp, wh)
+        assert wh["bytes"] <= 0.01 * wh["bytes_allgather"] * (world - 1), wh
+        for r, x, y in ((rp, xp, yp), (rh, xh, yh)):
+            assert (rf["steps_taken"], rf["attempted_steps"]) == (r["steps_taken"], r["attempted_steps"])
+            assert rf["primal_objective"] == r["primal_objective"] and rf["step_size"] == r["step_size"]
+            np.testing.assert_array_equal(xf, x)
+            np.testing.assert_array_equal(yf, y)
+
 def test_a_random_lp_keeps_its_all_gathers(monkeypatch):
     monkeypatch.setenv("CUOPT_AMD_SHARD_DATAFLOW", "owner")
     p = synthetic.generate(60000, 50000, 8, seed=3)
