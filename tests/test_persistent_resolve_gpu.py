@@ -3,6 +3,7 @@ bound changes, cpp/src/mip/relaxed_lp/relaxed_lp.cu:53-175).  The reference buil
 the scaling depends on A only (initial_scaling.cu:125-307), so a solver that keeps A, A^T, D_r, D_c and takes new
 bounds must be bit-identical to a fresh one on the modified LP.  That is what is pinned here, on every solver
 path (resident small-LP loop, multi-launch CSR stream, slab-major panels), plus HiGHS on the modified LPs."""
+import os
 import time
 
 import numpy as np
@@ -147,4 +148,5 @@ def test_config5_sequence_through_one_persistent_solver(golden_problems):
         f.close()
     t_fresh = time.perf_counter() - t0
     print("config-5 sequence of %d re-solves: persistent %.2f ms, solver per call %.2f ms" % (len(plan), 1e3 * t_reset, 1e3 * t_fresh))
-    assert t_reset < 1.1 * t_fresh  # set-up is ~0.5 ms of a ~9 ms solve here (streams and arena are recycled anyway)
+    if "PYTEST_XDIST_WORKER" not in os.environ:  # (a rate comparison: not under the contention soak, where four processes share the GPU)
+        assert t_reset < 1.1 * t_fresh  # set-up is ~0.5 ms of a ~9 ms solve here (streams and arena are recycled anyway)
