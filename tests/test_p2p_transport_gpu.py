@@ -116,8 +116,10 @@ def test_landing_block_across_two_processes():
     block, hipIpcOpenMemHandle with lazy peer access in the other process, its system-scope stores and release flag, this process's
     flag wait -- on one device, without a communicator (multi-rank RCCL refuses duplicate devices)"""
     import ctypes as C
+    import os
     import subprocess
     import sys
+    from cuopt_amd import capi
     count, seed = 100_000, 0.25
     handle = (C.c_uint8 * 64)()
     base = C.c_void_p()
@@ -125,7 +127,7 @@ def test_landing_block_across_two_processes():
     assert rc == 0, capi.lib.pdlpdev_last_error().decode()
     child = ("import sys, ctypes as C; sys.path.insert(0, %r); from cuopt_amd import capi; h = (C.c_uint8 * 64).from_buffer_copy(bytes.fromhex(sys.argv[1])); "
              "rc = capi.lib.pdlpdev_debug_ipc_store(0, h, %d, %r); print('store', rc, capi.lib.pdlpdev_last_error().decode() if rc else ''); sys.exit(0 if rc == 0 else 3)"
-             % (capi.ROOT if hasattr(capi, "ROOT") else __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), count, seed))
+             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), count, seed))
     r = subprocess.run([sys.executable, "-c", child, bytes(handle).hex()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
     wrong = capi.lib.pdlpdev_debug_ipc_wait(0, base, count, seed)
