@@ -149,6 +149,12 @@ static_assert(sizeof(BatchShared<8>) <= 80 * 1024 && sizeof(BatchShared<16>) <= 
 
 // row sums of the block [b0, b0 + 512) of panel rows [r0, r0 + nr): lane (g, h) -- group g of K / 2 lanes, lane h of it = the LPs 2h and
 // 2h + 1 -- ends with s[u][0..1] = the sums of row b0 + g + G * u for its two LPs
+// LDS hazards of batch_block_sums (round-6 audit; the stage round 5's contention run had caught one barrier short):
+//   prod[2][], scol[2][], sval[2][]  double-buffered by chunk parity.  Trip c (ends in barrier E(c)): reads scol / sval[(c + 1) & 1]
+//   (chunk c + 1's entries, written in trip c - 1), reads prod[(c - 1) & 1] (chunk c - 1's products, written in trip c - 1), writes
+//   prod[c & 1] (last read by the row sums of chunk c - 2 in trip c - 1, before E(c - 1)) and scol / sval[c & 1] with chunk c + 2's
+//   entries (last read by trip c - 1's requests for chunk c, before E(c - 1)).  Every write is separated from the last read of its slot
+//   by E(c - 1), every read from the write it depends on by E(c - 1) as well; the barrier in front of trip 0 covers the two staged chunks.
 template <int K>
 __device__ __forceinline__ void batch_block_sums(BatchShared<K>& S, int r0, int nr, int b0, const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
                                                  const double* __restrict__ val, const double* __restrict__ vK, double (&s)[BatchGeometry<K>::RU][2])

@@ -38,6 +38,13 @@ __device__ __forceinline__ double lds_row_sum(const double* prod, int a, int b)
   }
   return acc;
 }
+// LDS hazards of the resident loop (round-6 audit), barriers B1 ... B5 of an attempt (B5 sits inside block_sum_fast):
+//   xbar_s  written in the primal phase (own columns) before B1, gathered before B2; next written after B5 of the same attempt.
+//   prod    written before B2 (A xbar products, own slots) and before B4 (A^T y' products); read by the row sums before B3 / B5;
+//           each rewrite is behind the barrier that ends the previous readers (B3 -> B4's writes, B5 -> the next attempt's B2 writes).
+//   yn_s    written before B3 (own rows), gathered before B4; next written behind B1 ... B2 of the next attempt.
+//   red[2], pw[2]  by attempt parity: written before B5 / B3, read behind B5; the same parity is written again two attempts later,
+//           ten barriers on.  Constants (c_s, bounds) are written once before the first B1.
 template <int T, int Q, int U>
 __device__ __forceinline__ void resident_body(const SmallView& V, pdlpdev_ctl* __restrict__ ctl, pdlpdev_ctl* __restrict__ ctl_host,
                                               const pdlpdev_step_params& sp, int target_steps, int max_attempts, double* lds)

@@ -5,6 +5,10 @@
 
 namespace pdlp {
 
+// LDS hazards of jag_block (round-6 audit): nothing is double-buffered.  The column set xwin[] is filled once and is read-only behind
+// the first barrier; the strip psum[] is zeroed before that barrier, each of its entries is then written by exactly one lane (the
+// lane of the row's pass; rows of their own workgroups get their mark from one thread, never a pass), and read by the epilogue behind
+// the second barrier; the reduction scratch reuses xwin[] behind a third barrier.  No barrier inside the loop over the diagonals.
 template <class Epi, int WAVES>
 __device__ __forceinline__ void jag_block(const JagView& J, const double* __restrict__ vec, Epi& epi,
                                           double* __restrict__ partials)

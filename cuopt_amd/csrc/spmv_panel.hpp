@@ -164,6 +164,15 @@ __device__ __forceinline__ void panel_epilogue(const PanelView& P, Epi& epi, dou
   }
 }
 
+// LDS hazards of panel_spmv_block (round-6 audit; "reader -> next writer: the barrier between them"):
+//   prod[]  (ONE buffer; the chunk "one stage ahead" lives in REGISTERS: va / ja / ext_next)
+//            written by panel_products of chunk i between barrier T(i) [loop top] and barrier M(i) [after the next chunk's requests];
+//            read by the row sums of chunk i after M(i); next written by chunk i + 1 after T(i + 1) -- every row sum of chunk i ends
+//            before its thread arrives at T(i + 1).
+//   psum[]  zeroed before the first barrier; row r is read and written by lane r % 512 ONLY (also in the long-segment path: the lane
+//            that owns the row adds the wave's partial), the "not mine" marks are written after the first barrier to rows that have no
+//            segment in any tile; the epilogue reads behind the barrier after the loop.
+//   tile_s / base_s  written once before the first barrier, read-only afterwards.
 template <class Epi>
 __device__ __forceinline__ void panel_spmv_block(const PanelView& P, const double* __restrict__ vec,
                                                  Epi& epi, double* __restrict__ partials)
@@ -396,6 +405,15 @@ __device__ __forceinline__ void seg_rounds(const double* __restrict__ vec, int s
     }
   }
 }
+// LDS hazards of panel_seg_block (round-6 audit):
+//   rec[2][]  the edge-run records, double-buffered by chunk parity.  rec[p] is written by every wave during the rounds of chunk i
+//             (parity p), read by wave 0's join after the chunk's barrier B(i), and next written during the rounds of chunk i + 2,
+//             i.e. after B(i + 1) -- wave 0 finishes its join of chunk i, in program order, before it arrives at B(i + 1).
+//   psum[]    LDS atomics (ds_add_f64) from every wave, at most ONE emission per row and chunk (a row's interior run lies inside one
+//             wave-round; its edge runs go through the records), so two chunks' emissions to one row are separated by a barrier and
+//             the order of a row's additions is fixed.
+//   psum2[]   emitted to by wave 0 alone (the joined edge runs), in program order.
+//   the epilogue reads psum + psum2 behind the barrier after the loop.
 template <class Epi>
 __device__ __forceinline__ void panel_seg_block(const PanelView& P, const double* __restrict__ vec, Epi& epi, double* __restrict__ partials)
 {

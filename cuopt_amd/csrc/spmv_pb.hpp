@@ -5,6 +5,10 @@
 
 namespace pdlp {
 
+// LDS hazards of the gather-free kernels (round-6 audit): no stage is double-buffered.  Phase P fills its slice xs[] of the vector,
+// barrier, reads only.  Phase R parks the bin's image lp[] from registers (requested before the row descriptors), barrier, sums its
+// rows from it into strip[] (one lane per row), barrier, streams the epilogue, barrier, reuses lp[] as reduction scratch.  The products
+// travel from P to R through HBM across a kernel boundary.
 template <int THREADS>
 __device__ __forceinline__ void pb_products_block(const PbView& V, const double* __restrict__ vec, double* xs)
 {
