@@ -78,6 +78,29 @@ for k, cs in acc.items():
         print("   %-32s mean %.4g  (first %.4g, n %d)" % (c, sum(v) / len(v), v[0], len(v)))
 PYEOF
                cat "$OUT/${RND}_batch_spmv_pmc.txt" | cut -c1-150; rm -rf "$OUT"/bsp_pmc_? ;;
+    cell) # the sorted-cell probe (round 6, second design): cell:<workload>[:<NP S E PE PG atomic dbg reps>]  -- sweep when no configuration is given
+          W=${arg%%:*}; CFG=""; [ "$W" != "$arg" ] && CFG=${arg#*:}
+          [ -d /tmp/csr_$W ] || python scripts/dump_csr.py "$W" /tmp/csr_$W > "$OUT/cell_dump_$W.log" 2>&1
+          /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/sorted_cell_probe.hip -o /tmp/sorted_cell_probe > "$OUT/cell_build.log" 2>&1
+          timeout 900 /tmp/sorted_cell_probe /tmp/csr_$W $CFG >> "$OUT/${RND}_cell_probe_$W.txt" 2>&1; tail -n 40 "$OUT/${RND}_cell_probe_$W.txt" | cut -c1-260 ;;
+    cellpmc) W=${arg%%:*}; CFG=${arg#*:}; R=$PWD; i=0
+          for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+            i=$((i+1))
+            (cd /tmp && timeout -k 5 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/cell_pmc_$i" -- /tmp/sorted_cell_probe /tmp/csr_$W $CFG > "$R/$OUT/cell_pmc_$i.log" 2>&1)
+          done
+          python - "$OUT" > "$OUT/${RND}_cell_probe_${W}_pmc.txt" <<'PYEOF'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("%s/cell_pmc_*/*/*_counter_collection.csv" % out):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print("   %-32s mean %.4g  (first %.4g, n %d)" % (c, sum(v) / len(v), v[0], len(v)))
+PYEOF
+          cat "$OUT/${RND}_cell_probe_${W}_pmc.txt" | cut -c1-150; rm -rf "$OUT"/cell_pmc_? ;;
     tall) # the tall-panel probe (round 6): tall:<workload>[:<NP S SW LW CW D reps>]  -- sweep when no configuration is given
           W=${arg%%:*}; CFG=""; [ "$W" != "$arg" ] && CFG=${arg#*:}
           [ -d /tmp/csr_$W ] || python scripts/dump_csr.py "$W" /tmp/csr_$W > "$OUT/tall_dump_$W.log" 2>&1
