@@ -377,9 +377,301 @@ k_pb_rows(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, con
 }
 }  // namespace
 
+// ================================================================================================
+// gather-free layout with WIDE bins from a device-resident CSR (pdlp_kernels.hpp kPbw*, host reference: build_pb_wide in kernels_pb.hip;
+// returns 1: not built here, 0: built, or "does not fit" with dst->on false and *why set).  Bins are kPbwRows consecutive rows, so nothing
+// is searched for:
+//   * k_pbw_count: a workgroup per bin, an LDS histogram over the panels -> the B x S chunk table (16-bit) and the bin's image size;
+//   * the table's transposed exclusive scan gives the panel-major starts of phase P (the kernels of the other geometry);
+//   * k_pbw_place: a workgroup per bin.  An entry's rank inside its (bin, panel) chunk is the number of earlier entries of the bin, in
+//     (row, column) order, that fall into the same panel: the bin's entries are cut into 8 contiguous SEGMENTS, every segment is
+//     counted per panel (LDS atomics: order does not matter for a count), the counts are scanned per panel over the segments, and then
+//     ONE WAVE per segment walks it 64 entries at a time -- the lanes of equal panel find each other with 12 ballots, the earlier ones
+//     among them are the rank inside the tile, the segment's running count per panel (LDS, private to the wave) the rest;
+//   * k_pbw_levels: a workgroup per step of the image; the level of a slot = the number of earlier slots of the step with the same row:
+//     rounds of ds_min over a tag per row (the earliest pending slot of every row wins the round's level).
+// ================================================================================================
+namespace {
+constexpr int kPbwSeg = 8;
+constexpr int kPbwMaxPanels = 4096;  // 36 bytes of LDS per panel in k_pbw_place
+
+__global__ void __launch_bounds__(kT) k_pbw_rowin(int32_t rows, const int32_t* __restrict__ off, uint16_t* __restrict__ rowin)
+{
+  for (int64_t r = (int64_t)blockIdx.x * kT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kT) {
+    const uint16_t v = (uint16_t)(r & (kPbwRows - 1));
+    for (int k = off[r]; k < off[r + 1]; ++k) rowin[k] = v;
+  }
+}
+
+__global__ void __launch_bounds__(512)
+k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int panel_shift, int S, int32_t* __restrict__ bin_size,
+            int* __restrict__ flags /* [0] longest chunk, [1] largest bin */, uint16_t* __restrict__ cnt)
+{
+  extern __shared__ int hist[];
+  __shared__ int scratch[9];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = b * kPbwRows, r1 = min(rows, r0 + kPbwRows);
+  const int k0 = off[r0], k1 = off[r1];
+  for (int i = tid; i < S; i += 512) hist[i] = 0;
+  __syncthreads();
+  for (int k = k0 + tid; k < k1; k += 512) atomicAdd(&hist[idx[k] >> panel_shift], 1);
+  __syncthreads();
+  int sum = 0, longest = 0;
+  for (int i = tid; i < S; i += 512) {
+    const int c_ = hist[i];
+    sum += (c_ + 15) & ~15;
+    longest = max(longest, c_);
+    cnt[(size_t)b * S + i] = (uint16_t)c_;
+  }
+  int total = 0;
+  (void)block_exclusive_scan<512>(sum, scratch, &total);
+  for (int d = 1; d < 64; d <<= 1) longest = max(longest, __shfl_xor(longest, d, 64));
+  if ((tid & 63) == 0 && longest > 0) atomicMax(flags, longest);
+  if (tid == 0) {
+    total = (total + kPbwStep - 1) / kPbwStep * kPbwStep;
+    bin_size[b] = total;
+    atomicMax(flags + 1, total);
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const uint16_t* __restrict__ rowin, int panel_shift, int S, int B,
+            const int32_t* __restrict__ pstart, const int32_t* __restrict__ bin_e0, int32_t* __restrict__ perm, uint16_t* __restrict__ lidx,
+            int32_t* __restrict__ piece_dst, uint16_t* __restrict__ rib)
+{
+  extern __shared__ uint32_t sm[];
+  __shared__ int scratch[17];
+  uint32_t* tab = sm;                         // [kPbwSeg][S]: counts, then the segments' first ranks, then running ranks
+  int* lst      = (int*)(sm + kPbwSeg * S);   // [S] the chunk's place in the bin's image
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = b * kPbwRows, r1 = min(rows, r0 + kPbwRows);
+  const int k0 = off[r0], n = off[r1] - k0;
+  const int seglen = max(64, ((n + kPbwSeg * 64 - 1) / (kPbwSeg * 64)) * 64);
+  for (int i = tid; i < kPbwSeg * S; i += 1024) tab[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&tab[(i / seglen) * S + (idx[k0 + i] >> panel_shift)], 1u);
+  __syncthreads();
+  constexpr int KPT = kPbwMaxPanels / 1024;
+  int padv[KPT], sum = 0;
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const int key = tid * KPT + q;
+    padv[q]       = 0;
+    if (key < S) {
+      uint32_t run = 0;
+      for (int g = 0; g < kPbwSeg; ++g) {
+        const uint32_t c_ = tab[g * S + key];
+        tab[g * S + key]  = run;
+        run += c_;
+      }
+      padv[q] = (int)((run + 15u) & ~15u);
+    }
+    sum += padv[q];
+  }
+  int at        = block_exclusive_scan<1024>(sum, scratch, nullptr);
+  const int e0b = bin_e0[b];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const int key = tid * KPT + q;
+    if (key < S) {
+      lst[key] = at;
+      const int np_    = padv[q] >> 4;
+      const int32_t p0 = pstart[(size_t)key * B + b] >> 4, d0 = (e0b + at) >> 4;
+      for (int i = 0; i < np_; ++i) piece_dst[p0 + i] = d0 + i;
+    }
+    at += padv[q];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  if (wave >= kPbwSeg) return;
+  uint32_t* mine   = tab + wave * S;
+  const int segb   = wave * seglen, sege = min(n, segb + seglen);
+  const int cmask  = (1 << panel_shift) - 1;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i0 = segb; i0 < sege; i0 += 64) {
+    const int i      = i0 + lane;
+    const bool valid = i < sege;
+    const int k      = k0 + (valid ? i : segb);
+    const int col    = idx[k];
+    const int key    = col >> panel_shift;
+    unsigned long long mask = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 12; ++bit) {
+      const bool one = (key >> bit) & 1;
+      const unsigned long long bal = __ballot(one);
+      mask &= one ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t base = mine[key];
+      const int rank      = (int)base + __popcll(mask & lt);
+      if ((mask & lt) == 0ull) mine[key] = base + (uint32_t)__popcll(mask);  // (the first lane of the group; behind every lane's read: one wave's LDS operations execute in order)
+      const int32_t pp = pstart[(size_t)key * B + b] + rank;
+      perm[pp] = k;
+      lidx[pp] = (uint16_t)(col & cmask);
+      rib[(size_t)e0b + lst[key] + rank] = rowin[k];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_pbw_levels(uint16_t* __restrict__ rib, uint8_t* __restrict__ step_lv, int* __restrict__ fail)
+{
+  __shared__ uint32_t tag[kPbwRows];
+  const int t = threadIdx.x;
+  for (int i = t; i < kPbwRows; i += 1024) tag[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  uint16_t* w      = rib + (size_t)blockIdx.x * kPbwStep + t;
+  const uint16_t v = *w;
+  const int row    = v & (kPbwRows - 1);
+  bool pending     = v != 0xFFFFu;
+  int lvl = 0, round = 0;
+  for (;;) {
+    if (pending) atomicMin(&tag[row], (uint32_t)t);
+    __syncthreads();
+    const bool won = pending && tag[row] == (uint32_t)t;
+    __syncthreads();
+    if (won) tag[row] = 0xFFFFFFFFu, lvl = round, pending = false;
+    if (!__syncthreads_or(pending)) break;
+    if (++round > kPbwMaxLevel) {
+      if (t == 0) *fail = 1;
+      break;
+    }
+  }
+  if (v != 0xFFFFu) *w = (uint16_t)(row | lvl << 13);
+  if (t == 0) step_lv[blockIdx.x] = (uint8_t)min(round, kPbwMaxLevel);
+}
+}  // namespace
+
+int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
+                         int cus, bool forced, std::string* why)
+{
+  const int64_t nnz = rows > 0 ? h_off[rows] : 0;
+  if (rows <= 0 || cols <= 0 || nnz <= 0) { *why = "empty matrix"; return 0; }
+  const int panel_shift = cols > (1 << 21) ? 14 : 13;
+  const int S           = (int)(((int64_t)cols + (1 << panel_shift) - 1) >> panel_shift);
+  if (S > kPbwMaxPanels) return 1;
+  hipStream_t s = c->stream;
+  const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto plap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cuopt_amd setup]     gather-free (wide bins): %-14s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  std::vector<void*> tmp;
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() { for (void* p : v) (void)hipFree(p); }
+  } free_tmp{tmp};
+  auto talloc = [&](void** p, size_t bytes) -> int {
+    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    tmp.push_back(*p);
+    return 0;
+  };
+  int* d_scal = nullptr;  // [0] longest row, [1] longest chunk, [2] largest bin, [3] level overflow
+  TRY(talloc((void**)&d_scal, 4 * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d_scal, 0, 4 * sizeof(int), s));
+  k_max_row_len<<<grid_of(rows), kT, 0, s>>>(rows, d_off, d_scal);
+  const int B = (rows + kPbwRows - 1) / kPbwRows;
+  uint16_t* d_cnt = nullptr;
+  int32_t* d_bin_size = nullptr;
+  TRY(talloc((void**)&d_cnt, (size_t)B * S * sizeof(uint16_t)));
+  TRY(talloc((void**)&d_bin_size, (size_t)B * sizeof(int32_t)));
+  k_pbw_count<<<B, 512, (size_t)S * sizeof(int), s>>>(rows, d_off, d_idx, panel_shift, S, d_bin_size, d_scal + 1, d_cnt);
+  HIP_TRY(hipGetLastError());
+  int h_scal[4] = {0, 0, 0, 0};
+  std::vector<int32_t> bin_size(B), bin_e0((size_t)B + 1, 0), row0((size_t)B + 1);
+  HIP_TRY(hipMemcpyAsync(h_scal, d_scal, sizeof(h_scal), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(bin_size.data(), d_bin_size, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_scal[0] > (forced ? kPbCap / 2 : 256)) { *why = "a row with " + std::to_string(h_scal[0]) + " nonzeros"; return 0; }
+  if (h_scal[1] > 65535 || h_scal[2] > kPbwMaxSteps * kPbwStep) { *why = "a chunk of more than 65535 entries or a bin of more than 4096 steps"; return 0; }
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    row0[b]   = (int32_t)((int64_t)b * kPbwRows);
+    bin_e0[b] = (int32_t)total;
+    total += bin_size[b];
+    if (total >= ((int64_t)1 << 31) - 65536) { *why = "more than 2^31 padded entries"; return 0; }
+  }
+  row0[B] = rows, bin_e0[B] = (int32_t)total;
+  plap("chunk counts");
+  const int gshift = 4, G = 16;
+  const int64_t cells = (int64_t)S * B;
+  int32_t *d_sizes = nullptr, *d_pstart = nullptr, *d_bs = nullptr;
+  TRY(talloc((void**)&d_sizes, (size_t)cells * sizeof(int32_t)));
+  TRY(talloc((void**)&d_pstart, ((size_t)cells + 1) * sizeof(int32_t)));
+  TRY(talloc((void**)&d_bs, ((size_t)(cells + 1) / 4096 + 2) * sizeof(int32_t)));
+  k_pb_chunk_sizes<<<grid_of(cells), kT, 0, s>>>(d_cnt, S, B, gshift, d_sizes);
+  TRY(dev_exclusive_scan(s, d_sizes, d_pstart, cells, d_bs));
+  uint16_t* d_rowin = nullptr;
+  TRY(talloc((void**)&d_rowin, ((size_t)nnz + 64) * sizeof(uint16_t)));
+  k_pbw_rowin<<<grid_of(rows), kT, 0, s>>>(rows, d_off, d_rowin);
+  plap("chunk table");
+  int32_t *piece_dst = nullptr, *wg_e0 = nullptr, *wg_panel = nullptr, *bin_row0 = nullptr, *d_bin_e0 = nullptr;
+  uint16_t *lidx = nullptr, *rib = nullptr;
+  uint8_t* step_lv = nullptr;
+  double* prod = nullptr;
+  const size_t slack = (size_t)kPbwAhead * kPbwStep;
+  TRY(dev_alloc(c, &dst->perm, (size_t)total + 64));
+  TRY(dev_alloc(c, &piece_dst, (size_t)(total >> gshift) + 64));
+  TRY(dev_alloc(c, &lidx, (size_t)total + 64));
+  TRY(dev_alloc(c, &rib, (size_t)total + slack + 64));
+  TRY(dev_alloc(c, &step_lv, (size_t)(total >> 10) + 64));
+  HIP_TRY(hipMemsetAsync(dst->perm, 0xFF, (size_t)total * sizeof(int32_t), s));  // padding slots: -1 (their lidx: 0, dev_alloc's zero fill)
+  HIP_TRY(hipMemsetAsync(rib, 0xFF, (size_t)total * sizeof(uint16_t), s));        // padding slots: level 7
+  TRY(upload_i32(c, &bin_row0, row0.data(), row0.size()));
+  TRY(upload_i32(c, &d_bin_e0, bin_e0.data(), bin_e0.size()));
+  plap("alloc");
+  k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib);
+  HIP_TRY(hipGetLastError());
+  plap("place");
+  if (total > 0) k_pbw_levels<<<(unsigned)(total >> 10), 1024, 0, s>>>(rib, step_lv, d_scal + 3);
+  HIP_TRY(hipGetLastError());
+  // P workgroups: every panel's entries in Q parts (pieces are not split)
+  int32_t* d_pan = nullptr;
+  TRY(talloc((void**)&d_pan, ((size_t)S + 1) * sizeof(int32_t)));
+  k_pb_panel_starts<<<grid_of(S + 1), kT, 0, s>>>(d_pstart, S, B, d_pan);
+  std::vector<int32_t> pan((size_t)S + 1);
+  HIP_TRY(hipMemcpyAsync(pan.data(), d_pan, pan.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_scal + 3, d_scal + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  plap("levels");
+  if (h_scal[3]) { *why = "a row with more than 7 entries inside one step of its bin"; return 0; }  // (the arrays stay with the context until it is destroyed)
+  std::vector<int32_t> h_wg_e0, h_wg_panel;
+  const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
+  for (int s_ = 0; s_ < S; ++s_) {
+    const int64_t e0 = pan[s_], e1 = pan[s_ + 1];
+    const int64_t per = std::max<int64_t>(G, ((e1 - e0 + Q - 1) / Q + G - 1) / G * G);
+    for (int64_t e = e0; e < e1; e += per) {
+      h_wg_e0.push_back((int32_t)e);
+      h_wg_panel.push_back(s_);
+    }
+  }
+  h_wg_e0.push_back(pan[S]);
+  TRY(upload_i32(c, &wg_e0, h_wg_e0.data(), h_wg_e0.size()));
+  TRY(upload_i32(c, &wg_panel, h_wg_panel.data(), h_wg_panel.size()));
+  TRY(dev_alloc(c, &dst->val, (size_t)total + 64));
+  TRY(dev_alloc(c, &prod, (size_t)total + slack + 256));
+  HIP_TRY(hipStreamSynchronize(s));  // (the host vectors die here)
+  dst->v = PbView{rows, cols, S, B, gshift, panel_shift, (int)h_wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
+                  bin_row0, d_bin_e0, nullptr, nullptr, nullptr, nullptr, prod};
+  dst->v.wide = 1, dst->v.rib = rib, dst->v.step_lv = step_lv;
+  dst->np = total, dst->p_threads = panel_shift == 14 ? 1024 : 512, dst->pad = (double)total / (double)nnz;
+  dst->on = true;
+  plap("P workgroups");
+  return 0;
+}
+
 int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
                     int cus, bool forced, std::string* why)
 {
+  if (pb_wants_wide(cols)) {  // wide bins first; a matrix they cannot hold (or cannot be built for here) goes on to the image-in-LDS bins
+    std::string why_wide;
+    const int rc = build_pb_wide_device(c, dst, rows, cols, h_off, d_off, d_idx, cus, forced, &why_wide);
+    if (rc < 0 || (rc == 0 && dst->on)) return rc;
+    if (rc == 1) return 1;  // (the host builds: build_pb takes the same decision)
+  }
   const int64_t nnz = rows > 0 ? h_off[rows] : 0;
   if (rows <= 0 || cols <= 0 || nnz <= 0) { *why = "empty matrix"; return 0; }
   hipStream_t s = c->stream;

@@ -889,23 +889,25 @@ static int pb_products(pdlpdev_ctx* c, const pdlpdev_ctx::Pb& L, const double* v
   else launch_k(c, k_pb_products<512>, grid, 512, lds, L.v, c->ctl, v0, v1, mode, in_loop);
   return 0;
 }
-// ... and phase R with the epilogue of the call site
+// ... and phase R with the epilogue of the call site (two skeletons: the image in LDS, or -- wide bins -- the accumulators in LDS)
 template <typename... KArgs, typename... Args>
-static int pb_rows(pdlpdev_ctx* c, void (*kernel)(PbView, KArgs...), const pdlpdev_ctx::Pb& L, Args... args)
+static int pb_rows_launch(pdlpdev_ctx* c, void (*kernel)(PbView, KArgs...), const pdlpdev_ctx::Pb& L, Args... args)
 {
   static std::mutex mu;
   static std::vector<std::pair<const void*, int>> done;
+  const size_t lds  = L.v.wide ? kPbwLdsBytes : kPbLdsBytes;
   {
     std::lock_guard<std::mutex> lock(mu);
     const std::pair<const void*, int> key((const void*)kernel, c->device);
     if (std::find(done.begin(), done.end(), key) == done.end()) {
-      HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPbLdsBytes));
+      HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       done.push_back(key);
     }
   }
-  launch_k(c, kernel, (L.v.B + 7) & ~7, kPbThreads, kPbLdsBytes, L.v, args...);
+  launch_k(c, kernel, (L.v.B + 7) & ~7, L.v.wide ? kPbwThreads : kPbThreads, lds, L.v, args...);
   return 0;
 }
+#define pb_rows(ctx, KERNEL, L, ...) ((L).v.wide ? pb_rows_launch(ctx, KERNEL<true>, L, __VA_ARGS__) : pb_rows_launch(ctx, KERNEL<false>, L, __VA_ARGS__))
 
 // panel values <- current CSR values (after upload and again after scale_problem)
 int sync_panel_values(pdlpdev_ctx* c)
@@ -2330,16 +2332,20 @@ int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16])
   auto gather_free = [&](const pdlpdev_ctx::Pb& P, int64_t side_nnz, uint64_t* o) {  // (a side is in ONE layout: the panels' slots)
     if (!P.on) return;
     const PbView& v = P.v;
-    int32_t groups = 0;
-    (void)hipMemcpy(&groups, v.bin_grp + v.B, sizeof(int32_t), hipMemcpyDeviceToHost);
     o[0] = checksum_device(ctx, P.perm, (size_t)P.np * 4);
     o[1] = checksum_device(ctx, v.lidx, (size_t)P.np * 2);
     o[2] = checksum_device(ctx, v.piece_dst, (size_t)(P.np >> v.gshift) * 4);
-    o[3] = checksum_device(ctx, v.pos, (size_t)side_nnz * 2) ^ (checksum_device(ctx, v.sr, (size_t)v.rows * 4) * 3);
     o[4] = checksum_device(ctx, v.wg_e0, ((size_t)v.nwg + 1) * 4) ^ (checksum_device(ctx, v.wg_panel, (size_t)v.nwg * 4) * 3) ^
            (checksum_device(ctx, v.bin_row0, ((size_t)v.B + 1) * 4) * 5) ^ (checksum_device(ctx, v.bin_e0, ((size_t)v.B + 1) * 4) * 7) ^
-           (checksum_device(ctx, v.bin_grp, ((size_t)v.B + 1) * 4) * 11) ^ (checksum_device(ctx, v.grp_pos, ((size_t)groups + 1) * 4) * 13) ^
-           (uint64_t)v.S * 17 ^ (uint64_t)v.gshift * 19 ^ (uint64_t)v.panel_shift * 23 ^ (uint64_t)P.p_threads * 29;
+           (uint64_t)v.S * 17 ^ (uint64_t)v.gshift * 19 ^ (uint64_t)v.panel_shift * 23 ^ (uint64_t)P.p_threads * 29 ^ (uint64_t)v.wide * 31;
+    if (v.wide) {  // the slot words and the steps' levels instead of the rows by length and the jagged diagonals
+      o[3] = checksum_device(ctx, v.rib, (size_t)P.np * 2) ^ (checksum_device(ctx, v.step_lv, (size_t)(P.np >> 10)) * 3);
+      return;
+    }
+    int32_t groups = 0;
+    (void)hipMemcpy(&groups, v.bin_grp + v.B, sizeof(int32_t), hipMemcpyDeviceToHost);
+    o[3] = checksum_device(ctx, v.pos, (size_t)side_nnz * 2) ^ (checksum_device(ctx, v.sr, (size_t)v.rows * 4) * 3);
+    o[4] ^= (checksum_device(ctx, v.bin_grp, ((size_t)v.B + 1) * 4) * 11) ^ (checksum_device(ctx, v.grp_pos, ((size_t)groups + 1) * 4) * 13);
   };
   gather_free(ctx->pba, ctx->dense.on ? ctx->dense.hot_nnz : ctx->nnz, out + 3);
   gather_free(ctx->pbat, ctx->dense.on ? ctx->hot_nnz_at : ctx->nnz, out + 8);

@@ -217,24 +217,60 @@ __global__ void __launch_bounds__(THREADS)
 k_pb_products(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);
 extern template __global__ void k_pb_products<512>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);
 extern template __global__ void k_pb_products<1024>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);
-__global__ void __launch_bounds__(kPbThreads)
+// (phase R: WIDE = the wide-bin skeleton, 1024 threads; otherwise the image-in-LDS skeleton, 512)
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
 k_pb_a_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
             const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
             const p2pdev::Push* __restrict__ push);
-__global__ void __launch_bounds__(kPbThreads)
+extern template __global__ void k_pb_a_dual<false>(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
+            const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+            const p2pdev::Push* __restrict__ push);
+extern template __global__ void k_pb_a_dual<true>(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ y0, double* __restrict__ y1, const double* __restrict__ lo,
+            const double* __restrict__ hi, double* __restrict__ sumy, double* __restrict__ part, double* __restrict__ ycopy,
+            const p2pdev::Push* __restrict__ push);
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
 k_pb_at_step(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
              double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part);
-__global__ void __launch_bounds__(kPbThreads)
+extern template __global__ void k_pb_at_step<false>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
+             double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part);
+extern template __global__ void k_pb_at_step<true>(PbView V, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ x0, const double* __restrict__ x1,
+             double* __restrict__ aty0, double* __restrict__ aty1, double* __restrict__ part);
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
 k_pb_at_cur(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ aty0, double* __restrict__ aty1,
             double* __restrict__ out_override, int use_next);
-__global__ void __launch_bounds__(kPbThreads) k_pb_plain(PbView V, double* __restrict__ out);
-__global__ void __launch_bounds__(kPbThreads)
+extern template __global__ void k_pb_at_cur<false>(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ aty0, double* __restrict__ aty1,
+            double* __restrict__ out_override, int use_next);
+extern template __global__ void k_pb_at_cur<true>(PbView V, const pdlpdev_ctl* __restrict__ ctl, double* __restrict__ aty0, double* __restrict__ aty1,
+            double* __restrict__ out_override, int use_next);
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
+k_pb_plain(PbView V, double* __restrict__ out);
+extern template __global__ void k_pb_plain<false>(PbView V, double* __restrict__ out);
+extern template __global__ void k_pb_plain<true>(PbView V, double* __restrict__ out);
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
 k_pb_eval_primal(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
                  const double* __restrict__ avgy, const double* __restrict__ dr, const double* __restrict__ lo_u,
                  const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows, double* __restrict__ ax_out,
                  double* __restrict__ part);
-__global__ void __launch_bounds__(kPbThreads)
+extern template __global__ void k_pb_eval_primal<false>(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
+                 const double* __restrict__ avgy, const double* __restrict__ dr, const double* __restrict__ lo_u,
+                 const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows, double* __restrict__ ax_out,
+                 double* __restrict__ part);
+extern template __global__ void k_pb_eval_primal<true>(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ y0, const double* __restrict__ y1,
+                 const double* __restrict__ avgy, const double* __restrict__ dr, const double* __restrict__ lo_u,
+                 const double* __restrict__ hi_u, double eps_rel, double* __restrict__ linf_rows, double* __restrict__ ax_out,
+                 double* __restrict__ part);
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? kPbwThreads : kPbThreads)
 k_pb_eval_dual(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0, const double* __restrict__ x1,
+               const double* __restrict__ avgx, EvalDualCore core, double* __restrict__ part);
+extern template __global__ void k_pb_eval_dual<false>(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0, const double* __restrict__ x1,
+               const double* __restrict__ avgx, EvalDualCore core, double* __restrict__ part);
+extern template __global__ void k_pb_eval_dual<true>(PbView V, const pdlpdev_ctl* __restrict__ ctl, int which, const double* __restrict__ x0, const double* __restrict__ x1,
                const double* __restrict__ avgx, EvalDualCore core, double* __restrict__ part);
 __global__ void __launch_bounds__(kBlock)
 k_dense_rows(DenseView D, const pdlpdev_ctl* __restrict__ ctl, const double* __restrict__ v0, const double* __restrict__ v1, int mode, int in_loop);

@@ -302,6 +302,21 @@ constexpr int kPbMaxRows = 1024;   // rows per bin (two groups of 64 per wave)
 constexpr int kPbKU      = 16;     // jagged diagonals of positions requested before the bin's image has landed
 constexpr size_t kPbLdsBytes = sizeof(double) * (size_t)(kPbCap + kPbMaxRows + 128);
 typedef double pb_vec2d __attribute__((ext_vector_type(2)));
+// WIDE bins (round 6, profiles/r06_gather_free_at_scale.txt): beyond ~2 M columns the (panel, bin) chunks of the image-in-LDS geometry
+// shrink to a handful of entries -- panels x bins grows with the square of the size -- and phase P degenerates into 32-byte
+// scattered stores.  A wide bin is kPbwRows consecutive rows whose ACCUMULATORS live in LDS (64 KB: two workgroups per CU); its image
+// (chunks in panel order, padded to 16-entry pieces = whole 128-byte lines for phase P, the bin padded to whole steps) is STREAMED by
+// phase R in steps of kPbwStep products, lane <-> slot, with a static 16-bit word per slot: row in the bin (13 bits) and LEVEL (3 bits:
+// how many earlier slots of the same step belong to the same row; 7 = padding).  A step adds level 0, barrier, level 1, barrier, ...
+// up to the step's highest level (a byte per step): every accumulator gets one addition per phase, by one lane, in image order =
+// column order -- a row is still summed strictly left to right from 0.0, bit-identical to the sequential CSR sum.
+constexpr int kPbwRows     = 8192;
+constexpr int kPbwStep     = 1024;
+constexpr int kPbwThreads  = 1024;
+constexpr int kPbwMaxLevel = 6;
+constexpr int kPbwAhead    = 4;     // steps of products requested ahead (the arrays carry kPbwAhead steps of slack behind the last bin)
+constexpr int kPbwMaxSteps = 4096;  // steps of one bin (their levels sit in LDS as bytes)
+constexpr size_t kPbwLdsBytes = sizeof(double) * (size_t)(kPbwRows + 256) + kPbwMaxSteps;
 
 struct PbView {
   int rows, cols, S, B, gshift, panel_shift, nwg;  // G = 1 << gshift entries per piece, panels of 1 << panel_shift columns
@@ -318,6 +333,10 @@ struct PbView {
   const uint16_t* __restrict__ pos;      // nnz (+ pad): position inside the bin's image, jagged-diagonal order
   double* __restrict__ prod;             // padded entries (+ pad)
   const double* __restrict__ dense_add = nullptr;  // per row: what the dense segments contribute (see dense_plus)
+  // wide bins: sr / bin_grp / grp_pos / pos are unused (null)
+  int wide = 0;
+  const uint16_t* __restrict__ rib     = nullptr;  // per image slot: row in the bin | level << 13
+  const uint8_t* __restrict__ step_lv  = nullptr;  // per step of kPbwStep slots: its highest level
 };
 
 // phase P of one workgroup.  xs: LDS, 1 << panel_shift doubles.

@@ -51,6 +51,11 @@ struct PbHost {
   cuopt_amd::PoolArray<int32_t> perm, piece_dst;
   cuopt_amd::PoolArray<uint16_t> lidx, pos;
   cuopt_amd::PoolArray<uint32_t> sr;
+  // wide bins (build_pb_wide): bins of kPbwRows rows, 16-entry pieces, a slot word per image slot and a level per step instead of
+  // sr / bin_grp / grp_pos / pos
+  bool wide = false;
+  cuopt_amd::PoolArray<uint16_t> rib;
+  std::vector<uint8_t> step_lv;
 };
 
 // ---- dense row segments: detection and the sparse remainder (host) -----------------------------------------------------------
@@ -95,6 +100,8 @@ JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t*
 int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, const int32_t* d_off, const int32_t* d_idx,
                       const double* d_val);
 PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced);
+PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced);
+bool pb_wants_wide(int32_t cols);  // the geometry 'auto' takes for this many gathered columns (CUOPT_AMD_TUNE=pb_wide=0/1 overrides)
 int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h);
 void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t* idx, DenseHost* D);
 void strip_transpose(const DenseHost& Din, DenseHost* D, int32_t n, const int32_t* t_off, const int32_t* t_idx);

@@ -94,6 +94,8 @@ int build_jag_device(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, int32_t rows, int32_
                      const double* d_val, int mode, int cus);
 // gather-free layout from the device-resident CSR (kernels_setup.hip): 0 built or does not fit (dst->on says which, *why the reason),
 // 1 not handled here (nothing allocated: the host construction takes over), < 0 error
+int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
+                         int cus, bool forced, std::string* why);
 int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t cols, const int32_t* h_off, const int32_t* d_off, const int32_t* d_idx,
                     int cus, bool forced, std::string* why);
 int build_panels_device(pdlpdev_ctx* c, pdlpdev_ctx::Panels* dst, int32_t rows, int32_t cols, const int32_t* h_off,

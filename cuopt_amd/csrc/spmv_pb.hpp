@@ -151,4 +151,82 @@ __device__ __forceinline__ void pb_rows_block(const PbView& V, Epi& epi, double*
   }
 }
 
+// phase R of one WIDE bin (kPbwThreads threads, kPbwLdsBytes of dynamic LDS at `lds`).  LDS hazards: acc[] is zeroed, barrier; a step's
+// phase reads and writes only accumulators of pairwise different rows (the levels), a barrier ends every phase; the epilogue reads acc[]
+// behind the last phase's barrier; the reduction scratch is a region of its own.  Products and slot words are requested kPbwAhead steps
+// ahead into a ring of registers (straight-line code, counted vmcnt waits; the barriers leave vector-memory loads in flight).
+template <class Epi>
+__device__ __forceinline__ void pbw_rows_block(const PbView& V, Epi& epi, double* __restrict__ partials, double* lds)
+{
+  constexpr int T = kPbwThreads, WAVES = T / 64, PE = kPbwAhead;
+  double* acc   = lds;
+  double* red   = lds + kPbwRows;                                   // [256] reduction scratch
+  uint8_t* lvs  = reinterpret_cast<uint8_t*>(lds + kPbwRows + 256);  // [kPbwMaxSteps]
+  const int b   = xcd_remap((int)blockIdx.x, V.B);
+  if (b >= V.B) return;
+  const int tid   = (int)threadIdx.x;
+  const int e0    = V.bin_e0[b];
+  const int ns    = (V.bin_e0[b + 1] - e0) >> 10;
+  const int row0  = V.bin_row0[b];
+  const int brows = V.bin_row0[b + 1] - row0;
+  const double* __restrict__ prod = V.prod + e0 + tid;
+  // (the slot words travel as the 32-bit word that holds the lane's own and its neighbour's: a 16-bit load would be widened by a separate
+  //  instruction that the optimiser sinks away from the load -- to the loop's latch, behind a vmcnt(0))
+  const uint32_t* __restrict__ rib = reinterpret_cast<const uint32_t*>(V.rib + e0) + (tid >> 1);
+  const int half = (tid & 1) * 16;
+  double rv[PE];
+  uint32_t rr[PE];
+#pragma unroll
+  for (int d = 0; d < PE; ++d) {
+    rv[d] = __builtin_nontemporal_load(prod + (size_t)d * kPbwStep);
+    rr[d] = __builtin_nontemporal_load(rib + (size_t)d * (kPbwStep / 2));
+  }
+  for (int i = tid; i < kPbwRows; i += T) acc[i] = 0.0;
+  {
+    const uint8_t* lv = V.step_lv + (e0 >> 10);
+#pragma unroll 1
+    for (int i = tid; i < ns; i += T) lvs[i] = lv[i];
+  }
+  __syncthreads();
+  int s0 = 0;
+  do {  // (a do-while and no exit from the middle of the ring: the loop's head has one incoming state, the counted waits stay counted)
+#pragma unroll
+    for (int d = 0; d < PE; ++d) {
+      const int s        = s0 + d;
+      const bool live    = s < ns;  // (uniform; the ring's tail requests read the next bin's slots, or the slack behind the last one)
+      const uint32_t w   = (rr[d] >> half) & 0xFFFFu;
+      const double p     = rv[d];
+      const int row      = (int)(w & (kPbwRows - 1));
+      const unsigned lvl = w >> 13;
+      const int top      = __builtin_amdgcn_readfirstlane(live ? (int)lvs[s] : 0);
+      if (live && lvl == 0u) acc[row] = acc[row] + p;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int f = 1; f <= top; ++f) {  // (uniform trip count; no load inside)
+        if (lvl == (unsigned)f) acc[row] = acc[row] + p;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      // (behind the step's last use of the slot: the ring's registers are rewritten in place)
+      rv[d] = __builtin_nontemporal_load(prod + (size_t)(s + PE) * kPbwStep);
+      rr[d] = __builtin_nontemporal_load(rib + (size_t)(s + PE) * (kPbwStep / 2));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s0 += PE;
+  } while (s0 < ns);
+  double accq[Epi::NQ > 0 ? Epi::NQ : 1];
+#pragma unroll
+  for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) accq[q] = Epi::Op::identity();
+  for (int i = tid; i < brows; i += T) epi.row(row0 + i, dense_plus(V.dense_add, row0 + i, acc[i]), accq);
+  if constexpr (Epi::NQ > 0) {
+    block_reduce<typename Epi::Op, Epi::NQ, WAVES>(accq, red);
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < Epi::NQ; ++q) partials[(size_t)q * V.B + b] = accq[q];
+    }
+  }
+}
+
 }  // namespace pdlp

@@ -327,3 +327,30 @@ def test_problem_checking_through_the_c_api():
         prob.close()
         assert r["return_code"] == capi.CUOPT_VALIDATION_ERROR, change
         assert r["error_status"] == capi.CUOPT_VALIDATION_ERROR and message in r["error_string"], r["error_string"]
+
+
+@pytest.mark.parametrize("shape,transposed", [((200000, 30000, 3), False), ((200000, 30000, 3), True), ((30000, 200000, 16), False), ((30000, 200000, 16), True)])
+def test_wide_bins_of_the_gather_free_layout_on_the_host(shape, transposed):
+    """build_pb_wide (kernels_pb.hip) walked on the CPU exactly as phase P and phase R order the work -- pieces to image slots, steps of
+    1024 slots, one addition per row and level: the row sums are the sequential CSR sums bit for bit (the oracle's), every slot is
+    written once, no level exceeds its step's; a matrix whose rows crowd into few panels is refused"""
+    from cuopt_amd import synthetic
+    from oracle import orcbind
+    fn = capi.lib.pdlpdev_debug_pb_wide_host
+    fn.restype = C.c_int
+    p = synthetic.generate(*shape, seed=23)
+    m, n, off, idx, val = p["m"], p["n"], p["offsets"], p["indices"], p["values"]
+    if transposed:
+        off, idx, val = capi.csr_transpose(m, n, off, idx, val)
+        m, n = n, m
+    off, idx, val = (np.ascontiguousarray(a, t) for a, t in ((off, np.int32), (idx, np.int32), (val, np.float64)))
+    x = np.random.default_rng(1).standard_normal(n)
+    out, info = np.zeros(m), np.zeros(4, np.int64)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert fn(C.c_int32(m), C.c_int32(n), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
+    np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
+    assert info[1] == -(-m // 8192) and info[0] % 1024 == 0 and info[0] <= 1.06 * len(val) + 1024 * info[1] and info[3] <= 6
+    # ten entries per row over seven panels: more than seven of a row inside one step
+    q = synthetic.generate(60000, 50000, 10, seed=23)
+    off, idx, val = (np.ascontiguousarray(q[k], t) for k, t in (("offsets", np.int32), ("indices", np.int32), ("values", np.float64)))
+    assert fn(C.c_int32(q["m"]), C.c_int32(q["n"]), ptr(off), ptr(idx), ptr(val), ptr(np.zeros(q["n"])), ptr(np.zeros(q["m"])), None) == 1

@@ -3,6 +3,7 @@ widths, the automatic choice for gathered vectors beyond the panels' 16 slabs, a
 import numpy as np
 import pytest
 
+from conftest import set_tune
 from cuopt_amd import capi, synthetic
 from oracle import orcbind
 
@@ -63,3 +64,67 @@ def test_a_matrix_the_layout_cannot_hold_is_refused_loudly(monkeypatch):
              lb=np.zeros(n), ub=np.ones(n))
     with pytest.raises(Exception, match="gather-free"):
         capi.Device(p)
+
+
+@pytest.mark.parametrize("shape", [(200000, 30000, 3), (30000, 200000, 16), (400000, 400000, 6)], ids=["tall", "wide", "square"])
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_wide_bins_products_are_bit_exact_and_the_solve_reaches_the_optimum(shape, where, monkeypatch):
+    """the geometry 'auto' takes beyond 2 M columns (bins of 8192 rows whose accumulators live in LDS, the image streamed in steps of
+    1024 products, one addition per row and level), forced here on matrices of test size: both products bit-identical to the sequential
+    CSR sums, the first 40 iterations take the stream layout's decisions, a solve reaches the optimum -- with the layout built on the
+    device and on the host"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    set_tune(monkeypatch, pb_wide=1, pb_device=None if where == "device" else 0)
+    m, n, k = shape
+    p = synthetic.generate(m, n, k, seed=23)
+    dev = capi.Device(p)
+    lay = dev.layout()
+    assert lay["A"]["layout"] == lay["At"]["layout"] == "pb"
+    assert lay["A"]["workgroups"] == -(-m // 8192) and lay["At"]["workgroups"] == -(-n // 8192), "bins of 8192 rows: the wide geometry on both sides"
+    assert lay["A"]["padding_pct"] <= 12 and lay["At"]["padding_pct"] <= 12
+    _both_products_bit_exact(p, dev)
+    _both_products_bit_exact(p, dev, seed=2)
+    dev.close()
+    r = capi.solve(p, method=1, tol=1e-6)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "stream")
+    a = capi.Solver(p, tol=0.0, iteration_limit=40).advance()
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    b = capi.Solver(p, tol=0.0, iteration_limit=40).advance()
+    assert (a["steps_taken"], a["attempted_steps"]) == (b["steps_taken"], b["attempted_steps"])
+    assert b["step_size"] == pytest.approx(a["step_size"], rel=1e-9)
+
+
+def test_wide_bins_built_on_the_device_are_the_host_construction(monkeypatch):
+    """every array of the wide geometry (phase-P order, local columns, pieces, slot words with their levels, the steps' levels, bins,
+    P workgroups): FNV-1a checksums of build_pb_wide against the device construction (segment counts, ballots, ds_min rounds)"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    for shape, seed in (((200000, 30000, 3), 4), ((30000, 200000, 16), 6), ((300000, 250000, 5), 8)):
+        p = synthetic.generate(*shape, seed=seed)
+        set_tune(monkeypatch, pb_wide=1, pb_device=0)
+        host = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+        set_tune(monkeypatch, pb_wide=1, pb_device=None)
+        dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+        a, b = host.layout_checksums(), dev.layout_checksums()
+        assert (int(a[15]) >> 6) & 3 == 3, "both sides gather-free"
+        assert host.layout()["A"]["workgroups"] == -(-shape[0] // 8192)
+        np.testing.assert_array_equal(a, b)
+        host.close(), dev.close()
+
+
+def test_a_matrix_the_wide_bins_cannot_hold_takes_the_other_geometry(monkeypatch):
+    """ten entries per row over seven panels put more than seven entries of a row into one step: both constructions fall back to the
+    image-in-LDS bins, and agree"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    p = synthetic.generate(60000, 50000, 10, seed=23)
+    sums = []
+    for pb_device in (0, None):
+        set_tune(monkeypatch, pb_wide=1, pb_device=pb_device)
+        dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+        lay = dev.layout()
+        assert lay["A"]["layout"] == "pb" and lay["A"]["workgroups"] > -(-60000 // 8192)
+        _both_products_bit_exact(p, dev)
+        sums.append(dev.layout_checksums())
+        dev.close()
+    np.testing.assert_array_equal(sums[0], sums[1])
