@@ -443,7 +443,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny", "hard", "banded", "staircase", "block_angular", "powerlaw", "multiband", "dense_rows", "c3x10", "banded4",
-                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c5_batch256", "c5_batch64", "c5_batch1024", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
+                             "banded_shuffled", "staircase_shuffled", "block_angular_shuffled", "multiband_shuffled", "c3x100", "c3x200", "c5_batch256", "c5_batch64", "c5_batch1024", "c3_batch16", "c3_batch8", "c3_batch4", "c3_batch2", "c2_batch16", "c2_batch8", "c2_batch4"],
                     help="*_shuffled: the structured family under a seeded random row AND column permutation (the set-up's analysis pass has to find the structure)")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="lower bound on the duration of the timed region (timed_steps is rounded up): long enough for an outside observer that samples the GPU every few seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -541,6 +541,8 @@ def main():
         cfg = dict(kind=base, m=1_000_000, n=1_000_000, k=10, seed=7)
     elif base == "c3x100":
         cfg = dict(m=30_000_000, n=30_000_000, k=33, seed=2)
+    elif base == "c3x200":  # 1.98e9 nonzeros: the "2 B nonzeros" the reference's FAQ names as its capacity (int32 offsets: < 2^31)
+        cfg = dict(m=60_000_000, n=60_000_000, k=33, seed=2)
     else:
         cfg = dict(synthetic.CONFIGS[base])
     t_gen = time.time()
@@ -551,7 +553,7 @@ def main():
     if cache_file and os.path.exists(cache_file):
         z = np.load(cache_file, allow_pickle=False)
         p = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
-    elif args.workload == "c3x100":
+    elif args.workload in ("c3x100", "c3x200"):
         # 3e7 x 3e7 with 33 nonzeros per row: 9.9e8 nonzeros, generated ON THE DEVICE (pdlpdev_synthetic_lp: the host generator would
         # need minutes and tens of GB) -- the scale the reference's FAQ names for one 80 GB GPU (docs/cuopt/source/faq.rst:368-370)
         p = capi.synthetic_lp_on_device(cfg["m"], cfg["n"], cfg["k"], seed=cfg["seed"], device=local_rank)
@@ -561,7 +563,7 @@ def main():
         if shuffle:
             p = synthetic.shuffled(p, seed=5)
             p.pop("shuffle", None)
-        if cache_file and rank == 0 and args.workload != "c3x100":
+        if cache_file and rank == 0 and args.workload not in ("c3x100", "c3x200"):
             os.makedirs(cache, exist_ok=True)
             np.savez(cache_file, **{k: v for k, v in p.items() if isinstance(v, (np.ndarray, int, float, bool, np.integer, np.floating))})
     t_gen = time.time() - t_gen

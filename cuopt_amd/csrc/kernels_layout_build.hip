@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(kT) k_pbw_rowin(int32_t rows, const int32_t* _
 }
 
 __global__ void __launch_bounds__(512)
-k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int panel_shift, int S, int32_t* __restrict__ bin_size,
+k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, int panel_shift, int gshift, int S, int32_t* __restrict__ bin_size,
             int* __restrict__ flags /* [0] longest chunk, [1] largest bin */, uint16_t* __restrict__ cnt)
 {
   extern __shared__ int hist[];
@@ -416,10 +416,11 @@ k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
   __syncthreads();
   for (int k = k0 + tid; k < k1; k += 512) atomicAdd(&hist[idx[k] >> panel_shift], 1);
   __syncthreads();
+  const int gm = (1 << gshift) - 1;
   int sum = 0, longest = 0;
   for (int i = tid; i < S; i += 512) {
     const int c_ = hist[i];
-    sum += (c_ + 15) & ~15;
+    sum += (c_ + gm) & ~gm;
     longest = max(longest, c_);
     cnt[(size_t)b * S + i] = (uint16_t)c_;
   }
@@ -435,7 +436,7 @@ k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
 }
 
 __global__ void __launch_bounds__(1024)
-k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const uint16_t* __restrict__ rowin, int panel_shift, int S, int B,
+k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const uint16_t* __restrict__ rowin, int panel_shift, int gshift, int S, int B,
             const int32_t* __restrict__ pstart, const int32_t* __restrict__ bin_e0, int32_t* __restrict__ perm, uint16_t* __restrict__ lidx,
             int32_t* __restrict__ piece_dst, uint16_t* __restrict__ rib)
 {
@@ -452,6 +453,7 @@ k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
   for (int i = tid; i < n; i += 1024) atomicAdd(&tab[(i / seglen) * S + (idx[k0 + i] >> panel_shift)], 1u);
   __syncthreads();
   constexpr int KPT = kPbwMaxPanels / 1024;
+  const uint32_t gm = (1u << gshift) - 1u;
   int padv[KPT], sum = 0;
 #pragma unroll
   for (int q = 0; q < KPT; ++q) {
@@ -464,7 +466,7 @@ k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
         tab[g * S + key]  = run;
         run += c_;
       }
-      padv[q] = (int)((run + 15u) & ~15u);
+      padv[q] = (int)((run + gm) & ~gm);
     }
     sum += padv[q];
   }
@@ -475,8 +477,8 @@ k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
     const int key = tid * KPT + q;
     if (key < S) {
       lst[key] = at;
-      const int np_    = padv[q] >> 4;
-      const int32_t p0 = pstart[(size_t)key * B + b] >> 4, d0 = (e0b + at) >> 4;
+      const int np_    = padv[q] >> gshift;
+      const int32_t p0 = pstart[(size_t)key * B + b] >> gshift, d0 = (e0b + at) >> gshift;
       for (int i = 0; i < np_; ++i) piece_dst[p0 + i] = d0 + i;
     }
     at += padv[q];
@@ -578,7 +580,8 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   int32_t* d_bin_size = nullptr;
   TRY(talloc((void**)&d_cnt, (size_t)B * S * sizeof(uint16_t)));
   TRY(talloc((void**)&d_bin_size, (size_t)B * sizeof(int32_t)));
-  k_pbw_count<<<B, 512, (size_t)S * sizeof(int), s>>>(rows, d_off, d_idx, panel_shift, S, d_bin_size, d_scal + 1, d_cnt);
+  const int gshift = pbw_piece_shift(nnz, S, B), G = 1 << gshift;
+  k_pbw_count<<<B, 512, (size_t)S * sizeof(int), s>>>(rows, d_off, d_idx, panel_shift, gshift, S, d_bin_size, d_scal + 1, d_cnt);
   HIP_TRY(hipGetLastError());
   int h_scal[4] = {0, 0, 0, 0};
   std::vector<int32_t> bin_size(B), bin_e0((size_t)B + 1, 0), row0((size_t)B + 1);
@@ -596,7 +599,6 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   }
   row0[B] = rows, bin_e0[B] = (int32_t)total;
   plap("chunk counts");
-  const int gshift = 4, G = 16;
   const int64_t cells = (int64_t)S * B;
   int32_t *d_sizes = nullptr, *d_pstart = nullptr, *d_bs = nullptr;
   TRY(talloc((void**)&d_sizes, (size_t)cells * sizeof(int32_t)));
@@ -623,7 +625,7 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   TRY(upload_i32(c, &bin_row0, row0.data(), row0.size()));
   TRY(upload_i32(c, &d_bin_e0, bin_e0.data(), bin_e0.size()));
   plap("alloc");
-  k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib);
+  k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, gshift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib);
   HIP_TRY(hipGetLastError());
   plap("place");
   if (total > 0) k_pbw_levels<<<(unsigned)(total >> 10), 1024, 0, s>>>(rib, step_lv, d_scal + 3);

@@ -312,6 +312,8 @@ bool pb_wants_wide(int32_t cols)
   return cols > (1 << 21);
 }
 
+int pbw_piece_shift(int64_t nnz, int S, int B) { return nnz / ((int64_t)S * B) >= 96 ? 4 : 3; }
+
 PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced)
 {
   PbHost H;
@@ -330,11 +332,13 @@ PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32
   const int SP  = 1 << H.panel_shift;
   const int S   = (cols + SP - 1) >> H.panel_shift;
   H.S           = S;
-  constexpr int G = 16;
-  H.gshift        = 4;
   const int threads = cuopt_amd::host_threads();
   const int B       = (rows + kPbwRows - 1) / kPbwRows;
   H.B               = B;
+  // pieces of 16 entries (whole 128-byte lines for phase P's stores) unless the chunks are shorter than 96 entries (then 8: at 2e9
+  // nonzeros -- chunks of 74 -- 16-entry pieces pad by 11 % and push the image past 2^31 entries)
+  H.gshift    = pbw_piece_shift(nnz, S, B);
+  const int G = 1 << H.gshift;
   H.bin_row0.resize((size_t)B + 1);
   for (int b = 0; b <= B; ++b) H.bin_row0[b] = (int32_t)std::min<int64_t>(rows, (int64_t)b * kPbwRows);
   const std::vector<int32_t>& row0 = H.bin_row0;

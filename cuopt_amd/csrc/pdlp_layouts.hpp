@@ -101,6 +101,7 @@ int upload_jag(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, const JagHost& h, const in
                       const double* d_val);
 PbHost build_pb(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced);
 PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, int cus, bool forced);
+int pbw_piece_shift(int64_t nnz, int S, int B);  // 4 (16-entry pieces) or 3
 bool pb_wants_wide(int32_t cols);  // the geometry 'auto' takes for this many gathered columns (CUOPT_AMD_TUNE=pb_wide=0/1 overrides)
 int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h);
 void find_dense_segments(int32_t m, int32_t n, const int32_t* off, const int32_t* idx, DenseHost* D);

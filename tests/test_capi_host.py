@@ -329,7 +329,8 @@ def test_problem_checking_through_the_c_api():
         assert r["error_status"] == capi.CUOPT_VALIDATION_ERROR and message in r["error_string"], r["error_string"]
 
 
-@pytest.mark.parametrize("shape,transposed", [((200000, 30000, 3), False), ((200000, 30000, 3), True), ((30000, 200000, 16), False), ((30000, 200000, 16), True)])
+@pytest.mark.parametrize("shape,transposed", [((200000, 30000, 3), False), ((200000, 30000, 3), True), ((30000, 200000, 16), False), ((30000, 200000, 16), True),
+                                              ((1500000, 4400000, 3), False), ((1500000, 4400000, 3), True)])
 def test_wide_bins_of_the_gather_free_layout_on_the_host(shape, transposed):
     """build_pb_wide (kernels_pb.hip) walked on the CPU exactly as phase P and phase R order the work -- pieces to image slots, steps of
     1024 slots, one addition per row and level: the row sums are the sequential CSR sums bit for bit (the oracle's), every slot is
@@ -349,7 +350,7 @@ def test_wide_bins_of_the_gather_free_layout_on_the_host(shape, transposed):
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)
     assert fn(C.c_int32(m), C.c_int32(n), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
     np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
-    assert info[1] == -(-m // 8192) and info[0] % 1024 == 0 and info[0] <= 1.06 * len(val) + 1024 * info[1] and info[3] <= 6
+    assert info[1] == -(-m // 8192) and info[0] % 1024 == 0 and info[0] <= (1.06 if shape[1] < 4400000 else 1.25) * len(val) + 1024 * info[1] and info[3] <= 6
     # ten entries per row over seven panels: more than seven of a row inside one step
     q = synthetic.generate(60000, 50000, 10, seed=23)
     off, idx, val = (np.ascontiguousarray(q[k], t) for k, t in (("offsets", np.int32), ("indices", np.int32), ("values", np.float64)))

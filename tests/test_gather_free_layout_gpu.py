@@ -66,7 +66,7 @@ def test_a_matrix_the_layout_cannot_hold_is_refused_loudly(monkeypatch):
         capi.Device(p)
 
 
-@pytest.mark.parametrize("shape", [(200000, 30000, 3), (30000, 200000, 16), (400000, 400000, 6)], ids=["tall", "wide", "square"])
+@pytest.mark.parametrize("shape", [(200000, 30000, 3), (30000, 200000, 16), (400000, 400000, 6), (1500000, 4400000, 3)], ids=["tall", "wide", "square", "short_chunks"])
 @pytest.mark.parametrize("where", ["device", "host"])
 def test_wide_bins_products_are_bit_exact_and_the_solve_reaches_the_optimum(shape, where, monkeypatch):
     """the geometry 'auto' takes beyond 2 M columns (bins of 8192 rows whose accumulators live in LDS, the image streamed in steps of
@@ -81,10 +81,13 @@ def test_wide_bins_products_are_bit_exact_and_the_solve_reaches_the_optimum(shap
     lay = dev.layout()
     assert lay["A"]["layout"] == lay["At"]["layout"] == "pb"
     assert lay["A"]["workgroups"] == -(-m // 8192) and lay["At"]["workgroups"] == -(-n // 8192), "bins of 8192 rows: the wide geometry on both sides"
-    assert lay["A"]["padding_pct"] <= 12 and lay["At"]["padding_pct"] <= 12
+    # ("short_chunks": 269 panels of 16384 columns x 184 bins, chunks of ~90 / ~45 entries: 8-entry pieces, and a bin's rounding to whole steps shows)
+    assert shape[1] == 4400000 or (lay["A"]["padding_pct"] <= 12 and lay["At"]["padding_pct"] <= 12)
     _both_products_bit_exact(p, dev)
     _both_products_bit_exact(p, dev, seed=2)
     dev.close()
+    if shape[1] == 4400000:
+        return  # (the geometry's case; a solve of this LP to 1e-6 takes minutes and adds nothing to it)
     r = capi.solve(p, method=1, tol=1e-6)
     assert r["status"] == "Optimal"
     assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
@@ -100,7 +103,7 @@ def test_wide_bins_built_on_the_device_are_the_host_construction(monkeypatch):
     """every array of the wide geometry (phase-P order, local columns, pieces, slot words with their levels, the steps' levels, bins,
     P workgroups): FNV-1a checksums of build_pb_wide against the device construction (segment counts, ballots, ds_min rounds)"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
-    for shape, seed in (((200000, 30000, 3), 4), ((30000, 200000, 16), 6), ((300000, 250000, 5), 8)):
+    for shape, seed in (((200000, 30000, 3), 4), ((30000, 200000, 16), 6), ((300000, 250000, 5), 8), ((1500000, 4400000, 3), 9)):
         p = synthetic.generate(*shape, seed=seed)
         set_tune(monkeypatch, pb_wide=1, pb_device=0)
         host = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
