@@ -3,7 +3,7 @@ same GPU (scripts/gpu_session.sh <tag> soak:<rounds>): the double-buffered LDS s
 not depend on how the workgroups of a launch happen to be scheduled.  Round-5 review, item 4: two races had shown up only under
 exactly this kind of load.  Prints one line per round; "MISMATCH" anywhere fails the soak.
 
-  python scripts/contention_layouts.py panel|panel_seg|jag|pb|stream|resident [rounds]"""
+  python scripts/contention_layouts.py panel|panel_seg|jag|pb|pb_wide|stream|resident [rounds]"""
 import os
 import sys
 
@@ -13,9 +13,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 layout = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-tune = {"panel": "slab_bytes=16384,panel_seg=0,panel_nnz=6000", "panel_seg": "slab_bytes=16384,panel_seg=1,panel_nnz=6000", "jag": "jag_waves=8", "pb": "", "stream": "",
+tune = {"panel": "slab_bytes=16384,panel_seg=0,panel_nnz=6000", "panel_seg": "slab_bytes=16384,panel_seg=1,panel_nnz=6000", "jag": "jag_waves=8", "pb": "", "pb_wide": "pb_wide=1", "stream": "",
         "resident": ""}[layout]
-os.environ["CUOPT_AMD_SPMV_LAYOUT"] = {"panel_seg": "panel", "resident": "auto"}.get(layout, layout)
+os.environ["CUOPT_AMD_SPMV_LAYOUT"] = {"panel_seg": "panel", "resident": "auto", "pb_wide": "pb"}.get(layout, layout)
 os.environ["CUOPT_AMD_SMALL"] = "1" if layout == "resident" else "0"
 if tune:
     os.environ["CUOPT_AMD_TUNE"] = tune
@@ -28,6 +28,8 @@ if layout == "resident":
     p = synthetic.generate(1000, 1000, 8, seed=4)
 elif layout == "jag":
     p = synthetic.generate(60000, 60000, 10, seed=2, band=300)
+elif layout == "pb_wide":  # (three entries per row over 25 bins x 4 panels: the wide bins hold it; steps with levels 0 ... 6 on the A^T side)
+    p = synthetic.generate(200000, 30000, 3, seed=21)
 else:
     p = synthetic.generate(60000, 50000, 10, seed=21)
 to, ti, tv = orcbind.transpose(p["m"], p["n"], p["offsets"], p["indices"], p["values"])
@@ -41,8 +43,9 @@ bad = 0
 for r in range(rounds):
     dev = capi.Device(p)
     lay = dev.layout()
-    want = "panel" if layout == "panel_seg" else layout
+    want = {"panel_seg": "panel", "pb_wide": "pb"}.get(layout, layout)
     assert lay["A"]["layout"] == want or (layout == "resident" and lay["resident"]), lay
+    assert layout != "pb_wide" or lay["A"]["workgroups"] == -(-p["m"] // 8192), lay
     ok_spmv, bits = True, []
     for (x, y), (ra, rt) in zip(vecs, refs):
         for vec, tr, rows, ref in ((x, False, p["m"], ra), (y, True, p["n"], rt)):

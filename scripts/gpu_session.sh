@@ -128,11 +128,11 @@ for k, cs in acc.items():
         print("   %-32s mean %.4g  (first %.4g, n %d)" % (c, sum(v) / len(v), v[0], len(v)))
 PYEOF
           cat "$OUT/${RND}_tall_probe_${W}_pmc.txt" | cut -c1-150; rm -rf "$OUT"/tall_pmc_? ;;
-    soak) # the contention soak (round 6): soak:<rounds>  -- six processes, one per layout, each comparing with the oracle; then the WHOLE
+    soak) # the contention soak (round 6): soak:<rounds>  -- seven processes, one per layout, each comparing with the oracle; then the WHOLE
           # gpu suite under pytest -n 4, <rounds> times
           : > "$OUT/${RND}_contention.txt"
-          for L in panel panel_seg jag pb stream resident; do timeout 900 python scripts/contention_layouts.py $L ${arg:-3} > "$OUT/soak_$L.log" 2>&1 & done; wait
-          { echo "== six processes side by side, one per layout (scripts/contention_layouts.py), ${arg:-3} rounds each"; cat "$OUT"/soak_*.log | grep -E "round|Error|Traceback|assert"; } >> "$OUT/${RND}_contention.txt"
+          for L in panel panel_seg jag pb pb_wide stream resident; do timeout 900 python scripts/contention_layouts.py $L ${arg:-3} > "$OUT/soak_$L.log" 2>&1 & done; wait
+          { echo "== seven processes side by side, one per layout (scripts/contention_layouts.py), ${arg:-3} rounds each"; cat "$OUT"/soak_*.log | grep -E "round|Error|Traceback|assert"; } >> "$OUT/${RND}_contention.txt"
           for i in $(seq 1 ${arg:-3}); do
             timeout 2400 python -m pytest tests -q -m gpu -n 4 -p no:cacheprovider > "$OUT/soak_suite_$i.log" 2>&1
             { echo "== the whole -m gpu suite under pytest -n 4, run $i"; tail -n 6 "$OUT/soak_suite_$i.log"; grep -E "^(FAILED|ERROR)" "$OUT/soak_suite_$i.log"; } >> "$OUT/${RND}_contention.txt"
