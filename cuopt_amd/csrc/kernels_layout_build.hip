@@ -389,7 +389,9 @@ k_pb_rows(const int32_t* __restrict__ row0, const int32_t* __restrict__ off, con
 //     ONE WAVE per segment walks it 64 entries at a time -- the lanes of equal panel find each other with 12 ballots, the earlier ones
 //     among them are the rank inside the tile, the segment's running count per panel (LDS, private to the wave) the rest;
 //   * k_pbw_levels: a workgroup per step of the image; the level of a slot = the number of earlier slots of the step with the same row:
-//     rounds of ds_min over a tag per row (the earliest pending slot of every row wins the round's level).
+//     rounds of ds_min over a tag per row (the earliest pending slot of every row wins the round's level).  Rows still pending after
+//     the last level are SERIAL rows: flagged, collected, ordered on the host (a handful), their slots erased from the steps and
+//     listed (k_pbw_serial) from the slots phase 'place' noted per entry.
 // ================================================================================================
 namespace {
 constexpr int kPbwSeg = 8;
@@ -438,7 +440,7 @@ k_pbw_count(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
 __global__ void __launch_bounds__(1024)
 k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const uint16_t* __restrict__ rowin, int panel_shift, int gshift, int S, int B,
             const int32_t* __restrict__ pstart, const int32_t* __restrict__ bin_e0, int32_t* __restrict__ perm, uint16_t* __restrict__ lidx,
-            int32_t* __restrict__ piece_dst, uint16_t* __restrict__ rib)
+            int32_t* __restrict__ piece_dst, uint16_t* __restrict__ rib, int32_t* __restrict__ eslot)
 {
   extern __shared__ uint32_t sm[];
   __shared__ int scratch[17];
@@ -511,11 +513,13 @@ k_pbw_place(int32_t rows, const int32_t* __restrict__ off, const int32_t* __rest
       perm[pp] = k;
       lidx[pp] = (uint16_t)(col & cmask);
       rib[(size_t)e0b + lst[key] + rank] = rowin[k];
+      eslot[k] = e0b + lst[key] + rank;  // (where the entry's product lands: the serial rows' lists are made of these)
     }
   }
 }
 
-__global__ void __launch_bounds__(1024) k_pbw_levels(uint16_t* __restrict__ rib, uint8_t* __restrict__ step_lv, int* __restrict__ fail)
+__global__ void __launch_bounds__(1024)
+k_pbw_levels(uint16_t* __restrict__ rib, uint8_t* __restrict__ step_lv, const int32_t* __restrict__ bin_e0, int B, uint8_t* __restrict__ serial, int* __restrict__ fail)
 {
   __shared__ uint32_t tag[kPbwRows];
   const int t = threadIdx.x;
@@ -534,12 +538,47 @@ __global__ void __launch_bounds__(1024) k_pbw_levels(uint16_t* __restrict__ rib,
     if (won) tag[row] = 0xFFFFFFFFu, lvl = round, pending = false;
     if (!__syncthreads_or(pending)) break;
     if (++round > kPbwMaxLevel) {
-      if (t == 0) *fail = 1;
+      // rows still pending have more than kPbwMaxLevel + 1 entries in this step: serial rows (the step's bin: the last one that
+      // starts at or before the step)
+      if (pending) {
+        const int32_t at = (int32_t)(blockIdx.x * (unsigned)kPbwStep);
+        int lo = 0, hi = B;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (bin_e0[mid] <= at) lo = mid; else hi = mid;
+        }
+        serial[(size_t)lo * kPbwRows + row] = 1;
+        *fail = 1;
+      }
       break;
     }
   }
   if (v != 0xFFFFu) *w = (uint16_t)(row | lvl << 13);
   if (t == 0) step_lv[blockIdx.x] = (uint8_t)min(round, kPbwMaxLevel);
+}
+
+// the flagged rows, in any order (the host sorts the few there are)
+__global__ void __launch_bounds__(kT) k_pbw_collect(int32_t rows, const uint8_t* __restrict__ serial, int32_t cap, int32_t* __restrict__ list, int* __restrict__ count)
+{
+  for (int64_t r = (int64_t)blockIdx.x * kT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kT)
+    if (serial[r]) {
+      const int at = atomicAdd(count, 1);
+      if (at < cap) list[at] = (int32_t)r;
+    }
+}
+// a serial row's slots read as padding; its list keeps where its products land, in column order
+__global__ void __launch_bounds__(kT)
+k_pbw_serial(int32_t nser, const int32_t* __restrict__ ser_row, const int32_t* __restrict__ ser_eptr, const int32_t* __restrict__ off, const int32_t* __restrict__ eslot,
+             uint16_t* __restrict__ rib, int32_t* __restrict__ ser_slot)
+{
+  const int q = blockIdx.x;
+  if (q >= nser) return;
+  const int r = ser_row[q], k0 = off[r], n = off[r + 1] - k0, e0 = ser_eptr[q];
+  for (int i = threadIdx.x; i < n; i += kT) {
+    const int32_t slot = eslot[k0 + i];
+    ser_slot[e0 + i]   = slot;
+    rib[slot]          = 0xFFFFu;
+  }
 }
 }  // namespace
 
@@ -625,10 +664,15 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   TRY(upload_i32(c, &bin_row0, row0.data(), row0.size()));
   TRY(upload_i32(c, &d_bin_e0, bin_e0.data(), bin_e0.size()));
   plap("alloc");
-  k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, gshift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib);
+  int32_t* d_eslot = nullptr;
+  uint8_t* d_serial = nullptr;
+  TRY(talloc((void**)&d_eslot, ((size_t)nnz + 64) * sizeof(int32_t)));
+  TRY(talloc((void**)&d_serial, (size_t)B * kPbwRows));
+  HIP_TRY(hipMemsetAsync(d_serial, 0, (size_t)B * kPbwRows, s));
+  k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, gshift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib, d_eslot);
   HIP_TRY(hipGetLastError());
   plap("place");
-  if (total > 0) k_pbw_levels<<<(unsigned)(total >> 10), 1024, 0, s>>>(rib, step_lv, d_scal + 3);
+  if (total > 0) k_pbw_levels<<<(unsigned)(total >> 10), 1024, 0, s>>>(rib, step_lv, d_bin_e0, B, d_serial, d_scal + 3);
   HIP_TRY(hipGetLastError());
   // P workgroups: every panel's entries in Q parts (pieces are not split)
   int32_t* d_pan = nullptr;
@@ -639,7 +683,43 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   HIP_TRY(hipMemcpyAsync(h_scal + 3, d_scal + 3, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   plap("levels");
-  if (h_scal[3]) { *why = "a row with more than 7 entries inside one step of its bin"; return 0; }  // (the arrays stay with the context until it is destroyed)
+  int32_t *ser_ptr = nullptr, *ser_row = nullptr, *ser_eptr = nullptr, *ser_slot = nullptr;
+  int nser = 0;
+  if (h_scal[3]) {
+    // serial rows (a row with more than 7 entries inside one step of its bin): collected on the device, ordered and priced on the host
+    int32_t* d_list = nullptr;
+    int* d_count = nullptr;
+    const int32_t cap = (int32_t)std::min<int64_t>(rows, 1 << 22);
+    TRY(talloc((void**)&d_list, (size_t)cap * sizeof(int32_t)));
+    TRY(talloc((void**)&d_count, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), s));
+    k_pbw_collect<<<grid_of(rows), kT, 0, s>>>(rows, d_serial, cap, d_list, d_count);
+    int count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const char* too_many = "more than a tenth of the nonzeros in rows with more than 7 entries inside one step of their bin";
+    if (count > cap) { *why = too_many; return 0; }  // (the arrays stay with the context until it is destroyed)
+    std::vector<int32_t> h_row((size_t)count), h_ptr((size_t)B + 1, 0), h_eptr((size_t)count + 1, 0);
+    HIP_TRY(hipMemcpy(h_row.data(), d_list, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::sort(h_row.begin(), h_row.end());
+    int64_t ser_nnz = 0;
+    for (int q = 0; q < count; ++q) {
+      ser_nnz += h_off[h_row[q] + 1] - h_off[h_row[q]];
+      h_eptr[q + 1] = (int32_t)ser_nnz;
+      h_ptr[h_row[q] / kPbwRows + 1]++;
+    }
+    for (int b = 0; b < B; ++b) h_ptr[b + 1] += h_ptr[b];
+    if (ser_nnz * 10 > nnz) { *why = too_many; return 0; }
+    nser = count;
+    TRY(upload_i32(c, &ser_ptr, h_ptr.data(), h_ptr.size()));
+    TRY(upload_i32(c, &ser_row, h_row.data(), h_row.size()));
+    TRY(upload_i32(c, &ser_eptr, h_eptr.data(), h_eptr.size()));
+    TRY(dev_alloc(c, &ser_slot, (size_t)ser_nnz + 1));
+    k_pbw_serial<<<nser, kT, 0, s>>>(nser, ser_row, ser_eptr, d_off, d_eslot, rib, ser_slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));  // (the host vectors die here)
+    plap("serial rows");
+  }
   std::vector<int32_t> h_wg_e0, h_wg_panel;
   const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
   for (int s_ = 0; s_ < S; ++s_) {
@@ -659,6 +739,7 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   dst->v = PbView{rows, cols, S, B, gshift, panel_shift, (int)h_wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
                   bin_row0, d_bin_e0, nullptr, nullptr, nullptr, nullptr, prod};
   dst->v.wide = 1, dst->v.rib = rib, dst->v.step_lv = step_lv;
+  dst->v.nser = nser, dst->v.ser_ptr = ser_ptr, dst->v.ser_row = ser_row, dst->v.ser_eptr = ser_eptr, dst->v.ser_slot = ser_slot;
   dst->np = total, dst->p_threads = panel_shift == 14 ? 1024 : 512, dst->pad = (double)total / (double)nnz;
   dst->on = true;
   plap("P workgroups");

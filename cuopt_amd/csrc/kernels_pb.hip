@@ -391,13 +391,17 @@ PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32
     for (int64_t i = (int64_t)t * total / (threads * 4), e = (int64_t)(t + 1) * total / (threads * 4); i < e; ++i) H.perm[i] = -1, H.lidx[i] = 0, H.rib[i] = 0xFFFFu;
     if (t == 0) for (int64_t i = 0; i < (total >> H.gshift); ++i) H.piece_dst[i] = 0;
   }, total);
-  std::vector<int> level_overflow(threads * 4, 0);
+  // per bin: the serial rows it found (a row with more than kPbwMaxLevel + 1 entries inside one step) and their entries' slots
+  std::vector<std::vector<int32_t>> bin_ser(B);
+  std::vector<std::vector<std::vector<int32_t>>> bin_ser_slots(B);
   cuopt_amd::parallel_tasks(threads * 4, [&](int t) {
     std::vector<int32_t> cur(S);
-    std::vector<int32_t> stamp(kPbwRows), seen(kPbwRows);
+    std::vector<int32_t> stamp(kPbwRows), seen(kPbwRows), slot_of;
+    std::vector<char> serial(kPbwRows);
     for (int b = t; b < B; b += threads * 4) {
-      const int32_t r0 = row0[b], nr = row0[b + 1] - r0;
+      const int32_t r0 = row0[b], nr = row0[b + 1] - r0, k0 = off[r0];
       std::fill(cur.begin(), cur.end(), 0);
+      slot_of.resize((size_t)(off[r0 + nr] - k0));
       const int32_t* l = lstart.get() + (size_t)b * S;
       for (int32_t r = r0; r < r0 + nr; ++r)
         for (int k = off[r]; k < off[r + 1]; ++k) {
@@ -406,15 +410,18 @@ PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32
           const int32_t pp = pstart[(size_t)s_ * B + b] + rank;
           H.perm[pp]       = k;
           H.lidx[pp]       = (uint16_t)(idx[k] & (SP - 1));
-          H.rib[(size_t)H.bin_e0[b] + l[s_] + rank] = (uint16_t)(r - r0);
+          slot_of[k - k0]  = H.bin_e0[b] + l[s_] + rank;
+          H.rib[(size_t)slot_of[k - k0]] = (uint16_t)(r - r0);
         }
       for (int s_ = 0; s_ < S; ++s_) {
         const int np_ = (cnt[(size_t)b * S + s_] + G - 1) / G;
         const int32_t p0 = pstart[(size_t)s_ * B + b] >> H.gshift, d0 = (H.bin_e0[b] + l[s_]) >> H.gshift;
         for (int i = 0; i < np_; ++i) H.piece_dst[p0 + i] = d0 + i;
       }
-      // levels: how many earlier slots of the same step carry the same row
+      // levels: how many earlier slots of the same step carry the same row (a row beyond the last level: serial)
       std::fill(stamp.begin(), stamp.end(), -1);
+      std::fill(serial.begin(), serial.end(), 0);
+      bool any = false;
       for (int64_t st = H.bin_e0[b] >> 10; st < (H.bin_e0[b + 1] >> 10); ++st) {
         int top = 0;
         for (int i = 0; i < kPbwStep; ++i) {
@@ -423,15 +430,36 @@ PbHost build_pb_wide(int32_t rows, int32_t cols, const int32_t* off, const int32
           const int row = w;
           if (stamp[row] != (int32_t)st) stamp[row] = (int32_t)st, seen[row] = 0;
           const int lv = seen[row]++;
-          if (lv > kPbwMaxLevel) { level_overflow[t] = 1; continue; }
+          if (lv > kPbwMaxLevel) { serial[row] = 1, any = true; continue; }
           top = std::max(top, lv);
           w   = (uint16_t)(row | lv << 13);
         }
         H.step_lv[(size_t)st] = (uint8_t)top;
       }
+      if (any)
+        for (int i = 0; i < nr; ++i)
+          if (serial[i]) {
+            bin_ser[b].push_back(r0 + i);
+            bin_ser_slots[b].emplace_back();
+            for (int k = off[r0 + i]; k < off[r0 + i + 1]; ++k) {
+              H.rib[(size_t)slot_of[k - k0]] = 0xFFFFu;  // its slots read as padding: the steps never touch the row
+              bin_ser_slots[b].back().push_back(slot_of[k - k0]);
+            }
+          }
     }
   }, nnz);
-  if (*std::max_element(level_overflow.begin(), level_overflow.end())) { H.why = "a row with more than 7 entries inside one step of its bin"; return H; }
+  H.ser_ptr.assign((size_t)B + 1, 0);
+  H.ser_eptr.assign(1, 0);
+  for (int b = 0; b < B; ++b) {
+    for (size_t q = 0; q < bin_ser[b].size(); ++q) {
+      H.ser_row.push_back(bin_ser[b][q]);
+      H.ser_slot.insert(H.ser_slot.end(), bin_ser_slots[b][q].begin(), bin_ser_slots[b][q].end());
+      H.ser_eptr.push_back((int32_t)H.ser_slot.size());
+    }
+    H.ser_ptr[b + 1] = (int32_t)H.ser_row.size();
+  }
+  // (one lane per serial row: fine for a few long or clustered rows among short ones, a serial chain for a matrix made of them)
+  if ((int64_t)H.ser_slot.size() * 10 > nnz) { H.why = "more than a tenth of the nonzeros in rows with more than 7 entries inside one step of their bin"; return H; }
   // P workgroups: every panel's entries in Q parts (pieces are not split)
   const int Q = std::max(1, std::min(16, (4 * cus + S - 1) / S));
   for (int s_ = 0; s_ < S; ++s_) {
@@ -483,13 +511,22 @@ int upload_pb(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, const PbHost& h)
   dst->v = PbView{h.rows, h.cols, h.S, h.B, h.gshift, h.panel_shift, (int)h.wg_panel.size(), dst->val, lidx, piece_dst, wg_e0, wg_panel,
                   bin_row0, bin_e0, sr, bin_grp, grp_pos, pos, prod};
   dst->v.wide = h.wide ? 1 : 0, dst->v.rib = rib, dst->v.step_lv = step_lv;
+  if (h.wide && !h.ser_row.empty()) {
+    int32_t *ser_ptr = nullptr, *ser_row = nullptr, *ser_eptr = nullptr, *ser_slot = nullptr;
+    TRY(upload_i32(c, &ser_ptr, h.ser_ptr.data(), h.ser_ptr.size()));
+    TRY(upload_i32(c, &ser_row, h.ser_row.data(), h.ser_row.size()));
+    TRY(upload_i32(c, &ser_eptr, h.ser_eptr.data(), h.ser_eptr.size()));
+    TRY(upload_i32(c, &ser_slot, h.ser_slot.data(), h.ser_slot.size()));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dst->v.nser = (int)h.ser_row.size(), dst->v.ser_ptr = ser_ptr, dst->v.ser_row = ser_row, dst->v.ser_eptr = ser_eptr, dst->v.ser_slot = ser_slot;
+  }
   dst->np = h.np, dst->p_threads = h.p_threads, dst->pad = (double)h.np / (double)h.nnz;
   dst->on = true;
   return 0;
 }
 
 // ---- a CPU walk through the host construction (tests without a GPU): phase P and phase R of the wide bins, slot by slot, exactly as
-// the kernels order them; out = M x, info = {padded entries, bins, panels, highest level}.  Returns 1 when the layout cannot hold the
+// the kernels order them; out = M x, info = {padded entries, bins, panels, highest level, serial rows}.  Returns 1 when the layout cannot hold the
 // matrix (why: stderr), 2 on an inconsistency of the arrays.
 extern "C" int pdlpdev_debug_pb_wide_host(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, const double* val, const double* x, double* out,
                                           int64_t* info)
@@ -527,8 +564,18 @@ extern "C" int pdlpdev_debug_pb_wide_host(int32_t rows, int32_t cols, const int3
           acc[w & (kPbwRows - 1)] = acc[w & (kPbwRows - 1)] + prod[(size_t)st * kPbwStep + i];
         }
     }
+    if (!H.ser_row.empty())
+      for (int q = H.ser_ptr[b]; q < H.ser_ptr[b + 1]; ++q) {
+        double sum = 0.0;
+        for (int e = H.ser_eptr[q]; e < H.ser_eptr[q + 1]; ++e) {
+          if (!written[(size_t)H.ser_slot[e]] || H.rib[(size_t)H.ser_slot[e]] != 0xFFFFu) return 2;
+          sum = sum + prod[(size_t)H.ser_slot[e]];
+        }
+        if (acc[H.ser_row[q] - H.bin_row0[b]] != 0.0) return 2;  // (a step touched a serial row)
+        acc[H.ser_row[q] - H.bin_row0[b]] = sum;
+      }
     for (int i = 0; i < H.bin_row0[b + 1] - H.bin_row0[b]; ++i) out[H.bin_row0[b] + i] = acc[i];
   }
-  if (info) info[0] = H.np, info[1] = H.B, info[2] = H.S, info[3] = top_all;
+  if (info) info[0] = H.np, info[1] = H.B, info[2] = H.S, info[3] = top_all, info[4] = (int64_t)H.ser_row.size();
   return 0;
 }

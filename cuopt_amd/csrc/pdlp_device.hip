@@ -2339,7 +2339,13 @@ int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16])
            (checksum_device(ctx, v.bin_row0, ((size_t)v.B + 1) * 4) * 5) ^ (checksum_device(ctx, v.bin_e0, ((size_t)v.B + 1) * 4) * 7) ^
            (uint64_t)v.S * 17 ^ (uint64_t)v.gshift * 19 ^ (uint64_t)v.panel_shift * 23 ^ (uint64_t)P.p_threads * 29 ^ (uint64_t)v.wide * 31;
     if (v.wide) {  // the slot words and the steps' levels instead of the rows by length and the jagged diagonals
-      o[3] = checksum_device(ctx, v.rib, (size_t)P.np * 2) ^ (checksum_device(ctx, v.step_lv, (size_t)(P.np >> 10)) * 3);
+      o[3] = checksum_device(ctx, v.rib, (size_t)P.np * 2) ^ (checksum_device(ctx, v.step_lv, (size_t)(P.np >> 10)) * 3) ^ (uint64_t)v.nser * 37;
+      if (v.nser) {
+        int32_t ser_nnz = 0;
+        (void)hipMemcpy(&ser_nnz, v.ser_eptr + v.nser, sizeof(int32_t), hipMemcpyDeviceToHost);
+        o[3] ^= (checksum_device(ctx, v.ser_ptr, ((size_t)v.B + 1) * 4) * 5) ^ (checksum_device(ctx, v.ser_row, (size_t)v.nser * 4) * 7) ^
+                (checksum_device(ctx, v.ser_eptr, ((size_t)v.nser + 1) * 4) * 11) ^ (checksum_device(ctx, v.ser_slot, (size_t)ser_nnz * 4) * 13);
+      }
       return;
     }
     int32_t groups = 0;

@@ -337,6 +337,14 @@ struct PbView {
   int wide = 0;
   const uint16_t* __restrict__ rib     = nullptr;  // per image slot: row in the bin | level << 13
   const uint8_t* __restrict__ step_lv  = nullptr;  // per step of kPbwStep slots: its highest level
+  // SERIAL rows of the wide bins: a row with more than kPbwMaxLevel + 1 entries inside one step (a long or clustered row among short
+  // ones) leaves the steps altogether -- its slots read as padding -- and ONE lane adds its products up, left to right, behind the
+  // bin's last step
+  int nser = 0;
+  const int32_t* __restrict__ ser_ptr  = nullptr;  // B + 1 -> ser_row / ser_eptr
+  const int32_t* __restrict__ ser_row  = nullptr;  // nser rows, ascending
+  const int32_t* __restrict__ ser_eptr = nullptr;  // nser + 1 -> ser_slot
+  const int32_t* __restrict__ ser_slot = nullptr;  // the image slots of a serial row's entries, in column order
 };
 
 // phase P of one workgroup.  xs: LDS, 1 << panel_shift doubles.

@@ -56,6 +56,7 @@ struct PbHost {
   bool wide = false;
   cuopt_amd::PoolArray<uint16_t> rib;
   std::vector<uint8_t> step_lv;
+  std::vector<int32_t> ser_ptr, ser_row, ser_eptr, ser_slot;  // serial rows (PbView)
 };
 
 // ---- dense row segments: detection and the sparse remainder (host) -----------------------------------------------------------

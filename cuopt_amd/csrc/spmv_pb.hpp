@@ -153,7 +153,8 @@ __device__ __forceinline__ void pb_rows_block(const PbView& V, Epi& epi, double*
 
 // phase R of one WIDE bin (kPbwThreads threads, kPbwLdsBytes of dynamic LDS at `lds`).  LDS hazards: acc[] is zeroed, barrier; a step's
 // phase reads and writes only accumulators of pairwise different rows (the levels), a barrier ends every phase; the epilogue reads acc[]
-// behind the last phase's barrier; the reduction scratch is a region of its own.  Products and slot words are requested kPbwAhead steps
+// behind the last phase's barrier (serial rows: one lane writes the row's accumulator behind the last step, a barrier follows); the
+// reduction scratch is a region of its own.  Products and slot words are requested kPbwAhead steps
 // ahead into a ring of registers (straight-line code, counted vmcnt waits; the barriers leave vector-memory loads in flight).
 template <class Epi>
 __device__ __forceinline__ void pbw_rows_block(const PbView& V, Epi& epi, double* __restrict__ partials, double* lds)
@@ -216,6 +217,14 @@ __device__ __forceinline__ void pbw_rows_block(const PbView& V, Epi& epi, double
     }
     s0 += PE;
   } while (s0 < ns);
+  if (V.nser) {  // (uniform) serial rows: no step touched their accumulators; the products were written by phase P's kernel
+    for (int q = V.ser_ptr[b] + tid; q < V.ser_ptr[b + 1]; q += T) {
+      double sum = 0.0;
+      for (int e = V.ser_eptr[q]; e < V.ser_eptr[q + 1]; ++e) sum = sum + V.prod[V.ser_slot[e]];
+      acc[V.ser_row[q] - row0] = sum;
+    }
+    __syncthreads();
+  }
   double accq[Epi::NQ > 0 ? Epi::NQ : 1];
 #pragma unroll
   for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q) accq[q] = Epi::Op::identity();

@@ -182,6 +182,21 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
     return _finish(m, n, rows, cols, vals, rng, dict(seed=seed, k=k, kind=kind, hard=False, band=0))
 
 
+def generate_clustered(m, n, k=3, heavy=40, width=60, seed=11):
+    """S(m, n, k) plus `heavy` rows that also run through `width` CONSECUTIVE columns each (a budget / convexity row among short
+    ones): the rows the wide bins of the gather-free layout hand to single lanes (more than 7 entries of a row inside one step)"""
+    rng = np.random.default_rng(seed)
+    base = generate(m, n, k, seed=seed)
+    rows = np.repeat(np.arange(m, dtype=np.int64), k)
+    cols = base["indices"].astype(np.int64)
+    h_rows = np.sort(rng.choice(m, size=heavy, replace=False))
+    starts = rng.integers(0, n - width, size=heavy)
+    rows = np.concatenate([rows, np.repeat(h_rows, width)])
+    cols = np.concatenate([cols, (starts[:, None] + np.arange(width)[None, :]).reshape(-1)])
+    vals = rng.standard_normal(len(rows))
+    return _finish(m, n, rows, cols, vals, rng, dict(seed=seed, k=k, kind="clustered", hard=False, band=0, heavy_rows=h_rows))
+
+
 def shuffled(p, seed=5):
     """The same LP under a seeded random row AND column permutation -- how a structured model arrives when its MPS file lists rows
     and columns in modelling order rather than in the order of its structure.  Row i of the result is row rp[i] of p, column j is

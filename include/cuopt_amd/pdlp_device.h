@@ -214,9 +214,9 @@ int pdlpdev_debug_ipc_store(int device, const uint8_t handle[64], int count, dou
 int pdlpdev_debug_ipc_wait(int device, void* base, int count, double seed);
 int pdlpdev_debug_layout_checksums(pdlpdev_ctx* ctx, uint64_t out[16]);
 /* The wide-bin geometry of the gather-free layout walked on the CPU (no GPU needed): out = M x summed exactly as phase P and phase R order
-   the work; info = {padded entries, bins, panels, highest level}.  1: the geometry cannot hold the matrix, 2: inconsistent arrays. */
+   the work; info = {padded entries, bins, panels, highest level, serial rows}.  1: the geometry cannot hold the matrix, 2: inconsistent arrays. */
 int pdlpdev_debug_pb_wide_host(int32_t rows, int32_t cols, const int32_t* off, const int32_t* idx, const double* val, const double* x, double* out,
-                               int64_t info[4]);
+                               int64_t info[5]);
 /* A synthetic LP of the S(m, n, k) family GENERATED ON THE DEVICE and handed back in host arrays (scale checks near the reference's
  * stated capacity, docs/cuopt/source/faq.rst:368-370: 1e9 nonzeros take the host generator minutes and tens of GB): k entries per row,
  * one per stratum of n / k columns, values ~ N(0, 1); equalities on the first half of the rows, '>=' rows with slack on the second;

@@ -334,7 +334,7 @@ def test_problem_checking_through_the_c_api():
 def test_wide_bins_of_the_gather_free_layout_on_the_host(shape, transposed):
     """build_pb_wide (kernels_pb.hip) walked on the CPU exactly as phase P and phase R order the work -- pieces to image slots, steps of
     1024 slots, one addition per row and level: the row sums are the sequential CSR sums bit for bit (the oracle's), every slot is
-    written once, no level exceeds its step's; a matrix whose rows crowd into few panels is refused"""
+    written once, no level exceeds its step's; rows that crowd into one step become serial rows; chunks beyond 16 bits are refused"""
     from cuopt_amd import synthetic
     from oracle import orcbind
     fn = capi.lib.pdlpdev_debug_pb_wide_host
@@ -346,12 +346,42 @@ def test_wide_bins_of_the_gather_free_layout_on_the_host(shape, transposed):
         m, n = n, m
     off, idx, val = (np.ascontiguousarray(a, t) for a, t in ((off, np.int32), (idx, np.int32), (val, np.float64)))
     x = np.random.default_rng(1).standard_normal(n)
-    out, info = np.zeros(m), np.zeros(4, np.int64)
+    out, info = np.zeros(m), np.zeros(5, np.int64)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)
     assert fn(C.c_int32(m), C.c_int32(n), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
     np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
     assert info[1] == -(-m // 8192) and info[0] % 1024 == 0 and info[0] <= (1.06 if shape[1] < 4400000 else 1.25) * len(val) + 1024 * info[1] and info[3] <= 6
-    # ten entries per row over seven panels: more than seven of a row inside one step
+    assert info[4] == 0
+    # ten entries per row over seven panels: a few rows have more than seven entries inside one step -- serial rows, still exact
     q = synthetic.generate(60000, 50000, 10, seed=23)
     off, idx, val = (np.ascontiguousarray(q[k], t) for k, t in (("offsets", np.int32), ("indices", np.int32), ("values", np.float64)))
+    x, out = np.random.default_rng(3).standard_normal(q["n"]), np.zeros(q["m"])
+    assert fn(C.c_int32(q["m"]), C.c_int32(q["n"]), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
+    np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
+    assert 0 < info[4] < 600
+    # forty entries per row over three panels: chunks of more than 65535 entries -- refused
+    q = synthetic.generate(20000, 20000, 40, seed=23)
+    off, idx, val = (np.ascontiguousarray(q[k], t) for k, t in (("offsets", np.int32), ("indices", np.int32), ("values", np.float64)))
     assert fn(C.c_int32(q["m"]), C.c_int32(q["n"]), ptr(off), ptr(idx), ptr(val), ptr(np.zeros(q["n"])), ptr(np.zeros(q["m"])), None) == 1
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_wide_bins_hand_long_clustered_rows_to_single_lanes_on_the_host(transposed):
+    """40 rows that run through 60 consecutive columns each, among rows of three entries: in the A side's image such a row has dozens
+    of entries inside one step -- it leaves the steps (its slots read as padding) and is summed by one lane from its list of slots,
+    left to right: still the sequential CSR sum, bit for bit.  (On the A^T side the same entries are one per row.)"""
+    from cuopt_amd import synthetic
+    from oracle import orcbind
+    fn = capi.lib.pdlpdev_debug_pb_wide_host
+    fn.restype = C.c_int
+    p = synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11)
+    m, n, off, idx, val = p["m"], p["n"], p["offsets"], p["indices"], p["values"]
+    if transposed:
+        off, idx, val = capi.csr_transpose(m, n, off, idx, val)
+        m, n = n, m
+    off, idx, val = (np.ascontiguousarray(a, t) for a, t in ((off, np.int32), (idx, np.int32), (val, np.float64)))
+    x = np.random.default_rng(2).standard_normal(n)
+    out, info = np.zeros(m), np.zeros(5, np.int64)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert fn(C.c_int32(m), C.c_int32(n), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
+    np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
+    assert (info[4] == 40) if not transposed else (info[4] < 10), info  # (A^T: a column of twenty entries now and then crowds a step too)

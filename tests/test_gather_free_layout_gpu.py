@@ -117,17 +117,42 @@ def test_wide_bins_built_on_the_device_are_the_host_construction(monkeypatch):
 
 
 def test_a_matrix_the_wide_bins_cannot_hold_takes_the_other_geometry(monkeypatch):
-    """ten entries per row over seven panels put more than seven entries of a row into one step: both constructions fall back to the
+    """forty entries per row over three panels make chunks of more than 65535 entries: both constructions fall back to the
     image-in-LDS bins, and agree"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
-    p = synthetic.generate(60000, 50000, 10, seed=23)
+    p = synthetic.generate(20000, 20000, 40, seed=23)
     sums = []
     for pb_device in (0, None):
         set_tune(monkeypatch, pb_wide=1, pb_device=pb_device)
         dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
         lay = dev.layout()
-        assert lay["A"]["layout"] == "pb" and lay["A"]["workgroups"] > -(-60000 // 8192)
+        assert lay["A"]["layout"] == "pb" and lay["A"]["workgroups"] > -(-20000 // 8192)
         _both_products_bit_exact(p, dev)
         sums.append(dev.layout_checksums())
         dev.close()
     np.testing.assert_array_equal(sums[0], sums[1])
+
+
+def test_wide_bins_with_serial_rows(monkeypatch):
+    """short rows + 40 rows through 60 consecutive columns: the long rows leave the steps of their bins and are summed by single lanes
+    (PbView ser_*): products bit-exact on both sides, the device construction == the host's, the solve reaches the optimum"""
+    monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
+    for p in (synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11), synthetic.generate(60000, 50000, 10, seed=23)):
+        _serial_rows_case(p, monkeypatch)
+
+
+def _serial_rows_case(p, monkeypatch):
+    sums = []
+    for pb_device in (0, None):
+        set_tune(monkeypatch, pb_wide=1, pb_device=pb_device)
+        dev = capi.Device(p, analysis=capi.Analysis(p, reorder=False))
+        lay = dev.layout()
+        assert lay["A"]["layout"] == lay["At"]["layout"] == "pb" and lay["A"]["workgroups"] == -(-p["m"] // 8192), lay
+        _both_products_bit_exact(p, dev)
+        _both_products_bit_exact(p, dev, seed=3)
+        sums.append(dev.layout_checksums())
+        dev.close()
+    np.testing.assert_array_equal(sums[0], sums[1])
+    r = capi.solve(p, method=1, tol=1e-6)
+    assert r["status"] == "Optimal"
+    assert abs(r["objective"] - p["objective_star"]) <= 2e-5 * (1 + abs(p["objective_star"]))
