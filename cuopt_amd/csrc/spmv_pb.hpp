@@ -219,8 +219,15 @@ __device__ __forceinline__ void pbw_rows_block(const PbView& V, Epi& epi, double
   } while (s0 < ns);
   if (V.nser) {  // (uniform) serial rows: no step touched their accumulators; the products were written by phase P's kernel
     for (int q = V.ser_ptr[b] + tid; q < V.ser_ptr[b + 1]; q += T) {
-      double sum = 0.0;
-      for (int e = V.ser_eptr[q]; e < V.ser_eptr[q + 1]; ++e) sum = sum + V.prod[V.ser_slot[e]];
+      double sum   = 0.0;
+      const int e1 = V.ser_eptr[q + 1];
+      for (int e = V.ser_eptr[q]; e < e1; e += 8) {  // (eight scattered products in flight, added in order)
+        double pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pr[u] = e + u < e1 ? V.prod[V.ser_slot[e + u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = e + u < e1 ? sum + pr[u] : sum;
+      }
       acc[V.ser_row[q] - row0] = sum;
     }
     __syncthreads();
