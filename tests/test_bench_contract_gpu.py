@@ -28,7 +28,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=1e-3) and 0.0 < rf["frac"] < 1.0
-    assert rf["avg_launch_ms"] < d["ms_per_step"]
+    if "PYTEST_XDIST_WORKER" not in os.environ:  # (two timings of the same run: not under the contention soak, where the load changes between them)
+        assert rf["avg_launch_ms"] < d["ms_per_step"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == d["unit"]
     if "PYTEST_XDIST_WORKER" not in os.environ:  # (a rate comparison: not under the contention soak, where four processes share the GPU)
