@@ -679,6 +679,10 @@ __global__ void __launch_bounds__(kT) k_new_labels(int64_t nnz, const uint32_t* 
   }
 }
 
+__global__ void __launch_bounds__(kT) k_gather_f64(int64_t n, const double* __restrict__ src, const uint32_t* __restrict__ at, double* __restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) out[i] = src[at[i]];
+}
 __global__ void __launch_bounds__(kT) k_gather_u32(int64_t n, const uint32_t* __restrict__ src, const uint32_t* __restrict__ at, uint32_t* __restrict__ out)
 {
   for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) out[i] = src[at[i]];
@@ -1302,6 +1306,22 @@ int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, 
         TRY(build_permuted_pair(an, ro2n, co2n));
         an->permuted = true;
         an->ms_permute = lap("permuted pair");
+        // the vectors that travelled ahead follow the matrix into the new order, on the device (the maps are still in the arena):
+        // the host never gathers them, the context never uploads them
+        if (prefetch.worker.joinable()) prefetch.worker.join();
+        bool all = true;
+        for (int i = 0; i < 5; ++i) {
+          if (!an->pref_dev[i]) { all = all && !an->pref_src[i]; continue; }
+          const size_t count = i < 3 ? (size_t)n : (size_t)m;
+          double* d = nullptr;
+          HIP_TRY(hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(double)));  // (freed with pref_dev; the unpermuted copy it replaces: with `owned`)
+          k_gather_f64<<<grid_of((int64_t)count), kT, 0, s>>>((int64_t)count, an->pref_dev[i], i < 3 ? cn2o : rn2o, d);
+          an->owned.push_back(an->pref_dev[i]);
+          an->pref_dev[i] = d;
+        }
+        HIP_TRY(hipGetLastError());
+        an->pref_permuted = all;
+        if (all) lap("vectors");
       }
     }
     an->arena.release(mark);
@@ -1326,6 +1346,10 @@ int pdlpdev_analysis_info(pdlpdev_analysis* an, int32_t out[10])
   out[8] = an->bfs_levels, out[9] = an->cell_rounds;
   return 0;
 }
+
+// 1: the analysis reordered the matrix AND holds the problem vectors it was given in that order on the device (a context created from it
+// takes them from there whichever host arrays -- the caller's own -- it is handed); 0: the caller permutes and passes them
+int pdlpdev_analysis_vectors_in_order(pdlpdev_analysis* an) { return an && an->permuted && an->pref_permuted ? 1 : 0; }
 
 // the maps of an accepted ordering: row_new2old[m], col_new2old[n] (either may be null); returns 1 when permuted, 0 when not
 int pdlpdev_analysis_maps(pdlpdev_analysis* an, int32_t* row_new2old, int32_t* col_new2old)

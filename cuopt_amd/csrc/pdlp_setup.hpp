@@ -63,12 +63,14 @@ struct pdlpdev_analysis {
   std::string laps;          // "phase ms; phase ms; ..." of the last analyze call (CUOPT_AMD_TIMING prints it)
   double ms_transpose = 0, ms_order = 0, ms_permute = 0, ms_upload = 0;
   // the problem vectors (c, lo, hi, lb, ub as the caller holds them), uploaded by a helper thread while the analysis' kernels run:
-  // PCIe is idle once A is over.  A context created from an UNPERMUTED analysis copies them device to device (pdlp_create.hip).
+  // PCIe is idle once A is over.  A context created from the analysis copies them device to device (pdlp_create.hip).
   const double* pref_src[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double* pref_dev[5]       = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // (a permuted analysis gathers them into the new order on the device -- pref_permuted -- so that the host never does)
+  bool pref_permuted = false;
   const double* prefetched(const double* host) const
   {
-    if (permuted || !host) return nullptr;
+    if ((permuted && !pref_permuted) || !host) return nullptr;
     for (int i = 0; i < 5; ++i)
       if (pref_src[i] == host && pref_dev[i]) return pref_dev[i];
     return nullptr;

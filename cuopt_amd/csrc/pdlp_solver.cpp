@@ -977,6 +977,9 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
       s->reorder_method = permuted == 1 ? s->analysis_info[1] : 0;
       if (permuted != 1) {
         s->row_new2old.clear(), s->col_new2old.clear();
+      } else if (!sharded && pdlpdev_analysis_vectors_in_order(ag.an) == 1) {
+        // (the vectors that travelled ahead were gathered into the new order on the device: the context takes them from there -- it is
+        //  handed the SAME host pointers the analysis was -- and the host touches none of them)
       } else {
         auto gather = [](const std::vector<int32_t>& new2old, const double* src, cuopt_amd::PoolArray<double>& dst) {
           dst.reset(new2old.size());
