@@ -669,6 +669,7 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
   TRY(talloc((void**)&d_eslot, ((size_t)nnz + 64) * sizeof(int32_t)));
   TRY(talloc((void**)&d_serial, (size_t)B * kPbwRows));
   HIP_TRY(hipMemsetAsync(d_serial, 0, (size_t)B * kPbwRows, s));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_pbw_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kPbwSeg + 1) * kPbwMaxPanels * sizeof(uint32_t))));
   k_pbw_place<<<B, 1024, (size_t)(kPbwSeg + 1) * S * sizeof(uint32_t), s>>>(rows, d_off, d_idx, d_rowin, panel_shift, gshift, S, B, d_pstart, d_bin_e0, dst->perm, lidx, piece_dst, rib, d_eslot);
   HIP_TRY(hipGetLastError());
   plap("place");
