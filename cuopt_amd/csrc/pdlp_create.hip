@@ -93,15 +93,18 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
   HIP_TRY(hipSetDevice(device));
   const bool timing = getenv("CUOPT_AMD_TIMING") != nullptr;
   auto tlast = std::chrono::steady_clock::now();
+  pdlpdev_ctx* ctx = nullptr;
   auto lap = [&](const char* what) {
     if (!timing) return;
-    (void)hipDeviceSynchronize();
+    // (the context's own stream: a device-wide synchronisation would break a graph capture another thread's solver is in the middle of)
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    else (void)hipDeviceSynchronize();
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[cuopt_amd setup]   dev: %-22s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - tlast).count());
     tlast = now;
   };
-  pdlpdev_ctx* ctx = new pdlpdev_ctx();
-  ctx->device      = device;
+  ctx         = new pdlpdev_ctx();
+  ctx->device = device;
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cus = cus;

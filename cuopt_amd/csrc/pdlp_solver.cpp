@@ -79,6 +79,9 @@ struct Convergence {
 
 struct cuoptamd_solver {
   pdlpdev_ctx* dev = nullptr;
+  // the set-up's analysis object when its release was put off to the solver's end (its hipFree calls synchronise the device: 3 ms of a
+  // 25 ms set-up at 1e7 nonzeros; beyond a few GB of workspace it is released at once)
+  pdlpdev_analysis* spent_analysis = nullptr;
   cuoptamd_hyper H{};
   cuoptamd_settings S{};
   int32_t m_global = 0, n = 0, row_begin = 0, row_end = 0;
@@ -1017,7 +1020,8 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     // single GPU: the analysis' device arrays become the context's
     pdlpdev_create_hint(0);
     int rc = pdlpdev_create_from_analysis(&s->dev, ag.an, L->c, L->lo, L->hi, L->lb, L->ub);
-    ag.drop();
+    if (rc == 0 && nnz_g <= cuopt_amd::tune_int("keep_analysis_max_nnz", 50000000)) s->spent_analysis = ag.an, ag.an = nullptr;
+    else ag.drop();
     if (rc != 0) return fail(rc, "pdlpdev_create_from_analysis: %s", pdlpdev_last_error());
   } else {
   const int32_t k0 = L->offsets[s->row_begin];
@@ -1130,6 +1134,7 @@ void cuoptamd_solver_destroy(cuoptamd_solver* s)
 {
   if (!s) return;
   if (s->dev) pdlpdev_destroy(s->dev);
+  if (s->spent_analysis) pdlpdev_analysis_destroy(s->spent_analysis);
   delete s;
 }
 
@@ -1335,6 +1340,7 @@ int cuoptamd_solver_clone(cuoptamd_solver* parent, const double* lb, const doubl
   }
   const double t_dev = seconds_since(t0);
   cuoptamd_solver* s = new cuoptamd_solver(*parent);
+  s->spent_analysis = nullptr;  // (the parent's to release)
   s->dev             = dev;
   rc = cuoptamd_solver_reset(s, lb, ub, lo, hi, settings, nullptr, nullptr);
   if (timing) fprintf(stderr, "[cuopt_amd setup] clone: device context %.2f ms, reset to its bounds %.2f ms\n", 1e3 * t_dev, 1e3 * (seconds_since(t0) - t_dev));
