@@ -303,7 +303,7 @@ JagHost build_jag(int32_t rows, int32_t cols, const int32_t* off, const int32_t*
     if (H.saving < 0.35) return H;
   }
   // the partition: chunks of rows are cut independently (a chunk boundary is a block boundary), in parallel
-  const int32_t chunk_rows = 8 * brows;
+  const int32_t chunk_rows = 4 * brows;
   const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
   auto partition = [&](int32_t row_cap) {
     std::vector<std::vector<int32_t>> cuts(nchunks);

@@ -938,7 +938,7 @@ int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t 
 // jagged rows + LDS column sets from a device-resident CSR (returns 1: not built here -- nothing was allocated, the host constructs it;
 // 0: built, or "not worth it" with dst->on false and dst->saving set).  Every array is bit-identical to build_jag's (kernels_jag.hip),
 // which stays the tests' reference construction:
-//   * the partition: chunks of 8 * brows rows are cut independently, a workgroup per chunk grows block after block exactly like the
+//   * the partition: chunks of 4 * brows rows are cut independently, a workgroup per chunk grows block after block exactly like the
 //     sampled estimate does (k_jag_estimate: rows in order while their DISTINCT columns fit the LDS window, an open-addressing table in
 //     LDS, the host's two-step check near the limit) and prices every block's column set;
 //   * per block: its short rows sorted by length (descending, ties by row: a bitonic sort of unique words), passes of 64 dealt to the
@@ -1293,7 +1293,7 @@ int build_jag_device(pdlpdev_ctx* c, pdlpdev_ctx::Jag* dst, int32_t rows, int32_
     }
   }
   const int slots = cus * 2;  // workgroups resident at once: 80 KiB of LDS each
-  const int32_t chunk_rows = 8 * brows;
+  const int32_t chunk_rows = 4 * brows;
   const int nchunks        = (int)(((int64_t)rows + chunk_rows - 1) / chunk_rows);
   JagBlockMeta* d_meta = nullptr;
   int32_t* d_count     = nullptr;

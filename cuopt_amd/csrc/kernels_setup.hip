@@ -1159,13 +1159,65 @@ static int build_permuted_pair(pdlpdev_analysis* an, const int32_t* d_row_o2n, c
   return 0;
 }
 
+// The analysis' workspace (a few hundred MB at 1e7 nonzeros) outlives the analysis in a one-slot cache per process: releasing it is a
+// hipFree -- a device synchronisation, ~3 ms of a 25 ms set-up -- and the next analysis of a similar LP would ask for the same block
+// again.  Blocks beyond 2 GB are returned at once.
+namespace {
+struct SpareArena {
+  int device = -1;
+  char* base = nullptr;
+  size_t cap = 0;
+};
+std::mutex g_spare_mutex;
+SpareArena g_spare;
+constexpr size_t kSpareArenaMax = (size_t)2 << 30;
+char* take_spare_arena(int device, size_t bytes, size_t* cap)
+{
+  std::lock_guard<std::mutex> lock(g_spare_mutex);
+  if (g_spare.base && g_spare.device == device && g_spare.cap >= bytes && g_spare.cap <= 4 * bytes + ((size_t)64 << 20)) {
+    char* p = g_spare.base;
+    *cap    = g_spare.cap;
+    g_spare = SpareArena{};
+    return p;
+  }
+  return nullptr;
+}
+// true: kept (the caller must not free it)
+bool give_spare_arena(int device, char* base, size_t cap)
+{
+  if (!base || cap > kSpareArenaMax) return false;
+  char* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_spare_mutex);
+    if (g_spare.base && g_spare.cap >= cap) return false;  // (the larger one stays)
+    old     = g_spare.base;
+    g_spare = SpareArena{device, base, cap};
+  }
+  if (old) (void)hipFree(old);
+  return true;
+}
+}  // namespace
+
 extern "C" {
+
+// The workspace leaves a consumed analysis at once (to the one-slot cache, or back to the runtime when it is too large to keep): what
+// is left of the object -- small buffers -- may then wait for a convenient moment (the host driver: the solver's end).
+void pdlpdev_analysis_release_workspace(pdlpdev_analysis* an)
+{
+  if (!an || !an->arena.base) return;
+  (void)hipSetDevice(an->device);
+  if (an->stream) (void)hipStreamSynchronize(an->stream);
+  an->owned.erase(std::remove(an->owned.begin(), an->owned.end(), (void*)an->arena.base), an->owned.end());
+  if (!give_spare_arena(an->device, an->arena.base, an->arena.cap)) (void)hipFree(an->arena.base);
+  an->arena = DevArena{};
+}
 
 void pdlpdev_analysis_destroy(pdlpdev_analysis* an)
 {
   if (!an) return;
   (void)hipSetDevice(an->device);
   if (an->stream) (void)hipStreamSynchronize(an->stream);
+  pdlpdev_analysis_release_workspace(an);
   for (void* p : an->owned) (void)hipFree(p);
   for (double* p : an->pref_dev)
     if (p) (void)hipFree(p);
@@ -1251,8 +1303,14 @@ int pdlpdev_analyze_with_vectors(pdlpdev_analysis** out, int device, int32_t m, 
     const size_t words = (size_t)std::max<int64_t>(nnz, 1);
     const size_t verts = (size_t)std::max(m, n) + 64;
     size_t bytes = 4 * (words * (reorder ? 9 : 4) + (words / kRsTile + 2) * 256 + 4096) + (reorder ? 4 * verts * 20 + 48ull * 4096 * kLongRow * 4 + 4096ull * 4096 * 4 : 0) + (1 << 20);
-    an->arena.cap = bytes;
-    TRY(dmalloc((void**)&an->arena.base, bytes));
+    size_t spare_cap = 0;
+    if (char* spare = take_spare_arena(device, bytes, &spare_cap)) {  // (the last analysis' workspace: see SpareArena)
+      an->arena.base = spare, an->arena.cap = spare_cap;
+      an->owned.push_back(spare);
+    } else {
+      an->arena.cap = bytes;
+      TRY(dmalloc((void**)&an->arena.base, bytes));
+    }
   }
   an->ms_upload = lap("upload A");
   // (PCIe is idle from here on: the vectors cross it now, next to the transposition and the ordering search)

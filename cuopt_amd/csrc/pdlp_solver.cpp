@@ -79,8 +79,7 @@ struct Convergence {
 
 struct cuoptamd_solver {
   pdlpdev_ctx* dev = nullptr;
-  // the set-up's analysis object when its release was put off to the solver's end (its hipFree calls synchronise the device: 3 ms of a
-  // 25 ms set-up at 1e7 nonzeros; beyond a few GB of workspace it is released at once)
+  // the set-up's analysis object, minus its workspace, when its release was put off to the solver's end (cuoptamd_solver_create)
   pdlpdev_analysis* spent_analysis = nullptr;
   cuoptamd_hyper H{};
   cuoptamd_settings S{};
@@ -1020,8 +1019,15 @@ int cuoptamd_solver_create(cuoptamd_solver** out, const cuoptamd_lp* lp, const c
     // single GPU: the analysis' device arrays become the context's
     pdlpdev_create_hint(0);
     int rc = pdlpdev_create_from_analysis(&s->dev, ag.an, L->c, L->lo, L->hi, L->lb, L->ub);
-    if (rc == 0 && nnz_g <= cuopt_amd::tune_int("keep_analysis_max_nnz", 50000000)) s->spent_analysis = ag.an, ag.an = nullptr;
-    else ag.drop();
+    // the spent analysis: its workspace goes back at once (a one-slot cache: the next analysis, of this or of another solver, takes it
+    // from there), the hipFree calls of the rest -- each a device synchronisation, ~3 ms of a 25 ms set-up -- wait for the solver's end
+    // (CUOPT_AMD_TUNE=keep_analysis_max_nnz: the size up to which they do)
+    if (rc == 0 && nnz_g <= cuopt_amd::tune_int("keep_analysis_max_nnz", 50000000)) {
+      pdlpdev_analysis_release_workspace(ag.an);
+      s->spent_analysis = ag.an, ag.an = nullptr;
+    } else {
+      ag.drop();
+    }
     if (rc != 0) return fail(rc, "pdlpdev_create_from_analysis: %s", pdlpdev_last_error());
   } else {
   const int32_t k0 = L->offsets[s->row_begin];

@@ -196,6 +196,9 @@ int pdlpdev_analysis_maps(pdlpdev_analysis* an, int32_t* row_new2old, int32_t* c
 /* 1: a reordering analysis that also holds the vectors of pdlpdev_analyze_with_vectors in the NEW order on the device: pass the same host
    pointers to pdlpdev_create_from_analysis, nothing is gathered on the host or uploaded again */
 int pdlpdev_analysis_vectors_in_order(pdlpdev_analysis* an);
+/* A consumed analysis hands its workspace back at once (a one-slot cache for the next analysis, or the runtime); pdlpdev_analysis_destroy
+   of the rest may then wait. */
+void pdlpdev_analysis_release_workspace(pdlpdev_analysis* an);
 /* the matrices the device holds as host CSR: which = 0 A (m x n), 1 A^T; any pointer may be NULL */
 int pdlpdev_analysis_download(pdlpdev_analysis* an, int which, int32_t* offsets, int32_t* indices, double* values);
 /* c / lo / hi / lb / ub in the order of the matrices the device holds */
