@@ -1147,11 +1147,13 @@ static int build_permuted_pair(pdlpdev_analysis* an, const int32_t* d_row_o2n, c
   k_emit_csr<<<grid_of(nnz), kT, 0, s>>>(nnz, SB.v[slot], newrow, an->A.val, NT.idx, NT.val);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
-  // swap in
-  for (void* p : {(void*)an->A.off, (void*)an->A.idx, (void*)an->A.val, (void*)an->At.off, (void*)an->At.idx, (void*)an->At.val}) {
-    an->owned.erase(std::remove(an->owned.begin(), an->owned.end(), p), an->owned.end());
-    (void)hipFree(p);
-  }
+  // swap in.  (The matrices in the caller's order stay in `owned`: six hipFree calls here are six device synchronisations in the
+  // middle of the set-up; they go with the object -- up to 5e7 nonzeros at the solver's end, pdlp_solver.cpp -- unless they are large)
+  if (nnz > 50000000)
+    for (void* p : {(void*)an->A.off, (void*)an->A.idx, (void*)an->A.val, (void*)an->At.off, (void*)an->At.idx, (void*)an->At.val}) {
+      an->owned.erase(std::remove(an->owned.begin(), an->owned.end(), p), an->owned.end());
+      (void)hipFree(p);
+    }
   an->A = NA, an->At = NT;
   for (void* p : {(void*)NA.off, (void*)NA.idx, (void*)NA.val, (void*)NT.off, (void*)NT.idx, (void*)NT.val}) an->owned.push_back(p);
   an->have_hp = an->have_hp_off = an->have_hpt_off = an->have_hpt_idx = false;
