@@ -53,11 +53,67 @@ __global__ void __launch_bounds__(256) k_gather32x2(const int* __restrict__ idx,
   if (acc == 123.456) out[0] = acc;
 }
 
+// (3) What the L2 -> L1 fabric delivers (round 6): every workgroup re-reads a window that stays in its XCD's L2 -- WIDE: 16 bytes per lane,
+//     whole lines, the most the path can carry; LINE: 8 bytes out of every 128-byte line (what a gather that misses the L1 uses of the line
+//     it pulls).  `l2`: prints both rates; the unstructured SpMV's gathers are priced against them (profiles/r06_cell_probe.txt).
+__global__ void __launch_bounds__(256) k_l2_wide(const double2* __restrict__ v, int nchunks /* of 16 KB */, int reps, double* __restrict__ out)
+{
+  // (blockIdx & 7 = XCD: one window per XCD; workgroup j of the XCD reads chunk (j + 257 r) mod nchunks at repetition r: the CU's eight
+  //  workgroups never touch a chunk another of them read less than ~1 MB of traffic ago -- nothing comes out of the 32 KB L1)
+  const double2* w = v + (size_t)(blockIdx.x & 7) * nchunks * 1024;
+  const int j = blockIdx.x >> 3;
+  double acc = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    const double2* c = w + (size_t)((j + 257 * r) % nchunks) * 1024 + threadIdx.x;
+    const double2 q0 = c[0], q1 = c[256], q2 = c[512], q3 = c[768];
+    acc += (q0.x + q1.y) + (q2.x + q3.y);
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_l2_line(const double* __restrict__ v, int nchunks /* of 256 lines = 32 KB */, int reps, double* __restrict__ out)
+{
+  const double* w = v + (size_t)(blockIdx.x & 7) * nchunks * 4096;
+  const int j = blockIdx.x >> 3;
+  double acc = 0.0;
+  for (int r = 0; r < reps; r += 4) {  // (four independent lines per lane in flight)
+    double q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = w[(size_t)((j + 129 * (r + u)) % nchunks) * 4096 + threadIdx.x * 16 + (threadIdx.x & 15)];
+    acc += (q[0] + q[1]) + (q[2] + q[3]);
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
 static float time_ms(hipStream_t s, hipEvent_t e0, hipEvent_t e1) { float ms = 0; (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); (void)s; return ms; }
 
 int main(int argc, char** argv)
 {
   const bool calibrate = argc > 1 && !std::strcmp(argv[1], "calibrate");
+  if (argc > 1 && !std::strcmp(argv[1], "l2")) {
+    hipStream_t s; OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
+    double* out; OK(hipMalloc((void**)&out, 64));
+    std::printf("L2 -> L1: 2048 workgroups of 256 threads re-read a window that sits in their XCD's L2 (one window per XCD)\n");
+    std::printf("%-18s %16s %16s %22s\n", "window per XCD", "wide 16 B/lane", "8 B per line", "lines/s (8 B per line)");
+    for (int window_kb : {512, 1024, 2048, 3072}) {
+      const size_t bytes = (size_t)window_kb * 1024;
+      double* buf; OK(hipMalloc((void**)&buf, bytes * 8)); OK(hipMemset(buf, 0, bytes * 8));
+      const int cw = (int)(bytes / 16384), cl = (int)(bytes / 32768), reps = 256;
+      float tw = 0, tl = 0;
+      for (int rep = -2; rep < 5; ++rep) {
+        OK(hipEventRecord(e0, s)); k_l2_wide<<<2048, 256, 0, s>>>((const double2*)buf, cw, reps, out); OK(hipEventRecord(e1, s));
+        const float a = time_ms(s, e0, e1);
+        OK(hipEventRecord(e0, s)); k_l2_line<<<2048, 256, 0, s>>>(buf, cl, reps, out); OK(hipEventRecord(e1, s));
+        const float b = time_ms(s, e0, e1);
+        if (rep >= 0) tw += a, tl += b;
+      }
+      const double bw = 2048.0 * reps * 16384.0, lines = 2048.0 * reps * 256.0;
+      std::printf("%6d KiB         %10.1f TB/s %10.1f TB/s (as 128-B lines) %12.1f G lines/s\n", window_kb, bw / (tw / 5 * 1e-3) / 1e12, lines * 128 / (tl / 5 * 1e-3) / 1e12,
+                  lines / (tl / 5 * 1e-3) / 1e9);
+      (void)hipFree(buf);
+    }
+    return 0;
+  }
   hipStream_t s; OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   double* out; OK(hipMalloc((void**)&out, 64));
