@@ -84,6 +84,28 @@ __global__ void __launch_bounds__(256) k_l2_line(const double* __restrict__ v, i
   if (acc == 123.456) out[0] = acc;
 }
 
+// (3b) the same, with RANDOM lines of the window: mode 0 any line; mode 1 line = 16 q + (lane mod 16) with q random (every 16 lanes of a
+//      request cover the 16 residues of the line number: balanced if a channel is a residue); mode 2 the same with 32; mode 3 with 64
+__global__ void __launch_bounds__(256) k_l2_random(const double* __restrict__ v, int window_lines, int reps, int mode, double* __restrict__ out)
+{
+  const double* w = v + (size_t)(blockIdx.x & 7) * window_lines * 16;
+  unsigned long long state = 88172645463325252ull ^ ((unsigned long long)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull);
+  const int g = mode == 1 ? 16 : mode == 2 ? 32 : 64;
+  double acc = 0.0;
+  for (int r = 0; r < reps; r += 4) {
+    double q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      state ^= state << 13, state ^= state >> 7, state ^= state << 17;
+      const unsigned rnd = (unsigned)(state >> 20);
+      const int line     = mode == 0 ? (int)(rnd % (unsigned)window_lines) : (int)(rnd % (unsigned)(window_lines / g)) * g + (int)(threadIdx.x % g);
+      q[u] = w[(size_t)line * 16 + (threadIdx.x & 15)];
+    }
+    acc += (q[0] + q[1]) + (q[2] + q[3]);
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
 static float time_ms(hipStream_t s, hipEvent_t e0, hipEvent_t e1) { float ms = 0; (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); (void)s; return ms; }
 
 int main(int argc, char** argv)
@@ -108,8 +130,19 @@ int main(int argc, char** argv)
         if (rep >= 0) tw += a, tl += b;
       }
       const double bw = 2048.0 * reps * 16384.0, lines = 2048.0 * reps * 256.0;
-      std::printf("%6d KiB         %10.1f TB/s %10.1f TB/s (as 128-B lines) %12.1f G lines/s\n", window_kb, bw / (tw / 5 * 1e-3) / 1e12, lines * 128 / (tl / 5 * 1e-3) / 1e12,
+      std::printf("%6d KiB         %10.1f TB/s %10.1f TB/s (as 128-B lines) %12.1f G lines/s", window_kb, bw / (tw / 5 * 1e-3) / 1e12, lines * 128 / (tl / 5 * 1e-3) / 1e12,
                   lines / (tl / 5 * 1e-3) / 1e9);
+      std::printf("   random lines:");
+      for (int mode = 0; mode < 4; ++mode) {
+        float tr = 0;
+        for (int rep = -2; rep < 5; ++rep) {
+          OK(hipEventRecord(e0, s)); k_l2_random<<<2048, 256, 0, s>>>(buf, (int)(bytes / 128), reps, mode, out); OK(hipEventRecord(e1, s));
+          const float a = time_ms(s, e0, e1);
+          if (rep >= 0) tr += a;
+        }
+        std::printf(" %s %.1f", mode == 0 ? "any" : mode == 1 ? "| 16-residue" : mode == 2 ? "| 32-residue" : "| 64-residue", lines / (tr / 5 * 1e-3) / 1e9);
+      }
+      std::printf(" G lines/s\n");
       (void)hipFree(buf);
     }
     return 0;
