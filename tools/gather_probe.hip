@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256) k_l2_line(const double* __restrict__ v, i
 //      request cover the 16 residues of the line number: balanced if a channel is a residue); mode 2 the same with 32; mode 3 with 64
 __global__ void __launch_bounds__(256) k_l2_random(const double* __restrict__ v, int window_lines, int reps, int mode, double* __restrict__ out)
 {
-  const double* w = v + (size_t)(blockIdx.x & 7) * window_lines * 16;
+  // (mode >= 8: ONE window for the whole chip -- the gathered vector of an SpMV that is not walked in slabs)
+  const double* w = v + (mode >= 8 ? (size_t)0 : (size_t)(blockIdx.x & 7) * window_lines * 16);
+  mode &= 7;
   unsigned long long state = 88172645463325252ull ^ ((unsigned long long)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull);
   const int g = mode == 1 ? 16 : mode == 2 ? 32 : 64;
   double acc = 0.0;
@@ -143,6 +145,19 @@ int main(int argc, char** argv)
         std::printf(" %s %.1f", mode == 0 ? "any" : mode == 1 ? "| 16-residue" : mode == 2 ? "| 32-residue" : "| 64-residue", lines / (tr / 5 * 1e-3) / 1e9);
       }
       std::printf(" G lines/s\n");
+      if (window_kb == 3072) {
+        for (int shared_kb : {4096, 8192, 16384, 65536}) {  // one window for all eight XCDs
+          double* big; OK(hipMalloc((void**)&big, (size_t)shared_kb * 1024)); OK(hipMemset(big, 0, (size_t)shared_kb * 1024));
+          float tr = 0;
+          for (int rep = -2; rep < 5; ++rep) {
+            OK(hipEventRecord(e0, s)); k_l2_random<<<2048, 256, 0, s>>>(big, shared_kb * 8, reps, 8, out); OK(hipEventRecord(e1, s));
+            const float a = time_ms(s, e0, e1);
+            if (rep >= 0) tr += a;
+          }
+          std::printf("  ONE window of %6d KiB for the whole chip, random lines: %.1f G lines/s\n", shared_kb, lines / (tr / 5 * 1e-3) / 1e9);
+          (void)hipFree(big);
+        }
+      }
       (void)hipFree(buf);
     }
     return 0;
