@@ -108,6 +108,30 @@ __global__ void __launch_bounds__(256) k_l2_random(const double* __restrict__ v,
   if (acc == 123.456) out[0] = acc;
 }
 
+// (3c) the gather fed from MEMORY: indices (4 B) and values (8 B) streamed coalesced, one gather per index out of the XCD's window, U
+//      independent (index -> gather) chains per lane in flight: what an SpMV does, without rows and without LDS
+template <int U>
+__global__ void __launch_bounds__(256) k_stream_gather(const int* __restrict__ idx, const double* __restrict__ val, long long per_xcd, const double* __restrict__ v,
+                                                       int window_lines, double* __restrict__ out)
+{
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
+  const double* w = v + (size_t)xcd * window_lines * 16;
+  const int* ix = idx + (size_t)xcd * per_xcd;
+  const double* vl = val + (size_t)xcd * per_xcd;
+  double acc = 0.0;
+  for (long long k = (long long)j * 256 * U + threadIdx.x; k + (U - 1) * 256 < per_xcd; k += (long long)nb * 256 * U) {
+    int c[U];
+    double a[U], x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = __builtin_nontemporal_load(ix + k + u * 256), a[u] = __builtin_nontemporal_load(vl + k + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = w[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += a[u] * x[u];
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
 static float time_ms(hipStream_t s, hipEvent_t e0, hipEvent_t e1) { float ms = 0; (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); (void)s; return ms; }
 
 int main(int argc, char** argv)
@@ -159,6 +183,36 @@ int main(int argc, char** argv)
         }
       }
       (void)hipFree(buf);
+    }
+    {
+      // streamed indices: 1.25e6 gathers per XCD (1e7 in all) from a 1.33 MiB window per XCD, indices random doubles of the window
+      const long long per = 1250000;
+      const int wl = 10922;  // lines of a 1.33 MiB window
+      std::vector<int> h((size_t)per * 8);
+      unsigned long long st = 88172645463325252ull;
+      for (auto& e : h) { st ^= st << 13, st ^= st >> 7, st ^= st << 17; e = (int)((st >> 20) % (unsigned long long)(wl * 16)); }
+      int* di; double *dv, *dw;
+      OK(hipMalloc((void**)&di, h.size() * 4)); OK(hipMalloc((void**)&dv, h.size() * 8)); OK(hipMalloc((void**)&dw, (size_t)wl * 128 * 8));
+      OK(hipMemcpy(di, h.data(), h.size() * 4, hipMemcpyHostToDevice)); OK(hipMemset(dv, 0, h.size() * 8)); OK(hipMemset(dw, 0, (size_t)wl * 128 * 8));
+      std::printf("gathers fed from memory (1e7 indices + values streamed, 1.33 MiB window per XCD), G gathers/s by chains per lane and grid:\n");
+      for (int grid : {1024, 2048, 4096, 8192}) {
+        std::printf("  grid %5d:", grid);
+        for (int U : {1, 2, 4, 8}) {
+          float t = 0;
+          for (int rep = -2; rep < 5; ++rep) {
+            OK(hipEventRecord(e0, s));
+            if (U == 1) k_stream_gather<1><<<grid, 256, 0, s>>>(di, dv, per, dw, wl, out);
+            else if (U == 2) k_stream_gather<2><<<grid, 256, 0, s>>>(di, dv, per, dw, wl, out);
+            else if (U == 4) k_stream_gather<4><<<grid, 256, 0, s>>>(di, dv, per, dw, wl, out);
+            else k_stream_gather<8><<<grid, 256, 0, s>>>(di, dv, per, dw, wl, out);
+            OK(hipEventRecord(e1, s));
+            const float a = time_ms(s, e0, e1);
+            if (rep >= 0) t += a;
+          }
+          std::printf("  U=%d %6.1f (%5.1f us)", U, 1e7 / (t / 5 * 1e-3) / 1e9, t / 5 * 1e3);
+        }
+        std::printf("\n");
+      }
     }
     return 0;
   }
