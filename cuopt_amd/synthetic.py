@@ -182,13 +182,17 @@ def generate_structured(kind, m=1_000_000, n=1_000_000, k=10, seed=7):
     return _finish(m, n, rows, cols, vals, rng, dict(seed=seed, k=k, kind=kind, hard=False, band=0))
 
 
-def generate_clustered(m, n, k=3, heavy=40, width=60, seed=11):
+def generate_clustered(m, n, k=3, heavy=40, width=60, seed=11, empty_rows=None):
     """S(m, n, k) plus `heavy` rows that also run through `width` CONSECUTIVE columns each (a budget / convexity row among short
-    ones): the rows the wide bins of the gather-free layout hand to single lanes (more than 7 entries of a row inside one step)"""
+    ones): the rows the wide bins of the gather-free layout hand to single lanes (more than 7 entries of a row inside one step).
+    empty_rows = (first, last): these rows lose all their entries (a whole bin without a product)"""
     rng = np.random.default_rng(seed)
     base = generate(m, n, k, seed=seed)
     rows = np.repeat(np.arange(m, dtype=np.int64), k)
     cols = base["indices"].astype(np.int64)
+    if empty_rows is not None:
+        keep = (rows < empty_rows[0]) | (rows >= empty_rows[1])
+        rows, cols = rows[keep], cols[keep]
     h_rows = np.sort(rng.choice(m, size=heavy, replace=False))
     starts = rng.integers(0, n - width, size=heavy)
     rows = np.concatenate([rows, np.repeat(h_rows, width)])

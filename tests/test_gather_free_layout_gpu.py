@@ -137,7 +137,9 @@ def test_wide_bins_with_serial_rows(monkeypatch):
     """short rows + 40 rows through 60 consecutive columns: the long rows leave the steps of their bins and are summed by single lanes
     (PbView ser_*): products bit-exact on both sides, the device construction == the host's, the solve reaches the optimum"""
     monkeypatch.setenv("CUOPT_AMD_SPMV_LAYOUT", "pb")
-    for p in (synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11), synthetic.generate(60000, 50000, 10, seed=23)):
+    # (the third LP: rows 8192 ... 16383 -- the whole second bin of A -- have no entry at all)
+    for p in (synthetic.generate_clustered(200000, 30000, 3, heavy=40, width=60, seed=11), synthetic.generate(60000, 50000, 10, seed=23),
+              synthetic.generate_clustered(100000, 30000, 3, heavy=0, width=1, seed=12, empty_rows=(8192, 16384))):
         _serial_rows_case(p, monkeypatch)
 
 
