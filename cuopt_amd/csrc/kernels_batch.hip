@@ -536,7 +536,7 @@ int pdlpdev_clone_shared(pdlpdev_ctx** out, pdlpdev_ctx* parent)
   HIP_TRY(hipStreamSynchronize(parent->stream));
   pdlpdev_ctx* c = new pdlpdev_ctx(*parent);  // (pointers to the shared arrays, geometry, parameters: by value)
   *out           = c;
-  c->allocs.clear(), c->graphs.clear();
+  c->allocs.clear(), c->graphs.clear(), c->scratch.clear();
   c->shared_with_parent = true;
   c->parent = nullptr;  // (set once the clone is complete: a failed clone is destroyed without touching the parent's count)
   c->scal_h = nullptr, c->ctl_h = nullptr;  // (the parent's pinned block until the clone has its own: a clone that fails below must not free it)

@@ -600,13 +600,14 @@ int build_pb_wide_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int
     fprintf(stderr, "[cuopt_amd setup]     gather-free (wide bins): %-14s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
     t_last = now;
   };
-  std::vector<void*> tmp;
-  struct Free {
+  std::vector<void*> tmp;  // (the context's scratch blocks this construction holds: handed back, not freed, on every way out)
+  struct Release {
+    pdlpdev_ctx* c;
     std::vector<void*>& v;
-    ~Free() { for (void* p : v) (void)hipFree(p); }
-  } free_tmp{tmp};
+    ~Release() { for (void* p : v) scratch_release(c, p); }
+  } release_tmp{c, tmp};
   auto talloc = [&](void** p, size_t bytes) -> int {
-    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    TRY(scratch_take(c, p, bytes));
     tmp.push_back(*p);
     return 0;
   };
@@ -768,13 +769,14 @@ int build_pb_device(pdlpdev_ctx* c, pdlpdev_ctx::Pb* dst, int32_t rows, int32_t 
     fprintf(stderr, "[cuopt_amd setup]     gather-free: %-14s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
     t_last = now;
   };
-  std::vector<void*> tmp;  // device temporaries of this construction
-  struct Free {
+  std::vector<void*> tmp;  // (the context's scratch blocks this construction holds: handed back, not freed, on every way out)
+  struct Release {
+    pdlpdev_ctx* c;
     std::vector<void*>& v;
-    ~Free() { for (void* p : v) (void)hipFree(p); }
-  } free_tmp{tmp};
+    ~Release() { for (void* p : v) scratch_release(c, p); }
+  } release_tmp{c, tmp};
   auto talloc = [&](void** p, size_t bytes) -> int {
-    HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    TRY(scratch_take(c, p, bytes));
     tmp.push_back(*p);
     return 0;
   };

@@ -615,6 +615,7 @@ static int create_impl(pdlpdev_ctx** out, int device, int32_t m, int32_t n, cons
     }
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  scratch_free(ctx);  // (the layout constructions' temporaries: both sides are built)
   return 0;
 }
 
@@ -625,6 +626,7 @@ void pdlpdev_destroy(pdlpdev_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  scratch_free(ctx);
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   if (ctx->shared_with_parent && ctx->parent) ctx->parent->clones_alive -= 1;
   if (ctx->batches_alive > 0)  // (a batch holds plain pointers to its members: destroy it first)

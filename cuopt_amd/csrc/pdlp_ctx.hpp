@@ -501,7 +501,39 @@ struct pdlpdev_ctx {
   std::map<int, hipGraphExec_t> graphs;  // attempts-per-replay -> executable graph
   std::vector<void*> allocs;
   int64_t bytes = 0;
+  // Scratch of the layouts' device constructions (kernels_layout_build.hip): the A side's temporaries serve the A^T side again -- a
+  // hipMalloc of a few GB right after a hipFree of the same size took 1.9 s at 1e9 nonzeros (the first one of the process: 2 ms) --
+  // and go back to the runtime when the context has been created (scratch_free, pdlp_create.hip).
+  struct Scratch {
+    void* p;
+    size_t bytes;
+    bool busy;
+  };
+  std::vector<Scratch> scratch;
 };
+inline int scratch_take(pdlpdev_ctx* c, void** p, size_t bytes)
+{
+  bytes = std::max<size_t>(bytes, 256);
+  for (auto& b : c->scratch)
+    if (!b.busy && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096) {
+      b.busy = true;
+      *p     = b.p;
+      return 0;
+    }
+  HIP_TRY(hipMalloc(p, bytes));
+  c->scratch.push_back(pdlpdev_ctx::Scratch{*p, bytes, true});
+  return 0;
+}
+inline void scratch_release(pdlpdev_ctx* c, void* p)
+{
+  for (auto& b : c->scratch)
+    if (b.p == p) b.busy = false;
+}
+inline void scratch_free(pdlpdev_ctx* c)
+{
+  for (auto& b : c->scratch) (void)hipFree(b.p);
+  c->scratch.clear();
+}
 
 // one LP's arguments of k_step_decision_batch (pdlp_device.hip; launched by kernels_batch.hip)
 struct pdlpdev_decision_args {
